@@ -1,0 +1,868 @@
+/*
+ * tdc_oracle.c -- TEST INFRASTRUCTURE ONLY (see tdc_oracle.h).
+ *
+ * Plain C restatement of the tudocomp CPU path  lcpcomp(coder=huff, comp=arrays)  and of the
+ * pieces it is built from.  Written from the reference's behaviour; every function cites the
+ * reference file:line (relative to /root/reference/include/tudocomp/) it follows.
+ *
+ * The suffix array is built with an own SA-IS (induced sorting) -- the reference calls its vendored
+ * divsufsort (util/divsufsort.hpp:46-279); the suffix array of a text is unique, so any correct
+ * construction is bit-compatible (checked against a naive sort in tests/).
+ */
+#include "tdc_oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+static double now_s(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+
+void orc_free(void* p) { free(p); }
+
+/* ------------------------------------------------------------------------------------------------
+ * util.hpp:175-196  bits_for(0) = 1, else index of the highest set bit + 1
+ * ---------------------------------------------------------------------------------------------- */
+unsigned orc_bits_for(uint64_t v) {
+    unsigned b = 0;
+    if (v == 0) return 1;
+    while (v) { ++b; v >>= 1; }
+    return b;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Escaping: io/EscapeMap.hpp:10-24,39-64 (escape byte 0xFF, replacement pool starts at 0xFE),
+ * io/RestrictedBuffer.hpp:43-74.  With escape set {0}: 0x00 -> FF FE, 0xFF -> FF FF; a 0 is appended.
+ * KAT: test/tudocomp_tests.cpp:528-556.
+ * ---------------------------------------------------------------------------------------------- */
+size_t orc_escape(const uint8_t* in, size_t n, uint8_t* out) {
+    size_t o = 0;
+    for (size_t i = 0; i < n; ++i) {
+        uint8_t c = in[i];
+        if (c == 0x00)      { out[o++] = 0xFF; out[o++] = 0xFE; }
+        else if (c == 0xFF) { out[o++] = 0xFF; out[o++] = 0xFF; }
+        else                out[o++] = c;
+    }
+    out[o++] = 0;
+    return o;
+}
+
+/* io/RestrictedIOStream.hpp:32-61 : un-escape and drop the final 0 */
+size_t orc_unescape(const uint8_t* in, size_t n, uint8_t* out) {
+    size_t o = 0;
+    if (n && in[n - 1] == 0) --n;
+    for (size_t i = 0; i < n; ++i) {
+        uint8_t c = in[i];
+        if (c == 0xFF && i + 1 < n) {
+            uint8_t d = in[++i];
+            out[o++] = (d == 0xFE) ? 0x00 : d;   /* FF FE -> 00, FF FF -> FF */
+        } else out[o++] = c;
+    }
+    return o;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Suffix array by induced sorting (SA-IS, Nong/Zhang/Chan).  Requires T[n-1] to be the unique
+ * smallest symbol -- guaranteed by the 0 sentinel (ds/TextDS.hpp:132-138, ds/SADivSufSort.hpp:20-25).
+ * ---------------------------------------------------------------------------------------------- */
+#define SAIS_CHR(i) (cs == 4 ? ((const int32_t*)T)[i] : (int32_t)((const uint8_t*)T)[i])
+#define TGET(i)     ((t[(i) >> 3] >> ((i) & 7)) & 1)
+#define TSET(i, b)  (t[(i) >> 3] = (uint8_t)((b) ? (t[(i) >> 3] | (1u << ((i) & 7))) : (t[(i) >> 3] & ~(1u << ((i) & 7)))))
+#define IS_LMS(i)   ((i) > 0 && TGET(i) && !TGET((i) - 1))
+
+static void sais_buckets(const void* T, int32_t* bkt, int32_t n, int32_t K, int cs, int end) {
+    int32_t i, sum = 0;
+    for (i = 0; i < K; ++i) bkt[i] = 0;
+    for (i = 0; i < n; ++i) bkt[SAIS_CHR(i)]++;
+    for (i = 0; i < K; ++i) { sum += bkt[i]; bkt[i] = end ? sum : sum - bkt[i]; }
+}
+
+static void sais_induce_l(const uint8_t* t, int32_t* SA, const void* T, int32_t* bkt, int32_t n, int32_t K, int cs) {
+    sais_buckets(T, bkt, n, K, cs, 0);
+    for (int32_t i = 0; i < n; ++i) {
+        int32_t j = SA[i] - 1;
+        if (j >= 0 && !TGET(j)) SA[bkt[SAIS_CHR(j)]++] = j;
+    }
+}
+
+static void sais_induce_s(const uint8_t* t, int32_t* SA, const void* T, int32_t* bkt, int32_t n, int32_t K, int cs) {
+    sais_buckets(T, bkt, n, K, cs, 1);
+    for (int32_t i = n - 1; i >= 0; --i) {
+        int32_t j = SA[i] - 1;
+        if (j >= 0 && TGET(j)) SA[--bkt[SAIS_CHR(j)]] = j;
+    }
+}
+
+static int sais_main(const void* T, int32_t* SA, int32_t n, int32_t K, int cs) {
+    if (n == 1) { SA[0] = 0; return 0; }
+    uint8_t* t = (uint8_t*)calloc((size_t)n / 8 + 1, 1);
+    int32_t* bkt = (int32_t*)malloc(sizeof(int32_t) * (size_t)K);
+    if (!t || !bkt) { free(t); free(bkt); return -1; }
+    int32_t i, j;
+
+    /* classify: S-type = 1, L-type = 0 */
+    TSET(n - 1, 1);
+    TSET(n - 2, 0);
+    for (i = n - 3; i >= 0; --i) {
+        int32_t a = SAIS_CHR(i), b = SAIS_CHR(i + 1);
+        TSET(i, (a < b || (a == b && TGET(i + 1))) ? 1 : 0);
+    }
+
+    /* stage 1: sort all LMS substrings */
+    sais_buckets(T, bkt, n, K, cs, 1);
+    for (i = 0; i < n; ++i) SA[i] = -1;
+    for (i = 1; i < n; ++i) if (IS_LMS(i)) SA[--bkt[SAIS_CHR(i)]] = i;
+    sais_induce_l(t, SA, T, bkt, n, K, cs);
+    sais_induce_s(t, SA, T, bkt, n, K, cs);
+
+    /* compact the sorted LMS substrings into SA[0..n1) */
+    int32_t n1 = 0;
+    for (i = 0; i < n; ++i) if (IS_LMS(SA[i])) SA[n1++] = SA[i];
+    for (i = n1; i < n; ++i) SA[i] = -1;
+
+    /* name them */
+    int32_t name = 0, prev = -1;
+    for (i = 0; i < n1; ++i) {
+        int32_t pos = SA[i];
+        int diff = 0;
+        for (int32_t d = 0; d < n; ++d) {
+            if (prev == -1 || SAIS_CHR(pos + d) != SAIS_CHR(prev + d) || TGET(pos + d) != TGET(prev + d)) { diff = 1; break; }
+            if (d > 0 && (IS_LMS(pos + d) || IS_LMS(prev + d))) break;
+        }
+        if (diff) { ++name; prev = pos; }
+        SA[n1 + pos / 2] = name - 1;
+    }
+    for (i = n - 1, j = n - 1; i >= n1; --i) if (SA[i] >= 0) SA[j--] = SA[i];
+
+    /* stage 2: solve the reduced problem */
+    int32_t* SA1 = SA;
+    int32_t* s1 = SA + n - n1;
+    if (name < n1) {
+        if (sais_main(s1, SA1, n1, name, 4) != 0) { free(t); free(bkt); return -1; }
+    } else {
+        for (i = 0; i < n1; ++i) SA1[s1[i]] = i;
+    }
+
+    /* stage 3: induce the result */
+    sais_buckets(T, bkt, n, K, cs, 1);
+    for (i = 1, j = 0; i < n; ++i) if (IS_LMS(i)) s1[j++] = i;
+    for (i = 0; i < n1; ++i) SA1[i] = s1[SA1[i]];
+    for (i = n1; i < n; ++i) SA[i] = -1;
+    for (i = n1 - 1; i >= 0; --i) {
+        j = SA[i]; SA[i] = -1;
+        SA[--bkt[SAIS_CHR(j)]] = j;
+    }
+    sais_induce_l(t, SA, T, bkt, n, K, cs);
+    sais_induce_s(t, SA, T, bkt, n, K, cs);
+    free(t); free(bkt);
+    return 0;
+}
+
+int orc_suffix_array(const uint8_t* text, size_t n, uint32_t* sa) {
+    if (n == 0) return 0;
+    if (n >= 0x7FFFFFFFu) return -2;                 /* reference limit: n < 2^31 */
+    if (text[n - 1] != 0) return -3;                 /* ds/TextDS.hpp:132-138 */
+    return sais_main(text, (int32_t*)sa, (int32_t)n, 256, 1);
+}
+
+/* ds/ISAFromSA.hpp:37-39 */
+void orc_isa(const uint32_t* sa, size_t n, uint32_t* isa) {
+    for (size_t i = 0; i < n; ++i) isa[sa[i]] = (uint32_t)i;
+}
+
+/* ds/PhiFromSA.hpp:37-41 */
+void orc_phi(const uint32_t* sa, size_t n, uint32_t* phi) {
+    if (!n) return;
+    uint32_t prev = sa[0];
+    for (size_t i = 1; i < n; ++i) { phi[sa[i]] = prev; prev = sa[i]; }
+    phi[sa[0]] = sa[n - 1];
+}
+
+/* ds/PLCPFromPhi.hpp:38-44 ; entry n-1 is never read by this path, we define it 0 */
+uint32_t orc_plcp(const uint8_t* text, size_t n, const uint32_t* phi, uint32_t* plcp) {
+    uint32_t max = 0, l = 0;
+    if (!n) return 0;
+    for (size_t i = 0; i + 1 < n; ++i) {
+        const uint32_t phii = phi[i];
+        while (text[i + l] == text[phii + l]) ++l;
+        if (l > max) max = l;
+        plcp[i] = l;
+        if (l) --l;
+    }
+    plcp[n - 1] = 0;
+    return max;
+}
+
+/* ds/LCPFromPLCP.hpp:43-47 */
+void orc_lcp(const uint32_t* sa, const uint32_t* plcp, size_t n, uint32_t* lcp) {
+    if (!n) return;
+    lcp[0] = 0;
+    for (size_t i = 1; i < n; ++i) lcp[i] = plcp[sa[i]];
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * compressors/lcpcomp/compress/ArraysComp.hpp:36-117
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { uint32_t* a; size_t size, cap; } u32vec;
+static int vec_push(u32vec* v, uint32_t x) {
+    if (v->size == v->cap) {
+        size_t nc = v->cap ? v->cap * 2 : 4;
+        uint32_t* na = (uint32_t*)realloc(v->a, nc * sizeof(uint32_t));
+        if (!na) return -1;
+        v->a = na; v->cap = nc;
+    }
+    v->a[v->size++] = x;
+    return 0;
+}
+
+size_t orc_arrays_comp(const uint32_t* sa, const uint32_t* isa, uint32_t* lcp, size_t n,
+                       uint32_t maxlcp, uint32_t threshold, orc_factor** out) {
+    *out = NULL;
+    if (n == 0) return 0;
+    if ((uint64_t)maxlcp + 1 <= threshold) return 0;                         /* :50 */
+    const size_t cand_length = (size_t)maxlcp + 1 - threshold;               /* :51 */
+    u32vec* cand = (u32vec*)calloc(cand_length, sizeof(u32vec));
+    /* pre-size the lists (pure allocation detail) */
+    for (size_t i = 1; i < n; ++i) if (lcp[i] >= threshold) cand[lcp[i] - threshold].cap++;
+    for (size_t k = 0; k < cand_length; ++k)
+        if (cand[k].cap) cand[k].a = (uint32_t*)malloc(cand[k].cap * sizeof(uint32_t));
+    for (size_t i = 1; i < n; ++i) {                                         /* :54-58 fill candidates */
+        if (lcp[i] < threshold) continue;
+        u32vec* v = &cand[lcp[i] - threshold];
+        v->a[v->size++] = (uint32_t)i;
+    }
+    size_t z = 0, zcap = 1024;
+    orc_factor* F = (orc_factor*)malloc(zcap * sizeof(orc_factor));
+    for (size_t L = maxlcp; L >= threshold && L > 0; --L) {                  /* :72 */
+        u32vec* col = &cand[L - threshold];
+        for (size_t k = 0; k < col->size; ++k) {                             /* :82 */
+            const uint32_t index = col->a[k];
+            const uint32_t v = lcp[index];
+            if (v < L) {                                                     /* :85-89 lazy push-down */
+                if (v < threshold) continue;
+                vec_push(&cand[v - threshold], index);
+                continue;
+            }
+            const uint32_t pos = sa[index], src = sa[index - 1], len = lcp[index];   /* :91-94 */
+            if (z == zcap) { zcap *= 2; F = (orc_factor*)realloc(F, zcap * sizeof(orc_factor)); }
+            F[z].pos = pos; F[z].src = src; F[z].len = len; ++z;              /* :96 */
+            for (uint32_t j = 0; j < len; ++j) lcp[isa[pos + j]] = 0;         /* :99-101 */
+            const uint32_t max_affect = len < pos ? len : pos;                /* :103 */
+            for (uint32_t j = 0; j < max_affect; ++j) {                       /* :105-109 */
+                const uint32_t ind = isa[pos - j - 1];
+                if (j + 1 < lcp[ind]) lcp[ind] = j + 1;
+            }
+        }
+        free(col->a); col->a = NULL; col->size = col->cap = 0;               /* :112-113 */
+        if (L == 0) break;
+    }
+    for (size_t k = 0; k < cand_length; ++k) free(cand[k].a);
+    free(cand);
+    *out = F;
+    return z;
+}
+
+/* LZSSFactors.hpp:69-76 (positions are unique, so the order is fully determined) */
+static int cmp_factor_pos(const void* a, const void* b) {
+    const uint32_t x = ((const orc_factor*)a)->pos, y = ((const orc_factor*)b)->pos;
+    return x < y ? -1 : x > y;
+}
+void orc_sort_factors(orc_factor* f, size_t z) { qsort(f, z, sizeof(orc_factor), cmp_factor_pos); }
+
+/* LZSSFactors.hpp:79-132 */
+void orc_flatten(orc_factor* f, size_t z, uint64_t* num_flattened, uint64_t* max_depth) {
+    uint64_t nf = 0, md = 0;
+    if (z) {
+        const size_t fsize = (size_t)f[z - 1].pos + f[z - 1].len;           /* :86-90 */
+        uint32_t* fmap = (uint32_t*)calloc(fsize ? fsize : 1, sizeof(uint32_t));
+        for (size_t i = 0; i < z; ++i)                                       /* :92-97 */
+            for (size_t j = 0; j < f[i].len; ++j) fmap[f[i].pos + j] = (uint32_t)(i + 1);
+        for (size_t i = 0; i < z; ++i) {                                     /* :100-128 */
+            uint64_t depth = 0;
+            size_t src = f[i].src;
+            while (src < fsize && fmap[src]) {
+                const orc_factor* s = &f[fmap[src] - 1];
+                const size_t d = src - s->pos;
+                if (d + f[i].len <= s->len) { src = (size_t)s->src + d; ++depth; }
+                else break;
+            }
+            if (depth) { f[i].src = (uint32_t)src; ++nf; if (depth > md) md = depth; }
+        }
+        free(fmap);
+    }
+    if (num_flattened) *num_flattened = nf;
+    if (max_depth) *max_depth = md;
+}
+
+/* LZSSLiterals.hpp:10-50 : positions not covered by a factor, in text order */
+size_t orc_literal_positions(size_t n, const orc_factor* f, size_t z, uint32_t* positions) {
+    size_t cnt = 0, p = 0, k = 0;
+    while (k < z && p == f[k].pos) { p += f[k].len; ++k; }                  /* skip_factors() in the ctor */
+    while (p < n) {
+        positions[cnt++] = (uint32_t)p;
+        ++p;
+        while (k < z && p == f[k].pos) { p += f[k].len; ++k; }
+    }
+    return cnt;
+}
+
+/* HuffmanCoder.hpp:37-48 over TextLiterals */
+void orc_literal_histogram(const uint8_t* text, size_t n, const orc_factor* f, size_t z, uint32_t C[256]) {
+    memset(C, 0, 256 * sizeof(uint32_t));
+    size_t p = 0, k = 0;
+    while (k < z && p == f[k].pos) { p += f[k].len; ++k; }
+    while (p < n) {
+        C[text[p]]++;
+        ++p;
+        while (k < z && p == f[k].pos) { p += f[k].len; ++k; }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Huffman table.  HuffmanCoder.hpp:88-169 (gen_codelengths) uses std::make_heap/pop_heap/push_heap,
+ * :453-455 uses an (unstable) std::sort.  Their libstdc++ behaviour is restated here.
+ * ---------------------------------------------------------------------------------------------- */
+static size_t* HA;                                            /* the array A of gen_codelengths      */
+static int hcomp(size_t a, size_t b) { return HA[a] > HA[b]; }   /* :96 comp(a,b) = A[a] > A[b]       */
+typedef int (*cmp_fn)(size_t, size_t);
+
+static void h_push_heap_(size_t* first, long hole, long top, size_t val, cmp_fn comp) {
+    long parent = (hole - 1) / 2;
+    while (hole > top && comp(first[parent], val)) {
+        first[hole] = first[parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    first[hole] = val;
+}
+static void h_adjust_heap(size_t* first, long hole, long len, size_t val, cmp_fn comp) {
+    const long top = hole;
+    long c = hole;
+    while (c < (len - 1) / 2) {
+        c = 2 * (c + 1);
+        if (comp(first[c], first[c - 1])) --c;
+        first[hole] = first[c];
+        hole = c;
+    }
+    if ((len & 1) == 0 && c == (len - 2) / 2) {
+        c = 2 * (c + 1);
+        first[hole] = first[c - 1];
+        hole = c - 1;
+    }
+    h_push_heap_(first, hole, top, val, comp);
+}
+static void h_make_heap(size_t* first, long len, cmp_fn comp) {
+    if (len < 2) return;
+    long parent = (len - 2) / 2;
+    for (;;) {
+        size_t val = first[parent];
+        h_adjust_heap(first, parent, len, val, comp);
+        if (parent == 0) return;
+        --parent;
+    }
+}
+static void h_pop_heap(size_t* first, long len, cmp_fn comp) {          /* std::pop_heap(first, first+len) */
+    if (len > 1) {
+        size_t val = first[len - 1];
+        first[len - 1] = first[0];
+        h_adjust_heap(first, 0, len - 1, val, comp);
+    }
+}
+static void h_push_heap(size_t* first, long len, cmp_fn comp) {         /* std::push_heap(first, first+len) */
+    h_push_heap_(first, len - 1, 0, first[len - 1], comp);
+}
+
+/* libstdc++ std::sort (introsort + final insertion sort), comparator c(i,j) = len[i] < len[j] */
+static const uint8_t* SLEN;
+static int scomp(size_t i, size_t j) { return SLEN[(uint8_t)i] < SLEN[(uint8_t)j]; }
+static void s_swap(size_t* a, long i, long j) { size_t x = a[i]; a[i] = a[j]; a[j] = x; }
+static void s_unguarded_linear_insert(size_t* a, long i) {
+    size_t v = a[i];
+    while (scomp(v, a[i - 1])) { a[i] = a[i - 1]; --i; }
+    a[i] = v;
+}
+static void s_insertion_sort(size_t* a, long f, long l) {
+    if (f == l) return;
+    for (long i = f + 1; i < l; ++i) {
+        if (scomp(a[i], a[f])) {
+            size_t v = a[i];
+            memmove(&a[f + 1], &a[f], (size_t)(i - f) * sizeof(size_t));
+            a[f] = v;
+        } else s_unguarded_linear_insert(a, i);
+    }
+}
+static void s_move_median_to_first(size_t* a, long r, long x, long y, long z) {
+    if (scomp(a[x], a[y])) {
+        if (scomp(a[y], a[z])) s_swap(a, r, y);
+        else if (scomp(a[x], a[z])) s_swap(a, r, z);
+        else s_swap(a, r, x);
+    } else if (scomp(a[x], a[z])) s_swap(a, r, x);
+    else if (scomp(a[y], a[z])) s_swap(a, r, z);
+    else s_swap(a, r, y);
+}
+static long s_unguarded_partition(size_t* a, long f, long l, long p) {
+    for (;;) {
+        while (scomp(a[f], a[p])) ++f;
+        --l;
+        while (scomp(a[p], a[l])) --l;
+        if (!(f < l)) return f;
+        s_swap(a, f, l);
+        ++f;
+    }
+}
+static void s_heapsort_fallback(size_t* a, long f, long l) {
+    /* std::__partial_sort(f,l,l) = make_heap + sort_heap; not reached for sigma <= 256 in practice
+     * (depth limit 2*floor(log2 n)), restated for completeness. */
+    h_make_heap(a + f, l - f, scomp);
+    for (long len = l - f; len > 1; --len) h_pop_heap(a + f, len, scomp);
+}
+static void s_introsort_loop(size_t* a, long f, long l, long depth) {
+    while (l - f > 16) {
+        if (depth == 0) { s_heapsort_fallback(a, f, l); return; }
+        --depth;
+        long m = f + (l - f) / 2;
+        s_move_median_to_first(a, f, f + 1, m, l - 1);
+        long cut = s_unguarded_partition(a, f + 1, l, f);
+        s_introsort_loop(a, cut, l, depth);
+        l = cut;
+    }
+}
+static void s_sort(size_t* a, long n) {
+    if (n <= 1) return;
+    long lg = 0; { long x = n; while (x > 1) { x >>= 1; ++lg; } }
+    s_introsort_loop(a, 0, n, 2 * lg);
+    if (n > 16) {
+        s_insertion_sort(a, 0, 16);
+        for (long i = 16; i < n; ++i) s_unguarded_linear_insert(a, i);
+    } else s_insertion_sort(a, 0, n);
+}
+
+void orc_huffman_table(const uint32_t C[256], orc_hufftable* t) {
+    memset(t, 0, sizeof(*t));
+    size_t sigma = 0;
+    uint8_t from_eff[256];
+    for (int i = 0; i < 256; ++i) if (C[i]) from_eff[sigma++] = (uint8_t)i;      /* :51-78 */
+    t->sigma = (uint32_t)sigma;
+    if (sigma <= 1) return;                                                      /* :529-536 no table */
+
+    /* gen_codelengths :88-141 */
+    size_t A[512];
+    for (size_t i = 0; i < sigma; ++i) { A[sigma + i] = C[from_eff[i]]; A[i] = sigma + i; }
+    HA = A;
+    h_make_heap(A, (long)sigma, hcomp);
+    size_t h = sigma - 1;
+    while (h > 0) {
+        h_pop_heap(A, (long)h + 1, hcomp);
+        const size_t m1 = A[h];
+        --h;
+        h_pop_heap(A, (long)h + 1, hcomp);
+        const size_t m2 = A[h];
+        A[h + 1] = A[m1] + A[m2];
+        A[h] = h + 1;
+        A[m1] = A[m2] = h + 1;
+        h_push_heap(A, (long)h + 1, hcomp);
+    }
+    A[1] = 0;
+    for (size_t i = 2; i < 2 * sigma; ++i) A[i] = A[A[i]] + 1;
+    uint8_t codelengths[256];
+    for (size_t i = 0; i < sigma; ++i) codelengths[i] = (uint8_t)A[sigma + i];
+
+    /* gen_huffmantable :450-466 : order by code length with libstdc++'s std::sort */
+    size_t order[256];
+    for (size_t i = 0; i < sigma; ++i) order[i] = i;
+    SLEN = codelengths;
+    s_sort(order, (long)sigma);
+    uint8_t longest = 0;
+    for (size_t i = 0; i < sigma; ++i) if (codelengths[i] > longest) longest = codelengths[i];
+    uint8_t ordered_len[256];
+    for (size_t i = 0; i < sigma; ++i) { ordered_len[i] = codelengths[order[i]]; t->order[i] = from_eff[order[i]]; }
+    t->longest = longest;
+    /* gen_numl :173-187 (u8 counters like the reference) */
+    for (size_t i = 0; i < sigma; ++i) t->numl[ordered_len[i] - 1]++;
+    /* gen_first_codes :192-198 */
+    uint64_t firstcode[256];
+    firstcode[longest - 1] = 0;
+    for (size_t i = longest - 1; i > 0; --i) firstcode[i - 1] = (firstcode[i] + t->numl[i]) / 2;
+    /* gen_codewords :202-218 */
+    for (size_t i = 0; i < sigma; ++i) {
+        const uint8_t sym = t->order[i];
+        t->len_of[sym] = ordered_len[i];
+        t->code_of[sym] = firstcode[ordered_len[i] - 1]++;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * io/BitOStream.hpp:17-164
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { uint8_t* buf; size_t len, cap; uint8_t next; int cursor; int dirty; } bitout;
+
+static void bo_init(bitout* b) { b->buf = NULL; b->len = b->cap = 0; b->next = 0; b->cursor = 7; b->dirty = 0; }
+static void bo_put(bitout* b, uint8_t c) {
+    if (b->len == b->cap) { b->cap = b->cap ? b->cap * 2 : 256; b->buf = (uint8_t*)realloc(b->buf, b->cap); }
+    b->buf[b->len++] = c;
+}
+static void bo_write_next(bitout* b) { if (b->dirty) { bo_put(b, b->next); b->next = 0; b->cursor = 7; b->dirty = 0; } }   /* :33-38 */
+static void bo_write_bit(bitout* b, int set) {                                                                            /* :79-88 */
+    if (set) b->next |= (uint8_t)(1u << b->cursor);
+    b->dirty = 1;
+    if (--b->cursor < 0) bo_write_next(b);
+}
+static void bo_write_int(bitout* b, uint64_t v, unsigned bits) {                                                          /* :98-102 */
+    for (int i = (int)bits - 1; i >= 0; --i) bo_write_bit(b, i < 64 ? (int)((v >> i) & 1) : 0);
+}
+static void bo_write_compressed_int(bitout* b, uint64_t v, unsigned blk) {                                                /* :151-163 */
+    do {
+        uint64_t cur = v;                  /* write_int emits only the low blk bits; the odd mask at :155 is harmless */
+        v >>= blk;
+        bo_write_bit(b, v > 0);
+        bo_write_int(b, cur, blk);
+    } while (v > 0);
+}
+static void bo_finish(bitout* b) {                                                                                        /* dtor :53-64 */
+    uint8_t set = (uint8_t)(7 - b->cursor);
+    if (b->cursor >= 2) b->next |= set;
+    else { bo_write_next(b); b->next = set; }
+    b->dirty = 1;
+    bo_write_next(b);
+}
+
+int orc_bitstream_script(const uint64_t* ops, size_t n_ops, uint8_t** out, size_t* out_len) {
+    bitout b; bo_init(&b);
+    for (size_t i = 0; i < n_ops; ++i) {
+        const uint64_t kind = ops[3 * i], v = ops[3 * i + 1], bits = ops[3 * i + 2];
+        if (kind == 0) bo_write_bit(&b, v != 0);
+        else if (kind == 1) bo_write_int(&b, v, (unsigned)bits);
+        else bo_write_compressed_int(&b, v, (unsigned)bits);
+    }
+    bo_finish(&b);
+    *out = b.buf; *out_len = b.len;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * io/BitIStream.hpp:16-195
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { const uint8_t* p; size_t n, idx; uint8_t current, next; int is_final; uint8_t final_bits; uint8_t cursor; } bitin;
+
+static void bi_read_next(bitin* b) {                                     /* :27-63 */
+    b->current = b->next;
+    b->cursor = 7;
+    if (b->idx < b->n) {
+        b->next = b->p[b->idx++];
+        if (b->idx < b->n) {
+            /* stream still going */
+        } else {
+            b->final_bits = b->next & 0x7;     /* note: c still holds the last successfully read byte */
+            if (b->final_bits >= 6) { b->is_final = 1; b->next = 0; }
+        }
+    } else {
+        b->is_final = 1;
+        b->final_bits = b->current & 0x7;
+        b->next = 0;
+    }
+}
+static void bi_init(bitin* b, const uint8_t* p, size_t n) {              /* :71-83 */
+    memset(b, 0, sizeof(*b));
+    b->p = p; b->n = n;
+    if (n) { b->next = p[b->idx++]; bi_read_next(b); }
+    else { b->is_final = 1; b->final_bits = 0; }
+}
+static int bi_eof(const bitin* b) { return b->is_final && b->cursor <= (7 - b->final_bits); }   /* :191-193 */
+static unsigned bi_read_bit(bitin* b) {                                  /* :93-110 */
+    if (!bi_eof(b)) {
+        unsigned bit = (b->current >> b->cursor) & 1;
+        if (b->cursor) --b->cursor; else bi_read_next(b);
+        return bit;
+    }
+    return 0;
+}
+static uint64_t bi_read_int(bitin* b, unsigned amount) {                 /* :119-127 */
+    uint64_t v = 0;
+    for (unsigned i = 0; i < amount; ++i) { v <<= 1; v |= bi_read_bit(b); }
+    return v;
+}
+static uint64_t bi_read_compressed_int(bitin* b, unsigned blk) {         /* :174-188 */
+    uint64_t value = 0; unsigned i = 0; unsigned has_next;
+    do { has_next = bi_read_bit(b); value |= bi_read_int(b, blk) << (blk * (i++)); } while (has_next);
+    return value;
+}
+
+size_t orc_bitstream_count_bits(const uint8_t* in, size_t n) {
+    bitin b; bi_init(&b, in, n);
+    size_t cnt = 0;
+    while (!bi_eof(&b)) { bi_read_bit(&b); ++cnt; }
+    return cnt;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * HuffmanCoder::Encoder  (HuffmanCoder.hpp:521-570)
+ * ---------------------------------------------------------------------------------------------- */
+static void huff_write_header(bitout* b, const orc_hufftable* t) {
+    if (t->sigma <= 1) { bo_write_bit(b, 0); return; }                    /* :538-540 */
+    bo_write_bit(b, 1);                                                   /* :542 */
+    bo_write_compressed_int(b, t->longest, 7);                            /* huffmantable_encode :264-273 */
+    for (uint32_t i = 0; i < t->longest; ++i) bo_write_compressed_int(b, t->numl[i], 7);
+    bo_write_compressed_int(b, t->sigma, 7);
+    for (uint32_t i = 0; i < t->sigma; ++i) bo_write_int(b, t->order[i], 8);
+}
+static void huff_encode_literal(bitout* b, const orc_hufftable* t, uint8_t c) {   /* :562-569 */
+    if (t->sigma == 1) bo_write_int(b, c, 8);
+    else bo_write_int(b, t->code_of[c], t->len_of[c]);
+}
+
+int orc_huff_encode_literals(const uint8_t* lits, size_t n, int interleave, uint8_t** out, size_t* out_len) {
+    uint32_t C[256]; memset(C, 0, sizeof(C));
+    for (size_t i = 0; i < n; ++i) C[lits[i]]++;
+    orc_hufftable t; orc_huffman_table(C, &t);
+    bitout b; bo_init(&b);
+    huff_write_header(&b, &t);
+    int was_zero = 1;
+    for (size_t i = 0; i < n; ++i) {                                      /* test/test/util.hpp:586-597 */
+        if (was_zero && interleave) { bo_write_int(&b, 0x55, 8); was_zero = 0; }
+        huff_encode_literal(&b, &t, lits[i]);
+        if (lits[i] == 0) was_zero = 1;
+    }
+    bo_finish(&b);
+    *out = b.buf; *out_len = b.len;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * lzss::encode_text (LZSSCoding.hpp:18-92) with tdc::Encoder's binary integer coding (Coder.hpp:61-77)
+ * ---------------------------------------------------------------------------------------------- */
+int orc_encode_huff(const uint8_t* text, size_t n, const orc_factor* f, size_t z,
+                    uint8_t** out, size_t* out_len, orc_stats* st) {
+    uint32_t C[256];
+    orc_literal_histogram(text, n, f, z, C);
+    orc_hufftable t; orc_huffman_table(C, &t);
+    bitout b; bo_init(&b);
+    huff_write_header(&b, &t);                                            /* Encoder ctor */
+
+    uint64_t flen_min = 0xFFFFFFFFull, flen_max = 0, fdist_max = 0;       /* LZSSFactors.hpp:33-38 INDEX_MAX / 0 */
+    {
+        size_t p = 0;
+        for (size_t i = 0; i < z; ++i) {                                   /* :28-38 */
+            if (f[i].len < flen_min) flen_min = f[i].len;
+            if (f[i].len > flen_max) flen_max = f[i].len;
+            if (f[i].pos - p > fdist_max) fdist_max = f[i].pos - p;
+            p = (size_t)f[i].pos + f[i].len;
+        }
+        if (n - p > fdist_max) fdist_max = n - p;
+    }
+    const unsigned W = orc_bits_for(n);                                    /* Range text_r(n) */
+    const unsigned lbits = orc_bits_for(flen_max - flen_min);              /* MinDistributedRange; wraps like size_t when z=0, unused then */
+    const unsigned dbits = orc_bits_for(fdist_max);
+    bo_write_int(&b, n, 32);                                               /* :47 len_r */
+    bo_write_int(&b, flen_min, W);                                         /* :48 */
+    bo_write_int(&b, flen_max, W);                                         /* :49 */
+    bo_write_int(&b, fdist_max, W);                                        /* :50 */
+    size_t p = 0;
+    for (size_t i = 0; i < z; ++i) {                                       /* :54-81 */
+        if (f[i].pos == p) bo_write_bit(&b, 0);
+        else { bo_write_bit(&b, 1); bo_write_int(&b, f[i].pos - p, dbits); }
+        while (p < f[i].pos) huff_encode_literal(&b, &t, text[p++]);
+        bo_write_int(&b, f[i].src, W);
+        bo_write_int(&b, f[i].len - flen_min, lbits);
+        p += f[i].len;
+    }
+    if (p < n) { bo_write_bit(&b, 1); bo_write_int(&b, n - p, dbits); }    /* :83-86 */
+    while (p < n) huff_encode_literal(&b, &t, text[p++]);                  /* :88-91 */
+    bo_finish(&b);                                                         /* ~BitOStream */
+    *out = b.buf; *out_len = b.len;
+    if (st) { st->flen_min = flen_min; st->flen_max = flen_max; st->fdist_max = fdist_max; }
+    return 0;
+}
+
+/* LCPCompressor.hpp:100-138 */
+int orc_lcpcomp_huff_compress(const uint8_t* text, size_t n, uint32_t threshold, int flatten,
+                              uint8_t** out, size_t* out_len, orc_stats* stats) {
+    orc_stats local; if (!stats) stats = &local;
+    memset(stats, 0, sizeof(*stats));
+    stats->n = n;
+    if (n == 0 || text[n - 1] != 0) return -3;                             /* ds/TextDS.hpp:132-138 */
+    const double t0 = now_s();
+    uint32_t* sa = (uint32_t*)malloc(n * 4), *isa = (uint32_t*)malloc(n * 4);
+    uint32_t* phi = (uint32_t*)malloc(n * 4), *lcp = (uint32_t*)malloc(n * 4);
+    if (!sa || !isa || !phi || !lcp) { free(sa); free(isa); free(phi); free(lcp); return -1; }
+    double t = now_s();
+    int rc = orc_suffix_array(text, n, sa);
+    if (rc) { free(sa); free(isa); free(phi); free(lcp); return rc; }
+    stats->t_sa = now_s() - t; t = now_s();
+    orc_phi(sa, n, phi);                       stats->t_phi = now_s() - t; t = now_s();
+    const uint32_t maxlcp = orc_plcp(text, n, phi, phi);   /* in place over phi like the reference */
+    stats->t_plcp = now_s() - t; t = now_s();
+    orc_lcp(sa, phi, n, lcp);
+    orc_isa(sa, n, isa);                       stats->t_isa = now_s() - t; t = now_s();
+    free(phi);
+    stats->maxlcp = maxlcp;
+    orc_factor* F = NULL;
+    size_t z = orc_arrays_comp(sa, isa, lcp, n, maxlcp, threshold, &F);
+    stats->t_factorize = now_s() - t; t = now_s();
+    free(sa); free(isa); free(lcp);
+    stats->factors = z;
+    orc_sort_factors(F, z);                    stats->t_sort = now_s() - t; t = now_s();
+    if (flatten) orc_flatten(F, z, &stats->num_flattened, &stats->max_depth_lb);
+    stats->t_flatten = now_s() - t; t = now_s();
+    rc = orc_encode_huff(text, n, F, z, out, out_len, stats);
+    stats->t_encode = now_s() - t;
+    free(F);
+    stats->t_total = now_s() - t0;
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Decoder: HuffmanCoder::Decoder (HuffmanCoder.hpp:572-612) + lcpcomp::decode_text_internal
+ * (LCPCompressor.hpp:23-76).  The reference resolves forward references with ScanDec; the decoded
+ * text is unique, so references are resolved here by following source chains.
+ * ---------------------------------------------------------------------------------------------- */
+int orc_lcpcomp_huff_decompress(const uint8_t* in, size_t in_len, uint8_t** out, size_t* out_len) {
+    bitin b; bi_init(&b, in, in_len);
+    int have_table = (int)bi_read_bit(&b);
+    uint8_t order[256]; uint64_t firstcode[256]; size_t prefix_sum[256];
+    unsigned longest = 0; size_t sigma = 0;
+    if (have_table) {                                                       /* huffmantable_decode :278-290 */
+        longest = (unsigned)(bi_read_compressed_int(&b, 7) & 0xFF);
+        if (longest == 0) return -4;
+        uint8_t numl[256];
+        for (unsigned i = 0; i < longest; ++i) numl[i] = (uint8_t)bi_read_compressed_int(&b, 7);
+        sigma = (size_t)bi_read_compressed_int(&b, 7);
+        if (sigma > 256) return -4;
+        for (size_t i = 0; i < sigma; ++i) order[i] = (uint8_t)bi_read_int(&b, 8);
+        firstcode[longest - 1] = 0;                                         /* gen_first_codes :192-198 */
+        for (unsigned i = longest - 1; i > 0; --i) firstcode[i - 1] = (firstcode[i] + numl[i]) / 2;
+        size_t acc = 0;                                                      /* gen_prefix_sum_lengths :350-370 */
+        for (unsigned l = 0; l < longest; ++l) { prefix_sum[l] = acc; acc += numl[l]; }
+    }
+    const uint64_t n = bi_read_int(&b, 32);                                 /* :27 */
+    const unsigned W = orc_bits_for(n);
+    const uint64_t flen_min = bi_read_int(&b, W), flen_max = bi_read_int(&b, W);   /* :36-37 */
+    const uint64_t fdist_max = bi_read_int(&b, W);                          /* :41 */
+    const unsigned lbits = orc_bits_for(flen_max - flen_min), dbits = orc_bits_for(fdist_max);
+    uint8_t* text = (uint8_t*)malloc(n ? n : 1);
+    uint32_t* ref = (uint32_t*)malloc((n ? n : 1) * sizeof(uint32_t));      /* 0xFFFFFFFF = literal */
+    if (!text || !ref) { free(text); free(ref); return -1; }
+    uint64_t p = 0;
+    while (!bi_eof(&b)) {                                                   /* :45-66 */
+        uint64_t num = bi_read_bit(&b) ? bi_read_int(&b, dbits) : 0;
+        while (num--) {
+            uint8_t c;
+            if (!have_table) c = (uint8_t)bi_read_int(&b, 8);               /* :606-607 */
+            else {                                                           /* huffman_decode :377-397 */
+                uint64_t value = 0; unsigned length = 0;
+                do { value = (value << 1) + bi_read_bit(&b); ++length; } while (length <= longest && value < firstcode[length - 1]);
+                if (length > longest) { free(text); free(ref); return -4; }
+                --length;
+                c = order[prefix_sum[length] + (value - firstcode[length])];
+            }
+            if (p >= n) { free(text); free(ref); return -4; }
+            text[p] = c; ref[p] = 0xFFFFFFFFu; ++p;
+        }
+        if (!bi_eof(&b)) {
+            const uint64_t src = bi_read_int(&b, W);
+            const uint64_t len = flen_min + bi_read_int(&b, lbits);
+            if (p + len > n || src + len > n) { free(text); free(ref); return -4; }
+            for (uint64_t j = 0; j < len; ++j) ref[p + j] = (uint32_t)(src + j);
+            p += len;
+        }
+    }
+    if (p != n) { free(text); free(ref); return -5; }
+    /* resolve references (chains end in literals; no cycles in a valid stream) */
+    uint32_t* stack = (uint32_t*)malloc((n ? n : 1) * sizeof(uint32_t));
+    for (uint64_t i = 0; i < n; ++i) {
+        if (ref[i] == 0xFFFFFFFFu) continue;
+        size_t sp = 0; uint32_t q = (uint32_t)i;
+        while (ref[q] != 0xFFFFFFFFu) {
+            if (sp >= n) { free(stack); free(text); free(ref); return -6; }
+            stack[sp++] = q; q = ref[q];
+        }
+        const uint8_t c = text[q];
+        while (sp) { uint32_t r = stack[--sp]; text[r] = c; ref[r] = 0xFFFFFFFFu; }
+    }
+    free(stack); free(ref);
+    *out = text; *out_len = n;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * LZ78 (compressors/LZ78Compressor.hpp:64-140) with a first-child/next-sibling trie (all tries yield the
+ * same factor ids by contract, test/lz78_trie_tests.cpp:61-100) and EliasGammaCoder
+ * (coders/EliasGammaCoder.hpp:26-29, io/BitOStream.hpp:105-129).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { uint32_t* first_child; uint32_t* next_sibling; uint8_t* literal; size_t size, cap; } lz78trie;
+#define LZ78_UNDEF 0xFFFFFFFFu
+static void trie_add(lz78trie* t, uint8_t c) {
+    if (t->size == t->cap) {
+        t->cap = t->cap ? t->cap * 2 : 1024;
+        t->first_child = (uint32_t*)realloc(t->first_child, t->cap * 4);
+        t->next_sibling = (uint32_t*)realloc(t->next_sibling, t->cap * 4);
+        t->literal = (uint8_t*)realloc(t->literal, t->cap);
+    }
+    t->first_child[t->size] = LZ78_UNDEF; t->next_sibling[t->size] = LZ78_UNDEF; t->literal[t->size] = c; t->size++;
+}
+/* returns child id; *is_new set when inserted (lz78/BinaryTrie.hpp:73-107) */
+static uint32_t trie_find_or_insert(lz78trie* t, uint32_t parent, uint8_t c, int* is_new) {
+    const uint32_t newleaf = (uint32_t)t->size;
+    *is_new = 0;
+    if (t->first_child[parent] == LZ78_UNDEF) t->first_child[parent] = newleaf;
+    else {
+        uint32_t node = t->first_child[parent];
+        for (;;) {
+            if (c == t->literal[node]) return node;
+            if (t->next_sibling[node] == LZ78_UNDEF) { t->next_sibling[node] = newleaf; break; }
+            node = t->next_sibling[node];
+        }
+    }
+    trie_add(t, c);
+    *is_new = 1;
+    return newleaf;
+}
+
+size_t orc_lz78_factors(const uint8_t* in, size_t n, uint32_t** ids, uint8_t** chars) {
+    lz78trie t; memset(&t, 0, sizeof(t));
+    trie_add(&t, 0);                                                        /* root, id 0 */
+    size_t z = 0, cap = 1024;
+    uint32_t* I = (uint32_t*)malloc(cap * 4); uint8_t* Cc = (uint8_t*)malloc(cap);
+    uint32_t node = 0, parent = 0; uint8_t c = 0;
+    for (size_t i = 0; i < n; ++i) {                                         /* :97-121 */
+        c = in[i];
+        int is_new; uint32_t child = trie_find_or_insert(&t, node, c, &is_new);
+        if (is_new) {
+            if (z == cap) { cap *= 2; I = (uint32_t*)realloc(I, cap * 4); Cc = (uint8_t*)realloc(Cc, cap); }
+            I[z] = node; Cc[z] = c; ++z;
+            parent = node = 0;
+        } else { parent = node; node = child; }
+    }
+    if (node != 0) {                                                         /* :124-131 leftover phrase */
+        if (z == cap) { cap *= 2; I = (uint32_t*)realloc(I, cap * 4); Cc = (uint8_t*)realloc(Cc, cap); }
+        I[z] = parent; Cc[z] = c; ++z;
+    }
+    free(t.first_child); free(t.next_sibling); free(t.literal);
+    *ids = I; *chars = Cc;
+    return z;
+}
+
+static void bo_write_elias_gamma(bitout* b, uint64_t v) {                    /* io/BitOStream.hpp:105-129 */
+    const unsigned k = orc_bits_for(v);
+    for (unsigned i = 0; i < k; ++i) bo_write_bit(b, 0);                     /* write_unary(bits_for(v)) */
+    bo_write_bit(b, 1);
+    bo_write_int(b, v, k);
+}
+
+int orc_lz78_gamma_compress(const uint8_t* in, size_t n, uint8_t** out, size_t* out_len) {
+    uint32_t* ids; uint8_t* chars;
+    size_t z = orc_lz78_factors(in, n, &ids, &chars);
+    bitout b; bo_init(&b);
+    for (size_t i = 0; i < z; ++i) {
+        bo_write_elias_gamma(&b, ids[i]);
+        /* NB: the leftover phrase passes a (signed) char (LZ78Compressor.hpp:96,126); bytes >= 0x80 there
+         * sign-extend in the reference.  Not reproduced: inputs of configs 1-5 are ASCII. */
+        bo_write_elias_gamma(&b, chars[i]);
+    }
+    bo_finish(&b);
+    free(ids); free(chars);
+    *out = b.buf; *out_len = b.len;
+    return 0;
+}
