@@ -1,0 +1,119 @@
+/*
+ * tdc_gpu.h -- C ABI of the MI355X-native lcpcomp hot path (libtdc_gpu.so).
+ *
+ * This is the drop-in boundary for tudocomp's lcpcomp compressor: a tudocomp maintainer binds these entry
+ * points from  tdc::LCPCompressor<HuffmanCoder, lcpcomp::ArraysComp, ...>::compress
+ * (/root/reference/include/tudocomp/compressors/LCPCompressor.hpp:100-138); INTEGRATION.md shows the binding.
+ * Plain pointers and sizes only; no C++/torch types; no exception crosses the boundary.
+ *
+ * Conventions
+ *   - `text`/`n` is what Input::as_view() hands to compress(): already escaped, terminated by ONE 0 byte that
+ *     occurs nowhere else (ds/SADivSufSort.hpp:20-25, ds/TextDS.hpp:132-138).  n < 2^31 (32-bit len_t, def.hpp:103).
+ *   - every function returns 0 on success or a negative tdc_gpu_status; tdc_gpu_strerror() explains it.
+ *   - host output buffers returned through `uint8_t** out` are malloc'd by the library: free with tdc_gpu_free().
+ *   - a context owns one HIP stream and one device arena on one GPU; it is not thread-safe, use one per thread.
+ *     The library NEVER falls back to a CPU path: without a usable GPU every compute call fails with TDC_GPU_ERR_HIP.
+ */
+#ifndef TDC_GPU_H
+#define TDC_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    TDC_GPU_OK = 0,
+    TDC_GPU_ERR_HIP = -1,          /* HIP runtime error (no device, launch failure, ...) */
+    TDC_GPU_ERR_ARG = -2,          /* invalid argument (NULL pointer, threshold 0, extra 0 bytes in the text, ...) */
+    TDC_GPU_ERR_NO_SENTINEL = -3,  /* text does not end with 0: reference throws std::logic_error (TextDS.hpp:132-138) */
+    TDC_GPU_ERR_TOO_LARGE = -4,    /* n >= 2^31 */
+    TDC_GPU_ERR_OOM = -5,          /* device or host memory exhausted */
+    TDC_GPU_ERR_UNSUPPORTED = -6,  /* coder / strategy not available in this build */
+    TDC_GPU_ERR_INTERNAL = -7      /* invariant violated */
+} tdc_gpu_status;
+
+/* coder ids (option `coder` of lcpcomp, etc/registry_config.py:138-142) */
+enum { TDC_GPU_CODER_HUFF = 0 };
+
+typedef struct tdc_gpu_ctx tdc_gpu_ctx;
+
+/* Replaces the StatPhase log of LCPCompressor::compress (same keys: LCPCompressor.hpp:117-118, ArraysComp.hpp:43,60,
+ * LZSSFactors.hpp:130-131) plus device timings per phase in milliseconds (hipEvent). */
+typedef struct {
+    uint64_t n;                 /* text length incl. sentinel                                  */
+    uint64_t out_len;           /* compressed bytes                                            */
+    uint64_t factors;           /* "factors"                                                   */
+    uint64_t maxlcp;            /* "maxlcp"                                                    */
+    uint64_t entries;           /* "entries" (initial candidates)                              */
+    uint64_t num_flattened;     /* "num_flattened"                                             */
+    uint64_t max_depth_lb;      /* "max_depth_lb"                                              */
+    uint64_t flen_min, flen_max, fdist_max;
+    uint64_t pushes;            /* lazily pushed-down candidates                               */
+    uint32_t sa_rounds;         /* prefix-doubling rounds (incl. the initial sort)             */
+    uint32_t sa_init_syms;      /* symbols packed into the initial sort key                    */
+    uint32_t levels;            /* non-empty LCP levels processed                              */
+    uint32_t mis_rounds;        /* selection rounds over all levels                            */
+    uint32_t flatten_rounds;
+    uint32_t sigma;             /* literal alphabet size                                       */
+    uint64_t sa_sorted_elems;   /* total elements that went through the radix sort during SA   */
+    uint64_t arena_bytes;       /* device memory high-water mark                               */
+    float ms_h2d, ms_sa, ms_phi, ms_plcp, ms_factorize, ms_flatten, ms_encode, ms_d2h, ms_total;
+} tdc_gpu_stats;
+
+/* ---- context -------------------------------------------------------------------------------------------- */
+int  tdc_gpu_ctx_create(int device, tdc_gpu_ctx** ctx);
+void tdc_gpu_ctx_destroy(tdc_gpu_ctx* ctx);
+/* Pre-size the device arena for texts up to n bytes (optional; otherwise grown on demand). */
+int  tdc_gpu_ctx_reserve(tdc_gpu_ctx* ctx, size_t n);
+const char* tdc_gpu_strerror(int status);
+/* Human-readable detail of the last failure on this context ("" if none). */
+const char* tdc_gpu_last_error(const tdc_gpu_ctx* ctx);
+void tdc_gpu_free(void* p);
+
+/* ---- the hot path: replaces LCPCompressor::compress (LCPCompressor.hpp:100-138) --------------------------- */
+/* Host buffers in, host buffer out (H2D + all kernels + D2H).  threshold/flatten = the dynamic options of the
+ * same name (LCPCompressor.hpp:92-93, defaults 5 and 1).  `stats` may be NULL. */
+int tdc_gpu_lcpcomp_compress(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, uint32_t threshold, int flatten,
+                             int coder, uint8_t** out, size_t* out_len, tdc_gpu_stats* stats);
+/* Device-resident variant: d_text and d_out are device pointers on ctx's GPU (d_out 8-byte aligned, capacity out_cap
+ * bytes; tdc_gpu_lcpcomp_bound(n) always suffices).  Used by bench.py (inputs resident in HBM). */
+int tdc_gpu_lcpcomp_compress_dev(tdc_gpu_ctx* ctx, const void* d_text, size_t n, uint32_t threshold, int flatten,
+                                 int coder, void* d_out, size_t out_cap, size_t* out_len, tdc_gpu_stats* stats);
+size_t tdc_gpu_lcpcomp_bound(size_t n);
+
+/* ---- stage-level entry points (host buffers), used by the parity tests ------------------------------------ */
+/* ds/SADivSufSort.hpp:27-51 + ds/ISAFromSA.hpp:30-43 : sa / isa may be NULL */
+int tdc_gpu_suffix_array(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, uint32_t* sa, uint32_t* isa);
+/* TextDS::require(SA|ISA|PHI|PLCP|LCP) (ds/TextDS.hpp:247-292); any output may be NULL; plcp[n-1] = 0 */
+int tdc_gpu_textds(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, uint32_t* sa, uint32_t* isa, uint32_t* phi,
+                   uint32_t* plcp, uint32_t* lcp, uint32_t* maxlcp);
+/* ArraysComp::factorize + FactorBuffer::sort (+ flatten if requested): factors sorted by pos in three malloc'd arrays */
+int tdc_gpu_lcpcomp_factorize(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, uint32_t threshold, int flatten,
+                              uint32_t** pos, uint32_t** src, uint32_t** len, size_t* z, tdc_gpu_stats* stats);
+/* FactorBuffer::flatten on a caller-supplied factor list sorted by pos (LZSSFactors.hpp:79-132); src rewritten in place */
+int tdc_gpu_flatten(tdc_gpu_ctx* ctx, size_t n, const uint32_t* pos, uint32_t* src, const uint32_t* len, size_t z,
+                    uint64_t* num_flattened, uint64_t* max_depth_lb);
+/* HuffmanCoder::Encoder + lzss::encode_text on a caller-supplied factor list sorted by pos (LZSSCoding.hpp:18-92) */
+int tdc_gpu_encode_huff(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, const uint32_t* pos, const uint32_t* src,
+                        const uint32_t* len, size_t z, uint8_t** out, size_t* out_len);
+
+/* ---- host-side helpers (no GPU) --------------------------------------------------------------------------- */
+/* io/RestrictedBuffer.hpp:43-74 + io/EscapeMap.hpp:39-64 : 0x00 -> FF FE, 0xFF -> FF FF, append 0.
+ * out must hold 2*n+1 bytes; returns the escaped length. */
+size_t tdc_escape(const uint8_t* in, size_t n, uint8_t* out);
+/* io/RestrictedIOStream.hpp:13-89 : inverse (drops the final 0); returns the length. */
+size_t tdc_unescape(const uint8_t* in, size_t n, uint8_t* out);
+/* coders/HuffmanCoder.hpp:442-474 : canonical code for a literal histogram (for tests of the host table builder) */
+int tdc_huffman_table(const uint32_t counts[256], uint32_t* sigma, uint32_t* longest, uint8_t order[256],
+                      uint8_t len_of[256], uint64_t code_of[256]);
+/* synthetic corpora of the benchmark configurations */
+int tdc_gen_english(uint8_t* out, size_t n, uint64_t seed);
+int tdc_gen_dna(uint8_t* out, size_t n, uint64_t seed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

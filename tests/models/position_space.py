@@ -1,0 +1,142 @@
+"""Executable model of the device-side formulation of ArraysComp and flatten (DESIGN.md sections 4.4/4.5).
+
+Pure Python, small inputs only.  It mirrors the data flow of the HIP kernels (position-space arrays, the
+time-ordered push pool, MIS rounds among live entries, the final resolve pass) so that the *algorithm* can
+be checked against the oracle's direct restatement of the reference on the CPU, independently of the GPU.
+"""
+import numpy as np
+
+
+def factorize_position_space(n, isa, phi, plcp, maxlcp, threshold):
+    """Returns (factors in emission order [(pos, src, len)], total_rounds, stats)."""
+    if maxlcp + 1 <= threshold:
+        return [], 0, {}
+    cur = [int(x) for x in plcp]
+    cur[n - 1] = 0
+    # originals: positions with plcp >= threshold, ordered by (plcp, isa)  [isa >= 1 always: isa==0 is the sentinel]
+    orig = {}
+    order = sorted((p for p in range(n) if cur[p] >= threshold and isa[p] >= 1), key=lambda p: int(isa[p]))
+    for p in order:
+        orig.setdefault(cur[p], []).append(p)
+    resid = [cur[p] if (cur[p] >= threshold and isa[p] >= 1) else 0 for p in range(n)]
+    pool_p, pool_t = [], []
+    factors = []
+    rounds_total = 0
+    for L in range(maxlcp, threshold - 1, -1):
+        lst = list(orig.get(L, ())) + [p for p, t in zip(pool_p, pool_t) if t == L]
+        m = len(lst)
+        if m == 0:
+            continue
+        lidx = {p: k for k, p in enumerate(lst)}
+        assert len(lidx) == m
+        for p in lst:
+            assert resid[p] == L
+        vcur = [cur[p] for p in lst]
+        # state: 0 undecided (live only), 1 selected, 2 not selected
+        state = [0 if vcur[k] == L else 2 for k in range(m)]
+
+        def neighbours(p):
+            for q in range(max(0, p - L + 1), min(n, p + L)):
+                if q != p and resid[q] == L:
+                    yield q
+
+        while any(s == 0 for s in state):
+            rounds_total += 1
+            new_state = list(state)
+            for k in range(m):
+                if state[k] != 0:
+                    continue
+                p = lst[k]
+                blocked, hit = False, False
+                for q in neighbours(p):
+                    kq = lidx[q]
+                    if kq < k:
+                        if state[kq] == 0:
+                            blocked = True
+                            break
+                        if state[kq] == 1:
+                            hit = True
+                if not blocked:
+                    new_state[k] = 2 if hit else 1
+            state = new_state
+        # resolve pass for everything not selected
+        pushes = []
+        for k in range(m):
+            p = lst[k]
+            if state[k] == 1:
+                continue
+            v = vcur[k]
+            if v >= threshold:
+                for q in neighbours(p):
+                    kq = lidx[q]
+                    if kq < k and state[kq] == 1:
+                        v = 0 if q < p else min(v, q - p)
+            if v >= threshold:
+                pushes.append((p, v))       # resid is only rewritten by pushes, after the whole resolve pass
+        # apply selected
+        for k in range(m):
+            if state[k] != 1:
+                continue
+            p = lst[k]
+            factors.append((p, int(phi[p]), L))
+            for j in range(L):
+                cur[p + j] = 0
+            for j in range(min(L, p)):
+                q = p - 1 - j
+                cur[q] = min(cur[q], j + 1)
+        for p, v in pushes:
+            resid[p] = v
+            pool_p.append(p)
+            pool_t.append(v)
+    return factors, rounds_total, {"pushes": len(pool_p)}
+
+
+def flatten_rounds(factors):
+    """factors: list of (pos, src, len) sorted by pos.  Round-based equivalent of FactorBuffer::flatten.
+    Returns (new factor list, num_flattened, max_depth_lb, rounds)."""
+    z = len(factors)
+    if z == 0:
+        return [], 0, 0, 0
+    end = factors[-1][0] + factors[-1][2]
+    owner = [-1] * end
+    for i, (pos, src, ln) in enumerate(factors):
+        for j in range(ln):
+            owner[pos + j] = i
+    orig_src = [f[1] for f in factors]
+    final_src = list(orig_src)
+    done = [False] * z
+    cur_src = list(orig_src)
+    depth = [0] * z
+    rounds = 0
+    while not all(done):
+        rounds += 1
+        snapshot = list(done)
+        for i in range(z):
+            if done[i]:
+                continue
+            pos, _, ln = factors[i]
+            src = cur_src[i]
+            while True:
+                if src >= end or owner[src] < 0:
+                    done[i] = True
+                    break
+                s = owner[src]
+                spos, _, slen = factors[s]
+                d = src - spos
+                if d + ln > slen:
+                    done[i] = True
+                    break
+                if s < i:
+                    if not snapshot[s]:
+                        break           # wait for s
+                    ssrc = final_src[s]
+                else:
+                    ssrc = orig_src[s]  # s >= i: the sequential pass would still see the original value
+                src = ssrc + d
+                depth[i] += 1
+            cur_src[i] = src
+            if done[i]:
+                final_src[i] = src if depth[i] else orig_src[i]
+    out = [(f[0], final_src[i], f[2]) for i, f in enumerate(factors)]
+    nf = sum(1 for d in depth if d)
+    return out, nf, max(depth), rounds

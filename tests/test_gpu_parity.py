@@ -1,0 +1,149 @@
+"""GPU parity tests (pytest -m gpu): the HIP path, called through the C ABI, against the CPU oracle and the
+committed golden vectors.  Bit-exact everywhere (integer / byte / index work)."""
+import numpy as np
+import pytest
+
+import tudocomp_amd as T
+from oracle import oracle as O
+from tests import corpus
+from tests.util import load_json, sha256, factors_struct
+
+pytestmark = pytest.mark.gpu
+
+ANCH = load_json("survey_anchors.json")
+SMALL = corpus.small_corpus()
+IDS = [c[0] for c in SMALL]
+
+
+def _eq(name, got, want):
+    got, want = np.asarray(got), np.asarray(want)
+    assert got.shape == want.shape, "%s: shape %s != %s" % (name, got.shape, want.shape)
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, "%s: %d mismatches, first at %d: got %s want %s" % (
+        name, bad.size, bad[0], got[bad[0]:bad[0] + 8], want[bad[0]:bad[0] + 8])
+
+
+def _oracle_stages(text):
+    sa = O.suffix_array(text)
+    isa, phi, plcp, maxlcp = O.isa_phi_plcp(text, sa)
+    lcp = O.lcp_array(sa, plcp)
+    return sa, isa, phi, plcp, lcp, maxlcp
+
+
+@pytest.mark.parametrize("name,data", SMALL, ids=IDS)
+def test_textds_arrays(gpu_ctx, name, data):
+    text = O.escape(data)
+    sa, isa, phi, plcp, lcp, maxlcp = _oracle_stages(text)
+    g = gpu_ctx.textds(text)
+    _eq("sa", g["sa"], sa)
+    _eq("isa", g["isa"], isa)
+    _eq("phi", g["phi"], phi)
+    _eq("plcp", g["plcp"], plcp)
+    _eq("lcp", g["lcp"], lcp)
+    assert g["maxlcp"] == maxlcp
+
+
+@pytest.mark.parametrize("name,data", SMALL, ids=IDS)
+def test_factorize_and_flatten(gpu_ctx, name, data):
+    text = O.escape(data)
+    sa, isa, phi, plcp, lcp, maxlcp = _oracle_stages(text)
+    for thr in (1, 2, 3, 5):
+        ref = O.sort_factors(O.arrays_comp(sa, isa, lcp, maxlcp, thr))
+        pos, src, ln, st = gpu_ctx.factorize(text, thr, flatten=0)
+        _eq("pos t=%d" % thr, pos, ref["pos"])
+        _eq("len t=%d" % thr, ln, ref["len"])
+        _eq("src t=%d" % thr, src, ref["src"])
+        assert st["factors"] == len(ref) and st["maxlcp"] == maxlcp
+        fl, nf, md = O.flatten(ref)
+        pos2, src2, ln2, st2 = gpu_ctx.factorize(text, thr, flatten=1)
+        _eq("flat src t=%d" % thr, src2, fl["src"])
+        assert (st2["num_flattened"], st2["max_depth_lb"]) == (nf, md)
+        # stand-alone stage entry points on the oracle's factor list
+        src3, nf3, md3 = gpu_ctx.flatten(len(text), ref["pos"], ref["src"], ref["len"])
+        _eq("flatten() t=%d" % thr, src3, fl["src"])
+        assert (nf3, md3) == (nf, md)
+        want, _ = O.encode_huff(text, fl)
+        got = gpu_ctx.encode_huff(text, fl["pos"], fl["src"], fl["len"])
+        assert got == want, "encode_huff t=%d: %d vs %d bytes" % (thr, len(got), len(want))
+
+
+@pytest.mark.parametrize("name,data", SMALL, ids=IDS)
+def test_compress_bitexact_small(gpu_ctx, name, data):
+    text = O.escape(data)
+    for thr in (1, 2, 5):
+        for fl in (0, 1):
+            want, wst = O.lcpcomp_huff_compress(text, thr, fl)
+            got, st = gpu_ctx.lcpcomp_compress(text, thr, fl)
+            assert got == want, "t=%d flatten=%d: %d vs %d bytes" % (thr, fl, len(got), len(want))
+            for k in ("factors", "maxlcp", "num_flattened", "max_depth_lb", "flen_max", "fdist_max"):
+                assert st[k] == wst[k], k
+
+
+def test_compress_bitexact_random(gpu_ctx):
+    for name, data in corpus.random_small(300, seed=99):
+        text = O.escape(data)
+        for thr in (1, 2, 5):
+            want, _ = O.lcpcomp_huff_compress(text, thr, 1)
+            got, _ = gpu_ctx.lcpcomp_compress(text, thr, 1)
+            assert got == want, (name, thr, data)
+
+
+def test_survey_example(gpu_ctx):
+    e = ANCH["example"]
+    comp = T.LCPCompressor(gpu_ctx, coder="huff", threshold=e["threshold"])
+    assert comp.compress(e["text"].encode()).hex() == e["output_hex"]
+    pos, src, ln, _ = gpu_ctx.factorize(O.escape(e["text"].encode()), e["threshold"], flatten=1)
+    assert [list(map(int, t)) for t in zip(pos, src, ln)] == e["factors"]
+
+
+@pytest.mark.parametrize("a", ANCH["lcpcomp_huff"], ids=lambda a: "%s_t%d" % (a["text"], a["threshold"]))
+def test_reference_anchors(gpu_ctx, a):
+    t = ANCH["texts"][a["text"]]
+    data = (T.gen_english if t["gen"] == "english" else T.gen_dna)(t["n"], t["seed"]).tobytes()
+    out = T.LCPCompressor(gpu_ctx, threshold=a["threshold"]).compress(data)
+    assert len(out) == a["size"] and sha256(out) == a["sha256"]
+
+
+@pytest.mark.parametrize("gen,n,thr", [("english", 1 << 22, 2), ("dna", 1 << 22, 5), ("english", 1 << 24, 2), ("english", 1 << 26, 2)])
+def test_compress_bitexact_medium(gpu_ctx, gen, n, thr):
+    data = (T.gen_english(n, 42) if gen == "english" else T.gen_dna(n, 7)).tobytes()
+    text = O.escape(data)
+    want, wst = O.lcpcomp_huff_compress(text, thr, 1)
+    got, st = gpu_ctx.lcpcomp_compress(text, thr, 1)
+    assert len(got) == len(want) and sha256(got) == sha256(want)
+    for k in ("factors", "maxlcp", "num_flattened", "max_depth_lb"):
+        assert st[k] == wst[k], k
+    if gen == "english" and n == 1 << 24:
+        a = ANCH["lcpcomp_huff_16MiB"]
+        assert (len(got), st["factors"], st["maxlcp"], st["num_flattened"], st["max_depth_lb"]) == (
+            a["size"], a["factors"], a["maxlcp"], a["num_flattened"], a["max_depth_lb"])
+
+
+def test_full_size_roundtrip_256MiB(gpu_ctx):
+    """BASELINE.json config 2 at full size: size-independent property -- the oracle's decoder must reproduce the
+    input from the GPU stream, and the stream's header fields must be consistent with the reported statistics."""
+    n = 1 << 28
+    data = T.gen_english(n, 42)
+    text = np.concatenate([data, np.zeros(1, dtype=np.uint8)])      # generator emits no 0x00 / 0xFF
+    got, st = gpu_ctx.lcpcomp_compress(text, 2, 1)
+    assert st["n"] == n + 1 and st["out_len"] == len(got)
+    back = O.lcpcomp_huff_decompress(got)
+    assert len(back) == n + 1
+    assert sha256(back) == sha256(text.tobytes())
+
+
+def test_error_codes(gpu_ctx):
+    with pytest.raises(T.TdcGpuError) as e:
+        gpu_ctx.lcpcomp_compress(b"abc", 2, 1)
+    assert e.value.status == -3                      # no sentinel: reference throws std::logic_error (TextDS.hpp:132-138)
+    with pytest.raises(T.TdcGpuError) as e:
+        gpu_ctx.lcpcomp_compress(b"a\x00b\x00", 2, 1)
+    assert e.value.status == -2                      # unescaped 0 inside the text
+    with pytest.raises(T.TdcGpuError) as e:
+        gpu_ctx.lcpcomp_compress(b"abc\x00", 0, 1)
+    assert e.value.status == -2
+    with pytest.raises(RuntimeError, match="No implementation found"):
+        T.LCPCompressor(gpu_ctx, coder="arithmetic")
+    # the context is still usable afterwards
+    want, _ = O.lcpcomp_huff_compress(b"abcabc\x00", 2, 1)
+    assert gpu_ctx.lcpcomp_compress(b"abcabc\x00", 2, 1)[0] == want

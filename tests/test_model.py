@@ -1,0 +1,35 @@
+"""CPU tests: the position-space / round-based formulation used by the HIP kernels (tests/models/position_space.py)
+reproduces the reference's sequential ArraysComp and flatten exactly (factor lists incl. emission order)."""
+import pytest
+
+from oracle import oracle as O
+from tests import corpus
+from tests.models.position_space import factorize_position_space, flatten_rounds
+
+
+def _check(data, thresholds):
+    text = O.escape(data)
+    n = len(text)
+    sa = O.suffix_array(text)
+    isa, phi, plcp, maxlcp = O.isa_phi_plcp(text, sa)
+    lcp = O.lcp_array(sa, plcp)
+    for thr in thresholds:
+        ref = O.arrays_comp(sa, isa, lcp, maxlcp, thr)
+        ref_l = [(int(a), int(b), int(c)) for a, b, c in ref]
+        got, _, _ = factorize_position_space(n, isa, phi, plcp, maxlcp, thr)
+        assert got == ref_l
+        srt = O.sort_factors(ref)
+        fl, nf, md = O.flatten(srt)
+        mine, nf2, md2, _ = flatten_rounds([(int(a), int(b), int(c)) for a, b, c in srt])
+        assert mine == [(int(a), int(b), int(c)) for a, b, c in fl]
+        assert (nf, md) == (nf2, md2)
+
+
+@pytest.mark.parametrize("name,data", [c for c in corpus.small_corpus() if len(c[1]) <= 3000], ids=lambda x: x if isinstance(x, str) else "")
+def test_model_on_corpus(name, data):
+    _check(data, (1, 2, 5))
+
+
+def test_model_on_random_inputs():
+    for _, data in corpus.random_small(400, seed=7):
+        _check(data, (1, 2, 3, 5))

@@ -1,0 +1,195 @@
+"""tudocomp_amd -- MI355X-native lcpcomp hot path behind tudocomp's Compressor surface.
+
+Python face of the C ABI (include/tdc_gpu.h) used by the parity tests and bench.py.  The C++ facade that mirrors
+tdc::Compressor / the `tdc` command line lives in tudocomp_amd/host/.  Nothing here computes on the CPU: every
+method forwards to the HIP library and raises if it (or a GPU) is unavailable.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _native
+from ._native import Stats, LIB_PATH, SYMBOLS  # noqa: F401
+
+CODER_HUFF = 0
+
+
+class TdcGpuError(RuntimeError):
+    def __init__(self, status, detail=""):
+        self.status = status
+        msg = _native.load().tdc_gpu_strerror(status).decode()
+        super().__init__("%s (status %d)%s" % (msg, status, (": " + detail) if detail else ""))
+
+
+def _u8(b):
+    a = np.frombuffer(b, dtype=np.uint8) if isinstance(b, (bytes, bytearray, memoryview)) else np.ascontiguousarray(b, dtype=np.uint8)
+    return a
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def escape(data):
+    """Input restrictions 'escape {0} + null-terminate' (io/RestrictedBuffer.hpp:43-74): what Input::as_view() yields."""
+    L = _native.load()
+    a = _u8(data)
+    out = np.empty(2 * len(a) + 1, dtype=np.uint8)
+    n = L.tdc_escape(_ptr(a), len(a), _ptr(out))
+    return out[:n].tobytes()
+
+
+def unescape(data):
+    L = _native.load()
+    a = _u8(data)
+    out = np.empty(len(a) + 1, dtype=np.uint8)
+    n = L.tdc_unescape(_ptr(a), len(a), _ptr(out))
+    return out[:n].tobytes()
+
+
+def gen_english(n, seed=42):
+    out = np.empty(n, dtype=np.uint8)
+    _native.load().tdc_gen_english(_ptr(out), n, seed)
+    return out
+
+
+def gen_dna(n, seed=7):
+    out = np.empty(n, dtype=np.uint8)
+    _native.load().tdc_gen_dna(_ptr(out), n, seed)
+    return out
+
+
+def huffman_table(counts):
+    L = _native.load()
+    C = np.ascontiguousarray(counts, dtype=np.uint32)
+    sigma, longest = ctypes.c_uint32(), ctypes.c_uint32()
+    order = np.zeros(256, dtype=np.uint8)
+    len_of = np.zeros(256, dtype=np.uint8)
+    code_of = np.zeros(256, dtype=np.uint64)
+    rc = L.tdc_huffman_table(_ptr(C), ctypes.byref(sigma), ctypes.byref(longest), _ptr(order), _ptr(len_of), _ptr(code_of))
+    if rc:
+        raise TdcGpuError(rc)
+    return {"sigma": sigma.value, "longest": longest.value, "order": order, "len_of": len_of, "code_of": code_of}
+
+
+class Context:
+    """One GPU, one HIP stream, one device arena (tdc_gpu_ctx)."""
+
+    def __init__(self, device=0):
+        self._L = _native.load()
+        h = ctypes.c_void_p()
+        rc = self._L.tdc_gpu_ctx_create(device, ctypes.byref(h))
+        if rc:
+            raise TdcGpuError(rc, "tdc_gpu_ctx_create(device=%d)" % device)
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.tdc_gpu_ctx_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc):
+        if rc:
+            raise TdcGpuError(rc, self._L.tdc_gpu_last_error(self._h).decode())
+
+    def _take(self, ptr, nbytes):
+        out = ctypes.string_at(ptr, nbytes) if nbytes else b""
+        self._L.tdc_gpu_free(ptr)
+        return out
+
+    def reserve(self, n):
+        self._check(self._L.tdc_gpu_ctx_reserve(self._h, n))
+
+    # ---- hot path --------------------------------------------------------------------------------------
+    def lcpcomp_compress(self, text, threshold=5, flatten=1, coder=CODER_HUFF):
+        """text: escaped + 0-terminated view.  Returns (compressed bytes, stats dict)."""
+        a = _u8(text)
+        out, n, st = ctypes.c_void_p(), ctypes.c_size_t(), Stats()
+        self._check(self._L.tdc_gpu_lcpcomp_compress(self._h, _ptr(a), len(a), threshold, int(flatten), coder,
+                                                     ctypes.byref(out), ctypes.byref(n), ctypes.byref(st)))
+        return self._take(out, n.value), st.as_dict()
+
+    def lcpcomp_compress_dev(self, d_text, n, d_out, out_cap, threshold=5, flatten=1, coder=CODER_HUFF):
+        """Device-resident variant: d_text / d_out are raw device pointers (ints).  Returns (out_len, stats)."""
+        ol, st = ctypes.c_size_t(), Stats()
+        self._check(self._L.tdc_gpu_lcpcomp_compress_dev(self._h, ctypes.c_void_p(d_text), n, threshold, int(flatten),
+                                                         coder, ctypes.c_void_p(d_out), out_cap, ctypes.byref(ol),
+                                                         ctypes.byref(st)))
+        return ol.value, st.as_dict()
+
+    def bound(self, n):
+        return self._L.tdc_gpu_lcpcomp_bound(n)
+
+    # ---- stages ----------------------------------------------------------------------------------------
+    def suffix_array(self, text):
+        a = _u8(text)
+        sa = np.empty(len(a), dtype=np.uint32)
+        isa = np.empty(len(a), dtype=np.uint32)
+        self._check(self._L.tdc_gpu_suffix_array(self._h, _ptr(a), len(a), _ptr(sa), _ptr(isa)))
+        return sa, isa
+
+    def textds(self, text):
+        a = _u8(text)
+        n = len(a)
+        arrs = {k: np.empty(n, dtype=np.uint32) for k in ("sa", "isa", "phi", "plcp", "lcp")}
+        m = ctypes.c_uint32()
+        self._check(self._L.tdc_gpu_textds(self._h, _ptr(a), n, _ptr(arrs["sa"]), _ptr(arrs["isa"]), _ptr(arrs["phi"]),
+                                           _ptr(arrs["plcp"]), _ptr(arrs["lcp"]), ctypes.byref(m)))
+        arrs["maxlcp"] = m.value
+        return arrs
+
+    def factorize(self, text, threshold=5, flatten=0):
+        """Returns (pos, src, len) sorted by pos and the stats dict."""
+        a = _u8(text)
+        p, s, l = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        z, st = ctypes.c_size_t(), Stats()
+        self._check(self._L.tdc_gpu_lcpcomp_factorize(self._h, _ptr(a), len(a), threshold, int(flatten), ctypes.byref(p),
+                                                      ctypes.byref(s), ctypes.byref(l), ctypes.byref(z), ctypes.byref(st)))
+        out = [np.frombuffer(self._take(x, z.value * 4), dtype=np.uint32).copy() for x in (p, s, l)]
+        return out[0], out[1], out[2], st.as_dict()
+
+    def flatten(self, n, pos, src, length):
+        pos = np.ascontiguousarray(pos, dtype=np.uint32)
+        src = np.ascontiguousarray(src, dtype=np.uint32).copy()
+        length = np.ascontiguousarray(length, dtype=np.uint32)
+        nf, md = ctypes.c_uint64(), ctypes.c_uint64()
+        self._check(self._L.tdc_gpu_flatten(self._h, n, _ptr(pos), _ptr(src), _ptr(length), len(pos), ctypes.byref(nf),
+                                            ctypes.byref(md)))
+        return src, nf.value, md.value
+
+    def encode_huff(self, text, pos, src, length):
+        a = _u8(text)
+        pos = np.ascontiguousarray(pos, dtype=np.uint32)
+        src = np.ascontiguousarray(src, dtype=np.uint32)
+        length = np.ascontiguousarray(length, dtype=np.uint32)
+        out, n = ctypes.c_void_p(), ctypes.c_size_t()
+        self._check(self._L.tdc_gpu_encode_huff(self._h, _ptr(a), len(a), _ptr(pos), _ptr(src), _ptr(length), len(pos),
+                                                ctypes.byref(out), ctypes.byref(n)))
+        return self._take(out, n.value)
+
+
+class LCPCompressor:
+    """Mirror of tdc::LCPCompressor<coder, ArraysComp, ...> (compressors/LCPCompressor.hpp:79-151) as the
+    reference's test harness drives it (test/test/util.hpp:442-463): the input is wrapped with the compressor's
+    input restrictions (escape {0}, null-terminate) and handed to compress()."""
+
+    def __init__(self, ctx, coder="huff", threshold=5, flatten=1, comp="arrays"):
+        if coder != "huff" or comp != "arrays":
+            # same wording as Registry.hpp:214
+            raise RuntimeError("No implementation found for compressor lcpcomp(coder=%s,comp=%s)" % (coder, comp))
+        self.ctx, self.threshold, self.flatten = ctx, int(threshold), int(flatten)
+        self.last_stats = None
+
+    def compress(self, data):
+        out, st = self.ctx.lcpcomp_compress(escape(data), self.threshold, self.flatten)
+        self.last_stats = st
+        return out

@@ -1,0 +1,75 @@
+"""ctypes binding of libtdc_gpu.so (C ABI: include/tdc_gpu.h).
+
+There is no CPU fallback anywhere in this package: if the HIP library is missing or no GPU is usable, the
+calls raise.  The oracle under oracle/ is test infrastructure and is never imported from here.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtdc_gpu.so")
+
+# every symbol include/tdc_gpu.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "tdc_gpu_ctx_create", "tdc_gpu_ctx_destroy", "tdc_gpu_ctx_reserve", "tdc_gpu_strerror", "tdc_gpu_last_error",
+    "tdc_gpu_free", "tdc_gpu_lcpcomp_compress", "tdc_gpu_lcpcomp_compress_dev", "tdc_gpu_lcpcomp_bound",
+    "tdc_gpu_suffix_array", "tdc_gpu_textds", "tdc_gpu_lcpcomp_factorize", "tdc_gpu_flatten", "tdc_gpu_encode_huff",
+    "tdc_escape", "tdc_unescape", "tdc_huffman_table", "tdc_gen_english", "tdc_gen_dna",
+]
+
+
+class Stats(ctypes.Structure):
+    _fields_ = (
+        [(k, ctypes.c_uint64) for k in ("n", "out_len", "factors", "maxlcp", "entries", "num_flattened", "max_depth_lb",
+                                        "flen_min", "flen_max", "fdist_max", "pushes")] +
+        [(k, ctypes.c_uint32) for k in ("sa_rounds", "sa_init_syms", "levels", "mis_rounds", "flatten_rounds", "sigma")] +
+        [(k, ctypes.c_uint64) for k in ("sa_sorted_elems", "arena_bytes")] +
+        [(k, ctypes.c_float) for k in ("ms_h2d", "ms_sa", "ms_phi", "ms_plcp", "ms_factorize", "ms_flatten", "ms_encode",
+                                       "ms_d2h", "ms_total")])
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+_lib = None
+
+
+def load():
+    """Load libtdc_gpu.so; raises if it has not been built (python -c 'import __graft_entry__ as g; g.build()')."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("tudocomp_amd: %s is missing -- build it with `make -C tudocomp_amd/csrc` "
+                           "(there is no CPU fallback)" % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    vp, sz, u32, i32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_int
+    pvp, psz = ctypes.POINTER(vp), ctypes.POINTER(sz)
+    L.tdc_gpu_ctx_create.argtypes = [i32, pvp]
+    L.tdc_gpu_ctx_destroy.argtypes = [vp]
+    L.tdc_gpu_ctx_destroy.restype = None
+    L.tdc_gpu_ctx_reserve.argtypes = [vp, sz]
+    L.tdc_gpu_strerror.argtypes = [i32]
+    L.tdc_gpu_strerror.restype = ctypes.c_char_p
+    L.tdc_gpu_last_error.argtypes = [vp]
+    L.tdc_gpu_last_error.restype = ctypes.c_char_p
+    L.tdc_gpu_free.argtypes = [vp]
+    L.tdc_gpu_free.restype = None
+    L.tdc_gpu_lcpcomp_compress.argtypes = [vp, vp, sz, u32, i32, i32, pvp, psz, ctypes.POINTER(Stats)]
+    L.tdc_gpu_lcpcomp_compress_dev.argtypes = [vp, vp, sz, u32, i32, i32, vp, sz, psz, ctypes.POINTER(Stats)]
+    L.tdc_gpu_lcpcomp_bound.argtypes = [sz]
+    L.tdc_gpu_lcpcomp_bound.restype = sz
+    L.tdc_gpu_suffix_array.argtypes = [vp, vp, sz, vp, vp]
+    L.tdc_gpu_textds.argtypes = [vp, vp, sz, vp, vp, vp, vp, vp, ctypes.POINTER(u32)]
+    L.tdc_gpu_lcpcomp_factorize.argtypes = [vp, vp, sz, u32, i32, pvp, pvp, pvp, psz, ctypes.POINTER(Stats)]
+    L.tdc_gpu_flatten.argtypes = [vp, sz, vp, vp, vp, sz, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
+    L.tdc_gpu_encode_huff.argtypes = [vp, vp, sz, vp, vp, vp, sz, pvp, psz]
+    L.tdc_escape.argtypes = [vp, sz, vp]
+    L.tdc_escape.restype = sz
+    L.tdc_unescape.argtypes = [vp, sz, vp]
+    L.tdc_unescape.restype = sz
+    L.tdc_huffman_table.argtypes = [vp, ctypes.POINTER(u32), ctypes.POINTER(u32), vp, vp, vp]
+    L.tdc_gen_english.argtypes = [vp, sz, ctypes.c_uint64]
+    L.tdc_gen_dna.argtypes = [vp, sz, ctypes.c_uint64]
+    _lib = L
+    return L

@@ -1,0 +1,452 @@
+// api.hip -- the C ABI of include/tdc_gpu.h on top of the stage functions (stages.hpp).
+#include "../../include/tdc_gpu.h"
+#include "stages.hpp"
+#include "prim.hpp"
+#include "huffman_host.hpp"
+
+#include <new>
+#include <string>
+#include <stdlib.h>
+#include <string.h>
+
+using namespace tdc;
+
+struct tdc_gpu_ctx {
+    Ctx c;
+    std::string last_error;
+};
+
+namespace {
+
+struct ArgError { int code; const char* msg; };
+
+template <typename F>
+int guarded(tdc_gpu_ctx* ctx, F&& f) {
+    if (!ctx) return TDC_GPU_ERR_ARG;
+    ctx->last_error.clear();
+    try {
+        HIP_TRY(hipSetDevice(ctx->c.device));
+        f();
+        return TDC_GPU_OK;
+    } catch (const HipError& e) {
+        char buf[512];
+        snprintf(buf, sizeof(buf), "%s (%s:%d)", hipGetErrorString(e.e), e.file, e.line);
+        ctx->last_error = buf;
+        (void)hipGetLastError();
+        if (e.e == hipErrorOutOfMemory) return TDC_GPU_ERR_OOM;
+        if (e.e == hipErrorUnknown) return TDC_GPU_ERR_INTERNAL;
+        if (e.e == hipErrorInvalidValue && e.line < 0) return TDC_GPU_ERR_ARG;
+        return TDC_GPU_ERR_HIP;
+    } catch (const ArgError& e) {
+        ctx->last_error = e.msg;
+        return e.code;
+    } catch (const std::bad_alloc&) {
+        ctx->last_error = "host allocation failed";
+        return TDC_GPU_ERR_OOM;
+    } catch (...) {
+        ctx->last_error = "unknown exception";
+        return TDC_GPU_ERR_INTERNAL;
+    }
+}
+
+size_t arena_need(size_t n) { return 100 * n + ((size_t)64 << 20); }
+
+void check_text_args(const void* text, size_t n) {
+    if (!text) throw ArgError{TDC_GPU_ERR_ARG, "text is NULL"};
+    if (n == 0) throw ArgError{TDC_GPU_ERR_NO_SENTINEL, "empty view: the text must end with a 0 sentinel"};
+    if (n >= 0x7FFFFFFFull) throw ArgError{TDC_GPU_ERR_TOO_LARGE, "text length must be < 2^31 - 1 (32-bit len_t)"};
+}
+
+struct Events {
+    Ctx& c;
+    int used = 0;
+    explicit Events(Ctx& ctx) : c(ctx) {}
+    int tick() { HIP_TRY(hipEventRecord(c.ev[used], c.stream)); return used++; }
+    float ms(int a, int b) { float t = 0; HIP_TRY(hipEventElapsedTime(&t, c.ev[a], c.ev[b])); return t; }
+};
+
+struct DevArrays {
+    u32 *sa = nullptr, *isa = nullptr, *phi = nullptr, *plcp = nullptr;
+    FactorSpace fs;
+    u32 maxlcp = 0;
+};
+
+// Checks that the 0 byte occurs exactly once (at n-1, already verified by the caller).
+__global__ void count_zero_kernel(const u8* __restrict__ text, size_t n, u32* __restrict__ cnt) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    u32 local = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) local += (text[i] == 0);
+    local = wave_reduce_sum(local);
+    if (lane_id() == 0 && local) atomicAdd(cnt, local);
+}
+
+void validate_device_text(Ctx& c, const u8* d_text, size_t n) {
+    const size_t mark = c.arena.mark();
+    u32* d_cnt = c.arena.get<u32>(2);
+    HIP_TRY(hipMemsetAsync(d_cnt, 0, 2 * sizeof(u32), c.stream));
+    unsigned g = cdiv(n, 256 * 16); if (g > 2048) g = 2048; if (g == 0) g = 1;
+    count_zero_kernel<<<g, 256, 0, c.stream>>>(d_text, n, d_cnt);
+    LAUNCH_CHECK();
+    u8 last = 1;
+    HIP_TRY(hipMemcpyAsync(&last, d_text + n - 1, 1, hipMemcpyDeviceToHost, c.stream));
+    const u32 zeros = c.read(d_cnt);
+    c.arena.release(mark);
+    if (last != 0) throw ArgError{TDC_GPU_ERR_NO_SENTINEL, "text does not end with a 0 sentinel"};
+    if (zeros != 1) throw ArgError{TDC_GPU_ERR_ARG, "text contains 0 bytes besides the sentinel (escape the input first)"};
+}
+
+// SA -> ISA -> Phi -> PLCP  (TextDS::require, ds/TextDS.hpp:247-292)
+void run_textds(Ctx& c, const u8* d_text, size_t n, DevArrays& A, tdc_gpu_stats* st, Events* ev) {
+    A.sa = c.arena.get<u32>(n);
+    A.isa = c.arena.get<u32>(n);
+    A.phi = c.arena.get<u32>(n);
+    A.plcp = c.arena.get<u32>(n);
+    u32* d_max = c.arena.get<u32>(1);
+    SAStats ss;
+    const int e0 = ev ? ev->tick() : 0;
+    build_suffix_array(c, d_text, n, A.sa, A.isa, &ss);
+    const int e1 = ev ? ev->tick() : 0;
+    build_phi(c, A.sa, n, A.phi);
+    const int e2 = ev ? ev->tick() : 0;
+    build_plcp(c, d_text, n, A.phi, A.plcp, d_max);
+    const int e3 = ev ? ev->tick() : 0;
+    A.maxlcp = c.read(d_max);
+    if (st) {
+        st->maxlcp = A.maxlcp;
+        st->sa_rounds = ss.rounds; st->sa_init_syms = ss.init_syms; st->sa_sorted_elems = ss.sorted_elems;
+        if (ev) { st->ms_sa = ev->ms(e0, e1); st->ms_phi = ev->ms(e1, e2); st->ms_plcp = ev->ms(e2, e3); }
+    }
+}
+
+void run_factorize(Ctx& c, size_t n, DevArrays& A, u32 threshold, int flatten, tdc_gpu_stats* st, Events* ev) {
+    A.fs.flen = c.arena.get<u32>(n);
+    A.fs.owner = c.arena.get<u32>(n);
+    A.fs.fsrc = c.arena.get<u32>(n);
+    FactorizeStats fz;
+    FlattenStats fl;
+    const int e0 = ev ? ev->tick() : 0;
+    factorize_arrays(c, n, A.sa, A.isa, A.phi, A.plcp, A.maxlcp, threshold, A.fs, &fz);
+    const int e1 = ev ? ev->tick() : 0;
+    if (flatten) flatten_factors(c, n, A.fs, &fl);
+    const int e2 = ev ? ev->tick() : 0;
+    if (st) {
+        st->factors = fz.factors; st->entries = fz.entries; st->pushes = fz.pushes;
+        st->levels = fz.levels; st->mis_rounds = fz.rounds;
+        st->num_flattened = fl.num_flattened; st->max_depth_lb = fl.max_depth_lb; st->flatten_rounds = fl.rounds;
+        if (ev) { st->ms_factorize = ev->ms(e0, e1); st->ms_flatten = ev->ms(e1, e2); }
+    }
+}
+
+// whole pipeline on a device-resident text; output written to d_out (8-byte aligned, capacity out_cap)
+size_t run_pipeline(Ctx& c, const u8* d_text, size_t n, u32 threshold, int flatten, u8* d_out, size_t out_cap,
+                    tdc_gpu_stats* st, Events& ev) {
+    if (threshold == 0) throw ArgError{TDC_GPU_ERR_ARG, "threshold must be >= 1"};
+    validate_device_text(c, d_text, n);
+    DevArrays A;
+    run_textds(c, d_text, n, A, st, &ev);
+    run_factorize(c, n, A, threshold, flatten, st, &ev);
+    EncodeStats es;
+    const int e0 = ev.tick();
+    const size_t out_len = encode_huff(c, d_text, n, A.fs, d_out, out_cap, &es);
+    const int e1 = ev.tick();
+    HIP_TRY(hipStreamSynchronize(c.stream));
+    if (st) {
+        st->n = n; st->out_len = out_len;
+        st->flen_min = es.flen_min; st->flen_max = es.flen_max; st->fdist_max = es.fdist_max; st->sigma = es.sigma;
+        st->ms_encode = ev.ms(e0, e1);
+        st->arena_bytes = c.arena.high;
+    }
+    return out_len;
+}
+
+void validate_factor_list(size_t n, const uint32_t* pos, const uint32_t* src, const uint32_t* len, size_t z) {
+    uint64_t end = 0;
+    for (size_t i = 0; i < z; ++i) {
+        if (len[i] == 0) throw ArgError{TDC_GPU_ERR_ARG, "factor with length 0"};
+        if (pos[i] < end) throw ArgError{TDC_GPU_ERR_ARG, "factors must be sorted by pos and must not overlap"};
+        end = (uint64_t)pos[i] + len[i];
+        if (end > n) throw ArgError{TDC_GPU_ERR_ARG, "factor exceeds the text"};
+        if (src && (uint64_t)src[i] + len[i] > n) throw ArgError{TDC_GPU_ERR_ARG, "factor source exceeds the text"};
+    }
+}
+
+template <typename T> T* host_alloc(size_t count) {
+    T* p = (T*)malloc((count ? count : 1) * sizeof(T));
+    if (!p) throw std::bad_alloc();
+    return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* tdc_gpu_strerror(int status) {
+    switch (status) {
+        case TDC_GPU_OK: return "success";
+        case TDC_GPU_ERR_HIP: return "HIP runtime error (is a gfx950 GPU visible?)";
+        case TDC_GPU_ERR_ARG: return "invalid argument";
+        case TDC_GPU_ERR_NO_SENTINEL: return "Expected a sentinel byte (0) at the end of the input text";
+        case TDC_GPU_ERR_TOO_LARGE: return "input too large: text length must be < 2^31";
+        case TDC_GPU_ERR_OOM: return "out of memory";
+        case TDC_GPU_ERR_UNSUPPORTED: return "No implementation found for this coder/strategy";
+        case TDC_GPU_ERR_INTERNAL: return "internal error";
+        default: return "unknown status";
+    }
+}
+
+const char* tdc_gpu_last_error(const tdc_gpu_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+void tdc_gpu_free(void* p) { free(p); }
+
+int tdc_gpu_ctx_create(int device, tdc_gpu_ctx** out) {
+    if (!out) return TDC_GPU_ERR_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { (void)hipGetLastError(); return TDC_GPU_ERR_HIP; }
+    if (device < 0 || device >= count) return TDC_GPU_ERR_ARG;
+    tdc_gpu_ctx* ctx = new (std::nothrow) tdc_gpu_ctx();
+    if (!ctx) return TDC_GPU_ERR_OOM;
+    ctx->c.device = device;
+    try {
+        HIP_TRY(hipSetDevice(device));
+        HIP_TRY(hipStreamCreateWithFlags(&ctx->c.stream, hipStreamNonBlocking));
+        for (auto& e : ctx->c.ev) HIP_TRY(hipEventCreate(&e));
+        ctx->c.pinned_size = 4096;
+        HIP_TRY(hipHostMalloc(&ctx->c.pinned, ctx->c.pinned_size, hipHostMallocDefault));
+    } catch (const HipError&) {
+        (void)hipGetLastError();
+        tdc_gpu_ctx_destroy(ctx);
+        return TDC_GPU_ERR_HIP;
+    }
+    *out = ctx;
+    return TDC_GPU_OK;
+}
+
+void tdc_gpu_ctx_destroy(tdc_gpu_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->c.device);
+    if (ctx->c.stream) (void)hipStreamSynchronize(ctx->c.stream);
+    if (ctx->c.arena.base) (void)hipFree(ctx->c.arena.base);
+    if (ctx->c.pinned) (void)hipHostFree(ctx->c.pinned);
+    for (auto& e : ctx->c.ev) if (e) (void)hipEventDestroy(e);
+    if (ctx->c.stream) (void)hipStreamDestroy(ctx->c.stream);
+    delete ctx;
+}
+
+int tdc_gpu_ctx_reserve(tdc_gpu_ctx* ctx, size_t n) {
+    return guarded(ctx, [&] { ctx->c.ensure_arena(arena_need(n)); });
+}
+
+size_t tdc_gpu_lcpcomp_bound(size_t n) { return align_up(encode_bound(n) + 16, 8); }
+
+int tdc_gpu_lcpcomp_compress_dev(tdc_gpu_ctx* ctx, const void* d_text, size_t n, uint32_t threshold, int flatten, int coder,
+                                 void* d_out, size_t out_cap, size_t* out_len, tdc_gpu_stats* stats) {
+    return guarded(ctx, [&] {
+        if (coder != TDC_GPU_CODER_HUFF) throw ArgError{TDC_GPU_ERR_UNSUPPORTED, "only coder=huff is built"};
+        check_text_args(d_text, n);
+        if (!d_out || !out_len || ((uintptr_t)d_out & 7)) throw ArgError{TDC_GPU_ERR_ARG, "d_out must be non-NULL and 8-byte aligned"};
+        Ctx& c = ctx->c;
+        if (stats) memset(stats, 0, sizeof(*stats));
+        c.ensure_arena(arena_need(n));
+        Events ev(c);
+        const int e0 = ev.tick();
+        *out_len = run_pipeline(c, (const u8*)d_text, n, threshold, flatten, (u8*)d_out, out_cap, stats, ev);
+        const int e1 = ev.tick();
+        HIP_TRY(hipStreamSynchronize(c.stream));
+        if (stats) stats->ms_total = ev.ms(e0, e1);
+    });
+}
+
+int tdc_gpu_lcpcomp_compress(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, uint32_t threshold, int flatten, int coder,
+                             uint8_t** out, size_t* out_len, tdc_gpu_stats* stats) {
+    return guarded(ctx, [&] {
+        if (coder != TDC_GPU_CODER_HUFF) throw ArgError{TDC_GPU_ERR_UNSUPPORTED, "only coder=huff is built"};
+        check_text_args(text, n);
+        if (!out || !out_len) throw ArgError{TDC_GPU_ERR_ARG, "out/out_len is NULL"};
+        if (text[n - 1] != 0) throw ArgError{TDC_GPU_ERR_NO_SENTINEL, "text does not end with a 0 sentinel"};
+        Ctx& c = ctx->c;
+        if (stats) memset(stats, 0, sizeof(*stats));
+        c.ensure_arena(arena_need(n));
+        Events ev(c);
+        const int e0 = ev.tick();
+        u8* d_text = c.arena.get<u8>(n + 64);
+        HIP_TRY(hipMemcpyAsync(d_text, text, n, hipMemcpyHostToDevice, c.stream));
+        const int e1 = ev.tick();
+        const size_t cap = tdc_gpu_lcpcomp_bound(n);
+        u8* d_out = c.arena.get<u8>(cap);
+        const size_t len = run_pipeline(c, d_text, n, threshold, flatten, d_out, cap, stats, ev);
+        const int e2 = ev.tick();
+        uint8_t* h = host_alloc<uint8_t>(len);
+        HIP_TRY(hipMemcpyAsync(h, d_out, len, hipMemcpyDeviceToHost, c.stream));
+        const int e3 = ev.tick();
+        HIP_TRY(hipStreamSynchronize(c.stream));
+        *out = h; *out_len = len;
+        if (stats) { stats->ms_h2d = ev.ms(e0, e1); stats->ms_d2h = ev.ms(e2, e3); stats->ms_total = ev.ms(e0, e3); }
+    });
+}
+
+int tdc_gpu_suffix_array(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, uint32_t* sa, uint32_t* isa) {
+    return tdc_gpu_textds(ctx, text, n, sa, isa, nullptr, nullptr, nullptr, nullptr);
+}
+
+int tdc_gpu_textds(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, uint32_t* sa, uint32_t* isa, uint32_t* phi,
+                   uint32_t* plcp, uint32_t* lcp, uint32_t* maxlcp) {
+    return guarded(ctx, [&] {
+        check_text_args(text, n);
+        if (text[n - 1] != 0) throw ArgError{TDC_GPU_ERR_NO_SENTINEL, "text does not end with a 0 sentinel"};
+        Ctx& c = ctx->c;
+        c.ensure_arena(arena_need(n));
+        u8* d_text = c.arena.get<u8>(n + 64);
+        HIP_TRY(hipMemcpyAsync(d_text, text, n, hipMemcpyHostToDevice, c.stream));
+        validate_device_text(c, d_text, n);
+        DevArrays A;
+        if (!phi && !plcp && !lcp && !maxlcp) {
+            A.sa = c.arena.get<u32>(n);
+            A.isa = c.arena.get<u32>(n);
+            build_suffix_array(c, d_text, n, A.sa, A.isa, nullptr);
+        } else {
+            run_textds(c, d_text, n, A, nullptr, nullptr);
+        }
+        if (sa) HIP_TRY(hipMemcpyAsync(sa, A.sa, n * 4, hipMemcpyDeviceToHost, c.stream));
+        if (isa) HIP_TRY(hipMemcpyAsync(isa, A.isa, n * 4, hipMemcpyDeviceToHost, c.stream));
+        if (phi) HIP_TRY(hipMemcpyAsync(phi, A.phi, n * 4, hipMemcpyDeviceToHost, c.stream));
+        if (plcp) HIP_TRY(hipMemcpyAsync(plcp, A.plcp, n * 4, hipMemcpyDeviceToHost, c.stream));
+        if (lcp) {
+            u32* d_lcp = c.arena.get<u32>(n);
+            build_lcp(c, A.sa, A.plcp, n, d_lcp);
+            HIP_TRY(hipMemcpyAsync(lcp, d_lcp, n * 4, hipMemcpyDeviceToHost, c.stream));
+        }
+        if (maxlcp) *maxlcp = A.maxlcp;
+        HIP_TRY(hipStreamSynchronize(c.stream));
+    });
+}
+
+int tdc_gpu_lcpcomp_factorize(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, uint32_t threshold, int flatten,
+                              uint32_t** pos, uint32_t** src, uint32_t** len, size_t* z, tdc_gpu_stats* stats) {
+    return guarded(ctx, [&] {
+        check_text_args(text, n);
+        if (!pos || !src || !len || !z) throw ArgError{TDC_GPU_ERR_ARG, "output pointer is NULL"};
+        if (threshold == 0) throw ArgError{TDC_GPU_ERR_ARG, "threshold must be >= 1"};
+        if (text[n - 1] != 0) throw ArgError{TDC_GPU_ERR_NO_SENTINEL, "text does not end with a 0 sentinel"};
+        Ctx& c = ctx->c;
+        if (stats) memset(stats, 0, sizeof(*stats));
+        c.ensure_arena(arena_need(n));
+        Events ev(c);
+        u8* d_text = c.arena.get<u8>(n + 64);
+        HIP_TRY(hipMemcpyAsync(d_text, text, n, hipMemcpyHostToDevice, c.stream));
+        validate_device_text(c, d_text, n);
+        DevArrays A;
+        run_textds(c, d_text, n, A, stats, &ev);
+        run_factorize(c, n, A, threshold, flatten, stats, &ev);
+        u32* d_pos = c.arena.get<u32>(n), *d_src = c.arena.get<u32>(n), *d_len = c.arena.get<u32>(n);
+        const size_t cnt = extract_factors(c, n, A.fs, d_pos, d_src, d_len, n);
+        uint32_t* hp = host_alloc<uint32_t>(cnt), *hs = host_alloc<uint32_t>(cnt), *hl = host_alloc<uint32_t>(cnt);
+        if (cnt) {
+            HIP_TRY(hipMemcpyAsync(hp, d_pos, cnt * 4, hipMemcpyDeviceToHost, c.stream));
+            HIP_TRY(hipMemcpyAsync(hs, d_src, cnt * 4, hipMemcpyDeviceToHost, c.stream));
+            HIP_TRY(hipMemcpyAsync(hl, d_len, cnt * 4, hipMemcpyDeviceToHost, c.stream));
+        }
+        HIP_TRY(hipStreamSynchronize(c.stream));
+        *pos = hp; *src = hs; *len = hl; *z = cnt;
+        if (stats) { stats->n = n; stats->arena_bytes = c.arena.high; }
+    });
+}
+
+int tdc_gpu_flatten(tdc_gpu_ctx* ctx, size_t n, const uint32_t* pos, uint32_t* src, const uint32_t* len, size_t z,
+                    uint64_t* num_flattened, uint64_t* max_depth_lb) {
+    return guarded(ctx, [&] {
+        if (n == 0 || n >= 0x7FFFFFFFull) throw ArgError{TDC_GPU_ERR_ARG, "bad n"};
+        if (z && (!pos || !src || !len)) throw ArgError{TDC_GPU_ERR_ARG, "factor arrays are NULL"};
+        validate_factor_list(n, pos, src, len, z);
+        Ctx& c = ctx->c;
+        c.ensure_arena(arena_need(n));
+        FactorSpace fs;
+        fs.flen = c.arena.get<u32>(n); fs.owner = c.arena.get<u32>(n); fs.fsrc = c.arena.get<u32>(n);
+        u32* d_pos = c.arena.get<u32>(z + 1), *d_src = c.arena.get<u32>(z + 1), *d_len = c.arena.get<u32>(z + 1);
+        if (z) {
+            HIP_TRY(hipMemcpyAsync(d_pos, pos, z * 4, hipMemcpyHostToDevice, c.stream));
+            HIP_TRY(hipMemcpyAsync(d_src, src, z * 4, hipMemcpyHostToDevice, c.stream));
+            HIP_TRY(hipMemcpyAsync(d_len, len, z * 4, hipMemcpyHostToDevice, c.stream));
+        }
+        scatter_factors(c, n, d_pos, d_src, d_len, z, fs);
+        FlattenStats fl;
+        flatten_factors(c, n, fs, &fl);
+        const size_t cnt = extract_factors(c, n, fs, d_pos, d_src, nullptr, z + 1);
+        if (cnt != z) throw HipError{hipErrorUnknown, "flatten: factor count changed", (int)__LINE__};
+        if (z) HIP_TRY(hipMemcpyAsync(src, d_src, z * 4, hipMemcpyDeviceToHost, c.stream));
+        HIP_TRY(hipStreamSynchronize(c.stream));
+        if (num_flattened) *num_flattened = fl.num_flattened;
+        if (max_depth_lb) *max_depth_lb = fl.max_depth_lb;
+    });
+}
+
+int tdc_gpu_encode_huff(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, const uint32_t* pos, const uint32_t* src,
+                        const uint32_t* len, size_t z, uint8_t** out, size_t* out_len) {
+    return guarded(ctx, [&] {
+        check_text_args(text, n);
+        if (!out || !out_len) throw ArgError{TDC_GPU_ERR_ARG, "out/out_len is NULL"};
+        if (z && (!pos || !src || !len)) throw ArgError{TDC_GPU_ERR_ARG, "factor arrays are NULL"};
+        validate_factor_list(n, pos, src, len, z);
+        Ctx& c = ctx->c;
+        c.ensure_arena(arena_need(n));
+        u8* d_text = c.arena.get<u8>(n + 64);
+        HIP_TRY(hipMemcpyAsync(d_text, text, n, hipMemcpyHostToDevice, c.stream));
+        FactorSpace fs;
+        fs.flen = c.arena.get<u32>(n); fs.owner = c.arena.get<u32>(n); fs.fsrc = c.arena.get<u32>(n);
+        u32* d_pos = c.arena.get<u32>(z + 1), *d_src = c.arena.get<u32>(z + 1), *d_len = c.arena.get<u32>(z + 1);
+        if (z) {
+            HIP_TRY(hipMemcpyAsync(d_pos, pos, z * 4, hipMemcpyHostToDevice, c.stream));
+            HIP_TRY(hipMemcpyAsync(d_src, src, z * 4, hipMemcpyHostToDevice, c.stream));
+            HIP_TRY(hipMemcpyAsync(d_len, len, z * 4, hipMemcpyHostToDevice, c.stream));
+        }
+        scatter_factors(c, n, d_pos, d_src, d_len, z, fs);
+        const size_t cap = tdc_gpu_lcpcomp_bound(n);
+        u8* d_out = c.arena.get<u8>(cap);
+        const size_t l = encode_huff(c, d_text, n, fs, d_out, cap, nullptr);
+        uint8_t* h = host_alloc<uint8_t>(l);
+        HIP_TRY(hipMemcpyAsync(h, d_out, l, hipMemcpyDeviceToHost, c.stream));
+        HIP_TRY(hipStreamSynchronize(c.stream));
+        *out = h; *out_len = l;
+    });
+}
+
+// ---- host-side helpers ------------------------------------------------------------------------------------
+size_t tdc_escape(const uint8_t* in, size_t n, uint8_t* out) {
+    size_t o = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const uint8_t ch = in[i];
+        if (ch == 0x00) { out[o++] = 0xFF; out[o++] = 0xFE; }
+        else if (ch == 0xFF) { out[o++] = 0xFF; out[o++] = 0xFF; }
+        else out[o++] = ch;
+    }
+    out[o++] = 0;
+    return o;
+}
+
+size_t tdc_unescape(const uint8_t* in, size_t n, uint8_t* out) {
+    size_t o = 0;
+    if (n && in[n - 1] == 0) --n;
+    for (size_t i = 0; i < n; ++i) {
+        const uint8_t ch = in[i];
+        if (ch == 0xFF && i + 1 < n) { const uint8_t d = in[++i]; out[o++] = (d == 0xFE) ? 0x00 : d; }
+        else out[o++] = ch;
+    }
+    return o;
+}
+
+int tdc_huffman_table(const uint32_t counts[256], uint32_t* sigma, uint32_t* longest, uint8_t order[256],
+                      uint8_t len_of[256], uint64_t code_of[256]) {
+    if (!counts) return TDC_GPU_ERR_ARG;
+    try {
+        HuffTable t;
+        build_huffman_table(counts, &t);
+        if (sigma) *sigma = t.sigma;
+        if (longest) *longest = t.longest;
+        if (order) memcpy(order, t.order, 256);
+        if (len_of) memcpy(len_of, t.len_of, 256);
+        if (code_of) memcpy(code_of, t.code_of, 256 * sizeof(uint64_t));
+    } catch (...) { return TDC_GPU_ERR_OOM; }
+    return TDC_GPU_OK;
+}
+
+}  // extern "C"

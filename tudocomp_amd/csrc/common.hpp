@@ -1,0 +1,189 @@
+// common.hpp -- shared host/device helpers for the MI355X (gfx950) lcpcomp pipeline.
+// Wave size is 64 on CDNA4; every wave-level idiom below is written for 64 lanes.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <stdio.h>
+
+namespace tdc {
+
+typedef uint8_t  u8;
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+constexpr u32 NONE32 = 0xFFFFFFFFu;
+constexpr int WAVE = 64;
+
+// Error codes of the C ABI (include/tdc_gpu.h)
+enum {
+    TDC_OK = 0,
+    TDC_ERR_HIP = -1,          // a HIP runtime call failed (no device, OOM, launch failure)
+    TDC_ERR_ARG = -2,          // bad argument
+    TDC_ERR_NO_SENTINEL = -3,  // text does not end with the unique 0 (ds/TextDS.hpp:132-138)
+    TDC_ERR_TOO_LARGE = -4,    // n >= 2^31 (reference limit, 32-bit len_t)
+    TDC_ERR_OOM = -5,          // device arena too small
+    TDC_ERR_UNSUPPORTED = -6,  // coder / option not built
+    TDC_ERR_INTERNAL = -7,     // invariant violated (bug)
+};
+
+struct HipError { hipError_t e; const char* file; int line; };
+
+#define HIP_TRY(expr)                                                                  \
+    do {                                                                               \
+        hipError_t _e = (expr);                                                        \
+        if (_e != hipSuccess) throw ::tdc::HipError{_e, __FILE__, __LINE__};           \
+    } while (0)
+
+inline unsigned bits_for(u64 v) {   // util.hpp:194 of the reference: bits_for(0) == 1
+    unsigned b = 0;
+    if (v == 0) return 1;
+    while (v) { ++b; v >>= 1; }
+    return b;
+}
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
+
+// ------------------------------------------------------------------------------------------------
+// Device arena: one hipMalloc per context, bump allocation with mark/release.  All stages carve their
+// position-space arrays out of it, so a compress call performs no hipMalloc/hipFree in steady state.
+// ------------------------------------------------------------------------------------------------
+struct Arena {
+    char* base = nullptr;
+    size_t size = 0;
+    size_t top = 0;
+    size_t high = 0;
+
+    void* alloc(size_t bytes) {
+        size_t off = align_up(top, 256);
+        if (off + bytes > size) throw HipError{hipErrorOutOfMemory, "arena", (int)__LINE__};
+        top = off + bytes;
+        if (top > high) high = top;
+        return base + off;
+    }
+    template <typename T> T* get(size_t count) { return (T*)alloc(count * sizeof(T)); }
+    size_t mark() const { return top; }
+    void release(size_t m) { top = m; }
+};
+
+struct Ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    Arena arena;
+    hipEvent_t ev[16] = {};
+    void* pinned = nullptr;        // small pinned staging block for device->host scalars
+    size_t pinned_size = 0;
+
+    void ensure_arena(size_t bytes) {
+        if (arena.size >= bytes) { arena.top = 0; return; }
+        if (arena.base) { HIP_TRY(hipFree(arena.base)); arena.base = nullptr; arena.size = 0; }
+        HIP_TRY(hipMalloc((void**)&arena.base, bytes));
+        arena.size = bytes;
+        arena.top = 0;
+    }
+    // read back a few scalars (stream-ordered, synchronous)
+    template <typename T> T read(const T* dptr) {
+        T* h = (T*)pinned;
+        HIP_TRY(hipMemcpyAsync(h, dptr, sizeof(T), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        return *h;
+    }
+    template <typename T> void read_n(const T* dptr, T* out, size_t count) {
+        HIP_TRY(hipMemcpyAsync(out, dptr, sizeof(T) * count, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+    }
+};
+
+#define LAUNCH_CHECK() HIP_TRY(hipGetLastError())
+
+// ------------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------------
+#ifdef __HIPCC__
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+// Inclusive scan across the 64 lanes of a wave.
+template <typename T>
+__device__ __forceinline__ T wave_inclusive_sum(T v) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        T o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+__device__ __forceinline__ u32 wave_inclusive_max(u32 v) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        u32 o = __shfl_up(v, d, 64);
+        if (lane >= d) v = max(v, o);
+    }
+    return v;
+}
+template <typename T>
+__device__ __forceinline__ T wave_reduce_sum(T v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+__device__ __forceinline__ u32 wave_reduce_max(u32 v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d, 64));
+    return v;
+}
+__device__ __forceinline__ u32 wave_reduce_min(u32 v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = min(v, __shfl_xor(v, d, 64));
+    return v;
+}
+
+// Block-wide exclusive sum for a block of NW waves (NW*64 threads).  `smem` must hold NW+1 values of T.
+// Returns the exclusive prefix of `v` over the block in thread order; `total` receives the block sum.
+template <typename T, int NW>
+__device__ __forceinline__ T block_exclusive_sum(T v, T* smem, T& total) {
+    const int lane = lane_id(), w = wave_id();
+    T inc = wave_inclusive_sum(v);
+    if (lane == 63) smem[w] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        T run = 0;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) { T t = smem[i]; smem[i] = run; run += t; }
+        smem[NW] = run;
+    }
+    __syncthreads();
+    T res = smem[w] + inc - v;
+    total = smem[NW];
+    __syncthreads();
+    return res;
+}
+
+// Block-wide inclusive max (same contract).
+template <int NW>
+__device__ __forceinline__ u32 block_inclusive_max(u32 v, u32* smem, u32& total) {
+    const int lane = lane_id(), w = wave_id();
+    u32 inc = wave_inclusive_max(v);
+    if (lane == 63) smem[w] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 run = 0;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) { u32 t = smem[i]; smem[i] = run; run = max(run, t); }
+        smem[NW] = run;
+    }
+    __syncthreads();
+    u32 res = max(smem[w], inc);
+    total = smem[NW];
+    __syncthreads();
+    return res;
+}
+
+#endif  // __HIPCC__
+
+}  // namespace tdc

@@ -1,0 +1,173 @@
+// flatten.hip -- factor list <-> position space, and lzss::FactorBuffer::flatten
+// (compressors/lzss/LZSSFactors.hpp:79-132).
+//
+// flatten redirects the source of factor f through the factor s covering that source while the whole copy fits
+// inside s (:106-119).  The reference does it sequentially in position order, so f sees the ALREADY FLATTENED source
+// of an earlier factor (s.pos < f.pos) and the ORIGINAL source of a later one.  Device formulation: rounds; a factor
+// advances along its chain as long as every earlier factor it touches is final, otherwise it waits for the next
+// round.  A final source is published as ONE 32-bit word (NOT_DONE until then), so no flag/data ordering is needed.
+#include "stages.hpp"
+#include "prim.hpp"
+
+namespace tdc {
+
+__global__ void fstart_flag_kernel(const u32* __restrict__ flen, const u32* __restrict__ owner, size_t n, u32* __restrict__ flag) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    flag[p] = (flen[p] != 0 && owner[p] == (u32)p) ? 1u : 0u;
+}
+__global__ void fstart_scatter_kernel(const u32* __restrict__ flen, const u32* __restrict__ owner, const u32* __restrict__ fsrc,
+                                      const u32* __restrict__ offs, size_t n, size_t cap, u32* __restrict__ pos,
+                                      u32* __restrict__ src, u32* __restrict__ len) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const u32 l = flen[p];
+    if (l != 0 && owner[p] == (u32)p) {
+        const u32 o = offs[p];
+        if (o < cap) {
+            pos[o] = (u32)p;
+            if (src) src[o] = fsrc[p];
+            if (len) len[o] = l;
+        }
+    }
+}
+
+size_t extract_factors(Ctx& c, size_t n, FactorSpace fs, u32* pos, u32* src, u32* len, size_t cap) {
+    if (n == 0) return 0;
+    const size_t mark = c.arena.mark();
+    u32* offs = c.arena.get<u32>(n);
+    u32* d_total = c.arena.get<u32>(1);
+    const unsigned gn = cdiv(n, 256);
+    fstart_flag_kernel<<<gn, 256, 0, c.stream>>>(fs.flen, fs.owner, n, offs);
+    LAUNCH_CHECK();
+    exclusive_sum_u32(c, offs, offs, n, d_total);
+    fstart_scatter_kernel<<<gn, 256, 0, c.stream>>>(fs.flen, fs.owner, fs.fsrc, offs, n, cap, pos, src, len);
+    LAUNCH_CHECK();
+    const size_t z = c.read(d_total);
+    c.arena.release(mark);
+    return z;
+}
+
+__global__ void fspace_clear_kernel(size_t n, u32* __restrict__ flen, u32* __restrict__ owner) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    flen[p] = 0;
+    owner[p] = NONE32;
+}
+__global__ void fspace_scatter_kernel(const u32* __restrict__ pos, const u32* __restrict__ src, const u32* __restrict__ len,
+                                      size_t z, size_t n, u32* __restrict__ flen, u32* __restrict__ owner, u32* __restrict__ fsrc) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= z) return;
+    const u32 p = pos[i], l = len[i];
+    if ((size_t)p + l > n) return;        // validated on the host; never write out of bounds
+    flen[p] = l;
+    fsrc[p] = src[i];
+    for (u32 j = 0; j < l; ++j) owner[p + j] = p;
+}
+
+void scatter_factors(Ctx& c, size_t n, const u32* pos, const u32* src, const u32* len, size_t z, FactorSpace fs) {
+    if (n == 0) return;
+    fspace_clear_kernel<<<cdiv(n, 256), 256, 0, c.stream>>>(n, fs.flen, fs.owner);
+    LAUNCH_CHECK();
+    if (z) {
+        fspace_scatter_kernel<<<cdiv(z, 256), 256, 0, c.stream>>>(pos, src, len, z, n, fs.flen, fs.owner, fs.fsrc);
+        LAUNCH_CHECK();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+constexpr u32 NOT_DONE = 0xFFFFFFFFu;
+
+struct FlattenScalars { u32 waiting; u32 num_flattened; u32 max_depth; u32 pad; };
+
+__global__ void flatten_init_kernel(const u32* __restrict__ fpos, size_t z, const u32* __restrict__ orig,
+                                    u32* __restrict__ ffinal, u32* __restrict__ cursrc, u32* __restrict__ depth) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= z) return;
+    const u32 p = fpos[i];
+    ffinal[p] = NOT_DONE;
+    cursrc[i] = orig[p];
+    depth[i] = 0;
+}
+
+__global__ void flatten_round_kernel(const u32* __restrict__ fpos, size_t z, size_t n, const u32* __restrict__ flen,
+                                     const u32* __restrict__ owner, const u32* __restrict__ orig, u32* ffinal,
+                                     u32* __restrict__ cursrc, u32* __restrict__ depth, FlattenScalars* __restrict__ sc) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= z) return;
+    const u32 p = fpos[i];
+    if (ffinal[p] != NOT_DONE) return;
+    const u32 len = flen[p];
+    u32 src = cursrc[i];
+    u32 dep = depth[i];
+    bool finished = false;
+    for (;;) {
+        if ((size_t)src >= n || dep >= n) { finished = true; break; }   // :106 src < fmap.size()  (dep bound: no endless chains)
+        const u32 s = owner[src];
+        if (s == NONE32) { finished = true; break; }                    // :106 fmap[src] == 0
+        const u32 d = src - s;
+        if ((u64)d + len > (u64)flen[s]) { finished = true; break; }    // :110 copy does not fit inside s
+        u32 ssrc;
+        if (s < p) {                                                    // earlier factor: needs its final source
+            ssrc = ffinal[s];
+            if (ssrc == NOT_DONE) break;                                // wait for the next round
+        } else {
+            ssrc = orig[s];                                             // later factor: still unflattened at this point
+        }
+        src = ssrc + d;                                                 // :111
+        ++dep;
+    }
+    cursrc[i] = src;
+    depth[i] = dep;
+    if (finished) {
+        ffinal[p] = dep ? src : orig[p];                                // :122-124
+        if (dep) { atomicAdd(&sc->num_flattened, 1u); atomicMax(&sc->max_depth, dep); }
+    } else {
+        atomicAdd(&sc->waiting, 1u);
+    }
+}
+
+__global__ void flatten_commit_kernel(const u32* __restrict__ fpos, size_t z, const u32* __restrict__ ffinal, u32* __restrict__ fsrc) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= z) return;
+    const u32 p = fpos[i];
+    fsrc[p] = ffinal[p];
+}
+
+void flatten_factors(Ctx& c, size_t n, FactorSpace fs, FlattenStats* st) {
+    FlattenStats local;
+    if (!st) st = &local;
+    *st = FlattenStats();
+    if (n == 0) return;
+    hipStream_t s = c.stream;
+    const size_t mark = c.arena.mark();
+    u32* fpos = c.arena.get<u32>(n);
+    const size_t z = extract_factors(c, n, fs, fpos, nullptr, nullptr, n);
+    if (z == 0) { c.arena.release(mark); return; }
+    u32* ffinal = c.arena.get<u32>(n);          // position-indexed, only factor starts are touched
+    u32* cursrc = c.arena.get<u32>(z);
+    u32* depth = c.arena.get<u32>(z);
+    FlattenScalars* d_sc = (FlattenScalars*)c.arena.alloc(sizeof(FlattenScalars));
+    HIP_TRY(hipMemsetAsync(d_sc, 0, sizeof(FlattenScalars), s));
+    const unsigned gz = cdiv(z, 256);
+    flatten_init_kernel<<<gz, 256, 0, s>>>(fpos, z, fs.fsrc, ffinal, cursrc, depth);
+    LAUNCH_CHECK();
+    u32 waiting = (u32)z;
+    while (waiting) {
+        HIP_TRY(hipMemsetAsync(&d_sc->waiting, 0, sizeof(u32), s));
+        flatten_round_kernel<<<gz, 256, 0, s>>>(fpos, z, n, fs.flen, fs.owner, fs.fsrc, ffinal, cursrc, depth, d_sc);
+        LAUNCH_CHECK();
+        const u32 now = c.read(&d_sc->waiting);
+        st->rounds++;
+        if (now >= waiting) throw HipError{hipErrorUnknown, "flatten: rounds made no progress", (int)__LINE__};
+        waiting = now;
+    }
+    flatten_commit_kernel<<<gz, 256, 0, s>>>(fpos, z, ffinal, fs.fsrc);
+    LAUNCH_CHECK();
+    FlattenScalars h = c.read(d_sc);
+    st->num_flattened = h.num_flattened;
+    st->max_depth_lb = h.max_depth;
+    c.arena.release(mark);
+}
+
+}  // namespace tdc

@@ -1,0 +1,292 @@
+// prim.hip -- device-wide scans and the stable LSD radix sort (gfx950, wave64).
+//
+// Radix sort layout (one pass = 8 key bits):
+//   rs_count   : one workgroup per 4096-key tile builds a 256-bin LDS histogram -> counts[digit][tile]
+//   exclusive_sum over counts (digit-major) -> global start of every (digit, tile) run
+//   rs_scatter : the same tiling; ranks inside a tile come from a wave-level match (8 ballots / key) plus
+//                per-wave LDS counters, which keeps the sort stable without any LDS atomics.
+// Keys are read twice and written once per pass; values are read and written once.
+#include "prim.hpp"
+
+namespace tdc {
+
+// ------------------------------------------------------------------------------------------------
+// scans
+// ------------------------------------------------------------------------------------------------
+constexpr int SNW = 4;          // waves per workgroup
+constexpr int STILE = 4096;     // elements per workgroup: 4 rounds x 256 threads x 4 consecutive elements
+
+template <typename T, int OP>   // OP 0: sum, OP 1: max (identity 0, unsigned)
+__device__ __forceinline__ T op2(T a, T b) { return OP == 0 ? (T)(a + b) : (a > b ? a : b); }
+
+template <typename T, int OP>
+__device__ __forceinline__ T wave_inclusive_op(T v) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        T o = __shfl_up(v, d, 64);
+        if (lane >= d) v = op2<T, OP>(v, o);
+    }
+    return v;
+}
+
+// exclusive prefix over the 256 threads of the block; total = block aggregate. smem: SNW+1 entries.
+template <typename T, int OP>
+__device__ __forceinline__ T block_exclusive_op(T v, T* smem, T& total) {
+    const int lane = lane_id(), w = wave_id();
+    T inc = wave_inclusive_op<T, OP>(v);
+    T exc = __shfl_up(inc, 1, 64);
+    if (lane == 0) exc = 0;
+    if (lane == 63) smem[w] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        T run = 0;
+#pragma unroll
+        for (int i = 0; i < SNW; ++i) { T t = smem[i]; smem[i] = run; run = op2<T, OP>(run, t); }
+        smem[SNW] = run;
+    }
+    __syncthreads();
+    T res = op2<T, OP>(smem[w], exc);
+    total = smem[SNW];
+    __syncthreads();
+    return res;
+}
+
+template <typename T>
+__device__ __forceinline__ void load4(const T* __restrict__ in, size_t idx, size_t n, T (&v)[4]) {
+    if (idx + 4 <= n) {
+        const T* p = (const T*)__builtin_assume_aligned(in + idx, 16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = p[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = (idx + i < n) ? in[idx + i] : (T)0;
+    }
+}
+template <typename T>
+__device__ __forceinline__ void store4(T* __restrict__ out, size_t idx, size_t n, const T (&v)[4]) {
+    if (idx + 4 <= n) {
+        T* p = (T*)__builtin_assume_aligned(out + idx, 16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) p[i] = v[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (idx + i < n) out[idx + i] = v[i];
+    }
+}
+
+template <typename T, int OP>
+__global__ __launch_bounds__(256) void scan_reduce_kernel(const T* __restrict__ in, T* __restrict__ agg, size_t n) {
+    __shared__ T sm[SNW];
+    const size_t base = (size_t)blockIdx.x * STILE;
+    T acc = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const size_t idx = base + (size_t)r * 1024 + (size_t)threadIdx.x * 4;
+        T v[4];
+        load4(in, idx, n, v);
+        acc = op2<T, OP>(acc, op2<T, OP>(op2<T, OP>(v[0], v[1]), op2<T, OP>(v[2], v[3])));
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc = op2<T, OP>(acc, __shfl_xor(acc, d, 64));
+    if (lane_id() == 0) sm[wave_id()] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        T r = 0;
+#pragma unroll
+        for (int i = 0; i < SNW; ++i) r = op2<T, OP>(r, sm[i]);
+        agg[blockIdx.x] = r;
+    }
+}
+
+template <typename T, int OP, bool INCL>
+__global__ __launch_bounds__(256) void scan_apply_kernel(const T* in, T* out, const T* __restrict__ block_prefix,
+                                                          size_t n, T* d_total) {
+    __shared__ T sm[SNW + 1];
+    const size_t base = (size_t)blockIdx.x * STILE;
+    T carry = block_prefix ? block_prefix[blockIdx.x] : (T)0;
+#pragma unroll 1
+    for (int r = 0; r < 4; ++r) {
+        const size_t idx = base + (size_t)r * 1024 + (size_t)threadIdx.x * 4;
+        T v[4];
+        load4(in, idx, n, v);
+        T s[4];
+        s[0] = v[0];
+        s[1] = op2<T, OP>(s[0], v[1]);
+        s[2] = op2<T, OP>(s[1], v[2]);
+        s[3] = op2<T, OP>(s[2], v[3]);
+        T total;
+        const T excl = block_exclusive_op<T, OP>(s[3], sm, total);
+        const T pre = op2<T, OP>(carry, excl);
+        T o[4];
+        if (INCL) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = op2<T, OP>(pre, s[i]);
+        } else {
+            o[0] = pre;
+#pragma unroll
+            for (int i = 1; i < 4; ++i) o[i] = op2<T, OP>(pre, s[i - 1]);
+        }
+        store4(out, idx, n, o);
+        carry = op2<T, OP>(carry, total);
+    }
+    if (d_total && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *d_total = carry;
+}
+
+template <typename T, int OP, bool INCL>
+static void scan_impl(Ctx& c, const T* in, T* out, size_t n, T* d_total) {
+    if (n == 0) {
+        if (d_total) HIP_TRY(hipMemsetAsync(d_total, 0, sizeof(T), c.stream));
+        return;
+    }
+    const unsigned nb = cdiv(n, STILE);
+    if (nb == 1) {
+        scan_apply_kernel<T, OP, INCL><<<1, 256, 0, c.stream>>>(in, out, nullptr, n, d_total);
+        LAUNCH_CHECK();
+        return;
+    }
+    const size_t mark = c.arena.mark();
+    T* agg = c.arena.get<T>(nb);
+    scan_reduce_kernel<T, OP><<<nb, 256, 0, c.stream>>>(in, agg, n);
+    LAUNCH_CHECK();
+    scan_impl<T, OP, false>(c, agg, agg, nb, nullptr);     // exclusive prefix of the block aggregates
+    scan_apply_kernel<T, OP, INCL><<<nb, 256, 0, c.stream>>>(in, out, agg, n, d_total);
+    LAUNCH_CHECK();
+    c.arena.release(mark);
+}
+
+void exclusive_sum_u32(Ctx& c, const u32* in, u32* out, size_t n, u32* d_total) { scan_impl<u32, 0, false>(c, in, out, n, d_total); }
+void exclusive_sum_u64(Ctx& c, const u64* in, u64* out, size_t n, u64* d_total) { scan_impl<u64, 0, false>(c, in, out, n, d_total); }
+void inclusive_max_u32(Ctx& c, const u32* in, u32* out, size_t n) { scan_impl<u32, 1, true>(c, in, out, n, nullptr); }
+
+// ------------------------------------------------------------------------------------------------
+// fills
+// ------------------------------------------------------------------------------------------------
+__global__ void fill_u32_kernel(u32* p, size_t n, u32 v) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) p[i] = v;
+}
+void fill_u32(Ctx& c, u32* p, size_t n, u32 v) {
+    if (!n) return;
+    unsigned g = cdiv(n, 256); if (g > 8192) g = 8192;
+    fill_u32_kernel<<<g, 256, 0, c.stream>>>(p, n, v);
+    LAUNCH_CHECK();
+}
+void fill_u8(Ctx& c, u8* p, size_t n, u8 v) {
+    if (!n) return;
+    HIP_TRY(hipMemsetAsync(p, v, n, c.stream));
+}
+
+// ------------------------------------------------------------------------------------------------
+// radix sort
+// ------------------------------------------------------------------------------------------------
+constexpr int RS_ITEMS = 16;
+constexpr int RS_TILE = 256 * RS_ITEMS;    // 4096 keys per workgroup; wave w owns keys [w*1024, (w+1)*1024)
+
+template <typename K>
+__global__ __launch_bounds__(256) void rs_count_kernel(const K* __restrict__ keys, u32* __restrict__ counts, size_t n,
+                                                        u32 numTiles, int shift, u32 dmask) {
+    __shared__ u32 hist[256];
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    const size_t tileBase = (size_t)blockIdx.x * RS_TILE + (size_t)wave_id() * (64 * RS_ITEMS) + lane_id();
+#pragma unroll 4
+    for (int j = 0; j < RS_ITEMS; ++j) {
+        const size_t idx = tileBase + (size_t)j * 64;
+        const bool valid = idx < n;
+        const u32 d = valid ? (u32)((keys[idx] >> shift) & dmask) : 0u;
+        const u32 d0 = __builtin_amdgcn_readfirstlane(d);
+        if (__all(valid && d == d0)) {                 // whole wave in one bin: one LDS atomic instead of 64 colliding ones
+            if (lane_id() == 0) atomicAdd(&hist[d0], 64u);
+        } else if (valid) {
+            atomicAdd(&hist[d], 1u);
+        }
+    }
+    __syncthreads();
+    counts[(size_t)threadIdx.x * numTiles + blockIdx.x] = hist[threadIdx.x];
+}
+
+template <typename K>
+__global__ __launch_bounds__(256) void rs_scatter_kernel(const K* __restrict__ keys_in, const u32* __restrict__ vals_in,
+                                                          K* __restrict__ keys_out, u32* __restrict__ vals_out,
+                                                          const u32* __restrict__ offsets, size_t n, u32 numTiles,
+                                                          int shift, u32 dmask) {
+    __shared__ u32 wcnt[4][256];     // per-wave running digit counts
+    __shared__ u32 wbase[4][256];    // global start of (wave, digit) run
+    const int lane = lane_id(), w = wave_id();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wcnt[i][threadIdx.x] = 0;
+    __syncthreads();
+
+    K k[RS_ITEMS];
+    u32 v[RS_ITEMS];
+    u32 loc[RS_ITEMS];
+    volatile u32* mycnt = wcnt[w];
+    const size_t tileBase = (size_t)blockIdx.x * RS_TILE + (size_t)w * (64 * RS_ITEMS) + lane;
+    const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int j = 0; j < RS_ITEMS; ++j) {
+        const size_t idx = tileBase + (size_t)j * 64;
+        const bool valid = idx < n;
+        k[j] = valid ? keys_in[idx] : (K)0;
+        v[j] = valid ? vals_in[idx] : 0u;
+        const u32 d = (u32)((k[j] >> shift) & dmask);
+        u64 peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const u64 bal = __ballot(bit);
+            peers &= bit ? bal : ~bal;
+        }
+        const u32 prefix = mycnt[d];
+        const u32 rank = (u32)__popcll(peers & lt_mask);
+        loc[j] = prefix + rank;
+        if (valid && rank == 0) mycnt[d] = prefix + (u32)__popcll(peers);   // leader = lowest valid lane of the group
+    }
+    __syncthreads();
+    {
+        const u32 t = threadIdx.x;
+        u32 run = offsets[(size_t)t * numTiles + blockIdx.x];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { wbase[i][t] = run; run += wcnt[i][t]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RS_ITEMS; ++j) {
+        const size_t idx = tileBase + (size_t)j * 64;
+        if (idx < n) {
+            const u32 d = (u32)((k[j] >> shift) & dmask);
+            const u32 dst = wbase[w][d] + loc[j];
+            keys_out[dst] = k[j];
+            vals_out[dst] = v[j];
+        }
+    }
+}
+
+template <typename K>
+static int radix_sort_pairs(Ctx& c, K* keys[2], u32* vals[2], size_t n, int begin_bit, int end_bit) {
+    if (n == 0 || end_bit <= begin_bit) return 0;
+    const size_t mark = c.arena.mark();
+    const u32 numTiles = cdiv(n, RS_TILE);
+    u32* counts = c.arena.get<u32>((size_t)256 * numTiles);
+    int cur = 0;
+    for (int shift = begin_bit; shift < end_bit; shift += 8) {
+        const int bits = (end_bit - shift) < 8 ? (end_bit - shift) : 8;
+        const u32 dmask = (1u << bits) - 1u;
+        rs_count_kernel<K><<<numTiles, 256, 0, c.stream>>>(keys[cur], counts, n, numTiles, shift, dmask);
+        LAUNCH_CHECK();
+        exclusive_sum_u32(c, counts, counts, (size_t)256 * numTiles, nullptr);
+        rs_scatter_kernel<K><<<numTiles, 256, 0, c.stream>>>(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], counts, n,
+                                                              numTiles, shift, dmask);
+        LAUNCH_CHECK();
+        cur ^= 1;
+    }
+    c.arena.release(mark);
+    return cur;
+}
+
+int radix_sort_pairs_u64(Ctx& c, u64* keys[2], u32* vals[2], size_t n, int b, int e) { return radix_sort_pairs<u64>(c, keys, vals, n, b, e); }
+int radix_sort_pairs_u32(Ctx& c, u32* keys[2], u32* vals[2], size_t n, int b, int e) { return radix_sort_pairs<u32>(c, keys, vals, n, b, e); }
+
+}  // namespace tdc

@@ -1,0 +1,24 @@
+// prim.hpp -- device-wide primitives used by every stage: scans and a stable LSD radix sort.
+// All of them are HBM-bound; they are written for 64-lane waves and 256-thread workgroups.
+#pragma once
+#include "common.hpp"
+
+namespace tdc {
+
+// out[i] = sum_{j<i} in[j]   (in may alias out).  If d_total != nullptr it receives the grand total.
+void exclusive_sum_u32(Ctx& c, const u32* in, u32* out, size_t n, u32* d_total);
+void exclusive_sum_u64(Ctx& c, const u64* in, u64* out, size_t n, u64* d_total);
+// out[i] = max_{j<=i} in[j]
+void inclusive_max_u32(Ctx& c, const u32* in, u32* out, size_t n);
+
+// Stable LSD radix sort of (key, value) pairs on bits [begin_bit, end_bit) of the key, 8 bits per pass.
+// keys[0]/vals[0] hold the input; the function ping-pongs between [0] and [1] and returns the index of
+// the buffer pair that holds the sorted result.  Temporary storage comes from the arena (released on return).
+int radix_sort_pairs_u64(Ctx& c, u64* keys[2], u32* vals[2], size_t n, int begin_bit, int end_bit);
+int radix_sort_pairs_u32(Ctx& c, u32* keys[2], u32* vals[2], size_t n, int begin_bit, int end_bit);
+
+// fill / iota helpers
+void fill_u32(Ctx& c, u32* p, size_t n, u32 v);
+void fill_u8(Ctx& c, u8* p, size_t n, u8 v);
+
+}  // namespace tdc

@@ -1,0 +1,60 @@
+// stages.hpp -- host-callable stage functions of the device pipeline (all arrays are device pointers).
+// Each stage replaces one row of SURVEY.md section 8a; citations are relative to
+// /root/reference/include/tudocomp/.
+#pragma once
+#include "common.hpp"
+
+namespace tdc {
+
+struct SAStats { u32 rounds = 0; u32 sym_bits = 0; u32 init_syms = 0; u64 sorted_elems = 0; };
+
+// a2+a3: ds/SADivSufSort.hpp:27-51 and ds/ISAFromSA.hpp:30-43.
+// Prefix doubling; text[n-1] must be the unique 0.  sa and isa are caller-provided (n entries each).
+void build_suffix_array(Ctx& c, const u8* text, size_t n, u32* sa, u32* isa, SAStats* st);
+
+// a4: ds/PhiFromSA.hpp:35-45
+void build_phi(Ctx& c, const u32* sa, size_t n, u32* phi);
+// a5: ds/PLCPFromPhi.hpp:27-53 ; plcp[n-1] := 0 ; d_maxlcp (device u32) receives max PLCP
+void build_plcp(Ctx& c, const u8* text, size_t n, const u32* phi, u32* plcp, u32* d_maxlcp);
+// a6 (debug/fixtures only): ds/LCPFromPLCP.hpp:27-56
+void build_lcp(Ctx& c, const u32* sa, const u32* plcp, size_t n, u32* lcp);
+
+// Position-space factor representation shared by factorize / flatten / encode:
+//   flen[p]  : length of the factor that STARTS at p, 0 otherwise (after mark_literal_runs: run length at
+//              the first position of every literal run)
+//   owner[p] : start position of the factor covering p, NONE32 if p is a literal
+//   fsrc[p]  : source of the factor starting at p (valid where flen[p] > 0 and owner[p] == p)
+struct FactorSpace {
+    u32* flen = nullptr;
+    u32* owner = nullptr;
+    u32* fsrc = nullptr;
+};
+
+struct FactorizeStats { u64 factors = 0; u32 maxlcp = 0; u32 levels = 0; u32 rounds = 0; u64 pushes = 0; u64 entries = 0; };
+
+// a8: compressors/lcpcomp/compress/ArraysComp.hpp:36-117 in position space.
+// Inputs: sa, isa, phi, plcp (plcp is consumed: it becomes the working copy of the LCP values).
+// Outputs: fs.flen / fs.owner filled, fs.fsrc[p] = phi[p] at factor starts.
+void factorize_arrays(Ctx& c, size_t n, const u32* sa, const u32* isa, const u32* phi, u32* plcp, u32 maxlcp,
+                      u32 threshold, FactorSpace fs, FactorizeStats* st);
+
+struct FlattenStats { u64 num_flattened = 0; u64 max_depth_lb = 0; u32 rounds = 0; };
+// a10: compressors/lzss/LZSSFactors.hpp:79-132 ; rewrites fs.fsrc in place.
+void flatten_factors(Ctx& c, size_t n, FactorSpace fs, FlattenStats* st);
+
+// a9: extract the factor list sorted by pos (LZSSFactors.hpp:69-76): pos[], src[], len[] (z entries each,
+// arrays caller-provided with capacity cap).  Returns z.
+size_t extract_factors(Ctx& c, size_t n, FactorSpace fs, u32* pos, u32* src, u32* len, size_t cap);
+// inverse: scatter a sorted factor list into position space (used by the stage-level test entry points)
+void scatter_factors(Ctx& c, size_t n, const u32* pos, const u32* src, const u32* len, size_t z, FactorSpace fs);
+
+struct EncodeStats { u64 factors = 0; u64 flen_min = 0, flen_max = 0, fdist_max = 0; u64 out_bits = 0; u32 sigma = 0; };
+// a11-a14: LZSSLiterals.hpp:10-50, HuffmanCoder.hpp:37-48/442-474/526-569, LZSSCoding.hpp:18-92, BitOStream.hpp:53-64.
+// Writes the complete stream (incl. terminator) to d_out (capacity out_cap bytes); returns its length.
+// fs.flen is modified (literal-run lengths are stored at run starts).
+size_t encode_huff(Ctx& c, const u8* text, size_t n, FactorSpace fs, u8* d_out, size_t out_cap, EncodeStats* st);
+
+// worst-case output size of encode_huff for a text of n bytes
+size_t encode_bound(size_t n);
+
+}  // namespace tdc

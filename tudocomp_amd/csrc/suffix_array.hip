@@ -1,0 +1,213 @@
+// suffix_array.hip -- suffix array + inverse suffix array by prefix doubling (gfx950).
+//
+// Replaces ds/SADivSufSort.hpp:27-51 (divsufsort, util/divsufsort.hpp:46-279) and ds/ISAFromSA.hpp:30-43.
+// The suffix array of a text is unique, so the result is bit-identical to the reference's.
+//
+// Algorithm (Larsson/Sadakane-style doubling, all data-parallel):
+//   1. Pack the first k symbols of every suffix into a 64-bit key (symbols re-coded densely to b bits,
+//      k = floor(64 / b)), radix sort (key, position).  Suffixes are now sorted by their first h = k symbols.
+//   2. rank[i] := start index of i's group in the sorted order.  Groups of size 1 are final.
+//   3. While unresolved groups exist: for every unresolved suffix i build key (rank[i], rank[i + h]), sort the
+//      unresolved suffixes by it (groups stay inside their own index range), recompute group heads, drop the
+//      new singletons, h *= 2.
+//   The final rank array is the inverse suffix array.
+// The sentinel (unique smallest byte at n-1) guarantees i + h <= n-1 for every unresolved suffix.
+#include "stages.hpp"
+#include "prim.hpp"
+
+namespace tdc {
+
+struct CodeMap { u8 code[256]; };
+
+__global__ __launch_bounds__(256) void byte_hist_kernel(const u8* __restrict__ text, size_t n, u32* __restrict__ hist) {
+    __shared__ u32 h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) atomicAdd(&h[text[i]], 1u);
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+
+// 1024 positions per workgroup, symbols staged (already re-coded) in LDS.
+__global__ __launch_bounds__(256) void sa_init_keys_kernel(const u8* __restrict__ text, size_t n, CodeMap cm, int b, int k,
+                                                            u64* __restrict__ keys, u32* __restrict__ vals) {
+    __shared__ u8 s[1024 + 64];
+    __shared__ u8 code[256];
+    code[threadIdx.x] = cm.code[threadIdx.x];
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * 1024;
+    for (int i = threadIdx.x; i < 1024 + 64; i += 256) {
+        const size_t p = base + i;
+        s[i] = (p < n) ? code[text[p]] : (u8)0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int local = r * 256 + threadIdx.x;
+        const size_t p = base + local;
+        if (p < n) {
+            u64 key = 0;
+            for (int j = 0; j < k; ++j) key = (key << b) | s[local + j];
+            keys[p] = key;
+            vals[p] = (u32)p;
+        }
+    }
+}
+
+// head marker: index of the element if it starts a new group, else 0 (a max-scan then yields the group head)
+__global__ void sa_heads_kernel(const u64* __restrict__ keys, size_t m, u32* __restrict__ head) {
+    const size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= m) return;
+    head[a] = (a == 0 || keys[a] != keys[a - 1]) ? (u32)a : 0u;
+}
+
+// First round: every position is "active", pos[a] == a.
+__global__ void sa_first_update_kernel(const u32* __restrict__ vals, const u32* __restrict__ head, size_t n,
+                                       u32* __restrict__ sa, u32* __restrict__ rank, u32* __restrict__ keep) {
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const u32 h = head[j];
+    const u32 s = vals[j];
+    sa[j] = s;
+    rank[s] = h;
+    const bool single = (h == (u32)j) && (j + 1 == n || head[j + 1] == (u32)(j + 1));
+    keep[j] = single ? 0u : 1u;
+}
+__global__ void sa_first_compact_kernel(const u32* __restrict__ vals, const u32* __restrict__ head, const u32* __restrict__ offs,
+                                        size_t n, u32* __restrict__ a_sa, u32* __restrict__ a_pos, u32* __restrict__ a_r1) {
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const u32 h = head[j];
+    const bool single = (h == (u32)j) && (j + 1 == n || head[j + 1] == (u32)(j + 1));
+    if (!single) {
+        const u32 o = offs[j];
+        a_sa[o] = vals[j];
+        a_pos[o] = (u32)j;
+        a_r1[o] = h;
+    }
+}
+
+__global__ void sa_build_keys_kernel(const u32* __restrict__ a_sa, const u32* __restrict__ a_r1, size_t m, size_t n, u32 h,
+                                     int bn, const u32* __restrict__ rank, u64* __restrict__ keys, u32* __restrict__ vals) {
+    const size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= m) return;
+    const u32 s = a_sa[a];
+    const size_t t = (size_t)s + h;
+    const u32 r2 = (t < n) ? rank[t] : 0u;
+    keys[a] = ((u64)a_r1[a] << bn) | r2;
+    vals[a] = s;
+}
+
+__global__ void sa_update_kernel(const u64* __restrict__ keys, const u32* __restrict__ vals, const u32* __restrict__ head,
+                                 const u32* __restrict__ a_pos, size_t m, int bn, u32* __restrict__ sa, u32* __restrict__ rank,
+                                 u32* __restrict__ keep) {
+    const size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= m) return;
+    const u32 h = head[a];
+    const u32 s = vals[a];
+    const u32 newrank = a_pos[h];
+    sa[a_pos[a]] = s;
+    if (newrank != (u32)(keys[a] >> bn)) rank[s] = newrank;     // rank only moves when the group was split
+    const bool single = (h == (u32)a) && (a + 1 == m || head[a + 1] == (u32)(a + 1));
+    keep[a] = single ? 0u : 1u;
+}
+__global__ void sa_compact_kernel(const u32* __restrict__ vals, const u32* __restrict__ head, const u32* __restrict__ offs,
+                                  const u32* __restrict__ a_pos, size_t m, u32* __restrict__ b_sa, u32* __restrict__ b_pos,
+                                  u32* __restrict__ b_r1) {
+    const size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= m) return;
+    const u32 h = head[a];
+    const bool single = (h == (u32)a) && (a + 1 == m || head[a + 1] == (u32)(a + 1));
+    if (!single) {
+        const u32 o = offs[a];
+        b_sa[o] = vals[a];
+        b_pos[o] = a_pos[a];
+        b_r1[o] = a_pos[h];
+    }
+}
+
+void build_suffix_array(Ctx& c, const u8* text, size_t n, u32* sa, u32* isa, SAStats* st) {
+    SAStats local;
+    if (!st) st = &local;
+    *st = SAStats();
+    if (n == 0) return;
+    hipStream_t s = c.stream;
+    const size_t mark = c.arena.mark();
+
+    // --- dense symbol codes -----------------------------------------------------------------------
+    u32* d_hist = c.arena.get<u32>(256);
+    HIP_TRY(hipMemsetAsync(d_hist, 0, 256 * sizeof(u32), s));
+    {
+        unsigned g = cdiv(n, 256 * 16); if (g > 2048) g = 2048; if (g == 0) g = 1;
+        byte_hist_kernel<<<g, 256, 0, s>>>(text, n, d_hist);
+        LAUNCH_CHECK();
+    }
+    u32 h_hist[256];
+    c.read_n(d_hist, h_hist, 256);
+    CodeMap cm;
+    u32 sigma = 0;
+    for (int i = 0; i < 256; ++i) { cm.code[i] = (u8)sigma; if (h_hist[i]) ++sigma; }
+    // a byte that does not occur keeps the code of the next present byte; irrelevant (never looked up)
+    const int b = (int)bits_for(sigma > 1 ? sigma - 1 : 1);
+    int k = 64 / b;
+    if (k > 32) k = 32;
+    st->sym_bits = b; st->init_syms = k;
+
+    // --- buffers ----------------------------------------------------------------------------------
+    u64* keys[2] = { c.arena.get<u64>(n), c.arena.get<u64>(n) };
+    u32* vals[2] = { c.arena.get<u32>(n), c.arena.get<u32>(n) };
+    u32* head = c.arena.get<u32>(n);
+    u32* keep = c.arena.get<u32>(n);
+    u32* A_sa = c.arena.get<u32>(n), *A_pos = c.arena.get<u32>(n), *A_r1 = c.arena.get<u32>(n);
+    u32* B_sa = c.arena.get<u32>(n), *B_pos = c.arena.get<u32>(n), *B_r1 = c.arena.get<u32>(n);
+    u32* d_total = c.arena.get<u32>(1);
+    u32* rank = isa;
+
+    // --- initial sort by the first k symbols ------------------------------------------------------
+    sa_init_keys_kernel<<<cdiv(n, 1024), 256, 0, s>>>(text, n, cm, b, k, keys[0], vals[0]);
+    LAUNCH_CHECK();
+    int x = radix_sort_pairs_u64(c, keys, vals, n, 0, k * b);
+    st->sorted_elems += n;
+    const unsigned gn = cdiv(n, 256);
+    sa_heads_kernel<<<gn, 256, 0, s>>>(keys[x], n, head);
+    LAUNCH_CHECK();
+    inclusive_max_u32(c, head, head, n);
+    sa_first_update_kernel<<<gn, 256, 0, s>>>(vals[x], head, n, sa, rank, keep);
+    LAUNCH_CHECK();
+    exclusive_sum_u32(c, keep, keep, n, d_total);
+    sa_first_compact_kernel<<<gn, 256, 0, s>>>(vals[x], head, keep, n, A_sa, A_pos, A_r1);
+    LAUNCH_CHECK();
+    size_t m = c.read(d_total);
+    st->rounds = 1;
+
+    // --- doubling rounds --------------------------------------------------------------------------
+    const int bn = (int)bits_for(n - 1);
+    u64 h = (u64)k;
+    while (m > 0) {
+        if (h >= n) throw HipError{hipErrorUnknown, "suffix_array: doubling did not converge", (int)__LINE__};
+        const unsigned gm = cdiv(m, 256);
+        sa_build_keys_kernel<<<gm, 256, 0, s>>>(A_sa, A_r1, m, n, (u32)h, bn, rank, keys[0], vals[0]);
+        LAUNCH_CHECK();
+        x = radix_sort_pairs_u64(c, keys, vals, m, 0, 2 * bn);
+        st->sorted_elems += m;
+        sa_heads_kernel<<<gm, 256, 0, s>>>(keys[x], m, head);
+        LAUNCH_CHECK();
+        inclusive_max_u32(c, head, head, m);
+        sa_update_kernel<<<gm, 256, 0, s>>>(keys[x], vals[x], head, A_pos, m, bn, sa, rank, keep);
+        LAUNCH_CHECK();
+        exclusive_sum_u32(c, keep, keep, m, d_total);
+        sa_compact_kernel<<<gm, 256, 0, s>>>(vals[x], head, keep, A_pos, m, B_sa, B_pos, B_r1);
+        LAUNCH_CHECK();
+        m = c.read(d_total);
+        u32* t;
+        t = A_sa; A_sa = B_sa; B_sa = t;
+        t = A_pos; A_pos = B_pos; B_pos = t;
+        t = A_r1; A_r1 = B_r1; B_r1 = t;
+        h *= 2;
+        st->rounds++;
+    }
+    c.arena.release(mark);
+}
+
+}  // namespace tdc

@@ -2,7 +2,7 @@
  * textgen.c -- deterministic, integer-only synthetic corpora for the benchmark configurations
  * (BASELINE.json configs 2-5; generator specification: SURVEY.md section 8d).
  *
- * Host-side counterpart of the reference's string generators (include/tudocomp/generators/*,
+ * Host-side counterpart of the reference's string generators (include/tudocomp/generators/,
  * used by test/test/util.hpp:180-207): it only produces benchmark/test input, never output bits.
  */
 #include <stdint.h>
