@@ -57,12 +57,22 @@ void check_text_args(const void* text, size_t n) {
     if (n >= 0x7FFFFFFFull) throw ArgError{TDC_GPU_ERR_TOO_LARGE, "text length must be < 2^31 - 1 (32-bit len_t)"};
 }
 
+// Event marks are recorded while the pipeline is enqueued; the elapsed times are only read in finish(), after the
+// stream has been synchronised (hipEventElapsedTime on a pending event returns hipErrorNotReady).
 struct Events {
     Ctx& c;
     int used = 0;
+    struct Span { float* dst; int a, b; };
+    Span spans[16];
+    int nspans = 0;
     explicit Events(Ctx& ctx) : c(ctx) {}
     int tick() { HIP_TRY(hipEventRecord(c.ev[used], c.stream)); return used++; }
-    float ms(int a, int b) { float t = 0; HIP_TRY(hipEventElapsedTime(&t, c.ev[a], c.ev[b])); return t; }
+    void span(float* dst, int a, int b) { if (dst) spans[nspans++] = Span{dst, a, b}; }
+    void finish() {
+        HIP_TRY(hipStreamSynchronize(c.stream));
+        for (int i = 0; i < nspans; ++i) HIP_TRY(hipEventElapsedTime(spans[i].dst, c.ev[spans[i].a], c.ev[spans[i].b]));
+        nspans = 0;
+    }
 };
 
 struct DevArrays {
@@ -114,7 +124,7 @@ void run_textds(Ctx& c, const u8* d_text, size_t n, DevArrays& A, tdc_gpu_stats*
     if (st) {
         st->maxlcp = A.maxlcp;
         st->sa_rounds = ss.rounds; st->sa_init_syms = ss.init_syms; st->sa_sorted_elems = ss.sorted_elems;
-        if (ev) { st->ms_sa = ev->ms(e0, e1); st->ms_phi = ev->ms(e1, e2); st->ms_plcp = ev->ms(e2, e3); }
+        if (ev) { ev->span(&st->ms_sa, e0, e1); ev->span(&st->ms_phi, e1, e2); ev->span(&st->ms_plcp, e2, e3); }
     }
 }
 
@@ -133,7 +143,7 @@ void run_factorize(Ctx& c, size_t n, DevArrays& A, u32 threshold, int flatten, t
         st->factors = fz.factors; st->entries = fz.entries; st->pushes = fz.pushes;
         st->levels = fz.levels; st->mis_rounds = fz.rounds;
         st->num_flattened = fl.num_flattened; st->max_depth_lb = fl.max_depth_lb; st->flatten_rounds = fl.rounds;
-        if (ev) { st->ms_factorize = ev->ms(e0, e1); st->ms_flatten = ev->ms(e1, e2); }
+        if (ev) { ev->span(&st->ms_factorize, e0, e1); ev->span(&st->ms_flatten, e1, e2); }
     }
 }
 
@@ -153,7 +163,7 @@ size_t run_pipeline(Ctx& c, const u8* d_text, size_t n, u32 threshold, int flatt
     if (st) {
         st->n = n; st->out_len = out_len;
         st->flen_min = es.flen_min; st->flen_max = es.flen_max; st->fdist_max = es.fdist_max; st->sigma = es.sigma;
-        st->ms_encode = ev.ms(e0, e1);
+        ev.span(&st->ms_encode, e0, e1);
         st->arena_bytes = c.arena.high;
     }
     return out_len;
@@ -252,8 +262,8 @@ int tdc_gpu_lcpcomp_compress_dev(tdc_gpu_ctx* ctx, const void* d_text, size_t n,
         const int e0 = ev.tick();
         *out_len = run_pipeline(c, (const u8*)d_text, n, threshold, flatten, (u8*)d_out, out_cap, stats, ev);
         const int e1 = ev.tick();
-        HIP_TRY(hipStreamSynchronize(c.stream));
-        if (stats) stats->ms_total = ev.ms(e0, e1);
+        if (stats) ev.span(&stats->ms_total, e0, e1);
+        ev.finish();
     });
 }
 
@@ -279,9 +289,9 @@ int tdc_gpu_lcpcomp_compress(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, ui
         uint8_t* h = host_alloc<uint8_t>(len);
         HIP_TRY(hipMemcpyAsync(h, d_out, len, hipMemcpyDeviceToHost, c.stream));
         const int e3 = ev.tick();
-        HIP_TRY(hipStreamSynchronize(c.stream));
+        if (stats) { ev.span(&stats->ms_h2d, e0, e1); ev.span(&stats->ms_d2h, e2, e3); ev.span(&stats->ms_total, e0, e3); }
+        ev.finish();
         *out = h; *out_len = len;
-        if (stats) { stats->ms_h2d = ev.ms(e0, e1); stats->ms_d2h = ev.ms(e2, e3); stats->ms_total = ev.ms(e0, e3); }
     });
 }
 
@@ -346,7 +356,7 @@ int tdc_gpu_lcpcomp_factorize(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, u
             HIP_TRY(hipMemcpyAsync(hs, d_src, cnt * 4, hipMemcpyDeviceToHost, c.stream));
             HIP_TRY(hipMemcpyAsync(hl, d_len, cnt * 4, hipMemcpyDeviceToHost, c.stream));
         }
-        HIP_TRY(hipStreamSynchronize(c.stream));
+        ev.finish();
         *pos = hp; *src = hs; *len = hl; *z = cnt;
         if (stats) { stats->n = n; stats->arena_bytes = c.arena.high; }
     });
