@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py -- input MB/s of lcpcomp(coder=huff) on MI355X (BASELINE.json metric).
+
+A "step" is one pass of the hot path (suffix array -> ISA/Phi/PLCP -> ArraysComp factorization -> flatten ->
+Huffman bit-pack) over one batch of synthetic text that is already resident in HBM.
+
+  N = 1 : BASELINE.json configs[1] -- 256 MiB English-like text (SURVEY.md 8d generator, seed 42), threshold 2.
+  N > 1 : one process per GPU (torch.distributed, backend nccl = RCCL); every rank compresses its own shard
+          (seed 42 + rank, same size: weak scaling) and the per-shard streams are gathered on rank 0 over xGMI
+          into the block container.  value = bytes of all ranks / max-over-ranks time.
+
+Prints ONE JSON line (rank 0).  PyTorch is used for device memory and torch.distributed only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+DOMINANT = "rs_scatter_kernel<u64>"
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=1 << 28, help="input bytes per GPU (default 256 MiB = configs[1])")
+    ap.add_argument("--threshold", type=int, default=2)
+    ap.add_argument("--gen", default="english", choices=["english", "dna"])
+    ap.add_argument("--cpu-sample", type=int, default=1 << 26, help="bytes of the workload the CPU baseline is timed on")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def gather_streams(dist, torch, d_out, out_len, rank, world, device):
+    """Variable-size gather of the per-shard streams to rank 0: all_gather of the sizes, then point-to-point
+    sends (each peer has its own xGMI link to rank 0).  Returns the list of sizes (rank 0: also the buffers)."""
+    sizes = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([out_len], dtype=torch.int64, device=device))
+    sizes = [int(s.item()) for s in sizes]
+    bufs = None
+    if rank == 0:
+        bufs = [d_out[:out_len]] + [torch.empty(sizes[r], dtype=torch.uint8, device=device) for r in range(1, world)]
+        reqs = [dist.irecv(bufs[r], src=r) for r in range(1, world)]
+        for q in reqs:
+            q.wait()
+    else:
+        dist.send(d_out[:out_len], dst=0)
+    return sizes, bufs
+
+
+def cpu_baseline(args, text_np, gpu_prefix_stream):
+    """The oracle (bit-exact CPU port of the reference path), one core, on a bounded prefix of the workload."""
+    from oracle import oracle as O
+    import numpy as np
+    m = min(args.cpu_sample, len(text_np) - 1)
+    sample = np.concatenate([text_np[:m], np.zeros(1, dtype=np.uint8)])
+    t0 = time.perf_counter()
+    out, st = O.lcpcomp_huff_compress(sample, args.threshold, 1)
+    dt = time.perf_counter() - t0
+    res = {"value": round(m / 1e6 / dt, 3), "unit": "MB/s", "cores": 1, "kind": "port",
+           "sample": "first %d bytes of the workload text, lcpcomp(coder=huff,threshold=%d,flatten=1), %.1f s" % (m, args.threshold, dt)}
+    if gpu_prefix_stream is not None:
+        res["bit_exact_vs_gpu_on_sample"] = bool(out == gpu_prefix_stream)
+    return res
+
+
+def main():
+    args = parse_args()
+    import numpy as np
+    import torch
+    import tudocomp_amd as T
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs torchrun with %d processes (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    # ---- synthetic input, resident in HBM before the timed region ------------------------------------------
+    N = args.size
+    gen = T.gen_english if args.gen == "english" else T.gen_dna
+    seed = (42 if args.gen == "english" else 7) + rank
+    text_np = np.concatenate([gen(N, seed), np.zeros(1, dtype=np.uint8)])     # generators emit no 0x00 / 0xFF: n = N + 1
+    n = len(text_np)
+    d_text = torch.from_numpy(text_np).to(device)
+    ctx = T.Context(local_rank)
+    ctx.reserve(n)
+    cap = ctx.bound(n)
+    d_out = torch.empty(cap, dtype=torch.uint8, device=device)
+    torch.cuda.synchronize()
+
+    def step():
+        out_len, st = ctx.lcpcomp_compress_dev(d_text.data_ptr(), n, d_out.data_ptr(), cap, args.threshold, 1)
+        sizes = None
+        if world > 1:
+            sizes, _ = gather_streams(dist, torch, d_out, out_len, rank, world, device)
+        return out_len, st, sizes
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.set_profiling(True)
+    ctx.reset_profile()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out_len, st, sizes = step()
+    fence()
+    dt = time.perf_counter() - t0
+    prof = ctx.kernel_profile()
+    ctx.set_profiling(False)
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = world * N / 1e6 / (dt / args.steps)
+        k = prof.get(DOMINANT, {"ms": 0.0, "launches": 0, "bytes": 0})
+        roof = None
+        if k["launches"]:
+            achieved = k["bytes"] / (k["ms"] * 1e-3) / 1e9
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
+            if os.path.exists(pmc):
+                try:
+                    j = json.load(open(pmc))
+                    if j.get("workload_bytes") == N and j.get("kernel") == DOMINANT:
+                        traffic = j.get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            roof = {"bound": "hbm", "kernel": DOMINANT, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "launches_per_step": k["launches"] / args.steps,
+                    "avg_launch_ms": round(k["ms"] / k["launches"], 4),
+                    "algorithmic_bytes_per_launch": round(k["bytes"] / k["launches"]),
+                    "share_of_step": round(k["ms"] / args.steps / ms_per_step, 3)}
+        c_ratio = out_len / N
+        z = st["factors"]
+        b_alg = 44 + c_ratio + 48 * z / N
+        dev_ms = st["ms_total"]
+        line = {
+            "metric": "input MB/s end-to-end lcpcomp+huffman",
+            "value": round(value, 2), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32", "data": "synthetic",
+            "config": {"workload": "lcpcomp(coder=huff,threshold=%d,flatten=1,comp=arrays) on %d B %s text per GPU "
+                                   "(SURVEY 8d generator, seed %d+rank), resident in HBM" % (args.threshold, N, args.gen, seed - rank),
+                       "bytes_per_gpu": N, "parallelism": "independent shards x%d + RCCL gather to rank 0" % world if world > 1 else "single GPU"},
+            "roofline": roof,
+            "pipeline": {"B_alg_bytes_per_input_byte": round(b_alg, 2), "achieved_GBs": round(b_alg * N / (dev_ms * 1e-3) / 1e9, 1),
+                         "frac_of_hbm_peak": round(b_alg * N / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+            "stages_ms": {k2[3:]: round(v, 2) for k2, v in st.items() if k2.startswith("ms_")},
+            "stats": {k2: st[k2] for k2 in ("out_len", "factors", "maxlcp", "num_flattened", "sa_rounds", "levels", "mis_rounds",
+                                            "flatten_rounds", "pushes", "arena_bytes")},
+            "kernels": {name: {"ms_per_step": round(p["ms"] / args.steps, 3), "launches_per_step": p["launches"] / args.steps}
+                        for name, p in prof.items() if p["launches"]},
+        }
+        if sizes is not None:
+            line["gathered_bytes"] = sum(sizes)
+        if world == 1 and not args.no_cpu_baseline:
+            m = min(args.cpu_sample, N)
+            sample = np.concatenate([text_np[:m], np.zeros(1, dtype=np.uint8)])
+            gpu_prefix, _ = ctx.lcpcomp_compress(sample, args.threshold, 1)
+            line["cpu_baseline"] = cpu_baseline(args, text_np, gpu_prefix)
+        print(json.dumps(line))
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

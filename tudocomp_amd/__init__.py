@@ -106,6 +106,23 @@ class Context:
         self._L.tdc_gpu_free(ptr)
         return out
 
+    def set_profiling(self, enabled=True):
+        self._check(self._L.tdc_gpu_ctx_set_profiling(self._h, int(enabled)))
+
+    def reset_profile(self):
+        self._L.tdc_gpu_ctx_reset_profile(self._h)
+
+    def kernel_profile(self):
+        """{kernel name: {"ms", "launches", "bytes"}} since the last reset (only while profiling is enabled)."""
+        out, i = {}, 0
+        while True:
+            ms, ln, by = ctypes.c_double(), ctypes.c_uint64(), ctypes.c_uint64()
+            name = self._L.tdc_gpu_ctx_kernel_profile(self._h, i, ctypes.byref(ms), ctypes.byref(ln), ctypes.byref(by))
+            if name is None:
+                return out
+            out[name.decode()] = {"ms": ms.value, "launches": ln.value, "bytes": by.value}
+            i += 1
+
     def reserve(self, n):
         self._check(self._L.tdc_gpu_ctx_reserve(self._h, n))
 

@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libtdc_gpu.so")
 # every symbol include/tdc_gpu.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "tdc_gpu_ctx_create", "tdc_gpu_ctx_destroy", "tdc_gpu_ctx_reserve", "tdc_gpu_strerror", "tdc_gpu_last_error",
+    "tdc_gpu_ctx_set_profiling", "tdc_gpu_ctx_reset_profile", "tdc_gpu_ctx_kernel_profile",
     "tdc_gpu_free", "tdc_gpu_lcpcomp_compress", "tdc_gpu_lcpcomp_compress_dev", "tdc_gpu_lcpcomp_bound",
     "tdc_gpu_suffix_array", "tdc_gpu_textds", "tdc_gpu_lcpcomp_factorize", "tdc_gpu_flatten", "tdc_gpu_encode_huff",
     "tdc_escape", "tdc_unescape", "tdc_huffman_table", "tdc_gen_english", "tdc_gen_dna",
@@ -49,6 +50,12 @@ def load():
     L.tdc_gpu_ctx_destroy.argtypes = [vp]
     L.tdc_gpu_ctx_destroy.restype = None
     L.tdc_gpu_ctx_reserve.argtypes = [vp, sz]
+    L.tdc_gpu_ctx_set_profiling.argtypes = [vp, i32]
+    L.tdc_gpu_ctx_reset_profile.argtypes = [vp]
+    L.tdc_gpu_ctx_reset_profile.restype = None
+    L.tdc_gpu_ctx_kernel_profile.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64),
+                                             ctypes.POINTER(ctypes.c_uint64)]
+    L.tdc_gpu_ctx_kernel_profile.restype = ctypes.c_char_p
     L.tdc_gpu_strerror.argtypes = [i32]
     L.tdc_gpu_strerror.restype = ctypes.c_char_p
     L.tdc_gpu_last_error.argtypes = [vp]

@@ -72,6 +72,7 @@ struct Events {
         HIP_TRY(hipStreamSynchronize(c.stream));
         for (int i = 0; i < nspans; ++i) HIP_TRY(hipEventElapsedTime(spans[i].dst, c.ev[spans[i].a], c.ev[spans[i].b]));
         nspans = 0;
+        c.prof_collect();
     }
 };
 
@@ -239,8 +240,39 @@ void tdc_gpu_ctx_destroy(tdc_gpu_ctx* ctx) {
     if (ctx->c.arena.base) (void)hipFree(ctx->c.arena.base);
     if (ctx->c.pinned) (void)hipHostFree(ctx->c.pinned);
     for (auto& e : ctx->c.ev) if (e) (void)hipEventDestroy(e);
+    if (ctx->c.ev_pool) { for (int i = 0; i < ctx->c.ev_pool_size; ++i) if (ctx->c.ev_pool[i]) (void)hipEventDestroy(ctx->c.ev_pool[i]); free(ctx->c.ev_pool); }
+    free(ctx->c.pend);
     if (ctx->c.stream) (void)hipStreamDestroy(ctx->c.stream);
     delete ctx;
+}
+
+int tdc_gpu_ctx_set_profiling(tdc_gpu_ctx* ctx, int enabled) {
+    return guarded(ctx, [&] {
+        Ctx& c = ctx->c;
+        if (enabled && !c.ev_pool) {
+            c.ev_pool_size = 4096; c.pend_cap = 2048;
+            c.ev_pool = (hipEvent_t*)calloc(c.ev_pool_size, sizeof(hipEvent_t));
+            c.pend = (Ctx::Pending*)calloc(c.pend_cap, sizeof(Ctx::Pending));
+            if (!c.ev_pool || !c.pend) throw std::bad_alloc();
+            for (int i = 0; i < c.ev_pool_size; ++i) HIP_TRY(hipEventCreate(&c.ev_pool[i]));
+        }
+        c.profiling = enabled != 0;
+    });
+}
+
+void tdc_gpu_ctx_reset_profile(tdc_gpu_ctx* ctx) {
+    if (!ctx) return;
+    for (auto& k : ctx->c.kprof) k = KernelProfile();
+}
+
+const char* tdc_gpu_ctx_kernel_profile(const tdc_gpu_ctx* ctx, int idx, double* ms, uint64_t* launches, uint64_t* bytes) {
+    static const char* names[K_CLASS_COUNT] = { "rs_scatter_kernel<u64>", "rs_scatter_kernel<u32>", "rs_count_kernel", "scan" };
+    if (!ctx || idx < 0 || idx >= K_CLASS_COUNT) return nullptr;
+    const KernelProfile& k = ctx->c.kprof[idx];
+    if (ms) *ms = k.ms;
+    if (launches) *launches = k.launches;
+    if (bytes) *bytes = k.bytes;
+    return names[idx];
 }
 
 int tdc_gpu_ctx_reserve(tdc_gpu_ctx* ctx, size_t n) {

@@ -68,6 +68,16 @@ struct Arena {
     void release(size_t m) { top = m; }
 };
 
+// Live per-kernel timing (bench.py's roofline): HIP events on the launching stream around every launch of the
+// instrumented kernels, resolved after the stream has been synchronised.
+enum KernelClass { K_RS_SCATTER_U64 = 0, K_RS_SCATTER_U32, K_RS_COUNT, K_SCAN, K_CLASS_COUNT };
+
+struct KernelProfile {
+    double ms = 0;        // summed launch durations
+    u64 launches = 0;
+    u64 bytes = 0;        // summed algorithmic bytes
+};
+
 struct Ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -75,6 +85,34 @@ struct Ctx {
     hipEvent_t ev[16] = {};
     void* pinned = nullptr;        // small pinned staging block for device->host scalars
     size_t pinned_size = 0;
+
+    bool profiling = false;
+    KernelProfile kprof[K_CLASS_COUNT];
+    struct Pending { hipEvent_t a, b; int cls; u64 bytes; };
+    Pending* pend = nullptr;
+    int npend = 0, pend_cap = 0;
+    hipEvent_t* ev_pool = nullptr;
+    int ev_pool_size = 0, ev_pool_used = 0;
+
+    // returns the index of a pending record (or -1 when profiling is off / the pool is exhausted)
+    int prof_begin(int cls, u64 bytes) {
+        if (!profiling || npend >= pend_cap || ev_pool_used + 2 > ev_pool_size) return -1;
+        Pending& p = pend[npend];
+        p.a = ev_pool[ev_pool_used++]; p.b = ev_pool[ev_pool_used++]; p.cls = cls; p.bytes = bytes;
+        HIP_TRY(hipEventRecord(p.a, stream));
+        return npend++;
+    }
+    void prof_end(int idx) { if (idx >= 0) HIP_TRY(hipEventRecord(pend[idx].b, stream)); }
+    // call after a stream synchronisation
+    void prof_collect() {
+        for (int i = 0; i < npend; ++i) {
+            float t = 0;
+            HIP_TRY(hipEventElapsedTime(&t, pend[i].a, pend[i].b));
+            KernelProfile& k = kprof[pend[i].cls];
+            k.ms += t; k.launches++; k.bytes += pend[i].bytes;
+        }
+        npend = 0; ev_pool_used = 0;
+    }
 
     void ensure_arena(size_t bytes) {
         if (arena.size >= bytes) { arena.top = 0; return; }

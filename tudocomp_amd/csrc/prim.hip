@@ -274,12 +274,17 @@ static int radix_sort_pairs(Ctx& c, K* keys[2], u32* vals[2], size_t n, int begi
     for (int shift = begin_bit; shift < end_bit; shift += 8) {
         const int bits = (end_bit - shift) < 8 ? (end_bit - shift) : 8;
         const u32 dmask = (1u << bits) - 1u;
+        // algorithmic bytes: count reads every key once; scatter reads and writes every (key, value) pair once
+        const int pc = c.prof_begin(K_RS_COUNT, (u64)n * sizeof(K));
         rs_count_kernel<K><<<numTiles, 256, 0, c.stream>>>(keys[cur], counts, n, numTiles, shift, dmask);
         LAUNCH_CHECK();
+        c.prof_end(pc);
         exclusive_sum_u32(c, counts, counts, (size_t)256 * numTiles, nullptr);
+        const int ps = c.prof_begin(sizeof(K) == 8 ? K_RS_SCATTER_U64 : K_RS_SCATTER_U32, (u64)n * 2 * (sizeof(K) + sizeof(u32)));
         rs_scatter_kernel<K><<<numTiles, 256, 0, c.stream>>>(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], counts, n,
                                                               numTiles, shift, dmask);
         LAUNCH_CHECK();
+        c.prof_end(ps);
         cur ^= 1;
     }
     c.arena.release(mark);
