@@ -70,8 +70,8 @@ void tdc_gpu_ctx_destroy(tdc_gpu_ctx* ctx);
 int  tdc_gpu_ctx_reserve(tdc_gpu_ctx* ctx, size_t n);
 /* Live kernel timing for bench.py's roofline: when enabled, HIP events are recorded (on the launching stream) around
  * every launch of the instrumented kernels; tdc_gpu_ctx_kernel_profile() returns the sums since the last reset.
- * idx: 0 = radix scatter (u64 keys), 1 = radix scatter (u32 keys), 2 = radix count, 3 = scan.  Returns the kernel name
- * or NULL if idx is out of range. `bytes` = algorithmic bytes summed over the launches. */
+ * idx enumerates the instrumented kernel classes from 0; the function returns the class name, or NULL once idx is
+ * out of range. `bytes` = algorithmic bytes summed over the launches. */
 int  tdc_gpu_ctx_set_profiling(tdc_gpu_ctx* ctx, int enabled);
 void tdc_gpu_ctx_reset_profile(tdc_gpu_ctx* ctx);
 const char* tdc_gpu_ctx_kernel_profile(const tdc_gpu_ctx* ctx, int idx, double* ms, uint64_t* launches, uint64_t* bytes);

@@ -250,7 +250,7 @@ int tdc_gpu_ctx_set_profiling(tdc_gpu_ctx* ctx, int enabled) {
     return guarded(ctx, [&] {
         Ctx& c = ctx->c;
         if (enabled && !c.ev_pool) {
-            c.ev_pool_size = 4096; c.pend_cap = 2048;
+            c.ev_pool_size = 16384; c.pend_cap = 8192;
             c.ev_pool = (hipEvent_t*)calloc(c.ev_pool_size, sizeof(hipEvent_t));
             c.pend = (Ctx::Pending*)calloc(c.pend_cap, sizeof(Ctx::Pending));
             if (!c.ev_pool || !c.pend) throw std::bad_alloc();
@@ -266,7 +266,11 @@ void tdc_gpu_ctx_reset_profile(tdc_gpu_ctx* ctx) {
 }
 
 const char* tdc_gpu_ctx_kernel_profile(const tdc_gpu_ctx* ctx, int idx, double* ms, uint64_t* launches, uint64_t* bytes) {
-    static const char* names[K_CLASS_COUNT] = { "rs_scatter_kernel<u64>", "rs_scatter_kernel<u32>", "rs_count_kernel", "scan" };
+    static const char* names[K_CLASS_COUNT] = {
+        "rs_scatter_kernel<u64>", "rs_scatter_kernel<u32>", "rs_count_kernel", "scan_kernels",
+        "sa_update_kernels", "sa_build_keys_kernel", "phi_kernel", "plcp_kernel", "cand_kernels",
+        "level_init_kernel", "mis_round_kernel", "resolve_kernel", "push_kernel", "apply_kernel", "pool_kernels",
+        "flatten_round_kernel", "gaps_kernel", "literal_hist_kernel", "tile_bits_kernel", "pack_kernel", "extract_kernels" };
     if (!ctx || idx < 0 || idx >= K_CLASS_COUNT) return nullptr;
     const KernelProfile& k = ctx->c.kprof[idx];
     if (ms) *ms = k.ms;

@@ -70,7 +70,13 @@ struct Arena {
 
 // Live per-kernel timing (bench.py's roofline): HIP events on the launching stream around every launch of the
 // instrumented kernels, resolved after the stream has been synchronised.
-enum KernelClass { K_RS_SCATTER_U64 = 0, K_RS_SCATTER_U32, K_RS_COUNT, K_SCAN, K_CLASS_COUNT };
+enum KernelClass {
+    K_RS_SCATTER_U64 = 0, K_RS_SCATTER_U32, K_RS_COUNT, K_SCAN,
+    K_SA_RANK_SCATTER, K_SA_BUILD_KEYS, K_PHI, K_PLCP, K_CAND,
+    K_LEVEL_INIT, K_MIS_ROUND, K_RESOLVE, K_PUSH, K_APPLY, K_POOL,
+    K_FLATTEN_ROUND, K_ENC_GAPS, K_ENC_HIST, K_ENC_TILE_BITS, K_ENC_PACK, K_EXTRACT,
+    K_CLASS_COUNT
+};
 
 struct KernelProfile {
     double ms = 0;        // summed launch durations
@@ -103,6 +109,11 @@ struct Ctx {
         return npend++;
     }
     void prof_end(int idx) { if (idx >= 0) HIP_TRY(hipEventRecord(pend[idx].b, stream)); }
+    struct ProfScope {     // RAII: times everything enqueued on the stream between construction and destruction
+        Ctx& c; int idx;
+        ProfScope(Ctx& ctx, int cls, u64 bytes) : c(ctx), idx(ctx.prof_begin(cls, bytes)) {}
+        ~ProfScope() { if (idx >= 0) (void)hipEventRecord(c.pend[idx].b, c.stream); }
+    };
     // call after a stream synchronisation
     void prof_collect() {
         for (int i = 0; i < npend; ++i) {

@@ -41,28 +41,33 @@ constexpr int ENC_TILE = 256 * ENC_PER_THREAD;     // 2048 text positions per wo
 
 // gaps between consecutive factors (LZSSCoding.hpp:28-38) + min/max factor length (LZSSFactors.hpp:41-47);
 // stores the literal-run length at the first position of every run.
-__global__ void gaps_kernel(const u32* __restrict__ fpos, const u32* __restrict__ flen_list, size_t z, size_t n,
-                            u32* __restrict__ flen, EncScalars* __restrict__ sc) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    u32 gap = 0, lmin = 0xFFFFFFFFu, lmax = 0;
-    if (i < z) {
-        const u32 p = fpos[i];
+__global__ __launch_bounds__(256) void gaps_kernel(const u32* __restrict__ fpos, const u32* __restrict__ flen_list, size_t z,
+                                                    size_t n, u32* __restrict__ flen, EncScalars* __restrict__ sc) {
+    __shared__ u32 sg[4], smax[4], smin[4];
+    u32 gmax = 0, lmin = 0xFFFFFFFFu, lmax = 0;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < z; i += stride) {
+        const u32 p = fpos[i], l = flen_list[i];
         const u32 prev_end = (i == 0) ? 0u : fpos[i - 1] + flen_list[i - 1];
-        gap = p - prev_end;
+        const u32 gap = p - prev_end;
         if (gap) flen[prev_end] = gap;
-        lmin = lmax = flen_list[i];
+        gmax = max(gmax, gap);
+        lmin = min(lmin, l);
+        lmax = max(lmax, l);
         if (i + 1 == z) {
-            const u32 end = p + flen_list[i];
-            if ((size_t)end < n) { const u32 tail = (u32)(n - end); flen[end] = tail; gap = max(gap, tail); }
+            const u32 end = p + l;
+            if ((size_t)end < n) { const u32 tail = (u32)(n - end); flen[end] = tail; gmax = max(gmax, tail); }
         }
     }
-    gap = wave_reduce_max(gap);
+    gmax = wave_reduce_max(gmax);
     lmax = wave_reduce_max(lmax);
     lmin = wave_reduce_min(lmin);
-    if (lane_id() == 0) {
-        if (gap) atomicMax(&sc->fdist_max, gap);
-        if (lmax) atomicMax(&sc->flen_max, lmax);
-        if (lmin != 0xFFFFFFFFu) atomicMin(&sc->flen_min, lmin);
+    if (lane_id() == 0) { sg[wave_id()] = gmax; smax[wave_id()] = lmax; smin[wave_id()] = lmin; }
+    __syncthreads();
+    if (threadIdx.x == 0) {      // one atomic triple per workgroup (the grid is capped, so a few thousand in total)
+        atomicMax(&sc->fdist_max, max(max(sg[0], sg[1]), max(sg[2], sg[3])));
+        atomicMax(&sc->flen_max, max(max(smax[0], smax[1]), max(smax[2], smax[3])));
+        atomicMin(&sc->flen_min, min(min(smin[0], smin[1]), min(smin[2], smin[3])));
     }
 }
 
@@ -237,7 +242,9 @@ size_t encode_huff(Ctx& c, const u8* text, size_t n, FactorSpace fs, u8* d_out, 
     u32* d_hist = c.arena.get<u32>(256);
     HIP_TRY(hipMemsetAsync(d_hist, 0, 256 * sizeof(u32), s));
     if (z) {
-        gaps_kernel<<<cdiv(z, 256), 256, 0, s>>>(fpos, flist, z, n, fs.flen, d_sc);
+        unsigned g = cdiv(z, 256); if (g > 2048) g = 2048;
+        Ctx::ProfScope prof(c, K_ENC_GAPS, (u64)z * 12);
+        gaps_kernel<<<g, 256, 0, s>>>(fpos, flist, z, n, fs.flen, d_sc);
         LAUNCH_CHECK();
     } else {
         // no factor: one literal run covering the whole text (LZSSCoding.hpp:38, :83-91)
@@ -248,6 +255,7 @@ size_t encode_huff(Ctx& c, const u8* text, size_t n, FactorSpace fs, u8* d_out, 
     }
     {
         unsigned g = cdiv(n, 256 * 16); if (g > 2048) g = 2048; if (g == 0) g = 1;
+        Ctx::ProfScope prof(c, K_ENC_HIST, (u64)n * 5);
         literal_hist_kernel<<<g, 256, 0, s>>>(text, fs.owner, n, d_hist);
         LAUNCH_CHECK();
     }
@@ -279,8 +287,11 @@ size_t encode_huff(Ctx& c, const u8* text, size_t n, FactorSpace fs, u8* d_out, 
     const unsigned tiles = cdiv(n, ENC_TILE);
     u64* tile_bits = c.arena.get<u64>(tiles + 1);
     u64* d_total = c.arena.get<u64>(1);
-    tile_bits_kernel<<<tiles, 256, 0, s>>>(text, fs.owner, fs.flen, n, tab, P, tile_bits);
-    LAUNCH_CHECK();
+    {
+        Ctx::ProfScope prof(c, K_ENC_TILE_BITS, (u64)n * 9);
+        tile_bits_kernel<<<tiles, 256, 0, s>>>(text, fs.owner, fs.flen, n, tab, P, tile_bits);
+        LAUNCH_CHECK();
+    }
     exclusive_sum_u64(c, tile_bits, tile_bits, tiles, d_total);
     const u64 total_bits = base_bits + c.read(d_total);
     const size_t out_len = (size_t)(total_bits >> 3) + ((total_bits & 7) <= 5 ? 1 : 2);
@@ -290,8 +301,11 @@ size_t encode_huff(Ctx& c, const u8* text, size_t n, FactorSpace fs, u8* d_out, 
     // ---- pass 2: pack ----------------------------------------------------------------------------------------
     HIP_TRY(hipMemsetAsync(d_out, 0, padded, s));
     HIP_TRY(hipMemcpyAsync(d_out, hw.bytes.data(), hw.bytes.size(), hipMemcpyHostToDevice, s));
-    pack_kernel<<<tiles, 256, 0, s>>>(text, fs.owner, fs.flen, fs.fsrc, n, tab, P, tile_bits, base_bits, (u64*)d_out);
-    LAUNCH_CHECK();
+    {
+        Ctx::ProfScope prof(c, K_ENC_PACK, (u64)n * 9 + (u64)z * 4 + out_len);
+        pack_kernel<<<tiles, 256, 0, s>>>(text, fs.owner, fs.flen, fs.fsrc, n, tab, P, tile_bits, base_bits, (u64*)d_out);
+        LAUNCH_CHECK();
+    }
     terminator_kernel<<<1, 64, 0, s>>>(d_out, total_bits);
     LAUNCH_CHECK();
     HIP_TRY(hipStreamSynchronize(s));      // hw.bytes must outlive the async copy

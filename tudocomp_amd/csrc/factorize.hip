@@ -23,8 +23,8 @@
 namespace tdc {
 
 struct LevelScalars {
-    u32 live;        // entries with cur == L
-    u32 alive;       // entries with cur >= threshold
+    u32 live;        // != 0 iff some entry has cur == L
+    u32 alive;       // != 0 iff some entry has cur >= threshold
     u32 undecided;   // live entries still undecided after the last round
     u32 selected;    // factors emitted in this level
     u32 npush;       // entries pushed down from this level
@@ -91,10 +91,12 @@ __global__ void level_init_kernel(const u32* __restrict__ orig, u32 m0, const u3
         alive = (v >= threshold);
         state[k] = live ? 0u : 2u;
     }
+    // only "any live / any alive" is needed: plain flag stores (all writers store the same value) instead of
+    // millions of same-address atomics
     const u64 bl = __ballot(live), ba = __ballot(alive);
     if (lane_id() == 0) {
-        if (bl) atomicAdd(&sc->live, (u32)__popcll(bl));
-        if (ba) atomicAdd(&sc->alive, (u32)__popcll(ba));
+        if (bl) sc->live = 1u;
+        if (ba) sc->alive = 1u;
     }
 }
 
@@ -172,22 +174,35 @@ __global__ __launch_bounds__(256) void resolve_kernel(const u32* __restrict__ li
     const bool push = (st != 1u) && (v >= threshold);
     pushtgt[k] = push ? v : 0u;
     pushbin[k] = push ? 1u : 0u;
-    if (st == 1u) atomicAdd(&sc->selected, 1u);
+    if (G > 1) { if (st == 1u) atomicAdd(&sc->selected, 1u); }
+    else {
+        const u64 bs = __ballot(st == 1u);
+        if (bs && (u64)lane_id() == (u64)__builtin_ctzll(bs)) atomicAdd(&sc->selected, (u32)__popcll(bs));
+    }
 }
 
-__global__ void push_kernel(const u32* __restrict__ list, u32 m, const u32* __restrict__ pushtgt, const u32* __restrict__ poffs,
-                            u32 pool_top, u32* __restrict__ pool_p, u32* __restrict__ pool_t, u32* __restrict__ resid,
-                            u32* __restrict__ pushcnt) {
+// pushcnt[v] counts the pool entries per target level.  Targets cluster on a few small levels, so the counts are
+// first accumulated in an LDS histogram (targets < 1024) and flushed with one global atomic per non-empty bin.
+__global__ __launch_bounds__(256) void push_kernel(const u32* __restrict__ list, u32 m, const u32* __restrict__ pushtgt,
+                                                    const u32* __restrict__ poffs, u32 pool_top, u32* __restrict__ pool_p,
+                                                    u32* __restrict__ pool_t, u32* __restrict__ resid, u32* __restrict__ pushcnt) {
+    __shared__ u32 h[1024];
+    for (int i = threadIdx.x; i < 1024; i += 256) h[i] = 0;
+    __syncthreads();
     const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= m) return;
-    const u32 v = pushtgt[k];
-    if (!v) return;
-    const u32 p = list[k];
-    const u32 idx = pool_top + poffs[k];
-    pool_p[idx] = p;
-    pool_t[idx] = v;
-    resid[p] = v;
-    atomicAdd(&pushcnt[v], 1u);
+    if (k < m) {
+        const u32 v = pushtgt[k];
+        if (v) {
+            const u32 p = list[k];
+            const u32 idx = pool_top + poffs[k];
+            pool_p[idx] = p;
+            pool_t[idx] = v;
+            resid[p] = v;
+            if (v < 1024) atomicAdd(&h[v], 1u); else atomicAdd(&pushcnt[v], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 1024; i += 256) if (h[i]) atomicAdd(&pushcnt[i], h[i]);
 }
 
 // Emit the selected entries: factor (p, Phi[p], L); kill the covered positions, truncate the ones in front.
@@ -233,11 +248,17 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, const u32* isa, const u32
     u32* ckeys[2] = { c.arena.get<u32>(n), c.arena.get<u32>(n) };
     u32* cvals[2] = { c.arena.get<u32>(n), c.arena.get<u32>(n) };
     u32* d_total = c.arena.get<u32>(1);
-    cand_flag_kernel<<<gn, 256, 0, s>>>(sa, plcp, n, threshold, tmpA);
-    LAUNCH_CHECK();
+    {
+        Ctx::ProfScope prof(c, K_CAND, (u64)n * 12);
+        cand_flag_kernel<<<gn, 256, 0, s>>>(sa, plcp, n, threshold, tmpA);
+        LAUNCH_CHECK();
+    }
     exclusive_sum_u32(c, tmpA, tmpA, n, d_total);
-    cand_scatter_kernel<<<gn, 256, 0, s>>>(sa, plcp, tmpA, n, threshold, ckeys[0], cvals[0]);
-    LAUNCH_CHECK();
+    {
+        Ctx::ProfScope prof(c, K_CAND, (u64)n * 20);
+        cand_scatter_kernel<<<gn, 256, 0, s>>>(sa, plcp, tmpA, n, threshold, ckeys[0], cvals[0]);
+        LAUNCH_CHECK();
+    }
     const size_t entries = c.read(d_total);
     st->entries = entries;
     const int x = radix_sort_pairs_u32(c, ckeys, cvals, entries, 0, (int)bits_for(maxlcp));
@@ -283,6 +304,7 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, const u32* isa, const u32
             st->levels++;
             if (m1) {     // pushed part of the list: pool entries with target L, in pool (= encounter) order
                 const unsigned gp = cdiv(pool_top, 256);
+                Ctx::ProfScope prof(c, K_POOL, (u64)pool_top * 16 + (u64)m1 * 8);
                 pool_flag_kernel<<<gp, 256, 0, s>>>(pool_t, pool_top, L, pushbin);
                 LAUNCH_CHECK();
                 exclusive_sum_u32(c, pushbin, pushbin, pool_top, nullptr);
@@ -291,19 +313,25 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, const u32* isa, const u32
             }
             HIP_TRY(hipMemsetAsync(d_sc, 0, sizeof(LevelScalars), s));
             const unsigned gm = cdiv(m, 256);
-            level_init_kernel<<<gm, 256, 0, s>>>(cand + h_segstart[L], m0, pushed, m, L, threshold, cur, list, lidx, vcur, state, d_sc);
-            LAUNCH_CHECK();
+            {   // per entry: list source (4) + cur gather (4) + list/vcur/state (12) + lidx scatter (4)
+                Ctx::ProfScope prof(c, K_LEVEL_INIT, (u64)m * 24);
+                level_init_kernel<<<gm, 256, 0, s>>>(cand + h_segstart[L], m0, pushed, m, L, threshold, cur, list, lidx, vcur, state, d_sc);
+                LAUNCH_CHECK();
+            }
             h_sc = c.read(d_sc);
             if (h_sc.alive == 0) continue;          // every entry already erased (:86)
             const bool wide = (L > 24);
             const unsigned gw = wide ? cdiv((size_t)m * 64, 256) : gm;
             if (h_sc.live) {
-                u32 undecided = h_sc.live;
+                u32 undecided = m;
                 while (undecided) {
                     HIP_TRY(hipMemsetAsync(&d_sc->undecided, 0, sizeof(u32), s));
-                    if (wide) mis_round_kernel<64><<<gw, 256, 0, s>>>(list, m, L, n, resid, lidx, state, d_sc);
-                    else      mis_round_kernel<1><<<gw, 256, 0, s>>>(list, m, L, n, resid, lidx, state, d_sc);
-                    LAUNCH_CHECK();
+                    {   // per undecided entry: list + state (8) + a window of 2L-1 resid words
+                        Ctx::ProfScope prof(c, K_MIS_ROUND, (u64)m * 4 + (u64)undecided * (4 + 4ull * (2 * L - 1)));
+                        if (wide) mis_round_kernel<64><<<gw, 256, 0, s>>>(list, m, L, n, resid, lidx, state, d_sc);
+                        else      mis_round_kernel<1><<<gw, 256, 0, s>>>(list, m, L, n, resid, lidx, state, d_sc);
+                        LAUNCH_CHECK();
+                    }
                     const u32 now = c.read(&d_sc->undecided);
                     st->rounds++;
                     if (now >= undecided && now != 0) {
@@ -313,19 +341,25 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, const u32* isa, const u32
                     undecided = now;
                 }
             }
-            if (wide) resolve_kernel<64><<<gw, 256, 0, s>>>(list, m, L, threshold, n, resid, lidx, state, vcur, pushtgt, pushbin, d_sc);
-            else      resolve_kernel<1><<<gw, 256, 0, s>>>(list, m, L, threshold, n, resid, lidx, state, vcur, pushtgt, pushbin, d_sc);
-            LAUNCH_CHECK();
+            {   // per entry: state + vcur + list (12), outputs (8), and for live-or-stale entries the resid window
+                Ctx::ProfScope prof(c, K_RESOLVE, (u64)m * (20 + 4ull * (2 * L - 1)));
+                if (wide) resolve_kernel<64><<<gw, 256, 0, s>>>(list, m, L, threshold, n, resid, lidx, state, vcur, pushtgt, pushbin, d_sc);
+                else      resolve_kernel<1><<<gw, 256, 0, s>>>(list, m, L, threshold, n, resid, lidx, state, vcur, pushtgt, pushbin, d_sc);
+                LAUNCH_CHECK();
+            }
             exclusive_sum_u32(c, pushbin, pushbin, m, &d_sc->npush);
             h_sc = c.read(d_sc);
             // every push is caused by a truncation of a position in front of a factor, and factors are disjoint,
             // so the pool never needs more than n slots; checked before anything is written
             if (pool_top + h_sc.npush > n) throw HipError{hipErrorUnknown, "factorize: push pool overflow", (int)__LINE__};
             if (h_sc.npush) {
+                Ctx::ProfScope prof(c, K_PUSH, (u64)m * 8 + (u64)h_sc.npush * 16);
                 push_kernel<<<gm, 256, 0, s>>>(list, m, pushtgt, pushbin, (u32)pool_top, pool_p, pool_t, resid, pushcnt);
                 LAUNCH_CHECK();
             }
             if (h_sc.selected) {
+                // per entry: state + list (8); per factor: Phi, flen, fsrc (12) + L kills (8 B each) + L truncations (4 B each)
+                Ctx::ProfScope prof(c, K_APPLY, (u64)m * 8 + (u64)h_sc.selected * (12 + 12ull * L));
                 if (wide) apply_kernel<64><<<gw, 256, 0, s>>>(list, m, L, n, state, phi, cur, fs.flen, fs.owner, fs.fsrc);
                 else      apply_kernel<1><<<gw, 256, 0, s>>>(list, m, L, n, state, phi, cur, fs.flen, fs.owner, fs.fsrc);
                 LAUNCH_CHECK();

@@ -38,11 +38,17 @@ size_t extract_factors(Ctx& c, size_t n, FactorSpace fs, u32* pos, u32* src, u32
     u32* offs = c.arena.get<u32>(n);
     u32* d_total = c.arena.get<u32>(1);
     const unsigned gn = cdiv(n, 256);
-    fstart_flag_kernel<<<gn, 256, 0, c.stream>>>(fs.flen, fs.owner, n, offs);
-    LAUNCH_CHECK();
+    {
+        Ctx::ProfScope prof(c, K_EXTRACT, (u64)n * 12);
+        fstart_flag_kernel<<<gn, 256, 0, c.stream>>>(fs.flen, fs.owner, n, offs);
+        LAUNCH_CHECK();
+    }
     exclusive_sum_u32(c, offs, offs, n, d_total);
-    fstart_scatter_kernel<<<gn, 256, 0, c.stream>>>(fs.flen, fs.owner, fs.fsrc, offs, n, cap, pos, src, len);
-    LAUNCH_CHECK();
+    {
+        Ctx::ProfScope prof(c, K_EXTRACT, (u64)n * 12);
+        fstart_scatter_kernel<<<gn, 256, 0, c.stream>>>(fs.flen, fs.owner, fs.fsrc, offs, n, cap, pos, src, len);
+        LAUNCH_CHECK();
+    }
     const size_t z = c.read(d_total);
     c.arena.release(mark);
     return z;
@@ -155,8 +161,11 @@ void flatten_factors(Ctx& c, size_t n, FactorSpace fs, FlattenStats* st) {
     u32 waiting = (u32)z;
     while (waiting) {
         HIP_TRY(hipMemsetAsync(&d_sc->waiting, 0, sizeof(u32), s));
-        flatten_round_kernel<<<gz, 256, 0, s>>>(fpos, z, n, fs.flen, fs.owner, fs.fsrc, ffinal, cursrc, depth, d_sc);
-        LAUNCH_CHECK();
+        {   // per waiting factor: fpos, ffinal, flen, cursrc, depth (20) + one chain step (owner, flen, src: 12)
+            Ctx::ProfScope prof(c, K_FLATTEN_ROUND, (u64)z * 8 + (u64)waiting * 32);
+            flatten_round_kernel<<<gz, 256, 0, s>>>(fpos, z, n, fs.flen, fs.owner, fs.fsrc, ffinal, cursrc, depth, d_sc);
+            LAUNCH_CHECK();
+        }
         const u32 now = c.read(&d_sc->waiting);
         st->rounds++;
         if (now >= waiting) throw HipError{hipErrorUnknown, "flatten: rounds made no progress", (int)__LINE__};

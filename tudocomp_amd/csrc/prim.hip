@@ -147,6 +147,7 @@ static void scan_impl(Ctx& c, const T* in, T* out, size_t n, T* d_total) {
     }
     const size_t mark = c.arena.mark();
     T* agg = c.arena.get<T>(nb);
+    Ctx::ProfScope prof(c, K_SCAN, (u64)n * 3 * sizeof(T));    // two reads + one write of every element
     scan_reduce_kernel<T, OP><<<nb, 256, 0, c.stream>>>(in, agg, n);
     LAUNCH_CHECK();
     scan_impl<T, OP, false>(c, agg, agg, nb, nullptr);     // exclusive prefix of the block aggregates

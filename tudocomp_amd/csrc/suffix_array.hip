@@ -173,8 +173,11 @@ void build_suffix_array(Ctx& c, const u8* text, size_t n, u32* sa, u32* isa, SAS
     sa_heads_kernel<<<gn, 256, 0, s>>>(keys[x], n, head);
     LAUNCH_CHECK();
     inclusive_max_u32(c, head, head, n);
-    sa_first_update_kernel<<<gn, 256, 0, s>>>(vals[x], head, n, sa, rank, keep);
-    LAUNCH_CHECK();
+    {   // per element: read value + head (8 B), write sa + keep (8 B), scatter rank (4 B)
+        Ctx::ProfScope prof(c, K_SA_RANK_SCATTER, (u64)n * 20);
+        sa_first_update_kernel<<<gn, 256, 0, s>>>(vals[x], head, n, sa, rank, keep);
+        LAUNCH_CHECK();
+    }
     exclusive_sum_u32(c, keep, keep, n, d_total);
     sa_first_compact_kernel<<<gn, 256, 0, s>>>(vals[x], head, keep, n, A_sa, A_pos, A_r1);
     LAUNCH_CHECK();
@@ -187,15 +190,21 @@ void build_suffix_array(Ctx& c, const u8* text, size_t n, u32* sa, u32* isa, SAS
     while (m > 0) {
         if (h >= n) throw HipError{hipErrorUnknown, "suffix_array: doubling did not converge", (int)__LINE__};
         const unsigned gm = cdiv(m, 256);
-        sa_build_keys_kernel<<<gm, 256, 0, s>>>(A_sa, A_r1, m, n, (u32)h, bn, rank, keys[0], vals[0]);
-        LAUNCH_CHECK();
+        {   // per element: read sa + r1 (8 B), gather rank[sa+h] (4 B), write key + value (12 B)
+            Ctx::ProfScope prof(c, K_SA_BUILD_KEYS, (u64)m * 24);
+            sa_build_keys_kernel<<<gm, 256, 0, s>>>(A_sa, A_r1, m, n, (u32)h, bn, rank, keys[0], vals[0]);
+            LAUNCH_CHECK();
+        }
         x = radix_sort_pairs_u64(c, keys, vals, m, 0, 2 * bn);
         st->sorted_elems += m;
         sa_heads_kernel<<<gm, 256, 0, s>>>(keys[x], m, head);
         LAUNCH_CHECK();
         inclusive_max_u32(c, head, head, m);
-        sa_update_kernel<<<gm, 256, 0, s>>>(keys[x], vals[x], head, A_pos, m, bn, sa, rank, keep);
-        LAUNCH_CHECK();
+        {
+            Ctx::ProfScope prof(c, K_SA_RANK_SCATTER, (u64)m * 36);
+            sa_update_kernel<<<gm, 256, 0, s>>>(keys[x], vals[x], head, A_pos, m, bn, sa, rank, keep);
+            LAUNCH_CHECK();
+        }
         exclusive_sum_u32(c, keep, keep, m, d_total);
         sa_compact_kernel<<<gm, 256, 0, s>>>(vals[x], head, keep, A_pos, m, B_sa, B_pos, B_r1);
         LAUNCH_CHECK();

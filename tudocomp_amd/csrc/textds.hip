@@ -18,6 +18,7 @@ __global__ void phi_kernel(const u32* __restrict__ sa, size_t n, u32* __restrict
 
 void build_phi(Ctx& c, const u32* sa, size_t n, u32* phi) {
     if (!n) return;
+    Ctx::ProfScope prof(c, K_PHI, (u64)n * 8);                  // read SA, scatter Phi
     phi_kernel<<<cdiv(n, 256), 256, 0, c.stream>>>(sa, n, phi);
     LAUNCH_CHECK();
 }
@@ -52,6 +53,7 @@ void build_plcp(Ctx& c, const u8* text, size_t n, const u32* phi, u32* plcp, u32
     HIP_TRY(hipMemsetAsync(d_maxlcp, 0, sizeof(u32), c.stream));
     if (!n) return;
     const size_t threads = (n + PLCP_CHUNK - 1) / PLCP_CHUNK;
+    Ctx::ProfScope prof(c, K_PLCP, (u64)n * 10);                // Phi (4) + two text bytes + PLCP (4), SURVEY 8d
     plcp_kernel<<<cdiv(threads, 256), 256, 0, c.stream>>>(text, n, phi, plcp, d_maxlcp);
     LAUNCH_CHECK();
 }
