@@ -37,23 +37,6 @@ def parse_args():
     return ap.parse_args()
 
 
-def gather_streams(dist, torch, d_out, out_len, rank, world, device):
-    """Variable-size gather of the per-shard streams to rank 0: all_gather of the sizes, then point-to-point
-    sends (each peer has its own xGMI link to rank 0).  Returns the list of sizes (rank 0: also the buffers)."""
-    sizes = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
-    dist.all_gather(sizes, torch.tensor([out_len], dtype=torch.int64, device=device))
-    sizes = [int(s.item()) for s in sizes]
-    bufs = None
-    if rank == 0:
-        bufs = [d_out[:out_len]] + [torch.empty(sizes[r], dtype=torch.uint8, device=device) for r in range(1, world)]
-        reqs = [dist.irecv(bufs[r], src=r) for r in range(1, world)]
-        for q in reqs:
-            q.wait()
-    else:
-        dist.send(d_out[:out_len], dst=0)
-    return sizes, bufs
-
-
 def cpu_baseline(args, text_np, gpu_prefix_stream):
     """The oracle (bit-exact CPU port of the reference path), one core, on a bounded prefix of the workload."""
     from oracle import oracle as O
@@ -75,6 +58,7 @@ def main():
     import numpy as np
     import torch
     import tudocomp_amd as T
+    from tudocomp_amd.blocks import gather_streams
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

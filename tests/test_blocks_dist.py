@@ -1,0 +1,67 @@
+"""CPU tests of the multi-GPU path's exchange step: world-size-2 gloo run of the shard -> gather -> container flow
+(the per-shard streams come from the oracle here; on GPUs they come from the HIP path, byte-identical)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tudocomp_amd import blocks
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, tmpdir):
+    from oracle import oracle as O
+    import tudocomp_amd as T
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        shard = T.gen_english(20000 + 777 * rank, 42 + rank).tobytes()      # ragged shard sizes
+        stream, _ = O.lcpcomp_huff_compress(O.escape(shard), 2, 1)
+        buf = torch.zeros(len(stream) + 100, dtype=torch.uint8)             # capacity > length, like the bound()-sized buffer
+        buf[:len(stream)] = torch.from_numpy(np.frombuffer(stream, dtype=np.uint8).copy())
+        sizes, bufs = blocks.gather_streams(dist, torch, buf, len(stream), rank, world, torch.device("cpu"))
+        assert sizes[rank] == len(stream)
+        raw = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(raw, torch.tensor([len(shard)], dtype=torch.int64))
+        if rank == 0:
+            blob = blocks.pack_container([int(r.item()) for r in raw], [b.numpy().tobytes() for b in bufs])
+            with open(os.path.join(tmpdir, "container.bin"), "wb") as f:
+                f.write(blob)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_to_rank0_world2(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    from oracle import oracle as O
+    import tudocomp_amd as T
+    blob = open(tmp_path / "container.bin", "rb").read()
+    parts = blocks.unpack_container(blob)
+    assert len(parts) == world
+    for r, (raw_len, payload) in enumerate(parts):
+        shard = T.gen_english(20000 + 777 * r, 42 + r).tobytes()
+        assert raw_len == len(shard)
+        want, _ = O.lcpcomp_huff_compress(O.escape(shard), 2, 1)
+        assert payload == want                                   # byte-identical to the single-device stream
+        assert O.unescape(O.lcpcomp_huff_decompress(payload)) == shard
+
+
+def test_container_roundtrip_and_ranges():
+    parts = [b"", b"abc", bytes(range(256))]
+    blob = blocks.pack_container([0, 10, 300], parts)
+    assert [(r, bytes(p)) for r, p in blocks.unpack_container(blob)] == list(zip([0, 10, 300], parts))
+    assert blocks.shard_ranges(10, 4) == [(0, 4), (4, 8), (8, 10)]
+    assert blocks.shard_ranges(8, 4) == [(0, 4), (4, 8)]

@@ -1,0 +1,74 @@
+"""The mini `tdc` command line (tudocomp_amd/host): header contract, decompression (host code), error paths on CPU;
+compression + round trip on the GPU (BASELINE.json configs[0]: 64 KiB ASCII, lcpcomp(coder=huff,threshold=2))."""
+import os
+import subprocess
+
+import pytest
+
+import tudocomp_amd as T
+from oracle import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TDC = os.path.join(ROOT, "tudocomp_amd", "bin", "tdc")
+ALGO = "lcpcomp(coder=huff,threshold=2)"
+
+
+def _run(*args):
+    return subprocess.run([TDC] + list(args), capture_output=True, text=True)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tudocomp_amd", "host")])
+
+
+def test_list():
+    r = _run("-l")
+    assert r.returncode == 0 and "lcpcomp(coder=huff" in r.stdout
+
+
+def test_decompress_reads_header(tmp_path):
+    data = T.gen_english(5000, 3).tobytes() + b"\x00\xff tail"
+    payload, _ = O.lcpcomp_huff_compress(O.escape(data), 2, 1)
+    f = tmp_path / "x.tdc"
+    f.write_bytes(ALGO.encode() + b"%" + payload)              # tudocomp_driver.cpp:261-266
+    out = tmp_path / "x.out"
+    r = _run("-d", "-o", str(out), str(f))
+    assert r.returncode == 0, r.stderr
+    assert out.read_bytes() == data
+    # --raw needs the algorithm on the command line
+    f2 = tmp_path / "y.raw"
+    f2.write_bytes(payload)
+    out2 = tmp_path / "y.out"
+    assert _run("-d", "--raw", "-a", ALGO, "-o", str(out2), str(f2)).returncode == 0
+    assert out2.read_bytes() == data
+    # existing output without -f is refused
+    assert _run("-d", "-o", str(out), str(f)).returncode == 1
+
+
+def test_errors(tmp_path):
+    f = tmp_path / "in.txt"
+    f.write_bytes(b"no header here")
+    r = _run("-d", "-o", str(tmp_path / "o"), str(f))
+    assert r.returncode == 1 and "algorithm header" in r.stderr
+    r = _run("-a", "lz78(coder=gamma)", "-o", str(tmp_path / "o2"), str(f))
+    assert r.returncode == 1 and "No implementation found" in r.stderr
+    r = _run("-a", "lcpcomp(coder=arithmetic)", "-o", str(tmp_path / "o3"), str(f))
+    assert r.returncode == 1 and "No implementation found" in r.stderr
+
+
+@pytest.mark.gpu
+def test_config0_compress_roundtrip_64KiB(tmp_path):
+    data = T.gen_english(65536, 42).tobytes()
+    f = tmp_path / "english64k.txt"
+    f.write_bytes(data)
+    r = _run("-a", ALGO, "--stats", str(f))
+    assert r.returncode == 0, r.stderr
+    comp = (tmp_path / "english64k.txt.tdc").read_bytes()            # default output name: FILE.tdc
+    want, _ = O.lcpcomp_huff_compress(O.escape(data), 2, 1)
+    assert comp == ALGO.encode() + b"%" + want                       # header + bit-exact payload (38 687 B)
+    assert len(want) == 38687
+    assert '"factors"' in r.stdout
+    out = tmp_path / "back.txt"
+    assert _run("-d", "-o", str(out), str(tmp_path / "english64k.txt.tdc")).returncode == 0
+    assert out.read_bytes() == data

@@ -1,0 +1,302 @@
+// tdc_amd.hpp -- host-side C++ mirror of the slice of tudocomp's plugin surface that the lcpcomp hot path needs.
+//
+// Same names, argument meaning and error behaviour as the reference, so that its tests and driver read the same:
+//   tdc::Compressor          include/tudocomp/Compressor.hpp:19-43        -> tdc_amd::Compressor
+//   tdc::LCPCompressor       include/tudocomp/compressors/LCPCompressor.hpp:79-151 -> tdc_amd::LCPCompressor
+//   Input / Output wrapping  include/tudocomp/io/{Input,Output}.hpp, restrictions "escape {0} + null-terminate"
+//   Registry                 include/tudocomp/pre_header/Registry.hpp:11-25,204-231 (parse_algorithm_id / select_algorithm)
+// compress() forwards to the C ABI (include/tdc_gpu.h) -- there is no CPU compress path.
+// decompress() is host code, like in the reference (decode_text_internal + HuffmanCoder::Decoder, LCPCompressor.hpp:23-76,
+// coders/HuffmanCoder.hpp:572-612, io/BitIStream.hpp); the decoded text is unique, so references are resolved by
+// following source chains instead of the reference's ScanDec buffers.
+#pragma once
+
+#include <cstdint>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/tdc_gpu.h"
+
+namespace tdc_amd {
+
+using bytes = std::vector<uint8_t>;
+
+// ---- Input / Output ---------------------------------------------------------------------------------------
+struct InputRestrictions {
+    bool escape_zero = false;       // escape {0}        (ds/SADivSufSort.hpp:20-25)
+    bool null_terminate = false;    // append sentinel
+    bool has_restrictions() const { return escape_zero || null_terminate; }
+};
+
+class Input {
+    bytes m_data;
+    InputRestrictions m_restr;
+public:
+    Input() = default;
+    explicit Input(bytes data) : m_data(std::move(data)) {}
+    static Input from_memory(const void* p, size_t n) { return Input(bytes((const uint8_t*)p, (const uint8_t*)p + n)); }
+    static Input from_file(const std::string& path) {
+        std::ifstream f(path, std::ios::binary);
+        if (!f) throw std::runtime_error("Could not open file for reading: " + path);
+        return Input(bytes((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>()));
+    }
+    Input(const Input& other, InputRestrictions r) : m_data(other.m_data), m_restr(r) {}
+    Input(const Input& other, size_t from) : m_data(other.m_data.begin() + from, other.m_data.end()), m_restr(other.m_restr) {}
+    size_t size() const { return m_data.size(); }
+    const bytes& raw() const { return m_data; }
+    // Input::as_view(): materialises the restricted view (io/RestrictedBuffer.hpp:108-254)
+    bytes as_view() const {
+        if (!m_restr.has_restrictions()) return m_data;
+        bytes out(2 * m_data.size() + 1);
+        out.resize(tdc_escape(m_data.data(), m_data.size(), out.data()));
+        return out;
+    }
+};
+
+class Output {
+    bytes* m_vec = nullptr;
+    InputRestrictions m_restr;
+public:
+    Output() = default;
+    explicit Output(bytes& v) : m_vec(&v) {}
+    Output(const Output& other, InputRestrictions r) : m_vec(other.m_vec), m_restr(r) {}
+    void write(const uint8_t* p, size_t n) {
+        if (m_restr.has_restrictions()) {                       // un-escaping ostream filter (io/RestrictedIOStream.hpp:13-89)
+            bytes tmp(n + 1);
+            tmp.resize(tdc_unescape(p, n, tmp.data()));
+            m_vec->insert(m_vec->end(), tmp.begin(), tmp.end());
+        } else m_vec->insert(m_vec->end(), p, p + n);
+    }
+};
+
+// ---- options ------------------------------------------------------------------------------------------------
+struct AlgorithmValue {
+    std::string name;
+    std::map<std::string, std::string> args;      // key -> value text ("huff", "2", "scan(scans=6)")
+    std::string get(const std::string& k, const std::string& dflt) const {
+        auto it = args.find(k);
+        return it == args.end() ? dflt : it->second;
+    }
+    long get_int(const std::string& k, long dflt) const {
+        auto it = args.find(k);
+        return it == args.end() ? dflt : std::stol(it->second);
+    }
+};
+
+// name(arg, key=value, key=algo(...))  -- the subset of AlgorithmStringParser.hpp:94-300 this path needs
+inline AlgorithmValue parse_algorithm_id(const std::string& s, const std::vector<std::string>& positional = {}) {
+    AlgorithmValue av;
+    size_t i = 0;
+    auto skip = [&] { while (i < s.size() && isspace((unsigned char)s[i])) ++i; };
+    skip();
+    size_t b = i;
+    while (i < s.size() && (isalnum((unsigned char)s[i]) || s[i] == '_')) ++i;
+    av.name = s.substr(b, i - b);
+    if (av.name.empty()) throw std::runtime_error("Expected an algorithm name in '" + s + "'");
+    skip();
+    if (i == s.size()) return av;
+    if (s[i] != '(') throw std::runtime_error("Unexpected character in algorithm string '" + s + "'");
+    ++i;
+    size_t pos_idx = 0;
+    while (true) {
+        skip();
+        if (i < s.size() && s[i] == ')') { ++i; break; }
+        size_t st = i; int depth = 0;
+        while (i < s.size() && (depth > 0 || (s[i] != ',' && s[i] != ')'))) {
+            if (s[i] == '(') ++depth;
+            if (s[i] == ')') --depth;
+            ++i;
+        }
+        if (i >= s.size()) throw std::runtime_error("Unbalanced parentheses in algorithm string '" + s + "'");
+        std::string item = s.substr(st, i - st);
+        while (!item.empty() && isspace((unsigned char)item.back())) item.pop_back();
+        size_t eq = std::string::npos; depth = 0;
+        for (size_t j = 0; j < item.size(); ++j) {
+            if (item[j] == '(') ++depth; else if (item[j] == ')') --depth;
+            else if (item[j] == '=' && depth == 0) { eq = j; break; }
+        }
+        if (eq == std::string::npos) {
+            if (pos_idx >= positional.size()) throw std::runtime_error("Too many positional arguments in '" + s + "'");
+            av.args[positional[pos_idx++]] = item;
+        } else {
+            std::string k = item.substr(0, eq), v = item.substr(eq + 1);
+            while (!k.empty() && isspace((unsigned char)k.back())) k.pop_back();
+            while (!v.empty() && isspace((unsigned char)v.front())) v.erase(v.begin());
+            av.args[k] = v;
+        }
+        if (s[i] == ',') ++i;
+    }
+    return av;
+}
+
+// ---- bit input (io/BitIStream.hpp:16-195) --------------------------------------------------------------------
+class BitIStream {
+    const uint8_t* m_p; size_t m_n, m_idx = 0;
+    uint8_t m_current = 0, m_next = 0, m_final_bits = 0, m_cursor = 0;
+    bool m_is_final = false;
+    void read_next() {
+        m_current = m_next; m_cursor = 7;
+        if (m_idx < m_n) {
+            m_next = m_p[m_idx++];
+            if (m_idx == m_n) { m_final_bits = m_next & 7; if (m_final_bits >= 6) { m_is_final = true; m_next = 0; } }
+        } else { m_is_final = true; m_final_bits = m_current & 7; m_next = 0; }
+    }
+public:
+    BitIStream(const uint8_t* p, size_t n) : m_p(p), m_n(n) {
+        if (n) { m_next = m_p[m_idx++]; read_next(); } else { m_is_final = true; }
+    }
+    bool eof() const { return m_is_final && m_cursor <= (7 - m_final_bits); }
+    unsigned read_bit() {
+        if (eof()) return 0;
+        unsigned bit = (m_current >> m_cursor) & 1;
+        if (m_cursor) --m_cursor; else read_next();
+        return bit;
+    }
+    uint64_t read_int(unsigned bits) { uint64_t v = 0; while (bits--) v = (v << 1) | read_bit(); return v; }
+    uint64_t read_compressed_int(unsigned b = 7) {
+        uint64_t v = 0; unsigned i = 0; bool more;
+        do { more = read_bit(); v |= read_int(b) << (b * i++); } while (more);
+        return v;
+    }
+};
+
+inline unsigned bits_for(uint64_t v) { unsigned b = 0; if (!v) return 1; while (v) { ++b; v >>= 1; } return b; }
+
+// ---- Compressor ---------------------------------------------------------------------------------------------
+class Compressor {
+public:
+    virtual ~Compressor() = default;
+    virtual void compress(Input& input, Output& output) = 0;      // Compressor.hpp:36
+    virtual void decompress(Input& input, Output& output) = 0;    // Compressor.hpp:42
+    virtual InputRestrictions input_restrictions() const { return {}; }
+};
+
+struct GpuContext {
+    tdc_gpu_ctx* h = nullptr;
+    explicit GpuContext(int device = 0) {
+        int rc = tdc_gpu_ctx_create(device, &h);
+        if (rc) throw std::runtime_error(std::string("tdc_gpu_ctx_create: ") + tdc_gpu_strerror(rc));
+    }
+    ~GpuContext() { tdc_gpu_ctx_destroy(h); }
+    GpuContext(const GpuContext&) = delete;
+    GpuContext& operator=(const GpuContext&) = delete;
+};
+
+class LCPCompressor : public Compressor {
+    AlgorithmValue m_opts;
+    std::shared_ptr<GpuContext> m_ctx;
+public:
+    tdc_gpu_stats last_stats{};
+    // meta: type "compressor", name "lcpcomp", options coder, comp=arrays, dec=scan, threshold=5, flatten=1 (LCPCompressor.hpp:85-95)
+    LCPCompressor(AlgorithmValue opts, std::shared_ptr<GpuContext> ctx) : m_opts(std::move(opts)), m_ctx(std::move(ctx)) {
+        const std::string coder = m_opts.get("coder", ""), comp = m_opts.get("comp", "arrays");
+        if (coder != "huff" || (comp != "arrays" && comp != "arrays()"))
+            throw std::runtime_error("No implementation found for compressor lcpcomp(coder=" + coder + ",comp=" + comp + ")");   // Registry.hpp:214
+    }
+    InputRestrictions input_restrictions() const override { return {true, true}; }   // uses_textds (Meta.hpp:277-282)
+
+    void compress(Input& input, Output& output) override {
+        if (!m_ctx) m_ctx = std::make_shared<GpuContext>(0);
+        const bytes view = input.as_view();
+        uint8_t* out = nullptr; size_t out_len = 0;
+        const int rc = tdc_gpu_lcpcomp_compress(m_ctx->h, view.data(), view.size(), (uint32_t)m_opts.get_int("threshold", 5),
+                                                (int)m_opts.get_int("flatten", 1), TDC_GPU_CODER_HUFF, &out, &out_len, &last_stats);
+        if (rc == TDC_GPU_ERR_NO_SENTINEL) throw std::logic_error(tdc_gpu_strerror(rc));          // ds/TextDS.hpp:132-138
+        if (rc) throw std::runtime_error(std::string(tdc_gpu_strerror(rc)) + ": " + tdc_gpu_last_error(m_ctx->h));
+        output.write(out, out_len);
+        tdc_gpu_free(out);
+    }
+
+    void decompress(Input& input, Output& output) override {
+        const bytes& in = input.raw();
+        BitIStream bs(in.data(), in.size());
+        // HuffmanCoder::Decoder ctor (HuffmanCoder.hpp:581-597)
+        const bool have_table = bs.read_bit();
+        uint8_t order[256]; uint64_t firstcode[256]; size_t prefix_sum[256]; unsigned longest = 0;
+        if (have_table) {
+            longest = (unsigned)(bs.read_compressed_int() & 0xFF);
+            if (!longest) throw std::runtime_error("corrupt Huffman table");
+            uint8_t numl[256];
+            for (unsigned i = 0; i < longest; ++i) numl[i] = (uint8_t)bs.read_compressed_int();
+            const size_t sigma = bs.read_compressed_int();
+            if (sigma > 256) throw std::runtime_error("corrupt Huffman table");
+            for (size_t i = 0; i < sigma; ++i) order[i] = (uint8_t)bs.read_int(8);
+            firstcode[longest - 1] = 0;
+            for (unsigned i = longest - 1; i > 0; --i) firstcode[i - 1] = (firstcode[i] + numl[i]) / 2;
+            size_t acc = 0;
+            for (unsigned l = 0; l < longest; ++l) { prefix_sum[l] = acc; acc += numl[l]; }
+        }
+        // lcpcomp::decode_text_internal (LCPCompressor.hpp:23-76)
+        const uint64_t n = bs.read_int(32);
+        const unsigned W = bits_for(n);
+        const uint64_t flen_min = bs.read_int(W), flen_max = bs.read_int(W), fdist_max = bs.read_int(W);
+        const unsigned lbits = bits_for(flen_max - flen_min), dbits = bits_for(fdist_max);
+        bytes text(n);
+        std::vector<uint32_t> ref(n, 0xFFFFFFFFu);
+        uint64_t p = 0;
+        while (!bs.eof()) {
+            uint64_t num = bs.read_bit() ? bs.read_int(dbits) : 0;
+            while (num--) {
+                uint8_t ch;
+                if (!have_table) ch = (uint8_t)bs.read_int(8);
+                else {
+                    uint64_t value = 0; unsigned length = 0;
+                    do { value = (value << 1) + bs.read_bit(); ++length; } while (length <= longest && value < firstcode[length - 1]);
+                    if (length > longest) throw std::runtime_error("corrupt Huffman code");
+                    --length;
+                    ch = order[prefix_sum[length] + (value - firstcode[length])];
+                }
+                if (p >= n) throw std::runtime_error("corrupt stream: too many literals");
+                text[p++] = ch;
+            }
+            if (!bs.eof()) {
+                const uint64_t src = bs.read_int(W), len = flen_min + bs.read_int(lbits);
+                if (p + len > n || src + len > n) throw std::runtime_error("corrupt stream: factor out of range");
+                for (uint64_t j = 0; j < len; ++j) ref[p + j] = (uint32_t)(src + j);
+                p += len;
+            }
+        }
+        if (p != n) throw std::runtime_error("corrupt stream: length mismatch");
+        std::vector<uint32_t> stack;
+        for (uint64_t i = 0; i < n; ++i) {
+            if (ref[i] == 0xFFFFFFFFu) continue;
+            stack.clear();
+            uint32_t q = (uint32_t)i;
+            while (ref[q] != 0xFFFFFFFFu) {
+                if (stack.size() > n) throw std::runtime_error("corrupt stream: reference cycle");
+                stack.push_back(q); q = ref[q];
+            }
+            for (uint32_t r : stack) { text[r] = text[q]; ref[r] = 0xFFFFFFFFu; }
+        }
+        output.write(text.data(), text.size());
+    }
+};
+
+// ---- registry (what is actually registered; Registry.hpp:204-231) ---------------------------------------------
+struct Selection {
+    std::string id_string;
+    std::unique_ptr<Compressor> compressor;
+    InputRestrictions restrictions;
+};
+
+inline std::vector<std::string> registered_algorithms() {
+    return { "lcpcomp(coder=huff, comp=arrays, dec=scan(scans=6), threshold=5, flatten=1)   [MI355X, libtdc_gpu.so]" };
+}
+
+inline Selection select_algorithm(const std::string& id, std::shared_ptr<GpuContext> ctx = nullptr) {
+    AlgorithmValue av = parse_algorithm_id(id, {"coder", "comp", "dec", "textds"});
+    if (av.name != "lcpcomp") throw std::runtime_error("No implementation found for compressor " + id);
+    Selection s;
+    s.id_string = id;
+    auto c = std::make_unique<LCPCompressor>(av, std::move(ctx));
+    s.restrictions = c->input_restrictions();
+    s.compressor = std::move(c);
+    return s;
+}
+
+}  // namespace tdc_amd
