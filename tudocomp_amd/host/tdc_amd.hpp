@@ -189,9 +189,11 @@ struct GpuContext {
 
 class LCPCompressor : public Compressor {
     AlgorithmValue m_opts;
-    std::shared_ptr<GpuContext> m_ctx;
+    std::shared_ptr<GpuContext> m_ctx;       // created lazily by the first compress(): decompress() needs no GPU
+    int m_device = 0;
 public:
     tdc_gpu_stats last_stats{};
+    void set_device(int d) { m_device = d; }
     // meta: type "compressor", name "lcpcomp", options coder, comp=arrays, dec=scan, threshold=5, flatten=1 (LCPCompressor.hpp:85-95)
     LCPCompressor(AlgorithmValue opts, std::shared_ptr<GpuContext> ctx) : m_opts(std::move(opts)), m_ctx(std::move(ctx)) {
         const std::string coder = m_opts.get("coder", ""), comp = m_opts.get("comp", "arrays");
@@ -201,7 +203,7 @@ public:
     InputRestrictions input_restrictions() const override { return {true, true}; }   // uses_textds (Meta.hpp:277-282)
 
     void compress(Input& input, Output& output) override {
-        if (!m_ctx) m_ctx = std::make_shared<GpuContext>(0);
+        if (!m_ctx) m_ctx = std::make_shared<GpuContext>(m_device);
         const bytes view = input.as_view();
         uint8_t* out = nullptr; size_t out_len = 0;
         const int rc = tdc_gpu_lcpcomp_compress(m_ctx->h, view.data(), view.size(), (uint32_t)m_opts.get_int("threshold", 5),
@@ -288,12 +290,13 @@ inline std::vector<std::string> registered_algorithms() {
     return { "lcpcomp(coder=huff, comp=arrays, dec=scan(scans=6), threshold=5, flatten=1)   [MI355X, libtdc_gpu.so]" };
 }
 
-inline Selection select_algorithm(const std::string& id, std::shared_ptr<GpuContext> ctx = nullptr) {
+inline Selection select_algorithm(const std::string& id, std::shared_ptr<GpuContext> ctx = nullptr, int device = 0) {
     AlgorithmValue av = parse_algorithm_id(id, {"coder", "comp", "dec", "textds"});
     if (av.name != "lcpcomp") throw std::runtime_error("No implementation found for compressor " + id);
     Selection s;
     s.id_string = id;
     auto c = std::make_unique<LCPCompressor>(av, std::move(ctx));
+    c->set_device(device);
     s.restrictions = c->input_restrictions();
     s.compressor = std::move(c);
     return s;

@@ -62,7 +62,7 @@ int main(int argc, char** argv) {
         const auto t0 = std::chrono::steady_clock::now();
         Selection sel;
         if (!decompress) {
-            sel = select_algorithm(algo, std::make_shared<GpuContext>(device));
+            sel = select_algorithm(algo, nullptr, device);
             if (!raw) {                                                                  // :261-266
                 if (algo.find('%') != std::string::npos) fail("algorithm id must not contain '%'");
                 result.insert(result.end(), algo.begin(), algo.end());
