@@ -140,3 +140,91 @@ def flatten_rounds(factors):
     out = [(f[0], final_src[i], f[2]) for i, f in enumerate(factors)]
     nf = sum(1 for d in depth if d)
     return out, nf, max(depth), rounds
+
+
+def factorize_explicit_priority(n, isa, phi, plcp, maxlcp, threshold, rng=None):
+    """Second device formulation (factorize.hip): lists are UNORDERED sets, the list order of the reference lives in
+    an explicit priority array: prio[p] = ISA[p] for original candidates; entries pushed from level L get
+    prio = base + rank, where rank is their index after sorting the level's pushes by (target, old prio) and base
+    grows monotonically -- so inside every target list pushed entries follow the originals, later pushes follow
+    earlier ones, and pushes of one level keep their relative order.  `rng` shuffles every list to prove that no
+    result depends on list order."""
+    if maxlcp + 1 <= threshold:
+        return []
+    cur = [int(x) for x in plcp]
+    cur[n - 1] = 0
+    prio = [int(x) for x in isa]
+    resid = [cur[p] if cur[p] >= threshold else 0 for p in range(n)]
+    orig = {}
+    for p in range(n):                               # position order
+        if cur[p] >= threshold:
+            orig.setdefault(cur[p], []).append(p)
+    segs = {}                                        # target level -> list of pushed positions
+    prio_base = n
+    factors = []
+    UNDECIDED, SELECTED, NOTLIVE, REJECTED = 0, 1, 2, 3
+    pst = [NOTLIVE] * n
+    for L in range(maxlcp, threshold - 1, -1):
+        ent = list(orig.get(L, ())) + list(segs.get(L, ()))
+        if not ent:
+            continue
+        if rng:
+            rng.shuffle(ent)
+        live, stale = [], []
+        for p in ent:
+            assert resid[p] == L
+            v = cur[p]
+            if v == L:
+                live.append(p); pst[p] = UNDECIDED
+            else:
+                pst[p] = NOTLIVE
+                if v >= threshold:
+                    stale.append(p)
+
+        def window(p):
+            return range(max(0, p - L + 1), min(n, p + L))
+
+        while any(pst[p] == UNDECIDED for p in live):
+            snap = list(pst)
+            for p in live:
+                if snap[p] != UNDECIDED:
+                    continue
+                hit = blocked = False
+                for q in window(p):
+                    if q == p or resid[q] != L:
+                        continue
+                    if snap[q] == SELECTED:
+                        hit = True
+                        break
+                    if snap[q] == UNDECIDED and prio[q] < prio[p]:
+                        blocked = True
+                if hit:
+                    pst[p] = REJECTED
+                elif not blocked:
+                    pst[p] = SELECTED
+        pushes = []
+        for p in stale + [q for q in live if pst[q] == REJECTED]:
+            v = cur[p]
+            for q in window(p):
+                if q == p or resid[q] != L or pst[q] != SELECTED or prio[q] >= prio[p]:
+                    continue
+                if q < p:
+                    v = 0
+                    break
+                v = min(v, q - p)
+            if v >= threshold:
+                pushes.append((v, prio[p], p))
+        sel = sorted((p for p in live if pst[p] == SELECTED), key=lambda p: prio[p])
+        for p in sel:
+            factors.append((p, int(phi[p]), L))
+            for j in range(L):
+                cur[p + j] = 0
+            for j in range(min(L, p)):
+                cur[p - 1 - j] = min(cur[p - 1 - j], j + 1)
+        pushes.sort()
+        for i, (v, _, p) in enumerate(pushes):
+            resid[p] = v
+            prio[p] = prio_base + i
+            segs.setdefault(v, []).append(p)
+        prio_base += len(pushes)
+    return factors

@@ -33,3 +33,21 @@ def test_model_on_corpus(name, data):
 def test_model_on_random_inputs():
     for _, data in corpus.random_small(400, seed=7):
         _check(data, (1, 2, 3, 5))
+
+
+def test_explicit_priority_model_is_order_independent():
+    """The second formulation (unordered lists + explicit priorities, as implemented in factorize.hip) reproduces the
+    reference's factor list incl. emission order even when every list is shuffled."""
+    import random
+    from tests.models.position_space import factorize_explicit_priority
+    rng = random.Random(5)
+    cases = corpus.random_small(300, seed=11) + [c for c in corpus.small_corpus() if len(c[1]) <= 1500]
+    for _, data in cases:
+        text = O.escape(data)
+        n = len(text)
+        sa = O.suffix_array(text)
+        isa, phi, plcp, maxlcp = O.isa_phi_plcp(text, sa)
+        lcp = O.lcp_array(sa, plcp)
+        for thr in (1, 2, 5):
+            ref = [(int(a), int(b), int(c)) for a, b, c in O.arrays_comp(sa, isa, lcp, maxlcp, thr)]
+            assert factorize_explicit_priority(n, isa, phi, plcp, maxlcp, thr, rng) == ref

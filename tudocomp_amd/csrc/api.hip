@@ -49,7 +49,7 @@ int guarded(tdc_gpu_ctx* ctx, F&& f) {
     }
 }
 
-size_t arena_need(size_t n) { return 100 * n + ((size_t)64 << 20); }
+size_t arena_need(size_t n) { return 104 * n + ((size_t)64 << 20); }
 
 void check_text_args(const void* text, size_t n) {
     if (!text) throw ArgError{TDC_GPU_ERR_ARG, "text is NULL"};
@@ -148,8 +148,9 @@ void run_factorize(Ctx& c, size_t n, DevArrays& A, u32 threshold, int flatten, t
     }
 }
 
-// whole pipeline on a device-resident text; output written to d_out (8-byte aligned, capacity out_cap)
-size_t run_pipeline(Ctx& c, const u8* d_text, size_t n, u32 threshold, int flatten, u8* d_out, size_t out_cap,
+// whole pipeline on a device-resident text; output written to *d_out (8-byte aligned, capacity out_cap); if *d_out is
+// NULL the buffer is taken from the arena once the factorization scratch has been released
+size_t run_pipeline(Ctx& c, const u8* d_text, size_t n, u32 threshold, int flatten, u8** d_out_io, size_t out_cap,
                     tdc_gpu_stats* st, Events& ev) {
     if (threshold == 0) throw ArgError{TDC_GPU_ERR_ARG, "threshold must be >= 1"};
     validate_device_text(c, d_text, n);
@@ -157,6 +158,8 @@ size_t run_pipeline(Ctx& c, const u8* d_text, size_t n, u32 threshold, int flatt
     run_textds(c, d_text, n, A, st, &ev);
     run_factorize(c, n, A, threshold, flatten, st, &ev);
     EncodeStats es;
+    if (!*d_out_io) { out_cap = align_up(encode_bound(n) + 16, 8); *d_out_io = c.arena.get<u8>(out_cap); }
+    u8* d_out = *d_out_io;
     const int e0 = ev.tick();
     const size_t out_len = encode_huff(c, d_text, n, A.fs, d_out, out_cap, &es);
     const int e1 = ev.tick();
@@ -296,7 +299,8 @@ int tdc_gpu_lcpcomp_compress_dev(tdc_gpu_ctx* ctx, const void* d_text, size_t n,
         c.ensure_arena(arena_need(n));
         Events ev(c);
         const int e0 = ev.tick();
-        *out_len = run_pipeline(c, (const u8*)d_text, n, threshold, flatten, (u8*)d_out, out_cap, stats, ev);
+        u8* dst = (u8*)d_out;
+        *out_len = run_pipeline(c, (const u8*)d_text, n, threshold, flatten, &dst, out_cap, stats, ev);
         const int e1 = ev.tick();
         if (stats) ev.span(&stats->ms_total, e0, e1);
         ev.finish();
@@ -318,9 +322,8 @@ int tdc_gpu_lcpcomp_compress(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, ui
         u8* d_text = c.arena.get<u8>(n + 64);
         HIP_TRY(hipMemcpyAsync(d_text, text, n, hipMemcpyHostToDevice, c.stream));
         const int e1 = ev.tick();
-        const size_t cap = tdc_gpu_lcpcomp_bound(n);
-        u8* d_out = c.arena.get<u8>(cap);
-        const size_t len = run_pipeline(c, d_text, n, threshold, flatten, d_out, cap, stats, ev);
+        u8* d_out = nullptr;
+        const size_t len = run_pipeline(c, d_text, n, threshold, flatten, &d_out, 0, stats, ev);
         const int e2 = ev.tick();
         uint8_t* h = host_alloc<uint8_t>(len);
         HIP_TRY(hipMemcpyAsync(h, d_out, len, hipMemcpyDeviceToHost, c.stream));

@@ -5,46 +5,60 @@
 // entry whose LCP value still equals L, zeroes the LCP of the L covered text positions (:99-101) and truncates the
 // LCP of the up to L positions in front of it (:103-109).
 //
-// Device formulation (validated against the oracle by tests/models/position_space.py):
+// Device formulation (models: tests/models/position_space.py, checked against the oracle incl. emission order):
 //   * all state is indexed by TEXT POSITION p: cur[p] = lcp[isa[p]] (initially PLCP[p]), source = Phi[p];
-//   * resid[p] = level whose list currently holds p's entry; the pushed part of every list is kept in one
-//     time-ordered pool (pool index = encounter order), so list L = originals(L) ++ {pool entries with target L};
-//   * inside a level only "live" entries (cur == L) can be selected, and an entry is selected iff no EARLIER list
-//     entry within text distance < L is selected: the lexicographically-first maximal independent set in list
-//     order, computed by rounds in which an entry decides once all its earlier live neighbours have decided;
-//   * every non-selected entry then gets its encounter value v = cur reduced by the selected earlier neighbours
-//     (left neighbour covers it -> 0, right neighbour at distance d -> min(v, d)) and is appended to list v
-//     (or dropped if v < threshold);
+//   * resid[p] = level whose list currently holds p's entry.  Lists are UNORDERED sets kept in position order (so all
+//     per-level kernels walk the position-indexed arrays monotonically); the reference's list order lives in an
+//     explicit priority prio[p]: ISA[p] for original candidates (ascending SA index), and base + rank for entries
+//     pushed down from level L, where rank is the index after sorting that level's pushes by (target, old priority)
+//     and base grows monotonically -- pushed entries follow the originals, later pushes follow earlier ones, pushes of
+//     one level keep their order: exactly the reference's append order;
+//   * inside a level only "live" entries (cur == L) can be selected, and one is selected iff no live entry of HIGHER
+//     priority within text distance < L is selected: the lexicographically-first maximal independent set, computed by
+//     rounds in which an entry decides once all its higher-priority live neighbours have decided;
+//   * every other entry (stale or rejected) gets its encounter value v = cur reduced by the selected neighbours of
+//     higher priority (left neighbour covers it -> 0, right neighbour at distance d -> min(v, d)) and moves to list v
+//     (or is dropped if v < threshold);
 //   * kills (cur = 0, owner = factor start) and truncations (atomicMin) of all selected entries are applied last;
 //     they commute, so their order does not matter.
 #include "stages.hpp"
 #include "prim.hpp"
 
+#include <algorithm>
+#include <vector>
+
 namespace tdc {
 
+enum : u8 { ST_UNDECIDED = 0, ST_SELECTED = 1, ST_NOTLIVE = 2, ST_REJECTED = 3 };
+enum : u8 { CL_DEAD = 0, CL_LIVE = 1, CL_STALE = 2 };
+
 struct LevelScalars {
-    u32 live;        // != 0 iff some entry has cur == L
-    u32 alive;       // != 0 iff some entry has cur >= threshold
-    u32 undecided;   // live entries still undecided after the last round
-    u32 selected;    // factors emitted in this level
-    u32 npush;       // entries pushed down from this level
-    u32 pad[3];
+    u32 nlive, nstale;   // entries with cur == L / threshold <= cur < L
+    u32 undecided;       // live entries still undecided after the last round
+    u32 selected;        // factors emitted in this level
+    u32 npush;           // entries pushed down from this level
+    u32 nseg;            // distinct push targets of this level
+    u32 pad[2];
 };
 
-// ---- candidates ------------------------------------------------------------------------------------------
-__global__ void cand_flag_kernel(const u32* __restrict__ sa, const u32* __restrict__ plcp, size_t n, u32 threshold,
-                                 u32* __restrict__ flag) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    flag[i] = (i >= 1 && plcp[sa[i]] >= threshold) ? 1u : 0u;
-}
-__global__ void cand_scatter_kernel(const u32* __restrict__ sa, const u32* __restrict__ plcp, const u32* __restrict__ offs,
-                                    size_t n, u32 threshold, u32* __restrict__ keys, u32* __restrict__ vals) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || i == 0) return;
-    const u32 p = sa[i];
+struct PushSeg { u32 target, start; };
+
+// ---- candidates ("Fill candidates", :54-66) ----------------------------------------------------------------
+__global__ void cand_class_kernel(const u32* __restrict__ plcp, size_t n, u32 threshold, u8* __restrict__ cls,
+                                  u32* __restrict__ pos, u32* __restrict__ resid, u32* __restrict__ flen, u32* __restrict__ owner) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
     const u32 v = plcp[p];
-    if (v >= threshold) { const u32 o = offs[i]; keys[o] = v; vals[o] = p; }
+    const bool c = v >= threshold;       // PLCP[n-1] = 0, so the sentinel (SA index 0) is never a candidate
+    cls[p] = c ? 1 : 0;
+    pos[p] = (u32)p;
+    resid[p] = c ? v : 0u;
+    flen[p] = 0;
+    owner[p] = NONE32;
+}
+__global__ void gather_kernel(const u32* __restrict__ idx, size_t m, const u32* __restrict__ src, u32* __restrict__ dst) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) dst[i] = src[idx[i]];
 }
 __global__ void seg_bounds_kernel(const u32* __restrict__ keys, size_t m, u32* __restrict__ segstart, u32* __restrict__ segend) {
     const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -53,117 +67,74 @@ __global__ void seg_bounds_kernel(const u32* __restrict__ keys, size_t m, u32* _
     if (j == 0 || keys[j - 1] != k) segstart[k] = (u32)j;
     if (j + 1 == m || keys[j + 1] != k) segend[k] = (u32)(j + 1);
 }
-__global__ void resid_init_kernel(const u32* __restrict__ plcp, size_t n, u32 threshold, u32* __restrict__ resid,
-                                  u32* __restrict__ flen, u32* __restrict__ owner) {
-    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
-    const u32 v = plcp[p];
-    resid[p] = (v >= threshold) ? v : 0u;
-    flen[p] = 0;
-    owner[p] = NONE32;
-}
 
 // ---- per level ---------------------------------------------------------------------------------------------
-__global__ void pool_flag_kernel(const u32* __restrict__ pool_t, size_t top, u32 L, u32* __restrict__ flag) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= top) return;
-    flag[i] = (pool_t[i] == L) ? 1u : 0u;
-}
-__global__ void pool_gather_kernel(const u32* __restrict__ pool_p, const u32* __restrict__ pool_t, const u32* __restrict__ offs,
-                                   size_t top, u32 L, u32* __restrict__ dst) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= top) return;
-    if (pool_t[i] == L) dst[offs[i]] = pool_p[i];
-}
-
-__global__ void level_init_kernel(const u32* __restrict__ orig, u32 m0, const u32* __restrict__ pushed, u32 m, u32 L,
-                                  u32 threshold, const u32* __restrict__ cur, u32* __restrict__ list, u32* __restrict__ lidx,
-                                  u32* __restrict__ vcur, u32* __restrict__ state, LevelScalars* __restrict__ sc) {
+// classify the entries of the level: live / stale / dead; publishes the per-position state for the window scans
+__global__ void classify_kernel(const u32* __restrict__ orig, u32 m0, const u32* __restrict__ pushed, u32 m, u32 L,
+                                u32 threshold, const u32* __restrict__ cur, u32* __restrict__ ent, u8* __restrict__ cls,
+                                u8* __restrict__ pst) {
     const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
-    bool live = false, alive = false;
-    if (k < m) {
-        const u32 p = (k < m0) ? orig[k] : pushed[k - m0];
-        const u32 v = cur[p];
-        list[k] = p;
-        lidx[p] = k;
-        vcur[k] = v;
-        live = (v == L);
-        alive = (v >= threshold);
-        state[k] = live ? 0u : 2u;
-    }
-    // only "any live / any alive" is needed: plain flag stores (all writers store the same value) instead of
-    // millions of same-address atomics
-    const u64 bl = __ballot(live), ba = __ballot(alive);
-    if (lane_id() == 0) {
-        if (bl) sc->live = 1u;
-        if (ba) sc->alive = 1u;
-    }
+    if (k >= m) return;
+    const u32 p = (k < m0) ? orig[k] : pushed[k - m0];
+    const u32 v = cur[p];
+    const u8 c = (v == L) ? CL_LIVE : (v >= threshold ? CL_STALE : CL_DEAD);
+    ent[k] = p;
+    cls[k] = c;
+    pst[p] = (c == CL_LIVE) ? ST_UNDECIDED : ST_NOTLIVE;
 }
 
-// One MIS round.  G lanes cooperate on one entry (G = 1 for short levels, 64 for long ones).
+// One selection round over the live entries.  G lanes cooperate on one entry (1 for short levels, 64 for long ones).
 template <int G>
-__global__ __launch_bounds__(256) void mis_round_kernel(const u32* __restrict__ list, u32 m, u32 L, size_t n,
-                                                         const u32* __restrict__ resid, const u32* __restrict__ lidx,
-                                                         u32* state, LevelScalars* __restrict__ sc) {
-    const u32 gid = (blockIdx.x * blockDim.x + threadIdx.x) / G;
+__global__ __launch_bounds__(256) void mis_round_kernel(const u32* __restrict__ live, u32 nl, u32 L, size_t n,
+                                                         const u32* __restrict__ resid, const u32* __restrict__ prio, u8* pst,
+                                                         LevelScalars* __restrict__ sc) {
+    const u32 i = (blockIdx.x * blockDim.x + threadIdx.x) / G;
     const u32 sub = (G == 1) ? 0u : (threadIdx.x & (G - 1));
-    const u32 k = gid;
-    bool active = (k < m);
-    if (active) active = (state[k] == 0u);
+    if (i >= nl) return;                                  // whole groups leave together
+    const u32 p = live[i];
+    if (pst[p] != ST_UNDECIDED) return;
+    const u32 pr = prio[p];
     bool hit = false, blocked = false;
-    if (G == 1) { if (!active) return; }
-    else { if (!__any(active)) return; }
-    if (active) {
-        const u32 p = list[k];
-        const size_t lo = (p >= L - 1) ? (size_t)p - (L - 1) : 0;
-        size_t hi = (size_t)p + (L - 1);
-        if (hi > n - 1) hi = n - 1;
-        for (size_t q = lo + sub; q <= hi; q += G) {
-            if (q == p) continue;
-            if (resid[q] != L) continue;
-            const u32 kq = lidx[q];
-            if (kq >= k) continue;
-            const u32 stq = state[kq];
-            if (stq == 1u) { hit = true; break; }
-            if (stq == 0u) blocked = true;
-        }
+    const size_t lo = (p >= L - 1) ? (size_t)p - (L - 1) : 0;
+    size_t hi = (size_t)p + (L - 1);
+    if (hi > n - 1) hi = n - 1;
+    for (size_t q = lo + sub; q <= hi; q += G) {
+        if (q == p || resid[q] != L) continue;
+        const u8 s = pst[q];
+        if (s == ST_SELECTED) { hit = true; break; }      // selected neighbours always have higher priority than an undecided entry
+        if (s == ST_UNDECIDED && prio[q] < pr) blocked = true;
     }
-    if (G > 1) {   // all 64 lanes of the wave work on the same entry
+    if (G > 1) {
         hit = __any(hit);
         blocked = __any(blocked);
         if (sub != 0) return;
     }
-    if (!active) return;
-    if (hit) state[k] = 2u;
-    else if (!blocked) state[k] = 1u;
+    if (hit) pst[p] = ST_REJECTED;
+    else if (!blocked) pst[p] = ST_SELECTED;
     else atomicAdd(&sc->undecided, 1u);
 }
 
-// Encounter value of every non-selected entry; pushtgt[k] = new list (0 = dropped / selected).
+// Encounter value of the non-selected entries (:85-89): key = (target << 32) | old priority, rc = 1 if pushed down.
 template <int G>
-__global__ __launch_bounds__(256) void resolve_kernel(const u32* __restrict__ list, u32 m, u32 L, u32 threshold, size_t n,
-                                                       const u32* __restrict__ resid, const u32* __restrict__ lidx,
-                                                       const u32* __restrict__ state, const u32* __restrict__ vcur,
-                                                       u32* __restrict__ pushtgt, u32* __restrict__ pushbin,
-                                                       LevelScalars* __restrict__ sc) {
-    const u32 k = (blockIdx.x * blockDim.x + threadIdx.x) / G;
+__global__ __launch_bounds__(256) void resolve_kernel(const u32* __restrict__ list, u32 cnt, bool live_list, u32 L, u32 threshold,
+                                                       size_t n, const u32* __restrict__ resid, const u32* __restrict__ prio,
+                                                       const u8* __restrict__ pst, const u32* __restrict__ cur,
+                                                       u64* __restrict__ rkey, u32* __restrict__ rval, u8* __restrict__ rc) {
+    const u32 i = (blockIdx.x * blockDim.x + threadIdx.x) / G;
     const u32 sub = (G == 1) ? 0u : (threadIdx.x & (G - 1));
-    if (k >= m) return;                       // G divides the wave: whole groups leave together
-    const u32 st = state[k];
-    u32 v = (st == 1u) ? 0u : vcur[k];
-    if (st != 1u && v >= threshold) {
-        const u32 p = list[k];
+    if (i >= cnt) return;
+    const u32 p = list[i];
+    const bool skip = live_list && pst[p] != ST_REJECTED;      // selected entries of the live list are not pushed
+    u32 v = skip ? 0u : cur[p];
+    const u32 pr = prio[p];
+    if (!skip) {
         const size_t lo = (p >= L - 1) ? (size_t)p - (L - 1) : 0;
         size_t hi = (size_t)p + (L - 1);
         if (hi > n - 1) hi = n - 1;
         for (size_t q = lo + sub; q <= hi; q += G) {
-            if (q == p) continue;
-            if (resid[q] != L) continue;
-            const u32 kq = lidx[q];
-            if (kq >= k) continue;
-            if (state[kq] != 1u) continue;
-            if (q < p) { v = 0; break; }       // covered by a factor starting to the left  (:99-101)
-            const u32 d = (u32)(q - p);         // truncated by a factor starting to the right (:103-109)
+            if (q == p || resid[q] != L || pst[q] != ST_SELECTED || prio[q] >= pr) continue;
+            if (q < p) { v = 0; break; }             // covered by a factor starting to the left   (:99-101)
+            const u32 d = (u32)(q - p);               // truncated by a factor starting to the right (:103-109)
             if (d < v) v = d;
         }
     }
@@ -171,62 +142,61 @@ __global__ __launch_bounds__(256) void resolve_kernel(const u32* __restrict__ li
         v = wave_reduce_min(v);
         if (sub != 0) return;
     }
-    const bool push = (st != 1u) && (v >= threshold);
-    pushtgt[k] = push ? v : 0u;
-    pushbin[k] = push ? 1u : 0u;
-    if (G > 1) { if (st == 1u) atomicAdd(&sc->selected, 1u); }
-    else {
-        const u64 bs = __ballot(st == 1u);
-        if (bs && (u64)lane_id() == (u64)__builtin_ctzll(bs)) atomicAdd(&sc->selected, (u32)__popcll(bs));
-    }
+    const bool push = v >= threshold;
+    rc[i] = push ? 1 : 0;
+    rkey[i] = ((u64)v << 32) | pr;
+    rval[i] = p;
 }
 
-// pushcnt[v] counts the pool entries per target level.  Targets cluster on a few small levels, so the counts are
-// first accumulated in an LDS histogram (targets < 1024) and flushed with one global atomic per non-empty bin.
-__global__ __launch_bounds__(256) void push_kernel(const u32* __restrict__ list, u32 m, const u32* __restrict__ pushtgt,
-                                                    const u32* __restrict__ poffs, u32 pool_top, u32* __restrict__ pool_p,
-                                                    u32* __restrict__ pool_t, u32* __restrict__ resid, u32* __restrict__ pushcnt) {
-    __shared__ u32 h[1024];
-    for (int i = threadIdx.x; i < 1024; i += 256) h[i] = 0;
-    __syncthreads();
-    const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < m) {
-        const u32 v = pushtgt[k];
-        if (v) {
-            const u32 p = list[k];
-            const u32 idx = pool_top + poffs[k];
-            pool_p[idx] = p;
-            pool_t[idx] = v;
-            resid[p] = v;
-            if (v < 1024) atomicAdd(&h[v], 1u); else atomicAdd(&pushcnt[v], 1u);
-        }
+// The level's pushes, sorted by (target, old priority): new residence, new priority, pool slot, segment starts.
+__global__ void push_finalize_kernel(const u64* __restrict__ keys, const u32* __restrict__ vals, u32 npush, u32 prio_base,
+                                     u32* __restrict__ resid, u32* __restrict__ prio, u32* __restrict__ pool,
+                                     PushSeg* __restrict__ segs, u32 seg_cap, LevelScalars* __restrict__ sc) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npush) return;
+    const u32 tgt = (u32)(keys[i] >> 32);
+    const u32 p = vals[i];
+    resid[p] = tgt;
+    prio[p] = prio_base + i;
+    pool[i] = p;
+    if (i == 0 || (u32)(keys[i - 1] >> 32) != tgt) {
+        const u32 j = atomicAdd(&sc->nseg, 1u);
+        if (j < seg_cap) segs[j] = PushSeg{tgt, i};
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 1024; i += 256) if (h[i]) atomicAdd(&pushcnt[i], h[i]);
 }
 
 // Emit the selected entries: factor (p, Phi[p], L); kill the covered positions, truncate the ones in front.
 template <int G>
-__global__ __launch_bounds__(256) void apply_kernel(const u32* __restrict__ list, u32 m, u32 L, size_t n, const u32* __restrict__ state,
+__global__ __launch_bounds__(256) void apply_kernel(const u32* __restrict__ live, u32 nl, u32 L, size_t n, const u8* __restrict__ pst,
                                                      const u32* __restrict__ phi, u32* __restrict__ cur, u32* __restrict__ flen,
-                                                     u32* __restrict__ owner, u32* __restrict__ fsrc) {
-    const u32 k = (blockIdx.x * blockDim.x + threadIdx.x) / G;
+                                                     u32* __restrict__ owner, u32* __restrict__ fsrc, LevelScalars* __restrict__ sc) {
+    const u32 i = (blockIdx.x * blockDim.x + threadIdx.x) / G;
     const u32 sub = (G == 1) ? 0u : (threadIdx.x & (G - 1));
-    if (k >= m) return;
-    if (state[k] != 1u) return;
-    const u32 p = list[k];
-    if (sub == 0) { flen[p] = L; fsrc[p] = phi[p]; }
-    for (u32 j = sub; j < L && (size_t)p + j < n; j += G) {   // :99-101
-        cur[p + j] = 0;
-        owner[p + j] = p;
+    bool sel = false;
+    u32 p = 0;
+    if (i < nl) { p = live[i]; sel = (pst[p] == ST_SELECTED); }
+    if (sel) {
+        if (sub == 0) { flen[p] = L; fsrc[p] = phi[p]; }
+        for (u32 j = sub; j < L && (size_t)p + j < n; j += G) {   // :99-101
+            cur[p + j] = 0;
+            owner[p + j] = p;
+        }
+        const u32 aff = (L < p) ? L : p;                           // :103
+        for (u32 j = sub; j < aff; j += G) atomicMin(&cur[p - 1 - j], j + 1);   // :105-109
     }
-    const u32 aff = (L < p) ? L : p;                     // :103
-    for (u32 j = sub; j < aff; j += G) atomicMin(&cur[p - 1 - j], j + 1);   // :105-109
+    // factor count: one atomic per workgroup
+    __shared__ u32 cnt;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    const u64 b = __ballot(sel && sub == 0);
+    if (lane_id() == 0 && b) atomicAdd(&cnt, (u32)__popcll(b));
+    __syncthreads();
+    if (threadIdx.x == 0 && cnt) atomicAdd(&sc->selected, cnt);
 }
 
-void factorize_arrays(Ctx& c, size_t n, const u32* sa, const u32* isa, const u32* phi, u32* plcp, u32 maxlcp, u32 threshold,
+void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi, u32* plcp, u32 maxlcp, u32 threshold,
                       FactorSpace fs, FactorizeStats* st) {
-    (void)isa;   // priorities are implicit in the candidate order (ascending SA index), the ISA itself is not needed
+    (void)sa;    // the candidate order of the reference (ascending SA index) is carried by prio[] = ISA
     FactorizeStats local;
     if (!st) st = &local;
     *st = FactorizeStats();
@@ -236,144 +206,162 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, const u32* isa, const u32
     const size_t mark = c.arena.mark();
     const unsigned gn = cdiv(n, 256);
     u32* cur = plcp;
+    u32* prio = isa;
 
+    // ---- candidates: positions with PLCP >= threshold, in position order, stably sorted by PLCP value -----------
     u32* resid = c.arena.get<u32>(n);
-    resid_init_kernel<<<gn, 256, 0, s>>>(plcp, n, threshold, resid, fs.flen, fs.owner);
-    LAUNCH_CHECK();
-    if ((u64)maxlcp + 1 <= threshold || threshold == 0) { c.arena.release(mark); return; }   // ArraysComp.hpp:50
-
-    // ---- "Fill candidates" (:54-66): positions with LCP >= threshold in SA order, stably sorted by LCP value
-    u32* tmpA = c.arena.get<u32>(n);      // flags / offsets, later per-level temporaries
-    u32* tmpB = c.arena.get<u32>(n);
+    u8* cls = c.arena.get<u8>(n);
     u32* ckeys[2] = { c.arena.get<u32>(n), c.arena.get<u32>(n) };
     u32* cvals[2] = { c.arena.get<u32>(n), c.arena.get<u32>(n) };
-    u32* d_total = c.arena.get<u32>(1);
+    u32* d_cnt = c.arena.get<u32>(4);
+    u32* iota = ckeys[1];                       // scratch: position of every text position
     {
-        Ctx::ProfScope prof(c, K_CAND, (u64)n * 12);
-        cand_flag_kernel<<<gn, 256, 0, s>>>(sa, plcp, n, threshold, tmpA);
+        Ctx::ProfScope prof(c, K_CAND, (u64)n * 21);
+        cand_class_kernel<<<gn, 256, 0, s>>>(plcp, n, threshold, cls, iota, resid, fs.flen, fs.owner);
         LAUNCH_CHECK();
     }
-    exclusive_sum_u32(c, tmpA, tmpA, n, d_total);
-    {
-        Ctx::ProfScope prof(c, K_CAND, (u64)n * 20);
-        cand_scatter_kernel<<<gn, 256, 0, s>>>(sa, plcp, tmpA, n, threshold, ckeys[0], cvals[0]);
-        LAUNCH_CHECK();
-    }
-    const size_t entries = c.read(d_total);
+    if ((u64)maxlcp + 1 <= threshold || threshold == 0) { c.arena.release(mark); return; }   // ArraysComp.hpp:50
+    select_by_class(c, cls, 1, n, iota, cvals[0], nullptr, nullptr, d_cnt);
+    const size_t entries = c.read(d_cnt);
     st->entries = entries;
+    if (entries) {
+        Ctx::ProfScope prof(c, K_CAND, (u64)entries * 12);
+        gather_kernel<<<cdiv(entries, 256), 256, 0, s>>>(cvals[0], entries, plcp, ckeys[0]);
+        LAUNCH_CHECK();
+    }
     const int x = radix_sort_pairs_u32(c, ckeys, cvals, entries, 0, (int)bits_for(maxlcp));
     const u32* cand = cvals[x];
     const size_t nlev = (size_t)maxlcp + 2;
     u32* d_segstart = c.arena.get<u32>(nlev);
     u32* d_segend = c.arena.get<u32>(nlev);
-    u32* pushcnt = c.arena.get<u32>(nlev);
     HIP_TRY(hipMemsetAsync(d_segstart, 0, nlev * sizeof(u32), s));
     HIP_TRY(hipMemsetAsync(d_segend, 0, nlev * sizeof(u32), s));
-    HIP_TRY(hipMemsetAsync(pushcnt, 0, nlev * sizeof(u32), s));
     if (entries) {
         seg_bounds_kernel<<<cdiv(entries, 256), 256, 0, s>>>(ckeys[x], entries, d_segstart, d_segend);
         LAUNCH_CHECK();
     }
-    u32* h_segstart = (u32*)malloc(nlev * sizeof(u32));
-    u32* h_segend = (u32*)malloc(nlev * sizeof(u32));
-    if (!h_segstart || !h_segend) { free(h_segstart); free(h_segend); throw HipError{hipErrorOutOfMemory, "host", (int)__LINE__}; }
-    try {
-        c.read_n(d_segstart, h_segstart, nlev);
-        c.read_n(d_segend, h_segend, nlev);
+    std::vector<u32> h_segstart(nlev), h_segend(nlev);
+    c.read_n(d_segstart, h_segstart.data(), nlev);
+    c.read_n(d_segend, h_segend.data(), nlev);
 
-        // ---- per-level state -------------------------------------------------------------------------
-        u32* lidx = c.arena.get<u32>(n);
-        u32* pool_p = c.arena.get<u32>(n);
-        u32* pool_t = c.arena.get<u32>(n);
-        u32* list = ckeys[x ^ 1];           // the sort's scratch buffers are free now
-        u32* vcur = cvals[x ^ 1];
-        u32* state = ckeys[x];              // keys of the sorted candidates are no longer needed either
-        u32* pushed = c.arena.get<u32>(n);
-        u32* pushtgt = tmpA;
-        u32* pushbin = tmpB;
-        LevelScalars* d_sc = (LevelScalars*)c.arena.alloc(sizeof(LevelScalars));
-        LevelScalars h_sc;
-        size_t pool_top = 0;
+    // ---- per-level state ------------------------------------------------------------------------------------
+    u32* ent = cvals[x ^ 1];                    // the candidate sort's scratch buffers are free now
+    u32* live = ckeys[0];
+    u32* stale = ckeys[1];
+    u8* pst = c.arena.get<u8>(n);
+    u8* rc = c.arena.get<u8>(n);
+    u32* pool = c.arena.get<u32>(n);            // pushed entries, grouped by (source level, target)
+    u32* pushed = c.arena.get<u32>(n);
+    u64* rkey = c.arena.get<u64>(n);
+    u32* rval = c.arena.get<u32>(n);
+    u64* skeys[2] = { c.arena.get<u64>(n), c.arena.get<u64>(n) };
+    u32* svals[2] = { c.arena.get<u32>(n), c.arena.get<u32>(n) };
+    LevelScalars* d_sc = (LevelScalars*)c.arena.alloc(sizeof(LevelScalars));
+    const u32 seg_cap = 1u << 16;
+    PushSeg* d_segs = (PushSeg*)c.arena.alloc(sizeof(PushSeg) * seg_cap);
+    std::vector<PushSeg> h_segs(seg_cap);
+    LevelScalars h_sc;
 
-        for (u32 L = maxlcp; L >= threshold; --L) {
-            const u32 m0 = h_segend[L] - h_segstart[L];
-            u32 m1 = 0;
-            if (pool_top > 0) m1 = c.read(&pushcnt[L]);
-            const u32 m = m0 + m1;
-            if (m == 0) continue;
-            st->levels++;
-            if (m1) {     // pushed part of the list: pool entries with target L, in pool (= encounter) order
-                const unsigned gp = cdiv(pool_top, 256);
-                Ctx::ProfScope prof(c, K_POOL, (u64)pool_top * 16 + (u64)m1 * 8);
-                pool_flag_kernel<<<gp, 256, 0, s>>>(pool_t, pool_top, L, pushbin);
-                LAUNCH_CHECK();
-                exclusive_sum_u32(c, pushbin, pushbin, pool_top, nullptr);
-                pool_gather_kernel<<<gp, 256, 0, s>>>(pool_p, pool_t, pushbin, pool_top, L, pushed);
-                LAUNCH_CHECK();
-            }
-            HIP_TRY(hipMemsetAsync(d_sc, 0, sizeof(LevelScalars), s));
-            const unsigned gm = cdiv(m, 256);
-            {   // per entry: list source (4) + cur gather (4) + list/vcur/state (12) + lidx scatter (4)
-                Ctx::ProfScope prof(c, K_LEVEL_INIT, (u64)m * 24);
-                level_init_kernel<<<gm, 256, 0, s>>>(cand + h_segstart[L], m0, pushed, m, L, threshold, cur, list, lidx, vcur, state, d_sc);
-                LAUNCH_CHECK();
-            }
-            h_sc = c.read(d_sc);
-            if (h_sc.alive == 0) continue;          // every entry already erased (:86)
-            const bool wide = (L > 24);
-            const unsigned gw = wide ? cdiv((size_t)m * 64, 256) : gm;
-            if (h_sc.live) {
-                u32 undecided = m;
-                while (undecided) {
-                    HIP_TRY(hipMemsetAsync(&d_sc->undecided, 0, sizeof(u32), s));
-                    {   // per undecided entry: list + state (8) + a window of 2L-1 resid words
-                        Ctx::ProfScope prof(c, K_MIS_ROUND, (u64)m * 4 + (u64)undecided * (4 + 4ull * (2 * L - 1)));
-                        if (wide) mis_round_kernel<64><<<gw, 256, 0, s>>>(list, m, L, n, resid, lidx, state, d_sc);
-                        else      mis_round_kernel<1><<<gw, 256, 0, s>>>(list, m, L, n, resid, lidx, state, d_sc);
-                        LAUNCH_CHECK();
-                    }
-                    const u32 now = c.read(&d_sc->undecided);
-                    st->rounds++;
-                    if (now >= undecided && now != 0) {
-                        // the earliest undecided entry can always decide: no progress means a bug
-                        throw HipError{hipErrorUnknown, "factorize: MIS rounds made no progress", (int)__LINE__};
-                    }
-                    undecided = now;
+    struct PoolSeg { u32 off, cnt; };
+    std::vector<std::vector<PoolSeg>> pushed_into(nlev);     // per target level: its segments of the pool
+    size_t pool_top = 0;
+    u32 prio_base = (u32)n;
+
+    for (u32 L = maxlcp; L >= threshold; --L) {
+        const u32 m0 = h_segend[L] - h_segstart[L];
+        u32 m1 = 0;
+        for (const PoolSeg& sg : pushed_into[L]) {            // gather the pushed part of the list
+            HIP_TRY(hipMemcpyAsync(pushed + m1, pool + sg.off, (size_t)sg.cnt * sizeof(u32), hipMemcpyDeviceToDevice, s));
+            m1 += sg.cnt;
+        }
+        std::vector<PoolSeg>().swap(pushed_into[L]);
+        const u32 m = m0 + m1;
+        if (m == 0) continue;
+        st->levels++;
+        HIP_TRY(hipMemsetAsync(d_sc, 0, sizeof(LevelScalars), s));
+        const unsigned gm = cdiv(m, 256);
+        {   // per entry: list (4) + cur (4) + ent (4) + class and state bytes (2)
+            Ctx::ProfScope prof(c, K_LEVEL_INIT, (u64)m * 14);
+            classify_kernel<<<gm, 256, 0, s>>>(cand + h_segstart[L], m0, pushed, m, L, threshold, cur, ent, cls, pst);
+            LAUNCH_CHECK();
+        }
+        select_by_class(c, cls, CL_LIVE, m, ent, live, nullptr, nullptr, &d_sc->nlive);
+        select_by_class(c, cls, CL_STALE, m, ent, stale, nullptr, nullptr, &d_sc->nstale);
+        h_sc = c.read(d_sc);
+        const u32 nl = h_sc.nlive, ns = h_sc.nstale;
+        if (nl == 0 && ns == 0) continue;                     // every entry already erased (:86)
+        const bool wide = (L > 24);
+        const unsigned gl = wide ? cdiv((size_t)nl * 64, 256) : cdiv(nl, 256);
+        const unsigned gs = wide ? cdiv((size_t)ns * 64, 256) : cdiv(ns, 256);
+        if (nl) {
+            u32 undecided = nl;
+            while (undecided) {
+                HIP_TRY(hipMemsetAsync(&d_sc->undecided, 0, sizeof(u32), s));
+                {   // per undecided entry: list + prio + state (9) + a window of 2L-1 resid words and state bytes
+                    Ctx::ProfScope prof(c, K_MIS_ROUND, (u64)nl * 5 + (u64)undecided * (8 + 5ull * (2 * L - 1)));
+                    if (wide) mis_round_kernel<64><<<gl, 256, 0, s>>>(live, nl, L, n, resid, prio, pst, d_sc);
+                    else      mis_round_kernel<1><<<gl, 256, 0, s>>>(live, nl, L, n, resid, prio, pst, d_sc);
+                    LAUNCH_CHECK();
                 }
+                const u32 now = c.read(&d_sc->undecided);
+                st->rounds++;
+                // the undecided entry of highest priority can always decide: no progress means a bug
+                if (now >= undecided) throw HipError{hipErrorUnknown, "factorize: selection rounds made no progress", (int)__LINE__};
+                undecided = now;
             }
-            {   // per entry: state + vcur + list (12), outputs (8), and for live-or-stale entries the resid window
-                Ctx::ProfScope prof(c, K_RESOLVE, (u64)m * (20 + 4ull * (2 * L - 1)));
-                if (wide) resolve_kernel<64><<<gw, 256, 0, s>>>(list, m, L, threshold, n, resid, lidx, state, vcur, pushtgt, pushbin, d_sc);
-                else      resolve_kernel<1><<<gw, 256, 0, s>>>(list, m, L, threshold, n, resid, lidx, state, vcur, pushtgt, pushbin, d_sc);
+        }
+        {   // per entry: list, cur, prio (12) + window (5 B per position) + outputs (13)
+            Ctx::ProfScope prof(c, K_RESOLVE, (u64)(ns + nl) * (25 + 5ull * (2 * L - 1)));
+            if (ns) {
+                if (wide) resolve_kernel<64><<<gs, 256, 0, s>>>(stale, ns, false, L, threshold, n, resid, prio, pst, cur, rkey, rval, rc);
+                else      resolve_kernel<1><<<gs, 256, 0, s>>>(stale, ns, false, L, threshold, n, resid, prio, pst, cur, rkey, rval, rc);
                 LAUNCH_CHECK();
             }
-            exclusive_sum_u32(c, pushbin, pushbin, m, &d_sc->npush);
-            h_sc = c.read(d_sc);
+            if (nl) {
+                if (wide) resolve_kernel<64><<<gl, 256, 0, s>>>(live, nl, true, L, threshold, n, resid, prio, pst, cur, rkey + ns, rval + ns, rc + ns);
+                else      resolve_kernel<1><<<gl, 256, 0, s>>>(live, nl, true, L, threshold, n, resid, prio, pst, cur, rkey + ns, rval + ns, rc + ns);
+                LAUNCH_CHECK();
+            }
+        }
+        select_by_class(c, rc, 1, (size_t)ns + nl, rval, svals[0], rkey, skeys[0], &d_sc->npush);
+        if (nl) {
+            // per entry: list + state (5); per factor: Phi, flen, fsrc (12) + L kills (8 B each) + L truncations (4 B each)
+            Ctx::ProfScope prof(c, K_APPLY, (u64)nl * 5 + (u64)nl * (12 + 12ull * L));
+            if (wide) apply_kernel<64><<<gl, 256, 0, s>>>(live, nl, L, n, pst, phi, cur, fs.flen, fs.owner, fs.fsrc, d_sc);
+            else      apply_kernel<1><<<gl, 256, 0, s>>>(live, nl, L, n, pst, phi, cur, fs.flen, fs.owner, fs.fsrc, d_sc);
+            LAUNCH_CHECK();
+        }
+        h_sc = c.read(d_sc);
+        st->factors += h_sc.selected;
+        const u32 npush = h_sc.npush;
+        if (npush) {
             // every push is caused by a truncation of a position in front of a factor, and factors are disjoint,
             // so the pool never needs more than n slots; checked before anything is written
-            if (pool_top + h_sc.npush > n) throw HipError{hipErrorUnknown, "factorize: push pool overflow", (int)__LINE__};
-            if (h_sc.npush) {
-                Ctx::ProfScope prof(c, K_PUSH, (u64)m * 8 + (u64)h_sc.npush * 16);
-                push_kernel<<<gm, 256, 0, s>>>(list, m, pushtgt, pushbin, (u32)pool_top, pool_p, pool_t, resid, pushcnt);
+            if (pool_top + npush > n || (u64)prio_base + npush > 0xFFFFFFFFull)
+                throw HipError{hipErrorUnknown, "factorize: push pool overflow", (int)__LINE__};
+            const int y = radix_sort_pairs_u64(c, skeys, svals, npush, 0, 32 + (int)bits_for(L));
+            {
+                Ctx::ProfScope prof(c, K_PUSH, (u64)npush * 24);
+                push_finalize_kernel<<<cdiv(npush, 256), 256, 0, s>>>(skeys[y], svals[y], npush, prio_base, resid, prio,
+                                                                      pool + pool_top, d_segs, seg_cap, d_sc);
                 LAUNCH_CHECK();
             }
-            if (h_sc.selected) {
-                // per entry: state + list (8); per factor: Phi, flen, fsrc (12) + L kills (8 B each) + L truncations (4 B each)
-                Ctx::ProfScope prof(c, K_APPLY, (u64)m * 8 + (u64)h_sc.selected * (12 + 12ull * L));
-                if (wide) apply_kernel<64><<<gw, 256, 0, s>>>(list, m, L, n, state, phi, cur, fs.flen, fs.owner, fs.fsrc);
-                else      apply_kernel<1><<<gw, 256, 0, s>>>(list, m, L, n, state, phi, cur, fs.flen, fs.owner, fs.fsrc);
-                LAUNCH_CHECK();
+            const u32 nseg = c.read(&d_sc->nseg);
+            if (nseg > seg_cap) throw HipError{hipErrorUnknown, "factorize: too many push targets in one level", (int)__LINE__};
+            c.read_n(d_segs, h_segs.data(), nseg);
+            std::sort(h_segs.begin(), h_segs.begin() + nseg, [](const PushSeg& a, const PushSeg& b) { return a.start < b.start; });
+            for (u32 j = 0; j < nseg; ++j) {
+                const u32 end = (j + 1 < nseg) ? h_segs[j + 1].start : npush;
+                const u32 tgt = h_segs[j].target;
+                if (tgt >= L || tgt < threshold) throw HipError{hipErrorUnknown, "factorize: bad push target", (int)__LINE__};
+                pushed_into[tgt].push_back(PoolSeg{(u32)pool_top + h_segs[j].start, end - h_segs[j].start});
             }
-            pool_top += h_sc.npush;
-            st->factors += h_sc.selected;
-            st->pushes += h_sc.npush;
-            if (L == 0) break;
+            pool_top += npush;
+            prio_base += npush;
+            st->pushes += npush;
         }
-    } catch (...) {
-        free(h_segstart); free(h_segend);
-        throw;
+        if (L == 0) break;
     }
-    free(h_segstart); free(h_segend);
     c.arena.release(mark);
 }
 

@@ -161,6 +161,68 @@ void exclusive_sum_u64(Ctx& c, const u64* in, u64* out, size_t n, u64* d_total) 
 void inclusive_max_u32(Ctx& c, const u32* in, u32* out, size_t n) { scan_impl<u32, 1, true>(c, in, out, n, nullptr); }
 
 // ------------------------------------------------------------------------------------------------
+// selection (stream compaction by a class byte)
+// ------------------------------------------------------------------------------------------------
+constexpr int SEL_PER_THREAD = 8;
+constexpr int SEL_TILE = 256 * SEL_PER_THREAD;
+
+__device__ __forceinline__ u32 sel_load_mask(const u8* __restrict__ cls, u8 want, size_t k0, size_t m) {
+    u32 mask = 0;
+    if (k0 + SEL_PER_THREAD <= m) {
+        const u64 w = *(const u64*)__builtin_assume_aligned(cls + k0, 8);
+#pragma unroll
+        for (int j = 0; j < SEL_PER_THREAD; ++j) mask |= (((u8)(w >> (8 * j)) == want) ? 1u : 0u) << j;
+    } else {
+        for (int j = 0; j < SEL_PER_THREAD; ++j) if (k0 + j < m && cls[k0 + j] == want) mask |= 1u << j;
+    }
+    return mask;
+}
+
+__global__ __launch_bounds__(256) void sel_count_kernel(const u8* __restrict__ cls, u8 want, size_t m, u32* __restrict__ tilecnt) {
+    __shared__ u32 sm[4];
+    const size_t k0 = (size_t)blockIdx.x * SEL_TILE + (size_t)threadIdx.x * SEL_PER_THREAD;
+    u32 cnt = (k0 < m) ? (u32)__popc(sel_load_mask(cls, want, k0, m)) : 0u;
+    cnt = wave_reduce_sum(cnt);
+    if (lane_id() == 0) sm[wave_id()] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) tilecnt[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+__global__ __launch_bounds__(256) void sel_scatter_kernel(const u8* __restrict__ cls, u8 want, size_t m,
+                                                           const u32* __restrict__ tileoff, const u32* __restrict__ srcA,
+                                                           u32* __restrict__ outA, const u64* __restrict__ srcB,
+                                                           u64* __restrict__ outB) {
+    __shared__ u32 sm[5];
+    const size_t k0 = (size_t)blockIdx.x * SEL_TILE + (size_t)threadIdx.x * SEL_PER_THREAD;
+    const u32 mask = (k0 < m) ? sel_load_mask(cls, want, k0, m) : 0u;
+    u32 total;
+    u32 o = tileoff[blockIdx.x] + block_exclusive_sum<u32, 4>((u32)__popc(mask), sm, total);
+    if (!mask) return;
+#pragma unroll
+    for (int j = 0; j < SEL_PER_THREAD; ++j) {
+        if (mask & (1u << j)) {
+            outA[o] = srcA[k0 + j];
+            if (srcB) outB[o] = srcB[k0 + j];
+            ++o;
+        }
+    }
+}
+
+void select_by_class(Ctx& c, const u8* cls, u8 want, size_t m, const u32* srcA, u32* outA, const u64* srcB, u64* outB,
+                     u32* d_count) {
+    if (m == 0) { HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(u32), c.stream)); return; }
+    const size_t mark = c.arena.mark();
+    const unsigned tiles = cdiv(m, SEL_TILE);
+    u32* tilecnt = c.arena.get<u32>(tiles);
+    sel_count_kernel<<<tiles, 256, 0, c.stream>>>(cls, want, m, tilecnt);
+    LAUNCH_CHECK();
+    exclusive_sum_u32(c, tilecnt, tilecnt, tiles, d_count);
+    sel_scatter_kernel<<<tiles, 256, 0, c.stream>>>(cls, want, m, tilecnt, srcA, outA, srcB, outB);
+    LAUNCH_CHECK();
+    c.arena.release(mark);
+}
+
+// ------------------------------------------------------------------------------------------------
 // fills
 // ------------------------------------------------------------------------------------------------
 __global__ void fill_u32_kernel(u32* p, size_t n, u32 v) {

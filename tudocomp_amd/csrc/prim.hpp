@@ -17,6 +17,11 @@ void inclusive_max_u32(Ctx& c, const u32* in, u32* out, size_t n);
 int radix_sort_pairs_u64(Ctx& c, u64* keys[2], u32* vals[2], size_t n, int begin_bit, int end_bit);
 int radix_sort_pairs_u32(Ctx& c, u32* keys[2], u32* vals[2], size_t n, int begin_bit, int end_bit);
 
+// Order-preserving selection: for the k (ascending) with cls[k] == want, outA[j] = srcA[k] (and outB[j] = srcB[k] if
+// srcB != nullptr); *d_count (device) receives the number of selected elements.
+void select_by_class(Ctx& c, const u8* cls, u8 want, size_t m, const u32* srcA, u32* outA, const u64* srcB, u64* outB,
+                     u32* d_count);
+
 // fill / iota helpers
 void fill_u32(Ctx& c, u32* p, size_t n, u32 v);
 void fill_u8(Ctx& c, u8* p, size_t n, u8 v);

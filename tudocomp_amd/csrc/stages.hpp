@@ -33,9 +33,9 @@ struct FactorSpace {
 struct FactorizeStats { u64 factors = 0; u32 maxlcp = 0; u32 levels = 0; u32 rounds = 0; u64 pushes = 0; u64 entries = 0; };
 
 // a8: compressors/lcpcomp/compress/ArraysComp.hpp:36-117 in position space.
-// Inputs: sa, isa, phi, plcp (plcp is consumed: it becomes the working copy of the LCP values).
+// Inputs: isa, phi, plcp.  isa and plcp are consumed: they become the working priority / LCP arrays.
 // Outputs: fs.flen / fs.owner filled, fs.fsrc[p] = phi[p] at factor starts.
-void factorize_arrays(Ctx& c, size_t n, const u32* sa, const u32* isa, const u32* phi, u32* plcp, u32 maxlcp,
+void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi, u32* plcp, u32 maxlcp,
                       u32 threshold, FactorSpace fs, FactorizeStats* st);
 
 struct FlattenStats { u64 num_flattened = 0; u64 max_depth_lb = 0; u32 rounds = 0; };
