@@ -182,7 +182,10 @@ __global__ __launch_bounds__(256) void apply_kernel(const u32* __restrict__ live
             owner[p + j] = p;
         }
         const u32 aff = (L < p) ? L : p;                           // :103
-        for (u32 j = sub; j < aff; j += G) atomicMin(&cur[p - 1 - j], j + 1);   // :105-109
+        for (u32 j = sub; j < aff; j += G) {                         // :105-109
+            u32* q = &cur[p - 1 - j];
+            if (*q > j + 1) atomicMin(q, j + 1);                     // values only ever decrease: a stale read can only cause a redundant atomic
+        }
     }
     // factor count: one atomic per workgroup
     __shared__ u32 cnt;

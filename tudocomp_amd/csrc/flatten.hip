@@ -96,13 +96,15 @@ __global__ void flatten_init_kernel(const u32* __restrict__ fpos, size_t z, cons
     depth[i] = 0;
 }
 
-__global__ void flatten_round_kernel(const u32* __restrict__ fpos, size_t z, size_t n, const u32* __restrict__ flen,
-                                     const u32* __restrict__ owner, const u32* __restrict__ orig, u32* ffinal,
-                                     u32* __restrict__ cursrc, u32* __restrict__ depth, FlattenScalars* __restrict__ sc) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= z) return;
+// One round over the still-waiting factors (work[] holds their indices into fpos[]; wcls[j] = 1 if still waiting).
+__global__ void flatten_round_kernel(const u32* __restrict__ work, u32 nwork, const u32* __restrict__ fpos, size_t n,
+                                     const u32* __restrict__ flen, const u32* __restrict__ owner, const u32* __restrict__ orig,
+                                     u32* ffinal, u32* __restrict__ cursrc, u32* __restrict__ depth, u8* __restrict__ wcls,
+                                     FlattenScalars* __restrict__ sc) {
+    const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nwork) return;
+    const u32 i = work ? work[j] : j;
     const u32 p = fpos[i];
-    if (ffinal[p] != NOT_DONE) return;
     const u32 len = flen[p];
     u32 src = cursrc[i];
     u32 dep = depth[i];
@@ -125,12 +127,16 @@ __global__ void flatten_round_kernel(const u32* __restrict__ fpos, size_t z, siz
     }
     cursrc[i] = src;
     depth[i] = dep;
+    wcls[j] = finished ? 0 : 1;
     if (finished) {
         ffinal[p] = dep ? src : orig[p];                                // :122-124
         if (dep) { atomicAdd(&sc->num_flattened, 1u); atomicMax(&sc->max_depth, dep); }
-    } else {
-        atomicAdd(&sc->waiting, 1u);
     }
+}
+
+__global__ void flatten_iota_kernel(u32* __restrict__ a, u32 m) {
+    const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < m) a[j] = j;
 }
 
 __global__ void flatten_commit_kernel(const u32* __restrict__ fpos, size_t z, const u32* __restrict__ ffinal, u32* __restrict__ fsrc) {
@@ -158,18 +164,28 @@ void flatten_factors(Ctx& c, size_t n, FactorSpace fs, FlattenStats* st) {
     const unsigned gz = cdiv(z, 256);
     flatten_init_kernel<<<gz, 256, 0, s>>>(fpos, z, fs.fsrc, ffinal, cursrc, depth);
     LAUNCH_CHECK();
+    // work lists of the still-waiting factors, compacted after every round
+    u32* work[2] = { c.arena.get<u32>(z), c.arena.get<u32>(z) };
+    u8* wcls = c.arena.get<u8>(z);
+    u32* ident = c.arena.get<u32>(z);
+    flatten_iota_kernel<<<gz, 256, 0, s>>>(ident, (u32)z);
+    LAUNCH_CHECK();
     u32 waiting = (u32)z;
+    int cur_w = -1;                               // -1: the identity list (first round)
     while (waiting) {
-        HIP_TRY(hipMemsetAsync(&d_sc->waiting, 0, sizeof(u32), s));
-        {   // per waiting factor: fpos, ffinal, flen, cursrc, depth (20) + one chain step (owner, flen, src: 12)
-            Ctx::ProfScope prof(c, K_FLATTEN_ROUND, (u64)z * 8 + (u64)waiting * 32);
-            flatten_round_kernel<<<gz, 256, 0, s>>>(fpos, z, n, fs.flen, fs.owner, fs.fsrc, ffinal, cursrc, depth, d_sc);
+        {   // per waiting factor: fpos, flen, cursrc, depth (16) + one chain step (owner, flen, src: 12) + outputs (13)
+            Ctx::ProfScope prof(c, K_FLATTEN_ROUND, (u64)waiting * 41);
+            flatten_round_kernel<<<cdiv(waiting, 256), 256, 0, s>>>(cur_w < 0 ? nullptr : work[cur_w], waiting, fpos, n, fs.flen,
+                                                                    fs.owner, fs.fsrc, ffinal, cursrc, depth, wcls, d_sc);
             LAUNCH_CHECK();
         }
+        const int nxt = cur_w < 0 ? 0 : (cur_w ^ 1);
+        select_by_class(c, wcls, 1, waiting, cur_w < 0 ? ident : work[cur_w], work[nxt], nullptr, nullptr, &d_sc->waiting);
         const u32 now = c.read(&d_sc->waiting);
         st->rounds++;
         if (now >= waiting) throw HipError{hipErrorUnknown, "flatten: rounds made no progress", (int)__LINE__};
         waiting = now;
+        cur_w = nxt;
     }
     flatten_commit_kernel<<<gz, 256, 0, s>>>(fpos, z, ffinal, fs.fsrc);
     LAUNCH_CHECK();
