@@ -27,6 +27,14 @@ int guarded(tdc_gpu_ctx* ctx, F&& f) {
     try {
         HIP_TRY(hipSetDevice(ctx->c.device));
         f();
+        if (ctx->c.d_err) {                      // device-side error word (e.g. a look-back that timed out)
+            u32 e = 0;
+            HIP_TRY(hipMemcpy(&e, ctx->c.d_err, sizeof(u32), hipMemcpyDeviceToHost));
+            if (e) {
+                HIP_TRY(hipMemset(ctx->c.d_err, 0, sizeof(u32)));
+                throw HipError{hipErrorUnknown, "device-side error flag set (radix look-back timeout)", (int)e};
+            }
+        }
         return TDC_GPU_OK;
     } catch (const HipError& e) {
         char buf[512];
@@ -227,6 +235,9 @@ int tdc_gpu_ctx_create(int device, tdc_gpu_ctx** out) {
         for (auto& e : ctx->c.ev) HIP_TRY(hipEventCreate(&e));
         ctx->c.pinned_size = 4096;
         HIP_TRY(hipHostMalloc(&ctx->c.pinned, ctx->c.pinned_size, hipHostMallocDefault));
+        HIP_TRY(hipMalloc((void**)&ctx->c.d_err, 256));
+        HIP_TRY(hipMemset(ctx->c.d_err, 0, 256));
+        if (const char* m = getenv("TDC_GPU_RADIX")) ctx->c.radix_mode = (strcmp(m, "onesweep") == 0) ? 1 : (strcmp(m, "staged") == 0) ? 2 : 0;
     } catch (const HipError&) {
         (void)hipGetLastError();
         tdc_gpu_ctx_destroy(ctx);
@@ -242,6 +253,7 @@ void tdc_gpu_ctx_destroy(tdc_gpu_ctx* ctx) {
     if (ctx->c.stream) (void)hipStreamSynchronize(ctx->c.stream);
     if (ctx->c.arena.base) (void)hipFree(ctx->c.arena.base);
     if (ctx->c.pinned) (void)hipHostFree(ctx->c.pinned);
+    if (ctx->c.d_err) (void)hipFree(ctx->c.d_err);
     for (auto& e : ctx->c.ev) if (e) (void)hipEventDestroy(e);
     if (ctx->c.ev_pool) { for (int i = 0; i < ctx->c.ev_pool_size; ++i) if (ctx->c.ev_pool[i]) (void)hipEventDestroy(ctx->c.ev_pool[i]); free(ctx->c.ev_pool); }
     free(ctx->c.pend);
@@ -271,6 +283,7 @@ void tdc_gpu_ctx_reset_profile(tdc_gpu_ctx* ctx) {
 const char* tdc_gpu_ctx_kernel_profile(const tdc_gpu_ctx* ctx, int idx, double* ms, uint64_t* launches, uint64_t* bytes) {
     static const char* names[K_CLASS_COUNT] = {
         "rs_scatter_kernel<u64>", "rs_scatter_kernel<u32>", "rs_count_kernel", "scan_kernels",
+        "rs_onesweep_kernel<u64>", "rs_onesweep_kernel<u32>", "rs_hist_kernel",
         "sa_update_kernels", "sa_build_keys_kernel", "phi_kernel", "plcp_kernel", "cand_kernels",
         "level_init_kernel", "mis_round_kernel", "resolve_kernel", "push_kernel", "apply_kernel", "pool_kernels",
         "flatten_round_kernel", "gaps_kernel", "literal_hist_kernel", "tile_bits_kernel", "pack_kernel", "extract_kernels" };

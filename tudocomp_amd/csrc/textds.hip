@@ -23,27 +23,60 @@ void build_phi(Ctx& c, const u32* sa, size_t n, u32* phi) {
     LAUNCH_CHECK();
 }
 
-constexpr int PLCP_CHUNK = 32;   // consecutive text positions per thread
+constexpr int PLCP_CHUNK = 32;                    // consecutive text positions per thread
+constexpr int PLCP_TILE = 256 * PLCP_CHUNK;       // 8192 positions per workgroup
+constexpr int PLCP_HALO = 512;                    // text bytes staged beyond the tile for the T[i+l] side
 
+// A thread walks 32 consecutive positions, so its Phi reads / PLCP writes are strided by 128 B across the lanes of a
+// wave; going through LDS (row-padded to 33 words: conflict-free) turns both into fully coalesced 1 KiB transfers,
+// and the T[i+l] side of every comparison is served from a staged copy of the tile (+halo).  Only T[Phi[i]+l] stays
+// a global (data-dependent) read.
 __global__ __launch_bounds__(256) void plcp_kernel(const u8* __restrict__ text, size_t n, const u32* __restrict__ phi,
                                                     u32* __restrict__ plcp, u32* __restrict__ d_max) {
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t begin = t * PLCP_CHUNK;
+    __shared__ u32 sphi[256 * (PLCP_CHUNK + 1)];
+    __shared__ u8 stext[PLCP_TILE + PLCP_HALO];
+    const size_t base = (size_t)blockIdx.x * PLCP_TILE;
+    for (int k = threadIdx.x; k < PLCP_TILE; k += 256) {
+        const size_t p = base + k;
+        sphi[(k / PLCP_CHUNK) * (PLCP_CHUNK + 1) + (k % PLCP_CHUNK)] = (p < n) ? phi[p] : 0u;
+    }
+    for (int k = threadIdx.x * 4; k < PLCP_TILE + PLCP_HALO; k += 1024) {       // 4 bytes per lane (base is 4-aligned)
+        const size_t p = base + k;
+        u32 wv = 0;
+        if (p + 4 <= n) wv = *(const u32*)(text + p);
+        else for (int b = 0; b < 4; ++b) if (p + b < n) wv |= (u32)text[p + b] << (8 * b);
+        *(u32*)(stext + k) = wv;
+    }
+    __syncthreads();
     u32 mx = 0;
+    u32* row = sphi + threadIdx.x * (PLCP_CHUNK + 1);
+    const size_t begin = base + (size_t)threadIdx.x * PLCP_CHUNK;
     if (begin < n) {
-        size_t end = begin + PLCP_CHUNK;
-        if (end > n) end = n;
         u32 l = 0;
-        for (size_t i = begin; i < end; ++i) {
-            if (i == n - 1) { plcp[i] = 0; break; }
-            const size_t j = phi[i];
+        for (int c = 0; c < PLCP_CHUNK; ++c) {
+            const size_t i = begin + c;
+            if (i >= n) break;
+            if (i == n - 1) { row[c] = 0; break; }
+            const size_t j = row[c];
+            const u32 li = (u32)(i - base);                 // offset of i inside the staged text
             // the sentinel T[n-1] is unique, so the comparison stops before either index leaves the text;
             // the explicit bounds only keep a corrupted Phi from faulting
-            while (i + l < n && j + l < n && text[i + l] == text[j + l]) ++l;
-            plcp[i] = l;
+            for (;;) {
+                if (i + l >= n || j + l >= n) break;
+                const u32 off = li + l;
+                const u8 a = (off < PLCP_TILE + PLCP_HALO) ? stext[off] : text[i + l];
+                if (a != text[j + l]) break;
+                ++l;
+            }
+            row[c] = l;
             mx = max(mx, l);
             if (l) --l;
         }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < PLCP_TILE; k += 256) {
+        const size_t p = base + k;
+        if (p < n) plcp[p] = sphi[(k / PLCP_CHUNK) * (PLCP_CHUNK + 1) + (k % PLCP_CHUNK)];
     }
     mx = wave_reduce_max(mx);
     if (lane_id() == 0 && mx) atomicMax(d_max, mx);
@@ -52,9 +85,8 @@ __global__ __launch_bounds__(256) void plcp_kernel(const u8* __restrict__ text, 
 void build_plcp(Ctx& c, const u8* text, size_t n, const u32* phi, u32* plcp, u32* d_maxlcp) {
     HIP_TRY(hipMemsetAsync(d_maxlcp, 0, sizeof(u32), c.stream));
     if (!n) return;
-    const size_t threads = (n + PLCP_CHUNK - 1) / PLCP_CHUNK;
     Ctx::ProfScope prof(c, K_PLCP, (u64)n * 10);                // Phi (4) + two text bytes + PLCP (4), SURVEY 8d
-    plcp_kernel<<<cdiv(threads, 256), 256, 0, c.stream>>>(text, n, phi, plcp, d_maxlcp);
+    plcp_kernel<<<cdiv(n, PLCP_TILE), 256, 0, c.stream>>>(text, n, phi, plcp, d_maxlcp);
     LAUNCH_CHECK();
 }
 
