@@ -7,8 +7,9 @@
 //
 // Device formulation (models: tests/models/position_space.py, checked against the oracle incl. emission order):
 //   * all state is indexed by TEXT POSITION p: cur[p] = lcp[isa[p]] (initially PLCP[p]), source = Phi[p];
-//   * resid[p] = level whose list currently holds p's entry.  Lists are UNORDERED sets kept in position order (so all
-//     per-level kernels walk the position-indexed arrays monotonically); the reference's list order lives in an
+//   * every entry lives in exactly one list (its original level's segment of the sorted candidates, or one segment
+//     of the push pool).  Lists are UNORDERED sets kept in position order (so all per-level kernels walk the
+//     position-indexed arrays monotonically); the reference's list order lives in an
 //     explicit priority prio[p]: ISA[p] for original candidates (ascending SA index), and base + rank for entries
 //     pushed down from level L, where rank is the index after sorting that level's pushes by (target, old priority)
 //     and base grows monotonically -- pushed entries follow the originals, later pushes follow earlier ones, pushes of
@@ -20,7 +21,10 @@
 //     higher priority (left neighbour covers it -> 0, right neighbour at distance d -> min(v, d)) and moves to list v
 //     (or is dropped if v < threshold);
 //   * kills (cur = 0, owner = factor start) and truncations (atomicMin) of all selected entries are applied last;
-//     they commute, so their order does not matter.
+//     they commute, so their order does not matter;
+//   * the per-level state of a position is 2 bits in a bitmap (01 undecided live entry, 10 selected), so the
+//     "neighbours within distance < L" scans read one or two 64-bit words instead of 2L-1 array elements, and a
+//     decision is ONE atomic (xor 11: undecided -> selected, xor 01: undecided -> rejected).
 #include "stages.hpp"
 #include "prim.hpp"
 
@@ -29,7 +33,6 @@
 
 namespace tdc {
 
-enum : u8 { ST_UNDECIDED = 0, ST_SELECTED = 1, ST_NOTLIVE = 2, ST_REJECTED = 3 };
 enum : u8 { CL_DEAD = 0, CL_LIVE = 1, CL_STALE = 2 };
 
 struct LevelScalars {
@@ -43,16 +46,27 @@ struct LevelScalars {
 
 struct PushSeg { u32 target, start; };
 
+// ---- per-level state bitmap: 2 bits per text position, 32 positions per 64-bit word -----------------------------
+constexpr u64 BM_UNDECIDED_ALL = 0x5555555555555555ull;   // bit 0 of every pair
+constexpr u64 BM_SELECTED_ALL  = 0xAAAAAAAAAAAAAAAAull;   // bit 1 of every pair
+
+__device__ __forceinline__ u64 bm_range_mask(size_t word, size_t lo, size_t hi) {   // pairs of positions lo..hi inside `word`
+    const size_t w0 = word * 32;
+    const size_t first = lo > w0 ? lo - w0 : 0;
+    const size_t last = (hi < w0 + 31) ? hi - w0 : 31;
+    const u64 upto = (last == 31) ? ~0ull : ((1ull << (2 * (last + 1))) - 1);
+    return upto & ~((1ull << (2 * first)) - 1);
+}
+__device__ __forceinline__ u32 bm_state(const u64* __restrict__ bm, u32 p) { return (u32)(bm[p >> 5] >> (2 * (p & 31))) & 3u; }
+
 // ---- candidates ("Fill candidates", :54-66) ----------------------------------------------------------------
 __global__ void cand_class_kernel(const u32* __restrict__ plcp, size_t n, u32 threshold, u8* __restrict__ cls,
-                                  u32* __restrict__ pos, u32* __restrict__ resid, u32* __restrict__ flen, u32* __restrict__ owner) {
+                                  u32* __restrict__ pos, u32* __restrict__ flen, u32* __restrict__ owner) {
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     const u32 v = plcp[p];
-    const bool c = v >= threshold;       // PLCP[n-1] = 0, so the sentinel (SA index 0) is never a candidate
-    cls[p] = c ? 1 : 0;
+    cls[p] = (v >= threshold) ? 1 : 0;   // PLCP[n-1] = 0, so the sentinel (SA index 0) is never a candidate
     pos[p] = (u32)p;
-    resid[p] = c ? v : 0u;
     flen[p] = 0;
     owner[p] = NONE32;
 }
@@ -69,10 +83,10 @@ __global__ void seg_bounds_kernel(const u32* __restrict__ keys, size_t m, u32* _
 }
 
 // ---- per level ---------------------------------------------------------------------------------------------
-// classify the entries of the level: live / stale / dead; publishes the per-position state for the window scans
+// classify the entries of the level: live / stale / dead; live entries are marked undecided in the bitmap
 __global__ void classify_kernel(const u32* __restrict__ orig, u32 m0, const u32* __restrict__ pushed, u32 m, u32 L,
                                 u32 threshold, const u32* __restrict__ cur, u32* __restrict__ ent, u8* __restrict__ cls,
-                                u8* __restrict__ pst) {
+                                u64* __restrict__ bm) {
     const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= m) return;
     const u32 p = (k < m0) ? orig[k] : pushed[k - m0];
@@ -80,62 +94,73 @@ __global__ void classify_kernel(const u32* __restrict__ orig, u32 m0, const u32*
     const u8 c = (v == L) ? CL_LIVE : (v >= threshold ? CL_STALE : CL_DEAD);
     ent[k] = p;
     cls[k] = c;
-    pst[p] = (c == CL_LIVE) ? ST_UNDECIDED : ST_NOTLIVE;
+    if (c == CL_LIVE) atomicOr((unsigned long long*)&bm[p >> 5], 1ull << (2 * (p & 31)));
 }
 
 // One selection round over the live entries.  G lanes cooperate on one entry (1 for short levels, 64 for long ones).
 template <int G>
 __global__ __launch_bounds__(256) void mis_round_kernel(const u32* __restrict__ live, u32 nl, u32 L, size_t n,
-                                                         const u32* __restrict__ resid, const u32* __restrict__ prio, u8* pst,
-                                                         LevelScalars* __restrict__ sc) {
+                                                         const u32* __restrict__ prio, u64* bm, LevelScalars* __restrict__ sc) {
     const u32 i = (blockIdx.x * blockDim.x + threadIdx.x) / G;
     const u32 sub = (G == 1) ? 0u : (threadIdx.x & (G - 1));
     if (i >= nl) return;                                  // whole groups leave together
     const u32 p = live[i];
-    if (pst[p] != ST_UNDECIDED) return;
+    if (bm_state(bm, p) != 1u) return;                    // already decided (same word for all lanes of a group)
     const u32 pr = prio[p];
     bool hit = false, blocked = false;
     const size_t lo = (p >= L - 1) ? (size_t)p - (L - 1) : 0;
     size_t hi = (size_t)p + (L - 1);
     if (hi > n - 1) hi = n - 1;
-    for (size_t q = lo + sub; q <= hi; q += G) {
-        if (q == p || resid[q] != L) continue;
-        const u8 s = pst[q];
-        if (s == ST_SELECTED) { hit = true; break; }      // selected neighbours always have higher priority than an undecided entry
-        if (s == ST_UNDECIDED && prio[q] < pr) blocked = true;
+    for (size_t w = (lo >> 5) + sub; w <= (hi >> 5) && !hit; w += G) {
+        const u64 word = bm[w] & bm_range_mask(w, lo, hi);
+        if (word & BM_SELECTED_ALL) { hit = true; break; }   // a selected neighbour always outranks an undecided entry
+        u64 und = word & BM_UNDECIDED_ALL;
+        if (w == (p >> 5)) und &= ~(1ull << (2 * (p & 31)));
+        while (und) {
+            const int b = __builtin_ctzll(und);
+            und &= und - 1;
+            if (prio[w * 32 + (b >> 1)] < pr) { blocked = true; break; }
+        }
     }
     if (G > 1) {
         hit = __any(hit);
         blocked = __any(blocked);
         if (sub != 0) return;
     }
-    if (hit) pst[p] = ST_REJECTED;
-    else if (!blocked) pst[p] = ST_SELECTED;
+    // one atomic per decision: xor 01 = undecided -> rejected (00), xor 11 = undecided -> selected (10)
+    if (hit) atomicXor((unsigned long long*)&bm[p >> 5], 1ull << (2 * (p & 31)));
+    else if (!blocked) atomicXor((unsigned long long*)&bm[p >> 5], 3ull << (2 * (p & 31)));
     else atomicAdd(&sc->undecided, 1u);
 }
 
 // Encounter value of the non-selected entries (:85-89): key = (target << 32) | old priority, rc = 1 if pushed down.
 template <int G>
 __global__ __launch_bounds__(256) void resolve_kernel(const u32* __restrict__ list, u32 cnt, bool live_list, u32 L, u32 threshold,
-                                                       size_t n, const u32* __restrict__ resid, const u32* __restrict__ prio,
-                                                       const u8* __restrict__ pst, const u32* __restrict__ cur,
-                                                       u64* __restrict__ rkey, u32* __restrict__ rval, u8* __restrict__ rc) {
+                                                       size_t n, const u32* __restrict__ prio, const u64* __restrict__ bm,
+                                                       const u32* __restrict__ cur, u64* __restrict__ rkey, u32* __restrict__ rval,
+                                                       u8* __restrict__ rc) {
     const u32 i = (blockIdx.x * blockDim.x + threadIdx.x) / G;
     const u32 sub = (G == 1) ? 0u : (threadIdx.x & (G - 1));
     if (i >= cnt) return;
     const u32 p = list[i];
-    const bool skip = live_list && pst[p] != ST_REJECTED;      // selected entries of the live list are not pushed
+    const bool skip = live_list && bm_state(bm, p) == 2u;      // selected entries of the live list are not pushed
     u32 v = skip ? 0u : cur[p];
     const u32 pr = prio[p];
     if (!skip) {
         const size_t lo = (p >= L - 1) ? (size_t)p - (L - 1) : 0;
         size_t hi = (size_t)p + (L - 1);
         if (hi > n - 1) hi = n - 1;
-        for (size_t q = lo + sub; q <= hi; q += G) {
-            if (q == p || resid[q] != L || pst[q] != ST_SELECTED || prio[q] >= pr) continue;
-            if (q < p) { v = 0; break; }             // covered by a factor starting to the left   (:99-101)
-            const u32 d = (u32)(q - p);               // truncated by a factor starting to the right (:103-109)
-            if (d < v) v = d;
+        for (size_t w = (lo >> 5) + sub; w <= (hi >> 5) && v; w += G) {
+            u64 sel = bm[w] & bm_range_mask(w, lo, hi) & BM_SELECTED_ALL;
+            while (sel) {
+                const int b = __builtin_ctzll(sel);
+                sel &= sel - 1;
+                const size_t q = w * 32 + (b >> 1);
+                if (prio[q] >= pr) continue;             // selected later in the list: does not affect the encounter value
+                if (q < p) { v = 0; break; }             // covered by a factor starting to the left   (:99-101)
+                const u32 d = (u32)(q - p);               // truncated by a factor starting to the right (:103-109)
+                if (d < v) v = d;
+            }
         }
     }
     if (G > 1) {
@@ -150,13 +175,12 @@ __global__ __launch_bounds__(256) void resolve_kernel(const u32* __restrict__ li
 
 // The level's pushes, sorted by (target, old priority): new residence, new priority, pool slot, segment starts.
 __global__ void push_finalize_kernel(const u64* __restrict__ keys, const u32* __restrict__ vals, u32 npush, u32 prio_base,
-                                     u32* __restrict__ resid, u32* __restrict__ prio, u32* __restrict__ pool,
+                                     u32* __restrict__ prio, u32* __restrict__ pool,
                                      PushSeg* __restrict__ segs, u32 seg_cap, LevelScalars* __restrict__ sc) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= npush) return;
     const u32 tgt = (u32)(keys[i] >> 32);
     const u32 p = vals[i];
-    resid[p] = tgt;
     prio[p] = prio_base + i;
     pool[i] = p;
     if (i == 0 || (u32)(keys[i - 1] >> 32) != tgt) {
@@ -167,14 +191,14 @@ __global__ void push_finalize_kernel(const u64* __restrict__ keys, const u32* __
 
 // Emit the selected entries: factor (p, Phi[p], L); kill the covered positions, truncate the ones in front.
 template <int G>
-__global__ __launch_bounds__(256) void apply_kernel(const u32* __restrict__ live, u32 nl, u32 L, size_t n, const u8* __restrict__ pst,
+__global__ __launch_bounds__(256) void apply_kernel(const u32* __restrict__ live, u32 nl, u32 L, size_t n, u64* bm,
                                                      const u32* __restrict__ phi, u32* __restrict__ cur, u32* __restrict__ flen,
                                                      u32* __restrict__ owner, u32* __restrict__ fsrc, LevelScalars* __restrict__ sc) {
     const u32 i = (blockIdx.x * blockDim.x + threadIdx.x) / G;
     const u32 sub = (G == 1) ? 0u : (threadIdx.x & (G - 1));
     bool sel = false;
     u32 p = 0;
-    if (i < nl) { p = live[i]; sel = (pst[p] == ST_SELECTED); }
+    if (i < nl) { p = live[i]; sel = (bm_state(bm, p) == 2u); }
     if (sel) {
         if (sub == 0) { flen[p] = L; fsrc[p] = phi[p]; }
         for (u32 j = sub; j < L && (size_t)p + j < n; j += G) {   // :99-101
@@ -187,6 +211,9 @@ __global__ __launch_bounds__(256) void apply_kernel(const u32* __restrict__ live
             if (*q > j + 1) atomicMin(q, j + 1);                     // values only ever decrease: a stale read can only cause a redundant atomic
         }
     }
+    // leave the bitmap all-zero for the next level (every reader of this level's state ran in an earlier kernel)
+    if (G > 1) __builtin_amdgcn_wave_barrier();
+    if (sel && sub == 0) atomicAnd((unsigned long long*)&bm[p >> 5], ~(3ull << (2 * (p & 31))));
     // factor count: one atomic per workgroup
     __shared__ u32 cnt;
     if (threadIdx.x == 0) cnt = 0;
@@ -212,15 +239,14 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
     u32* prio = isa;
 
     // ---- candidates: positions with PLCP >= threshold, in position order, stably sorted by PLCP value -----------
-    u32* resid = c.arena.get<u32>(n);
     u8* cls = c.arena.get<u8>(n);
     u32* ckeys[2] = { c.arena.get<u32>(n), c.arena.get<u32>(n) };
     u32* cvals[2] = { c.arena.get<u32>(n), c.arena.get<u32>(n) };
     u32* d_cnt = c.arena.get<u32>(4);
     u32* iota = ckeys[1];                       // scratch: position of every text position
     {
-        Ctx::ProfScope prof(c, K_CAND, (u64)n * 21);
-        cand_class_kernel<<<gn, 256, 0, s>>>(plcp, n, threshold, cls, iota, resid, fs.flen, fs.owner);
+        Ctx::ProfScope prof(c, K_CAND, (u64)n * 17);
+        cand_class_kernel<<<gn, 256, 0, s>>>(plcp, n, threshold, cls, iota, fs.flen, fs.owner);
         LAUNCH_CHECK();
     }
     if ((u64)maxlcp + 1 <= threshold || threshold == 0) { c.arena.release(mark); return; }   // ArraysComp.hpp:50
@@ -251,7 +277,9 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
     u32* ent = cvals[x ^ 1];                    // the candidate sort's scratch buffers are free now
     u32* live = ckeys[0];
     u32* stale = ckeys[1];
-    u8* pst = c.arena.get<u8>(n);
+    const size_t bm_words = n / 32 + 2;
+    u64* bm = c.arena.get<u64>(bm_words);       // 2 state bits per position; all-zero between levels
+    HIP_TRY(hipMemsetAsync(bm, 0, bm_words * sizeof(u64), s));
     u8* rc = c.arena.get<u8>(n);
     u32* pool = c.arena.get<u32>(n);            // pushed entries, grouped by (source level, target)
     u32* pushed = c.arena.get<u32>(n);
@@ -283,9 +311,9 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
         st->levels++;
         HIP_TRY(hipMemsetAsync(d_sc, 0, sizeof(LevelScalars), s));
         const unsigned gm = cdiv(m, 256);
-        {   // per entry: list (4) + cur (4) + ent (4) + class and state bytes (2)
-            Ctx::ProfScope prof(c, K_LEVEL_INIT, (u64)m * 14);
-            classify_kernel<<<gm, 256, 0, s>>>(cand + h_segstart[L], m0, pushed, m, L, threshold, cur, ent, cls, pst);
+        {   // per entry: list (4) + cur (4) + ent (4) + class byte (1)
+            Ctx::ProfScope prof(c, K_LEVEL_INIT, (u64)m * 13);
+            classify_kernel<<<gm, 256, 0, s>>>(cand + h_segstart[L], m0, pushed, m, L, threshold, cur, ent, cls, bm);
             LAUNCH_CHECK();
         }
         select_by_class(c, cls, CL_LIVE, m, ent, live, nullptr, nullptr, &d_sc->nlive);
@@ -300,10 +328,10 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
             u32 undecided = nl;
             while (undecided) {
                 HIP_TRY(hipMemsetAsync(&d_sc->undecided, 0, sizeof(u32), s));
-                {   // per undecided entry: list + prio + state (9) + a window of 2L-1 resid words and state bytes
-                    Ctx::ProfScope prof(c, K_MIS_ROUND, (u64)nl * 5 + (u64)undecided * (8 + 5ull * (2 * L - 1)));
-                    if (wide) mis_round_kernel<64><<<gl, 256, 0, s>>>(live, nl, L, n, resid, prio, pst, d_sc);
-                    else      mis_round_kernel<1><<<gl, 256, 0, s>>>(live, nl, L, n, resid, prio, pst, d_sc);
+                {   // per live entry: list + its bitmap word (12); per undecided entry: prio (4) + the window's bitmap words
+                    Ctx::ProfScope prof(c, K_MIS_ROUND, (u64)nl * 12 + (u64)undecided * (4 + 8ull * ((2 * L - 2) / 32 + 2)));
+                    if (wide) mis_round_kernel<64><<<gl, 256, 0, s>>>(live, nl, L, n, prio, bm, d_sc);
+                    else      mis_round_kernel<1><<<gl, 256, 0, s>>>(live, nl, L, n, prio, bm, d_sc);
                     LAUNCH_CHECK();
                 }
                 const u32 now = c.read(&d_sc->undecided);
@@ -313,16 +341,16 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
                 undecided = now;
             }
         }
-        {   // per entry: list, cur, prio (12) + window (5 B per position) + outputs (13)
-            Ctx::ProfScope prof(c, K_RESOLVE, (u64)(ns + nl) * (25 + 5ull * (2 * L - 1)));
+        {   // per entry: list, cur, prio (12) + the window's bitmap words + outputs (13)
+            Ctx::ProfScope prof(c, K_RESOLVE, (u64)(ns + nl) * (25 + 8ull * ((2 * L - 2) / 32 + 2)));
             if (ns) {
-                if (wide) resolve_kernel<64><<<gs, 256, 0, s>>>(stale, ns, false, L, threshold, n, resid, prio, pst, cur, rkey, rval, rc);
-                else      resolve_kernel<1><<<gs, 256, 0, s>>>(stale, ns, false, L, threshold, n, resid, prio, pst, cur, rkey, rval, rc);
+                if (wide) resolve_kernel<64><<<gs, 256, 0, s>>>(stale, ns, false, L, threshold, n, prio, bm, cur, rkey, rval, rc);
+                else      resolve_kernel<1><<<gs, 256, 0, s>>>(stale, ns, false, L, threshold, n, prio, bm, cur, rkey, rval, rc);
                 LAUNCH_CHECK();
             }
             if (nl) {
-                if (wide) resolve_kernel<64><<<gl, 256, 0, s>>>(live, nl, true, L, threshold, n, resid, prio, pst, cur, rkey + ns, rval + ns, rc + ns);
-                else      resolve_kernel<1><<<gl, 256, 0, s>>>(live, nl, true, L, threshold, n, resid, prio, pst, cur, rkey + ns, rval + ns, rc + ns);
+                if (wide) resolve_kernel<64><<<gl, 256, 0, s>>>(live, nl, true, L, threshold, n, prio, bm, cur, rkey + ns, rval + ns, rc + ns);
+                else      resolve_kernel<1><<<gl, 256, 0, s>>>(live, nl, true, L, threshold, n, prio, bm, cur, rkey + ns, rval + ns, rc + ns);
                 LAUNCH_CHECK();
             }
         }
@@ -330,8 +358,8 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
         if (nl) {
             // per entry: list + state (5); per factor: Phi, flen, fsrc (12) + L kills (8 B each) + L truncations (4 B each)
             Ctx::ProfScope prof(c, K_APPLY, (u64)nl * 5 + (u64)nl * (12 + 12ull * L));
-            if (wide) apply_kernel<64><<<gl, 256, 0, s>>>(live, nl, L, n, pst, phi, cur, fs.flen, fs.owner, fs.fsrc, d_sc);
-            else      apply_kernel<1><<<gl, 256, 0, s>>>(live, nl, L, n, pst, phi, cur, fs.flen, fs.owner, fs.fsrc, d_sc);
+            if (wide) apply_kernel<64><<<gl, 256, 0, s>>>(live, nl, L, n, bm, phi, cur, fs.flen, fs.owner, fs.fsrc, d_sc);
+            else      apply_kernel<1><<<gl, 256, 0, s>>>(live, nl, L, n, bm, phi, cur, fs.flen, fs.owner, fs.fsrc, d_sc);
             LAUNCH_CHECK();
         }
         h_sc = c.read(d_sc);
@@ -345,7 +373,7 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
             const int y = radix_sort_pairs_u64(c, skeys, svals, npush, 0, 32 + (int)bits_for(L));
             {
                 Ctx::ProfScope prof(c, K_PUSH, (u64)npush * 24);
-                push_finalize_kernel<<<cdiv(npush, 256), 256, 0, s>>>(skeys[y], svals[y], npush, prio_base, resid, prio,
+                push_finalize_kernel<<<cdiv(npush, 256), 256, 0, s>>>(skeys[y], svals[y], npush, prio_base, prio,
                                                                       pool + pool_top, d_segs, seg_cap, d_sc);
                 LAUNCH_CHECK();
             }
