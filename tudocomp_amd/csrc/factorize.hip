@@ -35,6 +35,9 @@ namespace tdc {
 
 enum : u8 { CL_DEAD = 0, CL_LIVE = 1, CL_STALE = 2 };
 
+struct PushSeg { u32 target, start; };
+constexpr u32 SEG_INLINE = 252;      // segment descriptors that travel with the scalars in one read-back
+
 struct LevelScalars {
     u32 nlive, nstale;   // entries with cur == L / threshold <= cur < L
     u32 undecided;       // live entries still undecided after the last round
@@ -42,9 +45,8 @@ struct LevelScalars {
     u32 npush;           // entries pushed down from this level
     u32 nseg;            // distinct push targets of this level
     u32 pad[2];
+    PushSeg segs[SEG_INLINE];
 };
-
-struct PushSeg { u32 target, start; };
 
 // ---- per-level state bitmap: 2 bits per text position, 32 positions per 64-bit word -----------------------------
 constexpr u64 BM_UNDECIDED_ALL = 0x5555555555555555ull;   // bit 0 of every pair
@@ -97,7 +99,14 @@ __global__ void classify_kernel(const u32* __restrict__ orig, u32 m0, const u32*
     if (c == CL_LIVE) atomicOr((unsigned long long*)&bm[p >> 5], 1ull << (2 * (p & 31)));
 }
 
-// One selection round over the live entries.  G lanes cooperate on one entry (1 for short levels, 64 for long ones).
+// Selection rounds over the live entries.  G lanes cooperate on one entry (1 for short levels, 64 for long ones).
+// A blocked entry retries a few times inside the launch: the bitmap words are re-read with agent-scope (L1-bypassing)
+// loads, so decisions of other workgroups become visible without a kernel boundary.  Safe without any ordering:
+// a state only ever moves undecided -> {selected, rejected}, and a stale "undecided" merely postpones a decision.
+constexpr int MIS_TRIES = 6;
+
+__device__ __forceinline__ u64 bm_load(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 template <int G>
 __global__ __launch_bounds__(256) void mis_round_kernel(const u32* __restrict__ live, u32 nl, u32 L, size_t n,
                                                          const u32* __restrict__ prio, u64* bm, LevelScalars* __restrict__ sc) {
@@ -105,32 +114,34 @@ __global__ __launch_bounds__(256) void mis_round_kernel(const u32* __restrict__ 
     const u32 sub = (G == 1) ? 0u : (threadIdx.x & (G - 1));
     if (i >= nl) return;                                  // whole groups leave together
     const u32 p = live[i];
-    if (bm_state(bm, p) != 1u) return;                    // already decided (same word for all lanes of a group)
+    if (((bm_load(&bm[p >> 5]) >> (2 * (p & 31))) & 3u) != 1u) return;   // already decided (uniform inside a group)
     const u32 pr = prio[p];
-    bool hit = false, blocked = false;
     const size_t lo = (p >= L - 1) ? (size_t)p - (L - 1) : 0;
     size_t hi = (size_t)p + (L - 1);
     if (hi > n - 1) hi = n - 1;
-    for (size_t w = (lo >> 5) + sub; w <= (hi >> 5) && !hit; w += G) {
-        const u64 word = bm[w] & bm_range_mask(w, lo, hi);
-        if (word & BM_SELECTED_ALL) { hit = true; break; }   // a selected neighbour always outranks an undecided entry
-        u64 und = word & BM_UNDECIDED_ALL;
-        if (w == (p >> 5)) und &= ~(1ull << (2 * (p & 31)));
-        while (und) {
-            const int b = __builtin_ctzll(und);
-            und &= und - 1;
-            if (prio[w * 32 + (b >> 1)] < pr) { blocked = true; break; }
+    for (int attempt = 0; attempt < MIS_TRIES; ++attempt) {
+        bool hit = false, blocked = false;
+        for (size_t w = (lo >> 5) + sub; w <= (hi >> 5) && !hit; w += G) {
+            const u64 word = bm_load(&bm[w]) & bm_range_mask(w, lo, hi);
+            if (word & BM_SELECTED_ALL) { hit = true; break; }   // a selected neighbour always outranks an undecided entry
+            u64 und = word & BM_UNDECIDED_ALL;
+            if (w == (p >> 5)) und &= ~(1ull << (2 * (p & 31)));
+            while (und) {
+                const int b = __builtin_ctzll(und);
+                und &= und - 1;
+                if (prio[w * 32 + (b >> 1)] < pr) { blocked = true; break; }
+            }
         }
+        if (G > 1) {
+            hit = __any(hit);
+            blocked = __any(blocked);
+        }
+        // one atomic per decision: xor 01 = undecided -> rejected (00), xor 11 = undecided -> selected (10)
+        if (hit) { if (sub == 0) atomicXor((unsigned long long*)&bm[p >> 5], 1ull << (2 * (p & 31))); return; }
+        if (!blocked) { if (sub == 0) atomicXor((unsigned long long*)&bm[p >> 5], 3ull << (2 * (p & 31))); return; }
+        __builtin_amdgcn_s_sleep(8);
     }
-    if (G > 1) {
-        hit = __any(hit);
-        blocked = __any(blocked);
-        if (sub != 0) return;
-    }
-    // one atomic per decision: xor 01 = undecided -> rejected (00), xor 11 = undecided -> selected (10)
-    if (hit) atomicXor((unsigned long long*)&bm[p >> 5], 1ull << (2 * (p & 31)));
-    else if (!blocked) atomicXor((unsigned long long*)&bm[p >> 5], 3ull << (2 * (p & 31)));
-    else atomicAdd(&sc->undecided, 1u);
+    if (sub == 0) atomicAdd(&sc->undecided, 1u);
 }
 
 // Encounter value of the non-selected entries (:85-89): key = (target << 32) | old priority, rc = 1 if pushed down.
@@ -185,6 +196,7 @@ __global__ void push_finalize_kernel(const u64* __restrict__ keys, const u32* __
     pool[i] = p;
     if (i == 0 || (u32)(keys[i - 1] >> 32) != tgt) {
         const u32 j = atomicAdd(&sc->nseg, 1u);
+        if (j < SEG_INLINE) sc->segs[j] = PushSeg{tgt, i};
         if (j < seg_cap) segs[j] = PushSeg{tgt, i};
     }
 }
@@ -309,7 +321,7 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
         const u32 m = m0 + m1;
         if (m == 0) continue;
         st->levels++;
-        HIP_TRY(hipMemsetAsync(d_sc, 0, sizeof(LevelScalars), s));
+        HIP_TRY(hipMemsetAsync(d_sc, 0, 8 * sizeof(u32), s));
         const unsigned gm = cdiv(m, 256);
         {   // per entry: list (4) + cur (4) + ent (4) + class byte (1)
             Ctx::ProfScope prof(c, K_LEVEL_INIT, (u64)m * 13);
@@ -318,7 +330,7 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
         }
         select_by_class(c, cls, CL_LIVE, m, ent, live, nullptr, nullptr, &d_sc->nlive);
         select_by_class(c, cls, CL_STALE, m, ent, stale, nullptr, nullptr, &d_sc->nstale);
-        h_sc = c.read(d_sc);
+        c.read_n((const u32*)d_sc, (u32*)&h_sc, 8);
         const u32 nl = h_sc.nlive, ns = h_sc.nstale;
         if (nl == 0 && ns == 0) continue;                     // every entry already erased (:86)
         const bool wide = (L > 24);
@@ -362,7 +374,7 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
             else      apply_kernel<1><<<gl, 256, 0, s>>>(live, nl, L, n, bm, phi, cur, fs.flen, fs.owner, fs.fsrc, d_sc);
             LAUNCH_CHECK();
         }
-        h_sc = c.read(d_sc);
+        c.read_n((const u32*)d_sc, (u32*)&h_sc, 8);
         st->factors += h_sc.selected;
         const u32 npush = h_sc.npush;
         if (npush) {
@@ -377,9 +389,11 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
                                                                       pool + pool_top, d_segs, seg_cap, d_sc);
                 LAUNCH_CHECK();
             }
-            const u32 nseg = c.read(&d_sc->nseg);
+            c.read_n((const u32*)d_sc, (u32*)&h_sc, sizeof(LevelScalars) / sizeof(u32));   // scalars + inline segments: one sync
+            const u32 nseg = h_sc.nseg;
             if (nseg > seg_cap) throw HipError{hipErrorUnknown, "factorize: too many push targets in one level", (int)__LINE__};
-            c.read_n(d_segs, h_segs.data(), nseg);
+            if (nseg <= SEG_INLINE) std::copy(h_sc.segs, h_sc.segs + nseg, h_segs.begin());
+            else c.read_n(d_segs, h_segs.data(), nseg);
             std::sort(h_segs.begin(), h_segs.begin() + nseg, [](const PushSeg& a, const PushSeg& b) { return a.start < b.start; });
             for (u32 j = 0; j < nseg; ++j) {
                 const u32 end = (j + 1 < nseg) ? h_segs[j + 1].start : npush;

@@ -15,6 +15,8 @@
 #include "stages.hpp"
 #include "prim.hpp"
 
+#include <stdlib.h>
+
 namespace tdc {
 
 struct CodeMap { u8 code[256]; };
@@ -152,6 +154,7 @@ void build_suffix_array(Ctx& c, const u8* text, size_t n, u32* sa, u32* isa, SAS
     const int b = (int)bits_for(sigma > 1 ? sigma - 1 : 1);
     int k = 64 / b;
     if (k > 32) k = 32;
+    if (const char* e = getenv("TDC_GPU_SA_INIT_SYMS")) { const int v = atoi(e); if (v >= 1 && v < k) k = v; }   // tuning knob
     st->sym_bits = b; st->init_syms = k;
 
     // --- buffers ----------------------------------------------------------------------------------
