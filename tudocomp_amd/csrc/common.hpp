@@ -6,6 +6,7 @@
 #include <stdint.h>
 #include <stddef.h>
 #include <stdio.h>
+#include <string.h>
 
 namespace tdc {
 
@@ -143,8 +144,15 @@ struct Ctx {
         return *h;
     }
     template <typename T> void read_n(const T* dptr, T* out, size_t count) {
-        HIP_TRY(hipMemcpyAsync(out, dptr, sizeof(T) * count, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
+        const size_t bytes = sizeof(T) * count;
+        if (bytes <= pinned_size) {          // small read-backs go through the pinned block (pageable D2H copies are slow)
+            HIP_TRY(hipMemcpyAsync(pinned, dptr, bytes, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            memcpy(out, pinned, bytes);
+        } else {
+            HIP_TRY(hipMemcpyAsync(out, dptr, bytes, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+        }
     }
 };
 

@@ -184,6 +184,20 @@ __global__ __launch_bounds__(256) void resolve_kernel(const u32* __restrict__ li
     rval[i] = p;
 }
 
+// Pushed part of a level's list: concatenation of its pool segments (table: source offset / destination offset).
+struct GatherSeg { u32 src_off, dst_off; };
+__global__ void gather_segments_kernel(const u32* __restrict__ pool, const GatherSeg* __restrict__ tab, u32 nseg, u32 total,
+                                       u32* __restrict__ dst) {
+    const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= total) return;
+    u32 lo = 0, hi = nseg - 1;                       // last segment with dst_off <= k
+    while (lo < hi) {
+        const u32 mid = (lo + hi + 1) >> 1;
+        if (tab[mid].dst_off <= k) lo = mid; else hi = mid - 1;
+    }
+    dst[k] = pool[tab[lo].src_off + (k - tab[lo].dst_off)];
+}
+
 // The level's pushes, sorted by (target, old priority): new residence, new priority, pool slot, segment starts.
 __global__ void push_finalize_kernel(const u64* __restrict__ keys, const u32* __restrict__ vals, u32 npush, u32 prio_base,
                                      u32* __restrict__ prio, u32* __restrict__ pool,
@@ -305,6 +319,9 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
     std::vector<PushSeg> h_segs(seg_cap);
     LevelScalars h_sc;
 
+    const u32 gtab_cap = 1u << 16;
+    GatherSeg* d_gtab = (GatherSeg*)c.arena.alloc(sizeof(GatherSeg) * gtab_cap);
+    std::vector<GatherSeg> h_gtab(gtab_cap);
     struct PoolSeg { u32 off, cnt; };
     std::vector<std::vector<PoolSeg>> pushed_into(nlev);     // per target level: its segments of the pool
     size_t pool_top = 0;
@@ -313,9 +330,25 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
     for (u32 L = maxlcp; L >= threshold; --L) {
         const u32 m0 = h_segend[L] - h_segstart[L];
         u32 m1 = 0;
-        for (const PoolSeg& sg : pushed_into[L]) {            // gather the pushed part of the list
-            HIP_TRY(hipMemcpyAsync(pushed + m1, pool + sg.off, (size_t)sg.cnt * sizeof(u32), hipMemcpyDeviceToDevice, s));
-            m1 += sg.cnt;
+        {   // gather the pushed part of the list: one kernel per (at most gtab_cap) pool segments
+            const std::vector<PoolSeg>& segsL = pushed_into[L];
+            size_t done = 0;
+            while (done < segsL.size()) {
+                const size_t cntseg = std::min(segsL.size() - done, (size_t)gtab_cap);
+                u32 tot = 0;
+                for (size_t j = 0; j < cntseg; ++j) { h_gtab[j] = GatherSeg{segsL[done + j].off, tot}; tot += segsL[done + j].cnt; }
+                if (cntseg == 1) {
+                    HIP_TRY(hipMemcpyAsync(pushed + m1, pool + h_gtab[0].src_off, (size_t)tot * sizeof(u32), hipMemcpyDeviceToDevice, s));
+                } else {
+                    // the table is staged through pageable memory: the copy has left h_gtab when the call returns
+                    HIP_TRY(hipMemcpyAsync(d_gtab, h_gtab.data(), cntseg * sizeof(GatherSeg), hipMemcpyHostToDevice, s));
+                    gather_segments_kernel<<<cdiv(tot, 256), 256, 0, s>>>(pool, d_gtab, (u32)cntseg, tot, pushed + m1);
+                    LAUNCH_CHECK();
+                    HIP_TRY(hipStreamSynchronize(s));          // h_gtab is reused by the next chunk / level
+                }
+                m1 += tot;
+                done += cntseg;
+            }
         }
         std::vector<PoolSeg>().swap(pushed_into[L]);
         const u32 m = m0 + m1;
@@ -382,7 +415,7 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
             // so the pool never needs more than n slots; checked before anything is written
             if (pool_top + npush > n || (u64)prio_base + npush > 0xFFFFFFFFull)
                 throw HipError{hipErrorUnknown, "factorize: push pool overflow", (int)__LINE__};
-            const int y = radix_sort_pairs_u64(c, skeys, svals, npush, 0, 32 + (int)bits_for(L));
+            const int y = sort_pairs_u64_distinct(c, skeys, svals, npush, 0, 32 + (int)bits_for(L));   // priorities are distinct
             {
                 Ctx::ProfScope prof(c, K_PUSH, (u64)npush * 24);
                 push_finalize_kernel<<<cdiv(npush, 256), 256, 0, s>>>(skeys[y], svals[y], npush, prio_base, prio,
