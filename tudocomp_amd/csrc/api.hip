@@ -237,7 +237,7 @@ int tdc_gpu_ctx_create(int device, tdc_gpu_ctx** out) {
         HIP_TRY(hipHostMalloc(&ctx->c.pinned, ctx->c.pinned_size, hipHostMallocDefault));
         HIP_TRY(hipMalloc((void**)&ctx->c.d_err, 256));
         HIP_TRY(hipMemset(ctx->c.d_err, 0, 256));
-        if (const char* m = getenv("TDC_GPU_RADIX")) ctx->c.radix_mode = (strcmp(m, "onesweep") == 0) ? 1 : (strcmp(m, "staged") == 0) ? 2 : 0;
+        if (const char* m = getenv("TDC_GPU_RADIX_WAVES")) ctx->c.radix_waves = (atoi(m) == 8) ? 8 : 4;
     } catch (const HipError&) {
         (void)hipGetLastError();
         tdc_gpu_ctx_destroy(ctx);
@@ -283,7 +283,6 @@ void tdc_gpu_ctx_reset_profile(tdc_gpu_ctx* ctx) {
 const char* tdc_gpu_ctx_kernel_profile(const tdc_gpu_ctx* ctx, int idx, double* ms, uint64_t* launches, uint64_t* bytes) {
     static const char* names[K_CLASS_COUNT] = {
         "rs_scatter_kernel<u64>", "rs_scatter_kernel<u32>", "rs_count_kernel", "scan_kernels",
-        "rs_onesweep_kernel<u64>", "rs_onesweep_kernel<u32>", "rs_hist_kernel",
         "sa_update_kernels", "sa_build_keys_kernel", "phi_kernel", "plcp_kernel", "cand_kernels",
         "level_init_kernel", "mis_round_kernel", "resolve_kernel", "push_kernel", "apply_kernel", "pool_kernels",
         "flatten_round_kernel", "gaps_kernel", "literal_hist_kernel", "tile_bits_kernel", "pack_kernel", "extract_kernels" };

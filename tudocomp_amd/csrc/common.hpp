@@ -72,7 +72,7 @@ struct Arena {
 // Live per-kernel timing (bench.py's roofline): HIP events on the launching stream around every launch of the
 // instrumented kernels, resolved after the stream has been synchronised.
 enum KernelClass {
-    K_RS_SCATTER_U64 = 0, K_RS_SCATTER_U32, K_RS_COUNT, K_SCAN, K_RS_ONESWEEP_U64, K_RS_ONESWEEP_U32, K_RS_HIST,
+    K_RS_SCATTER_U64 = 0, K_RS_SCATTER_U32, K_RS_COUNT, K_SCAN,
     K_SA_RANK_SCATTER, K_SA_BUILD_KEYS, K_PHI, K_PLCP, K_CAND,
     K_LEVEL_INIT, K_MIS_ROUND, K_RESOLVE, K_PUSH, K_APPLY, K_POOL,
     K_FLATTEN_ROUND, K_ENC_GAPS, K_ENC_HIST, K_ENC_TILE_BITS, K_ENC_PACK, K_EXTRACT,
@@ -93,8 +93,7 @@ struct Ctx {
     void* pinned = nullptr;        // small pinned staging block for device->host scalars
     size_t pinned_size = 0;
     u32* d_err = nullptr;          // device error word (look-back timeouts etc.), checked at the end of every API call
-    int radix_mode = 0;            // 0: count / scan / scatter (default, fastest measured); 1: single kernel per digit with
-                                   // decoupled look-back; 2: count / scan + LDS-staged scatter   (env TDC_GPU_RADIX)
+    int radix_waves = 4;           // waves per radix-sort workgroup for large inputs (env TDC_GPU_RADIX_WAVES = 4 | 8; no measurable difference)
 
     bool profiling = false;
     KernelProfile kprof[K_CLASS_COUNT];

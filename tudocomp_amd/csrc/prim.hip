@@ -1,7 +1,7 @@
 // prim.hip -- device-wide scans and the stable LSD radix sort (gfx950, wave64).
 //
 // Radix sort layout (one pass = 8 key bits):
-//   rs_count   : one workgroup per 4096-key tile builds a 256-bin LDS histogram -> counts[digit][tile]
+//   rs_count   : one workgroup per tile (4096 or 8192 keys) builds a 256-bin LDS histogram -> counts[digit][tile]
 //   exclusive_sum over counts (digit-major) -> global start of every (digit, tile) run
 //   rs_scatter : the same tiling; ranks inside a tile come from a wave-level match (8 ballots / key) plus
 //                per-wave LDS counters, which keeps the sort stable without any LDS atomics.
@@ -244,16 +244,15 @@ void fill_u8(Ctx& c, u8* p, size_t n, u8 v) {
 // ------------------------------------------------------------------------------------------------
 // radix sort
 // ------------------------------------------------------------------------------------------------
-constexpr int RS_ITEMS = 16;
-constexpr int RS_TILE = 256 * RS_ITEMS;    // 4096 keys per workgroup; wave w owns keys [w*1024, (w+1)*1024)
+constexpr int RS_ITEMS = 16;               // keys per lane; wave w of a workgroup owns keys [w*1024, (w+1)*1024) of the tile
 
-template <typename K>
-__global__ __launch_bounds__(256) void rs_count_kernel(const K* __restrict__ keys, u32* __restrict__ counts, size_t n,
-                                                        u32 numTiles, int shift, u32 dmask) {
+template <typename K, int NW>
+__global__ __launch_bounds__(NW * 64) void rs_count_kernel(const K* __restrict__ keys, u32* __restrict__ counts, size_t n,
+                                                            u32 numTiles, int shift, u32 dmask) {
     __shared__ u32 hist[256];
-    hist[threadIdx.x] = 0;
+    if (threadIdx.x < 256) hist[threadIdx.x] = 0;
     __syncthreads();
-    const size_t tileBase = (size_t)blockIdx.x * RS_TILE + (size_t)wave_id() * (64 * RS_ITEMS) + lane_id();
+    const size_t tileBase = (size_t)blockIdx.x * (NW * 64 * RS_ITEMS) + (size_t)wave_id() * (64 * RS_ITEMS) + lane_id();
 #pragma unroll 4
     for (int j = 0; j < RS_ITEMS; ++j) {
         const size_t idx = tileBase + (size_t)j * 64;
@@ -267,26 +266,25 @@ __global__ __launch_bounds__(256) void rs_count_kernel(const K* __restrict__ key
         }
     }
     __syncthreads();
-    counts[(size_t)threadIdx.x * numTiles + blockIdx.x] = hist[threadIdx.x];
+    if (threadIdx.x < 256) counts[(size_t)threadIdx.x * numTiles + blockIdx.x] = hist[threadIdx.x];
 }
 
-template <typename K>
-__global__ __launch_bounds__(256) void rs_scatter_kernel(const K* __restrict__ keys_in, const u32* __restrict__ vals_in,
-                                                          K* __restrict__ keys_out, u32* __restrict__ vals_out,
-                                                          const u32* __restrict__ offsets, size_t n, u32 numTiles,
-                                                          int shift, u32 dmask) {
-    __shared__ u32 wcnt[4][256];     // per-wave running digit counts
-    __shared__ u32 wbase[4][256];    // global start of (wave, digit) run
+template <typename K, int NW>
+__global__ __launch_bounds__(NW * 64) void rs_scatter_kernel(const K* __restrict__ keys_in, const u32* __restrict__ vals_in,
+                                                              K* __restrict__ keys_out, u32* __restrict__ vals_out,
+                                                              const u32* __restrict__ offsets, size_t n, u32 numTiles,
+                                                              int shift, u32 dmask) {
+    __shared__ u32 wcnt[NW][256];     // per-wave running digit counts
+    __shared__ u32 wbase[NW][256];    // global start of (wave, digit) run
     const int lane = lane_id(), w = wave_id();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) wcnt[i][threadIdx.x] = 0;
+    for (int i = threadIdx.x; i < NW * 256; i += NW * 64) (&wcnt[0][0])[i] = 0;
     __syncthreads();
 
     K k[RS_ITEMS];
     u32 v[RS_ITEMS];
     u32 loc[RS_ITEMS];
     volatile u32* mycnt = wcnt[w];
-    const size_t tileBase = (size_t)blockIdx.x * RS_TILE + (size_t)w * (64 * RS_ITEMS) + lane;
+    const size_t tileBase = (size_t)blockIdx.x * (NW * 64 * RS_ITEMS) + (size_t)w * (64 * RS_ITEMS) + lane;
     const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
     for (int j = 0; j < RS_ITEMS; ++j) {
@@ -308,11 +306,11 @@ __global__ __launch_bounds__(256) void rs_scatter_kernel(const K* __restrict__ k
         if (valid && rank == 0) mycnt[d] = prefix + (u32)__popcll(peers);   // leader = lowest valid lane of the group
     }
     __syncthreads();
-    {
+    if (threadIdx.x < 256) {
         const u32 t = threadIdx.x;
         u32 run = offsets[(size_t)t * numTiles + blockIdx.x];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { wbase[i][t] = run; run += wcnt[i][t]; }
+        for (int i = 0; i < NW; ++i) { wbase[i][t] = run; run += wcnt[i][t]; }
     }
     __syncthreads();
 #pragma unroll
@@ -327,186 +325,27 @@ __global__ __launch_bounds__(256) void rs_scatter_kernel(const K* __restrict__ k
     }
 }
 
-// ---- single kernel per digit: decoupled look-back + LDS-staged, coalesced scatter --------------------------------
-// All digit histograms are taken up front (they are invariant under the permutations of the earlier passes), so a
-// pass only needs the running start of every digit across tiles.  Tiles take their id from an atomic ticket, publish
-// their per-digit counts as ONE 8-byte word {flag, count} (MI355X guide, Guideline 16 form R2: the data is the flag)
-// and look back over their predecessors until they meet an inclusive prefix.  Every spin is bounded.
-constexpr u64 RS_FLAG_AGG = 1ull << 62, RS_FLAG_PREFIX = 2ull << 62, RS_VAL_MASK = (1ull << 62) - 1;
-constexpr u32 RS_SPIN_LIMIT = 1u << 22;
-
-template <typename K>
-__global__ __launch_bounds__(256) void rs_hist_kernel(const K* __restrict__ keys, size_t n, int begin_bit, int end_bit,
-                                                       u32* __restrict__ hist /* [passes][256] */) {
-    __shared__ u32 h[8][256];
-    const int passes = (end_bit - begin_bit + 7) / 8;
-    for (int p = 0; p < passes; ++p) h[p][threadIdx.x] = 0;
-    __syncthreads();
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    const size_t rounds = (n + stride - 1) / stride;
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (size_t r = 0; r < rounds; ++r, i += stride) {        // uniform trip count: the ballots below need all lanes
-        const bool valid = i < n;
-        const K key = valid ? keys[i] : (K)0;
-        for (int p = 0; p < passes; ++p) {
-            const int shift = begin_bit + 8 * p;
-            const int bits = (end_bit - shift) < 8 ? (end_bit - shift) : 8;
-            const u32 d = (u32)((key >> shift) & ((1u << bits) - 1u));
-            const u32 d0 = __builtin_amdgcn_readfirstlane(d);
-            if (__all(valid && d == d0)) { if (lane_id() == 0) atomicAdd(&h[p][d0], 64u); }
-            else if (valid) atomicAdd(&h[p][d], 1u);
-        }
-    }
-    __syncthreads();
-    for (int p = 0; p < passes; ++p) if (h[p][threadIdx.x]) atomicAdd(&hist[p * 256 + threadIdx.x], h[p][threadIdx.x]);
-}
-
-// one workgroup per pass: exclusive scan of its 256 digit counts
-__global__ __launch_bounds__(256) void rs_hist_scan_kernel(u32* __restrict__ hist) {
-    __shared__ u32 sm[5];
-    u32* h = hist + blockIdx.x * 256;
-    u32 total;
-    const u32 e = block_exclusive_sum<u32, 4>(h[threadIdx.x], sm, total);
-    h[threadIdx.x] = e;
-}
-
-// LOOKBACK = false: the same kernel as the scatter half of the classic count / scan / scatter pass (global digit starts
-// of the tile come from the scanned counts, `gbase` = offsets[digit * numTiles + tile]).
-template <typename K, bool LOOKBACK>
-__global__ __launch_bounds__(256) void rs_onesweep_kernel(const K* __restrict__ keys_in, const u32* __restrict__ vals_in,
-                                                           K* __restrict__ keys_out, u32* __restrict__ vals_out, size_t n,
-                                                           int shift, u32 dmask, const u32* __restrict__ gbase, u64* desc,
-                                                           u32* tile_counter, u32* err, u32 numTiles) {
-    __shared__ u32 wcnt[4][256];     // per-wave digit counts, later: start of the wave's run inside the tile's digit run
-    __shared__ u32 tstart[256];      // start of digit d inside the (sorted) tile
-    __shared__ u32 gstart[256];      // global start of the tile's digit-d run
-    __shared__ u32 sscan[5];
-    __shared__ u32 s_tile;
-    __shared__ K skeys[RS_TILE];
-    __shared__ u32 svals[RS_TILE];
-    const int lane = lane_id(), w = wave_id();
-    if (LOOKBACK) { if (threadIdx.x == 0) s_tile = atomicAdd(tile_counter, 1u); }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) wcnt[i][threadIdx.x] = 0;
-    __syncthreads();
-    const u32 tile = LOOKBACK ? s_tile : blockIdx.x;
-
-    K k[RS_ITEMS];
-    u32 v[RS_ITEMS];
-    u32 loc[RS_ITEMS];
-    volatile u32* mycnt = wcnt[w];
-    const size_t tileBase = (size_t)tile * RS_TILE + (size_t)w * (64 * RS_ITEMS) + lane;
-    const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-#pragma unroll
-    for (int j = 0; j < RS_ITEMS; ++j) {
-        const size_t idx = tileBase + (size_t)j * 64;
-        const bool valid = idx < n;
-        k[j] = valid ? keys_in[idx] : (K)0;
-        v[j] = valid ? vals_in[idx] : 0u;
-        const u32 d = (u32)((k[j] >> shift) & dmask);
-        u64 peers = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const bool bit = (d >> b) & 1u;
-            const u64 bal = __ballot(bit);
-            peers &= bit ? bal : ~bal;
-        }
-        const u32 prefix = mycnt[d];
-        const u32 rank = (u32)__popcll(peers & lt_mask);
-        loc[j] = prefix + rank;
-        if (valid && rank == 0) mycnt[d] = prefix + (u32)__popcll(peers);
-    }
-    __syncthreads();
-    {
-        const u32 t = threadIdx.x;                 // this thread owns digit t
-        u32 agg = 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { const u32 cw = wcnt[i][t]; wcnt[i][t] = agg; agg += cw; }
-        u32 total;
-        tstart[t] = block_exclusive_sum<u32, 4>(agg, sscan, total);
-        u64* mine = desc + (size_t)tile * 256 + t;
-        u32 excl = 0;
-        if (!LOOKBACK) {
-            gstart[t] = gbase[(size_t)t * numTiles + tile];
-        } else if (tile == 0) {
-            __hip_atomic_store(mine, RS_FLAG_PREFIX | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            __hip_atomic_store(mine, RS_FLAG_AGG | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            long prev = (long)tile - 1;
-            u32 spins = 0;
-            for (;;) {
-                const u64 d64 = __hip_atomic_load(desc + (size_t)prev * 256 + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const u64 f = d64 >> 62;
-                if (f == 0) {
-                    if (++spins > RS_SPIN_LIMIT) { atomicOr(err, 1u); break; }     // never hang the GPU: report and leave
-                    __builtin_amdgcn_s_sleep(2);
-                    continue;
-                }
-                excl += (u32)(d64 & RS_VAL_MASK);
-                if (f == 2 || prev == 0) break;
-                --prev;
-            }
-            __hip_atomic_store(mine, RS_FLAG_PREFIX | (u64)(excl + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (LOOKBACK) gstart[t] = gbase[t] + excl;
-    }
-    __syncthreads();
-    // stage the tile in sorted order in LDS ...
-#pragma unroll
-    for (int j = 0; j < RS_ITEMS; ++j) {
-        const size_t idx = tileBase + (size_t)j * 64;
-        if (idx < n) {
-            const u32 d = (u32)((k[j] >> shift) & dmask);
-            const u32 tp = tstart[d] + wcnt[w][d] + loc[j];
-            skeys[tp] = k[j];
-            svals[tp] = v[j];
-        }
-    }
-    __syncthreads();
-    // ... and write it out: consecutive LDS slots of one digit go to consecutive global slots
-    const size_t tile0 = (size_t)tile * RS_TILE;
-    const u32 count = (n - tile0 < (size_t)RS_TILE) ? (u32)(n - tile0) : (u32)RS_TILE;
-#pragma unroll
-    for (int r = 0; r < RS_ITEMS; ++r) {
-        const u32 idx = r * 256 + threadIdx.x;
-        if (idx < count) {
-            const K key = skeys[idx];
-            const u32 d = (u32)((key >> shift) & dmask);
-            const u32 dst = gstart[d] + (idx - tstart[d]);
-            keys_out[dst] = key;
-            vals_out[dst] = svals[idx];
-        }
-    }
-}
-
-template <typename K>
-static int radix_sort_onesweep(Ctx& c, K* keys[2], u32* vals[2], size_t n, int begin_bit, int end_bit) {
+template <typename K, int NW>
+static int radix_sort_pairs_nw(Ctx& c, K* keys[2], u32* vals[2], size_t n, int begin_bit, int end_bit) {
     const size_t mark = c.arena.mark();
-    const u32 numTiles = cdiv(n, RS_TILE);
-    const int passes = (end_bit - begin_bit + 7) / 8;
-    u32* hist = c.arena.get<u32>(8 * 256 + 8);          // [passes][256] digit starts, then one tile ticket per pass
-    u32* tickets = hist + 8 * 256;
-    u64* desc = c.arena.get<u64>((size_t)numTiles * 256);
-    HIP_TRY(hipMemsetAsync(hist, 0, (8 * 256 + 8) * sizeof(u32), c.stream));
-    {
-        Ctx::ProfScope prof(c, K_RS_HIST, (u64)n * sizeof(K));
-        unsigned g = cdiv(n, 256 * 8); if (g > 2048) g = 2048; if (g == 0) g = 1;
-        rs_hist_kernel<K><<<g, 256, 0, c.stream>>>(keys[0], n, begin_bit, end_bit, hist);
-        LAUNCH_CHECK();
-        rs_hist_scan_kernel<<<passes, 256, 0, c.stream>>>(hist);
-        LAUNCH_CHECK();
-    }
+    constexpr int TILE = NW * 64 * RS_ITEMS;
+    const u32 numTiles = cdiv(n, TILE);
+    u32* counts = c.arena.get<u32>((size_t)256 * numTiles);
     int cur = 0;
-    for (int p = 0; p < passes; ++p) {
-        const int shift = begin_bit + 8 * p;
+    for (int shift = begin_bit; shift < end_bit; shift += 8) {
         const int bits = (end_bit - shift) < 8 ? (end_bit - shift) : 8;
         const u32 dmask = (1u << bits) - 1u;
-        HIP_TRY(hipMemsetAsync(desc, 0, (size_t)numTiles * 256 * sizeof(u64), c.stream));
-        // algorithmic bytes: every (key, value) pair is read once and written once
-        Ctx::ProfScope prof(c, sizeof(K) == 8 ? K_RS_ONESWEEP_U64 : K_RS_ONESWEEP_U32, (u64)n * 2 * (sizeof(K) + sizeof(u32)));
-        rs_onesweep_kernel<K, true><<<numTiles, 256, 0, c.stream>>>(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, shift, dmask,
-                                                                     hist + p * 256, desc, tickets + p, c.d_err, numTiles);
+        // algorithmic bytes: count reads every key once; scatter reads and writes every (key, value) pair once
+        const int pc = c.prof_begin(K_RS_COUNT, (u64)n * sizeof(K));
+        rs_count_kernel<K, NW><<<numTiles, NW * 64, 0, c.stream>>>(keys[cur], counts, n, numTiles, shift, dmask);
         LAUNCH_CHECK();
+        c.prof_end(pc);
+        exclusive_sum_u32(c, counts, counts, (size_t)256 * numTiles, nullptr);
+        const int ps = c.prof_begin(sizeof(K) == 8 ? K_RS_SCATTER_U64 : K_RS_SCATTER_U32, (u64)n * 2 * (sizeof(K) + sizeof(u32)));
+        rs_scatter_kernel<K, NW><<<numTiles, NW * 64, 0, c.stream>>>(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], counts, n,
+                                                                      numTiles, shift, dmask);
+        LAUNCH_CHECK();
+        c.prof_end(ps);
         cur ^= 1;
     }
     c.arena.release(mark);
@@ -516,33 +355,10 @@ static int radix_sort_onesweep(Ctx& c, K* keys[2], u32* vals[2], size_t n, int b
 template <typename K>
 static int radix_sort_pairs(Ctx& c, K* keys[2], u32* vals[2], size_t n, int begin_bit, int end_bit) {
     if (n == 0 || end_bit <= begin_bit) return 0;
-    if (c.radix_mode == 1 && c.d_err && end_bit - begin_bit <= 64) return radix_sort_onesweep<K>(c, keys, vals, n, begin_bit, end_bit);
-    const size_t mark = c.arena.mark();
-    const u32 numTiles = cdiv(n, RS_TILE);
-    u32* counts = c.arena.get<u32>((size_t)256 * numTiles);
-    int cur = 0;
-    for (int shift = begin_bit; shift < end_bit; shift += 8) {
-        const int bits = (end_bit - shift) < 8 ? (end_bit - shift) : 8;
-        const u32 dmask = (1u << bits) - 1u;
-        // algorithmic bytes: count reads every key once; scatter reads and writes every (key, value) pair once
-        const int pc = c.prof_begin(K_RS_COUNT, (u64)n * sizeof(K));
-        rs_count_kernel<K><<<numTiles, 256, 0, c.stream>>>(keys[cur], counts, n, numTiles, shift, dmask);
-        LAUNCH_CHECK();
-        c.prof_end(pc);
-        exclusive_sum_u32(c, counts, counts, (size_t)256 * numTiles, nullptr);
-        const int ps = c.prof_begin(sizeof(K) == 8 ? K_RS_SCATTER_U64 : K_RS_SCATTER_U32, (u64)n * 2 * (sizeof(K) + sizeof(u32)));
-        if (c.radix_mode == 2)      // classic count + scan, LDS-staged coalesced scatter
-            rs_onesweep_kernel<K, false><<<numTiles, 256, 0, c.stream>>>(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, shift,
-                                                                          dmask, counts, nullptr, nullptr, nullptr, numTiles);
-        else
-            rs_scatter_kernel<K><<<numTiles, 256, 0, c.stream>>>(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], counts, n,
-                                                                  numTiles, shift, dmask);
-        LAUNCH_CHECK();
-        c.prof_end(ps);
-        cur ^= 1;
-    }
-    c.arena.release(mark);
-    return cur;
+    // large inputs: 8 waves per workgroup (8192-key tiles: longer per-digit runs, half the count array);
+    // small inputs: 4 waves (more workgroups to fill the 256 CUs)
+    if (c.radix_waves == 8 && n >= ((size_t)1 << 22)) return radix_sort_pairs_nw<K, 8>(c, keys, vals, n, begin_bit, end_bit);
+    return radix_sort_pairs_nw<K, 4>(c, keys, vals, n, begin_bit, end_bit);
 }
 
 int radix_sort_pairs_u64(Ctx& c, u64* keys[2], u32* vals[2], size_t n, int b, int e) { return radix_sort_pairs<u64>(c, keys, vals, n, b, e); }
