@@ -35,8 +35,8 @@ typedef enum {
     TDC_GPU_ERR_INTERNAL = -7      /* invariant violated */
 } tdc_gpu_status;
 
-/* coder ids (option `coder` of lcpcomp, etc/registry_config.py:138-142) */
-enum { TDC_GPU_CODER_HUFF = 0 };
+/* coder ids (option `coder`, etc/registry_config.py:28-31,138-142) */
+enum { TDC_GPU_CODER_HUFF = 0, TDC_GPU_CODER_GAMMA = 1 };
 
 typedef struct tdc_gpu_ctx tdc_gpu_ctx;
 
@@ -90,6 +90,13 @@ int tdc_gpu_lcpcomp_compress(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, ui
 int tdc_gpu_lcpcomp_compress_dev(tdc_gpu_ctx* ctx, const void* d_text, size_t n, uint32_t threshold, int flatten,
                                  int coder, void* d_out, size_t out_cap, size_t* out_len, tdc_gpu_stats* stats);
 size_t tdc_gpu_lcpcomp_bound(size_t n);
+
+/* ---- LZ78 (BASELINE.json configs[3]): replaces LZ78Compressor<EliasGammaCoder, ...>::compress
+ * (compressors/LZ78Compressor.hpp:64-140).  No input restrictions (no escaping, no sentinel).  The parse is sequential
+ * and runs on the host; the Elias-gamma stream is packed on the GPU.  coder must be TDC_GPU_CODER_GAMMA.
+ * stats (may be NULL): n, out_len, factors (= number of phrases) and ms_encode / ms_total are filled. */
+int tdc_gpu_lz78_compress(tdc_gpu_ctx* ctx, const uint8_t* in, size_t n, int coder, uint8_t** out, size_t* out_len,
+                          tdc_gpu_stats* stats);
 
 /* ---- stage-level entry points (host buffers), used by the parity tests ------------------------------------ */
 /* ds/SADivSufSort.hpp:27-51 + ds/ISAFromSA.hpp:30-43 : sa / isa may be NULL */

@@ -46,12 +46,24 @@ def test_decompress_reads_header(tmp_path):
     assert _run("-d", "-o", str(out), str(f)).returncode == 1
 
 
+def test_lz78_decompress(tmp_path):
+    data = T.gen_english(3000, 9).tobytes() + bytes(range(256))
+    payload = O.lz78_gamma_compress(data[:-128])             # keep the left-over phrase ASCII
+    f = tmp_path / "z.tdc"
+    f.write_bytes(b"lz78(coder=gamma)%" + payload)
+    out = tmp_path / "z.out"
+    assert _run("-d", "-o", str(out), str(f)).returncode == 0
+    assert out.read_bytes() == data[:-128]
+
+
 def test_errors(tmp_path):
     f = tmp_path / "in.txt"
     f.write_bytes(b"no header here")
     r = _run("-d", "-o", str(tmp_path / "o"), str(f))
     assert r.returncode == 1 and "algorithm header" in r.stderr
-    r = _run("-a", "lz78(coder=gamma)", "-o", str(tmp_path / "o2"), str(f))
+    r = _run("-a", "lz78(coder=bit)", "-o", str(tmp_path / "o2"), str(f))
+    assert r.returncode == 1 and "No implementation found" in r.stderr
+    r = _run("-a", "lzss_lcp(coder=huff)", "-o", str(tmp_path / "o4"), str(f))
     assert r.returncode == 1 and "No implementation found" in r.stderr
     r = _run("-a", "lcpcomp(coder=arithmetic)", "-o", str(tmp_path / "o3"), str(f))
     assert r.returncode == 1 and "No implementation found" in r.stderr
@@ -71,4 +83,17 @@ def test_config0_compress_roundtrip_64KiB(tmp_path):
     assert '"factors"' in r.stdout
     out = tmp_path / "back.txt"
     assert _run("-d", "-o", str(out), str(tmp_path / "english64k.txt.tdc")).returncode == 0
+    assert out.read_bytes() == data
+
+
+@pytest.mark.gpu
+def test_config3_lz78_gamma_cli(tmp_path):
+    data = T.gen_english(65536, 42).tobytes()
+    f = tmp_path / "e.txt"
+    f.write_bytes(data)
+    assert _run("-a", "lz78(coder=gamma)", str(f)).returncode == 0
+    comp = (tmp_path / "e.txt.tdc").read_bytes()
+    assert comp == b"lz78(coder=gamma)%" + O.lz78_gamma_compress(data)
+    out = tmp_path / "e.back"
+    assert _run("-d", "-o", str(out), str(tmp_path / "e.txt.tdc")).returncode == 0
     assert out.read_bytes() == data

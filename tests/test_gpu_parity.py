@@ -147,3 +147,27 @@ def test_error_codes(gpu_ctx):
     # the context is still usable afterwards
     want, _ = O.lcpcomp_huff_compress(b"abcabc\x00", 2, 1)
     assert gpu_ctx.lcpcomp_compress(b"abcabc\x00", 2, 1)[0] == want
+
+
+# ---- BASELINE.json configs[3]: lz78(coder=gamma) ----------------------------------------------------------------
+@pytest.mark.parametrize("a", ANCH["lz78_gamma"], ids=lambda a: a["text"])
+def test_lz78_gamma_reference_anchors(gpu_ctx, a):
+    t = ANCH["texts"][a["text"]]
+    data = T.gen_english(t["n"], t["seed"]).tobytes()
+    out = T.LZ78Compressor(gpu_ctx, coder="gamma").compress(data)
+    assert len(out) == a["size"] and sha256(out) == a["sha256"]
+
+
+def test_lz78_gamma_bitexact(gpu_ctx):
+    cases = [(n, d) for n, d in SMALL if not d or d[-1] < 0x80] + corpus.random_small(100, seed=3)
+    for name, data in cases:
+        if data and data[-1] >= 0x80:
+            continue                                  # left-over phrase as signed char: undefined in the reference
+        got, st = gpu_ctx.lz78_compress(data)
+        assert got == O.lz78_gamma_compress(data), name
+        ids, _ = O.lz78_factors(data)
+        assert st["factors"] == len(ids)
+    big = T.gen_dna(1 << 22, 7).tobytes()
+    assert gpu_ctx.lz78_compress(big)[0] == O.lz78_gamma_compress(big)
+    with pytest.raises(RuntimeError, match="No implementation found"):
+        T.LZ78Compressor(gpu_ctx, coder="bit")

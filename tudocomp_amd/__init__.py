@@ -12,6 +12,7 @@ from . import _native
 from ._native import Stats, LIB_PATH, SYMBOLS  # noqa: F401
 
 CODER_HUFF = 0
+CODER_GAMMA = 1
 
 
 class TdcGpuError(RuntimeError):
@@ -143,6 +144,14 @@ class Context:
                                                          ctypes.byref(st)))
         return ol.value, st.as_dict()
 
+    def lz78_compress(self, data, coder=CODER_GAMMA):
+        """LZ78Compressor<EliasGammaCoder>::compress on raw bytes (no escaping).  Returns (stream, stats)."""
+        a = _u8(data)
+        out, n, st = ctypes.c_void_p(), ctypes.c_size_t(), Stats()
+        self._check(self._L.tdc_gpu_lz78_compress(self._h, _ptr(a), len(a), coder, ctypes.byref(out), ctypes.byref(n),
+                                                  ctypes.byref(st)))
+        return self._take(out, n.value), st.as_dict()
+
     def bound(self, n):
         return self._L.tdc_gpu_lcpcomp_bound(n)
 
@@ -208,5 +217,20 @@ class LCPCompressor:
 
     def compress(self, data):
         out, st = self.ctx.lcpcomp_compress(escape(data), self.threshold, self.flatten)
+        self.last_stats = st
+        return out
+
+
+class LZ78Compressor:
+    """Mirror of tdc::LZ78Compressor<coder, trie> (compressors/LZ78Compressor.hpp:45-161); no input restrictions."""
+
+    def __init__(self, ctx, coder="gamma", lz78trie="ternary"):
+        if coder != "gamma":
+            raise RuntimeError("No implementation found for compressor lz78(coder=%s,lz78trie=%s)" % (coder, lz78trie))
+        self.ctx = ctx
+        self.last_stats = None
+
+    def compress(self, data):
+        out, st = self.ctx.lz78_compress(data)
         self.last_stats = st
         return out

@@ -6,6 +6,7 @@
 
 #include <new>
 #include <string>
+#include <vector>
 #include <stdlib.h>
 #include <string.h>
 
@@ -341,6 +342,47 @@ int tdc_gpu_lcpcomp_compress(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, ui
         HIP_TRY(hipMemcpyAsync(h, d_out, len, hipMemcpyDeviceToHost, c.stream));
         const int e3 = ev.tick();
         if (stats) { ev.span(&stats->ms_h2d, e0, e1); ev.span(&stats->ms_d2h, e2, e3); ev.span(&stats->ms_total, e0, e3); }
+        ev.finish();
+        *out = h; *out_len = len;
+    });
+}
+
+int tdc_gpu_lz78_compress(tdc_gpu_ctx* ctx, const uint8_t* in, size_t n, int coder, uint8_t** out, size_t* out_len,
+                          tdc_gpu_stats* stats) {
+    return guarded(ctx, [&] {
+        if (coder != TDC_GPU_CODER_GAMMA) throw ArgError{TDC_GPU_ERR_UNSUPPORTED, "lz78: only coder=gamma is built"};
+        if ((!in && n) || !out || !out_len) throw ArgError{TDC_GPU_ERR_ARG, "NULL argument"};
+        if (n >= 0xFFFFFFFFull) throw ArgError{TDC_GPU_ERR_TOO_LARGE, "lz78: input must be < 2^32 bytes"};
+        Ctx& c = ctx->c;
+        if (stats) memset(stats, 0, sizeof(*stats));
+        std::vector<u32> ids;
+        std::vector<u8> chars;
+        bool high = false;
+        const size_t z = lz78_parse_host(in, n, ids, chars, &high);
+        if (high) throw ArgError{TDC_GPU_ERR_UNSUPPORTED,
+            "lz78: the left-over phrase ends in a byte >= 0x80; the reference encodes it as a signed char (undefined shifts) -- not reproduced"};
+        // arena: pairs (5 B each) + tile sums + worst-case output (2*33+2*9 bits = 84 bits < 11 B per pair)
+        const size_t cap = align_up(z * 11 + 64, 8);
+        c.ensure_arena(z * 5 + cap + ((size_t)64 << 20));
+        Events ev(c);
+        const int e0 = ev.tick();
+        u32* d_ids = c.arena.get<u32>(z + 1);
+        u8* d_chars = c.arena.get<u8>(z + 8);
+        u8* d_out = c.arena.get<u8>(cap);
+        if (z) {
+            HIP_TRY(hipMemcpyAsync(d_ids, ids.data(), z * 4, hipMemcpyHostToDevice, c.stream));
+            HIP_TRY(hipMemcpyAsync(d_chars, chars.data(), z, hipMemcpyHostToDevice, c.stream));
+        }
+        const int e1 = ev.tick();
+        const size_t len = lz78_gamma_encode(c, d_ids, d_chars, z, d_out, cap);
+        const int e2 = ev.tick();
+        uint8_t* h = host_alloc<uint8_t>(len);
+        HIP_TRY(hipMemcpyAsync(h, d_out, len, hipMemcpyDeviceToHost, c.stream));
+        const int e3 = ev.tick();
+        if (stats) {
+            stats->n = n; stats->out_len = len; stats->factors = z; stats->arena_bytes = c.arena.high;
+            ev.span(&stats->ms_h2d, e0, e1); ev.span(&stats->ms_encode, e1, e2); ev.span(&stats->ms_d2h, e2, e3); ev.span(&stats->ms_total, e0, e3);
+        }
         ev.finish();
         *out = h; *out_len = len;
     });

@@ -58,3 +58,11 @@ size_t encode_huff(Ctx& c, const u8* text, size_t n, FactorSpace fs, u8* d_out, 
 size_t encode_bound(size_t n);
 
 }  // namespace tdc
+#include <vector>
+namespace tdc {
+// a17: compressors/LZ78Compressor.hpp:64-140 -- sequential parse on the host; returns the number of (id, char) pairs
+size_t lz78_parse_host(const u8* in, size_t n, std::vector<u32>& ids, std::vector<u8>& chars, bool* leftover_is_high);
+// a16: coders/EliasGammaCoder.hpp:26-29 + io/BitOStream.hpp:105-129 on the device; returns the stream length
+size_t lz78_gamma_encode(Ctx& c, const u32* d_ids, const u8* d_chars, size_t z, u8* d_out, size_t out_cap);
+
+}  // namespace tdc

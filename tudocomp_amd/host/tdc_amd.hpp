@@ -279,6 +279,51 @@ public:
     }
 };
 
+// tdc::LZ78Compressor<EliasGammaCoder, trie>  (compressors/LZ78Compressor.hpp:45-161): no input restrictions.
+class LZ78Compressor : public Compressor {
+    AlgorithmValue m_opts;
+    std::shared_ptr<GpuContext> m_ctx;
+    int m_device = 0;
+public:
+    tdc_gpu_stats last_stats{};
+    void set_device(int d) { m_device = d; }
+    LZ78Compressor(AlgorithmValue opts, std::shared_ptr<GpuContext> ctx) : m_opts(std::move(opts)), m_ctx(std::move(ctx)) {
+        const std::string coder = m_opts.get("coder", "bit");                 // the reference's default coder is BitCoder
+        if (coder != "gamma")
+            throw std::runtime_error("No implementation found for compressor lz78(coder=" + coder + ")");   // Registry.hpp:214
+    }
+    void compress(Input& input, Output& output) override {
+        if (!m_ctx) m_ctx = std::make_shared<GpuContext>(m_device);
+        const bytes& in = input.raw();
+        uint8_t* out = nullptr; size_t out_len = 0;
+        const int rc = tdc_gpu_lz78_compress(m_ctx->h, in.data(), in.size(), TDC_GPU_CODER_GAMMA, &out, &out_len, &last_stats);
+        if (rc) throw std::runtime_error(std::string(tdc_gpu_strerror(rc)) + ": " + tdc_gpu_last_error(m_ctx->h));
+        output.write(out, out_len);
+        tdc_gpu_free(out);
+    }
+    // LZ78Compressor::decompress (:142-160) with EliasGammaCoder::Decoder: pairs until BitIStream eof
+    void decompress(Input& input, Output& output) override {
+        const bytes& in = input.raw();
+        BitIStream bs(in.data(), in.size());
+        std::vector<uint32_t> parent(1, 0);
+        std::vector<uint8_t> chr(1, 0);
+        bytes text, tmp;
+        auto gamma = [&]() -> uint64_t { unsigned b = 0; while (!bs.read_bit()) { if (++b > 64) throw std::runtime_error("corrupt gamma code"); } return bs.read_int(b); };
+        while (!bs.eof()) {
+            const uint64_t id = gamma();
+            const uint64_t c = gamma();
+            if (id >= parent.size()) throw std::runtime_error("corrupt stream: unknown phrase id");
+            tmp.clear();
+            for (uint64_t x = id; x != 0; x = parent[x]) tmp.push_back(chr[x]);
+            text.insert(text.end(), tmp.rbegin(), tmp.rend());
+            text.push_back((uint8_t)c);
+            parent.push_back((uint32_t)id);
+            chr.push_back((uint8_t)c);
+        }
+        output.write(text.data(), text.size());
+    }
+};
+
 // ---- registry (what is actually registered; Registry.hpp:204-231) ---------------------------------------------
 struct Selection {
     std::string id_string;
@@ -287,14 +332,21 @@ struct Selection {
 };
 
 inline std::vector<std::string> registered_algorithms() {
-    return { "lcpcomp(coder=huff, comp=arrays, dec=scan(scans=6), threshold=5, flatten=1)   [MI355X, libtdc_gpu.so]" };
+    return { "lcpcomp(coder=huff, comp=arrays, dec=scan(scans=6), threshold=5, flatten=1)   [MI355X, libtdc_gpu.so]",
+             "lz78(coder=gamma)                                                           [host parse + MI355X gamma packer]" };
 }
 
 inline Selection select_algorithm(const std::string& id, std::shared_ptr<GpuContext> ctx = nullptr, int device = 0) {
     AlgorithmValue av = parse_algorithm_id(id, {"coder", "comp", "dec", "textds"});
-    if (av.name != "lcpcomp") throw std::runtime_error("No implementation found for compressor " + id);
     Selection s;
     s.id_string = id;
+    if (av.name == "lz78") {
+        auto z = std::make_unique<LZ78Compressor>(parse_algorithm_id(id, {"coder", "lz78trie"}), std::move(ctx));
+        z->set_device(device);
+        s.compressor = std::move(z);
+        return s;
+    }
+    if (av.name != "lcpcomp") throw std::runtime_error("No implementation found for compressor " + id);
     auto c = std::make_unique<LCPCompressor>(av, std::move(ctx));
     c->set_device(device);
     s.restrictions = c->input_restrictions();

@@ -93,8 +93,7 @@ int main(int argc, char** argv) {
             std::printf("{\"meta\":{\"config\":\"%s\",\"input\":\"%s\",\"inputSize\":%zu,\"output\":\"%s\",\"outputSize\":%zu,"
                         "\"rate\":%.6f},\"timeTotalMs\":%.3f", algo.c_str(), file.c_str(), in_size, ofile.c_str(), result.size(),
                         in_size ? (double)result.size() / (double)in_size : 0.0, ms);
-            if (!decompress) {
-                auto* c = dynamic_cast<LCPCompressor*>(sel.compressor.get());
+            if (auto* c = decompress ? nullptr : dynamic_cast<LCPCompressor*>(sel.compressor.get())) {
                 const tdc_gpu_stats& st = c->last_stats;
                 std::printf(",\"stats\":{\"factors\":%llu,\"maxlcp\":%llu,\"entries\":%llu,\"num_flattened\":%llu,\"max_depth_lb\":%llu,"
                             "\"gpu_ms\":{\"sa\":%.3f,\"phi\":%.3f,\"plcp\":%.3f,\"factorize\":%.3f,\"flatten\":%.3f,\"encode\":%.3f,\"total\":%.3f}}",
