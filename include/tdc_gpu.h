@@ -98,6 +98,15 @@ size_t tdc_gpu_lcpcomp_bound(size_t n);
 int tdc_gpu_lz78_compress(tdc_gpu_ctx* ctx, const uint8_t* in, size_t n, int coder, uint8_t** out, size_t* out_len,
                           tdc_gpu_stats* stats);
 
+/* ---- lzss_lcp (SURVEY.md 8a row a18 / 8f "next" #1): replaces LZSSLCPCompressor<HuffmanCoder>::compress
+ * (compressors/LZSSLCPCompressor.hpp:41-123): greedy LZ77 parse via previous / next smaller values of the suffix array.
+ * Same text contract as lcpcomp (escaped, 0-terminated); option threshold (default 3, :30). */
+int tdc_gpu_lzss_lcp_compress(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, uint32_t threshold, int coder,
+                              uint8_t** out, size_t* out_len, tdc_gpu_stats* stats);
+/* the factor list of LZSSLCPCompressor.hpp:60-115 (sorted by pos), three malloc'd arrays */
+int tdc_gpu_lzss_lcp_factorize(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, uint32_t threshold,
+                               uint32_t** pos, uint32_t** src, uint32_t** len, size_t* z);
+
 /* ---- stage-level entry points (host buffers), used by the parity tests ------------------------------------ */
 /* ds/SADivSufSort.hpp:27-51 + ds/ISAFromSA.hpp:30-43 : sa / isa may be NULL */
 int tdc_gpu_suffix_array(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, uint32_t* sa, uint32_t* isa);

@@ -80,6 +80,11 @@ def lib():
                                       ctypes.POINTER(sz), ctypes.POINTER(Stats)]
         L.orc_lcpcomp_huff_decompress.argtypes = [ctypes.c_void_p, sz, ctypes.POINTER(ctypes.c_void_p),
                                                   ctypes.POINTER(sz)]
+        L.orc_lzss_lcp_factorize.restype = sz
+        L.orc_lzss_lcp_factorize.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, sz, ctypes.c_uint32,
+                                             ctypes.POINTER(ctypes.c_void_p)]
+        L.orc_lzss_lcp_huff_compress.argtypes = [ctypes.c_void_p, sz, ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p),
+                                                 ctypes.POINTER(sz), ctypes.POINTER(Stats)]
         L.orc_huff_encode_literals.argtypes = [ctypes.c_void_p, sz, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p),
                                                ctypes.POINTER(sz)]
         L.orc_bitstream_script.argtypes = [ctypes.c_void_p, sz, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(sz)]
@@ -214,6 +219,23 @@ def encode_huff(text, f):
     rc = lib().orc_encode_huff(p, len(a), f.ctypes.data_as(ctypes.c_void_p), len(f), ctypes.byref(out), ctypes.byref(n), ctypes.byref(st))
     if rc:
         raise RuntimeError("orc_encode_huff rc=%d" % rc)
+    return _take(out, n.value), st.as_dict()
+
+
+def lzss_lcp_factorize(sa, isa, lcp, threshold):
+    out = ctypes.c_void_p()
+    z = lib().orc_lzss_lcp_factorize(sa.ctypes.data_as(ctypes.c_void_p), isa.ctypes.data_as(ctypes.c_void_p),
+                                     lcp.ctypes.data_as(ctypes.c_void_p), len(sa), threshold, ctypes.byref(out))
+    raw = _take(out, z * 12) if out.value else b""
+    return np.frombuffer(raw, dtype=FACTOR_DTYPE).copy()
+
+
+def lzss_lcp_huff_compress(text, threshold=3):
+    a, p = _buf(text)
+    out, n, st = ctypes.c_void_p(), ctypes.c_size_t(), Stats()
+    rc = lib().orc_lzss_lcp_huff_compress(p, len(a), threshold, ctypes.byref(out), ctypes.byref(n), ctypes.byref(st))
+    if rc:
+        raise RuntimeError("orc_lzss_lcp_huff_compress rc=%d" % rc)
     return _take(out, n.value), st.as_dict()
 
 

@@ -714,6 +714,73 @@ int orc_lcpcomp_huff_compress(const uint8_t* text, size_t n, uint32_t threshold,
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * compressors/LZSSLCPCompressor.hpp:60-115  (lzss_lcp): for every text position the nearest SA neighbours that start
+ * EARLIER in the text (previous / next smaller value in SA), with the LCP minimum on the way; the longer one wins
+ * (ties: the upward / PSV side), then the parse jumps over the factor.
+ * ---------------------------------------------------------------------------------------------- */
+size_t orc_lzss_lcp_factorize(const uint32_t* sa, const uint32_t* isa, const uint32_t* lcp, size_t n, uint32_t threshold,
+                              orc_factor** out) {
+    size_t z = 0, zcap = 1024;
+    orc_factor* F = (orc_factor*)malloc(zcap * sizeof(orc_factor));
+    for (size_t i = 0; i + 1 < n;) {                                       /* :62 */
+        const size_t cur_pos = isa[i];
+        size_t psv_lcp = lcp[cur_pos];                                      /* :71-77 */
+        long long psv_pos = (long long)cur_pos - 1;
+        if (psv_lcp > 0) {
+            while (psv_pos >= 0 && sa[psv_pos] > sa[cur_pos]) {
+                const size_t l = lcp[psv_pos--];
+                if (l < psv_lcp) psv_lcp = l;
+            }
+        }
+        size_t nsv_lcp = 0;                                                 /* :82-96 */
+        size_t nsv_pos = cur_pos + 1;
+        if (nsv_pos < n) {
+            nsv_lcp = (size_t)-1 >> 1;
+            do {
+                if (lcp[nsv_pos] < nsv_lcp) nsv_lcp = lcp[nsv_pos];
+                if (sa[nsv_pos] < sa[cur_pos]) break;
+            } while (++nsv_pos < n);
+            if (nsv_pos >= n) nsv_lcp = 0;
+        }
+        const size_t max_lcp = psv_lcp > nsv_lcp ? psv_lcp : nsv_lcp;       /* :99 */
+        if (max_lcp >= threshold) {
+            const long long max_pos = (max_lcp == psv_lcp) ? psv_pos : (long long)nsv_pos;   /* :101 */
+            if (z == zcap) { zcap *= 2; F = (orc_factor*)realloc(F, zcap * sizeof(orc_factor)); }
+            F[z].pos = (uint32_t)i; F[z].src = sa[max_pos]; F[z].len = (uint32_t)max_lcp; ++z;   /* :105 */
+            i += max_lcp;
+        } else ++i;
+    }
+    *out = F;
+    return z;
+}
+
+int orc_lzss_lcp_huff_compress(const uint8_t* text, size_t n, uint32_t threshold, uint8_t** out, size_t* out_len, orc_stats* stats) {
+    orc_stats local; if (!stats) stats = &local;
+    memset(stats, 0, sizeof(*stats));
+    stats->n = n;
+    if (n == 0 || text[n - 1] != 0) return -3;
+    const double t0 = now_s();
+    uint32_t* sa = (uint32_t*)malloc(n * 4), *isa = (uint32_t*)malloc(n * 4);
+    uint32_t* phi = (uint32_t*)malloc(n * 4), *lcp = (uint32_t*)malloc(n * 4);
+    if (!sa || !isa || !phi || !lcp) { free(sa); free(isa); free(phi); free(lcp); return -1; }
+    int rc = orc_suffix_array(text, n, sa);
+    if (rc) { free(sa); free(isa); free(phi); free(lcp); return rc; }
+    orc_phi(sa, n, phi);
+    stats->maxlcp = orc_plcp(text, n, phi, phi);
+    orc_lcp(sa, phi, n, lcp);
+    orc_isa(sa, n, isa);
+    free(phi);
+    orc_factor* F = NULL;
+    const size_t z = orc_lzss_lcp_factorize(sa, isa, lcp, n, threshold, &F);
+    free(sa); free(isa); free(lcp);
+    stats->factors = z;
+    rc = orc_encode_huff(text, n, F, z, out, out_len, stats);
+    free(F);
+    stats->t_total = now_s() - t0;
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------------
  * Decoder: HuffmanCoder::Decoder (HuffmanCoder.hpp:572-612) + lcpcomp::decode_text_internal
  * (LCPCompressor.hpp:23-76).  The reference resolves forward references with ScanDec; the decoded
  * text is unique, so references are resolved here by following source chains.

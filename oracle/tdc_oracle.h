@@ -102,6 +102,13 @@ int orc_bitstream_script(const uint64_t* ops, size_t n_ops, uint8_t** out, size_
 /* io/BitIStream.hpp: count the bits readable until eof() (tudocomp_tests.cpp:700-727) */
 size_t orc_bitstream_count_bits(const uint8_t* in, size_t n);
 
+/* compressors/LZSSLCPCompressor.hpp:60-115 : greedy left-to-right LZ77 via ISA + naive PSV/NSV scans over SA/LCP.
+ * Factors come out sorted by pos.  Returns #factors, *out malloc'd. */
+size_t orc_lzss_lcp_factorize(const uint32_t* sa, const uint32_t* isa, const uint32_t* lcp, size_t n, uint32_t threshold,
+                              orc_factor** out);
+/* LZSSLCPCompressor::compress (:41-123) with coder = HuffmanCoder (default threshold 3, no flatten). */
+int orc_lzss_lcp_huff_compress(const uint8_t* text, size_t n, uint32_t threshold, uint8_t** out, size_t* out_len, orc_stats* stats);
+
 /* compressors/LZ78Compressor.hpp:64-140 + coders/EliasGammaCoder.hpp:26-29 (config 4) */
 int orc_lz78_gamma_compress(const uint8_t* in, size_t n, uint8_t** out, size_t* out_len);
 /* LZ78 factor list (parent id, char) for the cedar_tests KATs; returns #pairs, arrays malloc'd */

@@ -46,6 +46,16 @@ def test_decompress_reads_header(tmp_path):
     assert _run("-d", "-o", str(out), str(f)).returncode == 1
 
 
+def test_lzss_lcp_decompress(tmp_path):
+    data = T.gen_english(4000, 5).tobytes() + b"\x00\xff"
+    payload, _ = O.lzss_lcp_huff_compress(O.escape(data), 3)
+    f = tmp_path / "l.tdc"
+    f.write_bytes(b"lzss_lcp(coder=huff)%" + payload)
+    out = tmp_path / "l.out"
+    assert _run("-d", "-o", str(out), str(f)).returncode == 0
+    assert out.read_bytes() == data
+
+
 def test_lz78_decompress(tmp_path):
     data = T.gen_english(3000, 9).tobytes() + bytes(range(256))
     payload = O.lz78_gamma_compress(data[:-128])             # keep the left-over phrase ASCII
@@ -63,7 +73,9 @@ def test_errors(tmp_path):
     assert r.returncode == 1 and "algorithm header" in r.stderr
     r = _run("-a", "lz78(coder=bit)", "-o", str(tmp_path / "o2"), str(f))
     assert r.returncode == 1 and "No implementation found" in r.stderr
-    r = _run("-a", "lzss_lcp(coder=huff)", "-o", str(tmp_path / "o4"), str(f))
+    r = _run("-a", "lzss_lcp(coder=sle)", "-o", str(tmp_path / "o4"), str(f))
+    assert r.returncode == 1 and "No implementation found" in r.stderr
+    r = _run("-a", "lzw(coder=huff)", "-o", str(tmp_path / "o5"), str(f))
     assert r.returncode == 1 and "No implementation found" in r.stderr
     r = _run("-a", "lcpcomp(coder=arithmetic)", "-o", str(tmp_path / "o3"), str(f))
     assert r.returncode == 1 and "No implementation found" in r.stderr
@@ -94,6 +106,19 @@ def test_config3_lz78_gamma_cli(tmp_path):
     assert _run("-a", "lz78(coder=gamma)", str(f)).returncode == 0
     comp = (tmp_path / "e.txt.tdc").read_bytes()
     assert comp == b"lz78(coder=gamma)%" + O.lz78_gamma_compress(data)
+    out = tmp_path / "e.back"
+    assert _run("-d", "-o", str(out), str(tmp_path / "e.txt.tdc")).returncode == 0
+    assert out.read_bytes() == data
+
+
+@pytest.mark.gpu
+def test_lzss_lcp_cli(tmp_path):
+    data = T.gen_english(65536, 42).tobytes()
+    f = tmp_path / "e.txt"
+    f.write_bytes(data)
+    assert _run("-a", "lzss_lcp(coder=huff,threshold=3)", str(f)).returncode == 0
+    comp = (tmp_path / "e.txt.tdc").read_bytes()
+    assert comp == b"lzss_lcp(coder=huff,threshold=3)%" + O.lzss_lcp_huff_compress(O.escape(data), 3)[0]
     out = tmp_path / "e.back"
     assert _run("-d", "-o", str(out), str(tmp_path / "e.txt.tdc")).returncode == 0
     assert out.read_bytes() == data

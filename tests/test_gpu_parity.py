@@ -171,3 +171,35 @@ def test_lz78_gamma_bitexact(gpu_ctx):
     assert gpu_ctx.lz78_compress(big)[0] == O.lz78_gamma_compress(big)
     with pytest.raises(RuntimeError, match="No implementation found"):
         T.LZ78Compressor(gpu_ctx, coder="bit")
+
+
+# ---- lzss_lcp(coder=huff) -----------------------------------------------------------------------
+@pytest.mark.parametrize("name,data", SMALL, ids=IDS)
+def test_lzss_lcp_small(gpu_ctx, name, data):
+    text = O.escape(data)
+    sa, isa, phi, plcp, lcp, maxlcp = _oracle_stages(text)
+    for thr in (1, 2, 3, 5):
+        ref = O.lzss_lcp_factorize(sa, isa, lcp, thr)
+        pos, src, ln = gpu_ctx.lzss_lcp_factorize(text, thr)
+        _eq("pos t=%d" % thr, pos, ref["pos"])
+        _eq("len t=%d" % thr, ln, ref["len"])
+        _eq("src t=%d" % thr, src, ref["src"])
+        want, _ = O.lzss_lcp_huff_compress(text, thr)
+        got, st = gpu_ctx.lzss_lcp_compress(text, thr)
+        assert got == want and st["factors"] == len(ref)
+
+
+def test_lzss_lcp_random_and_medium(gpu_ctx):
+    for name, data in corpus.random_small(200, seed=17):
+        text = O.escape(data)
+        for thr in (1, 3):
+            assert gpu_ctx.lzss_lcp_compress(text, thr)[0] == O.lzss_lcp_huff_compress(text, thr)[0], (name, thr, data)
+    for gen, n in (("english", 1 << 22), ("dna", 1 << 21), ("english", 3 << 20)):
+        data = (T.gen_english(n, 42) if gen == "english" else T.gen_dna(n, 7)).tobytes()
+        text = O.escape(data)
+        want, wst = O.lzss_lcp_huff_compress(text, 3)
+        got, st = gpu_ctx.lzss_lcp_compress(text, 3)
+        assert sha256(got) == sha256(want) and st["factors"] == wst["factors"]
+        assert O.unescape(O.lcpcomp_huff_decompress(got)) == data
+    with pytest.raises(RuntimeError, match="No implementation found"):
+        T.LZSSLCPCompressor(gpu_ctx, coder="sle")

@@ -144,6 +144,22 @@ class Context:
                                                          ctypes.byref(st)))
         return ol.value, st.as_dict()
 
+    def lzss_lcp_compress(self, text, threshold=3, coder=CODER_HUFF):
+        """LZSSLCPCompressor<HuffmanCoder>::compress on an escaped + 0-terminated view.  Returns (stream, stats)."""
+        a = _u8(text)
+        out, n, st = ctypes.c_void_p(), ctypes.c_size_t(), Stats()
+        self._check(self._L.tdc_gpu_lzss_lcp_compress(self._h, _ptr(a), len(a), threshold, coder, ctypes.byref(out),
+                                                      ctypes.byref(n), ctypes.byref(st)))
+        return self._take(out, n.value), st.as_dict()
+
+    def lzss_lcp_factorize(self, text, threshold=3):
+        a = _u8(text)
+        p, s, l, z = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_size_t()
+        self._check(self._L.tdc_gpu_lzss_lcp_factorize(self._h, _ptr(a), len(a), threshold, ctypes.byref(p), ctypes.byref(s),
+                                                       ctypes.byref(l), ctypes.byref(z)))
+        out = [np.frombuffer(self._take(x, z.value * 4), dtype=np.uint32).copy() for x in (p, s, l)]
+        return out[0], out[1], out[2]
+
     def lz78_compress(self, data, coder=CODER_GAMMA):
         """LZ78Compressor<EliasGammaCoder>::compress on raw bytes (no escaping).  Returns (stream, stats)."""
         a = _u8(data)
@@ -232,5 +248,20 @@ class LZ78Compressor:
 
     def compress(self, data):
         out, st = self.ctx.lz78_compress(data)
+        self.last_stats = st
+        return out
+
+
+class LZSSLCPCompressor:
+    """Mirror of tdc::LZSSLCPCompressor<coder> (compressors/LZSSLCPCompressor.hpp:22-132): threshold defaults to 3."""
+
+    def __init__(self, ctx, coder="huff", threshold=3):
+        if coder != "huff":
+            raise RuntimeError("No implementation found for compressor lzss_lcp(coder=%s)" % coder)
+        self.ctx, self.threshold = ctx, int(threshold)
+        self.last_stats = None
+
+    def compress(self, data):
+        out, st = self.ctx.lzss_lcp_compress(escape(data), self.threshold)
         self.last_stats = st
         return out

@@ -14,7 +14,7 @@ SYMBOLS = [
     "tdc_gpu_ctx_create", "tdc_gpu_ctx_destroy", "tdc_gpu_ctx_reserve", "tdc_gpu_strerror", "tdc_gpu_last_error",
     "tdc_gpu_ctx_set_profiling", "tdc_gpu_ctx_reset_profile", "tdc_gpu_ctx_kernel_profile",
     "tdc_gpu_free", "tdc_gpu_lcpcomp_compress", "tdc_gpu_lcpcomp_compress_dev", "tdc_gpu_lcpcomp_bound",
-    "tdc_gpu_lz78_compress",
+    "tdc_gpu_lz78_compress", "tdc_gpu_lzss_lcp_compress", "tdc_gpu_lzss_lcp_factorize",
     "tdc_gpu_suffix_array", "tdc_gpu_textds", "tdc_gpu_lcpcomp_factorize", "tdc_gpu_flatten", "tdc_gpu_encode_huff",
     "tdc_escape", "tdc_unescape", "tdc_huffman_table", "tdc_gen_english", "tdc_gen_dna",
 ]
@@ -66,6 +66,8 @@ def load():
     L.tdc_gpu_lcpcomp_compress.argtypes = [vp, vp, sz, u32, i32, i32, pvp, psz, ctypes.POINTER(Stats)]
     L.tdc_gpu_lcpcomp_compress_dev.argtypes = [vp, vp, sz, u32, i32, i32, vp, sz, psz, ctypes.POINTER(Stats)]
     L.tdc_gpu_lz78_compress.argtypes = [vp, vp, sz, i32, pvp, psz, ctypes.POINTER(Stats)]
+    L.tdc_gpu_lzss_lcp_compress.argtypes = [vp, vp, sz, u32, i32, pvp, psz, ctypes.POINTER(Stats)]
+    L.tdc_gpu_lzss_lcp_factorize.argtypes = [vp, vp, sz, u32, pvp, pvp, pvp, psz]
     L.tdc_gpu_lcpcomp_bound.argtypes = [sz]
     L.tdc_gpu_lcpcomp_bound.restype = sz
     L.tdc_gpu_suffix_array.argtypes = [vp, vp, sz, vp, vp]

@@ -347,6 +347,88 @@ int tdc_gpu_lcpcomp_compress(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, ui
     });
 }
 
+namespace {
+// shared front end of the two lzss_lcp entry points: text to the device, SA + ISA, factorization into position space
+void run_lzss_lcp(Ctx& c, const uint8_t* text, size_t n, uint32_t threshold, u8** d_text_out, DevArrays& A, tdc_gpu_stats* st, Events& ev) {
+    if (threshold == 0) throw ArgError{TDC_GPU_ERR_ARG, "threshold must be >= 1"};
+    if (text[n - 1] != 0) throw ArgError{TDC_GPU_ERR_NO_SENTINEL, "text does not end with a 0 sentinel"};
+    c.ensure_arena(arena_need(n));
+    u8* d_text = c.arena.get<u8>(n + 64);
+    HIP_TRY(hipMemcpyAsync(d_text, text, n, hipMemcpyHostToDevice, c.stream));
+    validate_device_text(c, d_text, n);
+    A.sa = c.arena.get<u32>(n);
+    A.isa = c.arena.get<u32>(n);
+    A.fs.flen = c.arena.get<u32>(n); A.fs.owner = c.arena.get<u32>(n); A.fs.fsrc = c.arena.get<u32>(n);
+    SAStats ss;
+    const int e0 = ev.tick();
+    build_suffix_array(c, d_text, n, A.sa, A.isa, &ss);
+    const int e1 = ev.tick();
+    LzssStats ls;
+    lzss_lcp_factorize(c, d_text, n, A.sa, A.isa, threshold, A.fs, &ls);
+    const int e2 = ev.tick();
+    if (st) {
+        st->n = n; st->factors = ls.factors; st->sa_rounds = ss.rounds; st->sa_init_syms = ss.init_syms; st->sa_sorted_elems = ss.sorted_elems;
+        ev.span(&st->ms_sa, e0, e1); ev.span(&st->ms_factorize, e1, e2);
+    }
+    *d_text_out = d_text;
+}
+}  // namespace
+
+int tdc_gpu_lzss_lcp_compress(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, uint32_t threshold, int coder,
+                              uint8_t** out, size_t* out_len, tdc_gpu_stats* stats) {
+    return guarded(ctx, [&] {
+        if (coder != TDC_GPU_CODER_HUFF) throw ArgError{TDC_GPU_ERR_UNSUPPORTED, "lzss_lcp: only coder=huff is built"};
+        check_text_args(text, n);
+        if (!out || !out_len) throw ArgError{TDC_GPU_ERR_ARG, "out/out_len is NULL"};
+        Ctx& c = ctx->c;
+        if (stats) memset(stats, 0, sizeof(*stats));
+        Events ev(c);
+        DevArrays A;
+        u8* d_text = nullptr;
+        const int e0 = ev.tick();
+        run_lzss_lcp(c, text, n, threshold, &d_text, A, stats, ev);
+        const size_t cap = tdc_gpu_lcpcomp_bound(n);
+        u8* d_out = c.arena.get<u8>(cap);
+        EncodeStats es;
+        const int e1 = ev.tick();
+        const size_t len = encode_huff(c, d_text, n, A.fs, d_out, cap, &es);
+        const int e2 = ev.tick();
+        uint8_t* h = host_alloc<uint8_t>(len);
+        HIP_TRY(hipMemcpyAsync(h, d_out, len, hipMemcpyDeviceToHost, c.stream));
+        const int e3 = ev.tick();
+        if (stats) {
+            stats->out_len = len; stats->flen_min = es.flen_min; stats->flen_max = es.flen_max; stats->fdist_max = es.fdist_max;
+            stats->sigma = es.sigma; stats->arena_bytes = c.arena.high;
+            ev.span(&stats->ms_encode, e1, e2); ev.span(&stats->ms_d2h, e2, e3); ev.span(&stats->ms_total, e0, e3);
+        }
+        ev.finish();
+        *out = h; *out_len = len;
+    });
+}
+
+int tdc_gpu_lzss_lcp_factorize(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, uint32_t threshold,
+                               uint32_t** pos, uint32_t** src, uint32_t** len, size_t* z) {
+    return guarded(ctx, [&] {
+        check_text_args(text, n);
+        if (!pos || !src || !len || !z) throw ArgError{TDC_GPU_ERR_ARG, "output pointer is NULL"};
+        Ctx& c = ctx->c;
+        Events ev(c);
+        DevArrays A;
+        u8* d_text = nullptr;
+        run_lzss_lcp(c, text, n, threshold, &d_text, A, nullptr, ev);
+        u32* d_pos = c.arena.get<u32>(n), *d_src = c.arena.get<u32>(n), *d_len = c.arena.get<u32>(n);
+        const size_t cnt = extract_factors(c, n, A.fs, d_pos, d_src, d_len, n);
+        uint32_t* hp = host_alloc<uint32_t>(cnt), *hs = host_alloc<uint32_t>(cnt), *hl = host_alloc<uint32_t>(cnt);
+        if (cnt) {
+            HIP_TRY(hipMemcpyAsync(hp, d_pos, cnt * 4, hipMemcpyDeviceToHost, c.stream));
+            HIP_TRY(hipMemcpyAsync(hs, d_src, cnt * 4, hipMemcpyDeviceToHost, c.stream));
+            HIP_TRY(hipMemcpyAsync(hl, d_len, cnt * 4, hipMemcpyDeviceToHost, c.stream));
+        }
+        ev.finish();
+        *pos = hp; *src = hs; *len = hl; *z = cnt;
+    });
+}
+
 int tdc_gpu_lz78_compress(tdc_gpu_ctx* ctx, const uint8_t* in, size_t n, int coder, uint8_t** out, size_t* out_len,
                           tdc_gpu_stats* stats) {
     return guarded(ctx, [&] {

@@ -1,0 +1,283 @@
+// lzss_lcp.hip -- LZSSLCPCompressor's factorization (compressors/LZSSLCPCompressor.hpp:60-115) on the GPU.
+//
+// Reference, for every text position i (sequentially, skipping over emitted factors): walk the suffix array upwards from
+// isa[i] to the first suffix that starts EARLIER in the text (sa[r'] < i), taking the minimum LCP on the way; the same
+// downwards; the longer of the two common prefixes wins (ties: the upward side); if it reaches `threshold`, emit the
+// factor (i, that suffix, length) and continue at i + length, else at i + 1.
+//
+// Device formulation:
+//   1. ANSV: previous / next SMALLER VALUE of every suffix-array entry, with a three-level minimum hierarchy
+//      (groups of 32, tiles of 1024, super-tiles of 2^20 entries): the expected distance to the nearest smaller value
+//      is logarithmic, so most queries end inside their own group; the rest skip whole groups / tiles by their minima.
+//   2. the two common-prefix lengths by direct comparison with the chunked carry of the PLCP kernel
+//      (len[i] >= len[i-1] - 1 holds for either side: shifting the previous position's match by one gives a candidate).
+//   3. the greedy parse is the orbit of position 0 under next(i) = i + (len >= threshold ? len : 1).  It is marked
+//      hierarchically: exit of every position from its 1024-tile (pointer doubling in LDS), exit from its super-tile
+//      (right-to-left sweep over the tiles of a super-tile), a serial walk over the few super-tile entries, then the
+//      tile entries and finally the chain positions inside every tile, each level in parallel.
+#include "stages.hpp"
+#include "prim.hpp"
+
+namespace tdc {
+
+constexpr int ANSV_TILE = 1024, ANSV_SUPER = 1 << 20;     // plus groups of 32 entries inside a tile
+
+// ---- 1. ANSV ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ansv_mins_kernel(const u32* __restrict__ sa, size_t n, u32* __restrict__ gmin, u32* __restrict__ tmin) {
+    __shared__ u32 s[ANSV_TILE];
+    __shared__ u32 g[32];
+    const size_t base = (size_t)blockIdx.x * ANSV_TILE;
+    for (int k = threadIdx.x; k < ANSV_TILE; k += 256) s[k] = (base + k < n) ? sa[base + k] : NONE32;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        u32 m = NONE32;
+        for (int k = 0; k < 32; ++k) m = min(m, s[threadIdx.x * 32 + k]);
+        g[threadIdx.x] = m;
+        if (base + (size_t)threadIdx.x * 32 < n) gmin[base / 32 + threadIdx.x] = m;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 m = NONE32;
+        for (int k = 0; k < 32; ++k) m = min(m, g[k]);
+        tmin[blockIdx.x] = m;
+    }
+}
+__global__ void ansv_smin_kernel(const u32* __restrict__ tmin, size_t ntiles, u32* __restrict__ smin) {
+    const size_t sidx = blockIdx.x;                        // one workgroup per super-tile
+    __shared__ u32 sm[4];
+    u32 m = NONE32;
+    const size_t t0 = sidx * (ANSV_SUPER / ANSV_TILE);
+    for (size_t t = t0 + threadIdx.x; t < t0 + ANSV_SUPER / ANSV_TILE && t < ntiles; t += blockDim.x) m = min(m, tmin[t]);
+    m = wave_reduce_min(m);
+    if (lane_id() == 0) sm[wave_id()] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) smin[sidx] = min(min(sm[0], sm[1]), min(sm[2], sm[3]));
+}
+
+struct MinTree { const u32* sa; const u32* gmin; const u32* tmin; const u32* smin; size_t n; };
+
+__device__ __forceinline__ u32 last_smaller_in_group(const MinTree& T, size_t gg, u32 x) {
+    size_t q = gg * 32 + 31;
+    if (q > T.n - 1) q = T.n - 1;
+    for (;; --q) { if (T.sa[q] < x) return (u32)q; if (q == gg * 32) break; }
+    return NONE32;
+}
+__device__ __forceinline__ u32 last_smaller_in_tile(const MinTree& T, size_t tt, u32 x) {
+    size_t gg = tt * 32 + 31;
+    const size_t glast = (T.n - 1) / 32;
+    if (gg > glast) gg = glast;
+    for (;; --gg) { if (T.gmin[gg] < x) return last_smaller_in_group(T, gg, x); if (gg == tt * 32) break; }
+    return NONE32;
+}
+__device__ u32 prev_smaller(const MinTree& T, size_t r, u32 x) {
+    for (size_t q = r; q > (r & ~(size_t)31);) { --q; if (T.sa[q] < x) return (u32)q; }
+    for (size_t gg = r >> 5; gg > ((r >> 10) << 5);) { --gg; if (T.gmin[gg] < x) return last_smaller_in_group(T, gg, x); }
+    for (size_t tt = r >> 10; tt > ((r >> 20) << 10);) { --tt; if (T.tmin[tt] < x) return last_smaller_in_tile(T, tt, x); }
+    for (size_t ss = r >> 20; ss > 0;) {
+        --ss;
+        if (T.smin[ss] < x) {
+            size_t tt = ss * 1024 + 1023;
+            for (;; --tt) { if (T.tmin[tt] < x) return last_smaller_in_tile(T, tt, x); if (tt == ss * 1024) break; }
+        }
+    }
+    return NONE32;
+}
+__device__ __forceinline__ u32 first_smaller_in_group(const MinTree& T, size_t gg, u32 x) {
+    for (size_t q = gg * 32; q < gg * 32 + 32 && q < T.n; ++q) if (T.sa[q] < x) return (u32)q;
+    return NONE32;
+}
+__device__ __forceinline__ u32 first_smaller_in_tile(const MinTree& T, size_t tt, u32 x) {
+    const size_t ng = (T.n + 31) / 32;
+    for (size_t gg = tt * 32; gg < tt * 32 + 32 && gg < ng; ++gg) if (T.gmin[gg] < x) return first_smaller_in_group(T, gg, x);
+    return NONE32;
+}
+__device__ u32 next_smaller(const MinTree& T, size_t r, u32 x) {
+    const size_t ng = (T.n + 31) / 32, nt = (T.n + 1023) / 1024, ns = (T.n + ANSV_SUPER - 1) / ANSV_SUPER;
+    for (size_t q = r + 1; q < ((r >> 5) + 1) * 32 && q < T.n; ++q) if (T.sa[q] < x) return (u32)q;
+    for (size_t gg = (r >> 5) + 1; gg < ((r >> 10) + 1) * 32 && gg < ng; ++gg) if (T.gmin[gg] < x) return first_smaller_in_group(T, gg, x);
+    for (size_t tt = (r >> 10) + 1; tt < ((r >> 20) + 1) * 1024 && tt < nt; ++tt) if (T.tmin[tt] < x) return first_smaller_in_tile(T, tt, x);
+    for (size_t ss = (r >> 20) + 1; ss < ns; ++ss) {
+        if (T.smin[ss] < x) {
+            for (size_t tt = ss * 1024; tt < ss * 1024 + 1024 && tt < nt; ++tt) if (T.tmin[tt] < x) return first_smaller_in_tile(T, tt, x);
+        }
+    }
+    return NONE32;
+}
+
+// psrc[i] / nsrc[i] = text position of the previous / next suffix-array neighbour of suffix i that starts before i
+__global__ void ansv_query_kernel(MinTree T, u32* __restrict__ psrc, u32* __restrict__ nsrc) {
+    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= T.n) return;
+    const u32 x = T.sa[r];
+    const u32 pi = prev_smaller(T, r, x), ni = next_smaller(T, r, x);
+    psrc[x] = (pi == NONE32) ? NONE32 : T.sa[pi];
+    nsrc[x] = (ni == NONE32) ? NONE32 : T.sa[ni];
+}
+
+// ---- 3. candidate per position and the parse chain ---------------------------------------------------------------
+// clen / csrc overwrite plen / psrc in place
+__global__ void lzss_choose_kernel(size_t n, u32 threshold, u32* __restrict__ plen, const u32* __restrict__ nlen, u32* __restrict__ psrc,
+                                   const u32* __restrict__ nsrc, u32* __restrict__ next) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 len = 0, src = NONE32;
+    if (i + 1 < n) {                                     // the loop of the reference omits T[n-1] (:62)
+        const u32 pl = plen[i], nl = nlen[i];
+        const u32 best = max(pl, nl);                    // :99
+        if (best >= threshold) { len = best; src = (best == pl) ? psrc[i] : nsrc[i]; }   // :101 ties go to the PSV side
+    }
+    plen[i] = len;
+    psrc[i] = src;
+    const u64 nx = (u64)i + (len ? len : 1u);            // :107 / :109
+    next[i] = (u32)(nx > n ? n : nx);
+}
+
+__global__ __launch_bounds__(256) void chain_exit1_kernel(const u32* __restrict__ next, size_t n, u32* __restrict__ exit1) {
+    __shared__ u32 e[ANSV_TILE];
+    const size_t base = (size_t)blockIdx.x * ANSV_TILE;
+    const size_t tile_end = (base + ANSV_TILE < n) ? base + ANSV_TILE : n;
+    for (int k = threadIdx.x; k < ANSV_TILE; k += 256) e[k] = (base + k < n) ? next[base + k] : (u32)n;
+    __syncthreads();
+    // invariant: e[k] lies on k's chain and every chain position strictly between k and e[k] is inside the tile
+    for (int round = 0; round < 10; ++round) {
+        u32 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const u32 x = e[threadIdx.x + 256 * j]; v[j] = (x < tile_end) ? e[x - base] : x; }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e[threadIdx.x + 256 * j] = v[j];
+        __syncthreads();
+    }
+    for (int k = threadIdx.x; k < ANSV_TILE; k += 256) if (base + k < n) exit1[base + k] = e[k];
+}
+
+// one workgroup per super-tile, tiles from right to left; exit2 of a later tile is read back through L2 (agent-scope loads)
+__global__ __launch_bounds__(256) void chain_exit2_kernel(const u32* __restrict__ exit1, size_t n, u32* exit2) {
+    const size_t sbase = (size_t)blockIdx.x * ANSV_SUPER;
+    const size_t super_end = (sbase + ANSV_SUPER < n) ? sbase + ANSV_SUPER : n;
+    const size_t ntile = (super_end - sbase + ANSV_TILE - 1) / ANSV_TILE;
+    for (size_t tt = ntile; tt-- > 0;) {
+        const size_t base = sbase + tt * ANSV_TILE;
+        for (int k = threadIdx.x; k < ANSV_TILE; k += 256) {
+            const size_t i = base + k;
+            if (i < super_end) {
+                const u32 x = exit1[i];
+                const u32 y = (x >= super_end) ? x : __hip_atomic_load(&exit2[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&exit2[i], y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __syncthreads();          // includes the wait for this tile's stores
+    }
+}
+
+__global__ void chain_super_walk_kernel(const u32* __restrict__ exit2, size_t n, u32* __restrict__ super_entry) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    size_t e = 0, guard = 0;
+    const size_t nsuper = (n + ANSV_SUPER - 1) / ANSV_SUPER;
+    while (e < n && guard++ <= nsuper) { super_entry[e >> 20] = (u32)e; e = exit2[e]; }
+}
+__global__ void chain_tile_entries_kernel(const u32* __restrict__ exit1, size_t n, const u32* __restrict__ super_entry, size_t nsuper,
+                                          u32* __restrict__ tile_entry) {
+    const size_t sidx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (sidx >= nsuper) return;
+    size_t e = super_entry[sidx];
+    if (e == NONE32) return;
+    const size_t super_end = (sidx + 1) * (size_t)ANSV_SUPER < n ? (sidx + 1) * (size_t)ANSV_SUPER : n;
+    for (int guard = 0; e < super_end && guard <= ANSV_SUPER / ANSV_TILE; ++guard) { tile_entry[e >> 10] = (u32)e; e = exit1[e]; }
+}
+__global__ void chain_mark_kernel(const u32* __restrict__ next, size_t n, const u32* __restrict__ tile_entry, size_t ntiles,
+                                  u8* __restrict__ mark) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntiles) return;
+    size_t e = tile_entry[t];
+    if (e == NONE32) return;
+    const size_t tile_end = (t + 1) * (size_t)ANSV_TILE < n ? (t + 1) * (size_t)ANSV_TILE : n;
+    for (int guard = 0; e < tile_end && guard <= ANSV_TILE; ++guard) { mark[e] = 1; e = next[e]; }
+}
+
+__global__ void lzss_fspace_init_kernel(size_t n, u32* __restrict__ flen, u32* __restrict__ owner) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) { flen[p] = 0; owner[p] = NONE32; }
+}
+__global__ void lzss_emit_kernel(size_t n, const u8* __restrict__ mark, const u32* __restrict__ clen, const u32* __restrict__ csrc,
+                                 u32* __restrict__ flen, u32* __restrict__ owner, u32* __restrict__ fsrc, u32* __restrict__ count) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool f = false;
+    if (i < n && mark[i]) {
+        const u32 len = clen[i];
+        if (len) {
+            f = true;
+            flen[i] = len;
+            fsrc[i] = csrc[i];
+            for (u32 j = 0; j < len && i + j < n; ++j) owner[i + j] = (u32)i;
+        }
+    }
+    const u64 b = __ballot(f);
+    if (b && lane_id() == __builtin_ctzll(b)) atomicAdd(count, (u32)__popcll(b));
+}
+
+void lzss_lcp_factorize(Ctx& c, const u8* text, size_t n, const u32* sa, const u32* isa, u32 threshold, FactorSpace fs, LzssStats* st) {
+    (void)isa;
+    LzssStats local;
+    if (!st) st = &local;
+    *st = LzssStats();
+    if (n == 0) return;
+    hipStream_t s = c.stream;
+    const size_t mark0 = c.arena.mark();
+    const unsigned gn = cdiv(n, 256);
+    const size_t ntiles = (n + ANSV_TILE - 1) / ANSV_TILE, ngroups = (n + 31) / 32, nsuper = (n + ANSV_SUPER - 1) / ANSV_SUPER;
+
+    // 1. ANSV over the suffix array
+    u32* gmin = c.arena.get<u32>(ngroups);
+    u32* tmin = c.arena.get<u32>(ntiles);
+    u32* smin = c.arena.get<u32>(nsuper);
+    u32* psrc = c.arena.get<u32>(n), *nsrc = c.arena.get<u32>(n);
+    ansv_mins_kernel<<<(unsigned)ntiles, 256, 0, s>>>(sa, n, gmin, tmin);
+    LAUNCH_CHECK();
+    ansv_smin_kernel<<<(unsigned)nsuper, 256, 0, s>>>(tmin, ntiles, smin);
+    LAUNCH_CHECK();
+    MinTree T{sa, gmin, tmin, smin, n};
+    ansv_query_kernel<<<gn, 256, 0, s>>>(T, psrc, nsrc);
+    LAUNCH_CHECK();
+
+    // 2. common-prefix lengths of both sides
+    u32* plen = c.arena.get<u32>(n), *nlen = c.arena.get<u32>(n);
+    u32* d_tmp = c.arena.get<u32>(4);
+    build_lce_with_carry(c, text, n, psrc, plen, d_tmp);
+    build_lce_with_carry(c, text, n, nsrc, nlen, d_tmp + 1);
+
+    // 3. candidate per position, then the orbit of position 0
+    u32* next = c.arena.get<u32>(n);
+    lzss_choose_kernel<<<gn, 256, 0, s>>>(n, threshold, plen, nlen, psrc, nsrc, next);
+    LAUNCH_CHECK();
+    u32* clen = plen, *csrc = psrc;
+    u32* exit1 = nsrc;                                   // nsrc / nlen are free now
+    u32* exit2 = nlen;
+    chain_exit1_kernel<<<(unsigned)ntiles, 256, 0, s>>>(next, n, exit1);
+    LAUNCH_CHECK();
+    chain_exit2_kernel<<<(unsigned)nsuper, 256, 0, s>>>(exit1, n, exit2);
+    LAUNCH_CHECK();
+    u32* super_entry = c.arena.get<u32>(nsuper);
+    u32* tile_entry = c.arena.get<u32>(ntiles);
+    u8* mark = c.arena.get<u8>(n);
+    HIP_TRY(hipMemsetAsync(super_entry, 0xFF, nsuper * sizeof(u32), s));
+    HIP_TRY(hipMemsetAsync(tile_entry, 0xFF, ntiles * sizeof(u32), s));
+    HIP_TRY(hipMemsetAsync(mark, 0, n, s));
+    chain_super_walk_kernel<<<1, 64, 0, s>>>(exit2, n, super_entry);
+    LAUNCH_CHECK();
+    chain_tile_entries_kernel<<<cdiv(nsuper, 64), 64, 0, s>>>(exit1, n, super_entry, nsuper, tile_entry);
+    LAUNCH_CHECK();
+    chain_mark_kernel<<<cdiv(ntiles, 256), 256, 0, s>>>(next, n, tile_entry, ntiles, mark);
+    LAUNCH_CHECK();
+
+    // 4. factors into position space
+    HIP_TRY(hipMemsetAsync(d_tmp + 2, 0, sizeof(u32), s));
+    lzss_fspace_init_kernel<<<gn, 256, 0, s>>>(n, fs.flen, fs.owner);
+    LAUNCH_CHECK();
+    lzss_emit_kernel<<<gn, 256, 0, s>>>(n, mark, clen, csrc, fs.flen, fs.owner, fs.fsrc, d_tmp + 2);
+    LAUNCH_CHECK();
+    st->factors = c.read(d_tmp + 2);
+    c.arena.release(mark0);
+}
+
+}  // namespace tdc

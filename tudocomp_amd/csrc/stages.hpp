@@ -16,6 +16,9 @@ void build_suffix_array(Ctx& c, const u8* text, size_t n, u32* sa, u32* isa, SAS
 void build_phi(Ctx& c, const u32* sa, size_t n, u32* phi);
 // a5: ds/PLCPFromPhi.hpp:27-53 ; plcp[n-1] := 0 ; d_maxlcp (device u32) receives max PLCP
 void build_plcp(Ctx& c, const u8* text, size_t n, const u32* phi, u32* plcp, u32* d_maxlcp);
+// len[i] = lcp(T[i..], T[src[i]..]) for sources with len[i] >= len[i-1] - 1 (same chunked carry as build_plcp);
+// src[i] == NONE32 -> 0.  d_max receives the maximum.
+void build_lce_with_carry(Ctx& c, const u8* text, size_t n, const u32* src, u32* len, u32* d_max);
 // a6 (debug/fixtures only): ds/LCPFromPLCP.hpp:27-56
 void build_lcp(Ctx& c, const u32* sa, const u32* plcp, size_t n, u32* lcp);
 
@@ -56,6 +59,12 @@ size_t encode_huff(Ctx& c, const u8* text, size_t n, FactorSpace fs, u8* d_out, 
 
 // worst-case output size of encode_huff for a text of n bytes
 size_t encode_bound(size_t n);
+
+struct LzssStats { u64 factors = 0; };
+// a18: compressors/LZSSLCPCompressor.hpp:60-115 (lzss_lcp): greedy LZ77 parse from the previous / next smaller values of
+// the suffix array (ANSV) -- fills fs like factorize_arrays (no flatten for this compressor).
+void lzss_lcp_factorize(Ctx& c, const u8* text, size_t n, const u32* sa, const u32* isa, u32 threshold, FactorSpace fs,
+                        LzssStats* st);
 
 }  // namespace tdc
 #include <vector>

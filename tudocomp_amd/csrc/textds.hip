@@ -31,6 +31,9 @@ constexpr int PLCP_HALO = 512;                    // text bytes staged beyond th
 // wave; going through LDS (row-padded to 33 words: conflict-free) turns both into fully coalesced 1 KiB transfers,
 // and the T[i+l] side of every comparison is served from a staged copy of the tile (+halo).  Only T[Phi[i]+l] stays
 // a global (data-dependent) read.
+// ALLOW_NONE: src[i] == NONE32 means "no source", result 0 (used by the lzss_lcp PSV/NSV sides, where the same
+// lower bound len[i] >= len[i-1] - 1 holds).
+template <bool ALLOW_NONE>
 __global__ __launch_bounds__(256) void plcp_kernel(const u8* __restrict__ text, size_t n, const u32* __restrict__ phi,
                                                     u32* __restrict__ plcp, u32* __restrict__ d_max) {
     __shared__ u32 sphi[256 * (PLCP_CHUNK + 1)];
@@ -58,6 +61,7 @@ __global__ __launch_bounds__(256) void plcp_kernel(const u8* __restrict__ text, 
             if (i >= n) break;
             if (i == n - 1) { row[c] = 0; break; }
             const size_t j = row[c];
+            if (ALLOW_NONE && row[c] == NONE32) { row[c] = 0; l = 0; continue; }
             const u32 li = (u32)(i - base);                 // offset of i inside the staged text
             // the sentinel T[n-1] is unique, so the comparison stops before either index leaves the text;
             // the explicit bounds only keep a corrupted Phi from faulting
@@ -86,7 +90,15 @@ void build_plcp(Ctx& c, const u8* text, size_t n, const u32* phi, u32* plcp, u32
     HIP_TRY(hipMemsetAsync(d_maxlcp, 0, sizeof(u32), c.stream));
     if (!n) return;
     Ctx::ProfScope prof(c, K_PLCP, (u64)n * 10);                // Phi (4) + two text bytes + PLCP (4), SURVEY 8d
-    plcp_kernel<<<cdiv(n, PLCP_TILE), 256, 0, c.stream>>>(text, n, phi, plcp, d_maxlcp);
+    plcp_kernel<false><<<cdiv(n, PLCP_TILE), 256, 0, c.stream>>>(text, n, phi, plcp, d_maxlcp);
+    LAUNCH_CHECK();
+}
+
+void build_lce_with_carry(Ctx& c, const u8* text, size_t n, const u32* src, u32* len, u32* d_max) {
+    HIP_TRY(hipMemsetAsync(d_max, 0, sizeof(u32), c.stream));
+    if (!n) return;
+    Ctx::ProfScope prof(c, K_PLCP, (u64)n * 10);
+    plcp_kernel<true><<<cdiv(n, PLCP_TILE), 256, 0, c.stream>>>(text, n, src, len, d_max);
     LAUNCH_CHECK();
 }
 

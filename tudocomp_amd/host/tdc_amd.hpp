@@ -187,6 +187,72 @@ struct GpuContext {
     GpuContext& operator=(const GpuContext&) = delete;
 };
 
+// HuffmanCoder::Decoder + lzss token stream (decode_text_internal / lzss::decode_text): shared by lcpcomp and lzss_lcp.
+// References may point forwards (lcpcomp) or backwards (lzss_lcp); both are resolved by following source chains.
+inline void lzss_huff_decode(Input& input, Output& output) {
+    const bytes& in = input.raw();
+    BitIStream bs(in.data(), in.size());
+    // HuffmanCoder::Decoder ctor (HuffmanCoder.hpp:581-597)
+    const bool have_table = bs.read_bit();
+    uint8_t order[256]; uint64_t firstcode[256]; size_t prefix_sum[256]; unsigned longest = 0;
+    if (have_table) {
+        longest = (unsigned)(bs.read_compressed_int() & 0xFF);
+        if (!longest) throw std::runtime_error("corrupt Huffman table");
+        uint8_t numl[256];
+        for (unsigned i = 0; i < longest; ++i) numl[i] = (uint8_t)bs.read_compressed_int();
+        const size_t sigma = bs.read_compressed_int();
+        if (sigma > 256) throw std::runtime_error("corrupt Huffman table");
+        for (size_t i = 0; i < sigma; ++i) order[i] = (uint8_t)bs.read_int(8);
+        firstcode[longest - 1] = 0;
+        for (unsigned i = longest - 1; i > 0; --i) firstcode[i - 1] = (firstcode[i] + numl[i]) / 2;
+        size_t acc = 0;
+        for (unsigned l = 0; l < longest; ++l) { prefix_sum[l] = acc; acc += numl[l]; }
+    }
+    // lcpcomp::decode_text_internal (LCPCompressor.hpp:23-76)
+    const uint64_t n = bs.read_int(32);
+    const unsigned W = bits_for(n);
+    const uint64_t flen_min = bs.read_int(W), flen_max = bs.read_int(W), fdist_max = bs.read_int(W);
+    const unsigned lbits = bits_for(flen_max - flen_min), dbits = bits_for(fdist_max);
+    bytes text(n);
+    std::vector<uint32_t> ref(n, 0xFFFFFFFFu);
+    uint64_t p = 0;
+    while (!bs.eof()) {
+        uint64_t num = bs.read_bit() ? bs.read_int(dbits) : 0;
+        while (num--) {
+            uint8_t ch;
+            if (!have_table) ch = (uint8_t)bs.read_int(8);
+            else {
+                uint64_t value = 0; unsigned length = 0;
+                do { value = (value << 1) + bs.read_bit(); ++length; } while (length <= longest && value < firstcode[length - 1]);
+                if (length > longest) throw std::runtime_error("corrupt Huffman code");
+                --length;
+                ch = order[prefix_sum[length] + (value - firstcode[length])];
+            }
+            if (p >= n) throw std::runtime_error("corrupt stream: too many literals");
+            text[p++] = ch;
+        }
+        if (!bs.eof()) {
+            const uint64_t src = bs.read_int(W), len = flen_min + bs.read_int(lbits);
+            if (p + len > n || src + len > n) throw std::runtime_error("corrupt stream: factor out of range");
+            for (uint64_t j = 0; j < len; ++j) ref[p + j] = (uint32_t)(src + j);
+            p += len;
+        }
+    }
+    if (p != n) throw std::runtime_error("corrupt stream: length mismatch");
+    std::vector<uint32_t> stack;
+    for (uint64_t i = 0; i < n; ++i) {
+        if (ref[i] == 0xFFFFFFFFu) continue;
+        stack.clear();
+        uint32_t q = (uint32_t)i;
+        while (ref[q] != 0xFFFFFFFFu) {
+            if (stack.size() > n) throw std::runtime_error("corrupt stream: reference cycle");
+            stack.push_back(q); q = ref[q];
+        }
+        for (uint32_t r : stack) { text[r] = text[q]; ref[r] = 0xFFFFFFFFu; }
+    }
+    output.write(text.data(), text.size());
+}
+
 class LCPCompressor : public Compressor {
     AlgorithmValue m_opts;
     std::shared_ptr<GpuContext> m_ctx;       // created lazily by the first compress(): decompress() needs no GPU
@@ -214,69 +280,34 @@ public:
         tdc_gpu_free(out);
     }
 
-    void decompress(Input& input, Output& output) override {
-        const bytes& in = input.raw();
-        BitIStream bs(in.data(), in.size());
-        // HuffmanCoder::Decoder ctor (HuffmanCoder.hpp:581-597)
-        const bool have_table = bs.read_bit();
-        uint8_t order[256]; uint64_t firstcode[256]; size_t prefix_sum[256]; unsigned longest = 0;
-        if (have_table) {
-            longest = (unsigned)(bs.read_compressed_int() & 0xFF);
-            if (!longest) throw std::runtime_error("corrupt Huffman table");
-            uint8_t numl[256];
-            for (unsigned i = 0; i < longest; ++i) numl[i] = (uint8_t)bs.read_compressed_int();
-            const size_t sigma = bs.read_compressed_int();
-            if (sigma > 256) throw std::runtime_error("corrupt Huffman table");
-            for (size_t i = 0; i < sigma; ++i) order[i] = (uint8_t)bs.read_int(8);
-            firstcode[longest - 1] = 0;
-            for (unsigned i = longest - 1; i > 0; --i) firstcode[i - 1] = (firstcode[i] + numl[i]) / 2;
-            size_t acc = 0;
-            for (unsigned l = 0; l < longest; ++l) { prefix_sum[l] = acc; acc += numl[l]; }
-        }
-        // lcpcomp::decode_text_internal (LCPCompressor.hpp:23-76)
-        const uint64_t n = bs.read_int(32);
-        const unsigned W = bits_for(n);
-        const uint64_t flen_min = bs.read_int(W), flen_max = bs.read_int(W), fdist_max = bs.read_int(W);
-        const unsigned lbits = bits_for(flen_max - flen_min), dbits = bits_for(fdist_max);
-        bytes text(n);
-        std::vector<uint32_t> ref(n, 0xFFFFFFFFu);
-        uint64_t p = 0;
-        while (!bs.eof()) {
-            uint64_t num = bs.read_bit() ? bs.read_int(dbits) : 0;
-            while (num--) {
-                uint8_t ch;
-                if (!have_table) ch = (uint8_t)bs.read_int(8);
-                else {
-                    uint64_t value = 0; unsigned length = 0;
-                    do { value = (value << 1) + bs.read_bit(); ++length; } while (length <= longest && value < firstcode[length - 1]);
-                    if (length > longest) throw std::runtime_error("corrupt Huffman code");
-                    --length;
-                    ch = order[prefix_sum[length] + (value - firstcode[length])];
-                }
-                if (p >= n) throw std::runtime_error("corrupt stream: too many literals");
-                text[p++] = ch;
-            }
-            if (!bs.eof()) {
-                const uint64_t src = bs.read_int(W), len = flen_min + bs.read_int(lbits);
-                if (p + len > n || src + len > n) throw std::runtime_error("corrupt stream: factor out of range");
-                for (uint64_t j = 0; j < len; ++j) ref[p + j] = (uint32_t)(src + j);
-                p += len;
-            }
-        }
-        if (p != n) throw std::runtime_error("corrupt stream: length mismatch");
-        std::vector<uint32_t> stack;
-        for (uint64_t i = 0; i < n; ++i) {
-            if (ref[i] == 0xFFFFFFFFu) continue;
-            stack.clear();
-            uint32_t q = (uint32_t)i;
-            while (ref[q] != 0xFFFFFFFFu) {
-                if (stack.size() > n) throw std::runtime_error("corrupt stream: reference cycle");
-                stack.push_back(q); q = ref[q];
-            }
-            for (uint32_t r : stack) { text[r] = text[q]; ref[r] = 0xFFFFFFFFu; }
-        }
-        output.write(text.data(), text.size());
+    void decompress(Input& input, Output& output) override { lzss_huff_decode(input, output); }
+};
+
+// tdc::LZSSLCPCompressor<HuffmanCoder>  (compressors/LZSSLCPCompressor.hpp:22-132): threshold defaults to 3.
+class LZSSLCPCompressor : public Compressor {
+    AlgorithmValue m_opts;
+    std::shared_ptr<GpuContext> m_ctx;
+    int m_device = 0;
+public:
+    tdc_gpu_stats last_stats{};
+    void set_device(int d) { m_device = d; }
+    LZSSLCPCompressor(AlgorithmValue opts, std::shared_ptr<GpuContext> ctx) : m_opts(std::move(opts)), m_ctx(std::move(ctx)) {
+        const std::string coder = m_opts.get("coder", "");
+        if (coder != "huff") throw std::runtime_error("No implementation found for compressor lzss_lcp(coder=" + coder + ")");
     }
+    InputRestrictions input_restrictions() const override { return {true, true}; }
+    void compress(Input& input, Output& output) override {
+        if (!m_ctx) m_ctx = std::make_shared<GpuContext>(m_device);
+        const bytes view = input.as_view();
+        uint8_t* out = nullptr; size_t out_len = 0;
+        const int rc = tdc_gpu_lzss_lcp_compress(m_ctx->h, view.data(), view.size(), (uint32_t)m_opts.get_int("threshold", 3),
+                                                 TDC_GPU_CODER_HUFF, &out, &out_len, &last_stats);
+        if (rc == TDC_GPU_ERR_NO_SENTINEL) throw std::logic_error(tdc_gpu_strerror(rc));
+        if (rc) throw std::runtime_error(std::string(tdc_gpu_strerror(rc)) + ": " + tdc_gpu_last_error(m_ctx->h));
+        output.write(out, out_len);
+        tdc_gpu_free(out);
+    }
+    void decompress(Input& input, Output& output) override { lzss_huff_decode(input, output); }   // :125-130 (DecodeBackBuffer)
 };
 
 // tdc::LZ78Compressor<EliasGammaCoder, trie>  (compressors/LZ78Compressor.hpp:45-161): no input restrictions.
@@ -333,6 +364,7 @@ struct Selection {
 
 inline std::vector<std::string> registered_algorithms() {
     return { "lcpcomp(coder=huff, comp=arrays, dec=scan(scans=6), threshold=5, flatten=1)   [MI355X, libtdc_gpu.so]",
+             "lzss_lcp(coder=huff, threshold=3)                                           [MI355X, libtdc_gpu.so]",
              "lz78(coder=gamma)                                                           [host parse + MI355X gamma packer]" };
 }
 
@@ -343,6 +375,13 @@ inline Selection select_algorithm(const std::string& id, std::shared_ptr<GpuCont
     if (av.name == "lz78") {
         auto z = std::make_unique<LZ78Compressor>(parse_algorithm_id(id, {"coder", "lz78trie"}), std::move(ctx));
         z->set_device(device);
+        s.compressor = std::move(z);
+        return s;
+    }
+    if (av.name == "lzss_lcp") {
+        auto z = std::make_unique<LZSSLCPCompressor>(parse_algorithm_id(id, {"coder", "textds"}), std::move(ctx));
+        z->set_device(device);
+        s.restrictions = z->input_restrictions();
         s.compressor = std::move(z);
         return s;
     }
