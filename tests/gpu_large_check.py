@@ -1,5 +1,5 @@
 """Ad-hoc large-size check (run on a GPU box): compress a big synthetic text on the GPU, decode it with the oracle's
-decoder, compare.  Usage: python tests/gpu_large_check.py english|dna N [threshold]"""
+decoder, compare.  Usage: python tests/gpu_large_check.py english|dna N [threshold] [lcpcomp|lzss_lcp]"""
 import sys, time, os, hashlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -8,13 +8,14 @@ from oracle import oracle as O
 
 gen, N = sys.argv[1], int(float(sys.argv[2]))
 thr = int(sys.argv[3]) if len(sys.argv) > 3 else (2 if gen == "english" else 5)
+algo = sys.argv[4] if len(sys.argv) > 4 else "lcpcomp"
 t0 = time.time()
 data = T.gen_english(N, 42) if gen == "english" else T.gen_dna(N, 7)
 text = np.concatenate([data, np.zeros(1, dtype=np.uint8)])
 print("generated %d bytes in %.1f s" % (N, time.time() - t0), flush=True)
 with T.Context(0) as ctx:
     t0 = time.time()
-    out, st = ctx.lcpcomp_compress(text, thr, 1)
+    out, st = ctx.lcpcomp_compress(text, thr, 1) if algo == "lcpcomp" else ctx.lzss_lcp_compress(text, thr)
     print("compressed in %.2f s wall; device %.1f ms; out %d (ratio %.4f)" % (time.time() - t0, st["ms_total"], len(out), len(out) / N), flush=True)
     print({k: (round(v, 2) if isinstance(v, float) else v) for k, v in st.items()}, flush=True)
 t0 = time.time()
