@@ -61,6 +61,8 @@ typedef struct {
     uint64_t sa_sorted_elems;   /* total elements that went through the radix sort during SA   */
     uint64_t arena_bytes;       /* device memory high-water mark                               */
     float ms_h2d, ms_sa, ms_phi, ms_plcp, ms_factorize, ms_flatten, ms_encode, ms_d2h, ms_total;
+    uint32_t small_levels;      /* levels processed by the one-workgroup kernel                 */
+    uint32_t purges;            /* bulk removals of erased candidates                           */
 } tdc_gpu_stats;
 
 /* ---- context -------------------------------------------------------------------------------------------- */

@@ -27,7 +27,8 @@ class Stats(ctypes.Structure):
         [(k, ctypes.c_uint32) for k in ("sa_rounds", "sa_init_syms", "levels", "mis_rounds", "flatten_rounds", "sigma")] +
         [(k, ctypes.c_uint64) for k in ("sa_sorted_elems", "arena_bytes")] +
         [(k, ctypes.c_float) for k in ("ms_h2d", "ms_sa", "ms_phi", "ms_plcp", "ms_factorize", "ms_flatten", "ms_encode",
-                                       "ms_d2h", "ms_total")])
+                                       "ms_d2h", "ms_total")] +
+        [(k, ctypes.c_uint32) for k in ("small_levels", "purges")])
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -58,7 +58,7 @@ int guarded(tdc_gpu_ctx* ctx, F&& f) {
     }
 }
 
-size_t arena_need(size_t n) { return 104 * n + ((size_t)64 << 20); }
+size_t arena_need(size_t n) { return 112 * n + ((size_t)64 << 20); }
 
 void check_text_args(const void* text, size_t n) {
     if (!text) throw ArgError{TDC_GPU_ERR_ARG, "text is NULL"};
@@ -151,7 +151,7 @@ void run_factorize(Ctx& c, size_t n, DevArrays& A, u32 threshold, int flatten, t
     const int e2 = ev ? ev->tick() : 0;
     if (st) {
         st->factors = fz.factors; st->entries = fz.entries; st->pushes = fz.pushes;
-        st->levels = fz.levels; st->mis_rounds = fz.rounds;
+        st->levels = fz.levels; st->mis_rounds = fz.rounds; st->small_levels = fz.small_levels; st->purges = fz.purges;
         st->num_flattened = fl.num_flattened; st->max_depth_lb = fl.max_depth_lb; st->flatten_rounds = fl.rounds;
         if (ev) { ev->span(&st->ms_factorize, e0, e1); ev->span(&st->ms_flatten, e1, e2); }
     }
@@ -285,7 +285,7 @@ const char* tdc_gpu_ctx_kernel_profile(const tdc_gpu_ctx* ctx, int idx, double* 
     static const char* names[K_CLASS_COUNT] = {
         "rs_scatter_kernel<u64>", "rs_scatter_kernel<u32>", "rs_count_kernel", "scan_kernels",
         "sa_update_kernels", "sa_build_keys_kernel", "phi_kernel", "plcp_kernel", "cand_kernels",
-        "level_init_kernel", "mis_round_kernel", "resolve_kernel", "push_kernel", "apply_kernel", "pool_kernels",
+        "level_init_kernel", "mis_round_kernel", "resolve_kernel", "push_kernel", "apply_kernel", "pool_kernels", "small_level_kernel",
         "flatten_round_kernel", "gaps_kernel", "literal_hist_kernel", "tile_bits_kernel", "pack_kernel", "extract_kernels" };
     if (!ctx || idx < 0 || idx >= K_CLASS_COUNT) return nullptr;
     const KernelProfile& k = ctx->c.kprof[idx];

@@ -59,6 +59,7 @@ __device__ __forceinline__ u64 bm_range_mask(size_t word, size_t lo, size_t hi) 
     const u64 upto = (last == 31) ? ~0ull : ((1ull << (2 * (last + 1))) - 1);
     return upto & ~((1ull << (2 * first)) - 1);
 }
+__device__ __forceinline__ u64 bm_load(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ u32 bm_state(const u64* __restrict__ bm, u32 p) { return (u32)(bm[p >> 5] >> (2 * (p & 31))) & 3u; }
 
 // ---- candidates ("Fill candidates", :54-66) ----------------------------------------------------------------
@@ -104,8 +105,6 @@ __global__ void classify_kernel(const u32* __restrict__ orig, u32 m0, const u32*
 // loads, so decisions of other workgroups become visible without a kernel boundary.  Safe without any ordering:
 // a state only ever moves undecided -> {selected, rejected}, and a stale "undecided" merely postpones a decision.
 constexpr int MIS_TRIES = 6;
-
-__device__ __forceinline__ u64 bm_load(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 template <int G>
 __global__ __launch_bounds__(256) void mis_round_kernel(const u32* __restrict__ live, u32 nl, u32 L, size_t n,
@@ -182,6 +181,176 @@ __global__ __launch_bounds__(256) void resolve_kernel(const u32* __restrict__ li
     rc[i] = push ? 1 : 0;
     rkey[i] = ((u64)v << 32) | pr;
     rval[i] = p;
+}
+
+// ---- whole level in ONE workgroup -----------------------------------------------------------------------------
+// Levels with at most SMALL_M entries (the long tail of every text, and after a purge most levels of a text with long
+// repeats) are processed by a single launch: classify, selection rounds, encounter values, sort of the pushes
+// (bitonic, LDS), new priorities / pool slots / segments, apply.  One read-back per level instead of four or five.
+constexpr u32 SMALL_M = 2048;
+
+__global__ __launch_bounds__(256) void small_level_kernel(const u32* __restrict__ orig, u32 m0, const u32* __restrict__ pushed, u32 m,
+                                                           u32 L, u32 threshold, size_t n, u32* cur, u32* prio,
+                                                           const u32* __restrict__ phi, u32* __restrict__ flen, u32* __restrict__ owner,
+                                                           u32* __restrict__ fsrc, u32* __restrict__ pool, u32 prio_base,
+                                                           PushSeg* __restrict__ segs, u32 seg_cap, LevelScalars* __restrict__ sc) {
+    // The entries are sorted by text position in LDS, so "neighbours within distance < L" are adjacent slots: the
+    // whole level runs out of LDS, without the global state bitmap.
+    __shared__ u64 skey[SMALL_M];          // (position << 32 | k) for the position sort, later (target << 32 | priority)
+    __shared__ u32 pos_s[SMALL_M], pr_s[SMALL_M], v_s[SMALL_M], sval[SMALL_M];
+    __shared__ u8 st[SMALL_M];             // 0 undecided, 1 selected, 2 stale, 3 rejected, 4 dead
+    __shared__ u32 s_und, s_npush, s_sel, s_live, s_alive;
+    const u32 tid = threadIdx.x;
+    if (tid == 0) { s_npush = 0; s_sel = 0; s_live = 0; s_alive = 0; }
+    u32 np2 = 1;
+    while (np2 < m) np2 <<= 1;
+    for (u32 k = tid; k < np2; k += 256) {
+        if (k < m) { const u32 p = (k < m0) ? orig[k] : pushed[k - m0]; skey[k] = ((u64)p << 32) | k; }
+        else skey[k] = ~0ull;
+    }
+    __syncthreads();
+    // 1. sort by position (positions are distinct)
+    for (u32 k2 = 2; k2 <= np2; k2 <<= 1) {
+        for (u32 j = k2 >> 1; j > 0; j >>= 1) {
+            for (u32 i = tid; i < np2; i += 256) {
+                const u32 x = i ^ j;
+                if (x > i) {
+                    const bool up = (i & k2) == 0;
+                    const u64 a = skey[i], b = skey[x];
+                    if ((a > b) == up) { skey[i] = b; skey[x] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // 2. classify
+    for (u32 i = tid; i < m; i += 256) {
+        const u32 p = (u32)(skey[i] >> 32);
+        const u32 v = cur[p];
+        pos_s[i] = p; v_s[i] = v; pr_s[i] = prio[p];
+        const u8 c = (v == L) ? 0 : (v >= threshold ? 2 : 4);
+        st[i] = c;
+        if (c == 0) atomicAdd(&s_live, 1u);
+        if (c != 4) atomicAdd(&s_alive, 1u);
+    }
+    __syncthreads();
+    if (s_alive == 0) {                                   // every entry already erased (:86)
+        if (tid == 0) { sc->nlive = 0; sc->nstale = 0; sc->selected = 0; sc->npush = 0; sc->nseg = 0; }
+        return;
+    }
+    // 3. selection rounds (Jacobi: decisions are published after a barrier)
+    for (u32 round = 0; round <= m && s_live; ++round) {
+        if (tid == 0) s_und = 0;
+        __syncthreads();
+        u8 dec[SMALL_M / 256];
+#pragma unroll
+        for (u32 t = 0; t < SMALL_M / 256; ++t) {
+            const u32 i = tid + 256 * t;
+            dec[t] = 255;
+            if (i < m && st[i] == 0) {
+                const u32 p = pos_s[i], pr = pr_s[i];
+                bool hit = false, blocked = false;
+                for (u32 j = i; j-- > 0;) {               // left neighbours
+                    if (p - pos_s[j] >= L) break;
+                    const u8 sj = st[j];
+                    if (sj == 1) { hit = true; break; }
+                    if (sj == 0 && pr_s[j] < pr) blocked = true;
+                }
+                for (u32 j = i + 1; j < m && !hit; ++j) { // right neighbours
+                    if (pos_s[j] - p >= L) break;
+                    const u8 sj = st[j];
+                    if (sj == 1) { hit = true; break; }
+                    if (sj == 0 && pr_s[j] < pr) blocked = true;
+                }
+                if (hit) dec[t] = 3; else if (!blocked) dec[t] = 1; else atomicAdd(&s_und, 1u);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (u32 t = 0; t < SMALL_M / 256; ++t) { const u32 i = tid + 256 * t; if (dec[t] != 255) st[i] = dec[t]; }
+        const u32 und = s_und;                            // read before the barrier, reset (by thread 0) after it
+        __syncthreads();
+        if (und == 0) break;
+    }
+    __syncthreads();
+    // 4. encounter values of the stale and the rejected entries
+    for (u32 i = tid; i < m; i += 256) {
+        const u8 c = st[i];
+        if (c != 2 && c != 3) continue;
+        const u32 p = pos_s[i], pr = pr_s[i];
+        u32 v = v_s[i];
+        for (u32 j = i; j-- > 0 && v;) {                  // a selected left neighbour of higher priority covers p (:99-101)
+            if (p - pos_s[j] >= L) break;
+            if (st[j] == 1 && pr_s[j] < pr) v = 0;
+        }
+        for (u32 j = i + 1; j < m && v; ++j) {            // a selected right neighbour truncates (:103-109)
+            const u32 d = pos_s[j] - p;
+            if (d >= L) break;
+            if (st[j] == 1 && pr_s[j] < pr && d < v) v = d;
+        }
+        if (v >= threshold) {
+            const u32 idx = atomicAdd(&s_npush, 1u);
+            skey[idx] = ((u64)v << 32) | pr;              // the position sort is finished: skey is free
+            sval[idx] = p;
+        }
+    }
+    __syncthreads();
+    // 5. sort the pushes by (target, old priority)
+    const u32 npush = s_npush;
+    u32 nq2 = 1;
+    while (nq2 < npush) nq2 <<= 1;
+    for (u32 i = npush + tid; i < nq2; i += 256) { skey[i] = ~0ull; sval[i] = NONE32; }
+    __syncthreads();
+    for (u32 k2 = 2; k2 <= nq2; k2 <<= 1) {
+        for (u32 j = k2 >> 1; j > 0; j >>= 1) {
+            for (u32 i = tid; i < nq2; i += 256) {
+                const u32 x = i ^ j;
+                if (x > i) {
+                    const bool up = (i & k2) == 0;
+                    const u64 a = skey[i], b = skey[x];
+                    if ((a > b) == up) { skey[i] = b; skey[x] = a; const u32 t = sval[i]; sval[i] = sval[x]; sval[x] = t; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // 6. new priorities, pool slots, segments
+    for (u32 i = tid; i < npush; i += 256) {
+        const u32 p = sval[i];
+        prio[p] = prio_base + i;
+        pool[i] = p;
+    }
+    if (tid == 0) {
+        u32 nseg = 0;
+        for (u32 i = 0; i < npush; ++i) {
+            const u32 tgt = (u32)(skey[i] >> 32);
+            if (i == 0 || (u32)(skey[i - 1] >> 32) != tgt) {
+                if (nseg < SEG_INLINE) sc->segs[nseg] = PushSeg{tgt, i};
+                if (nseg < seg_cap) segs[nseg] = PushSeg{tgt, i};
+                ++nseg;
+            }
+        }
+        sc->nseg = nseg;
+        sc->npush = npush;
+    }
+    // 7. apply the selected entries (one wave per factor)
+    const u32 lane = tid & 63, wv = tid >> 6;
+    for (u32 i = wv; i < m; i += 4) {
+        if (st[i] != 1) continue;                         // wave-uniform
+        const u32 p = pos_s[i];
+        if (lane == 0) { flen[p] = L; fsrc[p] = phi[p]; atomicAdd(&s_sel, 1u); }
+        for (u32 j = lane; j < L && (size_t)p + j < n; j += 64) { cur[p + j] = 0; owner[p + j] = p; }
+        const u32 aff = (L < p) ? L : p;
+        for (u32 j = lane; j < aff; j += 64) { u32* q = &cur[p - 1 - j]; if (*q > j + 1) atomicMin(q, j + 1); }
+    }
+    __syncthreads();
+    if (tid == 0) { sc->selected = s_sel; sc->nlive = s_live; sc->nstale = s_alive - s_live; }
+}
+
+// ---- purge: drop the candidates that were erased by longer factors from all levels that are still to come ------------
+__global__ void purge_class_kernel(const u32* __restrict__ cand, size_t cnt, u32 threshold, const u32* __restrict__ cur, u8* __restrict__ cls) {
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < cnt) cls[j] = (cur[cand[j]] >= threshold) ? 1 : 0;
 }
 
 // Pushed part of a level's list: concatenation of its pool segments (table: source offset / destination offset).
@@ -284,7 +453,7 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
         gather_kernel<<<cdiv(entries, 256), 256, 0, s>>>(cvals[0], entries, plcp, ckeys[0]);
         LAUNCH_CHECK();
     }
-    const int x = radix_sort_pairs_u32(c, ckeys, cvals, entries, 0, (int)bits_for(maxlcp));
+    int x = radix_sort_pairs_u32(c, ckeys, cvals, entries, 0, (int)bits_for(maxlcp));
     const u32* cand = cvals[x];
     const size_t nlev = (size_t)maxlcp + 2;
     u32* d_segstart = c.arena.get<u32>(nlev);
@@ -300,9 +469,9 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
     c.read_n(d_segend, h_segend.data(), nlev);
 
     // ---- per-level state ------------------------------------------------------------------------------------
-    u32* ent = cvals[x ^ 1];                    // the candidate sort's scratch buffers are free now
-    u32* live = ckeys[0];
-    u32* stale = ckeys[1];
+    u32* ent = c.arena.get<u32>(n);
+    u32* live = c.arena.get<u32>(n);
+    u32* stale = c.arena.get<u32>(n);
     const size_t bm_words = n / 32 + 2;
     u64* bm = c.arena.get<u64>(bm_words);       // 2 state bits per position; all-zero between levels
     HIP_TRY(hipMemsetAsync(bm, 0, bm_words * sizeof(u64), s));
@@ -321,13 +490,48 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
 
     const u32 gtab_cap = 1u << 16;
     GatherSeg* d_gtab = (GatherSeg*)c.arena.alloc(sizeof(GatherSeg) * gtab_cap);
-    std::vector<GatherSeg> h_gtab(gtab_cap);
+    struct PinnedTab {                         // pinned, so the H2D copy is truly asynchronous
+        GatherSeg* p = nullptr;
+        ~PinnedTab() { if (p) (void)hipHostFree(p); }
+    } h_gtab_mem;
+    HIP_TRY(hipHostMalloc((void**)&h_gtab_mem.p, sizeof(GatherSeg) * gtab_cap, hipHostMallocDefault));
+    GatherSeg* h_gtab = h_gtab_mem.p;
     struct PoolSeg { u32 off, cnt; };
     std::vector<std::vector<PoolSeg>> pushed_into(nlev);     // per target level: its segments of the pool
     size_t pool_top = 0;
     u32 prio_base = (u32)n;
 
+    u32 dead_streak = 0, levels_since_purge = 1u << 30;
+    size_t cand_count = entries;
+
     for (u32 L = maxlcp; L >= threshold; --L) {
+        // ---- purge: after a run of large levels whose entries were (almost) all erased, drop the erased candidates of
+        //      every level still to come (they can never come back to life: cur only decreases)
+        if (dead_streak >= 4 && levels_since_purge >= 16) {
+            size_t cnt = 0;                                // candidates of the levels <= L form a prefix of the sorted array
+            for (u32 v = L;; --v) { if (h_segend[v] > h_segstart[v]) { cnt = h_segend[v]; break; } if (v == threshold) break; }
+            if (cnt > 65536) {
+                purge_class_kernel<<<cdiv(cnt, 256), 256, 0, s>>>(cvals[x], cnt, threshold, cur, cls);
+                LAUNCH_CHECK();
+                select_by_class(c, cls, 1, cnt, cvals[x], cvals[x ^ 1], nullptr, nullptr, d_cnt);
+                select_by_class(c, cls, 1, cnt, ckeys[x], ckeys[x ^ 1], nullptr, nullptr, d_cnt);
+                x ^= 1;
+                cand = cvals[x];
+                cand_count = c.read(d_cnt);
+                HIP_TRY(hipMemsetAsync(d_segstart, 0, ((size_t)L + 1) * sizeof(u32), s));
+                HIP_TRY(hipMemsetAsync(d_segend, 0, ((size_t)L + 1) * sizeof(u32), s));
+                if (cand_count) {
+                    seg_bounds_kernel<<<cdiv(cand_count, 256), 256, 0, s>>>(ckeys[x], cand_count, d_segstart, d_segend);
+                    LAUNCH_CHECK();
+                }
+                c.read_n(d_segstart, h_segstart.data(), (size_t)L + 1);
+                c.read_n(d_segend, h_segend.data(), (size_t)L + 1);
+                st->purges++;
+            }
+            levels_since_purge = 0;
+            dead_streak = 0;
+        }
+        ++levels_since_purge;
         const u32 m0 = h_segend[L] - h_segstart[L];
         u32 m1 = 0;
         {   // gather the pushed part of the list: one kernel per (at most gtab_cap) pool segments
@@ -340,11 +544,12 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
                 if (cntseg == 1) {
                     HIP_TRY(hipMemcpyAsync(pushed + m1, pool + h_gtab[0].src_off, (size_t)tot * sizeof(u32), hipMemcpyDeviceToDevice, s));
                 } else {
-                    // the table is staged through pageable memory: the copy has left h_gtab when the call returns
-                    HIP_TRY(hipMemcpyAsync(d_gtab, h_gtab.data(), cntseg * sizeof(GatherSeg), hipMemcpyHostToDevice, s));
+                    // every level ends with a synchronising read-back, so the pinned table is free again when the next level
+                    // fills it; only a second chunk inside the same level has to wait
+                    if (done) HIP_TRY(hipStreamSynchronize(s));
+                    HIP_TRY(hipMemcpyAsync(d_gtab, h_gtab, cntseg * sizeof(GatherSeg), hipMemcpyHostToDevice, s));
                     gather_segments_kernel<<<cdiv(tot, 256), 256, 0, s>>>(pool, d_gtab, (u32)cntseg, tot, pushed + m1);
                     LAUNCH_CHECK();
-                    HIP_TRY(hipStreamSynchronize(s));          // h_gtab is reused by the next chunk / level
                 }
                 m1 += tot;
                 done += cntseg;
@@ -354,6 +559,37 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
         const u32 m = m0 + m1;
         if (m == 0) continue;
         st->levels++;
+        if (m <= SMALL_M) {
+            // ---- whole level in one workgroup, one read-back ---------------------------------------------------------
+            if (pool_top + m > n || (u64)prio_base + m > 0xFFFFFFFFull)
+                throw HipError{hipErrorUnknown, "factorize: push pool overflow", (int)__LINE__};
+            {
+                Ctx::ProfScope prof(c, K_SMALL_LEVEL, (u64)m * 16);
+                small_level_kernel<<<1, 256, 0, s>>>(cand + h_segstart[L], m0, pushed, m, L, threshold, n, cur, prio, phi, fs.flen,
+                                                     fs.owner, fs.fsrc, pool + pool_top, prio_base, d_segs, seg_cap, d_sc);
+                LAUNCH_CHECK();
+            }
+            c.read_n((const u32*)d_sc, (u32*)&h_sc, sizeof(LevelScalars) / sizeof(u32));
+            st->small_levels++;
+            if (h_sc.nlive == 0 && h_sc.nstale == 0) continue;   // small levels do not count for the purge heuristic
+            st->factors += h_sc.selected;
+            const u32 npush = h_sc.npush, nseg = h_sc.nseg;
+            if (npush) {
+                if (nseg > seg_cap) throw HipError{hipErrorUnknown, "factorize: too many push targets in one level", (int)__LINE__};
+                if (nseg <= SEG_INLINE) std::copy(h_sc.segs, h_sc.segs + nseg, h_segs.begin());
+                else c.read_n(d_segs, h_segs.data(), nseg);
+                for (u32 j = 0; j < nseg; ++j) {           // written in order of `start` by one thread
+                    const u32 end = (j + 1 < nseg) ? h_segs[j + 1].start : npush;
+                    const u32 tgt = h_segs[j].target;
+                    if (tgt >= L || tgt < threshold) throw HipError{hipErrorUnknown, "factorize: bad push target", (int)__LINE__};
+                    pushed_into[tgt].push_back(PoolSeg{(u32)pool_top + h_segs[j].start, end - h_segs[j].start});
+                }
+                pool_top += npush;
+                prio_base += npush;
+                st->pushes += npush;
+            }
+            continue;
+        }
         HIP_TRY(hipMemsetAsync(d_sc, 0, 8 * sizeof(u32), s));
         const unsigned gm = cdiv(m, 256);
         {   // per entry: list (4) + cur (4) + ent (4) + class byte (1)
@@ -365,6 +601,7 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
         select_by_class(c, cls, CL_STALE, m, ent, stale, nullptr, nullptr, &d_sc->nstale);
         c.read_n((const u32*)d_sc, (u32*)&h_sc, 8);
         const u32 nl = h_sc.nlive, ns = h_sc.nstale;
+        if (((u64)nl + ns) * 16 < m) ++dead_streak; else dead_streak = 0;     // (almost) all entries already erased
         if (nl == 0 && ns == 0) continue;                     // every entry already erased (:86)
         const bool wide = (L > 24);
         const unsigned gl = wide ? cdiv((size_t)nl * 64, 256) : cdiv(nl, 256);

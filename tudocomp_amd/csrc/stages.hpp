@@ -33,7 +33,7 @@ struct FactorSpace {
     u32* fsrc = nullptr;
 };
 
-struct FactorizeStats { u64 factors = 0; u32 maxlcp = 0; u32 levels = 0; u32 rounds = 0; u64 pushes = 0; u64 entries = 0; };
+struct FactorizeStats { u64 factors = 0; u32 maxlcp = 0; u32 levels = 0; u32 rounds = 0; u64 pushes = 0; u64 entries = 0; u32 small_levels = 0; u32 purges = 0; };
 
 // a8: compressors/lcpcomp/compress/ArraysComp.hpp:36-117 in position space.
 // Inputs: isa, phi, plcp.  isa and plcp are consumed: they become the working priority / LCP arrays.
