@@ -243,6 +243,59 @@ __device__ __forceinline__ u32 block_inclusive_max(u32 v, u32* smem, u32& total)
     return res;
 }
 
+// ---- workgroup bitonic sort of 2048 (key, value) pairs held in registers ------------------------------------------
+// 256 threads x 8 elements; element index i = thread * 8 + r.  Compare-exchange partners at distance < 8 live in the
+// same thread, at distance 8..256 in the same wave (lane xor, __shfl_xor, no barrier); only distances >= 512 go through
+// LDS (3 barrier stages out of 66).  `xk` / `xv`: LDS scratch of 2048 entries each.  Ascending; keys must be distinct or
+// ties may land in any order.
+__device__ __forceinline__ void bitonic_cmpx(u64& ka, u32& va, u64& kb, u32& vb, bool up) {
+    if ((ka > kb) == up) { const u64 tk = ka; ka = kb; kb = tk; const u32 tv = va; va = vb; vb = tv; }
+}
+// `np2`: power of two >= number of real elements (the rest is padding with maximal keys): the network only has to
+// merge up to blocks of np2 elements, which shortens it from 66 to log2(np2)*(log2(np2)+1)/2 stages.
+__device__ inline void block_bitonic_sort_2048(u64 (&k)[8], u32 (&v)[8], u64* xk, u32* xv, u32 np2 = 2048) {
+    const u32 t = threadIdx.x;
+    for (u32 k2 = 2; k2 <= np2; k2 <<= 1) {
+        for (u32 j = k2 >> 1; j > 0; j >>= 1) {
+            if (j < 8) {                                   // same thread
+#pragma unroll
+                for (u32 r = 0; r < 8; ++r) {
+                    const u32 x = r ^ j;
+                    if (x > r) bitonic_cmpx(k[r], v[r], k[x], v[x], (((t * 8 + r) & k2) == 0));
+                }
+            } else if (j < 512) {                          // same wave: partner lane = lane ^ (j / 8)
+                const u32 lm = j >> 3;
+                const bool lower = ((t & lm) == 0);        // this thread holds the lower index of every pair
+#pragma unroll
+                for (u32 r = 0; r < 8; ++r) {
+                    const u64 ok = __shfl_xor(k[r], (int)lm, 64);
+                    const u32 ov = __shfl_xor(v[r], (int)lm, 64);
+                    const bool up = (((t * 8 + r) & k2) == 0);
+                    // the pair (lower index i, upper index i ^ j): keep min at the lower index iff `up`
+                    const bool take_other = lower ? ((k[r] > ok) == up) : ((ok > k[r]) == up);
+                    if (take_other) { k[r] = ok; v[r] = ov; }
+                }
+            } else {                                       // across waves: through LDS
+                __syncthreads();
+#pragma unroll
+                for (u32 r = 0; r < 8; ++r) { xk[t * 8 + r] = k[r]; xv[t * 8 + r] = v[r]; }
+                __syncthreads();
+                const bool lower = (((t * 8) & j) == 0);
+#pragma unroll
+                for (u32 r = 0; r < 8; ++r) {
+                    const u32 i = t * 8 + r;
+                    const u64 ok = xk[i ^ j];
+                    const u32 ov = xv[i ^ j];
+                    const bool up = ((i & k2) == 0);
+                    const bool take_other = lower ? ((k[r] > ok) == up) : ((ok > k[r]) == up);
+                    if (take_other) { k[r] = ok; v[r] = ov; }
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
 #endif  // __HIPCC__
 
 }  // namespace tdc

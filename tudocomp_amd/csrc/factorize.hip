@@ -189,49 +189,48 @@ __global__ __launch_bounds__(256) void resolve_kernel(const u32* __restrict__ li
 // (bitonic, LDS), new priorities / pool slots / segments, apply.  One read-back per level instead of four or five.
 constexpr u32 SMALL_M = 2048;
 
+constexpr u32 SMALL_APPLY_INLINE_MAX_L = 64;      // longer factors are applied by a separate, chip-wide launch
+
 __global__ __launch_bounds__(256) void small_level_kernel(const u32* __restrict__ orig, u32 m0, const u32* __restrict__ pushed, u32 m,
                                                            u32 L, u32 threshold, size_t n, u32* cur, u32* prio,
                                                            const u32* __restrict__ phi, u32* __restrict__ flen, u32* __restrict__ owner,
                                                            u32* __restrict__ fsrc, u32* __restrict__ pool, u32 prio_base,
-                                                           PushSeg* __restrict__ segs, u32 seg_cap, LevelScalars* __restrict__ sc) {
-    // The entries are sorted by text position in LDS, so "neighbours within distance < L" are adjacent slots: the
-    // whole level runs out of LDS, without the global state bitmap.
-    __shared__ u64 skey[SMALL_M];          // (position << 32 | k) for the position sort, later (target << 32 | priority)
-    __shared__ u32 pos_s[SMALL_M], pr_s[SMALL_M], v_s[SMALL_M], sval[SMALL_M];
+                                                           PushSeg* __restrict__ segs, u32 seg_cap, u32* __restrict__ sel_list,
+                                                           LevelScalars* __restrict__ sc) {
+    // The entries are sorted by text position (bitonic network in registers), so "neighbours within distance < L" are
+    // adjacent slots of LDS arrays: the whole level runs without the global state bitmap.
+    __shared__ u64 skey[SMALL_M];          // sort scratch, later the push records (target << 32 | priority)
+    __shared__ u32 sval[SMALL_M];
+    __shared__ u32 pos_s[SMALL_M], pr_s[SMALL_M], v_s[SMALL_M];
     __shared__ u8 st[SMALL_M];             // 0 undecided, 1 selected, 2 stale, 3 rejected, 4 dead
     __shared__ u32 s_und, s_npush, s_sel, s_live, s_alive;
     const u32 tid = threadIdx.x;
     if (tid == 0) { s_npush = 0; s_sel = 0; s_live = 0; s_alive = 0; }
-    u32 np2 = 1;
-    while (np2 < m) np2 <<= 1;
-    for (u32 k = tid; k < np2; k += 256) {
-        if (k < m) { const u32 p = (k < m0) ? orig[k] : pushed[k - m0]; skey[k] = ((u64)p << 32) | k; }
-        else skey[k] = ~0ull;
-    }
-    __syncthreads();
+    u64 k[8];
+    u32 v[8];
     // 1. sort by position (positions are distinct)
-    for (u32 k2 = 2; k2 <= np2; k2 <<= 1) {
-        for (u32 j = k2 >> 1; j > 0; j >>= 1) {
-            for (u32 i = tid; i < np2; i += 256) {
-                const u32 x = i ^ j;
-                if (x > i) {
-                    const bool up = (i & k2) == 0;
-                    const u64 a = skey[i], b = skey[x];
-                    if ((a > b) == up) { skey[i] = b; skey[x] = a; }
-                }
-            }
-            __syncthreads();
-        }
+#pragma unroll
+    for (u32 r = 0; r < 8; ++r) {
+        const u32 i = tid * 8 + r;
+        k[r] = (i < m) ? (u64)((i < m0) ? orig[i] : pushed[i - m0]) : ~0ull;
+        v[r] = 0;
     }
+    u32 mp2 = 8;
+    while (mp2 < m) mp2 <<= 1;
+    block_bitonic_sort_2048(k, v, skey, sval, mp2);
     // 2. classify
-    for (u32 i = tid; i < m; i += 256) {
-        const u32 p = (u32)(skey[i] >> 32);
-        const u32 v = cur[p];
-        pos_s[i] = p; v_s[i] = v; pr_s[i] = prio[p];
-        const u8 c = (v == L) ? 0 : (v >= threshold ? 2 : 4);
-        st[i] = c;
-        if (c == 0) atomicAdd(&s_live, 1u);
-        if (c != 4) atomicAdd(&s_alive, 1u);
+#pragma unroll
+    for (u32 r = 0; r < 8; ++r) {
+        const u32 i = tid * 8 + r;
+        if (i < m) {
+            const u32 p = (u32)k[r];
+            const u32 val = cur[p];
+            pos_s[i] = p; v_s[i] = val; pr_s[i] = prio[p];
+            const u8 c = (val == L) ? 0 : (val >= threshold ? 2 : 4);
+            st[i] = c;
+            if (c == 0) atomicAdd(&s_live, 1u);
+            if (c != 4) atomicAdd(&s_alive, 1u);
+        }
     }
     __syncthreads();
     if (s_alive == 0) {                                   // every entry already erased (:86)
@@ -242,11 +241,11 @@ __global__ __launch_bounds__(256) void small_level_kernel(const u32* __restrict_
     for (u32 round = 0; round <= m && s_live; ++round) {
         if (tid == 0) s_und = 0;
         __syncthreads();
-        u8 dec[SMALL_M / 256];
+        u8 dec[8];
 #pragma unroll
-        for (u32 t = 0; t < SMALL_M / 256; ++t) {
-            const u32 i = tid + 256 * t;
-            dec[t] = 255;
+        for (u32 r = 0; r < 8; ++r) {
+            const u32 i = tid * 8 + r;
+            dec[r] = 255;
             if (i < m && st[i] == 0) {
                 const u32 p = pos_s[i], pr = pr_s[i];
                 bool hit = false, blocked = false;
@@ -262,58 +261,53 @@ __global__ __launch_bounds__(256) void small_level_kernel(const u32* __restrict_
                     if (sj == 1) { hit = true; break; }
                     if (sj == 0 && pr_s[j] < pr) blocked = true;
                 }
-                if (hit) dec[t] = 3; else if (!blocked) dec[t] = 1; else atomicAdd(&s_und, 1u);
+                if (hit) dec[r] = 3; else if (!blocked) dec[r] = 1; else atomicAdd(&s_und, 1u);
             }
         }
         __syncthreads();
 #pragma unroll
-        for (u32 t = 0; t < SMALL_M / 256; ++t) { const u32 i = tid + 256 * t; if (dec[t] != 255) st[i] = dec[t]; }
+        for (u32 r = 0; r < 8; ++r) { const u32 i = tid * 8 + r; if (dec[r] != 255) st[i] = dec[r]; }
         const u32 und = s_und;                            // read before the barrier, reset (by thread 0) after it
         __syncthreads();
         if (und == 0) break;
     }
     __syncthreads();
-    // 4. encounter values of the stale and the rejected entries
+    // 4. encounter values of the stale and the rejected entries -> push records
     for (u32 i = tid; i < m; i += 256) {
         const u8 c = st[i];
         if (c != 2 && c != 3) continue;
         const u32 p = pos_s[i], pr = pr_s[i];
-        u32 v = v_s[i];
-        for (u32 j = i; j-- > 0 && v;) {                  // a selected left neighbour of higher priority covers p (:99-101)
+        u32 val = v_s[i];
+        for (u32 j = i; j-- > 0 && val;) {                // a selected left neighbour of higher priority covers p (:99-101)
             if (p - pos_s[j] >= L) break;
-            if (st[j] == 1 && pr_s[j] < pr) v = 0;
+            if (st[j] == 1 && pr_s[j] < pr) val = 0;
         }
-        for (u32 j = i + 1; j < m && v; ++j) {            // a selected right neighbour truncates (:103-109)
+        for (u32 j = i + 1; j < m && val; ++j) {          // a selected right neighbour truncates (:103-109)
             const u32 d = pos_s[j] - p;
             if (d >= L) break;
-            if (st[j] == 1 && pr_s[j] < pr && d < v) v = d;
+            if (st[j] == 1 && pr_s[j] < pr && d < val) val = d;
         }
-        if (v >= threshold) {
+        if (val >= threshold) {
             const u32 idx = atomicAdd(&s_npush, 1u);
-            skey[idx] = ((u64)v << 32) | pr;              // the position sort is finished: skey is free
+            skey[idx] = ((u64)val << 32) | pr;
             sval[idx] = p;
         }
     }
     __syncthreads();
     // 5. sort the pushes by (target, old priority)
     const u32 npush = s_npush;
-    u32 nq2 = 1;
-    while (nq2 < npush) nq2 <<= 1;
-    for (u32 i = npush + tid; i < nq2; i += 256) { skey[i] = ~0ull; sval[i] = NONE32; }
-    __syncthreads();
-    for (u32 k2 = 2; k2 <= nq2; k2 <<= 1) {
-        for (u32 j = k2 >> 1; j > 0; j >>= 1) {
-            for (u32 i = tid; i < nq2; i += 256) {
-                const u32 x = i ^ j;
-                if (x > i) {
-                    const bool up = (i & k2) == 0;
-                    const u64 a = skey[i], b = skey[x];
-                    if ((a > b) == up) { skey[i] = b; skey[x] = a; const u32 t = sval[i]; sval[i] = sval[x]; sval[x] = t; }
-                }
-            }
-            __syncthreads();
-        }
+#pragma unroll
+    for (u32 r = 0; r < 8; ++r) {
+        const u32 i = tid * 8 + r;
+        k[r] = (i < npush) ? skey[i] : ~0ull;
+        v[r] = (i < npush) ? sval[i] : NONE32;
     }
+    u32 qp2 = 8;
+    while (qp2 < npush) qp2 <<= 1;
+    if (npush > 1) block_bitonic_sort_2048(k, v, skey, sval, qp2); else __syncthreads();
+#pragma unroll
+    for (u32 r = 0; r < 8; ++r) { const u32 i = tid * 8 + r; skey[i] = k[r]; sval[i] = v[r]; }
+    __syncthreads();
     // 6. new priorities, pool slots, segments
     for (u32 i = tid; i < npush; i += 256) {
         const u32 p = sval[i];
@@ -333,18 +327,36 @@ __global__ __launch_bounds__(256) void small_level_kernel(const u32* __restrict_
         sc->nseg = nseg;
         sc->npush = npush;
     }
-    // 7. apply the selected entries (one wave per factor)
-    const u32 lane = tid & 63, wv = tid >> 6;
-    for (u32 i = wv; i < m; i += 4) {
-        if (st[i] != 1) continue;                         // wave-uniform
-        const u32 p = pos_s[i];
-        if (lane == 0) { flen[p] = L; fsrc[p] = phi[p]; atomicAdd(&s_sel, 1u); }
-        for (u32 j = lane; j < L && (size_t)p + j < n; j += 64) { cur[p + j] = 0; owner[p + j] = p; }
-        const u32 aff = (L < p) ? L : p;
-        for (u32 j = lane; j < aff; j += 64) { u32* q = &cur[p - 1 - j]; if (*q > j + 1) atomicMin(q, j + 1); }
+    // 7. the selected entries: applied here (one wave per factor) or, for long factors, listed for a chip-wide launch
+    if (L <= SMALL_APPLY_INLINE_MAX_L) {
+        const u32 lane = tid & 63, wv = tid >> 6;
+        for (u32 i = wv; i < m; i += 4) {
+            if (st[i] != 1) continue;                     // wave-uniform
+            const u32 p = pos_s[i];
+            if (lane == 0) { flen[p] = L; fsrc[p] = phi[p]; atomicAdd(&s_sel, 1u); }
+            for (u32 j = lane; j < L && (size_t)p + j < n; j += 64) { cur[p + j] = 0; owner[p + j] = p; }
+            const u32 aff = (L < p) ? L : p;
+            for (u32 j = lane; j < aff; j += 64) { u32* q = &cur[p - 1 - j]; if (*q > j + 1) atomicMin(q, j + 1); }
+        }
+    } else {
+        for (u32 i = tid; i < m; i += 256) if (st[i] == 1) sel_list[atomicAdd(&s_sel, 1u)] = pos_s[i];
     }
     __syncthreads();
     if (tid == 0) { sc->selected = s_sel; sc->nlive = s_live; sc->nstale = s_alive - s_live; }
+}
+
+// apply for a list of selected positions whose length is only known on the device (one wave per factor)
+__global__ __launch_bounds__(256) void apply_list_kernel(const u32* __restrict__ list, const u32* __restrict__ d_count, u32 L, size_t n,
+                                                          const u32* __restrict__ phi, u32* __restrict__ cur, u32* __restrict__ flen,
+                                                          u32* __restrict__ owner, u32* __restrict__ fsrc) {
+    const u32 i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const u32 lane = threadIdx.x & 63;
+    if (i >= *d_count) return;
+    const u32 p = list[i];
+    if (lane == 0) { flen[p] = L; fsrc[p] = phi[p]; }
+    for (u32 j = lane; j < L && (size_t)p + j < n; j += 64) { cur[p + j] = 0; owner[p + j] = p; }
+    const u32 aff = (L < p) ? L : p;
+    for (u32 j = lane; j < aff; j += 64) { u32* q = &cur[p - 1 - j]; if (*q > j + 1) atomicMin(q, j + 1); }
 }
 
 // ---- purge: drop the candidates that were erased by longer factors from all levels that are still to come ------------
@@ -566,8 +578,12 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
             {
                 Ctx::ProfScope prof(c, K_SMALL_LEVEL, (u64)m * 16);
                 small_level_kernel<<<1, 256, 0, s>>>(cand + h_segstart[L], m0, pushed, m, L, threshold, n, cur, prio, phi, fs.flen,
-                                                     fs.owner, fs.fsrc, pool + pool_top, prio_base, d_segs, seg_cap, d_sc);
+                                                     fs.owner, fs.fsrc, pool + pool_top, prio_base, d_segs, seg_cap, live, d_sc);
                 LAUNCH_CHECK();
+                if (L > SMALL_APPLY_INLINE_MAX_L) {        // long factors: the kills are spread over the whole chip
+                    apply_list_kernel<<<cdiv((size_t)m * 64, 256), 256, 0, s>>>(live, &d_sc->selected, L, n, phi, cur, fs.flen, fs.owner, fs.fsrc);
+                    LAUNCH_CHECK();
+                }
             }
             c.read_n((const u32*)d_sc, (u32*)&h_sc, sizeof(LevelScalars) / sizeof(u32));
             st->small_levels++;

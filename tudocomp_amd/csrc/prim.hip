@@ -369,41 +369,30 @@ constexpr int SMALL_SORT_MAX = 2048;
 __global__ __launch_bounds__(256) void small_sort_kernel(const u64* __restrict__ keys_in, const u32* __restrict__ vals_in,
                                                           u64* __restrict__ keys_out, u32* __restrict__ vals_out, u32 n, u32 np2,
                                                           u64 keymask) {
-    __shared__ u64 sk[SMALL_SORT_MAX];
-    __shared__ u32 sv[SMALL_SORT_MAX];
-    for (u32 i = threadIdx.x; i < np2; i += 256) {
-        sk[i] = (i < n) ? (keys_in[i] & keymask) : ~0ull;      // padding sorts to the end (real keys have < 64 sorted bits or are distinct from ~0)
-        sv[i] = (i < n) ? i : 0xFFFFFFFFu;                      // carry the input index: the full key is re-read at the end
+    __shared__ u64 xk[SMALL_SORT_MAX];
+    __shared__ u32 xv[SMALL_SORT_MAX];
+    u64 k[8];
+    u32 v[8];
+#pragma unroll
+    for (u32 r = 0; r < 8; ++r) {
+        const u32 i = threadIdx.x * 8 + r;
+        k[r] = (i < n) ? (keys_in[i] & keymask) : ~0ull;      // padding sorts to the end
+        v[r] = (i < n) ? i : 0xFFFFFFFFu;                      // carry the input index: the full pair is re-read at the end
     }
-    __syncthreads();
-    for (u32 k = 2; k <= np2; k <<= 1) {
-        for (u32 j = k >> 1; j > 0; j >>= 1) {
-            for (u32 i = threadIdx.x; i < np2; i += 256) {
-                const u32 x = i ^ j;
-                if (x > i) {
-                    const bool up = (i & k) == 0;
-                    const u64 a = sk[i], b = sk[x];
-                    // ties (only padding vs padding, or equal masked keys of padding) are broken by the index
-                    const bool gt = (a > b) || (a == b && sv[i] > sv[x]);
-                    if (gt == up) { sk[i] = b; sk[x] = a; const u32 t = sv[i]; sv[i] = sv[x]; sv[x] = t; }
-                }
-            }
-            __syncthreads();
-        }
-    }
-    for (u32 i = threadIdx.x; i < n; i += 256) {
-        const u32 src = sv[i];
-        keys_out[i] = keys_in[src];
-        vals_out[i] = vals_in[src];
+    block_bitonic_sort_2048(k, v, xk, xv, np2);
+#pragma unroll
+    for (u32 r = 0; r < 8; ++r) {
+        const u32 i = threadIdx.x * 8 + r;
+        if (i < n) { keys_out[i] = keys_in[v[r]]; vals_out[i] = vals_in[v[r]]; }
     }
 }
 
 int sort_pairs_u64_distinct(Ctx& c, u64* keys[2], u32* vals[2], size_t n, int b, int e) {
     if (n == 0 || e <= b) return 0;
     if (n > (size_t)SMALL_SORT_MAX || b != 0) return radix_sort_pairs<u64>(c, keys, vals, n, b, e);
-    u32 np2 = 2;
-    while (np2 < n) np2 <<= 1;
     const u64 keymask = (e >= 64) ? ~0ull : ((1ull << e) - 1);
+    u32 np2 = 8;
+    while (np2 < n) np2 <<= 1;
     small_sort_kernel<<<1, 256, 0, c.stream>>>(keys[0], vals[0], keys[1], vals[1], (u32)n, np2, keymask);
     LAUNCH_CHECK();
     return 1;
