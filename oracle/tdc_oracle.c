@@ -631,15 +631,75 @@ int orc_huff_encode_literals(const uint8_t* lits, size_t n, int interleave, uint
 }
 
 /* ------------------------------------------------------------------------------------------------
- * lzss::encode_text (LZSSCoding.hpp:18-92) with tdc::Encoder's binary integer coding (Coder.hpp:61-77)
+ * ArithmeticCoder::Encoder  (coders/ArithmeticCoder.hpp:35-177): static model, 64-bit interval, codes interleaved
+ * into the shared bit stream.  In lcpcomp this combination is not registered and not decodable by the reference
+ * (SURVEY 0.3); parity is defined on the compress side only.
  * ---------------------------------------------------------------------------------------------- */
-int orc_encode_huff(const uint8_t* text, size_t n, const orc_factor* f, size_t z,
-                    uint8_t** out, size_t* out_len, orc_stats* st) {
+typedef struct {
+    uint32_t C[256];                 /* normalised cumulative counts (:72-92) */
+    uint64_t lower, upper;           /* :39-40 */
+    uint8_t codebook_size;           /* :41 (uliteral_t: wraps at 256) */
+    uint32_t literal_count, literal_counter;   /* :43-44 */
+    uint64_t min_range;              /* :45 */
+} arith_enc;
+
+static void arith_init(arith_enc* a, const uint32_t counts[256], bitout* b) {
+    memcpy(a->C, counts, sizeof(a->C));
+    a->lower = 0; a->upper = ~0ull; a->codebook_size = 0; a->literal_counter = 0;
+    uint32_t* c = a->C;
+    if (c[0] != 0u) a->codebook_size++;                                   /* build_intervals :73-75 */
+    uint32_t min = 0xFFFFFFFFu;
+    for (int i = 1; i <= 255; ++i) {                                      /* :78-84 */
+        if (c[i] != 0u) { a->codebook_size++; if (c[i] < min) min = c[i]; }
+        c[i] = c[i] + c[i - 1];
+    }
+    a->literal_count = c[254];                                            /* :85 */
+    for (int i = 0; i <= 255; ++i) c[i] = c[i] / min;                     /* :88-90 */
+    a->min_range = c[254];                                                /* :91 */
+    bo_write_int(b, a->literal_count, 32);                                /* writeCodebook :128-143 */
+    bo_write_int(b, a->codebook_size, 8);
+    if (c[0] != 0u) { bo_write_int(b, 0, 8); bo_write_int(b, c[0], 32); }
+    for (int i = 1; i <= 255; ++i) if (c[i] != c[i - 1]) { bo_write_int(b, (uint64_t)i, 8); bo_write_int(b, c[i], 32); }
+}
+/* returns 0, or -1 when the reference itself would divide by zero (no literal byte >= 1 with a non-zero count) */
+static int arith_encode(arith_enc* a, bitout* b, uint8_t v) {            /* encode :169-176 */
+    a->literal_counter++;
+    uint64_t range = a->upper - a->lower;                                 /* setNewBounds :96-117 */
+    if (range < a->min_range) {
+        bo_write_int(b, a->lower, 64);
+        a->lower = 0; a->upper = ~0ull;
+        range = a->upper - a->lower;
+    }
+    const uint64_t tot = a->C[255];
+    if (tot == 0) return -1;
+    const uint64_t off_u = range <= tot ? (range * a->C[v]) / tot : (range / tot) * a->C[v];
+    a->upper = a->lower + off_u;
+    if (v != 0) {
+        const uint64_t off_l = range <= tot ? (range * a->C[v - 1]) / tot : (range / tot) * a->C[v - 1];
+        a->lower = a->lower + off_l;
+    }
+    if (a->literal_counter == a->literal_count) {                         /* postProcessing :151-155 */
+        bo_write_int(b, a->lower, 64);
+        bo_write_int(b, ~0ull, 64);
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * lzss::encode_text (LZSSCoding.hpp:18-92) with tdc::Encoder's binary integer coding (Coder.hpp:61-77)
+ * coder: 0 = HuffmanCoder, 1 = ArithmeticCoder
+ * ---------------------------------------------------------------------------------------------- */
+static int encode_stream(const uint8_t* text, size_t n, const orc_factor* f, size_t z, int coder,
+                         uint8_t** out, size_t* out_len, orc_stats* st) {
     uint32_t C[256];
     orc_literal_histogram(text, n, f, z, C);
-    orc_hufftable t; orc_huffman_table(C, &t);
+    orc_hufftable t; memset(&t, 0, sizeof(t));
+    arith_enc ac;
     bitout b; bo_init(&b);
-    huff_write_header(&b, &t);                                            /* Encoder ctor */
+    if (coder == 0) { orc_huffman_table(C, &t); huff_write_header(&b, &t); }   /* Encoder ctor */
+    else arith_init(&ac, C, &b);
+    int rc = 0;
+#define ENC_LITERAL(ch) do { if (coder == 0) huff_encode_literal(&b, &t, (ch)); else if (arith_encode(&ac, &b, (ch))) rc = -8; } while (0)
 
     uint64_t flen_min = 0xFFFFFFFFull, flen_max = 0, fdist_max = 0;       /* LZSSFactors.hpp:33-38 INDEX_MAX / 0 */
     {
@@ -663,22 +723,43 @@ int orc_encode_huff(const uint8_t* text, size_t n, const orc_factor* f, size_t z
     for (size_t i = 0; i < z; ++i) {                                       /* :54-81 */
         if (f[i].pos == p) bo_write_bit(&b, 0);
         else { bo_write_bit(&b, 1); bo_write_int(&b, f[i].pos - p, dbits); }
-        while (p < f[i].pos) huff_encode_literal(&b, &t, text[p++]);
+        while (p < f[i].pos) ENC_LITERAL(text[p++]);
         bo_write_int(&b, f[i].src, W);
         bo_write_int(&b, f[i].len - flen_min, lbits);
         p += f[i].len;
     }
     if (p < n) { bo_write_bit(&b, 1); bo_write_int(&b, n - p, dbits); }    /* :83-86 */
-    while (p < n) huff_encode_literal(&b, &t, text[p++]);                  /* :88-91 */
+    while (p < n) ENC_LITERAL(text[p++]);                                  /* :88-91 */
+#undef ENC_LITERAL
     bo_finish(&b);                                                         /* ~BitOStream */
     *out = b.buf; *out_len = b.len;
     if (st) { st->flen_min = flen_min; st->flen_max = flen_max; st->fdist_max = fdist_max; }
-    return 0;
+    return rc;
+}
+
+int orc_encode_huff(const uint8_t* text, size_t n, const orc_factor* f, size_t z,
+                    uint8_t** out, size_t* out_len, orc_stats* st) {
+    return encode_stream(text, n, f, z, 0, out, out_len, st);
+}
+int orc_encode_arith(const uint8_t* text, size_t n, const orc_factor* f, size_t z,
+                     uint8_t** out, size_t* out_len, orc_stats* st) {
+    return encode_stream(text, n, f, z, 1, out, out_len, st);
 }
 
 /* LCPCompressor.hpp:100-138 */
+static int lcpcomp_compress(const uint8_t* text, size_t n, uint32_t threshold, int flatten, int coder,
+                            uint8_t** out, size_t* out_len, orc_stats* stats);
 int orc_lcpcomp_huff_compress(const uint8_t* text, size_t n, uint32_t threshold, int flatten,
                               uint8_t** out, size_t* out_len, orc_stats* stats) {
+    return lcpcomp_compress(text, n, threshold, flatten, 0, out, out_len, stats);
+}
+/* LCPCompressor<ArithmeticCoder, ArraysComp, ...>::compress (BASELINE.json configs[2]) */
+int orc_lcpcomp_arith_compress(const uint8_t* text, size_t n, uint32_t threshold, int flatten,
+                               uint8_t** out, size_t* out_len, orc_stats* stats) {
+    return lcpcomp_compress(text, n, threshold, flatten, 1, out, out_len, stats);
+}
+static int lcpcomp_compress(const uint8_t* text, size_t n, uint32_t threshold, int flatten, int coder,
+                            uint8_t** out, size_t* out_len, orc_stats* stats) {
     orc_stats local; if (!stats) stats = &local;
     memset(stats, 0, sizeof(*stats));
     stats->n = n;
@@ -706,7 +787,7 @@ int orc_lcpcomp_huff_compress(const uint8_t* text, size_t n, uint32_t threshold,
     orc_sort_factors(F, z);                    stats->t_sort = now_s() - t; t = now_s();
     if (flatten) orc_flatten(F, z, &stats->num_flattened, &stats->max_depth_lb);
     stats->t_flatten = now_s() - t; t = now_s();
-    rc = orc_encode_huff(text, n, F, z, out, out_len, stats);
+    rc = encode_stream(text, n, F, z, coder, out, out_len, stats);
     stats->t_encode = now_s() - t;
     free(F);
     stats->t_total = now_s() - t0;

@@ -88,6 +88,12 @@ int orc_lcpcomp_huff_compress(const uint8_t* text, size_t n, uint32_t threshold,
 /* Encode a given, sorted factor list (LZSSCoding.hpp:18-92 + HuffmanCoder::Encoder :526-569 + BitOStream dtor). */
 int orc_encode_huff(const uint8_t* text, size_t n, const orc_factor* f, size_t z,
                     uint8_t** out, size_t* out_len, orc_stats* stats);
+/* The same with coder = ArithmeticCoder (coders/ArithmeticCoder.hpp:35-177; BASELINE.json configs[2]).  Compress side
+ * only: the reference cannot decode this combination.  Returns -8 where the reference would divide by 0. */
+int orc_lcpcomp_arith_compress(const uint8_t* text, size_t n, uint32_t threshold, int flatten,
+                               uint8_t** out, size_t* out_len, orc_stats* stats);
+int orc_encode_arith(const uint8_t* text, size_t n, const orc_factor* f, size_t z,
+                     uint8_t** out, size_t* out_len, orc_stats* stats);
 /* LCPCompressor.hpp:140-150 / decode_text_internal :23-76 with HuffmanCoder::Decoder.
  * Produces the (still escaped, 0-terminated) text. *out malloc'd. */
 int orc_lcpcomp_huff_decompress(const uint8_t* in, size_t in_len, uint8_t** out, size_t* out_len);

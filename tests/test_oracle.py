@@ -84,6 +84,12 @@ def test_survey_lcpcomp_anchors(a):
     assert O.unescape(O.lcpcomp_huff_decompress(out)) == data
 
 
+@pytest.mark.parametrize("a", ANCH["lcpcomp_arith"], ids=lambda a: "%s_t%d" % (a["text"], a["threshold"]))
+def test_survey_lcpcomp_arithmetic_anchor(a):
+    out, _ = O.lcpcomp_arith_compress(O.escape(_gen_text(a["text"])), a["threshold"], 1)
+    assert len(out) == a["size"] and sha256(out) == a["sha256"]
+
+
 @pytest.mark.parametrize("a", ANCH["lz78_gamma"], ids=lambda a: a["text"])
 def test_survey_lz78_anchors(a):
     out = O.lz78_gamma_compress(_gen_text(a["text"]))
