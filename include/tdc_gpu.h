@@ -36,7 +36,7 @@ typedef enum {
 } tdc_gpu_status;
 
 /* coder ids (option `coder`, etc/registry_config.py:28-31,138-142) */
-enum { TDC_GPU_CODER_HUFF = 0, TDC_GPU_CODER_GAMMA = 1 };
+enum { TDC_GPU_CODER_HUFF = 0, TDC_GPU_CODER_GAMMA = 1, TDC_GPU_CODER_ARITH = 2 };
 
 typedef struct tdc_gpu_ctx tdc_gpu_ctx;
 
@@ -84,7 +84,10 @@ void tdc_gpu_free(void* p);
 
 /* ---- the hot path: replaces LCPCompressor::compress (LCPCompressor.hpp:100-138) --------------------------- */
 /* Host buffers in, host buffer out (H2D + all kernels + D2H).  threshold/flatten = the dynamic options of the
- * same name (LCPCompressor.hpp:92-93, defaults 5 and 1).  `stats` may be NULL. */
+ * same name (LCPCompressor.hpp:92-93, defaults 5 and 1).  `stats` may be NULL.
+ * coder: TDC_GPU_CODER_HUFF (HuffmanCoder) or TDC_GPU_CODER_ARITH (ArithmeticCoder, coders/ArithmeticCoder.hpp:35-177 --
+ * compress side only: the reference itself cannot decode lcpcomp + arithmetic; returns
+ * TDC_GPU_ERR_UNSUPPORTED for inputs on which the reference divides by zero). */
 int tdc_gpu_lcpcomp_compress(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, uint32_t threshold, int flatten,
                              int coder, uint8_t** out, size_t* out_len, tdc_gpu_stats* stats);
 /* Device-resident variant: d_text and d_out are device pointers on ctx's GPU (d_out 8-byte aligned, capacity out_cap
@@ -124,6 +127,10 @@ int tdc_gpu_flatten(tdc_gpu_ctx* ctx, size_t n, const uint32_t* pos, uint32_t* s
 /* HuffmanCoder::Encoder + lzss::encode_text on a caller-supplied factor list sorted by pos (LZSSCoding.hpp:18-92) */
 int tdc_gpu_encode_huff(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, const uint32_t* pos, const uint32_t* src,
                         const uint32_t* len, size_t z, uint8_t** out, size_t* out_len);
+
+/* the same with ArithmeticCoder::Encoder as the literal coder (coders/ArithmeticCoder.hpp:35-177) */
+int tdc_gpu_encode_arith(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, const uint32_t* pos, const uint32_t* src,
+                         const uint32_t* len, size_t z, uint8_t** out, size_t* out_len);
 
 /* ---- host-side helpers (no GPU) --------------------------------------------------------------------------- */
 /* io/RestrictedBuffer.hpp:43-74 + io/EscapeMap.hpp:39-64 : 0x00 -> FF FE, 0xFF -> FF FF, append 0.

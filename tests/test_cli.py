@@ -77,8 +77,12 @@ def test_errors(tmp_path):
     assert r.returncode == 1 and "No implementation found" in r.stderr
     r = _run("-a", "lzw(coder=huff)", "-o", str(tmp_path / "o5"), str(f))
     assert r.returncode == 1 and "No implementation found" in r.stderr
-    r = _run("-a", "lcpcomp(coder=arithmetic)", "-o", str(tmp_path / "o3"), str(f))
+    r = _run("-a", "lcpcomp(coder=sle)", "-o", str(tmp_path / "o3"), str(f))
     assert r.returncode == 1 and "No implementation found" in r.stderr
+    g = tmp_path / "arith.tdc"
+    g.write_bytes(b"lcpcomp(coder=arithmetic)%" + b"\x00" * 16)
+    r = _run("-d", "-o", str(tmp_path / "o6"), str(g))
+    assert r.returncode == 1 and "cannot be decoded" in r.stderr
 
 
 @pytest.mark.gpu

@@ -143,7 +143,7 @@ def test_error_codes(gpu_ctx):
         gpu_ctx.lcpcomp_compress(b"abc\x00", 0, 1)
     assert e.value.status == -2
     with pytest.raises(RuntimeError, match="No implementation found"):
-        T.LCPCompressor(gpu_ctx, coder="arithmetic")
+        T.LCPCompressor(gpu_ctx, coder="sle")
     # the context is still usable afterwards
     want, _ = O.lcpcomp_huff_compress(b"abcabc\x00", 2, 1)
     assert gpu_ctx.lcpcomp_compress(b"abcabc\x00", 2, 1)[0] == want
@@ -203,3 +203,45 @@ def test_lzss_lcp_random_and_medium(gpu_ctx):
         assert O.unescape(O.lcpcomp_huff_decompress(got)) == data
     with pytest.raises(RuntimeError, match="No implementation found"):
         T.LZSSLCPCompressor(gpu_ctx, coder="sle")
+
+
+# ---- BASELINE.json configs[2]: LCPCompressor + ArithmeticCoder (compress side only) ---------------------
+@pytest.mark.parametrize("a", ANCH["lcpcomp_arith"], ids=lambda a: "%s_t%d" % (a["text"], a["threshold"]))
+def test_lcpcomp_arithmetic_reference_anchor(gpu_ctx, a):
+    t = ANCH["texts"][a["text"]]
+    data = T.gen_dna(t["n"], t["seed"]).tobytes()
+    out = T.LCPCompressor(gpu_ctx, coder="arithmetic", threshold=a["threshold"]).compress(data)
+    assert len(out) == a["size"] and sha256(out) == a["sha256"]
+
+
+def _arith_or_unsupported(gpu_ctx, text, thr, fl):
+    try:
+        want, _ = O.lcpcomp_arith_compress(text, thr, fl)
+    except RuntimeError:                                  # the reference divides by zero on this input
+        with pytest.raises(T.TdcGpuError) as e:
+            gpu_ctx.lcpcomp_compress(text, thr, fl, T.CODER_ARITH)
+        assert e.value.status == -6
+        return
+    got, _ = gpu_ctx.lcpcomp_compress(text, thr, fl, T.CODER_ARITH)
+    assert got == want, "arithmetic t=%d: %d vs %d bytes" % (thr, len(got), len(want))
+
+
+@pytest.mark.parametrize("name,data", SMALL, ids=IDS)
+def test_lcpcomp_arithmetic_small(gpu_ctx, name, data):
+    text = O.escape(data)
+    for thr in (1, 2, 5):
+        _arith_or_unsupported(gpu_ctx, text, thr, 1)
+
+
+def test_lcpcomp_arithmetic_random_and_medium(gpu_ctx):
+    for name, data in corpus.random_small(150, seed=23):
+        _arith_or_unsupported(gpu_ctx, O.escape(data), 2, 1)
+    for gen, n, thr in (("english", 1 << 22, 2), ("dna", 1 << 22, 5), ("english", 1 << 24, 5)):
+        data = (T.gen_english(n, 42) if gen == "english" else T.gen_dna(n, 7)).tobytes()
+        text = O.escape(data)
+        want, _ = O.lcpcomp_arith_compress(text, thr, 1)
+        got, _ = gpu_ctx.lcpcomp_compress(text, thr, 1, T.CODER_ARITH)
+        assert len(got) == len(want) and sha256(got) == sha256(want)
+    # a skewed literal distribution (long segments): exercises the sequential fall-back
+    skew = bytes([97] * 200000 + [98] * 3) * 3 + bytes(range(33, 120))
+    _arith_or_unsupported(gpu_ctx, O.escape(skew), 50000, 1)

@@ -13,6 +13,7 @@ from ._native import Stats, LIB_PATH, SYMBOLS  # noqa: F401
 
 CODER_HUFF = 0
 CODER_GAMMA = 1
+CODER_ARITH = 2
 
 
 class TdcGpuError(RuntimeError):
@@ -208,13 +209,16 @@ class Context:
                                             ctypes.byref(md)))
         return src, nf.value, md.value
 
-    def encode_huff(self, text, pos, src, length):
+    def encode_arith(self, text, pos, src, length):
+        return self.encode_huff(text, pos, src, length, _fn="tdc_gpu_encode_arith")
+
+    def encode_huff(self, text, pos, src, length, _fn="tdc_gpu_encode_huff"):
         a = _u8(text)
         pos = np.ascontiguousarray(pos, dtype=np.uint32)
         src = np.ascontiguousarray(src, dtype=np.uint32)
         length = np.ascontiguousarray(length, dtype=np.uint32)
         out, n = ctypes.c_void_p(), ctypes.c_size_t()
-        self._check(self._L.tdc_gpu_encode_huff(self._h, _ptr(a), len(a), _ptr(pos), _ptr(src), _ptr(length), len(pos),
+        self._check(getattr(self._L, _fn)(self._h, _ptr(a), len(a), _ptr(pos), _ptr(src), _ptr(length), len(pos),
                                                 ctypes.byref(out), ctypes.byref(n)))
         return self._take(out, n.value)
 
@@ -225,14 +229,15 @@ class LCPCompressor:
     input restrictions (escape {0}, null-terminate) and handed to compress()."""
 
     def __init__(self, ctx, coder="huff", threshold=5, flatten=1, comp="arrays"):
-        if coder != "huff" or comp != "arrays":
+        if coder not in ("huff", "arithmetic") or comp != "arrays":
             # same wording as Registry.hpp:214
             raise RuntimeError("No implementation found for compressor lcpcomp(coder=%s,comp=%s)" % (coder, comp))
         self.ctx, self.threshold, self.flatten = ctx, int(threshold), int(flatten)
+        self.coder = CODER_HUFF if coder == "huff" else CODER_ARITH
         self.last_stats = None
 
     def compress(self, data):
-        out, st = self.ctx.lcpcomp_compress(escape(data), self.threshold, self.flatten)
+        out, st = self.ctx.lcpcomp_compress(escape(data), self.threshold, self.flatten, self.coder)
         self.last_stats = st
         return out
 

@@ -44,7 +44,7 @@ int guarded(tdc_gpu_ctx* ctx, F&& f) {
         (void)hipGetLastError();
         if (e.e == hipErrorOutOfMemory) return TDC_GPU_ERR_OOM;
         if (e.e == hipErrorUnknown) return TDC_GPU_ERR_INTERNAL;
-        if (e.e == hipErrorInvalidValue && e.line < 0) return TDC_GPU_ERR_ARG;
+        if (e.e == hipErrorInvalidValue && e.line < 0) return TDC_GPU_ERR_UNSUPPORTED;
         return TDC_GPU_ERR_HIP;
     } catch (const ArgError& e) {
         ctx->last_error = e.msg;
@@ -159,7 +159,7 @@ void run_factorize(Ctx& c, size_t n, DevArrays& A, u32 threshold, int flatten, t
 
 // whole pipeline on a device-resident text; output written to *d_out (8-byte aligned, capacity out_cap); if *d_out is
 // NULL the buffer is taken from the arena once the factorization scratch has been released
-size_t run_pipeline(Ctx& c, const u8* d_text, size_t n, u32 threshold, int flatten, u8** d_out_io, size_t out_cap,
+size_t run_pipeline(Ctx& c, const u8* d_text, size_t n, u32 threshold, int flatten, int coder, u8** d_out_io, size_t out_cap,
                     tdc_gpu_stats* st, Events& ev) {
     if (threshold == 0) throw ArgError{TDC_GPU_ERR_ARG, "threshold must be >= 1"};
     validate_device_text(c, d_text, n);
@@ -170,7 +170,7 @@ size_t run_pipeline(Ctx& c, const u8* d_text, size_t n, u32 threshold, int flatt
     if (!*d_out_io) { out_cap = align_up(encode_bound(n) + 16, 8); *d_out_io = c.arena.get<u8>(out_cap); }
     u8* d_out = *d_out_io;
     const int e0 = ev.tick();
-    const size_t out_len = encode_huff(c, d_text, n, A.fs, d_out, out_cap, &es);
+    const size_t out_len = encode_stream(c, d_text, n, A.fs, coder == TDC_GPU_CODER_ARITH ? 1 : 0, d_out, out_cap, &es);
     const int e1 = ev.tick();
     HIP_TRY(hipStreamSynchronize(c.stream));
     if (st) {
@@ -304,7 +304,7 @@ size_t tdc_gpu_lcpcomp_bound(size_t n) { return align_up(encode_bound(n) + 16, 8
 int tdc_gpu_lcpcomp_compress_dev(tdc_gpu_ctx* ctx, const void* d_text, size_t n, uint32_t threshold, int flatten, int coder,
                                  void* d_out, size_t out_cap, size_t* out_len, tdc_gpu_stats* stats) {
     return guarded(ctx, [&] {
-        if (coder != TDC_GPU_CODER_HUFF) throw ArgError{TDC_GPU_ERR_UNSUPPORTED, "only coder=huff is built"};
+        if (coder != TDC_GPU_CODER_HUFF && coder != TDC_GPU_CODER_ARITH) throw ArgError{TDC_GPU_ERR_UNSUPPORTED, "lcpcomp: coder must be huff or arithmetic"};
         check_text_args(d_text, n);
         if (!d_out || !out_len || ((uintptr_t)d_out & 7)) throw ArgError{TDC_GPU_ERR_ARG, "d_out must be non-NULL and 8-byte aligned"};
         Ctx& c = ctx->c;
@@ -313,7 +313,7 @@ int tdc_gpu_lcpcomp_compress_dev(tdc_gpu_ctx* ctx, const void* d_text, size_t n,
         Events ev(c);
         const int e0 = ev.tick();
         u8* dst = (u8*)d_out;
-        *out_len = run_pipeline(c, (const u8*)d_text, n, threshold, flatten, &dst, out_cap, stats, ev);
+        *out_len = run_pipeline(c, (const u8*)d_text, n, threshold, flatten, coder, &dst, out_cap, stats, ev);
         const int e1 = ev.tick();
         if (stats) ev.span(&stats->ms_total, e0, e1);
         ev.finish();
@@ -323,7 +323,7 @@ int tdc_gpu_lcpcomp_compress_dev(tdc_gpu_ctx* ctx, const void* d_text, size_t n,
 int tdc_gpu_lcpcomp_compress(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, uint32_t threshold, int flatten, int coder,
                              uint8_t** out, size_t* out_len, tdc_gpu_stats* stats) {
     return guarded(ctx, [&] {
-        if (coder != TDC_GPU_CODER_HUFF) throw ArgError{TDC_GPU_ERR_UNSUPPORTED, "only coder=huff is built"};
+        if (coder != TDC_GPU_CODER_HUFF && coder != TDC_GPU_CODER_ARITH) throw ArgError{TDC_GPU_ERR_UNSUPPORTED, "lcpcomp: coder must be huff or arithmetic"};
         check_text_args(text, n);
         if (!out || !out_len) throw ArgError{TDC_GPU_ERR_ARG, "out/out_len is NULL"};
         if (text[n - 1] != 0) throw ArgError{TDC_GPU_ERR_NO_SENTINEL, "text does not end with a 0 sentinel"};
@@ -336,7 +336,7 @@ int tdc_gpu_lcpcomp_compress(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, ui
         HIP_TRY(hipMemcpyAsync(d_text, text, n, hipMemcpyHostToDevice, c.stream));
         const int e1 = ev.tick();
         u8* d_out = nullptr;
-        const size_t len = run_pipeline(c, d_text, n, threshold, flatten, &d_out, 0, stats, ev);
+        const size_t len = run_pipeline(c, d_text, n, threshold, flatten, coder, &d_out, 0, stats, ev);
         const int e2 = ev.tick();
         uint8_t* h = host_alloc<uint8_t>(len);
         HIP_TRY(hipMemcpyAsync(h, d_out, len, hipMemcpyDeviceToHost, c.stream));
@@ -565,7 +565,17 @@ int tdc_gpu_flatten(tdc_gpu_ctx* ctx, size_t n, const uint32_t* pos, uint32_t* s
     });
 }
 
+static int encode_entry(tdc_gpu_ctx* ctx, int coder, const uint8_t* text, size_t n, const uint32_t* pos, const uint32_t* src,
+                        const uint32_t* len, size_t z, uint8_t** out, size_t* out_len);
 int tdc_gpu_encode_huff(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, const uint32_t* pos, const uint32_t* src,
+                        const uint32_t* len, size_t z, uint8_t** out, size_t* out_len) {
+    return encode_entry(ctx, 0, text, n, pos, src, len, z, out, out_len);
+}
+int tdc_gpu_encode_arith(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, const uint32_t* pos, const uint32_t* src,
+                         const uint32_t* len, size_t z, uint8_t** out, size_t* out_len) {
+    return encode_entry(ctx, 1, text, n, pos, src, len, z, out, out_len);
+}
+static int encode_entry(tdc_gpu_ctx* ctx, int coder, const uint8_t* text, size_t n, const uint32_t* pos, const uint32_t* src,
                         const uint32_t* len, size_t z, uint8_t** out, size_t* out_len) {
     return guarded(ctx, [&] {
         check_text_args(text, n);
@@ -587,7 +597,7 @@ int tdc_gpu_encode_huff(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, const u
         scatter_factors(c, n, d_pos, d_src, d_len, z, fs);
         const size_t cap = tdc_gpu_lcpcomp_bound(n);
         u8* d_out = c.arena.get<u8>(cap);
-        const size_t l = encode_huff(c, d_text, n, fs, d_out, cap, nullptr);
+        const size_t l = encode_stream(c, d_text, n, fs, coder, d_out, cap, nullptr);
         uint8_t* h = host_alloc<uint8_t>(l);
         HIP_TRY(hipMemcpyAsync(h, d_out, l, hipMemcpyDeviceToHost, c.stream));
         HIP_TRY(hipStreamSynchronize(c.stream));

@@ -19,6 +19,7 @@
 #include "stages.hpp"
 #include "prim.hpp"
 #include "huffman_host.hpp"
+#include "arith.hpp"
 
 #include <string.h>
 
@@ -35,6 +36,15 @@ struct EncParams {
 };
 
 struct EncScalars { u32 flen_min, flen_max, fdist_max, pad; };
+
+// literal coder = ArithmeticCoder: what a literal contributes is looked up per literal ordinal (arith.hip)
+struct ArithDev {
+    const u32* litidx;     // nullptr: Huffman mode
+    const u8* amark;
+    const u64* fval;
+    u32 lc_index;
+    u64 pp_lb;
+};
 
 constexpr int ENC_PER_THREAD = 8;
 constexpr int ENC_TILE = 256 * ENC_PER_THREAD;     // 2048 text positions per workgroup
@@ -85,9 +95,11 @@ __global__ __launch_bounds__(256) void literal_hist_kernel(const u8* __restrict_
 
 // bits contributed by position p (see file header)
 __device__ __forceinline__ u32 position_cost(u32 own, u32 own_prev, bool first, u32 fl, u8 ch, u32 p, const u8* __restrict__ clen,
-                                             const EncParams& P) {
+                                             const EncParams& P, const ArithDev& A) {
     if (own == NONE32) {
-        u32 c = P.raw_literals ? 8u : (u32)clen[ch];
+        u32 c;
+        if (A.litidx) { const u32 k = A.litidx[p]; c = (A.amark[k] ? 64u : 0u) + (k == A.lc_index ? 128u : 0u); }
+        else c = P.raw_literals ? 8u : (u32)clen[ch];
         if (fl) c += 1u + P.dbits;
         return c;
     }
@@ -101,7 +113,7 @@ __device__ __forceinline__ u32 position_cost(u32 own, u32 own_prev, bool first, 
 
 __global__ __launch_bounds__(256) void tile_bits_kernel(const u8* __restrict__ text, const u32* __restrict__ owner,
                                                          const u32* __restrict__ flen, size_t n, CodeTable tab, EncParams P,
-                                                         u64* __restrict__ tile_bits) {
+                                                         ArithDev A, u64* __restrict__ tile_bits) {
     __shared__ u8 clen[256];
     __shared__ u32 sm[4];
     clen[threadIdx.x] = tab.len[threadIdx.x];
@@ -115,7 +127,7 @@ __global__ __launch_bounds__(256) void tile_bits_kernel(const u8* __restrict__ t
             const size_t p = p0 + j;
             if (p < n) {
                 const u32 own = owner[p];
-                sum += position_cost(own, prev, p == 0, flen[p], text[p], (u32)p, clen, P);
+                sum += position_cost(own, prev, p == 0, flen[p], text[p], (u32)p, clen, P, A);
                 prev = own;
             }
         }
@@ -160,8 +172,8 @@ struct BitSink {
 
 __global__ __launch_bounds__(256) void pack_kernel(const u8* __restrict__ text, const u32* __restrict__ owner,
                                                     const u32* __restrict__ flen, const u32* __restrict__ fsrc, size_t n,
-                                                    CodeTable tab, EncParams P, const u64* __restrict__ tile_off, u64 base_bits,
-                                                    u64* __restrict__ out) {
+                                                    CodeTable tab, EncParams P, ArithDev A, const u64* __restrict__ tile_off,
+                                                    u64 base_bits, u64* __restrict__ out) {
     __shared__ u8 clen[256];
     __shared__ u64 code[256];
     __shared__ u32 sm[5];
@@ -180,7 +192,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const u8* __restrict__ text, 
             const size_t p = p0 + j;
             if (p < n) {
                 own[j] = owner[p]; fl[j] = flen[p]; ch[j] = text[p];
-                sum += position_cost(own[j], prev, p == 0, fl[j], ch[j], (u32)p, clen, P);
+                sum += position_cost(own[j], prev, p == 0, fl[j], ch[j], (u32)p, clen, P, A);
                 prev = own[j];
             } else { own[j] = 0; fl[j] = 0; ch[j] = 0; }
         }
@@ -201,7 +213,12 @@ __global__ __launch_bounds__(256) void pack_kernel(const u8* __restrict__ text, 
             const u32 o = own[j];
             if (o == NONE32) {
                 if (fl[j]) { sink.append(1, 1); sink.append(fl[j], P.dbits); }           // LZSSCoding.hpp:62-68, :83-86
-                if (P.raw_literals) sink.append(ch[j], 8);                                // HuffmanCoder.hpp:565-566
+                if (A.litidx) {                                                           // ArithmeticCoder.hpp:96-104, :151-155
+                    const u32 k = A.litidx[p];
+                    if (A.amark[k]) sink.append(A.fval[k], 64);
+                    if (k == A.lc_index) { sink.append(A.pp_lb, 64); sink.append(~0ull, 64); }
+                }
+                else if (P.raw_literals) sink.append(ch[j], 8);                           // HuffmanCoder.hpp:565-566
                 else sink.append(code[ch[j]], clen[ch[j]]);                               // :568 huffman_encode
             } else if (o == (u32)p) {
                 if (p == 0 || prev != NONE32) sink.append(0, 1);                          // LZSSCoding.hpp:57-59
@@ -223,9 +240,13 @@ __global__ void terminator_kernel(u8* out, u64 total_bits) {
     else out[byte + 1] = (u8)u;
 }
 
-size_t encode_bound(size_t n) { return 10 * n + 4096; }
+size_t encode_bound(size_t n) { return 12 * n + 4096; }     // worst case per position: 1 + 32 bits of run header + 64 (+128 once) of arithmetic words
 
 size_t encode_huff(Ctx& c, const u8* text, size_t n, FactorSpace fs, u8* d_out, size_t out_cap, EncodeStats* st) {
+    return encode_stream(c, text, n, fs, 0, d_out, out_cap, st);
+}
+
+size_t encode_stream(Ctx& c, const u8* text, size_t n, FactorSpace fs, int coder, u8* d_out, size_t out_cap, EncodeStats* st) {
     EncodeStats local;
     if (!st) st = &local;
     *st = EncodeStats();
@@ -263,11 +284,22 @@ size_t encode_huff(Ctx& c, const u8* text, size_t n, FactorSpace fs, u8* d_out, 
     c.read_n(d_hist, h_hist, 256);
     h_sc = c.read(d_sc);
 
-    // ---- host: Huffman table + header (HuffmanCoder::Encoder ctor, LZSSCoding.hpp:47-50) ---------------------
+    // ---- host: coder header (HuffmanCoder::Encoder ctor :526-547 / ArithmeticCoder::Encoder ctor :158-164),
+    //      then the fields of LZSSCoding.hpp:47-50
     HuffTable ht;
-    build_huffman_table(h_hist, &ht);
     HostBitWriter hw;
-    write_huffman_header(hw, ht);
+    ArithDev A = { nullptr, nullptr, nullptr, 0, 0 };
+    if (coder == 0) {
+        build_huffman_table(h_hist, &ht);
+        write_huffman_header(hw, ht);
+    } else {
+        ArithModel am;
+        if (!arith_build_model(h_hist, &am, hw))
+            throw HipError{hipErrorInvalidValue, "arithmetic coder: all literal bytes >= 1 are absent (the reference divides by zero)", -1};
+        ArithPlan plan;
+        arith_prepare(c, text, n, fs.owner, am, &plan);
+        A.litidx = plan.litidx; A.amark = plan.amark; A.fval = plan.fval; A.lc_index = plan.lc_index; A.pp_lb = plan.pp_lb;
+    }
     EncParams P;
     P.W = bits_for(n);
     P.lbits = bits_for((u64)h_sc.flen_max - (u64)h_sc.flen_min);       // only used when z > 0
@@ -289,7 +321,7 @@ size_t encode_huff(Ctx& c, const u8* text, size_t n, FactorSpace fs, u8* d_out, 
     u64* d_total = c.arena.get<u64>(1);
     {
         Ctx::ProfScope prof(c, K_ENC_TILE_BITS, (u64)n * 9);
-        tile_bits_kernel<<<tiles, 256, 0, s>>>(text, fs.owner, fs.flen, n, tab, P, tile_bits);
+        tile_bits_kernel<<<tiles, 256, 0, s>>>(text, fs.owner, fs.flen, n, tab, P, A, tile_bits);
         LAUNCH_CHECK();
     }
     exclusive_sum_u64(c, tile_bits, tile_bits, tiles, d_total);
@@ -303,7 +335,7 @@ size_t encode_huff(Ctx& c, const u8* text, size_t n, FactorSpace fs, u8* d_out, 
     HIP_TRY(hipMemcpyAsync(d_out, hw.bytes.data(), hw.bytes.size(), hipMemcpyHostToDevice, s));
     {
         Ctx::ProfScope prof(c, K_ENC_PACK, (u64)n * 9 + (u64)z * 4 + out_len);
-        pack_kernel<<<tiles, 256, 0, s>>>(text, fs.owner, fs.flen, fs.fsrc, n, tab, P, tile_bits, base_bits, (u64*)d_out);
+        pack_kernel<<<tiles, 256, 0, s>>>(text, fs.owner, fs.flen, fs.fsrc, n, tab, P, A, tile_bits, base_bits, (u64*)d_out);
         LAUNCH_CHECK();
     }
     terminator_kernel<<<1, 64, 0, s>>>(d_out, total_bits);

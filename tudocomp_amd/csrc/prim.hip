@@ -223,6 +223,98 @@ void select_by_class(Ctx& c, const u8* cls, u8 want, size_t m, const u32* srcA, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// orbit marking (greedy parse chains)
+// ------------------------------------------------------------------------------------------------
+constexpr int ORB_TILE = 1024, ORB_SUPER = 1 << 20;
+
+__global__ __launch_bounds__(256) void chain_exit1_kernel(const u32* __restrict__ next, size_t n, u32* __restrict__ exit1) {
+    __shared__ u32 e[ORB_TILE];
+    const size_t base = (size_t)blockIdx.x * ORB_TILE;
+    const size_t tile_end = (base + ORB_TILE < n) ? base + ORB_TILE : n;
+    for (int k = threadIdx.x; k < ORB_TILE; k += 256) e[k] = (base + k < n) ? next[base + k] : (u32)n;
+    __syncthreads();
+    // invariant: e[k] lies on k's chain and every chain position strictly between k and e[k] is inside the tile
+    for (int round = 0; round < 10; ++round) {
+        u32 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const u32 x = e[threadIdx.x + 256 * j]; v[j] = (x < tile_end) ? e[x - base] : x; }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e[threadIdx.x + 256 * j] = v[j];
+        __syncthreads();
+    }
+    for (int k = threadIdx.x; k < ORB_TILE; k += 256) if (base + k < n) exit1[base + k] = e[k];
+}
+
+// one workgroup per super-tile, tiles from right to left; exit2 of a later tile is read back through L2 (agent-scope loads)
+__global__ __launch_bounds__(256) void chain_exit2_kernel(const u32* __restrict__ exit1, size_t n, u32* exit2) {
+    const size_t sbase = (size_t)blockIdx.x * ORB_SUPER;
+    const size_t super_end = (sbase + ORB_SUPER < n) ? sbase + ORB_SUPER : n;
+    const size_t ntile = (super_end - sbase + ORB_TILE - 1) / ORB_TILE;
+    for (size_t tt = ntile; tt-- > 0;) {
+        const size_t base = sbase + tt * ORB_TILE;
+        for (int k = threadIdx.x; k < ORB_TILE; k += 256) {
+            const size_t i = base + k;
+            if (i < super_end) {
+                const u32 x = exit1[i];
+                const u32 y = (x >= super_end) ? x : __hip_atomic_load(&exit2[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&exit2[i], y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __syncthreads();          // includes the wait for this tile's stores
+    }
+}
+
+__global__ void chain_super_walk_kernel(const u32* __restrict__ exit2, size_t n, u32* __restrict__ super_entry) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    size_t e = 0, guard = 0;
+    const size_t nsuper = (n + ORB_SUPER - 1) / ORB_SUPER;
+    while (e < n && guard++ <= nsuper) { super_entry[e >> 20] = (u32)e; e = exit2[e]; }
+}
+__global__ void chain_tile_entries_kernel(const u32* __restrict__ exit1, size_t n, const u32* __restrict__ super_entry, size_t nsuper,
+                                          u32* __restrict__ tile_entry) {
+    const size_t sidx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (sidx >= nsuper) return;
+    size_t e = super_entry[sidx];
+    if (e == NONE32) return;
+    const size_t super_end = (sidx + 1) * (size_t)ORB_SUPER < n ? (sidx + 1) * (size_t)ORB_SUPER : n;
+    for (int guard = 0; e < super_end && guard <= ORB_SUPER / ORB_TILE; ++guard) { tile_entry[e >> 10] = (u32)e; e = exit1[e]; }
+}
+__global__ void chain_mark_kernel(const u32* __restrict__ next, size_t n, const u32* __restrict__ tile_entry, size_t ntiles,
+                                  u8* __restrict__ mark) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntiles) return;
+    size_t e = tile_entry[t];
+    if (e == NONE32) return;
+    const size_t tile_end = (t + 1) * (size_t)ORB_TILE < n ? (t + 1) * (size_t)ORB_TILE : n;
+    for (int guard = 0; e < tile_end && guard <= ORB_TILE; ++guard) { mark[e] = 1; e = next[e]; }
+}
+
+
+void mark_orbit_u32(Ctx& c, const u32* next, size_t n, u8* mark, u32* exit1, u32* exit2) {
+    if (n == 0) return;
+    hipStream_t s = c.stream;
+    const size_t mark0 = c.arena.mark();
+    const size_t ntiles = (n + ORB_TILE - 1) / ORB_TILE, nsuper = (n + ORB_SUPER - 1) / ORB_SUPER;
+    chain_exit1_kernel<<<(unsigned)ntiles, 256, 0, s>>>(next, n, exit1);
+    LAUNCH_CHECK();
+    chain_exit2_kernel<<<(unsigned)nsuper, 256, 0, s>>>(exit1, n, exit2);
+    LAUNCH_CHECK();
+    u32* super_entry = c.arena.get<u32>(nsuper);
+    u32* tile_entry = c.arena.get<u32>(ntiles);
+    HIP_TRY(hipMemsetAsync(super_entry, 0xFF, nsuper * sizeof(u32), s));
+    HIP_TRY(hipMemsetAsync(tile_entry, 0xFF, ntiles * sizeof(u32), s));
+    HIP_TRY(hipMemsetAsync(mark, 0, n, s));
+    chain_super_walk_kernel<<<1, 64, 0, s>>>(exit2, n, super_entry);
+    LAUNCH_CHECK();
+    chain_tile_entries_kernel<<<cdiv(nsuper, 64), 64, 0, s>>>(exit1, n, super_entry, nsuper, tile_entry);
+    LAUNCH_CHECK();
+    chain_mark_kernel<<<cdiv(ntiles, 256), 256, 0, s>>>(next, n, tile_entry, ntiles, mark);
+    LAUNCH_CHECK();
+    c.arena.release(mark0);
+}
+
+// ------------------------------------------------------------------------------------------------
 // fills
 // ------------------------------------------------------------------------------------------------
 __global__ void fill_u32_kernel(u32* p, size_t n, u32 v) {

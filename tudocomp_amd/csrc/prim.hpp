@@ -27,6 +27,13 @@ int sort_pairs_u64_distinct(Ctx& c, u64* keys[2], u32* vals[2], size_t n, int be
 void select_by_class(Ctx& c, const u8* cls, u8 want, size_t m, const u32* srcA, u32* outA, const u64* srcB, u64* outB,
                      u32* d_count);
 
+// Orbit of element 0 under a strictly increasing successor function: next[i] > i, next[i] == n ends the chain.
+// mark[i] = 1 for every element on the chain 0, next[0], next[next[0]], ... ; 0 elsewhere.
+// scratch1 / scratch2: n u32 each.  Hierarchical: exit of every element from its 1024-tile (pointer doubling in LDS),
+// exit from its 2^20 super-tile (right-to-left sweep), a serial walk over the super-tile entries, then tile entries and
+// chain elements in parallel.
+void mark_orbit_u32(Ctx& c, const u32* next, size_t n, u8* mark, u32* scratch1, u32* scratch2);
+
 // fill / iota helpers
 void fill_u32(Ctx& c, u32* p, size_t n, u32 v);
 void fill_u8(Ctx& c, u8* p, size_t n, u8 v);

@@ -257,14 +257,18 @@ class LCPCompressor : public Compressor {
     AlgorithmValue m_opts;
     std::shared_ptr<GpuContext> m_ctx;       // created lazily by the first compress(): decompress() needs no GPU
     int m_device = 0;
+    int m_coder = TDC_GPU_CODER_HUFF;
 public:
     tdc_gpu_stats last_stats{};
     void set_device(int d) { m_device = d; }
     // meta: type "compressor", name "lcpcomp", options coder, comp=arrays, dec=scan, threshold=5, flatten=1 (LCPCompressor.hpp:85-95)
     LCPCompressor(AlgorithmValue opts, std::shared_ptr<GpuContext> ctx) : m_opts(std::move(opts)), m_ctx(std::move(ctx)) {
         const std::string coder = m_opts.get("coder", ""), comp = m_opts.get("comp", "arrays");
-        if (coder != "huff" || (comp != "arrays" && comp != "arrays()"))
+        // `arithmetic` is not in the reference's lcpcomp registry (etc/registry_config.py:138-142) but the template
+        // instantiates; BASELINE.json configs[2] asks for it, compress side only
+        if ((coder != "huff" && coder != "arithmetic") || (comp != "arrays" && comp != "arrays()"))
             throw std::runtime_error("No implementation found for compressor lcpcomp(coder=" + coder + ",comp=" + comp + ")");   // Registry.hpp:214
+        m_coder = (coder == "huff") ? TDC_GPU_CODER_HUFF : TDC_GPU_CODER_ARITH;
     }
     InputRestrictions input_restrictions() const override { return {true, true}; }   // uses_textds (Meta.hpp:277-282)
 
@@ -273,14 +277,19 @@ public:
         const bytes view = input.as_view();
         uint8_t* out = nullptr; size_t out_len = 0;
         const int rc = tdc_gpu_lcpcomp_compress(m_ctx->h, view.data(), view.size(), (uint32_t)m_opts.get_int("threshold", 5),
-                                                (int)m_opts.get_int("flatten", 1), TDC_GPU_CODER_HUFF, &out, &out_len, &last_stats);
+                                                (int)m_opts.get_int("flatten", 1), m_coder, &out, &out_len, &last_stats);
         if (rc == TDC_GPU_ERR_NO_SENTINEL) throw std::logic_error(tdc_gpu_strerror(rc));          // ds/TextDS.hpp:132-138
         if (rc) throw std::runtime_error(std::string(tdc_gpu_strerror(rc)) + ": " + tdc_gpu_last_error(m_ctx->h));
         output.write(out, out_len);
         tdc_gpu_free(out);
     }
 
-    void decompress(Input& input, Output& output) override { lzss_huff_decode(input, output); }
+    void decompress(Input& input, Output& output) override {
+        if (m_coder != TDC_GPU_CODER_HUFF)
+            throw std::runtime_error("lcpcomp(coder=arithmetic) streams cannot be decoded (neither can the reference: "
+                                     "consuming coders corrupt interleaved streams, docs/Documentation.md:1190-1203)");
+        lzss_huff_decode(input, output);
+    }
 };
 
 // tdc::LZSSLCPCompressor<HuffmanCoder>  (compressors/LZSSLCPCompressor.hpp:22-132): threshold defaults to 3.
@@ -364,6 +373,7 @@ struct Selection {
 
 inline std::vector<std::string> registered_algorithms() {
     return { "lcpcomp(coder=huff, comp=arrays, dec=scan(scans=6), threshold=5, flatten=1)   [MI355X, libtdc_gpu.so]",
+             "lcpcomp(coder=arithmetic, comp=arrays, threshold=5, flatten=1)              [MI355X, compress only]",
              "lzss_lcp(coder=huff, threshold=3)                                           [MI355X, libtdc_gpu.so]",
              "lz78(coder=gamma)                                                           [host parse + MI355X gamma packer]" };
 }
