@@ -238,6 +238,7 @@ int tdc_gpu_ctx_create(int device, tdc_gpu_ctx** out) {
         HIP_TRY(hipHostMalloc(&ctx->c.pinned, ctx->c.pinned_size, hipHostMallocDefault));
         HIP_TRY(hipMalloc((void**)&ctx->c.d_err, 256));
         HIP_TRY(hipMemset(ctx->c.d_err, 0, 256));
+        if (const char* m = getenv("TDC_GPU_SA_LOCAL")) ctx->c.sa_local_sort = atoi(m) ? 1 : 0;
         if (const char* m = getenv("TDC_GPU_RADIX_WAVES")) ctx->c.radix_waves = (atoi(m) == 8) ? 8 : 4;
     } catch (const HipError&) {
         (void)hipGetLastError();

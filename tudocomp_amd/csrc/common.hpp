@@ -93,6 +93,7 @@ struct Ctx {
     void* pinned = nullptr;        // small pinned staging block for device->host scalars
     size_t pinned_size = 0;
     u32* d_err = nullptr;          // device error word (look-back timeouts etc.), checked at the end of every API call
+    int sa_local_sort = 1;         // doubling rounds: sort whole runs inside 2048-element tiles locally (env TDC_GPU_SA_LOCAL=0 disables)
     int radix_waves = 4;           // waves per radix-sort workgroup for large inputs (env TDC_GPU_RADIX_WAVES = 4 | 8; no measurable difference)
 
     bool profiling = false;

@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void sel_scatter_kernel(const u8* __restrict__
 #pragma unroll
     for (int j = 0; j < SEL_PER_THREAD; ++j) {
         if (mask & (1u << j)) {
-            outA[o] = srcA[k0 + j];
+            outA[o] = srcA ? srcA[k0 + j] : (u32)(k0 + j);      // srcA == nullptr: select the indices themselves
             if (srcB) outB[o] = srcB[k0 + j];
             ++o;
         }

@@ -22,8 +22,8 @@ int radix_sort_pairs_u32(Ctx& c, u32* keys[2], u32* vals[2], size_t n, int begin
 // radix sort.  Used for the many tiny per-level sorts of the factorizer.
 int sort_pairs_u64_distinct(Ctx& c, u64* keys[2], u32* vals[2], size_t n, int begin_bit, int end_bit);
 
-// Order-preserving selection: for the k (ascending) with cls[k] == want, outA[j] = srcA[k] (and outB[j] = srcB[k] if
-// srcB != nullptr); *d_count (device) receives the number of selected elements.
+// Order-preserving selection: for the k (ascending) with cls[k] == want, outA[j] = srcA[k] (or k itself if srcA ==
+// nullptr) and outB[j] = srcB[k] if srcB != nullptr; *d_count (device) receives the number of selected elements.
 void select_by_class(Ctx& c, const u8* cls, u8 want, size_t m, const u32* srcA, u32* outA, const u64* srcB, u64* outB,
                      u32* d_count);
 

@@ -129,6 +129,50 @@ __global__ void sa_compact_kernel(const u32* __restrict__ vals, const u32* __res
     }
 }
 
+// Doubling round, local part: the active list is grouped by r1 (runs of equal high key half), and sorting by
+// (r1, r2) only permutes elements inside their run.  A 2048-element tile is sorted entirely in registers/LDS
+// (bitonic network); runs that continue across a tile border are only partially ordered by that and are flagged
+// (cls = 1) for the global radix sort.  Most runs are a handful of suffixes, so the global sort shrinks to a
+// small fraction of the active list.
+__global__ __launch_bounds__(256) void sa_local_sort_kernel(u64* __restrict__ keys, u32* __restrict__ vals, size_t m, int bn,
+                                                             u8* __restrict__ cls) {
+    __shared__ u64 xk[2048];
+    __shared__ u32 xv[2048];
+    const size_t base = (size_t)blockIdx.x * 2048;
+    const size_t end = (base + 2048 < m) ? base + 2048 : m;
+    u64 k[8];
+    u32 v[8];
+#pragma unroll
+    for (u32 r = 0; r < 8; ++r) {
+        const size_t i = base + threadIdx.x * 8 + r;
+        k[r] = (i < m) ? keys[i] : ~0ull;
+        v[r] = (i < m) ? vals[i] : 0u;
+    }
+    // runs that cross the tile borders
+    const u64 first_r1 = keys[base] >> bn, last_r1 = keys[end - 1] >> bn;
+    const bool open_l = base > 0 && (keys[base - 1] >> bn) == first_r1;
+    const bool open_r = end < m && (keys[end] >> bn) == last_r1;
+    block_bitonic_sort_2048(k, v, xk, xv);
+#pragma unroll
+    for (u32 r = 0; r < 8; ++r) {
+        const size_t i = base + threadIdx.x * 8 + r;
+        if (i < m) {
+            keys[i] = k[r];
+            vals[i] = v[r];
+            const u64 r1 = k[r] >> bn;                      // the sort keeps every element inside its run
+            cls[i] = ((open_l && r1 == first_r1) || (open_r && r1 == last_r1)) ? 1 : 0;
+        }
+    }
+}
+__global__ void sa_scatter_back_kernel(const u32* __restrict__ opos, const u64* __restrict__ okeys, const u32* __restrict__ ovals,
+                                       size_t mo, u64* __restrict__ keys, u32* __restrict__ vals) {
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= mo) return;
+    const u32 p = opos[j];
+    keys[p] = okeys[j];
+    vals[p] = ovals[j];
+}
+
 void build_suffix_array(Ctx& c, const u8* text, size_t n, u32* sa, u32* isa, SAStats* st) {
     SAStats local;
     if (!st) st = &local;
@@ -165,6 +209,8 @@ void build_suffix_array(Ctx& c, const u8* text, size_t n, u32* sa, u32* isa, SAS
     u32* A_sa = c.arena.get<u32>(n), *A_pos = c.arena.get<u32>(n), *A_r1 = c.arena.get<u32>(n);
     u32* B_sa = c.arena.get<u32>(n), *B_pos = c.arena.get<u32>(n), *B_r1 = c.arena.get<u32>(n);
     u32* d_total = c.arena.get<u32>(1);
+    u64* lkeys = c.arena.get<u64>(n / 2 + 2048);       // second buffers of the "open run" sort (at most half of the list...)
+    u32* lvals = c.arena.get<u32>(n / 2 + 2048);
     u32* rank = isa;
 
     // --- initial sort by the first k symbols ------------------------------------------------------
@@ -198,8 +244,33 @@ void build_suffix_array(Ctx& c, const u8* text, size_t n, u32* sa, u32* isa, SAS
             sa_build_keys_kernel<<<gm, 256, 0, s>>>(A_sa, A_r1, m, n, (u32)h, bn, rank, keys[0], vals[0]);
             LAUNCH_CHECK();
         }
-        x = radix_sort_pairs_u64(c, keys, vals, m, 0, 2 * bn);
-        st->sorted_elems += m;
+        if (c.sa_local_sort) {
+            // local part: whole runs inside 2048-element tiles; global part: only the runs that cross a tile border
+            u8* cls = (u8*)keep;                                   // scratch (keep is rewritten by sa_update_kernel)
+            sa_local_sort_kernel<<<cdiv(m, 2048), 256, 0, s>>>(keys[0], vals[0], m, bn, cls);
+            LAUNCH_CHECK();
+            u32* opos = B_sa;                                      // B_* are free until the compaction of this round
+            select_by_class(c, cls, 1, m, nullptr, opos, nullptr, nullptr, d_total);
+            const size_t mo = c.read(d_total);
+            if (mo > n / 2) {                                      // a few giant runs: sort everything globally
+                x = radix_sort_pairs_u64(c, keys, vals, m, 0, 2 * bn);
+                st->sorted_elems += m;
+            } else {
+            st->sorted_elems += mo;
+            if (mo) {
+                u64* ok2[2] = { keys[1], lkeys };
+                u32* ov2[2] = { vals[1], lvals };
+                select_by_class(c, cls, 1, m, vals[0], ov2[0], keys[0], ok2[0], d_total);
+                const int y = radix_sort_pairs_u64(c, ok2, ov2, mo, 0, 2 * bn);
+                sa_scatter_back_kernel<<<cdiv(mo, 256), 256, 0, s>>>(opos, ok2[y], ov2[y], mo, keys[0], vals[0]);
+                LAUNCH_CHECK();
+            }
+            x = 0;
+            }
+        } else {
+            x = radix_sort_pairs_u64(c, keys, vals, m, 0, 2 * bn);
+            st->sorted_elems += m;
+        }
         sa_heads_kernel<<<gm, 256, 0, s>>>(keys[x], m, head);
         LAUNCH_CHECK();
         inclusive_max_u32(c, head, head, m);
