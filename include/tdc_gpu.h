@@ -90,6 +90,11 @@ void tdc_gpu_free(void* p);
  * TDC_GPU_ERR_UNSUPPORTED for inputs on which the reference divides by zero). */
 int tdc_gpu_lcpcomp_compress(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, uint32_t threshold, int flatten,
                              int coder, uint8_t** out, size_t* out_len, tdc_gpu_stats* stats);
+/* Raw input variant: `data`/`n` is the UNRESTRICTED input (any bytes, no sentinel).  The library applies the
+ * compressor's input restrictions on the device -- escape {0} + null-terminate, i.e. what Input(inp, restrictions) does
+ * in tudocomp_driver.cpp:268-270 (io/RestrictedBuffer.hpp:43-74) -- and then compresses.  n < 2^30. */
+int tdc_gpu_lcpcomp_compress_raw(tdc_gpu_ctx* ctx, const uint8_t* data, size_t n, uint32_t threshold, int flatten,
+                                 int coder, uint8_t** out, size_t* out_len, tdc_gpu_stats* stats);
 /* Device-resident variant: d_text and d_out are device pointers on ctx's GPU (d_out 8-byte aligned, capacity out_cap
  * bytes; tdc_gpu_lcpcomp_bound(n) always suffices).  Used by bench.py (inputs resident in HBM). */
 int tdc_gpu_lcpcomp_compress_dev(tdc_gpu_ctx* ctx, const void* d_text, size_t n, uint32_t threshold, int flatten,

@@ -245,3 +245,17 @@ def test_lcpcomp_arithmetic_random_and_medium(gpu_ctx):
     # a skewed literal distribution (long segments): exercises the sequential fall-back
     skew = bytes([97] * 200000 + [98] * 3) * 3 + bytes(range(33, 120))
     _arith_or_unsupported(gpu_ctx, O.escape(skew), 50000, 1)
+
+
+# ---- escaping + sentinel on the device --------------------------------------------------------------
+def test_device_escape_matches_host(gpu_ctx):
+    k = load_json("reference_kats.json")["escaping"]
+    raw = bytes.fromhex(k["raw_hex"])
+    assert gpu_ctx.lcpcomp_compress_raw(raw, 2, 1)[0] == O.lcpcomp_huff_compress(bytes.fromhex(k["escaped_hex"]), 2, 1)[0]
+    rng = np.random.default_rng(3)
+    cases = [d for _, d in SMALL] + [rng.integers(0, 256, size=int(s), dtype=np.uint8).tobytes() for s in (1, 77, 4097, 300000)]
+    cases.append(bytes([0, 255]) * 5000)
+    for data in cases:
+        want, _ = O.lcpcomp_huff_compress(O.escape(data), 3, 1)
+        got, st = gpu_ctx.lcpcomp_compress_raw(data, 3, 1)
+        assert got == want and st["n"] == len(O.escape(data))

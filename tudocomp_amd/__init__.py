@@ -137,6 +137,14 @@ class Context:
                                                      ctypes.byref(out), ctypes.byref(n), ctypes.byref(st)))
         return self._take(out, n.value), st.as_dict()
 
+    def lcpcomp_compress_raw(self, data, threshold=5, flatten=1, coder=CODER_HUFF):
+        """data: unrestricted input; escaping + sentinel happen on the device.  Returns (compressed bytes, stats dict)."""
+        a = _u8(data)
+        out, n, st = ctypes.c_void_p(), ctypes.c_size_t(), Stats()
+        self._check(self._L.tdc_gpu_lcpcomp_compress_raw(self._h, _ptr(a), len(a), threshold, int(flatten), coder,
+                                                         ctypes.byref(out), ctypes.byref(n), ctypes.byref(st)))
+        return self._take(out, n.value), st.as_dict()
+
     def lcpcomp_compress_dev(self, d_text, n, d_out, out_cap, threshold=5, flatten=1, coder=CODER_HUFF):
         """Device-resident variant: d_text / d_out are raw device pointers (ints).  Returns (out_len, stats)."""
         ol, st = ctypes.c_size_t(), Stats()

@@ -13,7 +13,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "libtdc_gpu.so")
 SYMBOLS = [
     "tdc_gpu_ctx_create", "tdc_gpu_ctx_destroy", "tdc_gpu_ctx_reserve", "tdc_gpu_strerror", "tdc_gpu_last_error",
     "tdc_gpu_ctx_set_profiling", "tdc_gpu_ctx_reset_profile", "tdc_gpu_ctx_kernel_profile",
-    "tdc_gpu_free", "tdc_gpu_lcpcomp_compress", "tdc_gpu_lcpcomp_compress_dev", "tdc_gpu_lcpcomp_bound",
+    "tdc_gpu_free", "tdc_gpu_lcpcomp_compress", "tdc_gpu_lcpcomp_compress_raw", "tdc_gpu_lcpcomp_compress_dev",
+    "tdc_gpu_lcpcomp_bound",
     "tdc_gpu_lz78_compress", "tdc_gpu_lzss_lcp_compress", "tdc_gpu_lzss_lcp_factorize",
     "tdc_gpu_suffix_array", "tdc_gpu_textds", "tdc_gpu_lcpcomp_factorize", "tdc_gpu_flatten", "tdc_gpu_encode_huff",
     "tdc_gpu_encode_arith",
@@ -66,6 +67,7 @@ def load():
     L.tdc_gpu_free.argtypes = [vp]
     L.tdc_gpu_free.restype = None
     L.tdc_gpu_lcpcomp_compress.argtypes = [vp, vp, sz, u32, i32, i32, pvp, psz, ctypes.POINTER(Stats)]
+    L.tdc_gpu_lcpcomp_compress_raw.argtypes = [vp, vp, sz, u32, i32, i32, pvp, psz, ctypes.POINTER(Stats)]
     L.tdc_gpu_lcpcomp_compress_dev.argtypes = [vp, vp, sz, u32, i32, i32, vp, sz, psz, ctypes.POINTER(Stats)]
     L.tdc_gpu_lz78_compress.argtypes = [vp, vp, sz, i32, pvp, psz, ctypes.POINTER(Stats)]
     L.tdc_gpu_lzss_lcp_compress.argtypes = [vp, vp, sz, u32, i32, pvp, psz, ctypes.POINTER(Stats)]

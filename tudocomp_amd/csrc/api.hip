@@ -348,6 +348,34 @@ int tdc_gpu_lcpcomp_compress(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, ui
     });
 }
 
+int tdc_gpu_lcpcomp_compress_raw(tdc_gpu_ctx* ctx, const uint8_t* data, size_t n, uint32_t threshold, int flatten, int coder,
+                                 uint8_t** out, size_t* out_len, tdc_gpu_stats* stats) {
+    return guarded(ctx, [&] {
+        if (coder != TDC_GPU_CODER_HUFF && coder != TDC_GPU_CODER_ARITH) throw ArgError{TDC_GPU_ERR_UNSUPPORTED, "lcpcomp: coder must be huff or arithmetic"};
+        if ((!data && n) || !out || !out_len) throw ArgError{TDC_GPU_ERR_ARG, "NULL argument"};
+        if (n >= (1ull << 30)) throw ArgError{TDC_GPU_ERR_TOO_LARGE, "raw input must be < 2^30 bytes (the escaped text must stay < 2^31)"};
+        Ctx& c = ctx->c;
+        if (stats) memset(stats, 0, sizeof(*stats));
+        c.ensure_arena(arena_need(2 * n + 1) + n);
+        Events ev(c);
+        const int e0 = ev.tick();
+        u8* d_raw = c.arena.get<u8>(n + 64);
+        u8* d_text = c.arena.get<u8>(2 * n + 65);
+        if (n) HIP_TRY(hipMemcpyAsync(d_raw, data, n, hipMemcpyHostToDevice, c.stream));
+        const size_t tn = escape_device(c, d_raw, n, d_text);
+        const int e1 = ev.tick();
+        u8* d_out = nullptr;
+        const size_t len = run_pipeline(c, d_text, tn, threshold, flatten, coder, &d_out, 0, stats, ev);
+        const int e2 = ev.tick();
+        uint8_t* h = host_alloc<uint8_t>(len);
+        HIP_TRY(hipMemcpyAsync(h, d_out, len, hipMemcpyDeviceToHost, c.stream));
+        const int e3 = ev.tick();
+        if (stats) { ev.span(&stats->ms_h2d, e0, e1); ev.span(&stats->ms_d2h, e2, e3); ev.span(&stats->ms_total, e0, e3); }
+        ev.finish();
+        *out = h; *out_len = len;
+    });
+}
+
 namespace {
 // shared front end of the two lzss_lcp entry points: text to the device, SA + ISA, factorization into position space
 void run_lzss_lcp(Ctx& c, const uint8_t* text, size_t n, uint32_t threshold, u8** d_text_out, DevArrays& A, tdc_gpu_stats* st, Events& ev) {
