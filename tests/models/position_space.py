@@ -228,3 +228,191 @@ def factorize_explicit_priority(n, isa, phi, plcp, maxlcp, threshold, rng=None):
             segs.setdefault(v, []).append(p)
         prio_base += len(pushes)
     return factors
+
+
+def _global_levels(n, isa, plcp, maxlcp, threshold, lcut):
+    """Levels maxlcp .. lcut+1 of factorize_explicit_priority; returns the state handed to the tile pass:
+    (factors, cur, prio, resid).  resid[p] = level whose list holds p's entry (0: none)."""
+    cur = [int(x) for x in plcp]
+    cur[n - 1] = 0
+    prio = [int(x) for x in isa]
+    resid = [cur[p] if cur[p] >= threshold else 0 for p in range(n)]
+    lists = {}
+    for p in range(n):
+        if cur[p] >= threshold:
+            lists.setdefault(cur[p], []).append(p)
+    prio_base = n
+    factors = []
+    for L in range(maxlcp, max(lcut, threshold - 1), -1):
+        ent = lists.pop(L, [])
+        if not ent:
+            continue
+        live = [p for p in ent if cur[p] == L]
+        stale = [p for p in ent if threshold <= cur[p] < L]
+        und = set(live)
+        sel = set()
+        rej = set()
+        while und:
+            new_sel, new_rej = [], []
+            for p in und:
+                hit = blocked = False
+                for q in range(max(0, p - L + 1), min(n, p + L)):
+                    if q == p:
+                        continue
+                    if q in sel:
+                        hit = True
+                        break
+                    if q in und and prio[q] < prio[p]:
+                        blocked = True
+                if hit:
+                    new_rej.append(p)
+                elif not blocked:
+                    new_sel.append(p)
+            for p in new_sel:
+                sel.add(p); und.discard(p)
+            for p in new_rej:
+                rej.add(p); und.discard(p)
+        pushes = []
+        for p in stale + sorted(rej):
+            v = cur[p]
+            for q in range(max(0, p - L + 1), min(n, p + L)):
+                if q in sel and prio[q] < prio[p]:
+                    if q < p:
+                        v = 0
+                        break
+                    v = min(v, q - p)
+            if v >= threshold:
+                pushes.append((v, prio[p], p))
+        for p in ent:
+            resid[p] = 0
+        for p in sel:
+            factors.append((p, L))
+            for j in range(L):
+                cur[p + j] = 0
+            for j in range(min(L, p)):
+                cur[p - 1 - j] = min(cur[p - 1 - j], j + 1)
+        pushes.sort()
+        for i, (v, _, p) in enumerate(pushes):
+            resid[p] = v
+            prio[p] = prio_base + i
+            lists.setdefault(v, []).append(p)
+        prio_base += len(pushes)
+    return factors, cur, prio, resid
+
+
+def factorize_tile(n, w0, w1, a, b, cur_g, prio_g, resid_g, threshold, lcut):
+    """Levels lcut .. threshold for the window [w0, w1) of the text, computed from the window's slice of the global
+    state alone (factorize_tiles.hip).  Everything outside the window is unknown; [fl, fr) is the range of positions
+    whose state is still exactly known.  Returns (factors with a <= pos < b, valid)."""
+    INF = 1 << 60
+    cur = {p: cur_g[p] for p in range(w0, w1)}
+    res = {p: (resid_g[p] if resid_g[p] <= lcut else 0) for p in range(w0, w1)}
+    prio = {p: (0, prio_g[p]) for p in range(w0, w1)}          # (0, global) < (1, local)
+    fl = w0 if w0 > 0 else -INF
+    fr = w1 if w1 < n else INF
+    mid = (w0 + w1) // 2
+    local_base = 0
+    out = []
+    UND, SEL, REJ, UNC = 0, 1, 2, 3
+    for L in range(lcut, threshold - 1, -1):
+        lo, hi = max(w0, fl), min(w1, fr)
+        ent = [p for p in range(lo, hi) if res[p] == L]
+        exposed = lambda p: (p <= fl + L - 2) or (p + L - 1 >= fr)
+        st = {}
+        stale = []
+        for p in ent:
+            if cur[p] == L:
+                st[p] = UND
+            elif cur[p] >= threshold:
+                stale.append(p)
+        while any(s == UND for s in st.values()):
+            snap = dict(st)
+            progressed = False
+            for p, s in snap.items():
+                if s != UND:
+                    continue
+                hit = blocked = unc = False
+                for q in range(p - L + 1, p + L):
+                    if q == p or q not in snap:
+                        continue
+                    sq = snap[q]
+                    if sq == SEL:
+                        hit = True
+                        break
+                    if prio[q] < prio[p]:
+                        if sq == UND:
+                            blocked = True
+                        elif sq == UNC:
+                            unc = True
+                if hit:
+                    st[p] = REJ
+                elif not blocked:
+                    st[p] = UNC if (unc or exposed(p)) else SEL
+                if st[p] != UND:
+                    progressed = True
+            assert progressed
+        tainted = []
+        pushes = []
+        for p in stale + [q for q in ent if st.get(q) == REJ]:
+            v = cur[p]
+            uncertain = exposed(p)
+            for q in range(p - L + 1, p + L):
+                if q == p or q not in st or prio[q] >= prio[p]:
+                    continue
+                if st[q] == UNC:
+                    uncertain = True
+                elif st[q] == SEL:
+                    v = 0 if q < p else min(v, q - p)
+            if uncertain:
+                tainted.append((p, 1))
+            elif v >= threshold:
+                pushes.append((prio[p], v, p))
+        for p in ent:
+            if st.get(p) == UNC:
+                tainted.append((p, L))
+            res[p] = 0
+        for p in ent:
+            if st.get(p) == SEL:
+                if a <= p < b:
+                    out.append((p, L))
+                for j in range(L):
+                    if p + j in cur:
+                        cur[p + j] = 0
+                for j in range(L):
+                    q = p - 1 - j
+                    if q in cur:
+                        cur[q] = min(cur[q], j + 1)
+        pushes.sort()
+        for i, (_, v, p) in enumerate(pushes):
+            res[p] = v
+            prio[p] = (1, local_base + i)
+        local_base += len(pushes)
+        nfl = fl + (L - 1)
+        nfr = fr - (L - 1)
+        for p, reach in tainted:
+            if p < mid:
+                nfl = max(nfl, p + reach)
+            else:
+                nfr = min(nfr, p - reach + 1) if reach == 1 else min(nfr, p - (L - 1))
+        fl, fr = nfl, nfr
+    return out, (fl <= a and fr >= b)
+
+
+def factorize_hybrid_tiles(n, isa, phi, plcp, maxlcp, threshold, lcut, interior, halo):
+    """Global levels above lcut, tile-local levels below.  Returns (factor set {(pos, len)}, tiles, invalid tiles)."""
+    if maxlcp + 1 <= threshold:
+        return set(), 0, 0
+    factors, cur, prio, resid = _global_levels(n, isa, plcp, maxlcp, threshold, lcut)
+    out = set(factors)
+    tiles = invalid = 0
+    for a in range(0, n, interior):
+        b = min(n, a + interior)
+        w0, w1 = max(0, a - halo), min(n, b + halo)
+        fs, ok = factorize_tile(n, w0, w1, a, b, cur, prio, resid, threshold, min(lcut, maxlcp))
+        tiles += 1
+        if ok:
+            out.update(fs)
+        else:
+            invalid += 1
+            out.add(("invalid", a, b))
+    return out, tiles, invalid

@@ -51,3 +51,34 @@ def test_explicit_priority_model_is_order_independent():
         for thr in (1, 2, 5):
             ref = [(int(a), int(b), int(c)) for a, b, c in O.arrays_comp(sa, isa, lcp, maxlcp, thr)]
             assert factorize_explicit_priority(n, isa, phi, plcp, maxlcp, thr, rng) == ref
+
+
+def _tile_check(data, thr, lcut, interior, halo):
+    """Hybrid factorizer (global levels above lcut, window-local levels below; factorize_tiles.hip): every window that
+    reports itself valid must reproduce the reference's factors inside its interior exactly."""
+    from tests.models.position_space import factorize_hybrid_tiles
+    text = O.escape(data)
+    n = len(text)
+    sa = O.suffix_array(text)
+    isa, phi, plcp, maxlcp = O.isa_phi_plcp(text, sa)
+    lcp = O.lcp_array(sa, plcp)
+    ref = {(int(a), int(c)) for a, b, c in O.arrays_comp(sa, isa, lcp, maxlcp, thr)}
+    got, tiles, invalid = factorize_hybrid_tiles(n, isa, phi, plcp, maxlcp, thr, lcut, interior, halo)
+    inv = [(x[1], x[2]) for x in got if x[0] == "invalid"]
+    g = {x for x in got if x[0] != "invalid"}
+    covered = lambda p: any(a <= p < b for a, b in inv)
+    assert all(f in g for f in ref if not (f[1] <= lcut and covered(f[0])))
+    assert all(f in ref for f in g)
+    return tiles, invalid
+
+
+def test_tile_local_levels_model():
+    tiles = invalid = 0
+    cases = corpus.random_small(120, seed=11) + [c for c in corpus.small_corpus() if len(c[1]) <= 2000]
+    for _, data in cases:
+        for thr in (1, 2, 5):
+            for lcut, interior, halo in ((4, 32, 16), (6, 64, 40), (3, 16, 8), (100, 64, 32)):
+                t, i = _tile_check(data, thr, lcut, interior, halo)
+                tiles += t
+                invalid += i
+    assert 0 < invalid < tiles // 2          # both outcomes are exercised

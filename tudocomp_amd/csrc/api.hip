@@ -240,6 +240,8 @@ int tdc_gpu_ctx_create(int device, tdc_gpu_ctx** out) {
         HIP_TRY(hipMemset(ctx->c.d_err, 0, 256));
         if (const char* m = getenv("TDC_GPU_SA_LOCAL")) ctx->c.sa_local_sort = atoi(m) ? 1 : 0;
         if (const char* m = getenv("TDC_GPU_RADIX_WAVES")) ctx->c.radix_waves = (atoi(m) == 8) ? 8 : 4;
+        if (const char* m = getenv("TDC_GPU_XCD_REMAP")) ctx->c.xcd_remap = atoi(m) ? 1 : 0;
+        if (const char* m = getenv("TDC_GPU_BUCKET_SCATTER")) ctx->c.bucket_scatter = atoi(m) ? 1 : 0;
     } catch (const HipError&) {
         (void)hipGetLastError();
         tdc_gpu_ctx_destroy(ctx);

@@ -95,6 +95,8 @@ struct Ctx {
     u32* d_err = nullptr;          // device error word (look-back timeouts etc.), checked at the end of every API call
     int sa_local_sort = 1;         // doubling rounds: sort whole runs inside 2048-element tiles locally (env TDC_GPU_SA_LOCAL=0 disables)
     int radix_waves = 4;           // waves per radix-sort workgroup for large inputs (env TDC_GPU_RADIX_WAVES = 4 | 8; no measurable difference)
+    int xcd_remap = 0;             // radix sort / bucketed scatter: workgroups of one XCD walk one contiguous range of tiles (env TDC_GPU_XCD_REMAP=1; measured: no gain)
+    int bucket_scatter = 1;        // big random scatters (rank, Phi) go through one radix partition by destination window (env TDC_GPU_BUCKET_SCATTER=0 disables)
 
     bool profiling = false;
     KernelProfile kprof[K_CLASS_COUNT];
@@ -164,6 +166,12 @@ struct Ctx {
 #ifdef __HIPCC__
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one; observed behaviour, used for speed
+// only, never for correctness).  Streaming kernels whose neighbouring tiles write neighbouring addresses give every XCD
+// one contiguous range of tiles, so that the partial cache lines of consecutive tiles meet in ONE L2 and leave it as
+// whole lines.  per_xcd = ceil(tiles / 8) (grid = 8 * per_xcd), 0 = identity mapping.
+__device__ __forceinline__ u32 xcd_tile(u32 bid, u32 per_xcd) { return per_xcd ? (bid & 7u) * per_xcd + (bid >> 3) : bid; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 
 // Inclusive scan across the 64 lanes of a wave.

@@ -29,6 +29,8 @@
 #include "prim.hpp"
 
 #include <algorithm>
+#include <chrono>
+#include <stdlib.h>
 #include <vector>
 
 namespace tdc {
@@ -516,6 +518,8 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
     u32 dead_streak = 0, levels_since_purge = 1u << 30;
     size_t cand_count = entries;
 
+    const bool level_log = getenv("TDC_GPU_LEVEL_LOG") != nullptr;     // debugging aid: one line per large level on stderr
+    auto t_prev = std::chrono::steady_clock::now();
     for (u32 L = maxlcp; L >= threshold; --L) {
         // ---- purge: after a run of large levels whose entries were (almost) all erased, drop the erased candidates of
         //      every level still to come (they can never come back to life: cur only decreases)
@@ -663,6 +667,8 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
         c.read_n((const u32*)d_sc, (u32*)&h_sc, 8);
         st->factors += h_sc.selected;
         const u32 npush = h_sc.npush;
+        const u32 rounds_before = st->rounds;
+        (void)rounds_before;
         if (npush) {
             // every push is caused by a truncation of a position in front of a factor, and factors are disjoint,
             // so the pool never needs more than n slots; checked before anything is written
@@ -690,6 +696,12 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
             pool_top += npush;
             prio_base += npush;
             st->pushes += npush;
+        }
+        if (level_log) {
+            const auto t_now = std::chrono::steady_clock::now();
+            fprintf(stderr, "level %u m0 %u m1 %u live %u stale %u selected %u npush %u ms %.3f\n", L, m0, m1, nl, ns, h_sc.selected, npush,
+                    std::chrono::duration<double, std::milli>(t_now - t_prev).count());
+            t_prev = t_now;
         }
         if (L == 0) break;
     }

@@ -340,11 +340,13 @@ constexpr int RS_ITEMS = 16;               // keys per lane; wave w of a workgro
 
 template <typename K, int NW>
 __global__ __launch_bounds__(NW * 64) void rs_count_kernel(const K* __restrict__ keys, u32* __restrict__ counts, size_t n,
-                                                            u32 numTiles, int shift, u32 dmask) {
+                                                            u32 numTiles, int shift, u32 dmask, u32 per_xcd) {
     __shared__ u32 hist[256];
+    const u32 tile = xcd_tile(blockIdx.x, per_xcd);
+    if (tile >= numTiles) return;
     if (threadIdx.x < 256) hist[threadIdx.x] = 0;
     __syncthreads();
-    const size_t tileBase = (size_t)blockIdx.x * (NW * 64 * RS_ITEMS) + (size_t)wave_id() * (64 * RS_ITEMS) + lane_id();
+    const size_t tileBase = (size_t)tile * (NW * 64 * RS_ITEMS) + (size_t)wave_id() * (64 * RS_ITEMS) + lane_id();
 #pragma unroll 4
     for (int j = 0; j < RS_ITEMS; ++j) {
         const size_t idx = tileBase + (size_t)j * 64;
@@ -358,17 +360,19 @@ __global__ __launch_bounds__(NW * 64) void rs_count_kernel(const K* __restrict__
         }
     }
     __syncthreads();
-    if (threadIdx.x < 256) counts[(size_t)threadIdx.x * numTiles + blockIdx.x] = hist[threadIdx.x];
+    if (threadIdx.x < 256) counts[(size_t)threadIdx.x * numTiles + tile] = hist[threadIdx.x];
 }
 
 template <typename K, int NW>
 __global__ __launch_bounds__(NW * 64) void rs_scatter_kernel(const K* __restrict__ keys_in, const u32* __restrict__ vals_in,
                                                               K* __restrict__ keys_out, u32* __restrict__ vals_out,
                                                               const u32* __restrict__ offsets, size_t n, u32 numTiles,
-                                                              int shift, u32 dmask) {
+                                                              int shift, u32 dmask, u32 per_xcd) {
     __shared__ u32 wcnt[NW][256];     // per-wave running digit counts
     __shared__ u32 wbase[NW][256];    // global start of (wave, digit) run
     const int lane = lane_id(), w = wave_id();
+    const u32 tile = xcd_tile(blockIdx.x, per_xcd);
+    if (tile >= numTiles) return;
     for (int i = threadIdx.x; i < NW * 256; i += NW * 64) (&wcnt[0][0])[i] = 0;
     __syncthreads();
 
@@ -376,7 +380,7 @@ __global__ __launch_bounds__(NW * 64) void rs_scatter_kernel(const K* __restrict
     u32 v[RS_ITEMS];
     u32 loc[RS_ITEMS];
     volatile u32* mycnt = wcnt[w];
-    const size_t tileBase = (size_t)blockIdx.x * (NW * 64 * RS_ITEMS) + (size_t)w * (64 * RS_ITEMS) + lane;
+    const size_t tileBase = (size_t)tile * (NW * 64 * RS_ITEMS) + (size_t)w * (64 * RS_ITEMS) + lane;
     const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
     for (int j = 0; j < RS_ITEMS; ++j) {
@@ -400,7 +404,7 @@ __global__ __launch_bounds__(NW * 64) void rs_scatter_kernel(const K* __restrict
     __syncthreads();
     if (threadIdx.x < 256) {
         const u32 t = threadIdx.x;
-        u32 run = offsets[(size_t)t * numTiles + blockIdx.x];
+        u32 run = offsets[(size_t)t * numTiles + tile];
 #pragma unroll
         for (int i = 0; i < NW; ++i) { wbase[i][t] = run; run += wcnt[i][t]; }
     }
@@ -423,19 +427,21 @@ static int radix_sort_pairs_nw(Ctx& c, K* keys[2], u32* vals[2], size_t n, int b
     constexpr int TILE = NW * 64 * RS_ITEMS;
     const u32 numTiles = cdiv(n, TILE);
     u32* counts = c.arena.get<u32>((size_t)256 * numTiles);
+    const u32 per_xcd = (c.xcd_remap && numTiles >= 64) ? cdiv(numTiles, 8) : 0u;
+    const u32 grid = per_xcd ? 8 * per_xcd : numTiles;
     int cur = 0;
     for (int shift = begin_bit; shift < end_bit; shift += 8) {
         const int bits = (end_bit - shift) < 8 ? (end_bit - shift) : 8;
         const u32 dmask = (1u << bits) - 1u;
         // algorithmic bytes: count reads every key once; scatter reads and writes every (key, value) pair once
         const int pc = c.prof_begin(K_RS_COUNT, (u64)n * sizeof(K));
-        rs_count_kernel<K, NW><<<numTiles, NW * 64, 0, c.stream>>>(keys[cur], counts, n, numTiles, shift, dmask);
+        rs_count_kernel<K, NW><<<grid, NW * 64, 0, c.stream>>>(keys[cur], counts, n, numTiles, shift, dmask, per_xcd);
         LAUNCH_CHECK();
         c.prof_end(pc);
         exclusive_sum_u32(c, counts, counts, (size_t)256 * numTiles, nullptr);
         const int ps = c.prof_begin(sizeof(K) == 8 ? K_RS_SCATTER_U64 : K_RS_SCATTER_U32, (u64)n * 2 * (sizeof(K) + sizeof(u32)));
-        rs_scatter_kernel<K, NW><<<numTiles, NW * 64, 0, c.stream>>>(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], counts, n,
-                                                                      numTiles, shift, dmask);
+        rs_scatter_kernel<K, NW><<<grid, NW * 64, 0, c.stream>>>(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], counts, n,
+                                                                  numTiles, shift, dmask, per_xcd);
         LAUNCH_CHECK();
         c.prof_end(ps);
         cur ^= 1;
@@ -490,5 +496,44 @@ int sort_pairs_u64_distinct(Ctx& c, u64* keys[2], u32* vals[2], size_t n, int b,
     return 1;
 }
 int radix_sort_pairs_u32(Ctx& c, u32* keys[2], u32* vals[2], size_t n, int b, int e) { return radix_sort_pairs<u32>(c, keys, vals, n, b, e); }
+
+// ---- bucketed scatter ------------------------------------------------------------------------------------------
+// dst[idx[j]] = val[j] for m pairs with pairwise distinct idx < n_dst.  A direct scatter of 4-byte elements over a
+// gigabyte touches one DRAM line per element; one stable radix partition by the top 8 bits of idx turns it into a
+// streaming pass plus a scatter whose writes stay inside one n_dst/256 window per run (L2 / Infinity-Cache sized).
+constexpr int WS_ITEMS = 4;
+__global__ __launch_bounds__(256) void window_scatter_kernel(const u32* __restrict__ idx, const u32* __restrict__ val, size_t m,
+                                                              u32* __restrict__ dst, u32 numTiles, u32 per_xcd) {
+    const u32 tile = xcd_tile(blockIdx.x, per_xcd);
+    if (tile >= numTiles) return;
+    const size_t j0 = ((size_t)tile * 256 + threadIdx.x) * WS_ITEMS;
+    u32 k[WS_ITEMS], v[WS_ITEMS];
+    if ((((size_t)idx | (size_t)val) & 15) == 0) {               // the partitioned pairs; callers may pass offset views otherwise
+        load4(idx, j0, m, k);
+        load4(val, j0, m, v);
+    } else {
+#pragma unroll
+        for (int r = 0; r < WS_ITEMS; ++r) { k[r] = (j0 + r < m) ? idx[j0 + r] : 0u; v[r] = (j0 + r < m) ? val[j0 + r] : 0u; }
+    }
+#pragma unroll
+    for (int r = 0; r < WS_ITEMS; ++r) if (j0 + r < m) dst[k[r]] = v[r];
+}
+
+void bucketed_scatter_u32(Ctx& c, const u32* idx, const u32* val, size_t m, u32* dst, size_t n_dst, u32* tmp_idx, u32* tmp_val) {
+    if (m == 0) return;
+    const int bits = (int)bits_for(n_dst ? n_dst - 1 : 0);
+    const u32* k = idx;
+    const u32* v = val;
+    if (bits > 8 && m >= ((size_t)1 << 20)) {
+        u32* keys[2] = { const_cast<u32*>(idx), tmp_idx };      // one pass: [0] is only read
+        u32* vals[2] = { const_cast<u32*>(val), tmp_val };
+        const int x = radix_sort_pairs<u32>(c, keys, vals, m, bits - 8, bits);
+        k = keys[x]; v = vals[x];
+    }
+    const u32 numTiles = cdiv(m, 256 * WS_ITEMS);
+    const u32 per_xcd = (c.xcd_remap && numTiles >= 64) ? cdiv(numTiles, 8) : 0u;
+    window_scatter_kernel<<<per_xcd ? 8 * per_xcd : numTiles, 256, 0, c.stream>>>(k, v, m, dst, numTiles, per_xcd);
+    LAUNCH_CHECK();
+}
 
 }  // namespace tdc

@@ -65,6 +65,7 @@ __global__ void sa_heads_kernel(const u64* __restrict__ keys, size_t m, u32* __r
 }
 
 // First round: every position is "active", pos[a] == a.
+template <bool SCATTER_RANK>
 __global__ void sa_first_update_kernel(const u32* __restrict__ vals, const u32* __restrict__ head, size_t n,
                                        u32* __restrict__ sa, u32* __restrict__ rank, u32* __restrict__ keep) {
     const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -72,7 +73,7 @@ __global__ void sa_first_update_kernel(const u32* __restrict__ vals, const u32* 
     const u32 h = head[j];
     const u32 s = vals[j];
     sa[j] = s;
-    rank[s] = h;
+    if (SCATTER_RANK) rank[s] = h;
     const bool single = (h == (u32)j) && (j + 1 == n || head[j + 1] == (u32)(j + 1));
     keep[j] = single ? 0u : 1u;
 }
@@ -224,8 +225,15 @@ void build_suffix_array(Ctx& c, const u8* text, size_t n, u32* sa, u32* isa, SAS
     inclusive_max_u32(c, head, head, n);
     {   // per element: read value + head (8 B), write sa + keep (8 B), scatter rank (4 B)
         Ctx::ProfScope prof(c, K_SA_RANK_SCATTER, (u64)n * 20);
-        sa_first_update_kernel<<<gn, 256, 0, s>>>(vals[x], head, n, sa, rank, keep);
-        LAUNCH_CHECK();
+        if (c.bucket_scatter && n >= ((size_t)1 << 22)) {
+            // rank[vals[j]] = head[j] through a partition by destination window; the other key buffer is free scratch
+            sa_first_update_kernel<false><<<gn, 256, 0, s>>>(vals[x], head, n, sa, rank, keep);
+            LAUNCH_CHECK();
+            bucketed_scatter_u32(c, vals[x], head, n, rank, n, (u32*)keys[x ^ 1], vals[x ^ 1]);
+        } else {
+            sa_first_update_kernel<true><<<gn, 256, 0, s>>>(vals[x], head, n, sa, rank, keep);
+            LAUNCH_CHECK();
+        }
     }
     exclusive_sum_u32(c, keep, keep, n, d_total);
     sa_first_compact_kernel<<<gn, 256, 0, s>>>(vals[x], head, keep, n, A_sa, A_pos, A_r1);

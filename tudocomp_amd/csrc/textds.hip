@@ -6,6 +6,7 @@
 // Phi-algorithm's carry l = 0 at the start of its chunk and then uses plcp[i+1] >= plcp[i] - 1) is bit-identical
 // to the reference's sequential loop.
 #include "stages.hpp"
+#include "prim.hpp"
 
 namespace tdc {
 
@@ -16,9 +17,22 @@ __global__ void phi_kernel(const u32* __restrict__ sa, size_t n, u32* __restrict
     phi[s] = (i == 0) ? sa[n - 1] : sa[i - 1];
 }
 
+__global__ void phi_first_kernel(const u32* __restrict__ sa, size_t n, u32* __restrict__ phi) { phi[sa[0]] = sa[n - 1]; }
+
 void build_phi(Ctx& c, const u32* sa, size_t n, u32* phi) {
     if (!n) return;
     Ctx::ProfScope prof(c, K_PHI, (u64)n * 8);                  // read SA, scatter Phi
+    if (c.bucket_scatter && n >= ((size_t)1 << 22)) {
+        // pairs (sa[i], sa[i-1]), i = 1 .. n-1, partitioned by destination window, then scattered
+        const size_t mark = c.arena.mark();
+        u32* ti = c.arena.get<u32>(n);
+        u32* tv = c.arena.get<u32>(n);
+        bucketed_scatter_u32(c, sa + 1, sa, n - 1, phi, n, ti, tv);
+        phi_first_kernel<<<1, 1, 0, c.stream>>>(sa, n, phi);
+        LAUNCH_CHECK();
+        c.arena.release(mark);
+        return;
+    }
     phi_kernel<<<cdiv(n, 256), 256, 0, c.stream>>>(sa, n, phi);
     LAUNCH_CHECK();
 }
