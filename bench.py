@@ -158,7 +158,7 @@ def main():
                          "frac_of_hbm_peak": round(b_alg * N / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
             "stages_ms": {k2[3:]: round(v, 2) for k2, v in st.items() if k2.startswith("ms_")},
             "stats": {k2: st[k2] for k2 in ("out_len", "factors", "maxlcp", "num_flattened", "sa_rounds", "levels", "mis_rounds",
-                                            "flatten_rounds", "pushes", "arena_bytes", "sa_sorted_elems", "sa_init_syms", "small_levels", "purges")},
+                                            "flatten_rounds", "pushes", "arena_bytes", "sa_sorted_elems", "sa_init_syms", "small_levels", "purges", "window_pass", "window_lcut")},
             "kernels": {name: {"ms_per_step": round(p["ms"] / args.steps, 3), "launches_per_step": p["launches"] / args.steps}
                         for name, p in prof.items() if p["launches"]},
         }

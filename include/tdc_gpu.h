@@ -63,6 +63,8 @@ typedef struct {
     float ms_h2d, ms_sa, ms_phi, ms_plcp, ms_factorize, ms_flatten, ms_encode, ms_d2h, ms_total;
     uint32_t small_levels;      /* levels processed by the one-workgroup kernel                 */
     uint32_t purges;            /* bulk removals of erased candidates                           */
+    uint32_t window_pass;       /* low levels window-local in one launch: 0 not used, 1 done, 2 fell back to the level loop */
+    uint32_t window_lcut;       /* highest level handed to the (last) window pass                */
 } tdc_gpu_stats;
 
 /* ---- context -------------------------------------------------------------------------------------------- */

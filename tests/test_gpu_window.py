@@ -1,0 +1,96 @@
+"""GPU parity of the hybrid factorizer (pytest -m gpu): levels above TDC_GPU_WINDOW_LCUT through the global level loop,
+the levels below window by window in one launch (factorize_tiles.hip) -- including the fallback when a window cannot be
+completed.  Texts are just long enough for the window path (>= 64 Ki positions) so the oracle stays fast."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+import tudocomp_amd as T
+from oracle import oracle as O
+from tests import corpus
+
+pytestmark = pytest.mark.gpu
+
+
+def _texts():
+    rng = random.Random(77)
+    out = [
+        ("english_96k", T.gen_english(96 * 1024, 42).tobytes()),
+        ("english_300k", T.gen_english(300_000, 9).tobytes()),
+        ("dna_128k", T.gen_dna(128 * 1024, 7).tobytes()),
+        ("rand_s2_80k", bytes(rng.randrange(1, 3) for _ in range(80_000))),
+        ("rand_s4_100k", bytes(rng.randrange(1, 5) for _ in range(100_000))),
+        ("rand_s26_70k", bytes(rng.randrange(97, 123) for _ in range(70_000))),
+        ("planted4_90k", corpus.planted(90_000, 4, rng, replen=300)),
+        ("planted26_120k", corpus.planted(120_000, 26, rng, replen=40)),
+        ("runrich_70k", corpus.run_rich(70_000, rng)),
+        ("fib24", corpus.fib_word(24)[:100_000]),
+        ("thue17", corpus.thue_morse(17)),
+        ("periodic_7", (b"abcdefg" * 12_000)),
+        ("words_66k", b" ".join(rng.choice([b"alpha", b"beta", b"gamma", b"delta", b"pi", b"rho"]) for _ in range(20_000))),
+    ]
+    return out
+
+
+TEXTS = _texts()
+
+
+@pytest.fixture(scope="module")
+def ctx_for():
+    """Contexts per TDC_GPU_WINDOW_LCUT value (the knob is read when a context is created)."""
+    made = {}
+
+    def get(lcut):
+        if lcut not in made:
+            old = os.environ.get("TDC_GPU_WINDOW_LCUT")
+            os.environ["TDC_GPU_WINDOW_LCUT"] = str(lcut)
+            try:
+                made[lcut] = T.Context(0)
+            finally:
+                if old is None:
+                    del os.environ["TDC_GPU_WINDOW_LCUT"]
+                else:
+                    os.environ["TDC_GPU_WINDOW_LCUT"] = old
+        return made[lcut]
+    yield get
+    for c in made.values():
+        c.close()
+
+
+@pytest.mark.parametrize("name,data", TEXTS, ids=[t[0] for t in TEXTS])
+def test_window_levels_match_oracle(ctx_for, name, data):
+    text = O.escape(data)
+    sa = O.suffix_array(text)
+    isa, phi, plcp, maxlcp = O.isa_phi_plcp(text, sa)
+    lcp = O.lcp_array(sa, plcp)
+    seen = set()
+    for thr in (1, 2, 3, 5):
+        ref = O.sort_factors(O.arrays_comp(sa, isa, lcp, maxlcp, thr))
+        fl, nf, md = O.flatten(ref)
+        for lcut in (48, 3, 12, 63, 0):
+            ctx = ctx_for(lcut)
+            pos, src, ln, st = ctx.factorize(text, thr, flatten=1)
+            seen.add(st["window_pass"])
+            assert st["factors"] == len(ref), "%s t=%d lcut=%d: %d factors, want %d (window_pass %d)" % (
+                name, thr, lcut, st["factors"], len(ref), st["window_pass"])
+            assert np.array_equal(pos, ref["pos"]) and np.array_equal(ln, ref["len"]), "%s t=%d lcut=%d" % (name, thr, lcut)
+            assert np.array_equal(src, fl["src"]), "%s t=%d lcut=%d: flattened sources" % (name, thr, lcut)
+            assert (st["num_flattened"], st["max_depth_lb"]) == (nf, md)
+            if lcut == 0:
+                assert st["window_pass"] == 0
+    assert seen & {1, 2}, "the window pass never ran"
+
+
+def test_window_pass_is_used_and_stream_bit_exact(ctx_for):
+    """End to end on the bench corpus generator: the default configuration takes the window path (no fallback) and the
+    stream equals the oracle's."""
+    data = T.gen_english(1 << 21, 42).tobytes()
+    text = O.escape(data)
+    want, _ = O.lcpcomp_huff_compress(text, 2, 1)
+    got, st = ctx_for(48).lcpcomp_compress(text, threshold=2, flatten=1)
+    assert st["window_pass"] == 1
+    assert got == want
+    got0, st0 = ctx_for(0).lcpcomp_compress(text, threshold=2, flatten=1)
+    assert st0["window_pass"] == 0 and got0 == want

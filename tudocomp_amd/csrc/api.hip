@@ -151,7 +151,7 @@ void run_factorize(Ctx& c, size_t n, DevArrays& A, u32 threshold, int flatten, t
     const int e2 = ev ? ev->tick() : 0;
     if (st) {
         st->factors = fz.factors; st->entries = fz.entries; st->pushes = fz.pushes;
-        st->levels = fz.levels; st->mis_rounds = fz.rounds; st->small_levels = fz.small_levels; st->purges = fz.purges;
+        st->levels = fz.levels; st->mis_rounds = fz.rounds; st->small_levels = fz.small_levels; st->purges = fz.purges; st->window_pass = fz.window_pass; st->window_lcut = fz.window_lcut;
         st->num_flattened = fl.num_flattened; st->max_depth_lb = fl.max_depth_lb; st->flatten_rounds = fl.rounds;
         if (ev) { ev->span(&st->ms_factorize, e0, e1); ev->span(&st->ms_flatten, e1, e2); }
     }
@@ -240,6 +240,8 @@ int tdc_gpu_ctx_create(int device, tdc_gpu_ctx** out) {
         HIP_TRY(hipMemset(ctx->c.d_err, 0, 256));
         if (const char* m = getenv("TDC_GPU_SA_LOCAL")) ctx->c.sa_local_sort = atoi(m) ? 1 : 0;
         if (const char* m = getenv("TDC_GPU_RADIX_WAVES")) ctx->c.radix_waves = (atoi(m) == 8) ? 8 : 4;
+        if (const char* m = getenv("TDC_GPU_WINDOW_LCUT")) { const int v = atoi(m); ctx->c.window_lcut = v < 0 ? 0 : (v > 63 ? 63 : v); }
+        if (const char* m = getenv("TDC_GPU_WINDOW_THREADS")) ctx->c.window_threads = (atoi(m) == 512) ? 512 : 256;
         if (const char* m = getenv("TDC_GPU_XCD_REMAP")) ctx->c.xcd_remap = atoi(m) ? 1 : 0;
         if (const char* m = getenv("TDC_GPU_BUCKET_SCATTER")) ctx->c.bucket_scatter = atoi(m) ? 1 : 0;
     } catch (const HipError&) {
@@ -288,7 +290,7 @@ const char* tdc_gpu_ctx_kernel_profile(const tdc_gpu_ctx* ctx, int idx, double* 
     static const char* names[K_CLASS_COUNT] = {
         "rs_scatter_kernel<u64>", "rs_scatter_kernel<u32>", "rs_count_kernel", "scan_kernels",
         "sa_update_kernels", "sa_build_keys_kernel", "phi_kernel", "plcp_kernel", "cand_kernels",
-        "level_init_kernel", "mis_round_kernel", "resolve_kernel", "push_kernel", "apply_kernel", "pool_kernels", "small_level_kernel",
+        "level_init_kernel", "mis_round_kernel", "resolve_kernel", "push_kernel", "apply_kernel", "pool_kernels", "small_level_kernel", "window_levels_kernel",
         "flatten_round_kernel", "gaps_kernel", "literal_hist_kernel", "tile_bits_kernel", "pack_kernel", "extract_kernels" };
     if (!ctx || idx < 0 || idx >= K_CLASS_COUNT) return nullptr;
     const KernelProfile& k = ctx->c.kprof[idx];

@@ -74,7 +74,7 @@ struct Arena {
 enum KernelClass {
     K_RS_SCATTER_U64 = 0, K_RS_SCATTER_U32, K_RS_COUNT, K_SCAN,
     K_SA_RANK_SCATTER, K_SA_BUILD_KEYS, K_PHI, K_PLCP, K_CAND,
-    K_LEVEL_INIT, K_MIS_ROUND, K_RESOLVE, K_PUSH, K_APPLY, K_POOL, K_SMALL_LEVEL,
+    K_LEVEL_INIT, K_MIS_ROUND, K_RESOLVE, K_PUSH, K_APPLY, K_POOL, K_SMALL_LEVEL, K_WINDOW_LEVELS,
     K_FLATTEN_ROUND, K_ENC_GAPS, K_ENC_HIST, K_ENC_TILE_BITS, K_ENC_PACK, K_EXTRACT,
     K_CLASS_COUNT
 };
@@ -96,6 +96,8 @@ struct Ctx {
     int sa_local_sort = 1;         // doubling rounds: sort whole runs inside 2048-element tiles locally (env TDC_GPU_SA_LOCAL=0 disables)
     int radix_waves = 4;           // waves per radix-sort workgroup for large inputs (env TDC_GPU_RADIX_WAVES = 4 | 8; no measurable difference)
     int xcd_remap = 0;             // radix sort / bucketed scatter: workgroups of one XCD walk one contiguous range of tiles (env TDC_GPU_XCD_REMAP=1; measured: no gain)
+    int window_lcut = 48;          // factorize: levels <= this run window-local in one launch (env TDC_GPU_WINDOW_LCUT, 0 disables)
+    int window_threads = 256;      // threads per window workgroup (env TDC_GPU_WINDOW_THREADS = 256 | 512)
     int bucket_scatter = 1;        // big random scatters (rank, Phi) go through one radix partition by destination window (env TDC_GPU_BUCKET_SCATTER=0 disables)
 
     bool profiling = false;

@@ -27,6 +27,7 @@
 //     decision is ONE atomic (xor 11: undecided -> selected, xor 01: undecided -> rejected).
 #include "stages.hpp"
 #include "prim.hpp"
+#include "factorize_tiles.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -66,14 +67,14 @@ __device__ __forceinline__ u32 bm_state(const u64* __restrict__ bm, u32 p) { ret
 
 // ---- candidates ("Fill candidates", :54-66) ----------------------------------------------------------------
 __global__ void cand_class_kernel(const u32* __restrict__ plcp, size_t n, u32 threshold, u8* __restrict__ cls,
-                                  u32* __restrict__ pos, u32* __restrict__ flen, u32* __restrict__ owner) {
+                                  u32* __restrict__ pos, u32* __restrict__ flen, u8* __restrict__ res8) {
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     const u32 v = plcp[p];
     cls[p] = (v >= threshold) ? 1 : 0;   // PLCP[n-1] = 0, so the sentinel (SA index 0) is never a candidate
     pos[p] = (u32)p;
     flen[p] = 0;
-    owner[p] = NONE32;
+    if (res8) res8[p] = (v >= threshold) ? (u8)(v > 255u ? 255u : v) : (u8)0;   // list that holds the entry of p (saturated)
 }
 __global__ void gather_kernel(const u32* __restrict__ idx, size_t m, const u32* __restrict__ src, u32* __restrict__ dst) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -195,7 +196,7 @@ constexpr u32 SMALL_APPLY_INLINE_MAX_L = 64;      // longer factors are applied 
 
 __global__ __launch_bounds__(256) void small_level_kernel(const u32* __restrict__ orig, u32 m0, const u32* __restrict__ pushed, u32 m,
                                                            u32 L, u32 threshold, size_t n, u32* cur, u32* prio,
-                                                           const u32* __restrict__ phi, u32* __restrict__ flen, u32* __restrict__ owner,
+                                                           const u32* __restrict__ phi, u32* __restrict__ flen, u8* __restrict__ res8,
                                                            u32* __restrict__ fsrc, u32* __restrict__ pool, u32 prio_base,
                                                            PushSeg* __restrict__ segs, u32 seg_cap, u32* __restrict__ sel_list,
                                                            LevelScalars* __restrict__ sc) {
@@ -315,6 +316,7 @@ __global__ __launch_bounds__(256) void small_level_kernel(const u32* __restrict_
         const u32 p = sval[i];
         prio[p] = prio_base + i;
         pool[i] = p;
+        if (res8) { const u32 tgt = (u32)(skey[i] >> 32); res8[p] = (u8)(tgt > 255u ? 255u : tgt); }
     }
     if (tid == 0) {
         u32 nseg = 0;
@@ -336,7 +338,7 @@ __global__ __launch_bounds__(256) void small_level_kernel(const u32* __restrict_
             if (st[i] != 1) continue;                     // wave-uniform
             const u32 p = pos_s[i];
             if (lane == 0) { flen[p] = L; fsrc[p] = phi[p]; atomicAdd(&s_sel, 1u); }
-            for (u32 j = lane; j < L && (size_t)p + j < n; j += 64) { cur[p + j] = 0; owner[p + j] = p; }
+            for (u32 j = lane; j < L && (size_t)p + j < n; j += 64) cur[p + j] = 0;
             const u32 aff = (L < p) ? L : p;
             for (u32 j = lane; j < aff; j += 64) { u32* q = &cur[p - 1 - j]; if (*q > j + 1) atomicMin(q, j + 1); }
         }
@@ -350,13 +352,13 @@ __global__ __launch_bounds__(256) void small_level_kernel(const u32* __restrict_
 // apply for a list of selected positions whose length is only known on the device (one wave per factor)
 __global__ __launch_bounds__(256) void apply_list_kernel(const u32* __restrict__ list, const u32* __restrict__ d_count, u32 L, size_t n,
                                                           const u32* __restrict__ phi, u32* __restrict__ cur, u32* __restrict__ flen,
-                                                          u32* __restrict__ owner, u32* __restrict__ fsrc) {
+                                                          u32* __restrict__ fsrc) {
     const u32 i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const u32 lane = threadIdx.x & 63;
     if (i >= *d_count) return;
     const u32 p = list[i];
     if (lane == 0) { flen[p] = L; fsrc[p] = phi[p]; }
-    for (u32 j = lane; j < L && (size_t)p + j < n; j += 64) { cur[p + j] = 0; owner[p + j] = p; }
+    for (u32 j = lane; j < L && (size_t)p + j < n; j += 64) cur[p + j] = 0;
     const u32 aff = (L < p) ? L : p;
     for (u32 j = lane; j < aff; j += 64) { u32* q = &cur[p - 1 - j]; if (*q > j + 1) atomicMin(q, j + 1); }
 }
@@ -383,7 +385,7 @@ __global__ void gather_segments_kernel(const u32* __restrict__ pool, const Gathe
 
 // The level's pushes, sorted by (target, old priority): new residence, new priority, pool slot, segment starts.
 __global__ void push_finalize_kernel(const u64* __restrict__ keys, const u32* __restrict__ vals, u32 npush, u32 prio_base,
-                                     u32* __restrict__ prio, u32* __restrict__ pool,
+                                     u32* __restrict__ prio, u32* __restrict__ pool, u8* __restrict__ res8,
                                      PushSeg* __restrict__ segs, u32 seg_cap, LevelScalars* __restrict__ sc) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= npush) return;
@@ -391,6 +393,7 @@ __global__ void push_finalize_kernel(const u64* __restrict__ keys, const u32* __
     const u32 p = vals[i];
     prio[p] = prio_base + i;
     pool[i] = p;
+    if (res8) res8[p] = (u8)(tgt > 255u ? 255u : tgt);
     if (i == 0 || (u32)(keys[i - 1] >> 32) != tgt) {
         const u32 j = atomicAdd(&sc->nseg, 1u);
         if (j < SEG_INLINE) sc->segs[j] = PushSeg{tgt, i};
@@ -402,7 +405,7 @@ __global__ void push_finalize_kernel(const u64* __restrict__ keys, const u32* __
 template <int G>
 __global__ __launch_bounds__(256) void apply_kernel(const u32* __restrict__ live, u32 nl, u32 L, size_t n, u64* bm,
                                                      const u32* __restrict__ phi, u32* __restrict__ cur, u32* __restrict__ flen,
-                                                     u32* __restrict__ owner, u32* __restrict__ fsrc, LevelScalars* __restrict__ sc) {
+                                                     u32* __restrict__ fsrc, LevelScalars* __restrict__ sc) {
     const u32 i = (blockIdx.x * blockDim.x + threadIdx.x) / G;
     const u32 sub = (G == 1) ? 0u : (threadIdx.x & (G - 1));
     bool sel = false;
@@ -410,10 +413,7 @@ __global__ __launch_bounds__(256) void apply_kernel(const u32* __restrict__ live
     if (i < nl) { p = live[i]; sel = (bm_state(bm, p) == 2u); }
     if (sel) {
         if (sub == 0) { flen[p] = L; fsrc[p] = phi[p]; }
-        for (u32 j = sub; j < L && (size_t)p + j < n; j += G) {   // :99-101
-            cur[p + j] = 0;
-            owner[p + j] = p;
-        }
+        for (u32 j = sub; j < L && (size_t)p + j < n; j += G) cur[p + j] = 0;   // :99-101
         const u32 aff = (L < p) ? L : p;                           // :103
         for (u32 j = sub; j < aff; j += G) {                         // :105-109
             u32* q = &cur[p - 1 - j];
@@ -449,16 +449,24 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
 
     // ---- candidates: positions with PLCP >= threshold, in position order, stably sorted by PLCP value -----------
     u8* cls = c.arena.get<u8>(n);
+    // the low levels run window-local (factorize_tiles.hip) when the text is long enough; res8 = residence level per position
+    u32 lcut = 0;
+    if (c.window_lcut > 0 && n >= window_levels_min_text()) {
+        lcut = std::min<u32>((u32)c.window_lcut, window_levels_max_lcut());
+        if (lcut > maxlcp) lcut = maxlcp;
+        if (lcut < threshold) lcut = 0;
+    }
+    u8* res8 = lcut ? c.arena.get<u8>(n) : nullptr;
     u32* ckeys[2] = { c.arena.get<u32>(n), c.arena.get<u32>(n) };
     u32* cvals[2] = { c.arena.get<u32>(n), c.arena.get<u32>(n) };
     u32* d_cnt = c.arena.get<u32>(4);
     u32* iota = ckeys[1];                       // scratch: position of every text position
     {
         Ctx::ProfScope prof(c, K_CAND, (u64)n * 17);
-        cand_class_kernel<<<gn, 256, 0, s>>>(plcp, n, threshold, cls, iota, fs.flen, fs.owner);
+        cand_class_kernel<<<gn, 256, 0, s>>>(plcp, n, threshold, cls, iota, fs.flen, res8);
         LAUNCH_CHECK();
     }
-    if ((u64)maxlcp + 1 <= threshold || threshold == 0) { c.arena.release(mark); return; }   // ArraysComp.hpp:50
+    if ((u64)maxlcp + 1 <= threshold || threshold == 0) { c.arena.release(mark); build_owner(c, n, fs); return; }   // ArraysComp.hpp:50
     select_by_class(c, cls, 1, n, iota, cvals[0], nullptr, nullptr, d_cnt);
     const size_t entries = c.read(d_cnt);
     st->entries = entries;
@@ -521,6 +529,17 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
     const bool level_log = getenv("TDC_GPU_LEVEL_LOG") != nullptr;     // debugging aid: one line per large level on stderr
     auto t_prev = std::chrono::steady_clock::now();
     for (u32 L = maxlcp; L >= threshold; --L) {
+        if (lcut && L == lcut) {
+            // ---- all remaining levels window by window inside one launch; the global state stays untouched, so a failed
+            //      pass (a window whose known range shrank into its interior) simply continues with the loop below and
+            //      tries once more further down, where the borders of the known range move half as far
+            u64 nf = 0;
+            const bool ok = factorize_window_levels(c, n, cur, prio, res8, phi, lcut, threshold, fs, &nf);
+            st->window_pass = ok ? 1 : 2;
+            st->window_lcut = lcut;
+            if (ok) { st->factors += nf; break; }
+            lcut = (lcut > 24 && threshold <= 24) ? 24 : 0;
+        }
         // ---- purge: after a run of large levels whose entries were (almost) all erased, drop the erased candidates of
         //      every level still to come (they can never come back to life: cur only decreases)
         if (dead_streak >= 4 && levels_since_purge >= 16) {
@@ -582,10 +601,10 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
             {
                 Ctx::ProfScope prof(c, K_SMALL_LEVEL, (u64)m * 16);
                 small_level_kernel<<<1, 256, 0, s>>>(cand + h_segstart[L], m0, pushed, m, L, threshold, n, cur, prio, phi, fs.flen,
-                                                     fs.owner, fs.fsrc, pool + pool_top, prio_base, d_segs, seg_cap, live, d_sc);
+                                                     res8, fs.fsrc, pool + pool_top, prio_base, d_segs, seg_cap, live, d_sc);
                 LAUNCH_CHECK();
                 if (L > SMALL_APPLY_INLINE_MAX_L) {        // long factors: the kills are spread over the whole chip
-                    apply_list_kernel<<<cdiv((size_t)m * 64, 256), 256, 0, s>>>(live, &d_sc->selected, L, n, phi, cur, fs.flen, fs.owner, fs.fsrc);
+                    apply_list_kernel<<<cdiv((size_t)m * 64, 256), 256, 0, s>>>(live, &d_sc->selected, L, n, phi, cur, fs.flen, fs.fsrc);
                     LAUNCH_CHECK();
                 }
             }
@@ -660,8 +679,8 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
         if (nl) {
             // per entry: list + state (5); per factor: Phi, flen, fsrc (12) + L kills (8 B each) + L truncations (4 B each)
             Ctx::ProfScope prof(c, K_APPLY, (u64)nl * 5 + (u64)nl * (12 + 12ull * L));
-            if (wide) apply_kernel<64><<<gl, 256, 0, s>>>(live, nl, L, n, bm, phi, cur, fs.flen, fs.owner, fs.fsrc, d_sc);
-            else      apply_kernel<1><<<gl, 256, 0, s>>>(live, nl, L, n, bm, phi, cur, fs.flen, fs.owner, fs.fsrc, d_sc);
+            if (wide) apply_kernel<64><<<gl, 256, 0, s>>>(live, nl, L, n, bm, phi, cur, fs.flen, fs.fsrc, d_sc);
+            else      apply_kernel<1><<<gl, 256, 0, s>>>(live, nl, L, n, bm, phi, cur, fs.flen, fs.fsrc, d_sc);
             LAUNCH_CHECK();
         }
         c.read_n((const u32*)d_sc, (u32*)&h_sc, 8);
@@ -678,7 +697,7 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
             {
                 Ctx::ProfScope prof(c, K_PUSH, (u64)npush * 24);
                 push_finalize_kernel<<<cdiv(npush, 256), 256, 0, s>>>(skeys[y], svals[y], npush, prio_base, prio,
-                                                                      pool + pool_top, d_segs, seg_cap, d_sc);
+                                                                      pool + pool_top, res8, d_segs, seg_cap, d_sc);
                 LAUNCH_CHECK();
             }
             c.read_n((const u32*)d_sc, (u32*)&h_sc, sizeof(LevelScalars) / sizeof(u32));   // scalars + inline segments: one sync
@@ -706,6 +725,7 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
         if (L == 0) break;
     }
     c.arena.release(mark);
+    build_owner(c, n, fs);
 }
 
 }  // namespace tdc

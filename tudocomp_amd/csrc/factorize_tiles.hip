@@ -1,0 +1,498 @@
+// factorize_tiles.hip -- the LOW levels of lcpcomp::ArraysComp (compressors/lcpcomp/compress/ArraysComp.hpp:36-117),
+// one text window per workgroup, all levels of the window inside ONE launch.
+//
+// The level loop of factorize.hip costs ~20 launches and 4-5 host round trips per level, and every level touches
+// position-indexed arrays of the whole text.  But a level L only couples text positions at distance < L, so once the
+// levels above `lcut` are done the remaining ones can be evaluated window by window from LDS:
+//
+//   * a workgroup loads the slice [w0, w1) of the global state (cur = working LCP, res = level whose list holds the
+//     entry of a position, prio = list order) and runs the levels lcut .. threshold on it: collect the level's
+//     entries, selection rounds (lexicographically-first maximal independent set among the live entries), encounter
+//     values of the others, pushes (new residence + new priority), kills and truncations -- the same steps as the
+//     global kernels, on bytes in LDS;
+//   * everything outside the window is UNKNOWN.  [fl, fr) is the range of window positions whose state is still
+//     exactly what the sequential algorithm would have: unknown factors of level L reach L-1 positions into the window
+//     (kills from the left, truncations from the right), so both borders move by L-1 per level; an entry that could
+//     be affected by something unknown (within distance < L of the border, or next to such an entry with higher
+//     priority) gets the third selection state UNCERTAIN and pushes the border past everything it could touch;
+//   * a window is VALID iff its interior [a, b) is still inside [fl, fr) after the last level; only factors that start
+//     in the interior are written.  The halo (TH positions on either side) is sized for the worst case of the borders'
+//     unconditional movement plus one exposure jump per level; if any window ends up invalid (or overflows a fixed
+//     LDS list) the caller discards the results and runs the global level loop instead -- the global state is
+//     never modified here.
+//
+// Inside a window the list order of pushed entries is a window-local rank (flag bit + counter): priorities are only
+// ever compared between entries of one list at distance < L, i.e. inside one window, and a locally pushed entry follows
+// every entry that was already in the list, exactly like the global priorities.
+// Model: tests/models/position_space.py (factorize_tile), checked against the oracle on thousands of inputs.
+#include "stages.hpp"
+#include "prim.hpp"
+#include "factorize_tiles.hpp"
+
+#include <stdlib.h>
+
+namespace tdc {
+
+namespace {
+
+constexpr int TW = 16384;            // window positions
+#ifndef TDC_WIN_TH
+#define TDC_WIN_TH 2048
+#endif
+constexpr int TH = TDC_WIN_TH;       // halo on either side
+constexpr int TI = TW - 2 * TH;      // interior positions per window
+constexpr int TPAD = 8;              // bytes of padding behind every thread's chunk of the position-indexed LDS arrays
+#ifndef TDC_WIN_TE
+#define TDC_WIN_TE 1024
+#endif
+#ifndef TDC_WIN_TP
+#define TDC_WIN_TP 512
+#endif
+constexpr int TE = TDC_WIN_TE;       // alive entries per level and window
+constexpr int TP = TDC_WIN_TP;       // pushes per level and window
+constexpr int BIG = 1 << 29;
+
+// An entry of the current level, packed so that a neighbour costs ONE LDS read:
+//   [31:0] priority   [47:32] window position   [55:48] state (bit 7: priority is window-local)   [63:56] LCP value
+enum : u32 { S_UND = 0, S_SEL = 1, S_REJ = 2, S_UNC = 3, S_STALE = 4, S_PUSH = 5, S_DROP = 6, S_MASK = 7, S_LOCAL = 0x80 };
+// (all field accesses go through the 32-bit halves: 64-bit shifts are slow on this ISA)
+__device__ __forceinline__ u32 e_hi(u64 e) { return (u32)(e >> 32); }
+__device__ __forceinline__ int e_pos(u64 e) { return (int)(e_hi(e) & 0xFFFFu); }
+__device__ __forceinline__ u32 e_state(u64 e) { return (e_hi(e) >> 16) & S_MASK; }
+__device__ __forceinline__ u32 e_stbyte(u64 e) { return (e_hi(e) >> 16) & 0xFFu; }
+__device__ __forceinline__ u32 e_val(u64 e) { return e_hi(e) >> 24; }
+// list order: window-local priorities follow global ones
+__device__ __forceinline__ bool e_before(u64 a, u64 b) {
+    const u32 fa = e_hi(a) & 0x800000u, fb = e_hi(b) & 0x800000u;
+    return (fa != fb) ? (fa < fb) : ((u32)a < (u32)b);
+}
+__device__ __forceinline__ u64 e_key(u64 e) { return ((u64)((e_hi(e) >> 23) & 1u) << 32) | (u32)e; }
+__device__ __forceinline__ void e_set_state(u64* ent, int i, u32 st) { ((volatile u8*)&ent[i])[6] = (u8)st; }
+__device__ __forceinline__ void e_set_val(u64* ent, int i, u32 v) { ((volatile u8*)&ent[i])[7] = (u8)v; }
+__device__ __forceinline__ u64 e_load(const u64* ent, int i) {
+    return *(const volatile u64*)&ent[i];
+}
+
+struct WinScalars { u32 fail; int min_margin; unsigned long long factors; unsigned long long prof[16]; };
+
+// optional phase timing (compile with -DTDC_WIN_PROF): thread 0 of every workgroup sums s_memrealtime deltas per phase
+#ifdef TDC_WIN_PROF
+#define WPROF_DECL unsigned long long wp_t = __builtin_readcyclecounter(); unsigned long long wp_acc[12] = {0,0,0,0,0,0,0,0,0,0,0,0};
+#define WPROF(i) do { const unsigned long long wp_n = __builtin_readcyclecounter(); wp_acc[i] += wp_n - wp_t; wp_t = wp_n; } while (0)
+#define WPROF_CNT(i, v) do { wp_acc[i] += (v); } while (0)
+#define WPROF_FLUSH do { if (tid == 0) for (int wi = 0; wi < 12; ++wi) atomicAdd(&sc->prof[wi], wp_acc[wi]); } while (0)
+#else
+#define WPROF_DECL
+#define WPROF(i) do {} while (0)
+#define WPROF_CNT(i, v) do {} while (0)
+#define WPROF_FLUSH do {} while (0)
+#endif
+
+// Workgroup barrier that only waits for this wave's LDS traffic.  __syncthreads() also drains the vector-memory counter,
+// i.e. every barrier behind a global store would cost a round trip to L2.  Global data that IS handed between threads
+// (the window-local priorities) is ordered by the one full barrier per level.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int TT>      // threads per workgroup (256 or 512)
+__global__ __launch_bounds__(TT) void window_levels_kernel(const u32* __restrict__ cur_g, const u32* __restrict__ prio_g,
+                                                            const u8* __restrict__ res_g, const u32* __restrict__ phi, size_t n,
+                                                            u32 lcut, u32 threshold, u32 ntiles, u32* __restrict__ lprio_all,
+                                                            u32* __restrict__ flen, u32* __restrict__ fsrc, WinScalars* __restrict__ sc) {
+    // position q lives at byte PA(q): every 64-byte chunk (one thread's share of the dense passes) is followed by 8 bytes
+    // of padding, so the 64 lanes' 8-byte reads of "their" chunks hit 64 different banks (stride 72 B = 18 words)
+    constexpr int TCH = TW / TT;         // consecutive window positions per thread in the dense passes (64 or 32)
+    constexpr int TCS = (TCH == 64) ? 6 : 5;
+    constexpr int NWV = TT / 64;
+    static_assert((1 << TCS) == TCH, "chunk size");
+    __shared__ __attribute__((aligned(16))) u8 cur8[TT * (TCH + TPAD)];
+    __shared__ __attribute__((aligned(16))) u8 res8[TT * (TCH + TPAD)];    // [5:0] list level, bit 6: factor start (then [5:0] = length), bit 7: priority is window-local
+#define PA(q) ((q) + (((q) >> TCS) * TPAD))
+    __shared__ u64 ent[TE];
+    __shared__ u64 pkey[TP];
+    __shared__ unsigned short pidx[TP];
+    __shared__ u32 wtot[NWV];
+    __shared__ int s_und[3];
+    __shared__ int s_npush, s_tl, s_tr;
+    __shared__ u64 s_lvlmask;             // bit L: some window position resides in list L
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    u32* lprio = lprio_all + (size_t)blockIdx.x * TW;
+    WPROF_DECL
+
+    for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const size_t a = (size_t)tile * TI;
+        const size_t b = (a + TI < n) ? a + TI : n;
+        const size_t w0 = (a >= (size_t)TH) ? a - TH : 0;
+        const size_t w1 = (b + TH < n) ? b + TH : n;
+        const int wl = (int)(w1 - w0);
+        const int ia = (int)(a - w0), ib = (int)(b - w0);
+        const int mid = wl / 2;
+        __syncthreads();                                    // previous window's LDS is no longer read
+        WPROF(0);
+        if (tid == 0) { s_und[0] = 0; s_und[1] = 0; s_und[2] = 0; s_npush = 0; s_tl = -BIG; s_tr = BIG; s_lvlmask = 0; }
+        __syncthreads();
+        // ---- load the window: cur and residence as bytes (cur <= lcut everywhere once the levels above are done) ----
+        u64 mymask = 0;
+        for (int i = tid * 4; i < TW; i += TT * 4) {
+            u32 cw = 0, rw = 0;
+            const size_t gp = w0 + i;
+            if (gp + 4 <= w1) {
+                const uint4 cv = *(const uint4*)(cur_g + gp);                  // w0 and i are multiples of 4
+                const u32 rv4 = *(const u32*)(res_g + gp);
+                const u32 c4[4] = { cv.x, cv.y, cv.z, cv.w };
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    u32 rv = (rv4 >> (8 * k)) & 0xFFu;
+                    if (rv > lcut) rv = 0;                  // entries of higher lists are gone (selected, dropped or pushed down)
+                    cw |= (c4[k] > 255u ? 255u : c4[k]) << (8 * k);
+                    rw |= rv << (8 * k);
+                    mymask |= 1ull << rv;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (gp + k < w1) {
+                        const u32 cv = cur_g[gp + k];
+                        u32 rv = res_g[gp + k];
+                        if (rv > lcut) rv = 0;
+                        cw |= (cv > 255u ? 255u : cv) << (8 * k);
+                        rw |= rv << (8 * k);
+                        mymask |= 1ull << rv;
+                    }
+                }
+            }
+            *(u32*)&cur8[PA(i)] = cw;
+            *(u32*)&res8[PA(i)] = rw;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) mymask |= __shfl_xor(mymask, d, 64);
+        if (lane == 0) atomicOr((unsigned long long*)&s_lvlmask, (unsigned long long)mymask);
+        int fl = (w0 > 0) ? 0 : -BIG;                       // known range [fl, fr) in window offsets
+        int fr = (w1 < n) ? wl : BIG;
+        u32 local_base = 0;
+        u32 nsel_interior = 0;
+        bool failed = false;
+        __syncthreads();
+        WPROF(1);
+
+        for (u32 L = lcut; L >= threshold && !failed; --L) {
+            const int iL = (int)L;
+            if (((*(volatile u64*)&s_lvlmask >> L) & 1ull) == 0) { fl += iL - 1; fr -= iL - 1; continue; }   // nothing resides in list L
+            const int lo = fl > 0 ? fl : 0, hi = fr < wl ? fr : wl;
+            // ---- 1. collect the alive entries of list L in position order --------------------------------------
+            const int base = tid * TCH;
+            const int pbase = tid * (TCH + TPAD);
+            u64 amask = 0;
+            if (base < hi && base + TCH > lo) {
+                const u64 pat = (u64)L * 0x0101010101010101ull;
+                const u64 lo7 = 0x7F7F7F7F7F7F7F7Full;
+                u64 rws[TCH / 8], cws[TCH / 8];
+#pragma unroll
+                for (int k = 0; k < TCH / 8; ++k) { rws[k] = *(const u64*)&res8[pbase + 8 * k]; cws[k] = *(const u64*)&cur8[pbase + 8 * k]; }
+#pragma unroll
+                for (int k = 0; k < TCH / 8; ++k) {
+                    const u64 x = (rws[k] & lo7) ^ pat;
+                    u64 hit = ~(((x & lo7) + lo7) | x | lo7);          // 0x80 in every byte of x that is zero (exact)
+                    while (hit) {
+                        const int bb = __builtin_ctzll(hit) >> 3;
+                        hit &= hit - 1;
+                        const int pos = base + 8 * k + bb;
+                        if (pos < lo || pos >= hi) continue;                              // unknown: ignored from now on
+                        if (((u32)(cws[k] >> (8 * bb)) & 0xFFu) >= threshold) amask |= 1ull << (8 * k + bb);
+                        else res8[pbase + 8 * k + bb] = 0;                                // erased entry (:86)
+                    }
+                }
+            }
+            // the first priorities are requested before the barrier of the scan, so their latency overlaps it
+            u32 pre[2] = { 0, 0 };
+            {
+                u64 mm = amask;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    if (mm) {
+                        const int pos = base + __builtin_ctzll(mm);
+                        mm &= mm - 1;
+                        pre[q] = prio_g[w0 + pos];          // (a window-local priority is read behind the full barrier below)
+                    }
+                }
+            }
+            WPROF(2);
+            const u32 cnt = (u32)__popcll(amask);
+            const u32 inc = wave_inclusive_sum(cnt);
+            if (lane == 63) wtot[wv] = inc;
+            __syncthreads();                                // the level's one FULL barrier: lprio stores of earlier levels are complete
+            u32 off = inc - cnt, total = 0;
+#pragma unroll
+            for (int k = 0; k < NWV; ++k) { const u32 t = wtot[k]; if (k < wv) off += t; total += t; }
+            if (total > (u32)TE) { failed = true; break; }
+            const int m = (int)total;
+            int my_und = 0;
+            for (int q = 0; amask; ++q) {
+                const int bit = __builtin_ctzll(amask);
+                amask &= amask - 1;
+                const int pos = base + bit;
+                const u32 cv = cur8[PA(pos)];
+                const u32 local = res8[PA(pos)] & S_LOCAL;
+                const u32 pr = local ? lprio[pos] : ((q < 2) ? pre[q] : prio_g[w0 + pos]);
+                const u32 st = (cv == L ? S_UND : S_STALE) | local;
+                ent[off] = ((u64)((cv << 24) | (st << 16) | (u32)pos) << 32) | pr;
+                if (cv == L) ++my_und;
+                ++off;
+            }
+            my_und = wave_reduce_sum(my_und);
+            if (lane == 0 && my_und) atomicAdd(&s_und[0], my_und);
+            lds_barrier();
+            WPROF(3);
+            WPROF_CNT(8, 1); WPROF_CNT(9, m);
+            if (m == 0) { fl += iL - 1; fr -= iL - 1; continue; }
+
+            // ---- 2. selection rounds (in place: a state only ever moves away from UNDECIDED) ---------------------
+            // rotating counters: a round reads s_und[r], counts the entries it leaves undecided in s_und[r+1], clears s_und[r+2]
+            int r = 0;
+            for (int guard = 0; guard <= m; ++guard) {
+                const int und = *(volatile int*)&s_und[r];
+                if (und == 0) break;
+                const int rn = (r + 1) % 3, rc = (r + 2) % 3;
+                if (tid == 0) s_und[rc] = 0;
+                for (int i = lane * NWV + wv; i < m; i += TT) {                  // entries are dealt round-robin to the waves
+                    const u64 e = e_load(ent, i);
+                    u64 fL = (i > 0) ? e_load(ent, i - 1) : 0ull;               // both direct neighbours are requested up front
+                    u64 fR = (i + 1 < m) ? e_load(ent, i + 1) : 0ull;
+                    if (e_state(e) != S_UND) continue;
+                    const int p = e_pos(e);
+                    bool hit = false, blocked = false, unc = false;
+                    for (int j = i - 1; j >= 0; --j) {
+                        const u64 f = (j == i - 1) ? fL : e_load(ent, j);
+                        if (p - e_pos(f) >= iL) break;
+                        const u32 s = e_state(f);
+                        if (s == S_SEL) { hit = true; break; }
+                        if ((s == S_UND || s == S_UNC) && e_before(f, e)) { if (s == S_UND) blocked = true; else unc = true; }
+                    }
+                    for (int j = i + 1; j < m && !hit; ++j) {
+                        const u64 f = (j == i + 1) ? fR : e_load(ent, j);
+                        if (e_pos(f) - p >= iL) break;
+                        const u32 s = e_state(f);
+                        if (s == S_SEL) { hit = true; break; }
+                        if ((s == S_UND || s == S_UNC) && e_before(f, e)) { if (s == S_UND) blocked = true; else unc = true; }
+                    }
+                    const u32 keep = e_stbyte(e) & S_LOCAL;
+                    if (hit) e_set_state(ent, i, S_REJ | keep);
+                    else if (!blocked) {
+                        const bool exposed = (p <= fl + iL - 2) || (p + iL - 1 >= fr);
+                        e_set_state(ent, i, ((unc || exposed) ? S_UNC : S_SEL) | keep);
+                    } else atomicAdd(&s_und[rn], 1);
+                }
+                lds_barrier();
+                r = rn;
+                WPROF_CNT(10, 1);
+            }
+            WPROF(4);
+            if (*(volatile int*)&s_und[r] != 0) { failed = true; break; }     // cannot happen (the best undecided entry always decides)
+
+            // ---- 3. encounter values of the stale and the rejected entries, taint of the uncertain ones; the selected
+            //         entries truncate the positions in front of them (their ranges are disjoint) and are written out ------
+            for (int i0 = 0; i0 < m; i0 += TT) {
+                const int i = i0 + lane * NWV + wv;
+                const bool have = i < m;
+                const u64 e = have ? e_load(ent, i) : 0ull;
+                const u64 fL = (have && i > 0) ? e_load(ent, i - 1) : 0ull;
+                const u64 fR = (have && i + 1 < m) ? e_load(ent, i + 1) : 0ull;
+                const u32 s = have ? e_state(e) : (u32)S_DROP;
+                const int p = e_pos(e);
+                // selected entries: the lanes of the wave share the L positions in front of each of them; four entries per
+                // batch (their ranges are disjoint), so the four reads are in flight together
+                u64 selm = __ballot(s == S_SEL);
+                while (selm) {
+                    int qs[4];
+                    u32 cv[4];
+#pragma unroll
+                    for (int b4 = 0; b4 < 4; ++b4) {
+                        qs[b4] = -1;
+                        if (selm) {
+                            const int src = __builtin_ctzll(selm);
+                            selm &= selm - 1;
+                            const int q = __shfl(p, src, 64) - 1 - lane;
+                            if (lane < iL && q >= 0) qs[b4] = PA(q);
+                        }
+                    }
+#pragma unroll
+                    for (int b4 = 0; b4 < 4; ++b4) cv[b4] = (qs[b4] >= 0) ? cur8[qs[b4]] : 0u;
+#pragma unroll
+                    for (int b4 = 0; b4 < 4; ++b4) if (qs[b4] >= 0 && cv[b4] > (u32)lane + 1) cur8[qs[b4]] = (u8)(lane + 1);
+                }
+                if (s == S_SEL) continue;                   // (marked as a factor start in step 4, written out after the last level)
+                if (s == S_UNC) {                           // its factor may or may not exist: everything it could touch is unknown
+                    if (p < mid) atomicMax(&s_tl, p + iL); else atomicMin(&s_tr, p - (iL - 1));
+                    continue;
+                }
+                if (s != S_STALE && s != S_REJ) continue;
+                u32 v = e_val(e);
+                bool uncertain = (p <= fl + iL - 2) || (p + iL - 1 >= fr);
+                for (int j = i - 1; j >= 0; --j) {
+                    const u64 f = (j == i - 1) ? fL : e_load(ent, j);
+                    if (p - e_pos(f) >= iL) break;
+                    const u32 t = e_state(f);
+                    if ((t == S_SEL || t == S_UNC) && e_before(f, e)) { if (t == S_SEL) v = 0; else uncertain = true; }   // covered (:99-101)
+                }
+                for (int j = i + 1; j < m; ++j) {
+                    const u64 f = (j == i + 1) ? fR : e_load(ent, j);
+                    const int d = e_pos(f) - p;
+                    if (d >= iL) break;
+                    const u32 t = e_state(f);
+                    if ((t == S_SEL || t == S_UNC) && e_before(f, e)) { if (t == S_SEL) { if ((u32)d < v) v = (u32)d; } else uncertain = true; }   // truncated (:103-109)
+                }
+                if (uncertain) {
+                    if (p < mid) atomicMax(&s_tl, p + 1); else atomicMin(&s_tr, p);
+                    e_set_state(ent, i, S_DROP);
+                } else if (v >= threshold) {
+                    const int k = atomicAdd(&s_npush, 1);
+                    if (k < TP) { pkey[k] = e_key(e); pidx[k] = (unsigned short)i; }
+                    e_set_val(ent, i, v);
+                    e_set_state(ent, i, S_PUSH);
+                    atomicOr((unsigned long long*)&s_lvlmask, 1ull << v);
+                } else e_set_state(ent, i, S_DROP);
+            }
+            lds_barrier();
+            WPROF(5);
+            const int npush = s_npush;
+            if (npush > TP) { failed = true; break; }
+            // ---- 4. kills; new residence / priority of the pushed entries, every other entry leaves the lists ------
+            if (tid == 0) { s_und[0] = 0; s_und[1] = 0; s_und[2] = 0; }
+            for (int i0 = 0; i0 < m; i0 += TT) {
+                const int i = i0 + lane * NWV + wv;
+                const bool have = i < m;
+                const u64 e = have ? e_load(ent, i) : 0ull;
+                const u32 s = have ? e_state(e) : (u32)S_PUSH;
+                const int p = e_pos(e);
+                u64 selm = __ballot(s == S_SEL);
+                while (selm) {                              // kills (:99-101), one lane per covered position
+                    const int src = __builtin_ctzll(selm);
+                    selm &= selm - 1;
+                    const int q = __shfl(p, src, 64) + lane;
+                    if (lane < iL && q < wl) cur8[PA(q)] = 0;
+                }
+                if (s != S_PUSH) res8[PA(p)] = (s == S_SEL) ? (u8)(0x40u | L) : (u8)0;
+            }
+            if (npush) {
+                // rank by old priority: G lanes share one pushed entry
+                int G = 1;
+                while (G < 64 && npush * (G * 2) <= TT) G *= 2;
+                const int per = TT / G;
+                for (int k0 = 0; k0 < npush; k0 += per) {
+                    const int k = k0 + tid / G;
+                    const int sub = tid % G;
+                    const bool act = k < npush;
+                    const u64 key = act ? pkey[k] : 0ull;
+                    u32 rank = 0;
+                    if (act) {
+#pragma unroll 8
+                        for (int kk = sub; kk < npush; kk += G) rank += (pkey[kk] < key) ? 1u : 0u;
+                    }
+                    for (int d = G >> 1; d >= 1; d >>= 1) rank += __shfl_xor(rank, d, 64);
+                    if (act && sub == 0) {
+                        const int i = pidx[k];
+                        const u64 e = e_load(ent, i);
+                        const int p = e_pos(e);
+                        lprio[p] = local_base + rank;
+                        res8[PA(p)] = (u8)(e_val(e) | S_LOCAL);
+                    }
+                }
+            }
+            local_base += (u32)npush;
+            int nfl = fl + (iL - 1), nfr = fr - (iL - 1);
+            const int tl = s_tl, tr = s_tr;
+            if (tl > nfl) nfl = tl;
+            if (tr < nfr) nfr = tr;
+            fl = nfl; fr = nfr;
+            lds_barrier();
+            WPROF(6);
+            WPROF_CNT(11, npush);
+            if (tid == 0) { s_npush = 0; s_tl = -BIG; s_tr = BIG; }
+        }
+        if (tid == 0 && !failed) {                          // smallest distance left between a known-range border and the interior
+            int mg = BIG;
+            if (fl > -BIG / 2) mg = ia - fl;
+            if (fr < BIG / 2 && fr - ib < mg) mg = fr - ib;
+            atomicMin(&sc->min_margin, mg);
+        }
+        if (failed || fl > ia || fr < ib) { if (tid == 0) atomicOr(&sc->fail, 1u); }
+        else {
+            // ---- factor starts of the interior: (pos, Phi[pos], L)  (ArraysComp.hpp:91-96) ---------------------------
+            const int base = tid * TCH, pbase = tid * (TCH + TPAD);
+            if (base < ib && base + TCH > ia) {
+#pragma unroll
+                for (int k = 0; k < TCH; k += 8) {
+                    u64 w = (*(const u64*)&res8[pbase + k]) & 0x4040404040404040ull;
+                    const u64 rw = *(const u64*)&res8[pbase + k];
+                    while (w) {
+                        const int bb = __builtin_ctzll(w) >> 3;
+                        w &= w - 1;
+                        const int pos = base + k + bb;
+                        if (pos < ia || pos >= ib) continue;
+                        const size_t gp = w0 + pos;
+                        flen[gp] = (u32)(rw >> (8 * bb)) & 0x3Fu;
+                        fsrc[gp] = phi[gp];
+                        ++nsel_interior;
+                    }
+                }
+            }
+        }
+        nsel_interior = wave_reduce_sum(nsel_interior);
+        if (lane == 0 && nsel_interior) atomicAdd(&sc->factors, (unsigned long long)nsel_interior);
+        WPROF(7);
+    }
+    WPROF_FLUSH;
+}
+
+// a failed pass leaves factors of the low levels behind: remove them (factors of the global levels are longer than lcut)
+__global__ void window_cleanup_kernel(u32* __restrict__ flen, size_t n, u32 lcut) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n && flen[p] <= lcut) flen[p] = 0;
+}
+
+}  // namespace
+
+u32 window_levels_max_lcut() { return 63; }
+size_t window_levels_min_text() { return (size_t)4 * TW; }
+
+bool factorize_window_levels(Ctx& c, size_t n, const u32* cur, const u32* prio, const u8* res8, const u32* phi, u32 lcut, u32 threshold,
+                             FactorSpace fs, u64* nfactors) {
+    *nfactors = 0;
+    if (lcut < threshold) return true;
+    hipStream_t s = c.stream;
+    const size_t mark = c.arena.mark();
+    const u32 ntiles = cdiv(n, TI);
+    u32 grid = ntiles < 1536u ? ntiles : 1536u;
+    u32* lprio = c.arena.get<u32>((size_t)grid * TW);
+    WinScalars* d_sc = (WinScalars*)c.arena.alloc(sizeof(WinScalars));
+    HIP_TRY(hipMemsetAsync(d_sc, 0, sizeof(WinScalars), s));
+    { const int big = BIG; HIP_TRY(hipMemcpyAsync(&d_sc->min_margin, &big, sizeof(int), hipMemcpyHostToDevice, s)); }
+    {
+        // per window position: cur (4) + residence (1); per text position: ~0.3 priority reads and the factor output
+        Ctx::ProfScope prof(c, K_WINDOW_LEVELS, (u64)((double)n * TW / TI * 5) + (u64)n * 2);
+        static const unsigned dyn = getenv("TDC_GPU_WINDOW_DYNLDS") ? (unsigned)atoi(getenv("TDC_GPU_WINDOW_DYNLDS")) : 0u;   // occupancy experiments
+        if (c.window_threads == 512)
+            window_levels_kernel<512><<<grid, 512, dyn, s>>>(cur, prio, res8, phi, n, lcut, threshold, ntiles, lprio, fs.flen, fs.fsrc, d_sc);
+        else
+            window_levels_kernel<256><<<grid, 256, dyn, s>>>(cur, prio, res8, phi, n, lcut, threshold, ntiles, lprio, fs.flen, fs.fsrc, d_sc);
+        LAUNCH_CHECK();
+    }
+    const WinScalars h = c.read(d_sc);
+    c.arena.release(mark);
+#ifdef TDC_WIN_PROF
+    {
+        static const char* nm[12] = { "wait_prev", "load", "dense", "scan+write", "mis", "resolve", "apply", "tail", "levels", "entries", "rounds", "pushes" };
+        for (int i = 0; i < 12; ++i) fprintf(stderr, "winprof %-10s %llu\n", nm[i], h.prof[i]);
+        fprintf(stderr, "winprof windows %u grid %u min_margin %d fail %u\n", ntiles, grid, h.min_margin, h.fail);
+    }
+#endif
+    if (h.fail) {
+        window_cleanup_kernel<<<cdiv(n, 256), 256, 0, s>>>(fs.flen, n, lcut);
+        LAUNCH_CHECK();
+        return false;
+    }
+    *nfactors = h.factors;
+    return true;
+}
+
+}  // namespace tdc

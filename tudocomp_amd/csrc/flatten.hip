@@ -54,6 +54,49 @@ size_t extract_factors(Ctx& c, size_t n, FactorSpace fs, u32* pos, u32* src, u32
     return z;
 }
 
+// ---- owner[] from the factor starts ------------------------------------------------------------------------------
+__global__ void owner_flag_kernel(const u32* __restrict__ flen, size_t n, u32* __restrict__ flag, u32* __restrict__ owner) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    flag[p] = flen[p] != 0 ? 1u : 0u;
+    owner[p] = NONE32;
+}
+__global__ void owner_starts_kernel(const u32* __restrict__ flen, const u32* __restrict__ offs, size_t n, u32* __restrict__ pos) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n && flen[p] != 0) pos[offs[p]] = (u32)p;
+}
+template <int G>      // G lanes per factor
+__global__ void owner_fill_kernel(const u32* __restrict__ pos, size_t z, const u32* __restrict__ flen, size_t n, u32* __restrict__ owner) {
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const u32 sub = threadIdx.x % G;
+    if (i >= z) return;
+    const u32 p = pos[i], l = flen[p];
+    for (u32 j = sub; j < l && (size_t)p + j < n; j += G) owner[p + j] = p;
+}
+
+void build_owner(Ctx& c, size_t n, FactorSpace fs) {
+    if (n == 0) return;
+    const size_t mark = c.arena.mark();
+    u32* offs = c.arena.get<u32>(n);
+    u32* pos = c.arena.get<u32>(n);
+    u32* d_total = c.arena.get<u32>(1);
+    const unsigned gn = cdiv(n, 256);
+    Ctx::ProfScope prof(c, K_EXTRACT, (u64)n * 24);
+    owner_flag_kernel<<<gn, 256, 0, c.stream>>>(fs.flen, n, offs, fs.owner);
+    LAUNCH_CHECK();
+    exclusive_sum_u32(c, offs, offs, n, d_total);
+    owner_starts_kernel<<<gn, 256, 0, c.stream>>>(fs.flen, offs, n, pos);
+    LAUNCH_CHECK();
+    const size_t z = c.read(d_total);
+    if (z) {
+        // factors are disjoint and in position order: consecutive lanes fill consecutive ranges
+        if (z * 64 > n) owner_fill_kernel<8><<<cdiv(z * 8, 256), 256, 0, c.stream>>>(pos, z, fs.flen, n, fs.owner);
+        else            owner_fill_kernel<64><<<cdiv(z * 64, 256), 256, 0, c.stream>>>(pos, z, fs.flen, n, fs.owner);
+        LAUNCH_CHECK();
+    }
+    c.arena.release(mark);
+}
+
 __global__ void fspace_clear_kernel(size_t n, u32* __restrict__ flen, u32* __restrict__ owner) {
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;

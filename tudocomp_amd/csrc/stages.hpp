@@ -36,13 +36,18 @@ struct FactorSpace {
     u32* fsrc = nullptr;
 };
 
-struct FactorizeStats { u64 factors = 0; u32 maxlcp = 0; u32 levels = 0; u32 rounds = 0; u64 pushes = 0; u64 entries = 0; u32 small_levels = 0; u32 purges = 0; };
+struct FactorizeStats { u64 factors = 0; u32 maxlcp = 0; u32 levels = 0; u32 rounds = 0; u64 pushes = 0; u64 entries = 0; u32 small_levels = 0; u32 purges = 0;
+                        u32 window_pass = 0; /* 0 not used, 1 low levels done window-local, 2 window pass failed -> global loop */
+                        u32 window_lcut = 0; /* highest level of the last window pass */ };
 
 // a8: compressors/lcpcomp/compress/ArraysComp.hpp:36-117 in position space.
 // Inputs: isa, phi, plcp.  isa and plcp are consumed: they become the working priority / LCP arrays.
 // Outputs: fs.flen / fs.owner filled, fs.fsrc[p] = phi[p] at factor starts.
 void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi, u32* plcp, u32 maxlcp,
                       u32 threshold, FactorSpace fs, FactorizeStats* st);
+
+// owner[] from the factor starts (flen[p] != 0 exactly at factor starts): owner[q] = start of the factor covering q, else NONE32
+void build_owner(Ctx& c, size_t n, FactorSpace fs);
 
 struct FlattenStats { u64 num_flattened = 0; u64 max_depth_lb = 0; u32 rounds = 0; };
 // a10: compressors/lzss/LZSSFactors.hpp:79-132 ; rewrites fs.fsrc in place.
