@@ -142,6 +142,7 @@ void run_factorize(Ctx& c, size_t n, DevArrays& A, u32 threshold, int flatten, t
     A.fs.flen = c.arena.get<u32>(n);
     A.fs.owner = c.arena.get<u32>(n);
     A.fs.fsrc = c.arena.get<u32>(n);
+    A.fs.fpos = c.arena.get<u32>(n);
     FactorizeStats fz;
     FlattenStats fl;
     const int e0 = ev ? ev->tick() : 0;

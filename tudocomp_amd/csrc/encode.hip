@@ -57,8 +57,9 @@ __global__ __launch_bounds__(256) void gaps_kernel(const u32* __restrict__ fpos,
     u32 gmax = 0, lmin = 0xFFFFFFFFu, lmax = 0;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < z; i += stride) {
-        const u32 p = fpos[i], l = flen_list[i];
-        const u32 prev_end = (i == 0) ? 0u : fpos[i - 1] + flen_list[i - 1];
+        // flen_list == nullptr: the lengths are read at the factor starts (run lengths are written at run starts, never there)
+        const u32 p = fpos[i], l = flen_list ? flen_list[i] : flen[p];
+        const u32 prev_end = (i == 0) ? 0u : fpos[i - 1] + (flen_list ? flen_list[i - 1] : flen[fpos[i - 1]]);
         const u32 gap = p - prev_end;
         if (gap) flen[prev_end] = gap;
         gmax = max(gmax, gap);
@@ -254,9 +255,9 @@ size_t encode_stream(Ctx& c, const u8* text, size_t n, FactorSpace fs, int coder
     const size_t mark = c.arena.mark();
 
     // ---- factor list (position order), gaps, min/max lengths ------------------------------------------------
-    u32* fpos = c.arena.get<u32>(n);
-    u32* flist = c.arena.get<u32>(n);
-    const size_t z = extract_factors(c, n, fs, fpos, nullptr, flist, n);
+    u32* fpos = fs.have_list ? fs.fpos : c.arena.get<u32>(n);
+    u32* flist = fs.have_list ? nullptr : c.arena.get<u32>(n);
+    const size_t z = fs.have_list ? fs.nfact : extract_factors(c, n, fs, fpos, nullptr, flist, n);
     EncScalars* d_sc = (EncScalars*)c.arena.alloc(sizeof(EncScalars));
     EncScalars h_sc = { 0xFFFFFFFFu, 0u, 0u, 0u };          // LZSSFactors.hpp:33-38 : INDEX_MAX / 0
     HIP_TRY(hipMemcpyAsync(d_sc, &h_sc, sizeof(h_sc), hipMemcpyHostToDevice, s));

@@ -66,15 +66,38 @@ __device__ __forceinline__ u64 bm_load(const u64* p) { return __hip_atomic_load(
 __device__ __forceinline__ u32 bm_state(const u64* __restrict__ bm, u32 p) { return (u32)(bm[p >> 5] >> (2 * (p & 31))) & 3u; }
 
 // ---- candidates ("Fill candidates", :54-66) ----------------------------------------------------------------
-__global__ void cand_class_kernel(const u32* __restrict__ plcp, size_t n, u32 threshold, u8* __restrict__ cls,
-                                  u32* __restrict__ pos, u32* __restrict__ flen, u8* __restrict__ res8) {
+// cls[p] = 1 for the candidates whose level is above `lo` (the lists of the levels <= lo are only materialised if the
+// window pass fails); *d_entries counts all candidates ("entries" of the reference's log)
+__global__ __launch_bounds__(256) void cand_class_kernel(const u32* __restrict__ plcp, size_t n, u32 threshold, u32 lo, u8* __restrict__ cls,
+                                                          u32* __restrict__ flen, u8* __restrict__ res8, u32* __restrict__ d_entries) {
+    __shared__ u32 sm[4];
+    u32 cnt = 0;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
+        const u32 v = plcp[p];
+        const u32 is_cand = (v >= threshold) ? 1u : 0u;   // PLCP[n-1] = 0, so the sentinel (SA index 0) is never a candidate
+        cls[p] = (is_cand && v > lo) ? 1 : 0;
+        flen[p] = 0;
+        if (res8) res8[p] = is_cand ? (u8)(v > 255u ? 255u : v) : (u8)0;   // list that holds the entry of p (saturated)
+        cnt += is_cand;
+    }
+    cnt = wave_reduce_sum(cnt);
+    if (lane_id() == 0) sm[wave_id()] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) { const u32 t = sm[0] + sm[1] + sm[2] + sm[3]; if (t) atomicAdd(d_entries, t); }   // one atomic per workgroup (capped grid)
+}
+// after a failed window pass: the original candidates of the levels threshold .. lcut that are still in their lists
+// (pushed entries carry priorities >= n and are tracked by the push pool)
+__global__ void cand_rebuild_class_kernel(const u8* __restrict__ res8, const u32* __restrict__ prio, size_t n, u32 threshold, u32 lcut,
+                                          u8* __restrict__ cls) {
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
-    const u32 v = plcp[p];
-    cls[p] = (v >= threshold) ? 1 : 0;   // PLCP[n-1] = 0, so the sentinel (SA index 0) is never a candidate
-    pos[p] = (u32)p;
-    flen[p] = 0;
-    if (res8) res8[p] = (v >= threshold) ? (u8)(v > 255u ? 255u : v) : (u8)0;   // list that holds the entry of p (saturated)
+    const u32 r = res8[p];
+    cls[p] = (r >= threshold && r <= lcut && prio[p] < (u32)n) ? 1 : 0;
+}
+__global__ void gather_u8_kernel(const u32* __restrict__ idx, size_t m, const u8* __restrict__ src, u32* __restrict__ dst) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) dst[i] = src[idx[i]];
 }
 __global__ void gather_kernel(const u32* __restrict__ idx, size_t m, const u32* __restrict__ src, u32* __restrict__ dst) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -434,7 +457,7 @@ __global__ __launch_bounds__(256) void apply_kernel(const u32* __restrict__ live
 }
 
 void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi, u32* plcp, u32 maxlcp, u32 threshold,
-                      FactorSpace fs, FactorizeStats* st) {
+                      FactorSpace& fs, FactorizeStats* st) {
     (void)sa;    // the candidate order of the reference (ascending SA index) is carried by prio[] = ISA
     FactorizeStats local;
     if (!st) st = &local;
@@ -460,35 +483,43 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
     u32* ckeys[2] = { c.arena.get<u32>(n), c.arena.get<u32>(n) };
     u32* cvals[2] = { c.arena.get<u32>(n), c.arena.get<u32>(n) };
     u32* d_cnt = c.arena.get<u32>(4);
-    u32* iota = ckeys[1];                       // scratch: position of every text position
+    HIP_TRY(hipMemsetAsync(d_cnt, 0, 4 * sizeof(u32), s));
     {
-        Ctx::ProfScope prof(c, K_CAND, (u64)n * 17);
-        cand_class_kernel<<<gn, 256, 0, s>>>(plcp, n, threshold, cls, iota, fs.flen, res8);
+        Ctx::ProfScope prof(c, K_CAND, (u64)n * (lcut ? 10 : 9));
+        cand_class_kernel<<<(gn < 8192u ? gn : 8192u), 256, 0, s>>>(plcp, n, threshold, lcut, cls, fs.flen, res8, d_cnt + 1);
         LAUNCH_CHECK();
     }
     if ((u64)maxlcp + 1 <= threshold || threshold == 0) { c.arena.release(mark); build_owner(c, n, fs); return; }   // ArraysComp.hpp:50
-    select_by_class(c, cls, 1, n, iota, cvals[0], nullptr, nullptr, d_cnt);
-    const size_t entries = c.read(d_cnt);
-    st->entries = entries;
-    if (entries) {
-        Ctx::ProfScope prof(c, K_CAND, (u64)entries * 12);
-        gather_kernel<<<cdiv(entries, 256), 256, 0, s>>>(cvals[0], entries, plcp, ckeys[0]);
-        LAUNCH_CHECK();
-    }
-    int x = radix_sort_pairs_u32(c, ckeys, cvals, entries, 0, (int)bits_for(maxlcp));
-    const u32* cand = cvals[x];
     const size_t nlev = (size_t)maxlcp + 2;
     u32* d_segstart = c.arena.get<u32>(nlev);
     u32* d_segend = c.arena.get<u32>(nlev);
-    HIP_TRY(hipMemsetAsync(d_segstart, 0, nlev * sizeof(u32), s));
-    HIP_TRY(hipMemsetAsync(d_segend, 0, nlev * sizeof(u32), s));
-    if (entries) {
-        seg_bounds_kernel<<<cdiv(entries, 256), 256, 0, s>>>(ckeys[x], entries, d_segstart, d_segend);
-        LAUNCH_CHECK();
-    }
     std::vector<u32> h_segstart(nlev), h_segend(nlev);
-    c.read_n(d_segstart, h_segstart.data(), nlev);
-    c.read_n(d_segend, h_segend.data(), nlev);
+    int x = 0;
+    size_t cand_count = 0;
+    // candidate lists: the class-1 positions in position order, stably sorted by their level (key_plcp: level = PLCP value,
+    // else the residence byte)
+    auto build_lists = [&](bool key_plcp, u32 max_level) {
+        select_by_class(c, cls, 1, n, nullptr, cvals[0], nullptr, nullptr, d_cnt);
+        cand_count = c.read(d_cnt);
+        if (cand_count) {
+            Ctx::ProfScope prof(c, K_CAND, (u64)cand_count * 12);
+            if (key_plcp) gather_kernel<<<cdiv(cand_count, 256), 256, 0, s>>>(cvals[0], cand_count, plcp, ckeys[0]);
+            else          gather_u8_kernel<<<cdiv(cand_count, 256), 256, 0, s>>>(cvals[0], cand_count, res8, ckeys[0]);
+            LAUNCH_CHECK();
+        }
+        x = radix_sort_pairs_u32(c, ckeys, cvals, cand_count, 0, (int)bits_for(max_level));
+        HIP_TRY(hipMemsetAsync(d_segstart, 0, nlev * sizeof(u32), s));
+        HIP_TRY(hipMemsetAsync(d_segend, 0, nlev * sizeof(u32), s));
+        if (cand_count) {
+            seg_bounds_kernel<<<cdiv(cand_count, 256), 256, 0, s>>>(ckeys[x], cand_count, d_segstart, d_segend);
+            LAUNCH_CHECK();
+        }
+        c.read_n(d_segstart, h_segstart.data(), nlev);
+        c.read_n(d_segend, h_segend.data(), nlev);
+    };
+    build_lists(true, maxlcp);
+    st->entries = c.read(d_cnt + 1);
+    const u32* cand = cvals[x];
 
     // ---- per-level state ------------------------------------------------------------------------------------
     u32* ent = c.arena.get<u32>(n);
@@ -524,7 +555,6 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
     u32 prio_base = (u32)n;
 
     u32 dead_streak = 0, levels_since_purge = 1u << 30;
-    size_t cand_count = entries;
 
     const bool level_log = getenv("TDC_GPU_LEVEL_LOG") != nullptr;     // debugging aid: one line per large level on stderr
     auto t_prev = std::chrono::steady_clock::now();
@@ -538,7 +568,16 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
             st->window_pass = ok ? 1 : 2;
             st->window_lcut = lcut;
             if (ok) { st->factors += nf; break; }
-            lcut = (lcut > 24 && threshold <= 24) ? 24 : 0;
+            // the lists of the levels L .. threshold were never materialised: build them from the residence bytes
+            {
+                Ctx::ProfScope prof(c, K_CAND, (u64)n * 6);
+                cand_rebuild_class_kernel<<<gn, 256, 0, s>>>(res8, prio, n, threshold, L, cls);
+                LAUNCH_CHECK();
+            }
+            build_lists(false, L);
+            cand = cvals[x];
+            dead_streak = 0; levels_since_purge = 1u << 30;
+            lcut = 0;
         }
         // ---- purge: after a run of large levels whose entries were (almost) all erased, drop the erased candidates of
         //      every level still to come (they can never come back to life: cur only decreases)

@@ -74,21 +74,29 @@ __global__ void owner_fill_kernel(const u32* __restrict__ pos, size_t z, const u
     for (u32 j = sub; j < l && (size_t)p + j < n; j += G) owner[p + j] = p;
 }
 
-void build_owner(Ctx& c, size_t n, FactorSpace fs) {
+void build_owner(Ctx& c, size_t n, FactorSpace& fs) {
+    fs.have_list = false;
     if (n == 0) return;
     const size_t mark = c.arena.mark();
     u32* offs = c.arena.get<u32>(n);
-    u32* pos = c.arena.get<u32>(n);
+    u32* pos = fs.fpos ? fs.fpos : c.arena.get<u32>(n);
     u32* d_total = c.arena.get<u32>(1);
     const unsigned gn = cdiv(n, 256);
-    Ctx::ProfScope prof(c, K_EXTRACT, (u64)n * 24);
-    owner_flag_kernel<<<gn, 256, 0, c.stream>>>(fs.flen, n, offs, fs.owner);
-    LAUNCH_CHECK();
+    {
+        Ctx::ProfScope prof(c, K_EXTRACT, (u64)n * 12);
+        owner_flag_kernel<<<gn, 256, 0, c.stream>>>(fs.flen, n, offs, fs.owner);
+        LAUNCH_CHECK();
+    }
     exclusive_sum_u32(c, offs, offs, n, d_total);
-    owner_starts_kernel<<<gn, 256, 0, c.stream>>>(fs.flen, offs, n, pos);
-    LAUNCH_CHECK();
+    {
+        Ctx::ProfScope prof(c, K_EXTRACT, (u64)n * 8);
+        owner_starts_kernel<<<gn, 256, 0, c.stream>>>(fs.flen, offs, n, pos);
+        LAUNCH_CHECK();
+    }
     const size_t z = c.read(d_total);
+    if (fs.fpos) { fs.nfact = z; fs.have_list = true; }
     if (z) {
+        Ctx::ProfScope prof(c, K_EXTRACT, (u64)n * 4 + (u64)z * 8);
         // factors are disjoint and in position order: consecutive lanes fill consecutive ranges
         if (z * 64 > n) owner_fill_kernel<8><<<cdiv(z * 8, 256), 256, 0, c.stream>>>(pos, z, fs.flen, n, fs.owner);
         else            owner_fill_kernel<64><<<cdiv(z * 64, 256), 256, 0, c.stream>>>(pos, z, fs.flen, n, fs.owner);
@@ -196,8 +204,8 @@ void flatten_factors(Ctx& c, size_t n, FactorSpace fs, FlattenStats* st) {
     if (n == 0) return;
     hipStream_t s = c.stream;
     const size_t mark = c.arena.mark();
-    u32* fpos = c.arena.get<u32>(n);
-    const size_t z = extract_factors(c, n, fs, fpos, nullptr, nullptr, n);
+    u32* fpos = fs.have_list ? fs.fpos : c.arena.get<u32>(n);
+    const size_t z = fs.have_list ? fs.nfact : extract_factors(c, n, fs, fpos, nullptr, nullptr, n);
     if (z == 0) { c.arena.release(mark); return; }
     u32* ffinal = c.arena.get<u32>(n);          // position-indexed, only factor starts are touched
     u32* cursrc = c.arena.get<u32>(z);

@@ -34,6 +34,11 @@ struct FactorSpace {
     u32* flen = nullptr;
     u32* owner = nullptr;
     u32* fsrc = nullptr;
+    // optional: the factor starts in position order (n entries of capacity).  build_owner() fills it and sets
+    // have_list; flatten and encode then skip their own extraction (factor positions never change after that).
+    u32* fpos = nullptr;
+    size_t nfact = 0;
+    bool have_list = false;
 };
 
 struct FactorizeStats { u64 factors = 0; u32 maxlcp = 0; u32 levels = 0; u32 rounds = 0; u64 pushes = 0; u64 entries = 0; u32 small_levels = 0; u32 purges = 0;
@@ -44,10 +49,10 @@ struct FactorizeStats { u64 factors = 0; u32 maxlcp = 0; u32 levels = 0; u32 rou
 // Inputs: isa, phi, plcp.  isa and plcp are consumed: they become the working priority / LCP arrays.
 // Outputs: fs.flen / fs.owner filled, fs.fsrc[p] = phi[p] at factor starts.
 void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi, u32* plcp, u32 maxlcp,
-                      u32 threshold, FactorSpace fs, FactorizeStats* st);
+                      u32 threshold, FactorSpace& fs, FactorizeStats* st);
 
 // owner[] from the factor starts (flen[p] != 0 exactly at factor starts): owner[q] = start of the factor covering q, else NONE32
-void build_owner(Ctx& c, size_t n, FactorSpace fs);
+void build_owner(Ctx& c, size_t n, FactorSpace& fs);
 
 struct FlattenStats { u64 num_flattened = 0; u64 max_depth_lb = 0; u32 rounds = 0; };
 // a10: compressors/lzss/LZSSFactors.hpp:79-132 ; rewrites fs.fsrc in place.
