@@ -564,7 +564,8 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
             //      pass (a window whose known range shrank into its interior) simply continues with the loop below and
             //      tries once more further down, where the borders of the known range move half as far
             u64 nf = 0;
-            const bool ok = factorize_window_levels(c, n, cur, prio, res8, phi, lcut, threshold, fs, &nf);
+            const int why = factorize_window_levels(c, n, cur, prio, res8, phi, lcut, threshold, fs, &nf);
+            const bool ok = why == 0;
             st->window_pass = ok ? 1 : 2;
             st->window_lcut = lcut;
             if (ok) { st->factors += nf; break; }
@@ -577,7 +578,7 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
             build_lists(false, L);
             cand = cvals[x];
             dead_streak = 0; levels_since_purge = 1u << 30;
-            lcut = 0;
+            lcut = (why == 1 && L > 24 && threshold <= 24) ? 24 : 0;      // borders only: they move half as far from level 24 on
         }
         // ---- purge: after a run of large levels whose entries were (almost) all erased, drop the erased candidates of
         //      every level still to come (they can never come back to life: cur only decreases)

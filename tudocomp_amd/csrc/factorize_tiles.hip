@@ -415,7 +415,7 @@ __global__ __launch_bounds__(TT) void window_levels_kernel(const u32* __restrict
             if (fr < BIG / 2 && fr - ib < mg) mg = fr - ib;
             atomicMin(&sc->min_margin, mg);
         }
-        if (failed || fl > ia || fr < ib) { if (tid == 0) atomicOr(&sc->fail, 1u); }
+        if (failed || fl > ia || fr < ib) { if (tid == 0) atomicOr(&sc->fail, failed ? 2u : 1u); }   // 2: a fixed LDS list overflowed, 1: known range too small
         else {
             // ---- factor starts of the interior: (pos, Phi[pos], L)  (ArraysComp.hpp:91-96) ---------------------------
             const int base = tid * TCH, pbase = tid * (TCH + TPAD);
@@ -455,10 +455,10 @@ __global__ void window_cleanup_kernel(u32* __restrict__ flen, size_t n, u32 lcut
 u32 window_levels_max_lcut() { return 63; }
 size_t window_levels_min_text() { return (size_t)4 * TW; }
 
-bool factorize_window_levels(Ctx& c, size_t n, const u32* cur, const u32* prio, const u8* res8, const u32* phi, u32 lcut, u32 threshold,
-                             FactorSpace fs, u64* nfactors) {
+int factorize_window_levels(Ctx& c, size_t n, const u32* cur, const u32* prio, const u8* res8, const u32* phi, u32 lcut, u32 threshold,
+                            FactorSpace fs, u64* nfactors) {
     *nfactors = 0;
-    if (lcut < threshold) return true;
+    if (lcut < threshold) return 0;
     hipStream_t s = c.stream;
     const size_t mark = c.arena.mark();
     const u32 ntiles = cdiv(n, TI);
@@ -489,10 +489,10 @@ bool factorize_window_levels(Ctx& c, size_t n, const u32* cur, const u32* prio, 
     if (h.fail) {
         window_cleanup_kernel<<<cdiv(n, 256), 256, 0, s>>>(fs.flen, n, lcut);
         LAUNCH_CHECK();
-        return false;
+        return (int)h.fail;
     }
     *nfactors = h.factors;
-    return true;
+    return 0;
 }
 
 }  // namespace tdc

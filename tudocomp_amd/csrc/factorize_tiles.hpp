@@ -7,9 +7,10 @@ namespace tdc {
 // Levels lcut .. threshold of the factorization, every text window inside one launch.  Inputs are the global state after
 // the levels above lcut: cur (working LCP per position), prio (list order), res8 (level whose list holds the entry of a
 // position; 0 = none; values above lcut are stale).  Nothing of it is modified.  Writes flen / fsrc at the factor
-// starts and returns true; returns false (flen cleaned of the low-level factors again) if some window could not be
-// completed, in which case the caller runs the global level loop.
-bool factorize_window_levels(Ctx& c, size_t n, const u32* cur, const u32* prio, const u8* res8, const u32* phi, u32 lcut, u32 threshold,
+// starts and returns 0; returns a non-zero reason mask (flen cleaned of the low-level factors again) if some window could
+// not be completed -- bit 0: the known range shrank into an interior (a lower lcut may still work), bit 1: a level had
+// more entries than the fixed LDS lists hold -- in which case the caller runs the global level loop.
+int factorize_window_levels(Ctx& c, size_t n, const u32* cur, const u32* prio, const u8* res8, const u32* phi, u32 lcut, u32 threshold,
                              FactorSpace fs, u64* nfactors);
 u32 window_levels_max_lcut();       // one presence bit per level in a 64-bit mask
 size_t window_levels_min_text();    // shorter texts stay on the global path
