@@ -95,6 +95,8 @@ struct Ctx {
     u32* d_err = nullptr;          // device error word (look-back timeouts etc.), checked at the end of every API call
     int sa_local_sort = 1;         // doubling rounds: sort whole runs inside 2048-element tiles locally (env TDC_GPU_SA_LOCAL=0 disables)
     int radix_waves = 4;           // waves per radix-sort workgroup for large inputs (env TDC_GPU_RADIX_WAVES = 4 | 8; no measurable difference)
+    int radix_lds = 2;             // radix scatter: reorder the tile in LDS before writing: 0 never, 1 always, 2 for 32-bit keys only
+                                   // (measured: -33 % for u32 pairs, no gain for u64 pairs; env TDC_GPU_RADIX_LDS)
     int xcd_remap = 0;             // radix sort / bucketed scatter: workgroups of one XCD walk one contiguous range of tiles (env TDC_GPU_XCD_REMAP=1; measured: no gain)
     int window_lcut = 48;          // factorize: levels <= this run window-local in one launch (env TDC_GPU_WINDOW_LCUT, 0 disables)
     int window_threads = 256;      // threads per window workgroup (env TDC_GPU_WINDOW_THREADS = 256 | 512)

@@ -360,7 +360,53 @@ __global__ __launch_bounds__(NW * 64) void rs_count_kernel(const K* __restrict__
         }
     }
     __syncthreads();
-    if (threadIdx.x < 256) counts[(size_t)threadIdx.x * numTiles + tile] = hist[threadIdx.x];
+    if (threadIdx.x < 256) counts[(size_t)tile * 256 + threadIdx.x] = hist[threadIdx.x];      // tile-major: one coalesced KiB per tile
+}
+
+// counts[tile][digit] (tile-major) -> global start of every (digit, tile) run: the exclusive scan in digit-major order,
+// evaluated column-wise so that every access is a coalesced row of 256 counters.
+constexpr int CS_ROWS = 128;       // tiles per workgroup
+__global__ __launch_bounds__(256) void rs_colsum_kernel(const u32* __restrict__ counts, u32 numTiles, u32* __restrict__ blocksum) {
+    const u32 t0 = blockIdx.x * CS_ROWS;
+    const u32 t1 = (t0 + CS_ROWS < numTiles) ? t0 + CS_ROWS : numTiles;
+    u32 acc = 0;
+#pragma unroll 8
+    for (u32 t = t0; t < t1; ++t) acc += counts[(size_t)t * 256 + threadIdx.x];
+    blocksum[(size_t)blockIdx.x * 256 + threadIdx.x] = acc;
+}
+// one workgroup: per digit the exclusive prefix over the row blocks; dstart[d] = start of digit d
+__global__ __launch_bounds__(256) void rs_colbase_kernel(u32* __restrict__ blocksum, u32 numBlocks, u32* __restrict__ dstart) {
+    __shared__ u32 sm[5];
+    u32 run = 0;
+    u32 b = 0;
+    for (; b + 8 <= numBlocks; b += 8) {                    // eight independent loads in flight
+        u32 v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = blocksum[(size_t)(b + i) * 256 + threadIdx.x];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { blocksum[(size_t)(b + i) * 256 + threadIdx.x] = run; run += v[i]; }
+    }
+    for (; b < numBlocks; ++b) { const u32 v = blocksum[(size_t)b * 256 + threadIdx.x]; blocksum[(size_t)b * 256 + threadIdx.x] = run; run += v; }
+    u32 total;
+    dstart[threadIdx.x] = block_exclusive_sum<u32, 4>(run, sm, total);
+}
+__global__ __launch_bounds__(256) void rs_colapply_kernel(u32* __restrict__ counts, u32 numTiles, const u32* __restrict__ blocksum,
+                                                           const u32* __restrict__ dstart) {
+    const u32 t0 = blockIdx.x * CS_ROWS;
+    const u32 t1 = (t0 + CS_ROWS < numTiles) ? t0 + CS_ROWS : numTiles;
+    u32 run = blocksum[(size_t)blockIdx.x * 256 + threadIdx.x] + dstart[threadIdx.x];
+#pragma unroll 8
+    for (u32 t = t0; t < t1; ++t) { const u32 v = counts[(size_t)t * 256 + threadIdx.x]; counts[(size_t)t * 256 + threadIdx.x] = run; run += v; }
+}
+static void radix_offsets(Ctx& c, u32* counts, u32 numTiles, u32* blocksum) {
+    const u32 nb = cdiv(numTiles, CS_ROWS);
+    Ctx::ProfScope prof(c, K_SCAN, (u64)numTiles * 256 * 3 * sizeof(u32));
+    rs_colsum_kernel<<<nb, 256, 0, c.stream>>>(counts, numTiles, blocksum);
+    LAUNCH_CHECK();
+    rs_colbase_kernel<<<1, 256, 0, c.stream>>>(blocksum, nb, blocksum + (size_t)nb * 256);
+    LAUNCH_CHECK();
+    rs_colapply_kernel<<<nb, 256, 0, c.stream>>>(counts, numTiles, blocksum, blocksum + (size_t)nb * 256);
+    LAUNCH_CHECK();
 }
 
 template <typename K, int NW>
@@ -404,7 +450,7 @@ __global__ __launch_bounds__(NW * 64) void rs_scatter_kernel(const K* __restrict
     __syncthreads();
     if (threadIdx.x < 256) {
         const u32 t = threadIdx.x;
-        u32 run = offsets[(size_t)t * numTiles + tile];
+        u32 run = offsets[(size_t)tile * 256 + t];
 #pragma unroll
         for (int i = 0; i < NW; ++i) { wbase[i][t] = run; run += wcnt[i][t]; }
     }
@@ -421,12 +467,110 @@ __global__ __launch_bounds__(NW * 64) void rs_scatter_kernel(const K* __restrict
     }
 }
 
+// Variant that reorders the tile in LDS before writing: the direct scatter above issues one 8-byte write request per lane
+// (64 different cache lines per store instruction); here consecutive lanes write consecutive elements of a digit's run, so a
+// store instruction touches a handful of lines.  Same tiling, same stable ranks; the staging buffer holds the keys first and
+// is reused for the values.
+template <typename K, int NW>
+__global__ __launch_bounds__(NW * 64) void rs_scatter_lds_kernel(const K* __restrict__ keys_in, const u32* __restrict__ vals_in,
+                                                                  K* __restrict__ keys_out, u32* __restrict__ vals_out,
+                                                                  const u32* __restrict__ offsets, size_t n, u32 numTiles,
+                                                                  int shift, u32 dmask) {
+    constexpr int TILE = NW * 64 * RS_ITEMS;
+    __shared__ u32 wcnt[NW][256];     // per-wave digit counts, then start of the (wave, digit) run inside the sorted tile
+    __shared__ u32 gbase[256];        // global start of the digit's run minus its start inside the sorted tile
+    __shared__ K stage[TILE];
+    __shared__ u32 scan_sm[NW + 1];
+    const int lane = lane_id(), w = wave_id();
+    const u32 tile = blockIdx.x;
+    for (int i = threadIdx.x; i < NW * 256; i += NW * 64) (&wcnt[0][0])[i] = 0;
+    __syncthreads();
+
+    K k[RS_ITEMS];
+    u32 v[RS_ITEMS];
+    u32 loc[RS_ITEMS];
+    volatile u32* mycnt = wcnt[w];
+    const size_t tileBase = (size_t)tile * TILE + (size_t)w * (64 * RS_ITEMS) + lane;
+    const u32 tileCount = (u32)(((size_t)(tile + 1) * TILE <= n) ? (size_t)TILE : n - (size_t)tile * TILE);
+    const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int j = 0; j < RS_ITEMS; ++j) {
+        const size_t idx = tileBase + (size_t)j * 64;
+        const bool valid = idx < n;
+        k[j] = valid ? keys_in[idx] : (K)0;
+        v[j] = valid ? vals_in[idx] : 0u;
+        const u32 d = (u32)((k[j] >> shift) & dmask);
+        u64 peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const u64 bal = __ballot(bit);
+            peers &= bit ? bal : ~bal;
+        }
+        const u32 prefix = mycnt[d];
+        const u32 rank = (u32)__popcll(peers & lt_mask);
+        loc[j] = prefix + rank;
+        if (valid && rank == 0) mycnt[d] = prefix + (u32)__popcll(peers);
+    }
+    __syncthreads();
+    {   // thread t = digit t: runs inside the sorted tile (exclusive scan over the digits), per-wave starts, global base
+        const u32 t = threadIdx.x;
+        u32 tot = 0;
+        if (NW * 64 == 256 || t < 256) {
+#pragma unroll
+            for (int i = 0; i < NW; ++i) tot += wcnt[i][t];
+        }
+        u32 total;
+        const u32 start = block_exclusive_sum<u32, NW>((NW * 64 == 256 || t < 256) ? tot : 0u, scan_sm, total);
+        if (NW * 64 == 256 || t < 256) {
+            u32 run = start;
+#pragma unroll
+            for (int i = 0; i < NW; ++i) { const u32 c = wcnt[i][t]; wcnt[i][t] = run; run += c; }
+            gbase[t] = offsets[(size_t)tile * 256 + t] - start;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RS_ITEMS; ++j) {
+        const size_t idx = tileBase + (size_t)j * 64;
+        const u32 d = (u32)((k[j] >> shift) & dmask);
+        loc[j] += wcnt[w][d];                                   // position inside the sorted tile
+        if (idx < n) stage[loc[j]] = k[j];
+    }
+    __syncthreads();
+    u32 dst[RS_ITEMS];
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; ++r) {
+        const u32 sp = (u32)r * (NW * 64) + threadIdx.x;
+        dst[r] = 0xFFFFFFFFu;
+        if (sp < tileCount) {
+            const K key = stage[sp];
+            dst[r] = gbase[(u32)((key >> shift) & dmask)] + sp;
+            keys_out[dst[r]] = key;
+        }
+    }
+    __syncthreads();
+    u32* stage32 = (u32*)stage;
+#pragma unroll
+    for (int j = 0; j < RS_ITEMS; ++j) {
+        const size_t idx = tileBase + (size_t)j * 64;
+        if (idx < n) stage32[loc[j]] = v[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; ++r) {
+        const u32 sp = (u32)r * (NW * 64) + threadIdx.x;
+        if (dst[r] != 0xFFFFFFFFu) vals_out[dst[r]] = stage32[sp];
+    }
+}
+
 template <typename K, int NW>
 static int radix_sort_pairs_nw(Ctx& c, K* keys[2], u32* vals[2], size_t n, int begin_bit, int end_bit) {
     const size_t mark = c.arena.mark();
     constexpr int TILE = NW * 64 * RS_ITEMS;
     const u32 numTiles = cdiv(n, TILE);
     u32* counts = c.arena.get<u32>((size_t)256 * numTiles);
+    u32* blocksum = c.arena.get<u32>((size_t)256 * (cdiv(numTiles, CS_ROWS) + 1));     // + one row: start of every digit
     const u32 per_xcd = (c.xcd_remap && numTiles >= 64) ? cdiv(numTiles, 8) : 0u;
     const u32 grid = per_xcd ? 8 * per_xcd : numTiles;
     int cur = 0;
@@ -438,10 +582,14 @@ static int radix_sort_pairs_nw(Ctx& c, K* keys[2], u32* vals[2], size_t n, int b
         rs_count_kernel<K, NW><<<grid, NW * 64, 0, c.stream>>>(keys[cur], counts, n, numTiles, shift, dmask, per_xcd);
         LAUNCH_CHECK();
         c.prof_end(pc);
-        exclusive_sum_u32(c, counts, counts, (size_t)256 * numTiles, nullptr);
+        radix_offsets(c, counts, numTiles, blocksum);
         const int ps = c.prof_begin(sizeof(K) == 8 ? K_RS_SCATTER_U64 : K_RS_SCATTER_U32, (u64)n * 2 * (sizeof(K) + sizeof(u32)));
-        rs_scatter_kernel<K, NW><<<grid, NW * 64, 0, c.stream>>>(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], counts, n,
-                                                                  numTiles, shift, dmask, per_xcd);
+        if (NW == 4 && (c.radix_lds == 1 || (c.radix_lds == 2 && sizeof(K) == 4)))
+            rs_scatter_lds_kernel<K, NW><<<numTiles, NW * 64, 0, c.stream>>>(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], counts, n,
+                                                                          numTiles, shift, dmask);
+        else
+            rs_scatter_kernel<K, NW><<<grid, NW * 64, 0, c.stream>>>(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], counts, n,
+                                                                      numTiles, shift, dmask, per_xcd);
         LAUNCH_CHECK();
         c.prof_end(ps);
         cur ^= 1;
