@@ -97,7 +97,8 @@ struct Ctx {
     int radix_waves = 4;           // waves per radix-sort workgroup for large inputs (env TDC_GPU_RADIX_WAVES = 4 | 8; no measurable difference)
     int radix_lds = 2;             // radix scatter: reorder the tile in LDS before writing: 0 never, 1 always, 2 for 32-bit keys only
                                    // (measured: -33 % for u32 pairs, no gain for u64 pairs; env TDC_GPU_RADIX_LDS)
-    int xcd_remap = 0;             // radix sort / bucketed scatter: workgroups of one XCD walk one contiguous range of tiles (env TDC_GPU_XCD_REMAP=1; measured: no gain)
+    int xcd_remap = 0;             // XCD-contiguous tile walk (env TDC_GPU_XCD_REMAP): 0 = only in the final pass of the bucketed scatter
+                                   // (-1.2 ms of 7.3), 1 = also in the radix sort kernels (measured: no gain), 2 = nowhere
     int window_lcut = 48;          // factorize: levels <= this run window-local in one launch (env TDC_GPU_WINDOW_LCUT, 0 disables)
     int window_threads = 256;      // threads per window workgroup (env TDC_GPU_WINDOW_THREADS = 256 | 512)
     int bucket_scatter = 1;        // big random scatters (rank, Phi) go through one radix partition by destination window (env TDC_GPU_BUCKET_SCATTER=0 disables)

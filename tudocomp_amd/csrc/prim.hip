@@ -571,7 +571,7 @@ static int radix_sort_pairs_nw(Ctx& c, K* keys[2], u32* vals[2], size_t n, int b
     const u32 numTiles = cdiv(n, TILE);
     u32* counts = c.arena.get<u32>((size_t)256 * numTiles);
     u32* blocksum = c.arena.get<u32>((size_t)256 * (cdiv(numTiles, CS_ROWS) + 1));     // + one row: start of every digit
-    const u32 per_xcd = (c.xcd_remap && numTiles >= 64) ? cdiv(numTiles, 8) : 0u;
+    const u32 per_xcd = (c.xcd_remap == 1 && numTiles >= 64) ? cdiv(numTiles, 8) : 0u;
     const u32 grid = per_xcd ? 8 * per_xcd : numTiles;
     int cur = 0;
     for (int shift = begin_bit; shift < end_bit; shift += 8) {
@@ -667,19 +667,32 @@ __global__ __launch_bounds__(256) void window_scatter_kernel(const u32* __restri
     for (int r = 0; r < WS_ITEMS; ++r) if (j0 + r < m) dst[k[r]] = v[r];
 }
 
-void bucketed_scatter_u32(Ctx& c, const u32* idx, const u32* val, size_t m, u32* dst, size_t n_dst, u32* tmp_idx, u32* tmp_val) {
+void bucketed_scatter_u32(Ctx& c, const u32* idx, const u32* val, size_t m, u32* dst, size_t n_dst, u32* tmp_idx, u32* tmp_val,
+                          u32* tmp_idx2, u32* tmp_val2) {
     if (m == 0) return;
     const int bits = (int)bits_for(n_dst ? n_dst - 1 : 0);
     const u32* k = idx;
     const u32* v = val;
     if (bits > 8 && m >= ((size_t)1 << 20)) {
-        u32* keys[2] = { const_cast<u32*>(idx), tmp_idx };      // one pass: [0] is only read
-        u32* vals[2] = { const_cast<u32*>(val), tmp_val };
-        const int x = radix_sort_pairs<u32>(c, keys, vals, m, bits - 8, bits);
-        k = keys[x]; v = vals[x];
+        // two stable 8-bit passes (low digit first) = partition by the top 16 bits: the writes of the final pass stay inside
+        // windows of n_dst / 65536 elements, which L2 merges into whole lines
+        const int top = bits > 16 ? bits - 16 : 0;
+        const int mid = (bits - top > 8) ? top + 8 : bits;
+        u32* ka[2] = { const_cast<u32*>(idx), tmp_idx };        // one pass each: [0] is only read
+        u32* va[2] = { const_cast<u32*>(val), tmp_val };
+        radix_sort_pairs<u32>(c, ka, va, m, top, mid);
+        k = tmp_idx; v = tmp_val;
+        if (mid < bits && tmp_idx2 && tmp_val2) {
+            u32* kb[2] = { tmp_idx, tmp_idx2 };
+            u32* vb[2] = { tmp_val, tmp_val2 };
+            radix_sort_pairs<u32>(c, kb, vb, m, mid, bits);
+            k = tmp_idx2; v = tmp_val2;
+        }
     }
+    // every XCD walks one contiguous part of the partitioned pairs: all writes to a destination line then meet in ONE L2
+    // (measured without this: WRITE_SIZE = 9x the destination bytes, every 4-byte store left its L2 as a partial line)
     const u32 numTiles = cdiv(m, 256 * WS_ITEMS);
-    const u32 per_xcd = (c.xcd_remap && numTiles >= 64) ? cdiv(numTiles, 8) : 0u;
+    const u32 per_xcd = (c.xcd_remap != 2 && numTiles >= 64) ? cdiv(numTiles, 8) : 0u;
     window_scatter_kernel<<<per_xcd ? 8 * per_xcd : numTiles, 256, 0, c.stream>>>(k, v, m, dst, numTiles, per_xcd);
     LAUNCH_CHECK();
 }

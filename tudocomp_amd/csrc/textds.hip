@@ -27,7 +27,9 @@ void build_phi(Ctx& c, const u32* sa, size_t n, u32* phi) {
         const size_t mark = c.arena.mark();
         u32* ti = c.arena.get<u32>(n);
         u32* tv = c.arena.get<u32>(n);
-        bucketed_scatter_u32(c, sa + 1, sa, n - 1, phi, n, ti, tv);
+        u32* ti2 = c.arena.get<u32>(n);
+        u32* tv2 = c.arena.get<u32>(n);
+        bucketed_scatter_u32(c, sa + 1, sa, n - 1, phi, n, ti, tv, ti2, tv2);
         phi_first_kernel<<<1, 1, 0, c.stream>>>(sa, n, phi);
         LAUNCH_CHECK();
         c.arena.release(mark);
