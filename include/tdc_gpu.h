@@ -36,7 +36,7 @@ typedef enum {
 } tdc_gpu_status;
 
 /* coder ids (option `coder`, etc/registry_config.py:28-31,138-142) */
-enum { TDC_GPU_CODER_HUFF = 0, TDC_GPU_CODER_GAMMA = 1, TDC_GPU_CODER_ARITH = 2 };
+enum { TDC_GPU_CODER_HUFF = 0, TDC_GPU_CODER_GAMMA = 1, TDC_GPU_CODER_ARITH = 2, TDC_GPU_CODER_ASCII = 3 };
 
 typedef struct tdc_gpu_ctx tdc_gpu_ctx;
 
@@ -137,6 +137,9 @@ int tdc_gpu_encode_huff(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, const u
 
 /* the same with ArithmeticCoder::Encoder as the literal coder (coders/ArithmeticCoder.hpp:35-177) */
 int tdc_gpu_encode_arith(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, const uint32_t* pos, const uint32_t* src,
+                         const uint32_t* len, size_t z, uint8_t** out, size_t* out_len);
+/* coder = ASCIICoder (coders/ASCIICoder.hpp:29-50) */
+int tdc_gpu_encode_ascii(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, const uint32_t* pos, const uint32_t* src,
                          const uint32_t* len, size_t z, uint8_t** out, size_t* out_len);
 
 /* ---- host-side helpers (no GPU) --------------------------------------------------------------------------- */

@@ -76,6 +76,11 @@ def lib():
         L.orc_lcpcomp_huff_compress.argtypes = [ctypes.c_void_p, sz, ctypes.c_uint32, ctypes.c_int,
                                                 ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(sz),
                                                 ctypes.POINTER(Stats)]
+        L.orc_lcpcomp_ascii_compress.argtypes = [ctypes.c_void_p, sz, ctypes.c_uint32, ctypes.c_int,
+                                                 ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(sz), ctypes.POINTER(Stats)]
+        L.orc_encode_ascii.argtypes = [ctypes.c_void_p, sz, ctypes.c_void_p, sz, ctypes.POINTER(ctypes.c_void_p),
+                                       ctypes.POINTER(sz), ctypes.POINTER(Stats)]
+        L.orc_lcpcomp_ascii_decompress.argtypes = [ctypes.c_void_p, sz, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(sz)]
         L.orc_lcpcomp_arith_compress.argtypes = [ctypes.c_void_p, sz, ctypes.c_uint32, ctypes.c_int,
                                                  ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(sz),
                                                  ctypes.POINTER(Stats)]
@@ -226,6 +231,34 @@ def lcpcomp_arith_compress(text, threshold=5, flatten=1):
             lib().orc_free(out)
         raise RuntimeError("orc_lcpcomp_arith_compress rc=%d" % rc)
     return _take(out, n.value), st.as_dict()
+
+
+def lcpcomp_ascii_compress(text, threshold=5, flatten=1):
+    a, p = _buf(text)
+    out, n, st = ctypes.c_void_p(), ctypes.c_size_t(), Stats()
+    rc = lib().orc_lcpcomp_ascii_compress(p, len(a), threshold, flatten, ctypes.byref(out), ctypes.byref(n), ctypes.byref(st))
+    if rc:
+        raise RuntimeError("orc_lcpcomp_ascii_compress rc=%d" % rc)
+    return _take(out, n.value), st.as_dict()
+
+
+def encode_ascii(text, f):
+    a, p = _buf(text)
+    f = np.ascontiguousarray(f)
+    out, n, st = ctypes.c_void_p(), ctypes.c_size_t(), Stats()
+    rc = lib().orc_encode_ascii(p, len(a), f.ctypes.data_as(ctypes.c_void_p), len(f), ctypes.byref(out), ctypes.byref(n), ctypes.byref(st))
+    if rc:
+        raise RuntimeError("orc_encode_ascii rc=%d" % rc)
+    return _take(out, n.value), st.as_dict()
+
+
+def lcpcomp_ascii_decompress(stream):
+    a, p = _buf(stream)
+    out, n = ctypes.c_void_p(), ctypes.c_size_t()
+    rc = lib().orc_lcpcomp_ascii_decompress(p, len(a), ctypes.byref(out), ctypes.byref(n))
+    if rc:
+        raise RuntimeError("orc_lcpcomp_ascii_decompress rc=%d" % rc)
+    return _take(out, n.value)
 
 
 def encode_arith(text, f):

@@ -687,8 +687,15 @@ static int arith_encode(arith_enc* a, bitout* b, uint8_t v) {            /* enco
 
 /* ------------------------------------------------------------------------------------------------
  * lzss::encode_text (LZSSCoding.hpp:18-92) with tdc::Encoder's binary integer coding (Coder.hpp:61-77)
- * coder: 0 = HuffmanCoder, 1 = ArithmeticCoder
+ * coder: 0 = HuffmanCoder, 1 = ArithmeticCoder, 2 = ASCIICoder (coders/ASCIICoder.hpp:29-50: integers in decimal
+ * followed by ':', bits as '0' / '1', literals raw, and NO subtraction of the range minimum)
  * ---------------------------------------------------------------------------------------------- */
+static void ascii_int(bitout* b, uint64_t v) {                            /* ASCIICoder.hpp:33-39 */
+    char tmp[24]; int k = 0;
+    do { tmp[k++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (k) bo_write_int(b, (uint8_t)tmp[--k], 8);
+    bo_write_int(b, ':', 8);
+}
 static int encode_stream(const uint8_t* text, size_t n, const orc_factor* f, size_t z, int coder,
                          uint8_t** out, size_t* out_len, orc_stats* st) {
     uint32_t C[256];
@@ -697,9 +704,12 @@ static int encode_stream(const uint8_t* text, size_t n, const orc_factor* f, siz
     arith_enc ac;
     bitout b; bo_init(&b);
     if (coder == 0) { orc_huffman_table(C, &t); huff_write_header(&b, &t); }   /* Encoder ctor */
-    else arith_init(&ac, C, &b);
+    else if (coder == 1) arith_init(&ac, C, &b);
     int rc = 0;
-#define ENC_LITERAL(ch) do { if (coder == 0) huff_encode_literal(&b, &t, (ch)); else if (arith_encode(&ac, &b, (ch))) rc = -8; } while (0)
+#define ENC_LITERAL(ch) do { if (coder == 0) huff_encode_literal(&b, &t, (ch)); else if (coder == 2) bo_write_int(&b, (ch), 8); \
+                             else if (arith_encode(&ac, &b, (ch))) rc = -8; } while (0)
+#define ENC_INT(v, bits) do { if (coder == 2) ascii_int(&b, (v)); else bo_write_int(&b, (v), (bits)); } while (0)
+#define ENC_BIT(x) do { if (coder == 2) bo_write_int(&b, (x) ? '1' : '0', 8); else bo_write_bit(&b, (x)); } while (0)
 
     uint64_t flen_min = 0xFFFFFFFFull, flen_max = 0, fdist_max = 0;       /* LZSSFactors.hpp:33-38 INDEX_MAX / 0 */
     {
@@ -715,22 +725,25 @@ static int encode_stream(const uint8_t* text, size_t n, const orc_factor* f, siz
     const unsigned W = orc_bits_for(n);                                    /* Range text_r(n) */
     const unsigned lbits = orc_bits_for(flen_max - flen_min);              /* MinDistributedRange; wraps like size_t when z=0, unused then */
     const unsigned dbits = orc_bits_for(fdist_max);
-    bo_write_int(&b, n, 32);                                               /* :47 len_r */
-    bo_write_int(&b, flen_min, W);                                         /* :48 */
-    bo_write_int(&b, flen_max, W);                                         /* :49 */
-    bo_write_int(&b, fdist_max, W);                                        /* :50 */
+    const uint64_t lsub = (coder == 2) ? 0 : flen_min;                     /* ASCIICoder ignores the range */
+    ENC_INT(n, 32);                                                        /* :47 len_r */
+    ENC_INT(flen_min, W);                                                  /* :48 */
+    ENC_INT(flen_max, W);                                                  /* :49 */
+    ENC_INT(fdist_max, W);                                                 /* :50 */
     size_t p = 0;
     for (size_t i = 0; i < z; ++i) {                                       /* :54-81 */
-        if (f[i].pos == p) bo_write_bit(&b, 0);
-        else { bo_write_bit(&b, 1); bo_write_int(&b, f[i].pos - p, dbits); }
+        if (f[i].pos == p) ENC_BIT(0);
+        else { ENC_BIT(1); ENC_INT(f[i].pos - p, dbits); }
         while (p < f[i].pos) ENC_LITERAL(text[p++]);
-        bo_write_int(&b, f[i].src, W);
-        bo_write_int(&b, f[i].len - flen_min, lbits);
+        ENC_INT(f[i].src, W);
+        ENC_INT(f[i].len - lsub, lbits);
         p += f[i].len;
     }
-    if (p < n) { bo_write_bit(&b, 1); bo_write_int(&b, n - p, dbits); }    /* :83-86 */
+    if (p < n) { ENC_BIT(1); ENC_INT(n - p, dbits); }                      /* :83-86 */
     while (p < n) ENC_LITERAL(text[p++]);                                  /* :88-91 */
 #undef ENC_LITERAL
+#undef ENC_INT
+#undef ENC_BIT
     bo_finish(&b);                                                         /* ~BitOStream */
     *out = b.buf; *out_len = b.len;
     if (st) { st->flen_min = flen_min; st->flen_max = flen_max; st->fdist_max = fdist_max; }
@@ -745,6 +758,10 @@ int orc_encode_arith(const uint8_t* text, size_t n, const orc_factor* f, size_t 
                      uint8_t** out, size_t* out_len, orc_stats* st) {
     return encode_stream(text, n, f, z, 1, out, out_len, st);
 }
+int orc_encode_ascii(const uint8_t* text, size_t n, const orc_factor* f, size_t z,
+                     uint8_t** out, size_t* out_len, orc_stats* st) {
+    return encode_stream(text, n, f, z, 2, out, out_len, st);
+}
 
 /* LCPCompressor.hpp:100-138 */
 static int lcpcomp_compress(const uint8_t* text, size_t n, uint32_t threshold, int flatten, int coder,
@@ -757,6 +774,11 @@ int orc_lcpcomp_huff_compress(const uint8_t* text, size_t n, uint32_t threshold,
 int orc_lcpcomp_arith_compress(const uint8_t* text, size_t n, uint32_t threshold, int flatten,
                                uint8_t** out, size_t* out_len, orc_stats* stats) {
     return lcpcomp_compress(text, n, threshold, flatten, 1, out, out_len, stats);
+}
+/* lcpcomp(coder=ascii): the human-readable form of the same token stream */
+int orc_lcpcomp_ascii_compress(const uint8_t* text, size_t n, uint32_t threshold, int flatten,
+                               uint8_t** out, size_t* out_len, orc_stats* stats) {
+    return lcpcomp_compress(text, n, threshold, flatten, 2, out, out_len, stats);
 }
 static int lcpcomp_compress(const uint8_t* text, size_t n, uint32_t threshold, int flatten, int coder,
                             uint8_t** out, size_t* out_len, orc_stats* stats) {
@@ -866,6 +888,53 @@ int orc_lzss_lcp_huff_compress(const uint8_t* text, size_t n, uint32_t threshold
  * (LCPCompressor.hpp:23-76).  The reference resolves forward references with ScanDec; the decoded
  * text is unique, so references are resolved here by following source chains.
  * ---------------------------------------------------------------------------------------------- */
+/* The same with ASCIICoder::Decoder (ASCIICoder.hpp:53-84): every read is 8 bits; an integer ends at the first
+ * non-digit (the ':'), a bit is anything but '0'.  The stream ends with the BitOStream terminator byte. */
+static int ascii_read_int(const uint8_t* in, size_t len, size_t* at, uint64_t* v) {
+    uint64_t x = 0; int digits = 0;
+    while (*at < len) {
+        const uint8_t c = in[(*at)++];
+        if (c < '0' || c > '9') { *v = x; return digits ? 0 : -4; }
+        x = x * 10 + (c - '0'); ++digits;
+    }
+    return -4;
+}
+int orc_lcpcomp_ascii_decompress(const uint8_t* in, size_t in_len, uint8_t** out, size_t* out_len) {
+    if (in_len == 0) return -4;
+    const size_t len = in_len - 1;                                          /* minus the terminator byte (all writes are whole bytes) */
+    size_t at = 0;
+    uint64_t n, flen_min, flen_max, fdist_max;
+    if (ascii_read_int(in, len, &at, &n) || ascii_read_int(in, len, &at, &flen_min) ||
+        ascii_read_int(in, len, &at, &flen_max) || ascii_read_int(in, len, &at, &fdist_max)) return -4;
+    (void)flen_min; (void)flen_max; (void)fdist_max;
+    uint8_t* text = (uint8_t*)malloc(n ? n : 1);
+    uint32_t* ref = (uint32_t*)malloc((n ? n : 1) * sizeof(uint32_t));
+    if (!text || !ref) { free(text); free(ref); return -1; }
+    uint64_t p = 0;
+    while (at < len) {                                                      /* LCPCompressor.hpp:45-66 */
+        uint64_t num = 0;
+        if (in[at++] != '0') { if (ascii_read_int(in, len, &at, &num)) { free(text); free(ref); return -4; } }
+        if (p + num > n || at + num > len) { free(text); free(ref); return -4; }
+        while (num--) { text[p] = in[at++]; ref[p] = 0xFFFFFFFFu; ++p; }
+        if (at < len) {
+            uint64_t src, l;
+            if (ascii_read_int(in, len, &at, &src) || ascii_read_int(in, len, &at, &l)) { free(text); free(ref); return -4; }
+            if (p + l > n || src + l > n) { free(text); free(ref); return -4; }
+            for (uint64_t j = 0; j < l; ++j) ref[p + j] = (uint32_t)(src + j);
+            p += l;
+        }
+    }
+    if (p != n) { free(text); free(ref); return -5; }
+    for (uint64_t i = 0; i < n; ++i) {                                      /* chains end in literals */
+        uint32_t q = (uint32_t)i; uint64_t guard = 0;
+        while (ref[q] != 0xFFFFFFFFu) { q = ref[q]; if (++guard > n) { free(text); free(ref); return -6; } }
+        text[i] = text[q];
+    }
+    free(ref);
+    *out = text; *out_len = n;
+    return 0;
+}
+
 int orc_lcpcomp_huff_decompress(const uint8_t* in, size_t in_len, uint8_t** out, size_t* out_len) {
     bitin b; bi_init(&b, in, in_len);
     int have_table = (int)bi_read_bit(&b);

@@ -94,6 +94,13 @@ int orc_lcpcomp_arith_compress(const uint8_t* text, size_t n, uint32_t threshold
                                uint8_t** out, size_t* out_len, orc_stats* stats);
 int orc_encode_arith(const uint8_t* text, size_t n, const orc_factor* f, size_t z,
                      uint8_t** out, size_t* out_len, orc_stats* stats);
+/* The same with coder = ASCIICoder (coders/ASCIICoder.hpp:29-84): decimal integers + ':', '0'/'1' bits, raw literals.
+ * Pinned by the stream the reference printed for the SURVEY 8c example text. */
+int orc_lcpcomp_ascii_compress(const uint8_t* text, size_t n, uint32_t threshold, int flatten,
+                               uint8_t** out, size_t* out_len, orc_stats* stats);
+int orc_encode_ascii(const uint8_t* text, size_t n, const orc_factor* f, size_t z,
+                     uint8_t** out, size_t* out_len, orc_stats* stats);
+int orc_lcpcomp_ascii_decompress(const uint8_t* in, size_t in_len, uint8_t** out, size_t* out_len);
 /* LCPCompressor.hpp:140-150 / decode_text_internal :23-76 with HuffmanCoder::Decoder.
  * Produces the (still escaped, 0-terminated) text. *out malloc'd. */
 int orc_lcpcomp_huff_decompress(const uint8_t* in, size_t in_len, uint8_t** out, size_t* out_len);

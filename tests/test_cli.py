@@ -46,6 +46,18 @@ def test_decompress_reads_header(tmp_path):
     assert _run("-d", "-o", str(out), str(f)).returncode == 1
 
 
+def test_ascii_coder_decompress(tmp_path):
+    """lcpcomp(coder=ascii): host decoder of the facade (ASCIICoder::Decoder, coders/ASCIICoder.hpp:53-84)."""
+    data = T.gen_english(3000, 4).tobytes() + bytes([0, 255]) + b" 12:34:"
+    payload, _ = O.lcpcomp_ascii_compress(O.escape(data), 3, 1)
+    f = tmp_path / "a.tdc"
+    f.write_bytes(b"lcpcomp(coder=ascii,threshold=3)%" + payload)
+    out = tmp_path / "a.out"
+    r = _run("-d", "-o", str(out), str(f))
+    assert r.returncode == 0, r.stderr
+    assert out.read_bytes() == data
+
+
 def test_lzss_lcp_decompress(tmp_path):
     data = T.gen_english(4000, 5).tobytes() + b"\x00\xff"
     payload, _ = O.lzss_lcp_huff_compress(O.escape(data), 3)

@@ -259,3 +259,27 @@ def test_device_escape_matches_host(gpu_ctx):
         want, _ = O.lcpcomp_huff_compress(O.escape(data), 3, 1)
         got, st = gpu_ctx.lcpcomp_compress_raw(data, 3, 1)
         assert got == want and st["n"] == len(O.escape(data))
+
+
+def test_lcpcomp_ascii_coder(gpu_ctx):
+    """lcpcomp(coder=ascii): device stream == oracle == the reference's recorded example; round trip through
+    the oracle's ASCII decoder."""
+    e = ANCH["example"]
+    text = O.escape(e["text"].encode())
+    got, _ = gpu_ctx.lcpcomp_compress(text, e["threshold"], 1, T.CODER_ASCII)
+    assert got == e["ascii_output"].encode("latin-1") + bytes(1)
+    cases = [c for c in SMALL] + [("english_300k", T.gen_english(300_000, 3).tobytes()), ("dna_100k", T.gen_dna(100_000, 7).tobytes())]
+    for name, data in cases:
+        text = O.escape(data)
+        for thr in (1, 2, 5):
+            want, _ = O.lcpcomp_ascii_compress(text, thr, 1)
+            got, st = gpu_ctx.lcpcomp_compress(text, thr, 1, T.CODER_ASCII)
+            assert got == want, "%s t=%d: %d vs %d bytes" % (name, thr, len(got), len(want))
+    # stand-alone encoder entry point on a given factor list
+    text = O.escape(T.gen_english(50_000, 11).tobytes())
+    sa = O.suffix_array(text)
+    isa, phi, plcp, maxlcp = O.isa_phi_plcp(text, sa)
+    f = O.flatten(O.sort_factors(O.arrays_comp(sa, isa, O.lcp_array(sa, plcp), maxlcp, 2)))[0]
+    want, _ = O.encode_ascii(text, f)
+    assert gpu_ctx.encode_ascii(text, f["pos"], f["src"], f["len"]) == want
+    assert O.lcpcomp_ascii_decompress(want) == text

@@ -75,6 +75,20 @@ def test_survey_example_bytes_and_factors():
     assert [[int(a), int(b), int(c)] for a, b, c in f] == e["factors"]
 
 
+def test_survey_example_ascii_coder():
+    """lcpcomp(coder=ascii): the reference's recorded stream for the example text, plus round trips."""
+    e = ANCH["example"]
+    text = O.escape(e["text"].encode())
+    out, _ = O.lcpcomp_ascii_compress(text, e["threshold"], 1)
+    assert out == e["ascii_output"].encode("latin-1") + bytes(1)          # + BitOStream terminator (io/BitOStream.hpp:53-64)
+    assert O.lcpcomp_ascii_decompress(out) == text
+    for name, data in corpus.small_corpus():
+        t = O.escape(data)
+        for thr in (1, 2, 5):
+            s, _ = O.lcpcomp_ascii_compress(t, thr, 1)
+            assert O.lcpcomp_ascii_decompress(s) == t, name
+
+
 @pytest.mark.parametrize("a", ANCH["lcpcomp_huff"], ids=lambda a: "%s_t%d" % (a["text"], a["threshold"]))
 def test_survey_lcpcomp_anchors(a):
     data = _gen_text(a["text"])

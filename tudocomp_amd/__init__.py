@@ -14,6 +14,7 @@ from ._native import Stats, LIB_PATH, SYMBOLS  # noqa: F401
 CODER_HUFF = 0
 CODER_GAMMA = 1
 CODER_ARITH = 2
+CODER_ASCII = 3
 
 
 class TdcGpuError(RuntimeError):
@@ -217,6 +218,9 @@ class Context:
                                             ctypes.byref(md)))
         return src, nf.value, md.value
 
+    def encode_ascii(self, text, pos, src, length):
+        return self.encode_huff(text, pos, src, length, _fn="tdc_gpu_encode_ascii")
+
     def encode_arith(self, text, pos, src, length):
         return self.encode_huff(text, pos, src, length, _fn="tdc_gpu_encode_arith")
 
@@ -237,11 +241,11 @@ class LCPCompressor:
     input restrictions (escape {0}, null-terminate) and handed to compress()."""
 
     def __init__(self, ctx, coder="huff", threshold=5, flatten=1, comp="arrays"):
-        if coder not in ("huff", "arithmetic") or comp != "arrays":
+        if coder not in ("huff", "arithmetic", "ascii") or comp != "arrays":
             # same wording as Registry.hpp:214
             raise RuntimeError("No implementation found for compressor lcpcomp(coder=%s,comp=%s)" % (coder, comp))
         self.ctx, self.threshold, self.flatten = ctx, int(threshold), int(flatten)
-        self.coder = CODER_HUFF if coder == "huff" else CODER_ARITH
+        self.coder = {"huff": CODER_HUFF, "arithmetic": CODER_ARITH, "ascii": CODER_ASCII}[coder]
         self.last_stats = None
 
     def compress(self, data):

@@ -168,10 +168,11 @@ size_t run_pipeline(Ctx& c, const u8* d_text, size_t n, u32 threshold, int flatt
     run_textds(c, d_text, n, A, st, &ev);
     run_factorize(c, n, A, threshold, flatten, st, &ev);
     EncodeStats es;
-    if (!*d_out_io) { out_cap = align_up(encode_bound(n) + 16, 8); *d_out_io = c.arena.get<u8>(out_cap); }
+    const int enc_coder = coder == TDC_GPU_CODER_ARITH ? 1 : (coder == TDC_GPU_CODER_ASCII ? 2 : 0);
+    if (!*d_out_io) { out_cap = align_up(encode_bound_coder(n, enc_coder) + 16, 8); *d_out_io = c.arena.get<u8>(out_cap); }
     u8* d_out = *d_out_io;
     const int e0 = ev.tick();
-    const size_t out_len = encode_stream(c, d_text, n, A.fs, coder == TDC_GPU_CODER_ARITH ? 1 : 0, d_out, out_cap, &es);
+    const size_t out_len = encode_stream(c, d_text, n, A.fs, enc_coder, d_out, out_cap, &es);
     const int e1 = ev.tick();
     HIP_TRY(hipStreamSynchronize(c.stream));
     if (st) {
@@ -311,7 +312,7 @@ size_t tdc_gpu_lcpcomp_bound(size_t n) { return align_up(encode_bound(n) + 16, 8
 int tdc_gpu_lcpcomp_compress_dev(tdc_gpu_ctx* ctx, const void* d_text, size_t n, uint32_t threshold, int flatten, int coder,
                                  void* d_out, size_t out_cap, size_t* out_len, tdc_gpu_stats* stats) {
     return guarded(ctx, [&] {
-        if (coder != TDC_GPU_CODER_HUFF && coder != TDC_GPU_CODER_ARITH) throw ArgError{TDC_GPU_ERR_UNSUPPORTED, "lcpcomp: coder must be huff or arithmetic"};
+        if (coder != TDC_GPU_CODER_HUFF && coder != TDC_GPU_CODER_ARITH && coder != TDC_GPU_CODER_ASCII) throw ArgError{TDC_GPU_ERR_UNSUPPORTED, "lcpcomp: coder must be huff, arithmetic or ascii"};
         check_text_args(d_text, n);
         if (!d_out || !out_len || ((uintptr_t)d_out & 7)) throw ArgError{TDC_GPU_ERR_ARG, "d_out must be non-NULL and 8-byte aligned"};
         Ctx& c = ctx->c;
@@ -330,7 +331,7 @@ int tdc_gpu_lcpcomp_compress_dev(tdc_gpu_ctx* ctx, const void* d_text, size_t n,
 int tdc_gpu_lcpcomp_compress(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, uint32_t threshold, int flatten, int coder,
                              uint8_t** out, size_t* out_len, tdc_gpu_stats* stats) {
     return guarded(ctx, [&] {
-        if (coder != TDC_GPU_CODER_HUFF && coder != TDC_GPU_CODER_ARITH) throw ArgError{TDC_GPU_ERR_UNSUPPORTED, "lcpcomp: coder must be huff or arithmetic"};
+        if (coder != TDC_GPU_CODER_HUFF && coder != TDC_GPU_CODER_ARITH && coder != TDC_GPU_CODER_ASCII) throw ArgError{TDC_GPU_ERR_UNSUPPORTED, "lcpcomp: coder must be huff, arithmetic or ascii"};
         check_text_args(text, n);
         if (!out || !out_len) throw ArgError{TDC_GPU_ERR_ARG, "out/out_len is NULL"};
         if (text[n - 1] != 0) throw ArgError{TDC_GPU_ERR_NO_SENTINEL, "text does not end with a 0 sentinel"};
@@ -357,7 +358,7 @@ int tdc_gpu_lcpcomp_compress(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, ui
 int tdc_gpu_lcpcomp_compress_raw(tdc_gpu_ctx* ctx, const uint8_t* data, size_t n, uint32_t threshold, int flatten, int coder,
                                  uint8_t** out, size_t* out_len, tdc_gpu_stats* stats) {
     return guarded(ctx, [&] {
-        if (coder != TDC_GPU_CODER_HUFF && coder != TDC_GPU_CODER_ARITH) throw ArgError{TDC_GPU_ERR_UNSUPPORTED, "lcpcomp: coder must be huff or arithmetic"};
+        if (coder != TDC_GPU_CODER_HUFF && coder != TDC_GPU_CODER_ARITH && coder != TDC_GPU_CODER_ASCII) throw ArgError{TDC_GPU_ERR_UNSUPPORTED, "lcpcomp: coder must be huff, arithmetic or ascii"};
         if ((!data && n) || !out || !out_len) throw ArgError{TDC_GPU_ERR_ARG, "NULL argument"};
         if (n >= (1ull << 30)) throw ArgError{TDC_GPU_ERR_TOO_LARGE, "raw input must be < 2^30 bytes (the escaped text must stay < 2^31)"};
         Ctx& c = ctx->c;
@@ -610,6 +611,10 @@ int tdc_gpu_encode_arith(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, const 
                          const uint32_t* len, size_t z, uint8_t** out, size_t* out_len) {
     return encode_entry(ctx, 1, text, n, pos, src, len, z, out, out_len);
 }
+int tdc_gpu_encode_ascii(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, const uint32_t* pos, const uint32_t* src,
+                         const uint32_t* len, size_t z, uint8_t** out, size_t* out_len) {
+    return encode_entry(ctx, 2, text, n, pos, src, len, z, out, out_len);
+}
 static int encode_entry(tdc_gpu_ctx* ctx, int coder, const uint8_t* text, size_t n, const uint32_t* pos, const uint32_t* src,
                         const uint32_t* len, size_t z, uint8_t** out, size_t* out_len) {
     return guarded(ctx, [&] {
@@ -630,7 +635,7 @@ static int encode_entry(tdc_gpu_ctx* ctx, int coder, const uint8_t* text, size_t
             HIP_TRY(hipMemcpyAsync(d_len, len, z * 4, hipMemcpyHostToDevice, c.stream));
         }
         scatter_factors(c, n, d_pos, d_src, d_len, z, fs);
-        const size_t cap = tdc_gpu_lcpcomp_bound(n);
+        const size_t cap = align_up(encode_bound_coder(n, coder) + 16, 8);
         u8* d_out = c.arena.get<u8>(cap);
         const size_t l = encode_stream(c, d_text, n, fs, coder, d_out, cap, nullptr);
         uint8_t* h = host_alloc<uint8_t>(l);

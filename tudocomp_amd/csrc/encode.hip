@@ -33,7 +33,16 @@ struct CodeTable {
 struct EncParams {
     u32 W, lbits, dbits, flen_min;
     u32 raw_literals;     // sigma <= 1: literals are written as 8 raw bits (HuffmanCoder.hpp:565-566)
+    u32 ascii;            // ASCIICoder (coders/ASCIICoder.hpp:29-50): decimal integers + ':', '0'/'1', raw literals, no "- min"
 };
+
+// number of characters ASCIICoder writes for an integer: its decimal digits and the ':'
+__device__ __forceinline__ u32 ascii_int_chars(u32 v) {
+    u32 d = 1;
+    if (v >= 1000000000u) d = 10; else if (v >= 100000000u) d = 9; else if (v >= 10000000u) d = 8; else if (v >= 1000000u) d = 7;
+    else if (v >= 100000u) d = 6; else if (v >= 10000u) d = 5; else if (v >= 1000u) d = 4; else if (v >= 100u) d = 3; else if (v >= 10u) d = 2;
+    return d + 1;
+}
 
 struct EncScalars { u32 flen_min, flen_max, fdist_max, pad; };
 
@@ -96,7 +105,13 @@ __global__ __launch_bounds__(256) void literal_hist_kernel(const u8* __restrict_
 
 // bits contributed by position p (see file header)
 __device__ __forceinline__ u32 position_cost(u32 own, u32 own_prev, bool first, u32 fl, u8 ch, u32 p, const u8* __restrict__ clen,
+                                             const u32* __restrict__ fsrc,
                                              const EncParams& P, const ArithDev& A) {
+    if (P.ascii) {
+        if (own == NONE32) return 8u + (fl ? 8u * (1u + ascii_int_chars(fl)) : 0u);
+        if (own == p) return ((first || own_prev != NONE32) ? 8u : 0u) + 8u * (ascii_int_chars(fsrc[p]) + ascii_int_chars(fl));
+        return 0u;
+    }
     if (own == NONE32) {
         u32 c;
         if (A.litidx) { const u32 k = A.litidx[p]; c = (A.amark[k] ? 64u : 0u) + (k == A.lc_index ? 128u : 0u); }
@@ -113,7 +128,7 @@ __device__ __forceinline__ u32 position_cost(u32 own, u32 own_prev, bool first, 
 }
 
 __global__ __launch_bounds__(256) void tile_bits_kernel(const u8* __restrict__ text, const u32* __restrict__ owner,
-                                                         const u32* __restrict__ flen, size_t n, CodeTable tab, EncParams P,
+                                                         const u32* __restrict__ flen, const u32* __restrict__ fsrc, size_t n, CodeTable tab, EncParams P,
                                                          ArithDev A, u64* __restrict__ tile_bits) {
     __shared__ u8 clen[256];
     __shared__ u32 sm[4];
@@ -128,7 +143,7 @@ __global__ __launch_bounds__(256) void tile_bits_kernel(const u8* __restrict__ t
             const size_t p = p0 + j;
             if (p < n) {
                 const u32 own = owner[p];
-                sum += position_cost(own, prev, p == 0, flen[p], text[p], (u32)p, clen, P, A);
+                sum += position_cost(own, prev, p == 0, flen[p], text[p], (u32)p, clen, fsrc, P, A);
                 prev = own;
             }
         }
@@ -171,6 +186,19 @@ struct BitSink {
     }
 };
 
+// ASCIICoder::Encoder::encode(v, Range) (ASCIICoder.hpp:33-39): decimal digits, most significant first, then ':'
+__device__ __forceinline__ void append_ascii_int(BitSink& sink, u32 v) {
+    u32 pw = 1000000000u;
+    bool started = false;
+    for (int i = 0; i < 10; ++i) {
+        const u32 d = v / pw;
+        if (d || started || pw == 1u) { sink.append('0' + d, 8); started = true; }
+        v -= d * pw;
+        pw /= 10u;
+    }
+    sink.append(':', 8);
+}
+
 __global__ __launch_bounds__(256) void pack_kernel(const u8* __restrict__ text, const u32* __restrict__ owner,
                                                     const u32* __restrict__ flen, const u32* __restrict__ fsrc, size_t n,
                                                     CodeTable tab, EncParams P, ArithDev A, const u64* __restrict__ tile_off,
@@ -193,7 +221,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const u8* __restrict__ text, 
             const size_t p = p0 + j;
             if (p < n) {
                 own[j] = owner[p]; fl[j] = flen[p]; ch[j] = text[p];
-                sum += position_cost(own[j], prev, p == 0, fl[j], ch[j], (u32)p, clen, P, A);
+                sum += position_cost(own[j], prev, p == 0, fl[j], ch[j], (u32)p, clen, fsrc, P, A);
                 prev = own[j];
             } else { own[j] = 0; fl[j] = 0; ch[j] = 0; }
         }
@@ -212,7 +240,16 @@ __global__ __launch_bounds__(256) void pack_kernel(const u8* __restrict__ text, 
         const size_t p = p0 + j;
         if (p < n) {
             const u32 o = own[j];
-            if (o == NONE32) {
+            if (P.ascii) {
+                if (o == NONE32) {
+                    if (fl[j]) { sink.append('1', 8); append_ascii_int(sink, fl[j]); }
+                    sink.append(ch[j], 8);
+                } else if (o == (u32)p) {
+                    if (p == 0 || prev != NONE32) sink.append('0', 8);
+                    append_ascii_int(sink, fsrc[p]);
+                    append_ascii_int(sink, fl[j]);                                           // no "- flen_min" (ASCIICoder ignores the range)
+                }
+            } else if (o == NONE32) {
                 if (fl[j]) { sink.append(1, 1); sink.append(fl[j], P.dbits); }           // LZSSCoding.hpp:62-68, :83-86
                 if (A.litidx) {                                                           // ArithmeticCoder.hpp:96-104, :151-155
                     const u32 k = A.litidx[p];
@@ -241,7 +278,10 @@ __global__ void terminator_kernel(u8* out, u64 total_bits) {
     else out[byte + 1] = (u8)u;
 }
 
-size_t encode_bound(size_t n) { return 12 * n + 4096; }     // worst case per position: 1 + 32 bits of run header + 64 (+128 once) of arithmetic words
+// worst case per position: 1 + 32 bits of run header + 64 (+128 once) of arithmetic words; ASCIICoder (coder 2): a one-byte
+// factor costs '0' + two integers of up to 10 digits and ':' each
+size_t encode_bound(size_t n) { return 12 * n + 4096; }
+size_t encode_bound_coder(size_t n, int coder) { return (coder == 2 ? 24 : 12) * n + 4096; }
 
 size_t encode_huff(Ctx& c, const u8* text, size_t n, FactorSpace fs, u8* d_out, size_t out_cap, EncodeStats* st) {
     return encode_stream(c, text, n, fs, 0, d_out, out_cap, st);
@@ -290,7 +330,9 @@ size_t encode_stream(Ctx& c, const u8* text, size_t n, FactorSpace fs, int coder
     HuffTable ht;
     HostBitWriter hw;
     ArithDev A = { nullptr, nullptr, nullptr, 0, 0 };
-    if (coder == 0) {
+    if (coder == 2) {
+        memset(&ht, 0, sizeof(ht));                                        // ASCIICoder writes no header
+    } else if (coder == 0) {
         build_huffman_table(h_hist, &ht);
         write_huffman_header(hw, ht);
     } else {
@@ -307,10 +349,21 @@ size_t encode_stream(Ctx& c, const u8* text, size_t n, FactorSpace fs, int coder
     P.dbits = bits_for(h_sc.fdist_max);
     P.flen_min = h_sc.flen_min;
     P.raw_literals = (ht.sigma <= 1) ? 1u : 0u;
-    hw.write_int(n, 32);
-    hw.write_int(h_sc.flen_min, P.W);
-    hw.write_int(h_sc.flen_max, P.W);
-    hw.write_int(h_sc.fdist_max, P.W);
+    P.ascii = (coder == 2) ? 1u : 0u;
+    if (coder == 2) {
+        const u64 fields[4] = { (u64)n, h_sc.flen_min, h_sc.flen_max, h_sc.fdist_max };
+        for (u64 v : fields) {
+            char tmp[24]; int k = 0;
+            do { tmp[k++] = (char)('0' + v % 10); v /= 10; } while (v);
+            while (k) hw.write_int((u8)tmp[--k], 8);
+            hw.write_int(':', 8);
+        }
+    } else {
+        hw.write_int(n, 32);
+        hw.write_int(h_sc.flen_min, P.W);
+        hw.write_int(h_sc.flen_max, P.W);
+        hw.write_int(h_sc.fdist_max, P.W);
+    }
     const u64 base_bits = hw.nbits;
     CodeTable tab;
     memcpy(tab.code, ht.code_of, sizeof(tab.code));
@@ -322,7 +375,7 @@ size_t encode_stream(Ctx& c, const u8* text, size_t n, FactorSpace fs, int coder
     u64* d_total = c.arena.get<u64>(1);
     {
         Ctx::ProfScope prof(c, K_ENC_TILE_BITS, (u64)n * 9);
-        tile_bits_kernel<<<tiles, 256, 0, s>>>(text, fs.owner, fs.flen, n, tab, P, A, tile_bits);
+        tile_bits_kernel<<<tiles, 256, 0, s>>>(text, fs.owner, fs.flen, fs.fsrc, n, tab, P, A, tile_bits);
         LAUNCH_CHECK();
     }
     exclusive_sum_u64(c, tile_bits, tile_bits, tiles, d_total);

@@ -69,11 +69,13 @@ struct EncodeStats { u64 factors = 0; u64 flen_min = 0, flen_max = 0, fdist_max 
 // Writes the complete stream (incl. terminator) to d_out (capacity out_cap bytes); returns its length.
 // fs.flen is modified (literal-run lengths are stored at run starts).
 size_t encode_huff(Ctx& c, const u8* text, size_t n, FactorSpace fs, u8* d_out, size_t out_cap, EncodeStats* st);
-// the same with a selectable literal coder: 0 = HuffmanCoder, 1 = ArithmeticCoder (a15: coders/ArithmeticCoder.hpp:35-177)
+// the same with a selectable coder: 0 = HuffmanCoder, 1 = ArithmeticCoder (a15: coders/ArithmeticCoder.hpp:35-177),
+// 2 = ASCIICoder (coders/ASCIICoder.hpp:29-50; every integer and bit of the token stream as text)
 size_t encode_stream(Ctx& c, const u8* text, size_t n, FactorSpace fs, int coder, u8* d_out, size_t out_cap, EncodeStats* st);
 
 // worst-case output size of encode_huff for a text of n bytes
 size_t encode_bound(size_t n);
+size_t encode_bound_coder(size_t n, int coder);    // coder as in encode_stream (2 = ASCIICoder needs twice as much)
 
 struct LzssStats { u64 factors = 0; };
 // a18: compressors/LZSSLCPCompressor.hpp:60-115 (lzss_lcp): greedy LZ77 parse from the previous / next smaller values of

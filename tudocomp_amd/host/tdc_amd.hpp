@@ -253,6 +253,47 @@ inline void lzss_huff_decode(Input& input, Output& output) {
     output.write(text.data(), text.size());
 }
 
+// ASCIICoder::Decoder (coders/ASCIICoder.hpp:53-84) + the same token stream: integers are decimal digits up to the first
+// non-digit (':'), a bit is any byte but '0', literals are raw bytes; the BitOStream terminator byte ends the stream.
+inline void lzss_ascii_decode(Input& input, Output& output) {
+    const bytes& in = input.raw();
+    if (in.empty()) throw std::runtime_error("corrupt stream: empty");
+    const size_t len = in.size() - 1;
+    size_t at = 0;
+    auto read_int = [&]() -> uint64_t {
+        uint64_t v = 0; int digits = 0;
+        while (at < len) {
+            const uint8_t ch = in[at++];
+            if (ch < '0' || ch > '9') { if (!digits) break; return v; }
+            v = v * 10 + (ch - '0'); ++digits;
+        }
+        throw std::runtime_error("corrupt stream: integer expected");
+    };
+    const uint64_t n = read_int();
+    read_int(); read_int(); read_int();                        // flen_min, flen_max, fdist_max: not needed by this coder
+    bytes text(n);
+    std::vector<uint32_t> ref(n, 0xFFFFFFFFu);
+    uint64_t p = 0;
+    while (at < len) {
+        uint64_t num = (in[at++] != '0') ? read_int() : 0;
+        if (p + num > n || at + num > len) throw std::runtime_error("corrupt stream: too many literals");
+        while (num--) text[p++] = in[at++];
+        if (at < len) {
+            const uint64_t src = read_int(), l = read_int();
+            if (p + l > n || src + l > n) throw std::runtime_error("corrupt stream: factor out of range");
+            for (uint64_t j = 0; j < l; ++j) ref[p + j] = (uint32_t)(src + j);
+            p += l;
+        }
+    }
+    if (p != n) throw std::runtime_error("corrupt stream: length mismatch");
+    for (uint64_t i = 0; i < n; ++i) {
+        uint32_t q = (uint32_t)i; uint64_t guard = 0;
+        while (ref[q] != 0xFFFFFFFFu) { q = ref[q]; if (++guard > n) throw std::runtime_error("corrupt stream: reference cycle"); }
+        text[i] = text[q];
+    }
+    output.write(text.data(), text.size());
+}
+
 class LCPCompressor : public Compressor {
     AlgorithmValue m_opts;
     std::shared_ptr<GpuContext> m_ctx;       // created lazily by the first compress(): decompress() needs no GPU
@@ -266,9 +307,9 @@ public:
         const std::string coder = m_opts.get("coder", ""), comp = m_opts.get("comp", "arrays");
         // `arithmetic` is not in the reference's lcpcomp registry (etc/registry_config.py:138-142) but the template
         // instantiates; BASELINE.json configs[2] asks for it, compress side only
-        if ((coder != "huff" && coder != "arithmetic") || (comp != "arrays" && comp != "arrays()"))
+        if ((coder != "huff" && coder != "arithmetic" && coder != "ascii") || (comp != "arrays" && comp != "arrays()"))
             throw std::runtime_error("No implementation found for compressor lcpcomp(coder=" + coder + ",comp=" + comp + ")");   // Registry.hpp:214
-        m_coder = (coder == "huff") ? TDC_GPU_CODER_HUFF : TDC_GPU_CODER_ARITH;
+        m_coder = (coder == "huff") ? TDC_GPU_CODER_HUFF : (coder == "ascii" ? TDC_GPU_CODER_ASCII : TDC_GPU_CODER_ARITH);
     }
     InputRestrictions input_restrictions() const override { return {true, true}; }   // uses_textds (Meta.hpp:277-282)
 
@@ -285,6 +326,7 @@ public:
     }
 
     void decompress(Input& input, Output& output) override {
+        if (m_coder == TDC_GPU_CODER_ASCII) { lzss_ascii_decode(input, output); return; }
         if (m_coder != TDC_GPU_CODER_HUFF)
             throw std::runtime_error("lcpcomp(coder=arithmetic) streams cannot be decoded (neither can the reference: "
                                      "consuming coders corrupt interleaved streams, docs/Documentation.md:1190-1203)");
