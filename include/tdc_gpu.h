@@ -131,6 +131,15 @@ int tdc_gpu_lcpcomp_factorize(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, u
 /* FactorBuffer::flatten on a caller-supplied factor list sorted by pos (LZSSFactors.hpp:79-132); src rewritten in place */
 int tdc_gpu_flatten(tdc_gpu_ctx* ctx, size_t n, const uint32_t* pos, uint32_t* src, const uint32_t* len, size_t z,
                     uint64_t* num_flattened, uint64_t* max_depth_lb);
+/* ---- LCPCompressor::decompress (LCPCompressor.hpp:140-150 -> decode_text_internal :23-76, HuffmanCoder::Decoder
+ * coders/HuffmanCoder.hpp:572-612); lzss_lcp(coder=huff) streams have the same format (LZSSLCPCompressor.hpp:125-130).
+ * The token stream is parsed on the host (it has no synchronisation points); the references -- what ScanDec / CompactDec
+ * spend their time on (lcpcomp/decompress/ScanDec.hpp:146-247) -- are resolved on the device by pointer jumping.
+ * *out (malloc'd, free with tdc_gpu_free) receives the escaped, 0-terminated text exactly as compress() was given it.
+ * factors / rounds (nullable): number of factors in the stream / pointer-jumping rounds.  Malformed input: TDC_GPU_ERR_ARG. */
+int tdc_gpu_lcpcomp_decompress(tdc_gpu_ctx* ctx, const uint8_t* stream, size_t len, uint8_t** out, size_t* out_len,
+                               uint64_t* factors, uint32_t* rounds);
+
 /* HuffmanCoder::Encoder + lzss::encode_text on a caller-supplied factor list sorted by pos (LZSSCoding.hpp:18-92) */
 int tdc_gpu_encode_huff(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, const uint32_t* pos, const uint32_t* src,
                         const uint32_t* len, size_t z, uint8_t** out, size_t* out_len);

@@ -115,6 +115,19 @@ def test_config0_compress_roundtrip_64KiB(tmp_path):
 
 
 @pytest.mark.gpu
+def test_decompress_on_device(tmp_path):
+    """tdc -d with dec=gpu: host parse, references resolved on the device (tdc_gpu_lcpcomp_decompress)."""
+    data = T.gen_english(300_000, 8).tobytes() + bytes([0, 255, 0])
+    payload, _ = O.lcpcomp_huff_compress(O.escape(data), 2, 0)
+    f = tmp_path / "g.tdc"
+    f.write_bytes(b"lcpcomp(coder=huff,threshold=2,dec=gpu)%" + payload)
+    out = tmp_path / "g.out"
+    r = _run("-d", "-o", str(out), str(f))
+    assert r.returncode == 0, r.stderr
+    assert out.read_bytes() == data
+
+
+@pytest.mark.gpu
 def test_config3_lz78_gamma_cli(tmp_path):
     data = T.gen_english(65536, 42).tobytes()
     f = tmp_path / "e.txt"

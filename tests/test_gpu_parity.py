@@ -283,3 +283,37 @@ def test_lcpcomp_ascii_coder(gpu_ctx):
     want, _ = O.encode_ascii(text, f)
     assert gpu_ctx.encode_ascii(text, f["pos"], f["src"], f["len"]) == want
     assert O.lcpcomp_ascii_decompress(want) == text
+
+
+def test_device_decompress(gpu_ctx):
+    """LCPCompressor::decompress with the references resolved on the device (SURVEY 8f #2): oracle streams and GPU streams
+    decode to the escaped text; lzss_lcp streams share the format; malformed input is rejected, not crashed on."""
+    cases = [c for c in SMALL] + [("english_1M", T.gen_english(1 << 20, 42).tobytes()), ("dna_300k", T.gen_dna(300_000, 7).tobytes())]
+    for name, data in cases:
+        text = O.escape(data)
+        for thr, fl in ((1, 1), (2, 0), (5, 1)):
+            stream, _ = O.lcpcomp_huff_compress(text, thr, fl)
+            try:
+                decodable = O.lcpcomp_huff_decompress(stream) == text
+            except RuntimeError:
+                decodable = False
+            if not decodable:
+                # 256 literal codes of one length overflow the reference's u8 counters (HuffmanCoder.hpp:173-187): the
+                # reference cannot decode such a stream either; the device path must fail cleanly or agree with it
+                try:
+                    gpu_ctx.lcpcomp_decompress(stream)
+                except T.TdcGpuError:
+                    pass
+                continue
+            back, st = gpu_ctx.lcpcomp_decompress(stream)
+            assert back == text, "%s t=%d flatten=%d" % (name, thr, fl)
+        s2, _ = O.lzss_lcp_huff_compress(text, 3)
+        assert gpu_ctx.lcpcomp_decompress(s2)[0] == text, name
+    data = T.gen_english(1 << 24, 42)
+    text = np.concatenate([data, np.zeros(1, dtype=np.uint8)]).tobytes()
+    got, cst = gpu_ctx.lcpcomp_compress(text, 2, 0)                     # unflattened: deep source chains
+    back, st = gpu_ctx.lcpcomp_decompress(got)
+    assert back == text and st["factors"] == cst["factors"] and st["rounds"] >= 2
+    for bad in (b"", b"\x00", got[:1000], got[:len(got) // 2] + b"\x05"):
+        with pytest.raises(T.TdcGpuError):
+            gpu_ctx.lcpcomp_decompress(bad)

@@ -17,6 +17,7 @@ SYMBOLS = [
     "tdc_gpu_lcpcomp_bound",
     "tdc_gpu_lz78_compress", "tdc_gpu_lzss_lcp_compress", "tdc_gpu_lzss_lcp_factorize",
     "tdc_gpu_suffix_array", "tdc_gpu_textds", "tdc_gpu_lcpcomp_factorize", "tdc_gpu_flatten", "tdc_gpu_encode_huff",
+    "tdc_gpu_lcpcomp_decompress",
     "tdc_gpu_encode_arith",
     "tdc_gpu_encode_ascii",
     "tdc_escape", "tdc_unescape", "tdc_huffman_table", "tdc_gen_english", "tdc_gen_dna",
@@ -80,6 +81,7 @@ def load():
     L.tdc_gpu_lcpcomp_factorize.argtypes = [vp, vp, sz, u32, i32, pvp, pvp, pvp, psz, ctypes.POINTER(Stats)]
     L.tdc_gpu_flatten.argtypes = [vp, sz, vp, vp, vp, sz, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
     L.tdc_gpu_encode_huff.argtypes = [vp, vp, sz, vp, vp, vp, sz, pvp, psz]
+    L.tdc_gpu_lcpcomp_decompress.argtypes = [vp, vp, sz, pvp, psz, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32)]
     L.tdc_gpu_encode_arith.argtypes = [vp, vp, sz, vp, vp, vp, sz, pvp, psz]
     L.tdc_gpu_encode_ascii.argtypes = [vp, vp, sz, vp, vp, vp, sz, pvp, psz]
     L.tdc_escape.argtypes = [vp, sz, vp]

@@ -601,6 +601,23 @@ int tdc_gpu_flatten(tdc_gpu_ctx* ctx, size_t n, const uint32_t* pos, uint32_t* s
     });
 }
 
+int tdc_gpu_lcpcomp_decompress(tdc_gpu_ctx* ctx, const uint8_t* stream, size_t len, uint8_t** out, size_t* out_len,
+                               uint64_t* factors, uint32_t* rounds) {
+    return guarded(ctx, [&] {
+        if (!stream || !out || !out_len) throw ArgError{TDC_GPU_ERR_ARG, "NULL argument"};
+        std::vector<u8> text;
+        DecodeStats ds;
+        size_t n = 0;
+        try { n = decode_lzss_huff(ctx->c, stream, len, text, &ds); }
+        catch (const StreamFormatError& e) { throw ArgError{TDC_GPU_ERR_ARG, e.what}; }
+        uint8_t* h = host_alloc<uint8_t>(n);
+        if (n) memcpy(h, text.data(), n);
+        *out = h; *out_len = n;
+        if (factors) *factors = ds.factors;
+        if (rounds) *rounds = ds.rounds;
+    });
+}
+
 static int encode_entry(tdc_gpu_ctx* ctx, int coder, const uint8_t* text, size_t n, const uint32_t* pos, const uint32_t* src,
                         const uint32_t* len, size_t z, uint8_t** out, size_t* out_len);
 int tdc_gpu_encode_huff(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, const uint32_t* pos, const uint32_t* src,

@@ -330,6 +330,18 @@ public:
         if (m_coder != TDC_GPU_CODER_HUFF)
             throw std::runtime_error("lcpcomp(coder=arithmetic) streams cannot be decoded (neither can the reference: "
                                      "consuming coders corrupt interleaved streams, docs/Documentation.md:1190-1203)");
+        // dec=gpu (an addition to the reference's decoder strategies scan / compact / ..., LCPCompressor.hpp:88): the stream is
+        // parsed on the host, the references are resolved on the device (tdc_gpu_lcpcomp_decompress)
+        if (m_opts.get("dec", "scan") == "gpu") {
+            if (!m_ctx) m_ctx = std::make_shared<GpuContext>(m_device);
+            const bytes& in = input.raw();
+            uint8_t* out = nullptr; size_t out_len = 0;
+            const int rc = tdc_gpu_lcpcomp_decompress(m_ctx->h, in.data(), in.size(), &out, &out_len, nullptr, nullptr);
+            if (rc) throw std::runtime_error(std::string(tdc_gpu_strerror(rc)) + ": " + tdc_gpu_last_error(m_ctx->h));
+            output.write(out, out_len);
+            tdc_gpu_free(out);
+            return;
+        }
         lzss_huff_decode(input, output);
     }
 };
