@@ -100,7 +100,7 @@ struct Ctx {
     int xcd_remap = 0;             // XCD-contiguous tile walk (env TDC_GPU_XCD_REMAP): 0 = only in the final pass of the bucketed scatter
                                    // (-1.2 ms of 7.3), 1 = also in the radix sort kernels (measured: no gain), 2 = nowhere
     int window_lcut = 48;          // factorize: levels <= this run window-local in one launch (env TDC_GPU_WINDOW_LCUT, 0 disables)
-    int window_threads = 256;      // threads per window workgroup (env TDC_GPU_WINDOW_THREADS = 256 | 512)
+    int window_large_lists = 0;    // window pass: start with the large per-level lists (env TDC_GPU_WINDOW_LARGE=1; tests)
     int bucket_scatter = 1;        // big random scatters (rank, Phi) go through one radix partition by destination window (env TDC_GPU_BUCKET_SCATTER=0 disables)
 
     bool profiling = false;

@@ -41,15 +41,25 @@ constexpr int TW = 16384;            // window positions
 #endif
 constexpr int TH = TDC_WIN_TH;       // halo on either side
 constexpr int TI = TW - 2 * TH;      // interior positions per window
-constexpr int TPAD = 8;              // bytes of padding behind every thread's chunk of the position-indexed LDS arrays
-#ifndef TDC_WIN_TE
-#define TDC_WIN_TE 1024
-#endif
-#ifndef TDC_WIN_TP
-#define TDC_WIN_TP 512
-#endif
-constexpr int TE = TDC_WIN_TE;       // alive entries per level and window
-constexpr int TP = TDC_WIN_TP;       // pushes per level and window
+constexpr int TT = 256;              // threads per workgroup
+constexpr int TCH = TW / TT;         // consecutive window positions per thread in the dense passes (64)
+constexpr int NWV = TT / 64;
+// Two sizes of the per-level LDS lists (alive entries / pushes per level and window).  The small one leaves 40 KB of LDS
+// per workgroup, i.e. four workgroups per CU -- the kernel is latency bound, so its throughput follows the number of
+// resident workgroups; the large one (one workgroup per CU) takes over if a level overflows the small lists, e.g. on
+// texts with a random background, where a third of all positions sit in one level.
+constexpr int TE_SMALL = 512, TP_SMALL = 384;
+constexpr int TE_LARGE = 8192, TP_LARGE = 4096;
+
+// Position q of the window lives at byte PA(q) of the position-indexed LDS arrays.  A thread's dense passes read "its"
+// 64-byte chunk with 8-byte loads; rotating the 16 words of chunk t by 2*(t>>2) words puts the 64 lanes' loads on 64
+// different banks without any padding.
+__device__ __forceinline__ int PA(int q) {
+    const int t = q >> 6, w = (q >> 2) & 15;
+    return (t << 6) + (((w + 2 * (t >> 2)) & 15) << 2) + (q & 3);
+}
+// byte offset of the k-th 8-byte word (k = 0..7) of thread t's chunk
+__device__ __forceinline__ int PW(int t, int k) { return (t << 6) + (((2 * k + 2 * (t >> 2)) & 15) << 2); }
 constexpr int BIG = 1 << 29;
 
 // An entry of the current level, packed so that a neighbour costs ONE LDS read:
@@ -73,7 +83,7 @@ __device__ __forceinline__ u64 e_load(const u64* ent, int i) {
     return *(const volatile u64*)&ent[i];
 }
 
-struct WinScalars { u32 fail; int min_margin; unsigned long long factors; unsigned long long prof[16]; };
+struct WinScalars { u32 fail; int min_margin; unsigned long long factors; u32 max_entries, max_pushes; unsigned long long prof[16]; };
 
 // optional phase timing (compile with -DTDC_WIN_PROF): thread 0 of every workgroup sums s_memrealtime deltas per phase
 #ifdef TDC_WIN_PROF
@@ -93,20 +103,13 @@ struct WinScalars { u32 fail; int min_margin; unsigned long long factors; unsign
 // (the window-local priorities) is ordered by the one full barrier per level.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int TT>      // threads per workgroup (256 or 512)
-__global__ __launch_bounds__(TT) void window_levels_kernel(const u32* __restrict__ cur_g, const u32* __restrict__ prio_g,
+template <int TE, int TP, int WPE>      // list sizes; WPE = waves per SIMD the register budget is set for
+__global__ __launch_bounds__(TT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void window_levels_kernel(const u32* __restrict__ cur_g, const u32* __restrict__ prio_g,
                                                             const u8* __restrict__ res_g, const u32* __restrict__ phi, size_t n,
                                                             u32 lcut, u32 threshold, u32 ntiles, u32* __restrict__ lprio_all,
                                                             u32* __restrict__ flen, u32* __restrict__ fsrc, WinScalars* __restrict__ sc) {
-    // position q lives at byte PA(q): every 64-byte chunk (one thread's share of the dense passes) is followed by 8 bytes
-    // of padding, so the 64 lanes' 8-byte reads of "their" chunks hit 64 different banks (stride 72 B = 18 words)
-    constexpr int TCH = TW / TT;         // consecutive window positions per thread in the dense passes (64 or 32)
-    constexpr int TCS = (TCH == 64) ? 6 : 5;
-    constexpr int NWV = TT / 64;
-    static_assert((1 << TCS) == TCH, "chunk size");
-    __shared__ __attribute__((aligned(16))) u8 cur8[TT * (TCH + TPAD)];
-    __shared__ __attribute__((aligned(16))) u8 res8[TT * (TCH + TPAD)];    // [5:0] list level, bit 6: factor start (then [5:0] = length), bit 7: priority is window-local
-#define PA(q) ((q) + (((q) >> TCS) * TPAD))
+    __shared__ __attribute__((aligned(16))) u8 cur8[TW];
+    __shared__ __attribute__((aligned(16))) u8 res8[TW];    // [5:0] list level, bit 6: factor start (then [5:0] = length), bit 7: priority is window-local
     __shared__ u64 ent[TE];
     __shared__ u64 pkey[TP];
     __shared__ unsigned short pidx[TP];
@@ -181,14 +184,13 @@ __global__ __launch_bounds__(TT) void window_levels_kernel(const u32* __restrict
             const int lo = fl > 0 ? fl : 0, hi = fr < wl ? fr : wl;
             // ---- 1. collect the alive entries of list L in position order --------------------------------------
             const int base = tid * TCH;
-            const int pbase = tid * (TCH + TPAD);
             u64 amask = 0;
             if (base < hi && base + TCH > lo) {
                 const u64 pat = (u64)L * 0x0101010101010101ull;
                 const u64 lo7 = 0x7F7F7F7F7F7F7F7Full;
                 u64 rws[TCH / 8], cws[TCH / 8];
 #pragma unroll
-                for (int k = 0; k < TCH / 8; ++k) { rws[k] = *(const u64*)&res8[pbase + 8 * k]; cws[k] = *(const u64*)&cur8[pbase + 8 * k]; }
+                for (int k = 0; k < TCH / 8; ++k) { rws[k] = *(const u64*)&res8[PW(tid, k)]; cws[k] = *(const u64*)&cur8[PW(tid, k)]; }
 #pragma unroll
                 for (int k = 0; k < TCH / 8; ++k) {
                     const u64 x = (rws[k] & lo7) ^ pat;
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(TT) void window_levels_kernel(const u32* __restrict
                         const int pos = base + 8 * k + bb;
                         if (pos < lo || pos >= hi) continue;                              // unknown: ignored from now on
                         if (((u32)(cws[k] >> (8 * bb)) & 0xFFu) >= threshold) amask |= 1ull << (8 * k + bb);
-                        else res8[pbase + 8 * k + bb] = 0;                                // erased entry (:86)
+                        else res8[PW(tid, k) + bb] = 0;                                   // erased entry (:86)
                     }
                 }
             }
@@ -226,6 +228,9 @@ __global__ __launch_bounds__(TT) void window_levels_kernel(const u32* __restrict
             for (int k = 0; k < NWV; ++k) { const u32 t = wtot[k]; if (k < wv) off += t; total += t; }
             if (total > (u32)TE) { failed = true; break; }
             const int m = (int)total;
+#ifdef TDC_WIN_PROF
+            if (tid == 0) atomicMax(&sc->max_entries, total);
+#endif
             int my_und = 0;
             for (int q = 0; amask; ++q) {
                 const int bit = __builtin_ctzll(amask);
@@ -355,6 +360,9 @@ __global__ __launch_bounds__(TT) void window_levels_kernel(const u32* __restrict
             lds_barrier();
             WPROF(5);
             const int npush = s_npush;
+#ifdef TDC_WIN_PROF
+            if (tid == 0) atomicMax(&sc->max_pushes, (u32)npush);
+#endif
             if (npush > TP) { failed = true; break; }
             // ---- 4. kills; new residence / priority of the pushed entries, every other entry leaves the lists ------
             if (tid == 0) { s_und[0] = 0; s_und[1] = 0; s_und[2] = 0; }
@@ -418,12 +426,12 @@ __global__ __launch_bounds__(TT) void window_levels_kernel(const u32* __restrict
         if (failed || fl > ia || fr < ib) { if (tid == 0) atomicOr(&sc->fail, failed ? 2u : 1u); }   // 2: a fixed LDS list overflowed, 1: known range too small
         else {
             // ---- factor starts of the interior: (pos, Phi[pos], L)  (ArraysComp.hpp:91-96) ---------------------------
-            const int base = tid * TCH, pbase = tid * (TCH + TPAD);
+            const int base = tid * TCH;
             if (base < ib && base + TCH > ia) {
 #pragma unroll
                 for (int k = 0; k < TCH; k += 8) {
-                    u64 w = (*(const u64*)&res8[pbase + k]) & 0x4040404040404040ull;
-                    const u64 rw = *(const u64*)&res8[pbase + k];
+                    const u64 rw = *(const u64*)&res8[PW(tid, k >> 3)];
+                    u64 w = rw & 0x4040404040404040ull;
                     while (w) {
                         const int bb = __builtin_ctzll(w) >> 3;
                         w &= w - 1;
@@ -462,37 +470,41 @@ int factorize_window_levels(Ctx& c, size_t n, const u32* cur, const u32* prio, c
     hipStream_t s = c.stream;
     const size_t mark = c.arena.mark();
     const u32 ntiles = cdiv(n, TI);
-    u32 grid = ntiles < 1536u ? ntiles : 1536u;
+    u32 grid = ntiles < 2048u ? ntiles : 2048u;
     u32* lprio = c.arena.get<u32>((size_t)grid * TW);
     WinScalars* d_sc = (WinScalars*)c.arena.alloc(sizeof(WinScalars));
-    HIP_TRY(hipMemsetAsync(d_sc, 0, sizeof(WinScalars), s));
-    { const int big = BIG; HIP_TRY(hipMemcpyAsync(&d_sc->min_margin, &big, sizeof(int), hipMemcpyHostToDevice, s)); }
-    {
-        // per window position: cur (4) + residence (1); per text position: ~0.3 priority reads and the factor output
-        Ctx::ProfScope prof(c, K_WINDOW_LEVELS, (u64)((double)n * TW / TI * 5) + (u64)n * 2);
-        static const unsigned dyn = getenv("TDC_GPU_WINDOW_DYNLDS") ? (unsigned)atoi(getenv("TDC_GPU_WINDOW_DYNLDS")) : 0u;   // occupancy experiments
-        if (c.window_threads == 512)
-            window_levels_kernel<512><<<grid, 512, dyn, s>>>(cur, prio, res8, phi, n, lcut, threshold, ntiles, lprio, fs.flen, fs.fsrc, d_sc);
-        else
-            window_levels_kernel<256><<<grid, 256, dyn, s>>>(cur, prio, res8, phi, n, lcut, threshold, ntiles, lprio, fs.flen, fs.fsrc, d_sc);
-        LAUNCH_CHECK();
-    }
-    const WinScalars h = c.read(d_sc);
-    c.arena.release(mark);
+    WinScalars h;
+    int result = 0;
+    for (int attempt = c.window_large_lists ? 1 : 0; attempt < 2; ++attempt) {
+        HIP_TRY(hipMemsetAsync(d_sc, 0, sizeof(WinScalars), s));
+        { const int big = BIG; HIP_TRY(hipMemcpyAsync(&d_sc->min_margin, &big, sizeof(int), hipMemcpyHostToDevice, s)); }
+        {
+            // per window position: cur (4) + residence (1); per text position: ~0.3 priority reads and the factor output
+            Ctx::ProfScope prof(c, K_WINDOW_LEVELS, (u64)((double)n * TW / TI * 5) + (u64)n * 2);
+            if (attempt == 0)
+                window_levels_kernel<TE_SMALL, TP_SMALL, 4><<<grid, TT, 0, s>>>(cur, prio, res8, phi, n, lcut, threshold, ntiles, lprio, fs.flen, fs.fsrc, d_sc);
+            else
+                window_levels_kernel<TE_LARGE, TP_LARGE, 1><<<grid, TT, 0, s>>>(cur, prio, res8, phi, n, lcut, threshold, ntiles, lprio, fs.flen, fs.fsrc, d_sc);
+            LAUNCH_CHECK();
+        }
+        h = c.read(d_sc);
 #ifdef TDC_WIN_PROF
-    {
-        static const char* nm[12] = { "wait_prev", "load", "dense", "scan+write", "mis", "resolve", "apply", "tail", "levels", "entries", "rounds", "pushes" };
-        for (int i = 0; i < 12; ++i) fprintf(stderr, "winprof %-10s %llu\n", nm[i], h.prof[i]);
-        fprintf(stderr, "winprof windows %u grid %u min_margin %d fail %u\n", ntiles, grid, h.min_margin, h.fail);
-    }
+        {
+            static const char* nm[12] = { "wait_prev", "load", "dense", "scan+write", "mis", "resolve", "apply", "tail", "levels", "entries", "rounds", "pushes" };
+            for (int i = 0; i < 12; ++i) fprintf(stderr, "winprof %-10s %llu\n", nm[i], h.prof[i]);
+            fprintf(stderr, "winprof windows %u grid %u attempt %d min_margin %d fail %u max_entries %u max_pushes %u\n", ntiles, grid, attempt,
+                    h.min_margin, h.fail, h.max_entries, h.max_pushes);
+        }
 #endif
-    if (h.fail) {
-        window_cleanup_kernel<<<cdiv(n, 256), 256, 0, s>>>(fs.flen, n, lcut);
+        result = (int)h.fail;
+        if (!h.fail) break;
+        window_cleanup_kernel<<<cdiv(n, 256), 256, 0, s>>>(fs.flen, n, lcut);     // forget the factors of the failed pass
         LAUNCH_CHECK();
-        return (int)h.fail;
+        if (!(h.fail & 2u)) break;                                                  // larger lists do not move the borders
     }
-    *nfactors = h.factors;
-    return 0;
+    c.arena.release(mark);
+    if (result == 0) *nfactors = h.factors;
+    return result;
 }
 
 }  // namespace tdc

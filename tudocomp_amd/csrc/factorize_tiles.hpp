@@ -9,7 +9,8 @@ namespace tdc {
 // position; 0 = none; values above lcut are stale).  Nothing of it is modified.  Writes flen / fsrc at the factor
 // starts and returns 0; returns a non-zero reason mask (flen cleaned of the low-level factors again) if some window could
 // not be completed -- bit 0: the known range shrank into an interior (a lower lcut may still work), bit 1: a level had
-// more entries than the fixed LDS lists hold -- in which case the caller runs the global level loop.
+// more entries than even the large LDS lists hold (the pass retries by itself with the large lists when the small ones
+// overflow) -- in which case the caller runs the global level loop.
 int factorize_window_levels(Ctx& c, size_t n, const u32* cur, const u32* prio, const u8* res8, const u32* phi, u32 lcut, u32 threshold,
                              FactorSpace fs, u64* nfactors);
 u32 window_levels_max_lcut();       // one presence bit per level in a 64-bit mask
