@@ -104,12 +104,13 @@ __global__ __launch_bounds__(256) void literal_hist_kernel(const u8* __restrict_
 }
 
 // bits contributed by position p (see file header)
+template <bool ASCII>
 __device__ __forceinline__ u32 position_cost(u32 own, u32 own_prev, bool first, u32 fl, u8 ch, u32 p, const u8* __restrict__ clen,
                                              const u32* __restrict__ fsrc,
                                              const EncParams& P, const ArithDev& A) {
-    if (P.ascii) {
+    if (ASCII) {
         if (own == NONE32) return 8u + (fl ? 8u * (1u + ascii_int_chars(fl)) : 0u);
-        if (own == p) return ((first || own_prev != NONE32) ? 8u : 0u) + 8u * (ascii_int_chars(fsrc[p]) + ascii_int_chars(fl));
+        if (first || own != own_prev) return ((first || own_prev != NONE32) ? 8u : 0u) + 8u * (ascii_int_chars(fsrc[p]) + ascii_int_chars(fl));
         return 0u;
     }
     if (own == NONE32) {
@@ -119,7 +120,7 @@ __device__ __forceinline__ u32 position_cost(u32 own, u32 own_prev, bool first, 
         if (fl) c += 1u + P.dbits;
         return c;
     }
-    if (own == p) {
+    if (first || own != own_prev) {                 // a factor starts where the covering factor changes
         u32 c = P.W + P.lbits;
         if (first || own_prev != NONE32) c += 1u;
         return c;
@@ -127,6 +128,7 @@ __device__ __forceinline__ u32 position_cost(u32 own, u32 own_prev, bool first, 
     return 0u;
 }
 
+template <bool ASCII>
 __global__ __launch_bounds__(256) void tile_bits_kernel(const u8* __restrict__ text, const u32* __restrict__ owner,
                                                          const u32* __restrict__ flen, const u32* __restrict__ fsrc, size_t n, CodeTable tab, EncParams P,
                                                          ArithDev A, u64* __restrict__ tile_bits) {
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(256) void tile_bits_kernel(const u8* __restrict__ t
             const size_t p = p0 + j;
             if (p < n) {
                 const u32 own = owner[p];
-                sum += position_cost(own, prev, p == 0, flen[p], text[p], (u32)p, clen, fsrc, P, A);
+                sum += position_cost<ASCII>(own, prev, p == 0, flen[p], text[p], (u32)p, clen, fsrc, P, A);
                 prev = own;
             }
         }
@@ -199,6 +201,7 @@ __device__ __forceinline__ void append_ascii_int(BitSink& sink, u32 v) {
     sink.append(':', 8);
 }
 
+template <bool ASCII>
 __global__ __launch_bounds__(256) void pack_kernel(const u8* __restrict__ text, const u32* __restrict__ owner,
                                                     const u32* __restrict__ flen, const u32* __restrict__ fsrc, size_t n,
                                                     CodeTable tab, EncParams P, ArithDev A, const u64* __restrict__ tile_off,
@@ -221,7 +224,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const u8* __restrict__ text, 
             const size_t p = p0 + j;
             if (p < n) {
                 own[j] = owner[p]; fl[j] = flen[p]; ch[j] = text[p];
-                sum += position_cost(own[j], prev, p == 0, fl[j], ch[j], (u32)p, clen, fsrc, P, A);
+                sum += position_cost<ASCII>(own[j], prev, p == 0, fl[j], ch[j], (u32)p, clen, fsrc, P, A);
                 prev = own[j];
             } else { own[j] = 0; fl[j] = 0; ch[j] = 0; }
         }
@@ -240,11 +243,11 @@ __global__ __launch_bounds__(256) void pack_kernel(const u8* __restrict__ text, 
         const size_t p = p0 + j;
         if (p < n) {
             const u32 o = own[j];
-            if (P.ascii) {
+            if (ASCII) {
                 if (o == NONE32) {
                     if (fl[j]) { sink.append('1', 8); append_ascii_int(sink, fl[j]); }
                     sink.append(ch[j], 8);
-                } else if (o == (u32)p) {
+                } else if (p == 0 || o != prev) {
                     if (p == 0 || prev != NONE32) sink.append('0', 8);
                     append_ascii_int(sink, fsrc[p]);
                     append_ascii_int(sink, fl[j]);                                           // no "- flen_min" (ASCIICoder ignores the range)
@@ -258,7 +261,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const u8* __restrict__ text, 
                 }
                 else if (P.raw_literals) sink.append(ch[j], 8);                           // HuffmanCoder.hpp:565-566
                 else sink.append(code[ch[j]], clen[ch[j]]);                               // :568 huffman_encode
-            } else if (o == (u32)p) {
+            } else if (p == 0 || o != prev) {
                 if (p == 0 || prev != NONE32) sink.append(0, 1);                          // LZSSCoding.hpp:57-59
                 sink.append(fsrc[p], P.W);                                                // :77
                 sink.append(fl[j] - P.flen_min, P.lbits);                                 // :78
@@ -375,7 +378,8 @@ size_t encode_stream(Ctx& c, const u8* text, size_t n, FactorSpace fs, int coder
     u64* d_total = c.arena.get<u64>(1);
     {
         Ctx::ProfScope prof(c, K_ENC_TILE_BITS, (u64)n * 9);
-        tile_bits_kernel<<<tiles, 256, 0, s>>>(text, fs.owner, fs.flen, fs.fsrc, n, tab, P, A, tile_bits);
+        if (P.ascii) tile_bits_kernel<true><<<tiles, 256, 0, s>>>(text, fs.owner, fs.flen, fs.fsrc, n, tab, P, A, tile_bits);
+        else         tile_bits_kernel<false><<<tiles, 256, 0, s>>>(text, fs.owner, fs.flen, fs.fsrc, n, tab, P, A, tile_bits);
         LAUNCH_CHECK();
     }
     exclusive_sum_u64(c, tile_bits, tile_bits, tiles, d_total);
@@ -389,7 +393,8 @@ size_t encode_stream(Ctx& c, const u8* text, size_t n, FactorSpace fs, int coder
     HIP_TRY(hipMemcpyAsync(d_out, hw.bytes.data(), hw.bytes.size(), hipMemcpyHostToDevice, s));
     {
         Ctx::ProfScope prof(c, K_ENC_PACK, (u64)n * 9 + (u64)z * 4 + out_len);
-        pack_kernel<<<tiles, 256, 0, s>>>(text, fs.owner, fs.flen, fs.fsrc, n, tab, P, A, tile_bits, base_bits, (u64*)d_out);
+        if (P.ascii) pack_kernel<true><<<tiles, 256, 0, s>>>(text, fs.owner, fs.flen, fs.fsrc, n, tab, P, A, tile_bits, base_bits, (u64*)d_out);
+        else         pack_kernel<false><<<tiles, 256, 0, s>>>(text, fs.owner, fs.flen, fs.fsrc, n, tab, P, A, tile_bits, base_bits, (u64*)d_out);
         LAUNCH_CHECK();
     }
     terminator_kernel<<<1, 64, 0, s>>>(d_out, total_bits);

@@ -9,12 +9,15 @@
 #include "stages.hpp"
 #include "prim.hpp"
 
+#include <stdlib.h>
+
 namespace tdc {
 
 __global__ void fstart_flag_kernel(const u32* __restrict__ flen, const u32* __restrict__ owner, size_t n, u32* __restrict__ flag) {
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
-    flag[p] = (flen[p] != 0 && owner[p] == (u32)p) ? 1u : 0u;
+    const u32 o = owner[p];                                     // a factor starts where the covering factor changes
+    flag[p] = (flen[p] != 0 && o != NONE32 && (p == 0 || owner[p - 1] != o)) ? 1u : 0u;
 }
 __global__ void fstart_scatter_kernel(const u32* __restrict__ flen, const u32* __restrict__ owner, const u32* __restrict__ fsrc,
                                       const u32* __restrict__ offs, size_t n, size_t cap, u32* __restrict__ pos,
@@ -22,7 +25,8 @@ __global__ void fstart_scatter_kernel(const u32* __restrict__ flen, const u32* _
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     const u32 l = flen[p];
-    if (l != 0 && owner[p] == (u32)p) {
+    const u32 ow = owner[p];
+    if (l != 0 && ow != NONE32 && (p == 0 || owner[p - 1] != ow)) {
         const u32 o = offs[p];
         if (o < cap) {
             pos[o] = (u32)p;
@@ -54,7 +58,7 @@ size_t extract_factors(Ctx& c, size_t n, FactorSpace fs, u32* pos, u32* src, u32
     return z;
 }
 
-// ---- owner[] from the factor starts ------------------------------------------------------------------------------
+// ---- owner[] from the factor starts: owner[q] = index (in position order) of the factor covering q ------------------
 __global__ void owner_flag_kernel(const u32* __restrict__ flen, size_t n, u32* __restrict__ flag, u32* __restrict__ owner) {
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
@@ -71,7 +75,7 @@ __global__ void owner_fill_kernel(const u32* __restrict__ pos, size_t z, const u
     const u32 sub = threadIdx.x % G;
     if (i >= z) return;
     const u32 p = pos[i], l = flen[p];
-    for (u32 j = sub; j < l && (size_t)p + j < n; j += G) owner[p + j] = p;
+    for (u32 j = sub; j < l && (size_t)p + j < n; j += G) owner[p + j] = (u32)i;
 }
 
 void build_owner(Ctx& c, size_t n, FactorSpace& fs) {
@@ -119,7 +123,7 @@ __global__ void fspace_scatter_kernel(const u32* __restrict__ pos, const u32* __
     if ((size_t)p + l > n) return;        // validated on the host; never write out of bounds
     flen[p] = l;
     fsrc[p] = src[i];
-    for (u32 j = 0; j < l; ++j) owner[p + j] = p;
+    for (u32 j = 0; j < l; ++j) owner[p + j] = (u32)i;
 }
 
 void scatter_factors(Ctx& c, size_t n, const u32* pos, const u32* src, const u32* len, size_t z, FactorSpace fs) {
@@ -137,52 +141,66 @@ constexpr u32 NOT_DONE = 0xFFFFFFFFu;
 
 struct FlattenScalars { u32 waiting; u32 num_flattened; u32 max_depth; u32 pad; };
 
-__global__ void flatten_init_kernel(const u32* __restrict__ fpos, size_t z, const u32* __restrict__ orig,
-                                    u32* __restrict__ ffinal, u32* __restrict__ cursrc, u32* __restrict__ depth) {
+// Everything a chain step needs about a factor lives in compact arrays indexed by the factor's rank r in position order
+// (z entries: they stay in the Infinity Cache), only owner[] is position-indexed:
+//   rec[r] = pos | len << 32,  srcs[r] = original source,  fin[r] = final source (NOT_DONE until known)
+__global__ void flatten_init_kernel(const u32* __restrict__ fpos, size_t z, const u32* __restrict__ flen, const u32* __restrict__ orig,
+                                    u64* __restrict__ rec, u32* __restrict__ srcs, u32* __restrict__ fin, u32* __restrict__ cursrc,
+                                    u32* __restrict__ depth) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= z) return;
     const u32 p = fpos[i];
-    ffinal[p] = NOT_DONE;
-    cursrc[i] = orig[p];
+    const u32 o = orig[p];
+    rec[i] = (u64)p | ((u64)flen[p] << 32);
+    srcs[i] = o;
+    fin[i] = NOT_DONE;
+    cursrc[i] = o;
     depth[i] = 0;
 }
 
-// One round over the still-waiting factors (work[] holds their indices into fpos[]; wcls[j] = 1 if still waiting).
-__global__ void flatten_round_kernel(const u32* __restrict__ work, u32 nwork, const u32* __restrict__ fpos, size_t n,
-                                     const u32* __restrict__ flen, const u32* __restrict__ owner, const u32* __restrict__ orig,
-                                     u32* ffinal, u32* __restrict__ cursrc, u32* __restrict__ depth, u8* __restrict__ wcls,
-                                     FlattenScalars* __restrict__ sc) {
+// One round over the still-waiting factors (work[] holds their ranks; wcls[j] = 1 if still waiting).
+__global__ __launch_bounds__(256) void flatten_round_kernel(const u32* __restrict__ work, u32 nwork, size_t n, const u32* __restrict__ owner,
+                                                             const u64* __restrict__ rec, const u32* __restrict__ srcs, u32* fin,
+                                                             u32* __restrict__ cursrc, u32* __restrict__ depth, u8* __restrict__ wcls,
+                                                             FlattenScalars* __restrict__ sc, u32 max_steps) {
     const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= nwork) return;
-    const u32 i = work ? work[j] : j;
-    const u32 p = fpos[i];
-    const u32 len = flen[p];
-    u32 src = cursrc[i];
-    u32 dep = depth[i];
-    bool finished = false;
-    for (;;) {
-        if ((size_t)src >= n || dep >= n) { finished = true; break; }   // :106 src < fmap.size()  (dep bound: no endless chains)
-        const u32 s = owner[src];
-        if (s == NONE32) { finished = true; break; }                    // :106 fmap[src] == 0
-        const u32 d = src - s;
-        if ((u64)d + len > (u64)flen[s]) { finished = true; break; }    // :110 copy does not fit inside s
-        u32 ssrc;
-        if (s < p) {                                                    // earlier factor: needs its final source
-            ssrc = ffinal[s];
-            if (ssrc == NOT_DONE) break;                                // wait for the next round
-        } else {
-            ssrc = orig[s];                                             // later factor: still unflattened at this point
+    bool counted = false;
+    u32 dep = 0;
+    if (j < nwork) {
+        const u32 i = work ? work[j] : j;
+        const u32 len = (u32)(rec[i] >> 32);
+        u32 src = cursrc[i];
+        dep = depth[i];
+        bool finished = false;
+        for (u32 step = 0; step < max_steps; ++step) {      // a long chain continues in the next round, regrouped with its peers
+            if ((size_t)src >= n || dep >= n) { finished = true; break; }   // :106 src < fmap.size()  (dep bound: no endless chains)
+            const u32 r = owner[src];
+            if (r == NONE32) { finished = true; break; }                    // :106 fmap[src] == 0
+            const u64 sr = rec[r];
+            const u32 d = src - (u32)sr;
+            if ((u64)d + len > (sr >> 32)) { finished = true; break; }      // :110 copy does not fit inside s
+            u32 ssrc;
+            if (r < i) {                                                    // earlier factor: needs its final source
+                ssrc = fin[r];
+                if (ssrc == NOT_DONE) break;                                // wait for the next round
+            } else {
+                ssrc = srcs[r];                                             // later factor: still unflattened at this point
+            }
+            src = ssrc + d;                                                 // :111
+            ++dep;
         }
-        src = ssrc + d;                                                 // :111
-        ++dep;
+        cursrc[i] = src;
+        depth[i] = dep;
+        wcls[j] = finished ? 0 : 1;
+        if (finished) {
+            fin[i] = dep ? src : srcs[i];                                   // :122-124
+            counted = dep != 0;
+        }
     }
-    cursrc[i] = src;
-    depth[i] = dep;
-    wcls[j] = finished ? 0 : 1;
-    if (finished) {
-        ffinal[p] = dep ? src : orig[p];                                // :122-124
-        if (dep) { atomicAdd(&sc->num_flattened, 1u); atomicMax(&sc->max_depth, dep); }
-    }
+    // statistics: one atomic pair per wave
+    const u64 b = __ballot(counted);
+    const u32 mx = wave_reduce_max(counted ? dep : 0u);
+    if (lane_id() == 0 && b) { atomicAdd(&sc->num_flattened, (u32)__popcll(b)); atomicMax(&sc->max_depth, mx); }
 }
 
 __global__ void flatten_iota_kernel(u32* __restrict__ a, u32 m) {
@@ -190,11 +208,10 @@ __global__ void flatten_iota_kernel(u32* __restrict__ a, u32 m) {
     if (j < m) a[j] = j;
 }
 
-__global__ void flatten_commit_kernel(const u32* __restrict__ fpos, size_t z, const u32* __restrict__ ffinal, u32* __restrict__ fsrc) {
+__global__ void flatten_commit_kernel(const u32* __restrict__ fpos, size_t z, const u32* __restrict__ fin, u32* __restrict__ fsrc) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= z) return;
-    const u32 p = fpos[i];
-    fsrc[p] = ffinal[p];
+    fsrc[fpos[i]] = fin[i];
 }
 
 void flatten_factors(Ctx& c, size_t n, FactorSpace fs, FlattenStats* st) {
@@ -207,13 +224,15 @@ void flatten_factors(Ctx& c, size_t n, FactorSpace fs, FlattenStats* st) {
     u32* fpos = fs.have_list ? fs.fpos : c.arena.get<u32>(n);
     const size_t z = fs.have_list ? fs.nfact : extract_factors(c, n, fs, fpos, nullptr, nullptr, n);
     if (z == 0) { c.arena.release(mark); return; }
-    u32* ffinal = c.arena.get<u32>(n);          // position-indexed, only factor starts are touched
+    u64* rec = c.arena.get<u64>(z);
+    u32* srcs = c.arena.get<u32>(z);
+    u32* fin = c.arena.get<u32>(z);
     u32* cursrc = c.arena.get<u32>(z);
     u32* depth = c.arena.get<u32>(z);
     FlattenScalars* d_sc = (FlattenScalars*)c.arena.alloc(sizeof(FlattenScalars));
     HIP_TRY(hipMemsetAsync(d_sc, 0, sizeof(FlattenScalars), s));
     const unsigned gz = cdiv(z, 256);
-    flatten_init_kernel<<<gz, 256, 0, s>>>(fpos, z, fs.fsrc, ffinal, cursrc, depth);
+    flatten_init_kernel<<<gz, 256, 0, s>>>(fpos, z, fs.flen, fs.fsrc, rec, srcs, fin, cursrc, depth);
     LAUNCH_CHECK();
     // work lists of the still-waiting factors, compacted after every round
     u32* work[2] = { c.arena.get<u32>(z), c.arena.get<u32>(z) };
@@ -223,22 +242,28 @@ void flatten_factors(Ctx& c, size_t n, FactorSpace fs, FlattenStats* st) {
     LAUNCH_CHECK();
     u32 waiting = (u32)z;
     int cur_w = -1;                               // -1: the identity list (first round)
+    // steps per round: few in the first rounds (most chains are short; the lanes of a wave wait for the longest one),
+    // doubling afterwards
+    u32 max_steps = getenv("TDC_GPU_FLATTEN_STEPS") ? (u32)atoi(getenv("TDC_GPU_FLATTEN_STEPS")) : 1u;   // measured: 1,2,4,.. 8.5 ms; unlimited 11.2 ms
+    if (max_steps == 0) max_steps = 1u << 30;
     while (waiting) {
-        {   // per waiting factor: fpos, flen, cursrc, depth (16) + one chain step (owner, flen, src: 12) + outputs (13)
-            Ctx::ProfScope prof(c, K_FLATTEN_ROUND, (u64)waiting * 41);
-            flatten_round_kernel<<<cdiv(waiting, 256), 256, 0, s>>>(cur_w < 0 ? nullptr : work[cur_w], waiting, fpos, n, fs.flen,
-                                                                    fs.owner, fs.fsrc, ffinal, cursrc, depth, wcls, d_sc);
+        {   // per waiting factor: rec, cursrc, depth (16) + one chain step (owner, rec, source: 16) + outputs (13)
+            Ctx::ProfScope prof(c, K_FLATTEN_ROUND, (u64)waiting * 45);
+            flatten_round_kernel<<<cdiv(waiting, 256), 256, 0, s>>>(cur_w < 0 ? nullptr : work[cur_w], waiting, n, fs.owner, rec, srcs, fin,
+                                                                    cursrc, depth, wcls, d_sc, max_steps);
             LAUNCH_CHECK();
         }
         const int nxt = cur_w < 0 ? 0 : (cur_w ^ 1);
         select_by_class(c, wcls, 1, waiting, cur_w < 0 ? ident : work[cur_w], work[nxt], nullptr, nullptr, &d_sc->waiting);
         const u32 now = c.read(&d_sc->waiting);
         st->rounds++;
-        if (now >= waiting) throw HipError{hipErrorUnknown, "flatten: rounds made no progress", (int)__LINE__};
+        if (getenv("TDC_GPU_LEVEL_LOG")) fprintf(stderr, "flatten round %u: %u waiting -> %u\n", st->rounds, waiting, now);
+        if (now > waiting || (now == waiting && max_steps >= (1u << 30))) throw HipError{hipErrorUnknown, "flatten: rounds made no progress", (int)__LINE__};
         waiting = now;
         cur_w = nxt;
+        if (max_steps < (1u << 30)) max_steps *= 2;
     }
-    flatten_commit_kernel<<<gz, 256, 0, s>>>(fpos, z, ffinal, fs.fsrc);
+    flatten_commit_kernel<<<gz, 256, 0, s>>>(fpos, z, fin, fs.fsrc);
     LAUNCH_CHECK();
     FlattenScalars h = c.read(d_sc);
     st->num_flattened = h.num_flattened;

@@ -28,7 +28,8 @@ void build_lcp(Ctx& c, const u32* sa, const u32* plcp, size_t n, u32* lcp);
 // Position-space factor representation shared by factorize / flatten / encode:
 //   flen[p]  : length of the factor that STARTS at p, 0 otherwise (after mark_literal_runs: run length at
 //              the first position of every literal run)
-//   owner[p] : start position of the factor covering p, NONE32 if p is a literal
+//   owner[p] : identifies the factor covering p (its index in position order; lzss_lcp writes the start position
+//              instead), NONE32 if p is a literal.  A factor starts at p iff owner[p] != NONE32 and owner[p-1] != owner[p].
 //   fsrc[p]  : source of the factor starting at p (valid where flen[p] > 0 and owner[p] == p)
 struct FactorSpace {
     u32* flen = nullptr;
