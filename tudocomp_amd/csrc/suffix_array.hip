@@ -149,6 +149,14 @@ __global__ __launch_bounds__(256) void sa_local_sort_kernel(u64* __restrict__ ke
     __shared__ u32 xv[2048];
     const size_t base = (size_t)blockIdx.x * 2048;
     const size_t end = (base + 2048 < m) ? base + 2048 : m;
+    // runs that cross the tile borders
+    const u64 first_r1 = keys[base] >> bn, last_r1 = keys[end - 1] >> bn;
+    const bool open_l = base > 0 && (keys[base - 1] >> bn) == first_r1;
+    const bool open_r = end < m && (keys[end] >> bn) == last_r1;
+    if (first_r1 == last_r1 && (open_l || open_r)) {         // the whole tile lies inside one long run: left to the global sort
+        for (size_t i = base + threadIdx.x; i < end; i += 256) cls[i] = 1;
+        return;
+    }
     u64 k[8];
     u32 v[8];
 #pragma unroll
@@ -157,10 +165,6 @@ __global__ __launch_bounds__(256) void sa_local_sort_kernel(u64* __restrict__ ke
         k[r] = (i < m) ? keys[i] : ~0ull;
         v[r] = (i < m) ? vals[i] : 0u;
     }
-    // runs that cross the tile borders
-    const u64 first_r1 = keys[base] >> bn, last_r1 = keys[end - 1] >> bn;
-    const bool open_l = base > 0 && (keys[base - 1] >> bn) == first_r1;
-    const bool open_r = end < m && (keys[end] >> bn) == last_r1;
     block_bitonic_sort_2048(k, v, xk, xv);
 #pragma unroll
     for (u32 r = 0; r < 8; ++r) {
