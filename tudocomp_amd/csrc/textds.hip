@@ -39,11 +39,13 @@ void build_phi(Ctx& c, const u32* sa, size_t n, u32* phi) {
     LAUNCH_CHECK();
 }
 
-constexpr int PLCP_CHUNK = 32;                    // consecutive text positions per thread
+constexpr int PLCP_CHUNK = 16;                    // consecutive text positions per thread
 constexpr int PLCP_TILE = 256 * PLCP_CHUNK;       // 8192 positions per workgroup
 constexpr int PLCP_HALO = 512;                    // text bytes staged beyond the tile for the T[i+l] side
 
-// A thread walks 32 consecutive positions, so its Phi reads / PLCP writes are strided by 128 B across the lanes of a
+// A thread walks 16 consecutive positions (measured: 32 -> 7.8 ms, 16 -> 5.6 ms, 8 -> 7.3 ms at 2^28: the kernel is bound by the
+// latency of its dependent text reads, and LDS per workgroup sets how many threads a CU holds; shorter chunks restart the
+// carry more often), so its Phi reads / PLCP writes are strided by 64 B across the lanes of a
 // wave; going through LDS (row-padded to 33 words: conflict-free) turns both into fully coalesced 1 KiB transfers,
 // and the T[i+l] side of every comparison is served from a staged copy of the tile (+halo).  Only T[Phi[i]+l] stays
 // a global (data-dependent) read.
