@@ -238,6 +238,15 @@ int tdc_gpu_ctx_create(int device, tdc_gpu_ctx** out) {
         for (auto& e : ctx->c.ev) HIP_TRY(hipEventCreate(&e));
         ctx->c.pinned_size = 4096;
         HIP_TRY(hipHostMalloc(&ctx->c.pinned, ctx->c.pinned_size, hipHostMallocDefault));
+        if (const char* m = getenv("TDC_GPU_FASTREAD")) ctx->c.fast_read = atoi(m) ? 1 : 0;
+        if (ctx->c.fast_read) {
+            void* zc = nullptr;
+            if (hipHostMalloc(&zc, 4096 + 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+                void* dv = nullptr;
+                if (hipHostGetDevicePointer(&dv, zc, 0) == hipSuccess) { ctx->c.zc_host = (u32*)zc; ctx->c.zc_dev = (u32*)dv; memset(zc, 0, 4096 + 64); }
+                else { (void)hipHostFree(zc); (void)hipGetLastError(); }
+            } else (void)hipGetLastError();
+        }
         HIP_TRY(hipMalloc((void**)&ctx->c.d_err, 256));
         HIP_TRY(hipMemset(ctx->c.d_err, 0, 256));
         if (const char* m = getenv("TDC_GPU_SA_LOCAL")) ctx->c.sa_local_sort = atoi(m) ? 1 : 0;
@@ -262,6 +271,7 @@ void tdc_gpu_ctx_destroy(tdc_gpu_ctx* ctx) {
     if (ctx->c.stream) (void)hipStreamSynchronize(ctx->c.stream);
     if (ctx->c.arena.base) (void)hipFree(ctx->c.arena.base);
     if (ctx->c.pinned) (void)hipHostFree(ctx->c.pinned);
+    if (ctx->c.zc_host) (void)hipHostFree(ctx->c.zc_host);
     if (ctx->c.d_err) (void)hipFree(ctx->c.d_err);
     for (auto& e : ctx->c.ev) if (e) (void)hipEventDestroy(e);
     if (ctx->c.ev_pool) { for (int i = 0; i < ctx->c.ev_pool_size; ++i) if (ctx->c.ev_pool[i]) (void)hipEventDestroy(ctx->c.ev_pool[i]); free(ctx->c.ev_pool); }

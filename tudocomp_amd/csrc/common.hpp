@@ -85,6 +85,22 @@ struct KernelProfile {
     u64 bytes = 0;        // summed algorithmic bytes
 };
 
+#ifdef __HIPCC__
+// Small device -> host read-backs without a stream synchronisation: the words are stored straight into mapped host memory,
+// followed by a sequence number the host spins on (a hipMemcpyAsync + hipStreamSynchronize pair costs several times the
+// latency, and texts with long repeats need thousands of them).
+static __global__ void publish_words_kernel(const uint32_t* __restrict__ src, uint32_t nwords, uint32_t* host_dst, uint32_t* host_flag,
+                                            uint32_t seq) {
+    for (uint32_t i = threadIdx.x; i < nwords; i += blockDim.x)
+        __hip_atomic_store(&host_dst[i], src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence_system();
+        __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+#endif
+
 struct Ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -92,6 +108,10 @@ struct Ctx {
     hipEvent_t ev[16] = {};
     void* pinned = nullptr;        // small pinned staging block for device->host scalars
     size_t pinned_size = 0;
+    u32* zc_host = nullptr;        // mapped host block for publish_words_kernel: 1024 data words + the sequence word
+    u32* zc_dev = nullptr;         // the same block as seen from the device
+    u32 zc_seq = 0;
+    int fast_read = 1;             // env TDC_GPU_FASTREAD=0: read-backs through hipMemcpyAsync + hipStreamSynchronize
     u32* d_err = nullptr;          // device error word (look-back timeouts etc.), checked at the end of every API call
     int sa_local_sort = 1;         // doubling rounds: sort whole runs inside 2048-element tiles locally (env TDC_GPU_SA_LOCAL=0 disables)
     int radix_waves = 4;           // waves per radix-sort workgroup for large inputs (env TDC_GPU_RADIX_WAVES = 4 | 8; no measurable difference)
@@ -144,7 +164,29 @@ struct Ctx {
         arena.top = 0;
     }
     // read back a few scalars (stream-ordered, synchronous)
+#ifdef __HIPCC__
+    bool read_words_fast(const void* dptr, void* out, size_t bytes) {
+        if (!fast_read || !zc_host || bytes == 0 || bytes > 4096 || (bytes & 3) || ((uintptr_t)dptr & 3)) return false;
+        const u32 seq = ++zc_seq;
+        publish_words_kernel<<<1, 64, 0, stream>>>((const u32*)dptr, (u32)(bytes / 4), zc_dev, zc_dev + 1024, seq);
+        if (hipGetLastError() != hipSuccess) return false;
+        volatile u32* flag = zc_host + 1024;
+        for (u64 spins = 0;; ++spins) {
+            if (__atomic_load_n((const u32*)flag, __ATOMIC_ACQUIRE) == seq) break;
+            if ((spins & 0xFFFF) == 0xFFFF) {                    // every so often: has the stream failed?
+                const hipError_t q = hipStreamQuery(stream);
+                if (q != hipSuccess && q != hipErrorNotReady) throw HipError{q, __FILE__, __LINE__};
+            }
+        }
+        memcpy(out, zc_host, bytes);
+        return true;
+    }
+#else
+    bool read_words_fast(const void*, void*, size_t) { return false; }
+#endif
     template <typename T> T read(const T* dptr) {
+        T v;
+        if (read_words_fast(dptr, &v, sizeof(T))) return v;
         T* h = (T*)pinned;
         HIP_TRY(hipMemcpyAsync(h, dptr, sizeof(T), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
@@ -152,6 +194,7 @@ struct Ctx {
     }
     template <typename T> void read_n(const T* dptr, T* out, size_t count) {
         const size_t bytes = sizeof(T) * count;
+        if (read_words_fast(dptr, out, bytes)) return;
         if (bytes <= pinned_size) {          // small read-backs go through the pinned block (pageable D2H copies are slow)
             HIP_TRY(hipMemcpyAsync(pinned, dptr, bytes, hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
