@@ -159,7 +159,8 @@ def main():
             "stages_ms": {k2[3:]: round(v, 2) for k2, v in st.items() if k2.startswith("ms_")},
             "stats": {k2: st[k2] for k2 in ("out_len", "factors", "maxlcp", "num_flattened", "sa_rounds", "levels", "mis_rounds",
                                             "flatten_rounds", "pushes", "arena_bytes", "sa_sorted_elems", "sa_init_syms", "small_levels", "purges", "window_pass", "window_lcut")},
-            "kernels": {name: {"ms_per_step": round(p["ms"] / args.steps, 3), "launches_per_step": p["launches"] / args.steps}
+            "kernels": {name: {"ms_per_step": round(p["ms"] / args.steps, 3), "launches_per_step": p["launches"] / args.steps,
+                               "algorithmic_GBs": round(p["bytes"] / (p["ms"] * 1e-3) / 1e9, 1) if p["ms"] > 0 else None}
                         for name, p in prof.items() if p["launches"]},
         }
         if sizes is not None:
