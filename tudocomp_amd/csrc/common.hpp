@@ -115,10 +115,11 @@ struct Ctx {
     u32* d_err = nullptr;          // device error word (look-back timeouts etc.), checked at the end of every API call
     int sa_local_sort = 1;         // doubling rounds: sort whole runs inside 2048-element tiles locally (env TDC_GPU_SA_LOCAL=0 disables)
     int radix_waves = 4;           // waves per radix-sort workgroup for large inputs (env TDC_GPU_RADIX_WAVES = 4 | 8; no measurable difference)
-    int radix_lds = 2;             // radix scatter: reorder the tile in LDS before writing: 0 never, 1 always, 2 for 32-bit keys only
-                                   // (measured: -33 % for u32 pairs, no gain for u64 pairs; env TDC_GPU_RADIX_LDS)
-    int xcd_remap = 0;             // XCD-contiguous tile walk (env TDC_GPU_XCD_REMAP): 0 = only in the final pass of the bucketed scatter
-                                   // (-1.2 ms of 7.3), 1 = also in the radix sort kernels (measured: no gain), 2 = nowhere
+    int radix_lds = 1;             // radix scatter: reorder the tile in LDS before writing: 0 never, 1 always, 2 for 32-bit keys only
+                                   // (measured: -33 % for u32 pairs; u64 pairs only gain together with xcd_remap: 21.1 -> 18.5 ms; env TDC_GPU_RADIX_LDS)
+    int xcd_remap = 1;             // XCD-contiguous tile walk (env TDC_GPU_XCD_REMAP): 0 = only in the final pass of the bucketed scatter
+                                   // (-1.2 ms of 7.3), 1 = also in the radix sort kernels (with the LDS-reordered scatter the 128-byte
+                                   // pieces of neighbouring tiles then meet in one L2: -13 %), 2 = nowhere
     int window_lcut = 48;          // factorize: levels <= this run window-local in one launch (env TDC_GPU_WINDOW_LCUT, 0 disables)
     int window_large_lists = 0;    // window pass: start with the large per-level lists (env TDC_GPU_WINDOW_LARGE=1; tests)
     int bucket_scatter = 1;        // big random scatters (rank, Phi) go through one radix partition by destination window (env TDC_GPU_BUCKET_SCATTER=0 disables)

@@ -475,14 +475,15 @@ template <typename K, int NW>
 __global__ __launch_bounds__(NW * 64) void rs_scatter_lds_kernel(const K* __restrict__ keys_in, const u32* __restrict__ vals_in,
                                                                   K* __restrict__ keys_out, u32* __restrict__ vals_out,
                                                                   const u32* __restrict__ offsets, size_t n, u32 numTiles,
-                                                                  int shift, u32 dmask) {
+                                                                  int shift, u32 dmask, u32 per_xcd) {
     constexpr int TILE = NW * 64 * RS_ITEMS;
     __shared__ u32 wcnt[NW][256];     // per-wave digit counts, then start of the (wave, digit) run inside the sorted tile
     __shared__ u32 gbase[256];        // global start of the digit's run minus its start inside the sorted tile
     __shared__ K stage[TILE];
     __shared__ u32 scan_sm[NW + 1];
     const int lane = lane_id(), w = wave_id();
-    const u32 tile = blockIdx.x;
+    const u32 tile = xcd_tile(blockIdx.x, per_xcd);
+    if (tile >= numTiles) return;
     for (int i = threadIdx.x; i < NW * 256; i += NW * 64) (&wcnt[0][0])[i] = 0;
     __syncthreads();
 
@@ -585,8 +586,8 @@ static int radix_sort_pairs_nw(Ctx& c, K* keys[2], u32* vals[2], size_t n, int b
         radix_offsets(c, counts, numTiles, blocksum);
         const int ps = c.prof_begin(sizeof(K) == 8 ? K_RS_SCATTER_U64 : K_RS_SCATTER_U32, (u64)n * 2 * (sizeof(K) + sizeof(u32)));
         if (NW == 4 && (c.radix_lds == 1 || (c.radix_lds == 2 && sizeof(K) == 4)))
-            rs_scatter_lds_kernel<K, NW><<<numTiles, NW * 64, 0, c.stream>>>(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], counts, n,
-                                                                          numTiles, shift, dmask);
+            rs_scatter_lds_kernel<K, NW><<<grid, NW * 64, 0, c.stream>>>(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], counts, n,
+                                                                      numTiles, shift, dmask, per_xcd);
         else
             rs_scatter_kernel<K, NW><<<grid, NW * 64, 0, c.stream>>>(keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], counts, n,
                                                                       numTiles, shift, dmask, per_xcd);
