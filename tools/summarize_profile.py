@@ -40,11 +40,9 @@ want_u64 = "u64" in dom
 
 
 def match(name):
-    if key not in name:
-        return False
-    if "rs_scatter" in key:
-        return ("unsigned long" in name) == want_u64
-    return True
+    if "rs_scatter" in key:                      # both scatter kernels (direct and LDS-reordered) belong to the class
+        return "rs_scatter" in name and ("<unsigned long" in name) == want_u64
+    return key in name
 
 
 fl = [(k, v) for k, v in fetch.items() if match(k)]

@@ -472,7 +472,7 @@ __global__ __launch_bounds__(NW * 64) void rs_scatter_kernel(const K* __restrict
 // store instruction touches a handful of lines.  Same tiling, same stable ranks; the staging buffer holds the keys first and
 // is reused for the values.
 template <typename K, int NW>
-__global__ __launch_bounds__(NW * 64) void rs_scatter_lds_kernel(const K* __restrict__ keys_in, const u32* __restrict__ vals_in,
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void rs_scatter_lds_kernel(const K* __restrict__ keys_in, const u32* __restrict__ vals_in,
                                                                   K* __restrict__ keys_out, u32* __restrict__ vals_out,
                                                                   const u32* __restrict__ offsets, size_t n, u32 numTiles,
                                                                   int shift, u32 dmask, u32 per_xcd) {
