@@ -110,16 +110,19 @@ __global__ void sa_build_keys_kernel(const u32* __restrict__ a_sa, const u32* __
     vals[a] = s;
 }
 
+// newrank_out != nullptr: the new ranks are only written out (in list order); the caller scatters them to rank[] through the
+// bucketed scatter (writing an unchanged rank again is harmless)
 __global__ void sa_update_kernel(const u64* __restrict__ keys, const u32* __restrict__ vals, const u32* __restrict__ head,
                                  const u32* __restrict__ a_pos, size_t m, int bn, u32* __restrict__ sa, u32* __restrict__ rank,
-                                 u32* __restrict__ keep) {
+                                 u32* __restrict__ keep, u32* __restrict__ newrank_out) {
     const size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= m) return;
     const u32 h = head[a];
     const u32 s = vals[a];
     const u32 newrank = a_pos[h];
     sa[a_pos[a]] = s;
-    if (newrank != (u32)(keys[a] >> bn)) rank[s] = newrank;     // rank only moves when the group was split
+    if (newrank_out) newrank_out[a] = newrank;
+    else if (newrank != (u32)(keys[a] >> bn)) rank[s] = newrank;     // rank only moves when the group was split
     const bool single = (h == (u32)a) && (a + 1 == m || head[a + 1] == (u32)(a + 1));
     keep[a] = single ? 0u : 1u;
 }
@@ -304,8 +307,12 @@ void build_suffix_array(Ctx& c, const u8* text, size_t n, u32* sa, u32* isa, SAS
         inclusive_max_u32(c, head, head, m);
         {
             Ctx::ProfScope prof(c, K_SA_RANK_SCATTER, (u64)m * 36);
-            sa_update_kernel<<<gm, 256, 0, s>>>(keys[x], vals[x], head, A_pos, m, bn, sa, rank, keep);
+            // a large round scatters its ranks through the bucketed scatter (scratch: the other sort buffers, the B lists)
+            const bool bucketed = c.bucket_scatter && m >= ((size_t)1 << 24);
+            u32* nr = (u32*)keys[x ^ 1];
+            sa_update_kernel<<<gm, 256, 0, s>>>(keys[x], vals[x], head, A_pos, m, bn, sa, rank, keep, bucketed ? nr : nullptr);
             LAUNCH_CHECK();
+            if (bucketed) bucketed_scatter_u32(c, vals[x], nr, m, rank, n, nr + m, vals[x ^ 1], B_sa, B_pos);
         }
         exclusive_sum_u32(c, keep, keep, m, d_total);
         sa_compact_kernel<<<gm, 256, 0, s>>>(vals[x], head, keep, A_pos, m, B_sa, B_pos, B_r1);
