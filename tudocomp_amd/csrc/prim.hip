@@ -374,21 +374,48 @@ __global__ __launch_bounds__(256) void rs_colsum_kernel(const u32* __restrict__ 
     for (u32 t = t0; t < t1; ++t) acc += counts[(size_t)t * 256 + threadIdx.x];
     blocksum[(size_t)blockIdx.x * 256 + threadIdx.x] = acc;
 }
-// one workgroup: per digit the exclusive prefix over the row blocks; dstart[d] = start of digit d
-__global__ __launch_bounds__(256) void rs_colbase_kernel(u32* __restrict__ blocksum, u32 numBlocks, u32* __restrict__ dstart) {
-    __shared__ u32 sm[5];
-    u32 run = 0;
-    u32 b = 0;
-    for (; b + 8 <= numBlocks; b += 8) {                    // eight independent loads in flight
+// one workgroup of 1024 threads: per digit the exclusive prefix over the row blocks; dstart[d] = start of digit d.
+// Thread (g, d) owns a quarter of the rows of column d (the walk down a column is a chain of dependent round trips: four
+// shorter chains instead of one).
+__global__ __launch_bounds__(1024) void rs_colbase_kernel(u32* __restrict__ blocksum, u32 numBlocks, u32* __restrict__ dstart) {
+    __shared__ u32 part[4][256];
+    __shared__ u32 cs[256];
+    const u32 d = threadIdx.x & 255u, g = threadIdx.x >> 8;
+    const u32 per = (numBlocks + 3) / 4;
+    const u32 b0 = g * per < numBlocks ? g * per : numBlocks;
+    const u32 b1 = b0 + per < numBlocks ? b0 + per : numBlocks;
+    u32 acc = 0;
+    u32 b = b0;
+    for (; b + 8 <= b1; b += 8) {                           // eight independent loads in flight
         u32 v[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = blocksum[(size_t)(b + i) * 256 + threadIdx.x];
+        for (int i = 0; i < 8; ++i) v[i] = blocksum[(size_t)(b + i) * 256 + d];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { blocksum[(size_t)(b + i) * 256 + threadIdx.x] = run; run += v[i]; }
+        for (int i = 0; i < 8; ++i) acc += v[i];
     }
-    for (; b < numBlocks; ++b) { const u32 v = blocksum[(size_t)b * 256 + threadIdx.x]; blocksum[(size_t)b * 256 + threadIdx.x] = run; run += v; }
-    u32 total;
-    dstart[threadIdx.x] = block_exclusive_sum<u32, 4>(run, sm, total);
+    for (; b < b1; ++b) acc += blocksum[(size_t)b * 256 + d];
+    part[g][d] = acc;
+    __syncthreads();
+    u32 run = 0;
+    for (u32 k = 0; k < g; ++k) run += part[k][d];
+    if (g == 0) cs[d] = part[0][d] + part[1][d] + part[2][d] + part[3][d];
+    __syncthreads();
+    if (threadIdx.x < 64) {                                 // start of every digit: exclusive scan over the 256 column sums
+        const u32 l = threadIdx.x;
+        const u32 c0 = cs[4 * l], c1 = cs[4 * l + 1], c2 = cs[4 * l + 2], c3 = cs[4 * l + 3];
+        const u32 inc = wave_inclusive_sum(c0 + c1 + c2 + c3);
+        const u32 ex = inc - (c0 + c1 + c2 + c3);
+        dstart[4 * l] = ex; dstart[4 * l + 1] = ex + c0; dstart[4 * l + 2] = ex + c0 + c1; dstart[4 * l + 3] = ex + c0 + c1 + c2;
+    }
+    b = b0;
+    for (; b + 8 <= b1; b += 8) {
+        u32 v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = blocksum[(size_t)(b + i) * 256 + d];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { blocksum[(size_t)(b + i) * 256 + d] = run; run += v[i]; }
+    }
+    for (; b < b1; ++b) { const u32 v = blocksum[(size_t)b * 256 + d]; blocksum[(size_t)b * 256 + d] = run; run += v; }
 }
 __global__ __launch_bounds__(256) void rs_colapply_kernel(u32* __restrict__ counts, u32 numTiles, const u32* __restrict__ blocksum,
                                                            const u32* __restrict__ dstart) {
@@ -403,7 +430,7 @@ static void radix_offsets(Ctx& c, u32* counts, u32 numTiles, u32* blocksum) {
     Ctx::ProfScope prof(c, K_SCAN, (u64)numTiles * 256 * 3 * sizeof(u32));
     rs_colsum_kernel<<<nb, 256, 0, c.stream>>>(counts, numTiles, blocksum);
     LAUNCH_CHECK();
-    rs_colbase_kernel<<<1, 256, 0, c.stream>>>(blocksum, nb, blocksum + (size_t)nb * 256);
+    rs_colbase_kernel<<<1, 1024, 0, c.stream>>>(blocksum, nb, blocksum + (size_t)nb * 256);
     LAUNCH_CHECK();
     rs_colapply_kernel<<<nb, 256, 0, c.stream>>>(counts, numTiles, blocksum, blocksum + (size_t)nb * 256);
     LAUNCH_CHECK();
