@@ -94,3 +94,24 @@ def test_window_pass_is_used_and_stream_bit_exact(ctx_for):
     assert got == want
     got0, st0 = ctx_for(0).lcpcomp_compress(text, threshold=2, flatten=1)
     assert st0["window_pass"] == 0 and got0 == want
+
+
+def test_long_repeats_skip_erased_levels(ctx_for):
+    """Texts with long repeats: tens of thousands of consecutive levels hold one erased candidate each (the PLCP ramp inside
+    a repeat); the level loop probes how far such a run goes instead of paying a launch per level.  Bit-exact, and the
+    number of processed levels stays small."""
+    rng = random.Random(4)
+    blk = bytes(rng.randrange(97, 123) for _ in range(120_000))
+    cases = {
+        "twice": blk + b"#" + blk + T.gen_english(100_000, 5).tobytes(),
+        "nested": blk + b"#" + blk[1000:90_000] + b"$" + blk[500:60_000] + b"%" + blk[30_000:110_000] + T.gen_dna(80_000, 3).tobytes(),
+        "overlap": (blk[:50_000] * 3) + b"&" + blk[10_000:70_000],
+    }
+    for name, data in cases.items():
+        text = O.escape(data)
+        for thr in (2, 5):
+            want, wst = O.lcpcomp_huff_compress(text, thr, 1)
+            got, st = ctx_for(48).lcpcomp_compress(text, threshold=thr, flatten=1)
+            assert got == want, "%s t=%d" % (name, thr)
+            assert st["factors"] == wst["factors"] and st["maxlcp"] == wst["maxlcp"] and st["maxlcp"] >= 40_000
+            assert st["levels"] < 5_000, "%s t=%d: %d levels were processed one by one" % (name, thr, st["levels"])

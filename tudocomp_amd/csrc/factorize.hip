@@ -392,6 +392,19 @@ __global__ void purge_class_kernel(const u32* __restrict__ cand, size_t cnt, u32
     if (j < cnt) cls[j] = (cur[cand[j]] >= threshold) ? 1 : 0;
 }
 
+// Highest level in a range of the sorted candidate array that still holds an alive entry (0: none).  Texts with long repeats
+// have one erased candidate per level over tens of thousands of consecutive levels (the ramp PLCP = R, R-1, ... inside a
+// repeat of length R, erased by the factor of level R): one probe replaces a launch and a read-back per level.
+__global__ __launch_bounds__(256) void alive_max_level_kernel(const u32* __restrict__ levels, const u32* __restrict__ pos, size_t lo, size_t hi,
+                                                               const u32* __restrict__ cur, u32 threshold, u32* __restrict__ d_max) {
+    u32 best = 0;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t k = lo + (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < hi; k += stride)
+        if (cur[pos[k]] >= threshold) best = max(best, levels[k]);
+    best = wave_reduce_max(best);
+    if (lane_id() == 0 && best) atomicMax(d_max, best);
+}
+
 // Pushed part of a level's list: concatenation of its pool segments (table: source offset / destination offset).
 struct GatherSeg { u32 src_off, dst_off; };
 __global__ void gather_segments_kernel(const u32* __restrict__ pool, const GatherSeg* __restrict__ tab, u32 nseg, u32 total,
@@ -555,6 +568,7 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
     u32 prio_base = (u32)n;
 
     u32 dead_streak = 0, levels_since_purge = 1u << 30;
+    bool probe_dead = false;                    // the previous level held erased candidates only
 
     const bool level_log = getenv("TDC_GPU_LEVEL_LOG") != nullptr;     // debugging aid: one line per large level on stderr
     auto t_prev = std::chrono::steady_clock::now();
@@ -607,6 +621,37 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
             dead_streak = 0;
         }
         ++levels_since_purge;
+        if (probe_dead && pushed_into[L].empty()) {
+            // the last level was completely erased: look how far down that goes.  Range: the levels below L without pushed
+            // entries (never past the window cut), at most 4 Mi candidates.
+            const u32 floor_level = std::max<u32>(threshold, lcut ? lcut + 1 : 0);
+            u32 Lb = L;
+            size_t lo = (size_t)-1, hi = 0, cnt = 0;
+            for (u32 v = L;; --v) {
+                if (!pushed_into[v].empty() && v != L) break;
+                if (h_segend[v] > h_segstart[v]) {
+                    cnt += h_segend[v] - h_segstart[v];
+                    if (cnt > ((size_t)4 << 20) && v != L) break;
+                    lo = std::min(lo, (size_t)h_segstart[v]); hi = std::max(hi, (size_t)h_segend[v]);
+                }
+                Lb = v;
+                if (v == floor_level) break;
+            }
+            if (Lb < L) {
+                u32 alive = 0;
+                if (hi > lo) {
+                    HIP_TRY(hipMemsetAsync(d_cnt + 2, 0, sizeof(u32), s));
+                    unsigned g = cdiv(hi - lo, 256 * 4); if (g > 4096) g = 4096; if (g == 0) g = 1;
+                    alive_max_level_kernel<<<g, 256, 0, s>>>(ckeys[x], cvals[x], lo, hi, cur, threshold, d_cnt + 2);
+                    LAUNCH_CHECK();
+                    alive = c.read(d_cnt + 2);
+                }
+                st->probes++;
+                if (alive < Lb) { L = Lb; probe_dead = true; continue; }          // [Lb, L] all erased: the loop's --L goes on below Lb
+                if (alive < L) { L = alive + 1; probe_dead = false; continue; }   // (alive, L] erased: --L lands on `alive`
+            }
+            probe_dead = false;
+        }
         const u32 m0 = h_segend[L] - h_segstart[L];
         u32 m1 = 0;
         {   // gather the pushed part of the list: one kernel per (at most gtab_cap) pool segments
@@ -650,7 +695,7 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
             }
             c.read_n((const u32*)d_sc, (u32*)&h_sc, sizeof(LevelScalars) / sizeof(u32));
             st->small_levels++;
-            if (h_sc.nlive == 0 && h_sc.nstale == 0) continue;   // small levels do not count for the purge heuristic
+            if (h_sc.nlive == 0 && h_sc.nstale == 0) { probe_dead = true; continue; }   // small levels do not count for the purge heuristic
             st->factors += h_sc.selected;
             const u32 npush = h_sc.npush, nseg = h_sc.nseg;
             if (npush) {
@@ -681,7 +726,7 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
         c.read_n((const u32*)d_sc, (u32*)&h_sc, 8);
         const u32 nl = h_sc.nlive, ns = h_sc.nstale;
         if (((u64)nl + ns) * 16 < m) ++dead_streak; else dead_streak = 0;     // (almost) all entries already erased
-        if (nl == 0 && ns == 0) continue;                     // every entry already erased (:86)
+        if (nl == 0 && ns == 0) { probe_dead = true; continue; }   // every entry already erased (:86)
         const bool wide = (L > 24);
         const unsigned gl = wide ? cdiv((size_t)nl * 64, 256) : cdiv(nl, 256);
         const unsigned gs = wide ? cdiv((size_t)ns * 64, 256) : cdiv(ns, 256);
