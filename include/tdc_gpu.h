@@ -37,6 +37,8 @@ typedef enum {
 
 /* coder ids (option `coder`, etc/registry_config.py:28-31,138-142) */
 enum { TDC_GPU_CODER_HUFF = 0, TDC_GPU_CODER_GAMMA = 1, TDC_GPU_CODER_ARITH = 2, TDC_GPU_CODER_ASCII = 3 };
+/* factorization strategy of lcpcomp (option `comp`, LCPCompressor.hpp:87): ArraysComp or PLCPPeaksStrategy */
+enum { TDC_GPU_COMP_ARRAYS = 0, TDC_GPU_COMP_PLCPPEAKS = 1 };
 
 typedef struct tdc_gpu_ctx tdc_gpu_ctx;
 
@@ -92,6 +94,12 @@ void tdc_gpu_free(void* p);
  * TDC_GPU_ERR_UNSUPPORTED for inputs on which the reference divides by zero). */
 int tdc_gpu_lcpcomp_compress(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, uint32_t threshold, int flatten,
                              int coder, uint8_t** out, size_t* out_len, tdc_gpu_stats* stats);
+/* The same with a selectable factorization strategy: comp = TDC_GPU_COMP_ARRAYS (lcpcomp::ArraysComp, the default of the
+ * entry point above) or TDC_GPU_COMP_PLCPPEAKS (lcpcomp::PLCPPeaksStrategy, compressors/lcpcomp/compress/PLCPPeaksStrategy.hpp:36-80:
+ * strict local maxima of the PLCP array, one left-to-right scan). */
+int tdc_gpu_lcpcomp_compress_comp(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, uint32_t threshold, int flatten, int coder,
+                                  int comp, uint8_t** out, size_t* out_len, tdc_gpu_stats* stats);
+
 /* Raw input variant: `data`/`n` is the UNRESTRICTED input (any bytes, no sentinel).  The library applies the
  * compressor's input restrictions on the device -- escape {0} + null-terminate, i.e. what Input(inp, restrictions) does
  * in tudocomp_driver.cpp:268-270 (io/RestrictedBuffer.hpp:43-74) -- and then compresses.  n < 2^30. */

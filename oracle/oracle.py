@@ -76,6 +76,8 @@ def lib():
         L.orc_lcpcomp_huff_compress.argtypes = [ctypes.c_void_p, sz, ctypes.c_uint32, ctypes.c_int,
                                                 ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(sz),
                                                 ctypes.POINTER(Stats)]
+        L.orc_lcpcomp_peaks_huff_compress.argtypes = [ctypes.c_void_p, sz, ctypes.c_uint32, ctypes.c_int,
+                                                      ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(sz), ctypes.POINTER(Stats)]
         L.orc_lcpcomp_ascii_compress.argtypes = [ctypes.c_void_p, sz, ctypes.c_uint32, ctypes.c_int,
                                                  ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(sz), ctypes.POINTER(Stats)]
         L.orc_encode_ascii.argtypes = [ctypes.c_void_p, sz, ctypes.c_void_p, sz, ctypes.POINTER(ctypes.c_void_p),
@@ -230,6 +232,15 @@ def lcpcomp_arith_compress(text, threshold=5, flatten=1):
         if out.value:
             lib().orc_free(out)
         raise RuntimeError("orc_lcpcomp_arith_compress rc=%d" % rc)
+    return _take(out, n.value), st.as_dict()
+
+
+def lcpcomp_peaks_huff_compress(text, threshold=5, flatten=1):
+    a, p = _buf(text)
+    out, n, st = ctypes.c_void_p(), ctypes.c_size_t(), Stats()
+    rc = lib().orc_lcpcomp_peaks_huff_compress(p, len(a), threshold, flatten, ctypes.byref(out), ctypes.byref(n), ctypes.byref(st))
+    if rc:
+        raise RuntimeError("orc_lcpcomp_peaks_huff_compress rc=%d" % rc)
     return _take(out, n.value), st.as_dict()
 
 

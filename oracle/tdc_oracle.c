@@ -266,6 +266,33 @@ size_t orc_arrays_comp(const uint32_t* sa, const uint32_t* isa, uint32_t* lcp, s
 }
 
 /* LZSSFactors.hpp:69-76 (positions are unique, so the order is fully determined) */
+/* ------------------------------------------------------------------------------------------------
+ * lcpcomp::PLCPPeaksStrategy::factorize (compressors/lcpcomp/compress/PLCPPeaksStrategy.hpp:36-80): one left-to-right scan
+ * over the PLCP array; a position whose PLCP value is a strict local maximum (and >= threshold) becomes a factor
+ * (i, sa[isa[i]-1], plcp[i]) and the scan jumps behind it.  `plcp` is the array as PLCPFromPhi leaves it: entry n-1 still
+ * holds Phi[n-1] (ds/PLCPFromPhi.hpp:27-53), and the scan does read it at i = n-2.
+ * ---------------------------------------------------------------------------------------------- */
+size_t orc_plcp_peaks(const uint32_t* sa, const uint32_t* isa, const uint32_t* plcp, size_t n, uint32_t threshold,
+                      orc_factor** out) {
+    u32vec P = {0}, S = {0}, Ln = {0};
+    *out = NULL;
+    uint32_t last_replacement_pos = 0;                                       /* :52 */
+    for (uint32_t i = 0; (size_t)i + 1 < n; ) {                              /* :53 */
+        if ((i == last_replacement_pos || plcp[i] > plcp[i - 1]) && plcp[i] > plcp[i + 1] && plcp[i] >= threshold) {   /* :54 */
+            const uint32_t len = plcp[i];
+            vec_push(&P, i); vec_push(&S, sa[isa[i] - 1]); vec_push(&Ln, len);   /* :57-60 */
+            i += len;                                                         /* :72 */
+            last_replacement_pos = i - 1;                                    /* :73 */
+        } else ++i;                                                          /* :76 */
+    }
+    const size_t z = P.size;
+    orc_factor* f = (orc_factor*)malloc((z ? z : 1) * sizeof(orc_factor));
+    for (size_t k = 0; k < z; ++k) { f[k].pos = P.a[k]; f[k].src = S.a[k]; f[k].len = Ln.a[k]; }
+    free(P.a); free(S.a); free(Ln.a);
+    *out = f;
+    return z;
+}
+
 static int cmp_factor_pos(const void* a, const void* b) {
     const uint32_t x = ((const orc_factor*)a)->pos, y = ((const orc_factor*)b)->pos;
     return x < y ? -1 : x > y;
@@ -766,6 +793,14 @@ int orc_encode_ascii(const uint8_t* text, size_t n, const orc_factor* f, size_t 
 /* LCPCompressor.hpp:100-138 */
 static int lcpcomp_compress(const uint8_t* text, size_t n, uint32_t threshold, int flatten, int coder,
                             uint8_t** out, size_t* out_len, orc_stats* stats);
+static int g_strategy = 0;      /* 0 = ArraysComp, 1 = PLCPPeaksStrategy (set around one call; the oracle is single-threaded test code) */
+int orc_lcpcomp_peaks_huff_compress(const uint8_t* text, size_t n, uint32_t threshold, int flatten,
+                                    uint8_t** out, size_t* out_len, orc_stats* stats) {
+    g_strategy = 1;
+    const int rc = lcpcomp_compress(text, n, threshold, flatten, 0, out, out_len, stats);
+    g_strategy = 0;
+    return rc;
+}
 int orc_lcpcomp_huff_compress(const uint8_t* text, size_t n, uint32_t threshold, int flatten,
                               uint8_t** out, size_t* out_len, orc_stats* stats) {
     return lcpcomp_compress(text, n, threshold, flatten, 0, out, out_len, stats);
@@ -795,14 +830,17 @@ static int lcpcomp_compress(const uint8_t* text, size_t n, uint32_t threshold, i
     if (rc) { free(sa); free(isa); free(phi); free(lcp); return rc; }
     stats->t_sa = now_s() - t; t = now_s();
     orc_phi(sa, n, phi);                       stats->t_phi = now_s() - t; t = now_s();
+    const uint32_t phi_last = phi[n - 1];                  /* what PLCPFromPhi leaves in plcp[n-1] */
     const uint32_t maxlcp = orc_plcp(text, n, phi, phi);   /* in place over phi like the reference */
     stats->t_plcp = now_s() - t; t = now_s();
     orc_lcp(sa, phi, n, lcp);
     orc_isa(sa, n, isa);                       stats->t_isa = now_s() - t; t = now_s();
-    free(phi);
     stats->maxlcp = maxlcp;
     orc_factor* F = NULL;
-    size_t z = orc_arrays_comp(sa, isa, lcp, n, maxlcp, threshold, &F);
+    size_t z;
+    if (g_strategy == 1) { phi[n - 1] = phi_last; z = orc_plcp_peaks(sa, isa, phi, n, threshold, &F); }
+    else z = orc_arrays_comp(sa, isa, lcp, n, maxlcp, threshold, &F);
+    free(phi);
     stats->t_factorize = now_s() - t; t = now_s();
     free(sa); free(isa); free(lcp);
     stats->factors = z;

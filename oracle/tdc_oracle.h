@@ -85,6 +85,11 @@ void orc_huffman_table(const uint32_t C[256], orc_hufftable* t);
  * *out malloc'd; returns 0 on success. */
 int orc_lcpcomp_huff_compress(const uint8_t* text, size_t n, uint32_t threshold, int flatten,
                               uint8_t** out, size_t* out_len, orc_stats* stats);
+/* lcpcomp(comp=plcppeaks): PLCPPeaksStrategy (compressors/lcpcomp/compress/PLCPPeaksStrategy.hpp:36-80) instead of ArraysComp.
+ * The reference's tests hold no vector for it and none was recorded: pinned by its properties only (valid copies, round trip). */
+size_t orc_plcp_peaks(const uint32_t* sa, const uint32_t* isa, const uint32_t* plcp, size_t n, uint32_t threshold, orc_factor** out);
+int orc_lcpcomp_peaks_huff_compress(const uint8_t* text, size_t n, uint32_t threshold, int flatten,
+                                    uint8_t** out, size_t* out_len, orc_stats* stats);
 /* Encode a given, sorted factor list (LZSSCoding.hpp:18-92 + HuffmanCoder::Encoder :526-569 + BitOStream dtor). */
 int orc_encode_huff(const uint8_t* text, size_t n, const orc_factor* f, size_t z,
                     uint8_t** out, size_t* out_len, orc_stats* stats);

@@ -317,3 +317,22 @@ def test_device_decompress(gpu_ctx):
     for bad in (b"", b"\x00", got[:1000], got[:len(got) // 2] + b"\x05"):
         with pytest.raises(T.TdcGpuError):
             gpu_ctx.lcpcomp_decompress(bad)
+
+
+def test_lcpcomp_plcppeaks_strategy(gpu_ctx):
+    """lcpcomp(comp=plcppeaks): the peak scan as the orbit of position 0, bit-exact with the oracle's
+    restatement of PLCPPeaksStrategy (which the reference's tests do not pin: checked by its properties -- valid copies,
+    round trip through the decoder)."""
+    cases = [c for c in SMALL] + [("english_400k", T.gen_english(400_000, 21).tobytes()), ("dna_200k", T.gen_dna(200_000, 7).tobytes())]
+    for name, data in cases:
+        text = O.escape(data)
+        for thr in (1, 2, 5):
+            want, wst = O.lcpcomp_peaks_huff_compress(text, thr, 1)
+            got, st = gpu_ctx.lcpcomp_compress(text, thr, 1, T.CODER_HUFF, T.COMP_PLCPPEAKS)
+            assert got == want, "%s t=%d: %d vs %d bytes" % (name, thr, len(got), len(want))
+            assert st["factors"] == wst["factors"]
+            try:
+                ok = O.lcpcomp_huff_decompress(want) == text
+            except RuntimeError:
+                ok = None                       # 256 equal-length codes: undecodable for the reference as well
+            assert ok in (True, None), name

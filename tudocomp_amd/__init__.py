@@ -15,6 +15,8 @@ CODER_HUFF = 0
 CODER_GAMMA = 1
 CODER_ARITH = 2
 CODER_ASCII = 3
+COMP_ARRAYS = 0
+COMP_PLCPPEAKS = 1
 
 
 class TdcGpuError(RuntimeError):
@@ -130,12 +132,17 @@ class Context:
         self._check(self._L.tdc_gpu_ctx_reserve(self._h, n))
 
     # ---- hot path --------------------------------------------------------------------------------------
-    def lcpcomp_compress(self, text, threshold=5, flatten=1, coder=CODER_HUFF):
+    def lcpcomp_compress(self, text, threshold=5, flatten=1, coder=CODER_HUFF, comp=COMP_ARRAYS):
         """text: escaped + 0-terminated view.  Returns (compressed bytes, stats dict)."""
         a = _u8(text)
         out, n, st = ctypes.c_void_p(), ctypes.c_size_t(), Stats()
-        self._check(self._L.tdc_gpu_lcpcomp_compress(self._h, _ptr(a), len(a), threshold, int(flatten), coder,
-                                                     ctypes.byref(out), ctypes.byref(n), ctypes.byref(st)))
+        if comp == COMP_ARRAYS:
+            rc = self._L.tdc_gpu_lcpcomp_compress(self._h, _ptr(a), len(a), threshold, int(flatten), coder,
+                                                  ctypes.byref(out), ctypes.byref(n), ctypes.byref(st))
+        else:
+            rc = self._L.tdc_gpu_lcpcomp_compress_comp(self._h, _ptr(a), len(a), threshold, int(flatten), coder, comp,
+                                                       ctypes.byref(out), ctypes.byref(n), ctypes.byref(st))
+        self._check(rc)
         return self._take(out, n.value), st.as_dict()
 
     def lcpcomp_compress_raw(self, data, threshold=5, flatten=1, coder=CODER_HUFF):
@@ -251,15 +258,16 @@ class LCPCompressor:
     input restrictions (escape {0}, null-terminate) and handed to compress()."""
 
     def __init__(self, ctx, coder="huff", threshold=5, flatten=1, comp="arrays"):
-        if coder not in ("huff", "arithmetic", "ascii") or comp != "arrays":
+        if coder not in ("huff", "arithmetic", "ascii") or comp not in ("arrays", "plcppeaks"):
             # same wording as Registry.hpp:214
             raise RuntimeError("No implementation found for compressor lcpcomp(coder=%s,comp=%s)" % (coder, comp))
         self.ctx, self.threshold, self.flatten = ctx, int(threshold), int(flatten)
         self.coder = {"huff": CODER_HUFF, "arithmetic": CODER_ARITH, "ascii": CODER_ASCII}[coder]
+        self.comp = COMP_PLCPPEAKS if comp == "plcppeaks" else COMP_ARRAYS
         self.last_stats = None
 
     def compress(self, data):
-        out, st = self.ctx.lcpcomp_compress(escape(data), self.threshold, self.flatten, self.coder)
+        out, st = self.ctx.lcpcomp_compress(escape(data), self.threshold, self.flatten, self.coder, self.comp)
         self.last_stats = st
         return out
 

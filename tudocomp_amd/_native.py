@@ -18,6 +18,7 @@ SYMBOLS = [
     "tdc_gpu_lz78_compress", "tdc_gpu_lzss_lcp_compress", "tdc_gpu_lzss_lcp_factorize",
     "tdc_gpu_suffix_array", "tdc_gpu_textds", "tdc_gpu_lcpcomp_factorize", "tdc_gpu_flatten", "tdc_gpu_encode_huff",
     "tdc_gpu_lcpcomp_decompress",
+    "tdc_gpu_lcpcomp_compress_comp",
     "tdc_gpu_encode_arith",
     "tdc_gpu_encode_ascii",
     "tdc_escape", "tdc_unescape", "tdc_huffman_table", "tdc_gen_english", "tdc_gen_dna",
@@ -69,6 +70,7 @@ def load():
     L.tdc_gpu_free.argtypes = [vp]
     L.tdc_gpu_free.restype = None
     L.tdc_gpu_lcpcomp_compress.argtypes = [vp, vp, sz, u32, i32, i32, pvp, psz, ctypes.POINTER(Stats)]
+    L.tdc_gpu_lcpcomp_compress_comp.argtypes = [vp, vp, sz, u32, i32, i32, i32, pvp, psz, ctypes.POINTER(Stats)]
     L.tdc_gpu_lcpcomp_compress_raw.argtypes = [vp, vp, sz, u32, i32, i32, pvp, psz, ctypes.POINTER(Stats)]
     L.tdc_gpu_lcpcomp_compress_dev.argtypes = [vp, vp, sz, u32, i32, i32, vp, sz, psz, ctypes.POINTER(Stats)]
     L.tdc_gpu_lz78_compress.argtypes = [vp, vp, sz, i32, pvp, psz, ctypes.POINTER(Stats)]

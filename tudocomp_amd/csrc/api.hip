@@ -138,7 +138,7 @@ void run_textds(Ctx& c, const u8* d_text, size_t n, DevArrays& A, tdc_gpu_stats*
     }
 }
 
-void run_factorize(Ctx& c, size_t n, DevArrays& A, u32 threshold, int flatten, tdc_gpu_stats* st, Events* ev) {
+void run_factorize(Ctx& c, size_t n, DevArrays& A, u32 threshold, int flatten, tdc_gpu_stats* st, Events* ev, int strategy = 0) {
     A.fs.flen = c.arena.get<u32>(n);
     A.fs.owner = c.arena.get<u32>(n);
     A.fs.fsrc = c.arena.get<u32>(n);
@@ -146,7 +146,8 @@ void run_factorize(Ctx& c, size_t n, DevArrays& A, u32 threshold, int flatten, t
     FactorizeStats fz;
     FlattenStats fl;
     const int e0 = ev ? ev->tick() : 0;
-    factorize_arrays(c, n, A.sa, A.isa, A.phi, A.plcp, A.maxlcp, threshold, A.fs, &fz);
+    if (strategy == TDC_GPU_COMP_PLCPPEAKS) plcp_peaks_factorize(c, n, A.phi, A.plcp, threshold, A.fs, &fz.factors);
+    else factorize_arrays(c, n, A.sa, A.isa, A.phi, A.plcp, A.maxlcp, threshold, A.fs, &fz);
     const int e1 = ev ? ev->tick() : 0;
     if (flatten) flatten_factors(c, n, A.fs, &fl);
     const int e2 = ev ? ev->tick() : 0;
@@ -161,12 +162,12 @@ void run_factorize(Ctx& c, size_t n, DevArrays& A, u32 threshold, int flatten, t
 // whole pipeline on a device-resident text; output written to *d_out (8-byte aligned, capacity out_cap); if *d_out is
 // NULL the buffer is taken from the arena once the factorization scratch has been released
 size_t run_pipeline(Ctx& c, const u8* d_text, size_t n, u32 threshold, int flatten, int coder, u8** d_out_io, size_t out_cap,
-                    tdc_gpu_stats* st, Events& ev) {
+                    tdc_gpu_stats* st, Events& ev, int strategy = 0) {
     if (threshold == 0) throw ArgError{TDC_GPU_ERR_ARG, "threshold must be >= 1"};
     validate_device_text(c, d_text, n);
     DevArrays A;
     run_textds(c, d_text, n, A, st, &ev);
-    run_factorize(c, n, A, threshold, flatten, st, &ev);
+    run_factorize(c, n, A, threshold, flatten, st, &ev, strategy);
     EncodeStats es;
     const int enc_coder = coder == TDC_GPU_CODER_ARITH ? 1 : (coder == TDC_GPU_CODER_ASCII ? 2 : 0);
     if (!*d_out_io) { out_cap = align_up(encode_bound_coder(n, enc_coder) + 16, 8); *d_out_io = c.arena.get<u8>(out_cap); }
@@ -355,6 +356,34 @@ int tdc_gpu_lcpcomp_compress(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, ui
         const int e1 = ev.tick();
         u8* d_out = nullptr;
         const size_t len = run_pipeline(c, d_text, n, threshold, flatten, coder, &d_out, 0, stats, ev);
+        const int e2 = ev.tick();
+        uint8_t* h = host_alloc<uint8_t>(len);
+        HIP_TRY(hipMemcpyAsync(h, d_out, len, hipMemcpyDeviceToHost, c.stream));
+        const int e3 = ev.tick();
+        if (stats) { ev.span(&stats->ms_h2d, e0, e1); ev.span(&stats->ms_d2h, e2, e3); ev.span(&stats->ms_total, e0, e3); }
+        ev.finish();
+        *out = h; *out_len = len;
+    });
+}
+
+int tdc_gpu_lcpcomp_compress_comp(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, uint32_t threshold, int flatten, int coder,
+                                  int comp, uint8_t** out, size_t* out_len, tdc_gpu_stats* stats) {
+    return guarded(ctx, [&] {
+        if (coder != TDC_GPU_CODER_HUFF && coder != TDC_GPU_CODER_ARITH && coder != TDC_GPU_CODER_ASCII) throw ArgError{TDC_GPU_ERR_UNSUPPORTED, "lcpcomp: coder must be huff, arithmetic or ascii"};
+        if (comp != TDC_GPU_COMP_ARRAYS && comp != TDC_GPU_COMP_PLCPPEAKS) throw ArgError{TDC_GPU_ERR_UNSUPPORTED, "lcpcomp: comp must be arrays or plcppeaks"};
+        check_text_args(text, n);
+        if (!out || !out_len) throw ArgError{TDC_GPU_ERR_ARG, "out/out_len is NULL"};
+        if (text[n - 1] != 0) throw ArgError{TDC_GPU_ERR_NO_SENTINEL, "text does not end with a 0 sentinel"};
+        Ctx& c = ctx->c;
+        if (stats) memset(stats, 0, sizeof(*stats));
+        c.ensure_arena(arena_need(n));
+        Events ev(c);
+        const int e0 = ev.tick();
+        u8* d_text = c.arena.get<u8>(n + 64);
+        HIP_TRY(hipMemcpyAsync(d_text, text, n, hipMemcpyHostToDevice, c.stream));
+        const int e1 = ev.tick();
+        u8* d_out = nullptr;
+        const size_t len = run_pipeline(c, d_text, n, threshold, flatten, coder, &d_out, 0, stats, ev, comp);
         const int e2 = ev.tick();
         uint8_t* h = host_alloc<uint8_t>(len);
         HIP_TRY(hipMemcpyAsync(h, d_out, len, hipMemcpyDeviceToHost, c.stream));

@@ -153,6 +153,60 @@ __global__ void lzss_emit_kernel(size_t n, const u8* __restrict__ mark, const u3
     if (b && lane_id() == __builtin_ctzll(b)) atomicAdd(count, (u32)__popcll(b));
 }
 
+// ---- lcpcomp(comp=plcppeaks) ------------------------------------------------------------------------------------------------
+// lcpcomp::PLCPPeaksStrategy::factorize (compressors/lcpcomp/compress/PLCPPeaksStrategy.hpp:36-80): a left-to-right scan; a
+// position whose PLCP value is a strict local maximum and >= threshold becomes the factor (i, Phi[i], PLCP[i]) and the scan
+// jumps behind it.  `last_replacement_pos` of the reference only ever equals i at i = 0, so "peak" is a local property and
+// the scan is the orbit of position 0 under next(i) = peak(i) ? i + PLCP[i] : i + 1 -- the same chain marking as the lzss_lcp
+// parse.  The reference's PLCP array still holds Phi[n-1] in its last entry (ds/PLCPFromPhi.hpp:27-53) and the scan reads
+// it at i = n-2; the device PLCP has 0 there, so that one comparison takes the value from Phi.
+__device__ __forceinline__ bool plcp_peak(const u32* __restrict__ plcp, const u32* __restrict__ phi, size_t n, size_t i, u32 threshold) {
+    if (i + 1 >= n) return false;
+    const u32 v = plcp[i];
+    if (v < threshold) return false;
+    if (i != 0 && !(v > plcp[i - 1])) return false;
+    const u32 right = (i + 1 == n - 1) ? phi[n - 1] : plcp[i + 1];
+    return v > right;
+}
+__global__ void peaks_next_kernel(const u32* __restrict__ plcp, const u32* __restrict__ phi, size_t n, u32 threshold, u32* __restrict__ next) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    next[i] = plcp_peak(plcp, phi, n, i, threshold) ? (u32)(i + plcp[i]) : (u32)(i + 1);
+}
+__global__ void peaks_emit_kernel(const u32* __restrict__ plcp, const u32* __restrict__ phi, size_t n, u32 threshold, const u8* __restrict__ mark,
+                                  u32* __restrict__ flen, u32* __restrict__ fsrc, u32* __restrict__ count) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool f = false;
+    if (i < n) {
+        f = mark[i] && plcp_peak(plcp, phi, n, i, threshold);
+        flen[i] = f ? plcp[i] : 0u;
+        if (f) fsrc[i] = phi[i];
+    }
+    const u64 b = __ballot(f);
+    if (b && lane_id() == __builtin_ctzll(b)) atomicAdd(count, (u32)__popcll(b));
+}
+
+void plcp_peaks_factorize(Ctx& c, size_t n, const u32* phi, const u32* plcp, u32 threshold, FactorSpace& fs, u64* nfactors) {
+    *nfactors = 0;
+    if (n == 0) return;
+    hipStream_t s = c.stream;
+    const size_t mark0 = c.arena.mark();
+    const unsigned gn = cdiv(n, 256);
+    u32* next = c.arena.get<u32>(n);
+    u32* s1 = c.arena.get<u32>(n), *s2 = c.arena.get<u32>(n);
+    u8* mark = c.arena.get<u8>(n);
+    u32* d_cnt = c.arena.get<u32>(1);
+    peaks_next_kernel<<<gn, 256, 0, s>>>(plcp, phi, n, threshold, next);
+    LAUNCH_CHECK();
+    mark_orbit_u32(c, next, n, mark, s1, s2);
+    HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(u32), s));
+    peaks_emit_kernel<<<gn, 256, 0, s>>>(plcp, phi, n, threshold, mark, fs.flen, fs.fsrc, d_cnt);
+    LAUNCH_CHECK();
+    *nfactors = c.read(d_cnt);
+    c.arena.release(mark0);
+    build_owner(c, n, fs);
+}
+
 void lzss_lcp_factorize(Ctx& c, const u8* text, size_t n, const u32* sa, const u32* isa, u32 threshold, FactorSpace fs, LzssStats* st) {
     (void)isa;
     LzssStats local;

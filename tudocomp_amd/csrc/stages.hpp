@@ -56,6 +56,10 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
 // owner[] from the factor starts (flen[p] != 0 exactly at factor starts): owner[q] = start of the factor covering q, else NONE32
 void build_owner(Ctx& c, size_t n, FactorSpace& fs);
 
+// lcpcomp(comp=plcppeaks): lcpcomp::PLCPPeaksStrategy (compressors/lcpcomp/compress/PLCPPeaksStrategy.hpp:36-80); fills fs
+// (flen, fsrc, owner, factor list) like factorize_arrays
+void plcp_peaks_factorize(Ctx& c, size_t n, const u32* phi, const u32* plcp, u32 threshold, FactorSpace& fs, u64* nfactors);
+
 struct FlattenStats { u64 num_flattened = 0; u64 max_depth_lb = 0; u32 rounds = 0; };
 // a10: compressors/lzss/LZSSFactors.hpp:79-132 ; rewrites fs.fsrc in place.
 void flatten_factors(Ctx& c, size_t n, FactorSpace fs, FlattenStats* st);

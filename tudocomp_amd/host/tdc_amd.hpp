@@ -299,6 +299,7 @@ class LCPCompressor : public Compressor {
     std::shared_ptr<GpuContext> m_ctx;       // created lazily by the first compress(): decompress() needs no GPU
     int m_device = 0;
     int m_coder = TDC_GPU_CODER_HUFF;
+    int m_comp = TDC_GPU_COMP_ARRAYS;
 public:
     tdc_gpu_stats last_stats{};
     void set_device(int d) { m_device = d; }
@@ -307,7 +308,9 @@ public:
         const std::string coder = m_opts.get("coder", ""), comp = m_opts.get("comp", "arrays");
         // `arithmetic` is not in the reference's lcpcomp registry (etc/registry_config.py:138-142) but the template
         // instantiates; BASELINE.json configs[2] asks for it, compress side only
-        if ((coder != "huff" && coder != "arithmetic" && coder != "ascii") || (comp != "arrays" && comp != "arrays()"))
+        m_comp = (comp == "plcppeaks" || comp == "plcppeaks()") ? TDC_GPU_COMP_PLCPPEAKS : TDC_GPU_COMP_ARRAYS;
+        if ((coder != "huff" && coder != "arithmetic" && coder != "ascii") ||
+            (comp != "arrays" && comp != "arrays()" && comp != "plcppeaks" && comp != "plcppeaks()"))
             throw std::runtime_error("No implementation found for compressor lcpcomp(coder=" + coder + ",comp=" + comp + ")");   // Registry.hpp:214
         m_coder = (coder == "huff") ? TDC_GPU_CODER_HUFF : (coder == "ascii" ? TDC_GPU_CODER_ASCII : TDC_GPU_CODER_ARITH);
     }
@@ -317,8 +320,8 @@ public:
         if (!m_ctx) m_ctx = std::make_shared<GpuContext>(m_device);
         const bytes view = input.as_view();
         uint8_t* out = nullptr; size_t out_len = 0;
-        const int rc = tdc_gpu_lcpcomp_compress(m_ctx->h, view.data(), view.size(), (uint32_t)m_opts.get_int("threshold", 5),
-                                                (int)m_opts.get_int("flatten", 1), m_coder, &out, &out_len, &last_stats);
+        const int rc = tdc_gpu_lcpcomp_compress_comp(m_ctx->h, view.data(), view.size(), (uint32_t)m_opts.get_int("threshold", 5),
+                                                     (int)m_opts.get_int("flatten", 1), m_coder, m_comp, &out, &out_len, &last_stats);
         if (rc == TDC_GPU_ERR_NO_SENTINEL) throw std::logic_error(tdc_gpu_strerror(rc));          // ds/TextDS.hpp:132-138
         if (rc) throw std::runtime_error(std::string(tdc_gpu_strerror(rc)) + ": " + tdc_gpu_last_error(m_ctx->h));
         output.write(out, out_len);
