@@ -115,3 +115,35 @@ def test_long_repeats_skip_erased_levels(ctx_for):
             assert got == want, "%s t=%d" % (name, thr)
             assert st["factors"] == wst["factors"] and st["maxlcp"] == wst["maxlcp"] and st["maxlcp"] >= 40_000
             assert st["levels"] < 5_000, "%s t=%d: %d levels were processed one by one" % (name, thr, st["levels"])
+
+
+def test_structured_random_texts(ctx_for):
+    """Randomised structure (planted repeats of many lengths, runs, periodic stretches, alphabet sizes 2..200), just above
+    the window path's minimum length: full stream against the oracle for random thresholds / flatten settings."""
+    rng = random.Random(2026)
+    for case in range(40):
+        sigma = rng.choice([2, 3, 4, 8, 26, 200])
+        target = rng.randrange(66_000, 140_000)
+        parts, total = [], 0
+        pool = [bytes(rng.randrange(1, 1 + sigma) for _ in range(rng.choice([5, 40, 300, 3000, 20_000]))) for _ in range(6)]
+        while total < target:
+            r = rng.random()
+            if r < 0.35:
+                src = rng.choice(pool)
+                a = rng.randrange(len(src)); b = rng.randrange(a, len(src)) + 1
+                piece = src[a:b]
+            elif r < 0.45:
+                piece = bytes([rng.randrange(1, 1 + sigma)]) * rng.randrange(1, 400)
+            elif r < 0.55:
+                unit = bytes(rng.randrange(1, 1 + sigma) for _ in range(rng.randrange(2, 9)))
+                piece = unit * rng.randrange(2, 200)
+            else:
+                piece = bytes(rng.randrange(1, 1 + sigma) for _ in range(rng.randrange(1, 2000)))
+            parts.append(piece); total += len(piece)
+        text = O.escape(b"".join(parts))
+        thr = rng.choice([1, 2, 3, 5, 8, 20])
+        fl = rng.choice([0, 1])
+        want, wst = O.lcpcomp_huff_compress(text, thr, fl)
+        got, st = ctx_for(48).lcpcomp_compress(text, threshold=thr, flatten=fl)
+        assert got == want, "case %d (sigma %d, n %d, t %d, flatten %d, maxlcp %d, window_pass %d)" % (
+            case, sigma, len(text), thr, fl, wst["maxlcp"], st["window_pass"])
