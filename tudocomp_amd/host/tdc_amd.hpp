@@ -430,6 +430,9 @@ struct Selection {
 
 inline std::vector<std::string> registered_algorithms() {
     return { "lcpcomp(coder=huff, comp=arrays, dec=scan(scans=6), threshold=5, flatten=1)   [MI355X, libtdc_gpu.so]",
+             "lcpcomp(coder=huff, comp=plcppeaks, threshold=5, flatten=1)                 [MI355X, peak scan as an orbit marking]",
+             "lcpcomp(coder=huff, dec=gpu)                                                [decompression: host parse, references resolved on the MI355X]",
+             "lcpcomp(coder=ascii, comp=arrays, threshold=5, flatten=1)                   [MI355X; host decoder]",
              "lcpcomp(coder=arithmetic, comp=arrays, threshold=5, flatten=1)              [MI355X, compress only]",
              "lzss_lcp(coder=huff, threshold=3)                                           [MI355X, libtdc_gpu.so]",
              "lz78(coder=gamma)                                                           [host parse + MI355X gamma packer]" };
