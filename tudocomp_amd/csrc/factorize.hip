@@ -126,6 +126,31 @@ __global__ void classify_kernel(const u32* __restrict__ orig, u32 m0, const u32*
     if (c == CL_LIVE) atomicOr((unsigned long long*)&bm[p >> 5], 1ull << (2 * (p & 31)));
 }
 
+// Mid-size levels: the same classification, but the live / stale lists are filled by wave-aggregated atomic appends (lists are
+// unordered sets; position order only buys locality, which a list of < 2^20 entries does not need) -- one launch instead
+// of seven.
+__device__ __forceinline__ u32 wave_append(bool want, u32* counter) {
+    const u64 b = __ballot(want);
+    if (!b) return 0;
+    const int leader = __builtin_ctzll(b);
+    u32 base = 0;
+    if (lane_id() == leader) base = atomicAdd(counter, (u32)__popcll(b));
+    base = __shfl(base, leader, 64);
+    return base + (u32)__popcll(b & ((lane_id() == 0) ? 0ull : (~0ull >> (64 - lane_id()))));
+}
+__global__ void classify_append_kernel(const u32* __restrict__ orig, u32 m0, const u32* __restrict__ pushed, u32 m, u32 L,
+                                       u32 threshold, const u32* __restrict__ cur, u32* __restrict__ live, u32* __restrict__ stale,
+                                       u64* __restrict__ bm, LevelScalars* __restrict__ sc) {
+    const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 p = 0, v = 0;
+    if (k < m) { p = (k < m0) ? orig[k] : pushed[k - m0]; v = cur[p]; }
+    const bool is_live = k < m && v == L, is_stale = k < m && v != L && v >= threshold;
+    const u32 il = wave_append(is_live, &sc->nlive);
+    const u32 is = wave_append(is_stale, &sc->nstale);
+    if (is_live) { live[il] = p; atomicOr((unsigned long long*)&bm[p >> 5], 1ull << (2 * (p & 31))); }
+    if (is_stale) stale[is] = p;
+}
+
 // Selection rounds over the live entries.  G lanes cooperate on one entry (1 for short levels, 64 for long ones).
 // A blocked entry retries a few times inside the launch: the bitmap words are re-read with agent-scope (L1-bypassing)
 // loads, so decisions of other workgroups become visible without a kernel boundary.  Safe without any ordering:
@@ -174,10 +199,10 @@ template <int G>
 __global__ __launch_bounds__(256) void resolve_kernel(const u32* __restrict__ list, u32 cnt, bool live_list, u32 L, u32 threshold,
                                                        size_t n, const u32* __restrict__ prio, const u64* __restrict__ bm,
                                                        const u32* __restrict__ cur, u64* __restrict__ rkey, u32* __restrict__ rval,
-                                                       u8* __restrict__ rc) {
+                                                       u8* __restrict__ rc, u32* __restrict__ append_counter) {
     const u32 i = (blockIdx.x * blockDim.x + threadIdx.x) / G;
     const u32 sub = (G == 1) ? 0u : (threadIdx.x & (G - 1));
-    if (i >= cnt) return;
+    if (i >= cnt) { if (append_counter && G == 1) (void)wave_append(false, append_counter); return; }
     const u32 p = list[i];
     const bool skip = live_list && bm_state(bm, p) == 2u;      // selected entries of the live list are not pushed
     u32 v = skip ? 0u : cur[p];
@@ -204,6 +229,13 @@ __global__ __launch_bounds__(256) void resolve_kernel(const u32* __restrict__ li
         if (sub != 0) return;
     }
     const bool push = v >= threshold;
+    if (append_counter) {                                   // mid-size levels: push records appended directly (sorted afterwards)
+        u32 o;
+        if (G == 1) o = wave_append(push, append_counter);
+        else o = push ? atomicAdd(append_counter, 1u) : 0u;  // one entry per wave
+        if (push) { rkey[o] = ((u64)v << 32) | pr; rval[o] = p; }
+        return;
+    }
     rc[i] = push ? 1 : 0;
     rkey[i] = ((u64)v << 32) | pr;
     rval[i] = p;
@@ -716,13 +748,20 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
         }
         HIP_TRY(hipMemsetAsync(d_sc, 0, 8 * sizeof(u32), s));
         const unsigned gm = cdiv(m, 256);
-        {   // per entry: list (4) + cur (4) + ent (4) + class byte (1)
-            Ctx::ProfScope prof(c, K_LEVEL_INIT, (u64)m * 13);
-            classify_kernel<<<gm, 256, 0, s>>>(cand + h_segstart[L], m0, pushed, m, L, threshold, cur, ent, cls, bm);
+        const bool mid = m <= (1u << 20);                    // few enough entries: unordered lists, fewer launches
+        if (mid) {
+            Ctx::ProfScope prof(c, K_LEVEL_INIT, (u64)m * 12);
+            classify_append_kernel<<<gm, 256, 0, s>>>(cand + h_segstart[L], m0, pushed, m, L, threshold, cur, live, stale, bm, d_sc);
             LAUNCH_CHECK();
+        } else {
+            {   // per entry: list (4) + cur (4) + ent (4) + class byte (1)
+                Ctx::ProfScope prof(c, K_LEVEL_INIT, (u64)m * 13);
+                classify_kernel<<<gm, 256, 0, s>>>(cand + h_segstart[L], m0, pushed, m, L, threshold, cur, ent, cls, bm);
+                LAUNCH_CHECK();
+            }
+            select_by_class(c, cls, CL_LIVE, m, ent, live, nullptr, nullptr, &d_sc->nlive);
+            select_by_class(c, cls, CL_STALE, m, ent, stale, nullptr, nullptr, &d_sc->nstale);
         }
-        select_by_class(c, cls, CL_LIVE, m, ent, live, nullptr, nullptr, &d_sc->nlive);
-        select_by_class(c, cls, CL_STALE, m, ent, stale, nullptr, nullptr, &d_sc->nstale);
         c.read_n((const u32*)d_sc, (u32*)&h_sc, 8);
         const u32 nl = h_sc.nlive, ns = h_sc.nstale;
         if (((u64)nl + ns) * 16 < m) ++dead_streak; else dead_streak = 0;     // (almost) all entries already erased
@@ -749,18 +788,22 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
         }
         {   // per entry: list, cur, prio (12) + the window's bitmap words + outputs (13)
             Ctx::ProfScope prof(c, K_RESOLVE, (u64)(ns + nl) * (25 + 8ull * ((2 * L - 2) / 32 + 2)));
+            u32* app = mid ? &d_sc->npush : nullptr;         // mid: push records appended straight into the sort input
+            u64* rk = mid ? skeys[0] : rkey;
+            u32* rv = mid ? svals[0] : rval;
             if (ns) {
-                if (wide) resolve_kernel<64><<<gs, 256, 0, s>>>(stale, ns, false, L, threshold, n, prio, bm, cur, rkey, rval, rc);
-                else      resolve_kernel<1><<<gs, 256, 0, s>>>(stale, ns, false, L, threshold, n, prio, bm, cur, rkey, rval, rc);
+                if (wide) resolve_kernel<64><<<gs, 256, 0, s>>>(stale, ns, false, L, threshold, n, prio, bm, cur, rk, rv, rc, app);
+                else      resolve_kernel<1><<<gs, 256, 0, s>>>(stale, ns, false, L, threshold, n, prio, bm, cur, rk, rv, rc, app);
                 LAUNCH_CHECK();
             }
             if (nl) {
-                if (wide) resolve_kernel<64><<<gl, 256, 0, s>>>(live, nl, true, L, threshold, n, prio, bm, cur, rkey + ns, rval + ns, rc + ns);
-                else      resolve_kernel<1><<<gl, 256, 0, s>>>(live, nl, true, L, threshold, n, prio, bm, cur, rkey + ns, rval + ns, rc + ns);
+                const size_t o = mid ? 0 : ns;
+                if (wide) resolve_kernel<64><<<gl, 256, 0, s>>>(live, nl, true, L, threshold, n, prio, bm, cur, rk + o, rv + o, rc + o, app);
+                else      resolve_kernel<1><<<gl, 256, 0, s>>>(live, nl, true, L, threshold, n, prio, bm, cur, rk + o, rv + o, rc + o, app);
                 LAUNCH_CHECK();
             }
         }
-        select_by_class(c, rc, 1, (size_t)ns + nl, rval, svals[0], rkey, skeys[0], &d_sc->npush);
+        if (!mid) select_by_class(c, rc, 1, (size_t)ns + nl, rval, svals[0], rkey, skeys[0], &d_sc->npush);
         if (nl) {
             // per entry: list + state (5); per factor: Phi, flen, fsrc (12) + L kills (8 B each) + L truncations (4 B each)
             Ctx::ProfScope prof(c, K_APPLY, (u64)nl * 5 + (u64)nl * (12 + 12ull * L));

@@ -661,8 +661,100 @@ __global__ __launch_bounds__(256) void small_sort_kernel(const u64* __restrict__
     }
 }
 
+// ---- whole LSD radix sort of up to 8192 pairs in ONE workgroup and one launch ------------------------------------------
+// The multi-launch sort costs five launches per 8-bit pass whatever the size; the push lists of mid-size factorization levels
+// (a few thousand pairs, 45 key bits) are sorted thousands of times on texts with long repeats.  Same stable ranking as
+// rs_scatter_lds_kernel; the pairs stay in registers, the tile is re-ordered through LDS after every pass.
+constexpr int MID_NW = 8;
+constexpr int MID_SORT_MAX = MID_NW * 64 * RS_ITEMS;      // 8192
+__global__ __launch_bounds__(MID_NW * 64) void one_workgroup_radix_sort_kernel(const u64* __restrict__ keys_in, const u32* __restrict__ vals_in,
+                                                                                u64* __restrict__ keys_out, u32* __restrict__ vals_out, u32 n,
+                                                                                int begin_bit, int end_bit) {
+    constexpr int NW = MID_NW;
+    __shared__ u32 wcnt[NW][256];
+    __shared__ u64 stage[MID_SORT_MAX];
+    __shared__ u32 scan_sm[NW + 1];
+    const int lane = lane_id(), w = wave_id();
+    u64 k[RS_ITEMS];
+    u32 v[RS_ITEMS];
+    u32 loc[RS_ITEMS];
+    const u32 base = (u32)w * (64 * RS_ITEMS) + (u32)lane;
+#pragma unroll
+    for (int j = 0; j < RS_ITEMS; ++j) {
+        const u32 idx = base + (u32)j * 64;
+        k[j] = (idx < n) ? keys_in[idx] : ~0ull;             // padding: largest digit in every pass, stays behind the real pairs (stable)
+        v[j] = (idx < n) ? vals_in[idx] : 0u;
+    }
+    const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    volatile u32* mycnt = wcnt[w];
+    u32* stage32 = (u32*)stage;
+    for (int shift = begin_bit; shift < end_bit; shift += 8) {
+        const int bits = (end_bit - shift) < 8 ? (end_bit - shift) : 8;
+        const u32 dmask = (1u << bits) - 1u;
+        for (int i = threadIdx.x; i < NW * 256; i += NW * 64) (&wcnt[0][0])[i] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < RS_ITEMS; ++j) {
+            const u32 d = (u32)((k[j] >> shift) & dmask);
+            u64 peers = ~0ull;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const bool bit = (d >> b) & 1u;
+                const u64 bal = __ballot(bit);
+                peers &= bit ? bal : ~bal;
+            }
+            const u32 prefix = mycnt[d];
+            const u32 rank = (u32)__popcll(peers & lt_mask);
+            loc[j] = prefix + rank;
+            if (rank == 0) mycnt[d] = prefix + (u32)__popcll(peers);
+        }
+        __syncthreads();
+        {
+            const u32 t = threadIdx.x;
+            u32 tot = 0;
+            if (t < 256) {
+#pragma unroll
+                for (int i = 0; i < NW; ++i) tot += wcnt[i][t];
+            }
+            u32 total;
+            const u32 start = block_exclusive_sum<u32, NW>(t < 256 ? tot : 0u, scan_sm, total);
+            if (t < 256) {
+                u32 run = start;
+#pragma unroll
+                for (int i = 0; i < NW; ++i) { const u32 c = wcnt[i][t]; wcnt[i][t] = run; run += c; }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < RS_ITEMS; ++j) {
+            loc[j] += wcnt[w][(u32)((k[j] >> shift) & dmask)];
+            stage[loc[j]] = k[j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < RS_ITEMS; ++j) k[j] = stage[base + (u32)j * 64];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < RS_ITEMS; ++j) stage32[loc[j]] = v[j];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < RS_ITEMS; ++j) v[j] = stage32[base + (u32)j * 64];
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < RS_ITEMS; ++j) {
+        const u32 idx = base + (u32)j * 64;
+        if (idx < n) { keys_out[idx] = k[j]; vals_out[idx] = v[j]; }
+    }
+}
+
 int sort_pairs_u64_distinct(Ctx& c, u64* keys[2], u32* vals[2], size_t n, int b, int e) {
     if (n == 0 || e <= b) return 0;
+    if (n > (size_t)SMALL_SORT_MAX && n <= (size_t)MID_SORT_MAX) {
+        one_workgroup_radix_sort_kernel<<<1, MID_NW * 64, 0, c.stream>>>(keys[0], vals[0], keys[1], vals[1], (u32)n, b, e);
+        LAUNCH_CHECK();
+        return 1;
+    }
     if (n > (size_t)SMALL_SORT_MAX || b != 0) return radix_sort_pairs<u64>(c, keys, vals, n, b, e);
     const u64 keymask = (e >= 64) ? ~0ull : ((1ull << e) - 1);
     u32 np2 = 8;
