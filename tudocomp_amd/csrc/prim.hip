@@ -787,8 +787,22 @@ __global__ __launch_bounds__(256) void window_scatter_kernel(const u32* __restri
     for (int r = 0; r < WS_ITEMS; ++r) if (j0 + r < m) dst[k[r]] = v[r];
 }
 
+// Final pass when idx is a permutation of [0, m) (m = n_dst, or n_dst - 1 with only the last index missing): after the
+// partition by the top 16 bits window w holds exactly the pairs [w * W, (w + 1) * W), W = 2^(bits - 16).  One workgroup per
+// window: the values are scattered into an LDS image of the window, which then leaves as whole lines.
+constexpr u32 WIMG_MAX = 8192;
+__global__ __launch_bounds__(256) void window_image_kernel(const u32* __restrict__ idx, const u32* __restrict__ val, size_t m,
+                                                            u32* __restrict__ dst, u32 W) {
+    __shared__ u32 img[WIMG_MAX];
+    const size_t base = (size_t)blockIdx.x * W;
+    const size_t end = (base + W < m) ? base + W : m;
+    for (size_t j = base + threadIdx.x; j < end; j += 256) img[idx[j] & (W - 1)] = val[j];
+    __syncthreads();
+    for (size_t q = base + threadIdx.x; q < end; q += 256) dst[q] = img[q - base];
+}
+
 void bucketed_scatter_u32(Ctx& c, const u32* idx, const u32* val, size_t m, u32* dst, size_t n_dst, u32* tmp_idx, u32* tmp_val,
-                          u32* tmp_idx2, u32* tmp_val2) {
+                          u32* tmp_idx2, u32* tmp_val2, bool permutation) {
     if (m == 0) return;
     const int bits = (int)bits_for(n_dst ? n_dst - 1 : 0);
     const u32* k = idx;
@@ -808,6 +822,12 @@ void bucketed_scatter_u32(Ctx& c, const u32* idx, const u32* val, size_t m, u32*
             radix_sort_pairs<u32>(c, kb, vb, m, mid, bits);
             k = tmp_idx2; v = tmp_val2;
         }
+    }
+    if (permutation && k == tmp_idx2 && bits > 16 && (1u << (bits - 16)) <= WIMG_MAX) {
+        const u32 W = 1u << (bits - 16);
+        window_image_kernel<<<cdiv(m, W), 256, 0, c.stream>>>(k, v, m, dst, W);
+        LAUNCH_CHECK();
+        return;
     }
     // every XCD walks one contiguous part of the partitioned pairs: all writes to a destination line then meet in ONE L2
     // (measured without this: WRITE_SIZE = 9x the destination bytes, every 4-byte store left its L2 as a partial line)

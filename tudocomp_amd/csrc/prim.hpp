@@ -25,8 +25,10 @@ int sort_pairs_u64_distinct(Ctx& c, u64* keys[2], u32* vals[2], size_t n, int be
 // dst[idx[j]] = val[j], j < m, for pairwise distinct idx[j] < n_dst: a radix partition by the top 16 bits of idx (two
 // 8-bit passes; only the first one if tmp_idx2 / tmp_val2 are null), then a scatter whose writes stay inside one small
 // window per run.  idx / val are only read; the tmp arrays (m entries each) receive the partitioned pairs.
+// permutation: idx[] holds every index of [0, m) exactly once (the caller's promise) -- the final pass then writes whole
+// destination windows from an LDS image.
 void bucketed_scatter_u32(Ctx& c, const u32* idx, const u32* val, size_t m, u32* dst, size_t n_dst, u32* tmp_idx, u32* tmp_val,
-                          u32* tmp_idx2, u32* tmp_val2);
+                          u32* tmp_idx2, u32* tmp_val2, bool permutation = false);
 
 // Order-preserving selection: for the k (ascending) with cls[k] == want, outA[j] = srcA[k] (or k itself if srcA ==
 // nullptr) and outB[j] = srcB[k] if srcB != nullptr; *d_count (device) receives the number of selected elements.

@@ -252,7 +252,7 @@ void build_suffix_array(Ctx& c, const u8* text, size_t n, u32* sa, u32* isa, SAS
             // rank[vals[j]] = head[j] through a partition by destination window; the other key buffer is free scratch
             sa_first_update_kernel<false><<<gn, 256, 0, s>>>(vals[x], head, n, sa, rank, keep);
             LAUNCH_CHECK();
-            bucketed_scatter_u32(c, vals[x], head, n, rank, n, (u32*)keys[x ^ 1], vals[x ^ 1], B_sa, B_pos);   // B_* are free until the first compaction
+            bucketed_scatter_u32(c, vals[x], head, n, rank, n, (u32*)keys[x ^ 1], vals[x ^ 1], B_sa, B_pos, true);   // B_* are free until the first compaction; vals[x] = every position once
         } else {
             sa_first_update_kernel<true><<<gn, 256, 0, s>>>(vals[x], head, n, sa, rank, keep);
             LAUNCH_CHECK();

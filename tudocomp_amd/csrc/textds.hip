@@ -29,7 +29,7 @@ void build_phi(Ctx& c, const u32* sa, size_t n, u32* phi) {
         u32* tv = c.arena.get<u32>(n);
         u32* ti2 = c.arena.get<u32>(n);
         u32* tv2 = c.arena.get<u32>(n);
-        bucketed_scatter_u32(c, sa + 1, sa, n - 1, phi, n, ti, tv, ti2, tv2);
+        bucketed_scatter_u32(c, sa + 1, sa, n - 1, phi, n, ti, tv, ti2, tv2, true);     // sa[1..n-1] = every position but n-1 (= sa[0]) once
         phi_first_kernel<<<1, 1, 0, c.stream>>>(sa, n, phi);
         LAUNCH_CHECK();
         c.arena.release(mark);
