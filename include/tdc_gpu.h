@@ -36,7 +36,9 @@ typedef enum {
 } tdc_gpu_status;
 
 /* coder ids (option `coder`, etc/registry_config.py:28-31,138-142) */
-enum { TDC_GPU_CODER_HUFF = 0, TDC_GPU_CODER_GAMMA = 1, TDC_GPU_CODER_ARITH = 2, TDC_GPU_CODER_ASCII = 3 };
+enum { TDC_GPU_CODER_HUFF = 0, TDC_GPU_CODER_GAMMA = 1, TDC_GPU_CODER_ARITH = 2, TDC_GPU_CODER_ASCII = 3, TDC_GPU_CODER_SLE = 4 };
+/* coder=sle(kmer=K) (coders/SLECoder.hpp:36-40; the reference's default is 3): the option travels in bits 8.. of `coder` */
+#define TDC_GPU_CODER_SLE_K(K) (TDC_GPU_CODER_SLE | ((K) << 8))
 /* factorization strategy of lcpcomp (option `comp`, LCPCompressor.hpp:87): ArraysComp or PLCPPeaksStrategy */
 enum { TDC_GPU_COMP_ARRAYS = 0, TDC_GPU_COMP_PLCPPEAKS = 1 };
 
@@ -91,7 +93,9 @@ void tdc_gpu_free(void* p);
  * same name (LCPCompressor.hpp:92-93, defaults 5 and 1).  `stats` may be NULL.
  * coder: TDC_GPU_CODER_HUFF (HuffmanCoder) or TDC_GPU_CODER_ARITH (ArithmeticCoder, coders/ArithmeticCoder.hpp:35-177 --
  * compress side only: the reference itself cannot decode lcpcomp + arithmetic; returns
- * TDC_GPU_ERR_UNSUPPORTED for inputs on which the reference divides by zero). */
+ * TDC_GPU_ERR_UNSUPPORTED for inputs on which the reference divides by zero), TDC_GPU_CODER_ASCII (ASCIICoder) or
+ * TDC_GPU_CODER_SLE / TDC_GPU_CODER_SLE_K(k) (SLECoder, the coder of the reference's published lcpcomp runs,
+ * etc/compare-suites/default.suite:5; the device builds k <= 3 and returns TDC_GPU_ERR_UNSUPPORTED for 4..7). */
 int tdc_gpu_lcpcomp_compress(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, uint32_t threshold, int flatten,
                              int coder, uint8_t** out, size_t* out_len, tdc_gpu_stats* stats);
 /* The same with a selectable factorization strategy: comp = TDC_GPU_COMP_ARRAYS (lcpcomp::ArraysComp, the default of the
@@ -158,6 +162,9 @@ int tdc_gpu_encode_arith(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, const 
 /* coder = ASCIICoder (coders/ASCIICoder.hpp:29-50) */
 int tdc_gpu_encode_ascii(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, const uint32_t* pos, const uint32_t* src,
                          const uint32_t* len, size_t z, uint8_t** out, size_t* out_len);
+/* coder = SLECoder (coders/SLECoder.hpp:42-298), kmer = its option of that name (0 = default 3; device: <= 3) */
+int tdc_gpu_encode_sle(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, const uint32_t* pos, const uint32_t* src,
+                       const uint32_t* len, size_t z, uint32_t kmer, uint8_t** out, size_t* out_len);
 
 /* ---- host-side helpers (no GPU) --------------------------------------------------------------------------- */
 /* io/RestrictedBuffer.hpp:43-74 + io/EscapeMap.hpp:39-64 : 0x00 -> FF FE, 0xFF -> FF FF, append 0.

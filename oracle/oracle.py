@@ -83,6 +83,11 @@ def lib():
         L.orc_encode_ascii.argtypes = [ctypes.c_void_p, sz, ctypes.c_void_p, sz, ctypes.POINTER(ctypes.c_void_p),
                                        ctypes.POINTER(sz), ctypes.POINTER(Stats)]
         L.orc_lcpcomp_ascii_decompress.argtypes = [ctypes.c_void_p, sz, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(sz)]
+        L.orc_lcpcomp_sle_compress.argtypes = [ctypes.c_void_p, sz, ctypes.c_uint32, ctypes.c_int, ctypes.c_uint,
+                                               ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(sz), ctypes.POINTER(Stats)]
+        L.orc_encode_sle.argtypes = [ctypes.c_void_p, sz, ctypes.c_void_p, sz, ctypes.c_uint, ctypes.POINTER(ctypes.c_void_p),
+                                     ctypes.POINTER(sz), ctypes.POINTER(Stats)]
+        L.orc_lcpcomp_sle_decompress.argtypes = [ctypes.c_void_p, sz, ctypes.c_uint, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(sz)]
         L.orc_lcpcomp_arith_compress.argtypes = [ctypes.c_void_p, sz, ctypes.c_uint32, ctypes.c_int,
                                                  ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(sz),
                                                  ctypes.POINTER(Stats)]
@@ -269,6 +274,35 @@ def lcpcomp_ascii_decompress(stream):
     rc = lib().orc_lcpcomp_ascii_decompress(p, len(a), ctypes.byref(out), ctypes.byref(n))
     if rc:
         raise RuntimeError("orc_lcpcomp_ascii_decompress rc=%d" % rc)
+    return _take(out, n.value)
+
+
+def lcpcomp_sle_compress(text, threshold=5, flatten=1, kmer=3):
+    """lcpcomp(coder=sle(kmer)) -- coders/SLECoder.hpp"""
+    a, p = _buf(text)
+    out, n, st = ctypes.c_void_p(), ctypes.c_size_t(), Stats()
+    rc = lib().orc_lcpcomp_sle_compress(p, len(a), threshold, flatten, kmer, ctypes.byref(out), ctypes.byref(n), ctypes.byref(st))
+    if rc:
+        raise RuntimeError("orc_lcpcomp_sle_compress rc=%d" % rc)
+    return _take(out, n.value), st.as_dict()
+
+
+def encode_sle(text, f, kmer=3):
+    a, p = _buf(text)
+    f = np.ascontiguousarray(f)
+    out, n, st = ctypes.c_void_p(), ctypes.c_size_t(), Stats()
+    rc = lib().orc_encode_sle(p, len(a), f.ctypes.data_as(ctypes.c_void_p), len(f), kmer, ctypes.byref(out), ctypes.byref(n), ctypes.byref(st))
+    if rc:
+        raise RuntimeError("orc_encode_sle rc=%d" % rc)
+    return _take(out, n.value), st.as_dict()
+
+
+def lcpcomp_sle_decompress(stream, kmer=3):
+    a, p = _buf(stream)
+    out, n = ctypes.c_void_p(), ctypes.c_size_t()
+    rc = lib().orc_lcpcomp_sle_decompress(p, len(a), kmer, ctypes.byref(out), ctypes.byref(n))
+    if rc:
+        raise RuntimeError("orc_lcpcomp_sle_decompress rc=%d" % rc)
     return _take(out, n.value)
 
 

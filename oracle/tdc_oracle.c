@@ -712,10 +712,153 @@ static int arith_encode(arith_enc* a, bitout* b, uint8_t v) {            /* enco
     return 0;
 }
 
+
+/* ------------------------------------------------------------------------------------------------
+ * SLECoder (coders/SLECoder.hpp): "static low entropy" coder.  The alphabet is the literal bytes plus the eta most
+ * frequent k-mers of the literal runs (k = option "kmer", default 3); symbols are ranked by (count descending, symbol
+ * value ascending) (util/Counter.hpp:44-57; a k-mer's symbol value is its bytes, first byte most significant, with
+ * 0xFF in the top byte :18-26) and a rank is written in one of a few fixed classes (:165-213).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { uint64_t sym, cnt; } sle_ent;
+static int sle_cmp_sorted(const void* a, const void* b) {                  /* Counter::getSorted :44-57 */
+    const sle_ent* x = (const sle_ent*)a, *y = (const sle_ent*)b;
+    if (x->cnt != y->cnt) return x->cnt > y->cnt ? -1 : 1;
+    return x->sym < y->sym ? -1 : (x->sym > y->sym ? 1 : 0);
+}
+static int sle_cmp_u64(const void* a, const void* b) {
+    const uint64_t x = *(const uint64_t*)a, y = *(const uint64_t*)b;
+    return x < y ? -1 : (x > y ? 1 : 0);
+}
+static int sle_cmp_sym(const void* a, const void* b) { return sle_cmp_u64(&((const sle_ent*)a)->sym, &((const sle_ent*)b)->sym); }
+#define SLE_KMER_MASK (0xFFull << 56)
+typedef struct {
+    unsigned k, sigma_bits, cur;
+    size_t sigma;
+    sle_ent* ranked;           /* alphabet in rank order (sym, count) */
+    sle_ent* by_sym;           /* (sym, rank) sorted by sym */
+    uint8_t buf[8];
+} sle_enc;
+static uint64_t sle_compile_kmer(const uint8_t* kmer, unsigned k) {        /* :18-26 */
+    uint64_t x = 0;
+    for (unsigned i = 0; i < k; ++i) x |= (uint64_t)kmer[k - 1 - i] << (8 * i);
+    return x | SLE_KMER_MASK;
+}
+static long sle_rank(const sle_enc* e, uint64_t sym) {
+    sle_ent key = { sym, 0 };
+    const sle_ent* r = (const sle_ent*)bsearch(&key, e->by_sym, e->sigma, sizeof(sle_ent), sle_cmp_sym);
+    return r ? (long)r->cnt : -1;
+}
+/* Encoder ctor :83-160: count literals and the k-mers of the literal runs, extend the alphabet, write the ranking */
+static int sle_init(sle_enc* e, unsigned k, const uint8_t* text, size_t n, const orc_factor* f, size_t z, bitout* b) {
+    memset(e, 0, sizeof(*e));
+    e->k = k;
+    uint32_t* lpos = (uint32_t*)malloc((n ? n : 1) * sizeof(uint32_t));
+    if (!lpos) return -1;
+    const size_t nl = orc_literal_positions(n, f, z, lpos);
+    uint64_t C[256]; memset(C, 0, sizeof(C));
+    uint64_t* km = (uint64_t*)malloc((nl ? nl : 1) * sizeof(uint64_t));
+    if (!km) { free(lpos); return -1; }
+    size_t nk = 0;
+    unsigned cur = 0; size_t last = 0; uint8_t buf[8];
+    for (size_t i = 0; i < nl; ++i) {                                      /* :96-120 */
+        const size_t pos = lpos[i]; const uint8_t c = text[pos];
+        if (k > 1) {
+            if (pos != last + 1) cur = 0;
+            if (cur == k) { for (unsigned j = 0; j + 1 < k; ++j) buf[j] = buf[j + 1]; --cur; }   /* kmer_roll :55-66 */
+            buf[cur++] = c;
+            if (cur == k) km[nk++] = sle_compile_kmer(buf, k);
+        }
+        ++C[c];
+        last = pos;
+    }
+    free(lpos);
+    size_t sigma = 0;
+    for (int c = 0; c < 256; ++c) sigma += C[c] != 0;
+    e->sigma_bits = orc_bits_for(sigma - 1);
+    sle_ent* alpha = (sle_ent*)malloc((256 + 2048 + 8) * sizeof(sle_ent));
+    size_t na = 0;
+    for (int c = 0; c < 256; ++c) if (C[c]) { alpha[na].sym = (uint64_t)c; alpha[na].cnt = C[c]; ++na; }
+    if (k > 1) {                                                           /* :126-143 */
+        const unsigned add = (((size_t)1 << e->sigma_bits) == sigma) ? 1 : 2;
+        size_t eta = ((size_t)1 << (e->sigma_bits + add)) - sigma;
+        qsort(km, nk, sizeof(uint64_t), sle_cmp_u64);
+        size_t nd = 0;
+        sle_ent* kd = (sle_ent*)malloc((nk ? nk : 1) * sizeof(sle_ent));
+        for (size_t i = 0; i < nk;) { size_t j = i; while (j < nk && km[j] == km[i]) ++j; kd[nd].sym = km[i]; kd[nd].cnt = j - i; ++nd; i = j; }
+        qsort(kd, nd, sizeof(sle_ent), sle_cmp_sorted);
+        for (size_t i = 0; i < nd; ++i) { alpha[na++] = kd[i]; if (--eta == 0) break; }
+        free(kd);
+        sigma = na;
+        e->sigma_bits = orc_bits_for(sigma - 1);
+    }
+    free(km);
+    qsort(alpha, na, sizeof(sle_ent), sle_cmp_sorted);                     /* createRanking :60-70 */
+    e->sigma = na;
+    e->ranked = alpha;
+    e->by_sym = (sle_ent*)malloc((na ? na : 1) * sizeof(sle_ent));
+    for (size_t i = 0; i < na; ++i) { e->by_sym[i].sym = alpha[i].sym; e->by_sym[i].cnt = i; }
+    qsort(e->by_sym, na, sizeof(sle_ent), sle_cmp_sym);
+    bo_write_compressed_int(b, sigma, 7);                                  /* :155-158 */
+    for (size_t i = 0; i < na; ++i) bo_write_compressed_int(b, alpha[i].sym, 7);
+    e->cur = 0;
+    return 0;
+}
+static void sle_free(sle_enc* e) { free(e->ranked); free(e->by_sym); }
+static void sle_encode_sym(const sle_enc* e, bitout* b, uint64_t x) {      /* :182-245 */
+    const uint64_t r = (uint64_t)sle_rank(e, x);
+    const unsigned sb = e->sigma_bits;
+    if (sb < 4) bo_write_int(b, r, sb);
+    else if (sb < 6) {
+        if (r < 4) { bo_write_bit(b, 0); bo_write_int(b, r, 2); }
+        else { bo_write_bit(b, 1); bo_write_int(b, r, sb); }
+    } else if (sb == 6) {
+        if (r < 8) { bo_write_int(b, 0, 2); bo_write_int(b, r, 3); }
+        else if (r < 16) { bo_write_int(b, 1, 2); bo_write_int(b, r - 8, 3); }
+        else if (r < 32) { bo_write_int(b, 2, 2); bo_write_int(b, r - 16, 4); }
+        else { bo_write_int(b, 3, 2); bo_write_int(b, r, sb); }
+    } else {
+        if (r < 4) { bo_write_int(b, 0, 3); bo_write_int(b, r, 2); }
+        else if (r < 8) { bo_write_int(b, 1, 3); bo_write_int(b, r - 4, 2); }
+        else if (r < 12) { bo_write_int(b, 2, 3); bo_write_int(b, r - 8, 2); }
+        else if (r < 16) { bo_write_int(b, 3, 3); bo_write_int(b, r - 12, 2); }
+        else if (r < 24) { bo_write_int(b, 4, 3); bo_write_int(b, r - 16, 3); }
+        else if (r < 32) { bo_write_int(b, 5, 3); bo_write_int(b, r - 24, 3); }
+        else if (r < 40) { bo_write_int(b, 6, 3); bo_write_int(b, r - 32, 3); }
+        else { bo_write_int(b, 7, 3); bo_write_int(b, r, sb); }
+    }
+}
+static void sle_flush(sle_enc* e, bitout* b) {                             /* flush_kmer :172-180 */
+    for (unsigned i = 0; i < e->cur; ++i) sle_encode_sym(e, b, e->buf[i]);
+    e->cur = 0;
+}
+static void sle_literal(sle_enc* e, bitout* b, uint8_t c) {                /* encode(v, LiteralRange) :249-266 */
+    if (e->cur == e->k) {                                                  /* kmer_roll: the oldest byte leaves as a single symbol */
+        const uint8_t out = e->buf[0];
+        for (unsigned j = 0; j + 1 < e->k; ++j) e->buf[j] = e->buf[j + 1];
+        --e->cur;
+        e->buf[e->cur++] = c;
+        sle_encode_sym(e, b, out);
+    } else e->buf[e->cur++] = c;
+    if (e->cur == e->k) {
+        const uint64_t x = sle_compile_kmer(e->buf, e->k);
+        if (sle_rank(e, x) >= 0) { sle_encode_sym(e, b, x); e->cur = 0; }
+    }
+}
+static void sle_min_distributed(bitout* b, uint64_t v, unsigned bits) {    /* encode(v, MinDistributedRange) :274-296, v already minus min */
+    if (bits <= 5) bo_write_int(b, v, bits);
+    else if (v < 8) { bo_write_int(b, 0, 2); bo_write_int(b, v, 3); }
+    else if (v < 16) { bo_write_int(b, 1, 2); bo_write_int(b, v - 8, 3); }
+    else if (v < 32) { bo_write_int(b, 2, 2); bo_write_int(b, v - 16, 4); }
+    else { bo_write_int(b, 3, 2); bo_write_int(b, v, bits); }
+}
+static unsigned g_sle_k = 3;    /* option "kmer" (SLECoder.hpp:38); set around one call, the oracle is single-threaded test code */
+
 /* ------------------------------------------------------------------------------------------------
  * lzss::encode_text (LZSSCoding.hpp:18-92) with tdc::Encoder's binary integer coding (Coder.hpp:61-77)
  * coder: 0 = HuffmanCoder, 1 = ArithmeticCoder, 2 = ASCIICoder (coders/ASCIICoder.hpp:29-50: integers in decimal
- * followed by ':', bits as '0' / '1', literals raw, and NO subtraction of the range minimum)
+ * followed by ':', bits as '0' / '1', literals raw, and NO subtraction of the range minimum), 3 = SLECoder (above; every
+ * non-literal write first flushes the pending k-mer buffer, and the factor length -- a MinDistributedRange,
+ * LZSSCoding.hpp:42 -- has its own class code)
  * ---------------------------------------------------------------------------------------------- */
 static void ascii_int(bitout* b, uint64_t v) {                            /* ASCIICoder.hpp:33-39 */
     char tmp[24]; int k = 0;
@@ -729,14 +872,19 @@ static int encode_stream(const uint8_t* text, size_t n, const orc_factor* f, siz
     orc_literal_histogram(text, n, f, z, C);
     orc_hufftable t; memset(&t, 0, sizeof(t));
     arith_enc ac;
+    sle_enc se;
     bitout b; bo_init(&b);
     if (coder == 0) { orc_huffman_table(C, &t); huff_write_header(&b, &t); }   /* Encoder ctor */
     else if (coder == 1) arith_init(&ac, C, &b);
+    else if (coder == 3) { if (sle_init(&se, g_sle_k, text, n, f, z, &b)) return -1; }
     int rc = 0;
 #define ENC_LITERAL(ch) do { if (coder == 0) huff_encode_literal(&b, &t, (ch)); else if (coder == 2) bo_write_int(&b, (ch), 8); \
+                             else if (coder == 3) sle_literal(&se, &b, (ch)); \
                              else if (arith_encode(&ac, &b, (ch))) rc = -8; } while (0)
-#define ENC_INT(v, bits) do { if (coder == 2) ascii_int(&b, (v)); else bo_write_int(&b, (v), (bits)); } while (0)
-#define ENC_BIT(x) do { if (coder == 2) bo_write_int(&b, (x) ? '1' : '0', 8); else bo_write_bit(&b, (x)); } while (0)
+#define ENC_INT(v, bits) do { if (coder == 3) sle_flush(&se, &b); \
+                              if (coder == 2) ascii_int(&b, (v)); else bo_write_int(&b, (v), (bits)); } while (0)
+#define ENC_BIT(x) do { if (coder == 3) sle_flush(&se, &b); \
+                        if (coder == 2) bo_write_int(&b, (x) ? '1' : '0', 8); else bo_write_bit(&b, (x)); } while (0)
 
     uint64_t flen_min = 0xFFFFFFFFull, flen_max = 0, fdist_max = 0;       /* LZSSFactors.hpp:33-38 INDEX_MAX / 0 */
     {
@@ -763,7 +911,8 @@ static int encode_stream(const uint8_t* text, size_t n, const orc_factor* f, siz
         else { ENC_BIT(1); ENC_INT(f[i].pos - p, dbits); }
         while (p < f[i].pos) ENC_LITERAL(text[p++]);
         ENC_INT(f[i].src, W);
-        ENC_INT(f[i].len - lsub, lbits);
+        if (coder == 3) { sle_flush(&se, &b); sle_min_distributed(&b, f[i].len - lsub, lbits); }
+        else ENC_INT(f[i].len - lsub, lbits);
         p += f[i].len;
     }
     if (p < n) { ENC_BIT(1); ENC_INT(n - p, dbits); }                      /* :83-86 */
@@ -771,6 +920,7 @@ static int encode_stream(const uint8_t* text, size_t n, const orc_factor* f, siz
 #undef ENC_LITERAL
 #undef ENC_INT
 #undef ENC_BIT
+    if (coder == 3) { sle_flush(&se, &b); sle_free(&se); }                 /* ~Encoder :161-167 */
     bo_finish(&b);                                                         /* ~BitOStream */
     *out = b.buf; *out_len = b.len;
     if (st) { st->flen_min = flen_min; st->flen_max = flen_max; st->fdist_max = fdist_max; }
@@ -788,6 +938,15 @@ int orc_encode_arith(const uint8_t* text, size_t n, const orc_factor* f, size_t 
 int orc_encode_ascii(const uint8_t* text, size_t n, const orc_factor* f, size_t z,
                      uint8_t** out, size_t* out_len, orc_stats* st) {
     return encode_stream(text, n, f, z, 2, out, out_len, st);
+}
+
+int orc_encode_sle(const uint8_t* text, size_t n, const orc_factor* f, size_t z, unsigned kmer,
+                   uint8_t** out, size_t* out_len, orc_stats* st) {
+    if (kmer < 1 || kmer > 7) return -2;
+    g_sle_k = kmer;
+    const int rc = encode_stream(text, n, f, z, 3, out, out_len, st);
+    g_sle_k = 3;
+    return rc;
 }
 
 /* LCPCompressor.hpp:100-138 */
@@ -814,6 +973,15 @@ int orc_lcpcomp_arith_compress(const uint8_t* text, size_t n, uint32_t threshold
 int orc_lcpcomp_ascii_compress(const uint8_t* text, size_t n, uint32_t threshold, int flatten,
                                uint8_t** out, size_t* out_len, orc_stats* stats) {
     return lcpcomp_compress(text, n, threshold, flatten, 2, out, out_len, stats);
+}
+/* lcpcomp(coder=sle(kmer)): the coder of the reference's published lcpcomp runs (etc/compare-suites/default.suite:5) */
+int orc_lcpcomp_sle_compress(const uint8_t* text, size_t n, uint32_t threshold, int flatten, unsigned kmer,
+                             uint8_t** out, size_t* out_len, orc_stats* stats) {
+    if (kmer < 1 || kmer > 7) return -2;
+    g_sle_k = kmer;
+    const int rc = lcpcomp_compress(text, n, threshold, flatten, 3, out, out_len, stats);
+    g_sle_k = 3;
+    return rc;
 }
 static int lcpcomp_compress(const uint8_t* text, size_t n, uint32_t threshold, int flatten, int coder,
                             uint8_t** out, size_t* out_len, orc_stats* stats) {
@@ -962,6 +1130,97 @@ int orc_lcpcomp_ascii_decompress(const uint8_t* in, size_t in_len, uint8_t** out
             p += l;
         }
     }
+    if (p != n) { free(text); free(ref); return -5; }
+    for (uint64_t i = 0; i < n; ++i) {                                      /* chains end in literals */
+        uint32_t q = (uint32_t)i; uint64_t guard = 0;
+        while (ref[q] != 0xFFFFFFFFu) { q = ref[q]; if (++guard > n) { free(text); free(ref); return -6; } }
+        text[i] = text[q];
+    }
+    free(ref);
+    *out = text; *out_len = n;
+    return 0;
+}
+
+/* The same with SLECoder::Decoder (SLECoder.hpp:301-453): ranking header, rank classes, k-mer symbols expand to k
+ * literals; every non-literal read drops the rest of a pending k-mer (never needed for streams the encoder writes). */
+static uint64_t sle_read_rank(bitin* b, unsigned sb) {                      /* :367-397 */
+    if (sb < 4) return bi_read_int(b, sb);
+    if (sb < 6) return bi_read_bit(b) ? bi_read_int(b, sb) : bi_read_int(b, 2);
+    if (sb == 6) {
+        switch (bi_read_int(b, 2)) {
+            case 0: return bi_read_int(b, 3);
+            case 1: return 8 + bi_read_int(b, 3);
+            case 2: return 16 + bi_read_int(b, 4);
+            default: return bi_read_int(b, sb);
+        }
+    }
+    switch (bi_read_int(b, 3)) {
+        case 0: return bi_read_int(b, 2);
+        case 1: return 4 + bi_read_int(b, 2);
+        case 2: return 8 + bi_read_int(b, 2);
+        case 3: return 12 + bi_read_int(b, 2);
+        case 4: return 16 + bi_read_int(b, 3);
+        case 5: return 24 + bi_read_int(b, 3);
+        case 6: return 32 + bi_read_int(b, 3);
+        default: return bi_read_int(b, sb);
+    }
+}
+int orc_lcpcomp_sle_decompress(const uint8_t* in, size_t in_len, unsigned k, uint8_t** out, size_t* out_len) {
+    if (k < 1 || k > 7) return -2;
+    bitin b; bi_init(&b, in, in_len);
+    const size_t sigma = (size_t)bi_read_compressed_int(&b, 7);             /* Decoder ctor :325-340 */
+    if (sigma == 0 || sigma > 4096) return -4;
+    const unsigned sb = orc_bits_for(sigma - 1);
+    uint64_t* inv = (uint64_t*)malloc(sigma * sizeof(uint64_t));
+    for (size_t r = 0; r < sigma; ++r) inv[r] = bi_read_compressed_int(&b, 7);
+    uint8_t kmer[8]; size_t kread = (size_t)-1;
+    const uint64_t n = bi_read_int(&b, 32);
+    const unsigned W = orc_bits_for(n);
+    const uint64_t flen_min = bi_read_int(&b, W), flen_max = bi_read_int(&b, W);
+    const uint64_t fdist_max = bi_read_int(&b, W);
+    const unsigned lbits = orc_bits_for(flen_max - flen_min), dbits = orc_bits_for(fdist_max);
+    uint8_t* text = (uint8_t*)malloc(n ? n : 1);
+    uint32_t* ref = (uint32_t*)malloc((n ? n : 1) * sizeof(uint32_t));
+    if (!text || !ref || !inv) { free(text); free(ref); free(inv); return -1; }
+    uint64_t p = 0;
+#define SLE_EOF() (kread < k ? 0 : bi_eof(&b))                              /* eof :351-359 */
+    while (!SLE_EOF()) {
+        kread = (size_t)-1;
+        uint64_t num = bi_read_bit(&b) ? bi_read_int(&b, dbits) : 0;
+        while (num--) {
+            uint8_t c;
+            if (kread < k) c = kmer[kread++];                               /* :362-365 */
+            else {
+                const uint64_t r = sle_read_rank(&b, sb);
+                if (r >= sigma) { free(text); free(ref); free(inv); return -4; }
+                const uint64_t x = inv[r];
+                if ((x & SLE_KMER_MASK) == SLE_KMER_MASK) {                  /* decompile_kmer :28-32 */
+                    for (unsigned i = 0; i < k; ++i) kmer[k - 1 - i] = (uint8_t)(x >> (8 * i));
+                    kread = 1; c = kmer[0];
+                } else c = (uint8_t)x;
+            }
+            if (p >= n) { free(text); free(ref); free(inv); return -4; }
+            text[p] = c; ref[p] = 0xFFFFFFFFu; ++p;
+        }
+        if (!SLE_EOF()) {
+            kread = (size_t)-1;
+            const uint64_t src = bi_read_int(&b, W);
+            uint64_t v;                                                     /* decode(MinDistributedRange) :413-431 */
+            if (lbits <= 5) v = bi_read_int(&b, lbits);
+            else switch (bi_read_int(&b, 2)) {
+                case 0: v = bi_read_int(&b, 3); break;
+                case 1: v = 8 + bi_read_int(&b, 3); break;
+                case 2: v = 16 + bi_read_int(&b, 4); break;
+                default: v = bi_read_int(&b, lbits); break;
+            }
+            const uint64_t len = flen_min + v;
+            if (len == 0 || p + len > n || src + len > n) { free(text); free(ref); free(inv); return -4; }
+            for (uint64_t j = 0; j < len; ++j) ref[p + j] = (uint32_t)(src + j);
+            p += len;
+        }
+    }
+#undef SLE_EOF
+    free(inv);
     if (p != n) { free(text); free(ref); return -5; }
     for (uint64_t i = 0; i < n; ++i) {                                      /* chains end in literals */
         uint32_t q = (uint32_t)i; uint64_t guard = 0;

@@ -106,6 +106,12 @@ int orc_lcpcomp_ascii_compress(const uint8_t* text, size_t n, uint32_t threshold
 int orc_encode_ascii(const uint8_t* text, size_t n, const orc_factor* f, size_t z,
                      uint8_t** out, size_t* out_len, orc_stats* stats);
 int orc_lcpcomp_ascii_decompress(const uint8_t* in, size_t in_len, uint8_t** out, size_t* out_len);
+/* lcpcomp(coder=sle(kmer)) -- SLECoder (coders/SLECoder.hpp); kmer in 1..7 (the reference's default is 3) */
+int orc_lcpcomp_sle_compress(const uint8_t* text, size_t n, uint32_t threshold, int flatten, unsigned kmer,
+                             uint8_t** out, size_t* out_len, orc_stats* stats);
+int orc_encode_sle(const uint8_t* text, size_t n, const orc_factor* f, size_t z, unsigned kmer,
+                   uint8_t** out, size_t* out_len, orc_stats* st);
+int orc_lcpcomp_sle_decompress(const uint8_t* in, size_t in_len, unsigned kmer, uint8_t** out, size_t* out_len);
 /* LCPCompressor.hpp:140-150 / decode_text_internal :23-76 with HuffmanCoder::Decoder.
  * Produces the (still escaped, 0-terminated) text. *out malloc'd. */
 int orc_lcpcomp_huff_decompress(const uint8_t* in, size_t in_len, uint8_t** out, size_t* out_len);

@@ -58,6 +58,20 @@ def test_ascii_coder_decompress(tmp_path):
     assert out.read_bytes() == data
 
 
+@pytest.mark.parametrize("algo,k", [("lcpcomp(coder=sle,threshold=3)", 3), ("lcpcomp(coder=sle(kmer=2),threshold=3)", 2),
+                                    ("lcpcomp(coder=sle(1),threshold=3)", 1), ("lcpcomp(coder=sle(kmer=5),threshold=3)", 5)])
+def test_sle_coder_decompress(tmp_path, algo, k):
+    """lcpcomp(coder=sle(kmer)): host decoder of the facade (SLECoder::Decoder, coders/SLECoder.hpp:301-453)."""
+    data = T.gen_english(20000, 4).tobytes() + bytes([0, 255, 7]) + b"the the the "
+    payload, _ = O.lcpcomp_sle_compress(O.escape(data), 3, 1, k)
+    f = tmp_path / "s.tdc"
+    f.write_bytes(algo.encode() + b"%" + payload)
+    out = tmp_path / "s.out"
+    r = _run("-d", "-o", str(out), str(f))
+    assert r.returncode == 0, r.stderr
+    assert out.read_bytes() == data
+
+
 def test_lzss_lcp_decompress(tmp_path):
     data = T.gen_english(4000, 5).tobytes() + b"\x00\xff"
     payload, _ = O.lzss_lcp_huff_compress(O.escape(data), 3)
@@ -89,8 +103,10 @@ def test_errors(tmp_path):
     assert r.returncode == 1 and "No implementation found" in r.stderr
     r = _run("-a", "lzw(coder=huff)", "-o", str(tmp_path / "o5"), str(f))
     assert r.returncode == 1 and "No implementation found" in r.stderr
-    r = _run("-a", "lcpcomp(coder=sle)", "-o", str(tmp_path / "o3"), str(f))
+    r = _run("-a", "lcpcomp(coder=bit)", "-o", str(tmp_path / "o3"), str(f))
     assert r.returncode == 1 and "No implementation found" in r.stderr
+    r = _run("-a", "lcpcomp(coder=sle(kmer=9))", "-o", str(tmp_path / "o7"), str(f))
+    assert r.returncode == 1 and "kmer" in r.stderr
     g = tmp_path / "arith.tdc"
     g.write_bytes(b"lcpcomp(coder=arithmetic)%" + b"\x00" * 16)
     r = _run("-d", "-o", str(tmp_path / "o6"), str(g))

@@ -336,3 +336,54 @@ def test_lcpcomp_plcppeaks_strategy(gpu_ctx):
             except RuntimeError:
                 ok = None                       # 256 equal-length codes: undecodable for the reference as well
             assert ok in (True, None), name
+
+
+def _sle_cases():
+    rng = np.random.default_rng(11)
+    cases = [c for c in SMALL]
+    cases += [("english_300k", T.gen_english(300_000, 3).tobytes()), ("dna_100k", T.gen_dna(100_000, 7).tobytes()),
+              ("random_100k", rng.integers(0, 256, 100_000, dtype=np.uint8).tobytes()),           # sigma_bits >= 7, literal runs of many tiles
+              ("abc_periodic", b"abc" * 20_000 + b"xyz" + b"bca" * 10_000)]
+    for sig in (2, 5, 9, 17, 33, 65, 130):                                                        # every rank class of encode_sym
+        cases.append(("sigma%d" % sig, bytes(1 + int(x) % sig for x in rng.integers(0, 1 << 30, 20_000))))
+    return cases
+
+
+def test_lcpcomp_sle_coder(gpu_ctx):
+    """lcpcomp(coder=sle(kmer)) (coders/SLECoder.hpp): device stream == oracle for kmer 1..3, round trip through
+    the oracle's SLE decoder; kmer > 3 is refused, never approximated."""
+    for name, data in _sle_cases():
+        text = O.escape(data)
+        for thr in (2, 5):
+            for k in (1, 2, 3):
+                want, _ = O.lcpcomp_sle_compress(text, thr, 1, k)
+                got, st = gpu_ctx.lcpcomp_compress(text, thr, 1, T.CODER_SLE | (k << 8))
+                assert got == want, "%s t=%d k=%d: %d vs %d bytes" % (name, thr, k, len(got), len(want))
+        assert O.lcpcomp_sle_decompress(got, 3) == text
+    text = O.escape(T.gen_english(5000, 1).tobytes())
+    got, _ = gpu_ctx.lcpcomp_compress(text, 5, 1, T.CODER_SLE)                                    # kmer omitted = 3
+    assert got == O.lcpcomp_sle_compress(text, 5, 1, 3)[0]
+    with pytest.raises(T.TdcGpuError):
+        gpu_ctx.lcpcomp_compress(text, 5, 1, T.CODER_SLE | (4 << 8))
+    c = T.LCPCompressor(gpu_ctx, coder="sle", threshold=5)
+    data = T.gen_dna(50_000, 3).tobytes() + bytes([0, 255])
+    assert O.unescape(O.lcpcomp_sle_decompress(c.compress(data), 3)) == data
+
+
+def test_sle_literal_runs_without_factors(gpu_ctx):
+    """SLE k-mer buffer state carried across tiles: one literal run over the whole text (no factors), texts in which all
+    three alignments of a k-mer are ranked, and factor lists that cut the runs at every residue."""
+    rng = np.random.default_rng(3)
+    texts = [b"abc" * 30_000 + b"\0", b"ab" * 40_000 + b"\0", O.escape(T.gen_english(100_000, 9).tobytes()),
+             bytes(rng.integers(1, 4, 70_000, dtype=np.uint8)) + b"\0"]
+    none = np.zeros(0, dtype=np.uint32)
+    for text in texts:
+        for k in (1, 2, 3):
+            want, _ = O.encode_sle(text, factors_struct(none, none, none), k)
+            assert gpu_ctx.encode_sle(text, none, none, none, k) == want
+            # factors of length 2 every 7..23 positions (sources are irrelevant to the coder)
+            pos = np.cumsum(rng.integers(7, 24, len(text) // 16)).astype(np.uint32)
+            pos = pos[pos + 2 < len(text) - 1]
+            src = np.zeros_like(pos); ln = np.full_like(pos, 2)
+            want, _ = O.encode_sle(text, factors_struct(pos, src, ln), k)
+            assert gpu_ctx.encode_sle(text, pos, src, ln, k) == want

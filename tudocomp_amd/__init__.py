@@ -15,6 +15,7 @@ CODER_HUFF = 0
 CODER_GAMMA = 1
 CODER_ARITH = 2
 CODER_ASCII = 3
+CODER_SLE = 4            # coder=sle(kmer=k): CODER_SLE | (k << 8), k = 0 means the reference's default 3
 COMP_ARRAYS = 0
 COMP_PLCPPEAKS = 1
 
@@ -235,6 +236,17 @@ class Context:
                                             ctypes.byref(md)))
         return src, nf.value, md.value
 
+    def encode_sle(self, text, pos, src, length, kmer=3):
+        """SLECoder::Encoder (coders/SLECoder.hpp:42-298) + lzss::encode_text on a given factor list"""
+        a = _u8(text)
+        pos = np.ascontiguousarray(pos, dtype=np.uint32)
+        src = np.ascontiguousarray(src, dtype=np.uint32)
+        length = np.ascontiguousarray(length, dtype=np.uint32)
+        out, n = ctypes.c_void_p(), ctypes.c_size_t()
+        self._check(self._L.tdc_gpu_encode_sle(self._h, _ptr(a), len(a), _ptr(pos), _ptr(src), _ptr(length), len(pos), int(kmer),
+                                               ctypes.byref(out), ctypes.byref(n)))
+        return self._take(out, n.value)
+
     def encode_ascii(self, text, pos, src, length):
         return self.encode_huff(text, pos, src, length, _fn="tdc_gpu_encode_ascii")
 
@@ -257,12 +269,12 @@ class LCPCompressor:
     reference's test harness drives it (test/test/util.hpp:442-463): the input is wrapped with the compressor's
     input restrictions (escape {0}, null-terminate) and handed to compress()."""
 
-    def __init__(self, ctx, coder="huff", threshold=5, flatten=1, comp="arrays"):
-        if coder not in ("huff", "arithmetic", "ascii") or comp not in ("arrays", "plcppeaks"):
+    def __init__(self, ctx, coder="huff", threshold=5, flatten=1, comp="arrays", kmer=3):
+        if coder not in ("huff", "arithmetic", "ascii", "sle") or comp not in ("arrays", "plcppeaks"):
             # same wording as Registry.hpp:214
             raise RuntimeError("No implementation found for compressor lcpcomp(coder=%s,comp=%s)" % (coder, comp))
         self.ctx, self.threshold, self.flatten = ctx, int(threshold), int(flatten)
-        self.coder = {"huff": CODER_HUFF, "arithmetic": CODER_ARITH, "ascii": CODER_ASCII}[coder]
+        self.coder = {"huff": CODER_HUFF, "arithmetic": CODER_ARITH, "ascii": CODER_ASCII, "sle": CODER_SLE | (int(kmer) << 8)}[coder]
         self.comp = COMP_PLCPPEAKS if comp == "plcppeaks" else COMP_ARRAYS
         self.last_stats = None
 

@@ -58,7 +58,21 @@ int guarded(tdc_gpu_ctx* ctx, F&& f) {
     }
 }
 
-size_t arena_need(size_t n) { return 112 * n + ((size_t)64 << 20); }
+// + 192 MiB: fixed-size scratch (the SLE coder's 2^24-entry k-mer table and its sort buffers are the largest)
+size_t arena_need(size_t n) { return 112 * n + ((size_t)192 << 20); }
+
+// public coder id (+ SLE's kmer option in bits 8..) -> coder id of encode_stream
+int lcpcomp_enc_coder(int coder) {
+    const int base = coder & 0xFF, k = coder >> 8;
+    if (base == TDC_GPU_CODER_SLE) {
+        if (k < 0 || k > 7) throw ArgError{TDC_GPU_ERR_ARG, "sle: kmer must be in 1..7"};       // SLECoder.hpp:12,86 (max_kmer = 7)
+        return 3 | ((k ? k : 3) << 8);
+    }
+    if (k == 0 && base == TDC_GPU_CODER_HUFF) return 0;
+    if (k == 0 && base == TDC_GPU_CODER_ARITH) return 1;
+    if (k == 0 && base == TDC_GPU_CODER_ASCII) return 2;
+    throw ArgError{TDC_GPU_ERR_UNSUPPORTED, "lcpcomp: coder must be huff, arithmetic, ascii or sle"};
+}
 
 void check_text_args(const void* text, size_t n) {
     if (!text) throw ArgError{TDC_GPU_ERR_ARG, "text is NULL"};
@@ -169,7 +183,7 @@ size_t run_pipeline(Ctx& c, const u8* d_text, size_t n, u32 threshold, int flatt
     run_textds(c, d_text, n, A, st, &ev);
     run_factorize(c, n, A, threshold, flatten, st, &ev, strategy);
     EncodeStats es;
-    const int enc_coder = coder == TDC_GPU_CODER_ARITH ? 1 : (coder == TDC_GPU_CODER_ASCII ? 2 : 0);
+    const int enc_coder = lcpcomp_enc_coder(coder);
     if (!*d_out_io) { out_cap = align_up(encode_bound_coder(n, enc_coder) + 16, 8); *d_out_io = c.arena.get<u8>(out_cap); }
     u8* d_out = *d_out_io;
     const int e0 = ev.tick();
@@ -323,7 +337,7 @@ size_t tdc_gpu_lcpcomp_bound(size_t n) { return align_up(encode_bound(n) + 16, 8
 int tdc_gpu_lcpcomp_compress_dev(tdc_gpu_ctx* ctx, const void* d_text, size_t n, uint32_t threshold, int flatten, int coder,
                                  void* d_out, size_t out_cap, size_t* out_len, tdc_gpu_stats* stats) {
     return guarded(ctx, [&] {
-        if (coder != TDC_GPU_CODER_HUFF && coder != TDC_GPU_CODER_ARITH && coder != TDC_GPU_CODER_ASCII) throw ArgError{TDC_GPU_ERR_UNSUPPORTED, "lcpcomp: coder must be huff, arithmetic or ascii"};
+        (void)lcpcomp_enc_coder(coder);
         check_text_args(d_text, n);
         if (!d_out || !out_len || ((uintptr_t)d_out & 7)) throw ArgError{TDC_GPU_ERR_ARG, "d_out must be non-NULL and 8-byte aligned"};
         Ctx& c = ctx->c;
@@ -342,7 +356,7 @@ int tdc_gpu_lcpcomp_compress_dev(tdc_gpu_ctx* ctx, const void* d_text, size_t n,
 int tdc_gpu_lcpcomp_compress(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, uint32_t threshold, int flatten, int coder,
                              uint8_t** out, size_t* out_len, tdc_gpu_stats* stats) {
     return guarded(ctx, [&] {
-        if (coder != TDC_GPU_CODER_HUFF && coder != TDC_GPU_CODER_ARITH && coder != TDC_GPU_CODER_ASCII) throw ArgError{TDC_GPU_ERR_UNSUPPORTED, "lcpcomp: coder must be huff, arithmetic or ascii"};
+        (void)lcpcomp_enc_coder(coder);
         check_text_args(text, n);
         if (!out || !out_len) throw ArgError{TDC_GPU_ERR_ARG, "out/out_len is NULL"};
         if (text[n - 1] != 0) throw ArgError{TDC_GPU_ERR_NO_SENTINEL, "text does not end with a 0 sentinel"};
@@ -369,7 +383,7 @@ int tdc_gpu_lcpcomp_compress(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, ui
 int tdc_gpu_lcpcomp_compress_comp(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, uint32_t threshold, int flatten, int coder,
                                   int comp, uint8_t** out, size_t* out_len, tdc_gpu_stats* stats) {
     return guarded(ctx, [&] {
-        if (coder != TDC_GPU_CODER_HUFF && coder != TDC_GPU_CODER_ARITH && coder != TDC_GPU_CODER_ASCII) throw ArgError{TDC_GPU_ERR_UNSUPPORTED, "lcpcomp: coder must be huff, arithmetic or ascii"};
+        (void)lcpcomp_enc_coder(coder);
         if (comp != TDC_GPU_COMP_ARRAYS && comp != TDC_GPU_COMP_PLCPPEAKS) throw ArgError{TDC_GPU_ERR_UNSUPPORTED, "lcpcomp: comp must be arrays or plcppeaks"};
         check_text_args(text, n);
         if (!out || !out_len) throw ArgError{TDC_GPU_ERR_ARG, "out/out_len is NULL"};
@@ -397,7 +411,7 @@ int tdc_gpu_lcpcomp_compress_comp(tdc_gpu_ctx* ctx, const uint8_t* text, size_t 
 int tdc_gpu_lcpcomp_compress_raw(tdc_gpu_ctx* ctx, const uint8_t* data, size_t n, uint32_t threshold, int flatten, int coder,
                                  uint8_t** out, size_t* out_len, tdc_gpu_stats* stats) {
     return guarded(ctx, [&] {
-        if (coder != TDC_GPU_CODER_HUFF && coder != TDC_GPU_CODER_ARITH && coder != TDC_GPU_CODER_ASCII) throw ArgError{TDC_GPU_ERR_UNSUPPORTED, "lcpcomp: coder must be huff, arithmetic or ascii"};
+        (void)lcpcomp_enc_coder(coder);
         if ((!data && n) || !out || !out_len) throw ArgError{TDC_GPU_ERR_ARG, "NULL argument"};
         if (n >= (1ull << 30)) throw ArgError{TDC_GPU_ERR_TOO_LARGE, "raw input must be < 2^30 bytes (the escaped text must stay < 2^31)"};
         Ctx& c = ctx->c;
@@ -670,6 +684,11 @@ int tdc_gpu_encode_arith(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, const 
 int tdc_gpu_encode_ascii(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, const uint32_t* pos, const uint32_t* src,
                          const uint32_t* len, size_t z, uint8_t** out, size_t* out_len) {
     return encode_entry(ctx, 2, text, n, pos, src, len, z, out, out_len);
+}
+int tdc_gpu_encode_sle(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, const uint32_t* pos, const uint32_t* src,
+                       const uint32_t* len, size_t z, uint32_t kmer, uint8_t** out, size_t* out_len) {
+    if (kmer > 7) return TDC_GPU_ERR_ARG;
+    return encode_entry(ctx, 3 | ((int)(kmer ? kmer : 3) << 8), text, n, pos, src, len, z, out, out_len);
 }
 static int encode_entry(tdc_gpu_ctx* ctx, int coder, const uint8_t* text, size_t n, const uint32_t* pos, const uint32_t* src,
                         const uint32_t* len, size_t z, uint8_t** out, size_t* out_len) {

@@ -12,6 +12,7 @@ namespace tdc {
 
 typedef uint8_t  u8;
 typedef uint32_t u32;
+typedef uint16_t u16;
 typedef uint64_t u64;
 
 constexpr u32 NONE32 = 0xFFFFFFFFu;

@@ -22,6 +22,8 @@
 #include "arith.hpp"
 
 #include <string.h>
+#include <algorithm>
+#include <vector>
 
 namespace tdc {
 
@@ -282,22 +284,19 @@ __global__ void terminator_kernel(u8* out, u64 total_bits) {
 }
 
 // worst case per position: 1 + 32 bits of run header + 64 (+128 once) of arithmetic words; ASCIICoder (coder 2): a one-byte
-// factor costs '0' + two integers of up to 10 digits and ':' each
+// factor costs '0' + two integers of up to 10 digits and ':' each; SLECoder (coder 3): at most 13 bits per literal, 67 per factor,
+// and a ranking header of at most 1024 symbols of 10 bytes
 size_t encode_bound(size_t n) { return 12 * n + 4096; }
-size_t encode_bound_coder(size_t n, int coder) { return (coder == 2 ? 24 : 12) * n + 4096; }
+size_t encode_bound_coder(size_t n, int coder) { return ((coder & 0xFF) == 2 ? 24 : 12) * n + ((coder & 0xFF) == 3 ? 32768 : 4096); }
 
 size_t encode_huff(Ctx& c, const u8* text, size_t n, FactorSpace fs, u8* d_out, size_t out_cap, EncodeStats* st) {
     return encode_stream(c, text, n, fs, 0, d_out, out_cap, st);
 }
 
-size_t encode_stream(Ctx& c, const u8* text, size_t n, FactorSpace fs, int coder, u8* d_out, size_t out_cap, EncodeStats* st) {
-    EncodeStats local;
-    if (!st) st = &local;
-    *st = EncodeStats();
+// factor list in position order, gaps + min/max lengths (run lengths stored at run starts), literal histogram
+struct EncPrelude { size_t z; u32 hist[256]; EncScalars sc; };
+static void encode_prelude(Ctx& c, const u8* text, size_t n, FactorSpace& fs, EncPrelude& pre) {
     hipStream_t s = c.stream;
-    const size_t mark = c.arena.mark();
-
-    // ---- factor list (position order), gaps, min/max lengths ------------------------------------------------
     u32* fpos = fs.have_list ? fs.fpos : c.arena.get<u32>(n);
     u32* flist = fs.have_list ? nullptr : c.arena.get<u32>(n);
     const size_t z = fs.have_list ? fs.nfact : extract_factors(c, n, fs, fpos, nullptr, flist, n);
@@ -324,9 +323,26 @@ size_t encode_stream(Ctx& c, const u8* text, size_t n, FactorSpace fs, int coder
         literal_hist_kernel<<<g, 256, 0, s>>>(text, fs.owner, n, d_hist);
         LAUNCH_CHECK();
     }
-    u32 h_hist[256];
-    c.read_n(d_hist, h_hist, 256);
-    h_sc = c.read(d_sc);
+    c.read_n(d_hist, pre.hist, 256);
+    pre.sc = c.read(d_sc);
+    pre.z = z;
+}
+
+static size_t encode_sle(Ctx& c, const u8* text, size_t n, FactorSpace fs, u32 k, u8* d_out, size_t out_cap, EncodeStats* st);
+
+size_t encode_stream(Ctx& c, const u8* text, size_t n, FactorSpace fs, int coder, u8* d_out, size_t out_cap, EncodeStats* st) {
+    EncodeStats local;
+    if (!st) st = &local;
+    *st = EncodeStats();
+    if ((coder & 0xFF) == 3) return encode_sle(c, text, n, fs, (u32)(coder >> 8), d_out, out_cap, st);
+    hipStream_t s = c.stream;
+    const size_t mark = c.arena.mark();
+
+    EncPrelude pre;
+    encode_prelude(c, text, n, fs, pre);
+    const size_t z = pre.z;
+    const u32* h_hist = pre.hist;
+    EncScalars h_sc = pre.sc;
 
     // ---- host: coder header (HuffmanCoder::Encoder ctor :526-547 / ArithmeticCoder::Encoder ctor :158-164),
     //      then the fields of LZSSCoding.hpp:47-50
@@ -405,6 +421,402 @@ size_t encode_stream(Ctx& c, const u8* text, size_t n, FactorSpace fs, int coder
     st->flen_min = h_sc.flen_min; st->flen_max = h_sc.flen_max; st->fdist_max = h_sc.fdist_max;
     st->out_bits = total_bits;
     st->sigma = ht.sigma;
+    c.arena.release(mark);
+    return out_len;
+}
+
+// ============================================================================================================
+// coder = SLECoder (coders/SLECoder.hpp): literal bytes + the eta most frequent k-mers of the literal runs form one
+// alphabet, ranked by (count descending, symbol ascending) (util/Counter.hpp:44-70); a rank is written in a fixed class
+// code that depends on sigma_bits (:182-245); the factor length (a MinDistributedRange, LZSSCoding.hpp:42) has its own
+// class code (:274-296).  Inside a literal run the encoder keeps the last <= k literals in a buffer (:55-66, :249-266):
+// a full buffer whose k-mer is ranked is written as ONE symbol and the buffer restarts; otherwise the oldest byte leaves
+// as a single symbol; every non-literal write flushes the buffer as single symbols (:172-180).
+//
+// The buffer fill s in 0..k is the only state (the buffer content is the last s text bytes), and a literal position i
+// maps s -> fired(i) ? 0 : min(s+1, k) with fired(i) = ranked(i) && s >= k-1; a non-literal position maps every s to 0.
+// These maps compose associatively, so the fill at every position comes from a scan of 4-entry maps: per tile of 2048
+// positions, over the tile composites (one workgroup), and again inside the tile.  fired(i) makes i-k+1 the start of
+// a k-mer symbol and i-k+2..i its interior (no bits); every other literal is a single symbol.  Symbols are emitted in
+// text order (a rolled-out byte is older than everything in the buffer), so the stream is again a per-position cost.
+// ============================================================================================================
+constexpr u32 SLE_MAX_KMERS = 1024;           // eta <= 2^(8+2) - 129
+constexpr u16 SLE_LIT = 0x8000, SLE_RANKED = 0x4000, SLE_FIRED = 0x2000, SLE_RANK_MASK = 0x03FF;
+
+struct SleDev {
+    u16 rank_byte[256];
+    u32 sb, k, nk;
+    u32 f0, f1;              // state maps of a literal position without / with a ranked k-mer ending there (4 bits per state)
+    const u32* kval;         // ranked k-mers (byte string as an integer, first byte most significant), ascending
+    const u16* krank;
+};
+
+__device__ __forceinline__ u32 sle_key(const u8* __restrict__ text, size_t p, u32 k) {     // compile_kmer :18-26 without the marker byte
+    u32 x = 0;
+    for (u32 j = 0; j < k; ++j) x = (x << 8) | text[p - (k - 1) + j];
+    return x;
+}
+
+// Encoder ctor :96-120: every k-mer window that lies inside one literal run is counted
+__global__ __launch_bounds__(256) void sle_kmer_count_kernel(const u8* __restrict__ text, const u32* __restrict__ owner, size_t n, u32 k,
+                                                              u32* __restrict__ cnt) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x + (k - 1); p < n; p += stride) {
+        bool ok = true;
+        for (u32 j = 0; j < k; ++j) ok = ok && owner[p - j] == NONE32;
+        if (ok) atomicAdd(&cnt[sle_key(text, p, k)], 1u);
+    }
+}
+// distinct k-mers as sort keys: ascending key order == Counter::getSorted (count descending, k-mer ascending)
+__global__ __launch_bounds__(256) void sle_kmer_compact_kernel(const u32* __restrict__ cnt, size_t tsize, u64* __restrict__ keys,
+                                                                u32* __restrict__ d_count) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i0 = (size_t)blockIdx.x * blockDim.x; i0 < tsize; i0 += stride) {
+        const size_t i = i0 + threadIdx.x;
+        const u32 v = (i < tsize) ? cnt[i] : 0u;
+        const u64 m = __ballot(v != 0);
+        if (m == 0) continue;
+        u32 base = 0;
+        if (lane_id() == 0) base = atomicAdd(d_count, (u32)__popcll(m));
+        base = __shfl(base, 0);
+        if (v) keys[base + __popcll(m & ((1ull << lane_id()) - 1))] = ((u64)(0xFFFFFFFFu - v) << 24) | (u64)i;
+    }
+}
+
+// per position: literal? is the k-mer ending here ranked (and which rank)?
+__global__ __launch_bounds__(256) void sle_minfo_kernel(const u8* __restrict__ text, const u32* __restrict__ owner, size_t n, SleDev D,
+                                                         u16* __restrict__ minfo) {
+    __shared__ u32 kv[SLE_MAX_KMERS];
+    __shared__ u16 kr[SLE_MAX_KMERS];
+    for (u32 i = threadIdx.x; i < D.nk; i += blockDim.x) { kv[i] = D.kval[i]; kr[i] = D.krank[i]; }
+    __syncthreads();
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
+        u16 v = 0;
+        if (owner[p] == NONE32) {
+            v = SLE_LIT;
+            if (D.nk && p + 1 >= D.k) {
+                const u32 key = sle_key(text, p, D.k);
+                u32 lo = 0, hi = D.nk;                       // first entry >= key
+                while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (kv[mid] < key) lo = mid + 1; else hi = mid; }
+                if (lo < D.nk && kv[lo] == key) v |= SLE_RANKED | kr[lo];
+            }
+        }
+        minfo[p] = v;
+    }
+}
+
+// state maps: 4 bits per state, states 0..3
+constexpr u32 SLE_FN_ID = 0x3210u;
+__device__ __forceinline__ u32 sle_fn_apply(u32 f, u32 s) { return (f >> (4 * s)) & 15u; }
+__device__ __forceinline__ u32 sle_fn_compose(u32 first, u32 then) {
+    u32 r = 0;
+#pragma unroll
+    for (u32 s = 0; s < 4; ++s) r |= sle_fn_apply(then, sle_fn_apply(first, s)) << (4 * s);
+    return r;
+}
+__device__ __forceinline__ u32 sle_fn_of(u16 v, const SleDev& D) { return !(v & SLE_LIT) ? 0u : ((v & SLE_RANKED) ? D.f1 : D.f0); }
+
+// composite of the thread's ENC_PER_THREAD positions; exclusive scan over the workgroup -> map from the tile's entry
+// state to the state in front of the thread's first position; *tile_total = composite of the whole tile
+__device__ __forceinline__ u32 sle_block_scan(u32 mine, u32* smem, u32* tile_total) {
+    const int lane = lane_id(), w = wave_id();
+    u32 inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const u32 t = __shfl_up(inc, d);
+        if (lane >= d) inc = sle_fn_compose(t, inc);
+    }
+    if (lane == 63) smem[w] = inc;
+    __syncthreads();
+    u32 pre = SLE_FN_ID;
+    for (int i = 0; i < w; ++i) pre = sle_fn_compose(pre, smem[i]);
+    u32 excl = __shfl_up(inc, 1);
+    if (lane == 0) excl = SLE_FN_ID;
+    if (tile_total) {
+        u32 tot = SLE_FN_ID;
+        for (int i = 0; i < 4; ++i) tot = sle_fn_compose(tot, smem[i]);
+        *tile_total = tot;
+    }
+    return sle_fn_compose(pre, excl);
+}
+__device__ __forceinline__ u32 sle_thread_fn(const u16* __restrict__ minfo, size_t p0, size_t n, const SleDev& D) {
+    u32 f = SLE_FN_ID;
+#pragma unroll
+    for (int j = 0; j < ENC_PER_THREAD; ++j) {
+        const size_t p = p0 + j;
+        if (p < n) f = sle_fn_compose(f, sle_fn_of(minfo[p], D));
+    }
+    return f;
+}
+__global__ __launch_bounds__(256) void sle_tile_fn_kernel(const u16* __restrict__ minfo, size_t n, SleDev D, u32* __restrict__ tile_fn) {
+    __shared__ u32 sm[4];
+    const size_t p0 = (size_t)blockIdx.x * ENC_TILE + (size_t)threadIdx.x * ENC_PER_THREAD;
+    u32 tot;
+    sle_block_scan(sle_thread_fn(minfo, p0, n, D), sm, &tot);
+    if (threadIdx.x == 0) tile_fn[blockIdx.x] = tot;
+}
+// one workgroup: state in front of every tile (the text starts with an empty buffer)
+__global__ __launch_bounds__(1024) void sle_tile_scan_kernel(const u32* __restrict__ tile_fn, u32 tiles, u32* __restrict__ tile_in) {
+    __shared__ u32 f[1024];
+    __shared__ u32 sin[1024];
+    const u32 chunk = (tiles + 1023u) / 1024u;
+    const u32 t0 = threadIdx.x * chunk, t1 = min(tiles, t0 + chunk);
+    u32 comp = SLE_FN_ID;
+    for (u32 t = t0; t < t1; ++t) comp = sle_fn_compose(comp, tile_fn[t]);
+    f[threadIdx.x] = comp;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 state = 0;
+        for (u32 i = 0; i < 1024; ++i) { sin[i] = state; state = sle_fn_apply(f[i], state); }
+    }
+    __syncthreads();
+    u32 state = sin[threadIdx.x];
+    for (u32 t = t0; t < t1; ++t) { tile_in[t] = state; state = sle_fn_apply(tile_fn[t], state); }
+}
+// marks the positions where a k-mer symbol is written (its last byte)
+__global__ __launch_bounds__(256) void sle_fire_kernel(u16* __restrict__ minfo, size_t n, SleDev D, const u32* __restrict__ tile_in) {
+    __shared__ u32 sm[4];
+    const size_t p0 = (size_t)blockIdx.x * ENC_TILE + (size_t)threadIdx.x * ENC_PER_THREAD;
+    const u32 pre = sle_block_scan(sle_thread_fn(minfo, p0, n, D), sm, nullptr);
+    u32 s = sle_fn_apply(pre, tile_in[blockIdx.x]);
+#pragma unroll
+    for (int j = 0; j < ENC_PER_THREAD; ++j) {
+        const size_t p = p0 + j;
+        if (p >= n) break;
+        const u16 v = minfo[p];
+        if (!(v & SLE_LIT)) s = 0;
+        else if ((v & SLE_RANKED) && s + 1 >= D.k) { minfo[p] = v | SLE_FIRED; s = 0; }      // :258-265
+        else s = min(s + 1, D.k);                                                            // kmer_roll :55-66
+    }
+}
+
+__device__ __forceinline__ void sle_sym(u32 r, u32 sb, u64& code, u32& len) {                // encode_sym :182-245
+    if (sb < 4) { code = r; len = sb; }
+    else if (sb < 6) {
+        if (r < 4) { code = r; len = 3; } else { code = (1u << sb) | r; len = sb + 1; }
+    } else if (sb == 6) {
+        if (r < 8) { code = r; len = 5; }
+        else if (r < 16) { code = (1u << 3) | (r - 8); len = 5; }
+        else if (r < 32) { code = (2u << 4) | (r - 16); len = 6; }
+        else { code = (3u << 6) | r; len = 8; }
+    } else {
+        if (r < 16) { code = ((r >> 2) << 2) | (r & 3); len = 5; }                           // classes 0..3: 2 value bits
+        else if (r < 40) { const u32 cls = 4 + ((r - 16) >> 3); code = (cls << 3) | ((r - 16) & 7); len = 6; }
+        else { code = (7u << sb) | r; len = 3 + sb; }
+    }
+}
+__device__ __forceinline__ void sle_mdr(u32 v, u32 bits, u64& code, u32& len) {              // encode(v, MinDistributedRange) :274-296
+    if (bits <= 5) { code = v; len = bits; }
+    else if (v < 8) { code = v; len = 5; }
+    else if (v < 16) { code = (1u << 3) | (v - 8); len = 5; }
+    else if (v < 32) { code = (2u << 4) | (v - 16); len = 6; }
+    else { code = (3ull << bits) | v; len = 2 + bits; }
+}
+// the literal symbol written AT position p: 0 bits for the interior of a k-mer
+__device__ __forceinline__ void sle_literal(const u16* __restrict__ minfo, size_t p, size_t n, u8 ch, const u16* __restrict__ rank_byte,
+                                            const SleDev& D, u64& code, u32& len) {
+    code = 0; len = 0;
+    for (u32 j = 0; j + 1 < D.k; ++j) if (p + j < n && (minfo[p + j] & SLE_FIRED)) return;  // inside the k-mer that ends at p+j
+    if (D.k > 1 && p + D.k - 1 < n) {
+        const u16 v = minfo[p + D.k - 1];
+        if (v & SLE_FIRED) { sle_sym(v & SLE_RANK_MASK, D.sb, code, len); return; }
+    }
+    sle_sym(rank_byte[ch], D.sb, code, len);
+}
+
+template <bool PACK>
+__global__ __launch_bounds__(256) void sle_stream_kernel(const u8* __restrict__ text, const u32* __restrict__ owner,
+                                                          const u32* __restrict__ flen, const u32* __restrict__ fsrc, const u16* __restrict__ minfo,
+                                                          size_t n, SleDev D, EncParams P, u64* __restrict__ tile_bits, u64 base_bits,
+                                                          u64* __restrict__ out) {
+    __shared__ u16 rank_byte[256];
+    __shared__ u32 sm[5];
+    rank_byte[threadIdx.x] = D.rank_byte[threadIdx.x];
+    __syncthreads();
+    const size_t p0 = (size_t)blockIdx.x * ENC_TILE + (size_t)threadIdx.x * ENC_PER_THREAD;
+    u64 code[ENC_PER_THREAD];       // [0] run header / "0" bit, then literal symbol or src + len
+    u32 hdr[ENC_PER_THREAD], hlen[ENC_PER_THREAD], clen[ENC_PER_THREAD], slen[ENC_PER_THREAD], src[ENC_PER_THREAD];
+    u32 sum = 0;
+    if (p0 < n) {
+        u32 prev = (p0 == 0) ? 0u : owner[p0 - 1];
+#pragma unroll
+        for (int j = 0; j < ENC_PER_THREAD; ++j) {
+            const size_t p = p0 + j;
+            hdr[j] = 0; hlen[j] = 0; clen[j] = 0; slen[j] = 0; code[j] = 0; src[j] = 0;
+            if (p < n) {
+                const u32 own = owner[p], fl = flen[p];
+                if (own == NONE32) {
+                    if (fl) { hdr[j] = (1u << P.dbits) | fl; hlen[j] = 1 + P.dbits; }             // LZSSCoding.hpp:62-68 (dbits <= 31)
+                    sle_literal(minfo, p, n, text[p], rank_byte, D, code[j], clen[j]);
+                } else if (p == 0 || own != prev) {
+                    if (p == 0 || prev != NONE32) hlen[j] = 1;                                     // "0"
+                    src[j] = fsrc[p]; slen[j] = P.W;
+                    sle_mdr(fl - P.flen_min, P.lbits, code[j], clen[j]);
+                }
+                prev = own;
+                sum += hlen[j] + slen[j] + clen[j];
+            }
+        }
+    }
+    if (!PACK) {
+        sum = wave_reduce_sum(sum);
+        if (lane_id() == 0) sm[wave_id()] = sum;
+        __syncthreads();
+        if (threadIdx.x == 0) tile_bits[blockIdx.x] = (u64)sm[0] + sm[1] + sm[2] + sm[3];
+        return;
+    }
+    u32 total;
+    const u32 excl = block_exclusive_sum<u32, 4>(sum, sm, total);
+    if (p0 >= n) return;
+    BitSink sink;
+    sink.out = out;
+    sink.pos = base_bits + tile_bits[blockIdx.x] + excl;
+    sink.acc = 0;
+    sink.cnt = 0;
+#pragma unroll
+    for (int j = 0; j < ENC_PER_THREAD; ++j) {
+        if (p0 + j >= n) break;
+        sink.append(hdr[j], hlen[j]);
+        sink.append(src[j], slen[j]);
+        sink.append(code[j], clen[j]);
+    }
+    sink.flush();
+}
+
+static size_t encode_sle(Ctx& c, const u8* text, size_t n, FactorSpace fs, u32 k, u8* d_out, size_t out_cap, EncodeStats* st) {
+    if (k == 0) k = 3;                                                       // option "kmer", SLECoder.hpp:38
+    if (k > 3) throw HipError{hipErrorInvalidValue, "sle: k-mers longer than 3 bytes are not built on the device", -1};
+    hipStream_t s = c.stream;
+    const size_t mark = c.arena.mark();
+    EncPrelude pre;
+    encode_prelude(c, text, n, fs, pre);
+    const size_t z = pre.z;
+
+    // ---- alphabet (Encoder ctor :96-160) ---------------------------------------------------------------------
+    struct Ent { u64 sym, cnt; };
+    std::vector<Ent> alpha;
+    for (u32 ch = 0; ch < 256; ++ch) if (pre.hist[ch]) alpha.push_back({ (u64)ch, (u64)pre.hist[ch] });
+    size_t sigma = alpha.size();
+    u32 sb = bits_for(sigma - 1);
+    if (k > 1) {
+        const u32 add = (((size_t)1 << sb) == sigma) ? 1u : 2u;
+        const size_t eta = ((size_t)1 << (sb + add)) - sigma;
+        const size_t tsize = (size_t)1 << (8 * k);
+        u32* cnt = c.arena.get<u32>(tsize);
+        HIP_TRY(hipMemsetAsync(cnt, 0, tsize * sizeof(u32), s));
+        if (n >= k) {
+            unsigned g = cdiv(n, 256 * 8); if (g > 8192) g = 8192; if (g == 0) g = 1;
+            sle_kmer_count_kernel<<<g, 256, 0, s>>>(text, fs.owner, n, k, cnt);
+            LAUNCH_CHECK();
+        }
+        const size_t cap = std::min(tsize, n) + 64;
+        u64* keys[2] = { c.arena.get<u64>(cap), c.arena.get<u64>(cap) };
+        u32* vals[2] = { c.arena.get<u32>(cap), c.arena.get<u32>(cap) };
+        u32* d_count = c.arena.get<u32>(1);
+        HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(u32), s));
+        {
+            unsigned g = cdiv(tsize, 256 * 8); if (g > 8192) g = 8192;
+            sle_kmer_compact_kernel<<<g, 256, 0, s>>>(cnt, tsize, keys[0], d_count);
+            LAUNCH_CHECK();
+        }
+        const size_t distinct = c.read(d_count);
+        const size_t take = std::min(eta, distinct);
+        if (take) {
+            const int which = sort_pairs_u64_distinct(c, keys, vals, distinct, 0, 56);
+            std::vector<u64> top(take);
+            c.read_n(keys[which], top.data(), take);
+            for (u64 key : top)                                               // :132-136 (the most frequent eta k-mers join the alphabet)
+                alpha.push_back({ (key & 0xFFFFFFull) | (0xFFull << 56), (u64)(0xFFFFFFFFu - (u32)(key >> 24)) });
+        }
+        sigma = alpha.size();
+        sb = bits_for(sigma - 1);
+    }
+    std::sort(alpha.begin(), alpha.end(), [](const Ent& a, const Ent& b) {     // Counter::getSorted :44-57 (a total order)
+        return a.cnt != b.cnt ? a.cnt > b.cnt : a.sym < b.sym;
+    });
+    HostBitWriter hw;
+    hw.write_compressed_int(sigma);                                           // :155-158
+    for (const Ent& e : alpha) hw.write_compressed_int(e.sym);
+
+    SleDev D;
+    memset(&D, 0, sizeof(D));
+    D.sb = sb; D.k = k;
+    D.f0 = 0; D.f1 = 0;
+    for (u32 st4 = 0; st4 < 4; ++st4) {
+        D.f0 |= std::min(st4 + 1, k) << (4 * st4);
+        D.f1 |= ((st4 + 1 >= k) ? 0u : st4 + 1) << (4 * st4);
+    }
+    std::vector<std::pair<u32, u16>> km;
+    for (size_t r = 0; r < alpha.size(); ++r) {
+        if (alpha[r].sym >> 56) km.push_back({ (u32)(alpha[r].sym & 0xFFFFFFull), (u16)r });
+        else D.rank_byte[alpha[r].sym] = (u16)r;
+    }
+    std::sort(km.begin(), km.end());
+    D.nk = (u32)km.size();
+    u32 h_kval[SLE_MAX_KMERS]; u16 h_krank[SLE_MAX_KMERS];
+    if (D.nk > SLE_MAX_KMERS) throw HipError{hipErrorInvalidValue, "sle: alphabet extension too large", -1};
+    for (u32 i = 0; i < D.nk; ++i) { h_kval[i] = km[i].first; h_krank[i] = km[i].second; }
+    u32* d_kval = c.arena.get<u32>(SLE_MAX_KMERS);
+    u16* d_krank = c.arena.get<u16>(SLE_MAX_KMERS);
+    if (D.nk) {
+        HIP_TRY(hipMemcpyAsync(d_kval, h_kval, D.nk * sizeof(u32), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(d_krank, h_krank, D.nk * sizeof(u16), hipMemcpyHostToDevice, s));
+    }
+    D.kval = d_kval; D.krank = d_krank;
+
+    // ---- k-mer symbols: ranked windows, buffer-fill scan, fired positions ---------------------------------------
+    const unsigned tiles = cdiv(n, ENC_TILE);
+    u16* minfo = c.arena.get<u16>(n + 8);
+    {
+        unsigned g = cdiv(n, 256 * 8); if (g > 8192) g = 8192; if (g == 0) g = 1;
+        sle_minfo_kernel<<<g, 256, 0, s>>>(text, fs.owner, n, D, minfo);
+        LAUNCH_CHECK();
+    }
+    if (D.nk) {
+        u32* tile_fn = c.arena.get<u32>(tiles);
+        u32* tile_in = c.arena.get<u32>(tiles);
+        sle_tile_fn_kernel<<<tiles, 256, 0, s>>>(minfo, n, D, tile_fn);
+        LAUNCH_CHECK();
+        sle_tile_scan_kernel<<<1, 1024, 0, s>>>(tile_fn, tiles, tile_in);
+        LAUNCH_CHECK();
+        sle_fire_kernel<<<tiles, 256, 0, s>>>(minfo, n, D, tile_in);
+        LAUNCH_CHECK();
+    }
+
+    // ---- fields of LZSSCoding.hpp:47-50, then the token stream -----------------------------------------------------
+    EncParams P;
+    memset(&P, 0, sizeof(P));
+    P.W = bits_for(n);
+    P.lbits = bits_for((u64)pre.sc.flen_max - (u64)pre.sc.flen_min);
+    P.dbits = bits_for(pre.sc.fdist_max);
+    P.flen_min = pre.sc.flen_min;
+    hw.write_int(n, 32);
+    hw.write_int(pre.sc.flen_min, P.W);
+    hw.write_int(pre.sc.flen_max, P.W);
+    hw.write_int(pre.sc.fdist_max, P.W);
+    const u64 base_bits = hw.nbits;
+    u64* tile_bits = c.arena.get<u64>(tiles + 1);
+    u64* d_total = c.arena.get<u64>(1);
+    sle_stream_kernel<false><<<tiles, 256, 0, s>>>(text, fs.owner, fs.flen, fs.fsrc, minfo, n, D, P, tile_bits, 0, nullptr);
+    LAUNCH_CHECK();
+    exclusive_sum_u64(c, tile_bits, tile_bits, tiles, d_total);
+    const u64 total_bits = base_bits + c.read(d_total);
+    const size_t out_len = (size_t)(total_bits >> 3) + ((total_bits & 7) <= 5 ? 1 : 2);
+    const size_t padded = align_up(out_len + 8, 8);
+    if (padded > out_cap) throw HipError{hipErrorOutOfMemory, "encode: output buffer too small", (int)__LINE__};
+    HIP_TRY(hipMemsetAsync(d_out, 0, padded, s));
+    HIP_TRY(hipMemcpyAsync(d_out, hw.bytes.data(), hw.bytes.size(), hipMemcpyHostToDevice, s));
+    sle_stream_kernel<true><<<tiles, 256, 0, s>>>(text, fs.owner, fs.flen, fs.fsrc, minfo, n, D, P, tile_bits, base_bits, (u64*)d_out);
+    LAUNCH_CHECK();
+    terminator_kernel<<<1, 64, 0, s>>>(d_out, total_bits);
+    LAUNCH_CHECK();
+    HIP_TRY(hipStreamSynchronize(s));      // hw.bytes and the host tables must outlive the async copies
+
+    st->factors = z;
+    st->flen_min = pre.sc.flen_min; st->flen_max = pre.sc.flen_max; st->fdist_max = pre.sc.fdist_max;
+    st->out_bits = total_bits;
+    st->sigma = (u32)sigma;
     c.arena.release(mark);
     return out_len;
 }

@@ -294,12 +294,90 @@ inline void lzss_ascii_decode(Input& input, Output& output) {
     output.write(text.data(), text.size());
 }
 
+// SLECoder::Decoder (coders/SLECoder.hpp:301-453) + the same token stream: ranking header, rank class codes, k-mer
+// symbols expand to k literals; the factor length is a MinDistributedRange (:413-431).
+inline void lzss_sle_decode(Input& input, Output& output, unsigned k) {
+    const bytes& in = input.raw();
+    BitIStream bs(in.data(), in.size());
+    const size_t sigma = (size_t)bs.read_compressed_int();                   // Decoder ctor :325-340
+    if (sigma == 0 || sigma > 4096) throw std::runtime_error("corrupt SLE ranking");
+    const unsigned sb = bits_for(sigma - 1);
+    std::vector<uint64_t> inv(sigma);
+    for (size_t r = 0; r < sigma; ++r) inv[r] = bs.read_compressed_int();
+    auto read_rank = [&]() -> uint64_t {                                      // :367-397
+        if (sb < 4) return bs.read_int(sb);
+        if (sb < 6) return bs.read_bit() ? bs.read_int(sb) : bs.read_int(2);
+        if (sb == 6) {
+            switch (bs.read_int(2)) {
+                case 0: return bs.read_int(3);
+                case 1: return 8 + bs.read_int(3);
+                case 2: return 16 + bs.read_int(4);
+                default: return bs.read_int(sb);
+            }
+        }
+        const uint64_t cls = bs.read_int(3);
+        if (cls < 4) return 4 * cls + bs.read_int(2);
+        if (cls < 7) return 16 + 8 * (cls - 4) + bs.read_int(3);
+        return bs.read_int(sb);
+    };
+    uint8_t kmer[8]; size_t kread = (size_t)-1;
+    const uint64_t n = bs.read_int(32);
+    const unsigned W = bits_for(n);
+    const uint64_t flen_min = bs.read_int(W), flen_max = bs.read_int(W), fdist_max = bs.read_int(W);
+    const unsigned lbits = bits_for(flen_max - flen_min), dbits = bits_for(fdist_max);
+    bytes text(n);
+    std::vector<uint32_t> ref(n, 0xFFFFFFFFu);
+    uint64_t p = 0;
+    auto eof = [&] { return kread < k ? false : bs.eof(); };                  // :351-359
+    while (!eof()) {
+        kread = (size_t)-1;                                                   // decode(BitRange) resets the k-mer :433-437
+        uint64_t num = bs.read_bit() ? bs.read_int(dbits) : 0;
+        while (num--) {
+            uint8_t ch;
+            if (kread < k) ch = kmer[kread++];
+            else {
+                const uint64_t r = read_rank();
+                if (r >= sigma) throw std::runtime_error("corrupt stream: rank out of range");
+                const uint64_t x = inv[r];
+                if ((x >> 56) == 0xFF) { for (unsigned i = 0; i < k; ++i) kmer[k - 1 - i] = (uint8_t)(x >> (8 * i)); kread = 1; ch = kmer[0]; }
+                else ch = (uint8_t)x;
+            }
+            if (p >= n) throw std::runtime_error("corrupt stream: too many literals");
+            text[p++] = ch;
+        }
+        if (!eof()) {
+            kread = (size_t)-1;
+            const uint64_t src = bs.read_int(W);
+            uint64_t v;
+            if (lbits <= 5) v = bs.read_int(lbits);
+            else switch (bs.read_int(2)) {
+                case 0: v = bs.read_int(3); break;
+                case 1: v = 8 + bs.read_int(3); break;
+                case 2: v = 16 + bs.read_int(4); break;
+                default: v = bs.read_int(lbits); break;
+            }
+            const uint64_t len = flen_min + v;
+            if (len == 0 || p + len > n || src + len > n) throw std::runtime_error("corrupt stream: factor out of range");
+            for (uint64_t j = 0; j < len; ++j) ref[p + j] = (uint32_t)(src + j);
+            p += len;
+        }
+    }
+    if (p != n) throw std::runtime_error("corrupt stream: length mismatch");
+    for (uint64_t i = 0; i < n; ++i) {
+        uint32_t q = (uint32_t)i; uint64_t guard = 0;
+        while (ref[q] != 0xFFFFFFFFu) { q = ref[q]; if (++guard > n) throw std::runtime_error("corrupt stream: reference cycle"); }
+        text[i] = text[q];
+    }
+    output.write(text.data(), text.size());
+}
+
 class LCPCompressor : public Compressor {
     AlgorithmValue m_opts;
     std::shared_ptr<GpuContext> m_ctx;       // created lazily by the first compress(): decompress() needs no GPU
     int m_device = 0;
     int m_coder = TDC_GPU_CODER_HUFF;
     int m_comp = TDC_GPU_COMP_ARRAYS;
+    unsigned m_kmer = 3;
 public:
     tdc_gpu_stats last_stats{};
     void set_device(int d) { m_device = d; }
@@ -309,10 +387,17 @@ public:
         // `arithmetic` is not in the reference's lcpcomp registry (etc/registry_config.py:138-142) but the template
         // instantiates; BASELINE.json configs[2] asks for it, compress side only
         m_comp = (comp == "plcppeaks" || comp == "plcppeaks()") ? TDC_GPU_COMP_PLCPPEAKS : TDC_GPU_COMP_ARRAYS;
-        if ((coder != "huff" && coder != "arithmetic" && coder != "ascii") ||
+        const AlgorithmValue cv = coder.empty() ? AlgorithmValue() : parse_algorithm_id(coder, {"kmer"});
+        const std::string& cname = cv.name;
+        if ((cname != "huff" && cname != "arithmetic" && cname != "ascii" && cname != "sle") ||
             (comp != "arrays" && comp != "arrays()" && comp != "plcppeaks" && comp != "plcppeaks()"))
             throw std::runtime_error("No implementation found for compressor lcpcomp(coder=" + coder + ",comp=" + comp + ")");   // Registry.hpp:214
-        m_coder = (coder == "huff") ? TDC_GPU_CODER_HUFF : (coder == "ascii" ? TDC_GPU_CODER_ASCII : TDC_GPU_CODER_ARITH);
+        m_coder = (cname == "huff") ? TDC_GPU_CODER_HUFF : (cname == "ascii" ? TDC_GPU_CODER_ASCII : TDC_GPU_CODER_ARITH);
+        if (cname == "sle") {                                                 // option kmer = 3 (SLECoder.hpp:38)
+            m_kmer = (unsigned)cv.get_int("kmer", 3);
+            if (m_kmer < 1 || m_kmer > 7) throw std::runtime_error("sle: kmer must be in 1..7");
+            m_coder = TDC_GPU_CODER_SLE_K((int)m_kmer);
+        }
     }
     InputRestrictions input_restrictions() const override { return {true, true}; }   // uses_textds (Meta.hpp:277-282)
 
@@ -330,6 +415,7 @@ public:
 
     void decompress(Input& input, Output& output) override {
         if (m_coder == TDC_GPU_CODER_ASCII) { lzss_ascii_decode(input, output); return; }
+        if ((m_coder & 0xFF) == TDC_GPU_CODER_SLE) { lzss_sle_decode(input, output, m_kmer); return; }
         if (m_coder != TDC_GPU_CODER_HUFF)
             throw std::runtime_error("lcpcomp(coder=arithmetic) streams cannot be decoded (neither can the reference: "
                                      "consuming coders corrupt interleaved streams, docs/Documentation.md:1190-1203)");
@@ -433,6 +519,7 @@ inline std::vector<std::string> registered_algorithms() {
              "lcpcomp(coder=huff, comp=plcppeaks, threshold=5, flatten=1)                 [MI355X, peak scan as an orbit marking]",
              "lcpcomp(coder=huff, dec=gpu)                                                [decompression: host parse, references resolved on the MI355X]",
              "lcpcomp(coder=ascii, comp=arrays, threshold=5, flatten=1)                   [MI355X; host decoder]",
+             "lcpcomp(coder=sle(kmer=3), comp=arrays, threshold=5, flatten=1)             [MI355X, kmer <= 3; host decoder]",
              "lcpcomp(coder=arithmetic, comp=arrays, threshold=5, flatten=1)              [MI355X, compress only]",
              "lzss_lcp(coder=huff, threshold=3)                                           [MI355X, libtdc_gpu.so]",
              "lz78(coder=gamma)                                                           [host parse + MI355X gamma packer]" };
