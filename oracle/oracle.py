@@ -76,6 +76,11 @@ def lib():
         L.orc_lcpcomp_huff_compress.argtypes = [ctypes.c_void_p, sz, ctypes.c_uint32, ctypes.c_int,
                                                 ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(sz),
                                                 ctypes.POINTER(Stats)]
+        L.orc_max_lcp.restype = sz
+        L.orc_max_lcp.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, sz, ctypes.c_uint32,
+                                  ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p)]
+        L.orc_lcpcomp_maxlcp_huff_compress.argtypes = [ctypes.c_void_p, sz, ctypes.c_uint32, ctypes.c_int,
+                                                       ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(sz), ctypes.POINTER(Stats)]
         L.orc_lcpcomp_peaks_huff_compress.argtypes = [ctypes.c_void_p, sz, ctypes.c_uint32, ctypes.c_int,
                                                       ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(sz), ctypes.POINTER(Stats)]
         L.orc_lcpcomp_ascii_compress.argtypes = [ctypes.c_void_p, sz, ctypes.c_uint32, ctypes.c_int,
@@ -185,6 +190,16 @@ def arrays_comp(sa, isa, lcp, maxlcp, threshold):
     return np.frombuffer(raw, dtype=FACTOR_DTYPE).copy()
 
 
+def max_lcp(sa, isa, lcp, maxlcp, threshold):
+    """MaxLCPStrategy factor list in EMISSION order (compressors/lcpcomp/compress/MaxLCPStrategy.hpp:36-100)."""
+    lcp = lcp.copy()
+    out = ctypes.c_void_p()
+    z = lib().orc_max_lcp(sa.ctypes.data_as(ctypes.c_void_p), isa.ctypes.data_as(ctypes.c_void_p),
+                          lcp.ctypes.data_as(ctypes.c_void_p), len(sa), maxlcp, threshold, ctypes.byref(out))
+    raw = _take(out, z * 12) if out.value else b""
+    return np.frombuffer(raw, dtype=FACTOR_DTYPE).copy()
+
+
 def sort_factors(f):
     f = f.copy()
     lib().orc_sort_factors(f.ctypes.data_as(ctypes.c_void_p), len(f))
@@ -237,6 +252,16 @@ def lcpcomp_arith_compress(text, threshold=5, flatten=1):
         if out.value:
             lib().orc_free(out)
         raise RuntimeError("orc_lcpcomp_arith_compress rc=%d" % rc)
+    return _take(out, n.value), st.as_dict()
+
+
+def lcpcomp_maxlcp_huff_compress(text, threshold=5, flatten=1):
+    """lcpcomp(coder=huff, comp=max_lcp)"""
+    a, p = _buf(text)
+    out, n, st = ctypes.c_void_p(), ctypes.c_size_t(), Stats()
+    rc = lib().orc_lcpcomp_maxlcp_huff_compress(p, len(a), threshold, flatten, ctypes.byref(out), ctypes.byref(n), ctypes.byref(st))
+    if rc:
+        raise RuntimeError("orc_lcpcomp_maxlcp_huff_compress rc=%d" % rc)
     return _take(out, n.value), st.as_dict()
 
 

@@ -265,6 +265,91 @@ size_t orc_arrays_comp(const uint32_t* sa, const uint32_t* isa, uint32_t* lcp, s
     return z;
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * lcpcomp::MaxLCPStrategy::factorize (compressors/lcpcomp/compress/MaxLCPStrategy.hpp:36-100) over MaxLCPSuffixList
+ * (compressors/lcpcomp/MaxLCPSuffixList.hpp): a doubly linked list of SA indices in descending LCP order with an index
+ * of the first entry per LCP value; the head is taken, the covered suffixes are removed and the ones in front of the
+ * factor get their key decreased at once (remove + insert in front of their new level).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    uint32_t* lcp; size_t undef, first, last, size;
+    uint32_t* prev, *next, *lcp_index; uint8_t* contained; size_t maxlcp;
+} mlsl;
+static size_t mlsl_lookup(const mlsl* l, size_t lcp) {                       /* lookup_lcp_index :40-49 */
+    size_t result = l->undef;
+    while (lcp > 0 && result == l->undef) result = l->lcp_index[--lcp];
+    return result;
+}
+static void mlsl_insert(mlsl* l, size_t i) {                                 /* :86-124 */
+    const size_t lcp = l->lcp[i];
+    const size_t pos = mlsl_lookup(l, lcp);
+    if (pos == l->undef) {                                                   /* insert at end */
+        if (l->last != l->undef) l->next[l->last] = (uint32_t)i;
+        l->next[i] = (uint32_t)l->undef;
+        l->prev[i] = (uint32_t)l->last;
+        l->last = i;
+    } else {                                                                 /* insert in front of pos */
+        const size_t prev = l->prev[pos];
+        l->prev[i] = (uint32_t)prev;
+        l->next[i] = (uint32_t)pos;
+        if (prev != l->undef) l->next[prev] = (uint32_t)i; else l->first = i;
+        l->prev[pos] = (uint32_t)i;
+    }
+    l->lcp_index[lcp - 1] = (uint32_t)i;
+    if (l->first == l->undef) l->first = i;
+    l->contained[i] = 1;
+    ++l->size;
+}
+static void mlsl_remove(mlsl* l, size_t i) {                                 /* :129-160 */
+    if (l->prev[i] != l->undef) l->next[l->prev[i]] = l->next[i]; else l->first = l->next[i];
+    if (l->next[i] != l->undef) l->prev[l->next[i]] = l->prev[i]; else l->last = l->prev[i];
+    const size_t lcp = l->lcp[i];
+    if (l->lcp_index[lcp - 1] == i) {
+        const size_t k = l->next[i];
+        if (k != l->undef && l->lcp[k] == lcp) l->lcp_index[lcp - 1] = (uint32_t)k;
+        else l->lcp_index[lcp - 1] = (uint32_t)l->undef;
+    }
+    l->contained[i] = 0;
+    --l->size;
+}
+size_t orc_max_lcp(const uint32_t* sa, const uint32_t* isa, uint32_t* lcp, size_t n,
+                   uint32_t maxlcp, uint32_t threshold, orc_factor** out) {
+    *out = NULL;
+    if (n == 0) return 0;
+    mlsl l; memset(&l, 0, sizeof(l));
+    l.lcp = lcp; l.undef = n; l.first = n; l.last = n; l.maxlcp = maxlcp;
+    l.prev = (uint32_t*)malloc(n * 4); l.next = (uint32_t*)malloc(n * 4);
+    l.lcp_index = (uint32_t*)malloc(((size_t)maxlcp + 1) * 4);
+    l.contained = (uint8_t*)calloc(n, 1);
+    for (size_t i = 0; i < n; ++i) { l.prev[i] = (uint32_t)n; l.next[i] = (uint32_t)n; }
+    for (size_t i = 0; i <= maxlcp; ++i) l.lcp_index[i] = (uint32_t)n;
+    for (size_t i = 1; i < n; ++i) if (lcp[i] >= threshold) mlsl_insert(&l, i);   /* ctor :74-78 */
+    size_t z = 0, zcap = 1024;
+    orc_factor* F = (orc_factor*)malloc(zcap * sizeof(orc_factor));
+    while (l.size > 0) {                                                     /* MaxLCPStrategy.hpp:62-95 */
+        const size_t m = l.first;
+        const uint32_t fpos = sa[m], fsrc = sa[m - 1], flen = lcp[m];
+        if (z == zcap) { zcap *= 2; F = (orc_factor*)realloc(F, zcap * sizeof(orc_factor)); }
+        F[z].pos = fpos; F[z].src = fsrc; F[z].len = flen; ++z;
+        for (uint32_t k = 0; k < flen; ++k) {                                /* :74-79 */
+            const size_t i = isa[fpos + k];
+            if (l.contained[i]) mlsl_remove(&l, i);
+        }
+        for (uint32_t k = 0; k < flen && fpos > k; ++k) {                    /* :82-94 */
+            const size_t sp = fpos - k - 1;
+            const size_t i = isa[sp];
+            if (l.contained[i] && sp + lcp[i] > fpos) {
+                const uint32_t nl = (uint32_t)(fpos - sp);
+                if (nl >= threshold) { mlsl_remove(&l, i); lcp[i] = nl; mlsl_insert(&l, i); }   /* decrease_key :163-167 */
+                else mlsl_remove(&l, i);
+            }
+        }
+    }
+    free(l.prev); free(l.next); free(l.lcp_index); free(l.contained);
+    *out = F;
+    return z;
+}
+
 /* LZSSFactors.hpp:69-76 (positions are unique, so the order is fully determined) */
 /* ------------------------------------------------------------------------------------------------
  * lcpcomp::PLCPPeaksStrategy::factorize (compressors/lcpcomp/compress/PLCPPeaksStrategy.hpp:36-80): one left-to-right scan
@@ -952,10 +1037,18 @@ int orc_encode_sle(const uint8_t* text, size_t n, const orc_factor* f, size_t z,
 /* LCPCompressor.hpp:100-138 */
 static int lcpcomp_compress(const uint8_t* text, size_t n, uint32_t threshold, int flatten, int coder,
                             uint8_t** out, size_t* out_len, orc_stats* stats);
-static int g_strategy = 0;      /* 0 = ArraysComp, 1 = PLCPPeaksStrategy (set around one call; the oracle is single-threaded test code) */
+static int g_strategy = 0;      /* 0 = ArraysComp, 1 = PLCPPeaksStrategy, 2 = MaxLCPStrategy (set around one call; the oracle is single-threaded test code) */
 int orc_lcpcomp_peaks_huff_compress(const uint8_t* text, size_t n, uint32_t threshold, int flatten,
                                     uint8_t** out, size_t* out_len, orc_stats* stats) {
     g_strategy = 1;
+    const int rc = lcpcomp_compress(text, n, threshold, flatten, 0, out, out_len, stats);
+    g_strategy = 0;
+    return rc;
+}
+/* lcpcomp(coder=huff, comp=max_lcp) */
+int orc_lcpcomp_maxlcp_huff_compress(const uint8_t* text, size_t n, uint32_t threshold, int flatten,
+                                     uint8_t** out, size_t* out_len, orc_stats* stats) {
+    g_strategy = 2;
     const int rc = lcpcomp_compress(text, n, threshold, flatten, 0, out, out_len, stats);
     g_strategy = 0;
     return rc;
@@ -1007,6 +1100,7 @@ static int lcpcomp_compress(const uint8_t* text, size_t n, uint32_t threshold, i
     orc_factor* F = NULL;
     size_t z;
     if (g_strategy == 1) { phi[n - 1] = phi_last; z = orc_plcp_peaks(sa, isa, phi, n, threshold, &F); }
+    else if (g_strategy == 2) z = orc_max_lcp(sa, isa, lcp, n, maxlcp, threshold, &F);
     else z = orc_arrays_comp(sa, isa, lcp, n, maxlcp, threshold, &F);
     free(phi);
     stats->t_factorize = now_s() - t; t = now_s();

@@ -416,3 +416,64 @@ def factorize_hybrid_tiles(n, isa, phi, plcp, maxlcp, threshold, lcut, interior,
             invalid += 1
             out.add(("invalid", a, b))
     return out, tiles, invalid
+
+
+def max_lcp_position_space(n, isa, phi, plcp, maxlcp, threshold):
+    """Device formulation of lcpcomp::MaxLCPStrategy (MaxLCPStrategy.hpp:36-100 over MaxLCPSuffixList.hpp).
+
+    The reference's list is a stack per LCP level: an insert puts the entry in FRONT of its level (:86-124), the head of the
+    highest level is taken.  Key decreases happen at once, when the truncating factor is selected, and only into lower levels,
+    so when level L is reached its stack is final: the entries truncated to L, most recently truncated first, then the
+    original entries by DESCENDING suffix-array index.  A factor F truncates at most one entry to L (the one at
+    F.pos - L), so "most recently truncated" is the selection time of that factor.
+
+    Position space: cur[p] = current key, prio[p] = position in its level's stack (smaller first):
+      truncated by the t-th selected factor -> 2^31 - 1 - t,   never truncated -> 2^31 + (n - 1 - isa[p]).
+    Level L = all p with cur[p] == L; selected = lexicographically first maximal independent set under prio (conflict =
+    text distance < L); selected factors are numbered in prio order; kills, truncations (nearest start wins).
+    Returns the factors in emission order."""
+    if maxlcp < threshold:
+        return []
+    cur = [int(x) for x in plcp]
+    cur[n - 1] = 0
+    prio = [(1 << 31) + (n - 1 - int(isa[p])) for p in range(n)]
+    orig = {}
+    for p in range(n):
+        if cur[p] >= threshold and isa[p] >= 1:
+            orig.setdefault(cur[p], []).append(p)
+    pool = {}                        # level -> positions pushed into it (stale copies are filtered by cur[p] == L)
+    factors = []
+    t = 0
+    for L in range(maxlcp, threshold - 1, -1):
+        lst = [p for p in orig.get(L, ()) if cur[p] == L] + [p for p in pool.get(L, ()) if cur[p] == L]
+        assert len(set(lst)) == len(lst)
+        if not lst:
+            continue
+        live = sorted(lst, key=lambda p: prio[p])
+        sel = []
+        taken = set()
+        for p in live:               # sequential statement of the MIS (the kernels compute the same set by rounds)
+            if all(abs(p - q) >= L for q in taken):
+                taken.add(p)
+                sel.append(p)
+        lowered = {}
+        for j, p in enumerate(sel):
+            factors.append((p, int(phi[p]), L))
+        for p in sel:                # kills
+            for k in range(L):
+                if p + k < n:
+                    cur[p + k] = 0
+        for j, p in enumerate(sel):  # truncations: the nearest factor start in front of s wins
+            for k in range(min(L, p)):
+                s, d = p - 1 - k, k + 1
+                if cur[s] > d:
+                    cur[s] = d
+                    lowered[s] = True
+        for j, p in enumerate(sel):  # one event per (factor, level): the entry whose final key is its distance to p
+            for k in range(min(L, p)):
+                s, d = p - 1 - k, k + 1
+                if lowered.get(s) and cur[s] == d and d >= threshold:
+                    prio[s] = (1 << 31) - 1 - (t + j)
+                    pool.setdefault(d, []).append(s)
+        t += len(sel)
+    return factors

@@ -387,3 +387,27 @@ def test_sle_literal_runs_without_factors(gpu_ctx):
             src = np.zeros_like(pos); ln = np.full_like(pos, 2)
             want, _ = O.encode_sle(text, factors_struct(pos, src, ln), k)
             assert gpu_ctx.encode_sle(text, pos, src, ln, k) == want
+
+
+def test_lcpcomp_max_lcp_strategy(gpu_ctx):
+    """lcpcomp(comp=max_lcp) (MaxLCPStrategy.hpp:36-100 over MaxLCPSuffixList.hpp): the per-level stacks and the
+    eager key decreases as explicit priorities; bit-exact with the oracle's linked-list restatement (different tie order
+    than ArraysComp, so the streams differ from comp=arrays)."""
+    rng = np.random.default_rng(17)
+    cases = [c for c in SMALL] + [("english_400k", T.gen_english(400_000, 21).tobytes()), ("dna_200k", T.gen_dna(200_000, 7).tobytes()),
+                                  ("abc_periodic", b"abc" * 5000 + b"x" + b"cab" * 3000),
+                                  ("run_a", b"a" * 3000 + b"b" + b"a" * 2000),
+                                  ("sigma2", bytes(rng.integers(97, 99, 60_000, dtype=np.uint8)))]
+    differs = 0
+    for name, data in cases:
+        text = O.escape(data)
+        for thr in (1, 2, 5):
+            want, wst = O.lcpcomp_maxlcp_huff_compress(text, thr, 1)
+            got, st = gpu_ctx.lcpcomp_compress(text, thr, 1, T.CODER_HUFF, T.COMP_MAXLCP)
+            assert got == want, "%s t=%d: %d vs %d bytes" % (name, thr, len(got), len(want))
+            assert st["factors"] == wst["factors"]
+            differs += got != O.lcpcomp_huff_compress(text, thr, 1)[0]
+    assert differs > 0
+    c = T.LCPCompressor(gpu_ctx, coder="huff", threshold=3, comp="max_lcp")
+    data = T.gen_english(80_000, 2).tobytes() + bytes([0, 255, 0])
+    assert c.decompress(c.compress(data)) == data

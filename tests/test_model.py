@@ -82,3 +82,23 @@ def test_tile_local_levels_model():
                 tiles += t
                 invalid += i
     assert 0 < invalid < tiles // 2          # both outcomes are exercised
+
+
+def test_max_lcp_position_space_model():
+    """Device formulation of MaxLCPStrategy (stack order as explicit priorities, eager decreases as one push per factor and
+    level) == the oracle's linked-list restatement, including the emission order."""
+    import numpy as np
+    from tests.models.position_space import max_lcp_position_space
+    rng = np.random.default_rng(1)
+    cases = [("ex", b"abcdebcdeabcd abcdebcdeabcd banana bandana")] + [c for c in corpus.small_corpus() if len(c[1]) <= 1500]
+    for i in range(20):
+        sig = int(rng.integers(2, 5))
+        cases.append(("r%d" % i, bytes(rng.integers(97, 97 + sig, int(rng.integers(20, 300)), dtype=np.uint8))))
+    for name, data in cases:
+        t = O.escape(data)
+        sa = O.suffix_array(t)
+        isa, phi, plcp, maxlcp = O.isa_phi_plcp(t, sa)
+        lcp = O.lcp_array(sa, plcp)
+        for thr in (1, 2, 5):
+            want = [(int(f["pos"]), int(f["src"]), int(f["len"])) for f in O.max_lcp(sa, isa, lcp, maxlcp, thr)]
+            assert max_lcp_position_space(len(t), isa, phi, plcp, maxlcp, thr) == want, (name, thr)

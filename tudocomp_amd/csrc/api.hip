@@ -161,6 +161,7 @@ void run_factorize(Ctx& c, size_t n, DevArrays& A, u32 threshold, int flatten, t
     FlattenStats fl;
     const int e0 = ev ? ev->tick() : 0;
     if (strategy == TDC_GPU_COMP_PLCPPEAKS) plcp_peaks_factorize(c, n, A.phi, A.plcp, threshold, A.fs, &fz.factors);
+    else if (strategy == TDC_GPU_COMP_MAXLCP) factorize_max_lcp(c, n, A.isa, A.phi, A.plcp, A.maxlcp, threshold, A.fs, &fz);
     else factorize_arrays(c, n, A.sa, A.isa, A.phi, A.plcp, A.maxlcp, threshold, A.fs, &fz);
     const int e1 = ev ? ev->tick() : 0;
     if (flatten) flatten_factors(c, n, A.fs, &fl);
@@ -384,7 +385,7 @@ int tdc_gpu_lcpcomp_compress_comp(tdc_gpu_ctx* ctx, const uint8_t* text, size_t 
                                   int comp, uint8_t** out, size_t* out_len, tdc_gpu_stats* stats) {
     return guarded(ctx, [&] {
         (void)lcpcomp_enc_coder(coder);
-        if (comp != TDC_GPU_COMP_ARRAYS && comp != TDC_GPU_COMP_PLCPPEAKS) throw ArgError{TDC_GPU_ERR_UNSUPPORTED, "lcpcomp: comp must be arrays or plcppeaks"};
+        if (comp != TDC_GPU_COMP_ARRAYS && comp != TDC_GPU_COMP_PLCPPEAKS && comp != TDC_GPU_COMP_MAXLCP) throw ArgError{TDC_GPU_ERR_UNSUPPORTED, "lcpcomp: comp must be arrays, plcppeaks or max_lcp"};
         check_text_args(text, n);
         if (!out || !out_len) throw ArgError{TDC_GPU_ERR_ARG, "out/out_len is NULL"};
         if (text[n - 1] != 0) throw ArgError{TDC_GPU_ERR_NO_SENTINEL, "text does not end with a 0 sentinel"};

@@ -30,6 +30,7 @@
 #include "factorize_tiles.hpp"
 
 #include <algorithm>
+#include <map>
 #include <chrono>
 #include <stdlib.h>
 #include <vector>
@@ -851,6 +852,276 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
             t_prev = t_now;
         }
         if (L == 0) break;
+    }
+    c.arena.release(mark);
+    build_owner(c, n, fs);
+}
+
+// ============================================================================================================
+// lcpcomp::MaxLCPStrategy (compressors/lcpcomp/compress/MaxLCPStrategy.hpp:36-100) over MaxLCPSuffixList
+// (compressors/lcpcomp/MaxLCPSuffixList.hpp), in position space.
+//
+// The reference's list is one stack per LCP level: insert() puts an entry in FRONT of its level (:86-124) and the head of
+// the highest level is taken (:62-64).  Keys are decreased AT ONCE, when the truncating factor is selected (:82-94), and
+// only into lower levels -- so when level L is reached its stack is final: the entries that were truncated to L, most
+// recently truncated first, followed by the original entries by DESCENDING suffix-array index (the ctor inserts them in
+// ascending order, :74-78).  A factor truncates at most one entry to L (the one L positions in front of it), so "most
+// recently" is the selection time of that factor.  With
+//     prio[p] = 2^31 - 1 - t          for an entry whose last truncation came from the t-th selected factor
+//     prio[p] = 2^31 + (n - 1 - ISA[p])   for an entry that was never truncated
+// level L is the set {p : cur[p] == L} and the selected entries are its lexicographically first maximal independent set
+// under prio (conflict: text distance < L) -- the same selection kernel as ArraysComp.  Selected factors are numbered in
+// prio order (one small sort per level); kills and truncations commute; the entry that ends a level with
+// cur[s] == distance to a factor selected in this level, and was lowered in this level (stamp), is that factor's one
+// push.  Model: tests/models/position_space.py::max_lcp_position_space (equal to the oracle incl. emission order).
+// ============================================================================================================
+__global__ void mlcp_init_prio_kernel(u32* __restrict__ prio, size_t n) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) prio[p] = 0x80000000u + (u32)(n - 1 - prio[p]);
+}
+__global__ void mlcp_classify_kernel(const u32* __restrict__ orig, u32 m0, const u32* __restrict__ pushed, u32 m, u32 L,
+                                     const u32* __restrict__ cur, u32* __restrict__ live, u64* __restrict__ bm, LevelScalars* __restrict__ sc) {
+    const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 p = 0;
+    bool is_live = false;
+    if (k < m) { p = (k < m0) ? orig[k] : pushed[k - m0]; is_live = cur[p] == L; }
+    const u32 il = wave_append(is_live, &sc->nlive);
+    if (is_live) { live[il] = p; atomicOr((unsigned long long*)&bm[p >> 5], 1ull << (2 * (p & 31))); }
+}
+// selected entries -> (prio, position) records; the bitmap is left all-zero for the next level
+__global__ void mlcp_collect_kernel(const u32* __restrict__ live, u32 nl, const u32* __restrict__ prio, u64* bm,
+                                    u64* __restrict__ skey, u32* __restrict__ sval, LevelScalars* __restrict__ sc) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 p = 0;
+    bool sel = false;
+    if (i < nl) { p = live[i]; sel = bm_state(bm, p) == 2u; }
+    const u32 o = wave_append(sel, &sc->selected);
+    if (sel) {
+        skey[o] = prio[p]; sval[o] = p;
+        atomicAnd((unsigned long long*)&bm[p >> 5], ~(3ull << (2 * (p & 31))));
+    }
+}
+// factors of the level (sel[] in selection order): emit, kill the covered positions (:74-79), truncate the ones in front
+// (:82-94; the nearest start wins); stamp[s] = L marks the positions that were lowered in this level
+template <int G>
+__global__ __launch_bounds__(256) void mlcp_apply_kernel(const u32* __restrict__ sel, u32 nsel, u32 L, size_t n, const u32* __restrict__ phi,
+                                                          u32* __restrict__ cur, u32* __restrict__ flen, u32* __restrict__ fsrc,
+                                                          u32* __restrict__ stamp) {
+    const u32 i = (blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const u32 sub = (G == 1) ? 0u : (threadIdx.x & (G - 1));
+    if (i >= nsel) return;
+    const u32 p = sel[i];
+    if (sub == 0) { flen[p] = L; fsrc[p] = phi[p]; }
+    for (u32 j = sub; j < L && (size_t)p + j < n; j += G) cur[p + j] = 0;
+    const u32 aff = (L < p) ? L : p;
+    for (u32 j = sub; j < aff; j += G) {
+        u32* q = &cur[p - 1 - j];
+        if (*q > j + 1) { if (atomicMin(q, j + 1) > j + 1) stamp[p - 1 - j] = L; }
+    }
+}
+// decrease_key events (:88-90): record (new level << 32 | position), new priority = selection time of the factor
+template <int G>
+__global__ __launch_bounds__(256) void mlcp_push_kernel(const u32* __restrict__ sel, u32 nsel, u32 L, u32 threshold, u32 tbase,
+                                                         const u32* __restrict__ cur, const u32* __restrict__ stamp, u32* __restrict__ prio,
+                                                         u64* __restrict__ bkey, LevelScalars* __restrict__ sc) {
+    const u32 i = (blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const u32 sub = (G == 1) ? 0u : (threadIdx.x & (G - 1));
+    if (i >= nsel) return;
+    const u32 p = sel[i];
+    const u32 aff = (L < p) ? L : p;
+    for (u32 j = sub; j < aff; j += G) {
+        const u32 sp = p - 1 - j, d = j + 1;
+        if (d >= threshold && stamp[sp] == L && cur[sp] == d) {
+            prio[sp] = 0x7FFFFFFFu - (tbase + i);
+            bkey[atomicAdd(&sc->npush, 1u)] = ((u64)d << 32) | sp;
+        }
+    }
+}
+__global__ void mlcp_pool_kernel(const u64* __restrict__ keys, u32 npush, u32* __restrict__ pool, PushSeg* __restrict__ segs, u32 seg_cap,
+                                 LevelScalars* __restrict__ sc) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npush) return;
+    const u32 tgt = (u32)(keys[i] >> 32);
+    pool[i] = (u32)keys[i];
+    if (i == 0 || (u32)(keys[i - 1] >> 32) != tgt) {
+        const u32 j = atomicAdd(&sc->nseg, 1u);
+        if (j < SEG_INLINE) sc->segs[j] = PushSeg{tgt, i};
+        if (j < seg_cap) segs[j] = PushSeg{tgt, i};
+    }
+}
+
+void factorize_max_lcp(Ctx& c, size_t n, u32* isa, const u32* phi, u32* plcp, u32 maxlcp, u32 threshold, FactorSpace& fs,
+                       FactorizeStats* st) {
+    FactorizeStats local;
+    if (!st) st = &local;
+    *st = FactorizeStats();
+    st->maxlcp = maxlcp;
+    if (n == 0) return;
+    hipStream_t s = c.stream;
+    const size_t mark = c.arena.mark();
+    const unsigned gn = cdiv(n, 256);
+    u32* cur = plcp;
+    u32* prio = isa;
+
+    // ---- candidates sorted by level (ctor :74-78; the order inside a level lives in prio) --------------------------
+    u8* cls = c.arena.get<u8>(n);
+    u32* ckeys[2] = { c.arena.get<u32>(n), c.arena.get<u32>(n) };
+    u32* cvals[2] = { c.arena.get<u32>(n), c.arena.get<u32>(n) };
+    u32* d_cnt = c.arena.get<u32>(4);
+    HIP_TRY(hipMemsetAsync(d_cnt, 0, 4 * sizeof(u32), s));
+    cand_class_kernel<<<(gn < 8192u ? gn : 8192u), 256, 0, s>>>(plcp, n, threshold, 0u, cls, fs.flen, nullptr, d_cnt + 1);
+    LAUNCH_CHECK();
+    if (maxlcp < threshold || threshold == 0) { c.arena.release(mark); build_owner(c, n, fs); return; }
+    mlcp_init_prio_kernel<<<gn, 256, 0, s>>>(prio, n);
+    LAUNCH_CHECK();
+    select_by_class(c, cls, 1, n, nullptr, cvals[0], nullptr, nullptr, d_cnt);
+    const size_t cand_count = c.read(d_cnt);
+    st->entries = cand_count;
+    if (cand_count == 0) { c.arena.release(mark); build_owner(c, n, fs); return; }
+    gather_kernel<<<cdiv(cand_count, 256), 256, 0, s>>>(cvals[0], cand_count, plcp, ckeys[0]);
+    LAUNCH_CHECK();
+    const int x = radix_sort_pairs_u32(c, ckeys, cvals, cand_count, 0, (int)bits_for(maxlcp));
+    const size_t nlev = (size_t)maxlcp + 2;
+    u32* d_segstart = c.arena.get<u32>(nlev);
+    u32* d_segend = c.arena.get<u32>(nlev);
+    HIP_TRY(hipMemsetAsync(d_segstart, 0, nlev * sizeof(u32), s));
+    HIP_TRY(hipMemsetAsync(d_segend, 0, nlev * sizeof(u32), s));
+    seg_bounds_kernel<<<cdiv(cand_count, 256), 256, 0, s>>>(ckeys[x], cand_count, d_segstart, d_segend);
+    LAUNCH_CHECK();
+    std::vector<u32> h_segstart(nlev), h_segend(nlev);
+    c.read_n(d_segstart, h_segstart.data(), nlev);
+    c.read_n(d_segend, h_segend.data(), nlev);
+    std::vector<u32> init_levels;                               // levels with original entries, descending
+    for (u32 v = maxlcp; v >= threshold; --v) { if (h_segend[v] > h_segstart[v]) init_levels.push_back(v); if (v == 0) break; }
+    const u32* cand = cvals[x];
+
+    // ---- per-level state ------------------------------------------------------------------------------------------
+    u32* live = c.arena.get<u32>(n);
+    u32* pushed = c.arena.get<u32>(n);
+    u32* stamp = c.arena.get<u32>(n);
+    HIP_TRY(hipMemsetAsync(stamp, 0, n * sizeof(u32), s));
+    const size_t bm_words = n / 32 + 2;
+    u64* bm = c.arena.get<u64>(bm_words);
+    HIP_TRY(hipMemsetAsync(bm, 0, bm_words * sizeof(u64), s));
+    u64* skeys[2] = { c.arena.get<u64>(n), c.arena.get<u64>(n) };     // selected (prio, pos) records, later the level's pushes
+    u32* svals[2] = { c.arena.get<u32>(n), c.arena.get<u32>(n) };
+    const size_t pool_cap = 4 * n;
+    u32* pool = c.arena.get<u32>(pool_cap);
+    LevelScalars* d_sc = (LevelScalars*)c.arena.alloc(sizeof(LevelScalars));
+    const u32 seg_cap = 1u << 16;
+    PushSeg* d_segs = (PushSeg*)c.arena.alloc(sizeof(PushSeg) * seg_cap);
+    std::vector<PushSeg> h_segs(seg_cap);
+    LevelScalars h_sc;
+    const u32 gtab_cap = 1u << 16;
+    GatherSeg* d_gtab = (GatherSeg*)c.arena.alloc(sizeof(GatherSeg) * gtab_cap);
+    std::vector<GatherSeg> h_gtab(gtab_cap);
+    struct PoolSeg { u32 off, cnt; };
+    std::map<u32, std::vector<PoolSeg>> pushed_into;            // per target level: its segments of the pool
+    size_t pool_top = 0, ip = 0;
+    u32 tbase = 0, dead_streak = 0;
+
+    for (;;) {
+        const u32 l_init = ip < init_levels.size() ? init_levels[ip] : 0u;
+        const u32 l_pool = pushed_into.empty() ? 0u : pushed_into.rbegin()->first;
+        const u32 L = std::max(l_init, l_pool);
+        if (L < threshold || L == 0) break;
+        // a run of levels whose original entries were all erased: skip to the highest level that still holds a candidate
+        if (dead_streak >= 4 && l_pool < l_init && h_segend[l_init] > 0) {
+            const size_t hi = h_segend[l_init];
+            HIP_TRY(hipMemsetAsync(d_cnt + 2, 0, sizeof(u32), s));
+            unsigned g = cdiv(hi, 256 * 4); if (g > 4096) g = 4096; if (g == 0) g = 1;
+            alive_max_level_kernel<<<g, 256, 0, s>>>(ckeys[x], cvals[x], 0, hi, cur, threshold, d_cnt + 2);
+            LAUNCH_CHECK();
+            const u32 alive = c.read(d_cnt + 2);                  // original level of the highest candidate that is not erased
+            st->probes++;
+            dead_streak = 0;
+            if (alive < l_init) {
+                while (ip < init_levels.size() && init_levels[ip] > alive) ++ip;
+                continue;
+            }
+        }
+        u32 m0 = 0;
+        if (l_init == L) { m0 = h_segend[L] - h_segstart[L]; ++ip; }
+        u32 m1 = 0;
+        auto it = pushed_into.find(L);
+        if (it != pushed_into.end()) {
+            const std::vector<PoolSeg>& segsL = it->second;
+            size_t done = 0;
+            while (done < segsL.size()) {
+                const size_t cntseg = std::min(segsL.size() - done, (size_t)gtab_cap);
+                u32 tot = 0;
+                for (size_t j = 0; j < cntseg; ++j) { h_gtab[j] = GatherSeg{segsL[done + j].off, tot}; tot += segsL[done + j].cnt; }
+                if ((size_t)m1 + tot > n) throw HipError{hipErrorUnknown, "max_lcp: level list larger than the text", (int)__LINE__};
+                if (cntseg == 1) {
+                    HIP_TRY(hipMemcpyAsync(pushed + m1, pool + h_gtab[0].src_off, (size_t)tot * sizeof(u32), hipMemcpyDeviceToDevice, s));
+                } else {
+                    HIP_TRY(hipMemcpyAsync(d_gtab, h_gtab.data(), cntseg * sizeof(GatherSeg), hipMemcpyHostToDevice, s));
+                    gather_segments_kernel<<<cdiv(tot, 256), 256, 0, s>>>(pool, d_gtab, (u32)cntseg, tot, pushed + m1);
+                    LAUNCH_CHECK();
+                    HIP_TRY(hipStreamSynchronize(s));            // h_gtab is reused by the next chunk
+                }
+                m1 += tot;
+                done += cntseg;
+            }
+            pushed_into.erase(it);
+        }
+        const u32 m = m0 + m1;
+        st->levels++;
+        HIP_TRY(hipMemsetAsync(d_sc, 0, 8 * sizeof(u32), s));
+        mlcp_classify_kernel<<<cdiv(m, 256), 256, 0, s>>>(cand + h_segstart[L], m0, pushed, m, L, cur, live, bm, d_sc);
+        LAUNCH_CHECK();
+        const u32 nl = c.read(&d_sc->nlive);
+        if (nl == 0) { ++dead_streak; continue; }
+        dead_streak = 0;
+        const bool wide = L >= 128;
+        const unsigned gl = wide ? cdiv((size_t)nl * 64, 256) : cdiv(nl, 256);
+        for (u32 round = 0;; ++round) {
+            HIP_TRY(hipMemsetAsync(&d_sc->undecided, 0, sizeof(u32), s));
+            if (wide) mis_round_kernel<64><<<gl, 256, 0, s>>>(live, nl, L, n, prio, bm, d_sc);
+            else      mis_round_kernel<1><<<gl, 256, 0, s>>>(live, nl, L, n, prio, bm, d_sc);
+            LAUNCH_CHECK();
+            st->rounds++;
+            if (c.read(&d_sc->undecided) == 0) break;
+            if (round > nl + 8) throw HipError{hipErrorUnknown, "max_lcp: selection does not converge", (int)__LINE__};
+        }
+        mlcp_collect_kernel<<<cdiv(nl, 256), 256, 0, s>>>(live, nl, prio, bm, skeys[0], svals[0], d_sc);
+        LAUNCH_CHECK();
+        const u32 nsel = c.read(&d_sc->selected);
+        if (nsel == 0) throw HipError{hipErrorUnknown, "max_lcp: a live level selected nothing", (int)__LINE__};
+        const int y = sort_pairs_u64_distinct(c, skeys, svals, nsel, 0, 32);
+        const u32* sel = svals[y];
+        const unsigned gs = wide ? cdiv((size_t)nsel * 64, 256) : cdiv(nsel, 256);
+        if (wide) mlcp_apply_kernel<64><<<gs, 256, 0, s>>>(sel, nsel, L, n, phi, cur, fs.flen, fs.fsrc, stamp);
+        else      mlcp_apply_kernel<1><<<gs, 256, 0, s>>>(sel, nsel, L, n, phi, cur, fs.flen, fs.fsrc, stamp);
+        LAUNCH_CHECK();
+        u64* bkeys[2] = { skeys[y ^ 1], skeys[y] };                // sel = svals[y] stays untouched while the pushes are collected
+        if (wide) mlcp_push_kernel<64><<<gs, 256, 0, s>>>(sel, nsel, L, threshold, tbase, cur, stamp, prio, bkeys[0], d_sc);
+        else      mlcp_push_kernel<1><<<gs, 256, 0, s>>>(sel, nsel, L, threshold, tbase, cur, stamp, prio, bkeys[0], d_sc);
+        LAUNCH_CHECK();
+        const u32 npush = c.read(&d_sc->npush);
+        st->factors += nsel;
+        tbase += nsel;
+        if (npush) {
+            if (pool_top + npush > pool_cap) throw HipError{hipErrorUnknown, "max_lcp: push pool exhausted", (int)__LINE__};
+            u32* bvals[2] = { svals[0], svals[1] };               // values are not used; the records are (level, position) keys
+            const int w = sort_pairs_u64_distinct(c, bkeys, bvals, npush, 0, 32 + (int)bits_for(L));
+            mlcp_pool_kernel<<<cdiv(npush, 256), 256, 0, s>>>(bkeys[w], npush, pool + pool_top, d_segs, seg_cap, d_sc);
+            LAUNCH_CHECK();
+            c.read_n((const u32*)d_sc, (u32*)&h_sc, sizeof(LevelScalars) / sizeof(u32));
+            const u32 nseg = h_sc.nseg;
+            if (nseg > seg_cap) throw HipError{hipErrorUnknown, "max_lcp: too many push targets in one level", (int)__LINE__};
+            if (nseg > SEG_INLINE) c.read_n(d_segs, h_segs.data(), nseg);
+            else for (u32 j = 0; j < nseg; ++j) h_segs[j] = h_sc.segs[j];
+            std::sort(h_segs.begin(), h_segs.begin() + nseg, [](const PushSeg& a, const PushSeg& b) { return a.start < b.start; });
+            for (u32 j = 0; j < nseg; ++j) {
+                const u32 end = (j + 1 < nseg) ? h_segs[j + 1].start : npush;
+                const u32 tgt = h_segs[j].target;
+                if (tgt >= L || tgt < threshold) throw HipError{hipErrorUnknown, "max_lcp: bad push target", (int)__LINE__};
+                pushed_into[tgt].push_back(PoolSeg{(u32)pool_top + h_segs[j].start, end - h_segs[j].start});
+            }
+            pool_top += npush;
+            st->pushes += npush;
+        }
     }
     c.arena.release(mark);
     build_owner(c, n, fs);

@@ -59,6 +59,10 @@ void build_owner(Ctx& c, size_t n, FactorSpace& fs);
 // lcpcomp(comp=plcppeaks): lcpcomp::PLCPPeaksStrategy (compressors/lcpcomp/compress/PLCPPeaksStrategy.hpp:36-80); fills fs
 // (flen, fsrc, owner, factor list) like factorize_arrays
 void plcp_peaks_factorize(Ctx& c, size_t n, const u32* phi, const u32* plcp, u32 threshold, FactorSpace& fs, u64* nfactors);
+// lcpcomp::MaxLCPStrategy (compressors/lcpcomp/compress/MaxLCPStrategy.hpp:36-100) in position space; isa and plcp are
+// consumed like in factorize_arrays
+void factorize_max_lcp(Ctx& c, size_t n, u32* isa, const u32* phi, u32* plcp, u32 maxlcp, u32 threshold, FactorSpace& fs,
+                       FactorizeStats* st);
 
 struct FlattenStats { u64 num_flattened = 0; u64 max_depth_lb = 0; u32 rounds = 0; };
 // a10: compressors/lzss/LZSSFactors.hpp:79-132 ; rewrites fs.fsrc in place.
