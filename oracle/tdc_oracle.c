@@ -8,6 +8,11 @@
  * The suffix array is built with an own SA-IS (induced sorting) -- the reference calls its vendored
  * divsufsort (util/divsufsort.hpp:46-279); the suffix array of a text is unique, so any correct
  * construction is bit-compatible (checked against a naive sort in tests/).
+ *
+ * Pinned against the reference's own known-answer tests and recorded outputs (tests/golden/) for lcpcomp(huff / arithmetic,
+ * comp=arrays), lz78(gamma), the bit stream, Huffman tables and escaping.  PARITY UNPINNED (no recorded reference output
+ * exists): SLECoder (sle_*), PLCPPeaksStrategy (orc_plcp_peaks), MaxLCPStrategy (orc_max_lcp) -- restated from the
+ * reference's sources and checked by round trips / properties / an independent model only.
  */
 #include "tdc_oracle.h"
 
@@ -1188,6 +1193,23 @@ int orc_lzss_lcp_huff_compress(const uint8_t* text, size_t n, uint32_t threshold
  * (LCPCompressor.hpp:23-76).  The reference resolves forward references with ScanDec; the decoded
  * text is unique, so references are resolved here by following source chains.
  * ---------------------------------------------------------------------------------------------- */
+/* resolve references: every chain ends in a literal (no cycles in a valid stream); resolved chains are cut short */
+static int resolve_refs(uint8_t* text, uint32_t* ref, uint64_t n) {
+    uint32_t* stack = (uint32_t*)malloc((n ? n : 1) * sizeof(uint32_t));
+    if (!stack) return -1;
+    for (uint64_t i = 0; i < n; ++i) {
+        if (ref[i] == 0xFFFFFFFFu) continue;
+        size_t sp = 0; uint32_t q = (uint32_t)i;
+        while (ref[q] != 0xFFFFFFFFu) {
+            if (sp >= n) { free(stack); return -6; }
+            stack[sp++] = q; q = ref[q];
+        }
+        const uint8_t c = text[q];
+        while (sp) { uint32_t r = stack[--sp]; text[r] = c; ref[r] = 0xFFFFFFFFu; }
+    }
+    free(stack);
+    return 0;
+}
 /* The same with ASCIICoder::Decoder (ASCIICoder.hpp:53-84): every read is 8 bits; an integer ends at the first
  * non-digit (the ':'), a bit is anything but '0'.  The stream ends with the BitOStream terminator byte. */
 static int ascii_read_int(const uint8_t* in, size_t len, size_t* at, uint64_t* v) {
@@ -1225,11 +1247,7 @@ int orc_lcpcomp_ascii_decompress(const uint8_t* in, size_t in_len, uint8_t** out
         }
     }
     if (p != n) { free(text); free(ref); return -5; }
-    for (uint64_t i = 0; i < n; ++i) {                                      /* chains end in literals */
-        uint32_t q = (uint32_t)i; uint64_t guard = 0;
-        while (ref[q] != 0xFFFFFFFFu) { q = ref[q]; if (++guard > n) { free(text); free(ref); return -6; } }
-        text[i] = text[q];
-    }
+    if (resolve_refs(text, ref, n)) { free(text); free(ref); return -6; }
     free(ref);
     *out = text; *out_len = n;
     return 0;
@@ -1316,11 +1334,7 @@ int orc_lcpcomp_sle_decompress(const uint8_t* in, size_t in_len, unsigned k, uin
 #undef SLE_EOF
     free(inv);
     if (p != n) { free(text); free(ref); return -5; }
-    for (uint64_t i = 0; i < n; ++i) {                                      /* chains end in literals */
-        uint32_t q = (uint32_t)i; uint64_t guard = 0;
-        while (ref[q] != 0xFFFFFFFFu) { q = ref[q]; if (++guard > n) { free(text); free(ref); return -6; } }
-        text[i] = text[q];
-    }
+    if (resolve_refs(text, ref, n)) { free(text); free(ref); return -6; }
     free(ref);
     *out = text; *out_len = n;
     return 0;
