@@ -125,6 +125,20 @@ def test_config0_compress_roundtrip_64KiB(tmp_path):
     assert comp == ALGO.encode() + b"%" + want                       # header + bit-exact payload (38 687 B)
     assert len(want) == 38687
     assert '"factors"' in r.stdout
+    # --stats: the reference's schema (tudocomp_driver.cpp:361-391, tudocomp_stat/PhaseData.hpp:79-111)
+    import json
+    js = json.loads(r.stdout.strip().splitlines()[-1])
+    assert set(js["meta"]) >= {"title", "startTime", "config", "input", "inputSize", "output", "outputSize", "rate"}
+    assert js["meta"]["config"] == ALGO and js["meta"]["inputSize"] == 65536 and js["meta"]["outputSize"] == len(comp)
+    root = js["data"]
+    assert set(root) == {"title", "timeStart", "timeEnd", "memOff", "memPeak", "memFinal", "stats", "sub"}
+    titles = [p["title"] for p in root["sub"]]
+    assert titles == ["Construct Text DS", "Factorize", "Flatten Factors", "Encode Factors"]
+    assert [p["title"] for p in root["sub"][0]["sub"]] == ["Construct SA", "Construct Phi Array", "Construct PLCP Array"]
+    logged = {kv["key"]: kv["value"] for p in root["sub"] for kv in p["stats"]}
+    _, wst = O.lcpcomp_huff_compress(O.escape(data), 2, 1)
+    assert logged == {"maxlcp": str(wst["maxlcp"]), "entries": logged["entries"], "threshold": "2", "factors": str(wst["factors"]),
+                      "num_flattened": str(wst["num_flattened"]), "max_depth_lb": str(wst["max_depth_lb"])}
     out = tmp_path / "back.txt"
     assert _run("-d", "-o", str(out), str(tmp_path / "english64k.txt.tdc")).returncode == 0
     assert out.read_bytes() == data

@@ -381,6 +381,7 @@ class LCPCompressor : public Compressor {
 public:
     tdc_gpu_stats last_stats{};
     void set_device(int d) { m_device = d; }
+    long threshold() const { return m_opts.get_int("threshold", 5); }
     // meta: type "compressor", name "lcpcomp", options coder, comp=arrays, dec=scan, threshold=5, flatten=1 (LCPCompressor.hpp:85-95)
     LCPCompressor(AlgorithmValue opts, std::shared_ptr<GpuContext> ctx) : m_opts(std::move(opts)), m_ctx(std::move(ctx)) {
         const std::string coder = m_opts.get("coder", ""), comp = m_opts.get("comp", "arrays");

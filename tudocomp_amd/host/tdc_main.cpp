@@ -89,17 +89,59 @@ int main(int argc, char** argv) {
         std::ofstream of(ofile, std::ios::binary | std::ios::trunc);
         if (!of) fail("Could not open " + ofile + " for writing");
         of.write((const char*)result.data(), (std::streamsize)result.size());
-        if (stats) {                                                                      // :361-391 (same meta keys)
-            std::printf("{\"meta\":{\"config\":\"%s\",\"input\":\"%s\",\"inputSize\":%zu,\"output\":\"%s\",\"outputSize\":%zu,"
-                        "\"rate\":%.6f},\"timeTotalMs\":%.3f", algo.c_str(), file.c_str(), in_size, ofile.c_str(), result.size(),
-                        in_size ? (double)result.size() / (double)in_size : 0.0, ms);
-            if (auto* c = decompress ? nullptr : dynamic_cast<LCPCompressor*>(sel.compressor.get())) {
+        if (stats) {
+            // tudocomp_driver.cpp:361-391: {"meta": {...}, "data": <root phase>}; a phase is PhaseData::to_json
+            // (tudocomp_stat/PhaseData.hpp:79-111): title, timeStart / timeEnd (ms), memOff / memPeak / memFinal, stats as
+            // [{key, value}] (values are strings), sub phases.  Phase titles and logged keys are the reference's
+            // (LCPCompressor.hpp:104-136, ArraysComp.hpp:39-68, LZSSFactors.hpp:130-131); phase times are the device times
+            // of the stages laid end to end from the start of the run; the mem* fields hold device arena bytes (root only).
+            const long long wall0 = (long long)std::chrono::duration_cast<std::chrono::milliseconds>(t0.time_since_epoch()).count();
+            const long long epoch = (long long)std::chrono::duration_cast<std::chrono::seconds>(std::chrono::system_clock::now().time_since_epoch()).count();
+            std::string js;
+            char buf[1024];
+            auto phase_open = [&](const char* title, double a, double b, unsigned long long mem) {
+                std::snprintf(buf, sizeof(buf), "{\"title\":\"%s\",\"timeStart\":%lld,\"timeEnd\":%lld,\"memOff\":0,\"memPeak\":%llu,\"memFinal\":0,\"stats\":[",
+                              title, wall0 + (long long)a, wall0 + (long long)b, mem);
+                js += buf;
+            };
+            bool first_kv = true;
+            auto kv = [&](const char* k, unsigned long long v) {
+                std::snprintf(buf, sizeof(buf), "%s{\"key\":\"%s\",\"value\":\"%llu\"}", first_kv ? "" : ",", k, v);
+                js += buf; first_kv = false;
+            };
+            auto subs = [&] { js += "],\"sub\":["; first_kv = true; };
+            auto phase_close = [&] { js += "]}"; };
+            auto* c = decompress ? nullptr : dynamic_cast<LCPCompressor*>(sel.compressor.get());
+            if (c) {
                 const tdc_gpu_stats& st = c->last_stats;
-                std::printf(",\"stats\":{\"factors\":%llu,\"maxlcp\":%llu,\"entries\":%llu,\"num_flattened\":%llu,\"max_depth_lb\":%llu,"
-                            "\"gpu_ms\":{\"sa\":%.3f,\"phi\":%.3f,\"plcp\":%.3f,\"factorize\":%.3f,\"flatten\":%.3f,\"encode\":%.3f,\"total\":%.3f}}",
-                            (unsigned long long)st.factors, (unsigned long long)st.maxlcp, (unsigned long long)st.entries,
-                            (unsigned long long)st.num_flattened, (unsigned long long)st.max_depth_lb, st.ms_sa, st.ms_phi, st.ms_plcp,
-                            st.ms_factorize, st.ms_flatten, st.ms_encode, st.ms_total);
+                double t = st.ms_h2d;
+                phase_open("root", 0, ms, (unsigned long long)st.arena_bytes); subs();
+                phase_open("Construct Text DS", t, t + st.ms_sa + st.ms_phi + st.ms_plcp, 0); subs();
+                phase_open("Construct SA", t, t + st.ms_sa, 0); subs(); phase_close(); js += ","; t += st.ms_sa;
+                phase_open("Construct Phi Array", t, t + st.ms_phi, 0); subs(); phase_close(); js += ","; t += st.ms_phi;
+                phase_open("Construct PLCP Array", t, t + st.ms_plcp, 0); subs(); phase_close(); t += st.ms_plcp;
+                phase_close(); js += ",";
+                phase_open("Factorize", t, t + st.ms_factorize, 0);
+                kv("maxlcp", st.maxlcp); kv("entries", st.entries); kv("threshold", (unsigned long long)c->threshold());
+                kv("factors", st.factors);
+                subs(); phase_close(); js += ","; t += st.ms_factorize;
+                // "Sort Factors" has no device counterpart: factors are marks in position space
+                phase_open("Flatten Factors", t, t + st.ms_flatten, 0);
+                kv("num_flattened", st.num_flattened); kv("max_depth_lb", st.max_depth_lb);
+                subs(); phase_close(); js += ","; t += st.ms_flatten;
+                phase_open("Encode Factors", t, t + st.ms_encode, 0); subs(); phase_close();
+                phase_close();
+            } else {
+                phase_open("root", 0, ms, 0); subs(); phase_close();
+            }
+            std::printf("{\"meta\":{\"title\":\"\",\"startTime\":%lld,\"config\":\"%s\",\"input\":\"%s\",\"inputSize\":%zu,\"output\":\"%s\","
+                        "\"outputSize\":%zu,\"rate\":%.6f},\"data\":%s", epoch, algo.c_str(), file.c_str(), in_size, ofile.c_str(),
+                        result.size(), in_size ? (double)result.size() / (double)in_size : 0.0, js.c_str());
+            if (c) {                                                           // additions: wall time and the device stage times
+                const tdc_gpu_stats& st = c->last_stats;
+                std::printf(",\"timeTotalMs\":%.3f,\"gpu_ms\":{\"h2d\":%.3f,\"sa\":%.3f,\"phi\":%.3f,\"plcp\":%.3f,\"factorize\":%.3f,"
+                            "\"flatten\":%.3f,\"encode\":%.3f,\"d2h\":%.3f,\"total\":%.3f}",
+                            ms, st.ms_h2d, st.ms_sa, st.ms_phi, st.ms_plcp, st.ms_factorize, st.ms_flatten, st.ms_encode, st.ms_d2h, st.ms_total);
             }
             std::printf("}\n");
         }
