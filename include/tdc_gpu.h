@@ -95,7 +95,7 @@ void tdc_gpu_free(void* p);
  * compress side only: the reference itself cannot decode lcpcomp + arithmetic; returns
  * TDC_GPU_ERR_UNSUPPORTED for inputs on which the reference divides by zero), TDC_GPU_CODER_ASCII (ASCIICoder) or
  * TDC_GPU_CODER_SLE / TDC_GPU_CODER_SLE_K(k) (SLECoder, the coder of the reference's published lcpcomp runs,
- * etc/compare-suites/default.suite:5; the device builds k <= 3 and returns TDC_GPU_ERR_UNSUPPORTED for 4..7). */
+ * etc/compare-suites/default.suite:5; k in 1..7 = the reference's max_kmer, SLECoder.hpp:12). */
 int tdc_gpu_lcpcomp_compress(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, uint32_t threshold, int flatten,
                              int coder, uint8_t** out, size_t* out_len, tdc_gpu_stats* stats);
 /* The same with a selectable factorization strategy: comp = TDC_GPU_COMP_ARRAYS (lcpcomp::ArraysComp, the default of the
@@ -164,7 +164,7 @@ int tdc_gpu_encode_arith(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, const 
 /* coder = ASCIICoder (coders/ASCIICoder.hpp:29-50) */
 int tdc_gpu_encode_ascii(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, const uint32_t* pos, const uint32_t* src,
                          const uint32_t* len, size_t z, uint8_t** out, size_t* out_len);
-/* coder = SLECoder (coders/SLECoder.hpp:42-298), kmer = its option of that name (0 = default 3; device: <= 3) */
+/* coder = SLECoder (coders/SLECoder.hpp:42-298), kmer = its option of that name (0 = default 3; 1..7) */
 int tdc_gpu_encode_sle(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, const uint32_t* pos, const uint32_t* src,
                        const uint32_t* len, size_t z, uint32_t kmer, uint8_t** out, size_t* out_len);
 

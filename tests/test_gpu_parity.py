@@ -350,21 +350,21 @@ def _sle_cases():
 
 
 def test_lcpcomp_sle_coder(gpu_ctx):
-    """lcpcomp(coder=sle(kmer)) (coders/SLECoder.hpp): device stream == oracle for kmer 1..3, round trip through
-    the oracle's SLE decoder; kmer > 3 is refused, never approximated."""
+    """lcpcomp(coder=sle(kmer)) (coders/SLECoder.hpp): device stream == oracle for kmer 1..7 (counter table for
+    kmer <= 3, sorted windows above), round trip through the oracle's SLE decoder."""
     for name, data in _sle_cases():
         text = O.escape(data)
         for thr in (2, 5):
-            for k in (1, 2, 3):
+            for k in (1, 2, 3, 4, 5, 7):
                 want, _ = O.lcpcomp_sle_compress(text, thr, 1, k)
                 got, st = gpu_ctx.lcpcomp_compress(text, thr, 1, T.CODER_SLE | (k << 8))
                 assert got == want, "%s t=%d k=%d: %d vs %d bytes" % (name, thr, k, len(got), len(want))
-        assert O.lcpcomp_sle_decompress(got, 3) == text
+        assert O.lcpcomp_sle_decompress(got, k) == text
     text = O.escape(T.gen_english(5000, 1).tobytes())
     got, _ = gpu_ctx.lcpcomp_compress(text, 5, 1, T.CODER_SLE)                                    # kmer omitted = 3
     assert got == O.lcpcomp_sle_compress(text, 5, 1, 3)[0]
     with pytest.raises(T.TdcGpuError):
-        gpu_ctx.lcpcomp_compress(text, 5, 1, T.CODER_SLE | (4 << 8))
+        gpu_ctx.lcpcomp_compress(text, 5, 1, T.CODER_SLE | (8 << 8))                              # max_kmer = 7 (SLECoder.hpp:12)
     c = T.LCPCompressor(gpu_ctx, coder="sle", threshold=5)
     data = T.gen_dna(50_000, 3).tobytes() + bytes([0, 255])
     assert O.unescape(O.lcpcomp_sle_decompress(c.compress(data), 3)) == data
@@ -378,7 +378,7 @@ def test_sle_literal_runs_without_factors(gpu_ctx):
              bytes(rng.integers(1, 4, 70_000, dtype=np.uint8)) + b"\0"]
     none = np.zeros(0, dtype=np.uint32)
     for text in texts:
-        for k in (1, 2, 3):
+        for k in (1, 2, 3, 4, 6):
             want, _ = O.encode_sle(text, factors_struct(none, none, none), k)
             assert gpu_ctx.encode_sle(text, none, none, none, k) == want
             # factors of length 2 every 7..23 positions (sources are irrelevant to the coder)

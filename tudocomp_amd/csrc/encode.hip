@@ -446,13 +446,13 @@ constexpr u16 SLE_LIT = 0x8000, SLE_RANKED = 0x4000, SLE_FIRED = 0x2000, SLE_RAN
 struct SleDev {
     u16 rank_byte[256];
     u32 sb, k, nk;
-    u32 f0, f1;              // state maps of a literal position without / with a ranked k-mer ending there (4 bits per state)
-    const u32* kval;         // ranked k-mers (byte string as an integer, first byte most significant), ascending
+    u32 f0, f1;              // state maps of a literal position without / with a ranked k-mer ending there (4 bits per state, 8 states)
+    const u64* kval;         // ranked k-mers (byte string as an integer, first byte most significant), ascending
     const u16* krank;
 };
 
-__device__ __forceinline__ u32 sle_key(const u8* __restrict__ text, size_t p, u32 k) {     // compile_kmer :18-26 without the marker byte
-    u32 x = 0;
+__device__ __forceinline__ u64 sle_key(const u8* __restrict__ text, size_t p, u32 k) {     // compile_kmer :18-26 without the marker byte
+    u64 x = 0;
     for (u32 j = 0; j < k; ++j) x = (x << 8) | text[p - (k - 1) + j];
     return x;
 }
@@ -466,6 +466,41 @@ __global__ __launch_bounds__(256) void sle_kmer_count_kernel(const u8* __restric
         for (u32 j = 0; j < k; ++j) ok = ok && owner[p - j] == NONE32;
         if (ok) atomicAdd(&cnt[sle_key(text, p, k)], 1u);
     }
+}
+// k > 3 (no 256^k table): the windows themselves, to be sorted and run-length counted
+__global__ __launch_bounds__(256) void sle_kmer_keys_kernel(const u8* __restrict__ text, const u32* __restrict__ owner, size_t n, u32 k,
+                                                             u64* __restrict__ keys, u32* __restrict__ d_count) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t p0 = (size_t)blockIdx.x * blockDim.x + (k - 1); p0 < n; p0 += stride) {
+        const size_t p = p0 + threadIdx.x;
+        bool ok = p < n;
+        for (u32 j = 0; j < k && ok; ++j) ok = owner[p - j] == NONE32;
+        const u64 m = __ballot(ok);
+        if (m == 0) continue;
+        u32 base = 0;
+        if (lane_id() == 0) base = atomicAdd(d_count, (u32)__popcll(m));
+        base = __shfl(base, 0);
+        if (ok) keys[base + __popcll(m & ((1ull << lane_id()) - 1))] = sle_key(text, p, k);
+    }
+}
+__global__ void sle_run_heads_kernel(const u64* __restrict__ keys, size_t m, u8* __restrict__ head) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) head[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1 : 0;
+}
+// run j = [start[j], start[j+1]): sort key ~count (the k-mers are already ascending, the count sort is stable)
+__global__ void sle_run_counts_kernel(const u32* __restrict__ start, u32 runs, u32 total, u64* __restrict__ ckey, u32* __restrict__ cval) {
+    const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= runs) return;
+    const u32 end = (j + 1 < runs) ? start[j + 1] : total;
+    ckey[j] = (u64)(0xFFFFFFFFu - (end - start[j]));
+    cval[j] = start[j];
+}
+__global__ void sle_top_kernel(const u64* __restrict__ ckey, const u32* __restrict__ cval, u32 take, const u64* __restrict__ keys,
+                               u64* __restrict__ out_kmer, u32* __restrict__ out_cnt) {
+    const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= take) return;
+    out_kmer[j] = keys[cval[j]];
+    out_cnt[j] = 0xFFFFFFFFu - (u32)ckey[j];
 }
 // distinct k-mers as sort keys: ascending key order == Counter::getSorted (count descending, k-mer ascending)
 __global__ __launch_bounds__(256) void sle_kmer_compact_kernel(const u32* __restrict__ cnt, size_t tsize, u64* __restrict__ keys,
@@ -486,7 +521,7 @@ __global__ __launch_bounds__(256) void sle_kmer_compact_kernel(const u32* __rest
 // per position: literal? is the k-mer ending here ranked (and which rank)?
 __global__ __launch_bounds__(256) void sle_minfo_kernel(const u8* __restrict__ text, const u32* __restrict__ owner, size_t n, SleDev D,
                                                          u16* __restrict__ minfo) {
-    __shared__ u32 kv[SLE_MAX_KMERS];
+    __shared__ u64 kv[SLE_MAX_KMERS];
     __shared__ u16 kr[SLE_MAX_KMERS];
     for (u32 i = threadIdx.x; i < D.nk; i += blockDim.x) { kv[i] = D.kval[i]; kr[i] = D.krank[i]; }
     __syncthreads();
@@ -496,7 +531,7 @@ __global__ __launch_bounds__(256) void sle_minfo_kernel(const u8* __restrict__ t
         if (owner[p] == NONE32) {
             v = SLE_LIT;
             if (D.nk && p + 1 >= D.k) {
-                const u32 key = sle_key(text, p, D.k);
+                const u64 key = sle_key(text, p, D.k);
                 u32 lo = 0, hi = D.nk;                       // first entry >= key
                 while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (kv[mid] < key) lo = mid + 1; else hi = mid; }
                 if (lo < D.nk && kv[lo] == key) v |= SLE_RANKED | kr[lo];
@@ -506,13 +541,13 @@ __global__ __launch_bounds__(256) void sle_minfo_kernel(const u8* __restrict__ t
     }
 }
 
-// state maps: 4 bits per state, states 0..3
-constexpr u32 SLE_FN_ID = 0x3210u;
+// state maps: 4 bits per state, states 0..7 (k <= 7)
+constexpr u32 SLE_FN_ID = 0x76543210u;
 __device__ __forceinline__ u32 sle_fn_apply(u32 f, u32 s) { return (f >> (4 * s)) & 15u; }
 __device__ __forceinline__ u32 sle_fn_compose(u32 first, u32 then) {
     u32 r = 0;
 #pragma unroll
-    for (u32 s = 0; s < 4; ++s) r |= sle_fn_apply(then, sle_fn_apply(first, s)) << (4 * s);
+    for (u32 s = 0; s < 8; ++s) r |= sle_fn_apply(then, sle_fn_apply(first, s)) << (4 * s);
     return r;
 }
 __device__ __forceinline__ u32 sle_fn_of(u16 v, const SleDev& D) { return !(v & SLE_LIT) ? 0u : ((v & SLE_RANKED) ? D.f1 : D.f0); }
@@ -686,7 +721,7 @@ __global__ __launch_bounds__(256) void sle_stream_kernel(const u8* __restrict__ 
 
 static size_t encode_sle(Ctx& c, const u8* text, size_t n, FactorSpace fs, u32 k, u8* d_out, size_t out_cap, EncodeStats* st) {
     if (k == 0) k = 3;                                                       // option "kmer", SLECoder.hpp:38
-    if (k > 3) throw HipError{hipErrorInvalidValue, "sle: k-mers longer than 3 bytes are not built on the device", -1};
+    if (k > 7) throw HipError{hipErrorInvalidValue, "sle: kmer must be in 1..7 (SLECoder.hpp:12)", -1};
     hipStream_t s = c.stream;
     const size_t mark = c.arena.mark();
     EncPrelude pre;
@@ -702,33 +737,71 @@ static size_t encode_sle(Ctx& c, const u8* text, size_t n, FactorSpace fs, u32 k
     if (k > 1) {
         const u32 add = (((size_t)1 << sb) == sigma) ? 1u : 2u;
         const size_t eta = ((size_t)1 << (sb + add)) - sigma;
-        const size_t tsize = (size_t)1 << (8 * k);
-        u32* cnt = c.arena.get<u32>(tsize);
-        HIP_TRY(hipMemsetAsync(cnt, 0, tsize * sizeof(u32), s));
-        if (n >= k) {
-            unsigned g = cdiv(n, 256 * 8); if (g > 8192) g = 8192; if (g == 0) g = 1;
-            sle_kmer_count_kernel<<<g, 256, 0, s>>>(text, fs.owner, n, k, cnt);
-            LAUNCH_CHECK();
-        }
-        const size_t cap = std::min(tsize, n) + 64;
-        u64* keys[2] = { c.arena.get<u64>(cap), c.arena.get<u64>(cap) };
-        u32* vals[2] = { c.arena.get<u32>(cap), c.arena.get<u32>(cap) };
+        const size_t kmark = c.arena.mark();
         u32* d_count = c.arena.get<u32>(1);
         HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(u32), s));
-        {
-            unsigned g = cdiv(tsize, 256 * 8); if (g > 8192) g = 8192;
-            sle_kmer_compact_kernel<<<g, 256, 0, s>>>(cnt, tsize, keys[0], d_count);
-            LAUNCH_CHECK();
+        if (k <= 3) {
+            // a 256^k table of counters; the non-zero entries become sort keys (~count, k-mer)
+            const size_t tsize = (size_t)1 << (8 * k);
+            u32* cnt = c.arena.get<u32>(tsize);
+            HIP_TRY(hipMemsetAsync(cnt, 0, tsize * sizeof(u32), s));
+            if (n >= k) {
+                unsigned g = cdiv(n, 256 * 8); if (g > 8192) g = 8192; if (g == 0) g = 1;
+                sle_kmer_count_kernel<<<g, 256, 0, s>>>(text, fs.owner, n, k, cnt);
+                LAUNCH_CHECK();
+            }
+            const size_t cap = std::min(tsize, n) + 64;
+            u64* keys[2] = { c.arena.get<u64>(cap), c.arena.get<u64>(cap) };
+            u32* vals[2] = { c.arena.get<u32>(cap), c.arena.get<u32>(cap) };
+            {
+                unsigned g = cdiv(tsize, 256 * 8); if (g > 8192) g = 8192;
+                sle_kmer_compact_kernel<<<g, 256, 0, s>>>(cnt, tsize, keys[0], d_count);
+                LAUNCH_CHECK();
+            }
+            const size_t distinct = c.read(d_count);
+            const size_t take = std::min(eta, distinct);
+            if (take) {
+                const int which = sort_pairs_u64_distinct(c, keys, vals, distinct, 0, 56);
+                std::vector<u64> top(take);
+                c.read_n(keys[which], top.data(), take);
+                for (u64 key : top)                                           // :132-136 (the most frequent eta k-mers join the alphabet)
+                    alpha.push_back({ (key & 0xFFFFFFull) | (0xFFull << 56), (u64)(0xFFFFFFFFu - (u32)(key >> 24)) });
+            }
+        } else if (n >= k) {
+            // the windows as 8k-bit keys: sort, run-length count, stable sort of the runs by descending count
+            u64* keys[2] = { c.arena.get<u64>(n), c.arena.get<u64>(n) };
+            u32* vals[2] = { c.arena.get<u32>(n), c.arena.get<u32>(n) };
+            {
+                unsigned g = cdiv(n, 256 * 8); if (g > 8192) g = 8192; if (g == 0) g = 1;
+                sle_kmer_keys_kernel<<<g, 256, 0, s>>>(text, fs.owner, n, k, keys[0], d_count);
+                LAUNCH_CHECK();
+            }
+            const size_t windows = c.read(d_count);
+            if (windows) {
+                const int w = radix_sort_pairs_u64(c, keys, vals, windows, 0, 8 * (int)k);
+                u8* head = c.arena.get<u8>(windows);
+                sle_run_heads_kernel<<<cdiv(windows, 256), 256, 0, s>>>(keys[w], windows, head);
+                LAUNCH_CHECK();
+                u32* start = vals[w];                                         // the values of the first sort carry no information
+                select_by_class(c, head, 1, windows, nullptr, start, nullptr, nullptr, d_count);
+                const u32 runs = c.read(d_count);
+                u64* ckeys[2] = { keys[w ^ 1], c.arena.get<u64>(runs) };
+                u32* cvals[2] = { vals[w ^ 1], c.arena.get<u32>(runs) };
+                sle_run_counts_kernel<<<cdiv(runs, 256), 256, 0, s>>>(start, runs, (u32)windows, ckeys[0], cvals[0]);
+                LAUNCH_CHECK();
+                const int v = radix_sort_pairs_u64(c, ckeys, cvals, runs, 0, 32);
+                const u32 take = (u32)std::min<size_t>(eta, runs);
+                u64* d_km = c.arena.get<u64>(take);
+                u32* d_ct = c.arena.get<u32>(take);
+                sle_top_kernel<<<cdiv(take, 256), 256, 0, s>>>(ckeys[v], cvals[v], take, keys[w], d_km, d_ct);
+                LAUNCH_CHECK();
+                std::vector<u64> hk(take); std::vector<u32> hc(take);
+                c.read_n(d_km, hk.data(), take);
+                c.read_n(d_ct, hc.data(), take);
+                for (u32 j = 0; j < take; ++j) alpha.push_back({ hk[j] | (0xFFull << 56), (u64)hc[j] });
+            }
         }
-        const size_t distinct = c.read(d_count);
-        const size_t take = std::min(eta, distinct);
-        if (take) {
-            const int which = sort_pairs_u64_distinct(c, keys, vals, distinct, 0, 56);
-            std::vector<u64> top(take);
-            c.read_n(keys[which], top.data(), take);
-            for (u64 key : top)                                               // :132-136 (the most frequent eta k-mers join the alphabet)
-                alpha.push_back({ (key & 0xFFFFFFull) | (0xFFull << 56), (u64)(0xFFFFFFFFu - (u32)(key >> 24)) });
-        }
+        c.arena.release(kmark);
         sigma = alpha.size();
         sb = bits_for(sigma - 1);
     }
@@ -743,24 +816,24 @@ static size_t encode_sle(Ctx& c, const u8* text, size_t n, FactorSpace fs, u32 k
     memset(&D, 0, sizeof(D));
     D.sb = sb; D.k = k;
     D.f0 = 0; D.f1 = 0;
-    for (u32 st4 = 0; st4 < 4; ++st4) {
-        D.f0 |= std::min(st4 + 1, k) << (4 * st4);
-        D.f1 |= ((st4 + 1 >= k) ? 0u : st4 + 1) << (4 * st4);
+    for (u32 st8 = 0; st8 < 8; ++st8) {
+        D.f0 |= std::min(st8 + 1, k) << (4 * st8);
+        D.f1 |= ((st8 + 1 >= k) ? 0u : st8 + 1) << (4 * st8);
     }
-    std::vector<std::pair<u32, u16>> km;
+    std::vector<std::pair<u64, u16>> km;
     for (size_t r = 0; r < alpha.size(); ++r) {
-        if (alpha[r].sym >> 56) km.push_back({ (u32)(alpha[r].sym & 0xFFFFFFull), (u16)r });
+        if (alpha[r].sym >> 56) km.push_back({ alpha[r].sym & 0x00FFFFFFFFFFFFFFull, (u16)r });
         else D.rank_byte[alpha[r].sym] = (u16)r;
     }
     std::sort(km.begin(), km.end());
     D.nk = (u32)km.size();
-    u32 h_kval[SLE_MAX_KMERS]; u16 h_krank[SLE_MAX_KMERS];
+    u64 h_kval[SLE_MAX_KMERS]; u16 h_krank[SLE_MAX_KMERS];
     if (D.nk > SLE_MAX_KMERS) throw HipError{hipErrorInvalidValue, "sle: alphabet extension too large", -1};
     for (u32 i = 0; i < D.nk; ++i) { h_kval[i] = km[i].first; h_krank[i] = km[i].second; }
-    u32* d_kval = c.arena.get<u32>(SLE_MAX_KMERS);
+    u64* d_kval = c.arena.get<u64>(SLE_MAX_KMERS);
     u16* d_krank = c.arena.get<u16>(SLE_MAX_KMERS);
     if (D.nk) {
-        HIP_TRY(hipMemcpyAsync(d_kval, h_kval, D.nk * sizeof(u32), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(d_kval, h_kval, D.nk * sizeof(u64), hipMemcpyHostToDevice, s));
         HIP_TRY(hipMemcpyAsync(d_krank, h_krank, D.nk * sizeof(u16), hipMemcpyHostToDevice, s));
     }
     D.kval = d_kval; D.krank = d_krank;

@@ -521,7 +521,7 @@ inline std::vector<std::string> registered_algorithms() {
              "lcpcomp(coder=huff, comp=plcppeaks, threshold=5, flatten=1)                 [MI355X, peak scan as an orbit marking]",
              "lcpcomp(coder=huff, dec=gpu)                                                [decompression: host parse, references resolved on the MI355X]",
              "lcpcomp(coder=ascii, comp=arrays, threshold=5, flatten=1)                   [MI355X; host decoder]",
-             "lcpcomp(coder=sle(kmer=3), comp=arrays, threshold=5, flatten=1)             [MI355X, kmer <= 3; host decoder]",
+             "lcpcomp(coder=sle(kmer=3), comp=arrays, threshold=5, flatten=1)             [MI355X; host decoder]",
              "lcpcomp(coder=..., comp=max_lcp | plcppeaks, ...)                           [MI355X]",
              "lcpcomp(coder=arithmetic, comp=arrays, threshold=5, flatten=1)              [MI355X, compress only]",
              "lzss_lcp(coder=huff, threshold=3)                                           [MI355X, libtdc_gpu.so]",
