@@ -143,7 +143,9 @@ def test_error_codes(gpu_ctx):
         gpu_ctx.lcpcomp_compress(b"abc\x00", 0, 1)
     assert e.value.status == -2
     with pytest.raises(RuntimeError, match="No implementation found"):
-        T.LCPCompressor(gpu_ctx, coder="sle")
+        T.LCPCompressor(gpu_ctx, coder="bit")
+    with pytest.raises(RuntimeError, match="No implementation found"):
+        T.LCPCompressor(gpu_ctx, comp="heap")            # MaxHeapStrategy: not built
     # the context is still usable afterwards
     want, _ = O.lcpcomp_huff_compress(b"abcabc\x00", 2, 1)
     assert gpu_ctx.lcpcomp_compress(b"abcabc\x00", 2, 1)[0] == want

@@ -637,6 +637,205 @@ static int radix_sort_pairs(Ctx& c, K* keys[2], u32* vals[2], size_t n, int begi
 
 int radix_sort_pairs_u64(Ctx& c, u64* keys[2], u32* vals[2], size_t n, int b, int e) { return radix_sort_pairs<u64>(c, keys, vals, n, b, e); }
 
+// ---- pass 0 of the suffix array's initial sort, fed from the text ----------------------------------------------------
+// key(i) = the k recoded bytes text[i .. i+k) as a k-digit number in base sigma (zeros behind the text), value(i) = i.
+// The two kernels below are rs_count_kernel / rs_scatter_lds_kernel<u64, 4> with the loads replaced by that computation
+// (the tile's recoded bytes are staged in LDS), so the (key, index) arrays are first written by the scatter of pass 0
+// instead of being written, read by the count and read again by the scatter.
+constexpr int GEN_HALO = 32;          // k <= 32
+// recoded bytes of one tile (+ halo) into LDS; every thread fetches 16 consecutive bytes with one request (the loads of a
+// workgroup are all in flight together instead of one round trip per loop iteration)
+template <int NW>
+__device__ __forceinline__ void gen_stage_tile(const TextKeyGen& g, size_t t0, const u8* __restrict__ code, u8* __restrict__ sy) {
+    constexpr int TILE = NW * 64 * RS_ITEMS;
+    static_assert(TILE == NW * 64 * 16, "one 16-byte piece per thread");
+    const size_t p = t0 + (size_t)threadIdx.x * 16;
+    u8 b[16];
+    if (p + 16 <= g.n && (((size_t)g.text) & 15) == 0) {
+        const uint4 v = *(const uint4*)(g.text + p);
+        const u32 wv[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+        for (int i = 0; i < 16; ++i) b[i] = (u8)(wv[i >> 2] >> (8 * (i & 3)));
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) b[i] = (p + i < g.n) ? g.text[p + i] : (u8)0;
+    }
+    u32 o[4] = { 0, 0, 0, 0 };
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[i >> 2] |= (u32)((p + i < g.n) ? code[b[i]] : (u8)0) << (8 * (i & 3));
+    *(uint4*)(sy + (size_t)threadIdx.x * 16) = make_uint4(o[0], o[1], o[2], o[3]);
+    if (threadIdx.x < GEN_HALO) {
+        const size_t q = t0 + TILE + threadIdx.x;
+        sy[TILE + threadIdx.x] = (q < g.n) ? code[g.text[q]] : (u8)0;
+    }
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void rs_gen_count_kernel(TextKeyGen g, u32* __restrict__ counts, u32 numTiles, u32 dmask, u32 per_xcd) {
+    constexpr int TILE = NW * 64 * RS_ITEMS;
+    __shared__ u32 hist[256];
+    __shared__ u8 code[256];
+    __shared__ __align__(16) u8 sy[TILE + GEN_HALO];
+    const u32 tile = xcd_tile(blockIdx.x, per_xcd);
+    if (tile >= numTiles) return;
+    for (int i = threadIdx.x; i < 256; i += NW * 64) { hist[i] = 0; code[i] = g.code[i]; }
+    __syncthreads();
+    const size_t t0 = (size_t)tile * TILE;
+    gen_stage_tile<NW>(g, t0, code, sy);
+    __syncthreads();
+    // a lane owns RS_ITEMS consecutive positions (pass 0 need not be stable, so the order inside the tile is free): the key of
+    // the next position is the previous one minus its leading symbol, times sigma, plus the symbol that enters
+    const int lb = wave_id() * (64 * RS_ITEMS) + lane_id() * RS_ITEMS;
+    u32 acc = 0;                                          // the low 8 bits of the key survive 32-bit wrap-around
+    for (int t = 0; t < g.k; ++t) acc = acc * g.sigma + sy[lb + t];
+    const u32 top = (u32)g.top;
+#pragma unroll 4
+    for (int j = 0; j < RS_ITEMS; ++j) {
+        const bool valid = t0 + lb + j < g.n;
+        const u32 d = valid ? (acc & dmask) : 0u;
+        acc = (acc - (u32)sy[lb + j] * top) * g.sigma + sy[lb + j + g.k];
+        const u32 d0 = __builtin_amdgcn_readfirstlane(d);
+        if (__all(valid && d == d0)) {
+            if (lane_id() == 0) atomicAdd(&hist[d0], 64u);
+        } else if (valid) {
+            atomicAdd(&hist[d], 1u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) counts[(size_t)tile * 256 + threadIdx.x] = hist[threadIdx.x];
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void rs_gen_scatter_kernel(TextKeyGen g, u64* __restrict__ keys_out, u32* __restrict__ vals_out,
+                                                                  const u32* __restrict__ offsets, u32 numTiles, u32 dmask, u32 per_xcd) {
+    typedef u64 K;
+    constexpr int TILE = NW * 64 * RS_ITEMS;
+    __shared__ u32 wcnt[NW][256];
+    __shared__ u32 gbase[256];
+    __shared__ __align__(16) K stage[TILE];
+    __shared__ u32 scan_sm[NW + 1];
+    __shared__ u8 code[256];
+    const int lane = lane_id(), w = wave_id();
+    const u32 tile = xcd_tile(blockIdx.x, per_xcd);
+    if (tile >= numTiles) return;
+    const size_t n = g.n;
+    for (int i = threadIdx.x; i < NW * 256; i += NW * 64) (&wcnt[0][0])[i] = 0;
+    for (int i = threadIdx.x; i < 256; i += NW * 64) code[i] = g.code[i];
+    __syncthreads();
+    u8* sy = (u8*)stage;                                  // recoded bytes of the tile; dead before `stage` is written
+    const size_t t0 = (size_t)tile * TILE;
+    gen_stage_tile<NW>(g, t0, code, sy);
+    __syncthreads();
+
+    K k[RS_ITEMS];
+    u32 loc[RS_ITEMS];
+    volatile u32* mycnt = wcnt[w];
+    const int lb = w * (64 * RS_ITEMS) + lane * RS_ITEMS;  // a lane owns RS_ITEMS consecutive positions (see rs_gen_count_kernel)
+    const size_t tileBase = t0 + lb;
+    const u32 tileCount = (u32)(((size_t)(tile + 1) * TILE <= n) ? (size_t)TILE : n - t0);
+    const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    u64 key = 0;
+    for (int j0 = 0; j0 < g.k; j0 += g.chunk) {
+        const int len = (g.k - j0 < g.chunk) ? g.k - j0 : g.chunk;
+        u32 acc = 0, scale = 1;
+        for (int t = 0; t < len; ++t) { acc = acc * g.sigma + sy[lb + j0 + t]; scale *= g.sigma; }
+        key = (j0 == 0) ? (u64)acc : key * scale + acc;
+    }
+    u8 lead[RS_ITEMS], enter[RS_ITEMS];
+#pragma unroll
+    for (int j = 0; j < RS_ITEMS; ++j) { lead[j] = sy[lb + j]; enter[j] = sy[lb + j + g.k]; }
+#pragma unroll
+    for (int j = 0; j < RS_ITEMS; ++j) {
+        const bool valid = tileBase + (size_t)j < n;
+        k[j] = valid ? key : (K)0;
+        const u32 d = (u32)(k[j] & dmask);
+        u64 peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const u64 bal = __ballot(bit);
+            peers &= bit ? bal : ~bal;
+        }
+        const u32 prefix = mycnt[d];
+        const u32 rank = (u32)__popcll(peers & lt_mask);
+        loc[j] = prefix + rank;
+        if (valid && rank == 0) mycnt[d] = prefix + (u32)__popcll(peers);
+        key = (key - (u64)lead[j] * g.top) * g.sigma + enter[j];
+    }
+    __syncthreads();
+    {
+        const u32 t = threadIdx.x;
+        u32 tot = 0;
+        if (NW * 64 == 256 || t < 256) {
+#pragma unroll
+            for (int i = 0; i < NW; ++i) tot += wcnt[i][t];
+        }
+        u32 total;
+        const u32 start = block_exclusive_sum<u32, NW>((NW * 64 == 256 || t < 256) ? tot : 0u, scan_sm, total);
+        if (NW * 64 == 256 || t < 256) {
+            u32 run = start;
+#pragma unroll
+            for (int i = 0; i < NW; ++i) { const u32 c = wcnt[i][t]; wcnt[i][t] = run; run += c; }
+            gbase[t] = offsets[(size_t)tile * 256 + t] - start;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RS_ITEMS; ++j) {
+        const u32 d = (u32)(k[j] & dmask);
+        loc[j] += wcnt[w][d];
+        if (tileBase + (size_t)j < n) stage[loc[j]] = k[j];
+    }
+    __syncthreads();
+    u32 dst[RS_ITEMS];
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; ++r) {
+        const u32 sp = (u32)r * (NW * 64) + threadIdx.x;
+        dst[r] = 0xFFFFFFFFu;
+        if (sp < tileCount) {
+            const K key = stage[sp];
+            dst[r] = gbase[(u32)(key & dmask)] + sp;
+            keys_out[dst[r]] = key;
+        }
+    }
+    __syncthreads();
+    u32* stage32 = (u32*)stage;
+#pragma unroll
+    for (int j = 0; j < RS_ITEMS; ++j) {
+        const size_t idx = tileBase + (size_t)j;
+        if (idx < n) stage32[loc[j]] = (u32)idx;           // value = text position
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; ++r) {
+        const u32 sp = (u32)r * (NW * 64) + threadIdx.x;
+        if (dst[r] != 0xFFFFFFFFu) vals_out[dst[r]] = stage32[sp];
+    }
+}
+
+int radix_sort_text_keys_u64(Ctx& c, const TextKeyGen& g, u64* keys[2], u32* vals[2], int end_bit) {
+    const size_t n = g.n;
+    if (n == 0) return 0;
+    constexpr int NW = 4;
+    constexpr int TILE = NW * 64 * RS_ITEMS;
+    const size_t mark = c.arena.mark();
+    const u32 numTiles = cdiv(n, TILE);
+    u32* counts = c.arena.get<u32>((size_t)256 * numTiles);
+    u32* blocksum = c.arena.get<u32>((size_t)256 * (cdiv(numTiles, CS_ROWS) + 1));
+    const u32 per_xcd = (c.xcd_remap == 1 && numTiles >= 64) ? cdiv(numTiles, 8) : 0u;
+    const u32 grid = per_xcd ? 8 * per_xcd : numTiles;
+    const int bits = end_bit < 8 ? end_bit : 8;
+    const u32 dmask = (1u << bits) - 1u;
+    rs_gen_count_kernel<NW><<<grid, NW * 64, 0, c.stream>>>(g, counts, numTiles, dmask, per_xcd);
+    LAUNCH_CHECK();
+    radix_offsets(c, counts, numTiles, blocksum);
+    rs_gen_scatter_kernel<NW><<<grid, NW * 64, 0, c.stream>>>(g, keys[0], vals[0], counts, numTiles, dmask, per_xcd);
+    LAUNCH_CHECK();
+    c.arena.release(mark);
+    if (end_bit <= 8) return 0;
+    return radix_sort_pairs_u64(c, keys, vals, n, 8, end_bit);
+}
+
 // ---- one-workgroup bitonic sort for tiny inputs -----------------------------------------------------------------
 constexpr int SMALL_SORT_MAX = 2048;
 

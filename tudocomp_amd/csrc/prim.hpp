@@ -17,6 +17,12 @@ void inclusive_max_u32(Ctx& c, const u32* in, u32* out, size_t n);
 int radix_sort_pairs_u64(Ctx& c, u64* keys[2], u32* vals[2], size_t n, int begin_bit, int end_bit);
 int radix_sort_pairs_u32(Ctx& c, u32* keys[2], u32* vals[2], size_t n, int begin_bit, int end_bit);
 
+// The suffix array's initial sort: key(i) = the k recoded bytes text[i .. i+k) as a number in base sigma (zeros behind the
+// text), value(i) = i, i < n; sorted on bits [0, end_bit).  Pass 0 computes the keys from the text (no key / index arrays
+// are written beforehand); returns the index of the buffer pair that holds the result.
+struct TextKeyGen { const u8* text; size_t n; u32 sigma; int k, chunk; u64 top /* sigma^(k-1) */; u8 code[256]; };
+int radix_sort_text_keys_u64(Ctx& c, const TextKeyGen& g, u64* keys[2], u32* vals[2], int end_bit);
+
 // Same contract as radix_sort_pairs_u64 for keys that are pairwise DISTINCT on the sorted bits (stability is then
 // irrelevant): inputs of at most 2048 pairs are sorted by one workgroup in LDS (bitonic network), larger ones by the
 // radix sort.  Used for the many tiny per-level sorts of the factorizer.

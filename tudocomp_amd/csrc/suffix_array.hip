@@ -238,9 +238,18 @@ void build_suffix_array(Ctx& c, const u8* text, size_t n, u32* sa, u32* isa, SAS
     // --- initial sort by the first k symbols ------------------------------------------------------
     int chunk = 1;                                           // largest chunk with base^chunk < 2^32
     { u64 pw = base; while (pw * base < (1ull << 32)) { pw *= base; ++chunk; } }
-    sa_init_keys_kernel<<<cdiv(n, 1024), 256, 0, s>>>(text, n, cm, base, k, chunk, keys[0], vals[0]);
-    LAUNCH_CHECK();
-    int x = radix_sort_pairs_u64(c, keys, vals, n, 0, key_bits);
+    int x;
+    if (c.sa_fused_init && k <= 32) {                        // pass 0 of the sort computes the keys from the text
+        TextKeyGen g;
+        g.text = text; g.n = n; g.sigma = base; g.k = k; g.chunk = chunk;
+        g.top = 1; for (int i = 1; i < k; ++i) g.top *= base;
+        memcpy(g.code, cm.code, 256);
+        x = radix_sort_text_keys_u64(c, g, keys, vals, key_bits);
+    } else {
+        sa_init_keys_kernel<<<cdiv(n, 1024), 256, 0, s>>>(text, n, cm, base, k, chunk, keys[0], vals[0]);
+        LAUNCH_CHECK();
+        x = radix_sort_pairs_u64(c, keys, vals, n, 0, key_bits);
+    }
     st->sorted_elems += n;
     const unsigned gn = cdiv(n, 256);
     sa_heads_kernel<<<gn, 256, 0, s>>>(keys[x], n, head);
