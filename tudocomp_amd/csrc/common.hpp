@@ -184,6 +184,24 @@ struct Ctx {
         memcpy(out, zc_host, bytes);
         return true;
     }
+    // for kernels that publish their result themselves (same protocol as publish_words_kernel): the kernel stores its words
+    // at *dst (system scope), then `seq` at *flag; publish_wait spins on the flag and copies `bytes` (<= 4096) out
+    bool publish_begin(u32** dst, u32** flag, u32* seq) {
+        if (!fast_read || !zc_host) return false;
+        *seq = ++zc_seq; *dst = zc_dev; *flag = zc_dev + 1024;
+        return true;
+    }
+    void publish_wait(u32 seq, void* out, size_t bytes) {
+        volatile u32* flag = zc_host + 1024;
+        for (u64 spins = 0;; ++spins) {
+            if (__atomic_load_n((const u32*)flag, __ATOMIC_ACQUIRE) == seq) break;
+            if ((spins & 0xFFFF) == 0xFFFF) {
+                const hipError_t q = hipStreamQuery(stream);
+                if (q != hipSuccess && q != hipErrorNotReady) throw HipError{q, __FILE__, __LINE__};
+            }
+        }
+        memcpy(out, zc_host, bytes);
+    }
 #else
     bool read_words_fast(const void*, void*, size_t) { return false; }
 #endif
@@ -311,18 +329,25 @@ __device__ __forceinline__ u32 block_inclusive_max(u32 v, u32* smem, u32& total)
 __device__ __forceinline__ void bitonic_cmpx(u64& ka, u32& va, u64& kb, u32& vb, bool up) {
     if ((ka > kb) == up) { const u64 tk = ka; ka = kb; kb = tk; const u32 tv = va; va = vb; vb = tv; }
 }
+template <u32 J>
+__device__ __forceinline__ void bitonic_local(u64 (&k)[8], u32 (&v)[8], u32 t, u32 k2) {
+#pragma unroll
+    for (u32 r = 0; r < 8; ++r) {
+        constexpr u32 JJ = J;
+        const u32 x = r ^ JJ;
+        if (x > r) bitonic_cmpx(k[r], v[r], k[x], v[x], (((t * 8 + r) & k2) == 0));
+    }
+}
 // `np2`: power of two >= number of real elements (the rest is padding with maximal keys): the network only has to
 // merge up to blocks of np2 elements, which shortens it from 66 to log2(np2)*(log2(np2)+1)/2 stages.
 __device__ inline void block_bitonic_sort_2048(u64 (&k)[8], u32 (&v)[8], u64* xk, u32* xv, u32 np2 = 2048) {
     const u32 t = threadIdx.x;
     for (u32 k2 = 2; k2 <= np2; k2 <<= 1) {
         for (u32 j = k2 >> 1; j > 0; j >>= 1) {
-            if (j < 8) {                                   // same thread
-#pragma unroll
-                for (u32 r = 0; r < 8; ++r) {
-                    const u32 x = r ^ j;
-                    if (x > r) bitonic_cmpx(k[r], v[r], k[x], v[x], (((t * 8 + r) & k2) == 0));
-                }
+            if (j < 8) {                                   // same thread (register indices must be compile-time constants)
+                if (j == 4) bitonic_local<4>(k, v, t, k2);
+                else if (j == 2) bitonic_local<2>(k, v, t, k2);
+                else bitonic_local<1>(k, v, t, k2);
             } else if (j < 512) {                          // same wave: partner lane = lane ^ (j / 8)
                 const u32 lm = j >> 3;
                 const bool lower = ((t & lm) == 0);        // this thread holds the lower index of every pair

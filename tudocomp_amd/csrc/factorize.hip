@@ -40,7 +40,8 @@ namespace tdc {
 enum : u8 { CL_DEAD = 0, CL_LIVE = 1, CL_STALE = 2 };
 
 struct PushSeg { u32 target, start; };
-constexpr u32 SEG_INLINE = 252;      // segment descriptors that travel with the scalars in one read-back
+struct GatherSeg { u32 src_off, dst_off; };   // pushed part of a level's list = concatenation of pool segments
+constexpr u32 SEG_INLINE = 508;      // segment descriptors that travel with the scalars in one read-back
 
 struct LevelScalars {
     u32 nlive, nstale;   // entries with cur == L / threshold <= cur < L
@@ -250,33 +251,115 @@ constexpr u32 SMALL_M = 2048;
 
 constexpr u32 SMALL_APPLY_INLINE_MAX_L = 64;      // longer factors are applied by a separate, chip-wide launch
 
-__global__ __launch_bounds__(256) void small_level_kernel(const u32* __restrict__ orig, u32 m0, const u32* __restrict__ pushed, u32 m,
+// pushed part of a small level's list: read straight from the pool segments; their table (up to SMALL_GATHER entries) sits in
+// mapped host memory and is copied into LDS first
+constexpr u32 SMALL_GATHER = 2048;
+constexpr u32 SMALL_RAW = 8192;     // list entries a small level may hold before the erased ones are dropped (SMALL_M must survive)
+constexpr u32 SMALL_OUT_WORDS = 8 + 2 * SEG_INLINE;
+constexpr u32 SMALL_RANKSORT = 1024; // up to here a counting sort in LDS beats the bitonic network
+constexpr u32 SMALL_SELSCAN = 32;    // up to this many selected entries the encounter values scan the selected list, not the neighbours
+
+__global__ __launch_bounds__(256) void small_level_kernel(const u32* __restrict__ orig, u32 m0, const u32* __restrict__ pushed, u32 m_raw,
+                                                           const u32* __restrict__ pool_all, const GatherSeg* __restrict__ gtab, u32 gn,
                                                            u32 L, u32 threshold, size_t n, u32* cur, u32* prio,
                                                            const u32* __restrict__ phi, u32* __restrict__ flen, u8* __restrict__ res8,
                                                            u32* __restrict__ fsrc, u32* __restrict__ pool, u32 prio_base,
                                                            PushSeg* __restrict__ segs, u32 seg_cap, u32* __restrict__ sel_list,
-                                                           LevelScalars* __restrict__ sc) {
+                                                           u32 inline_budget, LevelScalars* __restrict__ sc,
+                                                           u32* zc_dst, u32* zc_flag, u32 zc_seq, unsigned long long* prof) {
+#define SPROF(k) do { if (prof) { const unsigned long long now_ = wall_clock64(); acc_prof[k] = now_ - t_prof; t_prof = now_; } } while (0)
+    unsigned long long t_prof = prof ? wall_clock64() : 0;
+    unsigned long long acc_prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // The entries are sorted by text position (bitonic network in registers), so "neighbours within distance < L" are
     // adjacent slots of LDS arrays: the whole level runs without the global state bitmap.
     __shared__ u64 skey[SMALL_M];          // sort scratch, later the push records (target << 32 | priority)
     __shared__ u32 sval[SMALL_M];
     __shared__ u32 pos_s[SMALL_M], pr_s[SMALL_M], v_s[SMALL_M];
     __shared__ u8 st[SMALL_M];             // 0 undecided, 1 selected, 2 stale, 3 rejected, 4 dead
-    __shared__ u32 s_und, s_npush, s_sel, s_live, s_alive;
+    __shared__ u32 s_und, s_npush, s_sel, s_live, s_alive, s_cnt, s_lst;
+    __shared__ u32 s_sellist[SMALL_SELSCAN];
+    __shared__ u32 s_out[SMALL_OUT_WORDS]; // the LevelScalars of this level: nlive nstale undecided selected npush nseg deferred bailed, segments
     const u32 tid = threadIdx.x;
-    if (tid == 0) { s_npush = 0; s_sel = 0; s_live = 0; s_alive = 0; }
+    if (tid == 0) { s_npush = 0; s_sel = 0; s_live = 0; s_alive = 0; s_cnt = 0; s_lst = 0; }
+    if (tid < 8) s_out[tid] = 0;
+    __syncthreads();
+    // the result goes to the scalars block and, without a further launch, into the mapped host block the host spins on
+    auto publish = [&]() {
+        __syncthreads();
+        const u32 words = 8 + 2 * min(s_out[5], SEG_INLINE);
+        for (u32 i = tid; i < words; i += 256) {
+            ((u32*)sc)[i] = s_out[i];
+            if (zc_dst) __hip_atomic_store(&zc_dst[i], s_out[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        if (zc_dst) {
+            __threadfence_system();
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(zc_flag, zc_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    };
+    // 0. drop the erased entries (texts with long repeats carry thousands of them per level).  Eight entries per thread and
+    //    step: the position loads are all in flight together, then the eight dependent cur[] loads (one workgroup has no
+    //    other way to hide the two round trips)
+    GatherSeg* gt = (GatherSeg*)skey;                     // skey is not used before the sorts
+    for (u32 i = tid; i < gn; i += 256) gt[i] = gtab[i];
+    if (gn) __syncthreads();
+    for (u32 base = 0; base < m_raw; base += 256 * 8) {
+        u32 pp[8], cc[8];
+#pragma unroll
+        for (u32 r = 0; r < 8; ++r) {
+            const u32 i = base + r * 256 + tid;
+            pp[r] = NONE32;
+            if (i < m0) pp[r] = orig[i];
+            else if (i < m_raw) {
+                if (gn == 0) pp[r] = pushed[i - m0];
+                else {
+                    const u32 q = i - m0;
+                    u32 lo = 0, hi = gn - 1;              // last segment with dst_off <= q
+                    while (lo < hi) { const u32 mid = (lo + hi + 1) >> 1; if (gt[mid].dst_off <= q) lo = mid; else hi = mid - 1; }
+                    pp[r] = pool_all[gt[lo].src_off + (q - gt[lo].dst_off)];
+                }
+            }
+        }
+#pragma unroll
+        for (u32 r = 0; r < 8; ++r) cc[r] = (pp[r] != NONE32) ? cur[pp[r]] : 0u;
+#pragma unroll
+        for (u32 r = 0; r < 8; ++r)
+            if (pp[r] != NONE32 && cc[r] >= threshold) { const u32 slot = atomicAdd(&s_cnt, 1u); if (slot < SMALL_M) pos_s[slot] = pp[r]; }
+    }
+    __syncthreads();
+    SPROF(0);
+    const u32 m = s_cnt;
+    if (m > SMALL_M) { if (tid == 0) s_out[7] = 1; publish(); return; }     // too many survivors: the general path takes the level
+    if (m == 0) { publish(); return; }                                      // every entry already erased (:86)
     u64 k[8];
     u32 v[8];
     // 1. sort by position (positions are distinct)
 #pragma unroll
     for (u32 r = 0; r < 8; ++r) {
         const u32 i = tid * 8 + r;
-        k[r] = (i < m) ? (u64)((i < m0) ? orig[i] : pushed[i - m0]) : ~0ull;
+        k[r] = (i < m) ? (u64)pos_s[i] : ~0ull;
         v[r] = 0;
     }
-    u32 mp2 = 8;
-    while (mp2 < m) mp2 <<= 1;
-    block_bitonic_sort_2048(k, v, skey, sval, mp2);
+    __syncthreads();
+    if (m <= SMALL_RANKSORT) {
+        // few survivors: every entry counts the smaller ones (independent LDS reads: no chain of dependent steps)
+        for (u32 i = tid; i < m; i += 256) {
+            const u32 p = pos_s[i];
+            u32 rk = 0;
+#pragma unroll 16
+            for (u32 j = 0; j < m; ++j) rk += (pos_s[j] < p) ? 1u : 0u;
+            sval[rk] = p;
+        }
+        __syncthreads();
+#pragma unroll
+        for (u32 r = 0; r < 8; ++r) { const u32 i = tid * 8 + r; k[r] = (i < m) ? (u64)sval[i] : ~0ull; }
+        __syncthreads();
+    } else {
+        u32 mp2 = 8;
+        while (mp2 < m) mp2 <<= 1;
+        block_bitonic_sort_2048(k, v, skey, sval, mp2);
+    }
+    SPROF(1);
     // 2. classify
 #pragma unroll
     for (u32 r = 0; r < 8; ++r) {
@@ -292,10 +375,8 @@ __global__ __launch_bounds__(256) void small_level_kernel(const u32* __restrict_
         }
     }
     __syncthreads();
-    if (s_alive == 0) {                                   // every entry already erased (:86)
-        if (tid == 0) { sc->nlive = 0; sc->nstale = 0; sc->selected = 0; sc->npush = 0; sc->nseg = 0; }
-        return;
-    }
+    if (s_alive == 0) { publish(); return; }
+    SPROF(2);
     // 3. selection rounds (Jacobi: decisions are published after a barrier)
     for (u32 round = 0; round <= m && s_live; ++round) {
         if (tid == 0) s_und = 0;
@@ -331,20 +412,36 @@ __global__ __launch_bounds__(256) void small_level_kernel(const u32* __restrict_
         if (und == 0) break;
     }
     __syncthreads();
+    SPROF(3);
     // 4. encounter values of the stale and the rejected entries -> push records
+    if (tid == 0) s_lst = 0;
+    __syncthreads();
+    for (u32 i = tid; i < m; i += 256) if (st[i] == 1) { const u32 o = atomicAdd(&s_lst, 1u); if (o < SMALL_SELSCAN) s_sellist[o] = i; }
+    __syncthreads();
+    const u32 nsel_scan = s_lst;
     for (u32 i = tid; i < m; i += 256) {
         const u8 c = st[i];
         if (c != 2 && c != 3) continue;
         const u32 p = pos_s[i], pr = pr_s[i];
         u32 val = v_s[i];
-        for (u32 j = i; j-- > 0 && val;) {                // a selected left neighbour of higher priority covers p (:99-101)
-            if (p - pos_s[j] >= L) break;
-            if (st[j] == 1 && pr_s[j] < pr) val = 0;
-        }
-        for (u32 j = i + 1; j < m && val; ++j) {          // a selected right neighbour truncates (:103-109)
-            const u32 d = pos_s[j] - p;
-            if (d >= L) break;
-            if (st[j] == 1 && pr_s[j] < pr && d < val) val = d;
+        if (nsel_scan <= SMALL_SELSCAN) {                 // few factors in this level: look at them only
+            for (u32 f = 0; f < nsel_scan && val; ++f) {
+                const u32 j = s_sellist[f];
+                if (pr_s[j] >= pr) continue;
+                const u32 q = pos_s[j];
+                if (q < p) { if (p - q < L) val = 0; }     // covered by a factor starting to the left   (:99-101)
+                else if (q - p < L && q - p < val) val = q - p;   // truncated by a factor starting to the right (:103-109)
+            }
+        } else {
+            for (u32 j = i; j-- > 0 && val;) {            // a selected left neighbour of higher priority covers p (:99-101)
+                if (p - pos_s[j] >= L) break;
+                if (st[j] == 1 && pr_s[j] < pr) val = 0;
+            }
+            for (u32 j = i + 1; j < m && val; ++j) {      // a selected right neighbour truncates (:103-109)
+                const u32 d = pos_s[j] - p;
+                if (d >= L) break;
+                if (st[j] == 1 && pr_s[j] < pr && d < val) val = d;
+            }
         }
         if (val >= threshold) {
             const u32 idx = atomicAdd(&s_npush, 1u);
@@ -353,56 +450,101 @@ __global__ __launch_bounds__(256) void small_level_kernel(const u32* __restrict_
         }
     }
     __syncthreads();
-    // 5. sort the pushes by (target, old priority)
+    // 5. sort the pushes by (target, old priority); afterwards pr_s[i] = target, v_s[i] = position of the i-th push
     const u32 npush = s_npush;
+    if (npush <= SMALL_RANKSORT) {
+        for (u32 i = tid; i < npush; i += 256) {
+            const u64 key = skey[i];
+            u32 rk = 0;
+#pragma unroll 16
+            for (u32 j = 0; j < npush; ++j) rk += (skey[j] < key) ? 1u : 0u;
+            pr_s[rk] = (u32)(key >> 32);
+            v_s[rk] = sval[i];
+        }
+        __syncthreads();
+    } else {
 #pragma unroll
-    for (u32 r = 0; r < 8; ++r) {
-        const u32 i = tid * 8 + r;
-        k[r] = (i < npush) ? skey[i] : ~0ull;
-        v[r] = (i < npush) ? sval[i] : NONE32;
+        for (u32 r = 0; r < 8; ++r) {
+            const u32 i = tid * 8 + r;
+            k[r] = (i < npush) ? skey[i] : ~0ull;
+            v[r] = (i < npush) ? sval[i] : NONE32;
+        }
+        u32 qp2 = 8;
+        while (qp2 < npush) qp2 <<= 1;
+        block_bitonic_sort_2048(k, v, skey, sval, qp2);
+#pragma unroll
+        for (u32 r = 0; r < 8; ++r) { const u32 i = tid * 8 + r; pr_s[i] = (u32)(k[r] >> 32); v_s[i] = v[r]; }
+        __syncthreads();
     }
-    u32 qp2 = 8;
-    while (qp2 < npush) qp2 <<= 1;
-    if (npush > 1) block_bitonic_sort_2048(k, v, skey, sval, qp2); else __syncthreads();
-#pragma unroll
-    for (u32 r = 0; r < 8; ++r) { const u32 i = tid * 8 + r; skey[i] = k[r]; sval[i] = v[r]; }
-    __syncthreads();
     // 6. new priorities, pool slots, segments
     for (u32 i = tid; i < npush; i += 256) {
-        const u32 p = sval[i];
+        const u32 p = v_s[i];
         prio[p] = prio_base + i;
         pool[i] = p;
-        if (res8) { const u32 tgt = (u32)(skey[i] >> 32); res8[p] = (u8)(tgt > 255u ? 255u : tgt); }
+        if (res8) { const u32 tgt = pr_s[i]; res8[p] = (u8)(tgt > 255u ? 255u : tgt); }
     }
-    if (tid == 0) {
-        u32 nseg = 0;
-        for (u32 i = 0; i < npush; ++i) {
-            const u32 tgt = (u32)(skey[i] >> 32);
-            if (i == 0 || (u32)(skey[i - 1] >> 32) != tgt) {
-                if (nseg < SEG_INLINE) sc->segs[nseg] = PushSeg{tgt, i};
-                if (nseg < seg_cap) segs[nseg] = PushSeg{tgt, i};
-                ++nseg;
-            }
+    {   // segment starts (a new target level), numbered in order of their start: flags + workgroup prefix sum
+        u32 heads = 0, cnt = 0;
+#pragma unroll
+        for (u32 r = 0; r < 8; ++r) {
+            const u32 i = tid * 8 + r;
+            if (i < npush && (i == 0 || pr_s[i - 1] != pr_s[i])) { heads |= 1u << r; ++cnt; }
         }
-        sc->nseg = nseg;
-        sc->npush = npush;
-    }
-    // 7. the selected entries: applied here (one wave per factor) or, for long factors, listed for a chip-wide launch
-    if (L <= SMALL_APPLY_INLINE_MAX_L) {
-        const u32 lane = tid & 63, wv = tid >> 6;
-        for (u32 i = wv; i < m; i += 4) {
-            if (st[i] != 1) continue;                     // wave-uniform
-            const u32 p = pos_s[i];
-            if (lane == 0) { flen[p] = L; fsrc[p] = phi[p]; atomicAdd(&s_sel, 1u); }
-            for (u32 j = lane; j < L && (size_t)p + j < n; j += 64) cur[p + j] = 0;
-            const u32 aff = (L < p) ? L : p;
-            for (u32 j = lane; j < aff; j += 64) { u32* q = &cur[p - 1 - j]; if (*q > j + 1) atomicMin(q, j + 1); }
+        __shared__ u32 seg_sm[5];
+        u32 nseg;
+        u32 o = block_exclusive_sum<u32, 4>(cnt, seg_sm, nseg);
+#pragma unroll
+        for (u32 r = 0; r < 8; ++r) {
+            if (!(heads & (1u << r))) continue;
+            const u32 i = tid * 8 + r, tgt = pr_s[i];
+            if (o < SEG_INLINE) { s_out[8 + 2 * o] = tgt; s_out[9 + 2 * o] = i; }
+            if (o < seg_cap) segs[o] = PushSeg{tgt, i};
+            ++o;
         }
-    } else {
-        for (u32 i = tid; i < m; i += 256) if (st[i] == 1) sel_list[atomicAdd(&s_sel, 1u)] = pos_s[i];
+        if (tid == 0) { s_out[5] = nseg; s_out[4] = npush; s_sel = 0; }
     }
     __syncthreads();
-    if (tid == 0) { sc->selected = s_sel; sc->nlive = s_live; sc->nstale = s_alive - s_live; }
+    SPROF(4);
+    // 7. the selected entries: applied here (short factors: one wave per factor; long ones: the whole workgroup per factor
+    //    while the level's total stays small) or listed for a chip-wide launch
+    for (u32 i = tid; i < m; i += 256) if (st[i] == 1) atomicAdd(&s_sel, 1u);
+    if (tid == 0) s_lst = 0;
+    __syncthreads();
+    const u32 nsel = s_sel;
+    if (L <= SMALL_APPLY_INLINE_MAX_L || (u64)nsel * L <= inline_budget) {
+        // one wave per factor (the factors of the level side by side); the truncation candidates are read eight per lane
+        // and step, so one factor costs a round trip or two instead of one per 64 positions
+        const u32 lane = tid & 63, wv = tid >> 6;
+        for (u32 i = tid; i < m; i += 256) if (st[i] == 1) sval[atomicAdd(&s_lst, 1u)] = pos_s[i];   // sval: free again after step 6
+        __syncthreads();
+        for (u32 f = wv; f < nsel; f += 4) {
+            const u32 p = sval[f];
+            if (lane == 0) { flen[p] = L; fsrc[p] = phi[p]; }
+            for (u32 j = lane; j < L && (size_t)p + j < n; j += 64) cur[p + j] = 0;
+            const u32 aff = (L < p) ? L : p;
+            for (u32 j0 = 0; j0 < aff; j0 += 64 * 8) {
+                u32 vv[8];
+#pragma unroll
+                for (u32 r = 0; r < 8; ++r) { const u32 j = j0 + r * 64 + lane; vv[r] = (j < aff) ? cur[p - 1 - j] : 0u; }
+#pragma unroll
+                for (u32 r = 0; r < 8; ++r) { const u32 j = j0 + r * 64 + lane; if (j < aff && vv[r] > j + 1) atomicMin(&cur[p - 1 - j], j + 1); }
+            }
+        }
+    } else {
+        for (u32 i = tid; i < m; i += 256) if (st[i] == 1) sel_list[atomicAdd(&s_lst, 1u)] = pos_s[i];
+        if (tid == 0) s_out[6] = 1;                       // deferred: the host launches apply_list_kernel
+    }
+    if (tid == 0) { s_out[3] = nsel; s_out[0] = s_live; s_out[1] = s_alive - s_live; }
+    __syncthreads();
+    SPROF(5);
+    publish();
+    SPROF(6);
+    if (prof && threadIdx.x == 0) {
+        unsigned long long* pf = prof + (m > SMALL_RANKSORT ? 16 : 0);
+        for (int q = 0; q < 7; ++q) pf[q] += acc_prof[q];
+        pf[8] += 1; pf[9] += m_raw; pf[10] += m; pf[11] += nsel; pf[12] += npush;
+    }
+#undef SPROF
 }
 
 // apply for a list of selected positions whose length is only known on the device (one wave per factor)
@@ -439,7 +581,6 @@ __global__ __launch_bounds__(256) void alive_max_level_kernel(const u32* __restr
 }
 
 // Pushed part of a level's list: concatenation of its pool segments (table: source offset / destination offset).
-struct GatherSeg { u32 src_off, dst_off; };
 __global__ void gather_segments_kernel(const u32* __restrict__ pool, const GatherSeg* __restrict__ tab, u32 nseg, u32 total,
                                        u32* __restrict__ dst) {
     const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -595,12 +736,17 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
     } h_gtab_mem;
     HIP_TRY(hipHostMalloc((void**)&h_gtab_mem.p, sizeof(GatherSeg) * gtab_cap, hipHostMallocDefault));
     GatherSeg* h_gtab = h_gtab_mem.p;
+    GatherSeg* d_hgtab = nullptr;               // the same table as seen from the device (small levels read it in place)
+    if (hipHostGetDevicePointer((void**)&d_hgtab, h_gtab, 0) != hipSuccess) { d_hgtab = nullptr; (void)hipGetLastError(); }
     struct PoolSeg { u32 off, cnt; };
     std::vector<std::vector<PoolSeg>> pushed_into(nlev);     // per target level: its segments of the pool
     size_t pool_top = 0;
     u32 prio_base = (u32)n;
 
     u32 dead_streak = 0, levels_since_purge = 1u << 30;
+    double host_prof[5] = {0, 0, 0, 0, 0};                // small levels, host side: prepare / launch / wait / bookkeeping (us), count
+    unsigned long long* d_sprof = nullptr;                 // TDC_GPU_SMALL_PROF=1: phase times of the small-level kernel on stderr
+    if (getenv("TDC_GPU_SMALL_PROF")) { d_sprof = (unsigned long long*)c.arena.alloc(32 * sizeof(unsigned long long)); HIP_TRY(hipMemsetAsync(d_sprof, 0, 32 * sizeof(unsigned long long), s)); }
     bool probe_dead = false;                    // the previous level held erased candidates only
 
     const bool level_log = getenv("TDC_GPU_LEVEL_LOG") != nullptr;     // debugging aid: one line per large level on stderr
@@ -687,8 +833,12 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
         }
         const u32 m0 = h_segend[L] - h_segstart[L];
         u32 m1 = 0;
-        {   // gather the pushed part of the list: one kernel per (at most gtab_cap) pool segments
-            const std::vector<PoolSeg>& segsL = pushed_into[L];
+        const auto hp0 = std::chrono::steady_clock::now();
+        const std::vector<PoolSeg>& segsL = pushed_into[L];
+        u32 m1_total = 0;
+        for (const PoolSeg& sg : segsL) m1_total += sg.cnt;
+        bool gathered = false;
+        auto gather_all = [&]() {   // the pushed part of the list: one kernel per (at most gtab_cap) pool segments
             size_t done = 0;
             while (done < segsL.size()) {
                 const size_t cntseg = std::min(segsL.size() - done, (size_t)gtab_cap);
@@ -707,46 +857,72 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
                 m1 += tot;
                 done += cntseg;
             }
-        }
-        std::vector<PoolSeg>().swap(pushed_into[L]);
-        const u32 m = m0 + m1;
-        if (m == 0) continue;
+            gathered = true;
+        };
+        const u32 m = m0 + m1_total;
+        if (m == 0) { std::vector<PoolSeg>().swap(pushed_into[L]); continue; }
         st->levels++;
-        if (m <= SMALL_M) {
-            // ---- whole level in one workgroup, one read-back ---------------------------------------------------------
-            if (pool_top + m > n || (u64)prio_base + m > 0xFFFFFFFFull)
+        if (m <= SMALL_RAW) {
+            // ---- whole level in one workgroup: ONE launch (list read from the pool segments, result published into mapped
+            //      host memory), falling back to the general path if more than SMALL_M entries are still alive
+            const u32 push_max = std::min<u32>(m, SMALL_M);      // at most one push per surviving entry
+            if (pool_top + push_max > n || (u64)prio_base + push_max > 0xFFFFFFFFull)
                 throw HipError{hipErrorUnknown, "factorize: push pool overflow", (int)__LINE__};
+            u32 gn = 0;
+            if (segsL.size() <= SMALL_GATHER && segsL.size() <= gtab_cap && d_hgtab) {
+                // the previous level's kernel has published its result, so it is done with the table
+                u32 tot = 0;
+                for (size_t j = 0; j < segsL.size(); ++j) { h_gtab[j] = GatherSeg{segsL[j].off, tot}; tot += segsL[j].cnt; }
+                gn = (u32)segsL.size();
+            } else gather_all();
+            u32* zdst = nullptr; u32* zflag = nullptr; u32 zseq = 0;
+            const bool zc = c.publish_begin(&zdst, &zflag, &zseq);
+            const auto hp1 = std::chrono::steady_clock::now();
             {
                 Ctx::ProfScope prof(c, K_SMALL_LEVEL, (u64)m * 16);
-                small_level_kernel<<<1, 256, 0, s>>>(cand + h_segstart[L], m0, pushed, m, L, threshold, n, cur, prio, phi, fs.flen,
-                                                     res8, fs.fsrc, pool + pool_top, prio_base, d_segs, seg_cap, live, d_sc);
+                small_level_kernel<<<1, 256, 0, s>>>(cand + h_segstart[L], m0, pushed, m, pool, d_hgtab, gn, L, threshold, n, cur, prio, phi, fs.flen,
+                                                     res8, fs.fsrc, pool + pool_top, prio_base, d_segs, seg_cap, live,
+                                                     /*inline_budget=*/1u << 17, d_sc, zdst, zflag, zseq, d_sprof);
                 LAUNCH_CHECK();
-                if (L > SMALL_APPLY_INLINE_MAX_L) {        // long factors: the kills are spread over the whole chip
-                    apply_list_kernel<<<cdiv((size_t)m * 64, 256), 256, 0, s>>>(live, &d_sc->selected, L, n, phi, cur, fs.flen, fs.fsrc);
+            }
+            const auto hp2 = std::chrono::steady_clock::now();
+            if (zc) c.publish_wait(zseq, &h_sc, sizeof(LevelScalars));
+            else c.read_n((const u32*)d_sc, (u32*)&h_sc, sizeof(LevelScalars) / sizeof(u32));
+            const auto hp3 = std::chrono::steady_clock::now();
+            host_prof[0] += std::chrono::duration<double, std::micro>(hp1 - hp0).count();
+            host_prof[1] += std::chrono::duration<double, std::micro>(hp2 - hp1).count();
+            host_prof[2] += std::chrono::duration<double, std::micro>(hp3 - hp2).count();
+            host_prof[4] += 1;
+            struct PostTimer { double* acc; std::chrono::steady_clock::time_point t0; ~PostTimer() { *acc += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); } } post_timer{&host_prof[3], hp3};
+            if (!h_sc.pad[1]) {
+                if (h_sc.pad[0]) {                         // many long factors: the kills are spread over the whole chip
+                    apply_list_kernel<<<cdiv((size_t)h_sc.selected * 64, 256), 256, 0, s>>>(live, &d_sc->selected, L, n, phi, cur, fs.flen, fs.fsrc);
                     LAUNCH_CHECK();
                 }
-            }
-            c.read_n((const u32*)d_sc, (u32*)&h_sc, sizeof(LevelScalars) / sizeof(u32));
-            st->small_levels++;
-            if (h_sc.nlive == 0 && h_sc.nstale == 0) { probe_dead = true; continue; }   // small levels do not count for the purge heuristic
-            st->factors += h_sc.selected;
-            const u32 npush = h_sc.npush, nseg = h_sc.nseg;
-            if (npush) {
-                if (nseg > seg_cap) throw HipError{hipErrorUnknown, "factorize: too many push targets in one level", (int)__LINE__};
-                if (nseg <= SEG_INLINE) std::copy(h_sc.segs, h_sc.segs + nseg, h_segs.begin());
-                else c.read_n(d_segs, h_segs.data(), nseg);
-                for (u32 j = 0; j < nseg; ++j) {           // written in order of `start` by one thread
-                    const u32 end = (j + 1 < nseg) ? h_segs[j + 1].start : npush;
-                    const u32 tgt = h_segs[j].target;
-                    if (tgt >= L || tgt < threshold) throw HipError{hipErrorUnknown, "factorize: bad push target", (int)__LINE__};
-                    pushed_into[tgt].push_back(PoolSeg{(u32)pool_top + h_segs[j].start, end - h_segs[j].start});
+                std::vector<PoolSeg>().swap(pushed_into[L]);
+                st->small_levels++;
+                if (h_sc.nlive == 0 && h_sc.nstale == 0) { probe_dead = true; continue; }   // small levels do not count for the purge heuristic
+                st->factors += h_sc.selected;
+                const u32 npush = h_sc.npush, nseg = h_sc.nseg;
+                if (npush) {
+                    if (nseg > seg_cap) throw HipError{hipErrorUnknown, "factorize: too many push targets in one level", (int)__LINE__};
+                    if (nseg <= SEG_INLINE) std::copy(h_sc.segs, h_sc.segs + nseg, h_segs.begin());
+                    else c.read_n(d_segs, h_segs.data(), nseg);
+                    for (u32 j = 0; j < nseg; ++j) {           // written in order of `start` by one thread
+                        const u32 end = (j + 1 < nseg) ? h_segs[j + 1].start : npush;
+                        const u32 tgt = h_segs[j].target;
+                        if (tgt >= L || tgt < threshold) throw HipError{hipErrorUnknown, "factorize: bad push target", (int)__LINE__};
+                        pushed_into[tgt].push_back(PoolSeg{(u32)pool_top + h_segs[j].start, end - h_segs[j].start});
+                    }
+                    pool_top += npush;
+                    prio_base += npush;
+                    st->pushes += npush;
                 }
-                pool_top += npush;
-                prio_base += npush;
-                st->pushes += npush;
+                continue;
             }
-            continue;
         }
+        if (!gathered) gather_all();
+        std::vector<PoolSeg>().swap(pushed_into[L]);
         HIP_TRY(hipMemsetAsync(d_sc, 0, 8 * sizeof(u32), s));
         const unsigned gm = cdiv(m, 256);
         const bool mid = m <= (1u << 20);                    // few enough entries: unordered lists, fewer launches
@@ -852,6 +1028,21 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
             t_prev = t_now;
         }
         if (L == 0) break;
+    }
+    if (d_sprof) {
+        unsigned long long hh[32];
+        HIP_TRY(hipMemcpyAsync(hh, d_sprof, sizeof(hh), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (host_prof[4] > 0)
+            fprintf(stderr, "small levels, host side, us per level: prepare %.1f launch %.1f wait %.1f bookkeeping %.1f\n", host_prof[0] / host_prof[4],
+                    host_prof[1] / host_prof[4], host_prof[2] / host_prof[4], host_prof[3] / host_prof[4]);
+        for (int part = 0; part < 2; ++part) {
+            const unsigned long long* h = hh + 16 * part;
+            const double lv = h[8] ? (double)h[8] : 1.0;
+            fprintf(stderr, "small levels with %s survivors: %llu; per level: raw %.0f alive %.1f selected %.2f pushes %.1f; us (100 MHz clock): load %.1f sort %.1f "
+                            "classify %.1f select %.1f push %.1f apply %.1f publish %.1f\n", part ? "> 1024" : "<= 1024", h[8], h[9] / lv, h[10] / lv, h[11] / lv,
+                    h[12] / lv, h[0] / 100.0 / lv, h[1] / 100.0 / lv, h[2] / 100.0 / lv, h[3] / 100.0 / lv, h[4] / 100.0 / lv, h[5] / 100.0 / lv, h[6] / 100.0 / lv);
+        }
     }
     c.arena.release(mark);
     build_owner(c, n, fs);
