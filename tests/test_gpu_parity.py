@@ -413,3 +413,44 @@ def test_lcpcomp_max_lcp_strategy(gpu_ctx):
     c = T.LCPCompressor(gpu_ctx, coder="huff", threshold=3, comp="max_lcp")
     data = T.gen_english(80_000, 2).tobytes() + bytes([0, 255, 0])
     assert c.decompress(c.compress(data)) == data
+
+
+def test_fuzz_all_variants(gpu_ctx):
+    """Structured random texts (tiny alphabets, planted repeats, runs, bytes that need escaping) through every coder and
+    strategy of the lcpcomp entry point: device stream == oracle stream."""
+    rng = np.random.default_rng(2024)
+
+    def make(i):
+        kind = i % 5
+        n = int(rng.integers(1, 2500))
+        if kind == 0:
+            return bytes(rng.integers(97, 97 + int(rng.integers(1, 5)), n, dtype=np.uint8))
+        if kind == 1:
+            base = bytes(rng.integers(0, 256, max(1, n // 8), dtype=np.uint8))
+            out = bytearray()
+            while len(out) < n:
+                s = int(rng.integers(0, len(base)))
+                out += base[s:s + int(rng.integers(1, 60))]
+            return bytes(out[:n])
+        if kind == 2:
+            return bytes([int(rng.integers(65, 70))]) * int(rng.integers(1, 400)) + bytes(rng.integers(65, 70, n // 4 + 1, dtype=np.uint8)) * 3
+        if kind == 3:
+            w = [bytes(rng.integers(97, 123, int(rng.integers(1, 7)), dtype=np.uint8)) for _ in range(12)]
+            return b" ".join(w[int(x)] for x in rng.integers(0, 12, n // 4 + 1))[:n]
+        return bytes(rng.integers(0, 256, n, dtype=np.uint8))
+
+    variants = [("huff/arrays", T.CODER_HUFF, T.COMP_ARRAYS, O.lcpcomp_huff_compress),
+                ("huff/max_lcp", T.CODER_HUFF, T.COMP_MAXLCP, O.lcpcomp_maxlcp_huff_compress),
+                ("huff/plcppeaks", T.CODER_HUFF, T.COMP_PLCPPEAKS, O.lcpcomp_peaks_huff_compress),
+                ("ascii/arrays", T.CODER_ASCII, T.COMP_ARRAYS, O.lcpcomp_ascii_compress)]
+    for k in (1, 2, 3, 4, 6):
+        variants.append(("sle%d/arrays" % k, T.CODER_SLE | (k << 8), T.COMP_ARRAYS,
+                         lambda t, thr, fl, k=k: O.lcpcomp_sle_compress(t, thr, fl, k)))
+    for i in range(120):
+        text = O.escape(make(i))
+        thr = int(rng.integers(1, 7))
+        fl = int(rng.integers(0, 2))
+        for name, coder, comp, oracle_fn in variants:
+            want, _ = oracle_fn(text, thr, fl)
+            got, _ = gpu_ctx.lcpcomp_compress(text, thr, fl, coder, comp)
+            assert got == want, "case %d %s t=%d flatten=%d n=%d" % (i, name, thr, fl, len(text))
