@@ -153,6 +153,10 @@ int tdc_gpu_flatten(tdc_gpu_ctx* ctx, size_t n, const uint32_t* pos, uint32_t* s
  * factors / rounds (nullable): number of factors in the stream / pointer-jumping rounds.  Malformed input: TDC_GPU_ERR_ARG. */
 int tdc_gpu_lcpcomp_decompress(tdc_gpu_ctx* ctx, const uint8_t* stream, size_t len, uint8_t** out, size_t* out_len,
                                uint64_t* factors, uint32_t* rounds);
+/* The same for a stream written with another coder: TDC_GPU_CODER_HUFF, TDC_GPU_CODER_ASCII (ASCIICoder::Decoder,
+ * coders/ASCIICoder.hpp:53-84) or TDC_GPU_CODER_SLE / TDC_GPU_CODER_SLE_K(k) (SLECoder::Decoder, coders/SLECoder.hpp:301-453). */
+int tdc_gpu_lcpcomp_decompress_coder(tdc_gpu_ctx* ctx, const uint8_t* stream, size_t len, int coder, uint8_t** out, size_t* out_len,
+                                     uint64_t* factors, uint32_t* rounds);
 
 /* HuffmanCoder::Encoder + lzss::encode_text on a caller-supplied factor list sorted by pos (LZSSCoding.hpp:18-92) */
 int tdc_gpu_encode_huff(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, const uint32_t* pos, const uint32_t* src,

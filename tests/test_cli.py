@@ -145,6 +145,19 @@ def test_config0_compress_roundtrip_64KiB(tmp_path):
 
 
 @pytest.mark.gpu
+def test_decompress_sle_on_device(tmp_path):
+    """tdc -d with coder=sle and dec=gpu (tdc_gpu_lcpcomp_decompress_coder)."""
+    data = T.gen_english(100_000, 3).tobytes() + bytes([255, 0])
+    payload, _ = O.lcpcomp_sle_compress(O.escape(data), 5, 1, 3)
+    f = tmp_path / "s.tdc"
+    f.write_bytes(b"lcpcomp(coder=sle,threshold=5,dec=gpu)%" + payload)
+    out = tmp_path / "s.out"
+    r = _run("-d", "-o", str(out), str(f))
+    assert r.returncode == 0, r.stderr
+    assert out.read_bytes() == data
+
+
+@pytest.mark.gpu
 def test_decompress_on_device(tmp_path):
     """tdc -d with dec=gpu: host parse, references resolved on the device (tdc_gpu_lcpcomp_decompress)."""
     data = T.gen_english(300_000, 8).tobytes() + bytes([0, 255, 0])

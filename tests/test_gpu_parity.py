@@ -454,3 +454,30 @@ def test_fuzz_all_variants(gpu_ctx):
             want, _ = oracle_fn(text, thr, fl)
             got, _ = gpu_ctx.lcpcomp_compress(text, thr, fl, coder, comp)
             assert got == want, "case %d %s t=%d flatten=%d n=%d" % (i, name, thr, fl, len(text))
+
+
+def test_device_decompress_sle_and_ascii(gpu_ctx):
+    """tdc_gpu_lcpcomp_decompress_coder: SLE and ASCII streams (host parse, references resolved on the device) -- oracle
+    streams decode to the text, device streams round-trip, damaged streams are rejected."""
+    cases = [("english", T.gen_english(200_000, 5).tobytes()), ("dna", T.gen_dna(120_000, 7).tobytes()),
+             ("bytes", bytes(np.random.default_rng(8).integers(0, 256, 30_000, dtype=np.uint8)))]
+    for name, data in cases:
+        text = O.escape(data)
+        for k in (1, 3, 5):
+            s, _ = O.lcpcomp_sle_compress(text, 3, 1, k)
+            back, st = gpu_ctx.lcpcomp_decompress(s, T.CODER_SLE | (k << 8))
+            assert back == text, (name, k)
+            g, _ = gpu_ctx.lcpcomp_compress(text, 3, 1, T.CODER_SLE | (k << 8), T.COMP_MAXLCP)
+            assert gpu_ctx.lcpcomp_decompress(g, T.CODER_SLE | (k << 8))[0] == text
+        s, _ = O.lcpcomp_ascii_compress(text, 4, 1)
+        back, st = gpu_ctx.lcpcomp_decompress(s, T.CODER_ASCII)
+        assert back == text, name
+    c = T.LCPCompressor(gpu_ctx, coder="sle", threshold=4, kmer=2)
+    data = T.gen_english(50_000, 1).tobytes() + bytes([0, 255])
+    assert c.decompress(c.compress(data)) == data
+    s, _ = O.lcpcomp_sle_compress(O.escape(b"abcabcabcabc hello hello hello"), 2, 1, 3)
+    for bad in (s[:3], b"\xff" * 40, s[:len(s) // 2]):
+        with pytest.raises(T.TdcGpuError):
+            gpu_ctx.lcpcomp_decompress(bad, T.CODER_SLE)
+    with pytest.raises(T.TdcGpuError):
+        gpu_ctx.lcpcomp_decompress(b"12:x", T.CODER_ASCII)

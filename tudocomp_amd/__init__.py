@@ -208,14 +208,14 @@ class Context:
         arrs["maxlcp"] = m.value
         return arrs
 
-    def lcpcomp_decompress(self, stream):
-        """LCPCompressor::decompress on a lcpcomp(coder=huff) / lzss_lcp(coder=huff) stream: returns the escaped,
-        0-terminated text and {"factors", "rounds"}."""
+    def lcpcomp_decompress(self, stream, coder=CODER_HUFF):
+        """LCPCompressor::decompress on a lcpcomp / lzss_lcp stream written with coder huff, ascii or sle (CODER_SLE | kmer << 8):
+        returns the escaped, 0-terminated text and {"factors", "rounds"}."""
         a = _u8(stream)
         p, n = ctypes.c_void_p(), ctypes.c_size_t()
         f, r = ctypes.c_uint64(), ctypes.c_uint32()
-        self._check(self._L.tdc_gpu_lcpcomp_decompress(self._h, _ptr(a), len(a), ctypes.byref(p), ctypes.byref(n), ctypes.byref(f),
-                                                       ctypes.byref(r)))
+        self._check(self._L.tdc_gpu_lcpcomp_decompress_coder(self._h, _ptr(a), len(a), coder, ctypes.byref(p), ctypes.byref(n),
+                                                             ctypes.byref(f), ctypes.byref(r)))
         return self._take(p, n.value), {"factors": f.value, "rounds": r.value}
 
     def factorize(self, text, threshold=5, flatten=0):
@@ -285,11 +285,11 @@ class LCPCompressor:
         return out
 
     def decompress(self, stream):
-        """LCPCompressor::decompress (coder=huff): references resolved on the device; the harness then removes the
-        input restrictions again (unescape, drop the sentinel)."""
-        if self.coder != CODER_HUFF:
-            raise RuntimeError("only coder=huff streams are decoded on the device")
-        text, _ = self.ctx.lcpcomp_decompress(stream)
+        """LCPCompressor::decompress (coder huff / ascii / sle): references resolved on the device; the harness then removes
+        the input restrictions again (unescape, drop the sentinel)."""
+        if self.coder == CODER_ARITH:
+            raise RuntimeError("lcpcomp(coder=arithmetic) streams cannot be decoded (neither can the reference)")
+        text, _ = self.ctx.lcpcomp_decompress(stream, self.coder)
         return unescape(text)
 
 

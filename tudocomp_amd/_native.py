@@ -22,6 +22,7 @@ SYMBOLS = [
     "tdc_gpu_encode_arith",
     "tdc_gpu_encode_ascii",
     "tdc_gpu_encode_sle",
+    "tdc_gpu_lcpcomp_decompress_coder",
     "tdc_escape", "tdc_unescape", "tdc_huffman_table", "tdc_gen_english", "tdc_gen_dna",
 ]
 
@@ -85,6 +86,7 @@ def load():
     L.tdc_gpu_flatten.argtypes = [vp, sz, vp, vp, vp, sz, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
     L.tdc_gpu_encode_huff.argtypes = [vp, vp, sz, vp, vp, vp, sz, pvp, psz]
     L.tdc_gpu_lcpcomp_decompress.argtypes = [vp, vp, sz, pvp, psz, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32)]
+    L.tdc_gpu_lcpcomp_decompress_coder.argtypes = [vp, vp, sz, ctypes.c_int, pvp, psz, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32)]
     L.tdc_gpu_encode_arith.argtypes = [vp, vp, sz, vp, vp, vp, sz, pvp, psz]
     L.tdc_gpu_encode_ascii.argtypes = [vp, vp, sz, vp, vp, vp, sz, pvp, psz]
     L.tdc_gpu_encode_sle.argtypes = [vp, vp, sz, vp, vp, vp, sz, ctypes.c_uint32, pvp, psz]

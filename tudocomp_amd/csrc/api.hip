@@ -658,12 +658,19 @@ int tdc_gpu_flatten(tdc_gpu_ctx* ctx, size_t n, const uint32_t* pos, uint32_t* s
 
 int tdc_gpu_lcpcomp_decompress(tdc_gpu_ctx* ctx, const uint8_t* stream, size_t len, uint8_t** out, size_t* out_len,
                                uint64_t* factors, uint32_t* rounds) {
+    return tdc_gpu_lcpcomp_decompress_coder(ctx, stream, len, TDC_GPU_CODER_HUFF, out, out_len, factors, rounds);
+}
+
+int tdc_gpu_lcpcomp_decompress_coder(tdc_gpu_ctx* ctx, const uint8_t* stream, size_t len, int coder, uint8_t** out, size_t* out_len,
+                                     uint64_t* factors, uint32_t* rounds) {
     return guarded(ctx, [&] {
         if (!stream || !out || !out_len) throw ArgError{TDC_GPU_ERR_ARG, "NULL argument"};
+        const int enc = lcpcomp_enc_coder(coder);
+        if (enc == 1) throw ArgError{TDC_GPU_ERR_UNSUPPORTED, "lcpcomp(coder=arithmetic) streams cannot be decoded (neither can the reference)"};
         std::vector<u8> text;
         DecodeStats ds;
         size_t n = 0;
-        try { n = decode_lzss_huff(ctx->c, stream, len, text, &ds); }
+        try { n = decode_lzss(ctx->c, stream, len, enc, text, &ds); }
         catch (const StreamFormatError& e) { throw ArgError{TDC_GPU_ERR_ARG, e.what}; }
         uint8_t* h = host_alloc<uint8_t>(n);
         if (n) memcpy(h, text.data(), n);

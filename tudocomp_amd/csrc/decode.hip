@@ -166,13 +166,129 @@ static u64 parse_lzss_huff_stream(const u8* in, size_t len, std::vector<u8>& tex
     return n;
 }
 
+// The same token stream written with SLECoder (coders/SLECoder.hpp:301-453: ranking header, rank class codes, k-mer symbols
+// expand to k literals, MinDistributedRange for the factor length).
+static u64 parse_lzss_sle_stream(const u8* in, size_t len, unsigned k, std::vector<u8>& text, std::vector<u32>& fpos,
+                                 std::vector<u32>& fsrc, std::vector<u32>& flen) {
+    FastBits bs(in, len);
+    const size_t sigma = (size_t)bs.read_compressed_int();                  // Decoder ctor :325-340
+    if (sigma == 0 || sigma > 4096) throw StreamError{"corrupt SLE ranking"};
+    const unsigned sb = bits_for(sigma - 1);
+    std::vector<u64> inv(sigma);
+    for (size_t r = 0; r < sigma; ++r) inv[r] = bs.read_compressed_int();
+    auto read_rank = [&]() -> u64 {                                           // :367-397
+        if (sb < 4) return bs.read(sb);
+        if (sb < 6) return bs.read(1) ? bs.read(sb) : bs.read(2);
+        if (sb == 6) {
+            switch (bs.read(2)) {
+                case 0: return bs.read(3);
+                case 1: return 8 + bs.read(3);
+                case 2: return 16 + bs.read(4);
+                default: return bs.read(sb);
+            }
+        }
+        const u64 cls = bs.read(3);
+        if (cls < 4) return 4 * cls + bs.read(2);
+        if (cls < 7) return 16 + 8 * (cls - 4) + bs.read(3);
+        return bs.read(sb);
+    };
+    const u64 n = bs.read(32);
+    const unsigned W = bits_for(n);
+    const u64 flen_min = bs.read(W), flen_max = bs.read(W), fdist_max = bs.read(W);
+    const unsigned lbits = bits_for(flen_max - flen_min), dbits = bits_for(fdist_max);
+    if (n == 0 || n >= 0x7FFFFFFFull) throw StreamError{"text length out of range"};
+    text.assign((size_t)n, 0);
+    u8 kmer[8]; size_t kread = (size_t)-1;
+    u64 p = 0;
+    auto eof = [&] { return kread < k ? false : bs.eof(); };                  // :351-359
+    while (!eof()) {
+        kread = (size_t)-1;
+        u64 num = bs.read(1) ? bs.read(dbits) : 0;
+        if (p + num > n) throw StreamError{"corrupt stream: too many literals"};
+        while (num--) {
+            u8 ch;
+            if (kread < k) ch = kmer[kread++];
+            else {
+                const u64 r = read_rank();
+                if (r >= sigma) throw StreamError{"corrupt stream: rank out of range"};
+                const u64 x = inv[(size_t)r];
+                if ((x >> 56) == 0xFF) { for (unsigned i = 0; i < k; ++i) kmer[k - 1 - i] = (u8)(x >> (8 * i)); kread = 1; ch = kmer[0]; }
+                else ch = (u8)x;
+            }
+            text[(size_t)p++] = ch;
+        }
+        if (!eof()) {
+            kread = (size_t)-1;
+            const u64 src = bs.read(W);
+            u64 v;                                                           // decode(MinDistributedRange) :413-431
+            if (lbits <= 5) v = bs.read(lbits);
+            else switch (bs.read(2)) {
+                case 0: v = bs.read(3); break;
+                case 1: v = 8 + bs.read(3); break;
+                case 2: v = 16 + bs.read(4); break;
+                default: v = bs.read(lbits); break;
+            }
+            const u64 l = flen_min + v;
+            if (l == 0 || p + l > n || src + l > n) throw StreamError{"corrupt stream: factor out of range"};
+            fpos.push_back((u32)p); fsrc.push_back((u32)src); flen.push_back((u32)l);
+            p += l;
+        }
+    }
+    if (p != n) throw StreamError{"corrupt stream: length mismatch"};
+    return n;
+}
+
+// ... and with ASCIICoder (coders/ASCIICoder.hpp:53-84): decimal integers up to the first non-digit, a bit is any byte but
+// '0', literals are raw bytes; the BitOStream terminator byte ends the stream.
+static u64 parse_lzss_ascii_stream(const u8* in, size_t in_len, std::vector<u8>& text, std::vector<u32>& fpos, std::vector<u32>& fsrc,
+                                   std::vector<u32>& flen) {
+    if (in_len == 0) throw StreamError{"corrupt stream: empty"};
+    const size_t len = in_len - 1;
+    size_t at = 0;
+    auto read_int = [&]() -> u64 {
+        u64 v = 0; int digits = 0;
+        while (at < len) {
+            const u8 ch = in[at++];
+            if (ch < '0' || ch > '9') { if (!digits) break; return v; }
+            if (digits >= 18) break;
+            v = v * 10 + (ch - '0'); ++digits;
+        }
+        throw StreamError{"corrupt stream: integer expected"};
+    };
+    const u64 n = read_int();
+    read_int(); read_int(); read_int();                                       // flen_min, flen_max, fdist_max: unused by this coder
+    if (n == 0 || n >= 0x7FFFFFFFull) throw StreamError{"text length out of range"};
+    text.assign((size_t)n, 0);
+    u64 p = 0;
+    while (at < len) {
+        u64 num = (in[at++] != '0') ? read_int() : 0;
+        if (p + num > n || at + num > len) throw StreamError{"corrupt stream: too many literals"};
+        while (num--) text[(size_t)p++] = in[at++];
+        if (at < len) {
+            const u64 src = read_int(), l = read_int();
+            if (l == 0 || p + l > n || src + l > n) throw StreamError{"corrupt stream: factor out of range"};
+            fpos.push_back((u32)p); fsrc.push_back((u32)src); flen.push_back((u32)l);
+            p += l;
+        }
+    }
+    if (p != n) throw StreamError{"corrupt stream: length mismatch"};
+    return n;
+}
+
 size_t decode_lzss_huff(Ctx& c, const u8* stream, size_t len, std::vector<u8>& text, DecodeStats* st) {
+    return decode_lzss(c, stream, len, 0, text, st);
+}
+
+// coder: 0 = HuffmanCoder, 2 = ASCIICoder, 3 | kmer << 8 = SLECoder (the coder ids of encode_stream)
+size_t decode_lzss(Ctx& c, const u8* stream, size_t len, int coder, std::vector<u8>& text, DecodeStats* st) {
     DecodeStats local;
     if (!st) st = &local;
     *st = DecodeStats();
     std::vector<u32> fpos, fsrc, flen;
     u64 n;
-    n = parse_lzss_huff_stream(stream, len, text, fpos, fsrc, flen);
+    if ((coder & 0xFF) == 3) n = parse_lzss_sle_stream(stream, len, (unsigned)(coder >> 8) ? (unsigned)(coder >> 8) : 3u, text, fpos, fsrc, flen);
+    else if (coder == 2) n = parse_lzss_ascii_stream(stream, len, text, fpos, fsrc, flen);
+    else n = parse_lzss_huff_stream(stream, len, text, fpos, fsrc, flen);
     const size_t z = fpos.size();
     st->factors = z;
     if (n == 0 || z == 0) return (size_t)n;

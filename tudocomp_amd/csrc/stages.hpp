@@ -101,6 +101,8 @@ namespace tdc {
 struct DecodeStats { u64 factors = 0; u32 rounds = 0; };
 struct StreamFormatError { const char* what; };          // malformed input
 size_t decode_lzss_huff(Ctx& c, const u8* stream, size_t len, std::vector<u8>& text, DecodeStats* st);
+// the same for streams written with another coder: 0 = HuffmanCoder, 2 = ASCIICoder, 3 | kmer << 8 = SLECoder
+size_t decode_lzss(Ctx& c, const u8* stream, size_t len, int coder, std::vector<u8>& text, DecodeStats* st);
 // a17: compressors/LZ78Compressor.hpp:64-140 -- sequential parse on the host; returns the number of (id, char) pairs
 size_t lz78_parse_host(const u8* in, size_t n, std::vector<u32>& ids, std::vector<u8>& chars, bool* leftover_is_high);
 // a16: coders/EliasGammaCoder.hpp:26-29 + io/BitOStream.hpp:105-129 on the device; returns the stream length

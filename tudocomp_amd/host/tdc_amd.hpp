@@ -416,18 +416,19 @@ public:
     }
 
     void decompress(Input& input, Output& output) override {
-        if (m_coder == TDC_GPU_CODER_ASCII) { lzss_ascii_decode(input, output); return; }
-        if ((m_coder & 0xFF) == TDC_GPU_CODER_SLE) { lzss_sle_decode(input, output, m_kmer); return; }
-        if (m_coder != TDC_GPU_CODER_HUFF)
+        if (m_coder == TDC_GPU_CODER_ARITH)
             throw std::runtime_error("lcpcomp(coder=arithmetic) streams cannot be decoded (neither can the reference: "
                                      "consuming coders corrupt interleaved streams, docs/Documentation.md:1190-1203)");
+        const bool on_device = m_opts.get("dec", "scan") == "gpu";
+        if (!on_device && m_coder == TDC_GPU_CODER_ASCII) { lzss_ascii_decode(input, output); return; }
+        if (!on_device && (m_coder & 0xFF) == TDC_GPU_CODER_SLE) { lzss_sle_decode(input, output, m_kmer); return; }
         // dec=gpu (an addition to the reference's decoder strategies scan / compact / ..., LCPCompressor.hpp:88): the stream is
         // parsed on the host, the references are resolved on the device (tdc_gpu_lcpcomp_decompress)
         if (m_opts.get("dec", "scan") == "gpu") {
             if (!m_ctx) m_ctx = std::make_shared<GpuContext>(m_device);
             const bytes& in = input.raw();
             uint8_t* out = nullptr; size_t out_len = 0;
-            const int rc = tdc_gpu_lcpcomp_decompress(m_ctx->h, in.data(), in.size(), &out, &out_len, nullptr, nullptr);
+            const int rc = tdc_gpu_lcpcomp_decompress_coder(m_ctx->h, in.data(), in.size(), m_coder, &out, &out_len, nullptr, nullptr);
             if (rc) throw std::runtime_error(std::string(tdc_gpu_strerror(rc)) + ": " + tdc_gpu_last_error(m_ctx->h));
             output.write(out, out_len);
             tdc_gpu_free(out);
