@@ -387,7 +387,7 @@ static int cmp_factor_pos(const void* a, const void* b) {
     const uint32_t x = ((const orc_factor*)a)->pos, y = ((const orc_factor*)b)->pos;
     return x < y ? -1 : x > y;
 }
-void orc_sort_factors(orc_factor* f, size_t z) { qsort(f, z, sizeof(orc_factor), cmp_factor_pos); }
+void orc_sort_factors(orc_factor* f, size_t z) { if (z) qsort(f, z, sizeof(orc_factor), cmp_factor_pos); }
 
 /* LZSSFactors.hpp:79-132 */
 void orc_flatten(orc_factor* f, size_t z, uint64_t* num_flattened, uint64_t* max_depth) {
