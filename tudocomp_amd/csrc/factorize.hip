@@ -571,13 +571,69 @@ __global__ void purge_class_kernel(const u32* __restrict__ cand, size_t cnt, u32
 // have one erased candidate per level over tens of thousands of consecutive levels (the ramp PLCP = R, R-1, ... inside a
 // repeat of length R, erased by the factor of level R): one probe replaces a launch and a read-back per level.
 __global__ __launch_bounds__(256) void alive_max_level_kernel(const u32* __restrict__ levels, const u32* __restrict__ pos, size_t lo, size_t hi,
-                                                               const u32* __restrict__ cur, u32 threshold, u32* __restrict__ d_max) {
-    u32 best = 0;
+                                                               const u32* __restrict__ cur, u32 threshold, u32* __restrict__ d_max,
+                                                               u32* __restrict__ d_maxcur = nullptr) {
+    u32 best = 0, bestcur = 0;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t k = lo + (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < hi; k += stride)
-        if (cur[pos[k]] >= threshold) best = max(best, levels[k]);
+    for (size_t k = lo + (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < hi; k += stride) {
+        const u32 v = cur[pos[k]];
+        if (v >= threshold) { best = max(best, levels[k]); bestcur = max(bestcur, v); }
+    }
     best = wave_reduce_max(best);
     if (lane_id() == 0 && best) atomicMax(d_max, best);
+    if (d_maxcur) { bestcur = wave_reduce_max(bestcur); if (lane_id() == 0 && bestcur) atomicMax(d_maxcur, bestcur); }
+}
+
+// The same question for pushed entries: highest target level among the given pool segments that still hold an alive entry.
+struct ProbeSeg { u32 off, cnt, level; };
+__global__ __launch_bounds__(256) void alive_max_pool_kernel(const u32* __restrict__ pool, const ProbeSeg* __restrict__ tab, size_t nseg,
+                                                              const u32* __restrict__ cur, u32 threshold, u32* __restrict__ d_max,
+                                                              u32* __restrict__ d_maxcur) {
+    u32 best = 0, bestcur = 0;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < nseg; k += stride) {
+        const ProbeSeg sg = tab[k];
+        if (!d_maxcur && sg.level <= best) continue;
+        for (u32 j = 0; j < sg.cnt; ++j) {
+            const u32 v = cur[pool[sg.off + j]];
+            if (v >= threshold) { best = max(best, sg.level); bestcur = max(bestcur, v); if (!d_maxcur) break; }
+        }
+    }
+    best = wave_reduce_max(best);
+    if (lane_id() == 0 && best) atomicMax(d_max, best);
+    if (d_maxcur) { bestcur = wave_reduce_max(bestcur); if (lane_id() == 0 && bestcur) atomicMax(d_maxcur, bestcur); }
+}
+
+// A run of levels (floor, top] without a live entry only moves its stale entries down (:85-89): collected in one go.  Record:
+// key = (top - level) << 32 | old priority (the order in which the level-by-level loop would meet the entries), value = position.
+__global__ __launch_bounds__(256) void stale_collect_orig_kernel(const u32* __restrict__ levels, const u32* __restrict__ pos, size_t lo, size_t hi,
+                                                                  u32 floor_lv, u32 top, const u32* __restrict__ cur, const u32* __restrict__ prio,
+                                                                  u32 threshold, u64* __restrict__ rkey, u32* __restrict__ rval, u32* __restrict__ d_count) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t k0 = lo + (size_t)blockIdx.x * blockDim.x; k0 < hi; k0 += stride) {
+        const size_t k = k0 + threadIdx.x;
+        u32 p = 0, lv = 0;
+        bool want = false;
+        if (k < hi) { lv = levels[k]; p = pos[k]; want = lv > floor_lv && lv <= top && cur[p] >= threshold; }
+        const u32 o = wave_append(want, d_count);
+        if (want) { rkey[o] = ((u64)(top - lv) << 32) | prio[p]; rval[o] = p; }
+    }
+}
+__global__ __launch_bounds__(256) void stale_collect_pool_kernel(const u32* __restrict__ pool, const ProbeSeg* __restrict__ tab, size_t nseg,
+                                                                  u32 floor_lv, u32 top, const u32* __restrict__ cur, const u32* __restrict__ prio,
+                                                                  u32 threshold, u64* __restrict__ rkey, u32* __restrict__ rval, u32* __restrict__ d_count) {
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nseg) return;
+    const ProbeSeg sg = tab[k];
+    if (sg.level <= floor_lv || sg.level > top) return;
+    for (u32 j = 0; j < sg.cnt; ++j) {
+        const u32 p = pool[sg.off + j];
+        if (cur[p] >= threshold) { const u32 o = atomicAdd(d_count, 1u); rkey[o] = ((u64)(top - sg.level) << 32) | prio[p]; rval[o] = p; }
+    }
+}
+__global__ void stale_target_keys_kernel(const u32* __restrict__ vals, u32 m, const u32* __restrict__ cur, u64* __restrict__ keys) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) keys[i] = (u64)cur[vals[i]] << 32;
 }
 
 // Pushed part of a level's list: concatenation of its pool segments (table: source offset / destination offset).
@@ -744,6 +800,8 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
     u32 prio_base = (u32)n;
 
     u32 dead_streak = 0, levels_since_purge = 1u << 30;
+    u32 dead_levels_run = 0;                               // consecutive levels whose entries were all erased
+    u32 nolive_run = 0, stale_trigger = 8;                 // consecutive levels without a live entry; run length that triggers the batch push
     double host_prof[5] = {0, 0, 0, 0, 0};                // small levels, host side: prepare / launch / wait / bookkeeping (us), count
     unsigned long long* d_sprof = nullptr;                 // TDC_GPU_SMALL_PROF=1: phase times of the small-level kernel on stderr
     if (getenv("TDC_GPU_SMALL_PROF")) { d_sprof = (unsigned long long*)c.arena.alloc(32 * sizeof(unsigned long long)); HIP_TRY(hipMemsetAsync(d_sprof, 0, 32 * sizeof(unsigned long long), s)); }
@@ -800,14 +858,24 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
             dead_streak = 0;
         }
         ++levels_since_purge;
-        if (probe_dead && pushed_into[L].empty()) {
-            // the last level was completely erased: look how far down that goes.  Range: the levels below L without pushed
-            // entries (never past the window cut), at most 4 Mi candidates.
+        const bool trigger_stale = nolive_run >= stale_trigger;     // a run of levels without a live entry (erased or stale entries only)
+        if ((probe_dead && (pushed_into[L].empty() || dead_levels_run >= 8)) || trigger_stale) {
+            // the last level was completely erased: look how far down that goes.  Range: the levels below L (never past the
+            // window cut) holding at most 4 Mi candidates; levels with pushed entries end the range -- unless a long run of
+            // erased levels has been seen, then their pool segments are examined as well (texts like Fibonacci words leave
+            // erased pushed entries in hundreds of thousands of consecutive levels).  After a long run of levels without a live
+            // entry the probe also returns the highest current value of an alive entry: no level above it can select
+            // anything, their stale entries are pushed down in one step.
             const u32 floor_level = std::max<u32>(threshold, lcut ? lcut + 1 : 0);
+            const bool deep = dead_levels_run >= 8 || trigger_stale;
+            std::vector<ProbeSeg> ptab;
             u32 Lb = L;
             size_t lo = (size_t)-1, hi = 0, cnt = 0;
             for (u32 v = L;; --v) {
-                if (!pushed_into[v].empty() && v != L) break;
+                if (!pushed_into[v].empty()) {
+                    if (v != L && (!deep || ptab.size() + pushed_into[v].size() > ((size_t)4 << 20))) break;
+                    for (const PoolSeg& sg : pushed_into[v]) ptab.push_back(ProbeSeg{sg.off, sg.cnt, v});
+                }
                 if (h_segend[v] > h_segstart[v]) {
                     cnt += h_segend[v] - h_segstart[v];
                     if (cnt > ((size_t)4 << 20) && v != L) break;
@@ -817,18 +885,90 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
                 if (v == floor_level) break;
             }
             if (Lb < L) {
-                u32 alive = 0;
-                if (hi > lo) {
-                    HIP_TRY(hipMemsetAsync(d_cnt + 2, 0, sizeof(u32), s));
-                    unsigned g = cdiv(hi - lo, 256 * 4); if (g > 4096) g = 4096; if (g == 0) g = 1;
-                    alive_max_level_kernel<<<g, 256, 0, s>>>(ckeys[x], cvals[x], lo, hi, cur, threshold, d_cnt + 2);
-                    LAUNCH_CHECK();
-                    alive = c.read(d_cnt + 2);
+                u32 alive = 0, livecur = 0;
+                const size_t pmark = c.arena.mark();
+                ProbeSeg* d_ptab = nullptr;
+                if (hi > lo || !ptab.empty()) {
+                    HIP_TRY(hipMemsetAsync(d_cnt + 2, 0, 2 * sizeof(u32), s));
+                    u32* d_maxcur = trigger_stale ? d_cnt + 3 : nullptr;
+                    if (hi > lo) {
+                        unsigned g = cdiv(hi - lo, 256 * 4); if (g > 4096) g = 4096; if (g == 0) g = 1;
+                        alive_max_level_kernel<<<g, 256, 0, s>>>(ckeys[x], cvals[x], lo, hi, cur, threshold, d_cnt + 2, d_maxcur);
+                        LAUNCH_CHECK();
+                    }
+                    if (!ptab.empty()) {
+                        d_ptab = (ProbeSeg*)c.arena.alloc(ptab.size() * sizeof(ProbeSeg));
+                        HIP_TRY(hipMemcpyAsync(d_ptab, ptab.data(), ptab.size() * sizeof(ProbeSeg), hipMemcpyHostToDevice, s));
+                        unsigned g = cdiv(ptab.size(), 256); if (g > 4096) g = 4096;
+                        alive_max_pool_kernel<<<g, 256, 0, s>>>(pool, d_ptab, ptab.size(), cur, threshold, d_cnt + 2, d_maxcur);
+                        LAUNCH_CHECK();
+                    }
+                    u32 two[2];
+                    c.read_n(d_cnt + 2, two, 2);           // synchronises: the host table has been copied
+                    alive = two[0]; livecur = two[1];
                 }
                 st->probes++;
-                if (alive < Lb) { L = Lb; probe_dead = true; continue; }          // [Lb, L] all erased: the loop's --L goes on below Lb
-                if (alive < L) { L = alive + 1; probe_dead = false; continue; }   // (alive, L] erased: --L lands on `alive`
-            }
+                if (alive < Lb) { c.arena.release(pmark); L = Lb; probe_dead = true; continue; }          // [Lb, L] all erased: the loop's --L goes on below Lb
+                if (alive < L) { c.arena.release(pmark); L = alive + 1; probe_dead = false; continue; }   // (alive, L] erased: --L lands on `alive`
+                if (trigger_stale) {
+                    // alive == L.  No alive entry of the range has a value above livecur, so the levels (floor, L] with
+                    // floor = max(livecur, Lb - 1) only push: all of them at once, numbered as the loop would number them
+                    const u32 floor_lv = std::max(livecur, Lb - 1);
+                    const u32 span = L - floor_lv;
+                    if (floor_lv < L && span >= 4) {
+                        HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(u32), s));
+                        if (hi > lo) {
+                            unsigned g = cdiv(hi - lo, 256 * 4); if (g > 4096) g = 4096; if (g == 0) g = 1;
+                            stale_collect_orig_kernel<<<g, 256, 0, s>>>(ckeys[x], cvals[x], lo, hi, floor_lv, L, cur, prio, threshold, skeys[0], svals[0], d_cnt);
+                            LAUNCH_CHECK();
+                        }
+                        if (!ptab.empty()) {
+                            stale_collect_pool_kernel<<<cdiv(ptab.size(), 256), 256, 0, s>>>(pool, d_ptab, ptab.size(), floor_lv, L, cur, prio, threshold,
+                                                                                         skeys[0], svals[0], d_cnt);
+                            LAUNCH_CHECK();
+                        }
+                        const u32 R = c.read(d_cnt);
+                        if (R) {
+                            if (pool_top + R > n || (u64)prio_base + R > 0xFFFFFFFFull)
+                                throw HipError{hipErrorUnknown, "factorize: push pool overflow", (int)__LINE__};
+                            const int ya = radix_sort_pairs_u64(c, skeys, svals, R, 0, 32 + (int)bits_for(span));     // order of the level-by-level loop
+                            stale_target_keys_kernel<<<cdiv(R, 256), 256, 0, s>>>(svals[ya], R, cur, skeys[ya]);
+                            LAUNCH_CHECK();
+                            u64* kb[2] = { skeys[ya], skeys[ya ^ 1] };
+                            u32* vb[2] = { svals[ya], svals[ya ^ 1] };
+                            const int yb = radix_sort_pairs_u64(c, kb, vb, R, 32, 32 + (int)bits_for(floor_lv));        // stable: grouped by target
+                            PushSeg* d_bsegs = (PushSeg*)c.arena.alloc((size_t)R * sizeof(PushSeg));
+                            HIP_TRY(hipMemsetAsync(d_sc, 0, 8 * sizeof(u32), s));
+                            push_finalize_kernel<<<cdiv(R, 256), 256, 0, s>>>(kb[yb], vb[yb], R, prio_base, prio, pool + pool_top, res8, d_bsegs, R, d_sc);
+                            LAUNCH_CHECK();
+                            const u32 nseg = c.read(&d_sc->nseg);
+                            std::vector<PushSeg> bsegs(nseg);
+                            c.read_n(d_bsegs, bsegs.data(), nseg);
+                            std::sort(bsegs.begin(), bsegs.end(), [](const PushSeg& a, const PushSeg& b) { return a.start < b.start; });
+                            for (u32 j = 0; j < nseg; ++j) {
+                                const u32 end = (j + 1 < nseg) ? bsegs[j + 1].start : R;
+                                const u32 tgt = bsegs[j].target;
+                                if (tgt > floor_lv || tgt < threshold) throw HipError{hipErrorUnknown, "factorize: bad push target", (int)__LINE__};
+                                pushed_into[tgt].push_back(PoolSeg{(u32)pool_top + bsegs[j].start, end - bsegs[j].start});
+                            }
+                            pool_top += R;
+                            prio_base += R;
+                            st->pushes += R;
+                        }
+                        for (u32 v = L; v > floor_lv; --v) std::vector<PoolSeg>().swap(pushed_into[v]);
+                        c.arena.release(pmark);
+                        st->levels += span;
+                        stale_trigger = span >= 64 ? 8u : std::min<u32>(stale_trigger * 2, 4096u);
+                        nolive_run = 0;
+                        L = floor_lv + 1;                  // the loop's --L lands on floor_lv
+                        probe_dead = false;
+                        continue;
+                    }
+                    stale_trigger = std::min<u32>(stale_trigger * 2, 4096u);     // nothing to gain here: ask less often
+                    nolive_run = 0;
+                }
+                c.arena.release(pmark);
+            } else if (trigger_stale) { stale_trigger = std::min<u32>(stale_trigger * 2, 4096u); nolive_run = 0; }
             probe_dead = false;
         }
         const u32 m0 = h_segend[L] - h_segstart[L];
@@ -901,7 +1041,9 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
                 }
                 std::vector<PoolSeg>().swap(pushed_into[L]);
                 st->small_levels++;
-                if (h_sc.nlive == 0 && h_sc.nstale == 0) { probe_dead = true; continue; }   // small levels do not count for the purge heuristic
+                if (h_sc.nlive == 0) ++nolive_run; else nolive_run = 0;
+                if (h_sc.nlive == 0 && h_sc.nstale == 0) { probe_dead = true; ++dead_levels_run; continue; }   // small levels do not count for the purge heuristic
+                dead_levels_run = 0;
                 st->factors += h_sc.selected;
                 const u32 npush = h_sc.npush, nseg = h_sc.nseg;
                 if (npush) {
@@ -942,7 +1084,9 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
         c.read_n((const u32*)d_sc, (u32*)&h_sc, 8);
         const u32 nl = h_sc.nlive, ns = h_sc.nstale;
         if (((u64)nl + ns) * 16 < m) ++dead_streak; else dead_streak = 0;     // (almost) all entries already erased
-        if (nl == 0 && ns == 0) { probe_dead = true; continue; }   // every entry already erased (:86)
+        if (nl == 0) ++nolive_run; else nolive_run = 0;
+        if (nl == 0 && ns == 0) { probe_dead = true; ++dead_levels_run; continue; }   // every entry already erased (:86)
+        dead_levels_run = 0;
         const bool wide = (L > 24);
         const unsigned gl = wide ? cdiv((size_t)nl * 64, 256) : cdiv(nl, 256);
         const unsigned gs = wide ? cdiv((size_t)ns * 64, 256) : cdiv(ns, 256);
@@ -1199,9 +1343,10 @@ void factorize_max_lcp(Ctx& c, size_t n, u32* isa, const u32* phi, u32* plcp, u3
     const size_t pool_cap = 4 * n;
     u32* pool = c.arena.get<u32>(pool_cap);
     LevelScalars* d_sc = (LevelScalars*)c.arena.alloc(sizeof(LevelScalars));
-    const u32 seg_cap = 1u << 16;
+    // one factor of length L can send up to L entries to L different levels (eager decreases): room for min(n, 4 Mi) targets
+    const u32 seg_cap = (u32)std::max<size_t>((size_t)1 << 16, std::min<size_t>(n, (size_t)4 << 20));
     PushSeg* d_segs = (PushSeg*)c.arena.alloc(sizeof(PushSeg) * seg_cap);
-    std::vector<PushSeg> h_segs(seg_cap);
+    std::vector<PushSeg> h_segs;
     LevelScalars h_sc;
     const u32 gtab_cap = 1u << 16;
     GatherSeg* d_gtab = (GatherSeg*)c.arena.alloc(sizeof(GatherSeg) * gtab_cap);
@@ -1301,6 +1446,7 @@ void factorize_max_lcp(Ctx& c, size_t n, u32* isa, const u32* phi, u32* plcp, u3
             c.read_n((const u32*)d_sc, (u32*)&h_sc, sizeof(LevelScalars) / sizeof(u32));
             const u32 nseg = h_sc.nseg;
             if (nseg > seg_cap) throw HipError{hipErrorUnknown, "max_lcp: too many push targets in one level", (int)__LINE__};
+            if (h_segs.size() < nseg) h_segs.resize(nseg);
             if (nseg > SEG_INLINE) c.read_n(d_segs, h_segs.data(), nseg);
             else for (u32 j = 0; j < nseg; ++j) h_segs[j] = h_sc.segs[j];
             std::sort(h_segs.begin(), h_segs.begin() + nseg, [](const PushSeg& a, const PushSeg& b) { return a.start < b.start; });
