@@ -147,3 +147,26 @@ def test_structured_random_texts(ctx_for):
         got, st = ctx_for(48).lcpcomp_compress(text, threshold=thr, flatten=fl)
         assert got == want, "case %d (sigma %d, n %d, t %d, flatten %d, maxlcp %d, window_pass %d)" % (
             case, sigma, len(text), thr, fl, wst["maxlcp"], st["window_pass"])
+
+
+@pytest.mark.gpu
+def test_extreme_repeat_structure(gpu_ctx):
+    """Runs, periodic texts and a Fibonacci word (a ramp of PLCP values over hundreds of thousands of levels, almost all of them
+    holding only erased or stale entries): both strategies equal the oracle, and the level loop skips / batches instead of
+    visiting every level."""
+    import time
+    N = 300_000
+    a, b = b"a", b"ab"
+    while len(b) < N:
+        a, b = b, b + a
+    cases = {"a^N": b"a" * N, "(ab)^N/2": b"ab" * (N // 2), "(abc)^k x (abc)^k": b"abc" * (N // 6) + b"x" + b"abc" * (N // 6),
+             "fibonacci": b[:N]}
+    for name, data in cases.items():
+        text = O.escape(data)
+        for comp, fn in ((T.COMP_ARRAYS, O.lcpcomp_huff_compress), (T.COMP_MAXLCP, O.lcpcomp_maxlcp_huff_compress)):
+            for thr in (2, 5):
+                t0 = time.time()
+                got, st = gpu_ctx.lcpcomp_compress(text, thr, 1, T.CODER_HUFF, comp)
+                dt = time.time() - t0
+                assert got == fn(text, thr, 1)[0], (name, comp, thr)
+                assert dt < 1.5, "%s comp=%d: %.2f s (a level-by-level walk over the ramp)" % (name, comp, dt)

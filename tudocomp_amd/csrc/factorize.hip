@@ -1285,6 +1285,32 @@ __global__ void mlcp_pool_kernel(const u64* __restrict__ keys, u32 npush, u32* _
     }
 }
 
+// MaxLCPStrategy keeps an entry in the list of its CURRENT value (eager decreases), so older copies in higher lists and in the
+// candidate array are dead weight: highest level that holds an entry whose value still equals the level of its list
+__global__ __launch_bounds__(256) void live_max_level_kernel(const u32* __restrict__ levels, const u32* __restrict__ pos, size_t lo, size_t hi,
+                                                              const u32* __restrict__ cur, u32* __restrict__ d_max) {
+    u32 best = 0;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t k = lo + (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < hi; k += stride) {
+        const u32 lv = levels[k];
+        if (lv > best && cur[pos[k]] == lv) best = lv;
+    }
+    best = wave_reduce_max(best);
+    if (lane_id() == 0 && best) atomicMax(d_max, best);
+}
+__global__ __launch_bounds__(256) void live_max_pool_kernel(const u32* __restrict__ pool, const ProbeSeg* __restrict__ tab, size_t nseg,
+                                                             const u32* __restrict__ cur, u32* __restrict__ d_max) {
+    u32 best = 0;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < nseg; k += stride) {
+        const ProbeSeg sg = tab[k];
+        if (sg.level <= best) continue;
+        for (u32 j = 0; j < sg.cnt; ++j) if (cur[pool[sg.off + j]] == sg.level) { best = sg.level; break; }
+    }
+    best = wave_reduce_max(best);
+    if (lane_id() == 0 && best) atomicMax(d_max, best);
+}
+
 void factorize_max_lcp(Ctx& c, size_t n, u32* isa, const u32* phi, u32* plcp, u32 maxlcp, u32 threshold, FactorSpace& fs,
                        FactorizeStats* st) {
     FactorizeStats local;
@@ -1361,18 +1387,38 @@ void factorize_max_lcp(Ctx& c, size_t n, u32* isa, const u32* phi, u32* plcp, u3
         const u32 l_pool = pushed_into.empty() ? 0u : pushed_into.rbegin()->first;
         const u32 L = std::max(l_init, l_pool);
         if (L < threshold || L == 0) break;
-        // a run of levels whose original entries were all erased: skip to the highest level that still holds a candidate
-        if (dead_streak >= 4 && l_pool < l_init && h_segend[l_init] > 0) {
-            const size_t hi = h_segend[l_init];
+        // a run of levels without a live entry: skip to the highest level that still holds one (candidates whose value is
+        // still their PLCP value; pool segments -- at most 4 Mi of them, from the top -- with an entry whose value is the
+        // segment's level)
+        if (dead_streak >= 8) {
             HIP_TRY(hipMemsetAsync(d_cnt + 2, 0, sizeof(u32), s));
-            unsigned g = cdiv(hi, 256 * 4); if (g > 4096) g = 4096; if (g == 0) g = 1;
-            alive_max_level_kernel<<<g, 256, 0, s>>>(ckeys[x], cvals[x], 0, hi, cur, threshold, d_cnt + 2);
-            LAUNCH_CHECK();
-            const u32 alive = c.read(d_cnt + 2);                  // original level of the highest candidate that is not erased
+            if (l_init && h_segend[l_init] > 0) {
+                const size_t hi = h_segend[l_init];
+                unsigned g = cdiv(hi, 256 * 4); if (g > 4096) g = 4096; if (g == 0) g = 1;
+                live_max_level_kernel<<<g, 256, 0, s>>>(ckeys[x], cvals[x], 0, hi, cur, d_cnt + 2);
+                LAUNCH_CHECK();
+            }
+            std::vector<ProbeSeg> ptab;
+            u32 pool_floor = 0;                                   // levels below this one were not examined
+            for (auto itp = pushed_into.rbegin(); itp != pushed_into.rend(); ++itp) {
+                if (ptab.size() + itp->second.size() > ((size_t)4 << 20) && !ptab.empty()) { pool_floor = itp->first + 1; break; }
+                for (const PoolSeg& sg : itp->second) ptab.push_back(ProbeSeg{sg.off, sg.cnt, itp->first});
+            }
+            const size_t pmark = c.arena.mark();
+            if (!ptab.empty()) {
+                ProbeSeg* d_ptab = (ProbeSeg*)c.arena.alloc(ptab.size() * sizeof(ProbeSeg));
+                HIP_TRY(hipMemcpyAsync(d_ptab, ptab.data(), ptab.size() * sizeof(ProbeSeg), hipMemcpyHostToDevice, s));
+                unsigned g = cdiv(ptab.size(), 256); if (g > 4096) g = 4096;
+                live_max_pool_kernel<<<g, 256, 0, s>>>(pool, d_ptab, ptab.size(), cur, d_cnt + 2);
+                LAUNCH_CHECK();
+            }
+            const u32 live = std::max(c.read(d_cnt + 2), pool_floor ? pool_floor - 1 : 0u);   // synchronises: the host table has been copied
+            c.arena.release(pmark);
             st->probes++;
             dead_streak = 0;
-            if (alive < l_init) {
-                while (ip < init_levels.size() && init_levels[ip] > alive) ++ip;
+            if (live < L) {
+                while (ip < init_levels.size() && init_levels[ip] > live) ++ip;
+                while (!pushed_into.empty() && pushed_into.rbegin()->first > live) pushed_into.erase(std::prev(pushed_into.end()));
                 continue;
             }
         }
