@@ -9,7 +9,19 @@ N = int(float(sys.argv[1])) if len(sys.argv) > 1 else 1_000_000
 a, b = b"a", b"ab"
 while len(b) < N:
     a, b = b, b + a
-cases = {"a^N": b"a" * N, "(ab)^N/2": b"ab" * (N // 2), "(abc)^k x (abc)^k": b"abc" * (N // 6) + b"x" + b"abc" * (N // 6), "fibonacci": b[:N]}
+import numpy as np
+rng = np.random.default_rng(5)
+base = rng.integers(97, 123, N // 20, dtype=np.uint8)
+versions = []
+for _ in range(20):                                   # a versioned collection: 20 copies of one document with 0.2 % point edits each
+    v = base.copy()
+    idx = rng.integers(0, len(v), max(1, len(v) // 500))
+    v[idx] = rng.integers(97, 123, len(idx), dtype=np.uint8)
+    versions.append(v.tobytes())
+    base = v
+runs = b"".join(bytes([int(c)]) * int(l) for c, l in zip(rng.integers(97, 100, N // 50), rng.integers(1, 100, N // 50)))
+cases = {"a^N": b"a" * N, "(ab)^N/2": b"ab" * (N // 2), "(abc)^k x (abc)^k": b"abc" * (N // 6) + b"x" + b"abc" * (N // 6), "fibonacci": b[:N],
+         "20 versions": b"".join(versions), "random runs": runs[:N]}
 with T.Context(0) as ctx:
     for name, data in cases.items():
         text = O.escape(data)

@@ -31,6 +31,7 @@
 
 #include <algorithm>
 #include <map>
+#include <unordered_map>
 #include <chrono>
 #include <stdlib.h>
 #include <vector>
@@ -734,8 +735,11 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
     }
     if ((u64)maxlcp + 1 <= threshold || threshold == 0) { c.arena.release(mark); build_owner(c, n, fs); return; }   // ArraysComp.hpp:50
     const size_t nlev = (size_t)maxlcp + 2;
-    u32* d_segstart = c.arena.get<u32>(nlev);
-    u32* d_segend = c.arena.get<u32>(nlev);
+    // first / last candidate index per level (device copies only live from seg_bounds_kernel to the read-back: they share the
+    // memory of the push records of the general path; a text that is one long run has as many levels as positions)
+    u64* rkey = c.arena.get<u64>(n + 2);
+    u32* d_segstart = (u32*)rkey;
+    u32* d_segend = d_segstart + nlev;
     std::vector<u32> h_segstart(nlev), h_segend(nlev);
     int x = 0;
     size_t cand_count = 0;
@@ -774,7 +778,6 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
     u8* rc = c.arena.get<u8>(n);
     u32* pool = c.arena.get<u32>(n);            // pushed entries, grouped by (source level, target)
     u32* pushed = c.arena.get<u32>(n);
-    u64* rkey = c.arena.get<u64>(n);
     u32* rval = c.arena.get<u32>(n);
     u64* skeys[2] = { c.arena.get<u64>(n), c.arena.get<u64>(n) };
     u32* svals[2] = { c.arena.get<u32>(n), c.arena.get<u32>(n) };
@@ -795,7 +798,17 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
     GatherSeg* d_hgtab = nullptr;               // the same table as seen from the device (small levels read it in place)
     if (hipHostGetDevicePointer((void**)&d_hgtab, h_gtab, 0) != hipSuccess) { d_hgtab = nullptr; (void)hipGetLastError(); }
     struct PoolSeg { u32 off, cnt; };
-    std::vector<std::vector<PoolSeg>> pushed_into(nlev);     // per target level: its segments of the pool
+    struct LevelLists {                                      // per target level: its segments of the pool (sparse: most levels of a
+        std::unordered_map<u32, std::vector<PoolSeg>> m;     // text with long repeats never receive a push)
+        const std::vector<PoolSeg>& get(u32 lv) const {
+            static const std::vector<PoolSeg> none;
+            if (m.empty()) return none;
+            auto it = m.find(lv);
+            return it == m.end() ? none : it->second;
+        }
+        std::vector<PoolSeg>& operator[](u32 lv) { return m[lv]; }
+        void drop(u32 lv) { m.erase(lv); }
+    } pushed_into;
     size_t pool_top = 0;
     u32 prio_base = (u32)n;
 
@@ -859,7 +872,7 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
         }
         ++levels_since_purge;
         const bool trigger_stale = nolive_run >= stale_trigger;     // a run of levels without a live entry (erased or stale entries only)
-        if ((probe_dead && (pushed_into[L].empty() || dead_levels_run >= 8)) || trigger_stale) {
+        if ((probe_dead && (pushed_into.get(L).empty() || dead_levels_run >= 8)) || trigger_stale) {
             // the last level was completely erased: look how far down that goes.  Range: the levels below L (never past the
             // window cut) holding at most 4 Mi candidates; levels with pushed entries end the range -- unless a long run of
             // erased levels has been seen, then their pool segments are examined as well (texts like Fibonacci words leave
@@ -872,9 +885,10 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
             u32 Lb = L;
             size_t lo = (size_t)-1, hi = 0, cnt = 0;
             for (u32 v = L;; --v) {
-                if (!pushed_into[v].empty()) {
-                    if (v != L && (!deep || ptab.size() + pushed_into[v].size() > ((size_t)4 << 20))) break;
-                    for (const PoolSeg& sg : pushed_into[v]) ptab.push_back(ProbeSeg{sg.off, sg.cnt, v});
+                const std::vector<PoolSeg>& pv = pushed_into.get(v);
+                if (!pv.empty()) {
+                    if (v != L && (!deep || ptab.size() + pv.size() > ((size_t)4 << 20))) break;
+                    for (const PoolSeg& sg : pv) ptab.push_back(ProbeSeg{sg.off, sg.cnt, v});
                 }
                 if (h_segend[v] > h_segstart[v]) {
                     cnt += h_segend[v] - h_segstart[v];
@@ -955,7 +969,7 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
                             prio_base += R;
                             st->pushes += R;
                         }
-                        for (u32 v = L; v > floor_lv; --v) std::vector<PoolSeg>().swap(pushed_into[v]);
+                        for (const ProbeSeg& sg : ptab) if (sg.level > floor_lv) pushed_into.drop(sg.level);
                         c.arena.release(pmark);
                         st->levels += span;
                         stale_trigger = span >= 64 ? 8u : std::min<u32>(stale_trigger * 2, 4096u);
@@ -974,7 +988,7 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
         const u32 m0 = h_segend[L] - h_segstart[L];
         u32 m1 = 0;
         const auto hp0 = std::chrono::steady_clock::now();
-        const std::vector<PoolSeg>& segsL = pushed_into[L];
+        const std::vector<PoolSeg>& segsL = pushed_into.get(L);
         u32 m1_total = 0;
         for (const PoolSeg& sg : segsL) m1_total += sg.cnt;
         bool gathered = false;
@@ -1000,7 +1014,7 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
             gathered = true;
         };
         const u32 m = m0 + m1_total;
-        if (m == 0) { std::vector<PoolSeg>().swap(pushed_into[L]); continue; }
+        if (m == 0) { pushed_into.drop(L); continue; }
         st->levels++;
         if (m <= SMALL_RAW) {
             // ---- whole level in one workgroup: ONE launch (list read from the pool segments, result published into mapped
@@ -1039,7 +1053,7 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
                     apply_list_kernel<<<cdiv((size_t)h_sc.selected * 64, 256), 256, 0, s>>>(live, &d_sc->selected, L, n, phi, cur, fs.flen, fs.fsrc);
                     LAUNCH_CHECK();
                 }
-                std::vector<PoolSeg>().swap(pushed_into[L]);
+                pushed_into.drop(L);
                 st->small_levels++;
                 if (h_sc.nlive == 0) ++nolive_run; else nolive_run = 0;
                 if (h_sc.nlive == 0 && h_sc.nstale == 0) { probe_dead = true; ++dead_levels_run; continue; }   // small levels do not count for the purge heuristic
@@ -1064,7 +1078,7 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
             }
         }
         if (!gathered) gather_all();
-        std::vector<PoolSeg>().swap(pushed_into[L]);
+        pushed_into.drop(L);
         HIP_TRY(hipMemsetAsync(d_sc, 0, 8 * sizeof(u32), s));
         const unsigned gm = cdiv(m, 256);
         const bool mid = m <= (1u << 20);                    // few enough entries: unordered lists, fewer launches
@@ -1343,8 +1357,9 @@ void factorize_max_lcp(Ctx& c, size_t n, u32* isa, const u32* phi, u32* plcp, u3
     LAUNCH_CHECK();
     const int x = radix_sort_pairs_u32(c, ckeys, cvals, cand_count, 0, (int)bits_for(maxlcp));
     const size_t nlev = (size_t)maxlcp + 2;
-    u32* d_segstart = c.arena.get<u32>(nlev);
-    u32* d_segend = c.arena.get<u32>(nlev);
+    u64* skeys0 = c.arena.get<u64>(n + 2);                       // later the selection records; first the per-level candidate ranges
+    u32* d_segstart = (u32*)skeys0;
+    u32* d_segend = d_segstart + nlev;
     HIP_TRY(hipMemsetAsync(d_segstart, 0, nlev * sizeof(u32), s));
     HIP_TRY(hipMemsetAsync(d_segend, 0, nlev * sizeof(u32), s));
     seg_bounds_kernel<<<cdiv(cand_count, 256), 256, 0, s>>>(ckeys[x], cand_count, d_segstart, d_segend);
@@ -1364,7 +1379,7 @@ void factorize_max_lcp(Ctx& c, size_t n, u32* isa, const u32* phi, u32* plcp, u3
     const size_t bm_words = n / 32 + 2;
     u64* bm = c.arena.get<u64>(bm_words);
     HIP_TRY(hipMemsetAsync(bm, 0, bm_words * sizeof(u64), s));
-    u64* skeys[2] = { c.arena.get<u64>(n), c.arena.get<u64>(n) };     // selected (prio, pos) records, later the level's pushes
+    u64* skeys[2] = { skeys0, c.arena.get<u64>(n) };              // selected (prio, pos) records, later the level's pushes
     u32* svals[2] = { c.arena.get<u32>(n), c.arena.get<u32>(n) };
     const size_t pool_cap = 4 * n;
     u32* pool = c.arena.get<u32>(pool_cap);

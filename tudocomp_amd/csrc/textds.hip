@@ -51,9 +51,60 @@ constexpr int PLCP_HALO = 512;                    // text bytes staged beyond th
 // a global (data-dependent) read.
 // ALLOW_NONE: src[i] == NONE32 means "no source", result 0 (used by the lzss_lcp PSV/NSV sides, where the same
 // lower bound len[i] >= len[i-1] - 1 holds).
+// ---- sampled PLCP values, coarse to fine ----------------------------------------------------------------------------------
+// PLCP[i] >= PLCP[b] - (i - b) for b < i.  The positions 256 k are computed exactly, one wave each, in five levels of spacing
+// 2^24, 2^20, 2^16, 2^12, 2^8: a sample starts from the bound given by the next coarser sample to its left.  A peak of height H
+// is followed by at least H positions of ramp, so over all levels the comparisons that the bounds do not save add up to
+// O(n) bytes; the top level (at most 128 samples) compares from scratch, 512 bytes per step and wave.
+constexpr int PLCP_SAMPLE = 256;
+
+__device__ __forceinline__ u32 wave_lcp(const u8* __restrict__ text, size_t n, size_t i, size_t j, u32 l) {
+    const size_t lim = n - (i > j ? i : j);                   // the unique sentinel ends the comparison before either suffix leaves the text
+    const int lane = lane_id();
+    for (;;) {
+        const size_t off = (size_t)l + 8 * (size_t)lane;
+        const bool full = off + 8 <= lim;
+        u64 a = 0, b = 0;
+        if (full) { __builtin_memcpy(&a, text + i + off, 8); __builtin_memcpy(&b, text + j + off, 8); }
+        const u64 x = a ^ b;
+        const u64 bad = __ballot(!full || x != 0);
+        if (bad == 0) { l += 512; continue; }
+        const int f = __builtin_ctzll(bad);                    // first lane with a mismatch or a word that sticks out of the text
+        const u64 xf = __shfl(x, f);
+        const bool ff = __shfl((int)full, f) != 0;
+        l += 8 * (u32)f;
+        if (ff) return l + ((u32)__builtin_ctzll(xf) >> 3);
+        while ((size_t)l < lim && text[i + l] == text[j + l]) ++l;     // the last few bytes in front of the sentinel
+        return l;
+    }
+}
+
+__global__ __launch_bounds__(256) void plcp_sample_kernel(const u8* __restrict__ text, size_t n, const u32* __restrict__ phi,
+                                                           u32* __restrict__ samples, u32 nsamp, u32 step, u32 parent_step) {
+    const size_t w = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t k = w * step;
+    if (k >= nsamp) return;
+    if (parent_step && k % parent_step == 0) return;           // computed by a coarser level
+    const size_t i = k * PLCP_SAMPLE;
+    u32 l = 0;
+    if (i + 1 < n) {
+        if (parent_step) {
+            const size_t kb = k - k % parent_step;
+            const u64 d = (u64)(k - kb) * PLCP_SAMPLE;
+            const u32 sb = samples[kb];
+            l = sb > d ? (u32)(sb - d) : 0u;
+        }
+        l = wave_lcp(text, n, i, phi[i], l);
+    }
+    if (lane_id() == 0) samples[k] = l;
+}
+
+// `samples` (nullable): exact results of the positions 256 k (plcp_sample_kernel).  A chunk then starts from the lower bound
+// sample - distance instead of 0: without it every chunk start of a text like a^N walks the whole repeat again
+// (n * average LCP / 16 byte steps: 7 s for 16 MB of one letter).
 template <bool ALLOW_NONE>
 __global__ __launch_bounds__(256) void plcp_kernel(const u8* __restrict__ text, size_t n, const u32* __restrict__ phi,
-                                                    u32* __restrict__ plcp, u32* __restrict__ d_max) {
+                                                    u32* __restrict__ plcp, u32* __restrict__ d_max, const u32* __restrict__ samples) {
     __shared__ u32 sphi[256 * (PLCP_CHUNK + 1)];
     __shared__ u8 stext[PLCP_TILE + PLCP_HALO];
     const size_t base = (size_t)blockIdx.x * PLCP_TILE;
@@ -74,6 +125,11 @@ __global__ __launch_bounds__(256) void plcp_kernel(const u8* __restrict__ text, 
     const size_t begin = base + (size_t)threadIdx.x * PLCP_CHUNK;
     if (begin < n) {
         u32 l = 0;
+        if (samples) {
+            const size_t b = begin & ~(size_t)(PLCP_SAMPLE - 1);
+            const u32 sb = samples[b / PLCP_SAMPLE], d = (u32)(begin - b);
+            l = sb > d ? sb - d : 0u;                         // len[i] >= len[b] - (i - b)
+        }
         // the source side is read through ONE cached aligned 8-byte word: when Phi[i+1] = Phi[i] + 1 (the common case) the
         // comparison of position i+1 resumes at the very address where that of position i stopped, so the word is
         // reused instead of fetching the line again (with ~1800 threads per CU neither L1 nor L2 keeps it)
@@ -117,15 +173,32 @@ void build_plcp(Ctx& c, const u8* text, size_t n, const u32* phi, u32* plcp, u32
     HIP_TRY(hipMemsetAsync(d_maxlcp, 0, sizeof(u32), c.stream));
     if (!n) return;
     Ctx::ProfScope prof(c, K_PLCP, (u64)n * 10);                // Phi (4) + two text bytes + PLCP (4), SURVEY 8d
-    plcp_kernel<false><<<cdiv(n, PLCP_TILE), 256, 0, c.stream>>>(text, n, phi, plcp, d_maxlcp);
+    const size_t mark = c.arena.mark();
+    u32* samples = nullptr;
+    if (c.plcp_samples && n >= ((size_t)1 << 16)) {
+        const u32 nsamp = (u32)cdiv(n, PLCP_SAMPLE);
+        samples = c.arena.get<u32>(nsamp);
+        u32 parent = 0;
+        for (u32 step = 1u << 16; step >= 1; step >>= 4) {        // spacing 2^24 ... 2^8 text positions
+            if (step < nsamp || step == 1) {
+                const size_t waves = cdiv(nsamp, step);
+                plcp_sample_kernel<<<cdiv(waves * 64, 256), 256, 0, c.stream>>>(text, n, phi, samples, nsamp, step, parent);
+                LAUNCH_CHECK();
+                parent = step;
+            }
+            if (step == 1) break;
+        }
+    }
+    plcp_kernel<false><<<cdiv(n, PLCP_TILE), 256, 0, c.stream>>>(text, n, phi, plcp, d_maxlcp, samples);
     LAUNCH_CHECK();
+    c.arena.release(mark);
 }
 
 void build_lce_with_carry(Ctx& c, const u8* text, size_t n, const u32* src, u32* len, u32* d_max) {
     HIP_TRY(hipMemsetAsync(d_max, 0, sizeof(u32), c.stream));
     if (!n) return;
     Ctx::ProfScope prof(c, K_PLCP, (u64)n * 10);
-    plcp_kernel<true><<<cdiv(n, PLCP_TILE), 256, 0, c.stream>>>(text, n, src, len, d_max);
+    plcp_kernel<true><<<cdiv(n, PLCP_TILE), 256, 0, c.stream>>>(text, n, src, len, d_max, nullptr);
     LAUNCH_CHECK();
 }
 
