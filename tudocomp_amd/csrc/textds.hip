@@ -79,6 +79,7 @@ __device__ __forceinline__ u32 wave_lcp(const u8* __restrict__ text, size_t n, s
     }
 }
 
+template <bool ALLOW_NONE>
 __global__ __launch_bounds__(256) void plcp_sample_kernel(const u8* __restrict__ text, size_t n, const u32* __restrict__ phi,
                                                            u32* __restrict__ samples, u32 nsamp, u32 step, u32 parent_step) {
     const size_t w = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(256) void plcp_sample_kernel(const u8* __restrict__
     if (parent_step && k % parent_step == 0) return;           // computed by a coarser level
     const size_t i = k * PLCP_SAMPLE;
     u32 l = 0;
-    if (i + 1 < n) {
+    if (i + 1 < n && !(ALLOW_NONE && phi[i] == NONE32)) {     // no source: length 0 (the bound of such a position is never positive)
         if (parent_step) {
             const size_t kb = k - k % parent_step;
             const u64 d = (u64)(k - kb) * PLCP_SAMPLE;
@@ -169,26 +170,31 @@ __global__ __launch_bounds__(256) void plcp_kernel(const u8* __restrict__ text, 
     if (lane_id() == 0 && mx) atomicMax(d_max, mx);
 }
 
+// exact values at the positions 256 k, coarse to fine (nullptr for short texts or when switched off)
+template <bool ALLOW_NONE>
+static u32* plcp_samples(Ctx& c, const u8* text, size_t n, const u32* src) {
+    if (!c.plcp_samples || n < ((size_t)1 << 16)) return nullptr;
+    const u32 nsamp = (u32)cdiv(n, PLCP_SAMPLE);
+    u32* samples = c.arena.get<u32>(nsamp);
+    u32 parent = 0;
+    for (u32 step = 1u << 16; step >= 1; step >>= 4) {            // spacing 2^24 ... 2^8 text positions
+        if (step < nsamp || step == 1) {
+            const size_t waves = cdiv(nsamp, step);
+            plcp_sample_kernel<ALLOW_NONE><<<cdiv(waves * 64, 256), 256, 0, c.stream>>>(text, n, src, samples, nsamp, step, parent);
+            LAUNCH_CHECK();
+            parent = step;
+        }
+        if (step == 1) break;
+    }
+    return samples;
+}
+
 void build_plcp(Ctx& c, const u8* text, size_t n, const u32* phi, u32* plcp, u32* d_maxlcp) {
     HIP_TRY(hipMemsetAsync(d_maxlcp, 0, sizeof(u32), c.stream));
     if (!n) return;
     Ctx::ProfScope prof(c, K_PLCP, (u64)n * 10);                // Phi (4) + two text bytes + PLCP (4), SURVEY 8d
     const size_t mark = c.arena.mark();
-    u32* samples = nullptr;
-    if (c.plcp_samples && n >= ((size_t)1 << 16)) {
-        const u32 nsamp = (u32)cdiv(n, PLCP_SAMPLE);
-        samples = c.arena.get<u32>(nsamp);
-        u32 parent = 0;
-        for (u32 step = 1u << 16; step >= 1; step >>= 4) {        // spacing 2^24 ... 2^8 text positions
-            if (step < nsamp || step == 1) {
-                const size_t waves = cdiv(nsamp, step);
-                plcp_sample_kernel<<<cdiv(waves * 64, 256), 256, 0, c.stream>>>(text, n, phi, samples, nsamp, step, parent);
-                LAUNCH_CHECK();
-                parent = step;
-            }
-            if (step == 1) break;
-        }
-    }
+    u32* samples = plcp_samples<false>(c, text, n, phi);
     plcp_kernel<false><<<cdiv(n, PLCP_TILE), 256, 0, c.stream>>>(text, n, phi, plcp, d_maxlcp, samples);
     LAUNCH_CHECK();
     c.arena.release(mark);
@@ -198,8 +204,11 @@ void build_lce_with_carry(Ctx& c, const u8* text, size_t n, const u32* src, u32*
     HIP_TRY(hipMemsetAsync(d_max, 0, sizeof(u32), c.stream));
     if (!n) return;
     Ctx::ProfScope prof(c, K_PLCP, (u64)n * 10);
-    plcp_kernel<true><<<cdiv(n, PLCP_TILE), 256, 0, c.stream>>>(text, n, src, len, d_max, nullptr);
+    const size_t mark = c.arena.mark();
+    u32* samples = plcp_samples<true>(c, text, n, src);
+    plcp_kernel<true><<<cdiv(n, PLCP_TILE), 256, 0, c.stream>>>(text, n, src, len, d_max, samples);
     LAUNCH_CHECK();
+    c.arena.release(mark);
 }
 
 __global__ void lcp_kernel(const u32* __restrict__ sa, const u32* __restrict__ plcp, size_t n, u32* __restrict__ lcp) {
