@@ -52,11 +52,11 @@ constexpr int PLCP_HALO = 512;                    // text bytes staged beyond th
 // ALLOW_NONE: src[i] == NONE32 means "no source", result 0 (used by the lzss_lcp PSV/NSV sides, where the same
 // lower bound len[i] >= len[i-1] - 1 holds).
 // ---- sampled PLCP values, coarse to fine ----------------------------------------------------------------------------------
-// PLCP[i] >= PLCP[b] - (i - b) for b < i.  The positions 256 k are computed exactly, one wave each, in five levels of spacing
-// 2^24, 2^20, 2^16, 2^12, 2^8: a sample starts from the bound given by the next coarser sample to its left.  A peak of height H
+// PLCP[i] >= PLCP[b] - (i - b) for b < i.  The positions 1024 k are computed exactly, one wave each, in five levels of spacing
+// 2^26, 2^22, 2^18, 2^14, 2^10: a sample starts from the bound given by the next coarser sample to its left.  A peak of height H
 // is followed by at least H positions of ramp, so over all levels the comparisons that the bounds do not save add up to
-// O(n) bytes; the top level (at most 128 samples) compares from scratch, 512 bytes per step and wave.
-constexpr int PLCP_SAMPLE = 256;
+// O(n) bytes; the top level (at most 32 samples) compares from scratch, 512 bytes per step and wave.
+constexpr int PLCP_SAMPLE = 1024;
 
 __device__ __forceinline__ u32 wave_lcp(const u8* __restrict__ text, size_t n, size_t i, size_t j, u32 l) {
     const size_t lim = n - (i > j ? i : j);                   // the unique sentinel ends the comparison before either suffix leaves the text
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void plcp_sample_kernel(const u8* __restrict__
     if (lane_id() == 0) samples[k] = l;
 }
 
-// `samples` (nullable): exact results of the positions 256 k (plcp_sample_kernel).  A chunk then starts from the lower bound
+// `samples` (nullable): exact results of the positions 1024 k (plcp_sample_kernel).  A chunk then starts from the lower bound
 // sample - distance instead of 0: without it every chunk start of a text like a^N walks the whole repeat again
 // (n * average LCP / 16 byte steps: 7 s for 16 MB of one letter).
 template <bool ALLOW_NONE>
@@ -170,14 +170,14 @@ __global__ __launch_bounds__(256) void plcp_kernel(const u8* __restrict__ text, 
     if (lane_id() == 0 && mx) atomicMax(d_max, mx);
 }
 
-// exact values at the positions 256 k, coarse to fine (nullptr for short texts or when switched off)
+// exact values at the positions 1024 k, coarse to fine (nullptr for short texts or when switched off)
 template <bool ALLOW_NONE>
 static u32* plcp_samples(Ctx& c, const u8* text, size_t n, const u32* src) {
     if (!c.plcp_samples || n < ((size_t)1 << 16)) return nullptr;
     const u32 nsamp = (u32)cdiv(n, PLCP_SAMPLE);
     u32* samples = c.arena.get<u32>(nsamp);
     u32 parent = 0;
-    for (u32 step = 1u << 16; step >= 1; step >>= 4) {            // spacing 2^24 ... 2^8 text positions
+    for (u32 step = 1u << 16; step >= 1; step >>= 4) {            // spacing 2^26 ... 2^10 text positions
         if (step < nsamp || step == 1) {
             const size_t waves = cdiv(nsamp, step);
             plcp_sample_kernel<ALLOW_NONE><<<cdiv(waves * 64, 256), 256, 0, c.stream>>>(text, n, src, samples, nsamp, step, parent);
