@@ -160,9 +160,12 @@ def test_extreme_repeat_structure(gpu_ctx):
     while len(b) < N:
         a, b = b, b + a
     cases = {"a^N": b"a" * N, "(ab)^N/2": b"ab" * (N // 2), "(abc)^k x (abc)^k": b"abc" * (N // 6) + b"x" + b"abc" * (N // 6),
-             "fibonacci": b[:N]}
+             "fibonacci": b[:N], "x a^N": b"x" + b"a" * N, "a^N x a^N y": b"a" * N + b"x" + b"a" * N + b"y"}
     for name, data in cases.items():
         text = O.escape(data)
+        t0 = time.time()
+        got, _ = gpu_ctx.lzss_lcp_compress(text, 3)                     # the LCE passes share the PLCP kernels
+        assert got == O.lzss_lcp_huff_compress(text, 3)[0] and time.time() - t0 < 1.5, name
         for comp, fn in ((T.COMP_ARRAYS, O.lcpcomp_huff_compress), (T.COMP_MAXLCP, O.lcpcomp_maxlcp_huff_compress)):
             for thr in (2, 5):
                 t0 = time.time()

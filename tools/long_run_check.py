@@ -6,7 +6,8 @@ import tudocomp_amd as T
 from oracle import oracle as O
 
 for N in [int(float(a)) for a in sys.argv[1:]] or [4_000_000]:
-    for name, data in (("a^N", b"a" * N), ("(ab)^N/2", b"ab" * (N // 2))):
+    for name, data in (("a^N", b"a" * N), ("(ab)^N/2", b"ab" * (N // 2)), ("x a^N (a jump right behind position 0)", b"x" + b"a" * (N - 1)),
+                       ("a^N/2 x a^N/2", b"a" * (N // 2) + b"x" + b"a" * (N // 2))):
         text = O.escape(data)
         with T.Context(0) as ctx:
             try:

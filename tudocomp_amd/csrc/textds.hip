@@ -100,12 +100,46 @@ __global__ __launch_bounds__(256) void plcp_sample_kernel(const u8* __restrict__
     if (lane_id() == 0) samples[k] = l;
 }
 
+// The bounds are loose behind a jump (len[b] small, len[b+1] huge: the position behind a mismatching byte in front of a long
+// repeat, or behind a position without source in the lzss_lcp passes): the one thread that owns the jump would walk the whole
+// repeat byte by byte (250 ns per dependent load), and so would every later chunk start of that sample interval.  An interval
+// [1024 k, 1024 (k+1)) can only hide a jump of more than 2048 if S[k+1] > S[k] + 1024 (values fall by at most one per
+// position); those intervals -- and the last, open one -- are computed here, position by position with the carry, one wave per
+// interval and 512 bytes per step; plcp_kernel then only copies them.
+template <bool ALLOW_NONE>
+__global__ __launch_bounds__(256) void plcp_refine_kernel(const u8* __restrict__ text, size_t n, const u32* __restrict__ src,
+                                                           const u32* __restrict__ samples, u32 nsamp, u32* __restrict__ out,
+                                                           u8* __restrict__ iflag, u32* __restrict__ d_max) {
+    const size_t k = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (k >= nsamp) return;
+    const u32 s0 = samples[k];
+    if (k + 1 < nsamp && samples[k + 1] <= s0 + PLCP_SAMPLE) { if (lane_id() == 0) iflag[k] = 0; return; }
+    const size_t b = k * PLCP_SAMPLE;
+    u32 l = s0, mx = s0;
+    if (lane_id() == 0) { iflag[k] = 1; out[b] = s0; }
+    for (int t = 1; t < PLCP_SAMPLE; ++t) {
+        const size_t i = b + (size_t)t;
+        if (i >= n) break;
+        if (l) --l;
+        if (i + 1 >= n) l = 0;
+        else {
+            const u32 j = src[i];
+            if (ALLOW_NONE && j == NONE32) l = 0;
+            else l = wave_lcp(text, n, i, j, l);
+        }
+        if (lane_id() == 0) out[i] = l;
+        mx = max(mx, l);
+    }
+    if (lane_id() == 0 && mx) atomicMax(d_max, mx);
+}
+
 // `samples` (nullable): exact results of the positions 1024 k (plcp_sample_kernel).  A chunk then starts from the lower bound
 // sample - distance instead of 0: without it every chunk start of a text like a^N walks the whole repeat again
 // (n * average LCP / 16 byte steps: 7 s for 16 MB of one letter).
 template <bool ALLOW_NONE>
 __global__ __launch_bounds__(256) void plcp_kernel(const u8* __restrict__ text, size_t n, const u32* __restrict__ phi,
-                                                    u32* __restrict__ plcp, u32* __restrict__ d_max, const u32* __restrict__ samples) {
+                                                    u32* __restrict__ plcp, u32* __restrict__ d_max, const u32* __restrict__ samples,
+                                                    const u8* __restrict__ iflag) {
     __shared__ u32 sphi[256 * (PLCP_CHUNK + 1)];
     __shared__ u8 stext[PLCP_TILE + PLCP_HALO];
     const size_t base = (size_t)blockIdx.x * PLCP_TILE;
@@ -124,7 +158,9 @@ __global__ __launch_bounds__(256) void plcp_kernel(const u8* __restrict__ text, 
     u32 mx = 0;
     u32* row = sphi + threadIdx.x * (PLCP_CHUNK + 1);
     const size_t begin = base + (size_t)threadIdx.x * PLCP_CHUNK;
-    if (begin < n) {
+    if (begin < n && samples && iflag[begin / PLCP_SAMPLE]) {
+        for (int c = 0; c < PLCP_CHUNK && begin + c < n; ++c) { row[c] = plcp[begin + c]; }     // computed by plcp_refine_kernel (its maximum too)
+    } else if (begin < n) {
         u32 l = 0;
         if (samples) {
             const size_t b = begin & ~(size_t)(PLCP_SAMPLE - 1);
@@ -170,9 +206,11 @@ __global__ __launch_bounds__(256) void plcp_kernel(const u8* __restrict__ text, 
     if (lane_id() == 0 && mx) atomicMax(d_max, mx);
 }
 
-// exact values at the positions 1024 k, coarse to fine (nullptr for short texts or when switched off)
+// exact values at the positions 1024 k, coarse to fine; the intervals that hide a jump are computed completely (into `out`)
+// (nullptr for short texts or when switched off)
 template <bool ALLOW_NONE>
-static u32* plcp_samples(Ctx& c, const u8* text, size_t n, const u32* src) {
+static u32* plcp_samples(Ctx& c, const u8* text, size_t n, const u32* src, u32* out, u32* d_max, u8** iflag_out) {
+    *iflag_out = nullptr;
     if (!c.plcp_samples || n < ((size_t)1 << 16)) return nullptr;
     const u32 nsamp = (u32)cdiv(n, PLCP_SAMPLE);
     u32* samples = c.arena.get<u32>(nsamp);
@@ -186,6 +224,10 @@ static u32* plcp_samples(Ctx& c, const u8* text, size_t n, const u32* src) {
         }
         if (step == 1) break;
     }
+    u8* iflag = c.arena.get<u8>(nsamp);
+    plcp_refine_kernel<ALLOW_NONE><<<cdiv((size_t)nsamp * 64, 256), 256, 0, c.stream>>>(text, n, src, samples, nsamp, out, iflag, d_max);
+    LAUNCH_CHECK();
+    *iflag_out = iflag;
     return samples;
 }
 
@@ -194,8 +236,9 @@ void build_plcp(Ctx& c, const u8* text, size_t n, const u32* phi, u32* plcp, u32
     if (!n) return;
     Ctx::ProfScope prof(c, K_PLCP, (u64)n * 10);                // Phi (4) + two text bytes + PLCP (4), SURVEY 8d
     const size_t mark = c.arena.mark();
-    u32* samples = plcp_samples<false>(c, text, n, phi);
-    plcp_kernel<false><<<cdiv(n, PLCP_TILE), 256, 0, c.stream>>>(text, n, phi, plcp, d_maxlcp, samples);
+    u8* iflag = nullptr;
+    u32* samples = plcp_samples<false>(c, text, n, phi, plcp, d_maxlcp, &iflag);
+    plcp_kernel<false><<<cdiv(n, PLCP_TILE), 256, 0, c.stream>>>(text, n, phi, plcp, d_maxlcp, samples, iflag);
     LAUNCH_CHECK();
     c.arena.release(mark);
 }
@@ -205,8 +248,9 @@ void build_lce_with_carry(Ctx& c, const u8* text, size_t n, const u32* src, u32*
     if (!n) return;
     Ctx::ProfScope prof(c, K_PLCP, (u64)n * 10);
     const size_t mark = c.arena.mark();
-    u32* samples = plcp_samples<true>(c, text, n, src);
-    plcp_kernel<true><<<cdiv(n, PLCP_TILE), 256, 0, c.stream>>>(text, n, src, len, d_max, samples);
+    u8* iflag = nullptr;
+    u32* samples = plcp_samples<true>(c, text, n, src, len, d_max, &iflag);
+    plcp_kernel<true><<<cdiv(n, PLCP_TILE), 256, 0, c.stream>>>(text, n, src, len, d_max, samples, iflag);
     LAUNCH_CHECK();
     c.arena.release(mark);
 }
