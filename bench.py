@@ -1,19 +1,27 @@
 #!/usr/bin/env python3
-"""bench.py -- input MB/s of lcpcomp(coder=huff) on MI355X (BASELINE.json metric).
+"""bench.py -- input MB/s of lcpcomp(coder=huff) on MI355X, END TO END (BASELINE.json metric).
 
-A "step" is one pass of the hot path (suffix array -> ISA/Phi/PLCP -> ArraysComp factorization -> flatten ->
-Huffman bit-pack) over one batch of synthetic text that is already resident in HBM.
+A "step" is one pass of the hot path over one batch of synthetic text: pinned host text -> H2D -> suffix array ->
+ISA/Phi/PLCP -> ArraysComp factorization -> flatten -> host Huffman table -> bit-pack -> D2H -> compressed bytes in pinned
+host memory.  Both transfers are INSIDE the timed region; `value` = input bytes / wall time.
 
-  N = 1 : BASELINE.json configs[1] -- 256 MiB English-like text (SURVEY.md 8d generator, seed 42), threshold 2.
-  N > 1 : one process per GPU (torch.distributed, backend nccl = RCCL); every rank compresses its own shard
-          (seed 42 + rank, same size: weak scaling) and the per-shard streams are gathered on rank 0 over xGMI
-          into the block container.  value = bytes of all ranks / max-over-ranks time.
+  N = 1 : the configuration the metric is quoted on: 2*10^9 B English-like text (SURVEY.md 8d generator, seed 42),
+          threshold 2, flatten 1, through the product's entry point tdc_gpu_lcpcomp_compress_into.
+          Extra keys (never `value`): "hbm_resident" = the same steps without the two transfers (device time of the
+          same calls), "configs1_256MiB" = BASELINE.json configs[1] (256 MiB) through the same entry point.
+  N > 1 : BASELINE.json configs[4]: one process per GPU (torch.distributed, backend nccl = RCCL); every rank compresses
+          its own 2*10^9 B shard (seed 42 + rank: weak scaling), the per-shard streams are gathered on rank 0 over xGMI
+          (grouped point-to-point) and rank 0 copies the block container to its host memory.
+          value = bytes of all ranks / max-over-ranks time.
 
-Prints ONE JSON line (rank 0).  PyTorch is used for device memory and torch.distributed only.
+After the timed steps ONE more step runs with per-kernel HIP-event timing switched on (untimed) -- the roofline object and
+the per-kernel table come from it.  Prints ONE JSON line (rank 0).  PyTorch is used for torch.distributed and the
+multi-GPU staging buffers only.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -22,6 +30,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+STAT_KEYS = ("out_len", "factors", "maxlcp", "num_flattened", "sa_rounds", "levels", "mis_rounds", "flatten_rounds", "pushes",
+             "arena_bytes", "sa_sorted_elems", "sa_init_syms", "small_levels", "purges", "window_pass", "window_lcut")
 
 
 def parse_args():
@@ -29,42 +39,110 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--size", type=int, default=1 << 28, help="input bytes per GPU (default 256 MiB = configs[1])")
+    ap.add_argument("--size", type=int, default=2_000_000_000, help="input bytes per GPU (default 2*10^9: the metric's text / one shard of configs[4])")
     ap.add_argument("--threshold", type=int, default=2)
     ap.add_argument("--gen", default="english", choices=["english", "dna"])
-    ap.add_argument("--cpu-sample", type=int, default=1 << 26, help="bytes of the workload the CPU baseline is timed on")
+    ap.add_argument("--cpu-sample", type=int, default=1 << 26, help="bytes of the workload the single-core CPU baseline is timed on")
+    ap.add_argument("--cpu-multi-sample", type=int, default=1 << 25, help="bytes per process of the multi-core CPU figure")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the 256 MiB extra figure")
     return ap.parse_args()
 
 
-def cpu_baseline(args, text_np, gpu_prefix_stream):
-    """The oracle (bit-exact CPU port of the reference path), one core, on a bounded prefix of the workload."""
-    from oracle import oracle as O
-    import numpy as np
-    m = min(args.cpu_sample, len(text_np) - 1)
-    sample = np.concatenate([text_np[:m], np.zeros(1, dtype=np.uint8)])
+# ---- CPU baseline: runs BEFORE this process touches the GPU (child processes are plain CPU programs) -------------------------
+_CPU_CHILD = r"""
+import sys, time, hashlib
+sys.path.insert(0, %r)
+import numpy as np
+import tudocomp_amd as T
+from oracle import oracle as O
+gen, seed, m, thr = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+text = (T.gen_english if gen == "english" else T.gen_dna)(m, seed)
+sample = np.concatenate([text, np.zeros(1, dtype=np.uint8)])
+t0 = time.perf_counter()
+out, st = O.lcpcomp_huff_compress(sample, thr, 1)
+dt = time.perf_counter() - t0
+print("%%.6f %%d %%s" %% (dt, len(out), hashlib.sha256(out).hexdigest()))
+"""
+
+
+def cpu_info():
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    flags = "gcc -O2 (oracle/Makefile)"
+    try:
+        for line in open(os.path.join(ROOT, "oracle", "Makefile")):
+            if line.strip().startswith("CFLAGS"):
+                flags = "gcc " + line.split("=", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return model, flags
+
+
+def cpu_baseline(args, seed):
+    """The oracle (bit-exact CPU port of the reference path).  (i) one core on the first --cpu-sample bytes of the workload
+    text (the generator's output for a shorter length is a prefix of the longer one); (ii) min(cores, 16) processes on
+    independent shards (seed + k) of --cpu-multi-sample bytes each."""
+    code = _CPU_CHILD % ROOT
+    m1 = min(args.cpu_sample, args.size)
+
+    def run(gen_seed, m):
+        return subprocess.Popen([sys.executable, "-c", code, args.gen, str(gen_seed), str(m), str(args.threshold)],
+                                stdout=subprocess.PIPE, text=True)
+
+    p = run(seed, m1)
+    dt1, len1, sha1 = p.communicate()[0].split()
+    if p.returncode:
+        raise RuntimeError("cpu baseline child failed")
+    dt1 = float(dt1)
+    model, flags = cpu_info()
+    res = {"value": round(m1 / 1e6 / dt1, 3), "unit": "MB/s", "cores": 1, "kind": "port",
+           "sample": "first %d bytes of the workload text, lcpcomp(coder=huff,threshold=%d,flatten=1), %.1f s" % (m1, args.threshold, dt1),
+           "cpu_model": model, "compiler_flags": flags, "host_cores": os.cpu_count()}
+    procs = max(1, min(os.cpu_count() or 1, 16))
+    m2 = min(args.cpu_multi_sample, args.size)
     t0 = time.perf_counter()
-    out, st = O.lcpcomp_huff_compress(sample, args.threshold, 1)
-    dt = time.perf_counter() - t0
-    res = {"value": round(m / 1e6 / dt, 3), "unit": "MB/s", "cores": 1, "kind": "port",
-           "sample": "first %d bytes of the workload text, lcpcomp(coder=huff,threshold=%d,flatten=1), %.1f s" % (m, args.threshold, dt)}
-    if gpu_prefix_stream is not None:
-        res["bit_exact_vs_gpu_on_sample"] = bool(out == gpu_prefix_stream)
-    return res
+    ps = [run(seed + 1000 + k, m2) for k in range(procs)]
+    ok = all(q.communicate()[0] and q.returncode == 0 for q in ps)
+    dtm = time.perf_counter() - t0
+    if ok:
+        res["multi_core"] = {"value": round(procs * m2 / 1e6 / dtm, 3), "unit": "MB/s", "cores": procs,
+                             "sample": "%d processes x %d-byte independent shards (seeds %d..), wall %.1f s incl. process start + text generation"
+                                       % (procs, m2, seed + 1000, dtm)}
+    return res, (m1, int(len1), sha1)
 
 
 def main():
     args = parse_args()
-    import numpy as np
-    import torch
-    import tudocomp_amd as T
-    from tudocomp_amd.blocks import gather_streams
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d needs torchrun with %d processes (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
+    N = args.size
+    n = N + 1                                            # generators emit no 0x00 / 0xFF: text = data + sentinel
+    if n >= 0x7FFFFFFF:
+        raise SystemExit("--size must stay below 2^31 - 2 (32-bit len_t of the reference)")
+    seed0 = 42 if args.gen == "english" else 7
+    seed = seed0 + rank
+
+    cpu_res = cpu_ref = None
+    if world == 1 and not args.no_cpu_baseline:
+        cpu_res, cpu_ref = cpu_baseline(args, seed)      # before any GPU initialisation in this process
+
+    import hashlib
+    import numpy as np
+    import torch
+    import tudocomp_amd as T
+    from tudocomp_amd.blocks import gather_streams, MAGIC
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -75,24 +153,38 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=device)
 
-    # ---- synthetic input, resident in HBM before the timed region ------------------------------------------
-    N = args.size
+    # ---- synthetic input in pinned host memory ---------------------------------------------------------------------------
     gen = T.gen_english if args.gen == "english" else T.gen_dna
-    seed = (42 if args.gen == "english" else 7) + rank
-    text_np = np.concatenate([gen(N, seed), np.zeros(1, dtype=np.uint8)])     # generators emit no 0x00 / 0xFF: n = N + 1
-    n = len(text_np)
-    d_text = torch.from_numpy(text_np).to(device)
+    h_text = T.PinnedBuffer(n)
+    gen(N, seed, out=h_text.a)
+    h_text.a[N] = 0
     ctx = T.Context(local_rank)
     ctx.reserve(n)
-    cap = ctx.bound(n)
-    d_out = torch.empty(cap, dtype=torch.uint8, device=device)
-    torch.cuda.synchronize()
+    out_cap = N + (1 << 20)                               # the stream of these texts is < 0.5 N; a larger one fails loudly
+    h_out = T.PinnedBuffer(out_cap)
+
+    d_text = d_out = h_container = None
+    if world > 1:                                         # multi-GPU staging: HBM text / stream buffers for the RCCL gather
+        t_text = torch.from_numpy(h_text.a)
+        d_text = torch.empty(n, dtype=torch.uint8, device=device)
+        d_out = torch.empty(out_cap, dtype=torch.uint8, device=device)
+        if rank == 0:
+            h_container = torch.empty(world * out_cap // 2 + 4096, dtype=torch.uint8).pin_memory()
 
     def step():
-        out_len, st = ctx.lcpcomp_compress_dev(d_text.data_ptr(), n, d_out.data_ptr(), cap, args.threshold, 1)
-        sizes = None
-        if world > 1:
-            sizes, _ = gather_streams(dist, torch, d_out, out_len, rank, world, device)
+        if world == 1:
+            out_len, st = ctx.lcpcomp_compress_into(h_text, n, h_out, args.threshold, 1)
+            return out_len, st, None
+        d_text.copy_(t_text, non_blocking=True)           # H2D of this rank's shard
+        torch.cuda.synchronize()                          # the library runs on its own stream (include/tdc_gpu.h)
+        out_len, st = ctx.lcpcomp_compress_dev(d_text.data_ptr(), n, d_out.data_ptr(), out_cap, args.threshold, 1)
+        sizes, bufs = gather_streams(dist, torch, d_out, out_len, rank, world, device)
+        if rank == 0:                                     # block container -> host memory of rank 0
+            off = len(MAGIC) + 4 + 16 * world
+            for b in bufs:
+                h_container[off:off + b.numel()].copy_(b, non_blocking=True)
+                off += b.numel()
+            torch.cuda.synchronize()
         return out_len, st, sizes
 
     def fence():
@@ -102,74 +194,110 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    ctx.set_profiling(True)
-    ctx.reset_profile()
     fence()
     t0 = time.perf_counter()
+    dev_ms = []
     for _ in range(args.steps):
         out_len, st, sizes = step()
+        dev_ms.append((st["ms_total"], st["ms_h2d"], st["ms_d2h"]))
     fence()
     dt = time.perf_counter() - t0
-    prof = ctx.kernel_profile()
-    ctx.set_profiling(False)
+    ranks_seen = world
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+        bitmap = torch.tensor([1 << rank], dtype=torch.int64, device=device)
+        dist.all_reduce(bitmap, op=dist.ReduceOp.SUM)
+        ranks_seen = bin(int(bitmap.item())).count("1")
+
+    # ---- one more step with per-kernel timing (untimed): roofline + kernel table ----------------------------------------------
+    ctx.set_profiling(True)
+    ctx.reset_profile()
+    _, st_prof, _ = step()
+    prof = ctx.kernel_profile()
+    ctx.set_profiling(False)
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = world * N / 1e6 / (dt / args.steps)
-        # dominant kernel = the instrumented kernel class with the largest summed launch time in the timed region
         DOMINANT = max(prof, key=lambda name: prof[name]["ms"]) if prof else None
         k = prof.get(DOMINANT, {"ms": 0.0, "launches": 0, "bytes": 0})
         roof = None
         if k["launches"]:
             achieved = k["bytes"] / (k["ms"] * 1e-3) / 1e9
-            traffic = None
+            traffic, traffic_src = None, None
             pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
             if os.path.exists(pmc):
                 try:
                     j = json.load(open(pmc))
                     if j.get("workload_bytes") == N and j.get("kernel") == DOMINANT:
                         traffic = j.get("hbm_bytes_per_launch")
+                        traffic_src = "static: %s (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of this workload, not measured in this run)" % j.get("source", "profiles/pmc_summary.json")
                 except Exception:
                     traffic = None
             roof = {"bound": "hbm", "kernel": DOMINANT, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "launches_per_step": k["launches"] / args.steps,
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                    "launches_per_step": k["launches"],
                     "avg_launch_ms": round(k["ms"] / k["launches"], 4),
                     "algorithmic_bytes_per_launch": round(k["bytes"] / k["launches"]),
-                    "share_of_step": round(k["ms"] / args.steps / ms_per_step, 3)}
+                    "share_of_device_time": round(k["ms"] / st_prof["ms_total"], 3) if st_prof["ms_total"] else None,
+                    "timing": "HIP events on the library's stream around every launch, one profiled step after the timed region"}
         c_ratio = out_len / N
         z = st["factors"]
         b_alg = 44 + c_ratio + 48 * z / N
-        dev_ms = st["ms_total"]
+        tot = sum(d[0] for d in dev_ms) / len(dev_ms)
+        h2d = sum(d[1] for d in dev_ms) / len(dev_ms)
+        d2h = sum(d[2] for d in dev_ms) / len(dev_ms)
+        kern_ms = tot - h2d - d2h if world == 1 else tot
+        if world == 1:
+            workload = ("lcpcomp(coder=huff,threshold=%d,flatten=1,comp=arrays) on %d B %s text (SURVEY 8d generator, seed %d): "
+                        "pinned host text -> H2D -> kernels + host Huffman table -> D2H -> stream in pinned host memory, all timed"
+                        % (args.threshold, N, args.gen, seed0))
+        else:
+            workload = ("BASELINE configs[4]: %d independent %d B %s shards (seeds %d+rank), per-shard lcpcomp(coder=huff,threshold=%d,flatten=1); "
+                        "H2D + kernels + RCCL gather of the streams to rank 0 + D2H of the block container, all timed"
+                        % (world, N, args.gen, seed0, args.threshold))
         line = {
             "metric": "input MB/s end-to-end lcpcomp+huffman",
             "value": round(value, 2), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "lcpcomp(coder=huff,threshold=%d,flatten=1,comp=arrays) on %d B %s text per GPU "
-                                   "(SURVEY 8d generator, seed %d+rank), resident in HBM" % (args.threshold, N, args.gen, seed - rank),
-                       "bytes_per_gpu": N, "parallelism": "independent shards x%d + RCCL gather to rank 0" % world if world > 1 else "single GPU"},
+            "config": {"workload": workload, "bytes_per_gpu": N,
+                       "parallelism": "independent shards x%d + RCCL gather to rank 0" % world if world > 1 else "single GPU"},
             "roofline": roof,
-            "pipeline": {"B_alg_bytes_per_input_byte": round(b_alg, 2), "achieved_GBs": round(b_alg * N / (dev_ms * 1e-3) / 1e9, 1),
-                         "frac_of_hbm_peak": round(b_alg * N / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+            "hbm_resident": {"value": round(N / 1e6 / (kern_ms * 1e-3), 2), "unit": "MB/s", "ms_per_step": round(kern_ms, 3),
+                             "note": "same steps, device time without the H2D / D2H transfers (per GPU)"},
+            "pipeline": {"B_alg_bytes_per_input_byte": round(b_alg, 2), "achieved_GBs": round(b_alg * N / (kern_ms * 1e-3) / 1e9, 1),
+                         "frac_of_hbm_peak": round(b_alg * N / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
             "stages_ms": {k2[3:]: round(v, 2) for k2, v in st.items() if k2.startswith("ms_")},
-            "stats": {k2: st[k2] for k2 in ("out_len", "factors", "maxlcp", "num_flattened", "sa_rounds", "levels", "mis_rounds",
-                                            "flatten_rounds", "pushes", "arena_bytes", "sa_sorted_elems", "sa_init_syms", "small_levels", "purges", "window_pass", "window_lcut")},
-            "kernels": {name: {"ms_per_step": round(p["ms"] / args.steps, 3), "launches_per_step": p["launches"] / args.steps,
+            "stats": {k2: st[k2] for k2 in STAT_KEYS},
+            "kernels": {name: {"ms_per_step": round(p["ms"], 3), "launches_per_step": p["launches"],
                                "algorithmic_GBs": round(p["bytes"] / (p["ms"] * 1e-3) / 1e9, 1) if p["ms"] > 0 else None}
                         for name, p in prof.items() if p["launches"]},
         }
-        if sizes is not None:
+        if world > 1:
+            line["ranks_seen"] = ranks_seen
+            line["world_size"] = dist.get_world_size()
             line["gathered_bytes"] = sum(sizes)
-        if world == 1 and not args.no_cpu_baseline:
-            m = min(args.cpu_sample, N)
-            sample = np.concatenate([text_np[:m], np.zeros(1, dtype=np.uint8)])
+        if cpu_res is not None:
+            m1, want_len, want_sha = cpu_ref
+            sample = np.concatenate([h_text.a[:m1], np.zeros(1, dtype=np.uint8)])
             gpu_prefix, _ = ctx.lcpcomp_compress(sample, args.threshold, 1)
-            line["cpu_baseline"] = cpu_baseline(args, text_np, gpu_prefix)
+            cpu_res["bit_exact_vs_gpu_on_sample"] = bool(len(gpu_prefix) == want_len and hashlib.sha256(gpu_prefix).hexdigest() == want_sha)
+            line["cpu_baseline"] = cpu_res
+        if world == 1 and not args.no_extra and N > (1 << 28):
+            m = 1 << 28
+            h_text.a[m] = 0                               # the first 256 MiB of the generator's output ARE its 256 MiB text
+            ts = []
+            for i in range(4):
+                t1 = time.perf_counter()
+                ol2, st2 = ctx.lcpcomp_compress_into(h_text, m + 1, h_out, args.threshold, 1)
+                ts.append(time.perf_counter() - t1)
+            t = sum(ts[1:]) / 3
+            line["configs1_256MiB"] = {"value": round(m / 1e6 / t, 2), "unit": "MB/s", "ms_per_step": round(t * 1e3, 3),
+                                       "device_only_ms": round(st2["ms_total"] - st2["ms_h2d"] - st2["ms_d2h"], 3), "out_len": ol2,
+                                       "note": "BASELINE configs[1] through the same end-to-end entry point, 3 steps after 1 warm-up"}
         print(json.dumps(line))
     ctx.close()
     if world > 1:

@@ -12,6 +12,7 @@
  *   - every function returns 0 on success or a negative tdc_gpu_status; tdc_gpu_strerror() explains it.
  *   - host output buffers returned through `uint8_t** out` are malloc'd by the library: free with tdc_gpu_free().
  *   - a context owns one HIP stream and one device arena on one GPU; it is not thread-safe, use one per thread.
+ *     Every call switches the calling thread to the context's device and restores the previous current device on return.
  *     The library NEVER falls back to a CPU path: without a usable GPU every compute call fails with TDC_GPU_ERR_HIP.
  */
 #ifndef TDC_GPU_H
@@ -106,16 +107,31 @@ int tdc_gpu_lcpcomp_compress(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, ui
 int tdc_gpu_lcpcomp_compress_comp(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, uint32_t threshold, int flatten, int coder,
                                   int comp, uint8_t** out, size_t* out_len, tdc_gpu_stats* stats);
 
+/* The metric's entry point (pinned host text -> compressed bytes in host memory): the same as
+ * tdc_gpu_lcpcomp_compress_comp, but the stream is written into the CALLER's buffer `out` of out_cap bytes (no allocation
+ * in the call).  *out_len receives the stream length; if it exceeds out_cap the call fails with TDC_GPU_ERR_OOM and *out_len
+ * holds the required size.  `text` and `out` should be pinned host memory (tdc_gpu_host_alloc, or hipHostMalloc /
+ * hipHostRegister by the embedding program): the two transfers then run at PCIe rate; pageable memory works but is staged
+ * by the runtime.  stats->ms_h2d / ms_d2h / ms_total cover the transfers. */
+int tdc_gpu_lcpcomp_compress_into(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, uint32_t threshold, int flatten, int coder,
+                                  int comp, uint8_t* out, size_t out_cap, size_t* out_len, tdc_gpu_stats* stats);
+/* Pinned (page-locked) host memory for the buffers above; NULL on failure.  Free with tdc_gpu_host_free. */
+void* tdc_gpu_host_alloc(size_t bytes);
+void  tdc_gpu_host_free(void* p);
+
 /* Raw input variant: `data`/`n` is the UNRESTRICTED input (any bytes, no sentinel).  The library applies the
  * compressor's input restrictions on the device -- escape {0} + null-terminate, i.e. what Input(inp, restrictions) does
  * in tudocomp_driver.cpp:268-270 (io/RestrictedBuffer.hpp:43-74) -- and then compresses.  n < 2^30. */
 int tdc_gpu_lcpcomp_compress_raw(tdc_gpu_ctx* ctx, const uint8_t* data, size_t n, uint32_t threshold, int flatten,
                                  int coder, uint8_t** out, size_t* out_len, tdc_gpu_stats* stats);
 /* Device-resident variant: d_text and d_out are device pointers on ctx's GPU (d_out 8-byte aligned, capacity out_cap
- * bytes; tdc_gpu_lcpcomp_bound(n) always suffices).  Used by bench.py (inputs resident in HBM). */
+ * bytes; tdc_gpu_lcpcomp_bound_coder(n, coder) always suffices -- tdc_gpu_lcpcomp_bound(n) is that bound for huff and
+ * arithmetic; ascii needs twice as much).  The call runs on the context's own stream: the caller must have finished
+ * (synchronised) whatever produced d_text before calling, and the stream is synchronised before the call returns. */
 int tdc_gpu_lcpcomp_compress_dev(tdc_gpu_ctx* ctx, const void* d_text, size_t n, uint32_t threshold, int flatten,
                                  int coder, void* d_out, size_t out_cap, size_t* out_len, tdc_gpu_stats* stats);
 size_t tdc_gpu_lcpcomp_bound(size_t n);
+size_t tdc_gpu_lcpcomp_bound_coder(size_t n, int coder);     /* 0 for an unknown coder */
 
 /* ---- LZ78 (BASELINE.json configs[3]): replaces LZ78Compressor<EliasGammaCoder, ...>::compress
  * (compressors/LZ78Compressor.hpp:64-140).  No input restrictions (no escaping, no sentinel).  The parse is sequential

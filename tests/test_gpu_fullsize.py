@@ -1,0 +1,113 @@
+"""Full-size GPU tests of the BASELINE.json configurations (pytest -m gpu).
+
+  * the metric's configuration -- 2*10^9 B English-like text through the end-to-end entry point with pinned host buffers:
+    size-independent properties (the oracle's decoder reproduces the input from the GPU stream; header fields = reported
+    statistics) plus a bit-exact comparison of a 32 MiB prefix text against the oracle's compressor;
+  * configs[2] (lcpcomp + ArithmeticCoder, DNA) and configs[3] (lz78 + Elias-gamma) at 256 MiB, byte for byte against the
+    oracle's compressors (minutes of CPU time for the oracle: these are the slowest tests of the suite).
+"""
+import numpy as np
+import pytest
+
+import tudocomp_amd as T
+from oracle import oracle as O
+from tests.util import sha256
+
+pytestmark = pytest.mark.gpu
+
+
+class _Bits:
+    """MSB-first bit reader (io/BitIStream.hpp) for the stream header only."""
+
+    def __init__(self, data):
+        self.d, self.p = data, 0
+
+    def bit(self):
+        b = (int(self.d[self.p >> 3]) >> (7 - (self.p & 7))) & 1
+        self.p += 1
+        return b
+
+    def int(self, bits):
+        v = 0
+        for _ in range(bits):
+            v = (v << 1) | self.bit()
+        return v
+
+    def compressed_int(self, b=7):            # io/BitIStream.hpp read_compressed_int: b-bit groups, each preceded by a "more" bit
+        v, shift = 0, 0
+        while True:
+            more = self.bit()
+            v |= self.int(b) << shift
+            shift += b
+            if not more:
+                return v
+
+
+def _header(stream):
+    """(n, flen_min, flen_max, fdist_max) of a lcpcomp(coder=huff) stream (LZSSCoding.hpp:27-41 behind the Huffman table)."""
+    r = _Bits(stream)
+    if r.bit():                               # huffmantable_encode (HuffmanCoder.hpp:264-273)
+        longest = r.compressed_int()
+        for _ in range(longest):
+            r.compressed_int()
+        sigma = r.compressed_int()
+        for _ in range(sigma):
+            r.int(8)
+    n = r.int(32)
+    w = O.bits_for(n)
+    return n, r.int(w), r.int(w), r.int(w)
+
+
+def test_metric_config_2e9_end_to_end(gpu_ctx):
+    N = 2_000_000_000
+    n = N + 1
+    h_text = T.PinnedBuffer(n)
+    h_out = T.PinnedBuffer(N)
+    try:
+        T.gen_english(N, 42, out=h_text.a)
+        h_text.a[N] = 0
+        out_len, st = gpu_ctx.lcpcomp_compress_into(h_text, n, h_out, 2, 1)
+        assert st["n"] == n and st["out_len"] == out_len and 0 < out_len < N
+        assert st["ms_h2d"] > 0 and st["ms_d2h"] > 0 and st["ms_total"] >= st["ms_h2d"] + st["ms_d2h"]
+        stream = h_out.a[:out_len]
+        hn, fmin, fmax, dmax = _header(stream)
+        assert (hn, fmin, fmax, dmax) == (n, st["flen_min"], st["flen_max"], st["fdist_max"])
+        assert fmin >= 2 and fmax <= st["maxlcp"]
+        back = O.lcpcomp_huff_decompress(stream)
+        assert len(back) == n
+        assert sha256(back) == sha256(h_text.a)
+        del back
+        # a buffer that is too small is refused with the required size, nothing is written past it
+        tiny = np.concatenate([h_text.a[:1 << 22], np.zeros(1, dtype=np.uint8)])
+        small = np.full(4096, 0xA5, dtype=np.uint8)
+        with pytest.raises(T.TdcGpuError) as e:
+            gpu_ctx.lcpcomp_compress_into(tiny, len(tiny), small[:1024], 2, 1)
+        assert bool((small[1024:] == 0xA5).all())
+        assert e.value.status == -5
+        # bit-exact against the oracle's compressor on a prefix text (the generator's shorter outputs are prefixes)
+        m = 1 << 25
+        sample = np.concatenate([h_text.a[:m], np.zeros(1, dtype=np.uint8)])
+        want, _ = O.lcpcomp_huff_compress(sample, 2, 1)
+        got_len, _ = gpu_ctx.lcpcomp_compress_into(sample, m + 1, h_out, 2, 1)
+        assert got_len == len(want) and h_out.a[:got_len].tobytes() == want
+    finally:
+        h_text.free()
+        h_out.free()
+
+
+def test_config2_arithmetic_dna_256MiB(gpu_ctx):
+    N = 1 << 28
+    text = np.concatenate([T.gen_dna(N, 7), np.zeros(1, dtype=np.uint8)])
+    got, st = gpu_ctx.lcpcomp_compress(text, 5, 1, T.CODER_ARITH)
+    want, _ = O.lcpcomp_arith_compress(text, 5, 1)
+    assert len(got) == len(want) and sha256(got) == sha256(want)
+    assert st["maxlcp"] >= 4096
+
+
+def test_config3_lz78_gamma_256MiB(gpu_ctx):
+    N = 1 << 28
+    data = T.gen_english(N, 42)
+    got, st = gpu_ctx.lz78_compress(data)
+    want = O.lz78_gamma_compress(data)
+    assert len(got) == len(want) and sha256(got) == sha256(want)
+    assert st["factors"] > 0

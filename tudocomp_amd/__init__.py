@@ -54,16 +54,19 @@ def unescape(data):
     return out[:n].tobytes()
 
 
-def gen_english(n, seed=42):
-    out = np.empty(n, dtype=np.uint8)
+def gen_english(n, seed=42, out=None):
+    """SURVEY.md 8d English-like generator; `out` (optional): a uint8 array of >= n bytes to fill in place."""
+    if out is None:
+        out = np.empty(n, dtype=np.uint8)
     _native.load().tdc_gen_english(_ptr(out), n, seed)
-    return out
+    return out[:n]
 
 
-def gen_dna(n, seed=7):
-    out = np.empty(n, dtype=np.uint8)
+def gen_dna(n, seed=7, out=None):
+    if out is None:
+        out = np.empty(n, dtype=np.uint8)
     _native.load().tdc_gen_dna(_ptr(out), n, seed)
-    return out
+    return out[:n]
 
 
 def huffman_table(counts):
@@ -77,6 +80,26 @@ def huffman_table(counts):
     if rc:
         raise TdcGpuError(rc)
     return {"sigma": sigma.value, "longest": longest.value, "order": order, "len_of": len_of, "code_of": code_of}
+
+
+class PinnedBuffer:
+    """Page-locked host memory (tdc_gpu_host_alloc) as a numpy uint8 array `.a`; the buffers of the end-to-end entry point."""
+
+    def __init__(self, nbytes):
+        self._L = _native.load()
+        self.nbytes = int(nbytes)
+        self.ptr = self._L.tdc_gpu_host_alloc(self.nbytes)
+        if not self.ptr:
+            raise TdcGpuError(-5, "tdc_gpu_host_alloc(%d)" % self.nbytes)
+        self.a = np.ctypeslib.as_array(ctypes.cast(self.ptr, ctypes.POINTER(ctypes.c_uint8)), shape=(max(self.nbytes, 1),))[:self.nbytes]
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            self.a = None
+            self._L.tdc_gpu_host_free(self.ptr)
+            self.ptr = None
+
+    __del__ = free
 
 
 class Context:
@@ -147,6 +170,16 @@ class Context:
         self._check(rc)
         return self._take(out, n.value), st.as_dict()
 
+    def lcpcomp_compress_into(self, text, n, out, threshold=5, flatten=1, coder=CODER_HUFF, comp=COMP_ARRAYS):
+        """End-to-end entry point: text (n bytes incl. sentinel) and out are host buffers (PinnedBuffer or numpy uint8 arrays);
+        the stream is written into out.  Returns (out_len, stats)."""
+        ta = text.a if isinstance(text, PinnedBuffer) else _u8(text)
+        oa = out.a if isinstance(out, PinnedBuffer) else out
+        ol, st = ctypes.c_size_t(), Stats()
+        self._check(self._L.tdc_gpu_lcpcomp_compress_into(self._h, _ptr(ta), n, threshold, int(flatten), coder, comp, _ptr(oa), len(oa),
+                                                          ctypes.byref(ol), ctypes.byref(st)))
+        return ol.value, st.as_dict()
+
     def lcpcomp_compress_raw(self, data, threshold=5, flatten=1, coder=CODER_HUFF):
         """data: unrestricted input; escaping + sentinel happen on the device.  Returns (compressed bytes, stats dict)."""
         a = _u8(data)
@@ -187,8 +220,8 @@ class Context:
                                                   ctypes.byref(st)))
         return self._take(out, n.value), st.as_dict()
 
-    def bound(self, n):
-        return self._L.tdc_gpu_lcpcomp_bound(n)
+    def bound(self, n, coder=None):
+        return self._L.tdc_gpu_lcpcomp_bound(n) if coder is None else self._L.tdc_gpu_lcpcomp_bound_coder(n, coder)
 
     # ---- stages ----------------------------------------------------------------------------------------
     def suffix_array(self, text):

@@ -14,7 +14,7 @@ SYMBOLS = [
     "tdc_gpu_ctx_create", "tdc_gpu_ctx_destroy", "tdc_gpu_ctx_reserve", "tdc_gpu_strerror", "tdc_gpu_last_error",
     "tdc_gpu_ctx_set_profiling", "tdc_gpu_ctx_reset_profile", "tdc_gpu_ctx_kernel_profile",
     "tdc_gpu_free", "tdc_gpu_lcpcomp_compress", "tdc_gpu_lcpcomp_compress_raw", "tdc_gpu_lcpcomp_compress_dev",
-    "tdc_gpu_lcpcomp_bound",
+    "tdc_gpu_lcpcomp_bound", "tdc_gpu_lcpcomp_bound_coder", "tdc_gpu_lcpcomp_compress_into", "tdc_gpu_host_alloc", "tdc_gpu_host_free",
     "tdc_gpu_lz78_compress", "tdc_gpu_lzss_lcp_compress", "tdc_gpu_lzss_lcp_factorize",
     "tdc_gpu_suffix_array", "tdc_gpu_textds", "tdc_gpu_lcpcomp_factorize", "tdc_gpu_flatten", "tdc_gpu_encode_huff",
     "tdc_gpu_lcpcomp_decompress",
@@ -80,6 +80,13 @@ def load():
     L.tdc_gpu_lzss_lcp_factorize.argtypes = [vp, vp, sz, u32, pvp, pvp, pvp, psz]
     L.tdc_gpu_lcpcomp_bound.argtypes = [sz]
     L.tdc_gpu_lcpcomp_bound.restype = sz
+    L.tdc_gpu_lcpcomp_bound_coder.argtypes = [sz, i32]
+    L.tdc_gpu_lcpcomp_bound_coder.restype = sz
+    L.tdc_gpu_lcpcomp_compress_into.argtypes = [vp, vp, sz, u32, i32, i32, i32, vp, sz, psz, ctypes.POINTER(Stats)]
+    L.tdc_gpu_host_alloc.argtypes = [sz]
+    L.tdc_gpu_host_alloc.restype = vp
+    L.tdc_gpu_host_free.argtypes = [vp]
+    L.tdc_gpu_host_free.restype = None
     L.tdc_gpu_suffix_array.argtypes = [vp, vp, sz, vp, vp]
     L.tdc_gpu_textds.argtypes = [vp, vp, sz, vp, vp, vp, vp, vp, ctypes.POINTER(u32)]
     L.tdc_gpu_lcpcomp_factorize.argtypes = [vp, vp, sz, u32, i32, pvp, pvp, pvp, psz, ctypes.POINTER(Stats)]

@@ -6,7 +6,7 @@ The reference has no block mode; the framing is this projec
 
 Every payload is byte-identical to the `--raw` lcpcomp stream of that shard.  Shards are independent, so there is no
 data-path collective during compression; afterwards the per-shard streams are gathered on rank 0: an all-gather of
-the sizes, then point-to-point sends (on a GPU node: RCCL over each peer's own xGMI link to rank 0).
+the sizes, then ONE group of point-to-point operations (on a GPU node: RCCL, every peer over its own xGMI link to rank 0).
 """
 import struct
 
@@ -52,11 +52,14 @@ def gather_streams(dist, torch, stream, length, rank, world, device):
     dist.all_gather(sizes, torch.tensor([length], dtype=torch.int64, device=device))
     sizes = [int(s.item()) for s in sizes]
     bufs = None
+    # one GROUP of point-to-point operations (ncclGroupStart ... ncclGroupEnd under RCCL): rank 0 posts all its receives at
+    # once, so the peers' streams arrive over their own xGMI links concurrently instead of one after the other
     if rank == 0:
         bufs = [stream[:length]] + [torch.empty(sizes[r], dtype=torch.uint8, device=device) for r in range(1, world)]
-        reqs = [dist.irecv(bufs[r], src=r) for r in range(1, world)]
-        for q in reqs:
-            q.wait()
+        ops = [dist.P2POp(dist.irecv, bufs[r], r) for r in range(1, world) if sizes[r]]
     else:
-        dist.send(stream[:length].contiguous(), dst=0)
+        ops = [dist.P2POp(dist.isend, stream[:length].contiguous(), 0)] if length else []
+    if ops:
+        for q in dist.batch_isend_irecv(ops):
+            q.wait()
     return sizes, bufs

@@ -21,12 +21,37 @@ namespace {
 
 struct ArgError { int code; const char* msg; };
 
+// hipSetDevice is a per-thread setting of the embedding program: switch to the context's device for the duration of one
+// API call only
+struct DeviceGuard {
+    int want, prev = -1;
+    explicit DeviceGuard(int d) : want(d) {}
+    hipError_t enter() {
+        if (hipGetDevice(&prev) != hipSuccess) { prev = -1; (void)hipGetLastError(); }
+        return prev == want ? hipSuccess : hipSetDevice(want);
+    }
+    ~DeviceGuard() { if (prev >= 0 && prev != want) (void)hipSetDevice(prev); }
+};
+
+// malloc'd host buffer that is freed unless release()d: the output buffers handed to the caller are allocated before the
+// last synchronisation, and an error surfacing there must not leak them
+struct HostBuf {
+    void* p = nullptr;
+    explicit HostBuf(size_t bytes) : p(malloc(bytes ? bytes : 1)) { if (!p) throw std::bad_alloc(); }
+    ~HostBuf() { free(p); }
+    template <typename T> T* as() { return (T*)p; }
+    template <typename T> T* release() { T* r = (T*)p; p = nullptr; return r; }
+    HostBuf(const HostBuf&) = delete;
+    HostBuf& operator=(const HostBuf&) = delete;
+};
+
 template <typename F>
 int guarded(tdc_gpu_ctx* ctx, F&& f) {
     if (!ctx) return TDC_GPU_ERR_ARG;
     ctx->last_error.clear();
+    DeviceGuard dg(ctx->c.device);               // the caller's current device is restored on every exit path
     try {
-        HIP_TRY(hipSetDevice(ctx->c.device));
+        HIP_TRY(dg.enter());
         f();
         if (ctx->c.d_err) {                      // device-side error word (e.g. a look-back that timed out)
             u32 e = 0;
@@ -211,12 +236,6 @@ void validate_factor_list(size_t n, const uint32_t* pos, const uint32_t* src, co
     }
 }
 
-template <typename T> T* host_alloc(size_t count) {
-    T* p = (T*)malloc((count ? count : 1) * sizeof(T));
-    if (!p) throw std::bad_alloc();
-    return p;
-}
-
 }  // namespace
 
 extern "C" {
@@ -336,6 +355,9 @@ int tdc_gpu_ctx_reserve(tdc_gpu_ctx* ctx, size_t n) {
 }
 
 size_t tdc_gpu_lcpcomp_bound(size_t n) { return align_up(encode_bound(n) + 16, 8); }
+size_t tdc_gpu_lcpcomp_bound_coder(size_t n, int coder) {
+    try { return align_up(encode_bound_coder(n, lcpcomp_enc_coder(coder)) + 16, 8); } catch (...) { return 0; }
+}
 
 int tdc_gpu_lcpcomp_compress_dev(tdc_gpu_ctx* ctx, const void* d_text, size_t n, uint32_t threshold, int flatten, int coder,
                                  void* d_out, size_t out_cap, size_t* out_len, tdc_gpu_stats* stats) {
@@ -356,88 +378,91 @@ int tdc_gpu_lcpcomp_compress_dev(tdc_gpu_ctx* ctx, const void* d_text, size_t n,
     });
 }
 
-int tdc_gpu_lcpcomp_compress(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, uint32_t threshold, int flatten, int coder,
-                             uint8_t** out, size_t* out_len, tdc_gpu_stats* stats) {
-    return guarded(ctx, [&] {
-        (void)lcpcomp_enc_coder(coder);
+namespace {
+// Host buffers in, host buffer out: H2D, (escape,) the whole pipeline, D2H.  The output goes either into a malloc'd buffer
+// (*ho.out) or into the caller's buffer ho.into of ho.cap bytes; copies from / to pinned memory (tdc_gpu_host_alloc) run at
+// PCIe speed, pageable memory is staged by the runtime.
+struct HostOut { uint8_t** out; uint8_t* into; size_t cap; size_t* out_len; };
+void compress_host(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, bool raw, uint32_t threshold, int flatten, int coder, int comp,
+                   HostOut ho, tdc_gpu_stats* stats) {
+    (void)lcpcomp_enc_coder(coder);
+    if (comp != TDC_GPU_COMP_ARRAYS && comp != TDC_GPU_COMP_PLCPPEAKS && comp != TDC_GPU_COMP_MAXLCP)
+        throw ArgError{TDC_GPU_ERR_UNSUPPORTED, "lcpcomp: comp must be arrays, plcppeaks or max_lcp"};
+    if (!ho.out_len || (!ho.out && !ho.into)) throw ArgError{TDC_GPU_ERR_ARG, "out/out_len is NULL"};
+    if (raw) {
+        if (!text && n) throw ArgError{TDC_GPU_ERR_ARG, "NULL argument"};
+        if (n >= (1ull << 30)) throw ArgError{TDC_GPU_ERR_TOO_LARGE, "raw input must be < 2^30 bytes (the escaped text must stay < 2^31)"};
+    } else {
         check_text_args(text, n);
-        if (!out || !out_len) throw ArgError{TDC_GPU_ERR_ARG, "out/out_len is NULL"};
         if (text[n - 1] != 0) throw ArgError{TDC_GPU_ERR_NO_SENTINEL, "text does not end with a 0 sentinel"};
-        Ctx& c = ctx->c;
-        if (stats) memset(stats, 0, sizeof(*stats));
-        c.ensure_arena(arena_need(n));
-        Events ev(c);
-        const int e0 = ev.tick();
-        u8* d_text = c.arena.get<u8>(n + 64);
+    }
+    Ctx& c = ctx->c;
+    if (stats) memset(stats, 0, sizeof(*stats));
+    c.ensure_arena(raw ? arena_need(2 * n + 1) + n : arena_need(n));
+    Events ev(c);
+    const int e0 = ev.tick();
+    u8* d_text;
+    size_t tn = n;
+    if (raw) {
+        u8* d_raw = c.arena.get<u8>(n + 64);
+        d_text = c.arena.get<u8>(2 * n + 65);
+        if (n) HIP_TRY(hipMemcpyAsync(d_raw, text, n, hipMemcpyHostToDevice, c.stream));
+        tn = escape_device(c, d_raw, n, d_text);
+    } else {
+        d_text = c.arena.get<u8>(n + 64);
         HIP_TRY(hipMemcpyAsync(d_text, text, n, hipMemcpyHostToDevice, c.stream));
-        const int e1 = ev.tick();
-        u8* d_out = nullptr;
-        const size_t len = run_pipeline(c, d_text, n, threshold, flatten, coder, &d_out, 0, stats, ev);
-        const int e2 = ev.tick();
-        uint8_t* h = host_alloc<uint8_t>(len);
-        HIP_TRY(hipMemcpyAsync(h, d_out, len, hipMemcpyDeviceToHost, c.stream));
+    }
+    const int e1 = ev.tick();
+    u8* d_out = nullptr;
+    const size_t len = run_pipeline(c, d_text, tn, threshold, flatten, coder, &d_out, 0, stats, ev, comp);
+    const int e2 = ev.tick();
+    *ho.out_len = len;
+    if (ho.into) {
+        if (len > ho.cap) throw ArgError{TDC_GPU_ERR_OOM, "output buffer too small (*out_len holds the required size)"};
+        HIP_TRY(hipMemcpyAsync(ho.into, d_out, len, hipMemcpyDeviceToHost, c.stream));
         const int e3 = ev.tick();
         if (stats) { ev.span(&stats->ms_h2d, e0, e1); ev.span(&stats->ms_d2h, e2, e3); ev.span(&stats->ms_total, e0, e3); }
         ev.finish();
-        *out = h; *out_len = len;
-    });
+    } else {
+        HostBuf h(len);
+        HIP_TRY(hipMemcpyAsync(h.p, d_out, len, hipMemcpyDeviceToHost, c.stream));
+        const int e3 = ev.tick();
+        if (stats) { ev.span(&stats->ms_h2d, e0, e1); ev.span(&stats->ms_d2h, e2, e3); ev.span(&stats->ms_total, e0, e3); }
+        ev.finish();
+        *ho.out = h.release<uint8_t>();
+    }
+}
+}  // namespace
+
+int tdc_gpu_lcpcomp_compress(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, uint32_t threshold, int flatten, int coder,
+                             uint8_t** out, size_t* out_len, tdc_gpu_stats* stats) {
+    return guarded(ctx, [&] { compress_host(ctx, text, n, false, threshold, flatten, coder, TDC_GPU_COMP_ARRAYS, HostOut{out, nullptr, 0, out_len}, stats); });
 }
 
 int tdc_gpu_lcpcomp_compress_comp(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, uint32_t threshold, int flatten, int coder,
                                   int comp, uint8_t** out, size_t* out_len, tdc_gpu_stats* stats) {
+    return guarded(ctx, [&] { compress_host(ctx, text, n, false, threshold, flatten, coder, comp, HostOut{out, nullptr, 0, out_len}, stats); });
+}
+
+int tdc_gpu_lcpcomp_compress_into(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, uint32_t threshold, int flatten, int coder,
+                                  int comp, uint8_t* out, size_t out_cap, size_t* out_len, tdc_gpu_stats* stats) {
     return guarded(ctx, [&] {
-        (void)lcpcomp_enc_coder(coder);
-        if (comp != TDC_GPU_COMP_ARRAYS && comp != TDC_GPU_COMP_PLCPPEAKS && comp != TDC_GPU_COMP_MAXLCP) throw ArgError{TDC_GPU_ERR_UNSUPPORTED, "lcpcomp: comp must be arrays, plcppeaks or max_lcp"};
-        check_text_args(text, n);
-        if (!out || !out_len) throw ArgError{TDC_GPU_ERR_ARG, "out/out_len is NULL"};
-        if (text[n - 1] != 0) throw ArgError{TDC_GPU_ERR_NO_SENTINEL, "text does not end with a 0 sentinel"};
-        Ctx& c = ctx->c;
-        if (stats) memset(stats, 0, sizeof(*stats));
-        c.ensure_arena(arena_need(n));
-        Events ev(c);
-        const int e0 = ev.tick();
-        u8* d_text = c.arena.get<u8>(n + 64);
-        HIP_TRY(hipMemcpyAsync(d_text, text, n, hipMemcpyHostToDevice, c.stream));
-        const int e1 = ev.tick();
-        u8* d_out = nullptr;
-        const size_t len = run_pipeline(c, d_text, n, threshold, flatten, coder, &d_out, 0, stats, ev, comp);
-        const int e2 = ev.tick();
-        uint8_t* h = host_alloc<uint8_t>(len);
-        HIP_TRY(hipMemcpyAsync(h, d_out, len, hipMemcpyDeviceToHost, c.stream));
-        const int e3 = ev.tick();
-        if (stats) { ev.span(&stats->ms_h2d, e0, e1); ev.span(&stats->ms_d2h, e2, e3); ev.span(&stats->ms_total, e0, e3); }
-        ev.finish();
-        *out = h; *out_len = len;
+        if (!out) throw ArgError{TDC_GPU_ERR_ARG, "out is NULL"};
+        compress_host(ctx, text, n, false, threshold, flatten, coder, comp, HostOut{nullptr, out, out_cap, out_len}, stats);
     });
 }
 
 int tdc_gpu_lcpcomp_compress_raw(tdc_gpu_ctx* ctx, const uint8_t* data, size_t n, uint32_t threshold, int flatten, int coder,
                                  uint8_t** out, size_t* out_len, tdc_gpu_stats* stats) {
-    return guarded(ctx, [&] {
-        (void)lcpcomp_enc_coder(coder);
-        if ((!data && n) || !out || !out_len) throw ArgError{TDC_GPU_ERR_ARG, "NULL argument"};
-        if (n >= (1ull << 30)) throw ArgError{TDC_GPU_ERR_TOO_LARGE, "raw input must be < 2^30 bytes (the escaped text must stay < 2^31)"};
-        Ctx& c = ctx->c;
-        if (stats) memset(stats, 0, sizeof(*stats));
-        c.ensure_arena(arena_need(2 * n + 1) + n);
-        Events ev(c);
-        const int e0 = ev.tick();
-        u8* d_raw = c.arena.get<u8>(n + 64);
-        u8* d_text = c.arena.get<u8>(2 * n + 65);
-        if (n) HIP_TRY(hipMemcpyAsync(d_raw, data, n, hipMemcpyHostToDevice, c.stream));
-        const size_t tn = escape_device(c, d_raw, n, d_text);
-        const int e1 = ev.tick();
-        u8* d_out = nullptr;
-        const size_t len = run_pipeline(c, d_text, tn, threshold, flatten, coder, &d_out, 0, stats, ev);
-        const int e2 = ev.tick();
-        uint8_t* h = host_alloc<uint8_t>(len);
-        HIP_TRY(hipMemcpyAsync(h, d_out, len, hipMemcpyDeviceToHost, c.stream));
-        const int e3 = ev.tick();
-        if (stats) { ev.span(&stats->ms_h2d, e0, e1); ev.span(&stats->ms_d2h, e2, e3); ev.span(&stats->ms_total, e0, e3); }
-        ev.finish();
-        *out = h; *out_len = len;
-    });
+    return guarded(ctx, [&] { compress_host(ctx, data, n, true, threshold, flatten, coder, TDC_GPU_COMP_ARRAYS, HostOut{out, nullptr, 0, out_len}, stats); });
 }
+
+void* tdc_gpu_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+void tdc_gpu_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
 namespace {
 // shared front end of the two lzss_lcp entry points: text to the device, SA + ISA, factorization into position space
@@ -485,8 +510,8 @@ int tdc_gpu_lzss_lcp_compress(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, u
         const int e1 = ev.tick();
         const size_t len = encode_huff(c, d_text, n, A.fs, d_out, cap, &es);
         const int e2 = ev.tick();
-        uint8_t* h = host_alloc<uint8_t>(len);
-        HIP_TRY(hipMemcpyAsync(h, d_out, len, hipMemcpyDeviceToHost, c.stream));
+        HostBuf h(len);
+        HIP_TRY(hipMemcpyAsync(h.p, d_out, len, hipMemcpyDeviceToHost, c.stream));
         const int e3 = ev.tick();
         if (stats) {
             stats->out_len = len; stats->flen_min = es.flen_min; stats->flen_max = es.flen_max; stats->fdist_max = es.fdist_max;
@@ -494,7 +519,7 @@ int tdc_gpu_lzss_lcp_compress(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, u
             ev.span(&stats->ms_encode, e1, e2); ev.span(&stats->ms_d2h, e2, e3); ev.span(&stats->ms_total, e0, e3);
         }
         ev.finish();
-        *out = h; *out_len = len;
+        *out = h.release<uint8_t>(); *out_len = len;
     });
 }
 
@@ -510,14 +535,14 @@ int tdc_gpu_lzss_lcp_factorize(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, 
         run_lzss_lcp(c, text, n, threshold, &d_text, A, nullptr, ev);
         u32* d_pos = c.arena.get<u32>(n), *d_src = c.arena.get<u32>(n), *d_len = c.arena.get<u32>(n);
         const size_t cnt = extract_factors(c, n, A.fs, d_pos, d_src, d_len, n);
-        uint32_t* hp = host_alloc<uint32_t>(cnt), *hs = host_alloc<uint32_t>(cnt), *hl = host_alloc<uint32_t>(cnt);
+        HostBuf hp(cnt * 4), hs(cnt * 4), hl(cnt * 4);
         if (cnt) {
-            HIP_TRY(hipMemcpyAsync(hp, d_pos, cnt * 4, hipMemcpyDeviceToHost, c.stream));
-            HIP_TRY(hipMemcpyAsync(hs, d_src, cnt * 4, hipMemcpyDeviceToHost, c.stream));
-            HIP_TRY(hipMemcpyAsync(hl, d_len, cnt * 4, hipMemcpyDeviceToHost, c.stream));
+            HIP_TRY(hipMemcpyAsync(hp.p, d_pos, cnt * 4, hipMemcpyDeviceToHost, c.stream));
+            HIP_TRY(hipMemcpyAsync(hs.p, d_src, cnt * 4, hipMemcpyDeviceToHost, c.stream));
+            HIP_TRY(hipMemcpyAsync(hl.p, d_len, cnt * 4, hipMemcpyDeviceToHost, c.stream));
         }
         ev.finish();
-        *pos = hp; *src = hs; *len = hl; *z = cnt;
+        *pos = hp.release<uint32_t>(); *src = hs.release<uint32_t>(); *len = hl.release<uint32_t>(); *z = cnt;
     });
 }
 
@@ -550,15 +575,15 @@ int tdc_gpu_lz78_compress(tdc_gpu_ctx* ctx, const uint8_t* in, size_t n, int cod
         const int e1 = ev.tick();
         const size_t len = lz78_gamma_encode(c, d_ids, d_chars, z, d_out, cap);
         const int e2 = ev.tick();
-        uint8_t* h = host_alloc<uint8_t>(len);
-        HIP_TRY(hipMemcpyAsync(h, d_out, len, hipMemcpyDeviceToHost, c.stream));
+        HostBuf h(len);
+        HIP_TRY(hipMemcpyAsync(h.p, d_out, len, hipMemcpyDeviceToHost, c.stream));
         const int e3 = ev.tick();
         if (stats) {
             stats->n = n; stats->out_len = len; stats->factors = z; stats->arena_bytes = c.arena.high;
             ev.span(&stats->ms_h2d, e0, e1); ev.span(&stats->ms_encode, e1, e2); ev.span(&stats->ms_d2h, e2, e3); ev.span(&stats->ms_total, e0, e3);
         }
         ev.finish();
-        *out = h; *out_len = len;
+        *out = h.release<uint8_t>(); *out_len = len;
     });
 }
 
@@ -617,14 +642,14 @@ int tdc_gpu_lcpcomp_factorize(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, u
         run_factorize(c, n, A, threshold, flatten, stats, &ev);
         u32* d_pos = c.arena.get<u32>(n), *d_src = c.arena.get<u32>(n), *d_len = c.arena.get<u32>(n);
         const size_t cnt = extract_factors(c, n, A.fs, d_pos, d_src, d_len, n);
-        uint32_t* hp = host_alloc<uint32_t>(cnt), *hs = host_alloc<uint32_t>(cnt), *hl = host_alloc<uint32_t>(cnt);
+        HostBuf hp(cnt * 4), hs(cnt * 4), hl(cnt * 4);
         if (cnt) {
-            HIP_TRY(hipMemcpyAsync(hp, d_pos, cnt * 4, hipMemcpyDeviceToHost, c.stream));
-            HIP_TRY(hipMemcpyAsync(hs, d_src, cnt * 4, hipMemcpyDeviceToHost, c.stream));
-            HIP_TRY(hipMemcpyAsync(hl, d_len, cnt * 4, hipMemcpyDeviceToHost, c.stream));
+            HIP_TRY(hipMemcpyAsync(hp.p, d_pos, cnt * 4, hipMemcpyDeviceToHost, c.stream));
+            HIP_TRY(hipMemcpyAsync(hs.p, d_src, cnt * 4, hipMemcpyDeviceToHost, c.stream));
+            HIP_TRY(hipMemcpyAsync(hl.p, d_len, cnt * 4, hipMemcpyDeviceToHost, c.stream));
         }
         ev.finish();
-        *pos = hp; *src = hs; *len = hl; *z = cnt;
+        *pos = hp.release<uint32_t>(); *src = hs.release<uint32_t>(); *len = hl.release<uint32_t>(); *z = cnt;
         if (stats) { stats->n = n; stats->arena_bytes = c.arena.high; }
     });
 }
@@ -673,9 +698,9 @@ int tdc_gpu_lcpcomp_decompress_coder(tdc_gpu_ctx* ctx, const uint8_t* stream, si
         size_t n = 0;
         try { n = decode_lzss(ctx->c, stream, len, enc, text, &ds); }
         catch (const StreamFormatError& e) { throw ArgError{TDC_GPU_ERR_ARG, e.what}; }
-        uint8_t* h = host_alloc<uint8_t>(n);
-        if (n) memcpy(h, text.data(), n);
-        *out = h; *out_len = n;
+        HostBuf h(n);
+        if (n) memcpy(h.p, text.data(), n);
+        *out = h.release<uint8_t>(); *out_len = n;
         if (factors) *factors = ds.factors;
         if (rounds) *rounds = ds.rounds;
     });
@@ -723,10 +748,10 @@ static int encode_entry(tdc_gpu_ctx* ctx, int coder, const uint8_t* text, size_t
         const size_t cap = align_up(encode_bound_coder(n, coder) + 16, 8);
         u8* d_out = c.arena.get<u8>(cap);
         const size_t l = encode_stream(c, d_text, n, fs, coder, d_out, cap, nullptr);
-        uint8_t* h = host_alloc<uint8_t>(l);
-        HIP_TRY(hipMemcpyAsync(h, d_out, l, hipMemcpyDeviceToHost, c.stream));
+        HostBuf h(l);
+        HIP_TRY(hipMemcpyAsync(h.p, d_out, l, hipMemcpyDeviceToHost, c.stream));
         HIP_TRY(hipStreamSynchronize(c.stream));
-        *out = h; *out_len = l;
+        *out = h.release<uint8_t>(); *out_len = l;
     });
 }
 
