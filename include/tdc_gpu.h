@@ -150,6 +150,9 @@ int tdc_gpu_lzss_lcp_factorize(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, 
                                uint32_t** pos, uint32_t** src, uint32_t** len, size_t* z);
 
 /* ---- stage-level entry points (host buffers), used by the parity tests ------------------------------------ */
+/* the device sorts behind the suffix array (no reference counterpart; for the tests): sorts n (key, value) pairs in place by
+ * the 64-bit key; algo 0 = stable 8-bit LSD radix sort, 1 = splitter-partition sort (unstable) */
+int tdc_gpu_sort_pairs_u64(tdc_gpu_ctx* ctx, uint64_t* keys, uint32_t* vals, size_t n, int algo);
 /* ds/SADivSufSort.hpp:27-51 + ds/ISAFromSA.hpp:30-43 : sa / isa may be NULL */
 int tdc_gpu_suffix_array(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, uint32_t* sa, uint32_t* isa);
 /* TextDS::require(SA|ISA|PHI|PLCP|LCP) (ds/TextDS.hpp:247-292); any output may be NULL; plcp[n-1] = 0 */

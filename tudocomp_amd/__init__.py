@@ -224,6 +224,13 @@ class Context:
         return self._L.tdc_gpu_lcpcomp_bound(n) if coder is None else self._L.tdc_gpu_lcpcomp_bound_coder(n, coder)
 
     # ---- stages ----------------------------------------------------------------------------------------
+    def sort_pairs_u64(self, keys, vals, algo=1):
+        """The device sorts behind the suffix array (algo 0: LSD radix, 1: splitter partition); returns sorted copies."""
+        k = np.ascontiguousarray(keys, dtype=np.uint64).copy()
+        v = np.ascontiguousarray(vals, dtype=np.uint32).copy()
+        self._check(self._L.tdc_gpu_sort_pairs_u64(self._h, _ptr(k), _ptr(v), len(k), int(algo)))
+        return k, v
+
     def suffix_array(self, text):
         a = _u8(text)
         sa = np.empty(len(a), dtype=np.uint32)

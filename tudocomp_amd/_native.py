@@ -16,7 +16,7 @@ SYMBOLS = [
     "tdc_gpu_free", "tdc_gpu_lcpcomp_compress", "tdc_gpu_lcpcomp_compress_raw", "tdc_gpu_lcpcomp_compress_dev",
     "tdc_gpu_lcpcomp_bound", "tdc_gpu_lcpcomp_bound_coder", "tdc_gpu_lcpcomp_compress_into", "tdc_gpu_host_alloc", "tdc_gpu_host_free",
     "tdc_gpu_lz78_compress", "tdc_gpu_lzss_lcp_compress", "tdc_gpu_lzss_lcp_factorize",
-    "tdc_gpu_suffix_array", "tdc_gpu_textds", "tdc_gpu_lcpcomp_factorize", "tdc_gpu_flatten", "tdc_gpu_encode_huff",
+    "tdc_gpu_sort_pairs_u64", "tdc_gpu_suffix_array", "tdc_gpu_textds", "tdc_gpu_lcpcomp_factorize", "tdc_gpu_flatten", "tdc_gpu_encode_huff",
     "tdc_gpu_lcpcomp_decompress",
     "tdc_gpu_lcpcomp_compress_comp",
     "tdc_gpu_encode_arith",
@@ -87,6 +87,7 @@ def load():
     L.tdc_gpu_host_alloc.restype = vp
     L.tdc_gpu_host_free.argtypes = [vp]
     L.tdc_gpu_host_free.restype = None
+    L.tdc_gpu_sort_pairs_u64.argtypes = [vp, vp, vp, sz, i32]
     L.tdc_gpu_suffix_array.argtypes = [vp, vp, sz, vp, vp]
     L.tdc_gpu_textds.argtypes = [vp, vp, sz, vp, vp, vp, vp, vp, ctypes.POINTER(u32)]
     L.tdc_gpu_lcpcomp_factorize.argtypes = [vp, vp, sz, u32, i32, pvp, pvp, pvp, psz, ctypes.POINTER(Stats)]

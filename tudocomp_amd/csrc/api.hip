@@ -293,6 +293,8 @@ int tdc_gpu_ctx_create(int device, tdc_gpu_ctx** out) {
         if (const char* m = getenv("TDC_GPU_RADIX_LDS")) { const int v = atoi(m); ctx->c.radix_lds = (v >= 0 && v <= 2) ? v : 2; }
         if (const char* m = getenv("TDC_GPU_XCD_REMAP")) { const int v = atoi(m); ctx->c.xcd_remap = (v >= 0 && v <= 2) ? v : 0; }
         if (const char* m = getenv("TDC_GPU_BUCKET_SCATTER")) ctx->c.bucket_scatter = atoi(m) ? 1 : 0;
+        if (const char* m = getenv("TDC_GPU_SSORT")) ctx->c.ssort = atoi(m) ? 1 : 0;
+        if (const char* m = getenv("TDC_GPU_SSORT_LEVELS")) { const int v = atoi(m); ctx->c.ssort_levels = (v >= 1 && v <= 3) ? v : 0; }
     } catch (const HipError&) {
         (void)hipGetLastError();
         tdc_gpu_ctx_destroy(ctx);
@@ -341,7 +343,8 @@ const char* tdc_gpu_ctx_kernel_profile(const tdc_gpu_ctx* ctx, int idx, double* 
         "rs_scatter_kernel<u64>", "rs_scatter_kernel<u32>", "rs_count_kernel", "scan_kernels",
         "sa_update_kernels", "sa_build_keys_kernel", "phi_kernel", "plcp_kernel", "cand_kernels",
         "level_init_kernel", "mis_round_kernel", "resolve_kernel", "push_kernel", "apply_kernel", "pool_kernels", "small_level_kernel", "window_levels_kernel",
-        "flatten_round_kernel", "gaps_kernel", "literal_hist_kernel", "tile_bits_kernel", "pack_kernel", "extract_kernels" };
+        "flatten_round_kernel", "gaps_kernel", "literal_hist_kernel", "tile_bits_kernel", "pack_kernel", "extract_kernels",
+        "ss_leaf_sort_kernel", "sa_local_sort_kernel" };
     if (!ctx || idx < 0 || idx >= K_CLASS_COUNT) return nullptr;
     const KernelProfile& k = ctx->c.kprof[idx];
     if (ms) *ms = k.ms;
@@ -584,6 +587,27 @@ int tdc_gpu_lz78_compress(tdc_gpu_ctx* ctx, const uint8_t* in, size_t n, int cod
         }
         ev.finish();
         *out = h.release<uint8_t>(); *out_len = len;
+    });
+}
+
+int tdc_gpu_sort_pairs_u64(tdc_gpu_ctx* ctx, uint64_t* keys, uint32_t* vals, size_t n, int algo) {
+    return guarded(ctx, [&] {
+        if (!keys || !vals) throw ArgError{TDC_GPU_ERR_ARG, "keys/vals is NULL"};
+        if (n == 0) return;
+        if (n >= 0xFFFFFFFFull) throw ArgError{TDC_GPU_ERR_TOO_LARGE, "at most 2^32 - 2 pairs"};
+        Ctx& c = ctx->c;
+        c.ensure_arena(64 * n + ((size_t)256 << 20));
+        u64* k[2] = { c.arena.get<u64>(n), c.arena.get<u64>(n) };
+        u32* v[2] = { c.arena.get<u32>(n), c.arena.get<u32>(n) };
+        HIP_TRY(hipMemcpyAsync(k[0], keys, n * 8, hipMemcpyHostToDevice, c.stream));
+        HIP_TRY(hipMemcpyAsync(v[0], vals, n * 4, hipMemcpyHostToDevice, c.stream));
+        int x;
+        if (algo == 1) { SplitSortStats ss; x = splitter_sort_pairs_u64(c, k, v, n, nullptr, &ss); }
+        else if (algo == 0) x = radix_sort_pairs_u64(c, k, v, n, 0, 64);
+        else throw ArgError{TDC_GPU_ERR_ARG, "algo must be 0 (LSD radix) or 1 (splitter partition)"};
+        HIP_TRY(hipMemcpyAsync(keys, k[x], n * 8, hipMemcpyDeviceToHost, c.stream));
+        HIP_TRY(hipMemcpyAsync(vals, v[x], n * 4, hipMemcpyDeviceToHost, c.stream));
+        HIP_TRY(hipStreamSynchronize(c.stream));
     });
 }
 

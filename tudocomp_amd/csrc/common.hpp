@@ -76,7 +76,7 @@ enum KernelClass {
     K_RS_SCATTER_U64 = 0, K_RS_SCATTER_U32, K_RS_COUNT, K_SCAN,
     K_SA_RANK_SCATTER, K_SA_BUILD_KEYS, K_PHI, K_PLCP, K_CAND,
     K_LEVEL_INIT, K_MIS_ROUND, K_RESOLVE, K_PUSH, K_APPLY, K_POOL, K_SMALL_LEVEL, K_WINDOW_LEVELS,
-    K_FLATTEN_ROUND, K_ENC_GAPS, K_ENC_HIST, K_ENC_TILE_BITS, K_ENC_PACK, K_EXTRACT,
+    K_FLATTEN_ROUND, K_ENC_GAPS, K_ENC_HIST, K_ENC_TILE_BITS, K_ENC_PACK, K_EXTRACT, K_SS_LEAF, K_SA_LOCAL_SORT,
     K_CLASS_COUNT
 };
 
@@ -125,6 +125,8 @@ struct Ctx {
                                    // pieces of neighbouring tiles then meet in one L2: -13 %), 2 = nowhere
     int window_lcut = 48;          // factorize: levels <= this run window-local in one launch (env TDC_GPU_WINDOW_LCUT, 0 disables)
     int window_large_lists = 0;    // window pass: start with the large per-level lists (env TDC_GPU_WINDOW_LARGE=1; tests)
+    int ssort = 1;                 // suffix array: splitter-partition sort (ssort.hip) instead of the 8-pass LSD sort for large inputs (env TDC_GPU_SSORT=0 disables)
+    int ssort_levels = 0;          // force the number of partition levels of the splitter sort (env TDC_GPU_SSORT_LEVELS = 1..3; tests)
     int bucket_scatter = 1;        // big random scatters (rank, Phi) go through one radix partition by destination window (env TDC_GPU_BUCKET_SCATTER=0 disables)
 
     bool profiling = false;

@@ -23,6 +23,14 @@ int radix_sort_pairs_u32(Ctx& c, u32* keys[2], u32* vals[2], size_t n, int begin
 struct TextKeyGen { const u8* text; size_t n; u32 sigma; int k, chunk; u64 top /* sigma^(k-1) */; u8 code[256]; };
 int radix_sort_text_keys_u64(Ctx& c, const TextKeyGen& g, u64* keys[2], u32* vals[2], int end_bit);
 
+// Splitter-partition sort (ssort.hip): UNSTABLE sort of the pairs by the whole 64-bit key in 2-3 partition levels on key ranks
+// (sampled splitters) plus one in-LDS sort of the leaves -- instead of eight LSD passes.  gen != nullptr: the pairs are
+// (key(i), i) of the text as in radix_sort_text_keys_u64 and keys[0] / vals[0] are not read; else keys[0] / vals[0] hold the
+// input.  Both buffer pairs are used; returns the index of the pair that holds the result.
+struct SplitSortStats { u32 levels = 0, range_leaves = 0, samples = 0, units = 0, large_leaves = 0; u64 large_pairs = 0; };
+bool splitter_sort_applicable(size_t n);
+int splitter_sort_pairs_u64(Ctx& c, u64* keys[2], u32* vals[2], size_t n, const TextKeyGen* gen, SplitSortStats* st);
+
 // Same contract as radix_sort_pairs_u64 for keys that are pairwise DISTINCT on the sorted bits (stability is then
 // irrelevant): inputs of at most 2048 pairs are sorted by one workgroup in LDS (bitonic network), larger ones by the
 // radix sort.  Used for the many tiny per-level sorts of the factorizer.

@@ -1,0 +1,738 @@
+// ssort.hip -- splitter-partition sort of (u64 key, u32 value) pairs (gfx950, wave64).
+//
+// The LSD radix sort of prim.hip moves every pair once per 8 key bits: eight passes for the 64-bit keys of the suffix
+// array's initial sort, whatever the keys look like.  Text keys are heavily skewed (a 13-symbol window of an English-like
+// text has far less than 64 bits of entropy), so a most-significant-digit split on key BITS leaves most pairs in huge
+// buckets.  This sort splits on key RANKS instead:
+//
+//   1. sample: S = os * (NS + 1) keys at pseudo-random positions, sorted with the LSD sort; every os-th one becomes a
+//      splitter sp[0 .. NS) (NS + 1 = F_1 * ... * F_L, the product of the level fan-outs).
+//   2. L partition levels (L <= 3).  lb(x) = #splitters < x.  Level l moves x into the sub-segment given by the l-th digit of
+//      lb(x) in the mixed radix (F_1, ..., F_L); the last level also splits off the keys EQUAL to a splitter
+//      (digit = 2 * (lb mod F_L) + [x == sp[lb]]), so a heavy key -- a key that occurs more than n / (NS + 1) times ends
+//      up in the sample several times -- lands in a leaf of its own that needs no sorting at all.  One level = a count pass
+//      and a scatter pass over tiles of 4096 pairs that never straddle a segment; the digit of a key is a binary search
+//      among the <= 255 splitters of its segment, held in LDS.
+//   3. leaves: the array is now ordered leaf by leaf, range leaves hold ~n / (NS + 1) keys (binomial spread; the
+//      oversampling factor os keeps them below the capacity of one workgroup with overwhelming probability).  Consecutive
+//      small leaves are packed into units of <= 8192 pairs; one workgroup sorts a unit entirely in LDS (LSD radix on the
+//      bits in which the unit's keys differ).  A leaf above 8192 pairs that is not an equality leaf goes through the LSD
+//      sort (never observed; kept for correctness).
+//
+// Traffic per pair: L * (8 + 24) + 24 bytes instead of 8 * (8 + 24); level 1 of the suffix array's sort computes its keys
+// from the text (no key array is read).  The sort is NOT stable (nothing downstream needs it: pairs with equal keys form one
+// group of the prefix doubling).
+#include "prim.hpp"
+
+#include <vector>
+
+namespace tdc {
+
+constexpr int SS_TILE = 4096;        // pairs per partition tile: 256 threads x 16
+constexpr int SS_ITEMS = 16;
+constexpr int SS_SMALL = 4096;       // leaves up to this size are packed into units
+constexpr int SS_UNIT_MAX = 8192;    // capacity of the leaf sort (one workgroup of 512 threads x 16)
+constexpr int SS_GEN_HALO = 32;
+
+struct SSLevel {
+    const u64* keys_in; const u32* vals_in;
+    u64* keys_out; u32* vals_out;
+    u32* counts;                 // [rows][D]: per-tile digit counts, then absolute offsets
+    const u32* blk_seg;          // [blocks] segment of every row block
+    const u32* blk_start;        // [nseg + 1] first row block of every segment
+    const u32* seg_start;        // [nseg + 1] first pair of every segment
+    const u64* sp;               // [NS + 1] splitters, sp[NS] = ~0
+    u32 nseg, F, stride, R, D, per_xcd;
+};
+
+// row (tile slot) -> segment, first pair, number of pairs; false: behind the last real row block
+__device__ __forceinline__ bool ss_row(const SSLevel& P, u32 row, u32& s, size_t& base, u32& cnt) {
+    const u32 blk = row / P.R;
+    if (blk >= P.blk_start[P.nseg]) return false;
+    s = P.blk_seg[blk];
+    const u64 t = (u64)(blk - P.blk_start[s]) * P.R + row % P.R;
+    const u32 s0 = P.seg_start[s], s1 = P.seg_start[s + 1];
+    const u64 off = t * SS_TILE;
+    base = s0; cnt = 0;
+    if (off >= (u64)(s1 - s0)) return true;              // padding row of the segment's last row block
+    base = (size_t)s0 + off;
+    const u64 left = (u64)(s1 - s0) - off;
+    cnt = left < SS_TILE ? (u32)left : (u32)SS_TILE;
+    return true;
+}
+
+// the (<= 256) splitters that matter inside segment s, padded with ~0
+template <bool LAST>
+__device__ __forceinline__ void ss_load_splitters(const SSLevel& P, u32 s, u64* spl) {
+    for (u32 i = threadIdx.x; i < 256; i += blockDim.x) {
+        u64 v = ~0ull;
+        if (LAST) { if (i < P.F) v = P.sp[(size_t)s * P.F + i]; }
+        else if (i + 1 < P.F) v = P.sp[((size_t)s * P.F + i + 1) * P.stride - 1];
+        spl[i] = v;
+    }
+}
+
+// #splitters < x among spl[0 .. 255) (branch-free binary search), then the digit
+template <bool LAST>
+__device__ __forceinline__ u32 ss_digit(const u64* spl, u64 x) {
+    u32 lo = 0;
+#pragma unroll
+    for (u32 step = 128; step >= 1; step >>= 1) lo += (spl[lo + step - 1] < x) ? step : 0u;
+    if (LAST) return 2 * lo + (spl[lo] == x ? 1u : 0u);
+    return lo;
+}
+
+// recoded bytes of one tile (+ halo) into LDS (see gen_stage_tile in prim.hip)
+__device__ __forceinline__ void ss_gen_stage(const TextKeyGen& g, size_t t0, const u8* __restrict__ code, u8* __restrict__ sy) {
+    const size_t p = t0 + (size_t)threadIdx.x * 16;
+    u8 b[16];
+    if (p + 16 <= g.n && (((size_t)g.text) & 15) == 0) {
+        const uint4 v = *(const uint4*)(g.text + p);
+        const u32 wv[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+        for (int i = 0; i < 16; ++i) b[i] = (u8)(wv[i >> 2] >> (8 * (i & 3)));
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) b[i] = (p + i < g.n) ? g.text[p + i] : (u8)0;
+    }
+    u32 o[4] = { 0, 0, 0, 0 };
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[i >> 2] |= (u32)((p + i < g.n) ? code[b[i]] : (u8)0) << (8 * (i & 3));
+    *(uint4*)(sy + (size_t)threadIdx.x * 16) = make_uint4(o[0], o[1], o[2], o[3]);
+    if (threadIdx.x < SS_GEN_HALO) {
+        const size_t q = t0 + SS_TILE + threadIdx.x;
+        sy[SS_TILE + threadIdx.x] = (q < g.n) ? code[g.text[q]] : (u8)0;
+    }
+}
+__device__ __forceinline__ u64 ss_gen_key(const TextKeyGen& g, const u8* sy, int lb) {
+    u64 key = 0;
+    for (int j0 = 0; j0 < g.k; j0 += g.chunk) {
+        const int len = (g.k - j0 < g.chunk) ? g.k - j0 : g.chunk;
+        u32 acc = 0, scale = 1;
+        for (int t = 0; t < len; ++t) { acc = acc * g.sigma + sy[lb + j0 + t]; scale *= g.sigma; }
+        key = (j0 == 0) ? (u64)acc : key * scale + acc;
+    }
+    return key;
+}
+
+// ---- sampling -----------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ size_t ss_sample_pos(u32 i, size_t n) {
+    const u64 h = ((u64)i + 1) * 0x9E3779B97F4A7C15ull;
+    return (size_t)(((unsigned __int128)(h ^ (h >> 29)) * n) >> 64);
+}
+template <bool GEN>
+__global__ __launch_bounds__(256) void ss_sample_kernel(const u64* __restrict__ keys, TextKeyGen g, size_t n, u32 S, u64* __restrict__ out,
+                                                        u32* __restrict__ dummy) {
+    __shared__ u8 code[256];
+    if (GEN) { code[threadIdx.x] = g.code[threadIdx.x]; __syncthreads(); }
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= S) return;
+    const size_t p = ss_sample_pos(i, n);
+    u64 key;
+    if (GEN) {
+        key = 0;
+        for (int j0 = 0; j0 < g.k; j0 += g.chunk) {
+            const int len = (g.k - j0 < g.chunk) ? g.k - j0 : g.chunk;
+            u32 acc = 0, scale = 1;
+            for (int t = 0; t < len; ++t) {
+                const size_t q = p + j0 + t;
+                acc = acc * g.sigma + ((q < n) ? code[g.text[q]] : 0u);
+                scale *= g.sigma;
+            }
+            key = (j0 == 0) ? (u64)acc : key * scale + acc;
+        }
+    } else key = keys[p];
+    out[i] = key;
+    dummy[i] = i;
+}
+__global__ void ss_pick_kernel(const u64* __restrict__ sorted, u32 NS, u32 os, u64* __restrict__ sp) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < NS) sp[i] = sorted[(size_t)(i + 1) * os - 1];
+    else if (i == NS) sp[i] = ~0ull;
+}
+
+// ---- row-block tables ------------------------------------------------------------------------------------------------------------
+__global__ void ss_nblk_kernel(const u32* __restrict__ seg_start, u32 nseg, u32 R, u32* __restrict__ nblk) {
+    const u32 s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s > nseg) return;
+    if (s == nseg) { nblk[s] = 0; return; }
+    const u64 size = seg_start[s + 1] - seg_start[s];
+    nblk[s] = (u32)((size + (u64)SS_TILE * R - 1) / ((u64)SS_TILE * R));
+}
+__global__ void ss_blkseg_kernel(const u32* __restrict__ blk_start, u32 nseg, u32* __restrict__ blk_seg) {
+    const u32 s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nseg) return;
+    for (u32 b = blk_start[s]; b < blk_start[s + 1]; ++b) blk_seg[b] = s;
+}
+
+// ---- count --------------------------------------------------------------------------------------------------------------------
+template <bool GEN, bool LAST>
+__global__ __launch_bounds__(256) void ss_count_kernel(SSLevel P, TextKeyGen g, u32 rows) {
+    __shared__ u32 hist[512];
+    __shared__ u64 spl[256];
+    __shared__ u8 code[256];
+    __shared__ __align__(16) u8 sy[GEN ? SS_TILE + SS_GEN_HALO : 16];
+    const u32 row = xcd_tile(blockIdx.x, P.per_xcd);
+    if (row >= rows) return;
+    u32 s, cnt; size_t base;
+    if (!ss_row(P, row, s, base, cnt)) return;
+    for (u32 i = threadIdx.x; i < P.D; i += 256) hist[i] = 0;
+    if (cnt == 0) {
+        for (u32 i = threadIdx.x; i < P.D; i += 256) P.counts[(size_t)row * P.D + i] = 0;
+        return;
+    }
+    ss_load_splitters<LAST>(P, s, spl);
+    if (GEN) code[threadIdx.x] = g.code[threadIdx.x];
+    __syncthreads();
+    if (GEN) { ss_gen_stage(g, base, code, sy); __syncthreads(); }
+    if (GEN) {
+        const int lb = wave_id() * (64 * SS_ITEMS) + lane_id() * SS_ITEMS;      // a lane owns 16 consecutive positions
+        u64 key = ss_gen_key(g, sy, lb);
+#pragma unroll 4
+        for (int j = 0; j < SS_ITEMS; ++j) {
+            const bool valid = (u32)(lb + j) < cnt;
+            const u32 d = valid ? ss_digit<LAST>(spl, key) : 0u;
+            key = (key - (u64)sy[lb + j] * g.top) * g.sigma + sy[lb + j + g.k];
+            const u32 d0 = __builtin_amdgcn_readfirstlane(d);
+            if (__all(valid && d == d0)) { if (lane_id() == 0) atomicAdd(&hist[d0], 64u); }
+            else if (valid) atomicAdd(&hist[d], 1u);
+        }
+    } else {
+        const u32 lb = wave_id() * (64 * SS_ITEMS) + lane_id();
+#pragma unroll 4
+        for (int j = 0; j < SS_ITEMS; ++j) {
+            const u32 e = lb + (u32)j * 64;
+            const bool valid = e < cnt;
+            const u32 d = valid ? ss_digit<LAST>(spl, P.keys_in[base + e]) : 0u;
+            const u32 d0 = __builtin_amdgcn_readfirstlane(d);
+            if (__all(valid && d == d0)) { if (lane_id() == 0) atomicAdd(&hist[d0], 64u); }
+            else if (valid) atomicAdd(&hist[d], 1u);
+        }
+    }
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < P.D; i += 256) P.counts[(size_t)row * P.D + i] = hist[i];
+}
+
+// ---- offsets: counts[row][d] -> first output slot of the (row, d) run ----------------------------------------------------------
+// (a) sum of every row block, (b) per segment: prefix over its row blocks + start of every digit (= the next level's segment
+// starts), (c) running prefix inside the row block
+__global__ __launch_bounds__(256) void ss_blocksum_kernel(const u32* __restrict__ counts, const u32* __restrict__ blk_start, u32 nseg,
+                                                          u32 R, u32 D, u32* __restrict__ bs) {
+    const u32 b = blockIdx.x;
+    if (b >= blk_start[nseg]) return;
+    for (u32 d = threadIdx.x; d < D; d += 256) {
+        u32 acc = 0;
+        for (u32 r = 0; r < R; ++r) acc += counts[((size_t)b * R + r) * D + d];
+        bs[(size_t)b * D + d] = acc;
+    }
+}
+// one workgroup of 1024 threads per segment; thread (g, d): digit d (and d + 256 when D = 512 ... handled by a loop), row-block
+// group g of G = 1024 / 256 = 4
+__global__ __launch_bounds__(1024) void ss_segbase_kernel(u32* __restrict__ bs, const u32* __restrict__ blk_start, const u32* __restrict__ seg_start,
+                                                          u32 D, u32* __restrict__ next_start) {
+    __shared__ u32 part[4][512];
+    __shared__ u32 dstart[512];
+    __shared__ u32 wsum[16];
+    const u32 s = blockIdx.x;
+    const u32 b0 = blk_start[s], b1 = blk_start[s + 1];
+    const u32 t = threadIdx.x & 255u, g = threadIdx.x >> 8;
+    const u32 nb = b1 - b0, per = (nb + 3) / 4;
+    const u32 lo = b0 + (g * per < nb ? g * per : nb);
+    const u32 hi = (lo + per < b1) ? lo + per : b1;
+    for (u32 d = t; d < D; d += 256) {
+        u32 acc = 0;
+        u32 b = lo;
+        for (; b + 8 <= hi; b += 8) {
+            u32 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = bs[(size_t)(b + i) * D + d];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc += v[i];
+        }
+        for (; b < hi; ++b) acc += bs[(size_t)b * D + d];
+        part[g][d] = acc;
+    }
+    __syncthreads();
+    // exclusive scan of the D digit totals (D <= 512): thread i < 512 owns digit i
+    u32 tot = 0;
+    if (threadIdx.x < 512 && threadIdx.x < D) tot = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+    u32 inc = wave_inclusive_sum(tot);
+    if (lane_id() == 63) wsum[wave_id()] = inc;
+    __syncthreads();
+    if (threadIdx.x < 512) {
+        u32 run = 0;
+        for (int w = 0; w < wave_id(); ++w) run += wsum[w];
+        if (threadIdx.x < D) {
+            const u32 st = seg_start[s] + run + inc - tot;
+            dstart[threadIdx.x] = st;
+            next_start[(size_t)s * D + threadIdx.x] = st;
+        }
+    }
+    __syncthreads();
+    for (u32 d = t; d < D; d += 256) {
+        u32 run = dstart[d];
+        for (u32 k = 0; k < g; ++k) run += part[k][d];
+        u32 b = lo;
+        for (; b + 8 <= hi; b += 8) {
+            u32 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = bs[(size_t)(b + i) * D + d];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { bs[(size_t)(b + i) * D + d] = run; run += v[i]; }
+        }
+        for (; b < hi; ++b) { const u32 v = bs[(size_t)b * D + d]; bs[(size_t)b * D + d] = run; run += v; }
+    }
+}
+__global__ __launch_bounds__(256) void ss_apply_kernel(u32* __restrict__ counts, const u32* __restrict__ blk_start, u32 nseg, u32 R, u32 D,
+                                                       const u32* __restrict__ bs) {
+    const u32 b = blockIdx.x;
+    if (b >= blk_start[nseg]) return;
+    for (u32 d = threadIdx.x; d < D; d += 256) {
+        u32 run = bs[(size_t)b * D + d];
+        for (u32 r = 0; r < R; ++r) {
+            const size_t i = ((size_t)b * R + r) * D + d;
+            const u32 v = counts[i];
+            counts[i] = run;
+            run += v;
+        }
+    }
+}
+__global__ void ss_set_word_kernel(u32* p, u32 v) { *p = v; }
+
+// ---- scatter ------------------------------------------------------------------------------------------------------------------
+// rs_scatter_lds_kernel of prim.hip with a splitter digit: ranks inside the tile from a wave-level match (NB ballots per key)
+// plus per-wave counters; the tile is written to LDS in digit order first, so that consecutive lanes write consecutive pairs of
+// a digit's run.  The splitters (and, for GEN, the tile's recoded bytes) live in the staging buffer until the digits are known.
+template <bool GEN, bool LAST>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void ss_scatter_kernel(SSLevel P, TextKeyGen g, u32 rows) {
+    constexpr int NB = LAST ? 9 : 8;
+    constexpr int DMAX = LAST ? 512 : 256;
+    __shared__ u16 wcnt[4][DMAX];
+    __shared__ u32 gbase[DMAX];
+    __shared__ __align__(16) u64 stage[SS_TILE];
+    __shared__ u32 scan_sm[5];
+    __shared__ u8 code[GEN ? 256 : 4];
+    const int lane = lane_id(), w = wave_id();
+    const u32 row = xcd_tile(blockIdx.x, P.per_xcd);
+    if (row >= rows) return;
+    u32 s, cnt; size_t base;
+    if (!ss_row(P, row, s, base, cnt) || cnt == 0) return;
+    u64* spl = stage;                                       // 2 KB
+    u8* sy = (u8*)(stage + 256);                            // 4 KB + halo, behind the splitters
+    u16* stage_d = (u16*)(stage + 2048);                    // digits of the staged values: second half of the buffer
+    u32* stage32 = (u32*)stage;
+    for (int i = threadIdx.x; i < 4 * DMAX; i += 256) (&wcnt[0][0])[i] = 0;
+    ss_load_splitters<LAST>(P, s, spl);
+    if (GEN) code[threadIdx.x] = g.code[threadIdx.x];
+    __syncthreads();
+    if (GEN) { ss_gen_stage(g, base, code, sy); __syncthreads(); }
+
+    u64 k[SS_ITEMS];
+    u32 v[SS_ITEMS];
+    u32 ld[SS_ITEMS];                                       // digit << 16 | rank inside the (wave, digit) run, later position in the tile
+    volatile u16* mycnt = wcnt[w];
+    const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const u32 lbs = GEN ? (u32)(w * (64 * SS_ITEMS) + lane * SS_ITEMS) : (u32)(w * (64 * SS_ITEMS) + lane);
+    u64 gkey = 0;
+    if (GEN) gkey = ss_gen_key(g, sy, (int)lbs);
+#pragma unroll
+    for (int j = 0; j < SS_ITEMS; ++j) {
+        const u32 e = GEN ? lbs + (u32)j : lbs + (u32)j * 64;
+        const bool valid = e < cnt;
+        if (GEN) {
+            k[j] = gkey; v[j] = (u32)(base + e);
+            gkey = (gkey - (u64)sy[lbs + j] * g.top) * g.sigma + sy[lbs + j + g.k];
+        } else {
+            k[j] = valid ? P.keys_in[base + e] : 0ull;
+            v[j] = valid ? P.vals_in[base + e] : 0u;
+        }
+        const u32 d = valid ? ss_digit<LAST>(spl, k[j]) : 0u;
+        u64 peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const u64 bal = __ballot(bit);
+            peers &= bit ? bal : ~bal;
+        }
+        const u32 prefix = mycnt[d];
+        const u32 rank = (u32)__popcll(peers & lt_mask);
+        ld[j] = (d << 16) | (prefix + rank);
+        if (valid && rank == 0) mycnt[d] = (u16)(prefix + (u32)__popcll(peers));
+    }
+    __syncthreads();
+    {   // digit runs inside the sorted tile (exclusive scan over the digits), per-wave starts, global base
+        const u32 t = threadIdx.x;
+        u32 tot[DMAX / 256], sum = 0;
+#pragma unroll
+        for (int q = 0; q < DMAX / 256; ++q) {               // thread t owns the digits t * (DMAX / 256) + q
+            const u32 d = t * (DMAX / 256) + q;
+            tot[q] = (u32)wcnt[0][d] + wcnt[1][d] + wcnt[2][d] + wcnt[3][d];
+            sum += tot[q];
+        }
+        u32 total;
+        u32 start = block_exclusive_sum<u32, 4>(sum, scan_sm, total);
+#pragma unroll
+        for (int q = 0; q < DMAX / 256; ++q) {
+            const u32 d = t * (DMAX / 256) + q;
+            u32 run = start;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const u32 c = wcnt[i][d]; wcnt[i][d] = (u16)run; run += c; }
+            gbase[d] = (d < P.D ? P.counts[(size_t)row * P.D + d] : 0u) - start;
+            start += tot[q];
+        }
+    }
+    __syncthreads();                                       // splitters / text bytes are dead from here on
+    u32 dst[SS_ITEMS];
+#pragma unroll
+    for (int j = 0; j < SS_ITEMS; ++j) {
+        const u32 e = GEN ? lbs + (u32)j : lbs + (u32)j * 64;
+        const u32 d = ld[j] >> 16;
+        const u32 pos = (ld[j] & 0xFFFFu) + wcnt[w][d];        // position inside the sorted tile
+        ld[j] = pos;
+        if (e < cnt) { stage32[pos] = v[j]; stage_d[pos] = (u16)d; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < SS_ITEMS; ++r) {
+        const u32 sp = (u32)r * 256 + threadIdx.x;
+        dst[r] = 0xFFFFFFFFu;
+        if (sp < cnt) {
+            dst[r] = gbase[stage_d[sp]] + sp;
+            P.vals_out[dst[r]] = stage32[sp];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < SS_ITEMS; ++j) {
+        const u32 e = GEN ? lbs + (u32)j : lbs + (u32)j * 64;
+        if (e < cnt) stage[ld[j]] = k[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < SS_ITEMS; ++r) {
+        const u32 sp = (u32)r * 256 + threadIdx.x;
+        if (dst[r] != 0xFFFFFFFFu) P.keys_out[dst[r]] = stage[sp];
+    }
+}
+
+// ---- leaves -> units ----------------------------------------------------------------------------------------------------------
+// class of leaf l: 0 small (<= SS_SMALL pairs, packed with its neighbours), 1 medium (a unit of its own), 2 skip (a large
+// equality leaf: all keys equal), 3 large (LSD fall-back)
+__device__ __forceinline__ u32 ss_leaf_class(const u32* __restrict__ leaf_start, u32 l) {
+    const u32 size = leaf_start[l + 1] - leaf_start[l];
+    if (size <= SS_SMALL) return 0;
+    if (l & 1u) return 2;
+    return size <= SS_UNIT_MAX ? 1u : 3u;
+}
+__device__ __forceinline__ bool ss_unit_first(const u32* __restrict__ leaf_start, u32 l, u32 cls) {
+    if (cls == 1) return true;
+    if (cls != 0) return false;
+    if (l == 0) return true;
+    return ss_leaf_class(leaf_start, l - 1) != 0 || (leaf_start[l] / SS_SMALL) != (leaf_start[l - 1] / SS_SMALL);
+}
+__global__ void ss_unit_flag_kernel(const u32* __restrict__ leaf_start, u32 nleaf, u32* __restrict__ flag, u32* __restrict__ large_list,
+                                    u32* __restrict__ large_count, u32 large_cap) {
+    const u32 l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= nleaf) return;
+    const u32 cls = ss_leaf_class(leaf_start, l);
+    flag[l] = ss_unit_first(leaf_start, l, cls) ? 1u : 0u;
+    if (cls == 3) { const u32 i = atomicAdd(large_count, 1u); if (i < large_cap) large_list[i] = l; }
+}
+// uidx = exclusive scan of flag; unit_rng[2u] / [2u + 1] = first pair / end of unit u
+__global__ void ss_unit_fill_kernel(const u32* __restrict__ leaf_start, u32 nleaf, const u32* __restrict__ uidx, u32* __restrict__ unit_rng) {
+    const u32 l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= nleaf) return;
+    const u32 cls = ss_leaf_class(leaf_start, l);
+    if (cls > 1) return;
+    const bool first = ss_unit_first(leaf_start, l, cls);
+    const u32 u = uidx[l] - (first ? 0u : 1u);               // exclusive scan: a first leaf sees its own index, the others the next one
+    if (first) unit_rng[2 * u] = leaf_start[l];
+    bool last = (cls == 1) || (l + 1 == nleaf);
+    if (!last) {
+        const u32 c2 = ss_leaf_class(leaf_start, l + 1);
+        last = c2 != 0 || (leaf_start[l + 1] / SS_SMALL) != (leaf_start[l] / SS_SMALL);
+    }
+    if (last) unit_rng[2 * u + 1] = leaf_start[l + 1];
+}
+
+// ---- leaf sort: one workgroup sorts one unit of <= 8192 pairs in LDS (stable LSD passes on the bits in which its keys differ) --
+constexpr int LS_NW = 8;
+__global__ __launch_bounds__(LS_NW * 64) void ss_leaf_sort_kernel(u64* __restrict__ keys, u32* __restrict__ vals, const u32* __restrict__ unit_rng,
+                                                                   u32 nunits, u32* __restrict__ d_err) {
+    __shared__ u32 wcnt[LS_NW][256];
+    __shared__ u64 stage[SS_UNIT_MAX];
+    __shared__ u32 scan_sm[LS_NW + 1];
+    __shared__ u64 red[2][LS_NW];
+    const u32 u = blockIdx.x;
+    if (u >= nunits) return;
+    const u32 a = unit_rng[2 * u], b = unit_rng[2 * u + 1];
+    const u32 m = b - a;
+    if (m <= 1) return;
+    if (m > SS_UNIT_MAX) { if (threadIdx.x == 0) atomicOr(d_err, 2u); return; }
+    const int lane = lane_id(), w = wave_id();
+    const u32 rows = (m + LS_NW * 64 - 1) / (LS_NW * 64);      // 64-pair rows per wave
+    const u32 wbase = (u32)w * rows * 64 + (u32)lane;           // logical slot of (w, j, lane) = wbase + 64 j
+    u64 k[SS_ITEMS];
+    u32 v[SS_ITEMS];
+    u32 loc[SS_ITEMS];
+    u64 kmin = ~0ull, kmax = 0;
+#pragma unroll
+    for (int j = 0; j < SS_ITEMS; ++j) {
+        const u32 L = wbase + (u32)j * 64;
+        const bool valid = (u32)j < rows && L < m;
+        k[j] = valid ? keys[(size_t)a + L] : 0ull;
+        v[j] = valid ? vals[(size_t)a + L] : 0u;
+        if (valid) { kmin = k[j] < kmin ? k[j] : kmin; kmax = k[j] > kmax ? k[j] : kmax; }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const u64 o1 = __shfl_xor(kmin, d, 64), o2 = __shfl_xor(kmax, d, 64);
+        kmin = o1 < kmin ? o1 : kmin; kmax = o2 > kmax ? o2 : kmax;
+    }
+    if (lane == 0) { red[0][w] = kmin; red[1][w] = kmax; }
+    __syncthreads();
+    kmin = red[0][0]; kmax = red[1][0];
+#pragma unroll
+    for (int i = 1; i < LS_NW; ++i) { kmin = red[0][i] < kmin ? red[0][i] : kmin; kmax = red[1][i] > kmax ? red[1][i] : kmax; }
+    const u64 diff = kmin ^ kmax;
+    if (diff == 0) return;                                      // all keys equal
+    const int nbits = 64 - __clzll((long long)diff);
+    const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    volatile u32* mycnt = wcnt[w];
+    u32* stage32 = (u32*)stage;
+    for (int shift = 0; shift < nbits; shift += 8) {
+        for (int i = threadIdx.x; i < LS_NW * 256; i += LS_NW * 64) (&wcnt[0][0])[i] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < SS_ITEMS; ++j) {
+            if ((u32)j < rows) {
+                const bool valid = wbase + (u32)j * 64 < m;
+                const u32 d = (u32)(k[j] >> shift) & 255u;
+                u64 peers = __ballot(valid);
+#pragma unroll
+                for (int bb = 0; bb < 8; ++bb) {
+                    const bool bit = (d >> bb) & 1u;
+                    const u64 bal = __ballot(bit);
+                    peers &= bit ? bal : ~bal;
+                }
+                const u32 prefix = mycnt[d];
+                const u32 rank = (u32)__popcll(peers & lt_mask);
+                loc[j] = prefix + rank;
+                if (valid && rank == 0) mycnt[d] = prefix + (u32)__popcll(peers);
+            }
+        }
+        __syncthreads();
+        {
+            const u32 t = threadIdx.x;
+            u32 tot = 0;
+            if (t < 256) {
+#pragma unroll
+                for (int i = 0; i < LS_NW; ++i) tot += wcnt[i][t];
+            }
+            u32 total;
+            const u32 start = block_exclusive_sum<u32, LS_NW>(t < 256 ? tot : 0u, scan_sm, total);
+            if (t < 256) {
+                u32 run = start;
+#pragma unroll
+                for (int i = 0; i < LS_NW; ++i) { const u32 c = wcnt[i][t]; wcnt[i][t] = run; run += c; }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < SS_ITEMS; ++j) {
+            if ((u32)j < rows && wbase + (u32)j * 64 < m) {
+                loc[j] += wcnt[w][(u32)(k[j] >> shift) & 255u];
+                stage[loc[j]] = k[j];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < SS_ITEMS; ++j) if ((u32)j < rows && wbase + (u32)j * 64 < m) k[j] = stage[wbase + (u32)j * 64];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < SS_ITEMS; ++j) if ((u32)j < rows && wbase + (u32)j * 64 < m) stage32[loc[j]] = v[j];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < SS_ITEMS; ++j) if ((u32)j < rows && wbase + (u32)j * 64 < m) v[j] = stage32[wbase + (u32)j * 64];
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < SS_ITEMS; ++j) {
+        const u32 L = wbase + (u32)j * 64;
+        if ((u32)j < rows && L < m) { keys[(size_t)a + L] = k[j]; vals[(size_t)a + L] = v[j]; }
+    }
+}
+
+// ---- host ---------------------------------------------------------------------------------------------------------------------
+static u32 pow2_ceil(u64 x) { u32 p = 1; while ((u64)p < x) p <<= 1; return p; }
+
+bool splitter_sort_applicable(size_t n) { return n >= ((size_t)1 << 20) && n < ((size_t)1 << 32); }
+
+int splitter_sort_pairs_u64(Ctx& c, u64* keys[2], u32* vals[2], size_t n, const TextKeyGen* gen, SplitSortStats* st) {
+    SplitSortStats local;
+    if (!st) st = &local;
+    *st = SplitSortStats();
+    hipStream_t s = c.stream;
+    const size_t mark = c.arena.mark();
+    TextKeyGen g;
+    if (gen) g = *gen; else memset(&g, 0, sizeof(g));
+
+    // ---- fan-outs: two levels while 65536 range leaves keep the average leaf <= 4352 pairs (oversampling 64 then keeps a
+    // leaf below the 8192 of one workgroup: 5 sigma), three levels with leaves of ~2048 above; c.ssort_levels forces L (tests)
+    int L = n <= (size_t)256 * 3072 ? 1 : ((n + 65535) / 65536 <= 4352 ? 2 : 3);
+    if (c.ssort_levels >= 1 && c.ssort_levels <= 3) L = c.ssort_levels;
+    u32 F[3] = { 1, 1, 1 };
+    u32 os;
+    {
+        const u32 cap = L == 1 ? 256u : (L == 2 ? 65536u : (1u << 24));
+        u32 nl = pow2_ceil((n + (L == 3 ? 2047 : 3071)) / (L == 3 ? 2048 : 3072));
+        if (nl > cap) nl = cap;
+        if (nl < (2u << (L - 1))) nl = 2u << (L - 1);           // every level splits at least in two
+        const u32 lastF = nl > 256 ? 256u : (L == 1 ? nl : nl >> (L - 1));
+        F[L - 1] = lastF;
+        u32 rest = nl / lastF;
+        if (L == 2) F[0] = rest;
+        if (L == 3) { F[0] = 1; while ((u64)F[0] * F[0] < rest) F[0] <<= 1; F[1] = rest / F[0]; if (F[1] < 2) { F[1] = 2; } }
+        const u64 avg = (n + nl - 1) / nl;
+        os = avg > 3072 ? 64 : (avg > 2304 ? 32 : 16);
+    }
+    const u32 NLr = F[0] * F[1] * F[2];          // range leaves
+    const u32 NS = NLr - 1;
+    const u32 S = os * NLr;
+    st->levels = (u32)L; st->range_leaves = NLr; st->samples = S;
+
+    // ---- splitters -----------------------------------------------------------------------------------------------------------
+    u64* sp = c.arena.get<u64>((size_t)NS + 1);
+    {
+        const size_t m2 = c.arena.mark();
+        u64* sk[2] = { c.arena.get<u64>(S), c.arena.get<u64>(S) };
+        u32* sv[2] = { c.arena.get<u32>(S), c.arena.get<u32>(S) };
+        if (gen) ss_sample_kernel<true><<<cdiv(S, 256), 256, 0, s>>>(nullptr, g, n, S, sk[0], sv[0]);
+        else ss_sample_kernel<false><<<cdiv(S, 256), 256, 0, s>>>(keys[0], g, n, S, sk[0], sv[0]);
+        LAUNCH_CHECK();
+        const int x = radix_sort_pairs_u64(c, sk, sv, S, 0, 64);
+        ss_pick_kernel<<<cdiv((size_t)NS + 1, 256), 256, 0, s>>>(sk[x], NS, os, sp);
+        LAUNCH_CHECK();
+        c.arena.release(m2);
+    }
+
+    // ---- partition levels ----------------------------------------------------------------------------------------------------
+    u32* seg_start = c.arena.get<u32>(2);
+    ss_set_word_kernel<<<1, 1, 0, s>>>(seg_start, 0u);
+    LAUNCH_CHECK();
+    ss_set_word_kernel<<<1, 1, 0, s>>>(seg_start + 1, (u32)n);
+    LAUNCH_CHECK();
+    u32 nseg = 1;
+    int cur = gen ? -1 : 0;                                   // buffer pair that holds the level's input (-1: the text)
+    for (int l = 0; l < L; ++l) {
+        const bool last = (l == L - 1);
+        const bool gl = gen && l == 0;
+        const u32 D = last ? 2 * F[l] : F[l];
+        u32 stride = 1;
+        for (int q = l + 1; q < L; ++q) stride *= F[q];
+        // rows per row block: long blocks while there are few segments, short ones when segments are small
+        const u64 tiles = (n + SS_TILE - 1) / SS_TILE;
+        u32 R = 128;
+        while (R > 1 && (u64)nseg * R > tiles / 8 + 64) R >>= 1;
+        const u32 blocks_ub = (u32)((tiles + R - 1) / R) + nseg;
+        const u32 rows = blocks_ub * R;
+        // the next level's segment starts are allocated below the level's scratch, so they survive its release
+        u32* nstart = c.arena.get<u32>((size_t)nseg * D + 1);
+        const size_t lm2 = c.arena.mark();
+        u32* blk_start = c.arena.get<u32>((size_t)nseg + 1);
+        u32* blk_seg = c.arena.get<u32>(blocks_ub);
+        u32* counts = c.arena.get<u32>((size_t)rows * D);
+        u32* bs = c.arena.get<u32>((size_t)blocks_ub * D);
+        ss_nblk_kernel<<<cdiv((size_t)nseg + 1, 256), 256, 0, s>>>(seg_start, nseg, R, blk_start);
+        LAUNCH_CHECK();
+        exclusive_sum_u32(c, blk_start, blk_start, (size_t)nseg + 1, nullptr);
+        ss_blkseg_kernel<<<cdiv(nseg, 256), 256, 0, s>>>(blk_start, nseg, blk_seg);
+        LAUNCH_CHECK();
+        SSLevel P;
+        P.keys_in = cur >= 0 ? keys[cur] : nullptr; P.vals_in = cur >= 0 ? vals[cur] : nullptr;
+        const int nxt = cur < 0 ? 0 : (cur ^ 1);
+        P.keys_out = keys[nxt]; P.vals_out = vals[nxt];
+        P.counts = counts; P.blk_seg = blk_seg; P.blk_start = blk_start; P.seg_start = seg_start; P.sp = sp;
+        P.nseg = nseg; P.F = F[l]; P.stride = stride; P.R = R; P.D = D;
+        P.per_xcd = (c.xcd_remap == 1 && rows >= 64) ? cdiv(rows, 8) : 0u;
+        const u32 grid = P.per_xcd ? 8 * P.per_xcd : rows;
+        {
+            const int pc = c.prof_begin(K_RS_COUNT, (u64)n * (gl ? 1 : 8));
+            if (gl && last) ss_count_kernel<true, true><<<grid, 256, 0, s>>>(P, g, rows);
+            else if (gl) ss_count_kernel<true, false><<<grid, 256, 0, s>>>(P, g, rows);
+            else if (last) ss_count_kernel<false, true><<<grid, 256, 0, s>>>(P, g, rows);
+            else ss_count_kernel<false, false><<<grid, 256, 0, s>>>(P, g, rows);
+            LAUNCH_CHECK();
+            c.prof_end(pc);
+        }
+        {
+            Ctx::ProfScope prof(c, K_SCAN, (u64)rows * D * 12);
+            ss_blocksum_kernel<<<blocks_ub, 256, 0, s>>>(counts, blk_start, nseg, R, D, bs);
+            LAUNCH_CHECK();
+            ss_segbase_kernel<<<nseg, 1024, 0, s>>>(bs, blk_start, seg_start, D, nstart);
+            LAUNCH_CHECK();
+            ss_set_word_kernel<<<1, 1, 0, s>>>(nstart + (size_t)nseg * D, (u32)n);
+            LAUNCH_CHECK();
+            ss_apply_kernel<<<blocks_ub, 256, 0, s>>>(counts, blk_start, nseg, R, D, bs);
+            LAUNCH_CHECK();
+        }
+        {
+            const int ps = c.prof_begin(K_RS_SCATTER_U64, (u64)n * (gl ? 13 : 24));
+            if (gl && last) ss_scatter_kernel<true, true><<<grid, 256, 0, s>>>(P, g, rows);
+            else if (gl) ss_scatter_kernel<true, false><<<grid, 256, 0, s>>>(P, g, rows);
+            else if (last) ss_scatter_kernel<false, true><<<grid, 256, 0, s>>>(P, g, rows);
+            else ss_scatter_kernel<false, false><<<grid, 256, 0, s>>>(P, g, rows);
+            LAUNCH_CHECK();
+            c.prof_end(ps);
+        }
+        c.arena.release(lm2);
+        seg_start = nstart;
+        nseg = nseg * D;
+        cur = nxt;
+    }
+    const u32 nleaf = nseg;
+    const u32* leaf_start = seg_start;
+
+    // ---- units + leaf sort ---------------------------------------------------------------------------------------------------
+    constexpr u32 LARGE_CAP = 1024;
+    u32* flag = c.arena.get<u32>((size_t)nleaf + 1);
+    u32* unit_rng = c.arena.get<u32>(2 * ((size_t)nleaf + 1));
+    u32* large = c.arena.get<u32>(LARGE_CAP + 2);              // [0] = count of large leaves, [1] = number of units, then the list
+    HIP_TRY(hipMemsetAsync(large, 0, 2 * sizeof(u32), s));
+    ss_unit_flag_kernel<<<cdiv(nleaf, 256), 256, 0, s>>>(leaf_start, nleaf, flag, large + 2, large, LARGE_CAP);
+    LAUNCH_CHECK();
+    exclusive_sum_u32(c, flag, flag, nleaf, large + 1);
+    ss_unit_fill_kernel<<<cdiv(nleaf, 256), 256, 0, s>>>(leaf_start, nleaf, flag, unit_rng);
+    LAUNCH_CHECK();
+    u32 hc[2];
+    c.read_n(large, hc, 2);
+    const u32 nlarge = hc[0], nunits = hc[1];
+    st->units = nunits; st->large_leaves = nlarge;
+    if (nunits) {
+        Ctx::ProfScope prof(c, K_SS_LEAF, (u64)n * 24);
+        ss_leaf_sort_kernel<<<nunits, LS_NW * 64, 0, s>>>(keys[cur], vals[cur], unit_rng, nunits, c.d_err);
+        LAUNCH_CHECK();
+    }
+    if (nlarge) {                                              // leaves above the workgroup capacity: LSD sort, one by one
+        if (nlarge > LARGE_CAP) throw HipError{hipErrorUnknown, "splitter sort: too many oversized leaves", (int)__LINE__};
+        std::vector<u32> ll(nlarge), ls((size_t)nleaf + 1);
+        HIP_TRY(hipMemcpyAsync(ll.data(), large + 2, nlarge * sizeof(u32), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(ls.data(), leaf_start, ((size_t)nleaf + 1) * sizeof(u32), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        for (u32 i = 0; i < nlarge; ++i) {
+            const size_t a = ls[ll[i]], b = ls[ll[i] + 1];
+            u64* kk[2] = { keys[cur] + a, keys[cur ^ 1] + a };
+            u32* vv[2] = { vals[cur] + a, vals[cur ^ 1] + a };
+            const int y = radix_sort_pairs_u64(c, kk, vv, b - a, 0, 64);
+            if (y == 1) {
+                HIP_TRY(hipMemcpyAsync(kk[0], kk[1], (b - a) * sizeof(u64), hipMemcpyDeviceToDevice, s));
+                HIP_TRY(hipMemcpyAsync(vv[0], vv[1], (b - a) * sizeof(u32), hipMemcpyDeviceToDevice, s));
+            }
+            st->large_pairs += b - a;
+        }
+    }
+    c.arena.release(mark);
+    return cur;
+}
+
+}  // namespace tdc

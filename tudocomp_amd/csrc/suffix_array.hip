@@ -244,7 +244,8 @@ void build_suffix_array(Ctx& c, const u8* text, size_t n, u32* sa, u32* isa, SAS
         g.text = text; g.n = n; g.sigma = base; g.k = k; g.chunk = chunk;
         g.top = 1; for (int i = 1; i < k; ++i) g.top *= base;
         memcpy(g.code, cm.code, 256);
-        x = radix_sort_text_keys_u64(c, g, keys, vals, key_bits);
+        if (c.ssort && splitter_sort_applicable(n)) x = splitter_sort_pairs_u64(c, keys, vals, n, &g, nullptr);   // 2-3 partition levels + leaf sort
+        else x = radix_sort_text_keys_u64(c, g, keys, vals, key_bits);
     } else {
         sa_init_keys_kernel<<<cdiv(n, 1024), 256, 0, s>>>(text, n, cm, base, k, chunk, keys[0], vals[0]);
         LAUNCH_CHECK();
@@ -287,13 +288,17 @@ void build_suffix_array(Ctx& c, const u8* text, size_t n, u32* sa, u32* isa, SAS
         if (c.sa_local_sort) {
             // local part: whole runs inside 2048-element tiles; global part: only the runs that cross a tile border
             u8* cls = (u8*)keep;                                   // scratch (keep is rewritten by sa_update_kernel)
-            sa_local_sort_kernel<<<cdiv(m, 2048), 256, 0, s>>>(keys[0], vals[0], m, bn, cls);
-            LAUNCH_CHECK();
+            {
+                Ctx::ProfScope prof(c, K_SA_LOCAL_SORT, (u64)m * 25);
+                sa_local_sort_kernel<<<cdiv(m, 2048), 256, 0, s>>>(keys[0], vals[0], m, bn, cls);
+                LAUNCH_CHECK();
+            }
             u32* opos = B_sa;                                      // B_* are free until the compaction of this round
             select_by_class(c, cls, 1, m, nullptr, opos, nullptr, nullptr, d_total);
             const size_t mo = c.read(d_total);
             if (mo > n / 2) {                                      // a few giant runs: sort everything globally
-                x = radix_sort_pairs_u64(c, keys, vals, m, 0, 2 * bn);
+                x = (c.ssort && splitter_sort_applicable(m)) ? splitter_sort_pairs_u64(c, keys, vals, m, nullptr, nullptr)
+                                                              : radix_sort_pairs_u64(c, keys, vals, m, 0, 2 * bn);
                 st->sorted_elems += m;
             } else {
             st->sorted_elems += mo;
@@ -301,7 +306,8 @@ void build_suffix_array(Ctx& c, const u8* text, size_t n, u32* sa, u32* isa, SAS
                 u64* ok2[2] = { keys[1], lkeys };
                 u32* ov2[2] = { vals[1], lvals };
                 select_by_class(c, cls, 1, m, vals[0], ov2[0], keys[0], ok2[0], d_total);
-                const int y = radix_sort_pairs_u64(c, ok2, ov2, mo, 0, 2 * bn);
+                const int y = (c.ssort && splitter_sort_applicable(mo)) ? splitter_sort_pairs_u64(c, ok2, ov2, mo, nullptr, nullptr)
+                                                                        : radix_sort_pairs_u64(c, ok2, ov2, mo, 0, 2 * bn);
                 sa_scatter_back_kernel<<<cdiv(mo, 256), 256, 0, s>>>(opos, ok2[y], ov2[y], mo, keys[0], vals[0]);
                 LAUNCH_CHECK();
             }
