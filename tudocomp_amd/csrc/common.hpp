@@ -283,6 +283,30 @@ __device__ __forceinline__ u32 wave_reduce_min(u32 v) {
     return v;
 }
 
+// LDS accesses that must really happen (counters and tables shared between the lanes of a wave, re-read after another lane
+// wrote them).  A `volatile` access through an ordinary pointer is compiled to a FLAT instruction with system-coherence bits
+// plus a full wait (the address-space inference leaves volatile accesses alone): several times the cost of a ds_ instruction.
+// The cast to the LDS address space keeps the access volatile AND a ds_read / ds_write.
+template <typename T> __device__ __forceinline__ T lds_load(const T* p) { return *(const volatile __attribute__((address_space(3))) T*)p; }
+template <typename T> __device__ __forceinline__ void lds_store(T* p, T v) { *(volatile __attribute__((address_space(3))) T*)p = v; }
+
+// Wave-level match through LDS: returns the mask of the lanes of this wave that hold a valid key with the same digit.
+// Every lane ORs its bit into the digit's slot of the wave's private table M (256 or 512 x u64, all zero on entry), reads the slot
+// back and clears it again (zero on exit).  OR is order-independent, so the result does not depend on how the LDS unit serialises
+// lanes that hit the same slot; LDS instructions of one wave execute in order.  The alternative -- one ballot per digit bit and
+// five 64-bit-mask VALU operations per lane for each of them -- made every radix pass VALU-bound on CDNA (a wave64 instruction
+// occupies a 16-lane SIMD for 4 cycles): ~46 VALU instructions per key against ~10 + 3 LDS operations.
+__device__ __forceinline__ u64 wave_match_lds(unsigned long long* M, u32 d, bool valid, u64 lanebit) {
+    const u32 d0 = __builtin_amdgcn_readfirstlane(d);
+    if (__all(valid && d == d0)) return ~0ull;                   // whole row in one bin (high-order digits, long runs)
+    if (valid) atomicOr(&M[d], (unsigned long long)lanebit);
+    __builtin_amdgcn_wave_barrier();
+    const u64 peers = valid ? lds_load(&M[d]) : 0ull;
+    __builtin_amdgcn_wave_barrier();
+    if (valid) lds_store(&M[d], 0ull);
+    return peers;
+}
+
 // Block-wide exclusive sum for a block of NW waves (NW*64 threads).  `smem` must hold NW+1 values of T.
 // Returns the exclusive prefix of `v` over the block in thread order; `total` receives the block sum.
 template <typename T, int NW>

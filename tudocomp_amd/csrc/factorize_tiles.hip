@@ -77,11 +77,10 @@ __device__ __forceinline__ bool e_before(u64 a, u64 b) {
     return (fa != fb) ? (fa < fb) : ((u32)a < (u32)b);
 }
 __device__ __forceinline__ u64 e_key(u64 e) { return ((u64)((e_hi(e) >> 23) & 1u) << 32) | (u32)e; }
-__device__ __forceinline__ void e_set_state(u64* ent, int i, u32 st) { ((volatile u8*)&ent[i])[6] = (u8)st; }
-__device__ __forceinline__ void e_set_val(u64* ent, int i, u32 v) { ((volatile u8*)&ent[i])[7] = (u8)v; }
-__device__ __forceinline__ u64 e_load(const u64* ent, int i) {
-    return *(const volatile u64*)&ent[i];
-}
+// (entries are re-read after other threads changed them: lds_load / lds_store keep the accesses real ds_ instructions)
+__device__ __forceinline__ void e_set_state(u64* ent, int i, u32 st) { lds_store((u8*)&ent[i] + 6, (u8)st); }
+__device__ __forceinline__ void e_set_val(u64* ent, int i, u32 v) { lds_store((u8*)&ent[i] + 7, (u8)v); }
+__device__ __forceinline__ u64 e_load(const u64* ent, int i) { return lds_load(&ent[i]); }
 
 struct WinScalars { u32 fail; int min_margin; unsigned long long factors; u32 max_entries, max_pushes; unsigned long long prof[16]; };
 
@@ -180,7 +179,7 @@ __global__ __launch_bounds__(TT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
 
         for (u32 L = lcut; L >= threshold && !failed; --L) {
             const int iL = (int)L;
-            if (((*(volatile u64*)&s_lvlmask >> L) & 1ull) == 0) { fl += iL - 1; fr -= iL - 1; continue; }   // nothing resides in list L
+            if (((lds_load(&s_lvlmask) >> L) & 1ull) == 0) { fl += iL - 1; fr -= iL - 1; continue; }   // nothing resides in list L
             const int lo = fl > 0 ? fl : 0, hi = fr < wl ? fr : wl;
             // ---- 1. collect the alive entries of list L in position order --------------------------------------
             const int base = tid * TCH;
@@ -255,7 +254,7 @@ __global__ __launch_bounds__(TT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
             // rotating counters: a round reads s_und[r], counts the entries it leaves undecided in s_und[r+1], clears s_und[r+2]
             int r = 0;
             for (int guard = 0; guard <= m; ++guard) {
-                const int und = *(volatile int*)&s_und[r];
+                const int und = lds_load(&s_und[r]);
                 if (und == 0) break;
                 const int rn = (r + 1) % 3, rc = (r + 2) % 3;
                 if (tid == 0) s_und[rc] = 0;
@@ -292,7 +291,7 @@ __global__ __launch_bounds__(TT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                 WPROF_CNT(10, 1);
             }
             WPROF(4);
-            if (*(volatile int*)&s_und[r] != 0) { failed = true; break; }     // cannot happen (the best undecided entry always decides)
+            if (lds_load(&s_und[r]) != 0) { failed = true; break; }     // cannot happen (the best undecided entry always decides)
 
             // ---- 3. encounter values of the stale and the rejected entries, taint of the uncertain ones; the selected
             //         entries truncate the positions in front of them (their ranges are disjoint) and are written out ------

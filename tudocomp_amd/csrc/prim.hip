@@ -452,7 +452,7 @@ __global__ __launch_bounds__(NW * 64) void rs_scatter_kernel(const K* __restrict
     K k[RS_ITEMS];
     u32 v[RS_ITEMS];
     u32 loc[RS_ITEMS];
-    volatile u32* mycnt = wcnt[w];
+    u32* mycnt = wcnt[w];
     const size_t tileBase = (size_t)tile * (NW * 64 * RS_ITEMS) + (size_t)w * (64 * RS_ITEMS) + lane;
     const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
@@ -469,10 +469,10 @@ __global__ __launch_bounds__(NW * 64) void rs_scatter_kernel(const K* __restrict
             const u64 bal = __ballot(bit);
             peers &= bit ? bal : ~bal;
         }
-        const u32 prefix = mycnt[d];
+        const u32 prefix = lds_load(&mycnt[d]);
         const u32 rank = (u32)__popcll(peers & lt_mask);
         loc[j] = prefix + rank;
-        if (valid && rank == 0) mycnt[d] = prefix + (u32)__popcll(peers);   // leader = lowest valid lane of the group
+        if (valid && rank == 0) lds_store(&mycnt[d], prefix + (u32)__popcll(peers));   // leader = lowest valid lane of the group
     }
     __syncthreads();
     if (threadIdx.x < 256) {
@@ -506,18 +506,21 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
     constexpr int TILE = NW * 64 * RS_ITEMS;
     __shared__ u32 wcnt[NW][256];     // per-wave digit counts, then start of the (wave, digit) run inside the sorted tile
     __shared__ u32 gbase[256];        // global start of the digit's run minus its start inside the sorted tile
-    __shared__ K stage[TILE];
+    __shared__ __align__(8) K stage[TILE];               // >= NW * 2 KB for both key widths
     __shared__ u32 scan_sm[NW + 1];
     const int lane = lane_id(), w = wave_id();
     const u32 tile = xcd_tile(blockIdx.x, per_xcd);
     if (tile >= numTiles) return;
-    for (int i = threadIdx.x; i < NW * 256; i += NW * 64) (&wcnt[0][0])[i] = 0;
+    for (int i = threadIdx.x; i < NW * 256; i += NW * 64) { (&wcnt[0][0])[i] = 0; ((unsigned long long*)stage)[i] = 0; }
     __syncthreads();
+    // the wave's lane-mask table of the LDS match: in the staging buffer, which is not needed before all ranks are known
+    unsigned long long* M = (unsigned long long*)stage + w * 256;
+    const u64 lanebit = 1ull << lane;
 
     K k[RS_ITEMS];
     u32 v[RS_ITEMS];
     u32 loc[RS_ITEMS];
-    volatile u32* mycnt = wcnt[w];
+    u32* mycnt = wcnt[w];
     const size_t tileBase = (size_t)tile * TILE + (size_t)w * (64 * RS_ITEMS) + lane;
     const u32 tileCount = (u32)(((size_t)(tile + 1) * TILE <= n) ? (size_t)TILE : n - (size_t)tile * TILE);
     const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -528,17 +531,11 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
         k[j] = valid ? keys_in[idx] : (K)0;
         v[j] = valid ? vals_in[idx] : 0u;
         const u32 d = (u32)((k[j] >> shift) & dmask);
-        u64 peers = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const bool bit = (d >> b) & 1u;
-            const u64 bal = __ballot(bit);
-            peers &= bit ? bal : ~bal;
-        }
-        const u32 prefix = mycnt[d];
+        const u64 peers = wave_match_lds(M, d, valid, lanebit);
+        const u32 prefix = lds_load(&mycnt[d]);
         const u32 rank = (u32)__popcll(peers & lt_mask);
         loc[j] = prefix + rank;
-        if (valid && rank == 0) mycnt[d] = prefix + (u32)__popcll(peers);
+        if (valid && rank == 0) lds_store(&mycnt[d], prefix + (u32)__popcll(peers));
     }
     __syncthreads();
     {   // thread t = digit t: runs inside the sorted tile (exclusive scan over the digits), per-wave starts, global base
@@ -719,17 +716,19 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
     const u32 tile = xcd_tile(blockIdx.x, per_xcd);
     if (tile >= numTiles) return;
     const size_t n = g.n;
-    for (int i = threadIdx.x; i < NW * 256; i += NW * 64) (&wcnt[0][0])[i] = 0;
+    for (int i = threadIdx.x; i < NW * 256; i += NW * 64) { (&wcnt[0][0])[i] = 0; ((unsigned long long*)stage)[1024 + i] = 0; }
     for (int i = threadIdx.x; i < 256; i += NW * 64) code[i] = g.code[i];
     __syncthreads();
     u8* sy = (u8*)stage;                                  // recoded bytes of the tile; dead before `stage` is written
+    unsigned long long* M = (unsigned long long*)stage + 1024 + w * 256;     // lane-mask tables of the LDS match, behind the bytes
+    const u64 lanebit = 1ull << lane;
     const size_t t0 = (size_t)tile * TILE;
     gen_stage_tile<NW>(g, t0, code, sy);
     __syncthreads();
 
     K k[RS_ITEMS];
     u32 loc[RS_ITEMS];
-    volatile u32* mycnt = wcnt[w];
+    u32* mycnt = wcnt[w];
     const int lb = w * (64 * RS_ITEMS) + lane * RS_ITEMS;  // a lane owns RS_ITEMS consecutive positions (see rs_gen_count_kernel)
     const size_t tileBase = t0 + lb;
     const u32 tileCount = (u32)(((size_t)(tile + 1) * TILE <= n) ? (size_t)TILE : n - t0);
@@ -749,17 +748,11 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
         const bool valid = tileBase + (size_t)j < n;
         k[j] = valid ? key : (K)0;
         const u32 d = (u32)(k[j] & dmask);
-        u64 peers = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const bool bit = (d >> b) & 1u;
-            const u64 bal = __ballot(bit);
-            peers &= bit ? bal : ~bal;
-        }
-        const u32 prefix = mycnt[d];
+        const u64 peers = wave_match_lds(M, d, valid, lanebit);
+        const u32 prefix = lds_load(&mycnt[d]);
         const u32 rank = (u32)__popcll(peers & lt_mask);
         loc[j] = prefix + rank;
-        if (valid && rank == 0) mycnt[d] = prefix + (u32)__popcll(peers);
+        if (valid && rank == 0) lds_store(&mycnt[d], prefix + (u32)__popcll(peers));
         key = (key - (u64)lead[j] * g.top) * g.sigma + enter[j];
     }
     __syncthreads();
@@ -885,27 +878,23 @@ __global__ __launch_bounds__(MID_NW * 64) void one_workgroup_radix_sort_kernel(c
         v[j] = (idx < n) ? vals_in[idx] : 0u;
     }
     const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    volatile u32* mycnt = wcnt[w];
+    u32* mycnt = wcnt[w];
     u32* stage32 = (u32*)stage;
+    unsigned long long* M = (unsigned long long*)stage + w * 256;     // lane-mask table of the LDS match (the staging buffer is idle while ranking)
+    const u64 lanebit = 1ull << lane;
     for (int shift = begin_bit; shift < end_bit; shift += 8) {
         const int bits = (end_bit - shift) < 8 ? (end_bit - shift) : 8;
         const u32 dmask = (1u << bits) - 1u;
-        for (int i = threadIdx.x; i < NW * 256; i += NW * 64) (&wcnt[0][0])[i] = 0;
+        for (int i = threadIdx.x; i < NW * 256; i += NW * 64) { (&wcnt[0][0])[i] = 0; stage[i] = 0; }   // counters + lane-mask tables
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < RS_ITEMS; ++j) {
             const u32 d = (u32)((k[j] >> shift) & dmask);
-            u64 peers = ~0ull;
-#pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                const bool bit = (d >> b) & 1u;
-                const u64 bal = __ballot(bit);
-                peers &= bit ? bal : ~bal;
-            }
-            const u32 prefix = mycnt[d];
+            const u64 peers = wave_match_lds(M, d, true, lanebit);
+            const u32 prefix = lds_load(&mycnt[d]);
             const u32 rank = (u32)__popcll(peers & lt_mask);
             loc[j] = prefix + rank;
-            if (rank == 0) mycnt[d] = prefix + (u32)__popcll(peers);
+            if (rank == 0) lds_store(&mycnt[d], prefix + (u32)__popcll(peers));
         }
         __syncthreads();
         {

@@ -27,7 +27,7 @@ int radix_sort_text_keys_u64(Ctx& c, const TextKeyGen& g, u64* keys[2], u32* val
 // (sampled splitters) plus one in-LDS sort of the leaves -- instead of eight LSD passes.  gen != nullptr: the pairs are
 // (key(i), i) of the text as in radix_sort_text_keys_u64 and keys[0] / vals[0] are not read; else keys[0] / vals[0] hold the
 // input.  Both buffer pairs are used; returns the index of the pair that holds the result.
-struct SplitSortStats { u32 levels = 0, range_leaves = 0, samples = 0, units = 0, large_leaves = 0; u64 large_pairs = 0; };
+struct SplitSortStats { u32 levels = 0, range_leaves = 0, samples = 0, units = 0, large_leaves = 0, wide_units = 0; u64 large_pairs = 0; };
 bool splitter_sort_applicable(size_t n);
 int splitter_sort_pairs_u64(Ctx& c, u64* keys[2], u32* vals[2], size_t n, const TextKeyGen* gen, SplitSortStats* st);
 

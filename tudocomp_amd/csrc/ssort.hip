@@ -42,6 +42,7 @@ struct SSLevel {
     const u32* blk_start;        // [nseg + 1] first row block of every segment
     const u32* seg_start;        // [nseg + 1] first pair of every segment
     const u64* sp;               // [NS + 1] splitters, sp[NS] = ~0
+    u16* digits;                 // [n] the level's digit of every pair of the input, written by the count pass for the scatter pass
     u32 nseg, F, stride, R, D, per_xcd;
 };
 
@@ -188,22 +189,34 @@ __global__ __launch_bounds__(256) void ss_count_kernel(SSLevel P, TextKeyGen g, 
     if (GEN) {
         const int lb = wave_id() * (64 * SS_ITEMS) + lane_id() * SS_ITEMS;      // a lane owns 16 consecutive positions
         u64 key = ss_gen_key(g, sy, lb);
-#pragma unroll 4
+        u32 pk[SS_ITEMS / 2];
+#pragma unroll
         for (int j = 0; j < SS_ITEMS; ++j) {
             const bool valid = (u32)(lb + j) < cnt;
             const u32 d = valid ? ss_digit<LAST>(spl, key) : 0u;
             key = (key - (u64)sy[lb + j] * g.top) * g.sigma + sy[lb + j + g.k];
+            pk[j >> 1] = (j & 1) ? (pk[j >> 1] | (d << 16)) : d;
             const u32 d0 = __builtin_amdgcn_readfirstlane(d);
             if (__all(valid && d == d0)) { if (lane_id() == 0) atomicAdd(&hist[d0], 64u); }
             else if (valid) atomicAdd(&hist[d], 1u);
         }
+        // the lane's 16 digits: 32 bytes, 32-byte aligned (tiles start at multiples of 4096); the array is padded to whole tiles
+        uint4* dp = (uint4*)(P.digits + base + lb);
+        dp[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        dp[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
     } else {
         const u32 lb = wave_id() * (64 * SS_ITEMS) + lane_id();
+        const u64* kp = P.keys_in + base + lb;
+        u16* dgp = P.digits + base + lb;
+        u64 kk[SS_ITEMS];
+#pragma unroll
+        for (int j = 0; j < SS_ITEMS; ++j) kk[j] = (lb + (u32)j * 64 < cnt) ? kp[j * 64] : 0ull;
 #pragma unroll 4
         for (int j = 0; j < SS_ITEMS; ++j) {
             const u32 e = lb + (u32)j * 64;
             const bool valid = e < cnt;
-            const u32 d = valid ? ss_digit<LAST>(spl, P.keys_in[base + e]) : 0u;
+            const u32 d = valid ? ss_digit<LAST>(spl, kk[j]) : 0u;
+            if (valid) dgp[j * 64] = (u16)d;
             const u32 d0 = __builtin_amdgcn_readfirstlane(d);
             if (__all(valid && d == d0)) { if (lane_id() == 0) atomicAdd(&hist[d0], 64u); }
             else if (valid) atomicAdd(&hist[d], 1u);
@@ -305,9 +318,8 @@ __global__ void ss_set_word_kernel(u32* p, u32 v) { *p = v; }
 // a digit's run.  The splitters (and, for GEN, the tile's recoded bytes) live in the staging buffer until the digits are known.
 template <bool GEN, bool LAST>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void ss_scatter_kernel(SSLevel P, TextKeyGen g, u32 rows) {
-    constexpr int NB = LAST ? 9 : 8;
     constexpr int DMAX = LAST ? 512 : 256;
-    __shared__ u16 wcnt[4][DMAX];
+    __shared__ __align__(16) u16 wcnt[4][DMAX];
     __shared__ u32 gbase[DMAX];
     __shared__ __align__(16) u64 stage[SS_TILE];
     __shared__ u32 scan_sm[5];
@@ -317,12 +329,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     if (row >= rows) return;
     u32 s, cnt; size_t base;
     if (!ss_row(P, row, s, base, cnt) || cnt == 0) return;
-    u64* spl = stage;                                       // 2 KB
-    u8* sy = (u8*)(stage + 256);                            // 4 KB + halo, behind the splitters
+    u8* sy = (u8*)stage;                                    // GEN: recoded bytes of the tile, 4 KB + halo
     u16* stage_d = (u16*)(stage + 2048);                    // digits of the staged values: second half of the buffer
     u32* stage32 = (u32*)stage;
-    for (int i = threadIdx.x; i < 4 * DMAX; i += 256) (&wcnt[0][0])[i] = 0;
-    ss_load_splitters<LAST>(P, s, spl);
+    unsigned long long* M = (unsigned long long*)stage + 1024 + w * DMAX;    // lane-mask tables of the LDS match: bytes 8 K .. 24 K
+    for (int i = threadIdx.x; i < 4 * DMAX; i += 256) { (&wcnt[0][0])[i] = 0; ((unsigned long long*)stage)[1024 + i] = 0; }
     if (GEN) code[threadIdx.x] = g.code[threadIdx.x];
     __syncthreads();
     if (GEN) { ss_gen_stage(g, base, code, sy); __syncthreads(); }
@@ -330,34 +341,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     u64 k[SS_ITEMS];
     u32 v[SS_ITEMS];
     u32 ld[SS_ITEMS];                                       // digit << 16 | rank inside the (wave, digit) run, later position in the tile
-    volatile u16* mycnt = wcnt[w];
+    u16* mycnt = wcnt[w];
+    const u64 lanebit = 1ull << lane;
     const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const u32 lbs = GEN ? (u32)(w * (64 * SS_ITEMS) + lane * SS_ITEMS) : (u32)(w * (64 * SS_ITEMS) + lane);
     u64 gkey = 0;
-    if (GEN) gkey = ss_gen_key(g, sy, (int)lbs);
+    u32 pk[SS_ITEMS / 2];                                   // GEN: the lane's 16 digits as written by the count pass
+    if (GEN) {
+        gkey = ss_gen_key(g, sy, (int)lbs);
+        const uint4* dp = (const uint4*)(P.digits + base + lbs);
+        const uint4 q0 = dp[0], q1 = dp[1];
+        pk[0] = q0.x; pk[1] = q0.y; pk[2] = q0.z; pk[3] = q0.w; pk[4] = q1.x; pk[5] = q1.y; pk[6] = q1.z; pk[7] = q1.w;
+    }
+    const u64* kp = GEN ? nullptr : P.keys_in + base + lbs;
+    const u32* vp = GEN ? nullptr : P.vals_in + base + lbs;
+    const u16* dgp = P.digits + base + lbs;
 #pragma unroll
-    for (int j = 0; j < SS_ITEMS; ++j) {
+    for (int j = 0; j < SS_ITEMS; ++j) {                    // all global loads first: they overlap, the ranking below is a chain of LDS operations
         const u32 e = GEN ? lbs + (u32)j : lbs + (u32)j * 64;
         const bool valid = e < cnt;
         if (GEN) {
             k[j] = gkey; v[j] = (u32)(base + e);
             gkey = (gkey - (u64)sy[lbs + j] * g.top) * g.sigma + sy[lbs + j + g.k];
+            ld[j] = (pk[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
         } else {
-            k[j] = valid ? P.keys_in[base + e] : 0ull;
-            v[j] = valid ? P.vals_in[base + e] : 0u;
+            k[j] = valid ? kp[j * 64] : 0ull;                   // one address per array, the row as an immediate offset
+            v[j] = valid ? vp[j * 64] : 0u;
+            ld[j] = valid ? (u32)dgp[j * 64] : 0u;
         }
-        const u32 d = valid ? ss_digit<LAST>(spl, k[j]) : 0u;
-        u64 peers = __ballot(valid);
+    }
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const bool bit = (d >> b) & 1u;
-            const u64 bal = __ballot(bit);
-            peers &= bit ? bal : ~bal;
-        }
-        const u32 prefix = mycnt[d];
+    for (int j = 0; j < SS_ITEMS; ++j) {
+        const u32 e = GEN ? lbs + (u32)j : lbs + (u32)j * 64;
+        const bool valid = e < cnt;
+        const u32 d = valid ? ld[j] : 0u;
+        const u64 peers = wave_match_lds(M, d, valid, lanebit);
+        const u32 prefix = lds_load(&mycnt[d]);
         const u32 rank = (u32)__popcll(peers & lt_mask);
         ld[j] = (d << 16) | (prefix + rank);
-        if (valid && rank == 0) mycnt[d] = (u16)(prefix + (u32)__popcll(peers));
+        if (valid && rank == 0) lds_store(&mycnt[d], (u16)(prefix + (u32)__popcll(peers)));
     }
     __syncthreads();
     {   // digit runs inside the sorted tile (exclusive scan over the digits), per-wave starts, global base
@@ -456,32 +478,62 @@ __global__ void ss_unit_fill_kernel(const u32* __restrict__ leaf_start, u32 nlea
 }
 
 // ---- leaf sort: one workgroup sorts one unit of <= 8192 pairs in LDS (stable LSD passes on the bits in which its keys differ) --
+// Ranks inside a wave come from a wave-level match (8 ballots per key); the running per-wave digit counters are bumped with
+// LDS atomics that RETURN the old value (ds_add_rtn): the 16 rows of a pass are then independent instructions in the wave's
+// in-order LDS queue, instead of a read-modify-write chain of 16 round trips.  When the differing key bits and a 13-bit slot
+// number fit one 64-bit word (almost always: the keys of a unit share their leading bits), only that word travels through
+// LDS in every pass and the values are fetched once at the end.
 constexpr int LS_NW = 8;
-__global__ __launch_bounds__(LS_NW * 64) void ss_leaf_sort_kernel(u64* __restrict__ keys, u32* __restrict__ vals, const u32* __restrict__ unit_rng,
-                                                                   u32 nunits, u32* __restrict__ d_err) {
-    __shared__ u32 wcnt[LS_NW][256];
-    __shared__ u64 stage[SS_UNIT_MAX];
-    __shared__ u32 scan_sm[LS_NW + 1];
+__device__ __forceinline__ u32 ls_rank(u32 d, bool valid, u32* mycnt, unsigned long long* M, u64 lanebit, u64 lt_mask) {
+    const u64 peers = wave_match_lds(M, d, valid, lanebit);
+    const u32 prefix = lds_load(&mycnt[d]);
+    const u32 rank = (u32)__popcll(peers & lt_mask);
+    if (valid && rank == 0) lds_store(&mycnt[d], prefix + (u32)__popcll(peers));
+    return prefix + rank;
+}
+// per-wave digit counts -> start of every (wave, digit) run inside the sorted unit; executed by ONE wave (lane l owns the
+// digits 4l .. 4l+3), the others wait at the barrier that follows
+__device__ __forceinline__ void ls_digit_starts(u32 (*wcnt)[256], int lane) {
+    uint4 c[LS_NW];
+    u32 t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+#pragma unroll
+    for (int i = 0; i < LS_NW; ++i) {
+        c[i] = *(const uint4*)&wcnt[i][4 * lane];
+        t0 += c[i].x; t1 += c[i].y; t2 += c[i].z; t3 += c[i].w;
+    }
+    const u32 sum = t0 + t1 + t2 + t3;
+    u32 r0 = wave_inclusive_sum(sum) - sum;
+    u32 r1 = r0 + t0, r2 = r1 + t1, r3 = r2 + t2;
+#pragma unroll
+    for (int i = 0; i < LS_NW; ++i) {
+        *(uint4*)&wcnt[i][4 * lane] = make_uint4(r0, r1, r2, r3);
+        r0 += c[i].x; r1 += c[i].y; r2 += c[i].z; r3 += c[i].w;
+    }
+}
+// Composite units: ROWS 64-pair rows per wave (the unit holds at most ROWS * 512 pairs; the host launches one variant per
+// size class, so the row loops carry no run-time bounds and the LDS operations of neighbouring rows overlap).  Units whose
+// differing bits do not fit the composite word are appended to wide_list (wide_list[0] = count) for ss_leaf_wide_kernel.
+template <int ROWS>
+__global__ __launch_bounds__(LS_NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void ss_leaf_comp_kernel(u64* __restrict__ keys, u32* __restrict__ vals, const u32* __restrict__ unit_rng,
+                                                                   const u32* __restrict__ list, u32 count, u32* __restrict__ d_err, u32* __restrict__ wide_list) {
+    __shared__ __align__(16) u32 wcnt[LS_NW][256];
+    __shared__ u64 stage[ROWS * LS_NW * 64];
     __shared__ u64 red[2][LS_NW];
-    const u32 u = blockIdx.x;
-    if (u >= nunits) return;
+    if (blockIdx.x >= count) return;
+    const u32 u = list[blockIdx.x];
     const u32 a = unit_rng[2 * u], b = unit_rng[2 * u + 1];
     const u32 m = b - a;
     if (m <= 1) return;
-    if (m > SS_UNIT_MAX) { if (threadIdx.x == 0) atomicOr(d_err, 2u); return; }
+    if (m > (u32)ROWS * LS_NW * 64) { if (threadIdx.x == 0) atomicOr(d_err, 2u); return; }
     const int lane = lane_id(), w = wave_id();
-    const u32 rows = (m + LS_NW * 64 - 1) / (LS_NW * 64);      // 64-pair rows per wave
-    const u32 wbase = (u32)w * rows * 64 + (u32)lane;           // logical slot of (w, j, lane) = wbase + 64 j
-    u64 k[SS_ITEMS];
-    u32 v[SS_ITEMS];
-    u32 loc[SS_ITEMS];
+    const u32 wbase = (u32)w * ROWS * 64 + (u32)lane;           // logical slot of (w, j, lane) = wbase + 64 j
+    u64 k[ROWS];
     u64 kmin = ~0ull, kmax = 0;
 #pragma unroll
-    for (int j = 0; j < SS_ITEMS; ++j) {
+    for (int j = 0; j < ROWS; ++j) {
         const u32 L = wbase + (u32)j * 64;
-        const bool valid = (u32)j < rows && L < m;
+        const bool valid = L < m;
         k[j] = valid ? keys[(size_t)a + L] : 0ull;
-        v[j] = valid ? vals[(size_t)a + L] : 0u;
         if (valid) { kmin = k[j] < kmin ? k[j] : kmin; kmax = k[j] > kmax ? k[j] : kmax; }
     }
 #pragma unroll
@@ -497,46 +549,91 @@ __global__ __launch_bounds__(LS_NW * 64) void ss_leaf_sort_kernel(u64* __restric
     const u64 diff = kmin ^ kmax;
     if (diff == 0) return;                                      // all keys equal
     const int nbits = 64 - __clzll((long long)diff);
+    if (nbits + 13 > 64) { if (threadIdx.x == 0) wide_list[1 + atomicAdd(wide_list, 1u)] = u; return; }
     const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    volatile u32* mycnt = wcnt[w];
+    u32* mycnt = wcnt[w];
     u32* stage32 = (u32*)stage;
-    for (int shift = 0; shift < nbits; shift += 8) {
-        for (int i = threadIdx.x; i < LS_NW * 256; i += LS_NW * 64) (&wcnt[0][0])[i] = 0;
-        __syncthreads();
+    // lane-mask table of the LDS match: in the staging buffer, idle while ranking (for ROWS = 4 the buffer is exactly the 8 tables)
+    unsigned long long* M = (unsigned long long*)stage + w * 256;
+    const u64 lanebit = 1ull << lane;
+    // composite word: (differing key bits) << 13 | slot
+    const u64 lowmask = (nbits == 64) ? ~0ull : ((1ull << nbits) - 1);
+    const u64 high = kmin & ~lowmask;                           // the bits all keys share
 #pragma unroll
-        for (int j = 0; j < SS_ITEMS; ++j) {
-            if ((u32)j < rows) {
-                const bool valid = wbase + (u32)j * 64 < m;
-                const u32 d = (u32)(k[j] >> shift) & 255u;
-                u64 peers = __ballot(valid);
+    for (int j = 0; j < ROWS; ++j) k[j] = ((k[j] & lowmask) << 13) | (u64)(wbase + (u32)j * 64);
+    for (int i = lane; i < 256; i += 64) mycnt[i] = 0;          // every wave owns (and clears) its own counters
+    u32 loc[ROWS];
+    for (int shift = 13; shift < 13 + nbits; shift += 8) {
+        for (int i = lane; i < 256; i += 64) M[i] = 0;          // the wave's own table; the staging buffer is idle here
 #pragma unroll
-                for (int bb = 0; bb < 8; ++bb) {
-                    const bool bit = (d >> bb) & 1u;
-                    const u64 bal = __ballot(bit);
-                    peers &= bit ? bal : ~bal;
-                }
-                const u32 prefix = mycnt[d];
-                const u32 rank = (u32)__popcll(peers & lt_mask);
-                loc[j] = prefix + rank;
-                if (valid && rank == 0) mycnt[d] = prefix + (u32)__popcll(peers);
-            }
+        for (int j = 0; j < ROWS; ++j) {
+            loc[j] = ls_rank((u32)(k[j] >> shift) & 255u, wbase + (u32)j * 64 < m, mycnt, M, lanebit, lt_mask);
+            if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);    // overlap the LDS operations of four rows, not of all (registers)
         }
         __syncthreads();
-        {
-            const u32 t = threadIdx.x;
-            u32 tot = 0;
-            if (t < 256) {
+        if (w == 0) ls_digit_starts(wcnt, lane);
+        __syncthreads();
 #pragma unroll
-                for (int i = 0; i < LS_NW; ++i) tot += wcnt[i][t];
-            }
-            u32 total;
-            const u32 start = block_exclusive_sum<u32, LS_NW>(t < 256 ? tot : 0u, scan_sm, total);
-            if (t < 256) {
-                u32 run = start;
+        for (int j = 0; j < ROWS; ++j)
+            if (wbase + (u32)j * 64 < m) stage[loc[j] + mycnt[(u32)(k[j] >> shift) & 255u]] = k[j];
+        for (int i = lane; i < 256; i += 64) mycnt[i] = 0;      // after this wave's last use; only this wave touches them before the next barrier
+        __syncthreads();
 #pragma unroll
-                for (int i = 0; i < LS_NW; ++i) { const u32 c = wcnt[i][t]; wcnt[i][t] = run; run += c; }
-            }
+        for (int j = 0; j < ROWS; ++j) if (wbase + (u32)j * 64 < m) k[j] = stage[wbase + (u32)j * 64];
+        __syncthreads();                                        // the match tables of the next pass overwrite the buffer
+    }
+    // values: they were not carried through the passes (registers); every thread parks the values of its original slots
+    // (still untouched in memory) in LDS, then picks up those of its sorted words
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) if (wbase + (u32)j * 64 < m) stage32[wbase + (u32)j * 64] = vals[(size_t)a + wbase + (u32)j * 64];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) {
+        const u32 L = wbase + (u32)j * 64;
+        if (L < m) {
+            keys[(size_t)a + L] = (k[j] >> 13) | high;
+            vals[(size_t)a + L] = stage32[(u32)k[j] & 8191u];
         }
+    }
+}
+
+// The units whose keys differ in more than 51 bits: (key, value) pairs through LDS, run-time row count.
+__global__ __launch_bounds__(LS_NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void ss_leaf_wide_kernel(u64* __restrict__ keys, u32* __restrict__ vals, const u32* __restrict__ unit_rng,
+                                                                   const u32* __restrict__ wide_list, u32 count, u32* __restrict__ d_err) {
+    __shared__ __align__(16) u32 wcnt[LS_NW][256];
+    __shared__ u64 stage[SS_UNIT_MAX];
+    if (blockIdx.x >= count) return;
+    const u32 u = wide_list[1 + blockIdx.x];
+    const u32 a = unit_rng[2 * u], b = unit_rng[2 * u + 1];
+    const u32 m = b - a;
+    if (m <= 1) return;
+    if (m > SS_UNIT_MAX) { if (threadIdx.x == 0) atomicOr(d_err, 2u); return; }
+    const int lane = lane_id(), w = wave_id();
+    const u32 rows = (m + LS_NW * 64 - 1) / (LS_NW * 64);      // 64-pair rows per wave
+    const u32 wbase = (u32)w * rows * 64 + (u32)lane;
+    u64 k[SS_ITEMS];
+    u32 v[SS_ITEMS];
+    u32 loc[SS_ITEMS];
+#pragma unroll
+    for (int j = 0; j < SS_ITEMS; ++j) {
+        const u32 L = wbase + (u32)j * 64;
+        const bool valid = (u32)j < rows && L < m;
+        k[j] = valid ? keys[(size_t)a + L] : 0ull;
+        v[j] = valid ? vals[(size_t)a + L] : 0u;
+    }
+    const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    u32* mycnt = wcnt[w];
+    u32* stage32 = (u32*)stage;
+    unsigned long long* M = (unsigned long long*)stage + w * 256;
+    const u64 lanebit = 1ull << lane;
+    for (int shift = 0; shift < 64; shift += 8) {
+        for (int i = threadIdx.x; i < LS_NW * 256; i += LS_NW * 64) { (&wcnt[0][0])[i] = 0; stage[i] = 0; }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < SS_ITEMS; ++j)
+            if ((u32)j < rows) loc[j] = ls_rank((u32)(k[j] >> shift) & 255u, wbase + (u32)j * 64 < m, mycnt, M, lanebit, lt_mask);
+        __syncthreads();
+        if (w == 0) ls_digit_starts(wcnt, lane);
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < SS_ITEMS; ++j) {
@@ -560,6 +657,27 @@ __global__ __launch_bounds__(LS_NW * 64) void ss_leaf_sort_kernel(u64* __restric
     for (int j = 0; j < SS_ITEMS; ++j) {
         const u32 L = wbase + (u32)j * 64;
         if ((u32)j < rows && L < m) { keys[(size_t)a + L] = k[j]; vals[(size_t)a + L] = v[j]; }
+    }
+}
+
+// units by size class (rows per wave of the composite kernel): class c = units of (2048 c, 2048 (c + 1)] pairs
+__global__ void ss_unit_class_kernel(const u32* __restrict__ unit_rng, const u32* __restrict__ d_nunits, u32* __restrict__ cls_count,
+                                     u32* __restrict__ cls_list, u32 cap) {
+    const u32 u = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 c = 4;
+    if (u < *d_nunits) {
+        const u32 m = unit_rng[2 * u + 1] - unit_rng[2 * u];
+        if (m > 1 && m <= SS_UNIT_MAX) c = (m - 1) / 2048;
+    }
+    const int lane = lane_id();
+#pragma unroll
+    for (u32 q = 0; q < 4; ++q) {                               // one atomic per wave and class
+        const u64 mask = __ballot(c == q);
+        if (!mask) continue;
+        u32 basei = 0;
+        if (lane == __ffsll((long long)mask) - 1) basei = atomicAdd(&cls_count[q], (u32)__popcll(mask));
+        basei = __shfl(basei, __ffsll((long long)mask) - 1, 64);
+        if (c == q) cls_list[(size_t)q * cap + basei + (u32)__popcll(mask & ((1ull << lane) - 1))] = u;
     }
 }
 
@@ -617,6 +735,7 @@ int splitter_sort_pairs_u64(Ctx& c, u64* keys[2], u32* vals[2], size_t n, const 
     }
 
     // ---- partition levels ----------------------------------------------------------------------------------------------------
+    u16* digits = c.arena.get<u16>(align_up(n, SS_TILE) + SS_TILE);
     u32* seg_start = c.arena.get<u32>(2);
     ss_set_word_kernel<<<1, 1, 0, s>>>(seg_start, 0u);
     LAUNCH_CHECK();
@@ -652,6 +771,7 @@ int splitter_sort_pairs_u64(Ctx& c, u64* keys[2], u32* vals[2], size_t n, const 
         P.keys_in = cur >= 0 ? keys[cur] : nullptr; P.vals_in = cur >= 0 ? vals[cur] : nullptr;
         const int nxt = cur < 0 ? 0 : (cur ^ 1);
         P.keys_out = keys[nxt]; P.vals_out = vals[nxt];
+        P.digits = digits;
         P.counts = counts; P.blk_seg = blk_seg; P.blk_start = blk_start; P.seg_start = seg_start; P.sp = sp;
         P.nseg = nseg; P.F = F[l]; P.stride = stride; P.R = R; P.D = D;
         P.per_xcd = (c.xcd_remap == 1 && rows >= 64) ? cdiv(rows, 8) : 0u;
@@ -697,26 +817,41 @@ int splitter_sort_pairs_u64(Ctx& c, u64* keys[2], u32* vals[2], size_t n, const 
     constexpr u32 LARGE_CAP = 1024;
     u32* flag = c.arena.get<u32>((size_t)nleaf + 1);
     u32* unit_rng = c.arena.get<u32>(2 * ((size_t)nleaf + 1));
-    u32* large = c.arena.get<u32>(LARGE_CAP + 2);              // [0] = count of large leaves, [1] = number of units, then the list
-    HIP_TRY(hipMemsetAsync(large, 0, 2 * sizeof(u32), s));
-    ss_unit_flag_kernel<<<cdiv(nleaf, 256), 256, 0, s>>>(leaf_start, nleaf, flag, large + 2, large, LARGE_CAP);
+    u32* large = c.arena.get<u32>(LARGE_CAP + 6);              // [0] = count of large leaves, [1] = number of units, [2..5] units per size class, then the list
+    u32* wide_list = c.arena.get<u32>((size_t)nleaf + 2);       // [0] = number of, [1..] = the units whose differing key bits do not fit the composite word
+    u32* cls_list = c.arena.get<u32>(4 * ((size_t)nleaf + 1));  // the units by size class
+    HIP_TRY(hipMemsetAsync(large, 0, 6 * sizeof(u32), s));       // [0] large leaves, [1] units, [2..5] units per size class
+    HIP_TRY(hipMemsetAsync(wide_list, 0, sizeof(u32), s));
+    ss_unit_flag_kernel<<<cdiv(nleaf, 256), 256, 0, s>>>(leaf_start, nleaf, flag, large + 6, large, LARGE_CAP);
     LAUNCH_CHECK();
     exclusive_sum_u32(c, flag, flag, nleaf, large + 1);
     ss_unit_fill_kernel<<<cdiv(nleaf, 256), 256, 0, s>>>(leaf_start, nleaf, flag, unit_rng);
     LAUNCH_CHECK();
-    u32 hc[2];
-    c.read_n(large, hc, 2);
+    ss_unit_class_kernel<<<cdiv((size_t)nleaf + 1, 256), 256, 0, s>>>(unit_rng, large + 1, large + 2, cls_list, nleaf + 1);
+    LAUNCH_CHECK();
+    u32 hc[6];
+    c.read_n(large, hc, 6);
     const u32 nlarge = hc[0], nunits = hc[1];
     st->units = nunits; st->large_leaves = nlarge;
-    if (nunits) {
+    {
         Ctx::ProfScope prof(c, K_SS_LEAF, (u64)n * 24);
-        ss_leaf_sort_kernel<<<nunits, LS_NW * 64, 0, s>>>(keys[cur], vals[cur], unit_rng, nunits, c.d_err);
-        LAUNCH_CHECK();
+        u64* K = keys[cur]; u32* V = vals[cur];
+        const u32 cap = nleaf + 1;
+        if (hc[2]) { ss_leaf_comp_kernel<4><<<hc[2], LS_NW * 64, 0, s>>>(K, V, unit_rng, cls_list, hc[2], c.d_err, wide_list); LAUNCH_CHECK(); }
+        if (hc[3]) { ss_leaf_comp_kernel<8><<<hc[3], LS_NW * 64, 0, s>>>(K, V, unit_rng, cls_list + (size_t)cap, hc[3], c.d_err, wide_list); LAUNCH_CHECK(); }
+        if (hc[4]) { ss_leaf_comp_kernel<12><<<hc[4], LS_NW * 64, 0, s>>>(K, V, unit_rng, cls_list + 2 * (size_t)cap, hc[4], c.d_err, wide_list); LAUNCH_CHECK(); }
+        if (hc[5]) { ss_leaf_comp_kernel<16><<<hc[5], LS_NW * 64, 0, s>>>(K, V, unit_rng, cls_list + 3 * (size_t)cap, hc[5], c.d_err, wide_list); LAUNCH_CHECK(); }
+        const u32 nwide = (hc[2] | hc[3] | hc[4] | hc[5]) ? c.read(wide_list) : 0u;
+        if (nwide) {                                            // rare: units whose keys differ in more than 51 bits
+            ss_leaf_wide_kernel<<<nwide, LS_NW * 64, 0, s>>>(K, V, unit_rng, wide_list, nwide, c.d_err);
+            LAUNCH_CHECK();
+            st->wide_units = nwide;
+        }
     }
     if (nlarge) {                                              // leaves above the workgroup capacity: LSD sort, one by one
         if (nlarge > LARGE_CAP) throw HipError{hipErrorUnknown, "splitter sort: too many oversized leaves", (int)__LINE__};
         std::vector<u32> ll(nlarge), ls((size_t)nleaf + 1);
-        HIP_TRY(hipMemcpyAsync(ll.data(), large + 2, nlarge * sizeof(u32), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(ll.data(), large + 6, nlarge * sizeof(u32), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipMemcpyAsync(ls.data(), leaf_start, ((size_t)nleaf + 1) * sizeof(u32), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         for (u32 i = 0; i < nlarge; ++i) {
