@@ -65,40 +65,6 @@ __global__ __launch_bounds__(256) void sa_init_keys_kernel(const u8* __restrict_
     }
 }
 
-// head marker: index of the element if it starts a new group, else 0 (a max-scan then yields the group head)
-__global__ void sa_heads_kernel(const u64* __restrict__ keys, size_t m, u32* __restrict__ head) {
-    const size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (a >= m) return;
-    head[a] = (a == 0 || keys[a] != keys[a - 1]) ? (u32)a : 0u;
-}
-
-// First round: every position is "active", pos[a] == a.
-template <bool SCATTER_RANK>
-__global__ void sa_first_update_kernel(const u32* __restrict__ vals, const u32* __restrict__ head, size_t n,
-                                       u32* __restrict__ sa, u32* __restrict__ rank, u32* __restrict__ keep) {
-    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    const u32 h = head[j];
-    const u32 s = vals[j];
-    sa[j] = s;
-    if (SCATTER_RANK) rank[s] = h;
-    const bool single = (h == (u32)j) && (j + 1 == n || head[j + 1] == (u32)(j + 1));
-    keep[j] = single ? 0u : 1u;
-}
-__global__ void sa_first_compact_kernel(const u32* __restrict__ vals, const u32* __restrict__ head, const u32* __restrict__ offs,
-                                        size_t n, u32* __restrict__ a_sa, u32* __restrict__ a_pos, u32* __restrict__ a_r1) {
-    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    const u32 h = head[j];
-    const bool single = (h == (u32)j) && (j + 1 == n || head[j + 1] == (u32)(j + 1));
-    if (!single) {
-        const u32 o = offs[j];
-        a_sa[o] = vals[j];
-        a_pos[o] = (u32)j;
-        a_r1[o] = h;
-    }
-}
-
 __global__ void sa_build_keys_kernel(const u32* __restrict__ a_sa, const u32* __restrict__ a_r1, size_t m, size_t n, u32 h,
                                      int bn, const u32* __restrict__ rank, u64* __restrict__ keys, u32* __restrict__ vals) {
     const size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -108,37 +74,6 @@ __global__ void sa_build_keys_kernel(const u32* __restrict__ a_sa, const u32* __
     const u32 r2 = (t < n) ? rank[t] : 0u;
     keys[a] = ((u64)a_r1[a] << bn) | r2;
     vals[a] = s;
-}
-
-// newrank_out != nullptr: the new ranks are only written out (in list order); the caller scatters them to rank[] through the
-// bucketed scatter (writing an unchanged rank again is harmless)
-__global__ void sa_update_kernel(const u64* __restrict__ keys, const u32* __restrict__ vals, const u32* __restrict__ head,
-                                 const u32* __restrict__ a_pos, size_t m, int bn, u32* __restrict__ sa, u32* __restrict__ rank,
-                                 u32* __restrict__ keep, u32* __restrict__ newrank_out) {
-    const size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (a >= m) return;
-    const u32 h = head[a];
-    const u32 s = vals[a];
-    const u32 newrank = a_pos[h];
-    sa[a_pos[a]] = s;
-    if (newrank_out) newrank_out[a] = newrank;
-    else if (newrank != (u32)(keys[a] >> bn)) rank[s] = newrank;     // rank only moves when the group was split
-    const bool single = (h == (u32)a) && (a + 1 == m || head[a + 1] == (u32)(a + 1));
-    keep[a] = single ? 0u : 1u;
-}
-__global__ void sa_compact_kernel(const u32* __restrict__ vals, const u32* __restrict__ head, const u32* __restrict__ offs,
-                                  const u32* __restrict__ a_pos, size_t m, u32* __restrict__ b_sa, u32* __restrict__ b_pos,
-                                  u32* __restrict__ b_r1) {
-    const size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (a >= m) return;
-    const u32 h = head[a];
-    const bool single = (h == (u32)a) && (a + 1 == m || head[a + 1] == (u32)(a + 1));
-    if (!single) {
-        const u32 o = offs[a];
-        b_sa[o] = vals[a];
-        b_pos[o] = a_pos[a];
-        b_r1[o] = a_pos[h];
-    }
 }
 
 // Doubling round, local part: the active list is grouped by r1 (runs of equal high key half), and sorting by
@@ -187,6 +122,170 @@ __global__ void sa_scatter_back_kernel(const u32* __restrict__ opos, const u64* 
     const u32 p = opos[j];
     keys[p] = okeys[j];
     vals[p] = ovals[j];
+}
+
+// ---- group bookkeeping of one round in ONE pass ------------------------------------------------------------------------------
+// Input: the (key, value) list sorted inside its groups; equal keys = one (new) group.  Per element: pos = its suffix-array slot
+// (the index itself in the first round, else a_pos[]), head = pos of the first element of its group.  Output: sa[pos] = value,
+// the new rank (= head) either into newrank_out[] (for the bucketed scatter) or straight into rank[], and the compacted list
+// (value, pos, head) of the elements whose group is not a singleton.  Replaces five passes (head flags, max-scan, update, sum-scan,
+// compaction: ~70 B per element) by one (~26 B): a tile of 2048 elements, the two running values that cross tile borders -- the
+// number of kept elements and the head of the run that is open at the border -- travel through a decoupled look-back chain
+// (one 64-bit descriptor per tile: 2 flag bits | 31-bit count | 31-bit head position).
+constexpr u32 GR_TILE = 2048, GR_NONE = 0x7FFFFFFFu;
+constexpr u64 GR_FLAG_AGG = 1ull << 62, GR_FLAG_INC = 2ull << 62;
+__device__ __forceinline__ u64 gr_pack(u64 flag, u32 count, u32 hp) { return flag | ((u64)count << 31) | (u64)hp; }
+__device__ __forceinline__ u32 gr_pad(u32 i) { return i + (i >> 3); }      // LDS slot of tile element i: threads read 8 consecutive elements
+template <bool FIRST>
+__global__ __launch_bounds__(256) void sa_groups_kernel(const u64* __restrict__ keys, const u32* __restrict__ vals, const u32* __restrict__ a_pos,
+                                                        size_t m, int bn, u32* __restrict__ sa, u32* __restrict__ rank, u32* __restrict__ newrank_out,
+                                                        u32* __restrict__ o_sa, u32* __restrict__ o_pos, u32* __restrict__ o_r1,
+                                                        u64* desc, u32* ticket, u32* __restrict__ d_total, u32* err, u32 numTiles) {
+    __shared__ u32 s_tile;
+    __shared__ u32 s_hp[4], s_cnt[5];
+    __shared__ u32 s_carry_hp, s_carry_cnt;
+    __shared__ u64 sk[GR_TILE + GR_TILE / 8 + 8];       // keys of the elements tile0 - 1 .. tile0 + 2048 (slot 0 = the predecessor)
+    __shared__ u32 sv[GR_TILE + GR_TILE / 8], sp[GR_TILE + GR_TILE / 8];
+    // Tiles are numbered by blockIdx: workgroups are dispatched in that order, so the predecessors of a running tile have been
+    // dispatched (a ticket counter would make that formal, but one device-wide atomic per tile on ONE address costs ~25 ns each:
+    // 3.6 ms for the 131 072 tiles of a 256 MiB text, more than the whole pass).  The look-back spin is bounded (error flag).
+    (void)ticket; (void)s_tile;
+    const u32 tile = blockIdx.x;
+    const int lane = lane_id(), w = wave_id();
+    const size_t t0 = (size_t)tile * GR_TILE;
+    // coalesced loads (a row of 256 consecutive elements per step) into LDS; sa[pos] = value on the way
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const u32 e = (u32)r * 256 + threadIdx.x;
+        const size_t i = t0 + e;
+        u64 kk = 0; u32 vv = 0, pp = 0;
+        if (i < m) {
+            kk = keys[i]; vv = vals[i]; pp = FIRST ? (u32)i : a_pos[i];
+            sa[pp] = vv;
+        }
+        sk[gr_pad(e + 1)] = kk; sv[gr_pad(e)] = vv; sp[gr_pad(e)] = pp;
+    }
+    if (threadIdx.x == 0) { sk[0] = (t0 >= 1) ? keys[t0 - 1] : 0ull; sk[gr_pad(GR_TILE + 1)] = (t0 + GR_TILE < m) ? keys[t0 + GR_TILE] : 0ull; }
+    __syncthreads();
+    const u32 l0 = threadIdx.x * 8;                     // the thread's 8 consecutive elements
+    const size_t i0 = t0 + l0;
+    u64 k[10];
+    u32 v[8], ps[8];
+#pragma unroll
+    for (int r = 0; r < 10; ++r) k[r] = sk[gr_pad(l0 + r)];      // k[r] = key of element i0 + r - 1
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { v[r] = sv[gr_pad(l0 + r)]; ps[r] = sp[gr_pad(l0 + r)]; }
+    // run starts, head position of every element as far as the thread can tell, number of elements to keep
+    u32 starts = 0;
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+        const size_t i = i0 + r;
+        if (i < m && (i == 0 || k[r + 1] != k[r])) starts |= 1u << r;
+        if (i == m) starts |= 1u << r;                  // the end of the list closes the last run
+    }
+    u32 hp[8];
+    u32 run = GR_NONE, keepmask = 0;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const size_t i = i0 + r;
+        if ((starts & (1u << r)) && i < m) run = ps[r];
+        hp[r] = run;
+        const bool single = ((starts >> r) & 3u) == 3u;  // starts a run and the next element starts one too
+        if (i < m && !single) keepmask |= 1u << r;
+    }
+    // across the threads of the tile: last run start before this thread, exclusive count of kept elements
+    u32 inc_hp = run;                                   // inclusive "last start" scan: the right operand wins unless it has none
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const u32 o = __shfl_up(inc_hp, d, 64);
+        if (lane >= d && inc_hp == GR_NONE) inc_hp = o;
+    }
+    const u32 mycnt = (u32)__popc(keepmask);
+    const u32 inc_cnt = wave_inclusive_sum(mycnt);
+    if (lane == 63) { s_hp[w] = inc_hp; s_cnt[w] = inc_cnt; }
+    __syncthreads();                                    // (also: every thread holds its elements in registers, the LDS tile is free)
+    u32 pre_hp = __shfl_up(inc_hp, 1, 64);              // last start in the earlier lanes of the wave
+    if (lane == 0) pre_hp = GR_NONE;
+    u32 pre_cnt = inc_cnt - mycnt;
+    u32 tile_hp = GR_NONE, tile_cnt = 0;
+    {   // earlier waves: the LAST one that has a start wins; counts add up
+        u32 whp = GR_NONE, wc = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i < w) { if (s_hp[i] != GR_NONE) whp = s_hp[i]; wc += s_cnt[i]; }
+            if (s_hp[i] != GR_NONE) tile_hp = s_hp[i];
+            tile_cnt += s_cnt[i];
+        }
+        if (pre_hp == GR_NONE) pre_hp = whp;
+        pre_cnt += wc;
+    }
+    // look-back: running values at the left border of the tile.  Wave 0 inspects 64 predecessors per step (lane l: tile - 1 - l -
+    // 64 step): the walk ends at the nearest tile that has published its inclusive values, and it only has to wait for tiles that
+    // have not even published their aggregate.
+    if (w == 0) {
+        u32 c_cnt = 0, c_hp = GR_NONE;
+        if (tile == 0) {
+            if (lane == 0) __hip_atomic_store(desc, gr_pack(GR_FLAG_INC, tile_cnt, tile_hp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (lane == 0) __hip_atomic_store(desc + tile, gr_pack(GR_FLAG_AGG, tile_cnt, tile_hp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            long base = (long)tile - 1;
+            u32 spins = 0;
+            for (;;) {
+                const long idx = base - lane;
+                const u64 d64 = (idx >= 0) ? __hip_atomic_load(desc + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                           : gr_pack(GR_FLAG_INC, 0u, GR_NONE);      // in front of tile 0: neutral, ends the walk
+                const u64 f = d64 >> 62;
+                const u64 m_inc = __ballot(f == 2), m_zero = __ballot(f == 0);
+                const int first_inc = m_inc ? __ffsll((long long)m_inc) - 1 : 64;
+                const u64 need = first_inc >= 63 ? ~0ull : ((2ull << first_inc) - 1);   // the lanes up to the nearest inclusive one
+                if (m_zero & need) {
+                    if (++spins > (1u << 22)) { if (lane == 0) atomicOr(err, 4u); break; }   // never hang the GPU: report and leave
+                    __builtin_amdgcn_s_sleep(1);
+                    continue;
+                }
+                const bool mine = (need >> lane) & 1ull;
+                c_cnt += wave_reduce_sum(mine ? (u32)((d64 >> 31) & 0x7FFFFFFFu) : 0u);
+                const u32 hpv = mine ? (u32)(d64 & 0x7FFFFFFFu) : GR_NONE;
+                const u64 m_hp = __ballot(hpv != GR_NONE);
+                if (c_hp == GR_NONE && m_hp) c_hp = __shfl(hpv, __ffsll((long long)m_hp) - 1, 64);   // the nearest tile that has a run start
+                if (first_inc < 64) break;
+                base -= 64;
+            }
+            if (lane == 0) __hip_atomic_store(desc + tile, gr_pack(GR_FLAG_INC, c_cnt + tile_cnt, tile_hp != GR_NONE ? tile_hp : c_hp), __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) {
+            s_carry_cnt = c_cnt; s_carry_hp = c_hp;
+            if (tile == numTiles - 1) *d_total = c_cnt + tile_cnt;
+        }
+    }
+    __syncthreads();
+    if (pre_hp == GR_NONE) pre_hp = s_carry_hp;
+    // results into LDS (heads by tile slot, the kept elements compacted), then coalesced stores
+    u32* c_sa = (u32*)sk; u32* c_pos = c_sa + GR_TILE; u32* c_r1 = sv; u32* s_h = sp;
+    u32 o = pre_cnt;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const u32 h = (hp[r] != GR_NONE) ? hp[r] : pre_hp;
+        s_h[gr_pad(l0 + r)] = h;
+        if (keepmask & (1u << r)) { c_sa[o] = v[r]; c_pos[o] = ps[r]; c_r1[o] = h; ++o; }
+    }
+    __syncthreads();
+    const size_t obase = s_carry_cnt;
+    for (u32 q = threadIdx.x; q < tile_cnt; q += 256) { o_sa[obase + q] = c_sa[q]; o_pos[obase + q] = c_pos[q]; o_r1[obase + q] = c_r1[q]; }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const u32 e = (u32)r * 256 + threadIdx.x;
+        const size_t i = t0 + e;
+        if (i < m) {
+            const u32 h = s_h[gr_pad(e)];
+            if (newrank_out) newrank_out[i] = h;
+            else {                                      // small inputs / rounds: straight into rank[]; later rounds only where the group was split
+                const u32 vv = vals[i];
+                if (FIRST || h != (u32)(keys[i] >> bn)) rank[vv] = h;
+            }
+        }
+    }
 }
 
 void build_suffix_array(Ctx& c, const u8* text, size_t n, u32* sa, u32* isa, SAStats* st) {
@@ -252,30 +351,25 @@ void build_suffix_array(Ctx& c, const u8* text, size_t n, u32* sa, u32* isa, SAS
         x = radix_sort_pairs_u64(c, keys, vals, n, 0, key_bits);
     }
     st->sorted_elems += n;
-    const unsigned gn = cdiv(n, 256);
-    sa_heads_kernel<<<gn, 256, 0, s>>>(keys[x], n, head);
-    LAUNCH_CHECK();
-    inclusive_max_u32(c, head, head, n);
-    {   // per element: read value + head (8 B), write sa + keep (8 B), scatter rank (4 B)
-        Ctx::ProfScope prof(c, K_SA_RANK_SCATTER, (u64)n * 20);
-        if (c.bucket_scatter && n >= ((size_t)1 << 22)) {
-            // rank[vals[j]] = head[j] through a partition by destination window; the other key buffer is free scratch
-            sa_first_update_kernel<false><<<gn, 256, 0, s>>>(vals[x], head, n, sa, rank, keep);
-            LAUNCH_CHECK();
-            bucketed_scatter_u32(c, vals[x], head, n, rank, n, (u32*)keys[x ^ 1], vals[x ^ 1], B_sa, B_pos, true);   // B_* are free until the first compaction; vals[x] = every position once
-        } else {
-            sa_first_update_kernel<true><<<gn, 256, 0, s>>>(vals[x], head, n, sa, rank, keep);
-            LAUNCH_CHECK();
-        }
+    const int bn = (int)bits_for(n - 1);
+    u64* gdesc = c.arena.get<u64>(cdiv(n, GR_TILE) + 1);       // look-back descriptors + ticket of the group kernel
+    u32* gticket = c.arena.get<u32>(1);
+    {   // per element: read key + value (12 B), write sa + head (8 B) + the kept elements (12 B each), scatter rank (4 B)
+        Ctx::ProfScope prof(c, K_SA_RANK_SCATTER, (u64)n * 30);
+        const u32 tiles = cdiv(n, GR_TILE);
+        HIP_TRY(hipMemsetAsync(gdesc, 0, (size_t)tiles * sizeof(u64), s));
+        HIP_TRY(hipMemsetAsync(gticket, 0, sizeof(u32), s));
+        const bool bucketed = c.bucket_scatter && n >= ((size_t)1 << 22);
+        sa_groups_kernel<true><<<tiles, 256, 0, s>>>(keys[x], vals[x], nullptr, n, bn, sa, rank, bucketed ? head : nullptr, A_sa, A_pos, A_r1,
+                                                     gdesc, gticket, d_total, c.d_err, tiles);
+        LAUNCH_CHECK();
+        // rank[vals[j]] = head[j] through a partition by destination window; the other key buffer and the B lists are free scratch
+        if (bucketed) bucketed_scatter_u32(c, vals[x], head, n, rank, n, (u32*)keys[x ^ 1], vals[x ^ 1], B_sa, B_pos, true);   // vals[x] = every position once
     }
-    exclusive_sum_u32(c, keep, keep, n, d_total);
-    sa_first_compact_kernel<<<gn, 256, 0, s>>>(vals[x], head, keep, n, A_sa, A_pos, A_r1);
-    LAUNCH_CHECK();
     size_t m = c.read(d_total);
     st->rounds = 1;
 
     // --- doubling rounds --------------------------------------------------------------------------
-    const int bn = (int)bits_for(n - 1);
     u64 h = (u64)k;
     while (m > 0) {
         if (h >= n) throw HipError{hipErrorUnknown, "suffix_array: doubling did not converge", (int)__LINE__};
@@ -317,21 +411,19 @@ void build_suffix_array(Ctx& c, const u8* text, size_t n, u32* sa, u32* isa, SAS
             x = radix_sort_pairs_u64(c, keys, vals, m, 0, 2 * bn);
             st->sorted_elems += m;
         }
-        sa_heads_kernel<<<gm, 256, 0, s>>>(keys[x], m, head);
-        LAUNCH_CHECK();
-        inclusive_max_u32(c, head, head, m);
         {
-            Ctx::ProfScope prof(c, K_SA_RANK_SCATTER, (u64)m * 36);
-            // a large round scatters its ranks through the bucketed scatter (scratch: the other sort buffers, the B lists)
+            Ctx::ProfScope prof(c, K_SA_RANK_SCATTER, (u64)m * 40);
+            // a large round scatters its ranks through the bucketed scatter (scratch: the other sort buffers, head / keep)
             const bool bucketed = c.bucket_scatter && m >= ((size_t)1 << 24);
             u32* nr = (u32*)keys[x ^ 1];
-            sa_update_kernel<<<gm, 256, 0, s>>>(keys[x], vals[x], head, A_pos, m, bn, sa, rank, keep, bucketed ? nr : nullptr);
+            const u32 tiles = cdiv(m, GR_TILE);
+            HIP_TRY(hipMemsetAsync(gdesc, 0, (size_t)tiles * sizeof(u64), s));
+            HIP_TRY(hipMemsetAsync(gticket, 0, sizeof(u32), s));
+            sa_groups_kernel<false><<<tiles, 256, 0, s>>>(keys[x], vals[x], A_pos, m, bn, sa, rank, bucketed ? nr : nullptr, B_sa, B_pos, B_r1,
+                                                          gdesc, gticket, d_total, c.d_err, tiles);
             LAUNCH_CHECK();
-            if (bucketed) bucketed_scatter_u32(c, vals[x], nr, m, rank, n, nr + m, vals[x ^ 1], B_sa, B_pos);
+            if (bucketed) bucketed_scatter_u32(c, vals[x], nr, m, rank, n, nr + m, vals[x ^ 1], head, keep);
         }
-        exclusive_sum_u32(c, keep, keep, m, d_total);
-        sa_compact_kernel<<<gm, 256, 0, s>>>(vals[x], head, keep, A_pos, m, B_sa, B_pos, B_r1);
-        LAUNCH_CHECK();
         m = c.read(d_total);
         u32* t;
         t = A_sa; A_sa = B_sa; B_sa = t;
