@@ -76,3 +76,16 @@ def test_no_cpu_fallback_without_gpu():
         pytest.skip("GPU present")
     with pytest.raises(T.TdcGpuError):
         T.Context(0)
+
+
+def test_huffman_selfcheck_passes_and_fixture_is_current():
+    """the start-up drift check of tdc_gpu_ctx_create (no GPU needed): this build's libstdc++ reproduces the fixture tables, and
+    the committed fixture equals what the generator script derives from the oracle today"""
+    import subprocess, sys, os
+    L = T._native.load()
+    assert L.tdc_huffman_selfcheck() == 0
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    inc = os.path.join(root, "tudocomp_amd", "csrc", "huffman_selfcheck.inc")
+    before = open(inc).read()
+    subprocess.check_call([sys.executable, os.path.join(root, "tools", "make_huffman_selfcheck.py")], stdout=subprocess.DEVNULL)
+    assert open(inc).read() == before

@@ -23,7 +23,7 @@ SYMBOLS = [
     "tdc_gpu_encode_ascii",
     "tdc_gpu_encode_sle",
     "tdc_gpu_lcpcomp_decompress_coder",
-    "tdc_escape", "tdc_unescape", "tdc_huffman_table", "tdc_gen_english", "tdc_gen_dna",
+    "tdc_escape", "tdc_unescape", "tdc_huffman_table", "tdc_huffman_selfcheck", "tdc_gen_english", "tdc_gen_dna",
 ]
 
 

@@ -264,6 +264,9 @@ int tdc_gpu_ctx_create(int device, tdc_gpu_ctx** out) {
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { (void)hipGetLastError(); return TDC_GPU_ERR_HIP; }
     if (device < 0 || device >= count) return TDC_GPU_ERR_ARG;
+    // libstdc++ drift check: a C++ library whose heap / sort tie order differs from the reference build's would change every
+    // Huffman stream silently (coders/HuffmanCoder.hpp:455 is an unstable std::sort)
+    if (!huffman_selfcheck()) return TDC_GPU_ERR_INTERNAL;
     tdc_gpu_ctx* ctx = new (std::nothrow) tdc_gpu_ctx();
     if (!ctx) return TDC_GPU_ERR_OOM;
     ctx->c.device = device;
@@ -802,6 +805,8 @@ size_t tdc_unescape(const uint8_t* in, size_t n, uint8_t* out) {
     }
     return o;
 }
+
+int tdc_huffman_selfcheck(void) { return huffman_selfcheck() ? TDC_GPU_OK : TDC_GPU_ERR_INTERNAL; }
 
 int tdc_huffman_table(const uint32_t counts[256], uint32_t* sigma, uint32_t* longest, uint8_t order[256],
                       uint8_t len_of[256], uint64_t code_of[256]) {

@@ -58,6 +58,22 @@ void build_huffman_table(const uint32_t C[256], HuffTable* t) {
     }
 }
 
+// Start-up self-check: the table depends on the tie behaviour of the C++ library's heap functions
+// and of its unstable std::sort.  Two fixtures with many equal counts are rebuilt and compared with the tables the oracle's
+// restatement of the reference build's behaviour yields (tools/make_huffman_selfcheck.py); a drifted library is refused.
+#include "huffman_selfcheck.inc"
+bool huffman_selfcheck() {
+    for (const auto& f : HUFF_SELFCHECK) {
+        uint32_t C[256];
+        for (int i = 0; i < 256; ++i) C[i] = f.counts[i];
+        HuffTable t;
+        build_huffman_table(C, &t);
+        if (t.sigma != f.sigma || t.longest != f.longest) return false;
+        if (memcmp(t.order, f.order, f.sigma) != 0 || memcmp(t.len_of, f.len_of, 256) != 0) return false;
+    }
+    return true;
+}
+
 void write_huffman_header(HostBitWriter& w, const HuffTable& t) {
     if (t.sigma <= 1) { w.write_bit(0); return; }                                     // :538-540
     w.write_bit(1);                                                                   // :542

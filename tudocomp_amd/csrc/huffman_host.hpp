@@ -43,6 +43,8 @@ struct HostBitWriter {
 };
 
 void build_huffman_table(const uint32_t C[256], HuffTable* t);
+// true iff this build's C++ library reproduces the reference's tables on the built-in fixtures (checked when a context is created)
+bool huffman_selfcheck();
 // HuffmanCoder::Encoder ctor: "0" if sigma <= 1, else "1" + table
 void write_huffman_header(HostBitWriter& w, const HuffTable& t);
 
