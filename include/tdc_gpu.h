@@ -121,7 +121,8 @@ void  tdc_gpu_host_free(void* p);
 
 /* Raw input variant: `data`/`n` is the UNRESTRICTED input (any bytes, no sentinel).  The library applies the
  * compressor's input restrictions on the device -- escape {0} + null-terminate, i.e. what Input(inp, restrictions) does
- * in tudocomp_driver.cpp:268-270 (io/RestrictedBuffer.hpp:43-74) -- and then compresses.  n < 2^30. */
+ * in tudocomp_driver.cpp:268-270 (io/RestrictedBuffer.hpp:43-74) -- and then compresses.  The escaped text (n + number of
+ * 0x00 / 0xFF bytes + 1) must stay below 2^31 - 1 bytes. */
 int tdc_gpu_lcpcomp_compress_raw(tdc_gpu_ctx* ctx, const uint8_t* data, size_t n, uint32_t threshold, int flatten,
                                  int coder, uint8_t** out, size_t* out_len, tdc_gpu_stats* stats);
 /* Device-resident variant: d_text and d_out are device pointers on ctx's GPU (d_out 8-byte aligned, capacity out_cap
@@ -132,6 +133,24 @@ int tdc_gpu_lcpcomp_compress_dev(tdc_gpu_ctx* ctx, const void* d_text, size_t n,
                                  int coder, void* d_out, size_t out_cap, size_t* out_len, tdc_gpu_stats* stats);
 size_t tdc_gpu_lcpcomp_bound(size_t n);
 size_t tdc_gpu_lcpcomp_bound_coder(size_t n, int coder);     /* 0 for an unknown coder */
+
+/* ---- block mode (north_star: inputs above one-GPU size shard into independent blocks; BASELINE.json configs[4]) ----
+ * `data`/`n` is the UNRESTRICTED input.  It is cut into ceil(n / block_size) blocks of block_size bytes (the last one shorter;
+ * block_size < 2^31 - 2 and small enough that the ESCAPED block stays below 2^31 - 1 bytes); block k is compressed exactly like
+ * tdc_gpu_lcpcomp_compress_raw(data + k * block_size, ...) -- own escaping + sentinel, own suffix array, factors and Huffman
+ * table -- on one of the `ndev` devices listed in `devices` (one host thread and one context per device, blocks handed out
+ * from a shared counter).  *out (malloc'd, tdc_gpu_free) receives the container
+ *     "tdcgpu-blocks%" | u32 G | G x { u64 raw_len, u64 comp_len } | payload_0 | ... | payload_{G-1}      (little endian)
+ * whose payloads are byte-identical to the single-block streams.  per_block (nullable): G stats records.
+ * The reference has no counterpart (32-bit len_t: an input is at most 2^31 - 1 bytes, def.hpp:103). */
+size_t tdc_gpu_blocks_count(size_t n, size_t block_size);
+int tdc_gpu_blocks_compress(const int* devices, int ndev, const uint8_t* data, size_t n, size_t block_size, uint32_t threshold,
+                            int flatten, int coder, uint8_t** out, size_t* out_len, tdc_gpu_stats* per_block);
+/* Inverse: every payload through tdc_gpu_lcpcomp_decompress_coder on ctx's device, restrictions removed (unescape, sentinel
+ * dropped), blocks concatenated.  A malformed container: TDC_GPU_ERR_ARG. */
+int tdc_gpu_blocks_decompress(tdc_gpu_ctx* ctx, const uint8_t* container, size_t len, int coder, uint8_t** out, size_t* out_len);
+/* number of visible devices (0 if none / no runtime) */
+int tdc_gpu_device_count(void);
 
 /* ---- LZ78 (BASELINE.json configs[3]): replaces LZ78Compressor<EliasGammaCoder, ...>::compress
  * (compressors/LZ78Compressor.hpp:64-140).  No input restrictions (no escaping, no sentinel).  The parse is sequential

@@ -1,0 +1,86 @@
+"""GPU tests of the product-level block mode (pytest -m gpu): tdc_gpu_blocks_compress / _decompress of the C ABI and
+`tdc --blocks`: every payload of the container is byte-identical to the oracle's stream of that block alone (own escaping,
+sentinel, suffix array, Huffman table), ragged last block, blocks that contain 0x00 / 0xFF, and the device round trip."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import tudocomp_amd as T
+from tudocomp_amd import blocks
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TDC = os.path.join(ROOT, "tudocomp_amd", "bin", "tdc")
+
+
+def _data():
+    rng = np.random.default_rng(11)
+    return (T.gen_english(300000, 42).tobytes() + bytes(rng.integers(0, 256, size=5000, dtype=np.uint8)) + b"\x00" * 300 + b"\xff" * 200 +
+            T.gen_dna(120000, 7).tobytes())
+
+
+@pytest.mark.parametrize("block_size", [65536, 100003, 1 << 20])
+def test_blocks_compress_payloads_equal_single_block_streams(gpu_ctx, block_size):
+    data = _data()
+    blob, st = T.blocks_compress(data, block_size, threshold=2, flatten=1)
+    parts = blocks.unpack_container(blob)
+    want_parts = [data[o:o + block_size] for o in range(0, len(data), block_size)]
+    assert len(parts) == len(want_parts) == len(st)
+    for k, ((raw_len, payload), part) in enumerate(zip(parts, want_parts)):
+        assert raw_len == len(part)
+        want, _ = O.lcpcomp_huff_compress(O.escape(part), 2, 1)
+        assert bytes(payload) == want, k
+        assert st[k]["out_len"] == len(want)
+    assert gpu_ctx.blocks_decompress(blob) == data                       # device decoder, restrictions removed per block
+    assert blocks.decompress_container(blob, lambda s: O.unescape(O.lcpcomp_huff_decompress(s))) == data
+
+
+def test_blocks_edge_cases(gpu_ctx):
+    blob, st = T.blocks_compress(b"", 4096, threshold=2)
+    assert blocks.unpack_container(blob) == [] and st == []
+    assert gpu_ctx.blocks_decompress(blob) == b""
+    blob, _ = T.blocks_compress(b"abc", 1, threshold=2)                   # one-byte blocks
+    assert [r for r, _ in blocks.unpack_container(blob)] == [1, 1, 1]
+    assert gpu_ctx.blocks_decompress(blob) == b"abc"
+    with pytest.raises(T.TdcGpuError):
+        T.blocks_compress(b"abc", 0)
+    with pytest.raises(T.TdcGpuError):
+        gpu_ctx.blocks_decompress(b"not a container")
+    bad = bytearray(T.blocks_compress(b"hello hello hello", 8, threshold=2)[0])
+    bad[-1] ^= 0x55
+    try:                                                                    # a damaged payload is refused or decodes to something else, never crashes
+        gpu_ctx.blocks_decompress(bytes(bad))
+    except T.TdcGpuError:
+        pass
+    assert T.device_count() >= 1
+
+
+def test_tdc_blocks_command_line_roundtrip(tmp_path):
+    data = _data()
+    f = tmp_path / "in.bin"
+    f.write_bytes(data)
+    algo = "lcpcomp(coder=huff,threshold=2)"
+    r = subprocess.run([TDC, "-a", algo, "--blocks", "131072", "-f", "-o", str(tmp_path / "c.tdc"), str(f)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    blob = (tmp_path / "c.tdc").read_bytes()
+    assert blob.startswith(algo.encode() + b"%" + blocks.MAGIC)
+    parts = blocks.unpack_container(blob[len(algo) + 1:])
+    assert [r_ for r_, _ in parts] == [min(131072, len(data) - o) for o in range(0, len(data), 131072)]
+    assert bytes(parts[1][1]) == O.lcpcomp_huff_compress(O.escape(data[131072:262144]), 2, 1)[0]
+    r = subprocess.run([TDC, "-d", "-f", "-o", str(tmp_path / "back"), str(tmp_path / "c.tdc")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert (tmp_path / "back").read_bytes() == data
+
+
+def test_raw_entry_point_accepts_more_than_2_pow_30_bytes_of_plain_text(gpu_ctx):
+    """the raw entry point used to stop at 2^30 input bytes (worst-case escaping); the escapes are now counted on the device"""
+    n = (1 << 30) + 4096
+    data = T.gen_english(n, 43)
+    out, st = gpu_ctx.lcpcomp_compress_raw(data, 2, 1)
+    assert st["n"] == n + 1 and len(out) == st["out_len"]
+    text = np.concatenate([data, np.zeros(1, dtype=np.uint8)])
+    assert O.lcpcomp_huff_decompress(out) == text.tobytes()

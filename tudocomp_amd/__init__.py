@@ -82,6 +82,31 @@ def huffman_table(counts):
     return {"sigma": sigma.value, "longest": longest.value, "order": order, "len_of": len_of, "code_of": code_of}
 
 
+def device_count():
+    return _native.load().tdc_gpu_device_count()
+
+
+def blocks_compress(data, block_size, threshold=5, flatten=1, coder=CODER_HUFF, devices=None):
+    """Block mode (tdc_gpu_blocks_compress): `data` (unrestricted bytes) is cut into blocks of block_size bytes, the blocks are
+    spread over `devices` (default: all visible ones), every block becomes a complete lcpcomp stream.  Returns (container bytes,
+    list of per-block stats dicts)."""
+    L = _native.load()
+    a = _u8(data)
+    if devices is None:
+        devices = list(range(max(1, device_count())))
+    devs = (ctypes.c_int * len(devices))(*devices)
+    G = L.tdc_gpu_blocks_count(len(a), block_size)
+    st = (Stats * max(G, 1))()
+    out, n = ctypes.c_void_p(), ctypes.c_size_t()
+    rc = L.tdc_gpu_blocks_compress(devs, len(devices), _ptr(a), len(a), block_size, threshold, int(flatten), coder,
+                                   ctypes.byref(out), ctypes.byref(n), st)
+    if rc:
+        raise TdcGpuError(rc, "tdc_gpu_blocks_compress")
+    blob = ctypes.string_at(out, n.value)
+    L.tdc_gpu_free(out)
+    return blob, [st[i].as_dict() for i in range(G)]
+
+
 class PinnedBuffer:
     """Page-locked host memory (tdc_gpu_host_alloc) as a numpy uint8 array `.a`; the buffers of the end-to-end entry point."""
 
@@ -257,6 +282,13 @@ class Context:
         self._check(self._L.tdc_gpu_lcpcomp_decompress_coder(self._h, _ptr(a), len(a), coder, ctypes.byref(p), ctypes.byref(n),
                                                              ctypes.byref(f), ctypes.byref(r)))
         return self._take(p, n.value), {"factors": f.value, "rounds": r.value}
+
+    def blocks_decompress(self, blob, coder=CODER_HUFF):
+        """inverse of blocks_compress on this context's device: the concatenated raw bytes"""
+        a = _u8(blob)
+        p, n = ctypes.c_void_p(), ctypes.c_size_t()
+        self._check(self._L.tdc_gpu_blocks_decompress(self._h, _ptr(a), len(a), coder, ctypes.byref(p), ctypes.byref(n)))
+        return self._take(p, n.value)
 
     def factorize(self, text, threshold=5, flatten=0):
         """Returns (pos, src, len) sorted by pos and the stats dict."""

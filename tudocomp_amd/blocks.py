@@ -38,6 +38,17 @@ def unpack_container(blob):
     return out
 
 
+def decompress_container(blob, decode_block):
+    """inverse of the block mode: decode_block(payload) -> the block's raw bytes (restrictions already removed)"""
+    out = []
+    for raw_len, payload in unpack_container(blob):
+        part = decode_block(bytes(payload))
+        if len(part) != raw_len:
+            raise ValueError("block length mismatch")
+        out.append(part)
+    return b"".join(out)
+
+
 def shard_ranges(total, shard):
     """Contiguous byte ranges [k*shard, (k+1)*shard); the last one may be shorter."""
     return [(o, min(o + shard, total)) for o in range(0, total, shard)]

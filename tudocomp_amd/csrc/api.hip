@@ -397,23 +397,32 @@ void compress_host(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, bool raw, ui
     if (!ho.out_len || (!ho.out && !ho.into)) throw ArgError{TDC_GPU_ERR_ARG, "out/out_len is NULL"};
     if (raw) {
         if (!text && n) throw ArgError{TDC_GPU_ERR_ARG, "NULL argument"};
-        if (n >= (1ull << 30)) throw ArgError{TDC_GPU_ERR_TOO_LARGE, "raw input must be < 2^30 bytes (the escaped text must stay < 2^31)"};
+        if (n >= 0x7FFFFFFEull) throw ArgError{TDC_GPU_ERR_TOO_LARGE, "raw input too large: the escaped text must stay < 2^31 - 1 bytes"};
     } else {
         check_text_args(text, n);
         if (text[n - 1] != 0) throw ArgError{TDC_GPU_ERR_NO_SENTINEL, "text does not end with a 0 sentinel"};
     }
     Ctx& c = ctx->c;
     if (stats) memset(stats, 0, sizeof(*stats));
-    c.ensure_arena(raw ? arena_need(2 * n + 1) + n : arena_need(n));
+    // raw input: sized for a text without escapes first; the 0x00 / 0xFF bytes are counted on the device after the upload
+    c.ensure_arena(raw ? arena_need(n + 1) + n + 64 : arena_need(n));
     Events ev(c);
     const int e0 = ev.tick();
     u8* d_text;
     size_t tn = n;
     if (raw) {
         u8* d_raw = c.arena.get<u8>(n + 64);
-        d_text = c.arena.get<u8>(2 * n + 65);
         if (n) HIP_TRY(hipMemcpyAsync(d_raw, text, n, hipMemcpyHostToDevice, c.stream));
-        tn = escape_device(c, d_raw, n, d_text);
+        tn = n + count_escapes_device(c, d_raw, n) + 1;
+        if (tn >= 0x7FFFFFFFull) throw ArgError{TDC_GPU_ERR_TOO_LARGE, "raw input too large: the escaped text must stay < 2^31 - 1 bytes"};
+        if (c.arena.size < arena_need(tn) + n + 64) {                        // many escapes: a larger arena, upload once more
+            HIP_TRY(hipStreamSynchronize(c.stream));
+            c.ensure_arena(arena_need(tn) + n + 64);
+            d_raw = c.arena.get<u8>(n + 64);
+            if (n) HIP_TRY(hipMemcpyAsync(d_raw, text, n, hipMemcpyHostToDevice, c.stream));
+        }
+        d_text = c.arena.get<u8>(tn + 64);
+        if (escape_device(c, d_raw, n, d_text) != tn) throw HipError{hipErrorUnknown, "escape: length mismatch", (int)__LINE__};
     } else {
         d_text = c.arena.get<u8>(n + 64);
         HIP_TRY(hipMemcpyAsync(d_text, text, n, hipMemcpyHostToDevice, c.stream));
@@ -461,6 +470,12 @@ int tdc_gpu_lcpcomp_compress_into(tdc_gpu_ctx* ctx, const uint8_t* text, size_t 
 int tdc_gpu_lcpcomp_compress_raw(tdc_gpu_ctx* ctx, const uint8_t* data, size_t n, uint32_t threshold, int flatten, int coder,
                                  uint8_t** out, size_t* out_len, tdc_gpu_stats* stats) {
     return guarded(ctx, [&] { compress_host(ctx, data, n, true, threshold, flatten, coder, TDC_GPU_COMP_ARRAYS, HostOut{out, nullptr, 0, out_len}, stats); });
+}
+
+int tdc_gpu_device_count(void) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return count;
 }
 
 void* tdc_gpu_host_alloc(size_t bytes) {

@@ -6,8 +6,9 @@
 
 namespace tdc {
 
-// a1: io/RestrictedBuffer.hpp:43-74 + io/EscapeMap.hpp:39-64 on the device (d_out: 2n+1 bytes); returns the escaped length
+// a1: io/RestrictedBuffer.hpp:43-74 + io/EscapeMap.hpp:39-64 on the device (d_out: n + #escapes + 1 bytes); returns the escaped length
 size_t escape_device(Ctx& c, const u8* d_in, size_t n, u8* d_out);
+size_t count_escapes_device(Ctx& c, const u8* d_in, size_t n);     // bytes the escaping adds
 
 struct SAStats { u32 rounds = 0; u32 sym_bits = 0; u32 init_syms = 0; u64 sorted_elems = 0; };
 

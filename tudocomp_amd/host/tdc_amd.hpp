@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "../../include/tdc_gpu.h"
+#include "tdc_coders.hpp"
 
 namespace tdc_amd {
 
@@ -65,6 +66,8 @@ public:
     Output() = default;
     explicit Output(bytes& v) : m_vec(&v) {}
     Output(const Output& other, InputRestrictions r) : m_vec(other.m_vec), m_restr(r) {}
+    // bytes that are already unrestricted (the blocks of a container remove their own restrictions)
+    void write_plain(const uint8_t* p, size_t n) { m_vec->insert(m_vec->end(), p, p + n); }
     void write(const uint8_t* p, size_t n) {
         if (m_restr.has_restrictions()) {                       // un-escaping ostream filter (io/RestrictedIOStream.hpp:13-89)
             bytes tmp(n + 1);
@@ -134,38 +137,7 @@ inline AlgorithmValue parse_algorithm_id(const std::string& s, const std::vector
     return av;
 }
 
-// ---- bit input (io/BitIStream.hpp:16-195) --------------------------------------------------------------------
-class BitIStream {
-    const uint8_t* m_p; size_t m_n, m_idx = 0;
-    uint8_t m_current = 0, m_next = 0, m_final_bits = 0, m_cursor = 0;
-    bool m_is_final = false;
-    void read_next() {
-        m_current = m_next; m_cursor = 7;
-        if (m_idx < m_n) {
-            m_next = m_p[m_idx++];
-            if (m_idx == m_n) { m_final_bits = m_next & 7; if (m_final_bits >= 6) { m_is_final = true; m_next = 0; } }
-        } else { m_is_final = true; m_final_bits = m_current & 7; m_next = 0; }
-    }
-public:
-    BitIStream(const uint8_t* p, size_t n) : m_p(p), m_n(n) {
-        if (n) { m_next = m_p[m_idx++]; read_next(); } else { m_is_final = true; }
-    }
-    bool eof() const { return m_is_final && m_cursor <= (7 - m_final_bits); }
-    unsigned read_bit() {
-        if (eof()) return 0;
-        unsigned bit = (m_current >> m_cursor) & 1;
-        if (m_cursor) --m_cursor; else read_next();
-        return bit;
-    }
-    uint64_t read_int(unsigned bits) { uint64_t v = 0; while (bits--) v = (v << 1) | read_bit(); return v; }
-    uint64_t read_compressed_int(unsigned b = 7) {
-        uint64_t v = 0; unsigned i = 0; bool more;
-        do { more = read_bit(); v |= read_int(b) << (b * i++); } while (more);
-        return v;
-    }
-};
-
-inline unsigned bits_for(uint64_t v) { unsigned b = 0; if (!v) return 1; while (v) { ++b; v >>= 1; } return b; }
+inline unsigned bits_for(uint64_t v) { return coder_bits_for(v); }
 
 // ---- Compressor ---------------------------------------------------------------------------------------------
 class Compressor {
@@ -187,112 +159,44 @@ struct GpuContext {
     GpuContext& operator=(const GpuContext&) = delete;
 };
 
-// HuffmanCoder::Decoder + lzss token stream (decode_text_internal / lzss::decode_text): shared by lcpcomp and lzss_lcp.
-// References may point forwards (lcpcomp) or backwards (lzss_lcp); both are resolved by following source chains.
-inline void lzss_huff_decode(Input& input, Output& output) {
+// coder_t::Decoder + lzss token stream (decode_text_internal / lzss::decode_text), shared by lcpcomp and lzss_lcp: the
+// Decoder classes of tdc_coders.hpp (HuffmanCoder::Decoder, coders/HuffmanCoder.hpp:572-612; ASCIICoder::Decoder,
+// coders/ASCIICoder.hpp:53-84).  References may point forwards (lcpcomp) or backwards (lzss_lcp).
+template <typename coder_t>
+inline void lzss_decode(Input& input, Output& output) {
     const bytes& in = input.raw();
-    BitIStream bs(in.data(), in.size());
-    // HuffmanCoder::Decoder ctor (HuffmanCoder.hpp:581-597)
-    const bool have_table = bs.read_bit();
-    uint8_t order[256]; uint64_t firstcode[256]; size_t prefix_sum[256]; unsigned longest = 0;
-    if (have_table) {
-        longest = (unsigned)(bs.read_compressed_int() & 0xFF);
-        if (!longest) throw std::runtime_error("corrupt Huffman table");
-        uint8_t numl[256];
-        for (unsigned i = 0; i < longest; ++i) numl[i] = (uint8_t)bs.read_compressed_int();
-        const size_t sigma = bs.read_compressed_int();
-        if (sigma > 256) throw std::runtime_error("corrupt Huffman table");
-        for (size_t i = 0; i < sigma; ++i) order[i] = (uint8_t)bs.read_int(8);
-        firstcode[longest - 1] = 0;
-        for (unsigned i = longest - 1; i > 0; --i) firstcode[i - 1] = (firstcode[i] + numl[i]) / 2;
-        size_t acc = 0;
-        for (unsigned l = 0; l < longest; ++l) { prefix_sum[l] = acc; acc += numl[l]; }
-    }
-    // lcpcomp::decode_text_internal (LCPCompressor.hpp:23-76)
-    const uint64_t n = bs.read_int(32);
-    const unsigned W = bits_for(n);
-    const uint64_t flen_min = bs.read_int(W), flen_max = bs.read_int(W), fdist_max = bs.read_int(W);
-    const unsigned lbits = bits_for(flen_max - flen_min), dbits = bits_for(fdist_max);
-    bytes text(n);
-    std::vector<uint32_t> ref(n, 0xFFFFFFFFu);
-    uint64_t p = 0;
-    while (!bs.eof()) {
-        uint64_t num = bs.read_bit() ? bs.read_int(dbits) : 0;
-        while (num--) {
-            uint8_t ch;
-            if (!have_table) ch = (uint8_t)bs.read_int(8);
-            else {
-                uint64_t value = 0; unsigned length = 0;
-                do { value = (value << 1) + bs.read_bit(); ++length; } while (length <= longest && value < firstcode[length - 1]);
-                if (length > longest) throw std::runtime_error("corrupt Huffman code");
-                --length;
-                ch = order[prefix_sum[length] + (value - firstcode[length])];
-            }
-            if (p >= n) throw std::runtime_error("corrupt stream: too many literals");
-            text[p++] = ch;
-        }
-        if (!bs.eof()) {
-            const uint64_t src = bs.read_int(W), len = flen_min + bs.read_int(lbits);
-            if (p + len > n || src + len > n) throw std::runtime_error("corrupt stream: factor out of range");
-            for (uint64_t j = 0; j < len; ++j) ref[p + j] = (uint32_t)(src + j);
-            p += len;
-        }
-    }
-    if (p != n) throw std::runtime_error("corrupt stream: length mismatch");
-    std::vector<uint32_t> stack;
-    for (uint64_t i = 0; i < n; ++i) {
-        if (ref[i] == 0xFFFFFFFFu) continue;
-        stack.clear();
-        uint32_t q = (uint32_t)i;
-        while (ref[q] != 0xFFFFFFFFu) {
-            if (stack.size() > n) throw std::runtime_error("corrupt stream: reference cycle");
-            stack.push_back(q); q = ref[q];
-        }
-        for (uint32_t r : stack) { text[r] = text[q]; ref[r] = 0xFFFFFFFFu; }
-    }
+    typename coder_t::Decoder decoder(std::make_shared<BitIStream>(in.data(), in.size()));
+    bytes text;
+    decode_text(decoder, text);
     output.write(text.data(), text.size());
 }
+inline void lzss_huff_decode(Input& input, Output& output) { lzss_decode<HuffmanCoder>(input, output); }
+inline void lzss_ascii_decode(Input& input, Output& output) { lzss_decode<ASCIICoder>(input, output); }
 
-// ASCIICoder::Decoder (coders/ASCIICoder.hpp:53-84) + the same token stream: integers are decimal digits up to the first
-// non-digit (':'), a bit is any byte but '0', literals are raw bytes; the BitOStream terminator byte ends the stream.
-inline void lzss_ascii_decode(Input& input, Output& output) {
-    const bytes& in = input.raw();
-    if (in.empty()) throw std::runtime_error("corrupt stream: empty");
-    const size_t len = in.size() - 1;
-    size_t at = 0;
-    auto read_int = [&]() -> uint64_t {
-        uint64_t v = 0; int digits = 0;
-        while (at < len) {
-            const uint8_t ch = in[at++];
-            if (ch < '0' || ch > '9') { if (!digits) break; return v; }
-            v = v * 10 + (ch - '0'); ++digits;
+// ---- block container (written by tdc_gpu_blocks_compress / tudocomp_amd.blocks): "tdcgpu-blocks%" | u32 G |
+//      G x { u64 raw_len, u64 comp_len } | payloads, little endian.  Every payload is a complete stream of its block.
+struct BlockContainer {
+    struct Block { uint64_t raw_len; const uint8_t* data; size_t len; };
+    static constexpr const char* MAGIC = "tdcgpu-blocks%";
+    static bool is_container(const uint8_t* p, size_t n) { return n >= 14 && std::memcmp(p, MAGIC, 14) == 0; }
+    static std::vector<Block> parse(const uint8_t* p, size_t n) {
+        if (!is_container(p, n) || n < 18) throw std::runtime_error("not a tdcgpu-blocks container");
+        auto u32at = [&](size_t o) { uint32_t v = 0; for (int i = 0; i < 4; ++i) v |= (uint32_t)p[o + i] << (8 * i); return v; };
+        auto u64at = [&](size_t o) { uint64_t v = 0; for (int i = 0; i < 8; ++i) v |= (uint64_t)p[o + i] << (8 * i); return v; };
+        const size_t G = u32at(14);
+        if (n < 18 + 16 * G) throw std::runtime_error("corrupt container: directory");
+        std::vector<Block> out;
+        size_t at = 18 + 16 * G;
+        for (size_t k = 0; k < G; ++k) {
+            const uint64_t raw = u64at(18 + 16 * k), comp = u64at(18 + 16 * k + 8);
+            if (comp > n - at) throw std::runtime_error("corrupt container: payload exceeds the file");
+            out.push_back(Block{raw, p + at, (size_t)comp});
+            at += comp;
         }
-        throw std::runtime_error("corrupt stream: integer expected");
-    };
-    const uint64_t n = read_int();
-    read_int(); read_int(); read_int();                        // flen_min, flen_max, fdist_max: not needed by this coder
-    bytes text(n);
-    std::vector<uint32_t> ref(n, 0xFFFFFFFFu);
-    uint64_t p = 0;
-    while (at < len) {
-        uint64_t num = (in[at++] != '0') ? read_int() : 0;
-        if (p + num > n || at + num > len) throw std::runtime_error("corrupt stream: too many literals");
-        while (num--) text[p++] = in[at++];
-        if (at < len) {
-            const uint64_t src = read_int(), l = read_int();
-            if (p + l > n || src + l > n) throw std::runtime_error("corrupt stream: factor out of range");
-            for (uint64_t j = 0; j < l; ++j) ref[p + j] = (uint32_t)(src + j);
-            p += l;
-        }
+        if (at != n) throw std::runtime_error("corrupt container: trailing bytes");
+        return out;
     }
-    if (p != n) throw std::runtime_error("corrupt stream: length mismatch");
-    for (uint64_t i = 0; i < n; ++i) {
-        uint32_t q = (uint32_t)i; uint64_t guard = 0;
-        while (ref[q] != 0xFFFFFFFFu) { q = ref[q]; if (++guard > n) throw std::runtime_error("corrupt stream: reference cycle"); }
-        text[i] = text[q];
-    }
-    output.write(text.data(), text.size());
-}
+};
 
 // SLECoder::Decoder (coders/SLECoder.hpp:301-453) + the same token stream: ranking header, rank class codes, k-mer
 // symbols expand to k literals; the factor length is a MinDistributedRange (:413-431).
@@ -415,7 +319,36 @@ public:
         tdc_gpu_free(out);
     }
 
+    // block mode (tdc --blocks SIZE): the UNRESTRICTED input is cut into blocks of block_size bytes, every block is compressed
+    // on one of the visible devices as a stream of its own (tdc_gpu_blocks_compress) and framed in the block container
+    void compress_blocks(const bytes& raw, size_t block_size, Output& output, int ndev = 0) {
+        int have = tdc_gpu_device_count();
+        if (have <= 0) throw std::runtime_error(std::string("tdc_gpu_blocks_compress: ") + tdc_gpu_strerror(TDC_GPU_ERR_HIP));
+        if (ndev > 0 && ndev < have) have = ndev;
+        std::vector<int> devs((size_t)have);
+        for (int i = 0; i < have; ++i) devs[(size_t)i] = i;
+        uint8_t* out = nullptr; size_t out_len = 0;
+        const int rc = tdc_gpu_blocks_compress(devs.data(), have, raw.data(), raw.size(), block_size, (uint32_t)m_opts.get_int("threshold", 5),
+                                               (int)m_opts.get_int("flatten", 1), m_coder, &out, &out_len, nullptr);
+        if (rc) throw std::runtime_error(std::string("tdc_gpu_blocks_compress: ") + tdc_gpu_strerror(rc));
+        output.write(out, out_len);
+        tdc_gpu_free(out);
+    }
+
     void decompress(Input& input, Output& output) override {
+        if (BlockContainer::is_container(input.raw().data(), input.raw().size())) {      // every payload is a stream of its own
+            const bytes& in = input.raw();
+            for (const BlockContainer::Block& b : BlockContainer::parse(in.data(), in.size())) {
+                Input part = Input::from_memory(b.data, b.len);
+                bytes plain;
+                Output po(plain);
+                Output restricted(po, input_restrictions());                              // the block's own escaping + sentinel
+                decompress(part, restricted);
+                if (plain.size() != b.raw_len) throw std::runtime_error("corrupt container: block length mismatch");
+                output.write_plain(plain.data(), plain.size());
+            }
+            return;
+        }
         if (m_coder == TDC_GPU_CODER_ARITH)
             throw std::runtime_error("lcpcomp(coder=arithmetic) streams cannot be decoded (neither can the reference: "
                                      "consuming coders corrupt interleaved streams, docs/Documentation.md:1190-1203)");
@@ -490,14 +423,14 @@ public:
     // LZ78Compressor::decompress (:142-160) with EliasGammaCoder::Decoder: pairs until BitIStream eof
     void decompress(Input& input, Output& output) override {
         const bytes& in = input.raw();
-        BitIStream bs(in.data(), in.size());
+        EliasGammaCoder::Decoder decoder(std::make_shared<BitIStream>(in.data(), in.size()));
         std::vector<uint32_t> parent(1, 0);
         std::vector<uint8_t> chr(1, 0);
         bytes text, tmp;
-        auto gamma = [&]() -> uint64_t { unsigned b = 0; while (!bs.read_bit()) { if (++b > 64) throw std::runtime_error("corrupt gamma code"); } return bs.read_int(b); };
-        while (!bs.eof()) {
-            const uint64_t id = gamma();
-            const uint64_t c = gamma();
+        const Range factor_r(0, std::numeric_limits<uint32_t>::max());       // the ranges are ignored by this coder (:26-29)
+        while (!decoder.eof()) {
+            const uint64_t id = decoder.decode<uint64_t>(factor_r);
+            const uint64_t c = decoder.decode<uint64_t>(factor_r);
             if (id >= parent.size()) throw std::runtime_error("corrupt stream: unknown phrase id");
             tmp.clear();
             for (uint64_t x = id; x != 0; x = parent[x]) tmp.push_back(chr[x]);

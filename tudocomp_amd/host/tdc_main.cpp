@@ -23,10 +23,12 @@ int main(int argc, char** argv) {
         {"force", no_argument, nullptr, 'f'},           {"list", no_argument, nullptr, 'l'},
         {"output", required_argument, nullptr, 'o'},    {"stats", no_argument, nullptr, 's'},
         {"raw", no_argument, nullptr, 1001},            {"help", no_argument, nullptr, 1000},
-        {"device", required_argument, nullptr, 1002},   {0, 0, 0, 0}};
+        {"device", required_argument, nullptr, 1002},   {"blocks", required_argument, nullptr, 1003},
+        {"devices", required_argument, nullptr, 1004},  {0, 0, 0, 0}};
     std::string algo, ofile;
     bool decompress = false, force = false, list = false, stats = false, raw = false;
-    int device = 0;
+    int device = 0, ndev = 0;
+    size_t block_size = 0;
     for (int c; (c = getopt_long(argc, argv, "a:dflo:s", OPTS, nullptr)) != -1;) {
         switch (c) {
             case 'a': algo = optarg; break;
@@ -37,8 +39,12 @@ int main(int argc, char** argv) {
             case 's': stats = true; break;
             case 1001: raw = true; break;
             case 1002: device = atoi(optarg); break;
+            case 1003: block_size = (size_t)strtoull(optarg, nullptr, 10); break;
+            case 1004: ndev = atoi(optarg); break;
             case 1000:
-                std::cout << "Usage: tdc [-a ALGORITHM] [-d] [-f] [-o OUTPUT] [--raw] [--stats] [--device N] FILE\n       tdc -l\n";
+                std::cout << "Usage: tdc [-a ALGORITHM] [-d] [-f] [-o OUTPUT] [--raw] [--stats] [--device N] [--blocks BYTES [--devices N]] FILE\n       tdc -l\n"
+                             "  --blocks BYTES  lcpcomp only: cut the input into independent blocks of BYTES bytes, spread them over the visible\n"
+                             "                  GPUs (or the first N with --devices) and frame the streams in a block container; -d detects it\n";
                 return 0;
             default: return 1;
         }
@@ -68,8 +74,14 @@ int main(int argc, char** argv) {
                 result.insert(result.end(), algo.begin(), algo.end());
                 result.push_back('%');
             }
-            if (sel.restrictions.has_restrictions()) inp = Input(inp, sel.restrictions);  // :268-270
-            sel.compressor->compress(inp, out);
+            if (block_size) {                                                            // block mode: restrictions are applied per block
+                auto* lc = dynamic_cast<LCPCompressor*>(sel.compressor.get());
+                if (!lc) fail("--blocks is only available for lcpcomp");
+                lc->compress_blocks(inp.raw(), block_size, out, ndev);
+            } else {
+                if (sel.restrictions.has_restrictions()) inp = Input(inp, sel.restrictions);  // :268-270
+                sel.compressor->compress(inp, out);
+            }
         } else {
             std::string header;
             if (!raw) {                                                                  // :284-313
@@ -82,7 +94,8 @@ int main(int argc, char** argv) {
             const std::string id = !algo.empty() ? algo : header;
             if (id.empty()) fail("No algorithm given (-a) and no header present");
             sel = select_algorithm(id);
-            if (sel.restrictions.has_restrictions()) out = Output(out, sel.restrictions);  // :336-338
+            const bool container = BlockContainer::is_container(inp.raw().data(), inp.raw().size());   // blocks undo their own restrictions
+            if (sel.restrictions.has_restrictions() && !container) out = Output(out, sel.restrictions);  // :336-338
             sel.compressor->decompress(inp, out);
         }
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
