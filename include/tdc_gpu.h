@@ -41,7 +41,7 @@ enum { TDC_GPU_CODER_HUFF = 0, TDC_GPU_CODER_GAMMA = 1, TDC_GPU_CODER_ARITH = 2,
 /* coder=sle(kmer=K) (coders/SLECoder.hpp:36-40; the reference's default is 3): the option travels in bits 8.. of `coder` */
 #define TDC_GPU_CODER_SLE_K(K) (TDC_GPU_CODER_SLE | ((K) << 8))
 /* factorization strategy of lcpcomp (option `comp`, LCPCompressor.hpp:87): ArraysComp or PLCPPeaksStrategy */
-enum { TDC_GPU_COMP_ARRAYS = 0, TDC_GPU_COMP_PLCPPEAKS = 1, TDC_GPU_COMP_MAXLCP = 2 };
+enum { TDC_GPU_COMP_ARRAYS = 0, TDC_GPU_COMP_PLCPPEAKS = 1, TDC_GPU_COMP_MAXLCP = 2, TDC_GPU_COMP_HEAP = 3 };
 
 typedef struct tdc_gpu_ctx tdc_gpu_ctx;
 
@@ -103,7 +103,9 @@ int tdc_gpu_lcpcomp_compress(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, ui
  * entry point above) or TDC_GPU_COMP_PLCPPEAKS (lcpcomp::PLCPPeaksStrategy, compressors/lcpcomp/compress/PLCPPeaksStrategy.hpp:36-80:
  * strict local maxima of the PLCP array, one left-to-right scan) or TDC_GPU_COMP_MAXLCP (lcpcomp::MaxLCPStrategy,
  * compressors/lcpcomp/compress/MaxLCPStrategy.hpp:36-100: the same greedy rule as ArraysComp with the tie order of its
- * per-level stacks and eager key decreases). */
+ * per-level stacks and eager key decreases) or TDC_GPU_COMP_HEAP (lcpcomp::MaxHeapStrategy, MaxHeapStrategy.hpp:36-101 over
+ * ds/ArrayMaxHeap.hpp: the strategy of the reference's published heap run; its tie order is the layout history of a binary
+ * heap, so the device replays the reference's loop with ONE thread -- a parity row, about a minute per MiB of text). */
 int tdc_gpu_lcpcomp_compress_comp(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, uint32_t threshold, int flatten, int coder,
                                   int comp, uint8_t** out, size_t* out_len, tdc_gpu_stats* stats);
 

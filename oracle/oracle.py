@@ -200,6 +200,31 @@ def max_lcp(sa, isa, lcp, maxlcp, threshold):
     return np.frombuffer(raw, dtype=FACTOR_DTYPE).copy()
 
 
+def max_heap(sa, isa, lcp, threshold):
+    """MaxHeapStrategy factor list in EMISSION order (compressors/lcpcomp/compress/MaxHeapStrategy.hpp:36-101)."""
+    lcp = lcp.copy()
+    out = ctypes.c_void_p()
+    L = lib()
+    L.orc_max_heap.restype = ctypes.c_size_t
+    L.orc_max_heap.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p)]
+    z = L.orc_max_heap(sa.ctypes.data_as(ctypes.c_void_p), isa.ctypes.data_as(ctypes.c_void_p), lcp.ctypes.data_as(ctypes.c_void_p),
+                       len(sa), threshold, ctypes.byref(out))
+    raw = _take(out, z * 12) if out.value else b""
+    return np.frombuffer(raw, dtype=FACTOR_DTYPE).copy()
+
+
+def lcpcomp_heap_huff_compress(text, threshold=5, flatten=1):
+    """lcpcomp(coder=huff, comp=heap)"""
+    a, p = _buf(text)
+    out, n, st = ctypes.c_void_p(), ctypes.c_size_t(), Stats()
+    L = lib()
+    L.orc_lcpcomp_heap_huff_compress.argtypes = L.orc_lcpcomp_maxlcp_huff_compress.argtypes
+    rc = L.orc_lcpcomp_heap_huff_compress(p, len(a), threshold, flatten, ctypes.byref(out), ctypes.byref(n), ctypes.byref(st))
+    if rc:
+        raise RuntimeError("orc_lcpcomp_heap_huff_compress rc=%d" % rc)
+    return _take(out, n.value), st.as_dict()
+
+
 def sort_factors(f):
     f = f.copy()
     lib().orc_sort_factors(f.ctypes.data_as(ctypes.c_void_p), len(f))

@@ -317,6 +317,82 @@ static void mlsl_remove(mlsl* l, size_t i) {                                 /* 
     l->contained[i] = 0;
     --l->size;
 }
+/* ------------------------------------------------------------------------------------------------
+ * lcpcomp::MaxHeapStrategy (compressors/lcpcomp/compress/MaxHeapStrategy.hpp:36-101) over tdc::ArrayMaxHeap
+ * (ds/ArrayMaxHeap.hpp:14-241): a binary max-heap of suffix-array indices keyed by lcp[], with a back mapping.
+ * Restated operation by operation, quirks included: remove() moves the LAST heap element into the hole and only ever
+ * sifts it DOWN (:156-170; the heap property may be violated towards the parent afterwards, the reference does not care),
+ * and the tie rules of perlocate_down compare the moved ELEMENT k with the child's heap POSITION (:114-119).
+ * The reference's tests hold no vector for this strategy: PARITY UNPINNED (properties + tests/models only).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { const uint32_t* key; uint32_t* heap; uint32_t* pos; size_t size, undef; } amh;
+static void amh_put(amh* h, size_t p, uint32_t i) { h->heap[p] = i; h->pos[i] = (uint32_t)p; }
+static void amh_insert(amh* h, uint32_t i) {                                 /* :61-78 */
+    size_t p = h->size++;
+    const uint32_t ki = h->key[i];
+    while (p > 0 && ki > h->key[h->heap[(p - 1) / 2]]) { amh_put(h, p, h->heap[(p - 1) / 2]); p = (p - 1) / 2; }
+    amh_put(h, p, i);
+}
+static void amh_perlocate_down(amh* h, size_t p, uint32_t k) {               /* :81-137 */
+    const uint32_t kk = h->key[k];
+    int dir;
+    do {
+        const size_t lc = 2 * p + 1, rc = 2 * p + 2;
+        const uint32_t kl = (lc < h->size) ? h->key[h->heap[lc]] : 0;
+        const uint32_t kr = (rc < h->size) ? h->key[h->heap[rc]] : 0;
+        if (kk < kl && kk < kr) dir = (kl > kr) ? 1 : 2;
+        else if (kk < kl) dir = 1;
+        else if (kk < kr) dir = 2;
+        else if (kk == kl && kk == kr) dir = (lc < rc) ? 1 : 2;
+        else if (kk == kl && k > lc) dir = 1;                                /* element index against heap position, as written */
+        else if (kk == kr && k > rc) dir = 2;
+        else dir = 0;
+        if (dir == 1) { amh_put(h, p, h->heap[lc]); p = lc; }
+        else if (dir == 2) { amh_put(h, p, h->heap[rc]); p = rc; }
+    } while (dir != 0);
+    amh_put(h, p, k);
+}
+static void amh_remove(amh* h, uint32_t i) {                                 /* :140-154 */
+    const size_t p = h->pos[i];
+    if (p != h->undef) {
+        const uint32_t k = h->heap[--h->size];
+        amh_perlocate_down(h, p, k);
+        h->pos[i] = (uint32_t)h->undef;
+    }
+}
+size_t orc_max_heap(const uint32_t* sa, const uint32_t* isa, uint32_t* lcp, size_t n, uint32_t threshold, orc_factor** out) {
+    *out = NULL;
+    if (n == 0) return 0;
+    size_t heap_size = 0;
+    for (size_t i = 1; i < n; ++i) if (lcp[i] >= threshold) ++heap_size;       /* MaxHeapStrategy.hpp:52-55 */
+    amh h; h.key = lcp; h.size = 0; h.undef = heap_size;
+    h.heap = (uint32_t*)malloc((heap_size ? heap_size : 1) * 4);
+    h.pos = (uint32_t*)malloc(n * 4);
+    for (size_t i = 0; i < n; ++i) h.pos[i] = (uint32_t)heap_size;
+    for (size_t i = 1; i < n; ++i) if (lcp[i] >= threshold) amh_insert(&h, (uint32_t)i);   /* :58-61 */
+    size_t z = 0, zcap = 1024;
+    orc_factor* F = (orc_factor*)malloc(zcap * sizeof(orc_factor));
+    while (h.size > 0) {                                                     /* :68-97 */
+        const size_t m = h.heap[0];
+        const uint32_t fpos = sa[m], fsrc = sa[m - 1], flen = lcp[m];
+        if (z == zcap) { zcap *= 2; F = (orc_factor*)realloc(F, zcap * sizeof(orc_factor)); }
+        F[z].pos = fpos; F[z].src = fsrc; F[z].len = flen; ++z;
+        for (uint32_t k = 0; k < flen; ++k) amh_remove(&h, isa[fpos + k]);   /* :79-81 */
+        for (uint32_t k = 0; k < flen && fpos > k; ++k) {                    /* :84-96 */
+            const size_t sp = fpos - k - 1;
+            const uint32_t i = isa[sp];
+            if (h.pos[i] != h.undef && sp + lcp[i] > fpos) {
+                const uint32_t nl = (uint32_t)(fpos - sp);
+                if (nl >= threshold) { lcp[i] = nl; amh_perlocate_down(&h, h.pos[i], i); }    /* decrease_key :157-170 */
+                else amh_remove(&h, i);
+            }
+        }
+    }
+    free(h.heap); free(h.pos);
+    *out = F;
+    return z;
+}
+
 size_t orc_max_lcp(const uint32_t* sa, const uint32_t* isa, uint32_t* lcp, size_t n,
                    uint32_t maxlcp, uint32_t threshold, orc_factor** out) {
     *out = NULL;
@@ -1058,6 +1134,14 @@ int orc_lcpcomp_maxlcp_huff_compress(const uint8_t* text, size_t n, uint32_t thr
     g_strategy = 0;
     return rc;
 }
+/* lcpcomp(coder=huff, comp=heap): MaxHeapStrategy */
+int orc_lcpcomp_heap_huff_compress(const uint8_t* text, size_t n, uint32_t threshold, int flatten,
+                                   uint8_t** out, size_t* out_len, orc_stats* stats) {
+    g_strategy = 3;
+    const int rc = lcpcomp_compress(text, n, threshold, flatten, 0, out, out_len, stats);
+    g_strategy = 0;
+    return rc;
+}
 int orc_lcpcomp_huff_compress(const uint8_t* text, size_t n, uint32_t threshold, int flatten,
                               uint8_t** out, size_t* out_len, orc_stats* stats) {
     return lcpcomp_compress(text, n, threshold, flatten, 0, out, out_len, stats);
@@ -1106,6 +1190,7 @@ static int lcpcomp_compress(const uint8_t* text, size_t n, uint32_t threshold, i
     size_t z;
     if (g_strategy == 1) { phi[n - 1] = phi_last; z = orc_plcp_peaks(sa, isa, phi, n, threshold, &F); }
     else if (g_strategy == 2) z = orc_max_lcp(sa, isa, lcp, n, maxlcp, threshold, &F);
+    else if (g_strategy == 3) z = orc_max_heap(sa, isa, lcp, n, threshold, &F);
     else z = orc_arrays_comp(sa, isa, lcp, n, maxlcp, threshold, &F);
     free(phi);
     stats->t_factorize = now_s() - t; t = now_s();

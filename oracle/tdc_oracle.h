@@ -88,6 +88,10 @@ int orc_lcpcomp_huff_compress(const uint8_t* text, size_t n, uint32_t threshold,
 /* lcpcomp(comp=plcppeaks): PLCPPeaksStrategy (compressors/lcpcomp/compress/PLCPPeaksStrategy.hpp:36-80) instead of ArraysComp.
  * The reference's tests hold no vector for it and none was recorded: pinned by its properties only (valid copies, round trip). */
 /* lcpcomp::MaxLCPStrategy (compressors/lcpcomp/compress/MaxLCPStrategy.hpp:36-100); lcp is modified; factors in emission order */
+/* lcpcomp::MaxHeapStrategy (MaxHeapStrategy.hpp:36-101, ds/ArrayMaxHeap.hpp): factors in emission order; lcp is modified */
+size_t orc_max_heap(const uint32_t* sa, const uint32_t* isa, uint32_t* lcp, size_t n, uint32_t threshold, orc_factor** out);
+int orc_lcpcomp_heap_huff_compress(const uint8_t* text, size_t n, uint32_t threshold, int flatten,
+                                   uint8_t** out, size_t* out_len, orc_stats* stats);
 size_t orc_max_lcp(const uint32_t* sa, const uint32_t* isa, uint32_t* lcp, size_t n,
                    uint32_t maxlcp, uint32_t threshold, orc_factor** out);
 int orc_lcpcomp_maxlcp_huff_compress(const uint8_t* text, size_t n, uint32_t threshold, int flatten,

@@ -145,7 +145,7 @@ def test_error_codes(gpu_ctx):
     with pytest.raises(RuntimeError, match="No implementation found"):
         T.LCPCompressor(gpu_ctx, coder="bit")
     with pytest.raises(RuntimeError, match="No implementation found"):
-        T.LCPCompressor(gpu_ctx, comp="heap")            # MaxHeapStrategy: not built
+        T.LCPCompressor(gpu_ctx, comp="bogus")
     # the context is still usable afterwards
     want, _ = O.lcpcomp_huff_compress(b"abcabc\x00", 2, 1)
     assert gpu_ctx.lcpcomp_compress(b"abcabc\x00", 2, 1)[0] == want
@@ -413,6 +413,24 @@ def test_lcpcomp_max_lcp_strategy(gpu_ctx):
     c = T.LCPCompressor(gpu_ctx, coder="huff", threshold=3, comp="max_lcp")
     data = T.gen_english(80_000, 2).tobytes() + bytes([0, 255, 0])
     assert c.decompress(c.compress(data)) == data
+
+
+def test_lcpcomp_heap_strategy(gpu_ctx):
+    """comp=heap (lcpcomp::MaxHeapStrategy, MaxHeapStrategy.hpp:36-101 over ds/ArrayMaxHeap.hpp): the device replays the reference's
+    heap loop; streams byte-identical to the oracle's restatement (which the reference does not pin: no vector for this strategy),
+    valid round trips, and a different factorization than comp=arrays where ties are broken differently"""
+    differs = 0
+    cases = SMALL + corpus.random_small(120, seed=77) + [("english64k", T.gen_english(1 << 16, 42).tobytes()), ("dna32k", T.gen_dna(1 << 15, 7).tobytes())]
+    for name, data in cases:
+        text = O.escape(data)
+        for thr in (2, 5):
+            want, _ = O.lcpcomp_heap_huff_compress(text, thr, 1)
+            got, st = gpu_ctx.lcpcomp_compress(text, thr, 1, T.CODER_HUFF, T.COMP_HEAP)
+            assert got == want, (name, thr)
+            assert O.lcpcomp_huff_decompress(got) == text
+            differs += got != O.lcpcomp_huff_compress(text, thr, 1)[0]
+    assert differs > 0
+    assert T.LCPCompressor(gpu_ctx, comp="heap", threshold=2).compress(b"abcabcabc abcabc") == O.lcpcomp_heap_huff_compress(O.escape(b"abcabcabc abcabc"), 2, 1)[0]
 
 
 def test_fuzz_all_variants(gpu_ctx):

@@ -191,3 +191,104 @@ def test_plcppeaks_strategy_properties():
             if back != text and len(set(text)) >= 256:
                 continue
             assert back == text, (name, thr)
+
+
+def test_max_heap_strategy_restatement_against_a_direct_model():
+    """orc_max_heap (MaxHeapStrategy.hpp:36-101 + ds/ArrayMaxHeap.hpp) against an independent pure-Python transcription of the same
+    two reference files, on small inputs; plus its properties: factors do not overlap, every factor is a valid copy of length >=
+    threshold, and the stream round-trips.  (The reference holds no vector for this strategy: parity unpinned.)"""
+    import random
+
+    def model(sa, isa, lcp, threshold):
+        n = len(sa)
+        lcp = list(lcp)
+        idx = [i for i in range(1, n) if lcp[i] >= threshold]
+        undef = len(idx)
+        heap, pos = [0] * max(undef, 1), [undef] * n
+        size = 0
+
+        def put(p, i):
+            heap[p] = i
+            pos[i] = p
+
+        def down(p, k):
+            kk = lcp[k]
+            while True:
+                lc, rc = 2 * p + 1, 2 * p + 2
+                kl = lcp[heap[lc]] if lc < size else 0
+                kr = lcp[heap[rc]] if rc < size else 0
+                if kk < kl and kk < kr:
+                    d = 1 if kl > kr else 2
+                elif kk < kl:
+                    d = 1
+                elif kk < kr:
+                    d = 2
+                elif kk == kl and kk == kr:
+                    d = 1
+                elif kk == kl and k > lc:
+                    d = 1
+                elif kk == kr and k > rc:
+                    d = 2
+                else:
+                    d = 0
+                if d == 0:
+                    break
+                c = lc if d == 1 else rc
+                put(p, heap[c])
+                p = c
+            put(p, k)
+
+        for i in idx:
+            p = size
+            size += 1
+            while p > 0 and lcp[i] > lcp[heap[(p - 1) // 2]]:
+                put(p, heap[(p - 1) // 2])
+                p = (p - 1) // 2
+            put(p, i)
+        out = []
+        while size > 0:
+            m = heap[0]
+            fpos, fsrc, fl = int(sa[m]), int(sa[m - 1]), lcp[m]
+            out.append((fpos, fsrc, fl))
+            for k in range(fl):
+                i = int(isa[fpos + k])
+                if pos[i] != undef:
+                    size -= 1
+                    last = heap[size]
+                    p = pos[i]
+                    down(p, last)
+                    pos[i] = undef
+            for k in range(fl):
+                if fpos <= k:
+                    break
+                s = fpos - k - 1
+                i = int(isa[s])
+                if pos[i] != undef and s + lcp[i] > fpos:
+                    nl = fpos - s
+                    if nl >= threshold:
+                        lcp[i] = nl
+                        down(pos[i], i)
+                    else:
+                        size -= 1
+                        last = heap[size]
+                        p = pos[i]
+                        down(p, last)
+                        pos[i] = undef
+        return out
+
+    rng = random.Random(5)
+    texts = [d for _, d in corpus.small_corpus() if len(d) <= 700] + [d for _, d in corpus.random_small(150, seed=31)]
+    for data in texts:
+        text = O.escape(data)
+        sa = O.suffix_array(text)
+        isa, phi, plcp, maxlcp = O.isa_phi_plcp(text, sa)
+        lcp = O.lcp_array(sa, plcp)
+        for thr in (1, 2, 3, 5):
+            f = O.max_heap(sa, isa, lcp, thr)
+            assert [(int(a), int(b), int(c)) for a, b, c in zip(f["pos"], f["src"], f["len"])] == model(sa, isa, lcp, thr)
+            covered = np.zeros(len(text), dtype=bool)
+            for p_, s_, l_ in zip(f["pos"], f["src"], f["len"]):
+                assert l_ >= thr and not covered[p_:p_ + l_].any() and text[p_:p_ + l_] == text[s_:s_ + l_]
+                covered[p_:p_ + l_] = True
+            out, _ = O.lcpcomp_heap_huff_compress(text, max(thr, 1), 1)
+            assert O.lcpcomp_huff_decompress(out) == text

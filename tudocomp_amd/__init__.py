@@ -19,6 +19,7 @@ CODER_SLE = 4            # coder=sle(kmer=k): CODER_SLE | (k << 8), k = 0 means 
 COMP_ARRAYS = 0
 COMP_PLCPPEAKS = 1
 COMP_MAXLCP = 2
+COMP_HEAP = 3
 
 
 class TdcGpuError(RuntimeError):
@@ -343,12 +344,12 @@ class LCPCompressor:
     input restrictions (escape {0}, null-terminate) and handed to compress()."""
 
     def __init__(self, ctx, coder="huff", threshold=5, flatten=1, comp="arrays", kmer=3):
-        if coder not in ("huff", "arithmetic", "ascii", "sle") or comp not in ("arrays", "plcppeaks", "max_lcp"):
+        if coder not in ("huff", "arithmetic", "ascii", "sle") or comp not in ("arrays", "plcppeaks", "max_lcp", "heap"):
             # same wording as Registry.hpp:214
             raise RuntimeError("No implementation found for compressor lcpcomp(coder=%s,comp=%s)" % (coder, comp))
         self.ctx, self.threshold, self.flatten = ctx, int(threshold), int(flatten)
         self.coder = {"huff": CODER_HUFF, "arithmetic": CODER_ARITH, "ascii": CODER_ASCII, "sle": CODER_SLE | (int(kmer) << 8)}[coder]
-        self.comp = {"arrays": COMP_ARRAYS, "plcppeaks": COMP_PLCPPEAKS, "max_lcp": COMP_MAXLCP}[comp]
+        self.comp = {"arrays": COMP_ARRAYS, "plcppeaks": COMP_PLCPPEAKS, "max_lcp": COMP_MAXLCP, "heap": COMP_HEAP}[comp]
         self.last_stats = None
 
     def compress(self, data):

@@ -187,6 +187,7 @@ void run_factorize(Ctx& c, size_t n, DevArrays& A, u32 threshold, int flatten, t
     const int e0 = ev ? ev->tick() : 0;
     if (strategy == TDC_GPU_COMP_PLCPPEAKS) plcp_peaks_factorize(c, n, A.phi, A.plcp, threshold, A.fs, &fz.factors);
     else if (strategy == TDC_GPU_COMP_MAXLCP) factorize_max_lcp(c, n, A.isa, A.phi, A.plcp, A.maxlcp, threshold, A.fs, &fz);
+    else if (strategy == TDC_GPU_COMP_HEAP) factorize_max_heap(c, n, A.sa, A.isa, A.plcp, A.maxlcp, threshold, A.fs, &fz);
     else factorize_arrays(c, n, A.sa, A.isa, A.phi, A.plcp, A.maxlcp, threshold, A.fs, &fz);
     const int e1 = ev ? ev->tick() : 0;
     if (flatten) flatten_factors(c, n, A.fs, &fl);
@@ -392,8 +393,8 @@ struct HostOut { uint8_t** out; uint8_t* into; size_t cap; size_t* out_len; };
 void compress_host(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, bool raw, uint32_t threshold, int flatten, int coder, int comp,
                    HostOut ho, tdc_gpu_stats* stats) {
     (void)lcpcomp_enc_coder(coder);
-    if (comp != TDC_GPU_COMP_ARRAYS && comp != TDC_GPU_COMP_PLCPPEAKS && comp != TDC_GPU_COMP_MAXLCP)
-        throw ArgError{TDC_GPU_ERR_UNSUPPORTED, "lcpcomp: comp must be arrays, plcppeaks or max_lcp"};
+    if (comp != TDC_GPU_COMP_ARRAYS && comp != TDC_GPU_COMP_PLCPPEAKS && comp != TDC_GPU_COMP_MAXLCP && comp != TDC_GPU_COMP_HEAP)
+        throw ArgError{TDC_GPU_ERR_UNSUPPORTED, "lcpcomp: comp must be arrays, plcppeaks, max_lcp or heap"};
     if (!ho.out_len || (!ho.out && !ho.into)) throw ArgError{TDC_GPU_ERR_ARG, "out/out_len is NULL"};
     if (raw) {
         if (!text && n) throw ArgError{TDC_GPU_ERR_ARG, "NULL argument"};

@@ -1325,6 +1325,100 @@ __global__ __launch_bounds__(256) void live_max_pool_kernel(const u32* __restric
     if (lane_id() == 0 && best) atomicMax(d_max, best);
 }
 
+// ---- lcpcomp::MaxHeapStrategy (compressors/lcpcomp/compress/MaxHeapStrategy.hpp:36-101 over ds/ArrayMaxHeap.hpp:14-241) ------
+// The tie order of this strategy is the LAYOUT of a binary heap after every insert / remove / decrease_key -- remove() moves the last
+// element into the hole and only ever sifts it down, perlocate_down() compares an element index with a heap position -- i.e. a
+// function of the whole operation history, one operation at a time.  There is no order-independent description a data-parallel
+// selection could evaluate, so this is a PARITY row, not a tuned one: ONE thread replays the reference's loop on the device
+// arrays (heap and back mapping in global memory; every step is a chain of dependent loads: ~1 minute per MiB of English text).
+__device__ __forceinline__ void amh_put(u32* heap, u32* hpos, u32 p, u32 i) { heap[p] = i; hpos[i] = p; }
+__device__ void amh_perlocate_down(const u32* key, u32* heap, u32* hpos, u32 size, u32 p, u32 k) {
+    const u32 kk = key[k];
+    int dir;
+    do {
+        const u32 lc = 2 * p + 1, rc = 2 * p + 2;
+        const u32 kl = (lc < size) ? key[heap[lc]] : 0u;
+        const u32 kr = (rc < size) ? key[heap[rc]] : 0u;
+        if (kk < kl && kk < kr) dir = (kl > kr) ? 1 : 2;
+        else if (kk < kl) dir = 1;
+        else if (kk < kr) dir = 2;
+        else if (kk == kl && kk == kr) dir = (lc < rc) ? 1 : 2;
+        else if (kk == kl && k > lc) dir = 1;                  // element index against heap position, as the reference writes it
+        else if (kk == kr && k > rc) dir = 2;
+        else dir = 0;
+        if (dir == 1) { amh_put(heap, hpos, p, heap[lc]); p = lc; }
+        else if (dir == 2) { amh_put(heap, hpos, p, heap[rc]); p = rc; }
+    } while (dir != 0);
+    amh_put(heap, hpos, p, k);
+}
+__global__ void max_heap_strategy_kernel(const u32* __restrict__ sa, const u32* __restrict__ isa, u32* lcp, u32 n, u32 threshold,
+                                         u32* heap, u32* hpos, u32* __restrict__ flen, u32* __restrict__ fsrc, unsigned long long* __restrict__ out) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    u32 heap_size = 0;
+    for (u32 i = 1; i < n; ++i) if (lcp[i] >= threshold) ++heap_size;                 // :52-55
+    const u32 undef = heap_size;
+    u32 size = 0;
+    for (u32 i = 0; i < n; ++i) hpos[i] = undef;
+    for (u32 i = 1; i < n; ++i) {                                                      // :58-61, ArrayMaxHeap::insert :61-78
+        if (lcp[i] < threshold) continue;
+        u32 p = size++;
+        const u32 ki = lcp[i];
+        while (p > 0 && ki > lcp[heap[(p - 1) / 2]]) { amh_put(heap, hpos, p, heap[(p - 1) / 2]); p = (p - 1) / 2; }
+        amh_put(heap, hpos, p, i);
+    }
+    unsigned long long z = 0;
+    while (size > 0) {                                                                 // :68-97
+        const u32 m = heap[0];
+        const u32 fpos = sa[m], fs_ = sa[m - 1], fl = lcp[m];
+        flen[fpos] = fl; fsrc[fpos] = fs_; ++z;
+        for (u32 k = 0; k < fl; ++k) {                                                 // remove overlapped entries :79-81
+            const u32 i = isa[fpos + k];
+            const u32 p = hpos[i];
+            if (p != undef) { const u32 last = heap[--size]; amh_perlocate_down(lcp, heap, hpos, size, p, last); hpos[i] = undef; }
+        }
+        for (u32 k = 0; k < fl && fpos > k; ++k) {                                     // correct intersecting entries :84-96
+            const u32 sp = fpos - k - 1;
+            const u32 i = isa[sp];
+            if (hpos[i] != undef && (u64)sp + lcp[i] > fpos) {
+                const u32 nl = fpos - sp;
+                if (nl >= threshold) { lcp[i] = nl; amh_perlocate_down(lcp, heap, hpos, size, hpos[i], i); }
+                else { const u32 p = hpos[i]; const u32 last = heap[--size]; amh_perlocate_down(lcp, heap, hpos, size, p, last); hpos[i] = undef; }
+            }
+        }
+    }
+    out[0] = z; out[1] = heap_size;
+}
+__global__ void fill_zero_u32_kernel(u32* p, size_t n) { const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = 0; }
+
+// sa / isa: the suffix array and its inverse (isa is only read here), plcp in position space; lcp = PLCP[SA[.]] is built into scratch
+void factorize_max_heap(Ctx& c, size_t n, const u32* sa, const u32* isa, const u32* plcp, u32 maxlcp, u32 threshold, FactorSpace& fs,
+                        FactorizeStats* st) {
+    FactorizeStats local;
+    if (!st) st = &local;
+    *st = FactorizeStats();
+    st->maxlcp = maxlcp;
+    if (n == 0) return;
+    hipStream_t s = c.stream;
+    const size_t mark = c.arena.mark();
+    fill_zero_u32_kernel<<<cdiv(n, 256), 256, 0, s>>>(fs.flen, n);
+    LAUNCH_CHECK();
+    if (maxlcp >= threshold && threshold > 0) {
+        u32* lcp = c.arena.get<u32>(n);
+        u32* heap = c.arena.get<u32>(n);
+        u32* hpos = c.arena.get<u32>(n);
+        unsigned long long* d_out = (unsigned long long*)c.arena.alloc(2 * sizeof(unsigned long long));
+        build_lcp(c, sa, plcp, n, lcp);
+        max_heap_strategy_kernel<<<1, 64, 0, s>>>(sa, isa, lcp, (u32)n, threshold, heap, hpos, fs.flen, fs.fsrc, d_out);
+        LAUNCH_CHECK();
+        u32 w[4];
+        c.read_n((const u32*)d_out, w, 4);
+        st->factors = (u64)w[0] | ((u64)w[1] << 32);
+        st->entries = (u64)w[2] | ((u64)w[3] << 32);
+    }
+    c.arena.release(mark);
+    build_owner(c, n, fs);
+}
+
 void factorize_max_lcp(Ctx& c, size_t n, u32* isa, const u32* phi, u32* plcp, u32 maxlcp, u32 threshold, FactorSpace& fs,
                        FactorizeStats* st) {
     FactorizeStats local;

@@ -65,6 +65,11 @@ void plcp_peaks_factorize(Ctx& c, size_t n, const u32* phi, const u32* plcp, u32
 void factorize_max_lcp(Ctx& c, size_t n, u32* isa, const u32* phi, u32* plcp, u32 maxlcp, u32 threshold, FactorSpace& fs,
                        FactorizeStats* st);
 
+// lcpcomp::MaxHeapStrategy (compressors/lcpcomp/compress/MaxHeapStrategy.hpp:36-101, ds/ArrayMaxHeap.hpp): sequential replay on
+// the device (a parity row: its tie order is the layout history of a binary heap); sa / isa / plcp are only read
+void factorize_max_heap(Ctx& c, size_t n, const u32* sa, const u32* isa, const u32* plcp, u32 maxlcp, u32 threshold, FactorSpace& fs,
+                        FactorizeStats* st);
+
 struct FlattenStats { u64 num_flattened = 0; u64 max_depth_lb = 0; u32 rounds = 0; };
 // a10: compressors/lzss/LZSSFactors.hpp:79-132 ; rewrites fs.fsrc in place.
 void flatten_factors(Ctx& c, size_t n, FactorSpace fs, FlattenStats* st);

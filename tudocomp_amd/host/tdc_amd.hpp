@@ -292,11 +292,13 @@ public:
         // `arithmetic` is not in the reference's lcpcomp registry (etc/registry_config.py:138-142) but the template
         // instantiates; BASELINE.json configs[2] asks for it, compress side only
         m_comp = (comp == "plcppeaks" || comp == "plcppeaks()") ? TDC_GPU_COMP_PLCPPEAKS
-               : (comp == "max_lcp" || comp == "max_lcp()") ? TDC_GPU_COMP_MAXLCP : TDC_GPU_COMP_ARRAYS;
+               : (comp == "max_lcp" || comp == "max_lcp()") ? TDC_GPU_COMP_MAXLCP
+               : (comp == "heap" || comp == "heap()") ? TDC_GPU_COMP_HEAP : TDC_GPU_COMP_ARRAYS;
         const AlgorithmValue cv = coder.empty() ? AlgorithmValue() : parse_algorithm_id(coder, {"kmer"});
         const std::string& cname = cv.name;
         if ((cname != "huff" && cname != "arithmetic" && cname != "ascii" && cname != "sle") ||
-            (comp != "arrays" && comp != "arrays()" && comp != "plcppeaks" && comp != "plcppeaks()" && comp != "max_lcp" && comp != "max_lcp()"))
+            (comp != "arrays" && comp != "arrays()" && comp != "plcppeaks" && comp != "plcppeaks()" && comp != "max_lcp" && comp != "max_lcp()" &&
+             comp != "heap" && comp != "heap()"))
             throw std::runtime_error("No implementation found for compressor lcpcomp(coder=" + coder + ",comp=" + comp + ")");   // Registry.hpp:214
         m_coder = (cname == "huff") ? TDC_GPU_CODER_HUFF : (cname == "ascii" ? TDC_GPU_CODER_ASCII : TDC_GPU_CODER_ARITH);
         if (cname == "sle") {                                                 // option kmer = 3 (SLECoder.hpp:38)
@@ -457,6 +459,7 @@ inline std::vector<std::string> registered_algorithms() {
              "lcpcomp(coder=ascii, comp=arrays, threshold=5, flatten=1)                   [MI355X; host decoder]",
              "lcpcomp(coder=sle(kmer=3), comp=arrays, threshold=5, flatten=1)             [MI355X; host decoder]",
              "lcpcomp(coder=..., comp=max_lcp | plcppeaks, ...)                           [MI355X]",
+             "lcpcomp(coder=..., comp=heap, ...)                                          [MI355X, sequential replay of the reference's heap: parity, not speed]",
              "lcpcomp(coder=arithmetic, comp=arrays, threshold=5, flatten=1)              [MI355X, compress only]",
              "lzss_lcp(coder=huff, threshold=3)                                           [MI355X, libtdc_gpu.so]",
              "lz78(coder=gamma)                                                           [host parse + MI355X gamma packer]" };
