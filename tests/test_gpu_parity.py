@@ -415,6 +415,25 @@ def test_lcpcomp_max_lcp_strategy(gpu_ctx):
     assert c.decompress(c.compress(data)) == data
 
 
+def test_committed_stage_fixture(gpu_ctx):
+    """the HIP path against COMMITTED per-stage data (tests/golden/oracle_stages.json, tests/make_golden.py), no live oracle involved"""
+    fx = load_json("oracle_stages.json")
+    for name, g in fx.items():
+        text = bytes.fromhex(g["text_hex"])
+        thr = g["threshold"]
+        arrs = gpu_ctx.textds(text)
+        _eq(name + " sa", arrs["sa"], g["sa"]); _eq(name + " isa", arrs["isa"], g["isa"])
+        _eq(name + " phi", arrs["phi"][:-1], g["phi"]); _eq(name + " plcp", arrs["plcp"][:-1], g["plcp"])
+        assert arrs["maxlcp"] == g["maxlcp"]
+        pos, src, length, st = gpu_ctx.factorize(text, thr, 0)
+        assert [list(map(int, t)) for t in zip(pos, src, length)] == g["factors_sorted"], name
+        pos, src, length, st = gpu_ctx.factorize(text, thr, 1)
+        assert [list(map(int, t)) for t in zip(pos, src, length)] == g["factors_flattened"], name
+        assert (st["num_flattened"], st["max_depth_lb"]) == (g["num_flattened"], g["max_depth_lb"])
+        assert gpu_ctx.lcpcomp_compress(text, thr, 1)[0].hex() == g["stream_hex"], name
+        assert T.escape(bytes.fromhex(g["data_hex"])) == text
+
+
 def test_lcpcomp_heap_strategy(gpu_ctx):
     """comp=heap (lcpcomp::MaxHeapStrategy, MaxHeapStrategy.hpp:36-101 over ds/ArrayMaxHeap.hpp): the device replays the reference's
     heap loop; streams byte-identical to the oracle's restatement (which the reference does not pin: no vector for this strategy),

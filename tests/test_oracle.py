@@ -292,3 +292,15 @@ def test_max_heap_strategy_restatement_against_a_direct_model():
                 covered[p_:p_ + l_] = True
             out, _ = O.lcpcomp_heap_huff_compress(text, max(thr, 1), 1)
             assert O.lcpcomp_huff_decompress(out) == text
+
+
+def test_oracle_reproduces_committed_stage_fixture():
+    """tests/golden/oracle_stages.json (written by tests/make_golden.py) is what today's oracle computes"""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(os.path.dirname(__file__), "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    want = load_json("oracle_stages.json")
+    assert set(want) == {name for name, _, _ in mg.INPUTS}
+    for name, data, thr in mg.INPUTS:
+        assert mg.stages(data, thr) == want[name], name
