@@ -141,34 +141,33 @@ constexpr u32 NOT_DONE = 0xFFFFFFFFu;
 
 struct FlattenScalars { u32 waiting; u32 num_flattened; u32 max_depth; u32 pad; };
 
-// Everything a chain step needs about a factor lives in compact arrays indexed by the factor's rank r in position order
-// (z entries: they stay in the Infinity Cache), only owner[] is position-indexed:
-//   rec[r] = pos | len << 32,  srcs[r] = original source,  fin[r] = final source (NOT_DONE until known)
+// Everything a chain step needs about a factor lives in ONE 16-byte record, indexed by the factor's rank r in position order:
+//   rec[r] = { pos, len, original source, final source (NOT_DONE until known) }
+// (one scattered line per step besides owner[src]; separate arrays for (pos, len), the original and the final source cost a line
+// each.  Finding the covering factor through a table of the first factor per 64-position block plus a scan of consecutive
+// records -- no owner[] line at all -- was built and measured slower: 6.6 vs 5.7 ms, the scan is a chain of dependent loads.)
 __global__ void flatten_init_kernel(const u32* __restrict__ fpos, size_t z, const u32* __restrict__ flen, const u32* __restrict__ orig,
-                                    u64* __restrict__ rec, u32* __restrict__ srcs, u32* __restrict__ fin, u32* __restrict__ cursrc,
-                                    u32* __restrict__ depth) {
+                                    uint4* __restrict__ rec, u32* __restrict__ cursrc, u32* __restrict__ depth) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= z) return;
     const u32 p = fpos[i];
     const u32 o = orig[p];
-    rec[i] = (u64)p | ((u64)flen[p] << 32);
-    srcs[i] = o;
-    fin[i] = NOT_DONE;
+    rec[i] = make_uint4(p, flen[p], o, NOT_DONE);
     cursrc[i] = o;
     depth[i] = 0;
 }
 
 // One round over the still-waiting factors (work[] holds their ranks; wcls[j] = 1 if still waiting).
 __global__ __launch_bounds__(256) void flatten_round_kernel(const u32* __restrict__ work, u32 nwork, size_t n, const u32* __restrict__ owner,
-                                                             const u64* __restrict__ rec, const u32* __restrict__ srcs, u32* fin,
-                                                             u32* __restrict__ cursrc, u32* __restrict__ depth, u8* __restrict__ wcls,
+                                                             uint4* rec, u32* __restrict__ cursrc, u32* __restrict__ depth, u8* __restrict__ wcls,
                                                              FlattenScalars* __restrict__ sc, u32 max_steps) {
     const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
     bool counted = false;
     u32 dep = 0;
     if (j < nwork) {
         const u32 i = work ? work[j] : j;
-        const u32 len = (u32)(rec[i] >> 32);
+        const uint4 me = rec[i];
+        const u32 len = me.y;
         u32 src = cursrc[i];
         dep = depth[i];
         bool finished = false;
@@ -176,15 +175,15 @@ __global__ __launch_bounds__(256) void flatten_round_kernel(const u32* __restric
             if ((size_t)src >= n || dep >= n) { finished = true; break; }   // :106 src < fmap.size()  (dep bound: no endless chains)
             const u32 r = owner[src];
             if (r == NONE32) { finished = true; break; }                    // :106 fmap[src] == 0
-            const u64 sr = rec[r];
-            const u32 d = src - (u32)sr;
-            if ((u64)d + len > (sr >> 32)) { finished = true; break; }      // :110 copy does not fit inside s
+            const uint4 sr = rec[r];
+            const u32 d = src - sr.x;
+            if ((u64)d + len > sr.y) { finished = true; break; }            // :110 copy does not fit inside s
             u32 ssrc;
             if (r < i) {                                                    // earlier factor: needs its final source
-                ssrc = fin[r];
+                ssrc = sr.w;
                 if (ssrc == NOT_DONE) break;                                // wait for the next round
             } else {
-                ssrc = srcs[r];                                             // later factor: still unflattened at this point
+                ssrc = sr.z;                                                // later factor: still unflattened at this point
             }
             src = ssrc + d;                                                 // :111
             ++dep;
@@ -193,7 +192,7 @@ __global__ __launch_bounds__(256) void flatten_round_kernel(const u32* __restric
         depth[i] = dep;
         wcls[j] = finished ? 0 : 1;
         if (finished) {
-            fin[i] = dep ? src : srcs[i];                                   // :122-124
+            ((u32*)&rec[i])[3] = dep ? src : me.z;                          // :122-124
             counted = dep != 0;
         }
     }
@@ -208,10 +207,11 @@ __global__ void flatten_iota_kernel(u32* __restrict__ a, u32 m) {
     if (j < m) a[j] = j;
 }
 
-__global__ void flatten_commit_kernel(const u32* __restrict__ fpos, size_t z, const u32* __restrict__ fin, u32* __restrict__ fsrc) {
+__global__ void flatten_commit_kernel(size_t z, const uint4* __restrict__ rec, u32* __restrict__ fsrc) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= z) return;
-    fsrc[fpos[i]] = fin[i];
+    const uint4 q = rec[i];
+    fsrc[q.x] = q.w;
 }
 
 void flatten_factors(Ctx& c, size_t n, FactorSpace fs, FlattenStats* st) {
@@ -224,15 +224,13 @@ void flatten_factors(Ctx& c, size_t n, FactorSpace fs, FlattenStats* st) {
     u32* fpos = fs.have_list ? fs.fpos : c.arena.get<u32>(n);
     const size_t z = fs.have_list ? fs.nfact : extract_factors(c, n, fs, fpos, nullptr, nullptr, n);
     if (z == 0) { c.arena.release(mark); return; }
-    u64* rec = c.arena.get<u64>(z);
-    u32* srcs = c.arena.get<u32>(z);
-    u32* fin = c.arena.get<u32>(z);
+    uint4* rec = (uint4*)c.arena.alloc(z * sizeof(uint4));
     u32* cursrc = c.arena.get<u32>(z);
     u32* depth = c.arena.get<u32>(z);
     FlattenScalars* d_sc = (FlattenScalars*)c.arena.alloc(sizeof(FlattenScalars));
     HIP_TRY(hipMemsetAsync(d_sc, 0, sizeof(FlattenScalars), s));
     const unsigned gz = cdiv(z, 256);
-    flatten_init_kernel<<<gz, 256, 0, s>>>(fpos, z, fs.flen, fs.fsrc, rec, srcs, fin, cursrc, depth);
+    flatten_init_kernel<<<gz, 256, 0, s>>>(fpos, z, fs.flen, fs.fsrc, rec, cursrc, depth);
     LAUNCH_CHECK();
     // work lists of the still-waiting factors, compacted after every round
     u32* work[2] = { c.arena.get<u32>(z), c.arena.get<u32>(z) };
@@ -251,9 +249,9 @@ void flatten_factors(Ctx& c, size_t n, FactorSpace fs, FlattenStats* st) {
     if (flat_growth < 2) flat_growth = 2;
     u32 stalled = 0;
     while (waiting) {
-        {   // per waiting factor: rec, cursrc, depth (16) + one chain step (owner, rec, source: 16) + outputs (13)
-            Ctx::ProfScope prof(c, K_FLATTEN_ROUND, (u64)waiting * 45);
-            flatten_round_kernel<<<cdiv(waiting, 256), 256, 0, s>>>(cur_w < 0 ? nullptr : work[cur_w], waiting, n, fs.owner, rec, srcs, fin,
+        {   // per waiting factor: record, cursrc, depth (24) + one chain step (block word + record: 20) + outputs (13)
+            Ctx::ProfScope prof(c, K_FLATTEN_ROUND, (u64)waiting * 57);
+            flatten_round_kernel<<<cdiv(waiting, 256), 256, 0, s>>>(cur_w < 0 ? nullptr : work[cur_w], waiting, n, fs.owner, rec,
                                                                     cursrc, depth, wcls, d_sc, max_steps);
             LAUNCH_CHECK();
         }
@@ -269,7 +267,7 @@ void flatten_factors(Ctx& c, size_t n, FactorSpace fs, FlattenStats* st) {
         cur_w = nxt;
         if (max_steps < (1u << 30)) max_steps = (max_steps > (1u << 30) / flat_growth) ? (1u << 30) : max_steps * flat_growth;
     }
-    flatten_commit_kernel<<<gz, 256, 0, s>>>(fpos, z, fin, fs.fsrc);
+    flatten_commit_kernel<<<gz, 256, 0, s>>>(z, rec, fs.fsrc);
     LAUNCH_CHECK();
     FlattenScalars h = c.read(d_sc);
     st->num_flattened = h.num_flattened;
