@@ -345,10 +345,10 @@ void tdc_gpu_ctx_reset_profile(tdc_gpu_ctx* ctx) {
 const char* tdc_gpu_ctx_kernel_profile(const tdc_gpu_ctx* ctx, int idx, double* ms, uint64_t* launches, uint64_t* bytes) {
     static const char* names[K_CLASS_COUNT] = {
         "rs_scatter_kernel<u64>", "rs_scatter_kernel<u32>", "rs_count_kernel", "scan_kernels",
-        "sa_update_kernels", "sa_build_keys_kernel", "phi_kernel", "plcp_kernel", "cand_kernels",
+        "sa_groups_kernel", "sa_build_keys_kernel", "phi_kernel", "plcp_kernel", "cand_kernels",
         "level_init_kernel", "mis_round_kernel", "resolve_kernel", "push_kernel", "apply_kernel", "pool_kernels", "small_level_kernel", "window_levels_kernel",
         "flatten_round_kernel", "gaps_kernel", "literal_hist_kernel", "tile_bits_kernel", "pack_kernel", "extract_kernels",
-        "ss_leaf_sort_kernel", "sa_local_sort_kernel" };
+        "ss_leaf_sort_kernel", "sa_local_sort_kernel", "window_scatter_kernels" };
     if (!ctx || idx < 0 || idx >= K_CLASS_COUNT) return nullptr;
     const KernelProfile& k = ctx->c.kprof[idx];
     if (ms) *ms = k.ms;

@@ -76,7 +76,7 @@ enum KernelClass {
     K_RS_SCATTER_U64 = 0, K_RS_SCATTER_U32, K_RS_COUNT, K_SCAN,
     K_SA_RANK_SCATTER, K_SA_BUILD_KEYS, K_PHI, K_PLCP, K_CAND,
     K_LEVEL_INIT, K_MIS_ROUND, K_RESOLVE, K_PUSH, K_APPLY, K_POOL, K_SMALL_LEVEL, K_WINDOW_LEVELS,
-    K_FLATTEN_ROUND, K_ENC_GAPS, K_ENC_HIST, K_ENC_TILE_BITS, K_ENC_PACK, K_EXTRACT, K_SS_LEAF, K_SA_LOCAL_SORT,
+    K_FLATTEN_ROUND, K_ENC_GAPS, K_ENC_HIST, K_ENC_TILE_BITS, K_ENC_PACK, K_EXTRACT, K_SS_LEAF, K_SA_LOCAL_SORT, K_WINDOW_SCATTER,
     K_CLASS_COUNT
 };
 

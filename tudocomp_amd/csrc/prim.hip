@@ -1013,6 +1013,7 @@ void bucketed_scatter_u32(Ctx& c, const u32* idx, const u32* val, size_t m, u32*
     }
     if (permutation && k == tmp_idx2 && bits > 16 && (1u << (bits - 16)) <= WIMG_MAX) {
         const u32 W = 1u << (bits - 16);
+        Ctx::ProfScope prof(c, K_WINDOW_SCATTER, (u64)m * 12);      // read the partitioned pairs, write every destination word once
         window_image_kernel<<<cdiv(m, W), 256, 0, c.stream>>>(k, v, m, dst, W);
         LAUNCH_CHECK();
         return;
@@ -1021,6 +1022,7 @@ void bucketed_scatter_u32(Ctx& c, const u32* idx, const u32* val, size_t m, u32*
     // (measured without this: WRITE_SIZE = 9x the destination bytes, every 4-byte store left its L2 as a partial line)
     const u32 numTiles = cdiv(m, 256 * WS_ITEMS);
     const u32 per_xcd = (c.xcd_remap != 2 && numTiles >= 64) ? cdiv(numTiles, 8) : 0u;
+    Ctx::ProfScope prof(c, K_WINDOW_SCATTER, (u64)m * 12);
     window_scatter_kernel<<<per_xcd ? 8 * per_xcd : numTiles, 256, 0, c.stream>>>(k, v, m, dst, numTiles, per_xcd);
     LAUNCH_CHECK();
 }

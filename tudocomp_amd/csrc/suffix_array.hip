@@ -354,15 +354,17 @@ void build_suffix_array(Ctx& c, const u8* text, size_t n, u32* sa, u32* isa, SAS
     const int bn = (int)bits_for(n - 1);
     u64* gdesc = c.arena.get<u64>(cdiv(n, GR_TILE) + 1);       // look-back descriptors + ticket of the group kernel
     u32* gticket = c.arena.get<u32>(1);
-    {   // per element: read key + value (12 B), write sa + head (8 B) + the kept elements (12 B each), scatter rank (4 B)
-        Ctx::ProfScope prof(c, K_SA_RANK_SCATTER, (u64)n * 30);
+    {
         const u32 tiles = cdiv(n, GR_TILE);
         HIP_TRY(hipMemsetAsync(gdesc, 0, (size_t)tiles * sizeof(u64), s));
         HIP_TRY(hipMemsetAsync(gticket, 0, sizeof(u32), s));
         const bool bucketed = c.bucket_scatter && n >= ((size_t)1 << 22);
-        sa_groups_kernel<true><<<tiles, 256, 0, s>>>(keys[x], vals[x], nullptr, n, bn, sa, rank, bucketed ? head : nullptr, A_sa, A_pos, A_r1,
-                                                     gdesc, gticket, d_total, c.d_err, tiles);
-        LAUNCH_CHECK();
+        {   // per element: read key + value (12 B), write sa + head (8 B) + the kept elements (12 B each, about half of them)
+            Ctx::ProfScope prof(c, K_SA_RANK_SCATTER, (u64)n * 26);
+            sa_groups_kernel<true><<<tiles, 256, 0, s>>>(keys[x], vals[x], nullptr, n, bn, sa, rank, bucketed ? head : nullptr, A_sa, A_pos, A_r1,
+                                                         gdesc, gticket, d_total, c.d_err, tiles);
+            LAUNCH_CHECK();
+        }
         // rank[vals[j]] = head[j] through a partition by destination window; the other key buffer and the B lists are free scratch
         if (bucketed) bucketed_scatter_u32(c, vals[x], head, n, rank, n, (u32*)keys[x ^ 1], vals[x ^ 1], B_sa, B_pos, true);   // vals[x] = every position once
     }
@@ -412,16 +414,18 @@ void build_suffix_array(Ctx& c, const u8* text, size_t n, u32* sa, u32* isa, SAS
             st->sorted_elems += m;
         }
         {
-            Ctx::ProfScope prof(c, K_SA_RANK_SCATTER, (u64)m * 40);
             // a large round scatters its ranks through the bucketed scatter (scratch: the other sort buffers, head / keep)
             const bool bucketed = c.bucket_scatter && m >= ((size_t)1 << 24);
             u32* nr = (u32*)keys[x ^ 1];
             const u32 tiles = cdiv(m, GR_TILE);
             HIP_TRY(hipMemsetAsync(gdesc, 0, (size_t)tiles * sizeof(u64), s));
             HIP_TRY(hipMemsetAsync(gticket, 0, sizeof(u32), s));
-            sa_groups_kernel<false><<<tiles, 256, 0, s>>>(keys[x], vals[x], A_pos, m, bn, sa, rank, bucketed ? nr : nullptr, B_sa, B_pos, B_r1,
-                                                          gdesc, gticket, d_total, c.d_err, tiles);
-            LAUNCH_CHECK();
+            {   // per element: key, value, position (16 B), sa + new rank (8 B), the kept elements (12 B each)
+                Ctx::ProfScope prof(c, K_SA_RANK_SCATTER, (u64)m * 30);
+                sa_groups_kernel<false><<<tiles, 256, 0, s>>>(keys[x], vals[x], A_pos, m, bn, sa, rank, bucketed ? nr : nullptr, B_sa, B_pos, B_r1,
+                                                              gdesc, gticket, d_total, c.d_err, tiles);
+                LAUNCH_CHECK();
+            }
             if (bucketed) bucketed_scatter_u32(c, vals[x], nr, m, rank, n, nr + m, vals[x ^ 1], head, keep);
         }
         m = c.read(d_total);

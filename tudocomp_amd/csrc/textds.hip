@@ -21,8 +21,7 @@ __global__ void phi_first_kernel(const u32* __restrict__ sa, size_t n, u32* __re
 
 void build_phi(Ctx& c, const u32* sa, size_t n, u32* phi) {
     if (!n) return;
-    Ctx::ProfScope prof(c, K_PHI, (u64)n * 8);                  // read SA, scatter Phi
-    if (c.bucket_scatter && n >= ((size_t)1 << 22)) {
+    if (c.bucket_scatter && n >= ((size_t)1 << 22)) {           // (timed under the radix and window_scatter classes)
         // pairs (sa[i], sa[i-1]), i = 1 .. n-1, partitioned by destination window, then scattered
         const size_t mark = c.arena.mark();
         u32* ti = c.arena.get<u32>(n);
@@ -35,6 +34,7 @@ void build_phi(Ctx& c, const u32* sa, size_t n, u32* phi) {
         c.arena.release(mark);
         return;
     }
+    Ctx::ProfScope prof(c, K_PHI, (u64)n * 8);                  // read SA, scatter Phi
     phi_kernel<<<cdiv(n, 256), 256, 0, c.stream>>>(sa, n, phi);
     LAUNCH_CHECK();
 }
