@@ -275,6 +275,8 @@ int tdc_gpu_ctx_create(int device, tdc_gpu_ctx** out) {
         HIP_TRY(hipSetDevice(device));
         HIP_TRY(hipStreamCreateWithFlags(&ctx->c.stream, hipStreamNonBlocking));
         for (auto& e : ctx->c.ev) HIP_TRY(hipEventCreate(&e));
+        HIP_TRY(hipStreamCreateWithFlags(&ctx->c.copy_stream, hipStreamNonBlocking));
+        for (auto& e : ctx->c.ev_copy) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         ctx->c.pinned_size = 4096;
         HIP_TRY(hipHostMalloc(&ctx->c.pinned, ctx->c.pinned_size, hipHostMallocDefault));
         if (const char* m = getenv("TDC_GPU_FASTREAD")) ctx->c.fast_read = atoi(m) ? 1 : 0;
@@ -298,6 +300,7 @@ int tdc_gpu_ctx_create(int device, tdc_gpu_ctx** out) {
         if (const char* m = getenv("TDC_GPU_XCD_REMAP")) { const int v = atoi(m); ctx->c.xcd_remap = (v >= 0 && v <= 2) ? v : 0; }
         if (const char* m = getenv("TDC_GPU_BUCKET_SCATTER")) ctx->c.bucket_scatter = atoi(m) ? 1 : 0;
         if (const char* m = getenv("TDC_GPU_SSORT")) ctx->c.ssort = atoi(m) ? 1 : 0;
+        if (const char* m = getenv("TDC_GPU_MSD_PARTITION")) ctx->c.msd_partition = atoi(m) ? 1 : 0;
         if (const char* m = getenv("TDC_GPU_SSORT_LEVELS")) { const int v = atoi(m); ctx->c.ssort_levels = (v >= 1 && v <= 3) ? v : 0; }
     } catch (const HipError&) {
         (void)hipGetLastError();
@@ -317,6 +320,8 @@ void tdc_gpu_ctx_destroy(tdc_gpu_ctx* ctx) {
     if (ctx->c.zc_host) (void)hipHostFree(ctx->c.zc_host);
     if (ctx->c.d_err) (void)hipFree(ctx->c.d_err);
     for (auto& e : ctx->c.ev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : ctx->c.ev_copy) if (e) (void)hipEventDestroy(e);
+    if (ctx->c.copy_stream) { (void)hipStreamSynchronize(ctx->c.copy_stream); (void)hipStreamDestroy(ctx->c.copy_stream); }
     if (ctx->c.ev_pool) { for (int i = 0; i < ctx->c.ev_pool_size; ++i) if (ctx->c.ev_pool[i]) (void)hipEventDestroy(ctx->c.ev_pool[i]); free(ctx->c.ev_pool); }
     free(ctx->c.pend);
     if (ctx->c.stream) (void)hipStreamDestroy(ctx->c.stream);
@@ -430,12 +435,22 @@ void compress_host(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, bool raw, ui
     }
     const int e1 = ev.tick();
     u8* d_out = nullptr;
+    struct SinkGuard {       // on every exit path: no copy into the caller's buffer is still in flight, the sink is forgotten
+        Ctx& c;
+        ~SinkGuard() { if (c.d2h_done && c.copy_stream) (void)hipStreamSynchronize(c.copy_stream); c.d2h_host = nullptr; c.d2h_cap = 0; c.d2h_done = 0; }
+    } sink_guard{c};
+    c.d2h_host = ho.into; c.d2h_cap = ho.into ? ho.cap : 0; c.d2h_done = 0;      // the encoder may start the D2H while it still packs
     const size_t len = run_pipeline(c, d_text, tn, threshold, flatten, coder, &d_out, 0, stats, ev, comp);
     const int e2 = ev.tick();
     *ho.out_len = len;
     if (ho.into) {
         if (len > ho.cap) throw ArgError{TDC_GPU_ERR_OOM, "output buffer too small (*out_len holds the required size)"};
-        HIP_TRY(hipMemcpyAsync(ho.into, d_out, len, hipMemcpyDeviceToHost, c.stream));
+        const size_t done = c.d2h_done <= len ? c.d2h_done : 0;
+        HIP_TRY(hipMemcpyAsync(ho.into + done, d_out + done, len - done, hipMemcpyDeviceToHost, c.stream));
+        if (done) {                                                          // the front part travels on the copy stream
+            HIP_TRY(hipEventRecord(c.ev_copy[9], c.copy_stream));
+            HIP_TRY(hipStreamWaitEvent(c.stream, c.ev_copy[9], 0));
+        }
         const int e3 = ev.tick();
         if (stats) { ev.span(&stats->ms_h2d, e0, e1); ev.span(&stats->ms_d2h, e2, e3); ev.span(&stats->ms_total, e0, e3); }
         ev.finish();

@@ -127,7 +127,16 @@ struct Ctx {
     int window_large_lists = 0;    // window pass: start with the large per-level lists (env TDC_GPU_WINDOW_LARGE=1; tests)
     int ssort = 1;                 // suffix array: splitter-partition sort (ssort.hip) instead of the 8-pass LSD sort for large inputs (env TDC_GPU_SSORT=0 disables)
     int ssort_levels = 0;          // force the number of partition levels of the splitter sort (env TDC_GPU_SSORT_LEVELS = 1..3; tests)
+    int msd_partition = 1;         // bucketed scatter: MSD partition with atomic slots instead of two stable LSD passes (env TDC_GPU_MSD_PARTITION=0)
     int bucket_scatter = 1;        // big random scatters (rank, Phi) go through one radix partition by destination window (env TDC_GPU_BUCKET_SCATTER=0 disables)
+
+    // overlapped D2H of the compressed stream (end-to-end entry point with a caller buffer): while the pack kernel works on the
+    // later tiles, the finished front part of the stream already travels to the host on a second stream
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_copy[10] = {};
+    u8* d2h_host = nullptr;        // destination (host) of the running call, or null
+    size_t d2h_cap = 0;
+    size_t d2h_done = 0;           // bytes of the stream already on their way when encode returns
 
     bool profiling = false;
     KernelProfile kprof[K_CLASS_COUNT];

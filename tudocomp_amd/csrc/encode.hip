@@ -207,14 +207,15 @@ template <bool ASCII>
 __global__ __launch_bounds__(256) void pack_kernel(const u8* __restrict__ text, const u32* __restrict__ owner,
                                                     const u32* __restrict__ flen, const u32* __restrict__ fsrc, size_t n,
                                                     CodeTable tab, EncParams P, ArithDev A, const u64* __restrict__ tile_off,
-                                                    u64 base_bits, u64* __restrict__ out) {
+                                                    u64 base_bits, u64* __restrict__ out, u32 tile0) {
     __shared__ u8 clen[256];
     __shared__ u64 code[256];
     __shared__ u32 sm[5];
     clen[threadIdx.x] = tab.len[threadIdx.x];
     code[threadIdx.x] = tab.code[threadIdx.x];
     __syncthreads();
-    const size_t p0 = (size_t)blockIdx.x * ENC_TILE + (size_t)threadIdx.x * ENC_PER_THREAD;
+    const u32 tile = blockIdx.x + tile0;
+    const size_t p0 = (size_t)tile * ENC_TILE + (size_t)threadIdx.x * ENC_PER_THREAD;
     u32 own[ENC_PER_THREAD], fl[ENC_PER_THREAD];
     u8 ch[ENC_PER_THREAD];
     u32 prev0 = 0, sum = 0;
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const u8* __restrict__ text, 
     if (p0 >= n) return;
     BitSink sink;
     sink.out = out;
-    sink.pos = base_bits + tile_off[blockIdx.x] + excl;
+    sink.pos = base_bits + tile_off[tile] + excl;
     sink.acc = 0;
     sink.cnt = 0;
     u32 prev = prev0;
@@ -272,6 +273,12 @@ __global__ __launch_bounds__(256) void pack_kernel(const u8* __restrict__ text, 
         }
     }
     sink.flush();
+}
+
+// out[q] = excl[(tiles * (q + 1)) / parts] for q < parts - 1 (bit offset at which chunk q of the pack ends), out[parts - 1] unused
+__global__ void pick_u64_kernel(const u64* __restrict__ excl, u32 tiles, u32 parts, u64* __restrict__ out) {
+    const u32 q = threadIdx.x;
+    if (q < parts) out[q] = (q + 1 < parts) ? excl[(u32)((u64)tiles * (q + 1) / parts)] : 0ull;
 }
 
 // io/BitOStream.hpp:53-64 : u = bits used in the last byte; u <= 5: OR u into that byte, else append a byte holding u.
@@ -409,9 +416,35 @@ size_t encode_stream(Ctx& c, const u8* text, size_t n, FactorSpace fs, int coder
     HIP_TRY(hipMemcpyAsync(d_out, hw.bytes.data(), hw.bytes.size(), hipMemcpyHostToDevice, s));
     {
         Ctx::ProfScope prof(c, K_ENC_PACK, (u64)n * 9 + (u64)z * 4 + out_len);
-        if (P.ascii) pack_kernel<true><<<tiles, 256, 0, s>>>(text, fs.owner, fs.flen, fs.fsrc, n, tab, P, A, tile_bits, base_bits, (u64*)d_out);
-        else         pack_kernel<false><<<tiles, 256, 0, s>>>(text, fs.owner, fs.flen, fs.fsrc, n, tab, P, A, tile_bits, base_bits, (u64*)d_out);
-        LAUNCH_CHECK();
+        // With a host destination (end-to-end entry point) the pack runs in 8 chunks of tiles: once a chunk is done the bytes in
+        // front of its last (possibly shared) 64-bit word are final and start their way to the host on the copy stream, while
+        // the next chunk is being packed.
+        constexpr u32 CH = 8;
+        const bool overlap = c.d2h_host && out_len <= c.d2h_cap && tiles >= 64 * CH && c.copy_stream;
+        u64 h_end[CH];
+        if (overlap) {
+            u64* d_pick = c.arena.get<u64>(CH);
+            pick_u64_kernel<<<1, 64, 0, s>>>(tile_bits, tiles, CH, d_pick);
+            LAUNCH_CHECK();
+            c.read_n(d_pick, h_end, CH);
+        }
+        size_t copied = 0;
+        for (u32 q = 0; q < (overlap ? CH : 1u); ++q) {
+            const u32 t0 = overlap ? (u32)((u64)tiles * q / CH) : 0u, t1 = overlap ? (u32)((u64)tiles * (q + 1) / CH) : tiles;
+            if (P.ascii) pack_kernel<true><<<t1 - t0, 256, 0, s>>>(text, fs.owner, fs.flen, fs.fsrc, n, tab, P, A, tile_bits, base_bits, (u64*)d_out, t0);
+            else         pack_kernel<false><<<t1 - t0, 256, 0, s>>>(text, fs.owner, fs.flen, fs.fsrc, n, tab, P, A, tile_bits, base_bits, (u64*)d_out, t0);
+            LAUNCH_CHECK();
+            if (overlap && q + 1 < CH) {
+                const size_t safe = (size_t)((base_bits + h_end[q]) / 64) * 8;          // bytes in front of the word the next chunk may still touch
+                if (safe > copied) {
+                    HIP_TRY(hipEventRecord(c.ev_copy[q], s));
+                    HIP_TRY(hipStreamWaitEvent(c.copy_stream, c.ev_copy[q], 0));
+                    HIP_TRY(hipMemcpyAsync(c.d2h_host + copied, d_out + copied, safe - copied, hipMemcpyDeviceToHost, c.copy_stream));
+                    copied = safe;
+                }
+            }
+        }
+        c.d2h_done = copied;
     }
     terminator_kernel<<<1, 64, 0, s>>>(d_out, total_bits);
     LAUNCH_CHECK();

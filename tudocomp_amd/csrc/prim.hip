@@ -995,7 +995,11 @@ void bucketed_scatter_u32(Ctx& c, const u32* idx, const u32* val, size_t m, u32*
     const int bits = (int)bits_for(n_dst ? n_dst - 1 : 0);
     const u32* k = idx;
     const u32* v = val;
-    if (bits > 8 && m >= ((size_t)1 << 20)) {
+    if (c.msd_partition && bits > 16 && m >= ((size_t)1 << 20) && tmp_idx2 && tmp_val2) {
+        // partition by the top 16 bits of idx: two MSD levels, no stability needed (ssort.hip)
+        msd_partition_pairs_u32(c, idx, val, m, bits, tmp_idx2, tmp_val2, tmp_idx, tmp_val);
+        k = tmp_idx2; v = tmp_val2;
+    } else if (bits > 8 && m >= ((size_t)1 << 20)) {
         // two stable 8-bit passes (low digit first) = partition by the top 16 bits: the writes of the final pass stay inside
         // windows of n_dst / 65536 elements, which L2 merges into whole lines
         const int top = bits > 16 ? bits - 16 : 0;

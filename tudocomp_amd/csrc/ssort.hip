@@ -319,6 +319,144 @@ __global__ void ss_set_word_kernel(u32* p, u32 v) { *p = v; }
 template <bool GEN, bool LAST>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void ss_scatter_kernel(SSLevel P, TextKeyGen g, u32 rows) {
     constexpr int DMAX = LAST ? 512 : 256;
+    __shared__ u32 tcnt[DMAX];            // keys of the tile per digit, then the start of the digit's run inside the sorted tile
+    __shared__ u32 gbase[DMAX];
+    __shared__ __align__(16) u64 stage[SS_TILE];
+    __shared__ u32 scan_sm[5];
+    __shared__ u8 code[GEN ? 256 : 4];
+    const int lane = lane_id(), w = wave_id();
+    const u32 row = xcd_tile(blockIdx.x, P.per_xcd);
+    if (row >= rows) return;
+    u32 s, cnt; size_t base;
+    if (!ss_row(P, row, s, base, cnt) || cnt == 0) return;
+    u8* sy = (u8*)stage;                                    // GEN: recoded bytes of the tile, 4 KB + halo
+    u16* stage_d = (u16*)(stage + 2048);                    // digits of the staged values: second half of the buffer
+    u32* stage32 = (u32*)stage;
+    for (int i = threadIdx.x; i < DMAX; i += 256) tcnt[i] = 0;
+    if (GEN) code[threadIdx.x] = g.code[threadIdx.x];
+    __syncthreads();
+    if (GEN) { ss_gen_stage(g, base, code, sy); __syncthreads(); }
+
+    u64 k[SS_ITEMS];
+    u32 v[SS_ITEMS];
+    u32 ld[SS_ITEMS];                                       // digit << 16 | rank inside the tile's digit run, later position in the tile
+    const u32 lbs = GEN ? (u32)(w * (64 * SS_ITEMS) + lane * SS_ITEMS) : (u32)(w * (64 * SS_ITEMS) + lane);
+    u64 gkey = 0;
+    u32 pk[SS_ITEMS / 2];                                   // GEN: the lane's 16 digits as written by the count pass
+    if (GEN) {
+        gkey = ss_gen_key(g, sy, (int)lbs);
+        const uint4* dp = (const uint4*)(P.digits + base + lbs);
+        const uint4 q0 = dp[0], q1 = dp[1];
+        pk[0] = q0.x; pk[1] = q0.y; pk[2] = q0.z; pk[3] = q0.w; pk[4] = q1.x; pk[5] = q1.y; pk[6] = q1.z; pk[7] = q1.w;
+    }
+    const u64* kp = GEN ? nullptr : P.keys_in + base + lbs;
+    const u32* vp = GEN ? nullptr : P.vals_in + base + lbs;
+    const u16* dgp = P.digits + base + lbs;
+#pragma unroll
+    for (int j = 0; j < SS_ITEMS; ++j) {                    // all global loads first: they overlap, the ranking below is a chain of LDS operations
+        const u32 e = GEN ? lbs + (u32)j : lbs + (u32)j * 64;
+        const bool valid = e < cnt;
+        if (GEN) {
+            k[j] = gkey; v[j] = (u32)(base + e);
+            gkey = (gkey - (u64)sy[lbs + j] * g.top) * g.sigma + sy[lbs + j + g.k];
+            ld[j] = (pk[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+        } else {
+            k[j] = valid ? kp[j * 64] : 0ull;                   // one address per array, the row as an immediate offset
+            v[j] = valid ? vp[j * 64] : 0u;
+            ld[j] = valid ? (u32)dgp[j * 64] : 0u;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < SS_ITEMS; ++j) {
+        const u32 e = GEN ? lbs + (u32)j : lbs + (u32)j * 64;
+        const bool valid = e < cnt;
+        const u32 d = valid ? ld[j] : 0u;
+        // a partition need not be stable: the rank inside the digit's run is whatever an LDS atomic hands out (a row whose
+        // lanes all hold the same digit -- heavy keys, high levels -- takes 64 ranks with one atomic)
+        u32 rank = 0;
+        {   // lanes that share a digit with many others (heavy keys fill a third of some tiles) would serialise their atomics:
+            // up to two big groups of the row are peeled off with one atomic each, the rest takes one atomic per lane
+            u64 rem = __ballot(valid);
+            bool done = !valid;
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                if (!rem) break;
+                const int lead = __ffsll((long long)rem) - 1;
+                const u32 dl = __shfl(d, lead, 64);
+                const u64 grp = __ballot(!done && d == dl);
+                const u32 c = (u32)__popcll(grp);
+                if (c < 8) break;
+                u32 b0 = 0;
+                if (lane == lead) b0 = atomicAdd(&tcnt[dl], c);
+                b0 = __shfl(b0, lead, 64);
+                if ((grp >> lane) & 1ull) { rank = b0 + (u32)__popcll(grp & ((1ull << lane) - 1)); done = true; }
+                rem &= ~grp;
+            }
+            if (!done) rank = atomicAdd(&tcnt[d], 1u);
+        }
+        ld[j] = (d << 16) | rank;
+    }
+    __syncthreads();
+    {   // digit runs inside the sorted tile (exclusive scan over the digits), per-wave starts, global base
+        const u32 t = threadIdx.x;
+        u32 tot[DMAX / 256], sum = 0;
+#pragma unroll
+        for (int q = 0; q < DMAX / 256; ++q) {               // thread t owns the digits t * (DMAX / 256) + q
+            tot[q] = tcnt[t * (DMAX / 256) + q];
+            sum += tot[q];
+        }
+        u32 total;
+        u32 start = block_exclusive_sum<u32, 4>(sum, scan_sm, total);
+#pragma unroll
+        for (int q = 0; q < DMAX / 256; ++q) {
+            const u32 d = t * (DMAX / 256) + q;
+            tcnt[d] = start;
+            gbase[d] = (d < P.D ? P.counts[(size_t)row * P.D + d] : 0u) - start;
+            start += tot[q];
+        }
+    }
+    __syncthreads();                                       // splitters / text bytes are dead from here on
+    u32 dst[SS_ITEMS];
+#pragma unroll
+    for (int j = 0; j < SS_ITEMS; ++j) {
+        const u32 e = GEN ? lbs + (u32)j : lbs + (u32)j * 64;
+        const u32 d = ld[j] >> 16;
+        const u32 pos = (ld[j] & 0xFFFFu) + tcnt[d];           // position inside the sorted tile
+        ld[j] = pos;
+        if (e < cnt) { stage32[pos] = v[j]; stage_d[pos] = (u16)d; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < SS_ITEMS; ++r) {
+        const u32 sp = (u32)r * 256 + threadIdx.x;
+        dst[r] = 0xFFFFFFFFu;
+        if (sp < cnt) {
+            dst[r] = gbase[stage_d[sp]] + sp;
+            P.vals_out[dst[r]] = stage32[sp];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < SS_ITEMS; ++j) {
+        const u32 e = GEN ? lbs + (u32)j : lbs + (u32)j * 64;
+        if (e < cnt) stage[ld[j]] = k[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < SS_ITEMS; ++r) {
+        const u32 sp = (u32)r * 256 + threadIdx.x;
+        if (dst[r] != 0xFFFFFFFFu) P.keys_out[dst[r]] = stage[sp];
+    }
+}
+
+// ---- scatter, stable variant: ranks from the wave-level LDS match (used for the LAST level, whose equality digits are skewed
+//      by construction: a heavy key fills a third of some tiles, and same-address LDS atomics serialise) ---------------------------
+// rs_scatter_lds_kernel of prim.hip with a splitter digit: ranks inside the tile from a wave-level match (NB ballots per key)
+// plus per-wave counters; the tile is written to LDS in digit order first, so that consecutive lanes write consecutive pairs of
+// a digit's run.  The splitters (and, for GEN, the tile's recoded bytes) live in the staging buffer until the digits are known.
+template <bool GEN, bool LAST>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void ss_scatter_stable_kernel(SSLevel P, TextKeyGen g, u32 rows) {
+    constexpr int DMAX = LAST ? 512 : 256;
     __shared__ __align__(16) u16 wcnt[4][DMAX];
     __shared__ u32 gbase[DMAX];
     __shared__ __align__(16) u64 stage[SS_TILE];
@@ -435,6 +573,184 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const u32 sp = (u32)r * 256 + threadIdx.x;
         if (dst[r] != 0xFFFFFFFFu) P.keys_out[dst[r]] = stage[sp];
     }
+}
+
+// ---- two-level MSD partition of (u32 index, u32 value) pairs by the top 16 bits of the index ------------------------------------
+// The first two passes of the bucketed scatter (prim.hip): dst[idx[j]] = val[j] wants its pairs grouped by destination window, in
+// ANY order inside a window.  Two stable LSD passes (low digit, then high digit) do that with a wave-level match per key; an
+// MSD split needs no stability at all -- level 1 on the top 8 bits, level 2 on the next 8 bits inside every level-1 bucket (the
+// segment machinery of the splitter sort) -- so a key's slot is whatever one LDS atomic hands out.
+struct PSLevel {
+    const u32* idx_in; const u32* val_in; u32* idx_out; u32* val_out;
+    u32* counts; const u32* blk_seg; const u32* blk_start; const u32* seg_start;
+    u32 nseg, R, per_xcd; int shift;
+};
+__device__ __forceinline__ bool ps_row(const PSLevel& P, u32 row, size_t& base, u32& cnt) {
+    const u32 blk = row / P.R;
+    if (blk >= P.blk_start[P.nseg]) return false;
+    const u32 s = P.blk_seg[blk];
+    const u64 t = (u64)(blk - P.blk_start[s]) * P.R + row % P.R;
+    const u32 s0 = P.seg_start[s], s1 = P.seg_start[s + 1];
+    const u64 off = t * SS_TILE;
+    base = s0; cnt = 0;
+    if (off >= (u64)(s1 - s0)) return true;
+    base = (size_t)s0 + off;
+    const u64 left = (u64)(s1 - s0) - off;
+    cnt = left < SS_TILE ? (u32)left : (u32)SS_TILE;
+    return true;
+}
+__global__ __launch_bounds__(256) void ps_count_kernel(PSLevel P, u32 rows) {
+    __shared__ u32 hist[256];
+    const u32 row = xcd_tile(blockIdx.x, P.per_xcd);
+    if (row >= rows) return;
+    size_t base; u32 cnt;
+    if (!ps_row(P, row, base, cnt)) return;
+    hist[threadIdx.x] = 0;
+    if (cnt == 0) { P.counts[(size_t)row * 256 + threadIdx.x] = 0; return; }
+    __syncthreads();
+    const u32 lb = wave_id() * (64 * SS_ITEMS) + lane_id();
+    const u32* ip = P.idx_in + base + lb;
+    u32 kk[SS_ITEMS];
+#pragma unroll
+    for (int j = 0; j < SS_ITEMS; ++j) kk[j] = (lb + (u32)j * 64 < cnt) ? ip[j * 64] : 0u;
+#pragma unroll
+    for (int j = 0; j < SS_ITEMS; ++j) {
+        const bool valid = lb + (u32)j * 64 < cnt;
+        const u32 d = (kk[j] >> P.shift) & 255u;
+        const u32 d0 = __builtin_amdgcn_readfirstlane(d);
+        if (__all(valid && d == d0)) { if (lane_id() == 0) atomicAdd(&hist[d0], 64u); }
+        else if (valid) atomicAdd(&hist[d], 1u);
+    }
+    __syncthreads();
+    P.counts[(size_t)row * 256 + threadIdx.x] = hist[threadIdx.x];
+}
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void ps_scatter_kernel(PSLevel P, u32 rows) {
+    __shared__ u32 tcnt[256];
+    __shared__ u32 gbase[256];
+    __shared__ u32 stage_i[SS_TILE];
+    __shared__ u32 stage_v[SS_TILE];
+    __shared__ u32 scan_sm[5];
+    const int lane = lane_id();
+    const u32 row = xcd_tile(blockIdx.x, P.per_xcd);
+    if (row >= rows) return;
+    size_t base; u32 cnt;
+    if (!ps_row(P, row, base, cnt) || cnt == 0) return;
+    tcnt[threadIdx.x] = 0;
+    __syncthreads();
+    const u32 lb = wave_id() * (64 * SS_ITEMS) + lane;
+    const u32* ip = P.idx_in + base + lb;
+    const u32* vp = P.val_in + base + lb;
+    u32 k[SS_ITEMS], v[SS_ITEMS], ld[SS_ITEMS];
+#pragma unroll
+    for (int j = 0; j < SS_ITEMS; ++j) {
+        const bool valid = lb + (u32)j * 64 < cnt;
+        k[j] = valid ? ip[j * 64] : 0u;
+        v[j] = valid ? vp[j * 64] : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < SS_ITEMS; ++j) {
+        const bool valid = lb + (u32)j * 64 < cnt;
+        const u32 d = (k[j] >> P.shift) & 255u;
+        const u32 d0 = __builtin_amdgcn_readfirstlane(d);
+        u32 rank = 0;
+        if (__all(valid && d == d0)) {
+            if (lane == 0) rank = atomicAdd(&tcnt[d0], 64u);
+            rank = __builtin_amdgcn_readfirstlane(rank) + (u32)lane;
+        } else if (valid) rank = atomicAdd(&tcnt[d], 1u);
+        ld[j] = rank;
+    }
+    __syncthreads();
+    {
+        const u32 t = threadIdx.x;
+        const u32 tot = tcnt[t];
+        u32 total;
+        const u32 start = block_exclusive_sum<u32, 4>(tot, scan_sm, total);
+        tcnt[t] = start;
+        gbase[t] = P.counts[(size_t)row * 256 + t] - start;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < SS_ITEMS; ++j) {
+        if (lb + (u32)j * 64 < cnt) {
+            const u32 pos = ld[j] + tcnt[(k[j] >> P.shift) & 255u];
+            stage_i[pos] = k[j]; stage_v[pos] = v[j];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < SS_ITEMS; ++r) {
+        const u32 sp = (u32)r * 256 + threadIdx.x;
+        if (sp < cnt) {
+            const u32 key = stage_i[sp];
+            const u32 dst = gbase[(key >> P.shift) & 255u] + sp;
+            P.idx_out[dst] = key;
+            P.val_out[dst] = stage_v[sp];
+        }
+    }
+}
+
+// idx / val (m pairs, only read) -> out_idx / out_val grouped by idx >> (bits - 16); tmp_*: m entries of scratch each
+void msd_partition_pairs_u32(Ctx& c, const u32* idx, const u32* val, size_t m, int bits, u32* out_idx, u32* out_val, u32* tmp_idx, u32* tmp_val) {
+    hipStream_t s = c.stream;
+    const size_t mark = c.arena.mark();
+    u32* seg_start = c.arena.get<u32>(2);
+    ss_set_word_kernel<<<1, 1, 0, s>>>(seg_start, 0u);
+    LAUNCH_CHECK();
+    ss_set_word_kernel<<<1, 1, 0, s>>>(seg_start + 1, (u32)m);
+    LAUNCH_CHECK();
+    u32 nseg = 1;
+    const u64 tiles = (m + SS_TILE - 1) / SS_TILE;
+    for (int l = 0; l < 2; ++l) {
+        u32 R = 128;
+        while (R > 1 && (u64)nseg * R > tiles / 8 + 64) R >>= 1;
+        const u32 blocks_ub = (u32)((tiles + R - 1) / R) + nseg;
+        const u32 rows = blocks_ub * R;
+        u32* nstart = c.arena.get<u32>((size_t)nseg * 256 + 1);
+        const size_t lm = c.arena.mark();
+        u32* blk_start = c.arena.get<u32>((size_t)nseg + 1);
+        u32* blk_seg = c.arena.get<u32>(blocks_ub);
+        u32* counts = c.arena.get<u32>((size_t)rows * 256);
+        u32* bs = c.arena.get<u32>((size_t)blocks_ub * 256);
+        ss_nblk_kernel<<<cdiv((size_t)nseg + 1, 256), 256, 0, s>>>(seg_start, nseg, R, blk_start);
+        LAUNCH_CHECK();
+        exclusive_sum_u32(c, blk_start, blk_start, (size_t)nseg + 1, nullptr);
+        ss_blkseg_kernel<<<cdiv(nseg, 256), 256, 0, s>>>(blk_start, nseg, blk_seg);
+        LAUNCH_CHECK();
+        PSLevel P;
+        P.idx_in = l == 0 ? idx : tmp_idx; P.val_in = l == 0 ? val : tmp_val;
+        P.idx_out = l == 0 ? tmp_idx : out_idx; P.val_out = l == 0 ? tmp_val : out_val;
+        P.counts = counts; P.blk_seg = blk_seg; P.blk_start = blk_start; P.seg_start = seg_start;
+        P.nseg = nseg; P.R = R; P.shift = bits - 8 * (l + 1);
+        P.per_xcd = (c.xcd_remap == 1 && rows >= 64) ? cdiv(rows, 8) : 0u;
+        const u32 grid = P.per_xcd ? 8 * P.per_xcd : rows;
+        {
+            const int pc = c.prof_begin(K_RS_COUNT, (u64)m * 4);
+            ps_count_kernel<<<grid, 256, 0, s>>>(P, rows);
+            LAUNCH_CHECK();
+            c.prof_end(pc);
+        }
+        {
+            Ctx::ProfScope prof(c, K_SCAN, (u64)rows * 256 * 12);
+            ss_blocksum_kernel<<<blocks_ub, 256, 0, s>>>(counts, blk_start, nseg, R, 256, bs);
+            LAUNCH_CHECK();
+            ss_segbase_kernel<<<nseg, 1024, 0, s>>>(bs, blk_start, seg_start, 256, nstart);
+            LAUNCH_CHECK();
+            ss_set_word_kernel<<<1, 1, 0, s>>>(nstart + (size_t)nseg * 256, (u32)m);
+            LAUNCH_CHECK();
+            ss_apply_kernel<<<blocks_ub, 256, 0, s>>>(counts, blk_start, nseg, R, 256, bs);
+            LAUNCH_CHECK();
+        }
+        {
+            const int ps = c.prof_begin(K_RS_SCATTER_U32, (u64)m * 16);
+            ps_scatter_kernel<<<grid, 256, 0, s>>>(P, rows);
+            LAUNCH_CHECK();
+            c.prof_end(ps);
+        }
+        c.arena.release(lm);
+        seg_start = nstart;
+        nseg *= 256;
+    }
+    c.arena.release(mark);
 }
 
 // ---- leaves -> units ----------------------------------------------------------------------------------------------------------
@@ -798,9 +1114,9 @@ int splitter_sort_pairs_u64(Ctx& c, u64* keys[2], u32* vals[2], size_t n, const 
         }
         {
             const int ps = c.prof_begin(K_RS_SCATTER_U64, (u64)n * (gl ? 13 : 24));
-            if (gl && last) ss_scatter_kernel<true, true><<<grid, 256, 0, s>>>(P, g, rows);
+            if (gl && last) ss_scatter_stable_kernel<true, true><<<grid, 256, 0, s>>>(P, g, rows);
             else if (gl) ss_scatter_kernel<true, false><<<grid, 256, 0, s>>>(P, g, rows);
-            else if (last) ss_scatter_kernel<false, true><<<grid, 256, 0, s>>>(P, g, rows);
+            else if (last) ss_scatter_stable_kernel<false, true><<<grid, 256, 0, s>>>(P, g, rows);
             else ss_scatter_kernel<false, false><<<grid, 256, 0, s>>>(P, g, rows);
             LAUNCH_CHECK();
             c.prof_end(ps);
