@@ -995,10 +995,14 @@ void bucketed_scatter_u32(Ctx& c, const u32* idx, const u32* val, size_t m, u32*
     const int bits = (int)bits_for(n_dst ? n_dst - 1 : 0);
     const u32* k = idx;
     const u32* v = val;
+    int part_bits = 16;                                          // index bits the partition has resolved
     if (c.msd_partition && bits > 16 && m >= ((size_t)1 << 20) && tmp_idx2 && tmp_val2) {
-        // partition by the top 16 bits of idx: two MSD levels, no stability needed (ssort.hip)
-        msd_partition_pairs_u32(c, idx, val, m, bits, tmp_idx2, tmp_val2, tmp_idx, tmp_val);
+        // partition by the top 16 (18 for more than 2^29 destinations: the windows of the final pass then still fit its LDS image)
+        // bits of idx: two MSD levels, no stability needed (ssort.hip)
+        const int db = (bits - 16 > 13) ? 9 : 8;
+        msd_partition_pairs_u32(c, idx, val, m, bits, db, tmp_idx2, tmp_val2, tmp_idx, tmp_val);
         k = tmp_idx2; v = tmp_val2;
+        part_bits = 2 * db;
     } else if (bits > 8 && m >= ((size_t)1 << 20)) {
         // two stable 8-bit passes (low digit first) = partition by the top 16 bits: the writes of the final pass stay inside
         // windows of n_dst / 65536 elements, which L2 merges into whole lines
@@ -1015,8 +1019,8 @@ void bucketed_scatter_u32(Ctx& c, const u32* idx, const u32* val, size_t m, u32*
             k = tmp_idx2; v = tmp_val2;
         }
     }
-    if (permutation && k == tmp_idx2 && bits > 16 && (1u << (bits - 16)) <= WIMG_MAX) {
-        const u32 W = 1u << (bits - 16);
+    if (permutation && k == tmp_idx2 && bits > part_bits && (1u << (bits - part_bits)) <= WIMG_MAX) {
+        const u32 W = 1u << (bits - part_bits);
         Ctx::ProfScope prof(c, K_WINDOW_SCATTER, (u64)m * 12);      // read the partitioned pairs, write every destination word once
         window_image_kernel<<<cdiv(m, W), 256, 0, c.stream>>>(k, v, m, dst, W);
         LAUNCH_CHECK();

@@ -31,9 +31,9 @@ struct SplitSortStats { u32 levels = 0, range_leaves = 0, samples = 0, units = 0
 bool splitter_sort_applicable(size_t n);
 int splitter_sort_pairs_u64(Ctx& c, u64* keys[2], u32* vals[2], size_t n, const TextKeyGen* gen, SplitSortStats* st);
 
-// Two-level MSD partition (ssort.hip): idx / val (m pairs, only read) -> out_idx / out_val grouped by idx >> (bits - 16), any order
-// inside a group; tmp_idx / tmp_val: m entries of scratch each.  bits >= 17.
-void msd_partition_pairs_u32(Ctx& c, const u32* idx, const u32* val, size_t m, int bits, u32* out_idx, u32* out_val, u32* tmp_idx, u32* tmp_val);
+// Two-level MSD partition (ssort.hip): idx / val (m pairs, only read) -> out_idx / out_val grouped by idx >> (bits - 2 * db), any
+// order inside a group; db = digit bits per level (8 or 9); tmp_idx / tmp_val: m entries of scratch each.  bits > 2 * db.
+void msd_partition_pairs_u32(Ctx& c, const u32* idx, const u32* val, size_t m, int bits, int db, u32* out_idx, u32* out_val, u32* tmp_idx, u32* tmp_val);
 
 // Same contract as radix_sort_pairs_u64 for keys that are pairwise DISTINCT on the sorted bits (stability is then
 // irrelevant): inputs of at most 2048 pairs are sorted by one workgroup in LDS (bitonic network), larger ones by the

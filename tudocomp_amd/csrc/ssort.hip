@@ -599,14 +599,16 @@ __device__ __forceinline__ bool ps_row(const PSLevel& P, u32 row, size_t& base, 
     cnt = left < SS_TILE ? (u32)left : (u32)SS_TILE;
     return true;
 }
+template <int DB>       // digit bits: 8, or 9 when the destination windows would otherwise exceed the LDS image of the final pass
 __global__ __launch_bounds__(256) void ps_count_kernel(PSLevel P, u32 rows) {
-    __shared__ u32 hist[256];
+    constexpr u32 D = 1u << DB;
+    __shared__ u32 hist[D];
     const u32 row = xcd_tile(blockIdx.x, P.per_xcd);
     if (row >= rows) return;
     size_t base; u32 cnt;
     if (!ps_row(P, row, base, cnt)) return;
-    hist[threadIdx.x] = 0;
-    if (cnt == 0) { P.counts[(size_t)row * 256 + threadIdx.x] = 0; return; }
+    for (u32 i = threadIdx.x; i < D; i += 256) hist[i] = 0;
+    if (cnt == 0) { for (u32 i = threadIdx.x; i < D; i += 256) P.counts[(size_t)row * D + i] = 0; return; }
     __syncthreads();
     const u32 lb = wave_id() * (64 * SS_ITEMS) + lane_id();
     const u32* ip = P.idx_in + base + lb;
@@ -616,17 +618,19 @@ __global__ __launch_bounds__(256) void ps_count_kernel(PSLevel P, u32 rows) {
 #pragma unroll
     for (int j = 0; j < SS_ITEMS; ++j) {
         const bool valid = lb + (u32)j * 64 < cnt;
-        const u32 d = (kk[j] >> P.shift) & 255u;
+        const u32 d = (kk[j] >> P.shift) & (D - 1);
         const u32 d0 = __builtin_amdgcn_readfirstlane(d);
         if (__all(valid && d == d0)) { if (lane_id() == 0) atomicAdd(&hist[d0], 64u); }
         else if (valid) atomicAdd(&hist[d], 1u);
     }
     __syncthreads();
-    P.counts[(size_t)row * 256 + threadIdx.x] = hist[threadIdx.x];
+    for (u32 i = threadIdx.x; i < D; i += 256) P.counts[(size_t)row * D + i] = hist[i];
 }
+template <int DB>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void ps_scatter_kernel(PSLevel P, u32 rows) {
-    __shared__ u32 tcnt[256];
-    __shared__ u32 gbase[256];
+    constexpr u32 D = 1u << DB;
+    __shared__ u32 tcnt[D];
+    __shared__ u32 gbase[D];
     __shared__ u32 stage_i[SS_TILE];
     __shared__ u32 stage_v[SS_TILE];
     __shared__ u32 scan_sm[5];
@@ -635,7 +639,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     if (row >= rows) return;
     size_t base; u32 cnt;
     if (!ps_row(P, row, base, cnt) || cnt == 0) return;
-    tcnt[threadIdx.x] = 0;
+    for (u32 i = threadIdx.x; i < D; i += 256) tcnt[i] = 0;
     __syncthreads();
     const u32 lb = wave_id() * (64 * SS_ITEMS) + lane;
     const u32* ip = P.idx_in + base + lb;
@@ -650,7 +654,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
     for (int j = 0; j < SS_ITEMS; ++j) {
         const bool valid = lb + (u32)j * 64 < cnt;
-        const u32 d = (k[j] >> P.shift) & 255u;
+        const u32 d = (k[j] >> P.shift) & (D - 1);
         const u32 d0 = __builtin_amdgcn_readfirstlane(d);
         u32 rank = 0;
         if (__all(valid && d == d0)) {
@@ -662,17 +666,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     __syncthreads();
     {
         const u32 t = threadIdx.x;
-        const u32 tot = tcnt[t];
+        u32 tot[D / 256], sum = 0;
+#pragma unroll
+        for (u32 q = 0; q < D / 256; ++q) { tot[q] = tcnt[t * (D / 256) + q]; sum += tot[q]; }
         u32 total;
-        const u32 start = block_exclusive_sum<u32, 4>(tot, scan_sm, total);
-        tcnt[t] = start;
-        gbase[t] = P.counts[(size_t)row * 256 + t] - start;
+        u32 start = block_exclusive_sum<u32, 4>(sum, scan_sm, total);
+#pragma unroll
+        for (u32 q = 0; q < D / 256; ++q) {
+            const u32 d = t * (D / 256) + q;
+            tcnt[d] = start;
+            gbase[d] = P.counts[(size_t)row * D + d] - start;
+            start += tot[q];
+        }
     }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < SS_ITEMS; ++j) {
         if (lb + (u32)j * 64 < cnt) {
-            const u32 pos = ld[j] + tcnt[(k[j] >> P.shift) & 255u];
+            const u32 pos = ld[j] + tcnt[(k[j] >> P.shift) & (D - 1)];
             stage_i[pos] = k[j]; stage_v[pos] = v[j];
         }
     }
@@ -682,17 +693,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const u32 sp = (u32)r * 256 + threadIdx.x;
         if (sp < cnt) {
             const u32 key = stage_i[sp];
-            const u32 dst = gbase[(key >> P.shift) & 255u] + sp;
+            const u32 dst = gbase[(key >> P.shift) & (D - 1)] + sp;
             P.idx_out[dst] = key;
             P.val_out[dst] = stage_v[sp];
         }
     }
 }
 
-// idx / val (m pairs, only read) -> out_idx / out_val grouped by idx >> (bits - 16); tmp_*: m entries of scratch each
-void msd_partition_pairs_u32(Ctx& c, const u32* idx, const u32* val, size_t m, int bits, u32* out_idx, u32* out_val, u32* tmp_idx, u32* tmp_val) {
+// idx / val (m pairs, only read) -> out_idx / out_val grouped by idx >> (bits - 2 * db), db = digit bits (8 or 9); tmp_*: m entries
+// of scratch each
+void msd_partition_pairs_u32(Ctx& c, const u32* idx, const u32* val, size_t m, int bits, int db, u32* out_idx, u32* out_val, u32* tmp_idx, u32* tmp_val) {
     hipStream_t s = c.stream;
     const size_t mark = c.arena.mark();
+    const u32 D = 1u << db;
     u32* seg_start = c.arena.get<u32>(2);
     ss_set_word_kernel<<<1, 1, 0, s>>>(seg_start, 0u);
     LAUNCH_CHECK();
@@ -705,12 +718,12 @@ void msd_partition_pairs_u32(Ctx& c, const u32* idx, const u32* val, size_t m, i
         while (R > 1 && (u64)nseg * R > tiles / 8 + 64) R >>= 1;
         const u32 blocks_ub = (u32)((tiles + R - 1) / R) + nseg;
         const u32 rows = blocks_ub * R;
-        u32* nstart = c.arena.get<u32>((size_t)nseg * 256 + 1);
+        u32* nstart = c.arena.get<u32>((size_t)nseg * D + 1);
         const size_t lm = c.arena.mark();
         u32* blk_start = c.arena.get<u32>((size_t)nseg + 1);
         u32* blk_seg = c.arena.get<u32>(blocks_ub);
-        u32* counts = c.arena.get<u32>((size_t)rows * 256);
-        u32* bs = c.arena.get<u32>((size_t)blocks_ub * 256);
+        u32* counts = c.arena.get<u32>((size_t)rows * D);
+        u32* bs = c.arena.get<u32>((size_t)blocks_ub * D);
         ss_nblk_kernel<<<cdiv((size_t)nseg + 1, 256), 256, 0, s>>>(seg_start, nseg, R, blk_start);
         LAUNCH_CHECK();
         exclusive_sum_u32(c, blk_start, blk_start, (size_t)nseg + 1, nullptr);
@@ -720,35 +733,35 @@ void msd_partition_pairs_u32(Ctx& c, const u32* idx, const u32* val, size_t m, i
         P.idx_in = l == 0 ? idx : tmp_idx; P.val_in = l == 0 ? val : tmp_val;
         P.idx_out = l == 0 ? tmp_idx : out_idx; P.val_out = l == 0 ? tmp_val : out_val;
         P.counts = counts; P.blk_seg = blk_seg; P.blk_start = blk_start; P.seg_start = seg_start;
-        P.nseg = nseg; P.R = R; P.shift = bits - 8 * (l + 1);
+        P.nseg = nseg; P.R = R; P.shift = bits - db * (l + 1);
         P.per_xcd = (c.xcd_remap == 1 && rows >= 64) ? cdiv(rows, 8) : 0u;
         const u32 grid = P.per_xcd ? 8 * P.per_xcd : rows;
         {
             const int pc = c.prof_begin(K_RS_COUNT, (u64)m * 4);
-            ps_count_kernel<<<grid, 256, 0, s>>>(P, rows);
+            if (db == 9) ps_count_kernel<9><<<grid, 256, 0, s>>>(P, rows); else ps_count_kernel<8><<<grid, 256, 0, s>>>(P, rows);
             LAUNCH_CHECK();
             c.prof_end(pc);
         }
         {
-            Ctx::ProfScope prof(c, K_SCAN, (u64)rows * 256 * 12);
-            ss_blocksum_kernel<<<blocks_ub, 256, 0, s>>>(counts, blk_start, nseg, R, 256, bs);
+            Ctx::ProfScope prof(c, K_SCAN, (u64)rows * D * 12);
+            ss_blocksum_kernel<<<blocks_ub, 256, 0, s>>>(counts, blk_start, nseg, R, D, bs);
             LAUNCH_CHECK();
-            ss_segbase_kernel<<<nseg, 1024, 0, s>>>(bs, blk_start, seg_start, 256, nstart);
+            ss_segbase_kernel<<<nseg, 1024, 0, s>>>(bs, blk_start, seg_start, D, nstart);
             LAUNCH_CHECK();
-            ss_set_word_kernel<<<1, 1, 0, s>>>(nstart + (size_t)nseg * 256, (u32)m);
+            ss_set_word_kernel<<<1, 1, 0, s>>>(nstart + (size_t)nseg * D, (u32)m);
             LAUNCH_CHECK();
-            ss_apply_kernel<<<blocks_ub, 256, 0, s>>>(counts, blk_start, nseg, R, 256, bs);
+            ss_apply_kernel<<<blocks_ub, 256, 0, s>>>(counts, blk_start, nseg, R, D, bs);
             LAUNCH_CHECK();
         }
         {
             const int ps = c.prof_begin(K_RS_SCATTER_U32, (u64)m * 16);
-            ps_scatter_kernel<<<grid, 256, 0, s>>>(P, rows);
+            if (db == 9) ps_scatter_kernel<9><<<grid, 256, 0, s>>>(P, rows); else ps_scatter_kernel<8><<<grid, 256, 0, s>>>(P, rows);
             LAUNCH_CHECK();
             c.prof_end(ps);
         }
         c.arena.release(lm);
         seg_start = nstart;
-        nseg *= 256;
+        nseg *= D;
     }
     c.arena.release(mark);
 }
