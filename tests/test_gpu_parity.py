@@ -415,6 +415,26 @@ def test_lcpcomp_max_lcp_strategy(gpu_ctx):
     assert c.decompress(c.compress(data)) == data
 
 
+def test_device_decompress_rejects_corrupt_tables(gpu_ctx):
+    """fuzzed Huffman tables / headers: the host parse in front of the device resolver refuses or decodes, never reads
+    behind its tables"""
+    text = O.escape(T.gen_english(5000, 3).tobytes())
+    good = O.lcpcomp_huff_compress(text, 2, 1)[0]
+    rng = np.random.default_rng(17)
+    refused = 0
+    for trial in range(200):
+        bad = bytearray(good)
+        for _ in range(3):
+            bad[int(rng.integers(0, 24))] ^= 1 << int(rng.integers(0, 8))
+        try:
+            gpu_ctx.lcpcomp_decompress(bytes(bad))
+        except T.TdcGpuError as e:
+            assert e.status in (-2, -5)
+            refused += 1
+    assert refused > 0
+    assert gpu_ctx.lcpcomp_decompress(good)[0] == text
+
+
 def test_committed_stage_fixture(gpu_ctx):
     """the HIP path against COMMITTED per-stage data (tests/golden/oracle_stages.json, tests/make_golden.py), no live oracle involved"""
     fx = load_json("oracle_stages.json")

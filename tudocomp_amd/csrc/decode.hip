@@ -104,14 +104,15 @@ static u64 parse_lzss_huff_stream(const u8* in, size_t len, std::vector<u8>& tex
     u64 firstcode[64];
     size_t prefix_sum[64];
     unsigned longest = 0;
+    u8 numl[64] = {0};
+    size_t sigma = 0;
     constexpr unsigned LUT_BITS = 12;
     std::vector<unsigned short> lut;                          // (symbol << 4) | code length, 0 = longer than LUT_BITS / invalid
     if (have_table) {
         longest = (unsigned)(bs.read_compressed_int() & 0xFF);
         if (longest == 0 || longest > 57) throw StreamError{"corrupt Huffman table"};
-        u8 numl[64];
         for (unsigned i = 0; i < longest; ++i) numl[i] = (u8)bs.read_compressed_int();
-        const size_t sigma = (size_t)bs.read_compressed_int();
+        sigma = (size_t)bs.read_compressed_int();
         if (sigma > 256) throw StreamError{"corrupt Huffman table"};
         for (size_t i = 0; i < sigma; ++i) order[i] = (u8)bs.read(8);
         firstcode[longest - 1] = 0;                                              // gen_first_codes :192-198
@@ -151,7 +152,9 @@ static u64 parse_lzss_huff_stream(const u8* in, size_t len, std::vector<u8>& tex
                 do { value = (value << 1) | ((w >> (63 - length)) & 1u); ++length; } while (length <= longest && value < firstcode[length - 1]);
                 if (length > longest) throw StreamError{"corrupt Huffman code"};
                 --length;
-                text[(size_t)p++] = order[prefix_sum[length] + (value - firstcode[length])];
+                const u64 off = value - firstcode[length];                        // a table that violates Kraft would index behind order[]
+                if (off >= numl[length] || prefix_sum[length] + off >= sigma) throw StreamError{"corrupt Huffman code"};
+                text[(size_t)p++] = order[prefix_sum[length] + off];
                 bs.pos += length + 1;
             }
         }
