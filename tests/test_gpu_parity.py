@@ -422,10 +422,10 @@ def test_device_decompress_rejects_corrupt_tables(gpu_ctx):
     good = O.lcpcomp_huff_compress(text, 2, 1)[0]
     rng = np.random.default_rng(17)
     refused = 0
-    for trial in range(200):
+    for trial in range(100):
         bad = bytearray(good)
         for _ in range(3):
-            bad[int(rng.integers(0, 24))] ^= 1 << int(rng.integers(0, 8))
+            bad[int(rng.integers(0, 16))] ^= 1 << int(rng.integers(0, 8))
         try:
             gpu_ctx.lcpcomp_decompress(bytes(bad))
         except T.TdcGpuError as e:

@@ -136,6 +136,11 @@ static u64 parse_lzss_huff_stream(const u8* in, size_t len, std::vector<u8>& tex
     const u64 flen_min = bs.read(W), flen_max = bs.read(W), fdist_max = bs.read(W);
     const unsigned lbits = bits_for(flen_max - flen_min), dbits = bits_for(fdist_max);
     if (n == 0 || n >= 0x7FFFFFFFull) throw StreamError{"text length out of range"};     // a text always holds its sentinel
+    {   // plausibility (a corrupt header would otherwise ask for gigabytes): a literal costs at least one bit, a factor at least W
+        // bits and covers at most flen_max positions
+        const u64 bits = (u64)len * 8;
+        if (n > bits + (bits / W + 1) * (flen_max ? flen_max : 1)) throw StreamError{"text length out of range"};
+    }
     text.assign((size_t)n, 0);
     u64 p = 0;
     while (!bs.eof()) {
