@@ -308,8 +308,10 @@ def factorize_tile(n, w0, w1, a, b, cur_g, prio_g, resid_g, threshold, lcut):
     cur = {p: cur_g[p] for p in range(w0, w1)}
     res = {p: (resid_g[p] if resid_g[p] <= lcut else 0) for p in range(w0, w1)}
     prio = {p: (0, prio_g[p]) for p in range(w0, w1)}          # (0, global) < (1, local)
-    fl = w0 if w0 > 0 else -INF
-    fr = w1 if w1 < n else INF
+    # the outermost lcut - 1 positions on either side only serve as upper bounds of what unknown factors can reach (see below)
+    strip = max(lcut - 1, 0)
+    fl = w0 + strip if w0 > 0 else -INF
+    fr = w1 - strip if w1 < n else INF
     mid = (w0 + w1) // 2
     local_base = 0
     out = []
@@ -317,7 +319,19 @@ def factorize_tile(n, w0, w1, a, b, cur_g, prio_g, resid_g, threshold, lcut):
     for L in range(lcut, threshold - 1, -1):
         lo, hi = max(w0, fl), min(w1, fr)
         ent = [p for p in range(lo, hi) if res[p] == L]
-        exposed = lambda p: (p <= fl + L - 2) or (p + L - 1 >= fr)
+        # An unknown factor of this level starts at an unknown position q whose working value -- which only ever decreases, and
+        # of which the window holds an upper bound (only effects of certain factors were applied) -- is still >= L.  On the left
+        # it covers up to q + L - 1, on the right it truncates down to q - (L - 1): the borders only move as far as such a q exists.
+        dfl, dfr = fl, fr
+        if fl > -INF:
+            qs = [q for q in range(max(fl - L + 1, w0), min(fl, w1)) if cur[q] >= L]
+            if qs:
+                dfl = max(qs) + L
+        if fr < INF:
+            qs = [q for q in range(max(fr, w0), min(fr + L - 1, w1)) if cur[q] >= L]
+            if qs:
+                dfr = min(qs) - (L - 1)
+        exposed = lambda p: (p < dfl) or (p >= dfr)
         st = {}
         stale = []
         for p in ent:
@@ -387,8 +401,8 @@ def factorize_tile(n, w0, w1, a, b, cur_g, prio_g, resid_g, threshold, lcut):
             res[p] = v
             prio[p] = (1, local_base + i)
         local_base += len(pushes)
-        nfl = fl + (L - 1)
-        nfr = fr - (L - 1)
+        nfl = dfl
+        nfr = dfr
         for p, reach in tainted:
             if p < mid:
                 nfl = max(nfl, p + reach)

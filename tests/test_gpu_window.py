@@ -83,6 +83,26 @@ def test_window_levels_match_oracle(ctx_for, name, data):
     assert seen & {1, 2}, "the window pass never ran"
 
 
+def test_smallest_halo_and_retry_with_the_largest(monkeypatch):
+    """The borders of a window's known range only move where an unknown factor can exist, so the first attempt runs with a small
+    halo (TDC_GPU_WINDOW_HALO; clamped to 2 * lcut + 64) and a failed border retries with the largest one.  Both outcomes must
+    give the oracle's factors: texts whose repeats are longer than the halo force the retry."""
+    rng = np.random.default_rng(99)
+    unit = bytes(rng.integers(97, 101, 150, dtype=np.uint8))
+    texts = [("english", T.gen_english(1 << 19, 3).tobytes()),
+             ("periodic", (unit * 2000)[:200000] + bytes(rng.integers(97, 123, 70000, dtype=np.uint8))),
+             ("mutated", b"".join(bytes([c if rng.random() > 0.002 else 120 for c in unit]) for _ in range(1500)))]
+    monkeypatch.setenv("TDC_GPU_WINDOW_HALO", "0")
+    monkeypatch.setenv("TDC_GPU_WINDOW_LCUT", "48")
+    with T.Context(0) as ctx:
+        for name, data in texts:
+            text = O.escape(data)
+            for thr in (2, 5):
+                want, _ = O.lcpcomp_huff_compress(text, thr, 1)
+                got, st = ctx.lcpcomp_compress(text, threshold=thr, flatten=1)
+                assert got == want, "%s t=%d (window_pass %d)" % (name, thr, st["window_pass"])
+
+
 def test_window_pass_is_used_and_stream_bit_exact(ctx_for):
     """End to end on the bench corpus generator: the default configuration takes the window path (no fallback) and the
     stream equals the oracle's."""

@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libtdc_gpu.so")
+# TDC_GPU_LIB: development aid for A/B runs of kernel variants (tools/build_variant.sh); the product is always lib/libtdc_gpu.so
+LIB_PATH = os.environ.get("TDC_GPU_LIB") or os.path.join(_HERE, "lib", "libtdc_gpu.so")
 
 # every symbol include/tdc_gpu.h declares (checked by tests/test_abi.py)
 SYMBOLS = [

@@ -11,15 +11,19 @@
 //     values of the others, pushes (new residence + new priority), kills and truncations -- the same steps as the
 //     global kernels, on bytes in LDS;
 //   * everything outside the window is UNKNOWN.  [fl, fr) is the range of window positions whose state is still
-//     exactly what the sequential algorithm would have: unknown factors of level L reach L-1 positions into the window
-//     (kills from the left, truncations from the right), so both borders move by L-1 per level; an entry that could
-//     be affected by something unknown (within distance < L of the border, or next to such an entry with higher
-//     priority) gets the third selection state UNCERTAIN and pushes the border past everything it could touch;
+//     exactly what the sequential algorithm would have.  An unknown factor of level L starts at an unknown position q
+//     whose working value is still >= L; working values only ever decrease and the window holds an upper bound of them
+//     everywhere (only the effects of certain factors are applied), so a border moves at level L exactly as far as such
+//     a q exists within reach: on the left the factor covers up to q + L - 1, on the right it truncates down to
+//     q - (L - 1).  (The worst case is L - 1 per level and side; on ordinary texts the borders move a few hundred
+//     positions in total, because the high levels are sparse.)  An entry that could be affected by something unknown
+//     (inside that reach, or next to such an entry with higher priority) gets the third selection state UNCERTAIN and
+//     pushes the border past everything it could touch;
 //   * a window is VALID iff its interior [a, b) is still inside [fl, fr) after the last level; only factors that start
-//     in the interior are written.  The halo (TH positions on either side) is sized for the worst case of the borders'
-//     unconditional movement plus one exposure jump per level; if any window ends up invalid (or overflows a fixed
-//     LDS list) the caller discards the results and runs the global level loop instead -- the global state is
-//     never modified here.
+//     in the interior are written.  The halo is a run-time value: the first attempt uses a small one, a window whose
+//     known range shrank into its interior makes the pass retry with the largest one; if that fails too (or a fixed LDS
+//     list overflows twice) the caller discards the results and runs the global level loop instead -- the global
+//     state is never modified here.
 //
 // Inside a window the list order of pushed entries is a window-local rank (flag bit + counter): priorities are only
 // ever compared between entries of one list at distance < L, i.e. inside one window, and a locally pushed entry follows
@@ -36,11 +40,7 @@ namespace tdc {
 namespace {
 
 constexpr int TW = 16384;            // window positions
-#ifndef TDC_WIN_TH
-#define TDC_WIN_TH 2048
-#endif
-constexpr int TH = TDC_WIN_TH;       // halo on either side
-constexpr int TI = TW - 2 * TH;      // interior positions per window
+constexpr int TH_MAX = 2048;         // halo on either side: a run-time value (multiple of 4), at most this
 constexpr int TT = 256;              // threads per workgroup
 constexpr int TCH = TW / TT;         // consecutive window positions per thread in the dense passes (64)
 constexpr int NWV = TT / 64;
@@ -61,6 +61,16 @@ __device__ __forceinline__ int PA(int q) {
 // byte offset of the k-th 8-byte word (k = 0..7) of thread t's chunk
 __device__ __forceinline__ int PW(int t, int k) { return (t << 6) + (((2 * k + 2 * (t >> 2)) & 15) << 2); }
 constexpr int BIG = 1 << 29;
+#ifdef TDC_WIN_DEAL_RR           // entries dealt round-robin to the waves
+#define WDEAL_FIRST (lane * NWV + wv)
+#define WDEAL_I0 0
+#define WDEAL_OFF (lane * NWV + wv)
+#else                            // a wave takes 64 consecutive entries; which wave takes the first block rotates with the level and the
+                                 // window (wave w of every workgroup sits on SIMD w: a fixed order would load one SIMD of the CU only)
+#define WDEAL_FIRST (wrot * 64 + lane)
+#define WDEAL_I0 (wrot * 64)
+#define WDEAL_OFF lane
+#endif
 
 // An entry of the current level, packed so that a neighbour costs ONE LDS read:
 //   [31:0] priority   [47:32] window position   [55:48] state (bit 7: priority is window-local)   [63:56] LCP value
@@ -105,7 +115,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 template <int TE, int TP, int WPE>      // list sizes; WPE = waves per SIMD the register budget is set for
 __global__ __launch_bounds__(TT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void window_levels_kernel(const u32* __restrict__ cur_g, const u32* __restrict__ prio_g,
                                                             const u8* __restrict__ res_g, const u32* __restrict__ phi, size_t n,
-                                                            u32 lcut, u32 threshold, u32 ntiles, u32* __restrict__ lprio_all,
+                                                            u32 lcut, u32 threshold, u32 ntiles, u32 halo, u32* __restrict__ lprio_all,
                                                             u32* __restrict__ flen, u32* __restrict__ fsrc, WinScalars* __restrict__ sc) {
     __shared__ __attribute__((aligned(16))) u8 cur8[TW];
     __shared__ __attribute__((aligned(16))) u8 res8[TW];    // [5:0] list level, bit 6: factor start (then [5:0] = length), bit 7: priority is window-local
@@ -121,6 +131,7 @@ __global__ __launch_bounds__(TT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
     u32* lprio = lprio_all + (size_t)blockIdx.x * TW;
     WPROF_DECL
 
+    const size_t TH = halo, TI = (size_t)TW - 2 * (size_t)halo;
     for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const size_t a = (size_t)tile * TI;
         const size_t b = (a + TI < n) ? a + TI : n;
@@ -169,8 +180,10 @@ __global__ __launch_bounds__(TT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) mymask |= __shfl_xor(mymask, d, 64);
         if (lane == 0) atomicOr((unsigned long long*)&s_lvlmask, (unsigned long long)mymask);
-        int fl = (w0 > 0) ? 0 : -BIG;                       // known range [fl, fr) in window offsets
-        int fr = (w1 < n) ? wl : BIG;
+        // known range [fl, fr) in window offsets.  The outermost lcut - 1 positions of a side that has unknown text behind it only
+        // serve as upper bounds of what unknown factors can reach (see "borders" below): nothing outside the window reaches further.
+        int fl = (w0 > 0) ? (int)lcut - 1 : -BIG;
+        int fr = (w1 < n) ? wl - ((int)lcut - 1) : BIG;
         u32 local_base = 0;
         u32 nsel_interior = 0;
         bool failed = false;
@@ -179,9 +192,25 @@ __global__ __launch_bounds__(TT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
 
         for (u32 L = lcut; L >= threshold && !failed; --L) {
             const int iL = (int)L;
-            if (((lds_load(&s_lvlmask) >> L) & 1ull) == 0) { fl += iL - 1; fr -= iL - 1; continue; }   // nothing resides in list L
+            const int wrot = (wv + (int)L + (int)tile) & (NWV - 1); (void)wrot;
+            // ---- borders: an unknown factor of this level starts at an unknown position q whose working value is still >= L.  Working
+            //      values only ever decrease and the window holds an upper bound of them everywhere (only the effects of certain
+            //      factors were applied), so the borders move exactly as far as such a q exists: on the left it covers up to q + L - 1,
+            //      on the right it truncates down to q - (L - 1).  (Every wave evaluates this for itself: two LDS reads, two ballots.)
+            int dfl = fl, dfr = fr;
+            if (fl > -BIG / 2) {
+                const int q = fl - 1 - lane;
+                const u64 mq = __ballot(lane < iL - 1 && q >= 0 && (u32)cur8[PA(q >= 0 ? q : 0)] >= L);
+                if (mq) dfl = fl - 1 - __builtin_ctzll(mq) + iL;
+            }
+            if (fr < BIG / 2) {
+                const int q = fr + lane;
+                const u64 mq = __ballot(lane < iL - 1 && q < wl && (u32)cur8[PA(q < wl ? q : 0)] >= L);
+                if (mq) dfr = fr + __builtin_ctzll(mq) - (iL - 1);
+            }
+            if (((lds_load(&s_lvlmask) >> L) & 1ull) == 0) { fl = dfl; fr = dfr; continue; }   // nothing resides in list L
             const int lo = fl > 0 ? fl : 0, hi = fr < wl ? fr : wl;
-            // ---- 1. collect the alive entries of list L in position order --------------------------------------
+#ifdef TDC_WIN_DENSE_LOOP
             const int base = tid * TCH;
             u64 amask = 0;
             if (base < hi && base + TCH > lo) {
@@ -204,18 +233,42 @@ __global__ __launch_bounds__(TT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                     }
                 }
             }
+#else
+            // ---- 1. collect the alive entries of list L in position order --------------------------------------
+            // (branch-free per 8-position word: byte flags 0x80 for "resides in list L" and for "still alive", a shift cascade turns
+            //  the flags into bits of the thread's 64-position mask; erased entries (:86) leave the list by a masked word store.
+            //  Positions outside the known range are not collected; erasing a dead entry there is harmless -- the range only shrinks.)
+            const int base = tid * TCH;
+            u64 amask = 0;
+            if (base < hi && base + TCH > lo) {
+                const u64 pat = (u64)L * 0x0101010101010101ull;
+                const u64 lo7 = 0x7F7F7F7F7F7F7F7Full, hi1 = 0x8080808080808080ull;
+                const u64 addc = (u64)(128u - threshold) * 0x0101010101010101ull;     // (c & 0x7F) + addc has bit 7 set iff (c & 0x7F) >= threshold
+                u64 rws[TCH / 8], cws[TCH / 8];
+#pragma unroll
+                for (int k = 0; k < TCH / 8; ++k) { rws[k] = *(const u64*)&res8[PW(tid, k)]; cws[k] = *(const u64*)&cur8[PW(tid, k)]; }
+#pragma unroll
+                for (int k = 0; k < TCH / 8; ++k) {
+                    const u64 x = (rws[k] & lo7) ^ pat;
+                    const u64 hit = ~(((x & lo7) + lo7) | x | lo7);            // 0x80 in every byte of x that is zero (exact)
+                    const u64 alive = (((cws[k] & lo7) + addc) | cws[k]) & hi1;  // 0x80 where cur >= threshold
+                    u64 ha = (hit & alive) >> 7;                                // flag bits at 0, 8, .., 56 -> bits 0..7
+                    ha |= ha >> 7; ha |= ha >> 14; ha |= ha >> 28;
+                    amask |= (ha & 0xFFull) << (8 * k);
+                    const u64 he = (hit & ~alive) >> 7;                         // erased entries of this word
+                    if (he) *(u64*)&res8[PW(tid, k)] = rws[k] & ~((he << 8) - he);
+                }
+                const int rlo = lo - base, rhi = hi - base;                     // known range, relative to the thread's chunk
+                if (rlo > 0) amask &= ~((1ull << rlo) - 1ull);
+                if (rhi < TCH) amask &= (1ull << rhi) - 1ull;
+            }
+#endif
             // the first priorities are requested before the barrier of the scan, so their latency overlaps it
-            u32 pre[2] = { 0, 0 };
+            u32 pre0 = 0, pre1 = 0;
             {
                 u64 mm = amask;
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    if (mm) {
-                        const int pos = base + __builtin_ctzll(mm);
-                        mm &= mm - 1;
-                        pre[q] = prio_g[w0 + pos];          // (a window-local priority is read behind the full barrier below)
-                    }
-                }
+                if (mm) { pre0 = prio_g[w0 + base + __builtin_ctzll(mm)]; mm &= mm - 1; }   // (a window-local priority is read behind the full barrier below)
+                if (mm) { pre1 = prio_g[w0 + base + __builtin_ctzll(mm)]; }
             }
             WPROF(2);
             const u32 cnt = (u32)__popcll(amask);
@@ -237,7 +290,7 @@ __global__ __launch_bounds__(TT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                 const int pos = base + bit;
                 const u32 cv = cur8[PA(pos)];
                 const u32 local = res8[PA(pos)] & S_LOCAL;
-                const u32 pr = local ? lprio[pos] : ((q < 2) ? pre[q] : prio_g[w0 + pos]);
+                const u32 pr = local ? lprio[pos] : ((q == 0) ? pre0 : (q == 1) ? pre1 : prio_g[w0 + pos]);
                 const u32 st = (cv == L ? S_UND : S_STALE) | local;
                 ent[off] = ((u64)((cv << 24) | (st << 16) | (u32)pos) << 32) | pr;
                 if (cv == L) ++my_und;
@@ -248,7 +301,7 @@ __global__ __launch_bounds__(TT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
             lds_barrier();
             WPROF(3);
             WPROF_CNT(8, 1); WPROF_CNT(9, m);
-            if (m == 0) { fl += iL - 1; fr -= iL - 1; continue; }
+            if (m == 0) { fl = dfl; fr = dfr; continue; }
 
             // ---- 2. selection rounds (in place: a state only ever moves away from UNDECIDED) ---------------------
             // rotating counters: a round reads s_und[r], counts the entries it leaves undecided in s_und[r+1], clears s_und[r+2]
@@ -258,7 +311,7 @@ __global__ __launch_bounds__(TT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                 if (und == 0) break;
                 const int rn = (r + 1) % 3, rc = (r + 2) % 3;
                 if (tid == 0) s_und[rc] = 0;
-                for (int i = lane * NWV + wv; i < m; i += TT) {                  // entries are dealt round-robin to the waves
+                for (int i = WDEAL_FIRST; i < m; i += TT) {                   // a wave takes 64 consecutive entries: waves without entries skip the round
                     const u64 e = e_load(ent, i);
                     u64 fL = (i > 0) ? e_load(ent, i - 1) : 0ull;               // both direct neighbours are requested up front
                     u64 fR = (i + 1 < m) ? e_load(ent, i + 1) : 0ull;
@@ -282,7 +335,7 @@ __global__ __launch_bounds__(TT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                     const u32 keep = e_stbyte(e) & S_LOCAL;
                     if (hit) e_set_state(ent, i, S_REJ | keep);
                     else if (!blocked) {
-                        const bool exposed = (p <= fl + iL - 2) || (p + iL - 1 >= fr);
+                        const bool exposed = (p < dfl) || (p >= dfr);
                         e_set_state(ent, i, ((unc || exposed) ? S_UNC : S_SEL) | keep);
                     } else atomicAdd(&s_und[rn], 1);
                 }
@@ -295,8 +348,8 @@ __global__ __launch_bounds__(TT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
 
             // ---- 3. encounter values of the stale and the rejected entries, taint of the uncertain ones; the selected
             //         entries truncate the positions in front of them (their ranges are disjoint) and are written out ------
-            for (int i0 = 0; i0 < m; i0 += TT) {
-                const int i = i0 + lane * NWV + wv;
+            for (int i0 = WDEAL_I0; i0 < m; i0 += TT) {          // 64 consecutive entries per wave; a wave without entries has nothing to do
+                const int i = i0 + WDEAL_OFF;
                 const bool have = i < m;
                 const u64 e = have ? e_load(ent, i) : 0ull;
                 const u64 fL = (have && i > 0) ? e_load(ent, i - 1) : 0ull;
@@ -331,7 +384,7 @@ __global__ __launch_bounds__(TT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                 }
                 if (s != S_STALE && s != S_REJ) continue;
                 u32 v = e_val(e);
-                bool uncertain = (p <= fl + iL - 2) || (p + iL - 1 >= fr);
+                bool uncertain = (p < dfl) || (p >= dfr);
                 for (int j = i - 1; j >= 0; --j) {
                     const u64 f = (j == i - 1) ? fL : e_load(ent, j);
                     if (p - e_pos(f) >= iL) break;
@@ -365,8 +418,8 @@ __global__ __launch_bounds__(TT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
             if (npush > TP) { failed = true; break; }
             // ---- 4. kills; new residence / priority of the pushed entries, every other entry leaves the lists ------
             if (tid == 0) { s_und[0] = 0; s_und[1] = 0; s_und[2] = 0; }
-            for (int i0 = 0; i0 < m; i0 += TT) {
-                const int i = i0 + lane * NWV + wv;
+            for (int i0 = WDEAL_I0; i0 < m; i0 += TT) {
+                const int i = i0 + WDEAL_OFF;
                 const bool have = i < m;
                 const u64 e = have ? e_load(ent, i) : 0ull;
                 const u32 s = have ? e_state(e) : (u32)S_PUSH;
@@ -406,7 +459,7 @@ __global__ __launch_bounds__(TT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                 }
             }
             local_base += (u32)npush;
-            int nfl = fl + (iL - 1), nfr = fr - (iL - 1);
+            int nfl = dfl, nfr = dfr;
             const int tl = s_tl, tr = s_tr;
             if (tl > nfl) nfl = tl;
             if (tr < nfr) nfr = tr;
@@ -468,22 +521,32 @@ int factorize_window_levels(Ctx& c, size_t n, const u32* cur, const u32* prio, c
     if (lcut < threshold) return 0;
     hipStream_t s = c.stream;
     const size_t mark = c.arena.mark();
-    const u32 ntiles = cdiv(n, TI);
-    u32 grid = ntiles < 2048u ? ntiles : 2048u;
-    u32* lprio = c.arena.get<u32>((size_t)grid * TW);
+    // Attempts: (halo, list size).  The borders of the known range normally move a few hundred positions (they only move where an
+    // unknown factor can exist), so the first attempt uses a small halo; a window whose known range shrank into its interior makes
+    // the pass retry with the largest halo (the worst case of lcut = 63 needs 1 953 + the jumps), an overflowing per-level list
+    // makes it retry with the large lists.
+    u32 halo = (u32)c.window_halo & ~3u;
+    if (halo < 2 * lcut + 64) halo = (2 * lcut + 64 + 3) & ~3u;
+    if (halo > (u32)TH_MAX) halo = TH_MAX;
+    bool large = c.window_large_lists != 0;
+    const u32 max_grid = 2048u;
+    u32* lprio = c.arena.get<u32>((size_t)max_grid * TW);
     WinScalars* d_sc = (WinScalars*)c.arena.alloc(sizeof(WinScalars));
     WinScalars h;
     int result = 0;
-    for (int attempt = c.window_large_lists ? 1 : 0; attempt < 2; ++attempt) {
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        const size_t ti = (size_t)TW - 2 * (size_t)halo;
+        const u32 ntiles = cdiv(n, ti);
+        const u32 grid = ntiles < max_grid ? ntiles : max_grid;
         HIP_TRY(hipMemsetAsync(d_sc, 0, sizeof(WinScalars), s));
         { const int big = BIG; HIP_TRY(hipMemcpyAsync(&d_sc->min_margin, &big, sizeof(int), hipMemcpyHostToDevice, s)); }
         {
             // per window position: cur (4) + residence (1); per text position: ~0.3 priority reads and the factor output
-            Ctx::ProfScope prof(c, K_WINDOW_LEVELS, (u64)((double)n * TW / TI * 5) + (u64)n * 2);
-            if (attempt == 0)
-                window_levels_kernel<TE_SMALL, TP_SMALL, 4><<<grid, TT, 0, s>>>(cur, prio, res8, phi, n, lcut, threshold, ntiles, lprio, fs.flen, fs.fsrc, d_sc);
+            Ctx::ProfScope prof(c, K_WINDOW_LEVELS, (u64)((double)n * TW / ti * 5) + (u64)n * 2);
+            if (!large)
+                window_levels_kernel<TE_SMALL, TP_SMALL, 4><<<grid, TT, 0, s>>>(cur, prio, res8, phi, n, lcut, threshold, ntiles, halo, lprio, fs.flen, fs.fsrc, d_sc);
             else
-                window_levels_kernel<TE_LARGE, TP_LARGE, 1><<<grid, TT, 0, s>>>(cur, prio, res8, phi, n, lcut, threshold, ntiles, lprio, fs.flen, fs.fsrc, d_sc);
+                window_levels_kernel<TE_LARGE, TP_LARGE, 1><<<grid, TT, 0, s>>>(cur, prio, res8, phi, n, lcut, threshold, ntiles, halo, lprio, fs.flen, fs.fsrc, d_sc);
             LAUNCH_CHECK();
         }
         h = c.read(d_sc);
@@ -491,15 +554,19 @@ int factorize_window_levels(Ctx& c, size_t n, const u32* cur, const u32* prio, c
         {
             static const char* nm[12] = { "wait_prev", "load", "dense", "scan+write", "mis", "resolve", "apply", "tail", "levels", "entries", "rounds", "pushes" };
             for (int i = 0; i < 12; ++i) fprintf(stderr, "winprof %-10s %llu\n", nm[i], h.prof[i]);
-            fprintf(stderr, "winprof windows %u grid %u attempt %d min_margin %d fail %u max_entries %u max_pushes %u\n", ntiles, grid, attempt,
-                    h.min_margin, h.fail, h.max_entries, h.max_pushes);
+            fprintf(stderr, "winprof windows %u grid %u attempt %d halo %u min_margin %d fail %u max_entries %u max_pushes %u\n", ntiles, grid, attempt,
+                    halo, h.min_margin, h.fail, h.max_entries, h.max_pushes);
         }
 #endif
+        if (getenv("TDC_GPU_LEVEL_LOG")) fprintf(stderr, "window pass: attempt %d halo %u lists %s -> fail %u, smallest margin %d\n", attempt, halo, large ? "large" : "small", h.fail, h.min_margin);
         result = (int)h.fail;
         if (!h.fail) break;
         window_cleanup_kernel<<<cdiv(n, 256), 256, 0, s>>>(fs.flen, n, lcut);     // forget the factors of the failed pass
         LAUNCH_CHECK();
-        if (!(h.fail & 2u)) break;                                                  // larger lists do not move the borders
+        bool again = false;
+        if ((h.fail & 2u) && !large) { large = true; again = true; }
+        if ((h.fail & 1u) && halo < (u32)TH_MAX) { halo = TH_MAX; again = true; }
+        if (!again) break;
     }
     c.arena.release(mark);
     if (result == 0) *nfactors = h.factors;
