@@ -59,53 +59,137 @@ size_t extract_factors(Ctx& c, size_t n, FactorSpace fs, u32* pos, u32* src, u32
 }
 
 // ---- owner[] from the factor starts: owner[q] = index (in position order) of the factor covering q ------------------
-__global__ void owner_flag_kernel(const u32* __restrict__ flen, size_t n, u32* __restrict__ flag, u32* __restrict__ owner) {
-    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
-    flag[p] = flen[p] != 0 ? 1u : 0u;
-    owner[p] = NONE32;
+// Two streaming passes over flen[] (a factor starts at p iff flen[p] != 0; factors are disjoint):
+//   owner_count_kernel : number of starts per tile of 4096 positions            (reads 4 B per position)
+//   owner_build_kernel : the tile's starts get consecutive ranks (tile base + rank inside the tile), their positions go to pos[],
+//                        and every position of the tile gets the rank of the covering factor or NONE32 -- last start at or before
+//                        it by a max-scan, "covered" by comparing with that start's length (reads 4 B, writes 4 B per position);
+//                        a factor that extends beyond its tile is recorded and
+//   owner_cross_kernel : fills the part of such a factor that lies in the following tiles (they hold no start there).
+// (Before: flag array, scan, scatter of the starts and a fill pass -- 72 B of traffic per position.)
+constexpr int OW_T = 256, OW_PER = 16, OW_TILE = OW_T * OW_PER;
+__device__ __forceinline__ u32 ow_idx(u32 i) { return i + (i >> 4); }      // LDS slot of tile position i: a thread reads 16 consecutive positions
+
+__global__ __launch_bounds__(OW_T) void owner_count_kernel(const u32* __restrict__ flen, size_t n, u32* __restrict__ tilecnt) {
+    __shared__ u32 sm[OW_T / 64];
+    const size_t base = (size_t)blockIdx.x * OW_TILE;
+    u32 cnt = 0;
+#pragma unroll
+    for (int r = 0; r < OW_PER / 4; ++r) {
+        const size_t p = base + ((size_t)r * OW_T + threadIdx.x) * 4;
+        if (p + 4 <= n) {
+            const uint4 v = *(const uint4*)(flen + p);
+            cnt += (v.x != 0) + (v.y != 0) + (v.z != 0) + (v.w != 0);
+        } else {
+            for (int k = 0; k < 4; ++k) if (p + k < n && flen[p + k] != 0) ++cnt;
+        }
+    }
+    cnt = wave_reduce_sum(cnt);
+    if (lane_id() == 0) sm[wave_id()] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) { u32 t = 0; for (int i = 0; i < OW_T / 64; ++i) t += sm[i]; tilecnt[blockIdx.x] = t; }
 }
-__global__ void owner_starts_kernel(const u32* __restrict__ flen, const u32* __restrict__ offs, size_t n, u32* __restrict__ pos) {
-    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < n && flen[p] != 0) pos[offs[p]] = (u32)p;
+
+__global__ __launch_bounds__(OW_T) void owner_build_kernel(const u32* __restrict__ flen, size_t n, const u32* __restrict__ tilebase,
+                                                           u32* __restrict__ pos, u32* __restrict__ owner, uint2* __restrict__ cross) {
+    __shared__ u32 s[OW_TILE + OW_TILE / 16 + 16];
+    __shared__ u32 sm[OW_T / 64 + 1], smx[OW_T / 64];
+    const size_t base = (size_t)blockIdx.x * OW_TILE;
+    const int lane = lane_id(), w = wave_id();
+#pragma unroll
+    for (int r = 0; r < OW_PER / 4; ++r) {                      // coalesced loads into LDS
+        const u32 i = ((u32)r * OW_T + threadIdx.x) * 4;
+        const size_t p = base + i;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (p + 4 <= n) v = *(const uint4*)(flen + p);
+        else {
+            if (p < n) v.x = flen[p];
+            if (p + 1 < n) v.y = flen[p + 1];
+            if (p + 2 < n) v.z = flen[p + 2];
+        }
+        const u32 q = ow_idx(i);                                // i is a multiple of 4: the four slots are consecutive
+        s[q] = v.x; s[q + 1] = v.y; s[q + 2] = v.z; s[q + 3] = v.w;
+    }
+    __syncthreads();
+    const u32 l0 = threadIdx.x * OW_PER;
+    u32 f[OW_PER];
+    u32 cnt = 0, mylast = 0;                                    // mylast: 1 + tile position of the thread's last start (0: none)
+#pragma unroll
+    for (int k = 0; k < OW_PER; ++k) {
+        f[k] = s[ow_idx(l0 + k)];
+        if (f[k] != 0) { ++cnt; mylast = l0 + k + 1; }
+    }
+    u32 total;
+    const u32 excl = block_exclusive_sum<u32, OW_T / 64>(cnt, sm, total);
+    // last start in the earlier threads of the tile (exclusive max-scan)
+    const u32 inc = wave_inclusive_max(mylast);
+    if (lane == 63) smx[w] = inc;
+    __syncthreads();
+    u32 cur_start = __shfl_up(inc, 1, 64);
+    if (lane == 0) cur_start = 0;
+    for (int i = 0; i < w; ++i) cur_start = max(cur_start, smx[i]);
+    u32 rank = tilebase[blockIdx.x] + excl;                     // rank of the thread's next start
+    u32 cur_rank = rank - 1;                                    // rank of the start at cur_start (if any)
+    u32 cur_len = cur_start ? s[ow_idx(cur_start - 1)] : 0u;
+    u32 out[OW_PER];
+#pragma unroll
+    for (int k = 0; k < OW_PER; ++k) {
+        const u32 pl = l0 + k;
+        if (f[k] != 0) {
+            cur_start = pl + 1; cur_len = f[k]; cur_rank = rank++;
+            if (base + pl < n) pos[cur_rank] = (u32)(base + pl);
+        }
+        out[k] = (cur_start != 0 && pl - (cur_start - 1) < cur_len) ? cur_rank : NONE32;
+    }
+    if (threadIdx.x == OW_T - 1) {                              // the tile's last factor may extend into the following tiles
+        const u32 end = cur_start ? cur_start - 1 + cur_len : 0u;          // (lengths are < 2^31)
+        cross[blockIdx.x] = (end > (u32)OW_TILE) ? make_uint2(cur_rank, end - (u32)OW_TILE) : make_uint2(NONE32, 0u);
+    }
+    __syncthreads();                                            // every thread has read what it needs from the tile
+#pragma unroll
+    for (int k = 0; k < OW_PER; ++k) s[ow_idx(l0 + k)] = out[k];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < OW_PER / 4; ++r) {                      // coalesced stores
+        const u32 i = ((u32)r * OW_T + threadIdx.x) * 4;
+        const size_t p = base + i;
+        const u32 q = ow_idx(i);
+        if (p + 4 <= n) *(uint4*)(owner + p) = make_uint4(s[q], s[q + 1], s[q + 2], s[q + 3]);
+        else for (int k = 0; k < 4; ++k) if (p + k < n) owner[p + k] = s[q + k];
+    }
 }
-template <int G>      // G lanes per factor
-__global__ void owner_fill_kernel(const u32* __restrict__ pos, size_t z, const u32* __restrict__ flen, size_t n, u32* __restrict__ owner) {
-    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
-    const u32 sub = threadIdx.x % G;
-    if (i >= z) return;
-    const u32 p = pos[i], l = flen[p];
-    for (u32 j = sub; j < l && (size_t)p + j < n; j += G) owner[p + j] = (u32)i;
+
+__global__ __launch_bounds__(256) void owner_cross_kernel(const uint2* __restrict__ cross, size_t n, u32* __restrict__ owner) {
+    const uint2 cr = cross[blockIdx.x];
+    if (cr.y == 0) return;
+    const size_t start = ((size_t)blockIdx.x + 1) * OW_TILE;
+    for (size_t j = threadIdx.x; j < cr.y && start + j < n; j += 256) owner[start + j] = cr.x;
 }
 
 void build_owner(Ctx& c, size_t n, FactorSpace& fs) {
     fs.have_list = false;
     if (n == 0) return;
     const size_t mark = c.arena.mark();
-    u32* offs = c.arena.get<u32>(n);
+    const u32 tiles = cdiv(n, OW_TILE);
+    u32* tilecnt = c.arena.get<u32>(tiles);
+    uint2* cross = (uint2*)c.arena.alloc((size_t)tiles * sizeof(uint2));
     u32* pos = fs.fpos ? fs.fpos : c.arena.get<u32>(n);
     u32* d_total = c.arena.get<u32>(1);
-    const unsigned gn = cdiv(n, 256);
     {
-        Ctx::ProfScope prof(c, K_EXTRACT, (u64)n * 12);
-        owner_flag_kernel<<<gn, 256, 0, c.stream>>>(fs.flen, n, offs, fs.owner);
+        Ctx::ProfScope prof(c, K_EXTRACT, (u64)n * 4);
+        owner_count_kernel<<<tiles, OW_T, 0, c.stream>>>(fs.flen, n, tilecnt);
         LAUNCH_CHECK();
     }
-    exclusive_sum_u32(c, offs, offs, n, d_total);
+    exclusive_sum_u32(c, tilecnt, tilecnt, tiles, d_total);
     {
         Ctx::ProfScope prof(c, K_EXTRACT, (u64)n * 8);
-        owner_starts_kernel<<<gn, 256, 0, c.stream>>>(fs.flen, offs, n, pos);
+        owner_build_kernel<<<tiles, OW_T, 0, c.stream>>>(fs.flen, n, tilecnt, pos, fs.owner, cross);
+        LAUNCH_CHECK();
+        owner_cross_kernel<<<tiles, 256, 0, c.stream>>>(cross, n, fs.owner);
         LAUNCH_CHECK();
     }
     const size_t z = c.read(d_total);
     if (fs.fpos) { fs.nfact = z; fs.have_list = true; }
-    if (z) {
-        Ctx::ProfScope prof(c, K_EXTRACT, (u64)n * 4 + (u64)z * 8);
-        // factors are disjoint and in position order: consecutive lanes fill consecutive ranges
-        if (z * 64 > n) owner_fill_kernel<8><<<cdiv(z * 8, 256), 256, 0, c.stream>>>(pos, z, fs.flen, n, fs.owner);
-        else            owner_fill_kernel<64><<<cdiv(z * 64, 256), 256, 0, c.stream>>>(pos, z, fs.flen, n, fs.owner);
-        LAUNCH_CHECK();
-    }
     c.arena.release(mark);
 }
 
