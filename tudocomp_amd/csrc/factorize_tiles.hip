@@ -61,16 +61,11 @@ __device__ __forceinline__ int PA(int q) {
 // byte offset of the k-th 8-byte word (k = 0..7) of thread t's chunk
 __device__ __forceinline__ int PW(int t, int k) { return (t << 6) + (((2 * k + 2 * (t >> 2)) & 15) << 2); }
 constexpr int BIG = 1 << 29;
-#ifdef TDC_WIN_DEAL_RR           // entries dealt round-robin to the waves
+// Entries are dealt round-robin to the four waves (entry i -> wave i mod 4): the phases of a level are latency chains, and a wave
+// that takes 64 consecutive entries (so that waves without entries could skip a phase) was measured 10 % slower.
 #define WDEAL_FIRST (lane * NWV + wv)
 #define WDEAL_I0 0
 #define WDEAL_OFF (lane * NWV + wv)
-#else                            // a wave takes 64 consecutive entries; which wave takes the first block rotates with the level and the
-                                 // window (wave w of every workgroup sits on SIMD w: a fixed order would load one SIMD of the CU only)
-#define WDEAL_FIRST (wrot * 64 + lane)
-#define WDEAL_I0 (wrot * 64)
-#define WDEAL_OFF lane
-#endif
 
 // An entry of the current level, packed so that a neighbour costs ONE LDS read:
 //   [31:0] priority   [47:32] window position   [55:48] state (bit 7: priority is window-local)   [63:56] LCP value
@@ -192,7 +187,6 @@ __global__ __launch_bounds__(TT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
 
         for (u32 L = lcut; L >= threshold && !failed; --L) {
             const int iL = (int)L;
-            const int wrot = (wv + (int)L + (int)tile) & (NWV - 1); (void)wrot;
             // ---- borders: an unknown factor of this level starts at an unknown position q whose working value is still >= L.  Working
             //      values only ever decrease and the window holds an upper bound of them everywhere (only the effects of certain
             //      factors were applied), so the borders move exactly as far as such a q exists: on the left it covers up to q + L - 1,
@@ -267,8 +261,13 @@ __global__ __launch_bounds__(TT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
             u32 pre0 = 0, pre1 = 0;
             {
                 u64 mm = amask;
+#ifdef TDC_WIN_FAKE_PRIO       // timing experiment only (wrong results): no global priority loads at all
+                if (mm) { pre0 = (u32)(w0 + base + __builtin_ctzll(mm)) * 2654435761u; mm &= mm - 1; }
+                if (mm) { pre1 = (u32)(w0 + base + __builtin_ctzll(mm)) * 2654435761u; }
+#else
                 if (mm) { pre0 = prio_g[w0 + base + __builtin_ctzll(mm)]; mm &= mm - 1; }   // (a window-local priority is read behind the full barrier below)
                 if (mm) { pre1 = prio_g[w0 + base + __builtin_ctzll(mm)]; }
+#endif
             }
             WPROF(2);
             const u32 cnt = (u32)__popcll(amask);
@@ -290,7 +289,11 @@ __global__ __launch_bounds__(TT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                 const int pos = base + bit;
                 const u32 cv = cur8[PA(pos)];
                 const u32 local = res8[PA(pos)] & S_LOCAL;
+#ifdef TDC_WIN_FAKE_PRIO
+                const u32 pr = local ? lprio[pos] : ((q == 0) ? pre0 : (q == 1) ? pre1 : (u32)(w0 + pos) * 2654435761u);
+#else
                 const u32 pr = local ? lprio[pos] : ((q == 0) ? pre0 : (q == 1) ? pre1 : prio_g[w0 + pos]);
+#endif
                 const u32 st = (cv == L ? S_UND : S_STALE) | local;
                 ent[off] = ((u64)((cv << 24) | (st << 16) | (u32)pos) << 32) | pr;
                 if (cv == L) ++my_und;
@@ -311,7 +314,7 @@ __global__ __launch_bounds__(TT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                 if (und == 0) break;
                 const int rn = (r + 1) % 3, rc = (r + 2) % 3;
                 if (tid == 0) s_und[rc] = 0;
-                for (int i = WDEAL_FIRST; i < m; i += TT) {                   // a wave takes 64 consecutive entries: waves without entries skip the round
+                for (int i = WDEAL_FIRST; i < m; i += TT) {
                     const u64 e = e_load(ent, i);
                     u64 fL = (i > 0) ? e_load(ent, i - 1) : 0ull;               // both direct neighbours are requested up front
                     u64 fR = (i + 1 < m) ? e_load(ent, i + 1) : 0ull;
@@ -348,7 +351,7 @@ __global__ __launch_bounds__(TT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
 
             // ---- 3. encounter values of the stale and the rejected entries, taint of the uncertain ones; the selected
             //         entries truncate the positions in front of them (their ranges are disjoint) and are written out ------
-            for (int i0 = WDEAL_I0; i0 < m; i0 += TT) {          // 64 consecutive entries per wave; a wave without entries has nothing to do
+            for (int i0 = WDEAL_I0; i0 < m; i0 += TT) {
                 const int i = i0 + WDEAL_OFF;
                 const bool have = i < m;
                 const u64 e = have ? e_load(ent, i) : 0ull;
