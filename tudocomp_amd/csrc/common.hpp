@@ -257,8 +257,20 @@ __device__ __forceinline__ u32 xcd_tile(u32 bid, u32 per_xcd) { return per_xcd ?
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 
 // Inclusive scan across the 64 lanes of a wave.
+// 32-bit values: DPP row shifts inside the four rows of 16 lanes (Hillis-Steele), then the last lane of row 0 / 2 is broadcast into
+// row 1 / 3 and lane 31 into the upper half -- six VALU instructions instead of six ds_bpermute round trips through the LDS crossbar.
+__device__ __forceinline__ u32 wave_inclusive_sum_u32(u32 v) {
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);    // row_shr:1
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);    // row_shr:2
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);    // row_shr:4
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);    // row_shr:8
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);    // row_bcast:15 into rows 1 and 3
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);    // row_bcast:31 into rows 2 and 3
+    return v;
+}
 template <typename T>
 __device__ __forceinline__ T wave_inclusive_sum(T v) {
+    if constexpr (sizeof(T) == 4) return (T)wave_inclusive_sum_u32((u32)v);
     const int lane = lane_id();
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -267,31 +279,25 @@ __device__ __forceinline__ T wave_inclusive_sum(T v) {
     }
     return v;
 }
-__device__ __forceinline__ u32 wave_inclusive_max(u32 v) {
-    const int lane = lane_id();
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        u32 o = __shfl_up(v, d, 64);
-        if (lane >= d) v = max(v, o);
-    }
+__device__ __forceinline__ u32 wave_inclusive_max(u32 v) {          // (0 is the identity: lanes without a source read 0)
+    v = max(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false));
+    v = max(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false));
+    v = max(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false));
+    v = max(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false));
+    v = max(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false));
+    v = max(v, (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false));
     return v;
 }
+// Reductions: the inclusive scan's last lane, read back through a scalar register (every lane gets the result).
 template <typename T>
 __device__ __forceinline__ T wave_reduce_sum(T v) {
+    if constexpr (sizeof(T) == 4) return (T)__builtin_amdgcn_readlane((int)wave_inclusive_sum_u32((u32)v), 63);
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
     return v;
 }
-__device__ __forceinline__ u32 wave_reduce_max(u32 v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d, 64));
-    return v;
-}
-__device__ __forceinline__ u32 wave_reduce_min(u32 v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v = min(v, __shfl_xor(v, d, 64));
-    return v;
-}
+__device__ __forceinline__ u32 wave_reduce_max(u32 v) { return (u32)__builtin_amdgcn_readlane((int)wave_inclusive_max(v), 63); }
+__device__ __forceinline__ u32 wave_reduce_min(u32 v) { return ~wave_reduce_max(~v); }
 
 // LDS accesses that must really happen (counters and tables shared between the lanes of a wave, re-read after another lane
 // wrote them).  A `volatile` access through an ordinary pointer is compiled to a FLAT instruction with system-coherence bits

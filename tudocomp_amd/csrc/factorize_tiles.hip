@@ -371,7 +371,7 @@ __global__ __launch_bounds__(TT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                         if (selm) {
                             const int src = __builtin_ctzll(selm);
                             selm &= selm - 1;
-                            const int q = __shfl(p, src, 64) - 1 - lane;
+                            const int q = __builtin_amdgcn_readlane(p, src) - 1 - lane;
                             if (lane < iL && q >= 0) qs[b4] = PA(q);
                         }
                     }
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(TT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                 while (selm) {                              // kills (:99-101), one lane per covered position
                     const int src = __builtin_ctzll(selm);
                     selm &= selm - 1;
-                    const int q = __shfl(p, src, 64) + lane;
+                    const int q = __builtin_amdgcn_readlane(p, src) + lane;
                     if (lane < iL && q < wl) cur8[PA(q)] = 0;
                 }
                 if (s != S_PUSH) res8[PA(p)] = (s == S_SEL) ? (u8)(0x40u | L) : (u8)0;
