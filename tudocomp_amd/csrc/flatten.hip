@@ -230,72 +230,108 @@ struct FlattenScalars { u32 waiting; u32 num_flattened; u32 max_depth; u32 pad; 
 // (one scattered line per step besides owner[src]; separate arrays for (pos, len), the original and the final source cost a line
 // each.  Finding the covering factor through a table of the first factor per 64-position block plus a scan of consecutive
 // records -- no owner[] line at all -- was built and measured slower: 6.6 vs 5.7 ms, the scan is a chain of dependent loads.)
+// A factor that has to wait for the next round travels as a 16-byte work item { rank, len, current source, depth }: the
+// rounds read and write their work lists sequentially (appended per wave, in any order -- the result of a factor does not
+// depend on the order in which the waiting ones are visited), nothing about a waiting factor is gathered again.
 __global__ void flatten_init_kernel(const u32* __restrict__ fpos, size_t z, const u32* __restrict__ flen, const u32* __restrict__ orig,
-                                    uint4* __restrict__ rec, u32* __restrict__ cursrc, u32* __restrict__ depth) {
+                                    uint4* __restrict__ rec) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= z) return;
     const u32 p = fpos[i];
-    const u32 o = orig[p];
-    rec[i] = make_uint4(p, flen[p], o, NOT_DONE);
-    cursrc[i] = o;
-    depth[i] = 0;
+    rec[i] = make_uint4(p, flen[p], orig[p], NOT_DONE);
 }
 
-// One round over the still-waiting factors (work[] holds their ranks; wcls[j] = 1 if still waiting).
-__global__ __launch_bounds__(256) void flatten_round_kernel(const u32* __restrict__ work, u32 nwork, size_t n, const u32* __restrict__ owner,
-                                                             uint4* rec, u32* __restrict__ cursrc, u32* __restrict__ depth, u8* __restrict__ wcls,
-                                                             FlattenScalars* __restrict__ sc, u32 max_steps) {
-    const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
-    bool counted = false;
-    u32 dep = 0;
-    if (j < nwork) {
-        const u32 i = work ? work[j] : j;
-        const uint4 me = rec[i];
-        const u32 len = me.y;
-        u32 src = cursrc[i];
-        dep = depth[i];
-        bool finished = false;
-        for (u32 step = 0; step < max_steps; ++step) {      // a long chain continues in the next round, regrouped with its peers
-            if ((size_t)src >= n || dep >= n) { finished = true; break; }   // :106 src < fmap.size()  (dep bound: no endless chains)
-            const u32 r = owner[src];
-            if (r == NONE32) { finished = true; break; }                    // :106 fmap[src] == 0
-            const uint4 sr = rec[r];
-            const u32 d = src - sr.x;
-            if ((u64)d + len > sr.y) { finished = true; break; }            // :110 copy does not fit inside s
-            u32 ssrc;
-            if (r < i) {                                                    // earlier factor: needs its final source
-                ssrc = sr.w;
-                if (ssrc == NOT_DONE) break;                                // wait for the next round
-            } else {
-                ssrc = sr.z;                                                // later factor: still unflattened at this point
-            }
-            src = ssrc + d;                                                 // :111
-            ++dep;
-        }
-        cursrc[i] = src;
-        depth[i] = dep;
-        wcls[j] = finished ? 0 : 1;
-        if (finished) {
-            ((u32*)&rec[i])[3] = dep ? src : me.z;                          // :122-124
-            counted = dep != 0;
+// One round over the still-waiting factors.  FIRST: every factor, state taken from its record; else the items of `work`.
+// A thread walks FL_K chains side by side: per step first the owner[] words of all of them, then the records -- FL_K independent
+// scattered loads in flight per thread instead of one.  The factors of a workgroup that have to wait are appended to the next
+// list with ONE atomic per workgroup (per wave it would be millions of atomics on one address: ~25 ns each, serialised).
+#ifndef TDC_FL_K
+#define TDC_FL_K 4
+#endif
+constexpr int FL_K = TDC_FL_K;
+template <bool FIRST>
+__global__ __launch_bounds__(256) void flatten_round_kernel(const uint4* __restrict__ work, u32 nwork, size_t n, const u32* __restrict__ owner,
+                                                             uint4* rec, uint4* __restrict__ next, FlattenScalars* __restrict__ sc, u32 max_steps) {
+    __shared__ u32 sm[5];
+    __shared__ u32 s_base;
+    const u32 base = blockIdx.x * (256u * FL_K);
+    u32 fi[FL_K], len[FL_K], src[FL_K], dep[FL_K];
+    u32 act = 0, fin = 0, valid = 0;             // bit r: chain r is still walking / finished / exists
+#pragma unroll
+    for (int r = 0; r < FL_K; ++r) {
+        const u32 j = base + (u32)r * 256u + threadIdx.x;
+        fi[r] = 0; len[r] = 0; src[r] = 0; dep[r] = 0;
+        if (j < nwork) {
+            if (FIRST) { const uint4 me = rec[j]; fi[r] = j; len[r] = me.y; src[r] = me.z; }
+            else { const uint4 it = work[j]; fi[r] = it.x; len[r] = it.y; src[r] = it.z; dep[r] = it.w; }
+            valid |= 1u << r;
         }
     }
+    act = valid;
+    for (u32 step = 0; step < max_steps && __any(act != 0); ++step) {   // a long chain continues in the next round, regrouped with its peers
+        u32 rr[FL_K];
+#pragma unroll
+        for (int r = 0; r < FL_K; ++r) {
+            rr[r] = NONE32;
+            if (act & (1u << r)) {
+                if ((size_t)src[r] >= n || dep[r] >= n) { act &= ~(1u << r); fin |= 1u << r; }   // :106 src < fmap.size()  (dep bound: no endless chains)
+                else rr[r] = owner[src[r]];
+            }
+        }
+        uint4 sr[FL_K];
+#pragma unroll
+        for (int r = 0; r < FL_K; ++r) {
+            sr[r] = make_uint4(0, 0, 0, 0);
+            if (act & (1u << r)) {
+                if (rr[r] == NONE32) { act &= ~(1u << r); fin |= 1u << r; }                       // :106 fmap[src] == 0
+                else sr[r] = rec[rr[r]];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < FL_K; ++r) {
+            if (!(act & (1u << r))) continue;
+            const u32 d = src[r] - sr[r].x;
+            if ((u64)d + len[r] > sr[r].y) { act &= ~(1u << r); fin |= 1u << r; continue; }      // :110 copy does not fit inside s
+            u32 ssrc;
+            if (rr[r] < fi[r]) {                                            // earlier factor: needs its final source
+                ssrc = sr[r].w;
+                if (ssrc == NOT_DONE) { act &= ~(1u << r); continue; }      // wait for the next round
+            } else {
+                ssrc = sr[r].z;                                             // later factor: still unflattened at this point
+            }
+            src[r] = ssrc + d;                                              // :111
+            ++dep[r];
+        }
+    }
+    u32 nflat = 0, mxdep = 0;
+#pragma unroll
+    for (int r = 0; r < FL_K; ++r) {
+        if (fin & (1u << r)) {
+            ((u32*)&rec[fi[r]])[3] = src[r];                                // :122-124 (dep == 0: src is still the original source)
+            if (dep[r]) { ++nflat; mxdep = max(mxdep, dep[r]); }
+        }
+    }
+    // the waiting factors of the workgroup go to the next list
+    const u32 wmask = valid & ~fin;
+    u32 total;
+    u32 off = block_exclusive_sum<u32, 4>((u32)__popc(wmask), sm, total);
+    if (threadIdx.x == 0) s_base = total ? atomicAdd(&sc->waiting, total) : 0u;
+    __syncthreads();
+    off += s_base;
+#pragma unroll
+    for (int r = 0; r < FL_K; ++r)
+        if (wmask & (1u << r)) next[off++] = make_uint4(fi[r], len[r], src[r], dep[r]);
     // statistics: one atomic pair per wave
-    const u64 b = __ballot(counted);
-    const u32 mx = wave_reduce_max(counted ? dep : 0u);
-    if (lane_id() == 0 && b) { atomicAdd(&sc->num_flattened, (u32)__popcll(b)); atomicMax(&sc->max_depth, mx); }
-}
-
-__global__ void flatten_iota_kernel(u32* __restrict__ a, u32 m) {
-    const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < m) a[j] = j;
+    nflat = wave_reduce_sum(nflat);
+    mxdep = wave_reduce_max(mxdep);
+    if (lane_id() == 0 && nflat) { atomicAdd(&sc->num_flattened, nflat); atomicMax(&sc->max_depth, mxdep); }
 }
 
 __global__ void flatten_commit_kernel(size_t z, const uint4* __restrict__ rec, u32* __restrict__ fsrc) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= z) return;
     const uint4 q = rec[i];
-    fsrc[q.x] = q.w;
+    if (q.w != q.z) fsrc[q.x] = q.w;              // only the flattened ones moved
 }
 
 void flatten_factors(Ctx& c, size_t n, FactorSpace fs, FlattenStats* st) {
@@ -309,23 +345,17 @@ void flatten_factors(Ctx& c, size_t n, FactorSpace fs, FlattenStats* st) {
     const size_t z = fs.have_list ? fs.nfact : extract_factors(c, n, fs, fpos, nullptr, nullptr, n);
     if (z == 0) { c.arena.release(mark); return; }
     uint4* rec = (uint4*)c.arena.alloc(z * sizeof(uint4));
-    u32* cursrc = c.arena.get<u32>(z);
-    u32* depth = c.arena.get<u32>(z);
     FlattenScalars* d_sc = (FlattenScalars*)c.arena.alloc(sizeof(FlattenScalars));
     HIP_TRY(hipMemsetAsync(d_sc, 0, sizeof(FlattenScalars), s));
     const unsigned gz = cdiv(z, 256);
-    flatten_init_kernel<<<gz, 256, 0, s>>>(fpos, z, fs.flen, fs.fsrc, rec, cursrc, depth);
+    flatten_init_kernel<<<gz, 256, 0, s>>>(fpos, z, fs.flen, fs.fsrc, rec);
     LAUNCH_CHECK();
-    // work lists of the still-waiting factors, compacted after every round
-    u32* work[2] = { c.arena.get<u32>(z), c.arena.get<u32>(z) };
-    u8* wcls = c.arena.get<u8>(z);
-    u32* ident = c.arena.get<u32>(z);
-    flatten_iota_kernel<<<gz, 256, 0, s>>>(ident, (u32)z);
-    LAUNCH_CHECK();
+    // work lists of the still-waiting factors (the first round visits every factor)
+    uint4* work[2] = { (uint4*)c.arena.alloc(z * sizeof(uint4)), nullptr };
     u32 waiting = (u32)z;
-    int cur_w = -1;                               // -1: the identity list (first round)
+    int cur_w = -1;                               // -1: every factor (first round)
     // steps per round: few in the first rounds (most chains are short; the lanes of a wave wait for the longest one),
-    // doubling afterwards
+    // growing afterwards
     u32 max_steps = getenv("TDC_GPU_FLATTEN_STEPS") ? (u32)atoi(getenv("TDC_GPU_FLATTEN_STEPS")) : 1u;   // measured: 1,2,4,.. 8.5 ms; unlimited 11.2 ms
     if (max_steps == 0) max_steps = 1u << 30;
     // budget growth per round (measured at 256 MiB: x2 8.4 ms, x4 7.4 ms, x8 7.0 ms)
@@ -333,14 +363,15 @@ void flatten_factors(Ctx& c, size_t n, FactorSpace fs, FlattenStats* st) {
     if (flat_growth < 2) flat_growth = 2;
     u32 stalled = 0;
     while (waiting) {
-        {   // per waiting factor: record, cursrc, depth (24) + one chain step (block word + record: 20) + outputs (13)
-            Ctx::ProfScope prof(c, K_FLATTEN_ROUND, (u64)waiting * 57);
-            flatten_round_kernel<<<cdiv(waiting, 256), 256, 0, s>>>(cur_w < 0 ? nullptr : work[cur_w], waiting, n, fs.owner, rec,
-                                                                    cursrc, depth, wcls, d_sc, max_steps);
+        const int nxt = cur_w < 0 ? 0 : (cur_w ^ 1);
+        if (!work[nxt]) work[nxt] = (uint4*)c.arena.alloc((size_t)waiting * sizeof(uint4));   // (the second list: at most the survivors of round 1)
+        HIP_TRY(hipMemsetAsync(&d_sc->waiting, 0, sizeof(u32), s));
+        {   // per waiting factor: its item (16) + one chain step (owner word + record: 20) + item / final source out (16)
+            Ctx::ProfScope prof(c, K_FLATTEN_ROUND, (u64)waiting * 52);
+            if (cur_w < 0) flatten_round_kernel<true><<<cdiv(waiting, 256 * FL_K), 256, 0, s>>>(nullptr, waiting, n, fs.owner, rec, work[nxt], d_sc, max_steps);
+            else flatten_round_kernel<false><<<cdiv(waiting, 256 * FL_K), 256, 0, s>>>(work[cur_w], waiting, n, fs.owner, rec, work[nxt], d_sc, max_steps);
             LAUNCH_CHECK();
         }
-        const int nxt = cur_w < 0 ? 0 : (cur_w ^ 1);
-        select_by_class(c, wcls, 1, waiting, cur_w < 0 ? ident : work[cur_w], work[nxt], nullptr, nullptr, &d_sc->waiting);
         const u32 now = c.read(&d_sc->waiting);
         st->rounds++;
         if (getenv("TDC_GPU_LEVEL_LOG")) fprintf(stderr, "flatten round %u: %u waiting -> %u\n", st->rounds, waiting, now);
