@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void plcp_kernel(const u8* __restrict__ text, 
                                                     u32* __restrict__ plcp, u32* __restrict__ d_max, const u32* __restrict__ samples,
                                                     const u8* __restrict__ iflag) {
     __shared__ u32 sphi[256 * (PLCP_CHUNK + 1)];
-    __shared__ u8 stext[PLCP_TILE + PLCP_HALO];
+    __shared__ __attribute__((aligned(8))) u8 stext[PLCP_TILE + PLCP_HALO + 8];    // (+8: the funnel shift reads the next aligned word)
     const size_t base = (size_t)blockIdx.x * PLCP_TILE;
     for (int k = threadIdx.x; k < PLCP_TILE; k += 256) {
         const size_t p = base + k;
@@ -167,11 +167,12 @@ __global__ __launch_bounds__(256) void plcp_kernel(const u8* __restrict__ text, 
             const u32 sb = samples[b / PLCP_SAMPLE], d = (u32)(begin - b);
             l = sb > d ? sb - d : 0u;                         // len[i] >= len[b] - (i - b)
         }
-        // the source side is read through ONE cached aligned 8-byte word: when Phi[i+1] = Phi[i] + 1 (the common case) the
-        // comparison of position i+1 resumes at the very address where that of position i stopped, so the word is
-        // reused instead of fetching the line again (with ~1800 threads per CU neither L1 nor L2 keeps it)
-        uintptr_t w_addr = ~(uintptr_t)0;                   // (absolute address: an aligned word never crosses a page, so reading the
-        u64 w_val = 0;                                      //  few bytes around the text's ends that share a word with it is safe)
+        // Eight bytes per step: the T[i+l] side from the staged text (two aligned LDS words, funnel-shifted), the T[Phi[i]+l] side
+        // as one unaligned 8-byte word that stays in registers -- when Phi[i+1] = Phi[i] + 1 (the common case) the comparison of
+        // position i+1 resumes at the very byte where that of position i stopped, i.e. inside the word already held (with ~1800
+        // threads per CU neither L1 nor L2 would still have the line).
+        uintptr_t w_addr = ~(uintptr_t)0xFF;                // address of the byte in bits 7..0 of w_val
+        u64 w_val = 0;
         for (int c = 0; c < PLCP_CHUNK; ++c) {
             const size_t i = begin + c;
             if (i >= n) break;
@@ -184,13 +185,26 @@ __global__ __launch_bounds__(256) void plcp_kernel(const u8* __restrict__ text, 
             for (;;) {
                 if (i + l >= n || j + l >= n) break;
                 const u32 off = li + l;
-                const u8 a = (off < PLCP_TILE + PLCP_HALO) ? stext[off] : text[i + l];
-                const uintptr_t pa = (uintptr_t)(text + j + l);
-                const uintptr_t wa = pa & ~(uintptr_t)7;
-                if (wa != w_addr) { w_addr = wa; w_val = *(const u64*)wa; }
-                const u8 b = (u8)(w_val >> (8 * (pa & 7)));
-                if (a != b) break;
-                ++l;
+                const size_t ri = n - (i + l), rj = n - (j + l);
+                if (ri >= 8 && rj >= 8 && off + 8 <= (u32)(PLCP_TILE + PLCP_HALO)) {
+                    const u32 ao = off & ~7u, as = (off & 7u) * 8u;
+                    const u64 alo = *(const u64*)(stext + ao), ahi = *(const u64*)(stext + ao + 8);
+                    const u64 a = as ? ((alo >> as) | (ahi << (64u - as))) : alo;
+                    const uintptr_t pa = (uintptr_t)(text + j + l);
+                    const uintptr_t sh = pa - w_addr;
+                    u64 b;
+                    u32 valid = 8;
+                    if (sh < 8) { b = w_val >> (8 * sh); valid = 8u - (u32)sh; }       // the tail of the word already held
+                    else { __builtin_memcpy(&w_val, (const void*)pa, 8); w_addr = pa; b = w_val; }
+                    u64 x = a ^ b;
+                    if (valid < 8) x &= (1ull << (8 * valid)) - 1ull;
+                    if (x) { l += (u32)__builtin_ctzll(x) >> 3; break; }
+                    l += valid;
+                } else {                                    // the last bytes of the text, or beyond the staged halo
+                    const u8 a1 = (off < (u32)(PLCP_TILE + PLCP_HALO)) ? stext[off] : text[i + l];
+                    if (a1 != text[j + l]) break;
+                    ++l;
+                }
             }
             row[c] = l;
             mx = max(mx, l);
