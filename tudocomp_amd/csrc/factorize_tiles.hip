@@ -39,16 +39,28 @@ namespace tdc {
 
 namespace {
 
-constexpr int TW = 16384;            // window positions
+#ifndef TDC_WIN_TW
+#define TDC_WIN_TW 16384
+#endif
+#ifndef TDC_WIN_WPE
+#define TDC_WIN_WPE 4
+#endif
+#ifndef TDC_WIN_TE
+#define TDC_WIN_TE 512
+#endif
+#ifndef TDC_WIN_TP
+#define TDC_WIN_TP 384
+#endif
+constexpr int TW = TDC_WIN_TW;       // window positions (a multiple of 64)
 constexpr int TH_MAX = 2048;         // halo on either side: a run-time value (multiple of 4), at most this
 constexpr int TT = 256;              // threads per workgroup
-constexpr int TCH = TW / TT;         // consecutive window positions per thread in the dense passes (64)
+constexpr int TCH = 64;              // consecutive window positions per thread in the dense passes (the first TW / 64 threads own a chunk)
 constexpr int NWV = TT / 64;
 // Two sizes of the per-level LDS lists (alive entries / pushes per level and window).  The small one leaves 40 KB of LDS
 // per workgroup, i.e. four workgroups per CU -- the kernel is latency bound, so its throughput follows the number of
 // resident workgroups; the large one (one workgroup per CU) takes over if a level overflows the small lists, e.g. on
 // texts with a random background, where a third of all positions sit in one level.
-constexpr int TE_SMALL = 512, TP_SMALL = 384;
+constexpr int TE_SMALL = TDC_WIN_TE, TP_SMALL = TDC_WIN_TP;
 constexpr int TE_LARGE = 8192, TP_LARGE = 4096;
 
 // Position q of the window lives at byte PA(q) of the position-indexed LDS arrays.  A thread's dense passes read "its"
@@ -204,30 +216,6 @@ __global__ __launch_bounds__(TT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
             }
             if (((lds_load(&s_lvlmask) >> L) & 1ull) == 0) { fl = dfl; fr = dfr; continue; }   // nothing resides in list L
             const int lo = fl > 0 ? fl : 0, hi = fr < wl ? fr : wl;
-#ifdef TDC_WIN_DENSE_LOOP
-            const int base = tid * TCH;
-            u64 amask = 0;
-            if (base < hi && base + TCH > lo) {
-                const u64 pat = (u64)L * 0x0101010101010101ull;
-                const u64 lo7 = 0x7F7F7F7F7F7F7F7Full;
-                u64 rws[TCH / 8], cws[TCH / 8];
-#pragma unroll
-                for (int k = 0; k < TCH / 8; ++k) { rws[k] = *(const u64*)&res8[PW(tid, k)]; cws[k] = *(const u64*)&cur8[PW(tid, k)]; }
-#pragma unroll
-                for (int k = 0; k < TCH / 8; ++k) {
-                    const u64 x = (rws[k] & lo7) ^ pat;
-                    u64 hit = ~(((x & lo7) + lo7) | x | lo7);          // 0x80 in every byte of x that is zero (exact)
-                    while (hit) {
-                        const int bb = __builtin_ctzll(hit) >> 3;
-                        hit &= hit - 1;
-                        const int pos = base + 8 * k + bb;
-                        if (pos < lo || pos >= hi) continue;                              // unknown: ignored from now on
-                        if (((u32)(cws[k] >> (8 * bb)) & 0xFFu) >= threshold) amask |= 1ull << (8 * k + bb);
-                        else res8[PW(tid, k) + bb] = 0;                                   // erased entry (:86)
-                    }
-                }
-            }
-#else
             // ---- 1. collect the alive entries of list L in position order --------------------------------------
             // (branch-free per 8-position word: byte flags 0x80 for "resides in list L" and for "still alive", a shift cascade turns
             //  the flags into bits of the thread's 64-position mask; erased entries (:86) leave the list by a masked word store.
@@ -256,7 +244,6 @@ __global__ __launch_bounds__(TT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                 if (rlo > 0) amask &= ~((1ull << rlo) - 1ull);
                 if (rhi < TCH) amask &= (1ull << rhi) - 1ull;
             }
-#endif
             // the first priorities are requested before the barrier of the scan, so their latency overlaps it
             u32 pre0 = 0, pre1 = 0;
             {
@@ -532,7 +519,7 @@ int factorize_window_levels(Ctx& c, size_t n, const u32* cur, const u32* prio, c
     if (halo < 2 * lcut + 64) halo = (2 * lcut + 64 + 3) & ~3u;
     if (halo > (u32)TH_MAX) halo = TH_MAX;
     bool large = c.window_large_lists != 0;
-    const u32 max_grid = 2048u;
+    const u32 max_grid = 512u * TDC_WIN_WPE;     // two rounds of resident workgroups
     u32* lprio = c.arena.get<u32>((size_t)max_grid * TW);
     WinScalars* d_sc = (WinScalars*)c.arena.alloc(sizeof(WinScalars));
     WinScalars h;
@@ -547,7 +534,7 @@ int factorize_window_levels(Ctx& c, size_t n, const u32* cur, const u32* prio, c
             // per window position: cur (4) + residence (1); per text position: ~0.3 priority reads and the factor output
             Ctx::ProfScope prof(c, K_WINDOW_LEVELS, (u64)((double)n * TW / ti * 5) + (u64)n * 2);
             if (!large)
-                window_levels_kernel<TE_SMALL, TP_SMALL, 4><<<grid, TT, 0, s>>>(cur, prio, res8, phi, n, lcut, threshold, ntiles, halo, lprio, fs.flen, fs.fsrc, d_sc);
+                window_levels_kernel<TE_SMALL, TP_SMALL, TDC_WIN_WPE><<<grid, TT, 0, s>>>(cur, prio, res8, phi, n, lcut, threshold, ntiles, halo, lprio, fs.flen, fs.fsrc, d_sc);
             else
                 window_levels_kernel<TE_LARGE, TP_LARGE, 1><<<grid, TT, 0, s>>>(cur, prio, res8, phi, n, lcut, threshold, ntiles, halo, lprio, fs.flen, fs.fsrc, d_sc);
             LAUNCH_CHECK();
