@@ -813,6 +813,7 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
     u32 prio_base = (u32)n;
 
     u32 dead_streak = 0, levels_since_purge = 1u << 30;
+    bool purge_pays = false;                               // a level too large for the one-workgroup path consisted mostly of erased entries
     u32 dead_levels_run = 0;                               // consecutive levels whose entries were all erased
     u32 nolive_run = 0, stale_trigger = 8;                 // consecutive levels without a live entry; run length that triggers the batch push
     double host_prof[5] = {0, 0, 0, 0, 0};                // small levels, host side: prepare / launch / wait / bookkeeping (us), count
@@ -846,7 +847,8 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
         }
         // ---- purge: after a run of large levels whose entries were (almost) all erased, drop the erased candidates of
         //      every level still to come (they can never come back to life: cur only decreases)
-        if (dead_streak >= 4 && levels_since_purge >= 16) {
+        if ((dead_streak >= 4 && levels_since_purge >= 16) || purge_pays) {
+            purge_pays = false;
             size_t cnt = 0;                                // candidates of the levels <= L form a prefix of the sorted array
             for (u32 v = L;; --v) { if (h_segend[v] > h_segstart[v]) { cnt = h_segend[v]; break; } if (v == threshold) break; }
             if (cnt > 65536) {
@@ -1098,6 +1100,16 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
         c.read_n((const u32*)d_sc, (u32*)&h_sc, 8);
         const u32 nl = h_sc.nlive, ns = h_sc.nstale;
         if (((u64)nl + ns) * 16 < m) ++dead_streak; else dead_streak = 0;     // (almost) all entries already erased
+        // Texts with long repeats: every level holds one candidate per PLCP ramp, nearly all of them erased by the ramp's first
+        // factor, and there are thousands of such levels.  Dropping the erased candidates of all remaining levels costs one pass
+        // over them (~0.1 ns per candidate); it pays when it turns enough of the levels to come into one-workgroup levels
+        // (~0.15 ms saved per level).
+        if (m > SMALL_RAW && ((u64)nl + ns) * 4 < m && levels_since_purge >= 16) {
+            const u32 floor_lv = std::max<u32>(lcut, threshold);
+            size_t cnt = 0;
+            for (u32 v = L;; --v) { if (h_segend[v] > h_segstart[v]) { cnt = h_segend[v]; break; } if (v == threshold) break; }
+            if (L > floor_lv && (u64)(L - floor_lv) * 1500000ull > cnt) purge_pays = true;
+        }
         if (nl == 0) ++nolive_run; else nolive_run = 0;
         if (nl == 0 && ns == 0) { probe_dead = true; ++dead_levels_run; continue; }   // every entry already erased (:86)
         dead_levels_run = 0;
