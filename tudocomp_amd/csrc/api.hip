@@ -296,6 +296,7 @@ int tdc_gpu_ctx_create(int device, tdc_gpu_ctx** out) {
         if (const char* m = getenv("TDC_GPU_WINDOW_HALO")) { const int v = atoi(m); ctx->c.window_halo = v < 0 ? 0 : (v > 2048 ? 2048 : v); }
         if (const char* m = getenv("TDC_GPU_WINDOW_LARGE")) ctx->c.window_large_lists = atoi(m) ? 1 : 0;
         if (const char* m = getenv("TDC_GPU_PLCP_SAMPLES")) ctx->c.plcp_samples = atoi(m) != 0;
+        if (const char* m = getenv("TDC_GPU_SA_REFINE")) ctx->c.sa_refine = atoi(m) != 0;
         if (const char* m = getenv("TDC_GPU_SA_FUSED_INIT")) ctx->c.sa_fused_init = atoi(m) != 0;
         if (const char* m = getenv("TDC_GPU_RADIX_LDS")) { const int v = atoi(m); ctx->c.radix_lds = (v >= 0 && v <= 2) ? v : 2; }
         if (const char* m = getenv("TDC_GPU_XCD_REMAP")) { const int v = atoi(m); ctx->c.xcd_remap = (v >= 0 && v <= 2) ? v : 0; }

@@ -117,6 +117,7 @@ struct Ctx {
     int sa_local_sort = 1;         // doubling rounds: sort whole runs inside 2048-element tiles locally (env TDC_GPU_SA_LOCAL=0 disables)
     int radix_waves = 4;           // waves per radix-sort workgroup for large inputs (env TDC_GPU_RADIX_WAVES = 4 | 8; no measurable difference)
     int plcp_samples = 1;          // PLCP: exact values at every 256th position first, as lower bounds for the chunks (env TDC_GPU_PLCP_SAMPLES=0: chunks start from 0)
+    int sa_refine = 1;             // suffix array: small groups of the initial order are refined from the text before the first round (env TDC_GPU_SA_REFINE=0 disables)
     int sa_fused_init = 1;         // suffix array: pass 0 of the initial sort computes its keys from the text (env TDC_GPU_SA_FUSED_INIT=0: separate key kernel)
     int radix_lds = 1;             // radix scatter: reorder the tile in LDS before writing: 0 never, 1 always, 2 for 32-bit keys only
                                    // (measured: -33 % for u32 pairs; u64 pairs only gain together with xcd_remap: 21.1 -> 18.5 ms; env TDC_GPU_RADIX_LDS)

@@ -124,6 +124,141 @@ __global__ void sa_scatter_back_kernel(const u32* __restrict__ opos, const u64* 
     vals[p] = ovals[j];
 }
 
+// ---- refinement of the initial order from the text ------------------------------------------------------------------------------
+// After the initial sort the suffixes are ordered by their first k symbols; most groups of equal keys are a handful of suffixes,
+// yet the first doubling round would send all their members (two thirds of a 2 GB English text) through a rank scatter, a
+// scattered rank gather, a sort and a second rank scatter.  Here every group of 2 .. RF_MAXRUN members that lies inside one tile is
+// ordered by the NEXT k symbols of its members right away: the keys come from the text (one scattered read per member -- the same
+// read the round's gather would have cost), the order inside the group from counting (lengths are tiny), and the groups' new
+// boundaries go out as one flag byte per element, which is all the bookkeeping pass needs.  Longer groups and groups that cross a
+// tile border (the frequent words) keep their order and stay one group: the doubling rounds, which start at h = k as before, deal
+// with them -- every group still shares at least k symbols -- and with the few short groups that tie on 2k symbols.
+#ifndef TDC_RF_MAXRUN
+#define TDC_RF_MAXRUN 256
+#endif
+constexpr u32 RF_TILE = 2048, RF_MAXRUN = TDC_RF_MAXRUN;     // (counting costs a group its length squared)
+struct RefineGen { const u8* text; size_t n; u32 sigma; int k, chunk; u8 code[256]; };
+__device__ __forceinline__ u64 rf_text_key(const RefineGen& g, const u8* __restrict__ code, size_t q) {
+    u64 w[4] = { 0, 0, 0, 0 };
+    if (q + 32 <= g.n) __builtin_memcpy(w, g.text + q, 32);   // four unaligned 8-byte words
+    else {
+#pragma unroll
+        for (int t = 0; t < 32; ++t) if (q + t < g.n) w[t >> 3] |= (u64)g.text[q + t] << (8 * (t & 7));
+    }
+    // the k-digit number in base sigma, evaluated in chunks that fit 32 bits (as the initial keys); static indices throughout
+    u64 key = 0;
+    u32 acc = 0, scale = 1;
+    int cnt = 0;
+    bool first = true;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        if (j < g.k) {
+            const u32 sym = (q + j < g.n) ? (u32)code[(u8)(w[j >> 3] >> (8 * (j & 7)))] : 0u;   // beyond the text: the padding the initial keys use
+            acc = acc * g.sigma + sym; scale *= g.sigma; ++cnt;
+            if (cnt == g.chunk || j == g.k - 1) { key = first ? (u64)acc : key * scale + acc; first = false; acc = 0; scale = 1; cnt = 0; }
+        }
+    }
+    return key;
+}
+__global__ __launch_bounds__(256) void sa_refine_kernel(const u64* __restrict__ keys, u32* __restrict__ vals, size_t m, RefineGen g,
+                                                        u8* __restrict__ flags) {
+    __shared__ u64 sk[RF_TILE + 2];          // keys of the elements t0 - 1 .. t0 + 2048, later the second keys of the refined elements
+    __shared__ u32 sp[RF_TILE], snew[RF_TILE];
+    __shared__ u64 hb[RF_TILE / 64 + 1];     // group heads of the tile as a bitmap; bit 2048: the element behind the tile starts a group
+    __shared__ u8 sflag[RF_TILE];
+    __shared__ u8 code[256];
+    __shared__ u32 s_any;
+    const size_t t0 = (size_t)blockIdx.x * RF_TILE;
+    const int lane = lane_id(), w = wave_id();
+    code[threadIdx.x] = g.code[threadIdx.x];
+    if (threadIdx.x == 0) s_any = 0;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const u32 e = (u32)r * 256 + threadIdx.x;
+        const size_t i = t0 + e;
+        sk[e + 1] = (i < m) ? keys[i] : 0ull;
+        const u32 pv = (i < m) ? vals[i] : 0u;
+        sp[e] = pv; snew[e] = pv;
+    }
+    if (threadIdx.x == 0) {
+        sk[0] = (t0 >= 1) ? keys[t0 - 1] : 0ull;
+        sk[RF_TILE + 1] = (t0 + RF_TILE < m) ? keys[t0 + RF_TILE] : 0ull;
+    }
+    __syncthreads();
+    // heads: one ballot per row of 64 consecutive elements = one word of the bitmap
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const u32 e = (u32)r * 256 + threadIdx.x;
+        const size_t i = t0 + e;
+        const bool head = i < m && (i == 0 || sk[e + 1] != sk[e]);
+        const u64 bm = __ballot(head || i >= m);               // (positions behind the end count as heads: they close the last group)
+        if (lane == 0) hb[r * 4 + w] = bm;
+        sflag[e] = head ? 1 : 0;
+    }
+    if (threadIdx.x == 0) hb[RF_TILE / 64] = (t0 + RF_TILE >= m || sk[RF_TILE + 1] != sk[RF_TILE]) ? 1ull : 0ull;
+    __syncthreads();
+    // the group of every element: [rs, re) if it lies inside the tile and has 2 .. RF_MAXRUN members
+    u32 rs[8], re[8];
+    u64 k2[8];
+    u32 mine = 0;                                              // bit r: element r of this thread is refined
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const u32 e = (u32)r * 256 + threadIdx.x;
+        rs[r] = re[r] = 0; k2[r] = 0;
+        if (t0 + e >= m) continue;
+        const u32 wi = e >> 6, b = e & 63;
+        const u64 cw = hb[wi];
+        // nearest head at or before e / behind e, looking at most RF_MAXRUN elements far
+        u64 x = cw & ((b == 63) ? ~0ull : ((2ull << b) - 1ull));
+        u32 wl = wi;
+        while (!x && wl > 0 && wi - wl < RF_MAXRUN / 64 + 1) x = hb[--wl];
+        if (!x) continue;                                      // the group starts further back, or in front of the tile
+        const u32 s0 = wl * 64 + 63 - (u32)__builtin_clzll(x);
+        u64 y = (b == 63) ? 0ull : (cw & (~0ull << (b + 1)));
+        u32 wr = wi;
+        while (!y && wr < RF_TILE / 64 && wr - wi < RF_MAXRUN / 64 + 1) y = hb[++wr];
+        if (!y) continue;                                      // ... ends further ahead, or behind the tile
+        const u32 e1 = wr * 64 + (u32)__builtin_ctzll(y);
+        const u32 len = e1 - s0;
+        if (len < 2 || len > RF_MAXRUN) continue;
+        rs[r] = s0; re[r] = e1; mine |= 1u << r;
+    }
+    // second keys of the refined elements, all of a thread's scattered reads in flight together
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+        if (mine & (1u << r)) k2[r] = rf_text_key(g, code, (size_t)sp[(u32)r * 256 + threadIdx.x] + (size_t)g.k);
+    if (__any(mine != 0) && lane == 0) s_any = 1;
+    __syncthreads();                                           // (every thread is done with the first keys)
+    if (s_any == 0) {                                          // nothing to refine here: only the flags go out
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { const u32 e = (u32)r * 256 + threadIdx.x; if (t0 + e < m) flags[t0 + e] = sflag[e]; }
+        return;
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) if (mine & (1u << r)) sk[(u32)r * 256 + threadIdx.x] = k2[r];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        if (!(mine & (1u << r))) continue;
+        const u32 e = (u32)r * 256 + threadIdx.x;
+        u32 less = 0, eqb = 0;
+        for (u32 j = rs[r]; j < re[r]; ++j) {
+            const u64 kj = sk[j];
+            less += (kj < k2[r]) ? 1u : 0u;
+            eqb += (kj == k2[r] && j < e) ? 1u : 0u;
+        }
+        const u32 t = rs[r] + less + eqb;
+        snew[t] = sp[e];
+        sflag[t] = (eqb == 0) ? 1 : 0;                          // the first member of its (k, 2k)-symbol group
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const u32 e = (u32)r * 256 + threadIdx.x;
+        if (t0 + e < m) { vals[t0 + e] = snew[e]; flags[t0 + e] = sflag[e]; }
+    }
+}
+
 // ---- group bookkeeping of one round in ONE pass ------------------------------------------------------------------------------
 // Input: the (key, value) list sorted inside its groups; equal keys = one (new) group.  Per element: pos = its suffix-array slot
 // (the index itself in the first round, else a_pos[]), head = pos of the first element of its group.  Output: sa[pos] = value,
@@ -140,7 +275,8 @@ template <bool FIRST>
 __global__ __launch_bounds__(256) void sa_groups_kernel(const u64* __restrict__ keys, const u32* __restrict__ vals, const u32* __restrict__ a_pos,
                                                         size_t m, int bn, u32* __restrict__ sa, u32* __restrict__ rank, u32* __restrict__ newrank_out,
                                                         u32* __restrict__ o_sa, u32* __restrict__ o_pos, u32* __restrict__ o_r1,
-                                                        u64* desc, u32* ticket, u32* __restrict__ d_total, u32* err, u32 numTiles) {
+                                                        u64* desc, u32* ticket, u32* __restrict__ d_total, u32* err, u32 numTiles,
+                                                        const u8* __restrict__ hflags = nullptr) {
     __shared__ u32 s_tile;
     __shared__ u32 s_hp[4], s_cnt[5];
     __shared__ u32 s_carry_hp, s_carry_cnt;
@@ -160,12 +296,12 @@ __global__ __launch_bounds__(256) void sa_groups_kernel(const u64* __restrict__ 
         const size_t i = t0 + e;
         u64 kk = 0; u32 vv = 0, pp = 0;
         if (i < m) {
-            kk = keys[i]; vv = vals[i]; pp = FIRST ? (u32)i : a_pos[i];
+            kk = hflags ? 0ull : keys[i]; vv = vals[i]; pp = FIRST ? (u32)i : a_pos[i];
             sa[pp] = vv;
         }
         sk[gr_pad(e + 1)] = kk; sv[gr_pad(e)] = vv; sp[gr_pad(e)] = pp;
     }
-    if (threadIdx.x == 0) { sk[0] = (t0 >= 1) ? keys[t0 - 1] : 0ull; sk[gr_pad(GR_TILE + 1)] = (t0 + GR_TILE < m) ? keys[t0 + GR_TILE] : 0ull; }
+    if (threadIdx.x == 0 && !hflags) { sk[0] = (t0 >= 1) ? keys[t0 - 1] : 0ull; sk[gr_pad(GR_TILE + 1)] = (t0 + GR_TILE < m) ? keys[t0 + GR_TILE] : 0ull; }
     __syncthreads();
     const u32 l0 = threadIdx.x * 8;                     // the thread's 8 consecutive elements
     const size_t i0 = t0 + l0;
@@ -180,7 +316,9 @@ __global__ __launch_bounds__(256) void sa_groups_kernel(const u64* __restrict__ 
 #pragma unroll
     for (int r = 0; r < 9; ++r) {
         const size_t i = i0 + r;
-        if (i < m && (i == 0 || k[r + 1] != k[r])) starts |= 1u << r;
+        // group heads: from the flags of the refinement pass if there was one (they also split groups of equal FIRST keys)
+        const bool head = hflags ? (i < m && hflags[i] != 0) : (i < m && (i == 0 || k[r + 1] != k[r]));
+        if (head) starts |= 1u << r;
         if (i == m) starts |= 1u << r;                  // the end of the list closes the last run
     }
     u32 hp[8];
@@ -351,6 +489,18 @@ void build_suffix_array(Ctx& c, const u8* text, size_t n, u32* sa, u32* isa, SAS
         x = radix_sort_pairs_u64(c, keys, vals, n, 0, key_bits);
     }
     st->sorted_elems += n;
+    // groups of a few suffixes are ordered by their next k symbols straight from the text (see sa_refine_kernel)
+    const u8* hflags = nullptr;
+    if (c.sa_refine && k <= 32 && n >= ((size_t)1 << 16)) {
+        RefineGen rg;
+        rg.text = text; rg.n = n; rg.sigma = base; rg.k = k; rg.chunk = chunk;
+        memcpy(rg.code, cm.code, 256);
+        u8* fl = (u8*)keep;                                  // free until the rounds use it as class bytes
+        Ctx::ProfScope prof(c, K_SA_BUILD_KEYS, (u64)n * 17 + (u64)n * 8);     // key + position in, position + flag out; ~0.4 scattered text reads per element
+        sa_refine_kernel<<<cdiv(n, RF_TILE), 256, 0, s>>>(keys[x], vals[x], n, rg, fl);
+        LAUNCH_CHECK();
+        hflags = fl;
+    }
     const int bn = (int)bits_for(n - 1);
     u64* gdesc = c.arena.get<u64>(cdiv(n, GR_TILE) + 1);       // look-back descriptors + ticket of the group kernel
     u32* gticket = c.arena.get<u32>(1);
@@ -362,7 +512,7 @@ void build_suffix_array(Ctx& c, const u8* text, size_t n, u32* sa, u32* isa, SAS
         {   // per element: read key + value (12 B), write sa + head (8 B) + the kept elements (12 B each, about half of them)
             Ctx::ProfScope prof(c, K_SA_RANK_SCATTER, (u64)n * 26);
             sa_groups_kernel<true><<<tiles, 256, 0, s>>>(keys[x], vals[x], nullptr, n, bn, sa, rank, bucketed ? head : nullptr, A_sa, A_pos, A_r1,
-                                                         gdesc, gticket, d_total, c.d_err, tiles);
+                                                         gdesc, gticket, d_total, c.d_err, tiles, hflags);
             LAUNCH_CHECK();
         }
         // rank[vals[j]] = head[j] through a partition by destination window; the other key buffer and the B lists are free scratch
