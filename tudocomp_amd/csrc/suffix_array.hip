@@ -313,13 +313,24 @@ __global__ __launch_bounds__(256) void sa_groups_kernel(const u64* __restrict__ 
     for (int r = 0; r < 8; ++r) { v[r] = sv[gr_pad(l0 + r)]; ps[r] = sp[gr_pad(l0 + r)]; }
     // run starts, head position of every element as far as the thread can tell, number of elements to keep
     u32 starts = 0;
+    if (hflags) {
+        // group heads from the flags of the refinement pass (they also split groups of equal FIRST keys): the thread's eight flag
+        // bytes are one aligned 8-byte word
+        u64 fw = 0;
+        if (i0 + 8 <= m) fw = *(const u64*)(hflags + i0);
+        else for (int r = 0; r < 8; ++r) if (i0 + r < m) fw |= (u64)hflags[i0 + r] << (8 * r);
 #pragma unroll
-    for (int r = 0; r < 9; ++r) {
-        const size_t i = i0 + r;
-        // group heads: from the flags of the refinement pass if there was one (they also split groups of equal FIRST keys)
-        const bool head = hflags ? (i < m && hflags[i] != 0) : (i < m && (i == 0 || k[r + 1] != k[r]));
-        if (head) starts |= 1u << r;
-        if (i == m) starts |= 1u << r;                  // the end of the list closes the last run
+        for (int r = 0; r < 8; ++r) if ((fw >> (8 * r)) & 0xFFull) starts |= 1u << r;
+        if (i0 + 8 < m) { if (hflags[i0 + 8]) starts |= 1u << 8; }
+#pragma unroll
+        for (int r = 0; r < 9; ++r) if (i0 + r == m) starts |= 1u << r;     // the end of the list closes the last run
+    } else {
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            const size_t i = i0 + r;
+            if (i < m && (i == 0 || k[r + 1] != k[r])) starts |= 1u << r;
+            if (i == m) starts |= 1u << r;                  // the end of the list closes the last run
+        }
     }
     u32 hp[8];
     u32 run = GR_NONE, keepmask = 0;
