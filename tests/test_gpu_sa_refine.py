@@ -1,0 +1,68 @@
+"""GPU parity of the suffix-array refinement pass (pytest -m gpu): suffix_array.hip sa_refine_kernel orders the small groups of the
+initial order by their next k symbols straight from the text.  It only runs for texts of at least 2^16 bytes, so the small corpus
+never reaches it: these texts do -- many small groups, groups on tile borders, groups of every length around the limit of 256, long
+periodic stretches, tiny and full byte alphabets -- and SA / ISA / Phi / PLCP must equal the oracle's (divsufsort semantics:
+ds/SADivSufSort.hpp:27-51, ds/ISAFromSA.hpp:30-43, ds/PhiFromSA.hpp:35-45, ds/PLCPFromPhi.hpp:27-53) with the pass on and off."""
+import numpy as np
+import pytest
+
+import tudocomp_amd as T
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _texts():
+    rng = np.random.default_rng(2024)
+    out = []
+    out.append(("english_200k", T.gen_english(200_000, 5).tobytes()))
+    out.append(("dna_150k", T.gen_dna(150_000, 3).tobytes()))
+    # words from a tiny vocabulary: thousands of groups of every size, most of them tying on the second key as well
+    voc = [bytes(rng.integers(97, 101, int(rng.integers(1, 6)), dtype=np.uint8)) for _ in range(40)]
+    out.append(("tiny_vocabulary", b" ".join(voc[int(i)] for i in rng.integers(0, 40, 40_000))))
+    # blocks repeated r times for r = 1 .. 600: groups of exactly r members (around the limit of 256 and beyond a tile)
+    blocks = []
+    for r in list(range(1, 40)) + [63, 64, 65, 127, 128, 129, 255, 256, 257, 300, 600]:
+        blk = bytes(rng.integers(65, 91, 24, dtype=np.uint8))
+        sep = [bytes(rng.integers(97, 123, 3, dtype=np.uint8)) for _ in range(r)]
+        blocks.append(b"".join(blk + s for s in sep))
+    rep = b"".join(blocks)
+    out.append(("group_sizes", rep + bytes(rng.integers(48, 58, 70_000 - min(len(rep), 60_000), dtype=np.uint8))))
+    out.append(("periodic", (b"abcab" * 30_000)[:100_000] + bytes(rng.integers(97, 99, 30_000, dtype=np.uint8))))
+    out.append(("all_bytes", bytes(rng.integers(1, 255, 90_000, dtype=np.uint8))))
+    out.append(("two_letters", bytes(rng.integers(97, 99, 120_000, dtype=np.uint8))))
+    out.append(("just_above_limit", bytes(rng.integers(97, 100, 65_535, dtype=np.uint8))))        # 65 536 bytes with the sentinel
+    return out
+
+
+TEXTS = _texts()
+
+
+@pytest.fixture(scope="module")
+def ctx_plain():
+    import os
+    old = os.environ.get("TDC_GPU_SA_REFINE")
+    os.environ["TDC_GPU_SA_REFINE"] = "0"
+    try:
+        c = T.Context(0)
+    finally:
+        if old is None:
+            del os.environ["TDC_GPU_SA_REFINE"]
+        else:
+            os.environ["TDC_GPU_SA_REFINE"] = old
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("name,data", TEXTS, ids=[t[0] for t in TEXTS])
+def test_text_index_with_and_without_refinement(gpu_ctx, ctx_plain, name, data):
+    text = O.escape(data)
+    sa = O.suffix_array(text)
+    isa, phi, plcp, maxlcp = O.isa_phi_plcp(text, sa)
+    for label, ctx in (("refined", gpu_ctx), ("plain", ctx_plain)):
+        g = ctx.textds(text)
+        assert np.array_equal(g["sa"], sa), "%s %s: SA" % (name, label)
+        assert np.array_equal(g["isa"], isa), "%s %s: ISA" % (name, label)
+        assert np.array_equal(g["phi"], phi), "%s %s: Phi" % (name, label)
+        assert np.array_equal(g["plcp"], plcp), "%s %s: PLCP" % (name, label)
+        assert g["maxlcp"] == maxlcp
