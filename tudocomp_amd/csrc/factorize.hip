@@ -71,9 +71,15 @@ __device__ __forceinline__ u32 bm_state(const u64* __restrict__ bm, u32 p) { ret
 // ---- candidates ("Fill candidates", :54-66) ----------------------------------------------------------------
 // cls[p] = 1 for the candidates whose level is above `lo` (the lists of the levels <= lo are only materialised if the
 // window pass fails); *d_entries counts all candidates ("entries" of the reference's log)
+// lvl_hist (nullable, 64 counters): every 16th candidate of a level below 64 is counted -- an estimate of how many entries a window of
+// the window pass will find in one level (its per-level LDS lists come in two sizes)
 __global__ __launch_bounds__(256) void cand_class_kernel(const u32* __restrict__ plcp, size_t n, u32 threshold, u32 lo, u8* __restrict__ cls,
-                                                          u32* __restrict__ flen, u8* __restrict__ res8, u32* __restrict__ d_entries) {
+                                                          u32* __restrict__ flen, u8* __restrict__ res8, u32* __restrict__ d_entries,
+                                                          u32* __restrict__ lvl_hist) {
     __shared__ u32 sm[4];
+    __shared__ u32 sh[64];
+    if (threadIdx.x < 64) sh[threadIdx.x] = 0;
+    __syncthreads();
     u32 cnt = 0;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
@@ -83,11 +89,13 @@ __global__ __launch_bounds__(256) void cand_class_kernel(const u32* __restrict__
         flen[p] = 0;
         if (res8) res8[p] = is_cand ? (u8)(v > 255u ? 255u : v) : (u8)0;   // list that holds the entry of p (saturated)
         cnt += is_cand;
+        if (lvl_hist && is_cand && v < 64u && (p & 15) == 0) atomicAdd(&sh[v], 1u);
     }
     cnt = wave_reduce_sum(cnt);
     if (lane_id() == 0) sm[wave_id()] = cnt;
     __syncthreads();
     if (threadIdx.x == 0) { const u32 t = sm[0] + sm[1] + sm[2] + sm[3]; if (t) atomicAdd(d_entries, t); }   // one atomic per workgroup (capped grid)
+    if (lvl_hist && threadIdx.x < 64 && sh[threadIdx.x]) atomicAdd(&lvl_hist[threadIdx.x], sh[threadIdx.x]);
 }
 // after a failed window pass: the original candidates of the levels threshold .. lcut that are still in their lists
 // (pushed entries carry priorities >= n and are tracked by the push pool)
@@ -728,9 +736,11 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
     u32* cvals[2] = { c.arena.get<u32>(n), c.arena.get<u32>(n) };
     u32* d_cnt = c.arena.get<u32>(4);
     HIP_TRY(hipMemsetAsync(d_cnt, 0, 4 * sizeof(u32), s));
+    u32* d_lvlhist = c.arena.get<u32>(64);
+    HIP_TRY(hipMemsetAsync(d_lvlhist, 0, 64 * sizeof(u32), s));
     {
         Ctx::ProfScope prof(c, K_CAND, (u64)n * (lcut ? 10 : 9));
-        cand_class_kernel<<<(gn < 8192u ? gn : 8192u), 256, 0, s>>>(plcp, n, threshold, lcut, cls, fs.flen, res8, d_cnt + 1);
+        cand_class_kernel<<<(gn < 8192u ? gn : 8192u), 256, 0, s>>>(plcp, n, threshold, lcut, cls, fs.flen, res8, d_cnt + 1, lcut ? d_lvlhist : nullptr);
         LAUNCH_CHECK();
     }
     if ((u64)maxlcp + 1 <= threshold || threshold == 0) { c.arena.release(mark); build_owner(c, n, fs); return; }   // ArraysComp.hpp:50
@@ -829,7 +839,18 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
             //      pass (a window whose known range shrank into its interior) simply continues with the loop below and
             //      tries once more further down, where the borders of the known range move half as far
             u64 nf = 0;
-            const int why = factorize_window_levels(c, n, cur, prio, res8, phi, lcut, threshold, fs, &nf);
+            // per-level lists of the window pass: start with the large ones if a level is expected to hold more entries per window than
+            // the small ones take (sampled histogram of the candidates' levels; most of a level's candidates are usually erased by then,
+            // hence the factor -- a wrong guess only costs time, the pass retries with the other size)
+            bool start_large = false;
+            {
+                u32 hh[64];
+                c.read_n(d_lvlhist, hh, 64);
+                u64 mx = 0;
+                for (u32 v = threshold; v <= lcut && v < 64u; ++v) mx = std::max<u64>(mx, hh[v]);
+                start_large = (double)mx * 16.0 * (double)window_levels_window() / (double)n > 4.0 * (double)window_levels_small_list();
+            }
+            const int why = factorize_window_levels(c, n, cur, prio, res8, phi, lcut, threshold, fs, &nf, start_large);
             const bool ok = why == 0;
             st->window_pass = ok ? 1 : 2;
             st->window_lcut = lcut;
@@ -1450,7 +1471,7 @@ void factorize_max_lcp(Ctx& c, size_t n, u32* isa, const u32* phi, u32* plcp, u3
     u32* cvals[2] = { c.arena.get<u32>(n), c.arena.get<u32>(n) };
     u32* d_cnt = c.arena.get<u32>(4);
     HIP_TRY(hipMemsetAsync(d_cnt, 0, 4 * sizeof(u32), s));
-    cand_class_kernel<<<(gn < 8192u ? gn : 8192u), 256, 0, s>>>(plcp, n, threshold, 0u, cls, fs.flen, nullptr, d_cnt + 1);
+    cand_class_kernel<<<(gn < 8192u ? gn : 8192u), 256, 0, s>>>(plcp, n, threshold, 0u, cls, fs.flen, nullptr, d_cnt + 1, nullptr);
     LAUNCH_CHECK();
     if (maxlcp < threshold || threshold == 0) { c.arena.release(mark); build_owner(c, n, fs); return; }
     mlcp_init_prio_kernel<<<gn, 256, 0, s>>>(prio, n);

@@ -503,10 +503,12 @@ __global__ void window_cleanup_kernel(u32* __restrict__ flen, size_t n, u32 lcut
 }  // namespace
 
 u32 window_levels_max_lcut() { return 63; }
+u32 window_levels_window() { return (u32)TW; }
+u32 window_levels_small_list() { return (u32)TE_SMALL; }
 size_t window_levels_min_text() { return (size_t)4 * TW; }
 
 int factorize_window_levels(Ctx& c, size_t n, const u32* cur, const u32* prio, const u8* res8, const u32* phi, u32 lcut, u32 threshold,
-                            FactorSpace fs, u64* nfactors) {
+                            FactorSpace fs, u64* nfactors, bool start_large) {
     *nfactors = 0;
     if (lcut < threshold) return 0;
     hipStream_t s = c.stream;
@@ -518,7 +520,7 @@ int factorize_window_levels(Ctx& c, size_t n, const u32* cur, const u32* prio, c
     u32 halo = (u32)c.window_halo & ~3u;
     if (halo < 2 * lcut + 64) halo = (2 * lcut + 64 + 3) & ~3u;
     if (halo > (u32)TH_MAX) halo = TH_MAX;
-    bool large = c.window_large_lists != 0;
+    bool large = c.window_large_lists != 0 || start_large;
     const u32 max_grid = 512u * TDC_WIN_WPE;     // two rounds of resident workgroups
     u32* lprio = c.arena.get<u32>((size_t)max_grid * TW);
     WinScalars* d_sc = (WinScalars*)c.arena.alloc(sizeof(WinScalars));
@@ -555,6 +557,7 @@ int factorize_window_levels(Ctx& c, size_t n, const u32* cur, const u32* prio, c
         LAUNCH_CHECK();
         bool again = false;
         if ((h.fail & 2u) && !large) { large = true; again = true; }
+        // (started with the large lists on a guess and a border failed: the retry keeps them -- they hold whatever the small ones do)
         if ((h.fail & 1u) && halo < (u32)TH_MAX) { halo = TH_MAX; again = true; }
         if (!again) break;
     }

@@ -12,7 +12,9 @@ namespace tdc {
 // more entries than even the large LDS lists hold (the pass retries by itself with the large lists when the small ones
 // overflow) -- in which case the caller runs the global level loop.
 int factorize_window_levels(Ctx& c, size_t n, const u32* cur, const u32* prio, const u8* res8, const u32* phi, u32 lcut, u32 threshold,
-                             FactorSpace fs, u64* nfactors);
+                             FactorSpace fs, u64* nfactors, bool start_large = false);
+u32 window_levels_window();         // positions per window
+u32 window_levels_small_list();     // entries of one level the small per-level lists hold
 u32 window_levels_max_lcut();       // one presence bit per level in a 64-bit mask
 size_t window_levels_min_text();    // shorter texts stay on the global path
 
