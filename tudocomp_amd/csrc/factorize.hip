@@ -312,6 +312,13 @@ __global__ __launch_bounds__(256) void small_level_kernel(const u32* __restrict_
     GatherSeg* gt = (GatherSeg*)skey;                     // skey is not used before the sorts
     for (u32 i = tid; i < gn; i += 256) gt[i] = gtab[i];
     if (gn) __syncthreads();
+    // The survivors keep the order of the list (row-wise ballots + a prefix over the rows and waves of a step): the original
+    // candidates of a level are in position order, so their survivors come out sorted and only the pushed ones -- usually a
+    // handful -- have to be ranked against them (step 1).
+    __shared__ u32 s_rowcnt[8][4];
+    __shared__ u32 s_run, s_nA;
+    if (tid == 0) { s_run = 0; s_nA = 0; }
+    __syncthreads();
     for (u32 base = 0; base < m_raw; base += 256 * 8) {
         u32 pp[8], cc[8];
 #pragma unroll
@@ -331,9 +338,38 @@ __global__ __launch_bounds__(256) void small_level_kernel(const u32* __restrict_
         }
 #pragma unroll
         for (u32 r = 0; r < 8; ++r) cc[r] = (pp[r] != NONE32) ? cur[pp[r]] : 0u;
+        u32 within[8];
+        u32 keepm = 0;
 #pragma unroll
-        for (u32 r = 0; r < 8; ++r)
-            if (pp[r] != NONE32 && cc[r] >= threshold) { const u32 slot = atomicAdd(&s_cnt, 1u); if (slot < SMALL_M) pos_s[slot] = pp[r]; }
+        for (u32 r = 0; r < 8; ++r) {
+            const bool keep = pp[r] != NONE32 && cc[r] >= threshold;
+            const u64 bm = __ballot(keep);
+            within[r] = (u32)__popcll(bm & ((1ull << (tid & 63)) - 1ull));
+            if ((tid & 63) == 0) s_rowcnt[r][tid >> 6] = (u32)__popcll(bm);
+            if (keep) keepm |= 1u << r;
+        }
+        __syncthreads();
+        const u32 run0 = s_run;
+        u32 nA_add = 0;
+        // slot of (row r, wave w, lane): everything in earlier rows, earlier waves of the row, earlier lanes of the wave
+        u32 before_row = 0;
+#pragma unroll
+        for (u32 r = 0; r < 8; ++r) {
+            u32 bw = 0;
+#pragma unroll
+            for (u32 wq = 0; wq < 4; ++wq) if (wq < (tid >> 6)) bw += s_rowcnt[r][wq];
+            if (keepm & (1u << r)) {
+                const u32 slot = run0 + before_row + bw + within[r];
+                if (slot < SMALL_M) pos_s[slot] = pp[r];
+                if (base + r * 256 + tid < m0) ++nA_add;
+            }
+            before_row += s_rowcnt[r][0] + s_rowcnt[r][1] + s_rowcnt[r][2] + s_rowcnt[r][3];
+        }
+        nA_add = wave_reduce_sum(nA_add);
+        if ((tid & 63) == 0 && nA_add) atomicAdd(&s_nA, nA_add);
+        __syncthreads();
+        if (tid == 0) { s_run = run0 + before_row; s_cnt = run0 + before_row; }
+        __syncthreads();
     }
     __syncthreads();
     SPROF(0);
@@ -350,7 +386,35 @@ __global__ __launch_bounds__(256) void small_level_kernel(const u32* __restrict_
         v[r] = 0;
     }
     __syncthreads();
-    if (m <= SMALL_RANKSORT) {
+    const u32 nA = s_nA, nB = m - nA;                       // survivors of the original candidates (in list order) / of the pushed part
+    // are the originals' survivors really ascending?  (they are whenever the candidate segment is in position order; checked, not assumed)
+    __shared__ u32 s_unsorted;
+    if (tid == 0) s_unsorted = 0;
+    __syncthreads();
+    for (u32 i = tid + 1; i < nA; i += 256) if (pos_s[i - 1] >= pos_s[i]) s_unsorted = 1;
+    __syncthreads();
+    if (!s_unsorted && (u64)nA * nB + (u64)nB * nB <= 256ull * 768ull) {
+        // sorted run A + a few unsorted entries B: an entry of A moves up by the number of smaller entries of B, an entry of B goes
+        // behind the smaller entries of A (binary search) and of B
+        for (u32 i = tid; i < m; i += 256) {
+            const u32 p = pos_s[i];
+            u32 rk;
+            if (i < nA) {
+                rk = i;
+                for (u32 j = nA; j < m; ++j) rk += (pos_s[j] < p) ? 1u : 0u;
+            } else {
+                u32 lo = 0, hi = nA;                          // number of entries of A below p
+                while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (pos_s[mid] < p) lo = mid + 1; else hi = mid; }
+                rk = lo;
+                for (u32 j = nA; j < m; ++j) rk += (pos_s[j] < p) ? 1u : 0u;
+            }
+            sval[rk] = p;
+        }
+        __syncthreads();
+#pragma unroll
+        for (u32 r = 0; r < 8; ++r) { const u32 i = tid * 8 + r; k[r] = (i < m) ? (u64)sval[i] : ~0ull; }
+        __syncthreads();
+    } else if (m <= SMALL_RANKSORT) {
         // few survivors: every entry counts the smaller ones (independent LDS reads: no chain of dependent steps)
         for (u32 i = tid; i < m; i += 256) {
             const u32 p = pos_s[i];
@@ -459,8 +523,48 @@ __global__ __launch_bounds__(256) void small_level_kernel(const u32* __restrict_
         }
     }
     __syncthreads();
-    // 5. sort the pushes by (target, old priority); afterwards pr_s[i] = target, v_s[i] = position of the i-th push
+    // 5. order the pushes by (target, old priority); afterwards pr_s[i] = target, v_s[i] = position of the i-th push.
+    //    Only the order INSIDE a target list matters (new priorities are only ever compared inside one list, and the pool keeps one
+    //    segment per target), and on texts with long repeats nearly every push of a level has a target of its own: targets are
+    //    counted in a hashed table; a push whose slot it has for itself takes the next free place (any order), the others -- real
+    //    duplicates and the rare hash collisions -- are ranked among themselves and follow.
     const u32 npush = s_npush;
+    __shared__ u32 s_hcnt[2048];
+    __shared__ unsigned short s_dl[SMALL_M];
+    __shared__ u32 s_nu, s_nd;
+    if (npush > 64) {
+        for (u32 i = tid; i < 2048; i += 256) s_hcnt[i] = 0;
+        if (tid == 0) { s_nu = 0; s_nd = 0; }
+        __syncthreads();
+        for (u32 i = tid; i < npush; i += 256) atomicAdd(&s_hcnt[((u32)(skey[i] >> 32) * 2654435761u) >> 21], 1u);
+        __syncthreads();
+        for (u32 i0 = 0; i0 < npush; i0 += 256) {
+            const u32 i = i0 + tid;
+            const bool have = i < npush;
+            const u64 key = have ? skey[i] : 0ull;
+            const bool uniq = have && s_hcnt[((u32)(key >> 32) * 2654435761u) >> 21] == 1u;
+            const u64 um = __ballot(uniq), dm = __ballot(have && !uniq);
+            u32 ub = 0, db = 0;
+            if ((tid & 63) == 0) { if (um) ub = atomicAdd(&s_nu, (u32)__popcll(um)); if (dm) db = atomicAdd(&s_nd, (u32)__popcll(dm)); }
+            ub = __builtin_amdgcn_readfirstlane(ub); db = __builtin_amdgcn_readfirstlane(db);
+            const u64 lt = (1ull << (tid & 63)) - 1ull;
+            if (uniq) { const u32 o = ub + (u32)__popcll(um & lt); pr_s[o] = (u32)(key >> 32); v_s[o] = sval[i]; }
+            else if (have) s_dl[db + (u32)__popcll(dm & lt)] = (unsigned short)i;
+        }
+        __syncthreads();
+        const u32 nu = s_nu, nd = s_nd;
+        if (nd > 512) goto full_sort;                           // many shared targets: ranking them by counting would cost nd^2
+        for (u32 a = tid; a < nd; a += 256) {
+            const u32 i = s_dl[a];
+            const u64 key = skey[i];
+            u32 rk = 0;
+            for (u32 b = 0; b < nd; ++b) rk += (skey[s_dl[b]] < key) ? 1u : 0u;      // (keys are distinct: the priority is part of them)
+            pr_s[nu + rk] = (u32)(key >> 32);
+            v_s[nu + rk] = sval[i];
+        }
+        __syncthreads();
+    } else {
+full_sort:
     if (npush <= SMALL_RANKSORT) {
         for (u32 i = tid; i < npush; i += 256) {
             const u64 key = skey[i];
@@ -484,6 +588,7 @@ __global__ __launch_bounds__(256) void small_level_kernel(const u32* __restrict_
 #pragma unroll
         for (u32 r = 0; r < 8; ++r) { const u32 i = tid * 8 + r; pr_s[i] = (u32)(k[r] >> 32); v_s[i] = v[r]; }
         __syncthreads();
+    }
     }
     // 6. new priorities, pool slots, segments
     for (u32 i = tid; i < npush; i += 256) {
