@@ -913,17 +913,24 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
     GatherSeg* d_hgtab = nullptr;               // the same table as seen from the device (small levels read it in place)
     if (hipHostGetDevicePointer((void**)&d_hgtab, h_gtab, 0) != hipSuccess) { d_hgtab = nullptr; (void)hipGetLastError(); }
     struct PoolSeg { u32 off, cnt; };
-    struct LevelLists {                                      // per target level: its segments of the pool (sparse: most levels of a
-        std::unordered_map<u32, std::vector<PoolSeg>> m;     // text with long repeats never receive a push)
+    struct LevelLists {                                      // per target level: its segments of the pool.  Flat table while the number
+        std::vector<std::vector<PoolSeg>> flat;              // of levels is moderate (a push costs one vector append: texts with long
+        std::unordered_map<u32, std::vector<PoolSeg>> m;     // repeats make hundreds of them per level), a sparse map for texts that are
+        void init(size_t levels) { if (levels <= ((size_t)1 << 20)) flat.resize(levels); }   // one long run (as many levels as positions)
         const std::vector<PoolSeg>& get(u32 lv) const {
             static const std::vector<PoolSeg> none;
+            if (!flat.empty()) return lv < flat.size() ? flat[lv] : none;
             if (m.empty()) return none;
             auto it = m.find(lv);
             return it == m.end() ? none : it->second;
         }
-        std::vector<PoolSeg>& operator[](u32 lv) { return m[lv]; }
-        void drop(u32 lv) { m.erase(lv); }
+        std::vector<PoolSeg>& operator[](u32 lv) { return !flat.empty() ? flat[lv] : m[lv]; }
+        void drop(u32 lv) {
+            if (!flat.empty()) { if (lv < flat.size()) std::vector<PoolSeg>().swap(flat[lv]); }
+            else m.erase(lv);
+        }
     } pushed_into;
+    pushed_into.init((size_t)maxlcp + 2);
     size_t pool_top = 0;
     u32 prio_base = (u32)n;
 
