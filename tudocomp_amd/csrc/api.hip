@@ -282,9 +282,9 @@ int tdc_gpu_ctx_create(int device, tdc_gpu_ctx** out) {
         if (const char* m = getenv("TDC_GPU_FASTREAD")) ctx->c.fast_read = atoi(m) ? 1 : 0;
         if (ctx->c.fast_read) {
             void* zc = nullptr;
-            if (hipHostMalloc(&zc, 4096 + 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+            if (hipHostMalloc(&zc, Ctx::ZC_WORDS * 4, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
                 void* dv = nullptr;
-                if (hipHostGetDevicePointer(&dv, zc, 0) == hipSuccess) { ctx->c.zc_host = (u32*)zc; ctx->c.zc_dev = (u32*)dv; memset(zc, 0, 4096 + 64); }
+                if (hipHostGetDevicePointer(&dv, zc, 0) == hipSuccess) { ctx->c.zc_host = (u32*)zc; ctx->c.zc_dev = (u32*)dv; memset(zc, 0, Ctx::ZC_WORDS * 4); }
                 else { (void)hipHostFree(zc); (void)hipGetLastError(); }
             } else (void)hipGetLastError();
         }

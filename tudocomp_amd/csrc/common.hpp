@@ -109,7 +109,8 @@ struct Ctx {
     hipEvent_t ev[16] = {};
     void* pinned = nullptr;        // small pinned staging block for device->host scalars
     size_t pinned_size = 0;
-    u32* zc_host = nullptr;        // mapped host block for publish_words_kernel: 1024 data words + the sequence word
+    static constexpr u32 ZC_SEG_OFF = 1040, ZC_WORDS = 1040 + 4096;   // words 1040 ..: up to 2048 (target, start) pairs of a one-workgroup level
+    u32* zc_host = nullptr;        // mapped host block for publish_words_kernel: 1024 data words + the sequence word (+ the segment area)
     u32* zc_dev = nullptr;         // the same block as seen from the device
     u32 zc_seq = 0;
     int fast_read = 1;             // env TDC_GPU_FASTREAD=0: read-backs through hipMemcpyAsync + hipStreamSynchronize

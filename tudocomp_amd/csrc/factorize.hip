@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void small_level_kernel(const u32* __restrict_
                                                            u32* __restrict__ fsrc, u32* __restrict__ pool, u32 prio_base,
                                                            PushSeg* __restrict__ segs, u32 seg_cap, u32* __restrict__ sel_list,
                                                            u32 inline_budget, LevelScalars* __restrict__ sc,
-                                                           u32* zc_dst, u32* zc_flag, u32 zc_seq, unsigned long long* prof) {
+                                                           u32* zc_dst, u32* zc_flag, u32 zc_seq, unsigned long long* prof, u32* zc_segs) {
 #define SPROF(k) do { if (prof) { const unsigned long long now_ = wall_clock64(); acc_prof[k] = now_ - t_prof; t_prof = now_; } } while (0)
     unsigned long long t_prof = prof ? wall_clock64() : 0;
     unsigned long long acc_prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -612,6 +612,10 @@ full_sort:
             if (!(heads & (1u << r))) continue;
             const u32 i = tid * 8 + r, tgt = pr_s[i];
             if (o < SEG_INLINE) { s_out[8 + 2 * o] = tgt; s_out[9 + 2 * o] = i; }
+            if (zc_segs && nseg > SEG_INLINE && o < SMALL_M) {    // more than the inline part holds: the whole list goes straight into the mapped host block (no read-back)
+                __hip_atomic_store(&zc_segs[2 * o], tgt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(&zc_segs[2 * o + 1], i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
             if (o < seg_cap) segs[o] = PushSeg{tgt, i};
             ++o;
         }
@@ -1171,7 +1175,7 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
                 Ctx::ProfScope prof(c, K_SMALL_LEVEL, (u64)m * 16);
                 small_level_kernel<<<1, 256, 0, s>>>(cand + h_segstart[L], m0, pushed, m, pool, d_hgtab, gn, L, threshold, n, cur, prio, phi, fs.flen,
                                                      res8, fs.fsrc, pool + pool_top, prio_base, d_segs, seg_cap, live,
-                                                     /*inline_budget=*/1u << 17, d_sc, zdst, zflag, zseq, d_sprof);
+                                                     /*inline_budget=*/1u << 17, d_sc, zdst, zflag, zseq, d_sprof, zc ? c.zc_dev + Ctx::ZC_SEG_OFF : nullptr);
                 LAUNCH_CHECK();
             }
             const auto hp2 = std::chrono::steady_clock::now();
@@ -1198,6 +1202,7 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
                 if (npush) {
                     if (nseg > seg_cap) throw HipError{hipErrorUnknown, "factorize: too many push targets in one level", (int)__LINE__};
                     if (nseg <= SEG_INLINE) std::copy(h_sc.segs, h_sc.segs + nseg, h_segs.begin());
+                    else if (zc && nseg <= SMALL_M) memcpy(h_segs.data(), c.zc_host + Ctx::ZC_SEG_OFF, (size_t)nseg * sizeof(PushSeg));   // published next to the scalars
                     else c.read_n(d_segs, h_segs.data(), nseg);
                     for (u32 j = 0; j < nseg; ++j) {           // written in order of `start` by one thread
                         const u32 end = (j + 1 < nseg) ? h_segs[j + 1].start : npush;
