@@ -282,9 +282,9 @@ int tdc_gpu_ctx_create(int device, tdc_gpu_ctx** out) {
         if (const char* m = getenv("TDC_GPU_FASTREAD")) ctx->c.fast_read = atoi(m) ? 1 : 0;
         if (ctx->c.fast_read) {
             void* zc = nullptr;
-            if (hipHostMalloc(&zc, Ctx::ZC_WORDS * 4, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+            if (hipHostMalloc(&zc, (size_t)Ctx::ZC_WORDS * Ctx::ZC_BLOCKS * 4, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
                 void* dv = nullptr;
-                if (hipHostGetDevicePointer(&dv, zc, 0) == hipSuccess) { ctx->c.zc_host = (u32*)zc; ctx->c.zc_dev = (u32*)dv; memset(zc, 0, Ctx::ZC_WORDS * 4); }
+                if (hipHostGetDevicePointer(&dv, zc, 0) == hipSuccess) { ctx->c.zc_host = (u32*)zc; ctx->c.zc_dev = (u32*)dv; memset(zc, 0, (size_t)Ctx::ZC_WORDS * Ctx::ZC_BLOCKS * 4); }
                 else { (void)hipHostFree(zc); (void)hipGetLastError(); }
             } else (void)hipGetLastError();
         }
@@ -296,6 +296,7 @@ int tdc_gpu_ctx_create(int device, tdc_gpu_ctx** out) {
         if (const char* m = getenv("TDC_GPU_WINDOW_HALO")) { const int v = atoi(m); ctx->c.window_halo = v < 0 ? 0 : (v > 2048 ? 2048 : v); }
         if (const char* m = getenv("TDC_GPU_WINDOW_LARGE")) ctx->c.window_large_lists = atoi(m) ? 1 : 0;
         if (const char* m = getenv("TDC_GPU_PLCP_SAMPLES")) ctx->c.plcp_samples = atoi(m) != 0;
+        if (const char* m = getenv("TDC_GPU_SMALL_PIPELINE")) ctx->c.small_pipeline = atoi(m) != 0;
         if (const char* m = getenv("TDC_GPU_SA_REFINE")) ctx->c.sa_refine = atoi(m) != 0;
         if (const char* m = getenv("TDC_GPU_SA_FUSED_INIT")) ctx->c.sa_fused_init = atoi(m) != 0;
         if (const char* m = getenv("TDC_GPU_RADIX_LDS")) { const int v = atoi(m); ctx->c.radix_lds = (v >= 0 && v <= 2) ? v : 2; }

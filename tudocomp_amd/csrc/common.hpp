@@ -110,6 +110,7 @@ struct Ctx {
     void* pinned = nullptr;        // small pinned staging block for device->host scalars
     size_t pinned_size = 0;
     static constexpr u32 ZC_SEG_OFF = 1040, ZC_WORDS = 1040 + 4096;   // words 1040 ..: up to 2048 (target, start) pairs of a one-workgroup level
+    static constexpr u32 ZC_BLOCKS = 3;                                // block 0: read() / publish_*; blocks 1, 2: two one-workgroup levels in flight
     u32* zc_host = nullptr;        // mapped host block for publish_words_kernel: 1024 data words + the sequence word (+ the segment area)
     u32* zc_dev = nullptr;         // the same block as seen from the device
     u32 zc_seq = 0;
@@ -118,6 +119,7 @@ struct Ctx {
     int sa_local_sort = 1;         // doubling rounds: sort whole runs inside 2048-element tiles locally (env TDC_GPU_SA_LOCAL=0 disables)
     int radix_waves = 4;           // waves per radix-sort workgroup for large inputs (env TDC_GPU_RADIX_WAVES = 4 | 8; no measurable difference)
     int plcp_samples = 1;          // PLCP: exact values at every 256th position first, as lower bounds for the chunks (env TDC_GPU_PLCP_SAMPLES=0: chunks start from 0)
+    int small_pipeline = 1;        // factorize: the kernel of the next one-workgroup level is queued while the current one runs (env TDC_GPU_SMALL_PIPELINE=0 disables)
     int sa_refine = 1;             // suffix array: small groups of the initial order are refined from the text before the first round (env TDC_GPU_SA_REFINE=0 disables)
     int sa_fused_init = 1;         // suffix array: pass 0 of the initial sort computes its keys from the text (env TDC_GPU_SA_FUSED_INIT=0: separate key kernel)
     int radix_lds = 1;             // radix scatter: reorder the tile in LDS before writing: 0 never, 1 always, 2 for 32-bit keys only
@@ -201,13 +203,13 @@ struct Ctx {
     }
     // for kernels that publish their result themselves (same protocol as publish_words_kernel): the kernel stores its words
     // at *dst (system scope), then `seq` at *flag; publish_wait spins on the flag and copies `bytes` (<= 4096) out
-    bool publish_begin(u32** dst, u32** flag, u32* seq) {
+    bool publish_begin(u32** dst, u32** flag, u32* seq, u32 block = 0) {
         if (!fast_read || !zc_host) return false;
-        *seq = ++zc_seq; *dst = zc_dev; *flag = zc_dev + 1024;
+        *seq = ++zc_seq; *dst = zc_dev + (size_t)block * ZC_WORDS; *flag = *dst + 1024;
         return true;
     }
-    void publish_wait(u32 seq, void* out, size_t bytes) {
-        volatile u32* flag = zc_host + 1024;
+    void publish_wait(u32 seq, void* out, size_t bytes, u32 block = 0) {
+        volatile u32* flag = zc_host + (size_t)block * ZC_WORDS + 1024;
         for (u64 spins = 0;; ++spins) {
             if (__atomic_load_n((const u32*)flag, __ATOMIC_ACQUIRE) == seq) break;
             if ((spins & 0xFFFF) == 0xFFFF) {
@@ -215,7 +217,7 @@ struct Ctx {
                 if (q != hipSuccess && q != hipErrorNotReady) throw HipError{q, __FILE__, __LINE__};
             }
         }
-        memcpy(out, zc_host, bytes);
+        memcpy(out, zc_host + (size_t)block * ZC_WORDS, bytes);
     }
 #else
     bool read_words_fast(const void*, void*, size_t) { return false; }

@@ -44,6 +44,12 @@ struct PushSeg { u32 target, start; };
 struct GatherSeg { u32 src_off, dst_off; };   // pushed part of a level's list = concatenation of pool segments
 constexpr u32 SEG_INLINE = 508;      // segment descriptors that travel with the scalars in one read-back
 
+// Two one-workgroup levels may be in flight: the kernel of level X is queued behind the kernel of the level Y above it before the host
+// has seen Y's result ("speculative": its list was put together without Y's pushes).  It checks Y's published result on the device
+// -- Y gave up, left its factors to a chip-wide launch, or pushed something into X: then X gives up as well, before it has changed
+// anything -- and takes its pool offset and priority base from this block, which every level updates.
+struct SmallCtl { u32 pool_top, prio_base; };
+
 struct LevelScalars {
     u32 nlive, nstale;   // entries with cur == L / threshold <= cur < L
     u32 undecided;       // live entries still undecided after the last round
@@ -272,10 +278,11 @@ __global__ __launch_bounds__(256) void small_level_kernel(const u32* __restrict_
                                                            const u32* __restrict__ pool_all, const GatherSeg* __restrict__ gtab, u32 gn,
                                                            u32 L, u32 threshold, size_t n, u32* cur, u32* prio,
                                                            const u32* __restrict__ phi, u32* __restrict__ flen, u8* __restrict__ res8,
-                                                           u32* __restrict__ fsrc, u32* __restrict__ pool, u32 prio_base,
+                                                           u32* __restrict__ fsrc, u32 pool_top_arg, u32 prio_base_arg,
                                                            PushSeg* __restrict__ segs, u32 seg_cap, u32* __restrict__ sel_list,
                                                            u32 inline_budget, LevelScalars* __restrict__ sc,
-                                                           u32* zc_dst, u32* zc_flag, u32 zc_seq, unsigned long long* prof, u32* zc_segs) {
+                                                           u32* zc_dst, u32* zc_flag, u32 zc_seq, unsigned long long* prof, u32* zc_segs,
+                                                           SmallCtl* __restrict__ ctl, u32 spec, const LevelScalars* prev_sc, const PushSeg* prev_segs) {
 #define SPROF(k) do { if (prof) { const unsigned long long now_ = wall_clock64(); acc_prof[k] = now_ - t_prof; t_prof = now_; } } while (0)
     unsigned long long t_prof = prof ? wall_clock64() : 0;
     unsigned long long acc_prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -289,9 +296,20 @@ __global__ __launch_bounds__(256) void small_level_kernel(const u32* __restrict_
     __shared__ u32 s_sellist[SMALL_SELSCAN];
     __shared__ u32 s_out[SMALL_OUT_WORDS]; // the LevelScalars of this level: nlive nstale undecided selected npush nseg deferred bailed, segments
     const u32 tid = threadIdx.x;
-    if (tid == 0) { s_npush = 0; s_sel = 0; s_live = 0; s_alive = 0; s_cnt = 0; s_lst = 0; }
+    __shared__ u32 s_bail;
+    if (tid == 0) { s_npush = 0; s_sel = 0; s_live = 0; s_alive = 0; s_cnt = 0; s_lst = 0; s_bail = 0; }
     if (tid < 8) s_out[tid] = 0;
     __syncthreads();
+    u32 pool_top = pool_top_arg, prio_base = prio_base_arg;
+    if (spec) {                                             // (see SmallCtl)
+        const u32* ps = (const u32*)prev_sc;
+        const u32 pn = ps[5];
+        if (ps[6] || ps[7] || pn > seg_cap) { if (tid == 0) s_bail = 1; }
+        else for (u32 i = tid; i < pn; i += 256) if (prev_segs[i].target == L) s_bail = 1;
+        __syncthreads();
+        pool_top = ctl->pool_top; prio_base = ctl->prio_base;
+    } else if (tid == 0) { ctl->pool_top = pool_top; ctl->prio_base = prio_base; }
+    u32* const pool = const_cast<u32*>(pool_all) + pool_top;
     // the result goes to the scalars block and, without a further launch, into the mapped host block the host spins on
     auto publish = [&]() {
         __syncthreads();
@@ -306,6 +324,7 @@ __global__ __launch_bounds__(256) void small_level_kernel(const u32* __restrict_
             if (tid == 0) __hip_atomic_store(zc_flag, zc_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     };
+    if (s_bail) { if (tid == 0) s_out[7] = 3; publish(); return; }     // the speculation failed: nothing has been touched
     // 0. drop the erased entries (texts with long repeats carry thousands of them per level).  Eight entries per thread and
     //    step: the position loads are all in flight together, then the eight dependent cur[] loads (one workgroup has no
     //    other way to hide the two round trips)
@@ -619,7 +638,7 @@ full_sort:
             if (o < seg_cap) segs[o] = PushSeg{tgt, i};
             ++o;
         }
-        if (tid == 0) { s_out[5] = nseg; s_out[4] = npush; s_sel = 0; }
+        if (tid == 0) { s_out[5] = nseg; s_out[4] = npush; s_sel = 0; ctl->pool_top = pool_top + npush; ctl->prio_base = prio_base + npush; }
     }
     __syncthreads();
     SPROF(4);
@@ -901,8 +920,12 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
     u64* skeys[2] = { c.arena.get<u64>(n), c.arena.get<u64>(n) };
     u32* svals[2] = { c.arena.get<u32>(n), c.arena.get<u32>(n) };
     LevelScalars* d_sc = (LevelScalars*)c.arena.alloc(sizeof(LevelScalars));
+    LevelScalars* d_sc2[2] = { d_sc, (LevelScalars*)c.arena.alloc(sizeof(LevelScalars)) };     // two one-workgroup levels in flight
+    SmallCtl* d_ctl = (SmallCtl*)c.arena.alloc(sizeof(SmallCtl));
     const u32 seg_cap = 1u << 16;
     PushSeg* d_segs = (PushSeg*)c.arena.alloc(sizeof(PushSeg) * seg_cap);
+    PushSeg* d_segs2[2] = { d_segs, (PushSeg*)c.arena.alloc(sizeof(PushSeg) * seg_cap) };
+    u32 force_general_level = NONE32;                      // a level the one-workgroup kernel gave up on
     std::vector<PushSeg> h_segs(seg_cap);
     LevelScalars h_sc;
 
@@ -1155,67 +1178,147 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
         const u32 m = m0 + m1_total;
         if (m == 0) { pushed_into.drop(L); continue; }
         st->levels++;
-        if (m <= SMALL_RAW) {
+        if (m <= SMALL_RAW && L != force_general_level) {
             // ---- whole level in one workgroup: ONE launch (list read from the pool segments, result published into mapped
-            //      host memory), falling back to the general path if more than SMALL_M entries are still alive
-            const u32 push_max = std::min<u32>(m, SMALL_M);      // at most one push per surviving entry
-            if (pool_top + push_max > n || (u64)prio_base + push_max > 0xFFFFFFFFull)
-                throw HipError{hipErrorUnknown, "factorize: push pool overflow", (int)__LINE__};
-            u32 gn = 0;
-            if (segsL.size() <= SMALL_GATHER && segsL.size() <= gtab_cap && d_hgtab) {
-                // the previous level's kernel has published its result, so it is done with the table
-                u32 tot = 0;
-                for (size_t j = 0; j < segsL.size(); ++j) { h_gtab[j] = GatherSeg{segsL[j].off, tot}; tot += segsL[j].cnt; }
-                gn = (u32)segsL.size();
-            } else gather_all();
-            u32* zdst = nullptr; u32* zflag = nullptr; u32 zseq = 0;
-            const bool zc = c.publish_begin(&zdst, &zflag, &zseq);
-            const auto hp1 = std::chrono::steady_clock::now();
-            {
-                Ctx::ProfScope prof(c, K_SMALL_LEVEL, (u64)m * 16);
-                small_level_kernel<<<1, 256, 0, s>>>(cand + h_segstart[L], m0, pushed, m, pool, d_hgtab, gn, L, threshold, n, cur, prio, phi, fs.flen,
-                                                     res8, fs.fsrc, pool + pool_top, prio_base, d_segs, seg_cap, live,
-                                                     /*inline_budget=*/1u << 17, d_sc, zdst, zflag, zseq, d_sprof, zc ? c.zc_dev + Ctx::ZC_SEG_OFF : nullptr);
-                LAUNCH_CHECK();
-            }
-            const auto hp2 = std::chrono::steady_clock::now();
-            if (zc) c.publish_wait(zseq, &h_sc, sizeof(LevelScalars));
-            else c.read_n((const u32*)d_sc, (u32*)&h_sc, sizeof(LevelScalars) / sizeof(u32));
-            const auto hp3 = std::chrono::steady_clock::now();
-            host_prof[0] += std::chrono::duration<double, std::micro>(hp1 - hp0).count();
-            host_prof[1] += std::chrono::duration<double, std::micro>(hp2 - hp1).count();
-            host_prof[2] += std::chrono::duration<double, std::micro>(hp3 - hp2).count();
-            host_prof[4] += 1;
-            struct PostTimer { double* acc; std::chrono::steady_clock::time_point t0; ~PostTimer() { *acc += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); } } post_timer{&host_prof[3], hp3};
-            if (!h_sc.pad[1]) {
-                if (h_sc.pad[0]) {                         // many long factors: the kills are spread over the whole chip
-                    apply_list_kernel<<<cdiv((size_t)h_sc.selected * 64, 256), 256, 0, s>>>(live, &d_sc->selected, L, n, phi, cur, fs.flen, fs.fsrc);
+            //      host memory), falling back to the general path if more than SMALL_M entries are still alive.  While the kernel
+            //      of a level runs, the kernel of the level below it is already queued ("speculative", see SmallCtl): the host's
+            //      turnaround between two levels -- result, bookkeeping, launch -- no longer leaves the GPU idle.
+            struct Flight { u32 L, m, m0, slot, zseq; bool zc, spec; };
+            auto list_size = [&](u32 lv, u32* m0_out, size_t* nsegs) {       // entries of a level as far as the host knows them
+                const u32 a0 = h_segend[lv] - h_segstart[lv];
+                const std::vector<PoolSeg>& sv = pushed_into.get(lv);
+                u64 t = a0;
+                for (const PoolSeg& sg : sv) t += sg.cnt;
+                *m0_out = a0; *nsegs = sv.size();
+                return t;
+            };
+            u64 inflight_push_max = 0;                              // upper bound of what the levels in flight may still push
+            auto launch_small = [&](u32 lv, u32 slot, bool spec, Flight* f) -> bool {
+                u32 a0; size_t ns;
+                const u64 mm = list_size(lv, &a0, &ns);
+                const std::vector<PoolSeg>& sv = pushed_into.get(lv);
+                const u32 half = gtab_cap / 2;
+                if ((spec || lv != L) && (mm == 0 || mm > SMALL_RAW || ns > SMALL_GATHER || ns > half || !d_hgtab)) return false;
+                const u32 push_max = (u32)std::min<u64>(mm, SMALL_M);          // at most one push per surviving entry
+                if (pool_top + inflight_push_max + push_max > n || (u64)prio_base + inflight_push_max + push_max > 0xFFFFFFFFull) {
+                    if (spec) return false;
+                    throw HipError{hipErrorUnknown, "factorize: push pool overflow", (int)__LINE__};
+                }
+                u32 gn = 0;
+                const u32* pushed_src = pushed;
+                if (ns <= SMALL_GATHER && ns <= half && d_hgtab) {
+                    // (each of the two levels in flight has its own half of the table)
+                    GatherSeg* ht = h_gtab + (size_t)slot * half;
+                    u32 tot = 0;
+                    for (size_t j2 = 0; j2 < ns; ++j2) { ht[j2] = GatherSeg{sv[j2].off, tot}; tot += sv[j2].cnt; }
+                    gn = (u32)ns;
+                } else gather_all();                                 // (never for a speculative launch)
+                u32* zdst = nullptr; u32* zflag = nullptr; u32 zseq = 0;
+                const bool zc = c.publish_begin(&zdst, &zflag, &zseq, 1 + slot);
+                if (spec && !zc) return false;
+                {
+                    Ctx::ProfScope prof(c, K_SMALL_LEVEL, mm * 16);
+                    small_level_kernel<<<1, 256, 0, s>>>(cand + h_segstart[lv], a0, pushed_src, (u32)mm, pool, d_hgtab ? d_hgtab + (size_t)slot * half : nullptr, gn, lv,
+                                                         threshold, n, cur, prio, phi, fs.flen, res8, fs.fsrc, (u32)pool_top, prio_base, d_segs2[slot], seg_cap, live,
+                                                         /*inline_budget=*/1u << 17, d_sc2[slot], zdst, zflag, zseq, d_sprof,
+                                                         zc ? c.zc_dev + (size_t)(1 + slot) * Ctx::ZC_WORDS + Ctx::ZC_SEG_OFF : nullptr,
+                                                         d_ctl, spec ? 1u : 0u, d_sc2[slot ^ 1], d_segs2[slot ^ 1]);
                     LAUNCH_CHECK();
                 }
-                pushed_into.drop(L);
-                st->small_levels++;
-                if (h_sc.nlive == 0) ++nolive_run; else nolive_run = 0;
-                if (h_sc.nlive == 0 && h_sc.nstale == 0) { probe_dead = true; ++dead_levels_run; continue; }   // small levels do not count for the purge heuristic
-                dead_levels_run = 0;
-                st->factors += h_sc.selected;
-                const u32 npush = h_sc.npush, nseg = h_sc.nseg;
-                if (npush) {
-                    if (nseg > seg_cap) throw HipError{hipErrorUnknown, "factorize: too many push targets in one level", (int)__LINE__};
-                    if (nseg <= SEG_INLINE) std::copy(h_sc.segs, h_sc.segs + nseg, h_segs.begin());
-                    else if (zc && nseg <= SMALL_M) memcpy(h_segs.data(), c.zc_host + Ctx::ZC_SEG_OFF, (size_t)nseg * sizeof(PushSeg));   // published next to the scalars
-                    else c.read_n(d_segs, h_segs.data(), nseg);
-                    for (u32 j = 0; j < nseg; ++j) {           // written in order of `start` by one thread
-                        const u32 end = (j + 1 < nseg) ? h_segs[j + 1].start : npush;
-                        const u32 tgt = h_segs[j].target;
-                        if (tgt >= L || tgt < threshold) throw HipError{hipErrorUnknown, "factorize: bad push target", (int)__LINE__};
-                        pushed_into[tgt].push_back(PoolSeg{(u32)pool_top + h_segs[j].start, end - h_segs[j].start});
+                inflight_push_max += push_max;
+                *f = Flight{lv, (u32)mm, a0, slot, zseq, zc, spec};
+                return true;
+            };
+            auto wait_small = [&](const Flight& f) {
+                if (f.zc) c.publish_wait(f.zseq, &h_sc, sizeof(LevelScalars), 1 + f.slot);
+                else c.read_n((const u32*)d_sc2[f.slot], (u32*)&h_sc, sizeof(LevelScalars) / sizeof(u32));
+            };
+            Flight cur_f, next_f;
+            const auto hp1 = std::chrono::steady_clock::now();
+            launch_small(L, 0, false, &cur_f);
+            const auto hp2 = std::chrono::steady_clock::now();
+            host_prof[0] += std::chrono::duration<double, std::micro>(hp1 - hp0).count();
+            host_prof[1] += std::chrono::duration<double, std::micro>(hp2 - hp1).count();
+            bool general_path = false, stop_chain = false;
+            for (;;) {
+                // queue the level below behind it, unless something the host has to decide first may be due there
+                bool has_next = false;
+                if (c.small_pipeline && !stop_chain && cur_f.L > threshold && cur_f.L - 1 > lcut && !purge_pays && dead_streak < 4 &&
+                    nolive_run + 2 < stale_trigger)
+                    has_next = launch_small(cur_f.L - 1, cur_f.slot ^ 1, true, &next_f);
+                const auto hw0 = std::chrono::steady_clock::now();
+                wait_small(cur_f);
+                const auto hw1 = std::chrono::steady_clock::now();
+                host_prof[2] += std::chrono::duration<double, std::micro>(hw1 - hw0).count();
+                host_prof[4] += 1;
+                struct PostTimer { double* acc; std::chrono::steady_clock::time_point t0; ~PostTimer() { *acc += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); } } post_timer{&host_prof[3], hw1};
+                const u32 LL = cur_f.L;
+                bool redo = false;
+                if (h_sc.pad[1] == 3) redo = true;                   // the speculation failed: the level has not been touched
+                else if (h_sc.pad[1]) general_path = true;           // too many survivors: the multi-launch path takes the level
+                else {
+                    if (h_sc.pad[0]) {                             // many long factors: the kills are spread over the whole chip
+                        apply_list_kernel<<<cdiv((size_t)h_sc.selected * 64, 256), 256, 0, s>>>(live, &d_sc2[cur_f.slot]->selected, LL, n, phi, cur, fs.flen, fs.fsrc);
+                        LAUNCH_CHECK();
                     }
-                    pool_top += npush;
-                    prio_base += npush;
-                    st->pushes += npush;
+                    pushed_into.drop(LL);
+                    st->small_levels++;
+                    if (LL != L) { st->levels++; ++levels_since_purge; }   // (the level the outer loop stands on has been counted)
+                    if (h_sc.nlive == 0) ++nolive_run; else nolive_run = 0;
+                    if (h_sc.nlive == 0 && h_sc.nstale == 0) { probe_dead = true; ++dead_levels_run; stop_chain = true; }   // small levels do not count for the purge heuristic
+                    else {
+                        probe_dead = false;
+                        dead_levels_run = 0;
+                        st->factors += h_sc.selected;
+                        const u32 npush = h_sc.npush, nseg = h_sc.nseg;
+                        if (npush) {
+                            if (nseg > seg_cap) throw HipError{hipErrorUnknown, "factorize: too many push targets in one level", (int)__LINE__};
+                            if (nseg <= SEG_INLINE) std::copy(h_sc.segs, h_sc.segs + nseg, h_segs.begin());
+                            else if (cur_f.zc && nseg <= SMALL_M)
+                                memcpy(h_segs.data(), c.zc_host + (size_t)(1 + cur_f.slot) * Ctx::ZC_WORDS + Ctx::ZC_SEG_OFF, (size_t)nseg * sizeof(PushSeg));   // published next to the scalars
+                            else c.read_n(d_segs2[cur_f.slot], h_segs.data(), nseg);
+                            for (u32 j2 = 0; j2 < nseg; ++j2) {       // written in order of `start` by one thread
+                                const u32 end = (j2 + 1 < nseg) ? h_segs[j2 + 1].start : npush;
+                                const u32 tgt = h_segs[j2].target;
+                                if (tgt >= LL || tgt < threshold) throw HipError{hipErrorUnknown, "factorize: bad push target", (int)__LINE__};
+                                pushed_into[tgt].push_back(PoolSeg{(u32)pool_top + h_segs[j2].start, end - h_segs[j2].start});
+                            }
+                            pool_top += npush;
+                            prio_base += npush;
+                            st->pushes += npush;
+                        }
+                    }
+                    if (nolive_run + 2 >= stale_trigger) stop_chain = true;
                 }
-                continue;
+                inflight_push_max = 0;
+                if (general_path) {
+                    if (has_next) wait_small(next_f);               // (it gave up as well: the level above it did)
+                    force_general_level = LL;
+                    if (LL != L) { L = LL + 1; general_path = false; }   // the outer loop comes back to this level and takes the multi-launch path
+                    break;
+                }
+                if (redo) {                                          // run the level again with the list the host knows now
+                    if (has_next) wait_small(next_f);               // (gave up as well)
+                    u32 a0; size_t ns;
+                    const u64 mm = list_size(LL, &a0, &ns);
+                    if (mm == 0 || mm > SMALL_RAW || !launch_small(LL, 0, false, &cur_f)) { L = LL + 1; break; }   // (too large now: the outer loop decides)
+                    continue;
+                }
+                if (!has_next) { L = LL; break; }                    // the outer loop goes on below this level
+                // the level below is in flight (or already done): it is the current one now
+                if (h_sc.pad[0]) {
+                    // this level's factors were applied by a separate launch behind the queued kernel, which gave up for that reason
+                    wait_small(next_f);
+                    u32 a0; size_t ns;
+                    const u64 mm = list_size(LL - 1, &a0, &ns);
+                    if (mm == 0 || mm > SMALL_RAW || !launch_small(LL - 1, 0, false, &cur_f)) { L = LL; break; }
+                    continue;
+                }
+                inflight_push_max = std::min<u64>(next_f.m, SMALL_M);
+                cur_f = next_f;
             }
+            if (!general_path) continue;
+            // (general path for level L: its list is re-read below)
         }
         if (!gathered) gather_all();
         pushed_into.drop(L);
