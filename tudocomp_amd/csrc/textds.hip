@@ -39,7 +39,10 @@ void build_phi(Ctx& c, const u32* sa, size_t n, u32* phi) {
     LAUNCH_CHECK();
 }
 
-constexpr int PLCP_CHUNK = 16;                    // consecutive text positions per thread
+#ifndef TDC_PLCP_CHUNK
+#define TDC_PLCP_CHUNK 16
+#endif
+constexpr int PLCP_CHUNK = TDC_PLCP_CHUNK;                    // consecutive text positions per thread
 constexpr int PLCP_TILE = 256 * PLCP_CHUNK;       // 8192 positions per workgroup
 constexpr int PLCP_HALO = 512;                    // text bytes staged beyond the tile for the T[i+l] side
 
