@@ -319,7 +319,12 @@ template <typename T> __device__ __forceinline__ void lds_store(T* p, T v) { *(v
 __device__ __forceinline__ u64 wave_match_lds(unsigned long long* M, u32 d, bool valid, u64 lanebit) {
     const u32 d0 = __builtin_amdgcn_readfirstlane(d);
     if (__all(valid && d == d0)) return ~0ull;                   // whole row in one bin (high-order digits, long runs)
+#ifdef TDC_MATCH_B64
     if (valid) atomicOr(&M[d], (unsigned long long)lanebit);
+#else
+    // (the lane's bit lives in one 32-bit half of the slot: a 4-byte LDS atomic occupies one bank instead of two)
+    if (valid) atomicOr((unsigned*)&M[d] + (lane_id() >> 5), (unsigned)(lanebit >> (32 * (lane_id() >> 5))));
+#endif
     __builtin_amdgcn_wave_barrier();
     const u64 peers = valid ? lds_load(&M[d]) : 0ull;
     __builtin_amdgcn_wave_barrier();
