@@ -49,6 +49,7 @@ template <typename F>
 int guarded(tdc_gpu_ctx* ctx, F&& f) {
     if (!ctx) return TDC_GPU_ERR_ARG;
     ctx->last_error.clear();
+    ctx->c.hist_ptr = nullptr;                   // the cached byte histogram belongs to ONE call (same address, other text: stale)
     DeviceGuard dg(ctx->c.device);               // the caller's current device is restored on every exit path
     try {
         HIP_TRY(dg.enter());
@@ -130,26 +131,21 @@ struct DevArrays {
     u32 maxlcp = 0;
 };
 
-// Checks that the 0 byte occurs exactly once (at n-1, already verified by the caller).
-__global__ void count_zero_kernel(const u8* __restrict__ text, size_t n, u32* __restrict__ cnt) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    u32 local = 0;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) local += (text[i] == 0);
-    local = wave_reduce_sum(local);
-    if (lane_id() == 0 && local) atomicAdd(cnt, local);
-}
-
+// Checks that the 0 byte occurs exactly once, at n - 1 (ds/TextDS.hpp:132-138).  The count comes from the byte histogram of the text,
+// which the suffix array needs anyway (one pass for both; a host-buffer call has accumulated it behind the upload already).
 void validate_device_text(Ctx& c, const u8* d_text, size_t n) {
-    const size_t mark = c.arena.mark();
-    u32* d_cnt = c.arena.get<u32>(2);
-    HIP_TRY(hipMemsetAsync(d_cnt, 0, 2 * sizeof(u32), c.stream));
-    unsigned g = cdiv(n, 256 * 16); if (g > 2048) g = 2048; if (g == 0) g = 1;
-    count_zero_kernel<<<g, 256, 0, c.stream>>>(d_text, n, d_cnt);
-    LAUNCH_CHECK();
+    if (!(c.hist_ptr == d_text && c.hist_n == n)) {
+        const size_t mark = c.arena.mark();
+        u32* d_hist = c.arena.get<u32>(256);
+        HIP_TRY(hipMemsetAsync(d_hist, 0, 256 * sizeof(u32), c.stream));
+        text_histogram_add(c, d_text, n, d_hist);
+        text_histogram_finish(c, d_text, n, d_hist);
+        c.arena.release(mark);
+    }
     u8 last = 1;
     HIP_TRY(hipMemcpyAsync(&last, d_text + n - 1, 1, hipMemcpyDeviceToHost, c.stream));
-    const u32 zeros = c.read(d_cnt);
-    c.arena.release(mark);
+    HIP_TRY(hipStreamSynchronize(c.stream));
+    const u32 zeros = c.hist_cache[0];
     if (last != 0) throw ArgError{TDC_GPU_ERR_NO_SENTINEL, "text does not end with a 0 sentinel"};
     if (zeros != 1) throw ArgError{TDC_GPU_ERR_ARG, "text contains 0 bytes besides the sentinel (escape the input first)"};
 }
@@ -434,7 +430,22 @@ void compress_host(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, bool raw, ui
         if (escape_device(c, d_raw, n, d_text) != tn) throw HipError{hipErrorUnknown, "escape: length mismatch", (int)__LINE__};
     } else {
         d_text = c.arena.get<u8>(n + 64);
-        HIP_TRY(hipMemcpyAsync(d_text, text, n, hipMemcpyHostToDevice, c.stream));
+        if (n >= ((size_t)1 << 26) && c.copy_stream) {
+            // the upload in eight chunks on the copy stream, the byte histogram of every chunk behind it on the compute stream
+            u32* d_hist = c.arena.get<u32>(256);
+            HIP_TRY(hipMemsetAsync(d_hist, 0, 256 * sizeof(u32), c.stream));
+            HIP_TRY(hipEventRecord(c.ev_copy[8], c.stream));                   // (the copy stream starts behind whatever the compute stream did before)
+            HIP_TRY(hipStreamWaitEvent(c.copy_stream, c.ev_copy[8], 0));
+            const size_t CH = 8, step = ((n + CH - 1) / CH + 255) & ~(size_t)255;
+            for (size_t q = 0, off = 0; q < CH && off < n; ++q, off += step) {
+                const size_t len = std::min(step, n - off);
+                HIP_TRY(hipMemcpyAsync(d_text + off, text + off, len, hipMemcpyHostToDevice, c.copy_stream));
+                HIP_TRY(hipEventRecord(c.ev_copy[q], c.copy_stream));
+                HIP_TRY(hipStreamWaitEvent(c.stream, c.ev_copy[q], 0));
+                text_histogram_add(c, d_text + off, len, d_hist);
+            }
+            text_histogram_finish(c, d_text, n, d_hist);
+        } else HIP_TRY(hipMemcpyAsync(d_text, text, n, hipMemcpyHostToDevice, c.stream));
     }
     const int e1 = ev.tick();
     u8* d_out = nullptr;

@@ -137,6 +137,11 @@ struct Ctx {
 
     // overlapped D2H of the compressed stream (end-to-end entry point with a caller buffer): while the pack kernel works on the
     // later tiles, the finished front part of the stream already travels to the host on a second stream
+    // byte histogram of the text a pipeline call works on: one pass serves the sentinel check (count of 0 bytes) and the suffix array's
+    // symbol codes; a host-buffer call accumulates it chunk by chunk behind the chunks of the upload
+    u32 hist_cache[256] = {};
+    const u8* hist_ptr = nullptr;
+    size_t hist_n = 0;
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_copy[10] = {};
     u8* d2h_host = nullptr;        // destination (host) of the running call, or null

@@ -15,6 +15,9 @@ struct SAStats { u32 rounds = 0; u32 sym_bits = 0; u32 init_syms = 0; u64 sorted
 // a2+a3: ds/SADivSufSort.hpp:27-51 and ds/ISAFromSA.hpp:30-43.
 // Prefix doubling; text[n-1] must be the unique 0.  sa and isa are caller-provided (n entries each).
 void build_suffix_array(Ctx& c, const u8* text, size_t n, u32* sa, u32* isa, SAStats* st);
+// byte histogram of a text into the context's cache (c.hist_cache / hist_ptr / hist_n): add() per part, finish() once
+void text_histogram_add(Ctx& c, const u8* part, size_t len, u32* d_hist);
+void text_histogram_finish(Ctx& c, const u8* text, size_t n, const u32* d_hist);
 
 // a4: ds/PhiFromSA.hpp:35-45
 void build_phi(Ctx& c, const u32* sa, size_t n, u32* phi);

@@ -31,6 +31,17 @@ __global__ __launch_bounds__(256) void byte_hist_kernel(const u8* __restrict__ t
     if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
 }
 
+void text_histogram_add(Ctx& c, const u8* part, size_t len, u32* d_hist) {       // d_hist: 256 device counters, accumulated
+    if (!len) return;
+    unsigned g = cdiv(len, 256 * 16); if (g > 2048) g = 2048; if (g == 0) g = 1;
+    byte_hist_kernel<<<g, 256, 0, c.stream>>>(part, len, d_hist);
+    LAUNCH_CHECK();
+}
+void text_histogram_finish(Ctx& c, const u8* text, size_t n, const u32* d_hist) {   // read-back into the context's cache
+    c.read_n(d_hist, c.hist_cache, 256);
+    c.hist_ptr = text; c.hist_n = n;
+}
+
 // 1024 positions per workgroup, symbols staged (already re-coded) in LDS.
 // key = the first k symbols of the suffix as a k-digit number in base sigma (dense codes): order-preserving and as many
 // symbols as 64 bits can hold (13 instead of 12 for the 29 symbols of the English-like corpus, 27 instead of 21 for DNA)
@@ -446,15 +457,13 @@ void build_suffix_array(Ctx& c, const u8* text, size_t n, u32* sa, u32* isa, SAS
     const size_t mark = c.arena.mark();
 
     // --- dense symbol codes -----------------------------------------------------------------------
-    u32* d_hist = c.arena.get<u32>(256);
-    HIP_TRY(hipMemsetAsync(d_hist, 0, 256 * sizeof(u32), s));
-    {
-        unsigned g = cdiv(n, 256 * 16); if (g > 2048) g = 2048; if (g == 0) g = 1;
-        byte_hist_kernel<<<g, 256, 0, s>>>(text, n, d_hist);
-        LAUNCH_CHECK();
+    if (!(c.hist_ptr == text && c.hist_n == n)) {            // (a pipeline call has usually counted the bytes already: sentinel check)
+        u32* d_hist = c.arena.get<u32>(256);
+        HIP_TRY(hipMemsetAsync(d_hist, 0, 256 * sizeof(u32), s));
+        text_histogram_add(c, text, n, d_hist);
+        text_histogram_finish(c, text, n, d_hist);
     }
-    u32 h_hist[256];
-    c.read_n(d_hist, h_hist, 256);
+    const u32* h_hist = c.hist_cache;
     CodeMap cm;
     u32 sigma = 0;
     for (int i = 0; i < 256; ++i) { cm.code[i] = (u8)sigma; if (h_hist[i]) ++sigma; }
