@@ -171,8 +171,8 @@ __device__ __forceinline__ u64 rf_text_key(const RefineGen& g, const u8* __restr
     }
     return key;
 }
-__global__ __launch_bounds__(256) void sa_refine_kernel(const u64* __restrict__ keys, u32* __restrict__ vals, size_t m, RefineGen g,
-                                                        u8* __restrict__ flags) {
+__global__ __launch_bounds__(256) void sa_refine_kernel(const u64* __restrict__ keys, const u32* __restrict__ vals, size_t m, RefineGen g,
+                                                        u8* __restrict__ flags, u32* __restrict__ vals_out) {
     __shared__ u64 sk[RF_TILE + 2];          // keys of the elements t0 - 1 .. t0 + 2048, later the second keys of the refined elements
     __shared__ u32 sp[RF_TILE], snew[RF_TILE];
     __shared__ u64 hb[RF_TILE / 64 + 1];     // group heads of the tile as a bitmap; bit 2048: the element behind the tile starts a group
@@ -240,9 +240,9 @@ __global__ __launch_bounds__(256) void sa_refine_kernel(const u64* __restrict__ 
         if (mine & (1u << r)) k2[r] = rf_text_key(g, code, (size_t)sp[(u32)r * 256 + threadIdx.x] + (size_t)g.k);
     if (__any(mine != 0) && lane == 0) s_any = 1;
     __syncthreads();                                           // (every thread is done with the first keys)
-    if (s_any == 0) {                                          // nothing to refine here: only the flags go out
+    if (s_any == 0) {                                          // nothing to refine here: the order as it is, and the flags
 #pragma unroll
-        for (int r = 0; r < 8; ++r) { const u32 e = (u32)r * 256 + threadIdx.x; if (t0 + e < m) flags[t0 + e] = sflag[e]; }
+        for (int r = 0; r < 8; ++r) { const u32 e = (u32)r * 256 + threadIdx.x; if (t0 + e < m) { vals_out[t0 + e] = sp[e]; flags[t0 + e] = sflag[e]; } }
         return;
     }
 #pragma unroll
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void sa_refine_kernel(const u64* __restrict__ 
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         const u32 e = (u32)r * 256 + threadIdx.x;
-        if (t0 + e < m) { vals[t0 + e] = snew[e]; flags[t0 + e] = sflag[e]; }
+        if (t0 + e < m) { vals_out[t0 + e] = snew[e]; flags[t0 + e] = sflag[e]; }
     }
 }
 
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256) void sa_groups_kernel(const u64* __restrict__ 
         u64 kk = 0; u32 vv = 0, pp = 0;
         if (i < m) {
             kk = hflags ? 0ull : keys[i]; vv = vals[i]; pp = FIRST ? (u32)i : a_pos[i];
-            sa[pp] = vv;
+            if (!(FIRST && vals == sa)) sa[pp] = vv;      // (after a refinement the refined order already IS the suffix array so far)
         }
         sk[gr_pad(e + 1)] = kk; sv[gr_pad(e)] = vv; sp[gr_pad(e)] = pp;
     }
@@ -517,7 +517,7 @@ void build_suffix_array(Ctx& c, const u8* text, size_t n, u32* sa, u32* isa, SAS
         memcpy(rg.code, cm.code, 256);
         u8* fl = (u8*)keep;                                  // free until the rounds use it as class bytes
         Ctx::ProfScope prof(c, K_SA_BUILD_KEYS, (u64)n * 17 + (u64)n * 8);     // key + position in, position + flag out; ~0.4 scattered text reads per element
-        sa_refine_kernel<<<cdiv(n, RF_TILE), 256, 0, s>>>(keys[x], vals[x], n, rg, fl);
+        sa_refine_kernel<<<cdiv(n, RF_TILE), 256, 0, s>>>(keys[x], vals[x], n, rg, fl, sa);       // the refined order goes straight into sa[]
         LAUNCH_CHECK();
         hflags = fl;
     }
@@ -531,12 +531,12 @@ void build_suffix_array(Ctx& c, const u8* text, size_t n, u32* sa, u32* isa, SAS
         const bool bucketed = c.bucket_scatter && n >= ((size_t)1 << 22);
         {   // per element: read key + value (12 B), write sa + head (8 B) + the kept elements (12 B each, about half of them)
             Ctx::ProfScope prof(c, K_SA_RANK_SCATTER, (u64)n * 26);
-            sa_groups_kernel<true><<<tiles, 256, 0, s>>>(keys[x], vals[x], nullptr, n, bn, sa, rank, bucketed ? head : nullptr, A_sa, A_pos, A_r1,
+            sa_groups_kernel<true><<<tiles, 256, 0, s>>>(keys[x], hflags ? sa : vals[x], nullptr, n, bn, sa, rank, bucketed ? head : nullptr, A_sa, A_pos, A_r1,
                                                          gdesc, gticket, d_total, c.d_err, tiles, hflags);
             LAUNCH_CHECK();
         }
         // rank[vals[j]] = head[j] through a partition by destination window; the other key buffer and the B lists are free scratch
-        if (bucketed) bucketed_scatter_u32(c, vals[x], head, n, rank, n, (u32*)keys[x ^ 1], vals[x ^ 1], B_sa, B_pos, true);   // vals[x] = every position once
+        if (bucketed) bucketed_scatter_u32(c, hflags ? sa : vals[x], head, n, rank, n, (u32*)keys[x ^ 1], vals[x ^ 1], B_sa, B_pos, true);   // every position once
     }
     size_t m = c.read(d_total);
     st->rounds = 1;
