@@ -248,13 +248,8 @@ __global__ __launch_bounds__(TT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
             u32 pre0 = 0, pre1 = 0;
             {
                 u64 mm = amask;
-#ifdef TDC_WIN_FAKE_PRIO       // timing experiment only (wrong results): no global priority loads at all
-                if (mm) { pre0 = (u32)(w0 + base + __builtin_ctzll(mm)) * 2654435761u; mm &= mm - 1; }
-                if (mm) { pre1 = (u32)(w0 + base + __builtin_ctzll(mm)) * 2654435761u; }
-#else
                 if (mm) { pre0 = prio_g[w0 + base + __builtin_ctzll(mm)]; mm &= mm - 1; }   // (a window-local priority is read behind the full barrier below)
                 if (mm) { pre1 = prio_g[w0 + base + __builtin_ctzll(mm)]; }
-#endif
             }
             WPROF(2);
             const u32 cnt = (u32)__popcll(amask);
@@ -276,11 +271,7 @@ __global__ __launch_bounds__(TT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                 const int pos = base + bit;
                 const u32 cv = cur8[PA(pos)];
                 const u32 local = res8[PA(pos)] & S_LOCAL;
-#ifdef TDC_WIN_FAKE_PRIO
-                const u32 pr = local ? lprio[pos] : ((q == 0) ? pre0 : (q == 1) ? pre1 : (u32)(w0 + pos) * 2654435761u);
-#else
                 const u32 pr = local ? lprio[pos] : ((q == 0) ? pre0 : (q == 1) ? pre1 : prio_g[w0 + pos]);
-#endif
                 const u32 st = (cv == L ? S_UND : S_STALE) | local;
                 ent[off] = ((u64)((cv << 24) | (st << 16) | (u32)pos) << 32) | pr;
                 if (cv == L) ++my_und;
