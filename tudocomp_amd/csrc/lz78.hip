@@ -10,33 +10,54 @@
 #include "prim.hpp"
 
 #include <vector>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <new>
 
 namespace tdc {
 
 // ---- host: LZ78 parse ------------------------------------------------------------------------------------------
 namespace {
 struct PhraseTable {                 // open addressing: key = (parent << 8 | byte) + 1, value = child id
-    std::vector<u64> keys;
-    std::vector<u32> vals;
+    struct Slot { u64 key; u32 val; u32 pad; };          // key and value in one 16-byte slot: a step down the trie is ONE cache miss
+    // the table of a 1 GB input is gigabytes large and every step lands on a random page: huge pages where the kernel grants them
+    struct Buf {
+        Slot* p = nullptr; size_t n = 0;
+        ~Buf() { free(p); }
+        void alloc(size_t count) {
+            free(p); p = nullptr; n = count;
+            const size_t bytes = (count * sizeof(Slot) + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+            p = (Slot*)aligned_alloc((size_t)2 << 20, bytes);
+            if (!p) throw std::bad_alloc();
+#ifdef MADV_HUGEPAGE
+            (void)madvise(p, bytes, MADV_HUGEPAGE);
+#endif
+            memset(p, 0, count * sizeof(Slot));
+        }
+        Slot& operator[](size_t i) { return p[i]; }
+        const Slot& operator[](size_t i) const { return p[i]; }
+        size_t size() const { return n; }
+        void swap(Buf& o) { std::swap(p, o.p); std::swap(n, o.n); }
+    } slots;
     u64 mask = 0;
     size_t used = 0;
-    void init(size_t cap_pow2) { keys.assign(cap_pow2, 0); vals.assign(cap_pow2, 0); mask = cap_pow2 - 1; used = 0; }
+    void init(size_t cap_pow2) { slots.alloc(cap_pow2); mask = cap_pow2 - 1; used = 0; }
     static u64 hash(u64 k) { k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33; return k; }
     void grow() {
-        std::vector<u64> ok; ok.swap(keys);
-        std::vector<u32> ov; ov.swap(vals);
+        Buf os; os.swap(slots);
         init((mask + 1) * 2);
-        for (size_t i = 0; i < ok.size(); ++i) if (ok[i]) insert(ok[i], ov[i]);
+        for (size_t i = 0; i < os.size(); ++i) if (os[i].key) insert(os[i].key, os[i].val);
     }
     void insert(u64 key, u32 val) {
         u64 h = hash(key) & mask;
-        while (keys[h]) h = (h + 1) & mask;
-        keys[h] = key; vals[h] = val; ++used;
+        while (slots[h].key) h = (h + 1) & mask;
+        slots[h].key = key; slots[h].val = val; ++used;
     }
     // returns child id or 0xFFFFFFFF
     u32 find(u64 key) const {
         u64 h = hash(key) & mask;
-        while (keys[h]) { if (keys[h] == key) return vals[h]; h = (h + 1) & mask; }
+        while (slots[h].key) { if (slots[h].key == key) return slots[h].val; h = (h + 1) & mask; }
         return NONE32;
     }
 };
