@@ -286,7 +286,7 @@ int tdc_gpu_ctx_create(int device, tdc_gpu_ctx** out) {
         }
         HIP_TRY(hipMalloc((void**)&ctx->c.d_err, 256));
         HIP_TRY(hipMemset(ctx->c.d_err, 0, 256));
-        if (const char* m = getenv("TDC_GPU_SA_LOCAL")) ctx->c.sa_local_sort = atoi(m) ? 1 : 0;
+        if (const char* m = getenv("TDC_GPU_SA_LOCAL")) ctx->c.sa_local_sort = atoi(m);
         if (const char* m = getenv("TDC_GPU_RADIX_WAVES")) ctx->c.radix_waves = (atoi(m) == 8) ? 8 : 4;
         if (const char* m = getenv("TDC_GPU_WINDOW_LCUT")) { const int v = atoi(m); ctx->c.window_lcut = v < 0 ? 0 : (v > 63 ? 63 : v); }
         if (const char* m = getenv("TDC_GPU_WINDOW_HALO")) { const int v = atoi(m); ctx->c.window_halo = v < 0 ? 0 : (v > 2048 ? 2048 : v); }
