@@ -9,7 +9,7 @@ src, out = sys.argv[1], sys.argv[2]
 f = glob.glob(src + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 rows = rows[len(rows) // 2:]                      # the second of the two identical calls
-short = lambda n: n.split("(")[0].replace("void ", "").replace("tdc::", "")[:70]
+short = lambda n: n.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("tdc::", "")[:70]
 tot = collections.OrderedDict()
 with open(out + "_seq.txt", "w") as g:
     t0 = int(rows[0]["Start_Timestamp"])

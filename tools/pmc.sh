@@ -17,7 +17,7 @@ cnt = collections.Counter()
 names = []
 for f in glob.glob(src + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("tdc::", "")[:60]
+        k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("tdc::", "")[:60]
         c = r["Counter_Name"]
         if c not in names: names.append(c)
         acc[k][c] += float(r["Counter_Value"])
