@@ -38,28 +38,56 @@ def _texts():
 TEXTS = _texts()
 
 
-@pytest.fixture(scope="module")
-def ctx_plain():
+def test_round_sort_choice_on_large_groups(gpu_ctx, ctx_plain, ctx_global_rounds):
+    """4 MiB of a tiny vocabulary: millions of unresolved suffixes in large groups after the initial sort -- the rounds take the
+    global splitter sort (by the library's own choice in the first two contexts, forced in the third); all three must give the
+    oracle's suffix array."""
+    rng = np.random.default_rng(77)
+    voc = [bytes(rng.integers(97, 100, int(rng.integers(2, 7)), dtype=np.uint8)) for _ in range(12)]
+    data = b" ".join(voc[int(i)] for i in rng.integers(0, 12, 900_000))[:4_000_000]
+    text = O.escape(data)
+    sa = O.suffix_array(text)
+    for ctx in (gpu_ctx, ctx_plain, ctx_global_rounds):
+        g_sa, g_isa = ctx.suffix_array(text)
+        assert np.array_equal(g_sa, sa)
+        assert np.array_equal(g_isa[sa], np.arange(len(sa), dtype=np.uint32))
+
+
+def _ctx_with(var, value):
     import os
-    old = os.environ.get("TDC_GPU_SA_REFINE")
-    os.environ["TDC_GPU_SA_REFINE"] = "0"
+    old = os.environ.get(var)
+    os.environ[var] = value
     try:
-        c = T.Context(0)
+        return T.Context(0)
     finally:
         if old is None:
-            del os.environ["TDC_GPU_SA_REFINE"]
+            del os.environ[var]
         else:
-            os.environ["TDC_GPU_SA_REFINE"] = old
+            os.environ[var] = old
+
+
+@pytest.fixture(scope="module")
+def ctx_plain():
+    c = _ctx_with("TDC_GPU_SA_REFINE", "0")
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def ctx_global_rounds():
+    """Doubling rounds sorted by one splitter sort of the whole active list (the choice the library makes by itself where the
+    unresolved groups are large; forced here so that small texts take it too -- it needs 2^20 active suffixes to apply)."""
+    c = _ctx_with("TDC_GPU_SA_LOCAL", "2")
     yield c
     c.close()
 
 
 @pytest.mark.parametrize("name,data", TEXTS, ids=[t[0] for t in TEXTS])
-def test_text_index_with_and_without_refinement(gpu_ctx, ctx_plain, name, data):
+def test_text_index_with_and_without_refinement(gpu_ctx, ctx_plain, ctx_global_rounds, name, data):
     text = O.escape(data)
     sa = O.suffix_array(text)
     isa, phi, plcp, maxlcp = O.isa_phi_plcp(text, sa)
-    for label, ctx in (("refined", gpu_ctx), ("plain", ctx_plain)):
+    for label, ctx in (("refined", gpu_ctx), ("plain", ctx_plain), ("global rounds", ctx_global_rounds)):
         g = ctx.textds(text)
         assert np.array_equal(g["sa"], sa), "%s %s: SA" % (name, label)
         assert np.array_equal(g["isa"], isa), "%s %s: ISA" % (name, label)
