@@ -70,6 +70,10 @@ typedef struct {
     uint32_t purges;            /* bulk removals of erased candidates                           */
     uint32_t window_pass;       /* low levels window-local in one launch: 0 not used, 1 done, 2 fell back to the level loop */
     uint32_t window_lcut;       /* highest level handed to the (last) window pass                */
+    uint32_t sa_key_words;      /* 64-bit words of the initial suffix-sort key (0: classic path, 1 | 2: wide bit-packed keys) */
+    uint32_t sa_text_rounds;    /* rank-free refinement rounds keyed from the text (wide path)     */
+    uint32_t sa_mode;           /* 1: ISA / Phi / PLCP came from the fused scatter of the final suffix array, 0: classic */
+    uint32_t reserved0;
 } tdc_gpu_stats;
 
 /* ---- context -------------------------------------------------------------------------------------------- */

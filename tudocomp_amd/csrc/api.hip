@@ -158,17 +158,26 @@ void run_textds(Ctx& c, const u8* d_text, size_t n, DevArrays& A, tdc_gpu_stats*
     A.plcp = c.arena.get<u32>(n);
     u32* d_max = c.arena.get<u32>(1);
     SAStats ss;
+    SAExtra ex;
+    ex.lcp8 = c.arena.get<u8>(n + 8);                         // neighbour LCPs of the wide path (suffix_array.hip)
     const int e0 = ev ? ev->tick() : 0;
-    build_suffix_array(c, d_text, n, A.sa, A.isa, &ss);
+    build_suffix_array(c, d_text, n, A.sa, A.isa, &ss, &ex);
     const int e1 = ev ? ev->tick() : 0;
-    build_phi(c, A.sa, n, A.phi);
-    const int e2 = ev ? ev->tick() : 0;
-    build_plcp(c, d_text, n, A.phi, A.plcp, d_max);
+    int e2;
+    if (ex.mode == 1) {                                       // ISA + Phi + PLCP in one scatter of the final suffix array
+        build_isa_phi_plcp_fused(c, A.sa, ex.lcp8, n, A.isa, A.phi, A.plcp, d_max);
+        e2 = ev ? ev->tick() : 0;
+    } else {
+        build_phi(c, A.sa, n, A.phi);
+        e2 = ev ? ev->tick() : 0;
+        build_plcp(c, d_text, n, A.phi, A.plcp, d_max);
+    }
     const int e3 = ev ? ev->tick() : 0;
     A.maxlcp = c.read(d_max);
     if (st) {
         st->maxlcp = A.maxlcp;
         st->sa_rounds = ss.rounds; st->sa_init_syms = ss.init_syms; st->sa_sorted_elems = ss.sorted_elems;
+        st->sa_key_words = ss.wide_kw; st->sa_text_rounds = ss.text_rounds; st->sa_mode = (uint32_t)ex.mode;
         if (ev) { ev->span(&st->ms_sa, e0, e1); ev->span(&st->ms_phi, e1, e2); ev->span(&st->ms_plcp, e2, e3); }
     }
 }
@@ -300,6 +309,13 @@ int tdc_gpu_ctx_create(int device, tdc_gpu_ctx** out) {
         if (const char* m = getenv("TDC_GPU_BUCKET_SCATTER")) ctx->c.bucket_scatter = atoi(m) ? 1 : 0;
         if (const char* m = getenv("TDC_GPU_SSORT")) ctx->c.ssort = atoi(m) ? 1 : 0;
         if (const char* m = getenv("TDC_GPU_MSD_PARTITION")) ctx->c.msd_partition = atoi(m) ? 1 : 0;
+        if (const char* m = getenv("TDC_GPU_WSORT")) ctx->c.wsort = atoi(m) ? 1 : 0;
+        if (const char* m = getenv("TDC_GPU_WSORT_MIN")) { const long v = atol(m); ctx->c.wsort_min = v < 4096 ? 4096 : (size_t)v; }
+        if (const char* m = getenv("TDC_GPU_WSORT_KW")) { const int v = atoi(m); ctx->c.wsort_kw = (v == 1 || v == 2) ? v : 0; }
+        if (const char* m = getenv("TDC_GPU_WSORT_ROUNDS")) { const int v = atoi(m); ctx->c.wsort_rounds = v < 0 ? 0 : (v > 100 ? 100 : v); }
+        if (const char* m = getenv("TDC_GPU_WSORT_SMALLRUN")) ctx->c.wsort_small = atoi(m) ? 1 : 0;
+        if (const char* m = getenv("TDC_GPU_WSORT_PACK")) { const int v = atoi(m); ctx->c.wsort_pack = (v == 1024 || v == 4096) ? v : 2048; }
+        if (const char* m = getenv("TDC_GPU_WSORT_CMAX")) { const int v = atoi(m); ctx->c.wsort_cmax = v < 1 ? 1 : (v > 64 ? 64 : v); }
         if (const char* m = getenv("TDC_GPU_SSORT_LEVELS")) { const int v = atoi(m); ctx->c.ssort_levels = (v >= 1 && v <= 3) ? v : 0; }
     } catch (const HipError&) {
         (void)hipGetLastError();

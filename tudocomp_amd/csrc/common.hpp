@@ -132,6 +132,13 @@ struct Ctx {
     int window_large_lists = 0;    // window pass: start with the large per-level lists (env TDC_GPU_WINDOW_LARGE=1; tests)
     int ssort = 1;                 // suffix array: splitter-partition sort (ssort.hip) instead of the 8-pass LSD sort for large inputs (env TDC_GPU_SSORT=0 disables)
     int ssort_levels = 0;          // force the number of partition levels of the splitter sort (env TDC_GPU_SSORT_LEVELS = 1..3; tests)
+    int wsort = 1;                 // suffix array: wide-key (bit-packed, 2 x 64 bits) initial sort + text rounds + fused ISA / Phi / PLCP scatter (env TDC_GPU_WSORT=0: round-2 path)
+    size_t wsort_min = (size_t)1 << 20;   // smallest text that takes it (env TDC_GPU_WSORT_MIN, >= 4096; tests)
+    int wsort_kw = 0;              // key words: 0 = by alphabet (2 when a word holds fewer than 16 symbols), 1 | 2 forced (env TDC_GPU_WSORT_KW)
+    int wsort_rounds = 24;         // most text rounds before the doubling fallback (env TDC_GPU_WSORT_ROUNDS; 0: straight to doubling)
+    int wsort_cmax = 16;           // leaf sort: runs of tying records up to this length are ordered by counting, longer ones by the wave kernel (env TDC_GPU_WSORT_CMAX, 1 .. 64)
+    int wsort_pack = 2048;         // leaf sort: leaves up to this size are packed into units of at most twice that (env TDC_GPU_WSORT_PACK: 1024 | 2048 | 4096)
+    int wsort_small = 0;           // tests: 1 = every run of a leaf unit counts as "big" (the chunk iterations run everywhere) (env TDC_GPU_WSORT_SMALLRUN)
     int msd_partition = 1;         // bucketed scatter: MSD partition with atomic slots instead of two stable LSD passes (env TDC_GPU_MSD_PARTITION=0)
     int bucket_scatter = 1;        // big random scatters (rank, Phi) go through one radix partition by destination window (env TDC_GPU_BUCKET_SCATTER=0 disables)
 

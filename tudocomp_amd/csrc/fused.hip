@@ -1,0 +1,277 @@
+// fused.hip -- ISA, Phi and PLCP from a final suffix array in ONE bucketed scatter (gfx950).
+//   isa[sa[i]] = i                        ds/ISAFromSA.hpp:30-43
+//   phi[sa[i]] = sa[i-1]                  ds/PhiFromSA.hpp:35-45     (phi[sa[0]] = sa[n-1])
+//   plcp[sa[i]] = lcp(sa[i-1], sa[i])     ds/PLCPFromPhi.hpp:27-53   (the values, here handed over by the sort: suffix_array.hip)
+// All three scatter along the same permutation i -> sa[i].  Round 2 ran two bucketed scatters of 8-byte pairs (first ranks, Phi) and
+// recomputed PLCP from the text with one scattered read per position; here ONE record (sa[i], i, sa[i-1], lcp) of 13 bytes travels
+// through one two-level partition by destination window (prim.hip bucketed_scatter_u32 explains why a partition beats a direct
+// scatter) and every window is written as whole lines from an LDS image, array by array.
+#include "stages.hpp"
+#include "prim.hpp"
+
+namespace tdc {
+
+constexpr int FS_TILE = 4096;        // = SS_TILE of ssort.hip (the row-block tables assume it)
+constexpr int FS_ITEMS = 16;
+constexpr u32 FS_WMAX = 8192;
+
+struct FSLevel {
+    const u32* idx_in; const u32* rank_in; const u32* prev_in; const u8* lcp_in;
+    u32* idx_out; u32* rank_out; u32* prev_out; u8* lcp_out;
+    u32* counts; const u32* blk_seg; const u32* blk_start; const u32* seg_start;
+    u32 nseg, R, per_xcd; int shift;
+};
+__device__ __forceinline__ bool fs_row(const FSLevel& P, u32 row, size_t& base, u32& cnt) {
+    const u32 blk = row / P.R;
+    if (blk >= P.blk_start[P.nseg]) return false;
+    const u32 s = P.blk_seg[blk];
+    const u64 t = (u64)(blk - P.blk_start[s]) * P.R + row % P.R;
+    const u32 s0 = P.seg_start[s], s1 = P.seg_start[s + 1];
+    const u64 off = t * FS_TILE;
+    base = s0; cnt = 0;
+    if (off >= (u64)(s1 - s0)) return true;
+    base = (size_t)s0 + off;
+    const u64 left = (u64)(s1 - s0) - off;
+    cnt = left < FS_TILE ? (u32)left : (u32)FS_TILE;
+    return true;
+}
+
+template <int DB>
+__global__ __launch_bounds__(256) void fs_count_kernel(FSLevel P, u32 rows) {
+    constexpr u32 D = 1u << DB;
+    __shared__ u32 hist[D];
+    const u32 row = xcd_tile(blockIdx.x, P.per_xcd);
+    if (row >= rows) return;
+    size_t base; u32 cnt;
+    if (!fs_row(P, row, base, cnt)) return;
+    for (u32 i = threadIdx.x; i < D; i += 256) hist[i] = 0;
+    if (cnt == 0) { for (u32 i = threadIdx.x; i < D; i += 256) P.counts[(size_t)row * D + i] = 0; return; }
+    __syncthreads();
+    const u32 lb = wave_id() * (64 * FS_ITEMS) + lane_id();
+    const u32* ip = P.idx_in + base + lb;
+    u32 kk[FS_ITEMS];
+#pragma unroll
+    for (int j = 0; j < FS_ITEMS; ++j) kk[j] = (lb + (u32)j * 64 < cnt) ? ip[j * 64] : 0u;
+#pragma unroll
+    for (int j = 0; j < FS_ITEMS; ++j) {
+        const bool valid = lb + (u32)j * 64 < cnt;
+        const u32 d = (kk[j] >> P.shift) & (D - 1);
+        const u32 d0 = __builtin_amdgcn_readfirstlane(d);
+        if (__all(valid && d == d0)) { if (lane_id() == 0) atomicAdd(&hist[d0], 64u); }
+        else if (valid) atomicAdd(&hist[d], 1u);
+    }
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < D; i += 256) P.counts[(size_t)row * D + i] = hist[i];
+}
+
+// FIRST: record j of the input is (sa[j + 1], j + 1, sa[j], lcp8[j + 1]) -- idx_in = sa + 1, prev_in = sa, lcp_in = lcp8 + 1, the rank
+// is the index.  The tile is written stream by stream, each staged in LDS in bucket order first (whole runs per bucket leave as
+// consecutive words).
+template <int DB, bool FIRST>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void fs_scatter_kernel(FSLevel P, u32 rows) {
+    constexpr u32 D = 1u << DB;
+    __shared__ u32 tcnt[D];
+    __shared__ u32 gbase[D];
+    __shared__ __align__(16) u32 stage[FS_TILE];
+    __shared__ u32 scan_sm[5];
+    const int lane = lane_id();
+    const u32 row = xcd_tile(blockIdx.x, P.per_xcd);
+    if (row >= rows) return;
+    size_t base; u32 cnt;
+    if (!fs_row(P, row, base, cnt) || cnt == 0) return;
+    for (u32 i = threadIdx.x; i < D; i += 256) tcnt[i] = 0;
+    __syncthreads();
+    const u32 lb = wave_id() * (64 * FS_ITEMS) + lane;
+    const u32* ip = P.idx_in + base + lb;
+    u32 k[FS_ITEMS], pos[FS_ITEMS];
+#pragma unroll
+    for (int j = 0; j < FS_ITEMS; ++j) k[j] = (lb + (u32)j * 64 < cnt) ? ip[j * 64] : 0u;
+#pragma unroll
+    for (int j = 0; j < FS_ITEMS; ++j) {
+        const bool valid = lb + (u32)j * 64 < cnt;
+        const u32 d = (k[j] >> P.shift) & (D - 1);
+        const u32 d0 = __builtin_amdgcn_readfirstlane(d);
+        u32 rank = 0;
+        if (__all(valid && d == d0)) {
+            if (lane == 0) rank = atomicAdd(&tcnt[d0], 64u);
+            rank = __builtin_amdgcn_readfirstlane(rank) + (u32)lane;
+        } else if (valid) rank = atomicAdd(&tcnt[d], 1u);
+        pos[j] = rank;
+    }
+    __syncthreads();
+    {
+        const u32 t = threadIdx.x;
+        u32 tot[D / 256], sum = 0;
+#pragma unroll
+        for (u32 q = 0; q < D / 256; ++q) { tot[q] = tcnt[t * (D / 256) + q]; sum += tot[q]; }
+        u32 total;
+        u32 start = block_exclusive_sum<u32, 4>(sum, scan_sm, total);
+#pragma unroll
+        for (u32 q = 0; q < D / 256; ++q) {
+            const u32 d = t * (D / 256) + q;
+            tcnt[d] = start;
+            gbase[d] = P.counts[(size_t)row * D + d] - start;
+            start += tot[q];
+        }
+    }
+    __syncthreads();
+    u32 dst[FS_ITEMS];
+    // stream 1: the destination index itself (its bucket gives every slot of the sorted tile its global address)
+#pragma unroll
+    for (int j = 0; j < FS_ITEMS; ++j) {
+        if (lb + (u32)j * 64 < cnt) { pos[j] += tcnt[(k[j] >> P.shift) & (D - 1)]; stage[pos[j]] = k[j]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < FS_ITEMS; ++r) {
+        const u32 sp = (u32)r * 256 + threadIdx.x;
+        dst[r] = 0xFFFFFFFFu;
+        if (sp < cnt) {
+            const u32 key = stage[sp];
+            dst[r] = gbase[(key >> P.shift) & (D - 1)] + sp;
+            P.idx_out[dst[r]] = key;
+        }
+    }
+    __syncthreads();
+    // stream 2: rank
+#pragma unroll
+    for (int j = 0; j < FS_ITEMS; ++j) {
+        const u32 e = lb + (u32)j * 64;
+        if (e < cnt) stage[pos[j]] = FIRST ? (u32)(base + e + 1) : P.rank_in[base + e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < FS_ITEMS; ++r) if (dst[r] != 0xFFFFFFFFu) P.rank_out[dst[r]] = stage[(u32)r * 256 + threadIdx.x];
+    __syncthreads();
+    // stream 3: predecessor in the suffix array
+#pragma unroll
+    for (int j = 0; j < FS_ITEMS; ++j) {
+        const u32 e = lb + (u32)j * 64;
+        if (e < cnt) stage[pos[j]] = P.prev_in[base + e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < FS_ITEMS; ++r) if (dst[r] != 0xFFFFFFFFu) P.prev_out[dst[r]] = stage[(u32)r * 256 + threadIdx.x];
+    __syncthreads();
+    // stream 4: LCP bytes
+    u8* stage8 = (u8*)stage;
+#pragma unroll
+    for (int j = 0; j < FS_ITEMS; ++j) {
+        const u32 e = lb + (u32)j * 64;
+        if (e < cnt) stage8[pos[j]] = P.lcp_in[base + e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < FS_ITEMS; ++r) if (dst[r] != 0xFFFFFFFFu) P.lcp_out[dst[r]] = stage8[(u32)r * 256 + threadIdx.x];
+}
+
+// After the partition by the top 2 * DB index bits, window w holds exactly the records of the positions [w * W, (w + 1) * W) (position
+// n - 1 = sa[0] has no record).  One workgroup per window: each array is scattered into an LDS image of the window and leaves as whole
+// lines.
+__global__ __launch_bounds__(256) void fs_image_kernel(const u32* __restrict__ idx, const u32* __restrict__ rank, const u32* __restrict__ prev,
+                                                        const u8* __restrict__ lcp, size_t m, u32 W, u32* __restrict__ isa, u32* __restrict__ phi,
+                                                        u32* __restrict__ plcp, u32* __restrict__ d_max) {
+    __shared__ u32 img[FS_WMAX];
+    const size_t base = (size_t)blockIdx.x * W;
+    const size_t end = (base + W < m) ? base + W : m;
+    for (size_t j = base + threadIdx.x; j < end; j += 256) img[idx[j] & (W - 1)] = rank[j];
+    __syncthreads();
+    for (size_t q = base + threadIdx.x; q < end; q += 256) isa[q] = img[q - base];
+    __syncthreads();
+    for (size_t j = base + threadIdx.x; j < end; j += 256) img[idx[j] & (W - 1)] = prev[j];
+    __syncthreads();
+    for (size_t q = base + threadIdx.x; q < end; q += 256) phi[q] = img[q - base];
+    __syncthreads();
+    u32 mx = 0;
+    for (size_t j = base + threadIdx.x; j < end; j += 256) { const u32 l = lcp[j]; img[idx[j] & (W - 1)] = l; mx = max(mx, l); }
+    __syncthreads();
+    for (size_t q = base + threadIdx.x; q < end; q += 256) plcp[q] = img[q - base];
+    mx = wave_reduce_max(mx);
+    if (lane_id() == 0 && mx) atomicMax(d_max, mx);
+}
+
+__global__ void fs_first_kernel(const u32* __restrict__ sa, size_t n, u32* __restrict__ isa, u32* __restrict__ phi, u32* __restrict__ plcp) {
+    const u32 p = sa[0];
+    isa[p] = 0; phi[p] = sa[n - 1]; plcp[p] = 0;
+}
+__global__ void fs_direct_kernel(const u32* __restrict__ sa, const u8* __restrict__ lcp8, size_t n, u32* __restrict__ isa, u32* __restrict__ phi,
+                                 u32* __restrict__ plcp, u32* __restrict__ d_max) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    u32 l = 0;
+    if (i < n) {
+        const u32 p = sa[i];
+        isa[p] = (u32)i;
+        phi[p] = (i == 0) ? sa[n - 1] : sa[i - 1];
+        l = (i == 0) ? 0u : (u32)lcp8[i];
+        plcp[p] = l;
+    }
+    l = wave_reduce_max(l);
+    if (lane_id() == 0 && l) atomicMax(d_max, l);
+}
+
+void build_isa_phi_plcp_fused(Ctx& c, const u32* sa, const u8* lcp8, size_t n, u32* isa, u32* phi, u32* plcp, u32* d_maxlcp) {
+    hipStream_t s = c.stream;
+    HIP_TRY(hipMemsetAsync(d_maxlcp, 0, sizeof(u32), s));
+    if (!n) return;
+    const int bits = (int)bits_for(n - 1);
+    if (n < ((size_t)1 << 20) || !c.bucket_scatter) {
+        Ctx::ProfScope prof(c, K_PHI, (u64)n * 17);
+        fs_direct_kernel<<<cdiv(n, 256), 256, 0, s>>>(sa, lcp8, n, isa, phi, plcp, d_maxlcp);
+        LAUNCH_CHECK();
+        return;
+    }
+    const size_t mark = c.arena.mark();
+    const size_t m = n - 1;                                   // records of the slots 1 .. n-1; slot 0 (position n-1) has none
+    const int db = (bits - 16 > 13) ? 9 : 8;
+    const u32 D = 1u << db;
+    u32* idx[2] = { c.arena.get<u32>(m), c.arena.get<u32>(m) };
+    u32* rk[2] = { c.arena.get<u32>(m), c.arena.get<u32>(m) };
+    u32* pv[2] = { c.arena.get<u32>(m), c.arena.get<u32>(m) };
+    u8* lc[2] = { c.arena.get<u8>(m + 8), c.arena.get<u8>(m + 8) };
+    const u32* seg_start = ss_first_segment(c, m);
+    u32 nseg = 1;
+    for (int l = 0; l < 2; ++l) {
+        u32* nstart = c.arena.get<u32>((size_t)nseg * D + 1);
+        const size_t lm = c.arena.mark();
+        SegTables Tb;
+        ss_level_tables(c, seg_start, nseg, m, D, Tb);
+        FSLevel P;
+        if (l == 0) { P.idx_in = sa + 1; P.rank_in = nullptr; P.prev_in = sa; P.lcp_in = lcp8 + 1; }
+        else { P.idx_in = idx[0]; P.rank_in = rk[0]; P.prev_in = pv[0]; P.lcp_in = lc[0]; }
+        P.idx_out = idx[l]; P.rank_out = rk[l]; P.prev_out = pv[l]; P.lcp_out = lc[l];
+        P.counts = Tb.counts; P.blk_seg = Tb.blk_seg; P.blk_start = Tb.blk_start; P.seg_start = seg_start;
+        P.nseg = nseg; P.R = Tb.R; P.shift = bits - db * (l + 1);
+        const u32 rows = Tb.rows;
+        P.per_xcd = (c.xcd_remap == 1 && rows >= 64) ? cdiv(rows, 8) : 0u;
+        const u32 grid = P.per_xcd ? 8 * P.per_xcd : rows;
+        {
+            const int pc = c.prof_begin(K_RS_COUNT, (u64)m * 4);
+            if (db == 9) fs_count_kernel<9><<<grid, 256, 0, s>>>(P, rows); else fs_count_kernel<8><<<grid, 256, 0, s>>>(P, rows);
+            LAUNCH_CHECK();
+            c.prof_end(pc);
+        }
+        ss_level_offsets(c, Tb, seg_start, nseg, D, nstart, m);
+        {
+            const int ps = c.prof_begin(K_RS_SCATTER_U32, (u64)m * (l == 0 ? 5 + 13 : 26));
+            if (l == 0) { if (db == 9) fs_scatter_kernel<9, true><<<grid, 256, 0, s>>>(P, rows); else fs_scatter_kernel<8, true><<<grid, 256, 0, s>>>(P, rows); }
+            else { if (db == 9) fs_scatter_kernel<9, false><<<grid, 256, 0, s>>>(P, rows); else fs_scatter_kernel<8, false><<<grid, 256, 0, s>>>(P, rows); }
+            LAUNCH_CHECK();
+            c.prof_end(ps);
+        }
+        c.arena.release(lm);
+        seg_start = nstart;
+        nseg *= D;
+    }
+    {
+        const u32 W = 1u << (bits - 2 * db);
+        if (W > FS_WMAX) throw HipError{hipErrorUnknown, "fused scatter: window larger than the LDS image", (int)__LINE__};
+        Ctx::ProfScope prof(c, K_WINDOW_SCATTER, (u64)m * 25);
+        fs_image_kernel<<<cdiv(m, W), 256, 0, s>>>(idx[1], rk[1], pv[1], lc[1], m, W, isa, phi, plcp, d_maxlcp);
+        LAUNCH_CHECK();
+        fs_first_kernel<<<1, 1, 0, s>>>(sa, n, isa, phi, plcp);
+        LAUNCH_CHECK();
+    }
+    c.arena.release(mark);
+}
+
+}  // namespace tdc

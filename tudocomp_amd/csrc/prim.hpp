@@ -35,6 +35,30 @@ int splitter_sort_pairs_u64(Ctx& c, u64* keys[2], u32* vals[2], size_t n, const 
 // order inside a group; db = digit bits per level (8 or 9); tmp_idx / tmp_val: m entries of scratch each.  bits > 2 * db.
 void msd_partition_pairs_u32(Ctx& c, const u32* idx, const u32* val, size_t m, int bits, int db, u32* out_idx, u32* out_val, u32* tmp_idx, u32* tmp_val);
 
+// ---- internals of the splitter sort shared between ssort.hip and wsort.hip ------------------------------------------------------
+struct SegTables { u32* blk_start; u32* blk_seg; u32* counts; u32* bs; u32 R, blocks_ub, rows; };
+struct UnitTables { u32* unit_rng; u32* cls_list; u32* large; u32 cap, large_cap; u32 hc[6]; /* large leaves, units, units per size class */ };
+u32* ss_first_segment(Ctx& c, size_t n);                                           // seg_start[2] = { 0, n } on the device
+void ss_level_tables(Ctx& c, const u32* seg_start, u32 nseg, size_t n, u32 D, SegTables& T);      // row-block tables + count arrays (arena)
+void ss_level_offsets(Ctx& c, const SegTables& T, const u32* seg_start, u32 nseg, u32 D, u32* nstart, size_t n);   // counts -> offsets, next segment starts
+void ss_build_units(Ctx& c, const u32* leaf_start, u32 nleaf, UnitTables& U, u32 small = 0);   // leaves -> units of <= 8192 pairs by size class (synchronises);
+                                                                                   // leaves of <= `small` pairs (0: 4096) are packed into units of <= 2 * small
+void ss_fanouts(Ctx& c, size_t n, int& L, u32 F[3], u32& os);                      // levels, fan-outs and oversampling for n pairs
+
+// ---- wide-key suffix sort (wsort.hip) ----------------------------------------------------------------------------------------------
+// key(p) = the s recoded bytes text[p .. p+s) as s fields of b bits, left-aligned in KW 64-bit words (pad zero bits below; zeros behind
+// the text).  Bit-packed keys make the common prefix of two keys a count of leading zeros, which is where the LCP values come from.
+struct WKeyGen { const u8* text; size_t n; int b, s, pad; u32 inv /* ceil(65536 / b) */; u8 code[256]; };
+struct WSortStats { u32 levels = 0, range_leaves = 0, samples = 0, units = 0, large_leaves = 0, kw = 0, refined_units = 0, trunc_units = 0, longrun_units = 0, leaf_stages = 0, wave_runs = 0; u64 large_pairs = 0; u64 nonheads = 0; };
+bool wsort_applicable(const Ctx& c, size_t n);
+int wsort_result_index(Ctx& c, size_t n);     // which of the two V buffers wsort_suffixes will return (so that the caller can make it sa[])
+// Sorts all suffixes of the text by key(p).  K1 / K2 / V: two buffers each (n entries; K2 unused for KW = 1).  Returns x: V[x] holds the
+// positions in sorted order; flags[i] = 1 where slot i starts a group of equal keys; lcp8[i] (valid where flags[i] = 1, i > 0) =
+// number of leading symbols the keys of slot i - 1 and slot i have in common.  st->nonheads = number of slots with flags = 0.
+int wsort_suffixes(Ctx& c, int KW, const WKeyGen& g, u64* K1[2], u64* K2[2], u32* V[2], size_t n, u8* flags, u8* lcp8, WSortStats* st);
+// Sorts m records (K1[0][j], K2[0][j], V[0][j]) by (k1, k2); k1_bits = significant bits of k1.  Returns the buffer index of the result.
+int wsort_records(Ctx& c, u64* K1[2], u64* K2[2], u32* V[2], size_t m, int k1_bits, WSortStats* st);
+
 // Same contract as radix_sort_pairs_u64 for keys that are pairwise DISTINCT on the sorted bits (stability is then
 // irrelevant): inputs of at most 2048 pairs are sorted by one workgroup in LDS (bitonic network), larger ones by the
 // radix sort.  Used for the many tiny per-level sorts of the factorizer.

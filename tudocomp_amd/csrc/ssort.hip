@@ -769,39 +769,39 @@ void msd_partition_pairs_u32(Ctx& c, const u32* idx, const u32* val, size_t m, i
 // ---- leaves -> units ----------------------------------------------------------------------------------------------------------
 // class of leaf l: 0 small (<= SS_SMALL pairs, packed with its neighbours), 1 medium (a unit of its own), 2 skip (a large
 // equality leaf: all keys equal), 3 large (LSD fall-back)
-__device__ __forceinline__ u32 ss_leaf_class(const u32* __restrict__ leaf_start, u32 l) {
+__device__ __forceinline__ u32 ss_leaf_class(const u32* __restrict__ leaf_start, u32 l, u32 small = SS_SMALL) {
     const u32 size = leaf_start[l + 1] - leaf_start[l];
-    if (size <= SS_SMALL) return 0;
+    if (size <= small) return 0;
     if (l & 1u) return 2;
     return size <= SS_UNIT_MAX ? 1u : 3u;
 }
-__device__ __forceinline__ bool ss_unit_first(const u32* __restrict__ leaf_start, u32 l, u32 cls) {
+__device__ __forceinline__ bool ss_unit_first(const u32* __restrict__ leaf_start, u32 l, u32 cls, u32 small = SS_SMALL) {
     if (cls == 1) return true;
     if (cls != 0) return false;
     if (l == 0) return true;
-    return ss_leaf_class(leaf_start, l - 1) != 0 || (leaf_start[l] / SS_SMALL) != (leaf_start[l - 1] / SS_SMALL);
+    return ss_leaf_class(leaf_start, l - 1, small) != 0 || (leaf_start[l] / small) != (leaf_start[l - 1] / small);
 }
 __global__ void ss_unit_flag_kernel(const u32* __restrict__ leaf_start, u32 nleaf, u32* __restrict__ flag, u32* __restrict__ large_list,
-                                    u32* __restrict__ large_count, u32 large_cap) {
+                                    u32* __restrict__ large_count, u32 large_cap, u32 small = SS_SMALL) {
     const u32 l = blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= nleaf) return;
-    const u32 cls = ss_leaf_class(leaf_start, l);
-    flag[l] = ss_unit_first(leaf_start, l, cls) ? 1u : 0u;
+    const u32 cls = ss_leaf_class(leaf_start, l, small);
+    flag[l] = ss_unit_first(leaf_start, l, cls, small) ? 1u : 0u;
     if (cls == 3) { const u32 i = atomicAdd(large_count, 1u); if (i < large_cap) large_list[i] = l; }
 }
 // uidx = exclusive scan of flag; unit_rng[2u] / [2u + 1] = first pair / end of unit u
-__global__ void ss_unit_fill_kernel(const u32* __restrict__ leaf_start, u32 nleaf, const u32* __restrict__ uidx, u32* __restrict__ unit_rng) {
+__global__ void ss_unit_fill_kernel(const u32* __restrict__ leaf_start, u32 nleaf, const u32* __restrict__ uidx, u32* __restrict__ unit_rng, u32 small = SS_SMALL) {
     const u32 l = blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= nleaf) return;
-    const u32 cls = ss_leaf_class(leaf_start, l);
+    const u32 cls = ss_leaf_class(leaf_start, l, small);
     if (cls > 1) return;
-    const bool first = ss_unit_first(leaf_start, l, cls);
+    const bool first = ss_unit_first(leaf_start, l, cls, small);
     const u32 u = uidx[l] - (first ? 0u : 1u);               // exclusive scan: a first leaf sees its own index, the others the next one
     if (first) unit_rng[2 * u] = leaf_start[l];
     bool last = (cls == 1) || (l + 1 == nleaf);
     if (!last) {
-        const u32 c2 = ss_leaf_class(leaf_start, l + 1);
-        last = c2 != 0 || (leaf_start[l + 1] / SS_SMALL) != (leaf_start[l] / SS_SMALL);
+        const u32 c2 = ss_leaf_class(leaf_start, l + 1, small);
+        last = c2 != 0 || (leaf_start[l + 1] / small) != (leaf_start[l] / small);
     }
     if (last) unit_rng[2 * u + 1] = leaf_start[l + 1];
 }
@@ -1197,6 +1197,82 @@ int splitter_sort_pairs_u64(Ctx& c, u64* keys[2], u32* vals[2], size_t n, const 
     }
     c.arena.release(mark);
     return cur;
+}
+
+// ---- the level / unit bookkeeping as host functions, shared with wsort.hip (same kernels as above) ------------------------------
+void ss_level_tables(Ctx& c, const u32* seg_start, u32 nseg, size_t n, u32 D, SegTables& T) {
+    hipStream_t s = c.stream;
+    const u64 tiles = (n + SS_TILE - 1) / SS_TILE;
+    u32 R = 128;
+    while (R > 1 && (u64)nseg * R > tiles / 8 + 64) R >>= 1;
+    T.R = R;
+    T.blocks_ub = (u32)((tiles + R - 1) / R) + nseg;
+    T.rows = T.blocks_ub * R;
+    T.blk_start = c.arena.get<u32>((size_t)nseg + 1);
+    T.blk_seg = c.arena.get<u32>(T.blocks_ub);
+    T.counts = c.arena.get<u32>((size_t)T.rows * D);
+    T.bs = c.arena.get<u32>((size_t)T.blocks_ub * D);
+    ss_nblk_kernel<<<cdiv((size_t)nseg + 1, 256), 256, 0, s>>>(seg_start, nseg, R, T.blk_start);
+    LAUNCH_CHECK();
+    exclusive_sum_u32(c, T.blk_start, T.blk_start, (size_t)nseg + 1, nullptr);
+    ss_blkseg_kernel<<<cdiv(nseg, 256), 256, 0, s>>>(T.blk_start, nseg, T.blk_seg);
+    LAUNCH_CHECK();
+}
+void ss_level_offsets(Ctx& c, const SegTables& T, const u32* seg_start, u32 nseg, u32 D, u32* nstart, size_t n) {
+    hipStream_t s = c.stream;
+    Ctx::ProfScope prof(c, K_SCAN, (u64)T.rows * D * 12);
+    ss_blocksum_kernel<<<T.blocks_ub, 256, 0, s>>>(T.counts, T.blk_start, nseg, T.R, D, T.bs);
+    LAUNCH_CHECK();
+    ss_segbase_kernel<<<nseg, 1024, 0, s>>>(T.bs, T.blk_start, seg_start, D, nstart);
+    LAUNCH_CHECK();
+    ss_set_word_kernel<<<1, 1, 0, s>>>(nstart + (size_t)nseg * D, (u32)n);
+    LAUNCH_CHECK();
+    ss_apply_kernel<<<T.blocks_ub, 256, 0, s>>>(T.counts, T.blk_start, nseg, T.R, D, T.bs);
+    LAUNCH_CHECK();
+}
+u32* ss_first_segment(Ctx& c, size_t n) {
+    u32* seg_start = c.arena.get<u32>(2);
+    ss_set_word_kernel<<<1, 1, 0, c.stream>>>(seg_start, 0u);
+    LAUNCH_CHECK();
+    ss_set_word_kernel<<<1, 1, 0, c.stream>>>(seg_start + 1, (u32)n);
+    LAUNCH_CHECK();
+    return seg_start;
+}
+void ss_build_units(Ctx& c, const u32* leaf_start, u32 nleaf, UnitTables& U, u32 small) {
+    if (small == 0) small = SS_SMALL;
+    hipStream_t s = c.stream;
+    constexpr u32 LARGE_CAP = 1024;
+    U.large_cap = LARGE_CAP;
+    u32* flag = c.arena.get<u32>((size_t)nleaf + 1);
+    U.unit_rng = c.arena.get<u32>(2 * ((size_t)nleaf + 1));
+    U.large = c.arena.get<u32>(LARGE_CAP + 6);
+    U.cls_list = c.arena.get<u32>(4 * ((size_t)nleaf + 1));
+    U.cap = nleaf + 1;
+    HIP_TRY(hipMemsetAsync(U.large, 0, 6 * sizeof(u32), s));
+    ss_unit_flag_kernel<<<cdiv(nleaf, 256), 256, 0, s>>>(leaf_start, nleaf, flag, U.large + 6, U.large, LARGE_CAP, small);
+    LAUNCH_CHECK();
+    exclusive_sum_u32(c, flag, flag, nleaf, U.large + 1);
+    ss_unit_fill_kernel<<<cdiv(nleaf, 256), 256, 0, s>>>(leaf_start, nleaf, flag, U.unit_rng, small);
+    LAUNCH_CHECK();
+    ss_unit_class_kernel<<<cdiv((size_t)nleaf + 1, 256), 256, 0, s>>>(U.unit_rng, U.large + 1, U.large + 2, U.cls_list, nleaf + 1);
+    LAUNCH_CHECK();
+    c.read_n(U.large, U.hc, 6);
+}
+void ss_fanouts(Ctx& c, size_t n, int& L, u32 F[3], u32& os) {
+    L = n <= (size_t)256 * 3072 ? 1 : ((n + 65535) / 65536 <= 4352 ? 2 : 3);
+    if (c.ssort_levels >= 1 && c.ssort_levels <= 3) L = c.ssort_levels;
+    F[0] = F[1] = F[2] = 1;
+    const u32 cap = L == 1 ? 256u : (L == 2 ? 65536u : (1u << 24));
+    u32 nl = pow2_ceil((n + (L == 3 ? 2047 : 3071)) / (L == 3 ? 2048 : 3072));
+    if (nl > cap) nl = cap;
+    if (nl < (2u << (L - 1))) nl = 2u << (L - 1);
+    const u32 lastF = nl > 256 ? 256u : (L == 1 ? nl : nl >> (L - 1));
+    F[L - 1] = lastF;
+    u32 rest = nl / lastF;
+    if (L == 2) F[0] = rest;
+    if (L == 3) { F[0] = 1; while ((u64)F[0] * F[0] < rest) F[0] <<= 1; F[1] = rest / F[0]; if (F[1] < 2) { F[1] = 2; } }
+    const u64 avg = (n + nl - 1) / nl;
+    os = avg > 3072 ? 64 : (avg > 2304 ? 32 : 16);
 }
 
 }  // namespace tdc

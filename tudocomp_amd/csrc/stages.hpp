@@ -10,11 +10,20 @@ namespace tdc {
 size_t escape_device(Ctx& c, const u8* d_in, size_t n, u8* d_out);
 size_t count_escapes_device(Ctx& c, const u8* d_in, size_t n);     // bytes the escaping adds
 
-struct SAStats { u32 rounds = 0; u32 sym_bits = 0; u32 init_syms = 0; u64 sorted_elems = 0; };
+struct SAStats { u32 rounds = 0; u32 sym_bits = 0; u32 init_syms = 0; u64 sorted_elems = 0;
+                 u32 wide_kw = 0; /* key words of the wide initial sort (0: classic path) */ u32 text_rounds = 0; u64 wide_nonheads = 0; };
+// Optional sink of the wide path (suffix_array.hip): lcp8 = n bytes for the LCP (in symbols) of every suffix-array slot with its
+// predecessor.  mode (out): 0 = classic result (sa and isa written), 1 = sa final and lcp8 valid but isa NOT written -- the caller
+// derives ISA, Phi and PLCP with build_isa_phi_plcp_fused().
+struct SAExtra { u8* lcp8 = nullptr; int mode = 0; };
 
 // a2+a3: ds/SADivSufSort.hpp:27-51 and ds/ISAFromSA.hpp:30-43.
 // Prefix doubling; text[n-1] must be the unique 0.  sa and isa are caller-provided (n entries each).
-void build_suffix_array(Ctx& c, const u8* text, size_t n, u32* sa, u32* isa, SAStats* st);
+void build_suffix_array(Ctx& c, const u8* text, size_t n, u32* sa, u32* isa, SAStats* st, SAExtra* ex = nullptr);
+// a3 + a4 + a5 in one pass over a final suffix array whose neighbour LCPs are known (lcp8[i] = lcp(T[sa[i-1]..], T[sa[i]..]), i >= 1):
+// isa[sa[i]] = i, phi[sa[i]] = sa[i-1] (phi[sa[0]] = sa[n-1]), plcp[sa[i]] = lcp8[i] (plcp[sa[0]] = 0); d_maxlcp receives the maximum.
+// ds/ISAFromSA.hpp:30-43, ds/PhiFromSA.hpp:35-45, ds/PLCPFromPhi.hpp:27-53 (same arrays, computed from the sort instead of the text)
+void build_isa_phi_plcp_fused(Ctx& c, const u32* sa, const u8* lcp8, size_t n, u32* isa, u32* phi, u32* plcp, u32* d_maxlcp);
 // byte histogram of a text into the context's cache (c.hist_cache / hist_ptr / hist_n): add() per part, finish() once
 void text_histogram_add(Ctx& c, const u8* part, size_t len, u32* d_hist);
 void text_histogram_finish(Ctx& c, const u8* text, size_t n, const u32* d_hist);

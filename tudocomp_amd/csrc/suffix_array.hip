@@ -282,16 +282,22 @@ constexpr u32 GR_TILE = 2048, GR_NONE = 0x7FFFFFFFu;
 constexpr u64 GR_FLAG_AGG = 1ull << 62, GR_FLAG_INC = 2ull << 62;
 __device__ __forceinline__ u64 gr_pack(u64 flag, u32 count, u32 hp) { return flag | ((u64)count << 31) | (u64)hp; }
 __device__ __forceinline__ u32 gr_pad(u32 i) { return i + (i >> 3); }      // LDS slot of tile element i: threads read 8 consecutive elements
-template <bool FIRST>
+// WIDE = 1: a text round of the rank-free path (suffix_array.hip build_suffix_array_wide).  keys = slot of the group head, keys2 = the
+// next 64 key bits of the suffix (bit-packed symbols from position + h): a new group starts where either differs.  A start inside a
+// parent group (keys equal, keys2 different) gets flags_out[pos] = 1 and lcp_out[pos] = h + number of leading symbols the two
+// second keys share (wr.inv = ceil(65536 / bits per symbol)); no rank is written.
+struct WideRound { const u64* keys2; u8* flags_out; u8* lcp_out; u32 h, inv; };
+template <bool FIRST, int WIDE>
 __global__ __launch_bounds__(256) void sa_groups_kernel(const u64* __restrict__ keys, const u32* __restrict__ vals, const u32* __restrict__ a_pos,
                                                         size_t m, int bn, u32* __restrict__ sa, u32* __restrict__ rank, u32* __restrict__ newrank_out,
                                                         u32* __restrict__ o_sa, u32* __restrict__ o_pos, u32* __restrict__ o_r1,
                                                         u64* desc, u32* ticket, u32* __restrict__ d_total, u32* err, u32 numTiles,
-                                                        const u8* __restrict__ hflags = nullptr) {
+                                                        const u8* __restrict__ hflags, WideRound wr) {
     __shared__ u32 s_tile;
     __shared__ u32 s_hp[4], s_cnt[5];
     __shared__ u32 s_carry_hp, s_carry_cnt;
     __shared__ u64 sk[GR_TILE + GR_TILE / 8 + 8];       // keys of the elements tile0 - 1 .. tile0 + 2048 (slot 0 = the predecessor)
+    __shared__ u64 sk2[WIDE ? GR_TILE + GR_TILE / 8 + 8 : 1];
     __shared__ u32 sv[GR_TILE + GR_TILE / 8], sp[GR_TILE + GR_TILE / 8];
     // Tiles are numbered by blockIdx: workgroups are dispatched in that order, so the predecessors of a running tile have been
     // dispatched (a ticket counter would make that formal, but one device-wide atomic per tile on ONE address costs ~25 ns each:
@@ -311,15 +317,22 @@ __global__ __launch_bounds__(256) void sa_groups_kernel(const u64* __restrict__ 
             if (!(FIRST && vals == sa)) sa[pp] = vv;      // (after a refinement the refined order already IS the suffix array so far)
         }
         sk[gr_pad(e + 1)] = kk; sv[gr_pad(e)] = vv; sp[gr_pad(e)] = pp;
+        if (WIDE) sk2[gr_pad(e + 1)] = (i < m) ? wr.keys2[i] : 0ull;
     }
     if (threadIdx.x == 0 && !hflags) { sk[0] = (t0 >= 1) ? keys[t0 - 1] : 0ull; sk[gr_pad(GR_TILE + 1)] = (t0 + GR_TILE < m) ? keys[t0 + GR_TILE] : 0ull; }
+    if (WIDE && threadIdx.x == 0) { sk2[0] = (t0 >= 1) ? wr.keys2[t0 - 1] : 0ull; sk2[gr_pad(GR_TILE + 1)] = (t0 + GR_TILE < m) ? wr.keys2[t0 + GR_TILE] : 0ull; }
     __syncthreads();
     const u32 l0 = threadIdx.x * 8;                     // the thread's 8 consecutive elements
     const size_t i0 = t0 + l0;
     u64 k[10];
     u32 v[8], ps[8];
+    u64 k2[WIDE ? 10 : 1];
 #pragma unroll
     for (int r = 0; r < 10; ++r) k[r] = sk[gr_pad(l0 + r)];      // k[r] = key of element i0 + r - 1
+    if (WIDE) {
+#pragma unroll
+        for (int r = 0; r < 10; ++r) k2[r] = sk2[gr_pad(l0 + r)];
+    }
 #pragma unroll
     for (int r = 0; r < 8; ++r) { v[r] = sv[gr_pad(l0 + r)]; ps[r] = sp[gr_pad(l0 + r)]; }
     // run starts, head position of every element as far as the thread can tell, number of elements to keep
@@ -339,8 +352,21 @@ __global__ __launch_bounds__(256) void sa_groups_kernel(const u64* __restrict__ 
 #pragma unroll
         for (int r = 0; r < 9; ++r) {
             const size_t i = i0 + r;
-            if (i < m && (i == 0 || k[r + 1] != k[r])) starts |= 1u << r;
+            bool differ = k[r + 1] != k[r];
+            if (WIDE) differ = differ || k2[r + 1] != k2[r];
+            if (i < m && (i == 0 || differ)) starts |= 1u << r;
             if (i == m) starts |= 1u << r;                  // the end of the list closes the last run
+        }
+    }
+    if (WIDE) {         // new group heads inside a parent group: flag and LCP (the parent borders have theirs already)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const size_t i = i0 + r;
+            if (i < m && i > 0 && ((starts >> r) & 1u) && k[r + 1] == k[r]) {
+                const u64 x = k2[r + 1] ^ k2[r];
+                wr.flags_out[ps[r]] = 1;
+                wr.lcp_out[ps[r]] = (u8)(wr.h + ((((u32)__builtin_clzll(x)) * wr.inv) >> 16));
+            }
         }
     }
     u32 hp[8];
@@ -446,7 +472,7 @@ __global__ __launch_bounds__(256) void sa_groups_kernel(const u64* __restrict__ 
         if (i < m) {
             const u32 h = s_h[gr_pad(e)];
             if (newrank_out) newrank_out[i] = h;
-            else {                                      // small inputs / rounds: straight into rank[]; later rounds only where the group was split
+            else if (!WIDE && rank) {                   // small inputs / rounds: straight into rank[]; later rounds only where the group was split
                 const u32 vv = vals[i];
                 if (FIRST || h != (u32)(keys[i] >> bn)) rank[vv] = h;
             }
@@ -454,10 +480,338 @@ __global__ __launch_bounds__(256) void sa_groups_kernel(const u64* __restrict__ 
     }
 }
 
-void build_suffix_array(Ctx& c, const u8* text, size_t n, u32* sa, u32* isa, SAStats* st) {
+// ---- text rounds of the rank-free path: keys of the unresolved suffixes -----------------------------------------------------------
+// k1 = slot of the group head, k2 = the s1 symbols behind the h the group already shares (bit-packed, left-aligned), v = position
+__global__ __launch_bounds__(256) void sa_round_keys_kernel(const u32* __restrict__ a_sa, const u32* __restrict__ a_r1, size_t m, WKeyGen g, u32 h,
+                                                            u64* __restrict__ k1, u64* __restrict__ k2, u32* __restrict__ v) {
+    __shared__ u8 code[256];
+    code[threadIdx.x] = g.code[threadIdx.x];
+    __syncthreads();
+    const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= m) return;
+    const u32 p = a_sa[j];
+    const size_t q = (size_t)p + h;
+    u64 w[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    const int nw = (g.s + 7) >> 3;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        if (t < nw) {
+            if (q + 8 * (size_t)t + 8 <= g.n) __builtin_memcpy(&w[t], g.text + q + 8 * t, 8);
+            else for (int e = 0; e < 8; ++e) if (q + 8 * (size_t)t + e < g.n) w[t] |= (u64)g.text[q + 8 * t + e] << (8 * e);
+        }
+    }
+    u64 key = 0;
+#pragma unroll
+    for (int t = 0; t < 64; ++t)
+        if (t < g.s) key = (key << g.b) | ((q + t < g.n) ? (u64)code[(u8)(w[t >> 3] >> (8 * (t & 7)))] : 0ull);
+    k1[j] = a_r1[j];
+    k2[j] = key << g.pad;
+    v[j] = p;
+}
+__global__ void sa_isa_direct_kernel(const u32* __restrict__ sa, size_t n, u32* __restrict__ isa) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) isa[sa[i]] = (u32)i;
+}
+
+// ---- fast path: the unresolved suffixes behind the wide sort, from the head flags alone ------------------------------------------------
+// A slot is resolved when it is a head and its successor is one too (a group of one).  Everything else -- a few per cent of a
+// natural-language text -- is compacted into the active list (position, slot, slot of its group's head) in slot order.  Two streaming
+// passes over the flag bytes (tiles of 4096 slots) with two small scans in between; the suffix array itself is not touched.
+constexpr u32 FC_TILE = 4096;
+__device__ __forceinline__ u32 fc_head_mask(const u8* __restrict__ flags, size_t n, size_t i0) {     // bit q: slot i0 + q is a head (q <= 16; slots >= n count as heads)
+    u32 mask = 0;
+    if (i0 + 17 <= n && ((i0 & 15) == 0) && ((((size_t)flags) & 15) == 0)) {
+        const uint4 v = *(const uint4*)(flags + i0);
+        const u32 wv[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+        for (int q = 0; q < 16; ++q) if ((wv[q >> 2] >> (8 * (q & 3))) & 0xFFu) mask |= 1u << q;
+        if (flags[i0 + 16]) mask |= 1u << 16;
+    } else {
+#pragma unroll
+        for (int q = 0; q < 17; ++q) if (i0 + q >= n || flags[i0 + q]) mask |= 1u << q;
+    }
+    if (i0 == 0) mask |= 1u;
+    return mask;
+}
+__global__ __launch_bounds__(256) void sa_flag_count_kernel(const u8* __restrict__ flags, size_t n, u32* __restrict__ tile_cnt, u32* __restrict__ tile_last) {
+    __shared__ u32 sm[5], sm2[5];
+    const size_t i0 = (size_t)blockIdx.x * FC_TILE + (size_t)threadIdx.x * 16;
+    u32 cnt = 0, last = 0;
+    if (i0 < n) {
+        const u32 h = fc_head_mask(flags, n, i0);
+        const u32 valid = (i0 + 16 <= n) ? 0xFFFFu : ((1u << (n - i0)) - 1u);
+        const u32 single = h & (h >> 1) & valid;
+        cnt = (u32)__popc(valid & ~single);
+        const u32 hv = h & valid;
+        if (hv) last = (u32)(i0 + 31 - __builtin_clz(hv)) + 1u;
+    }
+    u32 total;
+    (void)block_exclusive_sum<u32, 4>(cnt, sm, total);
+    u32 tmax;
+    (void)block_inclusive_max<4>(last, sm2, tmax);
+    if (threadIdx.x == 0) { tile_cnt[blockIdx.x] = total; tile_last[blockIdx.x] = tmax; }
+}
+__global__ __launch_bounds__(256) void sa_flag_compact_kernel(const u8* __restrict__ flags, const u32* __restrict__ v, size_t n, const u32* __restrict__ tile_off,
+                                                               const u32* __restrict__ tile_lastscan, u32* __restrict__ o_sa, u32* __restrict__ o_pos,
+                                                               u32* __restrict__ o_r1) {
+    __shared__ u32 sm[5], sm2[5];
+    const size_t i0 = (size_t)blockIdx.x * FC_TILE + (size_t)threadIdx.x * 16;
+    u32 cnt = 0, last = 0, h = 0, valid = 0, single = 0;
+    if (i0 < n) {
+        h = fc_head_mask(flags, n, i0);
+        valid = (i0 + 16 <= n) ? 0xFFFFu : ((1u << (n - i0)) - 1u);
+        single = h & (h >> 1) & valid;
+        cnt = (u32)__popc(valid & ~single);
+        const u32 hv = h & valid;
+        if (hv) last = (u32)(i0 + 31 - __builtin_clz(hv)) + 1u;
+    }
+    u32 total;
+    const u32 pre = block_exclusive_sum<u32, 4>(cnt, sm, total);
+    u32 tmax;
+    const u32 inc = block_inclusive_max<4>(last, sm2, tmax);
+    // head of the run that is open at the thread's first slot: the last head in front of it (earlier threads, earlier tiles)
+    u32 run = __shfl_up(inc, 1, 64);
+    if (lane_id() == 0) run = sm2[wave_id()];                       // (block_inclusive_max leaves the exclusive wave prefixes in sm2[0..3])
+    if (!cnt) return;
+    if (blockIdx.x > 0) run = max(run, tile_lastscan[blockIdx.x - 1]);
+    u32 o = tile_off[blockIdx.x] + pre;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        if (!((valid >> q) & 1u)) break;
+        if ((h >> q) & 1u) run = (u32)(i0 + q) + 1u;
+        if (!((single >> q) & 1u)) { o_sa[o] = v[i0 + q]; o_pos[o] = (u32)(i0 + q); o_r1[o] = run - 1u; ++o; }
+    }
+}
+
+namespace {
+struct SABufs {
+    u64* keys[2]; u32* vals[2];
+    u32 *head, *keep;
+    u32 *A_sa, *A_pos, *A_r1, *B_sa, *B_pos, *B_r1;
+    u32* d_total; u64* lkeys; u32* lvals; u64* gdesc; u32* gticket;
+};
+const WideRound NO_WIDE = { nullptr, nullptr, nullptr, 0, 0 };
+
+// first bookkeeping pass over the initial order (keys[x] / vals, or the head flags of a refinement / the wide sort) + the rank
+// scatter; returns the number of unresolved suffixes (h_tot = the kernel's counters)
+size_t first_groups(Ctx& c, size_t n, int bn, const u64* keys, const u32* vals, const u8* hflags, u32* sa, u32* rank, SABufs& B, bool want_ranks,
+                    u32 h_tot[4]) {
+    hipStream_t s = c.stream;
+    const u32 tiles = cdiv(n, GR_TILE);
+    HIP_TRY(hipMemsetAsync(B.gdesc, 0, (size_t)tiles * sizeof(u64), s));
+    HIP_TRY(hipMemsetAsync(B.gticket, 0, sizeof(u32), s));
+    HIP_TRY(hipMemsetAsync(B.d_total, 0, 4 * sizeof(u32), s));
+    const bool bucketed = want_ranks && c.bucket_scatter && n >= ((size_t)1 << 22);
+    {   // per element: read key + value (12 B), write sa + head (8 B) + the kept elements (12 B each, about half of them)
+        Ctx::ProfScope prof(c, K_SA_RANK_SCATTER, (u64)n * 26);
+        sa_groups_kernel<true, 0><<<tiles, 256, 0, s>>>(keys, vals, nullptr, n, bn, sa, want_ranks ? rank : nullptr, bucketed ? B.head : nullptr,
+                                                        B.A_sa, B.A_pos, B.A_r1, B.gdesc, B.gticket, B.d_total, c.d_err, tiles, hflags, NO_WIDE);
+        LAUNCH_CHECK();
+    }
+    // rank[vals[j]] = head[j] through a partition by destination window; the second key buffer and the B lists are free scratch
+    if (bucketed) bucketed_scatter_u32(c, vals, B.head, n, rank, n, (u32*)B.keys[1], B.vals[1], B.B_sa, B.B_pos, true);   // every position once
+    c.read_n(B.d_total, h_tot, 4);
+    return h_tot[0];
+}
+
+// prefix doubling from h on: the active list (A_sa, A_pos, A_r1) holds the m unresolved suffixes, rank[] is up to date
+void doubling_rounds(Ctx& c, size_t n, int bn, u32* sa, u32* rank, SABufs& B, size_t m, u64 h, u32 h_tot[4], SAStats* st) {
+    hipStream_t s = c.stream;
+    u64** keys = B.keys; u32** vals = B.vals;
+    // Sort of a round: groups of a handful of suffixes (random texts, DNA) are sorted inside 2048-element tiles and only the
+    // groups that cross tile borders go through a global sort; where the unresolved suffixes sit in large groups (the frequent
+    // words of a natural-language text: most of them would be border-crossing "open" groups anyway) ONE splitter sort of the whole
+    // active list is cheaper (2e9 B English: -14 ms; DNA: +11 ms the other way round).
+    auto big_groups = [&]() { return h_tot[2] != 0 && (u64)h_tot[1] >= 64ull * h_tot[2]; };
+    int x;
+    while (m > 0) {
+        if (h >= n) throw HipError{hipErrorUnknown, "suffix_array: doubling did not converge", (int)__LINE__};
+        const unsigned gm = cdiv(m, 256);
+        {   // per element: read sa + r1 (8 B), gather rank[sa+h] (4 B), write key + value (12 B)
+            Ctx::ProfScope prof(c, K_SA_BUILD_KEYS, (u64)m * 24);
+            sa_build_keys_kernel<<<gm, 256, 0, s>>>(B.A_sa, B.A_r1, m, n, (u32)h, bn, rank, keys[0], vals[0]);
+            LAUNCH_CHECK();
+        }
+        if ((c.sa_local_sort == 2 || (c.sa_local_sort == 1 && big_groups())) && c.ssort && splitter_sort_applicable(m)) {
+            x = splitter_sort_pairs_u64(c, keys, vals, m, nullptr, nullptr);
+            st->sorted_elems += m;
+        } else if (c.sa_local_sort) {
+            // local part: whole runs inside 2048-element tiles; global part: only the runs that cross a tile border
+            u8* cls = (u8*)B.keep;                                 // scratch
+            {
+                Ctx::ProfScope prof(c, K_SA_LOCAL_SORT, (u64)m * 25);
+                sa_local_sort_kernel<<<cdiv(m, 2048), 256, 0, s>>>(keys[0], vals[0], m, bn, cls);
+                LAUNCH_CHECK();
+            }
+            u32* opos = B.B_sa;                                    // B_* are free until the compaction of this round
+            select_by_class(c, cls, 1, m, nullptr, opos, nullptr, nullptr, B.d_total);
+            const size_t mo = c.read(B.d_total);
+            if (mo > n / 2) {                                      // a few giant runs: sort everything globally
+                x = (c.ssort && splitter_sort_applicable(m)) ? splitter_sort_pairs_u64(c, keys, vals, m, nullptr, nullptr)
+                                                              : radix_sort_pairs_u64(c, keys, vals, m, 0, 2 * bn);
+                st->sorted_elems += m;
+            } else {
+            st->sorted_elems += mo;
+            if (mo) {
+                u64* ok2[2] = { keys[1], B.lkeys };
+                u32* ov2[2] = { vals[1], B.lvals };
+                select_by_class(c, cls, 1, m, vals[0], ov2[0], keys[0], ok2[0], B.d_total);
+                const int y = (c.ssort && splitter_sort_applicable(mo)) ? splitter_sort_pairs_u64(c, ok2, ov2, mo, nullptr, nullptr)
+                                                                        : radix_sort_pairs_u64(c, ok2, ov2, mo, 0, 2 * bn);
+                sa_scatter_back_kernel<<<cdiv(mo, 256), 256, 0, s>>>(opos, ok2[y], ov2[y], mo, keys[0], vals[0]);
+                LAUNCH_CHECK();
+            }
+            x = 0;
+            }
+        } else {
+            x = radix_sort_pairs_u64(c, keys, vals, m, 0, 2 * bn);
+            st->sorted_elems += m;
+        }
+        {
+            // a large round scatters its ranks through the bucketed scatter (scratch: the other sort buffers, head / keep)
+            const bool bucketed = c.bucket_scatter && m >= ((size_t)1 << 24);
+            u32* nr = (u32*)keys[x ^ 1];
+            const u32 tiles = cdiv(m, GR_TILE);
+            HIP_TRY(hipMemsetAsync(B.gdesc, 0, (size_t)tiles * sizeof(u64), s));
+            HIP_TRY(hipMemsetAsync(B.gticket, 0, sizeof(u32), s));
+            HIP_TRY(hipMemsetAsync(B.d_total, 0, 4 * sizeof(u32), s));
+            {   // per element: key, value, position (16 B), sa + new rank (8 B), the kept elements (12 B each)
+                Ctx::ProfScope prof(c, K_SA_RANK_SCATTER, (u64)m * 30);
+                sa_groups_kernel<false, 0><<<tiles, 256, 0, s>>>(keys[x], vals[x], B.A_pos, m, bn, sa, rank, bucketed ? nr : nullptr, B.B_sa, B.B_pos, B.B_r1,
+                                                                 B.gdesc, B.gticket, B.d_total, c.d_err, tiles, nullptr, NO_WIDE);
+                LAUNCH_CHECK();
+            }
+            if (bucketed) bucketed_scatter_u32(c, vals[x], nr, m, rank, n, nr + m, vals[x ^ 1], B.head, B.keep);
+        }
+        c.read_n(B.d_total, h_tot, 4);
+        m = h_tot[0];
+        u32* t;
+        t = B.A_sa; B.A_sa = B.B_sa; B.B_sa = t;
+        t = B.A_pos; B.A_pos = B.B_pos; B.B_pos = t;
+        t = B.A_r1; B.A_r1 = B.B_r1; B.B_r1 = t;
+        h *= 2;
+        st->rounds++;
+    }
+}
+
+// The wide path (large texts): bit-packed 1- or 2-word keys through wsort.hip, then either
+//   * text rounds -- the unresolved suffixes (a few per cent) are sorted by (group head, next 64 key bits read from the text) until every
+//     group is a singleton; no rank array exists, the LCP of neighbouring suffixes falls out of the keys (lcp8), and ISA / Phi / PLCP are
+//     produced afterwards by ONE fused scatter (fused.hip).  Result mode 1: sa final, lcp8 valid, isa NOT written;
+//   * or, for texts with deep repeats (many unresolved suffixes, or the rounds do not get anywhere), the rank scatter + prefix doubling
+//     of the classic path from the depth reached so far.  Result mode 0.
+int build_suffix_array_wide(Ctx& c, const u8* text, size_t n, u32* sa, u32* isa, SAStats* st, SAExtra* ex, const CodeMap& cm, u32 sigma) {
+    hipStream_t s = c.stream;
+    const int b = (int)bits_for(sigma > 1 ? sigma - 1 : 1);
+    const int per_word = 64 / b;
+    const int KW = c.wsort_kw ? c.wsort_kw : (per_word < 16 ? 2 : 1);
+    WKeyGen g;
+    g.text = text; g.n = n; g.b = b;
+    g.s = (64 * KW) / b; if (g.s > 64) g.s = 64;
+    g.pad = 64 * KW - g.s * b;
+    g.inv = (65536u + (u32)b - 1) / (u32)b;
+    memcpy(g.code, cm.code, 256);
+    WKeyGen g1 = g;                                            // the 64-bit keys of the text rounds
+    g1.s = per_word > 64 ? 64 : per_word; g1.pad = 64 - g1.s * b;
+    st->sym_bits = b; st->init_syms = g.s;
+
+    SABufs B;
+    u64* K1[2] = { c.arena.get<u64>(n), c.arena.get<u64>(n) };
+    u64* K2[2] = { c.arena.get<u64>(n), c.arena.get<u64>(n) };  // (the rounds sort two-word records whatever the initial width)
+    u32* V[2] = { c.arena.get<u32>(n), c.arena.get<u32>(n) };
+    u32* vspare = nullptr;                                     // the sorted positions land in sa[] itself: no copy afterwards
+    { const int ri = wsort_result_index(c, n); vspare = V[ri]; V[ri] = sa; }
+    B.keys[0] = K1[0]; B.keys[1] = K1[1];
+    u8* flags = c.arena.get<u8>(n + 8);
+    u8* lcp8 = (ex && ex->lcp8) ? ex->lcp8 : c.arena.get<u8>(n + 8);
+    B.head = c.arena.get<u32>(n); B.keep = c.arena.get<u32>(n);
+    B.A_sa = c.arena.get<u32>(n); B.A_pos = c.arena.get<u32>(n); B.A_r1 = c.arena.get<u32>(n);
+    B.B_sa = c.arena.get<u32>(n); B.B_pos = c.arena.get<u32>(n); B.B_r1 = c.arena.get<u32>(n);
+    B.d_total = c.arena.get<u32>(4);
+    B.lkeys = c.arena.get<u64>(n / 2 + 2048);
+    B.lvals = c.arena.get<u32>(n / 2 + 2048);
+    B.gdesc = c.arena.get<u64>(cdiv(n, GR_TILE) + 1);
+    B.gticket = c.arena.get<u32>(1);
+    const int bn = (int)bits_for(n - 1);
+
+    WSortStats ws;
+    const int x = wsort_suffixes(c, KW, g, K1, K2, V, n, flags, lcp8, &ws);
+    st->sorted_elems += n;
+    st->wide_kw = (u32)KW; st->wide_nonheads = ws.nonheads;
+
+    // unresolved suffixes <= 2 * (slots that are not group heads): the text rounds pay while they are few
+    bool fast = ex != nullptr && c.wsort_rounds > 0 && 2 * ws.nonheads <= n / 8;
+    u32 h_tot[4] = { 0, 0, 0, 0 };
+    size_t m;
+    if (V[x] != sa) {                                          // (cannot happen: wsort_result_index names the buffer wsort returns)
+        HIP_TRY(hipMemcpyAsync(sa, V[x], n * sizeof(u32), hipMemcpyDeviceToDevice, s));
+    } else V[x] = vspare;                                      // sa[] is the result now; the rounds get the spare buffer to sort in
+    B.vals[0] = V[0]; B.vals[1] = V[1];                        // (scratch of the rank scatter / buffers of the doubling rounds)
+    if (fast) {
+        const u32 tiles = cdiv(n, FC_TILE);
+        u32* tile_cnt = c.arena.get<u32>(tiles + 1);
+        u32* tile_last = c.arena.get<u32>(tiles + 1);
+        Ctx::ProfScope prof(c, K_SA_RANK_SCATTER, (u64)n * 2 + 2 * ws.nonheads * 16);
+        sa_flag_count_kernel<<<tiles, 256, 0, s>>>(flags, n, tile_cnt, tile_last);
+        LAUNCH_CHECK();
+        exclusive_sum_u32(c, tile_cnt, tile_cnt, tiles, B.d_total);
+        inclusive_max_u32(c, tile_last, tile_last, tiles);
+        sa_flag_compact_kernel<<<tiles, 256, 0, s>>>(flags, sa, n, tile_cnt, tile_last, B.A_sa, B.A_pos, B.A_r1);
+        LAUNCH_CHECK();
+        m = c.read(B.d_total);
+    } else m = first_groups(c, n, bn, nullptr, sa, flags, sa, isa, B, true, h_tot);
+    st->rounds = 1;
+    u32 h = (u32)g.s;
+    int text_rounds = 0;
+    while (fast && m > 0) {
+        if (text_rounds >= c.wsort_rounds || h + (u32)g1.s > 250u) { fast = false; break; }
+        {   // per element: position, head (8 B), one scattered text read, three record words (20 B)
+            Ctx::ProfScope prof(c, K_SA_BUILD_KEYS, (u64)m * 28);
+            sa_round_keys_kernel<<<cdiv(m, 256), 256, 0, s>>>(B.A_sa, B.A_r1, m, g1, h, K1[0], K2[0], V[0]);
+            LAUNCH_CHECK();
+        }
+        const int y = wsort_records(c, K1, K2, V, m, bn, nullptr);
+        st->sorted_elems += m;
+        const u32 tiles = cdiv(m, GR_TILE);
+        HIP_TRY(hipMemsetAsync(B.gdesc, 0, (size_t)tiles * sizeof(u64), s));
+        HIP_TRY(hipMemsetAsync(B.gticket, 0, sizeof(u32), s));
+        HIP_TRY(hipMemsetAsync(B.d_total, 0, 4 * sizeof(u32), s));
+        {
+            Ctx::ProfScope prof(c, K_SA_RANK_SCATTER, (u64)m * 38);
+            const WideRound wr = { K2[y], flags, lcp8, h, g.inv };
+            sa_groups_kernel<false, 1><<<tiles, 256, 0, s>>>(K1[y], V[y], B.A_pos, m, bn, sa, nullptr, nullptr, B.B_sa, B.B_pos, B.B_r1,
+                                                             B.gdesc, B.gticket, B.d_total, c.d_err, tiles, nullptr, wr);
+            LAUNCH_CHECK();
+        }
+        c.read_n(B.d_total, h_tot, 4);
+        m = h_tot[0];
+        u32* t;
+        t = B.A_sa; B.A_sa = B.B_sa; B.B_sa = t;
+        t = B.A_pos; B.A_pos = B.B_pos; B.B_pos = t;
+        t = B.A_r1; B.A_r1 = B.B_r1; B.B_r1 = t;
+        h += (u32)g1.s;
+        ++text_rounds;
+        st->rounds++;
+    }
+    st->text_rounds = (u32)text_rounds;
+    if (fast) {                                                // every suffix is a group of its own: sa is final
+        if (!ex) throw HipError{hipErrorUnknown, "suffix_array: internal (fast path without a sink)", (int)__LINE__};
+        return 1;
+    }
+    if (text_rounds > 0) {
+        // the rounds gave up: ranks of the state reached so far (sa + head flags), then doubling from the common depth h
+        m = first_groups(c, n, bn, nullptr, sa, flags, sa, isa, B, true, h_tot);
+    }
+    doubling_rounds(c, n, bn, sa, isa, B, m, (u64)h, h_tot, st);
+    return 0;
+}
+}  // namespace
+
+void build_suffix_array(Ctx& c, const u8* text, size_t n, u32* sa, u32* isa, SAStats* st, SAExtra* ex) {
     SAStats local;
     if (!st) st = &local;
     *st = SAStats();
+    if (ex) ex->mode = 0;
     if (n == 0) return;
     hipStream_t s = c.stream;
     const size_t mark = c.arena.mark();
@@ -474,6 +828,14 @@ void build_suffix_array(Ctx& c, const u8* text, size_t n, u32* sa, u32* isa, SAS
     u32 sigma = 0;
     for (int i = 0; i < 256; ++i) { cm.code[i] = (u8)sigma; if (h_hist[i]) ++sigma; }
     // a byte that does not occur keeps the code of the next present byte; irrelevant (never looked up)
+
+    if (wsort_applicable(c, n)) {
+        const int mode = build_suffix_array_wide(c, text, n, sa, isa, st, ex, cm, sigma);
+        if (ex) ex->mode = mode;
+        c.arena.release(mark);
+        return;
+    }
+
     const int b = (int)bits_for(sigma > 1 ? sigma - 1 : 1);
     const u32 base = sigma > 2 ? sigma : 2;
     int k = 0;                                               // largest k with base^k <= 2^64, at most 32 (LDS halo of the key kernel)
@@ -487,15 +849,17 @@ void build_suffix_array(Ctx& c, const u8* text, size_t n, u32* sa, u32* isa, SAS
     st->sym_bits = b; st->init_syms = k;
 
     // --- buffers ----------------------------------------------------------------------------------
-    u64* keys[2] = { c.arena.get<u64>(n), c.arena.get<u64>(n) };
-    u32* vals[2] = { c.arena.get<u32>(n), c.arena.get<u32>(n) };
-    u32* head = c.arena.get<u32>(n);
-    u32* keep = c.arena.get<u32>(n);
-    u32* A_sa = c.arena.get<u32>(n), *A_pos = c.arena.get<u32>(n), *A_r1 = c.arena.get<u32>(n);
-    u32* B_sa = c.arena.get<u32>(n), *B_pos = c.arena.get<u32>(n), *B_r1 = c.arena.get<u32>(n);
-    u32* d_total = c.arena.get<u32>(4);                // [0] unresolved elements after a bookkeeping pass; [1], [2]: sampled elements / groups
-    u64* lkeys = c.arena.get<u64>(n / 2 + 2048);       // second buffers of the "open run" sort (at most half of the list...)
-    u32* lvals = c.arena.get<u32>(n / 2 + 2048);
+    SABufs B;
+    B.keys[0] = c.arena.get<u64>(n); B.keys[1] = c.arena.get<u64>(n);
+    B.vals[0] = c.arena.get<u32>(n); B.vals[1] = c.arena.get<u32>(n);
+    B.head = c.arena.get<u32>(n);
+    B.keep = c.arena.get<u32>(n);
+    B.A_sa = c.arena.get<u32>(n); B.A_pos = c.arena.get<u32>(n); B.A_r1 = c.arena.get<u32>(n);
+    B.B_sa = c.arena.get<u32>(n); B.B_pos = c.arena.get<u32>(n); B.B_r1 = c.arena.get<u32>(n);
+    B.d_total = c.arena.get<u32>(4);                // [0] unresolved elements after a bookkeeping pass; [1], [2]: sampled elements / groups
+    B.lkeys = c.arena.get<u64>(n / 2 + 2048);       // second buffers of the "open run" sort (at most half of the list...)
+    B.lvals = c.arena.get<u32>(n / 2 + 2048);
+    u64** keys = B.keys; u32** vals = B.vals;
     u32* rank = isa;
 
     // --- initial sort by the first k symbols ------------------------------------------------------
@@ -521,110 +885,21 @@ void build_suffix_array(Ctx& c, const u8* text, size_t n, u32* sa, u32* isa, SAS
         RefineGen rg;
         rg.text = text; rg.n = n; rg.sigma = base; rg.k = k; rg.chunk = chunk;
         memcpy(rg.code, cm.code, 256);
-        u8* fl = (u8*)keep;                                  // free until the rounds use it as class bytes
+        u8* fl = (u8*)B.keep;                                // free until the rounds use it as class bytes
         Ctx::ProfScope prof(c, K_SA_BUILD_KEYS, (u64)n * 17 + (u64)n * 8);     // key + position in, position + flag out; ~0.4 scattered text reads per element
         sa_refine_kernel<<<cdiv(n, RF_TILE), 256, 0, s>>>(keys[x], vals[x], n, rg, fl, sa);       // the refined order goes straight into sa[]
         LAUNCH_CHECK();
         hflags = fl;
     }
     const int bn = (int)bits_for(n - 1);
-    u64* gdesc = c.arena.get<u64>(cdiv(n, GR_TILE) + 1);       // look-back descriptors + ticket of the group kernel
-    u32* gticket = c.arena.get<u32>(1);
-    {
-        const u32 tiles = cdiv(n, GR_TILE);
-        HIP_TRY(hipMemsetAsync(gdesc, 0, (size_t)tiles * sizeof(u64), s));
-        HIP_TRY(hipMemsetAsync(gticket, 0, sizeof(u32), s));
-        HIP_TRY(hipMemsetAsync(d_total, 0, 4 * sizeof(u32), s));
-        const bool bucketed = c.bucket_scatter && n >= ((size_t)1 << 22);
-        {   // per element: read key + value (12 B), write sa + head (8 B) + the kept elements (12 B each, about half of them)
-            Ctx::ProfScope prof(c, K_SA_RANK_SCATTER, (u64)n * 26);
-            sa_groups_kernel<true><<<tiles, 256, 0, s>>>(keys[x], hflags ? sa : vals[x], nullptr, n, bn, sa, rank, bucketed ? head : nullptr, A_sa, A_pos, A_r1,
-                                                         gdesc, gticket, d_total, c.d_err, tiles, hflags);
-            LAUNCH_CHECK();
-        }
-        // rank[vals[j]] = head[j] through a partition by destination window; the other key buffer and the B lists are free scratch
-        if (bucketed) bucketed_scatter_u32(c, hflags ? sa : vals[x], head, n, rank, n, (u32*)keys[x ^ 1], vals[x ^ 1], B_sa, B_pos, true);   // every position once
-    }
+    B.gdesc = c.arena.get<u64>(cdiv(n, GR_TILE) + 1);       // look-back descriptors + ticket of the group kernel
+    B.gticket = c.arena.get<u32>(1);
     u32 h_tot[4];
-    c.read_n(d_total, h_tot, 4);
-    size_t m = h_tot[0];
-    // Sort of a round: groups of a handful of suffixes (random texts, DNA) are sorted inside 2048-element tiles and only the
-    // groups that cross tile borders go through a global sort; where the unresolved suffixes sit in large groups (the frequent
-    // words of a natural-language text: most of them would be border-crossing "open" groups anyway) ONE splitter sort of the whole
-    // active list is cheaper (2e9 B English: -14 ms; DNA: +11 ms the other way round).
-    auto big_groups = [&]() { return h_tot[2] != 0 && (u64)h_tot[1] >= 64ull * h_tot[2]; };
+    // (the rank scatter of first_groups uses keys[1] / vals[1] as scratch: the sorted pairs must be in the [0] buffers by then)
+    if (x != 0) { u64* tk = keys[0]; keys[0] = keys[1]; keys[1] = tk; u32* tv = vals[0]; vals[0] = vals[1]; vals[1] = tv; x = 0; }
+    const size_t m = first_groups(c, n, bn, keys[0], hflags ? sa : vals[0], hflags, sa, rank, B, true, h_tot);
     st->rounds = 1;
-
-    // --- doubling rounds --------------------------------------------------------------------------
-    u64 h = (u64)k;
-    while (m > 0) {
-        if (h >= n) throw HipError{hipErrorUnknown, "suffix_array: doubling did not converge", (int)__LINE__};
-        const unsigned gm = cdiv(m, 256);
-        {   // per element: read sa + r1 (8 B), gather rank[sa+h] (4 B), write key + value (12 B)
-            Ctx::ProfScope prof(c, K_SA_BUILD_KEYS, (u64)m * 24);
-            sa_build_keys_kernel<<<gm, 256, 0, s>>>(A_sa, A_r1, m, n, (u32)h, bn, rank, keys[0], vals[0]);
-            LAUNCH_CHECK();
-        }
-        if ((c.sa_local_sort == 2 || (c.sa_local_sort == 1 && big_groups())) && c.ssort && splitter_sort_applicable(m)) {
-            x = splitter_sort_pairs_u64(c, keys, vals, m, nullptr, nullptr);
-            st->sorted_elems += m;
-        } else if (c.sa_local_sort) {
-            // local part: whole runs inside 2048-element tiles; global part: only the runs that cross a tile border
-            u8* cls = (u8*)keep;                                   // scratch (keep is rewritten by sa_update_kernel)
-            {
-                Ctx::ProfScope prof(c, K_SA_LOCAL_SORT, (u64)m * 25);
-                sa_local_sort_kernel<<<cdiv(m, 2048), 256, 0, s>>>(keys[0], vals[0], m, bn, cls);
-                LAUNCH_CHECK();
-            }
-            u32* opos = B_sa;                                      // B_* are free until the compaction of this round
-            select_by_class(c, cls, 1, m, nullptr, opos, nullptr, nullptr, d_total);
-            const size_t mo = c.read(d_total);
-            if (mo > n / 2) {                                      // a few giant runs: sort everything globally
-                x = (c.ssort && splitter_sort_applicable(m)) ? splitter_sort_pairs_u64(c, keys, vals, m, nullptr, nullptr)
-                                                              : radix_sort_pairs_u64(c, keys, vals, m, 0, 2 * bn);
-                st->sorted_elems += m;
-            } else {
-            st->sorted_elems += mo;
-            if (mo) {
-                u64* ok2[2] = { keys[1], lkeys };
-                u32* ov2[2] = { vals[1], lvals };
-                select_by_class(c, cls, 1, m, vals[0], ov2[0], keys[0], ok2[0], d_total);
-                const int y = (c.ssort && splitter_sort_applicable(mo)) ? splitter_sort_pairs_u64(c, ok2, ov2, mo, nullptr, nullptr)
-                                                                        : radix_sort_pairs_u64(c, ok2, ov2, mo, 0, 2 * bn);
-                sa_scatter_back_kernel<<<cdiv(mo, 256), 256, 0, s>>>(opos, ok2[y], ov2[y], mo, keys[0], vals[0]);
-                LAUNCH_CHECK();
-            }
-            x = 0;
-            }
-        } else {
-            x = radix_sort_pairs_u64(c, keys, vals, m, 0, 2 * bn);
-            st->sorted_elems += m;
-        }
-        {
-            // a large round scatters its ranks through the bucketed scatter (scratch: the other sort buffers, head / keep)
-            const bool bucketed = c.bucket_scatter && m >= ((size_t)1 << 24);
-            u32* nr = (u32*)keys[x ^ 1];
-            const u32 tiles = cdiv(m, GR_TILE);
-            HIP_TRY(hipMemsetAsync(gdesc, 0, (size_t)tiles * sizeof(u64), s));
-            HIP_TRY(hipMemsetAsync(gticket, 0, sizeof(u32), s));
-            HIP_TRY(hipMemsetAsync(d_total, 0, 4 * sizeof(u32), s));
-            {   // per element: key, value, position (16 B), sa + new rank (8 B), the kept elements (12 B each)
-                Ctx::ProfScope prof(c, K_SA_RANK_SCATTER, (u64)m * 30);
-                sa_groups_kernel<false><<<tiles, 256, 0, s>>>(keys[x], vals[x], A_pos, m, bn, sa, rank, bucketed ? nr : nullptr, B_sa, B_pos, B_r1,
-                                                              gdesc, gticket, d_total, c.d_err, tiles);
-                LAUNCH_CHECK();
-            }
-            if (bucketed) bucketed_scatter_u32(c, vals[x], nr, m, rank, n, nr + m, vals[x ^ 1], head, keep);
-        }
-        c.read_n(d_total, h_tot, 4);
-        m = h_tot[0];
-        u32* t;
-        t = A_sa; A_sa = B_sa; B_sa = t;
-        t = A_pos; A_pos = B_pos; B_pos = t;
-        t = A_r1; A_r1 = B_r1; B_r1 = t;
-        h *= 2;
-        st->rounds++;
-    }
+    doubling_rounds(c, n, bn, sa, rank, B, m, (u64)k, h_tot, st);
     c.arena.release(mark);
 }
 

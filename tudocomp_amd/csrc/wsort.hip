@@ -1,0 +1,1282 @@
+// wsort.hip -- wide-key splitter sort of all suffixes of a text (gfx950, wave64): the suffix array's initial order.
+//
+// Replaces, for large texts, the 64-bit initial sort + refinement pass + first doubling round of suffix_array.hip
+// (ds/SADivSufSort.hpp:27-51 semantics: the suffix array is unique, any correct construction is bit-compatible).
+//
+// Keys are BIT-PACKED: the recoded symbols text[p .. p+s) as s fields of b bits, left-aligned in KW = 1 or 2 64-bit words.  Two keys
+// that differ share floor(clz(k ^ k') / b) symbols -- the LCP value of the two suffixes, for free, wherever the sort separates them.
+// With two words an English-like text (29 symbols, b = 5) is sorted by 25 symbols in one go: ~5 % of the suffixes of a 2 GB text
+// still tie afterwards, instead of two thirds after 13 symbols.
+//
+// Structure = ssort.hip (sampled splitters, 2-3 partition levels on key RANKS, in-LDS leaf sort), with these differences:
+//   * records are (k1, k2, position): 20 bytes; level 1 computes its keys from the text (no key array is read); the scatter pass
+//     stages one stream at a time through LDS, so the record width costs no registers;
+//   * splitter comparisons are 128-bit, so a heavy 64-bit prefix (a frequent word) is split by its second word across many leaves;
+//   * the leaf kernel sorts a unit (<= 8192 records) by k1 with the composite-word LSD passes of ssort.hip, then orders the runs
+//     of equal k1 by k2: runs of <= 256 by counting in LDS, longer ones by LSD passes on (run head, 16-bit chunk of k2) -- and
+//     writes, instead of the sorted keys, what the suffix array needs: the positions, one head flag per slot (slot starts a group of
+//     equal keys) and the LCP (in symbols) of every head with its predecessor.  Unit-border LCPs come from a tiny fix-up kernel
+//     that re-reads the two suffixes from the text.
+// The sort is not stable (equal keys form one group of the later rounds).
+#include "prim.hpp"
+
+#include <vector>
+#include <stdlib.h>
+
+namespace tdc {
+
+constexpr int WS_TILE = 4096;        // records per partition tile: 256 threads x 16
+constexpr int WS_ITEMS = 16;
+constexpr int WS_HALO = 64;          // symbols staged beyond a tile (s <= 64)
+constexpr int WS_SMALL = 4096;       // (as SS_SMALL: leaves up to this size are packed into units)
+constexpr int WS_UNIT_MAX = 8192;
+#ifndef TDC_WS_CMAX
+#define TDC_WS_CMAX 64
+#endif
+constexpr u32 WS_CMAX = TDC_WS_CMAX; // runs of equal k1 up to this length are ordered by counting (a member costs its run's length)
+constexpr u32 WS_WAVE_MAX = 1024;    // longer runs up to this length: one WAVE sorts the run (ws_run_wave_kernel); beyond: kernel A again
+
+struct WSLevel {
+    const u64* k1_in; const u64* k2_in; const u32* v_in;
+    u64* k1_out; u64* k2_out; u32* v_out;
+    u32* counts;                 // [rows][D]
+    const u32* blk_seg; const u32* blk_start; const u32* seg_start;
+    const u64* sp1; const u64* sp2;      // [NS + 1] splitters (high / low word), sp[NS] = ~0
+    u16* digits;
+    u32 nseg, F, stride, R, D, per_xcd;
+    size_t gen_off, gen_len;     // GEN level: the tiles cover text positions [gen_off, gen_off + gen_len)
+};
+
+__device__ __forceinline__ bool ws_row(const WSLevel& P, u32 row, u32& s, size_t& base, u32& cnt) {
+    const u32 blk = row / P.R;
+    if (blk >= P.blk_start[P.nseg]) return false;
+    s = P.blk_seg[blk];
+    const u64 t = (u64)(blk - P.blk_start[s]) * P.R + row % P.R;
+    const u32 s0 = P.seg_start[s], s1 = P.seg_start[s + 1];
+    const u64 off = t * WS_TILE;
+    base = s0; cnt = 0;
+    if (off >= (u64)(s1 - s0)) return true;
+    base = (size_t)s0 + off;
+    const u64 left = (u64)(s1 - s0) - off;
+    cnt = left < WS_TILE ? (u32)left : (u32)WS_TILE;
+    return true;
+}
+
+template <int KW, bool LAST>
+__device__ __forceinline__ void ws_load_splitters(const WSLevel& P, u32 s, u64* spl1, u64* spl2) {
+    for (u32 i = threadIdx.x; i < 256; i += blockDim.x) {
+        u64 a = ~0ull, b = ~0ull;
+        size_t idx = 0; bool have = false;
+        if (LAST) { if (i < P.F) { idx = (size_t)s * P.F + i; have = true; } }
+        else if (i + 1 < P.F) { idx = ((size_t)s * P.F + i + 1) * P.stride - 1; have = true; }
+        if (have) { a = P.sp1[idx]; if (KW == 2) b = P.sp2[idx]; }
+        spl1[i] = a;
+        if (KW == 2) spl2[i] = b;
+    }
+}
+
+// #splitters < x among spl[0 .. 255) (branch-free binary search, lexicographic on the two words), then the digit
+template <int KW, bool LAST>
+__device__ __forceinline__ u32 ws_digit(const u64* spl1, const u64* spl2, u64 x1, u64 x2) {
+    u32 lo = 0;
+#pragma unroll
+    for (u32 step = 128; step >= 1; step >>= 1) {
+        const u32 i = lo + step - 1;
+        const u64 a = spl1[i];
+        bool lt = a < x1;
+        if (KW == 2) { const u64 b = spl2[i]; lt = lt || (a == x1 && b < x2); }
+        lo += lt ? step : 0u;
+    }
+    if (LAST) {
+        bool eq = spl1[lo] == x1;
+        if (KW == 2) eq = eq && spl2[lo] == x2;
+        return 2 * lo + (eq ? 1u : 0u);
+    }
+    return lo;
+}
+
+// ---- keys from the text -----------------------------------------------------------------------------------------------------------
+// recoded bytes of the tile [t0, t0 + 4096) (+ halo) into LDS; positions >= n read as 0
+__device__ __forceinline__ void ws_gen_stage(const WKeyGen& g, size_t t0, const u8* __restrict__ code, u8* __restrict__ sy) {
+    const size_t p = t0 + (size_t)threadIdx.x * 16;
+    u8 b[16];
+    if (p + 16 <= g.n && (((size_t)(g.text + p)) & 15) == 0) {
+        const uint4 v = *(const uint4*)(g.text + p);
+        const u32 wv[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+        for (int i = 0; i < 16; ++i) b[i] = (u8)(wv[i >> 2] >> (8 * (i & 3)));
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) b[i] = (p + i < g.n) ? g.text[p + i] : (u8)0;
+    }
+    u32 o[4] = { 0, 0, 0, 0 };
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[i >> 2] |= (u32)((p + i < g.n) ? code[b[i]] : (u8)0) << (8 * (i & 3));
+    *(uint4*)(sy + (size_t)threadIdx.x * 16) = make_uint4(o[0], o[1], o[2], o[3]);
+    if (threadIdx.x < WS_HALO) {
+        const size_t q = t0 + WS_TILE + threadIdx.x;
+        sy[WS_TILE + threadIdx.x] = (q < g.n) ? code[g.text[q]] : (u8)0;
+    }
+}
+// key of the position whose symbols start at sy[lb]
+template <int KW>
+__device__ __forceinline__ void ws_key_first(const WKeyGen& g, const u8* sy, int lb, u64& a, u64& b) {
+    if (KW == 1) {
+        u64 k = 0;
+        for (int t = 0; t < g.s; ++t) k = (k << g.b) | sy[lb + t];
+        a = k << g.pad; b = 0;
+    } else {
+        unsigned __int128 k = 0;
+        for (int t = 0; t < g.s; ++t) k = (k << g.b) | sy[lb + t];
+        k <<= g.pad;
+        a = (u64)(k >> 64); b = (u64)k;
+    }
+}
+// key of the next position: the first symbol leaves at the top, `sym` enters behind the last one
+template <int KW>
+__device__ __forceinline__ void ws_key_roll(const WKeyGen& g, u64& a, u64& b, u32 sym) {
+    if (KW == 1) a = (a << g.b) | ((u64)sym << g.pad);
+    else {
+        unsigned __int128 k = ((unsigned __int128)a << 64) | b;
+        k = (k << g.b) | ((unsigned __int128)sym << g.pad);
+        a = (u64)(k >> 64); b = (u64)k;
+    }
+}
+// key of text position p straight from global memory (samples, unit borders)
+template <int KW>
+__device__ __forceinline__ void ws_key_global(const WKeyGen& g, const u8* __restrict__ code, size_t p, u64& a, u64& b) {
+    unsigned __int128 k = 0;
+    for (int t = 0; t < g.s; ++t) {
+        const size_t q = p + t;
+        k = (k << g.b) | ((q < g.n) ? (u32)code[g.text[q]] : 0u);
+    }
+    if (KW == 1) { a = (u64)k << g.pad; b = 0; }
+    else { k <<= g.pad; a = (u64)(k >> 64); b = (u64)k; }
+}
+
+// ---- sampling ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ size_t ws_sample_pos(u32 i, size_t n) {
+    const u64 h = ((u64)i + 1) * 0x9E3779B97F4A7C15ull;
+    return (size_t)(((unsigned __int128)(h ^ (h >> 29)) * n) >> 64);
+}
+template <int KW, bool GEN>
+__global__ __launch_bounds__(256) void ws_sample_kernel(const u64* __restrict__ k1, const u64* __restrict__ k2, WKeyGen g, size_t n, u32 S,
+                                                        u64* __restrict__ o1, u64* __restrict__ o2, u32* __restrict__ idx) {
+    __shared__ u8 code[256];
+    if (GEN) { code[threadIdx.x] = g.code[threadIdx.x]; __syncthreads(); }
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= S) return;
+    const size_t p = ws_sample_pos(i, n);
+    u64 a, b = 0;
+    if (GEN) ws_key_global<KW>(g, code, p, a, b);
+    else { a = k1[p]; if (KW == 2) b = k2[p]; }
+    o1[i] = a;
+    if (KW == 2) o2[i] = b;
+    idx[i] = i;
+}
+__global__ void ws_pick_kernel(const u64* __restrict__ s1, const u64* __restrict__ s2, u32 NS, u32 os, u64* __restrict__ sp1, u64* __restrict__ sp2) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < NS) { sp1[i] = s1[(size_t)(i + 1) * os - 1]; if (sp2) sp2[i] = s2[(size_t)(i + 1) * os - 1]; }
+    else if (i == NS) { sp1[i] = ~0ull; if (sp2) sp2[i] = ~0ull; }
+}
+
+// ---- LSD sort of wide records through the 64-bit radix sort (samples, small lists, oversized leaves) ----------------------------------
+__global__ void ws_iota_kernel(u32* __restrict__ p, size_t m) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) p[i] = (u32)i;
+}
+__global__ void ws_gather64_kernel(const u64* __restrict__ src, const u32* __restrict__ perm, size_t m, u64* __restrict__ dst) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) dst[i] = src[perm[i]];
+}
+__global__ void ws_gather32_kernel(const u32* __restrict__ src, const u32* __restrict__ perm, size_t m, u32* __restrict__ dst) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) dst[i] = src[perm[i]];
+}
+// (k1[0], k2[0], v[0]) -> (k1[1], k2[1], v[1]) sorted by (k1, k2), stable; k2 / v may be null pairs.  Scratch from the arena.
+static void ws_lsd_sort_wide(Ctx& c, u64* k1[2], u64* k2[2], u32* v[2], size_t m, int k1_bits) {
+    if (m == 0) return;
+    hipStream_t s = c.stream;
+    const size_t mark = c.arena.mark();
+    const unsigned g = cdiv(m, 256);
+    u64* A[2] = { c.arena.get<u64>(m), c.arena.get<u64>(m) };
+    u32* P[2] = { c.arena.get<u32>(m), c.arena.get<u32>(m) };
+    ws_iota_kernel<<<g, 256, 0, s>>>(P[0], m);
+    LAUNCH_CHECK();
+    int x = 0;
+    if (k2) {
+        HIP_TRY(hipMemcpyAsync(A[0], k2[0], m * sizeof(u64), hipMemcpyDeviceToDevice, s));
+        x = radix_sort_pairs_u64(c, A, P, m, 0, 64);
+    }
+    // stable by k1 on top of the k2 order
+    ws_gather64_kernel<<<g, 256, 0, s>>>(k1[0], P[x], m, A[x ^ 1]);
+    LAUNCH_CHECK();
+    u64* B[2] = { A[x ^ 1], A[x] };
+    u32* Q[2] = { P[x], P[x ^ 1] };
+    const int y = radix_sort_pairs_u64(c, B, Q, m, 0, k1_bits < 1 ? 1 : (k1_bits > 64 ? 64 : k1_bits));
+    HIP_TRY(hipMemcpyAsync(k1[1], B[y], m * sizeof(u64), hipMemcpyDeviceToDevice, s));
+    if (k2) { ws_gather64_kernel<<<g, 256, 0, s>>>(k2[0], Q[y], m, k2[1]); LAUNCH_CHECK(); }
+    if (v) { ws_gather32_kernel<<<g, 256, 0, s>>>(v[0], Q[y], m, v[1]); LAUNCH_CHECK(); }
+    c.arena.release(mark);
+}
+
+// ---- count ------------------------------------------------------------------------------------------------------------------------
+template <int KW, bool GEN, bool LAST>
+__global__ __launch_bounds__(256) void ws_count_kernel(WSLevel P, WKeyGen g, u32 rows) {
+    __shared__ u32 hist[512];
+    __shared__ u64 spl1[256];
+    __shared__ u64 spl2[KW == 2 ? 256 : 1];
+    __shared__ u8 code[256];
+    __shared__ __align__(16) u8 sy[GEN ? WS_TILE + WS_HALO : 16];
+    const u32 row = xcd_tile(blockIdx.x, P.per_xcd);
+    if (row >= rows) return;
+    u32 s, cnt; size_t base;
+    if (!ws_row(P, row, s, base, cnt)) return;
+    for (u32 i = threadIdx.x; i < P.D; i += 256) hist[i] = 0;
+    if (cnt == 0) {
+        for (u32 i = threadIdx.x; i < P.D; i += 256) P.counts[(size_t)row * P.D + i] = 0;
+        return;
+    }
+    ws_load_splitters<KW, LAST>(P, s, spl1, spl2);
+    if (GEN) code[threadIdx.x] = g.code[threadIdx.x];
+    __syncthreads();
+    if (GEN) { ws_gen_stage(g, P.gen_off + base, code, sy); __syncthreads(); }
+    if (GEN) {
+        const int lb = wave_id() * (64 * WS_ITEMS) + lane_id() * WS_ITEMS;      // a lane owns 16 consecutive positions
+        u64 ka, kb;
+        ws_key_first<KW>(g, sy, lb, ka, kb);
+        u32 pk[WS_ITEMS / 2];
+#pragma unroll
+        for (int j = 0; j < WS_ITEMS; ++j) {
+            const bool valid = (u32)(lb + j) < cnt;
+            const u32 d = valid ? ws_digit<KW, LAST>(spl1, spl2, ka, kb) : 0u;
+            ws_key_roll<KW>(g, ka, kb, sy[lb + j + g.s]);
+            pk[j >> 1] = (j & 1) ? (pk[j >> 1] | (d << 16)) : d;
+            const u32 d0 = __builtin_amdgcn_readfirstlane(d);
+            if (__all(valid && d == d0)) { if (lane_id() == 0) atomicAdd(&hist[d0], 64u); }
+            else if (valid) atomicAdd(&hist[d], 1u);
+        }
+        uint4* dp = (uint4*)(P.digits + base + lb);                             // 32 bytes, 32-byte aligned; the array is padded to whole tiles
+        dp[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        dp[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+    } else {
+        const u32 lb = wave_id() * (64 * WS_ITEMS) + lane_id();
+        const u64* kp1 = P.k1_in + base + lb;
+        const u64* kp2 = KW == 2 ? P.k2_in + base + lb : nullptr;
+        u16* dgp = P.digits + base + lb;
+#pragma unroll 4
+        for (int j = 0; j < WS_ITEMS; ++j) {
+            const u32 e = lb + (u32)j * 64;
+            const bool valid = e < cnt;
+            const u64 x1 = valid ? kp1[j * 64] : 0ull;
+            const u64 x2 = (KW == 2 && valid) ? kp2[j * 64] : 0ull;
+            const u32 d = valid ? ws_digit<KW, LAST>(spl1, spl2, x1, x2) : 0u;
+            if (valid) dgp[j * 64] = (u16)d;
+            const u32 d0 = __builtin_amdgcn_readfirstlane(d);
+            if (__all(valid && d == d0)) { if (lane_id() == 0) atomicAdd(&hist[d0], 64u); }
+            else if (valid) atomicAdd(&hist[d], 1u);
+        }
+    }
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < P.D; i += 256) P.counts[(size_t)row * P.D + i] = hist[i];
+}
+
+// ---- scatter ----------------------------------------------------------------------------------------------------------------------
+// Ranks inside the tile as in ssort.hip (LDS atomics with the two-group peel on the inner levels; the wave-level LDS match on the last
+// level, whose equality digits are skewed by construction).  The tile is then written stream by stream -- positions, k1, k2 -- each
+// staged in LDS in digit order first, so that consecutive lanes write consecutive records of a digit's run and the record width
+// costs no registers: keys are loaded (or, on the text level, generated) right before their stream is staged.
+template <int KW, bool GEN, bool LAST>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void ws_scatter_kernel(WSLevel P, WKeyGen g, u32 rows) {
+    constexpr int DMAX = LAST ? 512 : 256;
+    __shared__ u32 tcnt[LAST ? 4 : DMAX];
+    __shared__ __align__(16) u16 wcnt[LAST ? 4 : 1][LAST ? DMAX : 8];
+    __shared__ u32 gbase[DMAX];
+    __shared__ __align__(16) u64 stage[WS_TILE];
+    __shared__ u32 scan_sm[5];
+    __shared__ u8 code[GEN ? 256 : 4];
+    __shared__ __align__(16) u8 sy[GEN ? WS_TILE + WS_HALO : 16];
+    const int lane = lane_id(), w = wave_id();
+    const u32 row = xcd_tile(blockIdx.x, P.per_xcd);
+    if (row >= rows) return;
+    u32 s, cnt; size_t base;
+    if (!ws_row(P, row, s, base, cnt) || cnt == 0) return;
+    u16* stage_d = (u16*)(stage + 2048);                    // digits of the staged values: second half of the buffer
+    u32* stage32 = (u32*)stage;
+    unsigned long long* M = (unsigned long long*)stage + 1024 + w * DMAX;    // LAST: lane-mask tables of the LDS match (bytes 8 K .. 24 K)
+    if constexpr (LAST) { for (int i = threadIdx.x; i < 4 * DMAX; i += 256) { (&wcnt[0][0])[i] = 0; ((unsigned long long*)stage)[1024 + i] = 0; } }
+    else { for (int i = threadIdx.x; i < DMAX; i += 256) tcnt[i] = 0; }
+    if (GEN) code[threadIdx.x] = g.code[threadIdx.x];
+    __syncthreads();
+    if (GEN) { ws_gen_stage(g, P.gen_off + base, code, sy); __syncthreads(); }
+
+    u32 ld[WS_ITEMS];                                       // digit << 16 | rank inside the digit's (wave's) run, later position in the sorted tile
+    const u32 lbs = GEN ? (u32)(w * (64 * WS_ITEMS) + lane * WS_ITEMS) : (u32)(w * (64 * WS_ITEMS) + lane);
+    const u32 estep = GEN ? 1u : 64u;                       // element e of item j: lbs + j * estep
+    {
+        u32 dg[WS_ITEMS];
+        if (GEN) {
+            const uint4* dp = (const uint4*)(P.digits + base + lbs);
+            const uint4 q0 = dp[0], q1 = dp[1];
+            const u32 pk[8] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w };
+#pragma unroll
+            for (int j = 0; j < WS_ITEMS; ++j) dg[j] = (pk[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+        } else {
+            const u16* dgp = P.digits + base + lbs;
+#pragma unroll
+            for (int j = 0; j < WS_ITEMS; ++j) dg[j] = (lbs + (u32)j * 64 < cnt) ? (u32)dgp[j * 64] : 0u;
+        }
+        if constexpr (LAST) {
+            u16* mycnt = wcnt[w];
+            const u64 lanebit = 1ull << lane;
+            const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+            for (int j = 0; j < WS_ITEMS; ++j) {
+                const bool valid = lbs + (u32)j * estep < cnt;
+                const u32 d = valid ? dg[j] : 0u;
+                const u64 peers = wave_match_lds(M, d, valid, lanebit);
+                const u32 prefix = lds_load(&mycnt[d]);
+                const u32 rank = (u32)__popcll(peers & lt_mask);
+                ld[j] = (d << 16) | (prefix + rank);
+                if (valid && rank == 0) lds_store(&mycnt[d], (u16)(prefix + (u32)__popcll(peers)));
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < WS_ITEMS; ++j) {
+                const bool valid = lbs + (u32)j * estep < cnt;
+                const u32 d = valid ? dg[j] : 0u;
+                u32 rank = 0;
+                u64 rem = __ballot(valid);
+                bool done = !valid;
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    if (!rem) break;
+                    const int lead = __ffsll((long long)rem) - 1;
+                    const u32 dl = __shfl(d, lead, 64);
+                    const u64 grp = __ballot(!done && d == dl);
+                    const u32 cg = (u32)__popcll(grp);
+                    if (cg < 8) break;
+                    u32 b0 = 0;
+                    if (lane == lead) b0 = atomicAdd(&tcnt[dl], cg);
+                    b0 = __shfl(b0, lead, 64);
+                    if ((grp >> lane) & 1ull) { rank = b0 + (u32)__popcll(grp & ((1ull << lane) - 1)); done = true; }
+                    rem &= ~grp;
+                }
+                if (!done) rank = atomicAdd(&tcnt[d], 1u);
+                ld[j] = (d << 16) | rank;
+            }
+        }
+    }
+    __syncthreads();
+    {   // digit runs inside the sorted tile (exclusive scan over the digits), global base
+        const u32 t = threadIdx.x;
+        u32 tot[DMAX / 256], sum = 0;
+#pragma unroll
+        for (int q = 0; q < DMAX / 256; ++q) {
+            const u32 d = t * (DMAX / 256) + q;
+            if constexpr (LAST) tot[q] = (u32)wcnt[0][d] + wcnt[1][d] + wcnt[2][d] + wcnt[3][d];
+            else tot[q] = tcnt[d];
+            sum += tot[q];
+        }
+        u32 total;
+        u32 start = block_exclusive_sum<u32, 4>(sum, scan_sm, total);
+#pragma unroll
+        for (int q = 0; q < DMAX / 256; ++q) {
+            const u32 d = t * (DMAX / 256) + q;
+            if constexpr (LAST) {
+                u32 run = start;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { const u32 cw = wcnt[i][d]; wcnt[i][d] = (u16)run; run += cw; }
+            } else tcnt[d] = start;
+            gbase[d] = (d < P.D ? P.counts[(size_t)row * P.D + d] : 0u) - start;
+            start += tot[q];
+        }
+    }
+    __syncthreads();                                       // (the match tables in the staging buffer are dead from here on)
+    u32 dst[WS_ITEMS];
+#pragma unroll
+    for (int j = 0; j < WS_ITEMS; ++j) {
+        const u32 e = lbs + (u32)j * estep;
+        const u32 d = ld[j] >> 16;
+        u32 pos = ld[j] & 0xFFFFu;
+        if constexpr (LAST) pos += (u32)wcnt[w][d]; else pos += tcnt[d];
+        ld[j] = pos;
+        if (e < cnt) { stage32[pos] = GEN ? (u32)(P.gen_off + base + e) : P.v_in[base + e]; stage_d[pos] = (u16)d; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < WS_ITEMS; ++r) {
+        const u32 sp = (u32)r * 256 + threadIdx.x;
+        dst[r] = 0xFFFFFFFFu;
+        if (sp < cnt) {
+            dst[r] = gbase[stage_d[sp]] + sp;
+            P.v_out[dst[r]] = stage32[sp];
+        }
+    }
+    __syncthreads();
+    // key words, one stream at a time
+#pragma unroll
+    for (int word = 0; word < KW; ++word) {
+        if (GEN) {
+            u64 ka, kb;
+            ws_key_first<KW>(g, sy, (int)lbs, ka, kb);
+#pragma unroll
+            for (int j = 0; j < WS_ITEMS; ++j) {
+                if (lbs + (u32)j < cnt) stage[ld[j]] = word == 0 ? ka : kb;
+                ws_key_roll<KW>(g, ka, kb, sy[lbs + j + g.s]);
+            }
+        } else {
+            const u64* kp = (word == 0 ? P.k1_in : P.k2_in) + base + lbs;
+            u64 kk[WS_ITEMS];
+#pragma unroll
+            for (int j = 0; j < WS_ITEMS; ++j) kk[j] = (lbs + (u32)j * 64 < cnt) ? kp[j * 64] : 0ull;
+#pragma unroll
+            for (int j = 0; j < WS_ITEMS; ++j) if (lbs + (u32)j * 64 < cnt) stage[ld[j]] = kk[j];
+        }
+        __syncthreads();
+        u64* outp = word == 0 ? P.k1_out : P.k2_out;
+#pragma unroll
+        for (int r = 0; r < WS_ITEMS; ++r) {
+            const u32 sp = (u32)r * 256 + threadIdx.x;
+            if (dst[r] != 0xFFFFFFFFu) outp[dst[r]] = stage[sp];
+        }
+        if (word + 1 < KW) __syncthreads();
+    }
+}
+
+// ---- leaf sort ------------------------------------------------------------------------------------------------------------------------
+constexpr int WL_NW = 8;             // waves per leaf workgroup
+__device__ __forceinline__ u32 wl_rank(u32 d, bool valid, u32* mycnt, unsigned long long* M, u64 lanebit, u64 lt_mask) {
+    const u64 peers = wave_match_lds(M, d, valid, lanebit);
+    const u32 prefix = lds_load(&mycnt[d]);
+    const u32 rank = (u32)__popcll(peers & lt_mask);
+    if (valid && rank == 0) lds_store(&mycnt[d], prefix + (u32)__popcll(peers));
+    return prefix + rank;
+}
+__device__ __forceinline__ void wl_digit_starts(u32 (*wcnt)[256], int lane) {
+    uint4 cc[WL_NW];
+    u32 t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+#pragma unroll
+    for (int i = 0; i < WL_NW; ++i) {
+        cc[i] = *(const uint4*)&wcnt[i][4 * lane];
+        t0 += cc[i].x; t1 += cc[i].y; t2 += cc[i].z; t3 += cc[i].w;
+    }
+    const u32 sum = t0 + t1 + t2 + t3;
+    u32 r0 = wave_inclusive_sum(sum) - sum;
+    u32 r1 = r0 + t0, r2 = r1 + t1, r3 = r2 + t2;
+#pragma unroll
+    for (int i = 0; i < WL_NW; ++i) {
+        *(uint4*)&wcnt[i][4 * lane] = make_uint4(r0, r1, r2, r3);
+        r0 += cc[i].x; r1 += cc[i].y; r2 += cc[i].z; r3 += cc[i].w;
+    }
+}
+
+// A "unit" is a slot range [unit_rng[2u], unit_rng[2u + 1]) of at most 8192 records.  Stage 0: the units of ss_build_units (whole
+// leaves).  Later stages: long runs of tying records that the counting kernel handed back (see ws_leaf_count_kernel).
+struct WLeaf {
+    u64* k1; u64* k2; u32* v;
+    const u32* unit_rng;
+    u8* flags; u8* lcp;                  // head flag of every slot; suffix mode: LCP (symbols) of every head with its predecessor
+    u32* d_err;
+    u32 inv;                             // ceil(65536 / b)
+    u32 cmax;                            // counting limit (WS_CMAX; 1 in the test mode that hands every run back)
+};
+// lists a leaf kernel appends to
+struct WLists {
+    u32* rlist;         // kernel A: units whose records tie on k1 (not pure, nothing truncated): runs to be ordered by k2
+    u32* tlist;         // kernel A: units sorted by a TRUNCATED word that left ties (bit 31: pure, the word was k2)
+    u32* counters;      // [0] = |rlist|, [1] = |tlist|
+};
+struct WEmit {          // the counting kernel: long runs become units of the next stage
+    u32* rng;           // pairs (first slot, end slot | pure << 31), indexed by first slot / div: a run is longer than cmax = div - 1, so
+    u32 div;            // no two runs share an entry -- no atomics; empty entries are (0, 0).  ws_emit_compact_kernel lists them by class
+};
+
+template <int ROWS>
+struct WLState {
+    u32 (*wcnt)[256]; u64* stage;
+    u32 m, wbase;
+    int lane, w;
+};
+
+// stable LSD sort of the unit's words by the bits [shift0, shift0 + nb); on return k[j] = word at slot wbase + 64 j, stage[] = all words
+template <int ROWS>
+__device__ __forceinline__ void wl_lsd(const WLState<ROWS>& T, u64 (&k)[ROWS], int shift0, int nb) {
+    u32* mycnt = T.wcnt[T.w];
+    unsigned long long* M = (unsigned long long*)T.stage + T.w * 256;
+    const u64 lanebit = 1ull << T.lane;
+    const u64 lt_mask = (T.lane == 0) ? 0ull : (~0ull >> (64 - T.lane));
+    for (int i = T.lane; i < 256; i += 64) mycnt[i] = 0;
+    u32 loc[ROWS];
+    for (int shift = shift0; shift < shift0 + nb; shift += 8) {
+        for (int i = T.lane; i < 256; i += 64) M[i] = 0;
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) {
+            loc[j] = wl_rank((u32)(k[j] >> shift) & 255u, T.wbase + (u32)j * 64 < T.m, mycnt, M, lanebit, lt_mask);
+            if ((j & (ROWS >= 12 ? 1 : 3)) == (ROWS >= 12 ? 1 : 3)) __builtin_amdgcn_sched_barrier(0);   // (overlap the LDS operations of a few rows, not of all: registers)
+        }
+        __syncthreads();
+        if (T.w == 0) wl_digit_starts(T.wcnt, T.lane);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j)
+            if (T.wbase + (u32)j * 64 < T.m) T.stage[loc[j] + mycnt[(u32)(k[j] >> shift) & 255u]] = k[j];
+        for (int i = T.lane; i < 256; i += 64) mycnt[i] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) if (T.wbase + (u32)j * 64 < T.m) k[j] = T.stage[T.wbase + (u32)j * 64];
+        __syncthreads();
+    }
+}
+
+template <int ROWS>
+__device__ __forceinline__ void wl_minmax(u64 (*red)[WL_NW], const u64 (&k)[ROWS], u32 m, u32 wbase, int lane, int w, u64& kmin, u64& kmax) {
+    kmin = ~0ull; kmax = 0;
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j)
+        if (wbase + (u32)j * 64 < m) { kmin = k[j] < kmin ? k[j] : kmin; kmax = k[j] > kmax ? k[j] : kmax; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const u64 o1 = __shfl_xor(kmin, d, 64), o2 = __shfl_xor(kmax, d, 64);
+        kmin = o1 < kmin ? o1 : kmin; kmax = o2 > kmax ? o2 : kmax;
+    }
+    if (lane == 0) { red[0][w] = kmin; red[1][w] = kmax; }
+    __syncthreads();
+    kmin = red[0][0]; kmax = red[1][0];
+#pragma unroll
+    for (int i = 1; i < WL_NW; ++i) { kmin = red[0][i] < kmin ? red[0][i] : kmin; kmax = red[1][i] > kmax ? red[1][i] : kmax; }
+    __syncthreads();
+}
+
+// ---- leaf kernel A: one workgroup (512 threads) sorts one unit of <= ROWS * 512 records by its first differing word -----------------
+// X = k1, or k2 when all k1 of the unit are equal ("pure": a frequent first word fills whole leaves; so does every long run of equal
+// k1 that comes back as a unit of a later stage).  Composite-word LSD passes as in ssort.hip: (differing bits of X) << 13 | slot.  When
+// X differs in more than 51 bits the composite takes the TOP 51 of them; records that tie on those stay a run.  Written back: the
+// positions in sorted order, a head flag per slot (slot starts a run of tying records), suffix mode: the LCP (symbols) of every head
+// with its predecessor; X and k2 in the same order where a later kernel (or the caller: PAIRS) reads them.  Units with runs left go
+// to `rlist` (ties on the whole of k1: to be ordered by k2) or `tlist` (ties on a truncated word: to be ordered by the word itself
+// first); the counting kernel takes them from there.
+template <int KW, int ROWS, bool PAIRS>
+__global__ __launch_bounds__(WL_NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void ws_leaf_sort_kernel(WLeaf A, const u32* __restrict__ list, u32 count, WLists Q) {
+    constexpr u32 CAP = (u32)ROWS * WL_NW * 64;
+    __shared__ __align__(16) u32 wcnt[WL_NW][256];
+    __shared__ __align__(16) u64 stage[CAP];
+    __shared__ u64 red[2][WL_NW];
+    __shared__ u32 s_any;
+    if (blockIdx.x >= count) return;
+    const u32 u = list[blockIdx.x];
+    const u32 a = A.unit_rng[2 * u], braw = A.unit_rng[2 * u + 1];
+    const bool known_pure = KW == 2 && (braw >> 31) != 0;     // a run handed back by the counting kernel: its records tie on all of k1
+    const u32 bnd = braw & 0x7FFFFFFFu;
+    const u32 m = bnd - a;
+    if (m == 0) return;
+    if (m > CAP) { if (threadIdx.x == 0) atomicOr(A.d_err, 2u); return; }
+    if (threadIdx.x == 0) { A.flags[a] = 1; s_any = 0; }      // a unit starts at a leaf start / run start
+    if (m == 1) return;
+    const int lane = lane_id(), w = wave_id();
+    WLState<ROWS> T;
+    T.wcnt = wcnt; T.stage = stage;
+    T.m = m; T.wbase = (u32)w * ROWS * 64 + (u32)lane; T.lane = lane; T.w = w;
+    const u32 wbase = T.wbase;
+    u64* K1 = A.k1 + a;
+    u64* K2 = KW == 2 ? A.k2 + a : nullptr;
+
+    u64 c[ROWS];
+    u64 kmin = 0, kmax = 0;
+    if (!known_pure) {                                          // (the k1 slots of such a run were never brought into sorted order)
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) { const u32 L = wbase + (u32)j * 64; c[j] = (L < m) ? K1[L] : 0ull; }
+        wl_minmax<ROWS>(red, c, m, wbase, lane, w, kmin, kmax);
+    }
+    bool pure = false;
+    if (kmin == kmax) {
+        if (KW == 1) return;                                    // one group: nothing moves
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) { const u32 L = wbase + (u32)j * 64; c[j] = (L < m) ? K2[L] : 0ull; }
+        wl_minmax<ROWS>(red, c, m, wbase, lane, w, kmin, kmax);
+        pure = true;
+        if (kmin == kmax) return;
+    }
+    u64* Xp = pure ? K2 : K1;
+    const int nbits = 64 - __builtin_clzll(kmin ^ kmax);
+    const int nb = nbits > 51 ? 51 : nbits;                     // bits of X in the composite
+    const int sh = nbits - nb;                                  // low bits of X left out (ties on the rest are handed on)
+    const u64 cmask = (1ull << nb) - 1;
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) c[j] = (((c[j] >> sh) & cmask) << 13) | (u64)(wbase + (u32)j * 64);
+    wl_lsd<ROWS>(T, c, 13, nb);
+    // heads, LCPs
+    const u32 base_bits = pure ? 64u : 0u;
+    bool anyrun = false;
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) {
+        const u32 L = wbase + (u32)j * 64;
+        if (L < m && L > 0) {
+            const u64 x = (c[j] >> 13) ^ (stage[L - 1] >> 13);
+            A.flags[(size_t)a + L] = x ? 1 : 0;
+            if (x) { if (!PAIRS) A.lcp[(size_t)a + L] = (u8)(((base_bits + (u32)__builtin_clzll(x) - (u32)sh) * A.inv) >> 16); }
+            else anyrun = true;
+        }
+    }
+    if (__any(anyrun) && lane == 0) s_any = 1;
+    __syncthreads();                                            // (the staged composites have been read)
+    const bool runs = s_any != 0;
+    // positions in sorted order
+    {
+        u32* stage32 = (u32*)stage;
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) { const u32 L = wbase + (u32)j * 64; if (L < m) stage32[L] = A.v[(size_t)a + L]; }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) { const u32 L = wbase + (u32)j * 64; if (L < m) A.v[(size_t)a + L] = stage32[(u32)c[j] & 8191u]; }
+    }
+    const bool trunc_ties = sh > 0 && runs;                     // the counting kernel orders these runs by X itself first
+    if (PAIRS || trunc_ties) {                                  // X in sorted order
+        if (sh == 0) {                                          // rebuilt from the composite
+            const u64 high = kmin & ~cmask;
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j) { const u32 L = wbase + (u32)j * 64; if (L < m) Xp[L] = ((c[j] >> 13) & cmask) | high; }
+        } else {                                                // (all reads before the first write)
+            u64 t[ROWS];
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j) { const u32 L = wbase + (u32)j * 64; t[j] = (L < m) ? Xp[c[j] & 8191ull] : 0ull; }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j) { const u32 L = wbase + (u32)j * 64; if (L < m) Xp[L] = t[j]; }
+        }
+    }
+    if (KW == 2 && !pure && (runs || PAIRS)) {                  // k2 follows
+        u64 t[ROWS];
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) { const u32 L = wbase + (u32)j * 64; t[j] = (L < m) ? K2[c[j] & 8191ull] : 0ull; }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) { const u32 L = wbase + (u32)j * 64; if (L < m) K2[L] = t[j]; }
+    }
+    if (threadIdx.x == 0) {
+        if (trunc_ties) Q.tlist[atomicAdd(Q.counters + 1, 1u)] = u | (pure ? 0x80000000u : 0u);
+        else if (runs && KW == 2 && !pure) Q.rlist[atomicAdd(Q.counters, 1u)] = u;
+    }
+}
+
+// ---- leaf kernel B: the runs of a unit (head flags as left by kernel A) ordered by the word W, by COUNTING ------------------------
+// Every member of a run of 2 .. cmax slots counts the smaller words of its run in LDS (and the equal ones in front of it: stable); new
+// heads where the words differ.  `carry` (nullable): a second word array that follows the permutation.  base_bits: key bits in front
+// of W (0 for k1, 64 for k2) -- the LCP of a new head is (base_bits + common leading bits of W) / bits per symbol.  A longer run is left
+// as it is and, if E.unit_rng is set, becomes a unit of the next stage: kernel A sorts it (its records tie on everything in front of
+// W, so it is "pure" there, or differs only in the low bits a truncated composite left out).
+// All per-slot state lives in LDS and the row loops are real loops: a few dozen registers.
+struct WCount { u64* W; u64* carry; u32 base_bits; };
+// the run of slot s in the head bitmap hb (bit m is set: end sentinel; bit 0 is set): 0 = singleton, 1 = run [rs, re) of 2 .. cmax
+// slots, 2 = longer run
+__device__ __forceinline__ int wl_run(const u64* hb, u32 s, u32 m, u32 cmax, u32& rs, u32& re) {
+    const u32 wi = s >> 6, bt = s & 63, wlast = m >> 6;
+    const u64 cw = hb[wi];
+    u64 x = cw & ((bt == 63) ? ~0ull : ((2ull << bt) - 1ull));
+    u32 wl = wi;
+    while (!x && wl > 0 && wi - wl < WS_CMAX / 64 + 1) x = hb[--wl];
+    u64 y = (bt == 63) ? 0ull : (cw & (~0ull << (bt + 1)));
+    u32 wr = wi;
+    while (!y && wr < wlast && wr - wi < WS_CMAX / 64 + 1) y = hb[++wr];
+    if (!x || !y) return 2;
+    rs = wl * 64 + 63 - (u32)__builtin_clzll(x);
+    re = wr * 64 + (u32)__builtin_ctzll(y);
+    const u32 len = re - rs;
+    if (len == 1) return 0;
+    return len <= cmax ? 1 : 2;
+}
+// end of the run that starts at slot s (the next head behind s; the sentinel at m ends the walk)
+__device__ __forceinline__ u32 wl_run_end(const u64* hb, u32 s) {
+    u32 wi = s >> 6;
+    const u32 bt = s & 63;
+    u64 y = (bt == 63) ? 0ull : (hb[wi] & (~0ull << (bt + 1)));
+    while (!y) y = hb[++wi];
+    return wi * 64 + (u32)__builtin_ctzll(y);
+}
+template <int ROWS, bool PAIRS>
+__global__ __launch_bounds__(WL_NW * 64) void ws_leaf_count_kernel(WLeaf A, const u32* __restrict__ list, u32 count, u32 want_mask, u32 want_value,
+                                                                    WCount R, WEmit E) {
+    constexpr u32 CAP = (u32)ROWS * WL_NW * 64;
+    __shared__ u64 Wl[CAP];
+    __shared__ u32 P32[CAP];
+    __shared__ u8 hf[CAP];
+    __shared__ u64 hb[CAP / 64 + 1];
+    if (blockIdx.x >= count) return;
+    const u32 uraw = list[blockIdx.x];
+    if ((uraw & want_mask) != want_value) return;
+    const u32 u = uraw & 0x7FFFFFFFu;
+    const u32 a = A.unit_rng[2 * u], bnd = A.unit_rng[2 * u + 1] & 0x7FFFFFFFu;
+    const u32 m = bnd - a;
+    if (m <= 1 || m > CAP) return;
+    const int lane = lane_id(), w = wave_id();
+    const u32 wbase = (u32)w * ROWS * 64 + (u32)lane;
+    u64* W = R.W + a;
+#pragma unroll 1
+    for (int j = 0; j < ROWS; ++j) {
+        const u32 L = wbase + (u32)j * 64;
+        Wl[L] = (L < m) ? W[L] : 0ull;
+        const bool h = (L < m) && (L == 0 || A.flags[(size_t)a + L] != 0);
+        const u64 bm = __ballot(h || L == m);
+        if (lane == 0) hb[w * ROWS + j] = bm;
+    }
+    if (threadIdx.x == 0) hb[ROWS * WL_NW] = (m == CAP) ? 1ull : 0ull;
+    __syncthreads();
+#pragma unroll 1
+    for (int j = 0; j < ROWS; ++j) {
+        const u32 L = wbase + (u32)j * 64;
+        if (L < m) {
+            u32 rs = 0, re = 0;
+            u32 tgt = L, h = (u32)((hb[L >> 6] >> (L & 63)) & 1ull);
+            const int kind = wl_run(hb, L, m, A.cmax, rs, re);
+            if (kind == 1) {
+                u32 less = 0, eqb = 0;
+                const u64 me = Wl[L];
+                for (u32 q = rs; q < re; ++q) {
+                    const u64 kq = Wl[q];
+                    less += (kq < me) ? 1u : 0u;
+                    eqb += (kq == me && q < L) ? 1u : 0u;
+                }
+                tgt = rs + less + eqb;
+                h = (eqb == 0) ? 1u : 0u;
+            } else if (kind == 2 && h && E.rng) {                // the first slot of a long run hands it on
+                const u32 e = wl_run_end(hb, L);
+                const size_t i = (size_t)((a + L) / E.div);
+                E.rng[2 * i] = a + L;
+                E.rng[2 * i + 1] = (a + e) | (R.base_bits ? 0x80000000u : 0u);
+            }
+            P32[L] = tgt | (h << 16);
+        }
+    }
+    __syncthreads();
+    {   // the words, the head bits and the positions to their final slots
+        u64 wr[ROWS];
+        u32 tr[ROWS], vr[ROWS];
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) {
+            const u32 L = wbase + (u32)j * 64;
+            wr[j] = (L < m) ? Wl[L] : 0ull;
+            tr[j] = (L < m) ? P32[L] : 0u;
+            vr[j] = (L < m) ? A.v[(size_t)a + L] : 0u;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) {
+            const u32 L = wbase + (u32)j * 64;
+            if (L < m) { const u32 t = tr[j] & 0xFFFFu; Wl[t] = wr[j]; P32[t] = vr[j]; hf[t] = (u8)(tr[j] >> 16); }
+        }
+        if (R.carry) {                                          // (reads of the whole unit first, then the scattered writes)
+            u64* Cw = R.carry + a;
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j) { const u32 L = wbase + (u32)j * 64; wr[j] = (L < m) ? Cw[L] : 0ull; }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j) { const u32 L = wbase + (u32)j * 64; if (L < m) Cw[tr[j] & 0xFFFFu] = wr[j]; }
+        }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int j = 0; j < ROWS; ++j) {
+        const u32 L = wbase + (u32)j * 64;
+        if (L < m) {
+            const bool h = hf[L] != 0;
+            const bool old = (hb[L >> 6] >> (L & 63)) & 1ull;
+            A.v[(size_t)a + L] = P32[L];
+            if (PAIRS) W[L] = Wl[L];
+            if (h && !old) {
+                const u64 x = Wl[L] ^ Wl[L - 1];
+                A.flags[(size_t)a + L] = 1;
+                if (!PAIRS) A.lcp[(size_t)a + L] = (u8)(((R.base_bits + (x ? (u32)__builtin_clzll(x) : 64u)) * A.inv) >> 16);
+            }
+        }
+    }
+}
+// the runs handed on by the counting kernel, listed by class: 0 = pure and <= 1024 records (wave kernel), 1 .. 4 = kernel A by size
+constexpr u32 EC_TILE = 256 * 32;
+__global__ __launch_bounds__(256) void ws_emit_compact_kernel(const u32* __restrict__ rng, u32 nent, u32* __restrict__ lists, u32 cap, u32* __restrict__ counters) {
+    __shared__ u32 cnt[5], base[5];
+    if (threadIdx.x < 5) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const u32 i0 = blockIdx.x * EC_TILE + threadIdx.x;
+    u32 mycls = 0, myidx[32 / 8];                              // 4 bits per entry: class + 1 (0 = empty); local index recomputed in pass 2
+#pragma unroll
+    for (int q = 0; q < 4; ++q) myidx[q] = 0;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) {
+        const u32 i = i0 + (u32)q * 256;
+        u32 code = 0;
+        if (i < nent) {
+            const u32 a = rng[2 * (size_t)i], braw = rng[2 * (size_t)i + 1];
+            const u32 m = (braw & 0x7FFFFFFFu) - a;
+            if (m > 0) code = ((braw >> 31) && m <= WS_WAVE_MAX) ? 1u : 2u + (m - 1) / 2048;
+        }
+        myidx[q >> 3] |= code << (4 * (q & 7));
+        if (code) atomicAdd(&cnt[code - 1], 1u);
+    }
+    (void)mycls;
+    __syncthreads();
+    if (threadIdx.x < 5) { const u32 c = cnt[threadIdx.x]; base[threadIdx.x] = c ? atomicAdd(counters + 1 + threadIdx.x, c) : 0u; cnt[threadIdx.x] = 0; }
+    if (threadIdx.x == 0) { const u32 t = cnt[0] + cnt[1] + cnt[2] + cnt[3] + cnt[4]; (void)t; }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 32; ++q) {
+        const u32 code = (myidx[q >> 3] >> (4 * (q & 7))) & 15u;
+        if (code) {
+            const u32 k = base[code - 1] + atomicAdd(&cnt[code - 1], 1u);
+            if (k < cap) lists[(size_t)(code - 1) * cap + k] = i0 + (u32)q * 256;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void ws_count_flags_kernel(const u8* __restrict__ flags, size_t n, unsigned long long* __restrict__ d_nonheads) {
+    __shared__ u32 part[4];
+    u32 cnt = 0;
+    const size_t stride = (size_t)gridDim.x * 256 * 16;
+    for (size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 16; i0 < n; i0 += stride) {
+        if (i0 + 16 <= n && (((size_t)flags) & 15) == 0) {
+            const uint4 v = *(const uint4*)(flags + i0);
+            const u32 wv[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cnt += 4u - (u32)__popc(wv[q] & 0x01010101u);
+        } else for (size_t i = i0; i < n && i < i0 + 16; ++i) cnt += flags[i] ? 0u : 1u;
+    }
+    cnt = wave_reduce_sum(cnt);
+    if (lane_id() == 0) part[wave_id()] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) { const u32 t = part[0] + part[1] + part[2] + part[3]; if (t) atomicAdd(d_nonheads, (unsigned long long)t); }
+}
+
+// ---- one WAVE sorts one run of <= 1024 records that tie on k1, by the whole of k2 ---------------------------------------------------
+// The runs of 65 .. 1024 equal first words are the mid-frequency phrases of a text: hundreds of thousands of them, each far too small
+// for a 512-thread workgroup (kernel A spends its time in barriers and idle lanes there).  Here a wave owns a run: LSD passes over the
+// differing bits of k2 on (word, record number) pairs held in registers, ranks from the wave-level LDS match, no workgroup barrier
+// anywhere -- the four waves of a workgroup work on four runs independently.  Written back: positions in k2 order, head flags, LCPs
+// (base: the 64 bits of k1), PAIRS: k2 itself.
+constexpr int WR_ROWS = WS_WAVE_MAX / 64;
+template <bool PAIRS>
+__global__ __launch_bounds__(256) void ws_run_wave_kernel(WLeaf A, const u32* __restrict__ list, u32 count) {
+    __shared__ u64 sk[4][WS_WAVE_MAX];
+    __shared__ u16 sid[4][WS_WAVE_MAX];
+    __shared__ __align__(16) u32 cnt[4][256];
+    __shared__ u64 mt[4][256];
+    const int lane = lane_id(), w = wave_id();
+    const u32 r = blockIdx.x * 4 + (u32)w;
+    if (r >= count) return;
+    const u32 u = list[r];
+    const u32 a = A.unit_rng[2 * u], m = (A.unit_rng[2 * u + 1] & 0x7FFFFFFFu) - a;
+    if (m <= 1 || m > WS_WAVE_MAX) return;
+    u64* W = A.k2 + a;
+    if (m <= 64) {
+        // one record per lane: a bitonic network over the lanes on (word, lane) -- the lane number breaks ties and keeps the padding
+        // lanes (all-ones word, lane >= m) behind every record; no LDS arrays, no passes
+        u64 key = ((u32)lane < m) ? W[lane] : ~0ull;
+        u32 idl = (u32)lane;
+        const u32 vold = ((u32)lane < m) ? A.v[(size_t)a + lane] : 0u;
+#pragma unroll
+        for (u32 k2 = 2; k2 <= 64; k2 <<= 1) {
+#pragma unroll
+            for (u32 j = k2 >> 1; j > 0; j >>= 1) {
+                const u64 ok = __shfl_xor(key, (int)j, 64);
+                const u32 oi = __shfl_xor(idl, (int)j, 64);
+                const bool up = (((u32)lane & k2) == 0) || k2 == 64;
+                const bool lower = (((u32)lane & j) == 0);
+                const bool gt = key > ok || (key == ok && idl > oi);       // mine > the partner's
+                const bool take = lower ? (gt == up) : (!gt == up);
+                if (take) { key = ok; idl = oi; }
+            }
+        }
+        const u64 prev = __shfl_up(key, 1, 64);
+        const u32 vnew = __shfl(vold, (int)idl, 64);
+        if ((u32)lane < m) {
+            A.v[(size_t)a + lane] = vnew;
+            if (PAIRS) W[lane] = key;
+            if (lane > 0) {
+                const u64 x = key ^ prev;
+                A.flags[(size_t)a + lane] = x ? 1 : 0;
+                if (x && !PAIRS) A.lcp[(size_t)a + lane] = (u8)(((64u + (u32)__builtin_clzll(x)) * A.inv) >> 16);
+            }
+        }
+        return;
+    }
+    u64* K = sk[w]; u16* S = sid[w]; u32* mycnt = cnt[w];
+    unsigned long long* M = (unsigned long long*)mt[w];
+    const int rows = (int)((m + 63) >> 6);
+    u64 k[WR_ROWS];
+    u32 id[WR_ROWS];
+    u64 orv = 0, andv = ~0ull;
+#pragma unroll
+    for (int j = 0; j < WR_ROWS; ++j) {
+        const u32 L = (u32)j * 64 + (u32)lane;
+        k[j] = (j < rows && L < m) ? W[L] : 0ull;
+        id[j] = L;
+        if (j < rows && L < m) { orv |= k[j]; andv &= k[j]; }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { orv |= __shfl_xor(orv, d, 64); andv &= __shfl_xor(andv, d, 64); }
+    const u64 diff = orv ^ andv;                               // bits in which the words of the run differ
+    for (int i = lane; i < 256; i += 64) { mycnt[i] = 0; M[i] = 0; }
+    __builtin_amdgcn_wave_barrier();
+    if (diff) {
+        const int hi = 64 - __builtin_clzll(diff), lo = __builtin_ctzll(diff);
+        const u64 lanebit = 1ull << lane;
+        const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+        for (int shift = lo; shift < hi; shift += 8) {
+            if (((diff >> shift) & 255ull) == 0) continue;     // (a digit no word differs in)
+            u32 loc[WR_ROWS];
+#pragma unroll
+            for (int j = 0; j < WR_ROWS; ++j)
+                if (j < rows) loc[j] = wl_rank((u32)(k[j] >> shift) & 255u, (u32)j * 64 + (u32)lane < m, mycnt, M, lanebit, lt_mask);
+            __builtin_amdgcn_wave_barrier();
+            {   // digit starts: lane l owns the digits 4l .. 4l+3
+                const uint4 cc = *(const uint4*)&mycnt[4 * lane];
+                const u32 sum = cc.x + cc.y + cc.z + cc.w;
+                const u32 r0 = wave_inclusive_sum(sum) - sum;
+                *(uint4*)&mycnt[4 * lane] = make_uint4(r0, r0 + cc.x, r0 + cc.x + cc.y, r0 + cc.x + cc.y + cc.z);
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < WR_ROWS; ++j) {
+                if (j < rows && (u32)j * 64 + (u32)lane < m) {
+                    const u32 p = loc[j] + lds_load(&mycnt[(u32)(k[j] >> shift) & 255u]);
+                    lds_store(&K[p], k[j]); lds_store(&S[p], (u16)id[j]);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            for (int i = lane; i < 256; i += 64) mycnt[i] = 0;
+#pragma unroll
+            for (int j = 0; j < WR_ROWS; ++j) {
+                const u32 L = (u32)j * 64 + (u32)lane;
+                if (j < rows && L < m) { k[j] = lds_load(&K[L]); id[j] = (u32)lds_load(&S[L]); }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    // heads + LCPs from the sorted words (K[] holds them when a pass ran; else all words are equal)
+#pragma unroll
+    for (int j = 0; j < WR_ROWS; ++j) {
+        const u32 L = (u32)j * 64 + (u32)lane;
+        if (j < rows && L < m && L > 0) {
+            const u64 x = diff ? (k[j] ^ lds_load(&K[L - 1])) : 0ull;
+            A.flags[(size_t)a + L] = x ? 1 : 0;
+            if (x && !PAIRS) A.lcp[(size_t)a + L] = (u8)(((64u + (u32)__builtin_clzll(x)) * A.inv) >> 16);
+        }
+    }
+    if (!diff) return;
+    __builtin_amdgcn_wave_barrier();
+    // positions (parked in the staging words), k2
+    u32* P = (u32*)K;
+    u32 vr[WR_ROWS];
+#pragma unroll
+    for (int j = 0; j < WR_ROWS; ++j) { const u32 L = (u32)j * 64 + (u32)lane; vr[j] = (j < rows && L < m) ? A.v[(size_t)a + L] : 0u; }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < WR_ROWS; ++j) { const u32 L = (u32)j * 64 + (u32)lane; if (j < rows && L < m) lds_store(&P[L], vr[j]); }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < WR_ROWS; ++j) {
+        const u32 L = (u32)j * 64 + (u32)lane;
+        if (j < rows && L < m) {
+            A.v[(size_t)a + L] = lds_load(&P[id[j]]);
+            if (PAIRS) W[L] = k[j];
+        }
+    }
+}
+
+// ---- suffix mode: LCP at the leaf starts ---------------------------------------------------------------------------------------------
+// Every non-empty leaf starts a group (keys of different leaves differ); the LCP of its first slot with the slot in front of it is
+// counted from the text (two scattered reads per leaf: a few million in all).
+template <int KW>
+__global__ __launch_bounds__(256) void ws_fix_kernel(const u32* __restrict__ leaf_start, u32 nleaf, const u32* __restrict__ v, WKeyGen g,
+                                                     u8* __restrict__ flags, u8* __restrict__ lcp) {
+    __shared__ u8 code[256];
+    code[threadIdx.x] = g.code[threadIdx.x];
+    __syncthreads();
+    const u32 l = blockIdx.x * 256 + threadIdx.x;
+    if (l >= nleaf) return;
+    const u32 s = leaf_start[l];
+    if (s == leaf_start[l + 1]) return;
+    flags[s] = 1;
+    if (s == 0) { lcp[0] = 0; return; }
+    const size_t pa = v[s - 1], pb = v[s];
+    u32 t = 0;
+    while (t < (u32)g.s) {
+        const u32 ca = (pa + t < g.n) ? code[g.text[pa + t]] : 0u, cb = (pb + t < g.n) ? code[g.text[pb + t]] : 0u;
+        if (ca != cb) break;
+        ++t;
+    }
+    lcp[s] = (u8)t;
+}
+// flags / LCP of a range whose sorted keys are at hand (oversized leaves that went through the LSD fall-back); slot a itself is a
+// leaf start (ws_fix_kernel)
+template <int KW>
+__global__ void ws_range_flags_kernel(const u64* __restrict__ k1, const u64* __restrict__ k2, u32 a, u32 bnd, u32 inv, u8* __restrict__ flags,
+                                      u8* __restrict__ lcp) {
+    const u32 i = a + 1 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= bnd) return;
+    const u64 x1 = k1[i] ^ k1[i - 1];
+    const u64 x2 = KW == 2 ? (k2[i] ^ k2[i - 1]) : 0ull;
+    const bool h = x1 != 0 || x2 != 0;
+    flags[i] = h ? 1 : 0;
+    if (h && lcp) lcp[i] = (u8)(((x1 ? (u32)__builtin_clzll(x1) : 64u + (u32)__builtin_clzll(x2)) * inv) >> 16);
+}
+
+// ---- host -------------------------------------------------------------------------------------------------------------------------
+bool wsort_applicable(const Ctx& c, size_t n) { return c.wsort && n >= c.wsort_min && n < ((size_t)1 << 32); }
+int wsort_result_index(Ctx& c, size_t n) {                    // index of the V buffer that will hold wsort_suffixes' result
+    int L; u32 F[3], os;
+    ss_fanouts(c, n, L, F, os);
+    return (L - 1) & 1;
+}
+
+namespace {
+struct WPlan { int L; u32 F[3]; u32 os, NLr, NS, S; };
+
+template <int KW, bool GEN>
+void ws_splitters(Ctx& c, const WPlan& pl, const u64* k1, const u64* k2, const WKeyGen& g, size_t n, u64* sp1, u64* sp2) {
+    hipStream_t s = c.stream;
+    const size_t m2 = c.arena.mark();
+    const u32 S = pl.S;
+    u64* a1[2] = { c.arena.get<u64>(S), c.arena.get<u64>(S) };
+    u64* a2[2] = { nullptr, nullptr };
+    if (KW == 2) { a2[0] = c.arena.get<u64>(S); a2[1] = c.arena.get<u64>(S); }
+    u32* iv[2] = { c.arena.get<u32>(S), c.arena.get<u32>(S) };
+    ws_sample_kernel<KW, GEN><<<cdiv(S, 256), 256, 0, s>>>(k1, k2, g, n, S, a1[0], a2[0], iv[0]);
+    LAUNCH_CHECK();
+    if (KW == 1) {
+        const int x = radix_sort_pairs_u64(c, a1, iv, S, 0, 64);
+        ws_pick_kernel<<<cdiv((size_t)pl.NS + 1, 256), 256, 0, s>>>(a1[x], nullptr, pl.NS, pl.os, sp1, nullptr);
+        LAUNCH_CHECK();
+    } else {
+        ws_lsd_sort_wide(c, a1, a2, nullptr, S, 64);
+        ws_pick_kernel<<<cdiv((size_t)pl.NS + 1, 256), 256, 0, s>>>(a1[1], a2[1], pl.NS, pl.os, sp1, sp2);
+        LAUNCH_CHECK();
+    }
+    c.arena.release(m2);
+}
+
+template <int KW, bool GEN, bool PAIRS>
+int ws_sort_impl(Ctx& c, const WKeyGen* gen, u64* K1[2], u64* K2[2], u32* V[2], size_t n, int k1_bits, u8* flags, u8* lcp8, WSortStats* st) {
+    hipStream_t s = c.stream;
+    const size_t mark = c.arena.mark();
+    WKeyGen g;
+    if (gen) g = *gen; else memset(&g, 0, sizeof(g));
+    WPlan pl;
+    ss_fanouts(c, n, pl.L, pl.F, pl.os);
+    pl.NLr = pl.F[0] * pl.F[1] * pl.F[2]; pl.NS = pl.NLr - 1; pl.S = pl.os * pl.NLr;
+    const int L = pl.L;
+    st->levels = (u32)L; st->range_leaves = pl.NLr; st->samples = pl.S; st->kw = KW;
+
+    u64* sp1 = c.arena.get<u64>((size_t)pl.NS + 1);
+    u64* sp2 = KW == 2 ? c.arena.get<u64>((size_t)pl.NS + 1) : nullptr;
+    ws_splitters<KW, GEN>(c, pl, K1[0], KW == 2 ? K2[0] : nullptr, g, n, sp1, sp2);
+
+    unsigned long long* d_nonheads = (unsigned long long*)c.arena.get<u64>(1);
+    HIP_TRY(hipMemsetAsync(d_nonheads, 0, sizeof(u64), s));
+    if (PAIRS) flags = c.arena.get<u8>(n + 8);                 // (internal in this mode: run heads between the two leaf kernels)
+    HIP_TRY(hipMemsetAsync(flags, 0, n, s));
+
+    // ---- partition levels ----
+    u16* digits = c.arena.get<u16>(align_up(n, WS_TILE) + WS_TILE);
+    const u32* seg_start = ss_first_segment(c, n);
+    u32 nseg = 1;
+    int cur = GEN ? -1 : 0;
+    for (int l = 0; l < L; ++l) {
+        const bool last = (l == L - 1);
+        const bool gl = GEN && l == 0;
+        const u32 D = last ? 2 * pl.F[l] : pl.F[l];
+        u32 stride = 1;
+        for (int q = l + 1; q < L; ++q) stride *= pl.F[q];
+        u32* nstart = c.arena.get<u32>((size_t)nseg * D + 1);
+        const size_t lm2 = c.arena.mark();
+        SegTables Tb;
+        ss_level_tables(c, seg_start, nseg, n, D, Tb);
+        WSLevel P;
+        P.k1_in = cur >= 0 ? K1[cur] : nullptr; P.k2_in = (cur >= 0 && KW == 2) ? K2[cur] : nullptr; P.v_in = cur >= 0 ? V[cur] : nullptr;
+        const int nxt = cur < 0 ? 0 : (cur ^ 1);
+        P.k1_out = K1[nxt]; P.k2_out = KW == 2 ? K2[nxt] : nullptr; P.v_out = V[nxt];
+        P.digits = digits;
+        P.counts = Tb.counts; P.blk_seg = Tb.blk_seg; P.blk_start = Tb.blk_start; P.seg_start = seg_start; P.sp1 = sp1; P.sp2 = sp2;
+        P.nseg = nseg; P.F = pl.F[l]; P.stride = stride; P.R = Tb.R; P.D = D;
+        P.gen_off = 0; P.gen_len = n;
+        const u32 rows = Tb.rows;
+        P.per_xcd = (c.xcd_remap == 1 && rows >= 64) ? cdiv(rows, 8) : 0u;
+        const u32 grid = P.per_xcd ? 8 * P.per_xcd : rows;
+        {
+            const int pc = c.prof_begin(K_RS_COUNT, (u64)n * (gl ? 1 : 8 * KW));
+            if (gl && last) ws_count_kernel<KW, GEN, true><<<grid, 256, 0, s>>>(P, g, rows);
+            else if (gl) ws_count_kernel<KW, GEN, false><<<grid, 256, 0, s>>>(P, g, rows);
+            else if (last) ws_count_kernel<KW, false, true><<<grid, 256, 0, s>>>(P, g, rows);
+            else ws_count_kernel<KW, false, false><<<grid, 256, 0, s>>>(P, g, rows);
+            LAUNCH_CHECK();
+            c.prof_end(pc);
+        }
+        ss_level_offsets(c, Tb, seg_start, nseg, D, nstart, n);
+        {
+            const int ps = c.prof_begin(K_RS_SCATTER_U64, (u64)n * (gl ? 3 + 4 + 8 * KW : 2 * (4 + 8 * KW) + 2));
+            if (gl && last) ws_scatter_kernel<KW, GEN, true><<<grid, 256, 0, s>>>(P, g, rows);
+            else if (gl) ws_scatter_kernel<KW, GEN, false><<<grid, 256, 0, s>>>(P, g, rows);
+            else if (last) ws_scatter_kernel<KW, false, true><<<grid, 256, 0, s>>>(P, g, rows);
+            else ws_scatter_kernel<KW, false, false><<<grid, 256, 0, s>>>(P, g, rows);
+            LAUNCH_CHECK();
+            c.prof_end(ps);
+        }
+        c.arena.release(lm2);
+        seg_start = nstart;
+        nseg = nseg * D;
+        cur = nxt;
+    }
+    const u32 nleaf = nseg;
+    const u32* leaf_start = seg_start;
+
+    // ---- units + leaf sort ----
+    UnitTables U;
+    ss_build_units(c, leaf_start, nleaf, U, (u32)c.wsort_pack);   // small units: the 12- and 16-row leaf kernels run out of registers
+    const u32 nlarge = U.hc[0];
+    st->units = U.hc[1]; st->large_leaves = nlarge;
+    WLeaf A;
+    A.k1 = K1[cur]; A.k2 = KW == 2 ? K2[cur] : nullptr; A.v = V[cur]; A.unit_rng = U.unit_rng; A.flags = flags; A.lcp = lcp8;
+    A.d_err = c.d_err; A.inv = g.b ? (65536u + (u32)g.b - 1) / (u32)g.b : 65536u;
+    A.cmax = c.wsort_small ? 1u : (c.wsort_cmax < 1 ? 1u : (c.wsort_cmax > (int)WS_CMAX ? WS_CMAX : (u32)c.wsort_cmax));
+    {
+        // Stage 0: the units of the leaves.  Kernel A sorts every unit by its first differing word; the counting kernel orders the runs
+        // that are left (<= 256 members) by the next word and hands longer runs back as the units of the next stage.
+        Ctx::ProfScope prof(c, K_SS_LEAF, (u64)n * (PAIRS ? 2 * (4 + 8 * KW) : (4 + 8 * KW) + 6));
+        const u32* cur_rng = U.unit_rng;
+        const u32* cur_cls = U.cls_list;
+        size_t cur_cap = U.cap;
+        u32 cur_cnt[4] = { U.hc[2], U.hc[3], U.hc[4], U.hc[5] };
+        u32 wave_cnt = 0;                                        // runs for the wave kernel (class 0 of the previous stage's hand-over)
+        const u32* wave_list = nullptr;
+        const u32 ediv = A.cmax + 1;                            // a run that is handed on has more than cmax members
+        const u32 ecap2 = (u32)(n / ediv + 2);
+        u32* e_rng[2] = { c.arena.get<u32>(2 * (size_t)ecap2), c.arena.get<u32>(2 * (size_t)ecap2) };
+        u32* e_cls[2] = { c.arena.get<u32>(5 * (size_t)ecap2), c.arena.get<u32>(5 * (size_t)ecap2) };
+        u32* lc = c.arena.get<u32>(16);                          // [0..7]: per class |rlist|, |tlist|; [8..12]: next stage's units, per class
+        for (int stage = 0; stage < 8; ++stage) {
+            if (wave_cnt) {
+                A.unit_rng = cur_rng;
+                if (PAIRS) ws_run_wave_kernel<true><<<cdiv(wave_cnt, 4), 256, 0, s>>>(A, wave_list, wave_cnt);
+                else ws_run_wave_kernel<false><<<cdiv(wave_cnt, 4), 256, 0, s>>>(A, wave_list, wave_cnt);
+                LAUNCH_CHECK();
+                st->wave_runs += wave_cnt;
+                wave_cnt = 0;
+            }
+            if (!(cur_cnt[0] | cur_cnt[1] | cur_cnt[2] | cur_cnt[3])) break;
+            if (stage == 7) throw HipError{hipErrorUnknown, "wide splitter sort: leaf stages did not converge", (int)__LINE__};
+            const size_t lm3 = c.arena.mark();
+            u32* rl = c.arena.get<u32>(4 * cur_cap);
+            u32* tl = c.arena.get<u32>(4 * cur_cap);
+            HIP_TRY(hipMemsetAsync(lc, 0, 16 * sizeof(u32), s));
+            A.unit_rng = cur_rng;
+            for (int q = 0; q < 4; ++q) {
+                const u32 cnt = cur_cnt[q];
+                if (!cnt) continue;
+                const WLists Q = { rl + q * cur_cap, tl + q * cur_cap, lc + 2 * q };
+                const u32* lst = cur_cls + q * cur_cap;
+                if (q == 0) ws_leaf_sort_kernel<KW, 4, PAIRS><<<cnt, WL_NW * 64, 0, s>>>(A, lst, cnt, Q);
+                else if (q == 1) ws_leaf_sort_kernel<KW, 8, PAIRS><<<cnt, WL_NW * 64, 0, s>>>(A, lst, cnt, Q);
+                else if (q == 2) ws_leaf_sort_kernel<KW, 12, PAIRS><<<cnt, WL_NW * 64, 0, s>>>(A, lst, cnt, Q);
+                else ws_leaf_sort_kernel<KW, 16, PAIRS><<<cnt, WL_NW * 64, 0, s>>>(A, lst, cnt, Q);
+                LAUNCH_CHECK();
+            }
+            u32 hl[8];
+            c.read_n(lc, hl, 8);
+            HIP_TRY(hipMemsetAsync(e_rng[stage & 1], 0, 2 * (size_t)ecap2 * sizeof(u32), s));
+            const WEmit E = { e_rng[stage & 1], ediv };
+            const WEmit noE = { nullptr, 1 };
+            auto count_pass = [&](int q, const u32* lst, u32 cnt, u32 mask, u32 val, const WCount& R, const WEmit& Em) {
+                if (!cnt) return;
+                if (q == 0) ws_leaf_count_kernel<4, PAIRS><<<cnt, WL_NW * 64, 0, s>>>(A, lst, cnt, mask, val, R, Em);
+                else if (q == 1) ws_leaf_count_kernel<8, PAIRS><<<cnt, WL_NW * 64, 0, s>>>(A, lst, cnt, mask, val, R, Em);
+                else if (q == 2) ws_leaf_count_kernel<12, PAIRS><<<cnt, WL_NW * 64, 0, s>>>(A, lst, cnt, mask, val, R, Em);
+                else ws_leaf_count_kernel<16, PAIRS><<<cnt, WL_NW * 64, 0, s>>>(A, lst, cnt, mask, val, R, Em);
+                LAUNCH_CHECK();
+            };
+            for (int q = 0; q < 4; ++q) {
+                const u32 nt = hl[2 * q + 1], nr = hl[2 * q];
+                if (nt) {                                        // ties on a truncated word: by the word itself ...
+                    st->trunc_units += nt;
+                    const WCount t1 = { A.k1, KW == 2 ? A.k2 : nullptr, 0u };
+                    count_pass(q, tl + q * cur_cap, nt, 0x80000000u, 0u, t1, E);              // not pure: k1 (k2 follows)
+                    if (KW == 2) {
+                        const WCount t2 = { A.k2, nullptr, 64u };
+                        count_pass(q, tl + q * cur_cap, nt, 0x80000000u, 0x80000000u, t2, E);  // pure: k2
+                        count_pass(q, tl + q * cur_cap, nt, 0x80000000u, 0u, t2, noE);         // ... then the not-pure ones by k2 (their long
+                    }                                                                           //     runs are on their way already)
+                }
+                if (KW == 2 && nr) {
+                    st->refined_units += nr;
+                    const WCount r2 = { A.k2, nullptr, 64u };
+                    count_pass(q, rl + q * cur_cap, nr, 0u, 0u, r2, E);
+                }
+            }
+            ws_emit_compact_kernel<<<cdiv(ecap2, EC_TILE), 256, 0, s>>>(e_rng[stage & 1], ecap2, e_cls[stage & 1], ecap2, lc + 8);
+            LAUNCH_CHECK();
+            u32 he[6];
+            c.read_n(lc + 8, he, 6);
+            he[0] = he[1] + he[2] + he[3] + he[4] + he[5];
+            if (getenv("TDC_GPU_WSORT_LOG"))
+                fprintf(stderr, "[wsort] n=%zu stage %d: units %u %u %u %u | r/t lists %u/%u %u/%u %u/%u %u/%u | handed on %u (wave %u | %u %u %u %u)\n", n, stage,
+                        cur_cnt[0], cur_cnt[1], cur_cnt[2], cur_cnt[3], hl[0], hl[1], hl[2], hl[3], hl[4], hl[5], hl[6], hl[7], he[0], he[1], he[2], he[3], he[4], he[5]);
+            c.arena.release(lm3);
+            st->longrun_units += he[0];
+            cur_rng = e_rng[stage & 1]; cur_cls = e_cls[stage & 1] + ecap2; cur_cap = ecap2;
+            wave_list = e_cls[stage & 1]; wave_cnt = he[1];
+            for (int q = 0; q < 4; ++q) cur_cnt[q] = he[2 + q];
+            st->leaf_stages = (u32)stage + 1;
+        }
+    }
+    if (nlarge) {                                              // leaves above the workgroup capacity: LSD sort, one by one
+        if (nlarge > U.large_cap) throw HipError{hipErrorUnknown, "wide splitter sort: too many oversized leaves", (int)__LINE__};
+        std::vector<u32> ll(nlarge), ls((size_t)nleaf + 1);
+        HIP_TRY(hipMemcpyAsync(ll.data(), U.large + 6, nlarge * sizeof(u32), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(ls.data(), leaf_start, ((size_t)nleaf + 1) * sizeof(u32), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        for (u32 i = 0; i < nlarge; ++i) {
+            const size_t a = ls[ll[i]], b = ls[ll[i] + 1];
+            u64* kk1[2] = { K1[cur] + a, K1[cur ^ 1] + a };
+            u64* kk2[2] = { KW == 2 ? K2[cur] + a : nullptr, KW == 2 ? K2[cur ^ 1] + a : nullptr };
+            u32* vv[2] = { V[cur] + a, V[cur ^ 1] + a };
+            ws_lsd_sort_wide(c, kk1, KW == 2 ? kk2 : nullptr, vv, b - a, 64);
+            HIP_TRY(hipMemcpyAsync(kk1[0], kk1[1], (b - a) * sizeof(u64), hipMemcpyDeviceToDevice, s));
+            if (KW == 2) HIP_TRY(hipMemcpyAsync(kk2[0], kk2[1], (b - a) * sizeof(u64), hipMemcpyDeviceToDevice, s));
+            HIP_TRY(hipMemcpyAsync(vv[0], vv[1], (b - a) * sizeof(u32), hipMemcpyDeviceToDevice, s));
+            if (!PAIRS) {
+                ws_range_flags_kernel<KW><<<cdiv(b - a, 256), 256, 0, s>>>(kk1[0], kk2[0], 0u, (u32)(b - a), A.inv, flags + a, lcp8 + a);
+                LAUNCH_CHECK();
+            }
+            st->large_pairs += b - a;
+        }
+    }
+    if (!PAIRS) {
+        ws_fix_kernel<KW><<<cdiv(nleaf, 256), 256, 0, s>>>(leaf_start, nleaf, V[cur], g, flags, lcp8);
+        LAUNCH_CHECK();
+        { unsigned gq = cdiv(n, 256 * 16); if (gq > 4096) gq = 4096; ws_count_flags_kernel<<<gq, 256, 0, s>>>(flags, n, d_nonheads); }
+        LAUNCH_CHECK();
+        u64 nh = 0;
+        c.read_n((const u64*)d_nonheads, &nh, 1);
+        st->nonheads = nh;
+    }
+    c.arena.release(mark);
+    return cur;
+}
+}  // namespace
+
+int wsort_suffixes(Ctx& c, int KW, const WKeyGen& g, u64* K1[2], u64* K2[2], u32* V[2], size_t n, u8* flags, u8* lcp8, WSortStats* st) {
+    WSortStats local;
+    if (!st) st = &local;
+    *st = WSortStats();
+    if (KW == 2) return ws_sort_impl<2, true, false>(c, &g, K1, K2, V, n, 64, flags, lcp8, st);
+    return ws_sort_impl<1, true, false>(c, &g, K1, K2, V, n, 64, flags, lcp8, st);
+}
+
+int wsort_records(Ctx& c, u64* K1[2], u64* K2[2], u32* V[2], size_t m, int k1_bits, WSortStats* st) {
+    WSortStats local;
+    if (!st) st = &local;
+    *st = WSortStats();
+    if (m < ((size_t)1 << 16)) {                               // small lists: two stable LSD sorts
+        ws_lsd_sort_wide(c, K1, K2, V, m, k1_bits);
+        return 1;
+    }
+    return ws_sort_impl<2, false, true>(c, nullptr, K1, K2, V, m, k1_bits, nullptr, nullptr, st);
+}
+
+}  // namespace tdc
