@@ -73,7 +73,7 @@ typedef struct {
     uint32_t sa_key_words;      /* 64-bit words of the initial suffix-sort key (0: classic path, 1 | 2: wide bit-packed keys) */
     uint32_t sa_text_rounds;    /* rank-free refinement rounds keyed from the text (wide path)     */
     uint32_t sa_mode;           /* 1: ISA / Phi / PLCP came from the fused scatter of the final suffix array, 0: classic */
-    uint32_t reserved0;
+    uint32_t sa_overlapped;     /* 1: the first partition level of the suffix sort ran chunk by chunk behind the upload */
 } tdc_gpu_stats;
 
 /* ---- context -------------------------------------------------------------------------------------------- */

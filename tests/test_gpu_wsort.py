@@ -106,3 +106,28 @@ def test_default_context_takes_the_wide_path_for_large_texts(gpu_ctx):
     got, st = gpu_ctx.lcpcomp_compress(text, threshold=2, flatten=1)
     assert st["sa_key_words"] == 2, st
     assert got == want
+
+
+def test_level_one_behind_the_upload(gpu_ctx):
+    """Host-buffer calls of 2^26 bytes and more run the first partition level of the suffix sort chunk by chunk behind the upload
+    (code map and splitters from chunk 0).  Same stream as with the overlap switched off; a text whose later chunks bring byte values
+    chunk 0 does not have must fall back (and still give the same stream)."""
+    plain = _ctx_env({"TDC_GPU_WSORT_OVERLAP": "0"})
+    try:
+        n = (1 << 26) + 12345
+        for name, data in (("english", T.gen_english(n, 21)), ("dna", T.gen_dna(n, 4))):
+            text = np.concatenate([data, np.zeros(1, dtype=np.uint8)])
+            a, sa_ = gpu_ctx.lcpcomp_compress(text, threshold=3, flatten=1)
+            b, sb_ = plain.lcpcomp_compress(text, threshold=3, flatten=1)
+            assert sa_["sa_overlapped"] == 1 and sb_["sa_overlapped"] == 0, (name, sa_["sa_overlapped"], sb_["sa_overlapped"])
+            assert a == b, name
+        # new byte values in the second half: the provisional code map is wrong, the overlapped work is discarded
+        data = T.gen_english(n, 22)
+        data[n // 2:] = np.where(data[n // 2:] == ord("e"), ord("E"), data[n // 2:])
+        text = np.concatenate([data, np.zeros(1, dtype=np.uint8)])
+        a, sa_ = gpu_ctx.lcpcomp_compress(text, threshold=3, flatten=1)
+        b, sb_ = plain.lcpcomp_compress(text, threshold=3, flatten=1)
+        assert sa_["sa_overlapped"] == 0
+        assert a == b
+    finally:
+        plain.close()

@@ -14,6 +14,7 @@ using namespace tdc;
 
 struct tdc_gpu_ctx {
     Ctx c;
+    WPre pre;                   // level 1 of the suffix sort behind the upload (compress_host); c.wpre points here
     std::string last_error;
 };
 
@@ -177,7 +178,7 @@ void run_textds(Ctx& c, const u8* d_text, size_t n, DevArrays& A, tdc_gpu_stats*
     if (st) {
         st->maxlcp = A.maxlcp;
         st->sa_rounds = ss.rounds; st->sa_init_syms = ss.init_syms; st->sa_sorted_elems = ss.sorted_elems;
-        st->sa_key_words = ss.wide_kw; st->sa_text_rounds = ss.text_rounds; st->sa_mode = (uint32_t)ex.mode;
+        st->sa_key_words = ss.wide_kw; st->sa_text_rounds = ss.text_rounds; st->sa_mode = (uint32_t)ex.mode; st->sa_overlapped = ss.overlapped;
         if (ev) { ev->span(&st->ms_sa, e0, e1); ev->span(&st->ms_phi, e1, e2); ev->span(&st->ms_plcp, e2, e3); }
     }
 }
@@ -276,6 +277,7 @@ int tdc_gpu_ctx_create(int device, tdc_gpu_ctx** out) {
     tdc_gpu_ctx* ctx = new (std::nothrow) tdc_gpu_ctx();
     if (!ctx) return TDC_GPU_ERR_OOM;
     ctx->c.device = device;
+    ctx->c.wpre = &ctx->pre;
     try {
         HIP_TRY(hipSetDevice(device));
         HIP_TRY(hipStreamCreateWithFlags(&ctx->c.stream, hipStreamNonBlocking));
@@ -314,6 +316,7 @@ int tdc_gpu_ctx_create(int device, tdc_gpu_ctx** out) {
         if (const char* m = getenv("TDC_GPU_WSORT_KW")) { const int v = atoi(m); ctx->c.wsort_kw = (v == 1 || v == 2) ? v : 0; }
         if (const char* m = getenv("TDC_GPU_WSORT_ROUNDS")) { const int v = atoi(m); ctx->c.wsort_rounds = v < 0 ? 0 : (v > 100 ? 100 : v); }
         if (const char* m = getenv("TDC_GPU_WSORT_SMALLRUN")) ctx->c.wsort_small = atoi(m) ? 1 : 0;
+        if (const char* m = getenv("TDC_GPU_WSORT_OVERLAP")) ctx->c.wsort_overlap = atoi(m) ? 1 : 0;
         if (const char* m = getenv("TDC_GPU_WSORT_PACK")) { const int v = atoi(m); ctx->c.wsort_pack = (v == 1024 || v == 4096) ? v : 2048; }
         if (const char* m = getenv("TDC_GPU_WSORT_CMAX")) { const int v = atoi(m); ctx->c.wsort_cmax = v < 1 ? 1 : (v > 64 ? 64 : v); }
         if (const char* m = getenv("TDC_GPU_SSORT_LEVELS")) { const int v = atoi(m); ctx->c.ssort_levels = (v >= 1 && v <= 3) ? v : 0; }
@@ -447,20 +450,47 @@ void compress_host(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, bool raw, ui
     } else {
         d_text = c.arena.get<u8>(n + 64);
         if (n >= ((size_t)1 << 26) && c.copy_stream) {
-            // the upload in eight chunks on the copy stream, the byte histogram of every chunk behind it on the compute stream
+            // The upload in chunks on the copy stream.  Behind every chunk, on the compute stream: its byte histogram (sentinel check,
+            // symbol codes) and -- texts that take the wide suffix sort -- level 1 of that sort for the chunk in front of it (a key reads
+            // up to 64 bytes ahead), with the code map and the splitters taken from chunk 0 (prim.hpp WPre).  All copies are queued
+            // first: the one host wait in between (the histogram of chunk 0) does not stall them.
             u32* d_hist = c.arena.get<u32>(256);
             HIP_TRY(hipMemsetAsync(d_hist, 0, 256 * sizeof(u32), c.stream));
             HIP_TRY(hipEventRecord(c.ev_copy[8], c.stream));                   // (the copy stream starts behind whatever the compute stream did before)
             HIP_TRY(hipStreamWaitEvent(c.copy_stream, c.ev_copy[8], 0));
-            const size_t CH = 8, step = ((n + CH - 1) / CH + 255) & ~(size_t)255;
-            for (size_t q = 0, off = 0; q < CH && off < n; ++q, off += step) {
+            const bool try_pre = c.wsort_overlap && c.wpre && wsort_applicable(c, n);
+            const size_t CH = try_pre ? 16 : 8;
+            const size_t step = ((n + CH - 1) / CH + 4095) & ~(size_t)4095;
+            const size_t nch = (n + step - 1) / step;
+            size_t queued = 0;                                                  // copies handed to the copy stream so far
+            auto queue_copies = [&](size_t upto) {                              // (a few chunks ahead of the compute stream's work, not all at once:
+                for (; queued < nch && queued < upto; ++queued) {               //  the runtime batches what it is given in one go)
+                    const size_t off = queued * step, len = std::min(step, n - off);
+                    HIP_TRY(hipMemcpyAsync(d_text + off, text + off, len, hipMemcpyHostToDevice, c.copy_stream));
+                    HIP_TRY(hipEventRecord(c.ev_copy[16 + queued], c.copy_stream));
+                    (void)hipStreamQuery(c.copy_stream);                        // (submit now)
+                }
+            };
+            bool pre_on = false;
+            for (size_t q = 0, off = 0; q < nch; ++q, off += step) {
                 const size_t len = std::min(step, n - off);
-                HIP_TRY(hipMemcpyAsync(d_text + off, text + off, len, hipMemcpyHostToDevice, c.copy_stream));
-                HIP_TRY(hipEventRecord(c.ev_copy[q], c.copy_stream));
-                HIP_TRY(hipStreamWaitEvent(c.stream, c.ev_copy[q], 0));
+                queue_copies(q + 4);
+                HIP_TRY(hipStreamWaitEvent(c.stream, c.ev_copy[16 + q], 0));
                 text_histogram_add(c, d_text + off, len, d_hist);
+                if (q == 0 && try_pre) {
+                    u32 h0[256];
+                    c.read_n(d_hist, h0, 256);                                 // (waits for chunk 0 only; chunks 1 .. 3 are on their way)
+                    pre_on = wsort_pre_begin(c, *c.wpre, d_text, n, step, (u32)nch, h0);
+                    if (!pre_on) c.arena.release_top();
+                }
+                if (pre_on && q >= 1) wsort_pre_chunk(c, *c.wpre, (u32)q - 1);
             }
+            if (pre_on) wsort_pre_chunk(c, *c.wpre, (u32)nch - 1);
             text_histogram_finish(c, d_text, n, d_hist);
+            if (pre_on) {
+                wsort_pre_finish(c, *c.wpre, c.hist_cache);
+                if (!c.wpre->active) c.arena.release_top();                      // chunk 0 did not show every byte value: the classic order of things
+            }
         } else HIP_TRY(hipMemcpyAsync(d_text, text, n, hipMemcpyHostToDevice, c.stream));
     }
     const int e1 = ev.tick();
@@ -470,6 +500,7 @@ void compress_host(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, bool raw, ui
         ~SinkGuard() { if (c.d2h_done && c.copy_stream) (void)hipStreamSynchronize(c.copy_stream); c.d2h_host = nullptr; c.d2h_cap = 0; c.d2h_done = 0; }
     } sink_guard{c};
     c.d2h_host = ho.into; c.d2h_cap = ho.into ? ho.cap : 0; c.d2h_done = 0;      // the encoder may start the D2H while it still packs
+    struct PreGuard { Ctx& c; ~PreGuard() { if (c.wpre) { c.wpre->active = false; c.wpre->begun = false; } c.arena.release_top(); } } pre_guard{c};
     const size_t len = run_pipeline(c, d_text, tn, threshold, flatten, coder, &d_out, 0, stats, ev, comp);
     const int e2 = ev.tick();
     *ho.out_len = len;

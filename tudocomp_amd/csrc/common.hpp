@@ -58,14 +58,25 @@ struct Arena {
     size_t top = 0;
     size_t high = 0;
 
+    size_t top_hi = 0;          // bytes reserved at the END of the arena (alloc_top): scratch that must outlive bump-allocated neighbours
+
     void* alloc(size_t bytes) {
         size_t off = align_up(top, 256);
-        if (off + bytes > size) throw HipError{hipErrorOutOfMemory, "arena", (int)__LINE__};
+        if (off + bytes > size - top_hi) throw HipError{hipErrorOutOfMemory, "arena", (int)__LINE__};
         top = off + bytes;
         if (top > high) high = top;
         return base + off;
     }
     template <typename T> T* get(size_t count) { return (T*)alloc(count * sizeof(T)); }
+    void* alloc_top(size_t bytes) {
+        if (bytes + top_hi + 256 > size) throw HipError{hipErrorOutOfMemory, "arena (top)", (int)__LINE__};
+        const size_t off = (size - top_hi - bytes) & ~(size_t)255;
+        if (off < top) throw HipError{hipErrorOutOfMemory, "arena (top)", (int)__LINE__};
+        top_hi = size - off;
+        return base + off;
+    }
+    template <typename T> T* get_top(size_t count) { return (T*)alloc_top(count * sizeof(T)); }
+    void release_top() { top_hi = 0; }
     size_t mark() const { return top; }
     void release(size_t m) { top = m; }
 };
@@ -136,7 +147,8 @@ struct Ctx {
     size_t wsort_min = (size_t)1 << 20;   // smallest text that takes it (env TDC_GPU_WSORT_MIN, >= 4096; tests)
     int wsort_kw = 0;              // key words: 0 = by alphabet (2 when a word holds fewer than 16 symbols), 1 | 2 forced (env TDC_GPU_WSORT_KW)
     int wsort_rounds = 24;         // most text rounds before the doubling fallback (env TDC_GPU_WSORT_ROUNDS; 0: straight to doubling)
-    int wsort_cmax = 16;           // leaf sort: runs of tying records up to this length are ordered by counting, longer ones by the wave kernel (env TDC_GPU_WSORT_CMAX, 1 .. 64)
+    int wsort_cmax = 32;           // leaf sort: runs of tying records up to this length are ordered by counting, longer ones by the wave kernel (env TDC_GPU_WSORT_CMAX, 1 .. 64)
+    int wsort_overlap = 1;         // host-buffer calls: level 1 of the wide suffix sort runs chunk by chunk behind the upload (env TDC_GPU_WSORT_OVERLAP=0 disables)
     int wsort_pack = 2048;         // leaf sort: leaves up to this size are packed into units of at most twice that (env TDC_GPU_WSORT_PACK: 1024 | 2048 | 4096)
     int wsort_small = 0;           // tests: 1 = every run of a leaf unit counts as "big" (the chunk iterations run everywhere) (env TDC_GPU_WSORT_SMALLRUN)
     int msd_partition = 1;         // bucketed scatter: MSD partition with atomic slots instead of two stable LSD passes (env TDC_GPU_MSD_PARTITION=0)
@@ -150,7 +162,8 @@ struct Ctx {
     const u8* hist_ptr = nullptr;
     size_t hist_n = 0;
     hipStream_t copy_stream = nullptr;
-    hipEvent_t ev_copy[10] = {};
+    hipEvent_t ev_copy[40] = {};
+    struct WPre* wpre = nullptr;   // level 1 of the suffix sort done behind the upload (prim.hpp), owned by the API context
     u8* d2h_host = nullptr;        // destination (host) of the running call, or null
     size_t d2h_cap = 0;
     size_t d2h_done = 0;           // bytes of the stream already on their way when encode returns
@@ -189,6 +202,7 @@ struct Ctx {
     }
 
     void ensure_arena(size_t bytes) {
+        arena.top_hi = 0;
         if (arena.size >= bytes) { arena.top = 0; return; }
         if (arena.base) { HIP_TRY(hipFree(arena.base)); arena.base = nullptr; arena.size = 0; }
         HIP_TRY(hipMalloc((void**)&arena.base, bytes));

@@ -466,6 +466,7 @@ size_t encode_stream(Ctx& c, const u8* text, size_t n, FactorSpace fs, int coder
                     HIP_TRY(hipStreamWaitEvent(c.copy_stream, c.ev_copy[q], 0));
                     HIP_TRY(hipMemcpyAsync(c.d2h_host + copied, d_out + copied, safe - copied, hipMemcpyDeviceToHost, c.copy_stream));
                     copied = safe;
+                    c.d2h_done = copied;                     // (an error further down must still wait for this copy: api.hip SinkGuard)
                 }
             }
         }

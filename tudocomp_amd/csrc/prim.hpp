@@ -41,6 +41,7 @@ struct UnitTables { u32* unit_rng; u32* cls_list; u32* large; u32 cap, large_cap
 u32* ss_first_segment(Ctx& c, size_t n);                                           // seg_start[2] = { 0, n } on the device
 void ss_level_tables(Ctx& c, const u32* seg_start, u32 nseg, size_t n, u32 D, SegTables& T);      // row-block tables + count arrays (arena)
 void ss_level_offsets(Ctx& c, const SegTables& T, const u32* seg_start, u32 nseg, u32 D, u32* nstart, size_t n);   // counts -> offsets, next segment starts
+void ss_level_offsets_sub(Ctx& c, const SegTables& T, u32 nsub, const u32* blk_super, const u32* out_start, u32 nsuper, u32 D, u32* nstart, size_t n);
 void ss_build_units(Ctx& c, const u32* leaf_start, u32 nleaf, UnitTables& U, u32 small = 0);   // leaves -> units of <= 8192 pairs by size class (synchronises);
                                                                                    // leaves of <= `small` pairs (0: 4096) are packed into units of <= 2 * small
 void ss_fanouts(Ctx& c, size_t n, int& L, u32 F[3], u32& os);                      // levels, fan-outs and oversampling for n pairs
@@ -50,12 +51,34 @@ void ss_fanouts(Ctx& c, size_t n, int& L, u32 F[3], u32& os);                   
 // the text).  Bit-packed keys make the common prefix of two keys a count of leading zeros, which is where the LCP values come from.
 struct WKeyGen { const u8* text; size_t n; int b, s, pad; u32 inv /* ceil(65536 / b) */; u8 code[256]; };
 struct WSortStats { u32 levels = 0, range_leaves = 0, samples = 0, units = 0, large_leaves = 0, kw = 0, refined_units = 0, trunc_units = 0, longrun_units = 0, leaf_stages = 0, wave_runs = 0; u64 large_pairs = 0; u64 nonheads = 0; };
+// Level 1 of wsort_suffixes done chunk by chunk BEHIND THE UPLOAD of a host text (api.hip compress_host): the code map comes from the
+// bytes of chunk 0 (the full histogram confirms it afterwards, else the work is thrown away), the splitters from a sample of chunk 0,
+// and every chunk is counted and scattered into its own part of the record buffers as soon as it (and the chunk behind it: a key reads
+// up to 64 bytes ahead) has arrived.  Level 2 then reads the buckets of all chunks as pieces of one segment.  Buffers live at the top of
+// the arena (Arena::alloc_top) until the suffix array is done.
+struct WPre {
+    bool begun = false, active = false;
+    const u8* text = nullptr; size_t n = 0;
+    int KW = 0; WKeyGen g;
+    int L = 0; u32 F[3] = { 1, 1, 1 }; u32 os = 0, NLr = 0, NS = 0, S = 0;
+    u64* K1[2] = { nullptr, nullptr }; u64* K2[2] = { nullptr, nullptr }; u32* V[2] = { nullptr, nullptr };
+    u16* digits = nullptr; u64* sp1 = nullptr; u64* sp2 = nullptr;
+    u32 nchunks = 0; size_t chunk_len = 0;
+    u32* nstart_all = nullptr;       // [nchunks][F[0] + 1]: bucket starts of every chunk (absolute slots)
+    u32 present[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };   // byte values of the provisional code map
+};
+bool wsort_pre_begin(Ctx& c, WPre& P, const u8* text, size_t n, size_t chunk_len, u32 nchunks, const u32* hist0);   // false: not applicable
+void wsort_pre_chunk(Ctx& c, WPre& P, u32 q);                  // level 1 of chunk q (chunk q + 1 must have arrived)
+void wsort_pre_finish(Ctx& c, WPre& P, const u32* hist_full);  // sets P.active if the full histogram confirms the code map
 bool wsort_applicable(const Ctx& c, size_t n);
+void wsort_make_keygen(const Ctx& c, const u8* text, size_t n, u32 sigma, const u8* code, int& KW, WKeyGen& g);   // key layout for an alphabet
 int wsort_result_index(Ctx& c, size_t n);     // which of the two V buffers wsort_suffixes will return (so that the caller can make it sa[])
 // Sorts all suffixes of the text by key(p).  K1 / K2 / V: two buffers each (n entries; K2 unused for KW = 1).  Returns x: V[x] holds the
 // positions in sorted order; flags[i] = 1 where slot i starts a group of equal keys; lcp8[i] (valid where flags[i] = 1, i > 0) =
 // number of leading symbols the keys of slot i - 1 and slot i have in common.  st->nonheads = number of slots with flags = 0.
 int wsort_suffixes(Ctx& c, int KW, const WKeyGen& g, u64* K1[2], u64* K2[2], u32* V[2], size_t n, u8* flags, u8* lcp8, WSortStats* st);
+// the same behind a completed WPre (levels 2 .. L + leaves); the sorted positions land in v_final
+void wsort_suffixes_pre(Ctx& c, const WPre& P, u32* v_final, u8* flags, u8* lcp8, WSortStats* st);
 // Sorts m records (K1[0][j], K2[0][j], V[0][j]) by (k1, k2); k1_bits = significant bits of k1.  Returns the buffer index of the result.
 int wsort_records(Ctx& c, u64* K1[2], u64* K2[2], u32* V[2], size_t m, int k1_bits, WSortStats* st);
 

@@ -1230,6 +1230,21 @@ void ss_level_offsets(Ctx& c, const SegTables& T, const u32* seg_start, u32 nseg
     ss_apply_kernel<<<T.blocks_ub, 256, 0, s>>>(T.counts, T.blk_start, nseg, T.R, D, T.bs);
     LAUNCH_CHECK();
 }
+// the same for a level whose `nsub` input segments are pieces of `nsuper` output segments (consecutive groups of nsub / nsuper pieces:
+// wsort.hip merges the chunk-wise first level that way): blk_super[S] = first row block of super-segment S, out_start[S] = its first
+// output slot; nstart receives the nsuper * D + 1 digit starts
+void ss_level_offsets_sub(Ctx& c, const SegTables& T, u32 nsub, const u32* blk_super, const u32* out_start, u32 nsuper, u32 D, u32* nstart, size_t n) {
+    hipStream_t s = c.stream;
+    Ctx::ProfScope prof(c, K_SCAN, (u64)T.rows * D * 12);
+    ss_blocksum_kernel<<<T.blocks_ub, 256, 0, s>>>(T.counts, T.blk_start, nsub, T.R, D, T.bs);
+    LAUNCH_CHECK();
+    ss_segbase_kernel<<<nsuper, 1024, 0, s>>>(T.bs, blk_super, out_start, D, nstart);
+    LAUNCH_CHECK();
+    ss_set_word_kernel<<<1, 1, 0, s>>>(nstart + (size_t)nsuper * D, (u32)n);
+    LAUNCH_CHECK();
+    ss_apply_kernel<<<T.blocks_ub, 256, 0, s>>>(T.counts, T.blk_start, nsub, T.R, D, T.bs);
+    LAUNCH_CHECK();
+}
 u32* ss_first_segment(Ctx& c, size_t n) {
     u32* seg_start = c.arena.get<u32>(2);
     ss_set_word_kernel<<<1, 1, 0, c.stream>>>(seg_start, 0u);

@@ -702,25 +702,31 @@ void doubling_rounds(Ctx& c, size_t n, int bn, u32* sa, u32* rank, SABufs& B, si
 //     of the classic path from the depth reached so far.  Result mode 0.
 int build_suffix_array_wide(Ctx& c, const u8* text, size_t n, u32* sa, u32* isa, SAStats* st, SAExtra* ex, const CodeMap& cm, u32 sigma) {
     hipStream_t s = c.stream;
-    const int b = (int)bits_for(sigma > 1 ? sigma - 1 : 1);
-    const int per_word = 64 / b;
-    const int KW = c.wsort_kw ? c.wsort_kw : (per_word < 16 ? 2 : 1);
+    int KW;
     WKeyGen g;
-    g.text = text; g.n = n; g.b = b;
-    g.s = (64 * KW) / b; if (g.s > 64) g.s = 64;
-    g.pad = 64 * KW - g.s * b;
-    g.inv = (65536u + (u32)b - 1) / (u32)b;
-    memcpy(g.code, cm.code, 256);
+    wsort_make_keygen(c, text, n, sigma, cm.code, KW, g);
+    const int b = g.b;
+    const int per_word = 64 / b;
     WKeyGen g1 = g;                                            // the 64-bit keys of the text rounds
     g1.s = per_word > 64 ? 64 : per_word; g1.pad = 64 - g1.s * b;
     st->sym_bits = b; st->init_syms = g.s;
+    // level 1 may have been done behind the upload already (api.hip): its record buffers sit at the top of the arena
+    WPre* pre = (c.wpre && c.wpre->active && c.wpre->text == text && c.wpre->n == n && c.wpre->KW == KW) ? c.wpre : nullptr;
+    struct TopGuard { Ctx& c; WPre* p; ~TopGuard() { if (p) { p->active = false; p->begun = false; c.arena.release_top(); } } } top_guard{c, pre};
 
     SABufs B;
-    u64* K1[2] = { c.arena.get<u64>(n), c.arena.get<u64>(n) };
-    u64* K2[2] = { c.arena.get<u64>(n), c.arena.get<u64>(n) };  // (the rounds sort two-word records whatever the initial width)
-    u32* V[2] = { c.arena.get<u32>(n), c.arena.get<u32>(n) };
+    u64* K1[2]; u64* K2[2]; u32* V[2];
     u32* vspare = nullptr;                                     // the sorted positions land in sa[] itself: no copy afterwards
-    { const int ri = wsort_result_index(c, n); vspare = V[ri]; V[ri] = sa; }
+    if (pre) {
+        K1[0] = pre->K1[0]; K1[1] = pre->K1[1]; V[0] = pre->V[0]; V[1] = pre->V[1];
+        if (pre->KW == 2) { K2[0] = pre->K2[0]; K2[1] = pre->K2[1]; }
+        else { K2[0] = c.arena.get<u64>(n); K2[1] = c.arena.get<u64>(n); }       // (the rounds sort two-word records whatever the initial width)
+    } else {
+        K1[0] = c.arena.get<u64>(n); K1[1] = c.arena.get<u64>(n);
+        K2[0] = c.arena.get<u64>(n); K2[1] = c.arena.get<u64>(n);
+        V[0] = c.arena.get<u32>(n); V[1] = c.arena.get<u32>(n);
+        const int ri = wsort_result_index(c, n); vspare = V[ri]; V[ri] = sa;
+    }
     B.keys[0] = K1[0]; B.keys[1] = K1[1];
     u8* flags = c.arena.get<u8>(n + 8);
     u8* lcp8 = (ex && ex->lcp8) ? ex->lcp8 : c.arena.get<u8>(n + 8);
@@ -735,17 +741,22 @@ int build_suffix_array_wide(Ctx& c, const u8* text, size_t n, u32* sa, u32* isa,
     const int bn = (int)bits_for(n - 1);
 
     WSortStats ws;
-    const int x = wsort_suffixes(c, KW, g, K1, K2, V, n, flags, lcp8, &ws);
+    int x = 0;
+    if (pre) wsort_suffixes_pre(c, *pre, sa, flags, lcp8, &ws);
+    else x = wsort_suffixes(c, KW, g, K1, K2, V, n, flags, lcp8, &ws);
     st->sorted_elems += n;
+    st->overlapped = pre ? 1u : 0u;
     st->wide_kw = (u32)KW; st->wide_nonheads = ws.nonheads;
 
     // unresolved suffixes <= 2 * (slots that are not group heads): the text rounds pay while they are few
     bool fast = ex != nullptr && c.wsort_rounds > 0 && 2 * ws.nonheads <= n / 8;
     u32 h_tot[4] = { 0, 0, 0, 0 };
     size_t m;
-    if (V[x] != sa) {                                          // (cannot happen: wsort_result_index names the buffer wsort returns)
-        HIP_TRY(hipMemcpyAsync(sa, V[x], n * sizeof(u32), hipMemcpyDeviceToDevice, s));
-    } else V[x] = vspare;                                      // sa[] is the result now; the rounds get the spare buffer to sort in
+    if (!pre) {
+        if (V[x] != sa) {                                      // (cannot happen: wsort_result_index names the buffer wsort returns)
+            HIP_TRY(hipMemcpyAsync(sa, V[x], n * sizeof(u32), hipMemcpyDeviceToDevice, s));
+        } else V[x] = vspare;                                  // sa[] is the result now; the rounds get the spare buffer to sort in
+    }
     B.vals[0] = V[0]; B.vals[1] = V[1];                        // (scratch of the rank scatter / buffers of the doubling rounds)
     if (fast) {
         const u32 tiles = cdiv(n, FC_TILE);

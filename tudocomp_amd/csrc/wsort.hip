@@ -21,6 +21,7 @@
 #include "prim.hpp"
 
 #include <vector>
+#include <algorithm>
 #include <stdlib.h>
 
 namespace tdc {
@@ -41,6 +42,8 @@ struct WSLevel {
     u64* k1_out; u64* k2_out; u32* v_out;
     u32* counts;                 // [rows][D]
     const u32* blk_seg; const u32* blk_start; const u32* seg_start;
+    const u32* seg_end;          // end of every segment (seg_start + 1 where the segments are contiguous)
+    u32 sub;                     // pieces per splitter segment (1; the number of chunks on the level that merges a chunk-wise first level)
     const u64* sp1; const u64* sp2;      // [NS + 1] splitters (high / low word), sp[NS] = ~0
     u16* digits;
     u32 nseg, F, stride, R, D, per_xcd;
@@ -52,7 +55,7 @@ __device__ __forceinline__ bool ws_row(const WSLevel& P, u32 row, u32& s, size_t
     if (blk >= P.blk_start[P.nseg]) return false;
     s = P.blk_seg[blk];
     const u64 t = (u64)(blk - P.blk_start[s]) * P.R + row % P.R;
-    const u32 s0 = P.seg_start[s], s1 = P.seg_start[s + 1];
+    const u32 s0 = P.seg_start[s], s1 = P.seg_end[s];
     const u64 off = t * WS_TILE;
     base = s0; cnt = 0;
     if (off >= (u64)(s1 - s0)) return true;
@@ -63,7 +66,8 @@ __device__ __forceinline__ bool ws_row(const WSLevel& P, u32 row, u32& s, size_t
 }
 
 template <int KW, bool LAST>
-__device__ __forceinline__ void ws_load_splitters(const WSLevel& P, u32 s, u64* spl1, u64* spl2) {
+__device__ __forceinline__ void ws_load_splitters(const WSLevel& P, u32 s_piece, u64* spl1, u64* spl2) {
+    const u32 s = s_piece / P.sub;
     for (u32 i = threadIdx.x; i < 256; i += blockDim.x) {
         u64 a = ~0ull, b = ~0ull;
         size_t idx = 0; bool have = false;
@@ -790,16 +794,16 @@ __global__ __launch_bounds__(WL_NW * 64) void ws_leaf_count_kernel(WLeaf A, cons
         }
     }
 }
-// the runs handed on by the counting kernel, listed by class: 0 = pure and <= 1024 records (wave kernel), 1 .. 4 = kernel A by size
+// the runs handed on by the counting kernel, listed by class.  Runs whose records tie on all of k1 ("pure"): 0 = <= 32 records and
+// 1 = <= 64 (lane kernel), 2 = <= 256 and 3 = <= 1024 (wave kernel); everything else: 4 .. 7 = kernel A by size
 constexpr u32 EC_TILE = 256 * 32;
+constexpr int EC_NCLS = 8;
 __global__ __launch_bounds__(256) void ws_emit_compact_kernel(const u32* __restrict__ rng, u32 nent, u32* __restrict__ lists, u32 cap, u32* __restrict__ counters) {
-    __shared__ u32 cnt[5], base[5];
-    if (threadIdx.x < 5) cnt[threadIdx.x] = 0;
+    __shared__ u32 cnt[EC_NCLS], base[EC_NCLS];
+    if (threadIdx.x < EC_NCLS) cnt[threadIdx.x] = 0;
     __syncthreads();
     const u32 i0 = blockIdx.x * EC_TILE + threadIdx.x;
-    u32 mycls = 0, myidx[32 / 8];                              // 4 bits per entry: class + 1 (0 = empty); local index recomputed in pass 2
-#pragma unroll
-    for (int q = 0; q < 4; ++q) myidx[q] = 0;
+    u32 codes[4] = { 0, 0, 0, 0 };                             // 4 bits per entry: class + 1 (0 = empty)
 #pragma unroll
     for (int q = 0; q < 32; ++q) {
         const u32 i = i0 + (u32)q * 256;
@@ -807,19 +811,20 @@ __global__ __launch_bounds__(256) void ws_emit_compact_kernel(const u32* __restr
         if (i < nent) {
             const u32 a = rng[2 * (size_t)i], braw = rng[2 * (size_t)i + 1];
             const u32 m = (braw & 0x7FFFFFFFu) - a;
-            if (m > 0) code = ((braw >> 31) && m <= WS_WAVE_MAX) ? 1u : 2u + (m - 1) / 2048;
+            if (m > 0) {
+                if ((braw >> 31) && m <= WS_WAVE_MAX) code = m <= 32 ? 1u : (m <= 64 ? 2u : (m <= 256 ? 3u : 4u));
+                else code = 5u + (m - 1) / 2048;
+            }
         }
-        myidx[q >> 3] |= code << (4 * (q & 7));
+        codes[q >> 3] |= code << (4 * (q & 7));
         if (code) atomicAdd(&cnt[code - 1], 1u);
     }
-    (void)mycls;
     __syncthreads();
-    if (threadIdx.x < 5) { const u32 c = cnt[threadIdx.x]; base[threadIdx.x] = c ? atomicAdd(counters + 1 + threadIdx.x, c) : 0u; cnt[threadIdx.x] = 0; }
-    if (threadIdx.x == 0) { const u32 t = cnt[0] + cnt[1] + cnt[2] + cnt[3] + cnt[4]; (void)t; }
+    if (threadIdx.x < EC_NCLS) { const u32 c = cnt[threadIdx.x]; base[threadIdx.x] = c ? atomicAdd(counters + threadIdx.x, c) : 0u; cnt[threadIdx.x] = 0; }
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < 32; ++q) {
-        const u32 code = (myidx[q >> 3] >> (4 * (q & 7))) & 15u;
+        const u32 code = (codes[q >> 3] >> (4 * (q & 7))) & 15u;
         if (code) {
             const u32 k = base[code - 1] + atomicAdd(&cnt[code - 1], 1u);
             if (k < cap) lists[(size_t)(code - 1) * cap + k] = i0 + (u32)q * 256;
@@ -844,17 +849,58 @@ __global__ __launch_bounds__(256) void ws_count_flags_kernel(const u8* __restric
     if (threadIdx.x == 0) { const u32 t = part[0] + part[1] + part[2] + part[3]; if (t) atomicAdd(d_nonheads, (unsigned long long)t); }
 }
 
-// ---- one WAVE sorts one run of <= 1024 records that tie on k1, by the whole of k2 ---------------------------------------------------
+// ---- runs of <= 64 records that tie on k1: one record per LANE ------------------------------------------------------------------------
+// A bitonic network over W = 32 or 64 lanes on (word, lane) -- the lane number breaks ties and keeps the padding lanes (all-ones word,
+// lane >= m) behind every record.  No LDS, no passes, a dozen registers; W = 32: every wave sorts two runs at once.
+template <int W, bool PAIRS>
+__global__ __launch_bounds__(256) void ws_run_lane_kernel(WLeaf A, const u32* __restrict__ list, u32 count) {
+    const int lane = lane_id();
+    const u32 sub = (u32)lane / W, ll = (u32)lane % W;
+    const u32 r = (blockIdx.x * 4 + (u32)wave_id()) * (64 / W) + sub;
+    u32 a = 0, m = 0;
+    if (r < count) { const u32 u = list[r]; a = A.unit_rng[2 * u]; m = (A.unit_rng[2 * u + 1] & 0x7FFFFFFFu) - a; }
+    if (m > (u32)W) m = 0;                                     // (not this kernel's class: leave it alone)
+    u64* Wd = A.k2 + a;
+    u64 key = (ll < m) ? Wd[ll] : ~0ull;
+    u32 idl = ll;
+    const u32 vold = (ll < m) ? A.v[(size_t)a + ll] : 0u;
+#pragma unroll
+    for (u32 k2 = 2; k2 <= (u32)W; k2 <<= 1) {
+#pragma unroll
+        for (u32 j = k2 >> 1; j > 0; j >>= 1) {
+            const u64 ok = __shfl_xor(key, (int)j, 64);
+            const u32 oi = __shfl_xor(idl, (int)j, 64);
+            const bool up = ((ll & k2) == 0);
+            const bool lower = ((ll & j) == 0);
+            const bool gt = key > ok || (key == ok && idl > oi);           // mine > the partner's
+            const bool take = lower ? (gt == up) : (!gt == up);
+            if (take) { key = ok; idl = oi; }
+        }
+    }
+    const u64 prev = __shfl_up(key, 1, 64);
+    const u32 vnew = __shfl(vold, (int)(sub * W + idl), 64);
+    if (ll < m && m > 1) {
+        A.v[(size_t)a + ll] = vnew;
+        if (PAIRS) Wd[ll] = key;
+        if (ll > 0) {
+            const u64 x = key ^ prev;
+            A.flags[(size_t)a + ll] = x ? 1 : 0;
+            if (x && !PAIRS) A.lcp[(size_t)a + ll] = (u8)(((64u + (u32)__builtin_clzll(x)) * A.inv) >> 16);
+        }
+    }
+}
+
+// ---- one WAVE sorts one run of <= CAPR records that tie on k1, by the whole of k2 ---------------------------------------------------------
 // The runs of 65 .. 1024 equal first words are the mid-frequency phrases of a text: hundreds of thousands of them, each far too small
 // for a 512-thread workgroup (kernel A spends its time in barriers and idle lanes there).  Here a wave owns a run: LSD passes over the
 // differing bits of k2 on (word, record number) pairs held in registers, ranks from the wave-level LDS match, no workgroup barrier
 // anywhere -- the four waves of a workgroup work on four runs independently.  Written back: positions in k2 order, head flags, LCPs
-// (base: the 64 bits of k1), PAIRS: k2 itself.
-constexpr int WR_ROWS = WS_WAVE_MAX / 64;
-template <bool PAIRS>
+// (base: the 64 bits of k1), PAIRS: k2 itself.  CAPR = 256 | 1024: the small variant keeps a quarter of the LDS (more waves per CU).
+template <int CAPR, bool PAIRS>
 __global__ __launch_bounds__(256) void ws_run_wave_kernel(WLeaf A, const u32* __restrict__ list, u32 count) {
-    __shared__ u64 sk[4][WS_WAVE_MAX];
-    __shared__ u16 sid[4][WS_WAVE_MAX];
+    constexpr int WR_ROWS = CAPR / 64;
+    __shared__ u64 sk[4][CAPR];
+    __shared__ u16 sid[4][CAPR];
     __shared__ __align__(16) u32 cnt[4][256];
     __shared__ u64 mt[4][256];
     const int lane = lane_id(), w = wave_id();
@@ -862,40 +908,8 @@ __global__ __launch_bounds__(256) void ws_run_wave_kernel(WLeaf A, const u32* __
     if (r >= count) return;
     const u32 u = list[r];
     const u32 a = A.unit_rng[2 * u], m = (A.unit_rng[2 * u + 1] & 0x7FFFFFFFu) - a;
-    if (m <= 1 || m > WS_WAVE_MAX) return;
+    if (m <= 1 || m > (u32)CAPR) return;
     u64* W = A.k2 + a;
-    if (m <= 64) {
-        // one record per lane: a bitonic network over the lanes on (word, lane) -- the lane number breaks ties and keeps the padding
-        // lanes (all-ones word, lane >= m) behind every record; no LDS arrays, no passes
-        u64 key = ((u32)lane < m) ? W[lane] : ~0ull;
-        u32 idl = (u32)lane;
-        const u32 vold = ((u32)lane < m) ? A.v[(size_t)a + lane] : 0u;
-#pragma unroll
-        for (u32 k2 = 2; k2 <= 64; k2 <<= 1) {
-#pragma unroll
-            for (u32 j = k2 >> 1; j > 0; j >>= 1) {
-                const u64 ok = __shfl_xor(key, (int)j, 64);
-                const u32 oi = __shfl_xor(idl, (int)j, 64);
-                const bool up = (((u32)lane & k2) == 0) || k2 == 64;
-                const bool lower = (((u32)lane & j) == 0);
-                const bool gt = key > ok || (key == ok && idl > oi);       // mine > the partner's
-                const bool take = lower ? (gt == up) : (!gt == up);
-                if (take) { key = ok; idl = oi; }
-            }
-        }
-        const u64 prev = __shfl_up(key, 1, 64);
-        const u32 vnew = __shfl(vold, (int)idl, 64);
-        if ((u32)lane < m) {
-            A.v[(size_t)a + lane] = vnew;
-            if (PAIRS) W[lane] = key;
-            if (lane > 0) {
-                const u64 x = key ^ prev;
-                A.flags[(size_t)a + lane] = x ? 1 : 0;
-                if (x && !PAIRS) A.lcp[(size_t)a + lane] = (u8)(((64u + (u32)__builtin_clzll(x)) * A.inv) >> 16);
-            }
-        }
-        return;
-    }
     u64* K = sk[w]; u16* S = sid[w]; u32* mycnt = cnt[w];
     unsigned long long* M = (unsigned long long*)mt[w];
     const int rows = (int)((m + 63) >> 6);
@@ -1018,7 +1032,58 @@ __global__ void ws_range_flags_kernel(const u64* __restrict__ k1, const u64* __r
     if (h && lcp) lcp[i] = (u8)(((x1 ? (u32)__builtin_clzll(x1) : 64u + (u32)__builtin_clzll(x2)) * inv) >> 16);
 }
 
+// ---- tables of the level that merges a chunk-wise level 1 -----------------------------------------------------------------------------
+// nstart_all[q][b]: first slot of bucket b inside chunk q ([F0] = end of the chunk's part).  Piece b * nch + q = that range; out_start[b] =
+// first output slot of bucket b = total size of the buckets in front of it.
+__global__ __launch_bounds__(256) void ws_sub_tables_kernel(const u32* __restrict__ nstart_all, u32 F0, u32 nch, u32* __restrict__ seg_begin,
+                                                             u32* __restrict__ seg_end, u32* __restrict__ out_start) {
+    __shared__ u32 tot[256];
+    const u32 b = threadIdx.x;
+    u32 t = 0;
+    if (b < F0) {
+        for (u32 q = 0; q < nch; ++q) {
+            const u32 lo = nstart_all[(size_t)q * (F0 + 1) + b], hi = nstart_all[(size_t)q * (F0 + 1) + b + 1];
+            seg_begin[b * nch + q] = lo; seg_end[b * nch + q] = hi;
+            t += hi - lo;
+        }
+    }
+    tot[b] = t;
+    __syncthreads();
+    if (b == 0) {
+        u32 run = 0;
+        for (u32 i = 0; i < F0; ++i) { out_start[i] = run; run += tot[i]; }
+        out_start[F0] = run;
+    }
+}
+__global__ void ws_sub_nblk_kernel(const u32* __restrict__ seg_begin, const u32* __restrict__ seg_end, u32 nsub, u32 R, u32* __restrict__ nblk) {
+    const u32 sidx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sidx > nsub) return;
+    if (sidx == nsub) { nblk[sidx] = 0; return; }
+    const u64 size = seg_end[sidx] - seg_begin[sidx];
+    nblk[sidx] = (u32)((size + (u64)WS_TILE * R - 1) / ((u64)WS_TILE * R));
+}
+__global__ void ws_blkseg_kernel(const u32* __restrict__ blk_start, u32 nseg, u32* __restrict__ blk_seg) {
+    const u32 sidx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sidx >= nseg) return;
+    for (u32 b = blk_start[sidx]; b < blk_start[sidx + 1]; ++b) blk_seg[b] = sidx;
+}
+__global__ void ws_blk_super_kernel(const u32* __restrict__ blk_start, u32 nsuper, u32 sub, u32* __restrict__ blk_super) {
+    const u32 S = blockIdx.x * blockDim.x + threadIdx.x;
+    if (S <= nsuper) blk_super[S] = blk_start[(size_t)S * sub];
+}
+__global__ void ws_set2_kernel(u32* p, u32 a, u32 b) { p[0] = a; p[1] = b; }
+
 // ---- host -------------------------------------------------------------------------------------------------------------------------
+void wsort_make_keygen(const Ctx& c, const u8* text, size_t n, u32 sigma, const u8* code, int& KW, WKeyGen& g) {
+    const int b = (int)bits_for(sigma > 1 ? sigma - 1 : 1);
+    const int per_word = 64 / b;
+    KW = c.wsort_kw ? c.wsort_kw : (per_word < 16 ? 2 : 1);
+    g.text = text; g.n = n; g.b = b;
+    g.s = (64 * KW) / b; if (g.s > 64) g.s = 64;
+    g.pad = 64 * KW - g.s * b;
+    g.inv = (65536u + (u32)b - 1) / (u32)b;
+    memcpy(g.code, code, 256);
+}
 bool wsort_applicable(const Ctx& c, size_t n) { return c.wsort && n >= c.wsort_min && n < ((size_t)1 << 32); }
 int wsort_result_index(Ctx& c, size_t n) {                    // index of the V buffer that will hold wsort_suffixes' result
     int L; u32 F[3], os;
@@ -1052,21 +1117,30 @@ void ws_splitters(Ctx& c, const WPlan& pl, const u64* k1, const u64* k2, const W
     c.arena.release(m2);
 }
 
+// pre != nullptr: level 1 was done chunk by chunk behind the upload (WPre); the levels continue from its buckets and the sorted
+// positions land in v_final
 template <int KW, bool GEN, bool PAIRS>
-int ws_sort_impl(Ctx& c, const WKeyGen* gen, u64* K1[2], u64* K2[2], u32* V[2], size_t n, int k1_bits, u8* flags, u8* lcp8, WSortStats* st) {
+int ws_sort_impl(Ctx& c, const WKeyGen* gen, u64* K1[2], u64* K2[2], u32* V[2], size_t n, int k1_bits, u8* flags, u8* lcp8, WSortStats* st,
+                 const WPre* pre = nullptr, u32* v_final = nullptr) {
     hipStream_t s = c.stream;
     const size_t mark = c.arena.mark();
     WKeyGen g;
     if (gen) g = *gen; else memset(&g, 0, sizeof(g));
     WPlan pl;
-    ss_fanouts(c, n, pl.L, pl.F, pl.os);
-    pl.NLr = pl.F[0] * pl.F[1] * pl.F[2]; pl.NS = pl.NLr - 1; pl.S = pl.os * pl.NLr;
+    u64* sp1; u64* sp2;
+    if (pre) {
+        pl.L = pre->L; pl.F[0] = pre->F[0]; pl.F[1] = pre->F[1]; pl.F[2] = pre->F[2]; pl.os = pre->os;
+        pl.NLr = pre->NLr; pl.NS = pre->NS; pl.S = pre->S;
+        sp1 = pre->sp1; sp2 = pre->sp2;
+    } else {
+        ss_fanouts(c, n, pl.L, pl.F, pl.os);
+        pl.NLr = pl.F[0] * pl.F[1] * pl.F[2]; pl.NS = pl.NLr - 1; pl.S = pl.os * pl.NLr;
+        sp1 = c.arena.get<u64>((size_t)pl.NS + 1);
+        sp2 = KW == 2 ? c.arena.get<u64>((size_t)pl.NS + 1) : nullptr;
+        ws_splitters<KW, GEN>(c, pl, K1[0], KW == 2 ? K2[0] : nullptr, g, n, sp1, sp2);
+    }
     const int L = pl.L;
     st->levels = (u32)L; st->range_leaves = pl.NLr; st->samples = pl.S; st->kw = KW;
-
-    u64* sp1 = c.arena.get<u64>((size_t)pl.NS + 1);
-    u64* sp2 = KW == 2 ? c.arena.get<u64>((size_t)pl.NS + 1) : nullptr;
-    ws_splitters<KW, GEN>(c, pl, K1[0], KW == 2 ? K2[0] : nullptr, g, n, sp1, sp2);
 
     unsigned long long* d_nonheads = (unsigned long long*)c.arena.get<u64>(1);
     HIP_TRY(hipMemsetAsync(d_nonheads, 0, sizeof(u64), s));
@@ -1074,11 +1148,80 @@ int ws_sort_impl(Ctx& c, const WKeyGen* gen, u64* K1[2], u64* K2[2], u32* V[2], 
     HIP_TRY(hipMemsetAsync(flags, 0, n, s));
 
     // ---- partition levels ----
-    u16* digits = c.arena.get<u16>(align_up(n, WS_TILE) + WS_TILE);
-    const u32* seg_start = ss_first_segment(c, n);
+    u16* digits = pre ? pre->digits : c.arena.get<u16>(align_up(n, WS_TILE) + WS_TILE);
+    const u32* seg_start = pre ? nullptr : ss_first_segment(c, n);
     u32 nseg = 1;
     int cur = GEN ? -1 : 0;
-    for (int l = 0; l < L; ++l) {
+    u32* Vlast = nullptr;                                      // where the last level put the positions
+    if (pre) {
+        // ---- the level that merges the chunk-wise level 1: piece (b, q) = bucket b of chunk q, numbered b * nchunks + q, lies wherever
+        //      chunk q's scatter put it; the pieces of bucket b share its splitters and write into one output segment ----
+        const int l = 1;
+        const bool last = (l == L - 1);
+        const u32 F0 = pl.F[0], nch = pre->nchunks, nsub = F0 * nch;
+        const u32 D = last ? 2 * pl.F[l] : pl.F[l];
+        u32 stride = 1;
+        for (int q = l + 1; q < L; ++q) stride *= pl.F[q];
+        u32* nstart = c.arena.get<u32>((size_t)F0 * D + 1);
+        const size_t lm2 = c.arena.mark();
+        u32* seg_begin = c.arena.get<u32>(nsub + 1);
+        u32* seg_end = c.arena.get<u32>(nsub + 1);
+        u32* out_start = c.arena.get<u32>(F0 + 1);
+        ws_sub_tables_kernel<<<1, 256, 0, s>>>(pre->nstart_all, F0, nch, seg_begin, seg_end, out_start);
+        LAUNCH_CHECK();
+        SegTables Tb;
+        {
+            const u64 tiles = (n + WS_TILE - 1) / WS_TILE;
+            u32 R = 128;
+            while (R > 1 && (u64)nsub * R > tiles / 8 + 64) R >>= 1;
+            Tb.R = R; Tb.blocks_ub = (u32)((tiles + R - 1) / R) + nsub; Tb.rows = Tb.blocks_ub * R;
+            Tb.blk_start = c.arena.get<u32>((size_t)nsub + 1);
+            Tb.blk_seg = c.arena.get<u32>(Tb.blocks_ub);
+            Tb.counts = c.arena.get<u32>((size_t)Tb.rows * D);
+            Tb.bs = c.arena.get<u32>((size_t)Tb.blocks_ub * D);
+            ws_sub_nblk_kernel<<<cdiv((size_t)nsub + 1, 256), 256, 0, s>>>(seg_begin, seg_end, nsub, R, Tb.blk_start);
+            LAUNCH_CHECK();
+            exclusive_sum_u32(c, Tb.blk_start, Tb.blk_start, (size_t)nsub + 1, nullptr);
+            ws_blkseg_kernel<<<cdiv(nsub, 256), 256, 0, s>>>(Tb.blk_start, nsub, Tb.blk_seg);
+            LAUNCH_CHECK();
+        }
+        u32* blk_super = c.arena.get<u32>(F0 + 1);
+        ws_blk_super_kernel<<<cdiv(F0 + 1, 256), 256, 0, s>>>(Tb.blk_start, F0, nch, blk_super);
+        LAUNCH_CHECK();
+        WSLevel P;
+        P.k1_in = pre->K1[0]; P.k2_in = KW == 2 ? pre->K2[0] : nullptr; P.v_in = pre->V[0];
+        Vlast = last ? v_final : pre->V[1];
+        P.k1_out = pre->K1[1]; P.k2_out = KW == 2 ? pre->K2[1] : nullptr; P.v_out = Vlast;
+        P.digits = digits;
+        P.counts = Tb.counts; P.blk_seg = Tb.blk_seg; P.blk_start = Tb.blk_start; P.seg_start = seg_begin; P.seg_end = seg_end; P.sub = nch;
+        P.sp1 = sp1; P.sp2 = sp2;
+        P.nseg = nsub; P.F = pl.F[l]; P.stride = stride; P.R = Tb.R; P.D = D;
+        P.gen_off = 0; P.gen_len = n;
+        const u32 rows = Tb.rows;
+        P.per_xcd = (c.xcd_remap == 1 && rows >= 64) ? cdiv(rows, 8) : 0u;
+        const u32 grid = P.per_xcd ? 8 * P.per_xcd : rows;
+        {
+            const int pc = c.prof_begin(K_RS_COUNT, (u64)n * 8 * KW);
+            if (last) ws_count_kernel<KW, false, true><<<grid, 256, 0, s>>>(P, g, rows);
+            else ws_count_kernel<KW, false, false><<<grid, 256, 0, s>>>(P, g, rows);
+            LAUNCH_CHECK();
+            c.prof_end(pc);
+        }
+        ss_level_offsets_sub(c, Tb, nsub, blk_super, out_start, F0, D, nstart, n);
+        {
+            const int ps = c.prof_begin(K_RS_SCATTER_U64, (u64)n * (2 * (4 + 8 * KW) + 2));
+            if (last) ws_scatter_kernel<KW, false, true><<<grid, 256, 0, s>>>(P, g, rows);
+            else ws_scatter_kernel<KW, false, false><<<grid, 256, 0, s>>>(P, g, rows);
+            LAUNCH_CHECK();
+            c.prof_end(ps);
+        }
+        c.arena.release(lm2);
+        seg_start = nstart;
+        nseg = F0 * D;
+        cur = 1;
+        K1 = const_cast<u64**>(pre->K1); K2 = const_cast<u64**>(pre->K2); V = const_cast<u32**>(pre->V);
+    }
+    for (int l = pre ? 2 : 0; l < L; ++l) {
         const bool last = (l == L - 1);
         const bool gl = GEN && l == 0;
         const u32 D = last ? 2 * pl.F[l] : pl.F[l];
@@ -1089,11 +1232,15 @@ int ws_sort_impl(Ctx& c, const WKeyGen* gen, u64* K1[2], u64* K2[2], u32* V[2], 
         SegTables Tb;
         ss_level_tables(c, seg_start, nseg, n, D, Tb);
         WSLevel P;
-        P.k1_in = cur >= 0 ? K1[cur] : nullptr; P.k2_in = (cur >= 0 && KW == 2) ? K2[cur] : nullptr; P.v_in = cur >= 0 ? V[cur] : nullptr;
+        P.k1_in = cur >= 0 ? K1[cur] : nullptr; P.k2_in = (cur >= 0 && KW == 2) ? K2[cur] : nullptr;
+        P.v_in = pre ? Vlast : (cur >= 0 ? V[cur] : nullptr);
         const int nxt = cur < 0 ? 0 : (cur ^ 1);
-        P.k1_out = K1[nxt]; P.k2_out = KW == 2 ? K2[nxt] : nullptr; P.v_out = V[nxt];
+        P.k1_out = K1[nxt]; P.k2_out = KW == 2 ? K2[nxt] : nullptr;
+        P.v_out = (pre && last) ? v_final : V[nxt];
+        Vlast = P.v_out;
         P.digits = digits;
         P.counts = Tb.counts; P.blk_seg = Tb.blk_seg; P.blk_start = Tb.blk_start; P.seg_start = seg_start; P.sp1 = sp1; P.sp2 = sp2;
+        P.seg_end = seg_start + 1; P.sub = 1;
         P.nseg = nseg; P.F = pl.F[l]; P.stride = stride; P.R = Tb.R; P.D = D;
         P.gen_off = 0; P.gen_len = n;
         const u32 rows = Tb.rows;
@@ -1132,7 +1279,7 @@ int ws_sort_impl(Ctx& c, const WKeyGen* gen, u64* K1[2], u64* K2[2], u32* V[2], 
     const u32 nlarge = U.hc[0];
     st->units = U.hc[1]; st->large_leaves = nlarge;
     WLeaf A;
-    A.k1 = K1[cur]; A.k2 = KW == 2 ? K2[cur] : nullptr; A.v = V[cur]; A.unit_rng = U.unit_rng; A.flags = flags; A.lcp = lcp8;
+    A.k1 = K1[cur]; A.k2 = KW == 2 ? K2[cur] : nullptr; A.v = Vlast; A.unit_rng = U.unit_rng; A.flags = flags; A.lcp = lcp8;
     A.d_err = c.d_err; A.inv = g.b ? (65536u + (u32)g.b - 1) / (u32)g.b : 65536u;
     A.cmax = c.wsort_small ? 1u : (c.wsort_cmax < 1 ? 1u : (c.wsort_cmax > (int)WS_CMAX ? WS_CMAX : (u32)c.wsort_cmax));
     {
@@ -1143,21 +1290,23 @@ int ws_sort_impl(Ctx& c, const WKeyGen* gen, u64* K1[2], u64* K2[2], u32* V[2], 
         const u32* cur_cls = U.cls_list;
         size_t cur_cap = U.cap;
         u32 cur_cnt[4] = { U.hc[2], U.hc[3], U.hc[4], U.hc[5] };
-        u32 wave_cnt = 0;                                        // runs for the wave kernel (class 0 of the previous stage's hand-over)
+        u32 wave_cnt[4] = { 0, 0, 0, 0 };                        // runs for the lane / wave kernels (classes 0 .. 3 of the previous stage's hand-over)
         const u32* wave_list = nullptr;
         const u32 ediv = A.cmax + 1;                            // a run that is handed on has more than cmax members
         const u32 ecap2 = (u32)(n / ediv + 2);
         u32* e_rng[2] = { c.arena.get<u32>(2 * (size_t)ecap2), c.arena.get<u32>(2 * (size_t)ecap2) };
-        u32* e_cls[2] = { c.arena.get<u32>(5 * (size_t)ecap2), c.arena.get<u32>(5 * (size_t)ecap2) };
-        u32* lc = c.arena.get<u32>(16);                          // [0..7]: per class |rlist|, |tlist|; [8..12]: next stage's units, per class
+        u32* e_cls[2] = { c.arena.get<u32>(EC_NCLS * (size_t)ecap2), c.arena.get<u32>(EC_NCLS * (size_t)ecap2) };
+        u32* lc = c.arena.get<u32>(16);                          // [0..7]: per class |rlist|, |tlist|; [8..15]: next stage's units per class
         for (int stage = 0; stage < 8; ++stage) {
-            if (wave_cnt) {
+            if (wave_cnt[0] | wave_cnt[1] | wave_cnt[2] | wave_cnt[3]) {
                 A.unit_rng = cur_rng;
-                if (PAIRS) ws_run_wave_kernel<true><<<cdiv(wave_cnt, 4), 256, 0, s>>>(A, wave_list, wave_cnt);
-                else ws_run_wave_kernel<false><<<cdiv(wave_cnt, 4), 256, 0, s>>>(A, wave_list, wave_cnt);
-                LAUNCH_CHECK();
-                st->wave_runs += wave_cnt;
-                wave_cnt = 0;
+                const u32* l0 = wave_list, *l1 = wave_list + cur_cap, *l2 = wave_list + 2 * cur_cap, *l3 = wave_list + 3 * cur_cap;
+                if (wave_cnt[0]) { ws_run_lane_kernel<32, PAIRS><<<cdiv(wave_cnt[0], 8), 256, 0, s>>>(A, l0, wave_cnt[0]); LAUNCH_CHECK(); }
+                if (wave_cnt[1]) { ws_run_lane_kernel<64, PAIRS><<<cdiv(wave_cnt[1], 4), 256, 0, s>>>(A, l1, wave_cnt[1]); LAUNCH_CHECK(); }
+                if (wave_cnt[2]) { ws_run_wave_kernel<256, PAIRS><<<cdiv(wave_cnt[2], 4), 256, 0, s>>>(A, l2, wave_cnt[2]); LAUNCH_CHECK(); }
+                if (wave_cnt[3]) { ws_run_wave_kernel<1024, PAIRS><<<cdiv(wave_cnt[3], 4), 256, 0, s>>>(A, l3, wave_cnt[3]); LAUNCH_CHECK(); }
+                st->wave_runs += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+                wave_cnt[0] = wave_cnt[1] = wave_cnt[2] = wave_cnt[3] = 0;
             }
             if (!(cur_cnt[0] | cur_cnt[1] | cur_cnt[2] | cur_cnt[3])) break;
             if (stage == 7) throw HipError{hipErrorUnknown, "wide splitter sort: leaf stages did not converge", (int)__LINE__};
@@ -1210,17 +1359,16 @@ int ws_sort_impl(Ctx& c, const WKeyGen* gen, u64* K1[2], u64* K2[2], u32* V[2], 
             }
             ws_emit_compact_kernel<<<cdiv(ecap2, EC_TILE), 256, 0, s>>>(e_rng[stage & 1], ecap2, e_cls[stage & 1], ecap2, lc + 8);
             LAUNCH_CHECK();
-            u32 he[6];
-            c.read_n(lc + 8, he, 6);
-            he[0] = he[1] + he[2] + he[3] + he[4] + he[5];
+            u32 he[EC_NCLS];
+            c.read_n(lc + 8, he, EC_NCLS);
             if (getenv("TDC_GPU_WSORT_LOG"))
-                fprintf(stderr, "[wsort] n=%zu stage %d: units %u %u %u %u | r/t lists %u/%u %u/%u %u/%u %u/%u | handed on %u (wave %u | %u %u %u %u)\n", n, stage,
-                        cur_cnt[0], cur_cnt[1], cur_cnt[2], cur_cnt[3], hl[0], hl[1], hl[2], hl[3], hl[4], hl[5], hl[6], hl[7], he[0], he[1], he[2], he[3], he[4], he[5]);
+                fprintf(stderr, "[wsort] n=%zu stage %d: units %u %u %u %u | r/t lists %u/%u %u/%u %u/%u %u/%u | handed on: lane %u %u wave %u %u block %u %u %u %u\n", n, stage,
+                        cur_cnt[0], cur_cnt[1], cur_cnt[2], cur_cnt[3], hl[0], hl[1], hl[2], hl[3], hl[4], hl[5], hl[6], hl[7], he[0], he[1], he[2], he[3], he[4], he[5], he[6], he[7]);
             c.arena.release(lm3);
-            st->longrun_units += he[0];
-            cur_rng = e_rng[stage & 1]; cur_cls = e_cls[stage & 1] + ecap2; cur_cap = ecap2;
-            wave_list = e_cls[stage & 1]; wave_cnt = he[1];
-            for (int q = 0; q < 4; ++q) cur_cnt[q] = he[2 + q];
+            for (int q = 0; q < EC_NCLS; ++q) st->longrun_units += he[q];
+            cur_rng = e_rng[stage & 1]; cur_cls = e_cls[stage & 1] + 4 * (size_t)ecap2; cur_cap = ecap2;
+            wave_list = e_cls[stage & 1];
+            for (int q = 0; q < 4; ++q) { wave_cnt[q] = he[q]; cur_cnt[q] = he[4 + q]; }
             st->leaf_stages = (u32)stage + 1;
         }
     }
@@ -1234,7 +1382,7 @@ int ws_sort_impl(Ctx& c, const WKeyGen* gen, u64* K1[2], u64* K2[2], u32* V[2], 
             const size_t a = ls[ll[i]], b = ls[ll[i] + 1];
             u64* kk1[2] = { K1[cur] + a, K1[cur ^ 1] + a };
             u64* kk2[2] = { KW == 2 ? K2[cur] + a : nullptr, KW == 2 ? K2[cur ^ 1] + a : nullptr };
-            u32* vv[2] = { V[cur] + a, V[cur ^ 1] + a };
+            u32* vv[2] = { Vlast + a, V[cur ^ 1] + a };
             ws_lsd_sort_wide(c, kk1, KW == 2 ? kk2 : nullptr, vv, b - a, 64);
             HIP_TRY(hipMemcpyAsync(kk1[0], kk1[1], (b - a) * sizeof(u64), hipMemcpyDeviceToDevice, s));
             if (KW == 2) HIP_TRY(hipMemcpyAsync(kk2[0], kk2[1], (b - a) * sizeof(u64), hipMemcpyDeviceToDevice, s));
@@ -1247,7 +1395,7 @@ int ws_sort_impl(Ctx& c, const WKeyGen* gen, u64* K1[2], u64* K2[2], u32* V[2], 
         }
     }
     if (!PAIRS) {
-        ws_fix_kernel<KW><<<cdiv(nleaf, 256), 256, 0, s>>>(leaf_start, nleaf, V[cur], g, flags, lcp8);
+        ws_fix_kernel<KW><<<cdiv(nleaf, 256), 256, 0, s>>>(leaf_start, nleaf, Vlast, g, flags, lcp8);
         LAUNCH_CHECK();
         { unsigned gq = cdiv(n, 256 * 16); if (gq > 4096) gq = 4096; ws_count_flags_kernel<<<gq, 256, 0, s>>>(flags, n, d_nonheads); }
         LAUNCH_CHECK();
@@ -1266,6 +1414,104 @@ int wsort_suffixes(Ctx& c, int KW, const WKeyGen& g, u64* K1[2], u64* K2[2], u32
     *st = WSortStats();
     if (KW == 2) return ws_sort_impl<2, true, false>(c, &g, K1, K2, V, n, 64, flags, lcp8, st);
     return ws_sort_impl<1, true, false>(c, &g, K1, K2, V, n, 64, flags, lcp8, st);
+}
+
+void wsort_suffixes_pre(Ctx& c, const WPre& P, u32* v_final, u8* flags, u8* lcp8, WSortStats* st) {
+    WSortStats local;
+    if (!st) st = &local;
+    *st = WSortStats();
+    u64* K1[2] = { P.K1[0], P.K1[1] }; u64* K2[2] = { P.K2[0], P.K2[1] }; u32* V[2] = { P.V[0], P.V[1] };
+    if (P.KW == 2) (void)ws_sort_impl<2, true, false>(c, &P.g, K1, K2, V, P.n, 64, flags, lcp8, st, &P, v_final);
+    else (void)ws_sort_impl<1, true, false>(c, &P.g, K1, K2, V, P.n, 64, flags, lcp8, st, &P, v_final);
+}
+
+bool wsort_pre_begin(Ctx& c, WPre& P, const u8* text, size_t n, size_t chunk_len, u32 nchunks, const u32* hist0) {
+    P = WPre();
+    if (!c.wsort_overlap || !wsort_applicable(c, n) || nchunks < 2 || (chunk_len % WS_TILE) != 0 || chunk_len < ((size_t)1 << 22)) return false;
+    // provisional code map: the sentinel and the byte values of chunk 0, dense and in byte order
+    u8 code[256];
+    u32 sigma = 0;
+    for (int i = 0; i < 256; ++i) {
+        code[i] = (u8)sigma;
+        if (i == 0 || hist0[i]) { ++sigma; P.present[i >> 5] |= 1u << (i & 31); }
+    }
+    P.text = text; P.n = n; P.chunk_len = chunk_len; P.nchunks = nchunks;
+    wsort_make_keygen(c, text, n, sigma, code, P.KW, P.g);
+    ss_fanouts(c, n, P.L, P.F, P.os);
+    if (P.L < 2) return false;
+    P.NLr = P.F[0] * P.F[1] * P.F[2]; P.NS = P.NLr - 1; P.S = P.os * P.NLr;
+    Arena& A = c.arena;
+    P.K1[0] = A.get_top<u64>(n); P.K1[1] = A.get_top<u64>(n);
+    if (P.KW == 2) { P.K2[0] = A.get_top<u64>(n); P.K2[1] = A.get_top<u64>(n); }
+    P.V[0] = A.get_top<u32>(n); P.V[1] = A.get_top<u32>(n);
+    P.digits = A.get_top<u16>(align_up(n, WS_TILE) + WS_TILE);
+    P.sp1 = A.get_top<u64>((size_t)P.NS + 1);
+    P.sp2 = P.KW == 2 ? A.get_top<u64>((size_t)P.NS + 1) : nullptr;
+    P.nstart_all = A.get_top<u32>((size_t)nchunks * (P.F[0] + 1));
+    // splitters from a sample of chunk 0 (a key reads up to 64 bytes ahead: chunk 1 need not be there)
+    WPlan pl;
+    pl.L = P.L; pl.F[0] = P.F[0]; pl.F[1] = P.F[1]; pl.F[2] = P.F[2]; pl.os = P.os; pl.NLr = P.NLr; pl.NS = P.NS; pl.S = P.S;
+    const size_t n_sample = chunk_len - 64;
+    if (P.KW == 2) ws_splitters<2, true>(c, pl, nullptr, nullptr, P.g, n_sample, P.sp1, P.sp2);
+    else ws_splitters<1, true>(c, pl, nullptr, nullptr, P.g, n_sample, P.sp1, nullptr);
+    P.begun = true;
+    return true;
+}
+
+void wsort_pre_chunk(Ctx& c, WPre& P, u32 q) {
+    if (!P.begun) return;
+    hipStream_t s = c.stream;
+    const size_t off = (size_t)q * P.chunk_len;
+    if (off >= P.n) {                                          // (more chunks than text: an empty part)
+        ws_set2_kernel<<<1, 1, 0, s>>>(P.nstart_all + (size_t)q * (P.F[0] + 1), (u32)P.n, (u32)P.n);
+        return;
+    }
+    const size_t len = std::min(P.chunk_len, P.n - off);
+    const size_t mark = c.arena.mark();
+    u32* seg2 = c.arena.get<u32>(2);
+    ws_set2_kernel<<<1, 1, 0, s>>>(seg2, (u32)off, (u32)(off + len));
+    LAUNCH_CHECK();
+    const u32 D = P.F[0];
+    SegTables Tb;
+    ss_level_tables(c, seg2, 1, len, D, Tb);
+    WSLevel Lv;
+    Lv.k1_in = nullptr; Lv.k2_in = nullptr; Lv.v_in = nullptr;
+    Lv.k1_out = P.K1[0]; Lv.k2_out = P.KW == 2 ? P.K2[0] : nullptr; Lv.v_out = P.V[0];
+    Lv.digits = P.digits;
+    Lv.counts = Tb.counts; Lv.blk_seg = Tb.blk_seg; Lv.blk_start = Tb.blk_start; Lv.seg_start = seg2; Lv.seg_end = seg2 + 1; Lv.sub = 1;
+    Lv.sp1 = P.sp1; Lv.sp2 = P.sp2;
+    Lv.nseg = 1; Lv.F = P.F[0]; Lv.stride = P.F[1] * P.F[2]; Lv.R = Tb.R; Lv.D = D;
+    Lv.gen_off = 0; Lv.gen_len = P.n;
+    const u32 rows = Tb.rows;
+    Lv.per_xcd = (c.xcd_remap == 1 && rows >= 64) ? cdiv(rows, 8) : 0u;
+    const u32 grid = Lv.per_xcd ? 8 * Lv.per_xcd : rows;
+    {
+        const int pc = c.prof_begin(K_RS_COUNT, (u64)len);
+        if (P.KW == 2) ws_count_kernel<2, true, false><<<grid, 256, 0, s>>>(Lv, P.g, rows);
+        else ws_count_kernel<1, true, false><<<grid, 256, 0, s>>>(Lv, P.g, rows);
+        LAUNCH_CHECK();
+        c.prof_end(pc);
+    }
+    ss_level_offsets(c, Tb, seg2, 1, D, P.nstart_all + (size_t)q * (P.F[0] + 1), off + len);
+    {
+        const int ps = c.prof_begin(K_RS_SCATTER_U64, (u64)len * (3 + 4 + 8 * P.KW));
+        if (P.KW == 2) ws_scatter_kernel<2, true, false><<<grid, 256, 0, s>>>(Lv, P.g, rows);
+        else ws_scatter_kernel<1, true, false><<<grid, 256, 0, s>>>(Lv, P.g, rows);
+        LAUNCH_CHECK();
+        c.prof_end(ps);
+    }
+    c.arena.release(mark);
+}
+
+void wsort_pre_finish(Ctx& c, WPre& P, const u32* hist_full) {
+    (void)c;
+    P.active = false;
+    if (!P.begun) return;
+    for (int i = 1; i < 256; ++i) {
+        const bool in_map = (P.present[i >> 5] >> (i & 31)) & 1u;
+        if ((hist_full[i] != 0) != in_map) return;            // a byte value chunk 0 did not show (or the reverse): the keys are worthless
+    }
+    P.active = true;
 }
 
 int wsort_records(Ctx& c, u64* K1[2], u64* K2[2], u32* V[2], size_t m, int k1_bits, WSortStats* st) {
