@@ -53,7 +53,10 @@ namespace {
 #endif
 constexpr int TW = TDC_WIN_TW;       // window positions (a multiple of 64)
 constexpr int TH_MAX = 2048;         // halo on either side: a run-time value (multiple of 4), at most this
-constexpr int TT = 256;              // threads per workgroup
+#ifndef TDC_WIN_TT
+#define TDC_WIN_TT 256
+#endif
+constexpr int TT = TDC_WIN_TT;       // threads per workgroup (the first TW / 64 of them own a 64-position chunk of the window: TT >= TW / 64)
 constexpr int TCH = 64;              // consecutive window positions per thread in the dense passes (the first TW / 64 threads own a chunk)
 constexpr int NWV = TT / 64;
 // Two sizes of the per-level LDS lists (alive entries / pushes per level and window).  The small one leaves 40 KB of LDS
@@ -512,7 +515,7 @@ int factorize_window_levels(Ctx& c, size_t n, const u32* cur, const u32* prio, c
     if (halo < 2 * lcut + 64) halo = (2 * lcut + 64 + 3) & ~3u;
     if (halo > (u32)TH_MAX) halo = TH_MAX;
     bool large = c.window_large_lists != 0 || start_large;
-    const u32 max_grid = 512u * TDC_WIN_WPE;     // two rounds of resident workgroups
+    const u32 max_grid = 512u * TDC_WIN_WPE * (256 / TT);     // two rounds of resident workgroups
     u32* lprio = c.arena.get<u32>((size_t)max_grid * TW);
     WinScalars* d_sc = (WinScalars*)c.arena.alloc(sizeof(WinScalars));
     WinScalars h;

@@ -67,8 +67,14 @@ __global__ __launch_bounds__(256) void fs_count_kernel(FSLevel P, u32 rows) {
 // FIRST: record j of the input is (sa[j + 1], j + 1, sa[j], lcp8[j + 1]) -- idx_in = sa + 1, prev_in = sa, lcp_in = lcp8 + 1, the rank
 // is the index.  The tile is written stream by stream, each staged in LDS in bucket order first (whole runs per bucket leave as
 // consecutive words).
+#ifndef TDC_FS_WPE
+#define TDC_FS_WPE 4
+#endif
+#ifndef TDC_FS_PRELOAD
+#define TDC_FS_PRELOAD 1
+#endif
 template <int DB, bool FIRST>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void fs_scatter_kernel(FSLevel P, u32 rows) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TDC_FS_WPE, TDC_FS_WPE))) void fs_scatter_kernel(FSLevel P, u32 rows) {
     constexpr u32 D = 1u << DB;
     __shared__ u32 tcnt[D];
     __shared__ u32 gbase[D];
@@ -86,6 +92,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     u32 k[FS_ITEMS], pos[FS_ITEMS];
 #pragma unroll
     for (int j = 0; j < FS_ITEMS; ++j) k[j] = (lb + (u32)j * 64 < cnt) ? ip[j * 64] : 0u;
+#if TDC_FS_PRELOAD
+    // every stream of the thread's records is requested up front: the staging phases below then never wait for global memory
+    u32 rk[FS_ITEMS], pv[FS_ITEMS], lc[FS_ITEMS];
+#pragma unroll
+    for (int j = 0; j < FS_ITEMS; ++j) {
+        const u32 e = lb + (u32)j * 64;
+        const bool valid = e < cnt;
+        rk[j] = FIRST ? (u32)(base + e + 1) : (valid ? P.rank_in[base + e] : 0u);
+        pv[j] = valid ? P.prev_in[base + e] : 0u;
+        lc[j] = valid ? (u32)P.lcp_in[base + e] : 0u;
+    }
+#endif
 #pragma unroll
     for (int j = 0; j < FS_ITEMS; ++j) {
         const bool valid = lb + (u32)j * 64 < cnt;
@@ -137,7 +155,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
     for (int j = 0; j < FS_ITEMS; ++j) {
         const u32 e = lb + (u32)j * 64;
+#if TDC_FS_PRELOAD
+        if (e < cnt) stage[pos[j]] = rk[j];
+#else
         if (e < cnt) stage[pos[j]] = FIRST ? (u32)(base + e + 1) : P.rank_in[base + e];
+#endif
     }
     __syncthreads();
 #pragma unroll
@@ -147,7 +169,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
     for (int j = 0; j < FS_ITEMS; ++j) {
         const u32 e = lb + (u32)j * 64;
+#if TDC_FS_PRELOAD
+        if (e < cnt) stage[pos[j]] = pv[j];
+#else
         if (e < cnt) stage[pos[j]] = P.prev_in[base + e];
+#endif
     }
     __syncthreads();
 #pragma unroll
@@ -158,7 +184,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
     for (int j = 0; j < FS_ITEMS; ++j) {
         const u32 e = lb + (u32)j * 64;
+#if TDC_FS_PRELOAD
+        if (e < cnt) stage8[pos[j]] = (u8)lc[j];
+#else
         if (e < cnt) stage8[pos[j]] = P.lcp_in[base + e];
+#endif
     }
     __syncthreads();
 #pragma unroll

@@ -1273,12 +1273,13 @@ void ss_build_units(Ctx& c, const u32* leaf_start, u32 nleaf, UnitTables& U, u32
     LAUNCH_CHECK();
     c.read_n(U.large, U.hc, 6);
 }
-void ss_fanouts(Ctx& c, size_t n, int& L, u32 F[3], u32& os) {
+void ss_fanouts(Ctx& c, size_t n, int& L, u32 F[3], u32& os, u32 leaf3) {
     L = n <= (size_t)256 * 3072 ? 1 : ((n + 65535) / 65536 <= 4352 ? 2 : 3);
     if (c.ssort_levels >= 1 && c.ssort_levels <= 3) L = c.ssort_levels;
     F[0] = F[1] = F[2] = 1;
+    if (leaf3 == 0) leaf3 = 2048;                              // target leaf size with three levels
     const u32 cap = L == 1 ? 256u : (L == 2 ? 65536u : (1u << 24));
-    u32 nl = pow2_ceil((n + (L == 3 ? 2047 : 3071)) / (L == 3 ? 2048 : 3072));
+    u32 nl = pow2_ceil((n + (L == 3 ? leaf3 - 1 : 3071)) / (L == 3 ? leaf3 : 3072));
     if (nl > cap) nl = cap;
     if (nl < (2u << (L - 1))) nl = 2u << (L - 1);
     const u32 lastF = nl > 256 ? 256u : (L == 1 ? nl : nl >> (L - 1));

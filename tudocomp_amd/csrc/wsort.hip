@@ -457,24 +457,6 @@ __device__ __forceinline__ u32 wl_rank(u32 d, bool valid, u32* mycnt, unsigned l
     if (valid && rank == 0) lds_store(&mycnt[d], prefix + (u32)__popcll(peers));
     return prefix + rank;
 }
-__device__ __forceinline__ void wl_digit_starts(u32 (*wcnt)[256], int lane) {
-    uint4 cc[WL_NW];
-    u32 t0 = 0, t1 = 0, t2 = 0, t3 = 0;
-#pragma unroll
-    for (int i = 0; i < WL_NW; ++i) {
-        cc[i] = *(const uint4*)&wcnt[i][4 * lane];
-        t0 += cc[i].x; t1 += cc[i].y; t2 += cc[i].z; t3 += cc[i].w;
-    }
-    const u32 sum = t0 + t1 + t2 + t3;
-    u32 r0 = wave_inclusive_sum(sum) - sum;
-    u32 r1 = r0 + t0, r2 = r1 + t1, r3 = r2 + t2;
-#pragma unroll
-    for (int i = 0; i < WL_NW; ++i) {
-        *(uint4*)&wcnt[i][4 * lane] = make_uint4(r0, r1, r2, r3);
-        r0 += cc[i].x; r1 += cc[i].y; r2 += cc[i].z; r3 += cc[i].w;
-    }
-}
-
 // A "unit" is a slot range [unit_rng[2u], unit_rng[2u + 1]) of at most 8192 records.  Stage 0: the units of ss_build_units (whole
 // leaves).  Later stages: long runs of tying records that the counting kernel handed back (see ws_leaf_count_kernel).
 struct WLeaf {
@@ -496,45 +478,59 @@ struct WEmit {          // the counting kernel: long runs become units of the ne
     u32 div;            // no two runs share an entry -- no atomics; empty entries are (0, 0).  ws_emit_compact_kernel lists them by class
 };
 
-template <int ROWS>
+template <int ROWS, int NW = WL_NW>
 struct WLState {
-    u32 (*wcnt)[256]; u64* stage;
+    u32 (*wcnt)[256]; u32 (*wst)[256]; unsigned long long (*wm)[256]; u64* stage;
     u32 m, wbase;
     int lane, w;
 };
 
-// stable LSD sort of the unit's words by the bits [shift0, shift0 + nb); on return k[j] = word at slot wbase + 64 j, stage[] = all words
-template <int ROWS>
-__device__ __forceinline__ void wl_lsd(const WLState<ROWS>& T, u64 (&k)[ROWS], int shift0, int nb) {
+// Stable LSD sort of the unit's words by the bits [shift0, shift0 + nb); on return k[j] = word at slot wbase + 64 j.
+// Two workgroup barriers per pass (ssort.hip needs four): every wave derives the starts of ITS (wave, digit) runs from all waves'
+// counters by itself (eight 16-byte loads per lane) instead of waiting for wave 0 to do it for everybody, and the match tables of
+// the ranking have an LDS area of their own, so the ranks of the next pass may be taken while other waves still read the staging buffer.
+template <int ROWS, int NW>
+__device__ __forceinline__ void wl_lsd(const WLState<ROWS, NW>& T, u64 (&k)[ROWS], int shift0, int nb) {
     u32* mycnt = T.wcnt[T.w];
-    unsigned long long* M = (unsigned long long*)T.stage + T.w * 256;
+    u32* myst = T.wst[T.w];
+    unsigned long long* M = T.wm[T.w];
     const u64 lanebit = 1ull << T.lane;
     const u64 lt_mask = (T.lane == 0) ? 0ull : (~0ull >> (64 - T.lane));
-    for (int i = T.lane; i < 256; i += 64) mycnt[i] = 0;
+    for (int i = T.lane; i < 256; i += 64) { mycnt[i] = 0; M[i] = 0; }
     u32 loc[ROWS];
     for (int shift = shift0; shift < shift0 + nb; shift += 8) {
-        for (int i = T.lane; i < 256; i += 64) M[i] = 0;
 #pragma unroll
         for (int j = 0; j < ROWS; ++j) {
             loc[j] = wl_rank((u32)(k[j] >> shift) & 255u, T.wbase + (u32)j * 64 < T.m, mycnt, M, lanebit, lt_mask);
-            if ((j & (ROWS >= 12 ? 1 : 3)) == (ROWS >= 12 ? 1 : 3)) __builtin_amdgcn_sched_barrier(0);   // (overlap the LDS operations of a few rows, not of all: registers)
+            if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // (overlap the LDS operations of a few rows, not of all: registers)
         }
         __syncthreads();
-        if (T.w == 0) wl_digit_starts(T.wcnt, T.lane);
-        __syncthreads();
+        {   // starts of this wave's runs: lane l owns the digits 4l .. 4l+3
+            u32 t0 = 0, t1 = 0, t2 = 0, t3 = 0, p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                const uint4 cc = *(const uint4*)&T.wcnt[i][4 * T.lane];
+                if (i < T.w) { p0 += cc.x; p1 += cc.y; p2 += cc.z; p3 += cc.w; }
+                t0 += cc.x; t1 += cc.y; t2 += cc.z; t3 += cc.w;
+            }
+            const u32 sum = t0 + t1 + t2 + t3;
+            const u32 r0 = wave_inclusive_sum(sum) - sum;
+            *(uint4*)&myst[4 * T.lane] = make_uint4(r0 + p0, r0 + t0 + p1, r0 + t0 + t1 + p2, r0 + t0 + t1 + t2 + p3);
+        }
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int j = 0; j < ROWS; ++j)
-            if (T.wbase + (u32)j * 64 < T.m) T.stage[loc[j] + mycnt[(u32)(k[j] >> shift) & 255u]] = k[j];
-        for (int i = T.lane; i < 256; i += 64) mycnt[i] = 0;
+            if (T.wbase + (u32)j * 64 < T.m) T.stage[loc[j] + lds_load(&myst[(u32)(k[j] >> shift) & 255u])] = k[j];
         __syncthreads();
+        for (int i = T.lane; i < 256; i += 64) mycnt[i] = 0;    // (every wave has read the counters: they did so before their scatter)
 #pragma unroll
         for (int j = 0; j < ROWS; ++j) if (T.wbase + (u32)j * 64 < T.m) k[j] = T.stage[T.wbase + (u32)j * 64];
-        __syncthreads();
     }
+    __syncthreads();                                            // (callers reuse the staging buffer)
 }
 
-template <int ROWS>
-__device__ __forceinline__ void wl_minmax(u64 (*red)[WL_NW], const u64 (&k)[ROWS], u32 m, u32 wbase, int lane, int w, u64& kmin, u64& kmax) {
+template <int ROWS, int NW>
+__device__ __forceinline__ void wl_minmax(u64 (*red)[NW], const u64 (&k)[ROWS], u32 m, u32 wbase, int lane, int w, u64& kmin, u64& kmax) {
     kmin = ~0ull; kmax = 0;
 #pragma unroll
     for (int j = 0; j < ROWS; ++j)
@@ -548,7 +544,7 @@ __device__ __forceinline__ void wl_minmax(u64 (*red)[WL_NW], const u64 (&k)[ROWS
     __syncthreads();
     kmin = red[0][0]; kmax = red[1][0];
 #pragma unroll
-    for (int i = 1; i < WL_NW; ++i) { kmin = red[0][i] < kmin ? red[0][i] : kmin; kmax = red[1][i] > kmax ? red[1][i] : kmax; }
+    for (int i = 1; i < NW; ++i) { kmin = red[0][i] < kmin ? red[0][i] : kmin; kmax = red[1][i] > kmax ? red[1][i] : kmax; }
     __syncthreads();
 }
 
@@ -560,12 +556,14 @@ __device__ __forceinline__ void wl_minmax(u64 (*red)[WL_NW], const u64 (&k)[ROWS
 // with its predecessor; X and k2 in the same order where a later kernel (or the caller: PAIRS) reads them.  Units with runs left go
 // to `rlist` (ties on the whole of k1: to be ordered by k2) or `tlist` (ties on a truncated word: to be ordered by the word itself
 // first); the counting kernel takes them from there.
-template <int KW, int ROWS, bool PAIRS>
-__global__ __launch_bounds__(WL_NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void ws_leaf_sort_kernel(WLeaf A, const u32* __restrict__ list, u32 count, WLists Q) {
-    constexpr u32 CAP = (u32)ROWS * WL_NW * 64;
-    __shared__ __align__(16) u32 wcnt[WL_NW][256];
+template <int KW, int ROWS, int NW, bool PAIRS>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void ws_leaf_sort_kernel(WLeaf A, const u32* __restrict__ list, u32 count, WLists Q) {
+    constexpr u32 CAP = (u32)ROWS * NW * 64;
+    __shared__ __align__(16) u32 wcnt[NW][256];
+    __shared__ __align__(16) u32 wst[NW][256];
+    __shared__ unsigned long long wm[NW][256];
     __shared__ __align__(16) u64 stage[CAP];
-    __shared__ u64 red[2][WL_NW];
+    __shared__ u64 red[2][NW];
     __shared__ u32 s_any;
     if (blockIdx.x >= count) return;
     const u32 u = list[blockIdx.x];
@@ -578,8 +576,8 @@ __global__ __launch_bounds__(WL_NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4
     if (threadIdx.x == 0) { A.flags[a] = 1; s_any = 0; }      // a unit starts at a leaf start / run start
     if (m == 1) return;
     const int lane = lane_id(), w = wave_id();
-    WLState<ROWS> T;
-    T.wcnt = wcnt; T.stage = stage;
+    WLState<ROWS, NW> T;
+    T.wcnt = wcnt; T.wst = wst; T.wm = wm; T.stage = stage;
     T.m = m; T.wbase = (u32)w * ROWS * 64 + (u32)lane; T.lane = lane; T.w = w;
     const u32 wbase = T.wbase;
     u64* K1 = A.k1 + a;
@@ -590,14 +588,14 @@ __global__ __launch_bounds__(WL_NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4
     if (!known_pure) {                                          // (the k1 slots of such a run were never brought into sorted order)
 #pragma unroll
         for (int j = 0; j < ROWS; ++j) { const u32 L = wbase + (u32)j * 64; c[j] = (L < m) ? K1[L] : 0ull; }
-        wl_minmax<ROWS>(red, c, m, wbase, lane, w, kmin, kmax);
+        wl_minmax<ROWS, NW>(red, c, m, wbase, lane, w, kmin, kmax);
     }
     bool pure = false;
     if (kmin == kmax) {
         if (KW == 1) return;                                    // one group: nothing moves
 #pragma unroll
         for (int j = 0; j < ROWS; ++j) { const u32 L = wbase + (u32)j * 64; c[j] = (L < m) ? K2[L] : 0ull; }
-        wl_minmax<ROWS>(red, c, m, wbase, lane, w, kmin, kmax);
+        wl_minmax<ROWS, NW>(red, c, m, wbase, lane, w, kmin, kmax);
         pure = true;
         if (kmin == kmax) return;
     }
@@ -608,7 +606,7 @@ __global__ __launch_bounds__(WL_NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4
     const u64 cmask = (1ull << nb) - 1;
 #pragma unroll
     for (int j = 0; j < ROWS; ++j) c[j] = (((c[j] >> sh) & cmask) << 13) | (u64)(wbase + (u32)j * 64);
-    wl_lsd<ROWS>(T, c, 13, nb);
+    wl_lsd<ROWS, NW>(T, c, 13, nb);
     // heads, LCPs
     const u32 base_bits = pure ? 64u : 0u;
     bool anyrun = false;
@@ -697,10 +695,10 @@ __device__ __forceinline__ u32 wl_run_end(const u64* hb, u32 s) {
     while (!y) y = hb[++wi];
     return wi * 64 + (u32)__builtin_ctzll(y);
 }
-template <int ROWS, bool PAIRS>
-__global__ __launch_bounds__(WL_NW * 64) void ws_leaf_count_kernel(WLeaf A, const u32* __restrict__ list, u32 count, u32 want_mask, u32 want_value,
-                                                                    WCount R, WEmit E) {
-    constexpr u32 CAP = (u32)ROWS * WL_NW * 64;
+template <int ROWS, int NW, bool PAIRS>
+__global__ __launch_bounds__(NW * 64) void ws_leaf_count_kernel(WLeaf A, const u32* __restrict__ list, u32 count, u32 want_mask, u32 want_value,
+                                                                WCount R, WEmit E) {
+    constexpr u32 CAP = (u32)ROWS * NW * 64;
     __shared__ u64 Wl[CAP];
     __shared__ u32 P32[CAP];
     __shared__ u8 hf[CAP];
@@ -723,7 +721,7 @@ __global__ __launch_bounds__(WL_NW * 64) void ws_leaf_count_kernel(WLeaf A, cons
         const u64 bm = __ballot(h || L == m);
         if (lane == 0) hb[w * ROWS + j] = bm;
     }
-    if (threadIdx.x == 0) hb[ROWS * WL_NW] = (m == CAP) ? 1ull : 0ull;
+    if (threadIdx.x == 0) hb[ROWS * NW] = (m == CAP) ? 1ull : 0ull;
     __syncthreads();
 #pragma unroll 1
     for (int j = 0; j < ROWS; ++j) {
@@ -1087,7 +1085,7 @@ void wsort_make_keygen(const Ctx& c, const u8* text, size_t n, u32 sigma, const 
 bool wsort_applicable(const Ctx& c, size_t n) { return c.wsort && n >= c.wsort_min && n < ((size_t)1 << 32); }
 int wsort_result_index(Ctx& c, size_t n) {                    // index of the V buffer that will hold wsort_suffixes' result
     int L; u32 F[3], os;
-    ss_fanouts(c, n, L, F, os);
+    ss_fanouts(c, n, L, F, os, (u32)c.wsort_leaf);
     return (L - 1) & 1;
 }
 
@@ -1133,7 +1131,7 @@ int ws_sort_impl(Ctx& c, const WKeyGen* gen, u64* K1[2], u64* K2[2], u32* V[2], 
         pl.NLr = pre->NLr; pl.NS = pre->NS; pl.S = pre->S;
         sp1 = pre->sp1; sp2 = pre->sp2;
     } else {
-        ss_fanouts(c, n, pl.L, pl.F, pl.os);
+        ss_fanouts(c, n, pl.L, pl.F, pl.os, (u32)c.wsort_leaf);
         pl.NLr = pl.F[0] * pl.F[1] * pl.F[2]; pl.NS = pl.NLr - 1; pl.S = pl.os * pl.NLr;
         sp1 = c.arena.get<u64>((size_t)pl.NS + 1);
         sp2 = KW == 2 ? c.arena.get<u64>((size_t)pl.NS + 1) : nullptr;
@@ -1320,10 +1318,12 @@ int ws_sort_impl(Ctx& c, const WKeyGen* gen, u64* K1[2], u64* K2[2], u32* V[2], 
                 if (!cnt) continue;
                 const WLists Q = { rl + q * cur_cap, tl + q * cur_cap, lc + 2 * q };
                 const u32* lst = cur_cls + q * cur_cap;
-                if (q == 0) ws_leaf_sort_kernel<KW, 4, PAIRS><<<cnt, WL_NW * 64, 0, s>>>(A, lst, cnt, Q);
-                else if (q == 1) ws_leaf_sort_kernel<KW, 8, PAIRS><<<cnt, WL_NW * 64, 0, s>>>(A, lst, cnt, Q);
-                else if (q == 2) ws_leaf_sort_kernel<KW, 12, PAIRS><<<cnt, WL_NW * 64, 0, s>>>(A, lst, cnt, Q);
-                else ws_leaf_sort_kernel<KW, 16, PAIRS><<<cnt, WL_NW * 64, 0, s>>>(A, lst, cnt, Q);
+                // (units of <= 2048 records: four waves of eight rows -- a smaller workgroup, more units in flight per CU; the kernel
+                //  is bound by its chain of dependent steps, not by throughput)
+                if (q == 0) ws_leaf_sort_kernel<KW, 8, 4, PAIRS><<<cnt, 4 * 64, 0, s>>>(A, lst, cnt, Q);
+                else if (q == 1) ws_leaf_sort_kernel<KW, 8, 8, PAIRS><<<cnt, 8 * 64, 0, s>>>(A, lst, cnt, Q);
+                else if (q == 2) ws_leaf_sort_kernel<KW, 12, 8, PAIRS><<<cnt, 8 * 64, 0, s>>>(A, lst, cnt, Q);
+                else ws_leaf_sort_kernel<KW, 16, 8, PAIRS><<<cnt, 8 * 64, 0, s>>>(A, lst, cnt, Q);
                 LAUNCH_CHECK();
             }
             u32 hl[8];
@@ -1333,10 +1333,10 @@ int ws_sort_impl(Ctx& c, const WKeyGen* gen, u64* K1[2], u64* K2[2], u32* V[2], 
             const WEmit noE = { nullptr, 1 };
             auto count_pass = [&](int q, const u32* lst, u32 cnt, u32 mask, u32 val, const WCount& R, const WEmit& Em) {
                 if (!cnt) return;
-                if (q == 0) ws_leaf_count_kernel<4, PAIRS><<<cnt, WL_NW * 64, 0, s>>>(A, lst, cnt, mask, val, R, Em);
-                else if (q == 1) ws_leaf_count_kernel<8, PAIRS><<<cnt, WL_NW * 64, 0, s>>>(A, lst, cnt, mask, val, R, Em);
-                else if (q == 2) ws_leaf_count_kernel<12, PAIRS><<<cnt, WL_NW * 64, 0, s>>>(A, lst, cnt, mask, val, R, Em);
-                else ws_leaf_count_kernel<16, PAIRS><<<cnt, WL_NW * 64, 0, s>>>(A, lst, cnt, mask, val, R, Em);
+                if (q == 0) ws_leaf_count_kernel<8, 4, PAIRS><<<cnt, 4 * 64, 0, s>>>(A, lst, cnt, mask, val, R, Em);
+                else if (q == 1) ws_leaf_count_kernel<8, 8, PAIRS><<<cnt, 8 * 64, 0, s>>>(A, lst, cnt, mask, val, R, Em);
+                else if (q == 2) ws_leaf_count_kernel<12, 8, PAIRS><<<cnt, 8 * 64, 0, s>>>(A, lst, cnt, mask, val, R, Em);
+                else ws_leaf_count_kernel<16, 8, PAIRS><<<cnt, 8 * 64, 0, s>>>(A, lst, cnt, mask, val, R, Em);
                 LAUNCH_CHECK();
             };
             for (int q = 0; q < 4; ++q) {
@@ -1437,7 +1437,7 @@ bool wsort_pre_begin(Ctx& c, WPre& P, const u8* text, size_t n, size_t chunk_len
     }
     P.text = text; P.n = n; P.chunk_len = chunk_len; P.nchunks = nchunks;
     wsort_make_keygen(c, text, n, sigma, code, P.KW, P.g);
-    ss_fanouts(c, n, P.L, P.F, P.os);
+    ss_fanouts(c, n, P.L, P.F, P.os, (u32)c.wsort_leaf);
     if (P.L < 2) return false;
     P.NLr = P.F[0] * P.F[1] * P.F[2]; P.NS = P.NLr - 1; P.S = P.os * P.NLr;
     Arena& A = c.arena;
