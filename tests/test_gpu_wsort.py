@@ -37,6 +37,7 @@ VARIANTS = {
     "L3_chunks":   {"TDC_GPU_WSORT_MIN": "4096", "TDC_GPU_SSORT_LEVELS": "3", "TDC_GPU_WSORT_SMALLRUN": "1"},
     "no_rounds":   {"TDC_GPU_WSORT_MIN": "4096", "TDC_GPU_WSORT_ROUNDS": "0"},
     "one_round":   {"TDC_GPU_WSORT_MIN": "4096", "TDC_GPU_WSORT_ROUNDS": "1", "TDC_GPU_WSORT_KW": "1"},
+    "two_wide":    {"TDC_GPU_WSORT_MIN": "4096", "TDC_GPU_WSORT_TWO": "2"},     # two levels of 1024 buckets (texts of 4 MB and more)
 }
 
 
@@ -51,7 +52,7 @@ def ctxs():
 def _more_texts():
     rng = np.random.default_rng(99)
     out = list(TEXTS)
-    out.append(("english_3M", T.gen_english(3_000_000, 11).tobytes()))
+    out.append(("english_5M", T.gen_english(5_000_000, 11).tobytes()))
     out.append(("dna_2M", T.gen_dna(2_000_000, 5).tobytes()))
     # long repeats: the text rounds cannot finish (LCP of thousands) -- the doubling fall-back must take over from the depth reached
     blk = bytes(rng.integers(97, 123, 5000, dtype=np.uint8))

@@ -317,6 +317,7 @@ int tdc_gpu_ctx_create(int device, tdc_gpu_ctx** out) {
         if (const char* m = getenv("TDC_GPU_WSORT_ROUNDS")) { const int v = atoi(m); ctx->c.wsort_rounds = v < 0 ? 0 : (v > 100 ? 100 : v); }
         if (const char* m = getenv("TDC_GPU_WSORT_SMALLRUN")) ctx->c.wsort_small = atoi(m) ? 1 : 0;
         if (const char* m = getenv("TDC_GPU_WSORT_OVERLAP")) ctx->c.wsort_overlap = atoi(m) ? 1 : 0;
+        if (const char* m = getenv("TDC_GPU_WSORT_TWO")) { const int v = atoi(m); ctx->c.wsort_two = (v >= 0 && v <= 2) ? v : 0; }
         if (const char* m = getenv("TDC_GPU_WSORT_LEAF")) ctx->c.wsort_leaf = atoi(m) == 1024 ? 1024 : 2048;
         if (const char* m = getenv("TDC_GPU_WSORT_PACK")) { const int v = atoi(m); ctx->c.wsort_pack = (v == 1024 || v == 4096) ? v : 2048; }
         if (const char* m = getenv("TDC_GPU_WSORT_CMAX")) { const int v = atoi(m); ctx->c.wsort_cmax = v < 1 ? 1 : (v > 64 ? 64 : v); }

@@ -59,6 +59,8 @@ constexpr int TH_MAX = 2048;         // halo on either side: a run-time value (m
 constexpr int TT = TDC_WIN_TT;       // threads per workgroup (the first TW / 64 of them own a 64-position chunk of the window: TT >= TW / 64)
 constexpr int TCH = 64;              // consecutive window positions per thread in the dense passes (the first TW / 64 threads own a chunk)
 constexpr int NWV = TT / 64;
+constexpr int CPT = TW / (64 * TT) > 0 ? TW / (64 * TT) : 1;   // 64-position chunks per thread in the dense passes (thread t owns the chunks t * CPT ..)
+static_assert(TW % 64 == 0 && (TW / 64 <= TT * CPT), "every chunk of the window needs an owner");
 // Two sizes of the per-level LDS lists (alive entries / pushes per level and window).  The small one leaves 40 KB of LDS
 // per workgroup, i.e. four workgroups per CU -- the kernel is latency bound, so its throughput follows the number of
 // resident workgroups; the large one (one workgroup per CU) takes over if a level overflows the small lists, e.g. on
@@ -223,39 +225,48 @@ __global__ __launch_bounds__(TT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
             // (branch-free per 8-position word: byte flags 0x80 for "resides in list L" and for "still alive", a shift cascade turns
             //  the flags into bits of the thread's 64-position mask; erased entries (:86) leave the list by a masked word store.
             //  Positions outside the known range are not collected; erasing a dead entry there is harmless -- the range only shrinks.)
-            const int base = tid * TCH;
-            u64 amask = 0;
-            if (base < hi && base + TCH > lo) {
-                const u64 pat = (u64)L * 0x0101010101010101ull;
-                const u64 lo7 = 0x7F7F7F7F7F7F7F7Full, hi1 = 0x8080808080808080ull;
-                const u64 addc = (u64)(128u - threshold) * 0x0101010101010101ull;     // (c & 0x7F) + addc has bit 7 set iff (c & 0x7F) >= threshold
-                u64 rws[TCH / 8], cws[TCH / 8];
+            u64 amasks[CPT];
 #pragma unroll
-                for (int k = 0; k < TCH / 8; ++k) { rws[k] = *(const u64*)&res8[PW(tid, k)]; cws[k] = *(const u64*)&cur8[PW(tid, k)]; }
+            for (int cc = 0; cc < CPT; ++cc) {
+                const int chunk = tid * CPT + cc;
+                const int base = chunk * TCH;
+                u64 amask = 0;
+                if (base < TW && base < hi && base + TCH > lo) {
+                    const u64 pat = (u64)L * 0x0101010101010101ull;
+                    const u64 lo7 = 0x7F7F7F7F7F7F7F7Full, hi1 = 0x8080808080808080ull;
+                    const u64 addc = (u64)(128u - threshold) * 0x0101010101010101ull;     // (c & 0x7F) + addc has bit 7 set iff (c & 0x7F) >= threshold
+                    u64 rws[TCH / 8], cws[TCH / 8];
 #pragma unroll
-                for (int k = 0; k < TCH / 8; ++k) {
-                    const u64 x = (rws[k] & lo7) ^ pat;
-                    const u64 hit = ~(((x & lo7) + lo7) | x | lo7);            // 0x80 in every byte of x that is zero (exact)
-                    const u64 alive = (((cws[k] & lo7) + addc) | cws[k]) & hi1;  // 0x80 where cur >= threshold
-                    u64 ha = (hit & alive) >> 7;                                // flag bits at 0, 8, .., 56 -> bits 0..7
-                    ha |= ha >> 7; ha |= ha >> 14; ha |= ha >> 28;
-                    amask |= (ha & 0xFFull) << (8 * k);
-                    const u64 he = (hit & ~alive) >> 7;                         // erased entries of this word
-                    if (he) *(u64*)&res8[PW(tid, k)] = rws[k] & ~((he << 8) - he);
+                    for (int k = 0; k < TCH / 8; ++k) { rws[k] = *(const u64*)&res8[PW(chunk, k)]; cws[k] = *(const u64*)&cur8[PW(chunk, k)]; }
+#pragma unroll
+                    for (int k = 0; k < TCH / 8; ++k) {
+                        const u64 x = (rws[k] & lo7) ^ pat;
+                        const u64 hit = ~(((x & lo7) + lo7) | x | lo7);            // 0x80 in every byte of x that is zero (exact)
+                        const u64 alive = (((cws[k] & lo7) + addc) | cws[k]) & hi1;  // 0x80 where cur >= threshold
+                        u64 ha = (hit & alive) >> 7;                                // flag bits at 0, 8, .., 56 -> bits 0..7
+                        ha |= ha >> 7; ha |= ha >> 14; ha |= ha >> 28;
+                        amask |= (ha & 0xFFull) << (8 * k);
+                        const u64 he = (hit & ~alive) >> 7;                         // erased entries of this word
+                        if (he) *(u64*)&res8[PW(chunk, k)] = rws[k] & ~((he << 8) - he);
+                    }
+                    const int rlo = lo - base, rhi = hi - base;                     // known range, relative to the chunk
+                    if (rlo > 0) amask &= ~((1ull << rlo) - 1ull);
+                    if (rhi < TCH) amask &= (1ull << rhi) - 1ull;
                 }
-                const int rlo = lo - base, rhi = hi - base;                     // known range, relative to the thread's chunk
-                if (rlo > 0) amask &= ~((1ull << rlo) - 1ull);
-                if (rhi < TCH) amask &= (1ull << rhi) - 1ull;
+                amasks[cc] = amask;
             }
             // the first priorities are requested before the barrier of the scan, so their latency overlaps it
             u32 pre0 = 0, pre1 = 0;
             {
-                u64 mm = amask;
+                u64 mm = amasks[0];
+                const int base = tid * CPT * TCH;
                 if (mm) { pre0 = prio_g[w0 + base + __builtin_ctzll(mm)]; mm &= mm - 1; }   // (a window-local priority is read behind the full barrier below)
                 if (mm) { pre1 = prio_g[w0 + base + __builtin_ctzll(mm)]; }
             }
             WPROF(2);
-            const u32 cnt = (u32)__popcll(amask);
+            u32 cnt = 0;
+#pragma unroll
+            for (int cc = 0; cc < CPT; ++cc) cnt += (u32)__popcll(amasks[cc]);
             const u32 inc = wave_inclusive_sum(cnt);
             if (lane == 63) wtot[wv] = inc;
             __syncthreads();                                // the level's one FULL barrier: lprio stores of earlier levels are complete
@@ -268,17 +279,22 @@ __global__ __launch_bounds__(TT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
             if (tid == 0) atomicMax(&sc->max_entries, total);
 #endif
             int my_und = 0;
-            for (int q = 0; amask; ++q) {
-                const int bit = __builtin_ctzll(amask);
-                amask &= amask - 1;
-                const int pos = base + bit;
-                const u32 cv = cur8[PA(pos)];
-                const u32 local = res8[PA(pos)] & S_LOCAL;
-                const u32 pr = local ? lprio[pos] : ((q == 0) ? pre0 : (q == 1) ? pre1 : prio_g[w0 + pos]);
-                const u32 st = (cv == L ? S_UND : S_STALE) | local;
-                ent[off] = ((u64)((cv << 24) | (st << 16) | (u32)pos) << 32) | pr;
-                if (cv == L) ++my_und;
-                ++off;
+#pragma unroll
+            for (int cc = 0; cc < CPT; ++cc) {
+                u64 amask = amasks[cc];
+                const int base = (tid * CPT + cc) * TCH;
+                for (int q = 0; amask; ++q) {
+                    const int bit = __builtin_ctzll(amask);
+                    amask &= amask - 1;
+                    const int pos = base + bit;
+                    const u32 cv = cur8[PA(pos)];
+                    const u32 local = res8[PA(pos)] & S_LOCAL;
+                    const u32 pr = local ? lprio[pos] : ((cc == 0 && q == 0) ? pre0 : (cc == 0 && q == 1) ? pre1 : prio_g[w0 + pos]);
+                    const u32 st = (cv == L ? S_UND : S_STALE) | local;
+                    ent[off] = ((u64)((cv << 24) | (st << 16) | (u32)pos) << 32) | pr;
+                    if (cv == L) ++my_und;
+                    ++off;
+                }
             }
             my_und = wave_reduce_sum(my_und);
             if (lane == 0 && my_und) atomicAdd(&s_und[0], my_und);
@@ -462,21 +478,25 @@ __global__ __launch_bounds__(TT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
         if (failed || fl > ia || fr < ib) { if (tid == 0) atomicOr(&sc->fail, failed ? 2u : 1u); }   // 2: a fixed LDS list overflowed, 1: known range too small
         else {
             // ---- factor starts of the interior: (pos, Phi[pos], L)  (ArraysComp.hpp:91-96) ---------------------------
-            const int base = tid * TCH;
-            if (base < ib && base + TCH > ia) {
 #pragma unroll
-                for (int k = 0; k < TCH; k += 8) {
-                    const u64 rw = *(const u64*)&res8[PW(tid, k >> 3)];
-                    u64 w = rw & 0x4040404040404040ull;
-                    while (w) {
-                        const int bb = __builtin_ctzll(w) >> 3;
-                        w &= w - 1;
-                        const int pos = base + k + bb;
-                        if (pos < ia || pos >= ib) continue;
-                        const size_t gp = w0 + pos;
-                        flen[gp] = (u32)(rw >> (8 * bb)) & 0x3Fu;
-                        fsrc[gp] = phi[gp];
-                        ++nsel_interior;
+            for (int cc = 0; cc < CPT; ++cc) {
+                const int chunk = tid * CPT + cc;
+                const int base = chunk * TCH;
+                if (base < TW && base < ib && base + TCH > ia) {
+#pragma unroll
+                    for (int k = 0; k < TCH; k += 8) {
+                        const u64 rw = *(const u64*)&res8[PW(chunk, k >> 3)];
+                        u64 w = rw & 0x4040404040404040ull;
+                        while (w) {
+                            const int bb = __builtin_ctzll(w) >> 3;
+                            w &= w - 1;
+                            const int pos = base + k + bb;
+                            if (pos < ia || pos >= ib) continue;
+                            const size_t gp = w0 + pos;
+                            flen[gp] = (u32)(rw >> (8 * bb)) & 0x3Fu;
+                            fsrc[gp] = phi[gp];
+                            ++nsel_interior;
+                        }
                     }
                 }
             }

@@ -44,7 +44,7 @@ void ss_level_offsets(Ctx& c, const SegTables& T, const u32* seg_start, u32 nseg
 void ss_level_offsets_sub(Ctx& c, const SegTables& T, u32 nsub, const u32* blk_super, const u32* out_start, u32 nsuper, u32 D, u32* nstart, size_t n);
 void ss_build_units(Ctx& c, const u32* leaf_start, u32 nleaf, UnitTables& U, u32 small = 0);   // leaves -> units of <= 8192 pairs by size class (synchronises);
                                                                                    // leaves of <= `small` pairs (0: 4096) are packed into units of <= 2 * small
-void ss_fanouts(Ctx& c, size_t n, int& L, u32 F[3], u32& os, u32 leaf3 = 0);       // levels, fan-outs and oversampling for n pairs (leaf3: leaf size aimed at with three levels, 0 = 2048)
+void ss_fanouts(Ctx& c, size_t n, int& L, u32 F[3], u32& os, u32 leaf3 = 0, int wide2 = 0);       // levels, fan-outs and oversampling for n pairs (leaf3: leaf size aimed at with three levels, 0 = 2048)
 
 // ---- wide-key suffix sort (wsort.hip) ----------------------------------------------------------------------------------------------
 // key(p) = the s recoded bytes text[p .. p+s) as s fields of b bits, left-aligned in KW 64-bit words (pad zero bits below; zeros behind

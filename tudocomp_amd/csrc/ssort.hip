@@ -243,8 +243,8 @@ __global__ __launch_bounds__(256) void ss_blocksum_kernel(const u32* __restrict_
 // group g of G = 1024 / 256 = 4
 __global__ __launch_bounds__(1024) void ss_segbase_kernel(u32* __restrict__ bs, const u32* __restrict__ blk_start, const u32* __restrict__ seg_start,
                                                           u32 D, u32* __restrict__ next_start) {
-    __shared__ u32 part[4][512];
-    __shared__ u32 dstart[512];
+    __shared__ u32 part[4][2048];
+    __shared__ u32 dstart[2048];
     __shared__ u32 wsum[16];
     const u32 s = blockIdx.x;
     const u32 b0 = blk_start[s], b1 = blk_start[s + 1];
@@ -266,20 +266,20 @@ __global__ __launch_bounds__(1024) void ss_segbase_kernel(u32* __restrict__ bs, 
         part[g][d] = acc;
     }
     __syncthreads();
-    // exclusive scan of the D digit totals (D <= 512): thread i < 512 owns digit i
-    u32 tot = 0;
-    if (threadIdx.x < 512 && threadIdx.x < D) tot = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+    // exclusive scan of the D digit totals (D <= 2048): thread i owns the digits 2i and 2i + 1
+    const u32 d0 = 2 * threadIdx.x, d1 = d0 + 1;
+    const u32 tot0 = d0 < D ? part[0][d0] + part[1][d0] + part[2][d0] + part[3][d0] : 0u;
+    const u32 tot1 = d1 < D ? part[0][d1] + part[1][d1] + part[2][d1] + part[3][d1] : 0u;
+    const u32 tot = tot0 + tot1;
     u32 inc = wave_inclusive_sum(tot);
     if (lane_id() == 63) wsum[wave_id()] = inc;
     __syncthreads();
-    if (threadIdx.x < 512) {
+    {
         u32 run = 0;
         for (int w = 0; w < wave_id(); ++w) run += wsum[w];
-        if (threadIdx.x < D) {
-            const u32 st = seg_start[s] + run + inc - tot;
-            dstart[threadIdx.x] = st;
-            next_start[(size_t)s * D + threadIdx.x] = st;
-        }
+        const u32 st = seg_start[s] + run + inc - tot;
+        if (d0 < D) { dstart[d0] = st; next_start[(size_t)s * D + d0] = st; }
+        if (d1 < D) { dstart[d1] = st + tot0; next_start[(size_t)s * D + d1] = st + tot0; }
     }
     __syncthreads();
     for (u32 d = t; d < D; d += 256) {
@@ -1273,11 +1273,22 @@ void ss_build_units(Ctx& c, const u32* leaf_start, u32 nleaf, UnitTables& U, u32
     LAUNCH_CHECK();
     c.read_n(U.large, U.hc, 6);
 }
-void ss_fanouts(Ctx& c, size_t n, int& L, u32 F[3], u32& os, u32 leaf3) {
+void ss_fanouts(Ctx& c, size_t n, int& L, u32 F[3], u32& os, u32 leaf3, int wide2) {
     L = n <= (size_t)256 * 3072 ? 1 : ((n + 65535) / 65536 <= 4352 ? 2 : 3);
     if (c.ssort_levels >= 1 && c.ssort_levels <= 3) L = c.ssort_levels;
     F[0] = F[1] = F[2] = 1;
     if (leaf3 == 0) leaf3 = 2048;                              // target leaf size with three levels
+    if ((wide2 == 1 && L == 3) || wide2 == 2) {                // two levels of up to 1024 buckets instead of three of up to 256 (wsort.hip;
+        u32 nl2 = pow2_ceil((n + leaf3 - 1) / leaf3);          //  measured slower at 2e9: the 1024-way first level no longer hides behind the upload)
+        if (nl2 <= (1u << 20) && nl2 >= 2048u) {               // (2: whenever there are enough leaves for it -- tests)
+            L = 2;
+            F[1] = 1024u;
+            F[0] = nl2 / F[1];
+            const u64 avg2 = (n + nl2 - 1) / nl2;
+            os = avg2 > 3072 ? 64 : (avg2 > 2304 ? 32 : 16);
+            return;
+        }
+    }
     const u32 cap = L == 1 ? 256u : (L == 2 ? 65536u : (1u << 24));
     u32 nl = pow2_ceil((n + (L == 3 ? leaf3 - 1 : 3071)) / (L == 3 ? leaf3 : 3072));
     if (nl > cap) nl = cap;

@@ -65,10 +65,10 @@ __device__ __forceinline__ bool ws_row(const WSLevel& P, u32 row, u32& s, size_t
     return true;
 }
 
-template <int KW, bool LAST>
+template <int KW, bool LAST, int FMAX>
 __device__ __forceinline__ void ws_load_splitters(const WSLevel& P, u32 s_piece, u64* spl1, u64* spl2) {
     const u32 s = s_piece / P.sub;
-    for (u32 i = threadIdx.x; i < 256; i += blockDim.x) {
+    for (u32 i = threadIdx.x; i < (u32)FMAX; i += blockDim.x) {
         u64 a = ~0ull, b = ~0ull;
         size_t idx = 0; bool have = false;
         if (LAST) { if (i < P.F) { idx = (size_t)s * P.F + i; have = true; } }
@@ -79,12 +79,12 @@ __device__ __forceinline__ void ws_load_splitters(const WSLevel& P, u32 s_piece,
     }
 }
 
-// #splitters < x among spl[0 .. 255) (branch-free binary search, lexicographic on the two words), then the digit
-template <int KW, bool LAST>
+// #splitters < x among spl[0 .. FMAX - 1) (branch-free binary search, lexicographic on the two words), then the digit
+template <int KW, bool LAST, int FMAX>
 __device__ __forceinline__ u32 ws_digit(const u64* spl1, const u64* spl2, u64 x1, u64 x2) {
     u32 lo = 0;
 #pragma unroll
-    for (u32 step = 128; step >= 1; step >>= 1) {
+    for (u32 step = FMAX / 2; step >= 1; step >>= 1) {
         const u32 i = lo + step - 1;
         const u64 a = spl1[i];
         bool lt = a < x1;
@@ -225,11 +225,11 @@ static void ws_lsd_sort_wide(Ctx& c, u64* k1[2], u64* k2[2], u32* v[2], size_t m
 }
 
 // ---- count ------------------------------------------------------------------------------------------------------------------------
-template <int KW, bool GEN, bool LAST>
+template <int KW, bool GEN, bool LAST, int FMAX>
 __global__ __launch_bounds__(256) void ws_count_kernel(WSLevel P, WKeyGen g, u32 rows) {
-    __shared__ u32 hist[512];
-    __shared__ u64 spl1[256];
-    __shared__ u64 spl2[KW == 2 ? 256 : 1];
+    __shared__ u32 hist[2 * FMAX];
+    __shared__ u64 spl1[FMAX];
+    __shared__ u64 spl2[KW == 2 ? FMAX : 1];
     __shared__ u8 code[256];
     __shared__ __align__(16) u8 sy[GEN ? WS_TILE + WS_HALO : 16];
     const u32 row = xcd_tile(blockIdx.x, P.per_xcd);
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void ws_count_kernel(WSLevel P, WKeyGen g, u32
         for (u32 i = threadIdx.x; i < P.D; i += 256) P.counts[(size_t)row * P.D + i] = 0;
         return;
     }
-    ws_load_splitters<KW, LAST>(P, s, spl1, spl2);
+    ws_load_splitters<KW, LAST, FMAX>(P, s, spl1, spl2);
     if (GEN) code[threadIdx.x] = g.code[threadIdx.x];
     __syncthreads();
     if (GEN) { ws_gen_stage(g, P.gen_off + base, code, sy); __syncthreads(); }
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void ws_count_kernel(WSLevel P, WKeyGen g, u32
 #pragma unroll
         for (int j = 0; j < WS_ITEMS; ++j) {
             const bool valid = (u32)(lb + j) < cnt;
-            const u32 d = valid ? ws_digit<KW, LAST>(spl1, spl2, ka, kb) : 0u;
+            const u32 d = valid ? ws_digit<KW, LAST, FMAX>(spl1, spl2, ka, kb) : 0u;
             ws_key_roll<KW>(g, ka, kb, sy[lb + j + g.s]);
             pk[j >> 1] = (j & 1) ? (pk[j >> 1] | (d << 16)) : d;
             const u32 d0 = __builtin_amdgcn_readfirstlane(d);
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256) void ws_count_kernel(WSLevel P, WKeyGen g, u32
             const bool valid = e < cnt;
             const u64 x1 = valid ? kp1[j * 64] : 0ull;
             const u64 x2 = (KW == 2 && valid) ? kp2[j * 64] : 0ull;
-            const u32 d = valid ? ws_digit<KW, LAST>(spl1, spl2, x1, x2) : 0u;
+            const u32 d = valid ? ws_digit<KW, LAST, FMAX>(spl1, spl2, x1, x2) : 0u;
             if (valid) dgp[j * 64] = (u16)d;
             const u32 d0 = __builtin_amdgcn_readfirstlane(d);
             if (__all(valid && d == d0)) { if (lane_id() == 0) atomicAdd(&hist[d0], 64u); }
@@ -290,11 +290,12 @@ __global__ __launch_bounds__(256) void ws_count_kernel(WSLevel P, WKeyGen g, u32
 // level, whose equality digits are skewed by construction).  The tile is then written stream by stream -- positions, k1, k2 -- each
 // staged in LDS in digit order first, so that consecutive lanes write consecutive records of a digit's run and the record width
 // costs no registers: keys are loaded (or, on the text level, generated) right before their stream is staged.
-template <int KW, bool GEN, bool LAST>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void ws_scatter_kernel(WSLevel P, WKeyGen g, u32 rows) {
-    constexpr int DMAX = LAST ? 512 : 256;
-    __shared__ u32 tcnt[LAST ? 4 : DMAX];
-    __shared__ __align__(16) u16 wcnt[LAST ? 4 : 1][LAST ? DMAX : 8];
+template <int KW, bool GEN, bool LAST, int FMAX>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FMAX > 256 ? 3 : 4, FMAX > 256 ? 3 : 4))) void ws_scatter_kernel(WSLevel P, WKeyGen g, u32 rows) {
+    constexpr int DMAX = LAST ? 2 * FMAX : FMAX;
+    constexpr bool MATCH = LAST && FMAX <= 256;               // ranks from the wave-level LDS match (its tables need 8 bytes per wave and digit)
+    __shared__ u32 tcnt[MATCH ? 4 : DMAX];
+    __shared__ __align__(16) u16 wcnt[MATCH ? 4 : 1][MATCH ? DMAX : 8];
     __shared__ u32 gbase[DMAX];
     __shared__ __align__(16) u64 stage[WS_TILE];
     __shared__ u32 scan_sm[5];
@@ -307,8 +308,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     if (!ws_row(P, row, s, base, cnt) || cnt == 0) return;
     u16* stage_d = (u16*)(stage + 2048);                    // digits of the staged values: second half of the buffer
     u32* stage32 = (u32*)stage;
-    unsigned long long* M = (unsigned long long*)stage + 1024 + w * DMAX;    // LAST: lane-mask tables of the LDS match (bytes 8 K .. 24 K)
-    if constexpr (LAST) { for (int i = threadIdx.x; i < 4 * DMAX; i += 256) { (&wcnt[0][0])[i] = 0; ((unsigned long long*)stage)[1024 + i] = 0; } }
+    unsigned long long* M = (unsigned long long*)stage + 1024 + w * (MATCH ? DMAX : 0);    // MATCH: lane-mask tables of the LDS match (bytes 8 K .. 24 K)
+    if constexpr (MATCH) { for (int i = threadIdx.x; i < 4 * DMAX; i += 256) { (&wcnt[0][0])[i] = 0; ((unsigned long long*)stage)[1024 + i] = 0; } }
     else { for (int i = threadIdx.x; i < DMAX; i += 256) tcnt[i] = 0; }
     if (GEN) code[threadIdx.x] = g.code[threadIdx.x];
     __syncthreads();
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
             for (int j = 0; j < WS_ITEMS; ++j) dg[j] = (lbs + (u32)j * 64 < cnt) ? (u32)dgp[j * 64] : 0u;
         }
-        if constexpr (LAST) {
+        if constexpr (MATCH) {
             u16* mycnt = wcnt[w];
             const u64 lanebit = 1ull << lane;
             const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -378,7 +379,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
         for (int q = 0; q < DMAX / 256; ++q) {
             const u32 d = t * (DMAX / 256) + q;
-            if constexpr (LAST) tot[q] = (u32)wcnt[0][d] + wcnt[1][d] + wcnt[2][d] + wcnt[3][d];
+            if constexpr (MATCH) tot[q] = (u32)wcnt[0][d] + wcnt[1][d] + wcnt[2][d] + wcnt[3][d];
             else tot[q] = tcnt[d];
             sum += tot[q];
         }
@@ -387,7 +388,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
         for (int q = 0; q < DMAX / 256; ++q) {
             const u32 d = t * (DMAX / 256) + q;
-            if constexpr (LAST) {
+            if constexpr (MATCH) {
                 u32 run = start;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { const u32 cw = wcnt[i][d]; wcnt[i][d] = (u16)run; run += cw; }
@@ -403,7 +404,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const u32 e = lbs + (u32)j * estep;
         const u32 d = ld[j] >> 16;
         u32 pos = ld[j] & 0xFFFFu;
-        if constexpr (LAST) pos += (u32)wcnt[w][d]; else pos += tcnt[d];
+        if constexpr (MATCH) pos += (u32)wcnt[w][d]; else pos += tcnt[d];
         ld[j] = pos;
         if (e < cnt) { stage32[pos] = GEN ? (u32)(P.gen_off + base + e) : P.v_in[base + e]; stage_d[pos] = (u16)d; }
     }
@@ -1033,9 +1034,9 @@ __global__ void ws_range_flags_kernel(const u64* __restrict__ k1, const u64* __r
 // ---- tables of the level that merges a chunk-wise level 1 -----------------------------------------------------------------------------
 // nstart_all[q][b]: first slot of bucket b inside chunk q ([F0] = end of the chunk's part).  Piece b * nch + q = that range; out_start[b] =
 // first output slot of bucket b = total size of the buckets in front of it.
-__global__ __launch_bounds__(256) void ws_sub_tables_kernel(const u32* __restrict__ nstart_all, u32 F0, u32 nch, u32* __restrict__ seg_begin,
-                                                             u32* __restrict__ seg_end, u32* __restrict__ out_start) {
-    __shared__ u32 tot[256];
+__global__ __launch_bounds__(1024) void ws_sub_tables_kernel(const u32* __restrict__ nstart_all, u32 F0, u32 nch, u32* __restrict__ seg_begin,
+                                                              u32* __restrict__ seg_end, u32* __restrict__ out_start) {
+    __shared__ u32 tot[1024];
     const u32 b = threadIdx.x;
     u32 t = 0;
     if (b < F0) {
@@ -1085,7 +1086,7 @@ void wsort_make_keygen(const Ctx& c, const u8* text, size_t n, u32 sigma, const 
 bool wsort_applicable(const Ctx& c, size_t n) { return c.wsort && n >= c.wsort_min && n < ((size_t)1 << 32); }
 int wsort_result_index(Ctx& c, size_t n) {                    // index of the V buffer that will hold wsort_suffixes' result
     int L; u32 F[3], os;
-    ss_fanouts(c, n, L, F, os, (u32)c.wsort_leaf);
+    ss_fanouts(c, n, L, F, os, (u32)c.wsort_leaf, c.wsort_two);
     return (L - 1) & 1;
 }
 
@@ -1131,7 +1132,7 @@ int ws_sort_impl(Ctx& c, const WKeyGen* gen, u64* K1[2], u64* K2[2], u32* V[2], 
         pl.NLr = pre->NLr; pl.NS = pre->NS; pl.S = pre->S;
         sp1 = pre->sp1; sp2 = pre->sp2;
     } else {
-        ss_fanouts(c, n, pl.L, pl.F, pl.os, (u32)c.wsort_leaf);
+        ss_fanouts(c, n, pl.L, pl.F, pl.os, (u32)c.wsort_leaf, c.wsort_two);
         pl.NLr = pl.F[0] * pl.F[1] * pl.F[2]; pl.NS = pl.NLr - 1; pl.S = pl.os * pl.NLr;
         sp1 = c.arena.get<u64>((size_t)pl.NS + 1);
         sp2 = KW == 2 ? c.arena.get<u64>((size_t)pl.NS + 1) : nullptr;
@@ -1165,7 +1166,7 @@ int ws_sort_impl(Ctx& c, const WKeyGen* gen, u64* K1[2], u64* K2[2], u32* V[2], 
         u32* seg_begin = c.arena.get<u32>(nsub + 1);
         u32* seg_end = c.arena.get<u32>(nsub + 1);
         u32* out_start = c.arena.get<u32>(F0 + 1);
-        ws_sub_tables_kernel<<<1, 256, 0, s>>>(pre->nstart_all, F0, nch, seg_begin, seg_end, out_start);
+        ws_sub_tables_kernel<<<1, 1024, 0, s>>>(pre->nstart_all, F0, nch, seg_begin, seg_end, out_start);
         LAUNCH_CHECK();
         SegTables Tb;
         {
@@ -1200,16 +1201,16 @@ int ws_sort_impl(Ctx& c, const WKeyGen* gen, u64* K1[2], u64* K2[2], u32* V[2], 
         const u32 grid = P.per_xcd ? 8 * P.per_xcd : rows;
         {
             const int pc = c.prof_begin(K_RS_COUNT, (u64)n * 8 * KW);
-            if (last) ws_count_kernel<KW, false, true><<<grid, 256, 0, s>>>(P, g, rows);
-            else ws_count_kernel<KW, false, false><<<grid, 256, 0, s>>>(P, g, rows);
+            if (last) { if (P.F > 256) ws_count_kernel<KW, false, true, 1024><<<grid, 256, 0, s>>>(P, g, rows); else ws_count_kernel<KW, false, true, 256><<<grid, 256, 0, s>>>(P, g, rows); }
+            else { if (P.F > 256) ws_count_kernel<KW, false, false, 1024><<<grid, 256, 0, s>>>(P, g, rows); else ws_count_kernel<KW, false, false, 256><<<grid, 256, 0, s>>>(P, g, rows); }
             LAUNCH_CHECK();
             c.prof_end(pc);
         }
         ss_level_offsets_sub(c, Tb, nsub, blk_super, out_start, F0, D, nstart, n);
         {
             const int ps = c.prof_begin(K_RS_SCATTER_U64, (u64)n * (2 * (4 + 8 * KW) + 2));
-            if (last) ws_scatter_kernel<KW, false, true><<<grid, 256, 0, s>>>(P, g, rows);
-            else ws_scatter_kernel<KW, false, false><<<grid, 256, 0, s>>>(P, g, rows);
+            if (last) { if (P.F > 256) ws_scatter_kernel<KW, false, true, 1024><<<grid, 256, 0, s>>>(P, g, rows); else ws_scatter_kernel<KW, false, true, 256><<<grid, 256, 0, s>>>(P, g, rows); }
+            else { if (P.F > 256) ws_scatter_kernel<KW, false, false, 1024><<<grid, 256, 0, s>>>(P, g, rows); else ws_scatter_kernel<KW, false, false, 256><<<grid, 256, 0, s>>>(P, g, rows); }
             LAUNCH_CHECK();
             c.prof_end(ps);
         }
@@ -1246,20 +1247,20 @@ int ws_sort_impl(Ctx& c, const WKeyGen* gen, u64* K1[2], u64* K2[2], u32* V[2], 
         const u32 grid = P.per_xcd ? 8 * P.per_xcd : rows;
         {
             const int pc = c.prof_begin(K_RS_COUNT, (u64)n * (gl ? 1 : 8 * KW));
-            if (gl && last) ws_count_kernel<KW, GEN, true><<<grid, 256, 0, s>>>(P, g, rows);
-            else if (gl) ws_count_kernel<KW, GEN, false><<<grid, 256, 0, s>>>(P, g, rows);
-            else if (last) ws_count_kernel<KW, false, true><<<grid, 256, 0, s>>>(P, g, rows);
-            else ws_count_kernel<KW, false, false><<<grid, 256, 0, s>>>(P, g, rows);
+            if (gl && last) { if (P.F > 256) ws_count_kernel<KW, GEN, true, 1024><<<grid, 256, 0, s>>>(P, g, rows); else ws_count_kernel<KW, GEN, true, 256><<<grid, 256, 0, s>>>(P, g, rows); }
+            else if (gl) { if (P.F > 256) ws_count_kernel<KW, GEN, false, 1024><<<grid, 256, 0, s>>>(P, g, rows); else ws_count_kernel<KW, GEN, false, 256><<<grid, 256, 0, s>>>(P, g, rows); }
+            else if (last) { if (P.F > 256) ws_count_kernel<KW, false, true, 1024><<<grid, 256, 0, s>>>(P, g, rows); else ws_count_kernel<KW, false, true, 256><<<grid, 256, 0, s>>>(P, g, rows); }
+            else { if (P.F > 256) ws_count_kernel<KW, false, false, 1024><<<grid, 256, 0, s>>>(P, g, rows); else ws_count_kernel<KW, false, false, 256><<<grid, 256, 0, s>>>(P, g, rows); }
             LAUNCH_CHECK();
             c.prof_end(pc);
         }
         ss_level_offsets(c, Tb, seg_start, nseg, D, nstart, n);
         {
             const int ps = c.prof_begin(K_RS_SCATTER_U64, (u64)n * (gl ? 3 + 4 + 8 * KW : 2 * (4 + 8 * KW) + 2));
-            if (gl && last) ws_scatter_kernel<KW, GEN, true><<<grid, 256, 0, s>>>(P, g, rows);
-            else if (gl) ws_scatter_kernel<KW, GEN, false><<<grid, 256, 0, s>>>(P, g, rows);
-            else if (last) ws_scatter_kernel<KW, false, true><<<grid, 256, 0, s>>>(P, g, rows);
-            else ws_scatter_kernel<KW, false, false><<<grid, 256, 0, s>>>(P, g, rows);
+            if (gl && last) { if (P.F > 256) ws_scatter_kernel<KW, GEN, true, 1024><<<grid, 256, 0, s>>>(P, g, rows); else ws_scatter_kernel<KW, GEN, true, 256><<<grid, 256, 0, s>>>(P, g, rows); }
+            else if (gl) { if (P.F > 256) ws_scatter_kernel<KW, GEN, false, 1024><<<grid, 256, 0, s>>>(P, g, rows); else ws_scatter_kernel<KW, GEN, false, 256><<<grid, 256, 0, s>>>(P, g, rows); }
+            else if (last) { if (P.F > 256) ws_scatter_kernel<KW, false, true, 1024><<<grid, 256, 0, s>>>(P, g, rows); else ws_scatter_kernel<KW, false, true, 256><<<grid, 256, 0, s>>>(P, g, rows); }
+            else { if (P.F > 256) ws_scatter_kernel<KW, false, false, 1024><<<grid, 256, 0, s>>>(P, g, rows); else ws_scatter_kernel<KW, false, false, 256><<<grid, 256, 0, s>>>(P, g, rows); }
             LAUNCH_CHECK();
             c.prof_end(ps);
         }
@@ -1437,7 +1438,7 @@ bool wsort_pre_begin(Ctx& c, WPre& P, const u8* text, size_t n, size_t chunk_len
     }
     P.text = text; P.n = n; P.chunk_len = chunk_len; P.nchunks = nchunks;
     wsort_make_keygen(c, text, n, sigma, code, P.KW, P.g);
-    ss_fanouts(c, n, P.L, P.F, P.os, (u32)c.wsort_leaf);
+    ss_fanouts(c, n, P.L, P.F, P.os, (u32)c.wsort_leaf, c.wsort_two);
     if (P.L < 2) return false;
     P.NLr = P.F[0] * P.F[1] * P.F[2]; P.NS = P.NLr - 1; P.S = P.os * P.NLr;
     Arena& A = c.arena;
@@ -1487,16 +1488,16 @@ void wsort_pre_chunk(Ctx& c, WPre& P, u32 q) {
     const u32 grid = Lv.per_xcd ? 8 * Lv.per_xcd : rows;
     {
         const int pc = c.prof_begin(K_RS_COUNT, (u64)len);
-        if (P.KW == 2) ws_count_kernel<2, true, false><<<grid, 256, 0, s>>>(Lv, P.g, rows);
-        else ws_count_kernel<1, true, false><<<grid, 256, 0, s>>>(Lv, P.g, rows);
+        if (P.KW == 2) { if (Lv.F > 256) ws_count_kernel<2, true, false, 1024><<<grid, 256, 0, s>>>(Lv, P.g, rows); else ws_count_kernel<2, true, false, 256><<<grid, 256, 0, s>>>(Lv, P.g, rows); }
+        else { if (Lv.F > 256) ws_count_kernel<1, true, false, 1024><<<grid, 256, 0, s>>>(Lv, P.g, rows); else ws_count_kernel<1, true, false, 256><<<grid, 256, 0, s>>>(Lv, P.g, rows); }
         LAUNCH_CHECK();
         c.prof_end(pc);
     }
     ss_level_offsets(c, Tb, seg2, 1, D, P.nstart_all + (size_t)q * (P.F[0] + 1), off + len);
     {
         const int ps = c.prof_begin(K_RS_SCATTER_U64, (u64)len * (3 + 4 + 8 * P.KW));
-        if (P.KW == 2) ws_scatter_kernel<2, true, false><<<grid, 256, 0, s>>>(Lv, P.g, rows);
-        else ws_scatter_kernel<1, true, false><<<grid, 256, 0, s>>>(Lv, P.g, rows);
+        if (P.KW == 2) { if (Lv.F > 256) ws_scatter_kernel<2, true, false, 1024><<<grid, 256, 0, s>>>(Lv, P.g, rows); else ws_scatter_kernel<2, true, false, 256><<<grid, 256, 0, s>>>(Lv, P.g, rows); }
+        else { if (Lv.F > 256) ws_scatter_kernel<1, true, false, 1024><<<grid, 256, 0, s>>>(Lv, P.g, rows); else ws_scatter_kernel<1, true, false, 256><<<grid, 256, 0, s>>>(Lv, P.g, rows); }
         LAUNCH_CHECK();
         c.prof_end(ps);
     }
