@@ -86,7 +86,8 @@ int guarded(tdc_gpu_ctx* ctx, F&& f) {
 }
 
 // + 192 MiB: fixed-size scratch (the SLE coder's 2^24-entry k-mer table and its sort buffers are the largest)
-size_t arena_need(size_t n) { return 112 * n + ((size_t)192 << 20); }
+bool g_test_extra = false;    // TDC_GPU_WSORT_SMALLRUN (tests): every run of tying records is handed on, the hand-over lists need ~48 B per byte
+size_t arena_need(size_t n) { return (g_test_extra ? 176 : 112) * n + ((size_t)192 << 20); }
 
 // public coder id (+ SLE's kmer option in bits 8..) -> coder id of encode_stream
 int lcpcomp_enc_coder(int coder) {
@@ -315,7 +316,7 @@ int tdc_gpu_ctx_create(int device, tdc_gpu_ctx** out) {
         if (const char* m = getenv("TDC_GPU_WSORT_MIN")) { const long v = atol(m); ctx->c.wsort_min = v < 4096 ? 4096 : (size_t)v; }
         if (const char* m = getenv("TDC_GPU_WSORT_KW")) { const int v = atoi(m); ctx->c.wsort_kw = (v == 1 || v == 2) ? v : 0; }
         if (const char* m = getenv("TDC_GPU_WSORT_ROUNDS")) { const int v = atoi(m); ctx->c.wsort_rounds = v < 0 ? 0 : (v > 100 ? 100 : v); }
-        if (const char* m = getenv("TDC_GPU_WSORT_SMALLRUN")) ctx->c.wsort_small = atoi(m) ? 1 : 0;
+        if (const char* m = getenv("TDC_GPU_WSORT_SMALLRUN")) { ctx->c.wsort_small = atoi(m) ? 1 : 0; if (ctx->c.wsort_small) g_test_extra = true; }
         if (const char* m = getenv("TDC_GPU_WSORT_OVERLAP")) ctx->c.wsort_overlap = atoi(m) ? 1 : 0;
         if (const char* m = getenv("TDC_GPU_WSORT_TWO")) { const int v = atoi(m); ctx->c.wsort_two = (v >= 0 && v <= 2) ? v : 0; }
         if (const char* m = getenv("TDC_GPU_WSORT_LEAF")) ctx->c.wsort_leaf = atoi(m) == 1024 ? 1024 : 2048;

@@ -16,8 +16,8 @@ constexpr int FS_ITEMS = 16;
 constexpr u32 FS_WMAX = 8192;
 
 struct FSLevel {
-    const u32* idx_in; const u32* rank_in; const u32* prev_in; const u8* lcp_in;
-    u32* idx_out; u32* rank_out; u32* prev_out; u8* lcp_out;
+    const u32* idx_in; const u64* rp_in; const u32* prev_in; const u8* lcp_in;    // rp: rank | predecessor << 32 (level 1: rank = index, prev_in = sa)
+    u32* idx_out; u64* rp_out; u8* lcp_out;
     u32* counts; const u32* blk_seg; const u32* blk_start; const u32* seg_start;
     u32 nseg, R, per_xcd; int shift;
 };
@@ -70,15 +70,12 @@ __global__ __launch_bounds__(256) void fs_count_kernel(FSLevel P, u32 rows) {
 #ifndef TDC_FS_WPE
 #define TDC_FS_WPE 4
 #endif
-#ifndef TDC_FS_PRELOAD
-#define TDC_FS_PRELOAD 1
-#endif
 template <int DB, bool FIRST>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TDC_FS_WPE, TDC_FS_WPE))) void fs_scatter_kernel(FSLevel P, u32 rows) {
     constexpr u32 D = 1u << DB;
     __shared__ u32 tcnt[D];
     __shared__ u32 gbase[D];
-    __shared__ __align__(16) u32 stage[FS_TILE];
+    __shared__ __align__(16) u64 stage[FS_TILE];
     __shared__ u32 scan_sm[5];
     const int lane = lane_id();
     const u32 row = xcd_tile(blockIdx.x, P.per_xcd);
@@ -92,18 +89,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TDC_FS_WPE,
     u32 k[FS_ITEMS], pos[FS_ITEMS];
 #pragma unroll
     for (int j = 0; j < FS_ITEMS; ++j) k[j] = (lb + (u32)j * 64 < cnt) ? ip[j * 64] : 0u;
-#if TDC_FS_PRELOAD
     // every stream of the thread's records is requested up front: the staging phases below then never wait for global memory
-    u32 rk[FS_ITEMS], pv[FS_ITEMS], lc[FS_ITEMS];
+    u64 rp[FS_ITEMS];
+    u32 lc[FS_ITEMS];
 #pragma unroll
     for (int j = 0; j < FS_ITEMS; ++j) {
         const u32 e = lb + (u32)j * 64;
         const bool valid = e < cnt;
-        rk[j] = FIRST ? (u32)(base + e + 1) : (valid ? P.rank_in[base + e] : 0u);
-        pv[j] = valid ? P.prev_in[base + e] : 0u;
+        if (FIRST) rp[j] = (u64)(u32)(base + e + 1) | ((u64)(valid ? P.prev_in[base + e] : 0u) << 32);
+        else rp[j] = valid ? P.rp_in[base + e] : 0ull;
         lc[j] = valid ? (u32)P.lcp_in[base + e] : 0u;
     }
-#endif
 #pragma unroll
     for (int j = 0; j < FS_ITEMS; ++j) {
         const bool valid = lb + (u32)j * 64 < cnt;
@@ -134,10 +130,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TDC_FS_WPE,
     }
     __syncthreads();
     u32 dst[FS_ITEMS];
+    u32* stage32 = (u32*)stage;
     // stream 1: the destination index itself (its bucket gives every slot of the sorted tile its global address)
 #pragma unroll
     for (int j = 0; j < FS_ITEMS; ++j) {
-        if (lb + (u32)j * 64 < cnt) { pos[j] += tcnt[(k[j] >> P.shift) & (D - 1)]; stage[pos[j]] = k[j]; }
+        if (lb + (u32)j * 64 < cnt) { pos[j] += tcnt[(k[j] >> P.shift) & (D - 1)]; stage32[pos[j]] = k[j]; }
     }
     __syncthreads();
 #pragma unroll
@@ -145,51 +142,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TDC_FS_WPE,
         const u32 sp = (u32)r * 256 + threadIdx.x;
         dst[r] = 0xFFFFFFFFu;
         if (sp < cnt) {
-            const u32 key = stage[sp];
+            const u32 key = stage32[sp];
             dst[r] = gbase[(key >> P.shift) & (D - 1)] + sp;
             P.idx_out[dst[r]] = key;
         }
     }
     __syncthreads();
-    // stream 2: rank
+    // stream 2: rank and predecessor as one 8-byte word
 #pragma unroll
-    for (int j = 0; j < FS_ITEMS; ++j) {
-        const u32 e = lb + (u32)j * 64;
-#if TDC_FS_PRELOAD
-        if (e < cnt) stage[pos[j]] = rk[j];
-#else
-        if (e < cnt) stage[pos[j]] = FIRST ? (u32)(base + e + 1) : P.rank_in[base + e];
-#endif
-    }
+    for (int j = 0; j < FS_ITEMS; ++j) if (lb + (u32)j * 64 < cnt) stage[pos[j]] = rp[j];
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < FS_ITEMS; ++r) if (dst[r] != 0xFFFFFFFFu) P.rank_out[dst[r]] = stage[(u32)r * 256 + threadIdx.x];
+    for (int r = 0; r < FS_ITEMS; ++r) if (dst[r] != 0xFFFFFFFFu) P.rp_out[dst[r]] = stage[(u32)r * 256 + threadIdx.x];
     __syncthreads();
-    // stream 3: predecessor in the suffix array
-#pragma unroll
-    for (int j = 0; j < FS_ITEMS; ++j) {
-        const u32 e = lb + (u32)j * 64;
-#if TDC_FS_PRELOAD
-        if (e < cnt) stage[pos[j]] = pv[j];
-#else
-        if (e < cnt) stage[pos[j]] = P.prev_in[base + e];
-#endif
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < FS_ITEMS; ++r) if (dst[r] != 0xFFFFFFFFu) P.prev_out[dst[r]] = stage[(u32)r * 256 + threadIdx.x];
-    __syncthreads();
-    // stream 4: LCP bytes
+    // stream 3: LCP bytes
     u8* stage8 = (u8*)stage;
 #pragma unroll
-    for (int j = 0; j < FS_ITEMS; ++j) {
-        const u32 e = lb + (u32)j * 64;
-#if TDC_FS_PRELOAD
-        if (e < cnt) stage8[pos[j]] = (u8)lc[j];
-#else
-        if (e < cnt) stage8[pos[j]] = P.lcp_in[base + e];
-#endif
-    }
+    for (int j = 0; j < FS_ITEMS; ++j) if (lb + (u32)j * 64 < cnt) stage8[pos[j]] = (u8)lc[j];
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < FS_ITEMS; ++r) if (dst[r] != 0xFFFFFFFFu) P.lcp_out[dst[r]] = stage8[(u32)r * 256 + threadIdx.x];
@@ -198,21 +167,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TDC_FS_WPE,
 // After the partition by the top 2 * DB index bits, window w holds exactly the records of the positions [w * W, (w + 1) * W) (position
 // n - 1 = sa[0] has no record).  One workgroup per window: each array is scattered into an LDS image of the window and leaves as whole
 // lines.
-__global__ __launch_bounds__(256) void fs_image_kernel(const u32* __restrict__ idx, const u32* __restrict__ rank, const u32* __restrict__ prev,
-                                                        const u8* __restrict__ lcp, size_t m, u32 W, u32* __restrict__ isa, u32* __restrict__ phi,
-                                                        u32* __restrict__ plcp, u32* __restrict__ d_max) {
+__global__ __launch_bounds__(256) void fs_image_kernel(const u32* __restrict__ idx, const u64* __restrict__ rp, const u8* __restrict__ lcp, size_t m, u32 W,
+                                                        u32* __restrict__ isa, u32* __restrict__ phi, u32* __restrict__ plcp, u32* __restrict__ d_max) {
     __shared__ u32 img[FS_WMAX];
     const size_t base = (size_t)blockIdx.x * W;
     const size_t end = (base + W < m) ? base + W : m;
-    for (size_t j = base + threadIdx.x; j < end; j += 256) img[idx[j] & (W - 1)] = rank[j];
+    u32 mx = 0;
+    for (size_t j = base + threadIdx.x; j < end; j += 256) img[idx[j] & (W - 1)] = (u32)rp[j];
     __syncthreads();
     for (size_t q = base + threadIdx.x; q < end; q += 256) isa[q] = img[q - base];
     __syncthreads();
-    for (size_t j = base + threadIdx.x; j < end; j += 256) img[idx[j] & (W - 1)] = prev[j];
+    for (size_t j = base + threadIdx.x; j < end; j += 256) img[idx[j] & (W - 1)] = (u32)(rp[j] >> 32);     // (the window's records are still in L2)
     __syncthreads();
     for (size_t q = base + threadIdx.x; q < end; q += 256) phi[q] = img[q - base];
     __syncthreads();
-    u32 mx = 0;
     for (size_t j = base + threadIdx.x; j < end; j += 256) { const u32 l = lcp[j]; img[idx[j] & (W - 1)] = l; mx = max(mx, l); }
     __syncthreads();
     for (size_t q = base + threadIdx.x; q < end; q += 256) plcp[q] = img[q - base];
@@ -255,8 +223,7 @@ void build_isa_phi_plcp_fused(Ctx& c, const u32* sa, const u8* lcp8, size_t n, u
     const int db = (bits - 16 > 13) ? 9 : 8;
     const u32 D = 1u << db;
     u32* idx[2] = { c.arena.get<u32>(m), c.arena.get<u32>(m) };
-    u32* rk[2] = { c.arena.get<u32>(m), c.arena.get<u32>(m) };
-    u32* pv[2] = { c.arena.get<u32>(m), c.arena.get<u32>(m) };
+    u64* rp[2] = { c.arena.get<u64>(m), c.arena.get<u64>(m) };
     u8* lc[2] = { c.arena.get<u8>(m + 8), c.arena.get<u8>(m + 8) };
     const u32* seg_start = ss_first_segment(c, m);
     u32 nseg = 1;
@@ -266,9 +233,9 @@ void build_isa_phi_plcp_fused(Ctx& c, const u32* sa, const u8* lcp8, size_t n, u
         SegTables Tb;
         ss_level_tables(c, seg_start, nseg, m, D, Tb);
         FSLevel P;
-        if (l == 0) { P.idx_in = sa + 1; P.rank_in = nullptr; P.prev_in = sa; P.lcp_in = lcp8 + 1; }
-        else { P.idx_in = idx[0]; P.rank_in = rk[0]; P.prev_in = pv[0]; P.lcp_in = lc[0]; }
-        P.idx_out = idx[l]; P.rank_out = rk[l]; P.prev_out = pv[l]; P.lcp_out = lc[l];
+        if (l == 0) { P.idx_in = sa + 1; P.rp_in = nullptr; P.prev_in = sa; P.lcp_in = lcp8 + 1; }
+        else { P.idx_in = idx[0]; P.rp_in = rp[0]; P.prev_in = nullptr; P.lcp_in = lc[0]; }
+        P.idx_out = idx[l]; P.rp_out = rp[l]; P.lcp_out = lc[l];
         P.counts = Tb.counts; P.blk_seg = Tb.blk_seg; P.blk_start = Tb.blk_start; P.seg_start = seg_start;
         P.nseg = nseg; P.R = Tb.R; P.shift = bits - db * (l + 1);
         const u32 rows = Tb.rows;
@@ -296,7 +263,7 @@ void build_isa_phi_plcp_fused(Ctx& c, const u32* sa, const u8* lcp8, size_t n, u
         const u32 W = 1u << (bits - 2 * db);
         if (W > FS_WMAX) throw HipError{hipErrorUnknown, "fused scatter: window larger than the LDS image", (int)__LINE__};
         Ctx::ProfScope prof(c, K_WINDOW_SCATTER, (u64)m * 25);
-        fs_image_kernel<<<cdiv(m, W), 256, 0, s>>>(idx[1], rk[1], pv[1], lc[1], m, W, isa, phi, plcp, d_maxlcp);
+        fs_image_kernel<<<cdiv(m, W), 256, 0, s>>>(idx[1], rp[1], lc[1], m, W, isa, phi, plcp, d_maxlcp);
         LAUNCH_CHECK();
         fs_first_kernel<<<1, 1, 0, s>>>(sa, n, isa, phi, plcp);
         LAUNCH_CHECK();
