@@ -8,7 +8,9 @@ host memory.  Both transfers are INSIDE the timed region; `value` = input bytes 
   N = 1 : the configuration the metric is quoted on: 2*10^9 B English-like text (SURVEY.md 8d generator, seed 42),
           threshold 2, flatten 1, through the product's entry point tdc_gpu_lcpcomp_compress_into.
           Extra keys (never `value`): "hbm_resident" = the same steps without the two transfers (device time of the
-          same calls), "configs1_256MiB" = BASELINE.json configs[1] (256 MiB) through the same entry point.
+          same calls), "configs1_256MiB" = BASELINE.json configs[1] (256 MiB) through the same entry point,
+          "configs2_dna_1e9" = BASELINE.json configs[2] (10^9 B DNA, LCPCompressor + ArithmeticCoder, threshold 5) through
+          the same entry point, its stream checked against the CPU oracle on a 32 MiB DNA sample.
   N > 1 : BASELINE.json configs[4]: one process per GPU (torch.distributed, backend nccl = RCCL); every rank compresses
           its own 2*10^9 B shard (seed 42 + rank: weak scaling), the per-shard streams are gathered on rank 0 over xGMI
           (grouped point-to-point) and rank 0 copies the block container to its host memory.
@@ -31,7 +33,8 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 STAT_KEYS = ("out_len", "factors", "maxlcp", "num_flattened", "sa_rounds", "levels", "mis_rounds", "flatten_rounds", "pushes",
-             "arena_bytes", "sa_sorted_elems", "sa_init_syms", "small_levels", "purges", "window_pass", "window_lcut")
+             "arena_bytes", "sa_sorted_elems", "sa_init_syms", "small_levels", "purges", "window_pass", "window_lcut",
+             "sa_key_words", "sa_text_rounds", "sa_mode", "sa_overlapped")
 
 
 def parse_args():
@@ -45,7 +48,8 @@ def parse_args():
     ap.add_argument("--cpu-sample", type=int, default=1 << 26, help="bytes of the workload the single-core CPU baseline is timed on")
     ap.add_argument("--cpu-multi-sample", type=int, default=1 << 25, help="bytes per process of the multi-core CPU figure")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the 256 MiB extra figure")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra figures (256 MiB English, 10^9 B DNA)")
+    ap.add_argument("--dna-sample", type=int, default=1 << 25, help="bytes of DNA text the oracle compresses for the configs[2] check")
     return ap.parse_args()
 
 
@@ -57,10 +61,11 @@ import numpy as np
 import tudocomp_amd as T
 from oracle import oracle as O
 gen, seed, m, thr = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+coder = sys.argv[5] if len(sys.argv) > 5 else "huff"
 text = (T.gen_english if gen == "english" else T.gen_dna)(m, seed)
 sample = np.concatenate([text, np.zeros(1, dtype=np.uint8)])
 t0 = time.perf_counter()
-out, st = O.lcpcomp_huff_compress(sample, thr, 1)
+out, st = (O.lcpcomp_arith_compress if coder == "arith" else O.lcpcomp_huff_compress)(sample, thr, 1)
 dt = time.perf_counter() - t0
 print("%%.6f %%d %%s" %% (dt, len(out), hashlib.sha256(out).hexdigest()))
 """
@@ -116,7 +121,15 @@ def cpu_baseline(args, seed):
         res["multi_core"] = {"value": round(procs * m2 / 1e6 / dtm, 3), "unit": "MB/s", "cores": procs,
                              "sample": "%d processes x %d-byte independent shards (seeds %d..), wall %.1f s incl. process start + text generation"
                                        % (procs, m2, seed + 1000, dtm)}
-    return res, (m1, int(len1), sha1)
+    dna_ref = None
+    if not args.no_extra and args.gen == "english" and args.size > (1 << 30):
+        # configs[2] check: the oracle's LCPCompressor<ArithmeticCoder> stream of a DNA sample (threshold 5), compared with the GPU's below
+        md = args.dna_sample
+        q = subprocess.Popen([sys.executable, "-c", code, "dna", "7", str(md), "5", "arith"], stdout=subprocess.PIPE, text=True)
+        o = q.communicate()[0].split()
+        if q.returncode == 0 and len(o) == 3:
+            dna_ref = (md, int(o[1]), o[2], float(o[0]))
+    return res, (m1, int(len1), sha1), dna_ref
 
 
 def main():
@@ -133,9 +146,9 @@ def main():
     seed0 = 42 if args.gen == "english" else 7
     seed = seed0 + rank
 
-    cpu_res = cpu_ref = None
+    cpu_res = cpu_ref = dna_ref = None
     if world == 1 and not args.no_cpu_baseline:
-        cpu_res, cpu_ref = cpu_baseline(args, seed)      # before any GPU initialisation in this process
+        cpu_res, cpu_ref, dna_ref = cpu_baseline(args, seed)      # before any GPU initialisation in this process
 
     import hashlib
     import numpy as np
@@ -298,6 +311,28 @@ def main():
             line["configs1_256MiB"] = {"value": round(m / 1e6 / t, 2), "unit": "MB/s", "ms_per_step": round(t * 1e3, 3),
                                        "device_only_ms": round(st2["ms_total"] - st2["ms_h2d"] - st2["ms_d2h"], 3), "out_len": ol2,
                                        "note": "BASELINE configs[1] through the same end-to-end entry point, 3 steps after 1 warm-up"}
+        if world == 1 and not args.no_extra and args.gen == "english" and N > (1 << 30):
+            # BASELINE.json configs[2]: 10^9 B DNA (sigma = 4), LCPCompressor + ArithmeticCoder, threshold 5 (the compressor's default)
+            md = 1_000_000_000
+            T.gen_dna(md, 7, out=h_text.a)
+            h_text.a[md] = 0
+            ts, st3, ol3 = [], None, 0
+            for i in range(3):
+                t1 = time.perf_counter()
+                ol3, st3 = ctx.lcpcomp_compress_into(h_text, md + 1, h_out, 5, 1, T.CODER_ARITH)
+                ts.append(time.perf_counter() - t1)
+            t = sum(ts[1:]) / 2
+            dna = {"value": round(md / 1e6 / t, 2), "unit": "MB/s", "ms_per_step": round(t * 1e3, 3), "out_len": ol3,
+                   "stages_ms": {k2[3:]: round(v, 2) for k2, v in st3.items() if k2.startswith("ms_")},
+                   "stats": {k2: st3[k2] for k2 in ("factors", "maxlcp", "levels", "small_levels", "purges", "sa_key_words", "sa_mode")},
+                   "note": "BASELINE configs[2] (SURVEY 8d DNA generator, seed 7) through the same end-to-end entry point, 2 steps after 1 warm-up"}
+            if dna_ref is not None:
+                m3, want_len3, want_sha3, cpu_s = dna_ref
+                sample = np.concatenate([h_text.a[:m3], np.zeros(1, dtype=np.uint8)])
+                got3, _ = ctx.lcpcomp_compress(sample, 5, 1, T.CODER_ARITH)
+                dna["bit_exact_vs_oracle_on_sample"] = bool(len(got3) == want_len3 and hashlib.sha256(got3).hexdigest() == want_sha3)
+                dna["sample"] = "first %d bytes of the DNA text; oracle (1 core) %.1f s" % (m3, cpu_s)
+            line["configs2_dna_1e9"] = dna
         print(json.dumps(line))
     ctx.close()
     if world > 1:

@@ -81,6 +81,11 @@ int  tdc_gpu_ctx_create(int device, tdc_gpu_ctx** ctx);
 void tdc_gpu_ctx_destroy(tdc_gpu_ctx* ctx);
 /* Pre-size the device arena for texts up to n bytes (optional; otherwise grown on demand). */
 int  tdc_gpu_ctx_reserve(tdc_gpu_ctx* ctx, size_t n);
+/* Device memory a context holds while it works on a text of n bytes (its arena; 112 bytes per text byte + 192 MiB), and what the
+ * device has: callers that place several contexts on one device (block mode, one process per GPU next to RCCL buffers) size
+ * their shards with it.  A call whose arena does not fit fails with TDC_GPU_ERR_OOM and a message that names both numbers. */
+size_t tdc_gpu_arena_bytes(size_t n);
+int  tdc_gpu_device_memory(int device, size_t* free_bytes, size_t* total_bytes);
 /* Live kernel timing for bench.py's roofline: when enabled, HIP events are recorded (on the launching stream) around
  * every launch of the instrumented kernels; tdc_gpu_ctx_kernel_profile() returns the sums since the last reset.
  * idx enumerates the instrumented kernel classes from 0; the function returns the class name, or NULL once idx is

@@ -59,6 +59,55 @@ def test_gather_to_rank0_world2(tmp_path):
         assert O.unescape(O.lcpcomp_huff_decompress(payload)) == shard
 
 
+def _shard4(rank):
+    import tudocomp_amd as T
+    if rank == 2:
+        return b""                                                        # an empty shard (fewer blocks than ranks)
+    return T.gen_english(15000 + 1234 * rank + (7 if rank == 3 else 0), 142 + rank).tobytes()
+
+
+def _worker4(rank, world, port, tmpdir):
+    from oracle import oracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        shard = _shard4(rank)
+        stream = O.lcpcomp_huff_compress(O.escape(shard), 2, 1)[0] if shard else b""
+        buf = torch.zeros(len(stream) + 64, dtype=torch.uint8)
+        if stream:
+            buf[:len(stream)] = torch.from_numpy(np.frombuffer(stream, dtype=np.uint8).copy())
+        sizes, bufs = blocks.gather_streams(dist, torch, buf, len(stream), rank, world, torch.device("cpu"))
+        assert sizes[rank] == len(stream) and len(sizes) == world
+        raw = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(raw, torch.tensor([len(shard)], dtype=torch.int64))
+        if rank == 0:
+            blob = blocks.pack_container([int(r.item()) for r in raw], [b.numpy().tobytes() for b in bufs])
+            with open(os.path.join(tmpdir, "container4.bin"), "wb") as f:
+                f.write(blob)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_to_rank0_world4_with_empty_and_ragged_shards(tmp_path):
+    """configs[4] rehearsed at world size 4 on the CPU (gloo): one rank has nothing to send, one has a ragged shard; the grouped
+    point-to-point gather must still deliver every stream to rank 0 in rank order."""
+    world = 4
+    mp.spawn(_worker4, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    from oracle import oracle as O
+    parts = blocks.unpack_container(open(tmp_path / "container4.bin", "rb").read())
+    assert len(parts) == world
+    for r, (raw_len, payload) in enumerate(parts):
+        shard = _shard4(r)
+        assert raw_len == len(shard)
+        if shard:
+            assert payload == O.lcpcomp_huff_compress(O.escape(shard), 2, 1)[0]
+            assert O.unescape(O.lcpcomp_huff_decompress(payload)) == shard
+        else:
+            assert payload == b""
+
+
 def test_container_roundtrip_and_ranges():
     parts = [b"", b"abc", bytes(range(256))]
     blob = blocks.pack_container([0, 10, 300], parts)

@@ -58,6 +58,44 @@ def test_ascii_coder_decompress(tmp_path):
     assert out.read_bytes() == data
 
 
+def test_host_decoders_under_asan(tmp_path):
+    """The host decoders (token-stream parse, chain resolution, Huffman / SLE / ASCII / gamma coders of host/tdc_coders.hpp) parse
+    untrusted streams: the AddressSanitizer + UBSan build of the command line decodes valid streams of every coder and a series of
+    damaged ones (truncated, bit-flipped) without a sanitizer report -- a damaged stream may be refused or decode to something else."""
+    host = os.path.join(ROOT, "tudocomp_amd", "host")
+    subprocess.check_call(["make", "-s", "-C", host, "asan"])
+    tdc_asan = os.path.join(ROOT, "tudocomp_amd", "bin", "tdc_asan")
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:exitcode=86", UBSAN_OPTIONS="halt_on_error=1:exitcode=87")
+    data = T.gen_english(4000, 9).tobytes() + b"\x00\xff xyz " * 5
+    text = O.escape(data)
+    streams = [
+        (b"lcpcomp(coder=huff,threshold=2)%", O.lcpcomp_huff_compress(text, 2, 1)[0]),
+        (b"lcpcomp(coder=ascii,threshold=3)%", O.lcpcomp_ascii_compress(text, 3, 1)[0]),
+        (b"lcpcomp(coder=sle,threshold=3)%", O.lcpcomp_sle_compress(text, 3, 1, 3)[0]),
+        (b"lz78(coder=gamma)%", O.lz78_gamma_compress(data)),
+    ]
+    import random
+    rnd = random.Random(5)
+    for i, (hdr, payload) in enumerate(streams):
+        f = tmp_path / ("s%d.tdc" % i)
+        f.write_bytes(hdr + payload)
+        out = tmp_path / ("s%d.out" % i)
+        r = subprocess.run([tdc_asan, "-d", "-f", "-o", str(out), str(f)], capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr
+        assert out.read_bytes() == data
+        for trial in range(12):                                   # damaged variants: any exit status but the sanitizers'
+            bad = bytearray(payload)
+            if trial % 3 == 0:
+                bad = bad[:rnd.randrange(0, len(bad))]
+            else:
+                for _ in range(1 + trial % 4):
+                    bad[rnd.randrange(len(bad))] ^= 1 << rnd.randrange(8)
+            g = tmp_path / "bad.tdc"
+            g.write_bytes(hdr + bytes(bad))
+            r = subprocess.run([tdc_asan, "-d", "-f", "-o", str(tmp_path / "bad.out"), str(g)], capture_output=True, text=True, env=env)
+            assert r.returncode not in (86, 87) and "Sanitizer" not in r.stderr, (hdr, trial, r.stderr[-2000:])
+
+
 @pytest.mark.parametrize("algo,k", [("lcpcomp(coder=sle,threshold=3)", 3), ("lcpcomp(coder=sle(kmer=2),threshold=3)", 2),
                                     ("lcpcomp(coder=sle(1),threshold=3)", 1), ("lcpcomp(coder=sle(kmer=5),threshold=3)", 5)])
 def test_sle_coder_decompress(tmp_path, algo, k):

@@ -39,6 +39,37 @@ def test_blocks_compress_payloads_equal_single_block_streams(gpu_ctx, block_size
     assert blocks.decompress_container(blob, lambda s: O.unescape(O.lcpcomp_huff_decompress(s))) == data
 
 
+def test_blocks_two_workers_on_one_device(gpu_ctx):
+    """devices = [0, 0]: the threaded branch of tdc_gpu_blocks_compress (one host thread + one context per listed device, blocks
+    handed out from a shared counter) runs on the ONE GPU of the test box -- the same code that spreads blocks over eight devices.
+    Seven ragged blocks; every payload must equal the oracle's stream of its block, whichever worker took it."""
+    data = _data()
+    block_size = 70001
+    blob, st = T.blocks_compress(data, block_size, threshold=2, flatten=1, devices=[0, 0])
+    parts = blocks.unpack_container(blob)
+    want_parts = [data[o:o + block_size] for o in range(0, len(data), block_size)]
+    assert len(parts) == len(want_parts) >= 5
+    for k, ((raw_len, payload), part) in enumerate(zip(parts, want_parts)):
+        assert raw_len == len(part)
+        want, _ = O.lcpcomp_huff_compress(O.escape(part), 2, 1)
+        assert bytes(payload) == want, k
+    assert gpu_ctx.blocks_decompress(blob) == data
+    # a single listed device with more blocks than devices: the library adds a second worker on its own when memory allows
+    blob1, _ = T.blocks_compress(data, block_size, threshold=2, flatten=1, devices=[0])
+    assert blob1 == blob
+
+
+def test_arena_budget_is_reported(gpu_ctx):
+    """tdc_gpu_arena_bytes / tdc_gpu_device_memory: what a shard costs and what the device has"""
+    L = T._native.load()
+    assert L.tdc_gpu_arena_bytes(2_000_000_001) == 112 * 2_000_000_001 + (192 << 20)
+    import ctypes
+    fr, tot = ctypes.c_size_t(), ctypes.c_size_t()
+    assert L.tdc_gpu_device_memory(0, ctypes.byref(fr), ctypes.byref(tot)) == 0
+    assert tot.value > 200e9 and fr.value <= tot.value
+    assert L.tdc_gpu_device_memory(99, ctypes.byref(fr), ctypes.byref(tot)) != 0
+
+
 def test_blocks_edge_cases(gpu_ctx):
     blob, st = T.blocks_compress(b"", 4096, threshold=2)
     assert blocks.unpack_container(blob) == [] and st == []

@@ -63,6 +63,15 @@ def _gen_text(name):
     return data
 
 
+@pytest.mark.parametrize("k", KATS["bwt"], ids=lambda k: k["source"][:24])
+def test_suffix_array_bwt_kat(k):
+    """the one suffix-array vector the reference's tests hold: the BWT of a 0-terminated view (sa[j] != 0 ? t[sa[j] - 1] : t[n - 1])"""
+    text = bytes.fromhex(k["text_hex"])
+    sa = O.suffix_array(text)
+    bwt = bytes(text[int(i) - 1] if int(i) != 0 else text[-1] for i in sa)
+    assert bwt == bytes.fromhex(k["bwt_hex"])
+
+
 def test_survey_example_bytes_and_factors():
     e = ANCH["example"]
     text = O.escape(e["text"].encode())

@@ -55,17 +55,25 @@ def unescape(data):
     return out[:n].tobytes()
 
 
+def _gen_target(n, out):
+    """the array a native generator fills: a fresh one, or the caller's -- which must really hold n contiguous bytes"""
+    if out is None:
+        return np.empty(n, dtype=np.uint8)
+    if not isinstance(out, np.ndarray) or out.dtype != np.uint8 or out.ndim != 1 or not out.flags.c_contiguous or out.size < n:
+        raise ValueError("out must be a contiguous one-dimensional uint8 array of at least n bytes")
+    return out
+
+
 def gen_english(n, seed=42, out=None):
     """SURVEY.md 8d English-like generator; `out` (optional): a uint8 array of >= n bytes to fill in place."""
-    if out is None:
-        out = np.empty(n, dtype=np.uint8)
+    out = _gen_target(n, out)
     _native.load().tdc_gen_english(_ptr(out), n, seed)
     return out[:n]
 
 
 def gen_dna(n, seed=7, out=None):
-    if out is None:
-        out = np.empty(n, dtype=np.uint8)
+    """SURVEY.md 8d DNA generator; `out` as in gen_english."""
+    out = _gen_target(n, out)
     _native.load().tdc_gen_dna(_ptr(out), n, seed)
     return out[:n]
 

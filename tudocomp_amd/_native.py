@@ -25,6 +25,7 @@ SYMBOLS = [
     "tdc_gpu_encode_sle",
     "tdc_gpu_lcpcomp_decompress_coder",
     "tdc_escape", "tdc_unescape", "tdc_huffman_table", "tdc_huffman_selfcheck", "tdc_gpu_blocks_count", "tdc_gpu_blocks_compress", "tdc_gpu_blocks_decompress", "tdc_gpu_device_count", "tdc_gen_english", "tdc_gen_dna",
+    "tdc_gpu_arena_bytes", "tdc_gpu_device_memory",
 ]
 
 
@@ -80,6 +81,9 @@ def load():
     L.tdc_gpu_lz78_compress.argtypes = [vp, vp, sz, i32, pvp, psz, ctypes.POINTER(Stats)]
     L.tdc_gpu_lzss_lcp_compress.argtypes = [vp, vp, sz, u32, i32, pvp, psz, ctypes.POINTER(Stats)]
     L.tdc_gpu_lzss_lcp_factorize.argtypes = [vp, vp, sz, u32, pvp, pvp, pvp, psz]
+    L.tdc_gpu_arena_bytes.argtypes = [sz]
+    L.tdc_gpu_arena_bytes.restype = sz
+    L.tdc_gpu_device_memory.argtypes = [i32, psz, psz]
     L.tdc_gpu_lcpcomp_bound.argtypes = [sz]
     L.tdc_gpu_lcpcomp_bound.restype = sz
     L.tdc_gpu_lcpcomp_bound_coder.argtypes = [sz, i32]

@@ -102,6 +102,21 @@ int lcpcomp_enc_coder(int coder) {
     throw ArgError{TDC_GPU_ERR_UNSUPPORTED, "lcpcomp: coder must be huff, arithmetic, ascii or sle"};
 }
 
+// the context's arena for a call; a device that cannot hold it is reported with both numbers instead of a bare allocation failure
+void reserve_arena(Ctx& c, size_t bytes) {
+    if (c.arena.size < bytes) {
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr + c.arena.size < bytes) {
+            static thread_local char msg[256];
+            snprintf(msg, sizeof(msg), "device %d has %.1f GB free of %.1f GB, this call needs an arena of %.1f GB (112 bytes per text byte + 192 MiB): "
+                     "use smaller blocks (tdc_gpu_arena_bytes)", c.device, (double)(fr + c.arena.size) / 1e9, (double)tot / 1e9, (double)bytes / 1e9);
+            throw ArgError{TDC_GPU_ERR_OOM, msg};
+        }
+        (void)hipGetLastError();
+    }
+    c.ensure_arena(bytes);
+}
+
 void check_text_args(const void* text, size_t n) {
     if (!text) throw ArgError{TDC_GPU_ERR_ARG, "text is NULL"};
     if (n == 0) throw ArgError{TDC_GPU_ERR_NO_SENTINEL, "empty view: the text must end with a 0 sentinel"};
@@ -279,8 +294,9 @@ int tdc_gpu_ctx_create(int device, tdc_gpu_ctx** out) {
     if (!ctx) return TDC_GPU_ERR_OOM;
     ctx->c.device = device;
     ctx->c.wpre = &ctx->pre;
+    DeviceGuard dg(device);                      // (the caller's current device is restored on every exit path)
     try {
-        HIP_TRY(hipSetDevice(device));
+        HIP_TRY(dg.enter());
         HIP_TRY(hipStreamCreateWithFlags(&ctx->c.stream, hipStreamNonBlocking));
         for (auto& e : ctx->c.ev) HIP_TRY(hipEventCreate(&e));
         HIP_TRY(hipStreamCreateWithFlags(&ctx->c.copy_stream, hipStreamNonBlocking));
@@ -334,7 +350,8 @@ int tdc_gpu_ctx_create(int device, tdc_gpu_ctx** out) {
 
 void tdc_gpu_ctx_destroy(tdc_gpu_ctx* ctx) {
     if (!ctx) return;
-    (void)hipSetDevice(ctx->c.device);
+    DeviceGuard dg(ctx->c.device);
+    (void)dg.enter();
     if (ctx->c.stream) (void)hipStreamSynchronize(ctx->c.stream);
     if (ctx->c.arena.base) (void)hipFree(ctx->c.arena.base);
     if (ctx->c.pinned) (void)hipHostFree(ctx->c.pinned);
@@ -374,7 +391,8 @@ const char* tdc_gpu_ctx_kernel_profile(const tdc_gpu_ctx* ctx, int idx, double* 
         "sa_groups_kernel", "sa_build_keys_kernel", "phi_kernel", "plcp_kernel", "cand_kernels",
         "level_init_kernel", "mis_round_kernel", "resolve_kernel", "push_kernel", "apply_kernel", "pool_kernels", "small_level_kernel", "window_levels_kernel",
         "flatten_round_kernel", "gaps_kernel", "literal_hist_kernel", "tile_bits_kernel", "pack_kernel", "extract_kernels",
-        "ss_leaf_sort_kernel", "sa_local_sort_kernel", "window_scatter_kernels" };
+        "ss_leaf_sort_kernel", "sa_local_sort_kernel", "window_scatter_kernels",
+        "ws_leaf_sort_kernel", "ws_leaf_count_kernel", "ws_run_kernels", "fs_image_kernel" };
     if (!ctx || idx < 0 || idx >= K_CLASS_COUNT) return nullptr;
     const KernelProfile& k = ctx->c.kprof[idx];
     if (ms) *ms = k.ms;
@@ -383,8 +401,19 @@ const char* tdc_gpu_ctx_kernel_profile(const tdc_gpu_ctx* ctx, int idx, double* 
     return names[idx];
 }
 
+size_t tdc_gpu_arena_bytes(size_t n) { return arena_need(n); }
+
+int tdc_gpu_device_memory(int device, size_t* free_bytes, size_t* total_bytes) {
+    if (!free_bytes || !total_bytes) return TDC_GPU_ERR_ARG;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) { (void)hipGetLastError(); return TDC_GPU_ERR_ARG; }
+    DeviceGuard dg(device);
+    if (dg.enter() != hipSuccess || hipMemGetInfo(free_bytes, total_bytes) != hipSuccess) { (void)hipGetLastError(); return TDC_GPU_ERR_HIP; }
+    return TDC_GPU_OK;
+}
+
 int tdc_gpu_ctx_reserve(tdc_gpu_ctx* ctx, size_t n) {
-    return guarded(ctx, [&] { ctx->c.ensure_arena(arena_need(n)); });
+    return guarded(ctx, [&] { reserve_arena(ctx->c, arena_need(n)); });
 }
 
 size_t tdc_gpu_lcpcomp_bound(size_t n) { return align_up(encode_bound(n) + 16, 8); }
@@ -400,7 +429,7 @@ int tdc_gpu_lcpcomp_compress_dev(tdc_gpu_ctx* ctx, const void* d_text, size_t n,
         if (!d_out || !out_len || ((uintptr_t)d_out & 7)) throw ArgError{TDC_GPU_ERR_ARG, "d_out must be non-NULL and 8-byte aligned"};
         Ctx& c = ctx->c;
         if (stats) memset(stats, 0, sizeof(*stats));
-        c.ensure_arena(arena_need(n));
+        reserve_arena(c, arena_need(n));
         Events ev(c);
         const int e0 = ev.tick();
         u8* dst = (u8*)d_out;
@@ -432,7 +461,7 @@ void compress_host(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, bool raw, ui
     Ctx& c = ctx->c;
     if (stats) memset(stats, 0, sizeof(*stats));
     // raw input: sized for a text without escapes first; the 0x00 / 0xFF bytes are counted on the device after the upload
-    c.ensure_arena(raw ? arena_need(n + 1) + n + 64 : arena_need(n));
+    reserve_arena(c, raw ? arena_need(n + 1) + n + 64 : arena_need(n));
     Events ev(c);
     const int e0 = ev.tick();
     u8* d_text;
@@ -444,7 +473,7 @@ void compress_host(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, bool raw, ui
         if (tn >= 0x7FFFFFFFull) throw ArgError{TDC_GPU_ERR_TOO_LARGE, "raw input too large: the escaped text must stay < 2^31 - 1 bytes"};
         if (c.arena.size < arena_need(tn) + n + 64) {                        // many escapes: a larger arena, upload once more
             HIP_TRY(hipStreamSynchronize(c.stream));
-            c.ensure_arena(arena_need(tn) + n + 64);
+            reserve_arena(c, arena_need(tn) + n + 64);
             d_raw = c.arena.get<u8>(n + 64);
             if (n) HIP_TRY(hipMemcpyAsync(d_raw, text, n, hipMemcpyHostToDevice, c.stream));
         }
@@ -570,7 +599,7 @@ namespace {
 void run_lzss_lcp(Ctx& c, const uint8_t* text, size_t n, uint32_t threshold, u8** d_text_out, DevArrays& A, tdc_gpu_stats* st, Events& ev) {
     if (threshold == 0) throw ArgError{TDC_GPU_ERR_ARG, "threshold must be >= 1"};
     if (text[n - 1] != 0) throw ArgError{TDC_GPU_ERR_NO_SENTINEL, "text does not end with a 0 sentinel"};
-    c.ensure_arena(arena_need(n));
+    reserve_arena(c, arena_need(n));
     u8* d_text = c.arena.get<u8>(n + 64);
     HIP_TRY(hipMemcpyAsync(d_text, text, n, hipMemcpyHostToDevice, c.stream));
     validate_device_text(c, d_text, n);
@@ -663,7 +692,7 @@ int tdc_gpu_lz78_compress(tdc_gpu_ctx* ctx, const uint8_t* in, size_t n, int cod
             "lz78: the left-over phrase ends in a byte >= 0x80; the reference encodes it as a signed char (undefined shifts) -- not reproduced"};
         // arena: pairs (5 B each) + tile sums + worst-case output (2*33+2*9 bits = 84 bits < 11 B per pair)
         const size_t cap = align_up(z * 11 + 64, 8);
-        c.ensure_arena(z * 5 + cap + ((size_t)64 << 20));
+        reserve_arena(c, z * 5 + cap + ((size_t)64 << 20));
         Events ev(c);
         const int e0 = ev.tick();
         u32* d_ids = c.arena.get<u32>(z + 1);
@@ -694,7 +723,7 @@ int tdc_gpu_sort_pairs_u64(tdc_gpu_ctx* ctx, uint64_t* keys, uint32_t* vals, siz
         if (n == 0) return;
         if (n >= 0xFFFFFFFFull) throw ArgError{TDC_GPU_ERR_TOO_LARGE, "at most 2^32 - 2 pairs"};
         Ctx& c = ctx->c;
-        c.ensure_arena(64 * n + ((size_t)256 << 20));
+        reserve_arena(c, 64 * n + ((size_t)256 << 20));
         u64* k[2] = { c.arena.get<u64>(n), c.arena.get<u64>(n) };
         u32* v[2] = { c.arena.get<u32>(n), c.arena.get<u32>(n) };
         HIP_TRY(hipMemcpyAsync(k[0], keys, n * 8, hipMemcpyHostToDevice, c.stream));
@@ -719,7 +748,7 @@ int tdc_gpu_textds(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, uint32_t* sa
         check_text_args(text, n);
         if (text[n - 1] != 0) throw ArgError{TDC_GPU_ERR_NO_SENTINEL, "text does not end with a 0 sentinel"};
         Ctx& c = ctx->c;
-        c.ensure_arena(arena_need(n));
+        reserve_arena(c, arena_need(n));
         u8* d_text = c.arena.get<u8>(n + 64);
         HIP_TRY(hipMemcpyAsync(d_text, text, n, hipMemcpyHostToDevice, c.stream));
         validate_device_text(c, d_text, n);
@@ -754,7 +783,7 @@ int tdc_gpu_lcpcomp_factorize(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, u
         if (text[n - 1] != 0) throw ArgError{TDC_GPU_ERR_NO_SENTINEL, "text does not end with a 0 sentinel"};
         Ctx& c = ctx->c;
         if (stats) memset(stats, 0, sizeof(*stats));
-        c.ensure_arena(arena_need(n));
+        reserve_arena(c, arena_need(n));
         Events ev(c);
         u8* d_text = c.arena.get<u8>(n + 64);
         HIP_TRY(hipMemcpyAsync(d_text, text, n, hipMemcpyHostToDevice, c.stream));
@@ -783,7 +812,7 @@ int tdc_gpu_flatten(tdc_gpu_ctx* ctx, size_t n, const uint32_t* pos, uint32_t* s
         if (z && (!pos || !src || !len)) throw ArgError{TDC_GPU_ERR_ARG, "factor arrays are NULL"};
         validate_factor_list(n, pos, src, len, z);
         Ctx& c = ctx->c;
-        c.ensure_arena(arena_need(n));
+        reserve_arena(c, arena_need(n));
         FactorSpace fs;
         fs.flen = c.arena.get<u32>(n); fs.owner = c.arena.get<u32>(n); fs.fsrc = c.arena.get<u32>(n);
         u32* d_pos = c.arena.get<u32>(z + 1), *d_src = c.arena.get<u32>(z + 1), *d_len = c.arena.get<u32>(z + 1);
@@ -855,7 +884,7 @@ static int encode_entry(tdc_gpu_ctx* ctx, int coder, const uint8_t* text, size_t
         if (z && (!pos || !src || !len)) throw ArgError{TDC_GPU_ERR_ARG, "factor arrays are NULL"};
         validate_factor_list(n, pos, src, len, z);
         Ctx& c = ctx->c;
-        c.ensure_arena(arena_need(n));
+        reserve_arena(c, arena_need(n));
         u8* d_text = c.arena.get<u8>(n + 64);
         HIP_TRY(hipMemcpyAsync(d_text, text, n, hipMemcpyHostToDevice, c.stream));
         FactorSpace fs;

@@ -11,6 +11,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -34,47 +35,76 @@ int tdc_gpu_blocks_compress(const int* devices, int ndev, const uint8_t* data, s
     if (block_size == 0 || block_size >= 0x7FFFFFFEull) return TDC_GPU_ERR_ARG;
     const size_t G = tdc_gpu_blocks_count(n, block_size);
     if (G > 0xFFFFFFFFull) return TDC_GPU_ERR_TOO_LARGE;
-    std::vector<uint8_t*> streams(G, nullptr);
-    std::vector<size_t> lens(G, 0);
-    std::atomic<size_t> next(0);
-    std::atomic<int> status(TDC_GPU_OK);
-    auto worker = [&](int device) {
-        tdc_gpu_ctx* ctx = nullptr;
-        int rc = tdc_gpu_ctx_create(device, &ctx);
-        if (rc) { int ok = TDC_GPU_OK; status.compare_exchange_strong(ok, rc); return; }
-        for (;;) {
-            const size_t k = next.fetch_add(1);
-            if (k >= G || status.load() != TDC_GPU_OK) break;
-            const size_t off = k * block_size, len = (off + block_size <= n) ? block_size : n - off;
-            rc = tdc_gpu_lcpcomp_compress_raw(ctx, data + off, len, threshold, flatten, coder, &streams[k], &lens[k], per_block ? &per_block[k] : nullptr);
-            if (rc) { int ok = TDC_GPU_OK; status.compare_exchange_strong(ok, rc); break; }
+    // nothing may leave this function but a status code: every C++ failure (allocation, thread creation) is mapped to one, the workers
+    // that did start are always joined, and the per-block streams are freed on every path
+    try {
+        std::vector<uint8_t*> streams(G, nullptr);
+        struct FreeStreams { std::vector<uint8_t*>& s; ~FreeStreams() { for (uint8_t* p : s) tdc_gpu_free(p); } } free_streams{streams};
+        std::vector<size_t> lens(G, 0);
+        std::atomic<size_t> next(0);
+        std::atomic<int> status(TDC_GPU_OK);
+        auto fail = [&](int rc) { int ok = TDC_GPU_OK; status.compare_exchange_strong(ok, rc); };
+        auto worker = [&](int device) noexcept {
+            try {
+                tdc_gpu_ctx* ctx = nullptr;
+                int rc = tdc_gpu_ctx_create(device, &ctx);
+                if (rc) { fail(rc); return; }
+                for (;;) {
+                    const size_t k = next.fetch_add(1);
+                    if (k >= G || status.load() != TDC_GPU_OK) break;
+                    const size_t off = k * block_size, len = (off + block_size <= n) ? block_size : n - off;
+                    rc = tdc_gpu_lcpcomp_compress_raw(ctx, data + off, len, threshold, flatten, coder, &streams[k], &lens[k], per_block ? &per_block[k] : nullptr);
+                    if (rc) { fail(rc); break; }
+                }
+                tdc_gpu_ctx_destroy(ctx);
+            } catch (...) { fail(TDC_GPU_ERR_INTERNAL); }
+        };
+        // One worker (host thread + context) per listed device.  Where blocks outnumber the devices and a device has room for two
+        // arenas, it gets a second worker: the upload of one block then overlaps the kernels of another (a context's calls are
+        // synchronous; two contexts on one device run on their own streams).
+        std::vector<int> slots(devices, devices + ndev);
+        if (G > (size_t)ndev) {
+            const size_t need = tdc_gpu_arena_bytes(block_size < n ? block_size + 1 : n + 1);
+            for (int d = 0; d < ndev; ++d) {
+                bool listed_before = false;
+                for (int e = 0; e < d; ++e) listed_before = listed_before || devices[e] == devices[d];
+                size_t free_b = 0, total_b = 0;
+                if (!listed_before && tdc_gpu_device_memory(devices[d], &free_b, &total_b) == TDC_GPU_OK && free_b / 2 > need + (need >> 4)) slots.push_back(devices[d]);
+            }
         }
-        tdc_gpu_ctx_destroy(ctx);
-    };
-    if (ndev == 1 || G <= 1) worker(devices[0]);
-    else {
-        std::vector<std::thread> th;
-        for (int d = 0; d < ndev && (size_t)d < G; ++d) th.emplace_back(worker, devices[d]);
-        for (auto& t : th) t.join();
-    }
-    int rc = status.load();
-    size_t total = MAGIC_LEN + 4 + 16 * G;
-    for (size_t k = 0; k < G; ++k) total += lens[k];
-    uint8_t* blob = nullptr;
-    if (rc == TDC_GPU_OK && !(blob = (uint8_t*)malloc(total ? total : 1))) rc = TDC_GPU_ERR_OOM;
-    if (rc == TDC_GPU_OK) {
-        memcpy(blob, MAGIC, MAGIC_LEN);
-        put_u32(blob + MAGIC_LEN, (uint32_t)G);
-        size_t dir = MAGIC_LEN + 4, pay = dir + 16 * G;
-        for (size_t k = 0; k < G; ++k) {
-            const size_t off = k * block_size, len = (off + block_size <= n) ? block_size : n - off;
-            put_u64(blob + dir, len); put_u64(blob + dir + 8, lens[k]); dir += 16;
-            memcpy(blob + pay, streams[k], lens[k]); pay += lens[k];
+        if (slots.size() > G) slots.resize(G ? G : 1);
+        if (slots.size() <= 1 || G <= 1) worker(slots[0]);
+        else {
+            std::vector<std::thread> th;
+            struct Joiner { std::vector<std::thread>& t; ~Joiner() { for (auto& x : t) if (x.joinable()) x.join(); } } joiner{th};
+            th.reserve(slots.size());
+            for (size_t i = 0; i < slots.size(); ++i) {
+                try { th.emplace_back(worker, slots[i]); }
+                catch (...) { fail(TDC_GPU_ERR_INTERNAL); break; }            // (the workers already running are joined by the guard)
+            }
         }
-        *out = blob; *out_len = total;
+        int rc = status.load();
+        size_t total = MAGIC_LEN + 4 + 16 * G;
+        for (size_t k = 0; k < G; ++k) total += lens[k];
+        uint8_t* blob = nullptr;
+        if (rc == TDC_GPU_OK && !(blob = (uint8_t*)malloc(total ? total : 1))) rc = TDC_GPU_ERR_OOM;
+        if (rc == TDC_GPU_OK) {
+            memcpy(blob, MAGIC, MAGIC_LEN);
+            put_u32(blob + MAGIC_LEN, (uint32_t)G);
+            size_t dir = MAGIC_LEN + 4, pay = dir + 16 * G;
+            for (size_t k = 0; k < G; ++k) {
+                const size_t off = k * block_size, len = (off + block_size <= n) ? block_size : n - off;
+                put_u64(blob + dir, len); put_u64(blob + dir + 8, lens[k]); dir += 16;
+                memcpy(blob + pay, streams[k], lens[k]); pay += lens[k];
+            }
+            *out = blob; *out_len = total;
+        }
+        return rc;
+    } catch (const std::bad_alloc&) {
+        return TDC_GPU_ERR_OOM;
+    } catch (...) {
+        return TDC_GPU_ERR_INTERNAL;
     }
-    for (size_t k = 0; k < G; ++k) tdc_gpu_free(streams[k]);
-    return rc;
 }
 
 int tdc_gpu_blocks_decompress(tdc_gpu_ctx* ctx, const uint8_t* blob, size_t len, int coder, uint8_t** out, size_t* out_len) {

@@ -88,6 +88,7 @@ enum KernelClass {
     K_SA_RANK_SCATTER, K_SA_BUILD_KEYS, K_PHI, K_PLCP, K_CAND,
     K_LEVEL_INIT, K_MIS_ROUND, K_RESOLVE, K_PUSH, K_APPLY, K_POOL, K_SMALL_LEVEL, K_WINDOW_LEVELS,
     K_FLATTEN_ROUND, K_ENC_GAPS, K_ENC_HIST, K_ENC_TILE_BITS, K_ENC_PACK, K_EXTRACT, K_SS_LEAF, K_SA_LOCAL_SORT, K_WINDOW_SCATTER,
+    K_WS_LEAF_SORT, K_WS_LEAF_COUNT, K_WS_RUN, K_FS_IMAGE,
     K_CLASS_COUNT
 };
 

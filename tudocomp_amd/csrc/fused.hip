@@ -262,7 +262,7 @@ void build_isa_phi_plcp_fused(Ctx& c, const u32* sa, const u8* lcp8, size_t n, u
     {
         const u32 W = 1u << (bits - 2 * db);
         if (W > FS_WMAX) throw HipError{hipErrorUnknown, "fused scatter: window larger than the LDS image", (int)__LINE__};
-        Ctx::ProfScope prof(c, K_WINDOW_SCATTER, (u64)m * 25);
+        Ctx::ProfScope prof(c, K_FS_IMAGE, (u64)m * 25);
         fs_image_kernel<<<cdiv(m, W), 256, 0, s>>>(idx[1], rp[1], lc[1], m, W, isa, phi, plcp, d_maxlcp);
         LAUNCH_CHECK();
         fs_first_kernel<<<1, 1, 0, s>>>(sa, n, isa, phi, plcp);

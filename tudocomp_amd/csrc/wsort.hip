@@ -1284,7 +1284,6 @@ int ws_sort_impl(Ctx& c, const WKeyGen* gen, u64* K1[2], u64* K2[2], u32* V[2], 
     {
         // Stage 0: the units of the leaves.  Kernel A sorts every unit by its first differing word; the counting kernel orders the runs
         // that are left (<= 256 members) by the next word and hands longer runs back as the units of the next stage.
-        Ctx::ProfScope prof(c, K_SS_LEAF, (u64)n * (PAIRS ? 2 * (4 + 8 * KW) : (4 + 8 * KW) + 6));
         const u32* cur_rng = U.unit_rng;
         const u32* cur_cls = U.cls_list;
         size_t cur_cap = U.cap;
@@ -1298,6 +1297,7 @@ int ws_sort_impl(Ctx& c, const WKeyGen* gen, u64* K1[2], u64* K2[2], u32* V[2], 
         u32* lc = c.arena.get<u32>(16);                          // [0..7]: per class |rlist|, |tlist|; [8..15]: next stage's units per class
         for (int stage = 0; stage < 8; ++stage) {
             if (wave_cnt[0] | wave_cnt[1] | wave_cnt[2] | wave_cnt[3]) {
+                Ctx::ProfScope prof(c, K_WS_RUN, 0);
                 A.unit_rng = cur_rng;
                 const u32* l0 = wave_list, *l1 = wave_list + cur_cap, *l2 = wave_list + 2 * cur_cap, *l3 = wave_list + 3 * cur_cap;
                 if (wave_cnt[0]) { ws_run_lane_kernel<32, PAIRS><<<cdiv(wave_cnt[0], 8), 256, 0, s>>>(A, l0, wave_cnt[0]); LAUNCH_CHECK(); }
@@ -1314,6 +1314,8 @@ int ws_sort_impl(Ctx& c, const WKeyGen* gen, u64* K1[2], u64* K2[2], u32* V[2], 
             u32* tl = c.arena.get<u32>(4 * cur_cap);
             HIP_TRY(hipMemsetAsync(lc, 0, 16 * sizeof(u32), s));
             A.unit_rng = cur_rng;
+            // (stage 0 sorts every record once: keys + position in, position + flag + LCP out; the later stages re-sort the long runs)
+            const int pa = c.prof_begin(K_WS_LEAF_SORT, stage == 0 ? (u64)n * (4 + 8 * KW + 6) : 0);
             for (int q = 0; q < 4; ++q) {
                 const u32 cnt = cur_cnt[q];
                 if (!cnt) continue;
@@ -1327,8 +1329,10 @@ int ws_sort_impl(Ctx& c, const WKeyGen* gen, u64* K1[2], u64* K2[2], u32* V[2], 
                 else ws_leaf_sort_kernel<KW, 16, 8, PAIRS><<<cnt, 8 * 64, 0, s>>>(A, lst, cnt, Q);
                 LAUNCH_CHECK();
             }
+            c.prof_end(pa);
             u32 hl[8];
             c.read_n(lc, hl, 8);
+            const int pb = c.prof_begin(K_WS_LEAF_COUNT, stage == 0 ? (u64)n * (8 + 4 + 1 + 4 + 2) : 0);
             HIP_TRY(hipMemsetAsync(e_rng[stage & 1], 0, 2 * (size_t)ecap2 * sizeof(u32), s));
             const WEmit E = { e_rng[stage & 1], ediv };
             const WEmit noE = { nullptr, 1 };
@@ -1358,6 +1362,7 @@ int ws_sort_impl(Ctx& c, const WKeyGen* gen, u64* K1[2], u64* K2[2], u32* V[2], 
                     count_pass(q, rl + q * cur_cap, nr, 0u, 0u, r2, E);
                 }
             }
+            c.prof_end(pb);
             ws_emit_compact_kernel<<<cdiv(ecap2, EC_TILE), 256, 0, s>>>(e_rng[stage & 1], ecap2, e_cls[stage & 1], ecap2, lc + 8);
             LAUNCH_CHECK();
             u32 he[EC_NCLS];

@@ -459,7 +459,7 @@ inline std::vector<std::string> registered_algorithms() {
              "lcpcomp(coder=ascii, comp=arrays, threshold=5, flatten=1)                   [MI355X; host decoder]",
              "lcpcomp(coder=sle(kmer=3), comp=arrays, threshold=5, flatten=1)             [MI355X; host decoder]",
              "lcpcomp(coder=..., comp=max_lcp | plcppeaks, ...)                           [MI355X]",
-             "lcpcomp(coder=..., comp=heap, ...)                                          [MI355X, sequential replay of the reference's heap: parity, not speed]",
+             "lcpcomp(coder=..., comp=heap, ...)                                          [MI355X, sequential replay of the reference's heap: a parity row, about a minute per MiB -- inputs of a few hundred KiB at most]",
              "lcpcomp(coder=arithmetic, comp=arrays, threshold=5, flatten=1)              [MI355X, compress only]",
              "lzss_lcp(coder=huff, threshold=3)                                           [MI355X, libtdc_gpu.so]",
              "lz78(coder=gamma)                                                           [host parse + MI355X gamma packer]" };
