@@ -334,6 +334,7 @@ int tdc_gpu_ctx_create(int device, tdc_gpu_ctx** out) {
         if (const char* m = getenv("TDC_GPU_WSORT_ROUNDS")) { const int v = atoi(m); ctx->c.wsort_rounds = v < 0 ? 0 : (v > 100 ? 100 : v); }
         if (const char* m = getenv("TDC_GPU_WSORT_SMALLRUN")) { ctx->c.wsort_small = atoi(m) ? 1 : 0; if (ctx->c.wsort_small) g_test_extra = true; }
         if (const char* m = getenv("TDC_GPU_WSORT_OVERLAP")) ctx->c.wsort_overlap = atoi(m) ? 1 : 0;
+        if (const char* m = getenv("TDC_GPU_WSORT_FUSE")) ctx->c.wsort_fuse = atoi(m) ? 1 : 0;
         if (const char* m = getenv("TDC_GPU_WSORT_TWO")) { const int v = atoi(m); ctx->c.wsort_two = (v >= 0 && v <= 2) ? v : 0; }
         if (const char* m = getenv("TDC_GPU_WSORT_LEAF")) ctx->c.wsort_leaf = atoi(m) == 1024 ? 1024 : 2048;
         if (const char* m = getenv("TDC_GPU_WSORT_PACK")) { const int v = atoi(m); ctx->c.wsort_pack = (v == 1024 || v == 4096) ? v : 2048; }

@@ -451,6 +451,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FMAX > 256 
 
 // ---- leaf sort ------------------------------------------------------------------------------------------------------------------------
 constexpr int WL_NW = 8;             // waves per leaf workgroup
+#ifndef WL_NBMAX
+#define WL_NBMAX 51
+#endif
 __device__ __forceinline__ u32 wl_rank(u32 d, bool valid, u32* mycnt, unsigned long long* M, u64 lanebit, u64 lt_mask) {
     const u64 peers = wave_match_lds(M, d, valid, lanebit);
     const u32 prefix = lds_load(&mycnt[d]);
@@ -549,6 +552,32 @@ __device__ __forceinline__ void wl_minmax(u64 (*red)[NW], const u64 (&k)[ROWS], 
     __syncthreads();
 }
 
+// the run of slot s in the head bitmap hb (bit m is set: end sentinel; bit 0 is set): 0 = singleton, 1 = run [rs, re) of 2 .. cmax
+// slots, 2 = longer run
+__device__ __forceinline__ int wl_run(const u64* hb, u32 s, u32 m, u32 cmax, u32& rs, u32& re) {
+    const u32 wi = s >> 6, bt = s & 63, wlast = m >> 6;
+    const u64 cw = hb[wi];
+    u64 x = cw & ((bt == 63) ? ~0ull : ((2ull << bt) - 1ull));
+    u32 wl = wi;
+    while (!x && wl > 0 && wi - wl < WS_CMAX / 64 + 1) x = hb[--wl];
+    u64 y = (bt == 63) ? 0ull : (cw & (~0ull << (bt + 1)));
+    u32 wr = wi;
+    while (!y && wr < wlast && wr - wi < WS_CMAX / 64 + 1) y = hb[++wr];
+    if (!x || !y) return 2;
+    rs = wl * 64 + 63 - (u32)__builtin_clzll(x);
+    re = wr * 64 + (u32)__builtin_ctzll(y);
+    const u32 len = re - rs;
+    if (len == 1) return 0;
+    return len <= cmax ? 1 : 2;
+}
+// end of the run that starts at slot s (the next head behind s; the sentinel at m ends the walk)
+__device__ __forceinline__ u32 wl_run_end(const u64* hb, u32 s) {
+    u32 wi = s >> 6;
+    const u32 bt = s & 63;
+    u64 y = (bt == 63) ? 0ull : (hb[wi] & (~0ull << (bt + 1)));
+    while (!y) y = hb[++wi];
+    return wi * 64 + (u32)__builtin_ctzll(y);
+}
 // ---- leaf kernel A: one workgroup (512 threads) sorts one unit of <= ROWS * 512 records by its first differing word -----------------
 // X = k1, or k2 when all k1 of the unit are equal ("pure": a frequent first word fills whole leaves; so does every long run of equal
 // k1 that comes back as a unit of a later stage).  Composite-word LSD passes as in ssort.hip: (differing bits of X) << 13 | slot.  When
@@ -558,10 +587,12 @@ __device__ __forceinline__ void wl_minmax(u64 (*red)[NW], const u64 (&k)[ROWS], 
 // to `rlist` (ties on the whole of k1: to be ordered by k2) or `tlist` (ties on a truncated word: to be ordered by the word itself
 // first); the counting kernel takes them from there.
 template <int KW, int ROWS, int NW, bool PAIRS>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void ws_leaf_sort_kernel(WLeaf A, const u32* __restrict__ list, u32 count, WLists Q) {
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void ws_leaf_sort_kernel(WLeaf A, const u32* __restrict__ list, u32 count, WLists Q, WEmit E) {
     constexpr u32 CAP = (u32)ROWS * NW * 64;
-    __shared__ __align__(16) u32 wcnt[NW][256];
-    __shared__ __align__(16) u32 wst[NW][256];
+    constexpr bool FUSE = KW == 2 && CAP <= 2u * NW * 256u;   // the counting step below needs a word per slot in the counter tables
+    __shared__ __align__(16) u32 wtab[2][NW][256];
+    u32 (*wcnt)[256] = wtab[0];
+    u32 (*wst)[256] = wtab[1];
     __shared__ unsigned long long wm[NW][256];
     __shared__ __align__(16) u64 stage[CAP];
     __shared__ u64 red[2][NW];
@@ -602,7 +633,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
     }
     u64* Xp = pure ? K2 : K1;
     const int nbits = 64 - __builtin_clzll(kmin ^ kmax);
-    const int nb = nbits > 51 ? 51 : nbits;                     // bits of X in the composite
+    const int nb = nbits > WL_NBMAX ? WL_NBMAX : nbits;         // bits of X in the composite
     const int sh = nbits - nb;                                  // low bits of X left out (ties on the rest are handed on)
     const u64 cmask = (1ull << nb) - 1;
 #pragma unroll
@@ -611,29 +642,114 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
     // heads, LCPs
     const u32 base_bits = pure ? 64u : 0u;
     bool anyrun = false;
+    u64* hb = (u64*)&wm[0][0];                                  // head bitmap of the unit (the match tables are dead); bit m: end sentinel
+    u8* hf = (u8*)(hb + 128);
 #pragma unroll
     for (int j = 0; j < ROWS; ++j) {
         const u32 L = wbase + (u32)j * 64;
+        bool hd = L == 0;
         if (L < m && L > 0) {
             const u64 x = (c[j] >> 13) ^ (stage[L - 1] >> 13);
             A.flags[(size_t)a + L] = x ? 1 : 0;
-            if (x) { if (!PAIRS) A.lcp[(size_t)a + L] = (u8)(((base_bits + (u32)__builtin_clzll(x) - (u32)sh) * A.inv) >> 16); }
+            if (x) { hd = true; if (!PAIRS) A.lcp[(size_t)a + L] = (u8)(((base_bits + (u32)__builtin_clzll(x) - (u32)sh) * A.inv) >> 16); }
             else anyrun = true;
         }
+        if (FUSE) { const u64 bm = __ballot(hd || L == m); if (lane == 0) hb[w * ROWS + j] = bm; }
     }
+    if (FUSE && threadIdx.x == 0) hb[ROWS * NW] = (m == CAP) ? 1ull : 0ull;
     if (__any(anyrun) && lane == 0) s_any = 1;
     __syncthreads();                                            // (the staged composites have been read)
     const bool runs = s_any != 0;
+    const bool trunc_ties = sh > 0 && runs;                     // the counting kernel orders these runs by X itself first
     // positions in sorted order
+    u32 vs[ROWS];
     {
         u32* stage32 = (u32*)stage;
 #pragma unroll
         for (int j = 0; j < ROWS; ++j) { const u32 L = wbase + (u32)j * 64; if (L < m) stage32[L] = A.v[(size_t)a + L]; }
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < ROWS; ++j) { const u32 L = wbase + (u32)j * 64; if (L < m) A.v[(size_t)a + L] = stage32[(u32)c[j] & 8191u]; }
+        for (int j = 0; j < ROWS; ++j) { const u32 L = wbase + (u32)j * 64; vs[j] = (L < m) ? stage32[(u32)c[j] & 8191u] : 0u; }
     }
-    const bool trunc_ties = sh > 0 && runs;                     // the counting kernel orders these runs by X itself first
+    if (FUSE && runs && !pure && !trunc_ties && E.rng) {
+        // The runs that are left tie on all of k1: ordered by k2 right here, by counting, as ws_leaf_count_kernel does it for the units
+        // of the lists (the sorted k2, the positions and the head bits never leave the workgroup; runs of more than cmax records are
+        // handed on).  All per-slot state in LDS, the row loops are real loops.
+        u64 t[ROWS];
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) { const u32 L = wbase + (u32)j * 64; t[j] = (L < m) ? K2[c[j] & 8191ull] : 0ull; }
+        if (PAIRS) {                                            // k1 in sorted order (rebuilt from the composite: sh == 0)
+            const u64 high = kmin & ~cmask;
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j) { const u32 L = wbase + (u32)j * 64; if (L < m) K1[L] = ((c[j] >> 13) & cmask) | high; }
+        }
+        __syncthreads();                                        // (the staged positions have been read)
+        u64* Wl = stage;
+        u32* P32 = &wtab[0][0][0];
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) { const u32 L = wbase + (u32)j * 64; if (L < m) Wl[L] = t[j]; }
+        if (threadIdx.x == 0) s_any = 0;                        // from here on: some run of the unit is handed on
+        __syncthreads();
+#pragma unroll 1
+        for (int j = 0; j < ROWS; ++j) {
+            const u32 L = wbase + (u32)j * 64;
+            if (L < m) {
+                u32 rs = 0, re = 0;
+                u32 tgt = L, h = (u32)((hb[L >> 6] >> (L & 63)) & 1ull);
+                const int kind = wl_run(hb, L, m, A.cmax, rs, re);
+                if (kind == 1) {
+                    u32 less = 0, eqb = 0;
+                    const u64 me = Wl[L];
+                    for (u32 q = rs; q < re; ++q) {
+                        const u64 kq = Wl[q];
+                        less += (kq < me) ? 1u : 0u;
+                        eqb += (kq == me && q < L) ? 1u : 0u;
+                    }
+                    tgt = rs + less + eqb;
+                    h = (eqb == 0) ? 1u : 0u;
+                } else if (kind == 2) {
+                    if (h) {                                    // the first slot of a long run hands it on
+                        const u32 e = wl_run_end(hb, L);
+                        const size_t i = (size_t)((a + L) / E.div);
+                        E.rng[2 * i] = a + L;
+                        E.rng[2 * i + 1] = (a + e) | 0x80000000u;
+                        s_any = 1;
+                    }
+                }
+                P32[L] = tgt | (h << 16);
+            }
+        }
+        __syncthreads();
+        u32 tr[ROWS];
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) { const u32 L = wbase + (u32)j * 64; tr[j] = (L < m) ? P32[L] : 0u; }
+        const bool handed = s_any != 0;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) {
+            const u32 L = wbase + (u32)j * 64;
+            if (L < m) { const u32 d = tr[j] & 0xFFFFu; Wl[d] = t[j]; P32[d] = vs[j]; hf[d] = (u8)(tr[j] >> 16); }
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int j = 0; j < ROWS; ++j) {
+            const u32 L = wbase + (u32)j * 64;
+            if (L < m) {
+                const bool h = hf[L] != 0;
+                const bool old = (hb[L >> 6] >> (L & 63)) & 1ull;
+                A.v[(size_t)a + L] = P32[L];
+                if (PAIRS || handed) K2[L] = Wl[L];             // (a run that goes on is read from here by the next stage)
+                if (h && !old) {
+                    const u64 x = Wl[L] ^ Wl[L - 1];
+                    A.flags[(size_t)a + L] = 1;
+                    if (!PAIRS) A.lcp[(size_t)a + L] = (u8)(((64u + (x ? (u32)__builtin_clzll(x) : 64u)) * A.inv) >> 16);
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) { const u32 L = wbase + (u32)j * 64; if (L < m) A.v[(size_t)a + L] = vs[j]; }
     if (PAIRS || trunc_ties) {                                  // X in sorted order
         if (sh == 0) {                                          // rebuilt from the composite
             const u64 high = kmin & ~cmask;
@@ -670,32 +786,6 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 // W, so it is "pure" there, or differs only in the low bits a truncated composite left out).
 // All per-slot state lives in LDS and the row loops are real loops: a few dozen registers.
 struct WCount { u64* W; u64* carry; u32 base_bits; };
-// the run of slot s in the head bitmap hb (bit m is set: end sentinel; bit 0 is set): 0 = singleton, 1 = run [rs, re) of 2 .. cmax
-// slots, 2 = longer run
-__device__ __forceinline__ int wl_run(const u64* hb, u32 s, u32 m, u32 cmax, u32& rs, u32& re) {
-    const u32 wi = s >> 6, bt = s & 63, wlast = m >> 6;
-    const u64 cw = hb[wi];
-    u64 x = cw & ((bt == 63) ? ~0ull : ((2ull << bt) - 1ull));
-    u32 wl = wi;
-    while (!x && wl > 0 && wi - wl < WS_CMAX / 64 + 1) x = hb[--wl];
-    u64 y = (bt == 63) ? 0ull : (cw & (~0ull << (bt + 1)));
-    u32 wr = wi;
-    while (!y && wr < wlast && wr - wi < WS_CMAX / 64 + 1) y = hb[++wr];
-    if (!x || !y) return 2;
-    rs = wl * 64 + 63 - (u32)__builtin_clzll(x);
-    re = wr * 64 + (u32)__builtin_ctzll(y);
-    const u32 len = re - rs;
-    if (len == 1) return 0;
-    return len <= cmax ? 1 : 2;
-}
-// end of the run that starts at slot s (the next head behind s; the sentinel at m ends the walk)
-__device__ __forceinline__ u32 wl_run_end(const u64* hb, u32 s) {
-    u32 wi = s >> 6;
-    const u32 bt = s & 63;
-    u64 y = (bt == 63) ? 0ull : (hb[wi] & (~0ull << (bt + 1)));
-    while (!y) y = hb[++wi];
-    return wi * 64 + (u32)__builtin_ctzll(y);
-}
 template <int ROWS, int NW, bool PAIRS>
 __global__ __launch_bounds__(NW * 64) void ws_leaf_count_kernel(WLeaf A, const u32* __restrict__ list, u32 count, u32 want_mask, u32 want_value,
                                                                 WCount R, WEmit E) {
@@ -1315,6 +1405,9 @@ int ws_sort_impl(Ctx& c, const WKeyGen* gen, u64* K1[2], u64* K2[2], u32* V[2], 
             HIP_TRY(hipMemsetAsync(lc, 0, 16 * sizeof(u32), s));
             A.unit_rng = cur_rng;
             // (stage 0 sorts every record once: keys + position in, position + flag + LCP out; the later stages re-sort the long runs)
+            HIP_TRY(hipMemsetAsync(e_rng[stage & 1], 0, 2 * (size_t)ecap2 * sizeof(u32), s));
+            const WEmit E = { e_rng[stage & 1], ediv };
+            const WEmit EA = { c.wsort_fuse ? E.rng : nullptr, ediv };   // kernel A orders the short runs of its units itself
             const int pa = c.prof_begin(K_WS_LEAF_SORT, stage == 0 ? (u64)n * (4 + 8 * KW + 6) : 0);
             for (int q = 0; q < 4; ++q) {
                 const u32 cnt = cur_cnt[q];
@@ -1323,18 +1416,16 @@ int ws_sort_impl(Ctx& c, const WKeyGen* gen, u64* K1[2], u64* K2[2], u32* V[2], 
                 const u32* lst = cur_cls + q * cur_cap;
                 // (units of <= 2048 records: four waves of eight rows -- a smaller workgroup, more units in flight per CU; the kernel
                 //  is bound by its chain of dependent steps, not by throughput)
-                if (q == 0) ws_leaf_sort_kernel<KW, 8, 4, PAIRS><<<cnt, 4 * 64, 0, s>>>(A, lst, cnt, Q);
-                else if (q == 1) ws_leaf_sort_kernel<KW, 8, 8, PAIRS><<<cnt, 8 * 64, 0, s>>>(A, lst, cnt, Q);
-                else if (q == 2) ws_leaf_sort_kernel<KW, 12, 8, PAIRS><<<cnt, 8 * 64, 0, s>>>(A, lst, cnt, Q);
-                else ws_leaf_sort_kernel<KW, 16, 8, PAIRS><<<cnt, 8 * 64, 0, s>>>(A, lst, cnt, Q);
+                if (q == 0) ws_leaf_sort_kernel<KW, 8, 4, PAIRS><<<cnt, 4 * 64, 0, s>>>(A, lst, cnt, Q, EA);
+                else if (q == 1) ws_leaf_sort_kernel<KW, 8, 8, PAIRS><<<cnt, 8 * 64, 0, s>>>(A, lst, cnt, Q, EA);
+                else if (q == 2) ws_leaf_sort_kernel<KW, 12, 8, PAIRS><<<cnt, 8 * 64, 0, s>>>(A, lst, cnt, Q, EA);
+                else ws_leaf_sort_kernel<KW, 16, 8, PAIRS><<<cnt, 8 * 64, 0, s>>>(A, lst, cnt, Q, EA);
                 LAUNCH_CHECK();
             }
             c.prof_end(pa);
             u32 hl[8];
             c.read_n(lc, hl, 8);
             const int pb = c.prof_begin(K_WS_LEAF_COUNT, stage == 0 ? (u64)n * (8 + 4 + 1 + 4 + 2) : 0);
-            HIP_TRY(hipMemsetAsync(e_rng[stage & 1], 0, 2 * (size_t)ecap2 * sizeof(u32), s));
-            const WEmit E = { e_rng[stage & 1], ediv };
             const WEmit noE = { nullptr, 1 };
             auto count_pass = [&](int q, const u32* lst, u32 cnt, u32 mask, u32 val, const WCount& R, const WEmit& Em) {
                 if (!cnt) return;
