@@ -676,16 +676,30 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
         // of the lists (the sorted k2, the positions and the head bits never leave the workgroup; runs of more than cmax records are
         // handed on).  All per-slot state in LDS, the row loops are real loops.
         u64 t[ROWS];
+        u64* Wl = stage;
+        u32* P32 = &wtab[0][0][0];
+#ifndef WL_K2_LDS                                            // (through LDS instead -- coalesced load, permuted LDS read -- measured the same: 55.9 vs 55.6 ms)
 #pragma unroll
         for (int j = 0; j < ROWS; ++j) { const u32 L = wbase + (u32)j * 64; t[j] = (L < m) ? K2[c[j] & 8191ull] : 0ull; }
+        __syncthreads();                                        // (the staged positions have been read)
+#else
+        // the second words follow the permutation through LDS as well (coalesced load, permuted LDS read): a gather from global
+        // memory moves a whole line per record
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) { const u32 L = wbase + (u32)j * 64; t[j] = (L < m) ? K2[L] : 0ull; }
+        __syncthreads();                                        // (the staged positions have been read)
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) { const u32 L = wbase + (u32)j * 64; if (L < m) Wl[L] = t[j]; }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) { const u32 L = wbase + (u32)j * 64; t[j] = (L < m) ? Wl[c[j] & 8191ull] : 0ull; }
+        __syncthreads();
+#endif
         if (PAIRS) {                                            // k1 in sorted order (rebuilt from the composite: sh == 0)
             const u64 high = kmin & ~cmask;
 #pragma unroll
             for (int j = 0; j < ROWS; ++j) { const u32 L = wbase + (u32)j * 64; if (L < m) K1[L] = ((c[j] >> 13) & cmask) | high; }
         }
-        __syncthreads();                                        // (the staged positions have been read)
-        u64* Wl = stage;
-        u32* P32 = &wtab[0][0][0];
 #pragma unroll
         for (int j = 0; j < ROWS; ++j) { const u32 L = wbase + (u32)j * 64; if (L < m) Wl[L] = t[j]; }
         if (threadIdx.x == 0) s_any = 0;                        // from here on: some run of the unit is handed on
