@@ -121,7 +121,7 @@ struct Ctx {
     hipEvent_t ev[16] = {};
     void* pinned = nullptr;        // small pinned staging block for device->host scalars
     size_t pinned_size = 0;
-    static constexpr u32 ZC_SEG_OFF = 1040, ZC_WORDS = 1040 + 4096;   // words 1040 ..: up to 2048 (target, start) pairs of a one-workgroup level
+    static constexpr u32 ZC_SEG_OFF = 1040, ZC_WORDS = 1040 + 8192;   // words 1040 ..: up to 4096 (target, start) pairs of a one-workgroup level
     static constexpr u32 ZC_BLOCKS = 3;                                // block 0: read() / publish_*; blocks 1, 2: two one-workgroup levels in flight
     u32* zc_host = nullptr;        // mapped host block for publish_words_kernel: 1024 data words + the sequence word (+ the segment area)
     u32* zc_dev = nullptr;         // the same block as seen from the device
@@ -131,6 +131,7 @@ struct Ctx {
     int sa_local_sort = 1;         // doubling rounds: sort whole runs inside 2048-element tiles locally (env TDC_GPU_SA_LOCAL=0 disables)
     int radix_waves = 4;           // waves per radix-sort workgroup for large inputs (env TDC_GPU_RADIX_WAVES = 4 | 8; no measurable difference)
     int plcp_samples = 1;          // PLCP: exact values at every 256th position first, as lower bounds for the chunks (env TDC_GPU_PLCP_SAMPLES=0: chunks start from 0)
+    int small_big = 1;             // factorize: one-workgroup levels with up to 4096 survivors run on a 512-thread instance of the kernel (env TDC_GPU_SMALL_BIG=0: multi-launch path above 2048)
     int small_pipeline = 1;        // factorize: the kernel of the next one-workgroup level is queued while the current one runs (env TDC_GPU_SMALL_PIPELINE=0 disables)
     int sa_refine = 1;             // suffix array: small groups of the initial order are refined from the text before the first round (env TDC_GPU_SA_REFINE=0 disables)
     int sa_fused_init = 1;         // suffix array: pass 0 of the initial sort computes its keys from the text (env TDC_GPU_SA_FUSED_INIT=0: separate key kernel)

@@ -270,11 +270,17 @@ constexpr u32 SMALL_APPLY_INLINE_MAX_L = 64;      // longer factors are applied 
 // mapped host memory and is copied into LDS first
 constexpr u32 SMALL_GATHER = 2048;
 constexpr u32 SMALL_RAW = 8192;     // list entries a small level may hold before the erased ones are dropped (SMALL_M must survive)
+// A second instance of the kernel with 512 threads holds twice as many survivors: texts with long repeats have thousands of levels in a
+// row whose lists hold 5 000 - 10 000 entries, 2 500 - 5 000 of them still alive (10^9 B of DNA: 1 383 levels, 0.36 ms each on the
+// multi-launch path against ~0.06 ms here).
+constexpr u32 SMALL_M_BIG = 4096;
+constexpr u32 SMALL_RAW_BIG = 16384;
 constexpr u32 SMALL_OUT_WORDS = 8 + 2 * SEG_INLINE;
 constexpr u32 SMALL_RANKSORT = 1024; // up to here a counting sort in LDS beats the bitonic network
 constexpr u32 SMALL_SELSCAN = 32;    // up to this many selected entries the encounter values scan the selected list, not the neighbours
 
-__global__ __launch_bounds__(256) void small_level_kernel(const u32* __restrict__ orig, u32 m0, const u32* __restrict__ pushed, u32 m_raw,
+template <int NT>
+__global__ __launch_bounds__(NT) void small_level_kernel(const u32* __restrict__ orig, u32 m0, const u32* __restrict__ pushed, u32 m_raw,
                                                            const u32* __restrict__ pool_all, const GatherSeg* __restrict__ gtab, u32 gn,
                                                            u32 L, u32 threshold, size_t n, u32* cur, u32* prio,
                                                            const u32* __restrict__ phi, u32* __restrict__ flen, u8* __restrict__ res8,
@@ -284,14 +290,16 @@ __global__ __launch_bounds__(256) void small_level_kernel(const u32* __restrict_
                                                            u32* zc_dst, u32* zc_flag, u32 zc_seq, unsigned long long* prof, u32* zc_segs,
                                                            SmallCtl* __restrict__ ctl, u32 spec, const LevelScalars* prev_sc, const PushSeg* prev_segs) {
 #define SPROF(k) do { if (prof) { const unsigned long long now_ = wall_clock64(); acc_prof[k] = now_ - t_prof; t_prof = now_; } } while (0)
+    constexpr u32 SM = (u32)NT * 8;                          // survivors the workgroup holds (eight per thread)
+    constexpr u32 NWV = (u32)NT / 64;
     unsigned long long t_prof = prof ? wall_clock64() : 0;
     unsigned long long acc_prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // The entries are sorted by text position (bitonic network in registers), so "neighbours within distance < L" are
     // adjacent slots of LDS arrays: the whole level runs without the global state bitmap.
-    __shared__ u64 skey[SMALL_M];          // sort scratch, later the push records (target << 32 | priority)
-    __shared__ u32 sval[SMALL_M];
-    __shared__ u32 pos_s[SMALL_M], pr_s[SMALL_M], v_s[SMALL_M];
-    __shared__ u8 st[SMALL_M];             // 0 undecided, 1 selected, 2 stale, 3 rejected, 4 dead
+    __shared__ u64 skey[SM];          // sort scratch, later the push records (target << 32 | priority)
+    __shared__ u32 sval[SM];
+    __shared__ u32 pos_s[SM], pr_s[SM], v_s[SM];
+    __shared__ u8 st[SM];             // 0 undecided, 1 selected, 2 stale, 3 rejected, 4 dead
     __shared__ u32 s_und, s_npush, s_sel, s_live, s_alive, s_cnt, s_lst;
     __shared__ u32 s_sellist[SMALL_SELSCAN];
     __shared__ u32 s_out[SMALL_OUT_WORDS]; // the LevelScalars of this level: nlive nstale undecided selected npush nseg deferred bailed, segments
@@ -305,7 +313,7 @@ __global__ __launch_bounds__(256) void small_level_kernel(const u32* __restrict_
         const u32* ps = (const u32*)prev_sc;
         const u32 pn = ps[5];
         if (ps[6] || ps[7] || pn > seg_cap) { if (tid == 0) s_bail = 1; }
-        else for (u32 i = tid; i < pn; i += 256) if (prev_segs[i].target == L) s_bail = 1;
+        else for (u32 i = tid; i < pn; i += NT) if (prev_segs[i].target == L) s_bail = 1;
         __syncthreads();
         pool_top = ctl->pool_top; prio_base = ctl->prio_base;
     } else if (tid == 0) { ctl->pool_top = pool_top; ctl->prio_base = prio_base; }
@@ -314,7 +322,7 @@ __global__ __launch_bounds__(256) void small_level_kernel(const u32* __restrict_
     auto publish = [&]() {
         __syncthreads();
         const u32 words = 8 + 2 * min(s_out[5], SEG_INLINE);
-        for (u32 i = tid; i < words; i += 256) {
+        for (u32 i = tid; i < words; i += NT) {
             ((u32*)sc)[i] = s_out[i];
             if (zc_dst) __hip_atomic_store(&zc_dst[i], s_out[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
@@ -329,20 +337,20 @@ __global__ __launch_bounds__(256) void small_level_kernel(const u32* __restrict_
     //    step: the position loads are all in flight together, then the eight dependent cur[] loads (one workgroup has no
     //    other way to hide the two round trips)
     GatherSeg* gt = (GatherSeg*)skey;                     // skey is not used before the sorts
-    for (u32 i = tid; i < gn; i += 256) gt[i] = gtab[i];
+    for (u32 i = tid; i < gn; i += NT) gt[i] = gtab[i];
     if (gn) __syncthreads();
     // The survivors keep the order of the list (row-wise ballots + a prefix over the rows and waves of a step): the original
     // candidates of a level are in position order, so their survivors come out sorted and only the pushed ones -- usually a
     // handful -- have to be ranked against them (step 1).
-    __shared__ u32 s_rowcnt[8][4];
+    __shared__ u32 s_rowcnt[8][NWV];
     __shared__ u32 s_run, s_nA;
     if (tid == 0) { s_run = 0; s_nA = 0; }
     __syncthreads();
-    for (u32 base = 0; base < m_raw; base += 256 * 8) {
+    for (u32 base = 0; base < m_raw; base += NT * 8) {
         u32 pp[8], cc[8];
 #pragma unroll
         for (u32 r = 0; r < 8; ++r) {
-            const u32 i = base + r * 256 + tid;
+            const u32 i = base + r * NT + tid;
             pp[r] = NONE32;
             if (i < m0) pp[r] = orig[i];
             else if (i < m_raw) {
@@ -376,13 +384,13 @@ __global__ __launch_bounds__(256) void small_level_kernel(const u32* __restrict_
         for (u32 r = 0; r < 8; ++r) {
             u32 bw = 0;
 #pragma unroll
-            for (u32 wq = 0; wq < 4; ++wq) if (wq < (tid >> 6)) bw += s_rowcnt[r][wq];
+            for (u32 wq = 0; wq < NWV; ++wq) if (wq < (tid >> 6)) bw += s_rowcnt[r][wq];
             if (keepm & (1u << r)) {
                 const u32 slot = run0 + before_row + bw + within[r];
-                if (slot < SMALL_M) pos_s[slot] = pp[r];
-                if (base + r * 256 + tid < m0) ++nA_add;
+                if (slot < SM) pos_s[slot] = pp[r];
+                if (base + r * NT + tid < m0) ++nA_add;
             }
-            before_row += s_rowcnt[r][0] + s_rowcnt[r][1] + s_rowcnt[r][2] + s_rowcnt[r][3];
+            for (u32 wq = 0; wq < NWV; ++wq) before_row += s_rowcnt[r][wq];
         }
         nA_add = wave_reduce_sum(nA_add);
         if ((tid & 63) == 0 && nA_add) atomicAdd(&s_nA, nA_add);
@@ -393,7 +401,7 @@ __global__ __launch_bounds__(256) void small_level_kernel(const u32* __restrict_
     __syncthreads();
     SPROF(0);
     const u32 m = s_cnt;
-    if (m > SMALL_M) { if (tid == 0) s_out[7] = 1; publish(); return; }     // too many survivors: the general path takes the level
+    if (m > SM) { if (tid == 0) s_out[7] = 1; publish(); return; }     // too many survivors: the general path takes the level
     if (m == 0) { publish(); return; }                                      // every entry already erased (:86)
     u64 k[8];
     u32 v[8];
@@ -410,12 +418,12 @@ __global__ __launch_bounds__(256) void small_level_kernel(const u32* __restrict_
     __shared__ u32 s_unsorted;
     if (tid == 0) s_unsorted = 0;
     __syncthreads();
-    for (u32 i = tid + 1; i < nA; i += 256) if (pos_s[i - 1] >= pos_s[i]) s_unsorted = 1;
+    for (u32 i = tid + 1; i < nA; i += NT) if (pos_s[i - 1] >= pos_s[i]) s_unsorted = 1;
     __syncthreads();
-    if (!s_unsorted && (u64)nA * nB + (u64)nB * nB <= 256ull * 768ull) {
+    if (!s_unsorted && (u64)nA * nB + (u64)nB * nB <= (u64)NT * 768ull) {
         // sorted run A + a few unsorted entries B: an entry of A moves up by the number of smaller entries of B, an entry of B goes
         // behind the smaller entries of A (binary search) and of B
-        for (u32 i = tid; i < m; i += 256) {
+        for (u32 i = tid; i < m; i += NT) {
             const u32 p = pos_s[i];
             u32 rk;
             if (i < nA) {
@@ -435,7 +443,7 @@ __global__ __launch_bounds__(256) void small_level_kernel(const u32* __restrict_
         __syncthreads();
     } else if (m <= SMALL_RANKSORT) {
         // few survivors: every entry counts the smaller ones (independent LDS reads: no chain of dependent steps)
-        for (u32 i = tid; i < m; i += 256) {
+        for (u32 i = tid; i < m; i += NT) {
             const u32 p = pos_s[i];
             u32 rk = 0;
 #pragma unroll 16
@@ -508,10 +516,10 @@ __global__ __launch_bounds__(256) void small_level_kernel(const u32* __restrict_
     // 4. encounter values of the stale and the rejected entries -> push records
     if (tid == 0) s_lst = 0;
     __syncthreads();
-    for (u32 i = tid; i < m; i += 256) if (st[i] == 1) { const u32 o = atomicAdd(&s_lst, 1u); if (o < SMALL_SELSCAN) s_sellist[o] = i; }
+    for (u32 i = tid; i < m; i += NT) if (st[i] == 1) { const u32 o = atomicAdd(&s_lst, 1u); if (o < SMALL_SELSCAN) s_sellist[o] = i; }
     __syncthreads();
     const u32 nsel_scan = s_lst;
-    for (u32 i = tid; i < m; i += 256) {
+    for (u32 i = tid; i < m; i += NT) {
         const u8 c = st[i];
         if (c != 2 && c != 3) continue;
         const u32 p = pos_s[i], pr = pr_s[i];
@@ -548,20 +556,64 @@ __global__ __launch_bounds__(256) void small_level_kernel(const u32* __restrict_
     //    counted in a hashed table; a push whose slot it has for itself takes the next free place (any order), the others -- real
     //    duplicates and the rare hash collisions -- are ranked among themselves and follow.
     const u32 npush = s_npush;
-    __shared__ u32 s_hcnt[2048];
-    __shared__ unsigned short s_dl[SMALL_M];
+    constexpr u32 HB = NT >= 512 ? 12u : 11u;                   // hashed target counters: 2^HB
+    __shared__ u32 s_hcnt[1u << HB];
+    __shared__ unsigned short s_dl[SM];
     __shared__ u32 s_nu, s_nd;
-    if (npush > 64) {
-        for (u32 i = tid; i < 2048; i += 256) s_hcnt[i] = 0;
+    bool ordered = false;
+    if (npush > 64 && L <= (1u << HB)) {
+        // Every target (< L) has a counter of its own: counting sort by target, then the members of a target's group -- mostly one, a
+        // handful at most on texts with long repeats -- rank themselves by priority inside the group.  (The hashed counters below
+        // send two pushes in five to the "duplicates" through collisions alone once a level pushes thousands of entries, and more than
+        // 512 of those mean a full bitonic sort: 65 us of the 140 us such a level takes at 10^9 B of DNA.)
+        constexpr u32 TE = (1u << HB) / NT;
+        __shared__ u32 cs_sm[NWV + 1];
+        for (u32 i = tid; i < (1u << HB); i += NT) s_hcnt[i] = 0;
+        if (tid == 0) s_nd = 0;
+        __syncthreads();
+        for (u32 i = tid; i < npush; i += NT) atomicAdd(&s_hcnt[(u32)(skey[i] >> 32)], 1u);
+        __syncthreads();
+        u32 loc[TE], sum = 0, gmax = 0;
+#pragma unroll
+        for (u32 e = 0; e < TE; ++e) { loc[e] = s_hcnt[tid * TE + e]; sum += loc[e]; gmax = max(gmax, loc[e]); }
+        u32 total;
+        u32 start = block_exclusive_sum<u32, (int)NWV>(sum, cs_sm, total);
+#pragma unroll
+        for (u32 e = 0; e < TE; ++e) { s_hcnt[tid * TE + e] = start; start += loc[e]; }
+        gmax = wave_reduce_max(gmax);
+        if ((tid & 63) == 0 && gmax) atomicMax(&s_nd, gmax);
+        __syncthreads();
+        const u32 group_max = s_nd;
+        __syncthreads();                                        // (s_nd is reset below)
+        if (group_max <= 64) {                                  // (a crowded target: the general orderings below)
+            for (u32 i = tid; i < npush; i += NT) s_dl[atomicAdd(&s_hcnt[(u32)(skey[i] >> 32)], 1u)] = (unsigned short)i;
+            __syncthreads();                                    // s_hcnt[t] is the END of target t's group now, i.e. the start of the next one
+            for (u32 a = tid; a < npush; a += NT) {
+                const u32 i = s_dl[a];
+                const u64 key = skey[i];
+                const u32 t = (u32)(key >> 32);
+                const u32 lo = t ? s_hcnt[t - 1] : 0u, hi = s_hcnt[t];
+                u32 rk = 0;
+                if (hi - lo > 1) for (u32 b = lo; b < hi; ++b) rk += (skey[s_dl[b]] < key) ? 1u : 0u;   // (keys are distinct: the priority is part of them)
+                pr_s[lo + rk] = t;
+                v_s[lo + rk] = sval[i];
+            }
+            __syncthreads();
+            ordered = true;
+        }
+    }
+    if (ordered) {
+    } else if (npush > 64) {
+        for (u32 i = tid; i < (1u << HB); i += NT) s_hcnt[i] = 0;
         if (tid == 0) { s_nu = 0; s_nd = 0; }
         __syncthreads();
-        for (u32 i = tid; i < npush; i += 256) atomicAdd(&s_hcnt[((u32)(skey[i] >> 32) * 2654435761u) >> 21], 1u);
+        for (u32 i = tid; i < npush; i += NT) atomicAdd(&s_hcnt[((u32)(skey[i] >> 32) * 2654435761u) >> (32 - HB)], 1u);
         __syncthreads();
-        for (u32 i0 = 0; i0 < npush; i0 += 256) {
+        for (u32 i0 = 0; i0 < npush; i0 += NT) {
             const u32 i = i0 + tid;
             const bool have = i < npush;
             const u64 key = have ? skey[i] : 0ull;
-            const bool uniq = have && s_hcnt[((u32)(key >> 32) * 2654435761u) >> 21] == 1u;
+            const bool uniq = have && s_hcnt[((u32)(key >> 32) * 2654435761u) >> (32 - HB)] == 1u;
             const u64 um = __ballot(uniq), dm = __ballot(have && !uniq);
             u32 ub = 0, db = 0;
             if ((tid & 63) == 0) { if (um) ub = atomicAdd(&s_nu, (u32)__popcll(um)); if (dm) db = atomicAdd(&s_nd, (u32)__popcll(dm)); }
@@ -573,7 +625,7 @@ __global__ __launch_bounds__(256) void small_level_kernel(const u32* __restrict_
         __syncthreads();
         const u32 nu = s_nu, nd = s_nd;
         if (nd > 512) goto full_sort;                           // many shared targets: ranking them by counting would cost nd^2
-        for (u32 a = tid; a < nd; a += 256) {
+        for (u32 a = tid; a < nd; a += NT) {
             const u32 i = s_dl[a];
             const u64 key = skey[i];
             u32 rk = 0;
@@ -585,7 +637,7 @@ __global__ __launch_bounds__(256) void small_level_kernel(const u32* __restrict_
     } else {
 full_sort:
     if (npush <= SMALL_RANKSORT) {
-        for (u32 i = tid; i < npush; i += 256) {
+        for (u32 i = tid; i < npush; i += NT) {
             const u64 key = skey[i];
             u32 rk = 0;
 #pragma unroll 16
@@ -610,7 +662,7 @@ full_sort:
     }
     }
     // 6. new priorities, pool slots, segments
-    for (u32 i = tid; i < npush; i += 256) {
+    for (u32 i = tid; i < npush; i += NT) {
         const u32 p = v_s[i];
         prio[p] = prio_base + i;
         pool[i] = p;
@@ -623,15 +675,15 @@ full_sort:
             const u32 i = tid * 8 + r;
             if (i < npush && (i == 0 || pr_s[i - 1] != pr_s[i])) { heads |= 1u << r; ++cnt; }
         }
-        __shared__ u32 seg_sm[5];
+        __shared__ u32 seg_sm[NWV + 1];
         u32 nseg;
-        u32 o = block_exclusive_sum<u32, 4>(cnt, seg_sm, nseg);
+        u32 o = block_exclusive_sum<u32, (int)NWV>(cnt, seg_sm, nseg);
 #pragma unroll
         for (u32 r = 0; r < 8; ++r) {
             if (!(heads & (1u << r))) continue;
             const u32 i = tid * 8 + r, tgt = pr_s[i];
             if (o < SEG_INLINE) { s_out[8 + 2 * o] = tgt; s_out[9 + 2 * o] = i; }
-            if (zc_segs && nseg > SEG_INLINE && o < SMALL_M) {    // more than the inline part holds: the whole list goes straight into the mapped host block (no read-back)
+            if (zc_segs && nseg > SEG_INLINE && o < SM) {    // more than the inline part holds: the whole list goes straight into the mapped host block (no read-back)
                 __hip_atomic_store(&zc_segs[2 * o], tgt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 __hip_atomic_store(&zc_segs[2 * o + 1], i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
@@ -644,7 +696,7 @@ full_sort:
     SPROF(4);
     // 7. the selected entries: applied here (short factors: one wave per factor; long ones: the whole workgroup per factor
     //    while the level's total stays small) or listed for a chip-wide launch
-    for (u32 i = tid; i < m; i += 256) if (st[i] == 1) atomicAdd(&s_sel, 1u);
+    for (u32 i = tid; i < m; i += NT) if (st[i] == 1) atomicAdd(&s_sel, 1u);
     if (tid == 0) s_lst = 0;
     __syncthreads();
     const u32 nsel = s_sel;
@@ -652,9 +704,9 @@ full_sort:
         // one wave per factor (the factors of the level side by side); the truncation candidates are read eight per lane
         // and step, so one factor costs a round trip or two instead of one per 64 positions
         const u32 lane = tid & 63, wv = tid >> 6;
-        for (u32 i = tid; i < m; i += 256) if (st[i] == 1) sval[atomicAdd(&s_lst, 1u)] = pos_s[i];   // sval: free again after step 6
+        for (u32 i = tid; i < m; i += NT) if (st[i] == 1) sval[atomicAdd(&s_lst, 1u)] = pos_s[i];   // sval: free again after step 6
         __syncthreads();
-        for (u32 f = wv; f < nsel; f += 4) {
+        for (u32 f = wv; f < nsel; f += NWV) {
             const u32 p = sval[f];
             if (lane == 0) { flen[p] = L; fsrc[p] = phi[p]; }
             for (u32 j = lane; j < L && (size_t)p + j < n; j += 64) cur[p + j] = 0;
@@ -668,7 +720,7 @@ full_sort:
             }
         }
     } else {
-        for (u32 i = tid; i < m; i += 256) if (st[i] == 1) sel_list[atomicAdd(&s_lst, 1u)] = pos_s[i];
+        for (u32 i = tid; i < m; i += NT) if (st[i] == 1) sel_list[atomicAdd(&s_lst, 1u)] = pos_s[i];
         if (tid == 0) s_out[6] = 1;                       // deferred: the host launches apply_list_kernel
     }
     if (tid == 0) { s_out[3] = nsel; s_out[0] = s_live; s_out[1] = s_alive - s_live; }
@@ -964,6 +1016,7 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
     u32 dead_streak = 0, levels_since_purge = 1u << 30;
     bool purge_pays = false;                               // a level too large for the one-workgroup path consisted mostly of erased entries
     u32 dead_levels_run = 0;                               // consecutive levels whose entries were all erased
+    u32 last_alive = 0;                                    // survivors of the last one-workgroup level (chooses the instance of the next one)
     u32 nolive_run = 0, stale_trigger = 8;                 // consecutive levels without a live entry; run length that triggers the batch push
     double host_prof[5] = {0, 0, 0, 0, 0};                // small levels, host side: prepare / launch / wait / bookkeeping (us), count
     unsigned long long* d_sprof = nullptr;                 // TDC_GPU_SMALL_PROF=1: phase times of the small-level kernel on stderr
@@ -1178,12 +1231,12 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
         const u32 m = m0 + m1_total;
         if (m == 0) { pushed_into.drop(L); continue; }
         st->levels++;
-        if (m <= SMALL_RAW && L != force_general_level) {
+        if (m <= (c.small_big ? SMALL_RAW_BIG : SMALL_RAW) && L != force_general_level) {
             // ---- whole level in one workgroup: ONE launch (list read from the pool segments, result published into mapped
             //      host memory), falling back to the general path if more than SMALL_M entries are still alive.  While the kernel
             //      of a level runs, the kernel of the level below it is already queued ("speculative", see SmallCtl): the host's
             //      turnaround between two levels -- result, bookkeeping, launch -- no longer leaves the GPU idle.
-            struct Flight { u32 L, m, m0, slot, zseq; bool zc, spec; };
+            struct Flight { u32 L, m, m0, slot, zseq; bool zc, spec, big; };
             auto list_size = [&](u32 lv, u32* m0_out, size_t* nsegs) {       // entries of a level as far as the host knows them
                 const u32 a0 = h_segend[lv] - h_segstart[lv];
                 const std::vector<PoolSeg>& sv = pushed_into.get(lv);
@@ -1193,13 +1246,17 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
                 return t;
             };
             u64 inflight_push_max = 0;                              // upper bound of what the levels in flight may still push
+            const u32 raw_cap = c.small_big ? SMALL_RAW_BIG : SMALL_RAW;
             auto launch_small = [&](u32 lv, u32 slot, bool spec, Flight* f) -> bool {
                 u32 a0; size_t ns;
                 const u64 mm = list_size(lv, &a0, &ns);
                 const std::vector<PoolSeg>& sv = pushed_into.get(lv);
                 const u32 half = gtab_cap / 2;
-                if ((spec || lv != L) && (mm == 0 || mm > SMALL_RAW || ns > SMALL_GATHER || ns > half || !d_hgtab)) return false;
-                const u32 push_max = (u32)std::min<u64>(mm, SMALL_M);          // at most one push per surviving entry
+                if ((spec || lv != L) && (mm == 0 || mm > raw_cap || ns > SMALL_GATHER || ns > half || !d_hgtab)) return false;
+                // the 512-thread instance where the list is long or the levels above had many survivors (a level that overflows the
+                // small instance would be run twice)
+                const bool big = c.small_big == 2 || (c.small_big && (mm > SMALL_RAW || last_alive > SMALL_M * 3 / 4));   // (2: always -- tests)
+                const u32 push_max = (u32)std::min<u64>(mm, big ? SMALL_M_BIG : SMALL_M);          // at most one push per surviving entry
                 if (pool_top + inflight_push_max + push_max > n || (u64)prio_base + inflight_push_max + push_max > 0xFFFFFFFFull) {
                     if (spec) return false;
                     throw HipError{hipErrorUnknown, "factorize: push pool overflow", (int)__LINE__};
@@ -1218,15 +1275,21 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
                 if (spec && !zc) return false;
                 {
                     Ctx::ProfScope prof(c, K_SMALL_LEVEL, mm * 16);
-                    small_level_kernel<<<1, 256, 0, s>>>(cand + h_segstart[lv], a0, pushed_src, (u32)mm, pool, d_hgtab ? d_hgtab + (size_t)slot * half : nullptr, gn, lv,
-                                                         threshold, n, cur, prio, phi, fs.flen, res8, fs.fsrc, (u32)pool_top, prio_base, d_segs2[slot], seg_cap, live,
-                                                         /*inline_budget=*/1u << 17, d_sc2[slot], zdst, zflag, zseq, d_sprof,
-                                                         zc ? c.zc_dev + (size_t)(1 + slot) * Ctx::ZC_WORDS + Ctx::ZC_SEG_OFF : nullptr,
-                                                         d_ctl, spec ? 1u : 0u, d_sc2[slot ^ 1], d_segs2[slot ^ 1]);
+                    u32* zsegs = zc ? c.zc_dev + (size_t)(1 + slot) * Ctx::ZC_WORDS + Ctx::ZC_SEG_OFF : nullptr;
+                    if (big)
+                        small_level_kernel<512><<<1, 512, 0, s>>>(cand + h_segstart[lv], a0, pushed_src, (u32)mm, pool, d_hgtab ? d_hgtab + (size_t)slot * half : nullptr, gn, lv,
+                                                                  threshold, n, cur, prio, phi, fs.flen, res8, fs.fsrc, (u32)pool_top, prio_base, d_segs2[slot], seg_cap, live,
+                                                                  /*inline_budget=*/1u << 17, d_sc2[slot], zdst, zflag, zseq, d_sprof, zsegs,
+                                                                  d_ctl, spec ? 1u : 0u, d_sc2[slot ^ 1], d_segs2[slot ^ 1]);
+                    else
+                        small_level_kernel<256><<<1, 256, 0, s>>>(cand + h_segstart[lv], a0, pushed_src, (u32)mm, pool, d_hgtab ? d_hgtab + (size_t)slot * half : nullptr, gn, lv,
+                                                                  threshold, n, cur, prio, phi, fs.flen, res8, fs.fsrc, (u32)pool_top, prio_base, d_segs2[slot], seg_cap, live,
+                                                                  /*inline_budget=*/1u << 17, d_sc2[slot], zdst, zflag, zseq, d_sprof, zsegs,
+                                                                  d_ctl, spec ? 1u : 0u, d_sc2[slot ^ 1], d_segs2[slot ^ 1]);
                     LAUNCH_CHECK();
                 }
                 inflight_push_max += push_max;
-                *f = Flight{lv, (u32)mm, a0, slot, zseq, zc, spec};
+                *f = Flight{lv, (u32)mm, a0, slot, zseq, zc, spec, big};
                 return true;
             };
             auto wait_small = [&](const Flight& f) {
@@ -1255,8 +1318,10 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
                 const u32 LL = cur_f.L;
                 bool redo = false;
                 if (h_sc.pad[1] == 3) redo = true;                   // the speculation failed: the level has not been touched
+                else if (h_sc.pad[1] && c.small_big && !cur_f.big) { last_alive = SMALL_M + 1; redo = true; }   // too many survivors for 256 threads: once more with 512
                 else if (h_sc.pad[1]) general_path = true;           // too many survivors: the multi-launch path takes the level
                 else {
+                    last_alive = h_sc.nlive + h_sc.nstale;
                     if (h_sc.pad[0]) {                             // many long factors: the kills are spread over the whole chip
                         apply_list_kernel<<<cdiv((size_t)h_sc.selected * 64, 256), 256, 0, s>>>(live, &d_sc2[cur_f.slot]->selected, LL, n, phi, cur, fs.flen, fs.fsrc);
                         LAUNCH_CHECK();
@@ -1274,7 +1339,7 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
                         if (npush) {
                             if (nseg > seg_cap) throw HipError{hipErrorUnknown, "factorize: too many push targets in one level", (int)__LINE__};
                             if (nseg <= SEG_INLINE) std::copy(h_sc.segs, h_sc.segs + nseg, h_segs.begin());
-                            else if (cur_f.zc && nseg <= SMALL_M)
+                            else if (cur_f.zc && nseg <= SMALL_M_BIG)
                                 memcpy(h_segs.data(), c.zc_host + (size_t)(1 + cur_f.slot) * Ctx::ZC_WORDS + Ctx::ZC_SEG_OFF, (size_t)nseg * sizeof(PushSeg));   // published next to the scalars
                             else c.read_n(d_segs2[cur_f.slot], h_segs.data(), nseg);
                             for (u32 j2 = 0; j2 < nseg; ++j2) {       // written in order of `start` by one thread
@@ -1301,7 +1366,7 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
                     if (has_next) wait_small(next_f);               // (gave up as well)
                     u32 a0; size_t ns;
                     const u64 mm = list_size(LL, &a0, &ns);
-                    if (mm == 0 || mm > SMALL_RAW || !launch_small(LL, 0, false, &cur_f)) { L = LL + 1; break; }   // (too large now: the outer loop decides)
+                    if (mm == 0 || mm > raw_cap || !launch_small(LL, 0, false, &cur_f)) { L = LL + 1; break; }   // (too large now: the outer loop decides)
                     continue;
                 }
                 if (!has_next) { L = LL; break; }                    // the outer loop goes on below this level
@@ -1311,10 +1376,10 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
                     wait_small(next_f);
                     u32 a0; size_t ns;
                     const u64 mm = list_size(LL - 1, &a0, &ns);
-                    if (mm == 0 || mm > SMALL_RAW || !launch_small(LL - 1, 0, false, &cur_f)) { L = LL; break; }
+                    if (mm == 0 || mm > raw_cap || !launch_small(LL - 1, 0, false, &cur_f)) { L = LL; break; }
                     continue;
                 }
-                inflight_push_max = std::min<u64>(next_f.m, SMALL_M);
+                inflight_push_max = std::min<u64>(next_f.m, next_f.big ? SMALL_M_BIG : SMALL_M);
                 cur_f = next_f;
             }
             if (!general_path) continue;
