@@ -1328,6 +1328,7 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
                     }
                     pushed_into.drop(LL);
                     st->small_levels++;
+                    if (level_log) fprintf(stderr, "small %u m %u m0 %u live %u stale %u npush %u big %d\n", LL, cur_f.m, cur_f.m0, h_sc.nlive, h_sc.nstale, h_sc.npush, (int)cur_f.big);
                     if (LL != L) { st->levels++; ++levels_since_purge; }   // (the level the outer loop stands on has been counted)
                     if (h_sc.nlive == 0) ++nolive_run; else nolive_run = 0;
                     if (h_sc.nlive == 0 && h_sc.nstale == 0) { probe_dead = true; ++dead_levels_run; stop_chain = true; }   // small levels do not count for the purge heuristic
