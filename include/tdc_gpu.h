@@ -232,8 +232,8 @@ int tdc_huffman_table(const uint32_t counts[256], uint32_t* sigma, uint32_t* lon
                       uint8_t len_of[256], uint64_t code_of[256]);
 /* The start-up check of tdc_gpu_ctx_create() on its own (no GPU): rebuilds two built-in fixture tables (sigma 40 and 200, many
  * equal counts) and compares them with what the reference build yields; TDC_GPU_ERR_INTERNAL if this build's C++ library
- * orders ties differently (coders/HuffmanCoder.hpp:88-120 heap functions, :455 unstable std::sort) -- tdc_gpu_ctx_create()
- * then fails with the same code. */
+ * orders ties differently (coders/HuffmanCoder.hpp:88-120 heap functions, :455 unstable std::sort) -- every call with
+ * coder=huff on a context then fails with the same code (the other coders, lz78 and decompression are not affected). */
 int tdc_huffman_selfcheck(void);
 /* synthetic corpora of the benchmark configurations */
 int tdc_gen_english(uint8_t* out, size_t n, uint64_t seed);

@@ -384,6 +384,8 @@ size_t encode_stream(Ctx& c, const u8* text, size_t n, FactorSpace fs, int coder
     if (coder == 2) {
         memset(&ht, 0, sizeof(ht));                                        // ASCIICoder writes no header
     } else if (coder == 0) {
+        if (!c.huff_ok)
+            throw HipError{hipErrorUnknown, "Huffman self-check failed: this C++ library breaks ties differently from the reference build, coder=huff streams would differ", (int)__LINE__};
         build_huffman_table(h_hist, &ht);
         write_huffman_header(hw, ht);
     } else {

@@ -291,9 +291,8 @@ template <bool FIRST, int WIDE>
 __global__ __launch_bounds__(256) void sa_groups_kernel(const u64* __restrict__ keys, const u32* __restrict__ vals, const u32* __restrict__ a_pos,
                                                         size_t m, int bn, u32* __restrict__ sa, u32* __restrict__ rank, u32* __restrict__ newrank_out,
                                                         u32* __restrict__ o_sa, u32* __restrict__ o_pos, u32* __restrict__ o_r1,
-                                                        u64* desc, u32* ticket, u32* __restrict__ d_total, u32* err, u32 numTiles,
+                                                        u64* desc, u32* __restrict__ d_total, u32* err, u32 numTiles,
                                                         const u8* __restrict__ hflags, WideRound wr) {
-    __shared__ u32 s_tile;
     __shared__ u32 s_hp[4], s_cnt[5];
     __shared__ u32 s_carry_hp, s_carry_cnt;
     __shared__ u64 sk[GR_TILE + GR_TILE / 8 + 8];       // keys of the elements tile0 - 1 .. tile0 + 2048 (slot 0 = the predecessor)
@@ -301,8 +300,8 @@ __global__ __launch_bounds__(256) void sa_groups_kernel(const u64* __restrict__ 
     __shared__ u32 sv[GR_TILE + GR_TILE / 8], sp[GR_TILE + GR_TILE / 8];
     // Tiles are numbered by blockIdx: workgroups are dispatched in that order, so the predecessors of a running tile have been
     // dispatched (a ticket counter would make that formal, but one device-wide atomic per tile on ONE address costs ~25 ns each:
-    // 3.6 ms for the 131 072 tiles of a 256 MiB text, more than the whole pass).  The look-back spin is bounded (error flag).
-    (void)ticket; (void)s_tile;
+    // 3.6 ms for the 131 072 tiles of a 256 MiB text, more than the whole pass).  The look-back spin is bounded by wall-clock time
+    // (30 s: another context's long kernel on the same device only delays it), then the error flag is raised instead of hanging.
     const u32 tile = blockIdx.x;
     const int lane = lane_id(), w = wave_id();
     const size_t t0 = (size_t)tile * GR_TILE;
@@ -422,6 +421,7 @@ __global__ __launch_bounds__(256) void sa_groups_kernel(const u64* __restrict__ 
             if (lane == 0) __hip_atomic_store(desc + tile, gr_pack(GR_FLAG_AGG, tile_cnt, tile_hp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             long base = (long)tile - 1;
             u32 spins = 0;
+            const unsigned long long spin_t0 = wall_clock64();
             for (;;) {
                 const long idx = base - lane;
                 const u64 d64 = (idx >= 0) ? __hip_atomic_load(desc + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
@@ -431,7 +431,10 @@ __global__ __launch_bounds__(256) void sa_groups_kernel(const u64* __restrict__ 
                 const int first_inc = m_inc ? __ffsll((long long)m_inc) - 1 : 64;
                 const u64 need = first_inc >= 63 ? ~0ull : ((2ull << first_inc) - 1);   // the lanes up to the nearest inclusive one
                 if (m_zero & need) {
-                    if (++spins > (1u << 22)) { if (lane == 0) atomicOr(err, 4u); break; }   // never hang the GPU: report and leave
+                    if ((++spins & 1023u) == 0 && wall_clock64() - spin_t0 > 3000000000ull) {   // (100 MHz clock) never hang the GPU: report and leave
+                        if (lane == 0) atomicOr(err, 4u);
+                        break;
+                    }
                     __builtin_amdgcn_s_sleep(1);
                     continue;
                 }
@@ -588,7 +591,7 @@ struct SABufs {
     u64* keys[2]; u32* vals[2];
     u32 *head, *keep;
     u32 *A_sa, *A_pos, *A_r1, *B_sa, *B_pos, *B_r1;
-    u32* d_total; u64* lkeys; u32* lvals; u64* gdesc; u32* gticket;
+    u32* d_total; u64* lkeys; u32* lvals; u64* gdesc;
 };
 const WideRound NO_WIDE = { nullptr, nullptr, nullptr, 0, 0 };
 
@@ -599,13 +602,12 @@ size_t first_groups(Ctx& c, size_t n, int bn, const u64* keys, const u32* vals, 
     hipStream_t s = c.stream;
     const u32 tiles = cdiv(n, GR_TILE);
     HIP_TRY(hipMemsetAsync(B.gdesc, 0, (size_t)tiles * sizeof(u64), s));
-    HIP_TRY(hipMemsetAsync(B.gticket, 0, sizeof(u32), s));
     HIP_TRY(hipMemsetAsync(B.d_total, 0, 4 * sizeof(u32), s));
     const bool bucketed = want_ranks && c.bucket_scatter && n >= ((size_t)1 << 22);
     {   // per element: read key + value (12 B), write sa + head (8 B) + the kept elements (12 B each, about half of them)
         Ctx::ProfScope prof(c, K_SA_RANK_SCATTER, (u64)n * 26);
         sa_groups_kernel<true, 0><<<tiles, 256, 0, s>>>(keys, vals, nullptr, n, bn, sa, want_ranks ? rank : nullptr, bucketed ? B.head : nullptr,
-                                                        B.A_sa, B.A_pos, B.A_r1, B.gdesc, B.gticket, B.d_total, c.d_err, tiles, hflags, NO_WIDE);
+                                                        B.A_sa, B.A_pos, B.A_r1, B.gdesc, B.d_total, c.d_err, tiles, hflags, NO_WIDE);
         LAUNCH_CHECK();
     }
     // rank[vals[j]] = head[j] through a partition by destination window; the second key buffer and the B lists are free scratch
@@ -673,12 +675,11 @@ void doubling_rounds(Ctx& c, size_t n, int bn, u32* sa, u32* rank, SABufs& B, si
             u32* nr = (u32*)keys[x ^ 1];
             const u32 tiles = cdiv(m, GR_TILE);
             HIP_TRY(hipMemsetAsync(B.gdesc, 0, (size_t)tiles * sizeof(u64), s));
-            HIP_TRY(hipMemsetAsync(B.gticket, 0, sizeof(u32), s));
             HIP_TRY(hipMemsetAsync(B.d_total, 0, 4 * sizeof(u32), s));
             {   // per element: key, value, position (16 B), sa + new rank (8 B), the kept elements (12 B each)
                 Ctx::ProfScope prof(c, K_SA_RANK_SCATTER, (u64)m * 30);
                 sa_groups_kernel<false, 0><<<tiles, 256, 0, s>>>(keys[x], vals[x], B.A_pos, m, bn, sa, rank, bucketed ? nr : nullptr, B.B_sa, B.B_pos, B.B_r1,
-                                                                 B.gdesc, B.gticket, B.d_total, c.d_err, tiles, nullptr, NO_WIDE);
+                                                                 B.gdesc, B.d_total, c.d_err, tiles, nullptr, NO_WIDE);
                 LAUNCH_CHECK();
             }
             if (bucketed) bucketed_scatter_u32(c, vals[x], nr, m, rank, n, nr + m, vals[x ^ 1], B.head, B.keep);
@@ -737,7 +738,6 @@ int build_suffix_array_wide(Ctx& c, const u8* text, size_t n, u32* sa, u32* isa,
     B.lkeys = c.arena.get<u64>(n / 2 + 2048);
     B.lvals = c.arena.get<u32>(n / 2 + 2048);
     B.gdesc = c.arena.get<u64>(cdiv(n, GR_TILE) + 1);
-    B.gticket = c.arena.get<u32>(1);
     const int bn = (int)bits_for(n - 1);
 
     WSortStats ws;
@@ -785,13 +785,12 @@ int build_suffix_array_wide(Ctx& c, const u8* text, size_t n, u32* sa, u32* isa,
         st->sorted_elems += m;
         const u32 tiles = cdiv(m, GR_TILE);
         HIP_TRY(hipMemsetAsync(B.gdesc, 0, (size_t)tiles * sizeof(u64), s));
-        HIP_TRY(hipMemsetAsync(B.gticket, 0, sizeof(u32), s));
         HIP_TRY(hipMemsetAsync(B.d_total, 0, 4 * sizeof(u32), s));
         {
             Ctx::ProfScope prof(c, K_SA_RANK_SCATTER, (u64)m * 38);
             const WideRound wr = { K2[y], flags, lcp8, h, g.inv };
             sa_groups_kernel<false, 1><<<tiles, 256, 0, s>>>(K1[y], V[y], B.A_pos, m, bn, sa, nullptr, nullptr, B.B_sa, B.B_pos, B.B_r1,
-                                                             B.gdesc, B.gticket, B.d_total, c.d_err, tiles, nullptr, wr);
+                                                             B.gdesc, B.d_total, c.d_err, tiles, nullptr, wr);
             LAUNCH_CHECK();
         }
         c.read_n(B.d_total, h_tot, 4);
@@ -903,8 +902,7 @@ void build_suffix_array(Ctx& c, const u8* text, size_t n, u32* sa, u32* isa, SAS
         hflags = fl;
     }
     const int bn = (int)bits_for(n - 1);
-    B.gdesc = c.arena.get<u64>(cdiv(n, GR_TILE) + 1);       // look-back descriptors + ticket of the group kernel
-    B.gticket = c.arena.get<u32>(1);
+    B.gdesc = c.arena.get<u64>(cdiv(n, GR_TILE) + 1);       // look-back descriptors of the group kernel
     u32 h_tot[4];
     // (the rank scatter of first_groups uses keys[1] / vals[1] as scratch: the sorted pairs must be in the [0] buffers by then)
     if (x != 0) { u64* tk = keys[0]; keys[0] = keys[1]; keys[1] = tk; u32* tv = vals[0]; vals[0] = vals[1]; vals[1] = tv; x = 0; }
