@@ -7,6 +7,6 @@ R=$PWD
 mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/kt_$TAG
-timeout 900 rocprofv3 --kernel-trace --output-format csv -d /tmp/kt_$TAG -- python3 $R/tools/run_once.py $GEN $N $THR > $R/gpurun_out/ktrace_$TAG.run 2>&1
+timeout 900 rocprofv3 --kernel-trace --output-format csv -d /tmp/kt_$TAG -- python3 $R/tools/run_once.py $GEN $N $THR ${5:-huff} > $R/gpurun_out/ktrace_$TAG.run 2>&1
 python3 $R/tools/kernel_times.py /tmp/kt_$TAG $R/gpurun_out/ktrace_$TAG
 cd $R

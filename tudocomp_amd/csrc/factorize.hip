@@ -280,7 +280,7 @@ constexpr u32 SMALL_RANKSORT = 1024; // up to here a counting sort in LDS beats 
 constexpr u32 SMALL_SELSCAN = 32;    // up to this many selected entries the encounter values scan the selected list, not the neighbours
 
 template <int NT>
-__global__ __launch_bounds__(NT) void small_level_kernel(const u32* __restrict__ orig, u32 m0, const u32* __restrict__ pushed, u32 m_raw,
+__global__ __launch_bounds__(NT) void small_level_kernel(const u32* __restrict__ orig, u32 m0_arg, const u32* __restrict__ pushed, u32 m_raw_arg,
                                                            const u32* __restrict__ pool_all, const GatherSeg* __restrict__ gtab, u32 gn,
                                                            u32 L, u32 threshold, size_t n, u32* cur, u32* prio,
                                                            const u32* __restrict__ phi, u32* __restrict__ flen, u8* __restrict__ res8,
@@ -288,7 +288,11 @@ __global__ __launch_bounds__(NT) void small_level_kernel(const u32* __restrict__
                                                            PushSeg* __restrict__ segs, u32 seg_cap, u32* __restrict__ sel_list,
                                                            u32 inline_budget, LevelScalars* __restrict__ sc,
                                                            u32* zc_dst, u32* zc_flag, u32 zc_seq, unsigned long long* prof, u32* zc_segs,
-                                                           SmallCtl* __restrict__ ctl, u32 spec, const LevelScalars* prev_sc, const PushSeg* prev_segs) {
+                                                           SmallCtl* __restrict__ ctl, u32 spec, const LevelScalars* prev_sc, const PushSeg* prev_segs,
+                                                           const u32* __restrict__ m0_dev) {
+    // (level_purge_kernel may have shortened the original part of the list: the rest of the segment are copies of one erased entry)
+    u32 m0 = m0_arg, m_raw = m_raw_arg;
+    if (m0_dev) { const u32 d = *m0_dev; if (d < m0) { m_raw -= m0 - d; m0 = d; } }
 #define SPROF(k) do { if (prof) { const unsigned long long now_ = wall_clock64(); acc_prof[k] = now_ - t_prof; t_prof = now_; } } while (0)
     constexpr u32 SM = (u32)NT * 8;                          // survivors the workgroup holds (eight per thread)
     constexpr u32 NWV = (u32)NT / 64;
@@ -736,6 +740,54 @@ full_sort:
 #undef SPROF
 }
 
+// ---- purge ahead: the lists of the next 64 levels, in place ------------------------------------------------------------------------
+// Every factor of a level above leaves one erased candidate behind in each list below it (the ramp of its repeat), so on texts with long
+// repeats a list of 10 000 candidates holds a few hundred alive ones -- and the one-workgroup level kernel spends half its time loading
+// the rest.  The global purge (below) rewrites all lists still to come and costs more than it saves once the lists fit one workgroup.
+// This kernel only touches the lists of the next 64 levels, one workgroup per list: alive entries first, in their old order (the level
+// kernel relies on it), the rest of the segment filled with ONE of the list's erased positions -- such an entry stays erased for good
+// (cur only decreases), every consumer drops it, and sixty gathers of one address cost one.  Segment bounds do not change.
+struct PurgeWin { u32 start[64]; u32 cnt[64]; u32 level[64]; u32 n; };
+constexpr u32 PURGE_CAP = 16384;
+__global__ __launch_bounds__(1024) void level_purge_kernel(u32* __restrict__ cand, PurgeWin W, u32 threshold, const u32* __restrict__ cur, u32* __restrict__ lcount) {
+    __shared__ u32 buf[PURGE_CAP];
+    __shared__ u32 s_w[16], s_dead;
+    const u32 lv = blockIdx.x;
+    if (lv >= W.n) return;
+    const u32 m = W.cnt[lv];
+    if (m < 1024 || m > PURGE_CAP) return;
+    u32* list = cand + W.start[lv];
+    const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) s_dead = NONE32;
+    __syncthreads();
+    u32 base = 0;
+    for (u32 i0 = 0; i0 < m; i0 += 1024 * 4) {
+        u32 p[4];
+        bool al[4];
+#pragma unroll
+        for (u32 r = 0; r < 4; ++r) { const u32 i = i0 + r * 1024 + tid; p[r] = (i < m) ? list[i] : NONE32; }
+#pragma unroll
+        for (u32 r = 0; r < 4; ++r) al[r] = p[r] != NONE32 && cur[p[r]] >= threshold;
+#pragma unroll
+        for (u32 r = 0; r < 4; ++r) {
+            const u64 bm = __ballot(al[r]);
+            if (lane == 0) s_w[wv] = (u32)__popcll(bm);
+            __syncthreads();
+            u32 off = base, tot = 0;
+#pragma unroll
+            for (u32 q = 0; q < 16; ++q) { const u32 t = s_w[q]; if (q < wv) off += t; tot += t; }
+            if (al[r]) buf[off + (u32)__popcll(bm & ((1ull << lane) - 1ull))] = p[r];
+            else if (p[r] != NONE32) s_dead = p[r];
+            base += tot;
+            __syncthreads();
+        }
+    }
+    const u32 dead = s_dead;
+    if (tid == 0) lcount[W.level[lv]] = base;               // (the level kernel stops there)
+    if (base == m) return;                                  // nothing erased
+    for (u32 i = tid; i < m; i += 1024) list[i] = (i < base) ? buf[i] : dead;
+}
+
 // apply for a list of selected positions whose length is only known on the device (one wave per factor)
 __global__ __launch_bounds__(256) void apply_list_kernel(const u32* __restrict__ list, const u32* __restrict__ d_count, u32 L, size_t n,
                                                           const u32* __restrict__ phi, u32* __restrict__ cur, u32* __restrict__ flen,
@@ -1017,6 +1069,29 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
     bool purge_pays = false;                               // a level too large for the one-workgroup path consisted mostly of erased entries
     u32 dead_levels_run = 0;                               // consecutive levels whose entries were all erased
     u32 last_alive = 0;                                    // survivors of the last one-workgroup level (chooses the instance of the next one)
+    u32* d_lcount = c.arena.get<u32>(nlev);                // per level: entries of the original list that are left after level_purge_kernel (all ones: not purged)
+    HIP_TRY(hipMemsetAsync(d_lcount, 0xFF, nlev * sizeof(u32), s));
+    u32 purge_next = 0xFFFFFFFFu;                          // level_purge_kernel has been run for the levels >= purge_next
+    auto purge_ahead = [&](u32 lv) {                       // called before anything reads the list of level lv
+        if (!c.level_purge || lv >= purge_next) return;
+        PurgeWin W;
+        W.n = 0;
+        const u32 floor_lv = std::max<u32>(lcut + 1, threshold);
+        u32 v = lv;
+        bool any = false;
+        for (; W.n < 64 && v >= floor_lv; --v) {
+            W.start[W.n] = h_segstart[v];
+            W.cnt[W.n] = h_segend[v] - h_segstart[v];
+            W.level[W.n] = v;
+            if (W.cnt[W.n] >= 1024 && W.cnt[W.n] <= PURGE_CAP) any = true;
+            ++W.n;
+            if (v == 0) break;
+        }
+        purge_next = (lv >= 64) ? lv - 63 : 0;
+        if (!any) return;
+        level_purge_kernel<<<W.n, 1024, 0, s>>>(cvals[x], W, threshold, cur, d_lcount);
+        LAUNCH_CHECK();
+    };
     u32 nolive_run = 0, stale_trigger = 8;                 // consecutive levels without a live entry; run length that triggers the batch push
     double host_prof[5] = {0, 0, 0, 0, 0};                // small levels, host side: prepare / launch / wait / bookkeeping (us), count
     unsigned long long* d_sprof = nullptr;                 // TDC_GPU_SMALL_PROF=1: phase times of the small-level kernel on stderr
@@ -1054,6 +1129,8 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
                 LAUNCH_CHECK();
             }
             build_lists(false, L);
+            HIP_TRY(hipMemsetAsync(d_lcount, 0xFF, nlev * sizeof(u32), s));
+            purge_next = 0xFFFFFFFFu;
             cand = cvals[x];
             dead_streak = 0; levels_since_purge = 1u << 30;
             lcut = (why == 1 && L > 24 && threshold <= 24) ? 24 : 0;      // borders only: they move half as far from level 24 on
@@ -1081,6 +1158,8 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
                 c.read_n(d_segstart, h_segstart.data(), (size_t)L + 1);
                 c.read_n(d_segend, h_segend.data(), (size_t)L + 1);
                 st->purges++;
+                HIP_TRY(hipMemsetAsync(d_lcount, 0xFF, nlev * sizeof(u32), s));      // new lists: counts unknown, nothing purged ahead
+                purge_next = 0xFFFFFFFFu;
             }
             levels_since_purge = 0;
             dead_streak = 0;
@@ -1253,6 +1332,7 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
                 const std::vector<PoolSeg>& sv = pushed_into.get(lv);
                 const u32 half = gtab_cap / 2;
                 if ((spec || lv != L) && (mm == 0 || mm > raw_cap || ns > SMALL_GATHER || ns > half || !d_hgtab)) return false;
+                purge_ahead(lv);
                 // the 512-thread instance where the list is long or the levels above had many survivors (a level that overflows the
                 // small instance would be run twice)
                 const bool big = c.small_big == 2 || (c.small_big && (mm > SMALL_RAW || last_alive > SMALL_M * 3 / 4));   // (2: always -- tests)
@@ -1280,12 +1360,12 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
                         small_level_kernel<512><<<1, 512, 0, s>>>(cand + h_segstart[lv], a0, pushed_src, (u32)mm, pool, d_hgtab ? d_hgtab + (size_t)slot * half : nullptr, gn, lv,
                                                                   threshold, n, cur, prio, phi, fs.flen, res8, fs.fsrc, (u32)pool_top, prio_base, d_segs2[slot], seg_cap, live,
                                                                   /*inline_budget=*/1u << 17, d_sc2[slot], zdst, zflag, zseq, d_sprof, zsegs,
-                                                                  d_ctl, spec ? 1u : 0u, d_sc2[slot ^ 1], d_segs2[slot ^ 1]);
+                                                                  d_ctl, spec ? 1u : 0u, d_sc2[slot ^ 1], d_segs2[slot ^ 1], d_lcount + lv);
                     else
                         small_level_kernel<256><<<1, 256, 0, s>>>(cand + h_segstart[lv], a0, pushed_src, (u32)mm, pool, d_hgtab ? d_hgtab + (size_t)slot * half : nullptr, gn, lv,
                                                                   threshold, n, cur, prio, phi, fs.flen, res8, fs.fsrc, (u32)pool_top, prio_base, d_segs2[slot], seg_cap, live,
                                                                   /*inline_budget=*/1u << 17, d_sc2[slot], zdst, zflag, zseq, d_sprof, zsegs,
-                                                                  d_ctl, spec ? 1u : 0u, d_sc2[slot ^ 1], d_segs2[slot ^ 1]);
+                                                                  d_ctl, spec ? 1u : 0u, d_sc2[slot ^ 1], d_segs2[slot ^ 1], d_lcount + lv);
                     LAUNCH_CHECK();
                 }
                 inflight_push_max += push_max;
@@ -1386,6 +1466,7 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
             if (!general_path) continue;
             // (general path for level L: its list is re-read below)
         }
+        purge_ahead(L);
         if (!gathered) gather_all();
         pushed_into.drop(L);
         HIP_TRY(hipMemsetAsync(d_sc, 0, 8 * sizeof(u32), s));
