@@ -12,9 +12,13 @@ host memory.  Both transfers are INSIDE the timed region; `value` = input bytes 
           "configs2_dna_1e9" = BASELINE.json configs[2] (10^9 B DNA, LCPCompressor + ArithmeticCoder, threshold 5) through
           the same entry point, its stream checked against the CPU oracle on a 32 MiB DNA sample.
   N > 1 : BASELINE.json configs[4]: one process per GPU (torch.distributed, backend nccl = RCCL); every rank compresses
-          its own 2*10^9 B shard (seed 42 + rank: weak scaling), the per-shard streams are gathered on rank 0 over xGMI
-          (grouped point-to-point) and rank 0 copies the block container to its host memory.
-          value = bytes of all ranks / max-over-ranks time.
+          its own 2*10^9 B shard (seed 42 + rank: weak scaling) exactly as in the N = 1 case (pinned host text, upload
+          overlapped with the first partition level), keeps the stream on its GPU, the ranks all-gather the stream sizes
+          and every rank downloads its stream to its offset of ONE block container in the node's shared host memory --
+          eight shards over eight host links at once.  Where the shared segment cannot be set up,
+          the streams are gathered on rank 0 over xGMI (grouped point-to-point) and rank 0 downloads the container
+          ("exchange" in the line says which).  value = bytes of all ranks / max-over-ranks time.
+          TDC_BENCH_BACKEND=gloo rehearses the N > 1 path with several ranks on ONE GPU (collectives on CPU tensors).
 
 After the timed steps ONE more step runs with per-kernel HIP-event timing switched on (untimed) -- the roofline object and
 the per-kernel table come from it.  Prints ONE JSON line (rank 0).  PyTorch is used for torch.distributed and the
@@ -154,40 +158,84 @@ def main():
     import numpy as np
     import torch
     import tudocomp_amd as T
-    from tudocomp_amd.blocks import gather_streams, MAGIC
+    from tudocomp_amd.blocks import gather_streams, MAGIC, SharedContainer, payload_offsets, header_len, unpack_container
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    backend = os.environ.get("TDC_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()   # (gloo rehearsal: ranks may share a GPU)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    coll_device = device if backend == "nccl" else torch.device("cpu")     # where the tensors of the collectives live
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend=backend)
 
     # ---- synthetic input in pinned host memory ---------------------------------------------------------------------------
     gen = T.gen_english if args.gen == "english" else T.gen_dna
     h_text = T.PinnedBuffer(n)
     gen(N, seed, out=h_text.a)
     h_text.a[N] = 0
-    ctx = T.Context(local_rank)
+    ctx = T.Context(dev_index)
     ctx.reserve(n)
     out_cap = N + (1 << 20)                               # the stream of these texts is < 0.5 N; a larger one fails loudly
     h_out = T.PinnedBuffer(out_cap)
 
-    d_text = d_out = h_container = None
-    if world > 1:                                         # multi-GPU staging: HBM text / stream buffers for the RCCL gather
-        t_text = torch.from_numpy(h_text.a)
-        d_text = torch.empty(n, dtype=torch.uint8, device=device)
-        d_out = torch.empty(out_cap, dtype=torch.uint8, device=device)
-        if rank == 0:
-            h_container = torch.empty(world * out_cap // 2 + 4096, dtype=torch.uint8).pin_memory()
+    d_text = d_out = h_container = shared = None
+    exchange = None
+    if world > 1:
+        # the block container of the node: one shared-memory segment that every rank maps and page-locks
+        cont_cap = world * (out_cap // 2) + 4096
+        ok = 1
+        try:
+            name = "tdc_blocks_%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "run"))
+            if rank == 0:
+                shared = SharedContainer(name, cont_cap, create=True)
+            dist.barrier()
+            if rank != 0:
+                shared = SharedContainer(name, cont_cap, create=False)
+            if not shared.register(T.host_register):
+                ok = 0
+        except Exception:
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int64, device=coll_device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1 and not os.environ.get("TDC_BENCH_RCCL_GATHER"):
+            exchange = "shared host memory"
+        else:                                             # fall back: HBM staging buffers for the RCCL gather to rank 0
+            exchange = "rccl gather to rank 0"
+            if shared is not None:
+                shared.close(T.host_unregister)
+                shared = None
+            if backend != "nccl":
+                raise SystemExit("the RCCL gather needs the nccl backend")
+            t_text = torch.from_numpy(h_text.a)
+            d_text = torch.empty(n, dtype=torch.uint8, device=device)
+            d_out = torch.empty(out_cap, dtype=torch.uint8, device=device)
+            if rank == 0:
+                h_container = torch.empty(cont_cap, dtype=torch.uint8).pin_memory()
 
     def step():
         if world == 1:
             out_len, st = ctx.lcpcomp_compress_into(h_text, n, h_out, args.threshold, 1)
             return out_len, st, None
+        if shared is not None:
+            out_len, st = ctx.lcpcomp_compress_keep(h_text, n, args.threshold, 1)       # as N = 1, the stream stays in HBM
+            szt = [torch.zeros(1, dtype=torch.int64, device=coll_device) for _ in range(world)]
+            dist.all_gather(szt, torch.tensor([out_len], dtype=torch.int64, device=coll_device))
+            sizes = [int(x.item()) for x in szt]
+            offs, end = payload_offsets(sizes)
+            if end > shared.capacity:
+                raise SystemExit("block container too small")
+            ctx.stream_fetch(shared.a[offs[rank]:offs[rank] + out_len])                  # D2H to this rank's place in the container
+            if rank == 0:
+                shared.write_header([N] * world, sizes)
+            return out_len, st, sizes
         d_text.copy_(t_text, non_blocking=True)           # H2D of this rank's shard
         torch.cuda.synchronize()                          # the library runs on its own stream (include/tdc_gpu.h)
         out_len, st = ctx.lcpcomp_compress_dev(d_text.data_ptr(), n, d_out.data_ptr(), out_cap, args.threshold, 1)
@@ -216,13 +264,26 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     ranks_seen = world
+    container_ok = None
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=coll_device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-        bitmap = torch.tensor([1 << rank], dtype=torch.int64, device=device)
+        bitmap = torch.tensor([1 << rank], dtype=torch.int64, device=coll_device)
         dist.all_reduce(bitmap, op=dist.ReduceOp.SUM)
         ranks_seen = bin(int(bitmap.item())).count("1")
+        if shared is not None:
+            # untimed check of the last step's container: every rank downloads its stream once more into private memory and compares
+            # it with what rank 0 reads at that rank's offset of the shared segment (hash exchange), rank 0 parses the framing
+            mine = np.empty(out_len, dtype=np.uint8)
+            ctx.stream_fetch(mine)
+            hs = hashlib.sha256(mine).digest()
+            hv = [torch.zeros(32, dtype=torch.uint8, device=coll_device) for _ in range(world)]
+            dist.all_gather(hv, torch.frombuffer(bytearray(hs), dtype=torch.uint8).to(coll_device))
+            if rank == 0:
+                parts = unpack_container(shared.blob(sizes))
+                container_ok = len(parts) == world and all(
+                    int(parts[r][0]) == N and hashlib.sha256(parts[r][1]).digest() == bytes(hv[r].cpu().numpy()) for r in range(world))
 
     # ---- one more step with per-kernel timing (untimed): roofline + kernel table ----------------------------------------------
     ctx.set_profiling(True)
@@ -262,22 +323,24 @@ def main():
         tot = sum(d[0] for d in dev_ms) / len(dev_ms)
         h2d = sum(d[1] for d in dev_ms) / len(dev_ms)
         d2h = sum(d[2] for d in dev_ms) / len(dev_ms)
-        kern_ms = tot - h2d - d2h if world == 1 else tot
+        kern_ms = tot - h2d - d2h if (world == 1 or shared is not None) else tot     # (the RCCL path hands the library a device text)
         if world == 1:
             workload = ("lcpcomp(coder=huff,threshold=%d,flatten=1,comp=arrays) on %d B %s text (SURVEY 8d generator, seed %d): "
                         "pinned host text -> H2D -> kernels + host Huffman table -> D2H -> stream in pinned host memory, all timed"
                         % (args.threshold, N, args.gen, seed0))
         else:
             workload = ("BASELINE configs[4]: %d independent %d B %s shards (seeds %d+rank), per-shard lcpcomp(coder=huff,threshold=%d,flatten=1); "
-                        "H2D + kernels + RCCL gather of the streams to rank 0 + D2H of the block container, all timed"
-                        % (world, N, args.gen, seed0, args.threshold))
+                        "%s, all timed"
+                        % (world, N, args.gen, seed0, args.threshold,
+                           "pinned host text -> H2D -> kernels -> all-gather of the stream sizes -> every rank's D2H to its offset of the block container in shared host memory"
+                           if shared is not None else "H2D + kernels + RCCL gather of the streams to rank 0 + D2H of the block container"))
         line = {
             "metric": "input MB/s end-to-end lcpcomp+huffman",
             "value": round(value, 2), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": workload, "bytes_per_gpu": N,
-                       "parallelism": "independent shards x%d + RCCL gather to rank 0" % world if world > 1 else "single GPU"},
+                       "parallelism": ("independent shards x%d, %s" % (world, exchange)) if world > 1 else "single GPU"},
             "roofline": roof,
             "hbm_resident": {"value": round(N / 1e6 / (kern_ms * 1e-3), 2), "unit": "MB/s", "ms_per_step": round(kern_ms, 3),
                              "note": "same steps, device time without the H2D / D2H transfers (per GPU)"},
@@ -293,6 +356,10 @@ def main():
             line["ranks_seen"] = ranks_seen
             line["world_size"] = dist.get_world_size()
             line["gathered_bytes"] = sum(sizes)
+            line["exchange"] = exchange
+            line["collective_backend"] = backend
+            if container_ok is not None:
+                line["container_ok"] = bool(container_ok)
         if cpu_res is not None:
             m1, want_len, want_sha = cpu_ref
             sample = np.concatenate([h_text.a[:m1], np.zeros(1, dtype=np.uint8)])
@@ -334,9 +401,12 @@ def main():
                 dna["sample"] = "first %d bytes of the DNA text; oracle (1 core) %.1f s" % (m3, cpu_s)
             line["configs2_dna_1e9"] = dna
         print(json.dumps(line))
+    if world > 1:
+        dist.barrier()                                     # nobody unmaps the container while rank 0 still reads it
+    if shared is not None:
+        shared.close(T.host_unregister)
     ctx.close()
     if world > 1:
-        dist.barrier()
         dist.destroy_process_group()
 
 

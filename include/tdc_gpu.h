@@ -126,6 +126,18 @@ int tdc_gpu_lcpcomp_compress_comp(tdc_gpu_ctx* ctx, const uint8_t* text, size_t 
  * by the runtime.  stats->ms_h2d / ms_d2h / ms_total cover the transfers. */
 int tdc_gpu_lcpcomp_compress_into(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, uint32_t threshold, int flatten, int coder,
                                   int comp, uint8_t* out, size_t out_cap, size_t* out_len, tdc_gpu_stats* stats);
+/* One process per GPU, one container per node (SURVEY.md 8e replaces nothing of the reference: its 32-bit len_t has
+ * no block mode).  tdc_gpu_lcpcomp_compress_keep is tdc_gpu_lcpcomp_compress_into without the download: the stream STAYS on the
+ * device inside the context until the next call on it, *out_len receives its length.  Once the ranks have exchanged their lengths,
+ * tdc_gpu_stream_fetch copies the kept stream to `dst` -- this rank's offset in a container that all ranks map, e.g. a POSIX
+ * shared-memory segment page-locked with tdc_gpu_host_register -- so every shard travels over its own GPU's host link instead of
+ * all of them through rank 0.  tdc_gpu_stream_fetch: *len (nullable) receives the stream length; TDC_GPU_ERR_OOM if cap is smaller. */
+int tdc_gpu_lcpcomp_compress_keep(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, uint32_t threshold, int flatten, int coder,
+                                  int comp, size_t* out_len, tdc_gpu_stats* stats);
+int tdc_gpu_stream_fetch(tdc_gpu_ctx* ctx, uint8_t* dst, size_t cap, size_t* len);
+/* Page-lock / release host memory the embedding program allocated itself (hipHostRegister): transfers then run at PCIe rate. */
+int tdc_gpu_host_register(void* p, size_t bytes);
+int tdc_gpu_host_unregister(void* p);
 /* Pinned (page-locked) host memory for the buffers above; NULL on failure.  Free with tdc_gpu_host_free. */
 void* tdc_gpu_host_alloc(size_t bytes);
 void  tdc_gpu_host_free(void* p);

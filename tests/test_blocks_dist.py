@@ -114,3 +114,59 @@ def test_container_roundtrip_and_ranges():
     assert [(r, bytes(p)) for r, p in blocks.unpack_container(blob)] == list(zip([0, 10, 300], parts))
     assert blocks.shard_ranges(10, 4) == [(0, 4), (4, 8), (8, 10)]
     assert blocks.shard_ranges(8, 4) == [(0, 4), (4, 8)]
+
+
+def _worker_shared(rank, world, port, tmpdir):
+    """the exchange through ONE shared-memory container (bench.py's default for N > 1): sizes all-gathered, every rank writes its
+    stream at its own offset, rank 0 the header"""
+    from oracle import oracle as O
+    import tudocomp_amd as T
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    shared = None
+    try:
+        shard = b"" if rank == 2 else T.gen_dna(15000 + 4321 * rank, 7 + rank).tobytes()       # rank 2: an empty shard
+        stream, _ = O.lcpcomp_huff_compress(O.escape(shard), 3, 1)
+        name = "tdc_test_blocks_%d" % port
+        if rank == 0:
+            shared = blocks.SharedContainer(name, 1 << 20, create=True)
+        dist.barrier()
+        if rank != 0:
+            shared = blocks.SharedContainer(name, 1 << 20, create=False)
+        szt = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(szt, torch.tensor([len(stream)], dtype=torch.int64))
+        sizes = [int(x.item()) for x in szt]
+        raw = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(raw, torch.tensor([len(shard)], dtype=torch.int64))
+        offs, end = blocks.payload_offsets(sizes)
+        assert offs[0] == blocks.header_len(world) and end == offs[-1] + sizes[-1]
+        shared.a[offs[rank]:offs[rank] + len(stream)] = np.frombuffer(stream, dtype=np.uint8)
+        if rank == 0:
+            shared.write_header([int(r.item()) for r in raw], sizes)
+        dist.barrier()                                       # every payload is in place
+        if rank == 0:
+            with open(os.path.join(tmpdir, "shared_container.bin"), "wb") as f:
+                f.write(shared.blob(sizes))
+        dist.barrier()
+    finally:
+        if shared is not None:
+            shared.close()
+        dist.destroy_process_group()
+
+
+def test_container_in_shared_memory_world3(tmp_path):
+    world = 3
+    port = _free_port()
+    mp.spawn(_worker_shared, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    from oracle import oracle as O
+    import tudocomp_amd as T
+    assert not os.path.exists("/dev/shm/tdc_test_blocks_%d" % port)          # rank 0 removed the segment
+    parts = blocks.unpack_container(open(tmp_path / "shared_container.bin", "rb").read())
+    assert len(parts) == world
+    for r, (raw_len, payload) in enumerate(parts):
+        shard = b"" if r == 2 else T.gen_dna(15000 + 4321 * r, 7 + r).tobytes()
+        assert raw_len == len(shard)
+        want, _ = O.lcpcomp_huff_compress(O.escape(shard), 3, 1)
+        assert payload == want
+        assert O.unescape(O.lcpcomp_huff_decompress(payload)) == shard

@@ -115,3 +115,32 @@ def test_raw_entry_point_accepts_more_than_2_pow_30_bytes_of_plain_text(gpu_ctx)
     assert st["n"] == n + 1 and len(out) == st["out_len"]
     text = np.concatenate([data, np.zeros(1, dtype=np.uint8)])
     assert O.lcpcomp_huff_decompress(out) == text.tobytes()
+
+
+def test_kept_stream_is_fetched_into_registered_shared_memory(gpu_ctx, tmp_path):
+    """tdc_gpu_lcpcomp_compress_keep / tdc_gpu_stream_fetch / tdc_gpu_host_register: the one-process-per-GPU block mode downloads
+    every rank's stream to its offset of a container in shared memory (bench.py N > 1)"""
+    import numpy as np
+    from oracle import oracle as O
+    data = T.gen_english(3_000_000, 17).tobytes()
+    text = O.escape(data)
+    want, _ = O.lcpcomp_huff_compress(text, 2, 1)
+    ta = np.frombuffer(text, dtype=np.uint8)
+    ln, st = gpu_ctx.lcpcomp_compress_keep(ta, len(ta), 2, 1)
+    assert ln == len(want) and st["ms_d2h"] == 0
+    shared = blocks.SharedContainer("tdc_test_keep_%d" % os.getpid(), 4 << 20, create=True)
+    try:
+        assert shared.register(T.host_register)
+        off = blocks.header_len(1)
+        assert gpu_ctx.stream_fetch(shared.a[off:off + ln]) == ln
+        shared.write_header([len(data)], [ln])
+        assert blocks.unpack_container(shared.blob([ln])) == [(len(data), want)]
+        again = np.zeros(ln + 5, dtype=np.uint8)                 # the stream may be fetched again, into pageable memory too
+        assert gpu_ctx.stream_fetch(again) == ln and again[:ln].tobytes() == want
+        with pytest.raises(T.TdcGpuError):
+            gpu_ctx.stream_fetch(np.zeros(ln - 1, dtype=np.uint8))          # too small
+        gpu_ctx.suffix_array(O.escape(b"abracadabra"))                     # any other call: the kept stream is gone
+        with pytest.raises(T.TdcGpuError):
+            gpu_ctx.stream_fetch(again)
+    finally:
+        shared.close(T.host_unregister)

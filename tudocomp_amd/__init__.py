@@ -136,6 +136,17 @@ class PinnedBuffer:
     __del__ = free
 
 
+def host_register(a):
+    """page-lock the memory of a numpy array the caller allocated itself (e.g. a memory-mapped shared segment): True on success"""
+    if not (isinstance(a, np.ndarray) and a.flags.c_contiguous):
+        raise ValueError("host_register: a C-contiguous numpy array is needed")
+    return _native.load().tdc_gpu_host_register(ctypes.c_void_p(a.ctypes.data), a.nbytes) == 0
+
+
+def host_unregister(a):
+    return _native.load().tdc_gpu_host_unregister(ctypes.c_void_p(a.ctypes.data)) == 0
+
+
 class Context:
     """One GPU, one HIP stream, one device arena (tdc_gpu_ctx)."""
 
@@ -213,6 +224,24 @@ class Context:
         self._check(self._L.tdc_gpu_lcpcomp_compress_into(self._h, _ptr(ta), n, threshold, int(flatten), coder, comp, _ptr(oa), len(oa),
                                                           ctypes.byref(ol), ctypes.byref(st)))
         return ol.value, st.as_dict()
+
+    def lcpcomp_compress_keep(self, text, n, threshold=5, flatten=1, coder=CODER_HUFF, comp=COMP_ARRAYS):
+        """lcpcomp_compress_into without the download: the stream stays on the device until the next call on this context
+        (stream_fetch copies it out).  Returns (out_len, stats)."""
+        ta = text.a if isinstance(text, PinnedBuffer) else _u8(text)
+        ol, st = ctypes.c_size_t(), Stats()
+        self._check(self._L.tdc_gpu_lcpcomp_compress_keep(self._h, _ptr(ta), n, threshold, int(flatten), coder, comp, ctypes.byref(ol), ctypes.byref(st)))
+        return ol.value, st.as_dict()
+
+    def stream_fetch(self, out):
+        """copy the stream kept by lcpcomp_compress_keep into the host buffer `out` (a writable, contiguous numpy uint8 array or a
+        PinnedBuffer -- e.g. this rank's slice of a container in shared memory).  Returns the stream length."""
+        oa = out.a if isinstance(out, PinnedBuffer) else out
+        if not (isinstance(oa, np.ndarray) and oa.dtype == np.uint8 and oa.flags.c_contiguous and oa.flags.writeable):
+            raise ValueError("stream_fetch: `out` must be a writable, C-contiguous uint8 array")
+        ln = ctypes.c_size_t()
+        self._check(self._L.tdc_gpu_stream_fetch(self._h, _ptr(oa), oa.size, ctypes.byref(ln)))
+        return ln.value
 
     def lcpcomp_compress_raw(self, data, threshold=5, flatten=1, coder=CODER_HUFF):
         """data: unrestricted input; escaping + sentinel happen on the device.  Returns (compressed bytes, stats dict)."""

@@ -5,9 +5,14 @@ The reference has no block mode; the framing is this projec
     b"tdcgpu-blocks%" | u32 G | G x { u64 raw_len, u64 comp_len } | payload_0 | ... | payload_{G-1}
 
 Every payload is byte-identical to the `--raw` lcpcomp stream of that shard.  Shards are independent, so there is no
-data-path collective during compression; afterwards the per-shard streams are gathered on rank 0: an all-gather of
-the sizes, then ONE group of point-to-point operations (on a GPU node: RCCL, every peer over its own xGMI link to rank 0).
+data-path collective during compression.  Afterwards the container is put together in the node's host memory, one of two ways:
+  * SharedContainer (default where POSIX shared memory can be mapped): all ranks map ONE segment; after an all-gather of the
+    stream sizes every rank downloads its own stream straight to its offset (tdc_gpu_stream_fetch) -- eight shards travel over
+    eight host links at once, nothing passes through rank 0's GPU;
+  * gather_streams: all-gather of the sizes, then ONE group of point-to-point operations (on a GPU node: RCCL, every peer over its
+    own xGMI link to rank 0), and rank 0 downloads the whole container over its one host link.
 """
+import os
 import struct
 
 MAGIC = b"tdcgpu-blocks%"
@@ -52,6 +57,61 @@ def decompress_container(blob, decode_block):
 def shard_ranges(total, shard):
     """Contiguous byte ranges [k*shard, (k+1)*shard); the last one may be shorter."""
     return [(o, min(o + shard, total)) for o in range(0, total, shard)]
+
+
+def header_len(world):
+    return len(MAGIC) + 4 + 16 * world
+
+
+def payload_offsets(sizes):
+    """byte offset of every rank's payload in the container (tightly packed behind the header)"""
+    offs, o = [], header_len(len(sizes))
+    for s in sizes:
+        offs.append(o)
+        o += int(s)
+    return offs, o
+
+
+class SharedContainer:
+    """The block container of one node in POSIX shared memory.  Rank 0 creates the segment, the others attach after a barrier; every
+    rank may page-lock its mapping (`register`) so that downloads into it run at PCIe rate.  `a` is the numpy uint8 view."""
+
+    def __init__(self, name, capacity, create):
+        import numpy as np
+        self.path = os.path.join("/dev/shm", name)
+        self.capacity = int(capacity)
+        self.created = bool(create)
+        self.registered = False
+        if create:
+            with open(self.path, "wb") as f:
+                f.truncate(self.capacity)
+        self.a = np.memmap(self.path, dtype=np.uint8, mode="r+", shape=(self.capacity,))
+
+    def register(self, host_register):
+        self.registered = bool(host_register(self.a))
+        return self.registered
+
+    def write_header(self, raw_lens, sizes):
+        head = MAGIC + struct.pack("<I", len(sizes))
+        for r, c in zip(raw_lens, sizes):
+            head += struct.pack("<QQ", int(r), int(c))
+        self.a[:len(head)] = memoryview(head)
+
+    def blob(self, sizes):
+        """the container as bytes (tests; a writer would hand `a[:end]` to write())"""
+        _, end = payload_offsets(sizes)
+        return bytes(self.a[:end])
+
+    def close(self, host_unregister=None):
+        if self.registered and host_unregister is not None:
+            host_unregister(self.a)
+            self.registered = False
+        self.a = None
+        if self.created:
+            try:
+                os.unlink(self.path)
+            except OSError:
+                pass
 
 
 def gather_streams(dist, torch, stream, length, rank, world, device):

@@ -16,6 +16,8 @@ struct tdc_gpu_ctx {
     Ctx c;
     WPre pre;                   // level 1 of the suffix sort behind the upload (compress_host); c.wpre points here
     std::string last_error;
+    const u8* kept = nullptr;   // tdc_gpu_lcpcomp_compress_keep: the stream of the last call, in the arena (until the next call)
+    size_t kept_len = 0;
 };
 
 namespace {
@@ -50,6 +52,7 @@ template <typename F>
 int guarded(tdc_gpu_ctx* ctx, F&& f) {
     if (!ctx) return TDC_GPU_ERR_ARG;
     ctx->last_error.clear();
+    ctx->kept = nullptr; ctx->kept_len = 0;      // (every call may reuse the arena)
     ctx->c.hist_ptr = nullptr;                   // the cached byte histogram belongs to ONE call (same address, other text: stale)
     DeviceGuard dg(ctx->c.device);               // the caller's current device is restored on every exit path
     try {
@@ -448,13 +451,13 @@ namespace {
 // Host buffers in, host buffer out: H2D, (escape,) the whole pipeline, D2H.  The output goes either into a malloc'd buffer
 // (*ho.out) or into the caller's buffer ho.into of ho.cap bytes; copies from / to pinned memory (tdc_gpu_host_alloc) run at
 // PCIe speed, pageable memory is staged by the runtime.
-struct HostOut { uint8_t** out; uint8_t* into; size_t cap; size_t* out_len; };
+struct HostOut { uint8_t** out; uint8_t* into; size_t cap; size_t* out_len; bool keep = false; };   // keep: the stream stays on the device (ctx->kept)
 void compress_host(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, bool raw, uint32_t threshold, int flatten, int coder, int comp,
                    HostOut ho, tdc_gpu_stats* stats) {
     (void)lcpcomp_enc_coder(coder);
     if (comp != TDC_GPU_COMP_ARRAYS && comp != TDC_GPU_COMP_PLCPPEAKS && comp != TDC_GPU_COMP_MAXLCP && comp != TDC_GPU_COMP_HEAP)
         throw ArgError{TDC_GPU_ERR_UNSUPPORTED, "lcpcomp: comp must be arrays, plcppeaks, max_lcp or heap"};
-    if (!ho.out_len || (!ho.out && !ho.into)) throw ArgError{TDC_GPU_ERR_ARG, "out/out_len is NULL"};
+    if (!ho.out_len || (!ho.out && !ho.into && !ho.keep)) throw ArgError{TDC_GPU_ERR_ARG, "out/out_len is NULL"};
     if (raw) {
         if (!text && n) throw ArgError{TDC_GPU_ERR_ARG, "NULL argument"};
         if (n >= 0x7FFFFFFEull) throw ArgError{TDC_GPU_ERR_TOO_LARGE, "raw input too large: the escaped text must stay < 2^31 - 1 bytes"};
@@ -540,7 +543,11 @@ void compress_host(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, bool raw, ui
     const size_t len = run_pipeline(c, d_text, tn, threshold, flatten, coder, &d_out, 0, stats, ev, comp);
     const int e2 = ev.tick();
     *ho.out_len = len;
-    if (ho.into) {
+    if (ho.keep) {
+        if (stats) { ev.span(&stats->ms_h2d, e0, e1); ev.span(&stats->ms_total, e0, e2); }
+        ev.finish();
+        ctx->kept = d_out; ctx->kept_len = len;
+    } else if (ho.into) {
         if (len > ho.cap) throw ArgError{TDC_GPU_ERR_OOM, "output buffer too small (*out_len holds the required size)"};
         const size_t done = c.d2h_done <= len ? c.d2h_done : 0;
         HIP_TRY(hipMemcpyAsync(ho.into + done, d_out + done, len - done, hipMemcpyDeviceToHost, c.stream));
@@ -578,6 +585,41 @@ int tdc_gpu_lcpcomp_compress_into(tdc_gpu_ctx* ctx, const uint8_t* text, size_t 
         if (!out) throw ArgError{TDC_GPU_ERR_ARG, "out is NULL"};
         compress_host(ctx, text, n, false, threshold, flatten, coder, comp, HostOut{nullptr, out, out_cap, out_len}, stats);
     });
+}
+
+int tdc_gpu_lcpcomp_compress_keep(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, uint32_t threshold, int flatten, int coder,
+                                  int comp, size_t* out_len, tdc_gpu_stats* stats) {
+    return guarded(ctx, [&] {
+        HostOut ho{nullptr, nullptr, 0, out_len};
+        ho.keep = true;
+        compress_host(ctx, text, n, false, threshold, flatten, coder, comp, ho, stats);
+    });
+}
+
+int tdc_gpu_stream_fetch(tdc_gpu_ctx* ctx, uint8_t* dst, size_t cap, size_t* len) {
+    if (!ctx) return TDC_GPU_ERR_ARG;
+    const u8* kept = ctx->kept;
+    const size_t kept_len = ctx->kept_len;
+    const int rc = guarded(ctx, [&] {
+        if (!kept) throw ArgError{TDC_GPU_ERR_ARG, "no stream is kept on this context (tdc_gpu_lcpcomp_compress_keep, and no other call since)"};
+        if (len) *len = kept_len;
+        if (!dst || cap < kept_len) throw ArgError{TDC_GPU_ERR_OOM, "destination too small (*len holds the stream length)"};
+        if (kept_len) HIP_TRY(hipMemcpyAsync(dst, kept, kept_len, hipMemcpyDeviceToHost, ctx->c.stream));
+        HIP_TRY(hipStreamSynchronize(ctx->c.stream));
+    });
+    ctx->kept = kept; ctx->kept_len = kept_len;      // (may be fetched again)
+    return rc;
+}
+
+int tdc_gpu_host_register(void* p, size_t bytes) {
+    if (!p || !bytes) return TDC_GPU_ERR_ARG;
+    if (hipHostRegister(p, bytes, hipHostRegisterPortable) != hipSuccess) { (void)hipGetLastError(); return TDC_GPU_ERR_HIP; }
+    return TDC_GPU_OK;
+}
+int tdc_gpu_host_unregister(void* p) {
+    if (!p) return TDC_GPU_ERR_ARG;
+    if (hipHostUnregister(p) != hipSuccess) { (void)hipGetLastError(); return TDC_GPU_ERR_HIP; }
+    return TDC_GPU_OK;
 }
 
 int tdc_gpu_lcpcomp_compress_raw(tdc_gpu_ctx* ctx, const uint8_t* data, size_t n, uint32_t threshold, int flatten, int coder,
