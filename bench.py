@@ -136,6 +136,29 @@ def cpu_baseline(args, seed):
     return res, (m1, int(len1), sha1), dna_ref
 
 
+def bind_to_gpu_numa_node(torch, dev_index):
+    """Run this process (and the threads it starts) on the CPUs of the NUMA node the GPU hangs on, so that the pinned text / stream
+    buffers are first touched there and the transfers do not cross the socket link: with one process per GPU nobody else does it.
+    Best effort: returns the node or None (no topology information, or none of the node's CPUs are allowed to this process)."""
+    try:
+        p = torch.cuda.get_device_properties(dev_index)
+        bdf = "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read())
+        if node < 0:
+            return None
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        allowed = os.sched_getaffinity(0) & cpus
+        if not allowed:
+            return None
+        os.sched_setaffinity(0, allowed)
+        return node
+    except Exception:
+        return None
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -167,6 +190,7 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     coll_device = device if backend == "nccl" else torch.device("cpu")     # where the tensors of the collectives live
+    numa_node = bind_to_gpu_numa_node(torch, dev_index) if not os.environ.get("TDC_BENCH_NO_NUMA") else None
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -357,6 +381,7 @@ def main():
             line["world_size"] = dist.get_world_size()
             line["gathered_bytes"] = sum(sizes)
             line["exchange"] = exchange
+            line["numa_node_rank0"] = numa_node
             line["collective_backend"] = backend
             if container_ok is not None:
                 line["container_ok"] = bool(container_ok)
