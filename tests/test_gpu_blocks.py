@@ -144,3 +144,16 @@ def test_kept_stream_is_fetched_into_registered_shared_memory(gpu_ctx, tmp_path)
             gpu_ctx.stream_fetch(again)
     finally:
         shared.close(T.host_unregister)
+
+
+def test_blocks_container_of_several_megabytes(gpu_ctx):
+    """above 1 MiB the payloads are copied into the container by several host threads side by side"""
+    data = T.gen_english(6_300_000, 77).tobytes()
+    block_size = 1_500_000
+    blob, _ = T.blocks_compress(data, block_size, threshold=2, flatten=1)
+    parts = blocks.unpack_container(blob)
+    assert [r for r, _ in parts] == [1_500_000] * 4 + [300_000] and len(blob) > (1 << 20)
+    for k, (raw_len, payload) in enumerate(parts):
+        single, _ = gpu_ctx.lcpcomp_compress_raw(data[k * block_size:(k + 1) * block_size], 2, 1)
+        assert bytes(payload) == single, k
+    assert gpu_ctx.blocks_decompress(blob) == data

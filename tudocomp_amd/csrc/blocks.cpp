@@ -92,11 +92,27 @@ int tdc_gpu_blocks_compress(const int* devices, int ndev, const uint8_t* data, s
             memcpy(blob, MAGIC, MAGIC_LEN);
             put_u32(blob + MAGIC_LEN, (uint32_t)G);
             size_t dir = MAGIC_LEN + 4, pay = dir + 16 * G;
+            std::vector<size_t> at(G, 0);
             for (size_t k = 0; k < G; ++k) {
                 const size_t off = k * block_size, len = (off + block_size <= n) ? block_size : n - off;
                 put_u64(blob + dir, len); put_u64(blob + dir + 8, lens[k]); dir += 16;
-                memcpy(blob + pay, streams[k], lens[k]); pay += lens[k];
+                at[k] = pay; pay += lens[k];
             }
+            // the payloads into place: a 2 GB block leaves 0.7 GB of stream, one thread copies that at ~8 GB/s -- several blocks are
+            // copied side by side (the copies are independent; if a thread cannot be started the loop below does it all)
+            const size_t nt = (total > ((size_t)1 << 20) && G > 1) ? (G < 8 ? G : 8) : 1;
+            bool copied = false;
+            if (nt > 1) {
+                try {
+                    std::vector<std::thread> ct;
+                    struct Joiner { std::vector<std::thread>& t; ~Joiner() { for (auto& x : t) if (x.joinable()) x.join(); } } cj{ct};
+                    ct.reserve(nt);
+                    for (size_t i = 0; i < nt; ++i)
+                        ct.emplace_back([&, i] { for (size_t k = i; k < G; k += nt) memcpy(blob + at[k], streams[k], lens[k]); });
+                    copied = true;
+                } catch (...) { copied = false; }
+            }
+            if (!copied) for (size_t k = 0; k < G; ++k) memcpy(blob + at[k], streams[k], lens[k]);
             *out = blob; *out_len = total;
         }
         return rc;
