@@ -3,9 +3,10 @@
 //   phi[sa[i]] = sa[i-1]                  ds/PhiFromSA.hpp:35-45     (phi[sa[0]] = sa[n-1])
 //   plcp[sa[i]] = lcp(sa[i-1], sa[i])     ds/PLCPFromPhi.hpp:27-53   (the values, here handed over by the sort: suffix_array.hip)
 // All three scatter along the same permutation i -> sa[i].  Round 2 ran two bucketed scatters of 8-byte pairs (first ranks, Phi) and
-// recomputed PLCP from the text with one scattered read per position; here ONE record (sa[i], i, sa[i-1], lcp) of 13 bytes travels
+// recomputed PLCP from the text with one scattered read per position; here ONE record (sa[i], i, sa[i-1], lcp) travels
 // through one two-level partition by destination window (prim.hip bucketed_scatter_u32 explains why a partition beats a direct
-// scatter) and every window is written as whole lines from an LDS image, array by array.
+// scatter) and every window is written as whole lines from an LDS image, array by array.  The record is 12 bytes: behind the first
+// level the top digit of the destination is implied by the bucket, and the LCP byte takes its place in the index word.
 #include "stages.hpp"
 #include "prim.hpp"
 
@@ -20,6 +21,7 @@ struct FSLevel {
     u32* idx_out; u64* rp_out; u8* lcp_out;
     u32* counts; const u32* blk_seg; const u32* blk_start; const u32* seg_start;
     u32 nseg, R, per_xcd; int shift;
+    int lsh;                                                  // FIRST: the LCP byte goes to the bits [lsh, lsh + 8) of the index word (the top digit leaves)
 };
 __device__ __forceinline__ bool fs_row(const FSLevel& P, u32 row, size_t& base, u32& cnt) {
     const u32 blk = row / P.R;
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TDC_FS_WPE,
         const bool valid = e < cnt;
         if (FIRST) rp[j] = (u64)(u32)(base + e + 1) | ((u64)(valid ? P.prev_in[base + e] : 0u) << 32);
         else rp[j] = valid ? P.rp_in[base + e] : 0ull;
-        lc[j] = valid ? (u32)P.lcp_in[base + e] : 0u;
+        lc[j] = (FIRST && valid) ? (u32)P.lcp_in[base + e] : 0u;
     }
 #pragma unroll
     for (int j = 0; j < FS_ITEMS; ++j) {
@@ -131,10 +133,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TDC_FS_WPE,
     __syncthreads();
     u32 dst[FS_ITEMS];
     u32* stage32 = (u32*)stage;
-    // stream 1: the destination index itself (its bucket gives every slot of the sorted tile its global address)
+    // stream 1: the destination index (FIRST: low bits + the LCP byte); its bucket gives every slot of the sorted tile its global address
+    unsigned short* stage_d = (unsigned short*)(stage + FS_TILE / 2);          // digits of the staged words: second half of the buffer
 #pragma unroll
     for (int j = 0; j < FS_ITEMS; ++j) {
-        if (lb + (u32)j * 64 < cnt) { pos[j] += tcnt[(k[j] >> P.shift) & (D - 1)]; stage32[pos[j]] = k[j]; }
+        if (lb + (u32)j * 64 < cnt) {
+            const u32 d = (k[j] >> P.shift) & (D - 1);
+            pos[j] += tcnt[d];
+            stage32[pos[j]] = FIRST ? ((k[j] & ((1u << P.lsh) - 1u)) | (lc[j] << P.lsh)) : k[j];
+            stage_d[pos[j]] = (unsigned short)d;
+        }
     }
     __syncthreads();
 #pragma unroll
@@ -142,9 +150,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TDC_FS_WPE,
         const u32 sp = (u32)r * 256 + threadIdx.x;
         dst[r] = 0xFFFFFFFFu;
         if (sp < cnt) {
-            const u32 key = stage32[sp];
-            dst[r] = gbase[(key >> P.shift) & (D - 1)] + sp;
-            P.idx_out[dst[r]] = key;
+            dst[r] = gbase[stage_d[sp]] + sp;
+            P.idx_out[dst[r]] = stage32[sp];
         }
     }
     __syncthreads();
@@ -154,20 +161,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TDC_FS_WPE,
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < FS_ITEMS; ++r) if (dst[r] != 0xFFFFFFFFu) P.rp_out[dst[r]] = stage[(u32)r * 256 + threadIdx.x];
-    __syncthreads();
-    // stream 3: LCP bytes
-    u8* stage8 = (u8*)stage;
-#pragma unroll
-    for (int j = 0; j < FS_ITEMS; ++j) if (lb + (u32)j * 64 < cnt) stage8[pos[j]] = (u8)lc[j];
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < FS_ITEMS; ++r) if (dst[r] != 0xFFFFFFFFu) P.lcp_out[dst[r]] = stage8[(u32)r * 256 + threadIdx.x];
 }
 
 // After the partition by the top 2 * DB index bits, window w holds exactly the records of the positions [w * W, (w + 1) * W) (position
 // n - 1 = sa[0] has no record).  One workgroup per window: each array is scattered into an LDS image of the window and leaves as whole
 // lines.
-__global__ __launch_bounds__(256) void fs_image_kernel(const u32* __restrict__ idx, const u64* __restrict__ rp, const u8* __restrict__ lcp, size_t m, u32 W,
+__global__ __launch_bounds__(256) void fs_image_kernel(const u32* __restrict__ idx, const u64* __restrict__ rp, int lsh, size_t m, u32 W,
                                                         u32* __restrict__ isa, u32* __restrict__ phi, u32* __restrict__ plcp, u32* __restrict__ d_max) {
     __shared__ u32 img[FS_WMAX];
     const size_t base = (size_t)blockIdx.x * W;
@@ -181,7 +180,7 @@ __global__ __launch_bounds__(256) void fs_image_kernel(const u32* __restrict__ i
     __syncthreads();
     for (size_t q = base + threadIdx.x; q < end; q += 256) phi[q] = img[q - base];
     __syncthreads();
-    for (size_t j = base + threadIdx.x; j < end; j += 256) { const u32 l = lcp[j]; img[idx[j] & (W - 1)] = l; mx = max(mx, l); }
+    for (size_t j = base + threadIdx.x; j < end; j += 256) { const u32 x = idx[j], l = (x >> lsh) & 0xFFu; img[x & (W - 1)] = l; mx = max(mx, l); }
     __syncthreads();
     for (size_t q = base + threadIdx.x; q < end; q += 256) plcp[q] = img[q - base];
     mx = wave_reduce_max(mx);
@@ -224,7 +223,6 @@ void build_isa_phi_plcp_fused(Ctx& c, const u32* sa, const u8* lcp8, size_t n, u
     const u32 D = 1u << db;
     u32* idx[2] = { c.arena.get<u32>(m), c.arena.get<u32>(m) };
     u64* rp[2] = { c.arena.get<u64>(m), c.arena.get<u64>(m) };
-    u8* lc[2] = { c.arena.get<u8>(m + 8), c.arena.get<u8>(m + 8) };
     const u32* seg_start = ss_first_segment(c, m);
     u32 nseg = 1;
     for (int l = 0; l < 2; ++l) {
@@ -234,8 +232,9 @@ void build_isa_phi_plcp_fused(Ctx& c, const u32* sa, const u8* lcp8, size_t n, u
         ss_level_tables(c, seg_start, nseg, m, D, Tb);
         FSLevel P;
         if (l == 0) { P.idx_in = sa + 1; P.rp_in = nullptr; P.prev_in = sa; P.lcp_in = lcp8 + 1; }
-        else { P.idx_in = idx[0]; P.rp_in = rp[0]; P.prev_in = nullptr; P.lcp_in = lc[0]; }
-        P.idx_out = idx[l]; P.rp_out = rp[l]; P.lcp_out = lc[l];
+        else { P.idx_in = idx[0]; P.rp_in = rp[0]; P.prev_in = nullptr; P.lcp_in = nullptr; }
+        P.idx_out = idx[l]; P.rp_out = rp[l]; P.lcp_out = nullptr;
+        P.lsh = bits - db;
         P.counts = Tb.counts; P.blk_seg = Tb.blk_seg; P.blk_start = Tb.blk_start; P.seg_start = seg_start;
         P.nseg = nseg; P.R = Tb.R; P.shift = bits - db * (l + 1);
         const u32 rows = Tb.rows;
@@ -249,7 +248,7 @@ void build_isa_phi_plcp_fused(Ctx& c, const u32* sa, const u8* lcp8, size_t n, u
         }
         ss_level_offsets(c, Tb, seg_start, nseg, D, nstart, m);
         {
-            const int ps = c.prof_begin(K_RS_SCATTER_U32, (u64)m * (l == 0 ? 5 + 13 : 26));
+            const int ps = c.prof_begin(K_RS_SCATTER_U32, (u64)m * (l == 0 ? 5 + 12 : 24));
             if (l == 0) { if (db == 9) fs_scatter_kernel<9, true><<<grid, 256, 0, s>>>(P, rows); else fs_scatter_kernel<8, true><<<grid, 256, 0, s>>>(P, rows); }
             else { if (db == 9) fs_scatter_kernel<9, false><<<grid, 256, 0, s>>>(P, rows); else fs_scatter_kernel<8, false><<<grid, 256, 0, s>>>(P, rows); }
             LAUNCH_CHECK();
@@ -262,8 +261,8 @@ void build_isa_phi_plcp_fused(Ctx& c, const u32* sa, const u8* lcp8, size_t n, u
     {
         const u32 W = 1u << (bits - 2 * db);
         if (W > FS_WMAX) throw HipError{hipErrorUnknown, "fused scatter: window larger than the LDS image", (int)__LINE__};
-        Ctx::ProfScope prof(c, K_FS_IMAGE, (u64)m * 25);
-        fs_image_kernel<<<cdiv(m, W), 256, 0, s>>>(idx[1], rp[1], lc[1], m, W, isa, phi, plcp, d_maxlcp);
+        Ctx::ProfScope prof(c, K_FS_IMAGE, (u64)m * 24);
+        fs_image_kernel<<<cdiv(m, W), 256, 0, s>>>(idx[1], rp[1], bits - db, m, W, isa, phi, plcp, d_maxlcp);
         LAUNCH_CHECK();
         fs_first_kernel<<<1, 1, 0, s>>>(sa, n, isa, phi, plcp);
         LAUNCH_CHECK();
