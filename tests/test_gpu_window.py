@@ -193,3 +193,17 @@ def test_extreme_repeat_structure(gpu_ctx):
                 dt = time.time() - t0
                 assert got == fn(text, thr, 1)[0], (name, comp, thr)
                 assert dt < 1.5, "%s comp=%d: %.2f s (a level-by-level walk over the ramp)" % (name, comp, dt)
+
+
+def test_large_lists_give_the_same_factors(monkeypatch):
+    """TDC_GPU_WINDOW_LARGE=1: the window pass starts with the large per-level lists (one workgroup per CU).  Texts with one crowded
+    level overflow the small lists and end up there by themselves; here every text is forced through them."""
+    monkeypatch.setenv("TDC_GPU_WINDOW_LARGE", "1")
+    with T.Context(0) as ctx:
+        for name, data in TEXTS[:7] + [("dna_1M", T.gen_dna(1 << 20, 3).tobytes())]:
+            text = O.escape(data)
+            for thr in (2, 5):
+                want, _ = O.lcpcomp_huff_compress(text, thr, 1)
+                got, st = ctx.lcpcomp_compress(text, threshold=thr, flatten=1)
+                assert st["window_pass"] in (1, 2), (name, thr)
+                assert got == want, "%s t=%d (window_pass %d)" % (name, thr, st["window_pass"])
