@@ -4,7 +4,8 @@ text rounds of suffix_array.hip and the fused ISA / Phi / PLCP scatter of fused.
 default; TDC_GPU_WSORT_MIN lowers that so that the adversarial texts of test_gpu_sa_refine.py -- groups of every size around the
 counting limit of 256, periodic stretches, tiny and full byte alphabets -- reach it too.  SA / ISA / Phi / PLCP must equal the
 oracle's (ds/SADivSufSort.hpp:27-51, ds/ISAFromSA.hpp:30-43, ds/PhiFromSA.hpp:35-45, ds/PLCPFromPhi.hpp:27-53) in every variant:
-one / two key words, 1 / 2 / 3 partition levels, the chunk iterations forced on every run, text rounds on, cut short, and off."""
+one / two key words, 1 / 2 / 3 partition levels, the chunk iterations forced on every run, text rounds on, cut short, and off,
+runs ordered inside the sort kernel or by the counting kernel, counting limits 16 and 64."""
 import os
 
 import numpy as np
@@ -38,6 +39,8 @@ VARIANTS = {
     "no_rounds":   {"TDC_GPU_WSORT_MIN": "4096", "TDC_GPU_WSORT_ROUNDS": "0"},
     "one_round":   {"TDC_GPU_WSORT_MIN": "4096", "TDC_GPU_WSORT_ROUNDS": "1", "TDC_GPU_WSORT_KW": "1"},
     "two_wide":    {"TDC_GPU_WSORT_MIN": "4096", "TDC_GPU_WSORT_TWO": "2"},     # two levels of 1024 buckets (texts of 4 MB and more)
+    "no_fuse":     {"TDC_GPU_WSORT_MIN": "4096", "TDC_GPU_WSORT_FUSE": "0"},    # runs of a unit ordered by the separate counting kernel
+    "cmax_64":     {"TDC_GPU_WSORT_MIN": "4096", "TDC_GPU_WSORT_CMAX": "64"},   # counting up to 64 members (default 16)
 }
 
 
