@@ -121,7 +121,7 @@ struct Ctx {
     hipEvent_t ev[16] = {};
     void* pinned = nullptr;        // small pinned staging block for device->host scalars
     size_t pinned_size = 0;
-    static constexpr u32 ZC_SEG_OFF = 1040, ZC_WORDS = 1040 + 8192;   // words 1040 ..: up to 4096 (target, start) pairs of a one-workgroup level
+    static constexpr u32 ZC_SEG_OFF = 1040, ZC_WORDS = 1040 + 16384;  // words 1040 ..: up to 8192 (target, start) pairs of a one-workgroup level
     static constexpr u32 ZC_BLOCKS = 3;                                // block 0: read() / publish_*; blocks 1, 2: two one-workgroup levels in flight
     u32* zc_host = nullptr;        // mapped host block for publish_words_kernel: 1024 data words + the sequence word (+ the segment area)
     u32* zc_dev = nullptr;         // the same block as seen from the device

@@ -275,11 +275,14 @@ constexpr u32 SMALL_RAW = 8192;     // list entries a small level may hold befor
 // multi-launch path against ~0.06 ms here).
 constexpr u32 SMALL_M_BIG = 4096;
 constexpr u32 SMALL_RAW_BIG = 16384;
+// ... and a third one with 1 024 threads holds 8 192 (the SLIM layout of the kernel: LDS is what limits it)
+constexpr u32 SMALL_M_SLIM = 8192;
+constexpr u32 SMALL_RAW_SLIM = 32768;
 constexpr u32 SMALL_OUT_WORDS = 8 + 2 * SEG_INLINE;
 constexpr u32 SMALL_RANKSORT = 1024; // up to here a counting sort in LDS beats the bitonic network
 constexpr u32 SMALL_SELSCAN = 32;    // up to this many selected entries the encounter values scan the selected list, not the neighbours
 
-template <int NT>
+template <int NT, bool SLIM = false>
 __global__ __launch_bounds__(NT) void small_level_kernel(const u32* __restrict__ orig, u32 m0_arg, const u32* __restrict__ pushed, u32 m_raw_arg,
                                                            const u32* __restrict__ pool_all, const GatherSeg* __restrict__ gtab, u32 gn,
                                                            u32 L, u32 threshold, size_t n, u32* cur, u32* prio,
@@ -290,9 +293,13 @@ __global__ __launch_bounds__(NT) void small_level_kernel(const u32* __restrict__
                                                            u32* zc_dst, u32* zc_flag, u32 zc_seq, unsigned long long* prof, u32* zc_segs,
                                                            SmallCtl* __restrict__ ctl, u32 spec, const LevelScalars* prev_sc, const PushSeg* prev_segs,
                                                            const u32* __restrict__ m0_dev) {
-    // (level_purge_kernel may have shortened the original part of the list: the rest of the segment are copies of one erased entry)
-    u32 m0 = m0_arg, m_raw = m_raw_arg;
-    if (m0_dev) { const u32 d = *m0_dev; if (d < m0) { m_raw -= m0 - d; m0 = d; } }
+    // Everything the first step needs from global memory is requested before anything waits: the purged length of the list, the first
+    // entries of the original candidates (entries behind the purged length are copies of one erased entry: harmless) and, further
+    // down, the gather table -- a one-workgroup kernel has nothing else to hide these round trips behind (20 us of the 40 a level takes).
+    const u32 m0_purged = m0_dev ? *m0_dev : NONE32;
+    u32 pre_orig[8];
+#pragma unroll
+    for (u32 r = 0; r < 8; ++r) { const u32 i = r * (u32)NT + threadIdx.x; pre_orig[r] = (i < m0_arg) ? orig[i] : NONE32; }
 #define SPROF(k) do { if (prof) { const unsigned long long now_ = wall_clock64(); acc_prof[k] = now_ - t_prof; t_prof = now_; } } while (0)
     constexpr u32 SM = (u32)NT * 8;                          // survivors the workgroup holds (eight per thread)
     constexpr u32 NWV = (u32)NT / 64;
@@ -300,15 +307,31 @@ __global__ __launch_bounds__(NT) void small_level_kernel(const u32* __restrict__
     unsigned long long acc_prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // The entries are sorted by text position (bitonic network in registers), so "neighbours within distance < L" are
     // adjacent slots of LDS arrays: the whole level runs without the global state bitmap.
-    __shared__ u64 skey[SM];          // sort scratch, later the push records (target << 32 | priority)
-    __shared__ u32 sval[SM];
-    __shared__ u32 pos_s[SM], pr_s[SM], v_s[SM];
-    __shared__ u8 st[SM];             // 0 undecided, 1 selected, 2 stale, 3 rejected, 4 dead
+    // SLIM (1 024 threads, 8 192 survivors): 15 bytes of LDS per survivor instead of 27 -- the sort scratch lies over the priority / value
+    // arrays and the target table (all dead while the positions are sorted), a push is recorded IN PLACE (value and state of its
+    // entry) and ordered by the counting sort on the target only; a level that needs the general orderings goes to the multi-launch path.
+    constexpr u32 HB = SLIM ? 13u : (NT >= 512 ? 12u : 11u);    // target counters: 2^HB
+    __shared__ __align__(16) u64 skey_a[SLIM ? 1 : SM];         // sort scratch, later the push records (target << 32 | priority)
+    __shared__ u32 sval_a[SLIM ? 1 : SM];
+    __shared__ u32 pos_s[SM];
+    __shared__ __align__(16) u32 pr_v[2 * SM];
+    __shared__ u32 s_hcnt[1u << HB];
+    u32* const pr_s = pr_v;
+    u32* const v_s = pr_v + SM;
+    u64* const skey = SLIM ? (u64*)pr_v : skey_a;
+    u32* const sval = SLIM ? s_hcnt : sval_a;
+    static_assert(!SLIM || (1u << HB) >= SM, "the table doubles as the 32-bit sort scratch");
+    __shared__ u8 st[SM];             // 0 undecided, 1 selected, 2 stale, 3 rejected, 4 dead, 5 (SLIM) pushes: v_s holds the target
     __shared__ u32 s_und, s_npush, s_sel, s_live, s_alive, s_cnt, s_lst;
     __shared__ u32 s_sellist[SMALL_SELSCAN];
     __shared__ u32 s_out[SMALL_OUT_WORDS]; // the LevelScalars of this level: nlive nstale undecided selected npush nseg deferred bailed, segments
     const u32 tid = threadIdx.x;
     __shared__ u32 s_bail;
+    GatherSeg* gt = (GatherSeg*)skey;                     // skey is not used before the sorts
+    for (u32 i = tid; i < gn; i += NT) gt[i] = gtab[i];  // (mapped host memory: the longest of the round trips)
+    // (level_purge_kernel may have shortened the original part of the list: the rest of the segment are copies of one erased entry)
+    u32 m0 = m0_arg, m_raw = m_raw_arg;
+    if (m0_purged < m0) { m_raw -= m0 - m0_purged; m0 = m0_purged; }
     if (tid == 0) { s_npush = 0; s_sel = 0; s_live = 0; s_alive = 0; s_cnt = 0; s_lst = 0; s_bail = 0; }
     if (tid < 8) s_out[tid] = 0;
     __syncthreads();
@@ -340,9 +363,6 @@ __global__ __launch_bounds__(NT) void small_level_kernel(const u32* __restrict__
     // 0. drop the erased entries (texts with long repeats carry thousands of them per level).  Eight entries per thread and
     //    step: the position loads are all in flight together, then the eight dependent cur[] loads (one workgroup has no
     //    other way to hide the two round trips)
-    GatherSeg* gt = (GatherSeg*)skey;                     // skey is not used before the sorts
-    for (u32 i = tid; i < gn; i += NT) gt[i] = gtab[i];
-    if (gn) __syncthreads();
     // The survivors keep the order of the list (row-wise ballots + a prefix over the rows and waves of a step): the original
     // candidates of a level are in position order, so their survivors come out sorted and only the pushed ones -- usually a
     // handful -- have to be ranked against them (step 1).
@@ -356,7 +376,7 @@ __global__ __launch_bounds__(NT) void small_level_kernel(const u32* __restrict__
         for (u32 r = 0; r < 8; ++r) {
             const u32 i = base + r * NT + tid;
             pp[r] = NONE32;
-            if (i < m0) pp[r] = orig[i];
+            if (i < m0) pp[r] = (base == 0) ? pre_orig[r] : orig[i];
             else if (i < m_raw) {
                 if (gn == 0) pp[r] = pushed[i - m0];
                 else {
@@ -548,9 +568,12 @@ __global__ __launch_bounds__(NT) void small_level_kernel(const u32* __restrict__
             }
         }
         if (val >= threshold) {
-            const u32 idx = atomicAdd(&s_npush, 1u);
-            skey[idx] = ((u64)val << 32) | pr;
-            sval[idx] = p;
+            if constexpr (SLIM) { v_s[i] = val; st[i] = 5; atomicAdd(&s_npush, 1u); }
+            else {
+                const u32 idx = atomicAdd(&s_npush, 1u);
+                skey[idx] = ((u64)val << 32) | pr;
+                sval[idx] = p;
+            }
         }
     }
     __syncthreads();
@@ -560,10 +583,68 @@ __global__ __launch_bounds__(NT) void small_level_kernel(const u32* __restrict__
     //    counted in a hashed table; a push whose slot it has for itself takes the next free place (any order), the others -- real
     //    duplicates and the rare hash collisions -- are ranked among themselves and follow.
     const u32 npush = s_npush;
-    constexpr u32 HB = NT >= 512 ? 12u : 11u;                   // hashed target counters: 2^HB
-    __shared__ u32 s_hcnt[1u << HB];
     __shared__ unsigned short s_dl[SM];
     __shared__ u32 s_nu, s_nd;
+    __shared__ u32 seg_sm[NWV + 1];
+    if constexpr (SLIM) {
+        // 5' + 6'. counting sort of the pushing entries on their target; pool slots, priorities and segments straight from the table
+        if (npush && L > (1u << HB)) { if (tid == 0) { s_out[7] = 2; s_out[1] = m; } publish(); return; }      // code 2 + the survivors: this instance cannot order the pushes (nothing has been written yet)
+        u32 nseg = 0;
+        if (npush) {
+            constexpr u32 TE = (1u << HB) / NT;
+            for (u32 i = tid; i < (1u << HB); i += NT) s_hcnt[i] = 0;
+            if (tid == 0) s_nd = 0;
+            __syncthreads();
+            for (u32 i = tid; i < m; i += NT) if (st[i] == 5) atomicAdd(&s_hcnt[v_s[i]], 1u);
+            __syncthreads();
+            u32 loc[TE], sum = 0, gmax = 0, nz = 0;
+#pragma unroll
+            for (u32 e = 0; e < TE; ++e) { loc[e] = s_hcnt[tid * TE + e]; sum += loc[e]; gmax = max(gmax, loc[e]); nz += loc[e] ? 1u : 0u; }
+            u32 total;
+            u32 start = block_exclusive_sum<u32, (int)NWV>(sum, seg_sm, total);
+            __syncthreads();
+            u32 o = block_exclusive_sum<u32, (int)NWV>(nz, seg_sm, nseg);
+            gmax = wave_reduce_max(gmax);
+            if ((tid & 63) == 0 && gmax) atomicMax(&s_nd, gmax);
+            __syncthreads();
+            if (s_nd > 64) {                                    // a crowded target: ranking inside its group would be quadratic
+                __syncthreads();
+                if (tid == 0) { s_out[7] = 2; s_out[1] = m; }
+                publish();
+                return;
+            }
+#pragma unroll
+            for (u32 e = 0; e < TE; ++e) {
+                const u32 t = tid * TE + e;
+                s_hcnt[t] = start;
+                if (loc[e]) {                                    // a segment of the pool: target t, first slot `start`
+                    if (o < SEG_INLINE) { s_out[8 + 2 * o] = t; s_out[9 + 2 * o] = start; }
+                    if (zc_segs && nseg > SEG_INLINE && o < SM) {
+                        __hip_atomic_store(&zc_segs[2 * o], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        __hip_atomic_store(&zc_segs[2 * o + 1], start, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                    if (o < seg_cap) segs[o] = PushSeg{t, start};
+                    ++o;
+                }
+                start += loc[e];
+            }
+            __syncthreads();
+            for (u32 i = tid; i < m; i += NT) if (st[i] == 5) s_dl[atomicAdd(&s_hcnt[v_s[i]], 1u)] = (unsigned short)i;
+            __syncthreads();                                    // s_hcnt[t] is the END of target t's group now
+            for (u32 a = tid; a < npush; a += NT) {
+                const u32 i = s_dl[a];
+                const u32 t = v_s[i], pr = pr_s[i];
+                const u32 lo = t ? s_hcnt[t - 1] : 0u, hi = s_hcnt[t];
+                u32 rk = 0;
+                if (hi - lo > 1) for (u32 b = lo; b < hi; ++b) rk += (pr_s[s_dl[b]] < pr) ? 1u : 0u;   // (priorities are distinct)
+                const u32 f = lo + rk, p = pos_s[i];
+                prio[p] = prio_base + f;
+                pool[f] = p;
+                if (res8) res8[p] = (u8)(t > 255u ? 255u : t);
+            }
+        }
+        if (tid == 0) { s_out[5] = nseg; s_out[4] = npush; s_sel = 0; ctl->pool_top = pool_top + npush; ctl->prio_base = prio_base + npush; }
+    } else {
     bool ordered = false;
     if (npush > 64 && L <= (1u << HB)) {
         // Every target (< L) has a counter of its own: counting sort by target, then the members of a target's group -- mostly one, a
@@ -679,7 +760,6 @@ full_sort:
             const u32 i = tid * 8 + r;
             if (i < npush && (i == 0 || pr_s[i - 1] != pr_s[i])) { heads |= 1u << r; ++cnt; }
         }
-        __shared__ u32 seg_sm[NWV + 1];
         u32 nseg;
         u32 o = block_exclusive_sum<u32, (int)NWV>(cnt, seg_sm, nseg);
 #pragma unroll
@@ -695,6 +775,7 @@ full_sort:
             ++o;
         }
         if (tid == 0) { s_out[5] = nseg; s_out[4] = npush; s_sel = 0; ctl->pool_top = pool_top + npush; ctl->prio_base = prio_base + npush; }
+    }
     }
     __syncthreads();
     SPROF(4);
@@ -748,7 +829,7 @@ full_sort:
 // kernel relies on it), the rest of the segment filled with ONE of the list's erased positions -- such an entry stays erased for good
 // (cur only decreases), every consumer drops it, and sixty gathers of one address cost one.  Segment bounds do not change.
 struct PurgeWin { u32 start[64]; u32 cnt[64]; u32 level[64]; u32 n; };
-constexpr u32 PURGE_CAP = 16384;
+constexpr u32 PURGE_CAP = 32768;      // (128 KB of LDS: as long as the longest list a one-workgroup level may hold)
 __global__ __launch_bounds__(1024) void level_purge_kernel(u32* __restrict__ cand, PurgeWin W, u32 threshold, const u32* __restrict__ cur, u32* __restrict__ lcount) {
     __shared__ u32 buf[PURGE_CAP];
     __shared__ u32 s_w[16], s_dead;
@@ -1069,6 +1150,8 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
     bool purge_pays = false;                               // a level too large for the one-workgroup path consisted mostly of erased entries
     u32 dead_levels_run = 0;                               // consecutive levels whose entries were all erased
     u32 last_alive = 0;                                    // survivors of the last one-workgroup level (chooses the instance of the next one)
+    int force_inst = -1;                                   // the instance a level is run again on
+    u32 slim_penalty = 0;                                  // levels for which the 1 024-thread instance is not tried (it gave up on a level)
     u32* d_lcount = c.arena.get<u32>(nlev);                // per level: entries of the original list that are left after level_purge_kernel (all ones: not purged)
     HIP_TRY(hipMemsetAsync(d_lcount, 0xFF, nlev * sizeof(u32), s));
     u32 purge_next = 0xFFFFFFFFu;                          // level_purge_kernel has been run for the levels >= purge_next
@@ -1310,12 +1393,12 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
         const u32 m = m0 + m1_total;
         if (m == 0) { pushed_into.drop(L); continue; }
         st->levels++;
-        if (m <= (c.small_big ? SMALL_RAW_BIG : SMALL_RAW) && L != force_general_level) {
+        if (m <= (c.small_big ? SMALL_RAW_SLIM : SMALL_RAW) && L != force_general_level) {
             // ---- whole level in one workgroup: ONE launch (list read from the pool segments, result published into mapped
             //      host memory), falling back to the general path if more than SMALL_M entries are still alive.  While the kernel
             //      of a level runs, the kernel of the level below it is already queued ("speculative", see SmallCtl): the host's
             //      turnaround between two levels -- result, bookkeeping, launch -- no longer leaves the GPU idle.
-            struct Flight { u32 L, m, m0, slot, zseq; bool zc, spec, big; };
+            struct Flight { u32 L, m, m0, slot, zseq; bool zc, spec; int inst; };
             auto list_size = [&](u32 lv, u32* m0_out, size_t* nsegs) {       // entries of a level as far as the host knows them
                 const u32 a0 = h_segend[lv] - h_segstart[lv];
                 const std::vector<PoolSeg>& sv = pushed_into.get(lv);
@@ -1325,7 +1408,7 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
                 return t;
             };
             u64 inflight_push_max = 0;                              // upper bound of what the levels in flight may still push
-            const u32 raw_cap = c.small_big ? SMALL_RAW_BIG : SMALL_RAW;
+            const u32 raw_cap = c.small_big ? SMALL_RAW_SLIM : SMALL_RAW;
             auto launch_small = [&](u32 lv, u32 slot, bool spec, Flight* f) -> bool {
                 u32 a0; size_t ns;
                 const u64 mm = list_size(lv, &a0, &ns);
@@ -1335,8 +1418,20 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
                 purge_ahead(lv);
                 // the 512-thread instance where the list is long or the levels above had many survivors (a level that overflows the
                 // small instance would be run twice)
-                const bool big = c.small_big == 2 || (c.small_big && (mm > SMALL_RAW || last_alive > SMALL_M * 3 / 4));   // (2: always -- tests)
-                const u32 push_max = (u32)std::min<u64>(mm, big ? SMALL_M_BIG : SMALL_M);          // at most one push per surviving entry
+                // instance: 0 = 256 threads, 1 = 512, 2 = 1 024 (SLIM); small_big 2 / 3: always the second / third (tests)
+                int inst = 0;
+                if (c.small_big == 2) inst = 1;
+                else if (c.small_big == 3) inst = 2;
+                else if (c.small_big) {
+                    // The 1 024-thread instance is the fastest for every level (fewer dependent rounds in each step: 37 against 49 us
+                    // for a level with 300 survivors) but cannot order a crowded target or targets above its table: where it gave
+                    // up recently, or the level lies above the table, the instance is chosen by the survivors of the level above.
+                    if (lv <= (1u << 13) && slim_penalty == 0) inst = 2;
+                    else if (last_alive > SMALL_M * 3 / 4 || mm > SMALL_RAW) inst = 1;
+                    if (force_inst >= 0 && !spec) { inst = force_inst; force_inst = -1; }       // (a level that is run again)
+                }
+                const u32 m_inst = inst == 2 ? SMALL_M_SLIM : (inst ? SMALL_M_BIG : SMALL_M);
+                const u32 push_max = (u32)std::min<u64>(mm, m_inst);          // at most one push per surviving entry
                 if (pool_top + inflight_push_max + push_max > n || (u64)prio_base + inflight_push_max + push_max > 0xFFFFFFFFull) {
                     if (spec) return false;
                     throw HipError{hipErrorUnknown, "factorize: push pool overflow", (int)__LINE__};
@@ -1356,7 +1451,12 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
                 {
                     Ctx::ProfScope prof(c, K_SMALL_LEVEL, mm * 16);
                     u32* zsegs = zc ? c.zc_dev + (size_t)(1 + slot) * Ctx::ZC_WORDS + Ctx::ZC_SEG_OFF : nullptr;
-                    if (big)
+                    if (inst == 2)
+                        small_level_kernel<1024, true><<<1, 1024, 0, s>>>(cand + h_segstart[lv], a0, pushed_src, (u32)mm, pool, d_hgtab ? d_hgtab + (size_t)slot * half : nullptr, gn, lv,
+                                                                  threshold, n, cur, prio, phi, fs.flen, res8, fs.fsrc, (u32)pool_top, prio_base, d_segs2[slot], seg_cap, live,
+                                                                  /*inline_budget=*/1u << 17, d_sc2[slot], zdst, zflag, zseq, d_sprof, zsegs,
+                                                                  d_ctl, spec ? 1u : 0u, d_sc2[slot ^ 1], d_segs2[slot ^ 1], d_lcount + lv);
+                    else if (inst == 1)
                         small_level_kernel<512><<<1, 512, 0, s>>>(cand + h_segstart[lv], a0, pushed_src, (u32)mm, pool, d_hgtab ? d_hgtab + (size_t)slot * half : nullptr, gn, lv,
                                                                   threshold, n, cur, prio, phi, fs.flen, res8, fs.fsrc, (u32)pool_top, prio_base, d_segs2[slot], seg_cap, live,
                                                                   /*inline_budget=*/1u << 17, d_sc2[slot], zdst, zflag, zseq, d_sprof, zsegs,
@@ -1369,7 +1469,7 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
                     LAUNCH_CHECK();
                 }
                 inflight_push_max += push_max;
-                *f = Flight{lv, (u32)mm, a0, slot, zseq, zc, spec, big};
+                *f = Flight{lv, (u32)mm, a0, slot, zseq, zc, spec, inst};
                 return true;
             };
             auto wait_small = [&](const Flight& f) {
@@ -1398,17 +1498,26 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
                 const u32 LL = cur_f.L;
                 bool redo = false;
                 if (h_sc.pad[1] == 3) redo = true;                   // the speculation failed: the level has not been touched
-                else if (h_sc.pad[1] && c.small_big && !cur_f.big) { last_alive = SMALL_M + 1; redo = true; }   // too many survivors for 256 threads: once more with 512
+                else if (h_sc.pad[1] && c.small_big == 1) {                // gave up (1: too many survivors, 2: cannot order these pushes): another instance?
+                    int nxt = -1;
+                    if (h_sc.pad[1] == 2) {                                  // the 1 024-thread instance: a crowded target, or targets above its table
+                        slim_penalty = 8;                                    // (not again for a few levels)
+                        if (h_sc.nstale <= SMALL_M_BIG) nxt = h_sc.nstale > SMALL_M ? 1 : 0;     // (nstale: the survivors, published with the code)
+                    } else if (cur_f.inst == 0) nxt = 1;
+                    else if (cur_f.inst == 1 && cur_f.L <= (1u << 13) && slim_penalty == 0) nxt = 2;
+                    if (nxt >= 0) { force_inst = nxt; redo = true; } else general_path = true;
+                }
                 else if (h_sc.pad[1]) general_path = true;           // too many survivors: the multi-launch path takes the level
                 else {
                     last_alive = h_sc.nlive + h_sc.nstale;
+                    if (slim_penalty) --slim_penalty;
                     if (h_sc.pad[0]) {                             // many long factors: the kills are spread over the whole chip
                         apply_list_kernel<<<cdiv((size_t)h_sc.selected * 64, 256), 256, 0, s>>>(live, &d_sc2[cur_f.slot]->selected, LL, n, phi, cur, fs.flen, fs.fsrc);
                         LAUNCH_CHECK();
                     }
                     pushed_into.drop(LL);
                     st->small_levels++;
-                    if (level_log) fprintf(stderr, "small %u m %u m0 %u live %u stale %u npush %u big %d\n", LL, cur_f.m, cur_f.m0, h_sc.nlive, h_sc.nstale, h_sc.npush, (int)cur_f.big);
+                    if (level_log) fprintf(stderr, "small %u m %u m0 %u live %u stale %u npush %u big %d\n", LL, cur_f.m, cur_f.m0, h_sc.nlive, h_sc.nstale, h_sc.npush, cur_f.inst);
                     if (LL != L) { st->levels++; ++levels_since_purge; }   // (the level the outer loop stands on has been counted)
                     if (h_sc.nlive == 0) ++nolive_run; else nolive_run = 0;
                     if (h_sc.nlive == 0 && h_sc.nstale == 0) { probe_dead = true; ++dead_levels_run; stop_chain = true; }   // small levels do not count for the purge heuristic
@@ -1420,7 +1529,7 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
                         if (npush) {
                             if (nseg > seg_cap) throw HipError{hipErrorUnknown, "factorize: too many push targets in one level", (int)__LINE__};
                             if (nseg <= SEG_INLINE) std::copy(h_sc.segs, h_sc.segs + nseg, h_segs.begin());
-                            else if (cur_f.zc && nseg <= SMALL_M_BIG)
+                            else if (cur_f.zc && nseg <= SMALL_M_SLIM)
                                 memcpy(h_segs.data(), c.zc_host + (size_t)(1 + cur_f.slot) * Ctx::ZC_WORDS + Ctx::ZC_SEG_OFF, (size_t)nseg * sizeof(PushSeg));   // published next to the scalars
                             else c.read_n(d_segs2[cur_f.slot], h_segs.data(), nseg);
                             for (u32 j2 = 0; j2 < nseg; ++j2) {       // written in order of `start` by one thread
@@ -1460,13 +1569,14 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
                     if (mm == 0 || mm > raw_cap || !launch_small(LL - 1, 0, false, &cur_f)) { L = LL; break; }
                     continue;
                 }
-                inflight_push_max = std::min<u64>(next_f.m, next_f.big ? SMALL_M_BIG : SMALL_M);
+                inflight_push_max = std::min<u64>(next_f.m, next_f.inst == 2 ? SMALL_M_SLIM : (next_f.inst ? SMALL_M_BIG : SMALL_M));
                 cur_f = next_f;
             }
             if (!general_path) continue;
             // (general path for level L: its list is re-read below)
         }
         purge_ahead(L);
+        if (slim_penalty) --slim_penalty;                   // (a level on the multi-launch path counts as well)
         if (!gathered) gather_all();
         pushed_into.drop(L);
         HIP_TRY(hipMemsetAsync(d_sc, 0, 8 * sizeof(u32), s));
