@@ -67,6 +67,10 @@ static_assert(TW % 64 == 0 && (TW / 64 <= TT * CPT), "every chunk of the window 
 // texts with a random background, where a third of all positions sit in one level.
 constexpr int TE_SMALL = TDC_WIN_TE, TP_SMALL = TDC_WIN_TP;
 constexpr int TE_LARGE = 8192, TP_LARGE = 4096;
+#ifndef TDC_WIN_TT_LARGE
+#define TDC_WIN_TT_LARGE 1024
+#endif
+constexpr int TT_LARGE = TDC_WIN_TT_LARGE;     // threads of the large variant: one workgroup per CU, so it may as well fill the CU
 
 // Position q of the window lives at byte PA(q) of the position-indexed LDS arrays.  A thread's dense passes read "its"
 // 64-byte chunk with 8-byte loads; rotating the 16 words of chunk t by 2*(t>>2) words puts the 64 lanes' loads on 64
@@ -124,11 +128,17 @@ struct WinScalars { u32 fail; int min_margin; unsigned long long factors; u32 ma
 // (the window-local priorities) is ordered by the one full barrier per level.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int TE, int TP, int WPE>      // list sizes; WPE = waves per SIMD the register budget is set for
-__global__ __launch_bounds__(TT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void window_levels_kernel(const u32* __restrict__ cur_g, const u32* __restrict__ prio_g,
+template <int KT, int TE, int TP, int WPE>      // threads, list sizes; WPE = waves per SIMD the register budget is set for
+__global__ __launch_bounds__(KT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void window_levels_kernel(const u32* __restrict__ cur_g, const u32* __restrict__ prio_g,
                                                             const u8* __restrict__ res_g, const u32* __restrict__ phi, size_t n,
                                                             u32 lcut, u32 threshold, u32 ntiles, u32 halo, u32* __restrict__ lprio_all,
                                                             u32* __restrict__ flen, u32* __restrict__ fsrc, WinScalars* __restrict__ sc) {
+    // (the constants of the small variant, redefined for this instance's thread count: the large lists leave room for one workgroup per
+    //  CU, which then runs 1 024 threads instead of 256)
+    constexpr int TT = KT;
+    constexpr int NWV = KT / 64;
+    constexpr int CPT = TW / (64 * KT) > 0 ? TW / (64 * KT) : 1;
+    static_assert(TW / 64 <= KT * CPT, "every chunk of the window needs an owner");
     __shared__ __attribute__((aligned(16))) u8 cur8[TW];
     __shared__ __attribute__((aligned(16))) u8 res8[TW];    // [5:0] list level, bit 6: factor start (then [5:0] = length), bit 7: priority is window-local
     __shared__ u64 ent[TE];
@@ -550,9 +560,9 @@ int factorize_window_levels(Ctx& c, size_t n, const u32* cur, const u32* prio, c
             // per window position: cur (4) + residence (1); per text position: ~0.3 priority reads and the factor output
             Ctx::ProfScope prof(c, K_WINDOW_LEVELS, (u64)((double)n * TW / ti * 5) + (u64)n * 2);
             if (!large)
-                window_levels_kernel<TE_SMALL, TP_SMALL, TDC_WIN_WPE><<<grid, TT, 0, s>>>(cur, prio, res8, phi, n, lcut, threshold, ntiles, halo, lprio, fs.flen, fs.fsrc, d_sc);
+                window_levels_kernel<TT, TE_SMALL, TP_SMALL, TDC_WIN_WPE><<<grid, TT, 0, s>>>(cur, prio, res8, phi, n, lcut, threshold, ntiles, halo, lprio, fs.flen, fs.fsrc, d_sc);
             else
-                window_levels_kernel<TE_LARGE, TP_LARGE, 1><<<grid, TT, 0, s>>>(cur, prio, res8, phi, n, lcut, threshold, ntiles, halo, lprio, fs.flen, fs.fsrc, d_sc);
+                window_levels_kernel<TT_LARGE, TE_LARGE, TP_LARGE, TT_LARGE / 256><<<grid < 512u ? grid : 512u, TT_LARGE, 0, s>>>(cur, prio, res8, phi, n, lcut, threshold, ntiles, halo, lprio, fs.flen, fs.fsrc, d_sc);
             LAUNCH_CHECK();
         }
         h = c.read(d_sc);
