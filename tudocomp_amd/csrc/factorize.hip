@@ -485,6 +485,7 @@ __global__ __launch_bounds__(NT) void small_level_kernel(const u32* __restrict__
     }
     SPROF(1);
     // 2. classify
+    u32 nlive_t = 0, nalive_t = 0;
 #pragma unroll
     for (u32 r = 0; r < 8; ++r) {
         const u32 i = tid * 8 + r;
@@ -494,10 +495,13 @@ __global__ __launch_bounds__(NT) void small_level_kernel(const u32* __restrict__
             pos_s[i] = p; v_s[i] = val; pr_s[i] = prio[p];
             const u8 c = (val == L) ? 0 : (val >= threshold ? 2 : 4);
             st[i] = c;
-            if (c == 0) atomicAdd(&s_live, 1u);
-            if (c != 4) atomicAdd(&s_alive, 1u);
+            nlive_t += (c == 0) ? 1u : 0u;
+            nalive_t += (c != 4) ? 1u : 0u;
         }
     }
+    // (one atomic per wave: thousands of survivors counting on two LDS words one by one cost 10 us)
+    nlive_t = wave_reduce_sum(nlive_t); nalive_t = wave_reduce_sum(nalive_t);
+    if ((tid & 63) == 0) { if (nlive_t) atomicAdd(&s_live, nlive_t); if (nalive_t) atomicAdd(&s_alive, nalive_t); }
     __syncthreads();
     if (s_alive == 0) { publish(); return; }
     SPROF(2);
@@ -543,9 +547,11 @@ __global__ __launch_bounds__(NT) void small_level_kernel(const u32* __restrict__
     for (u32 i = tid; i < m; i += NT) if (st[i] == 1) { const u32 o = atomicAdd(&s_lst, 1u); if (o < SMALL_SELSCAN) s_sellist[o] = i; }
     __syncthreads();
     const u32 nsel_scan = s_lst;
-    for (u32 i = tid; i < m; i += NT) {
-        const u8 c = st[i];
-        if (c != 2 && c != 3) continue;
+    for (u32 i0 = 0; i0 < m; i0 += NT) {
+        const u32 i = i0 + tid;
+        const u8 c = (i < m) ? st[i] : (u8)4;
+        bool pushes = false;
+        if (c == 2 || c == 3) {
         const u32 p = pos_s[i], pr = pr_s[i];
         u32 val = v_s[i];
         if (nsel_scan <= SMALL_SELSCAN) {                 // few factors in this level: look at them only
@@ -568,12 +574,17 @@ __global__ __launch_bounds__(NT) void small_level_kernel(const u32* __restrict__
             }
         }
         if (val >= threshold) {
-            if constexpr (SLIM) { v_s[i] = val; st[i] = 5; atomicAdd(&s_npush, 1u); }
+            if constexpr (SLIM) { v_s[i] = val; st[i] = 5; pushes = true; }
             else {
                 const u32 idx = atomicAdd(&s_npush, 1u);
                 skey[idx] = ((u64)val << 32) | pr;
                 sval[idx] = p;
             }
+        }
+        }
+        if constexpr (SLIM) {                              // (one atomic per wave)
+            const u64 bp = __ballot(pushes);
+            if ((tid & 63) == 0 && bp) atomicAdd(&s_npush, (u32)__popcll(bp));
         }
     }
     __syncthreads();
