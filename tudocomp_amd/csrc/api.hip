@@ -207,6 +207,7 @@ void run_factorize(Ctx& c, size_t n, DevArrays& A, u32 threshold, int flatten, t
     A.fs.owner = c.arena.get<u32>(n);
     A.fs.fsrc = c.arena.get<u32>(n);
     A.fs.fpos = c.arena.get<u32>(n);
+    A.fs.cls = c.arena.get<u8>(n + 64);                  // class bytes for the encoder (filled by build_owner)
     FactorizeStats fz;
     FlattenStats fl;
     const int e0 = ev ? ev->tick() : 0;

@@ -127,6 +127,26 @@ __global__ __launch_bounds__(256) void literal_hist_kernel(const u8* __restrict_
     __syncthreads();
     if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
 }
+// the same from the class bytes of FactorSpace::cls (0 = literal): 2 bytes per position instead of 5, sixteen positions per load
+__global__ __launch_bounds__(256) void literal_hist_cls_kernel(const u8* __restrict__ text, const u8* __restrict__ cls, size_t n,
+                                                                u32* __restrict__ hist) {
+    __shared__ u32 h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const size_t stride = (size_t)gridDim.x * blockDim.x * 16;
+    for (size_t p = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 16; p < n; p += stride) {
+        if (p + 16 <= n && ((((size_t)text) | ((size_t)cls)) & 15) == 0) {
+            const uint4 t = *(const uint4*)(text + p), k = *(const uint4*)(cls + p);
+            const u32 tw[4] = { t.x, t.y, t.z, t.w }, kw[4] = { k.x, k.y, k.z, k.w };
+#pragma unroll
+            for (int j = 0; j < 16; ++j) if (((kw[j >> 2] >> (8 * (j & 3))) & 0xFFu) == 0u) atomicAdd(&h[(tw[j >> 2] >> (8 * (j & 3))) & 0xFFu], 1u);
+        } else {
+            for (size_t q = p; q < n && q < p + 16; ++q) if (cls[q] == 0) atomicAdd(&h[text[q]], 1u);
+        }
+    }
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
 
 // bits contributed by position p (see file header)
 template <bool ASCII>
@@ -153,6 +173,20 @@ __device__ __forceinline__ u32 position_cost(u32 own, u32 own_prev, bool first, 
     return 0u;
 }
 
+// the same from class bytes (FactorSpace::cls; not for the ASCII coder, which needs the values): cl / prevcl = class of p / of p - 1
+__device__ __forceinline__ u32 position_cost_cls(u32 cl, u32 prevcl, bool first, u8 ch, u32 p, const u8* __restrict__ clen,
+                                                 const EncParams& P, const ArithDev& A) {
+    if (cl == 0u) {
+        u32 c;
+        if (A.litidx) { const u32 k = A.litidx[p]; c = (A.amark[k] ? 64u : 0u) + (k == A.lc_index ? 128u : 0u); }
+        else c = P.raw_literals ? 8u : (u32)clen[ch];
+        if (first || prevcl != 0u) c += 1u + P.dbits;           // a literal run starts here: flen[p] holds its length
+        return c;
+    }
+    if (cl == 2u) return P.W + P.lbits + ((first || prevcl != 0u) ? 1u : 0u);
+    return 0u;
+}
+
 template <bool ASCII>
 __global__ __launch_bounds__(256) void tile_bits_kernel(const u8* __restrict__ text, const u32* __restrict__ owner,
                                                          const u32* __restrict__ flen, const u32* __restrict__ fsrc, size_t n, CodeTable tab, EncParams P,
@@ -174,6 +208,33 @@ __global__ __launch_bounds__(256) void tile_bits_kernel(const u8* __restrict__ t
             if (p < n) {
                 sum += position_cost<ASCII>(own[j], prev, p == 0, fl[j], ch[j], (u32)p, clen, fsrc, P, A);
                 prev = own[j];
+            }
+        }
+    }
+    sum = wave_reduce_sum(sum);
+    if (lane_id() == 0) sm[wave_id()] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_bits[blockIdx.x] = (u64)sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+__global__ __launch_bounds__(256) void tile_bits_cls_kernel(const u8* __restrict__ text, const u8* __restrict__ cls, size_t n, CodeTable tab, EncParams P,
+                                                             ArithDev A, u64* __restrict__ tile_bits) {
+    __shared__ u8 clen[256];
+    __shared__ u32 sm[4];
+    clen[threadIdx.x] = tab.len[threadIdx.x];
+    __syncthreads();
+    const size_t p0 = (size_t)blockIdx.x * ENC_TILE + (size_t)threadIdx.x * ENC_PER_THREAD;
+    u32 sum = 0;
+    if (p0 < n) {
+        u8 cl[ENC_PER_THREAD], ch[ENC_PER_THREAD];
+        load8_u8(cls, p0, n, cl); load8_u8(text, p0, n, ch);
+        u32 prev = (p0 == 0) ? 0u : (u32)cls[p0 - 1];
+#pragma unroll
+        for (int j = 0; j < ENC_PER_THREAD; ++j) {
+            const size_t p = p0 + j;
+            if (p < n) {
+                sum += position_cost_cls(cl[j], prev, p == 0, ch[j], (u32)p, clen, P, A);
+                prev = cl[j];
             }
         }
     }
@@ -300,6 +361,69 @@ __global__ __launch_bounds__(256) void pack_kernel(const u8* __restrict__ text, 
     sink.flush();
 }
 
+// pack_kernel<false> on the class bytes of FactorSpace::cls instead of owner[] (3 bytes less per position in each of the two passes of a tile)
+__global__ __launch_bounds__(256) void pack_cls_kernel(const u8* __restrict__ text, const u8* __restrict__ cls,
+                                                        const u32* __restrict__ flen, const u32* __restrict__ fsrc, size_t n,
+                                                        CodeTable tab, EncParams P, ArithDev A, const u64* __restrict__ tile_off,
+                                                        u64 base_bits, u64* __restrict__ out, u32 tile0) {
+    __shared__ u8 clen[256];
+    __shared__ u64 code[256];
+    __shared__ u32 sm[5];
+    clen[threadIdx.x] = tab.len[threadIdx.x];
+    code[threadIdx.x] = tab.code[threadIdx.x];
+    __syncthreads();
+    const u32 tile = blockIdx.x + tile0;
+    const size_t p0 = (size_t)tile * ENC_TILE + (size_t)threadIdx.x * ENC_PER_THREAD;
+    u32 fl[ENC_PER_THREAD];
+    u8 cl[ENC_PER_THREAD], ch[ENC_PER_THREAD];
+    u32 prev0 = 0, sum = 0;
+    if (p0 < n) {
+        load8_u8(cls, p0, n, cl); load8_u32(flen, p0, n, fl); load8_u8(text, p0, n, ch);
+        prev0 = (p0 == 0) ? 0u : (u32)cls[p0 - 1];
+        u32 prev = prev0;
+#pragma unroll
+        for (int j = 0; j < ENC_PER_THREAD; ++j) {
+            const size_t p = p0 + j;
+            if (p < n) {
+                sum += position_cost_cls(cl[j], prev, p == 0, ch[j], (u32)p, clen, P, A);
+                prev = cl[j];
+            }
+        }
+    }
+    u32 total;
+    const u32 excl = block_exclusive_sum<u32, 4>(sum, sm, total);
+    if (p0 >= n) return;
+    BitSink sink;
+    sink.out = out;
+    sink.pos = base_bits + tile_off[tile] + excl;
+    sink.acc = 0;
+    sink.cnt = 0;
+    u32 prev = prev0;
+#pragma unroll
+    for (int j = 0; j < ENC_PER_THREAD; ++j) {
+        const size_t p = p0 + j;
+        if (p < n) {
+            const u32 o = cl[j];
+            if (o == 0u) {
+                if (p == 0 || prev != 0u) { sink.append(1, 1); sink.append(fl[j], P.dbits); }   // LZSSCoding.hpp:62-68, :83-86 (a literal run starts)
+                if (A.litidx) {                                                           // ArithmeticCoder.hpp:96-104, :151-155
+                    const u32 k = A.litidx[p];
+                    if (A.amark[k]) sink.append(A.fval[k], 64);
+                    if (k == A.lc_index) { sink.append(A.pp_lb, 64); sink.append(~0ull, 64); }
+                }
+                else if (P.raw_literals) sink.append(ch[j], 8);                           // HuffmanCoder.hpp:565-566
+                else sink.append(code[ch[j]], clen[ch[j]]);                               // :568 huffman_encode
+            } else if (o == 2u) {
+                if (p == 0 || prev != 0u) sink.append(0, 1);                              // LZSSCoding.hpp:57-59
+                sink.append(fsrc[p], P.W);                                                // :77
+                sink.append(fl[j] - P.flen_min, P.lbits);                                 // :78
+            }
+            prev = o;
+        }
+    }
+    sink.flush();
+}
+
 // out[q] = excl[(tiles * (q + 1)) / parts] for q < parts - 1 (bit offset at which chunk q of the pack ends), out[parts - 1] unused
 __global__ void pick_u64_kernel(const u64* __restrict__ excl, u32 tiles, u32 parts, u64* __restrict__ out) {
     const u32 q = threadIdx.x;
@@ -352,7 +476,8 @@ static void encode_prelude(Ctx& c, const u8* text, size_t n, FactorSpace& fs, En
     {
         unsigned g = cdiv(n, 256 * 16); if (g > 2048) g = 2048; if (g == 0) g = 1;
         Ctx::ProfScope prof(c, K_ENC_HIST, (u64)n * 5);
-        literal_hist_kernel<<<g, 256, 0, s>>>(text, fs.owner, n, d_hist);
+        if (fs.have_cls) literal_hist_cls_kernel<<<g, 256, 0, s>>>(text, fs.cls, n, d_hist);
+        else literal_hist_kernel<<<g, 256, 0, s>>>(text, fs.owner, n, d_hist);
         LAUNCH_CHECK();
     }
     c.read_n(d_hist, pre.hist, 256);
@@ -429,6 +554,7 @@ size_t encode_stream(Ctx& c, const u8* text, size_t n, FactorSpace fs, int coder
     {
         Ctx::ProfScope prof(c, K_ENC_TILE_BITS, (u64)n * 9);
         if (P.ascii) tile_bits_kernel<true><<<tiles, 256, 0, s>>>(text, fs.owner, fs.flen, fs.fsrc, n, tab, P, A, tile_bits);
+        else if (fs.have_cls) tile_bits_cls_kernel<<<tiles, 256, 0, s>>>(text, fs.cls, n, tab, P, A, tile_bits);
         else         tile_bits_kernel<false><<<tiles, 256, 0, s>>>(text, fs.owner, fs.flen, fs.fsrc, n, tab, P, A, tile_bits);
         LAUNCH_CHECK();
     }
@@ -459,6 +585,7 @@ size_t encode_stream(Ctx& c, const u8* text, size_t n, FactorSpace fs, int coder
         for (u32 q = 0; q < (overlap ? CH : 1u); ++q) {
             const u32 t0 = overlap ? (u32)((u64)tiles * q / CH) : 0u, t1 = overlap ? (u32)((u64)tiles * (q + 1) / CH) : tiles;
             if (P.ascii) pack_kernel<true><<<t1 - t0, 256, 0, s>>>(text, fs.owner, fs.flen, fs.fsrc, n, tab, P, A, tile_bits, base_bits, (u64*)d_out, t0);
+            else if (fs.have_cls) pack_cls_kernel<<<t1 - t0, 256, 0, s>>>(text, fs.cls, fs.flen, fs.fsrc, n, tab, P, A, tile_bits, base_bits, (u64*)d_out, t0);
             else         pack_kernel<false><<<t1 - t0, 256, 0, s>>>(text, fs.owner, fs.flen, fs.fsrc, n, tab, P, A, tile_bits, base_bits, (u64*)d_out, t0);
             LAUNCH_CHECK();
             if (overlap && q + 1 < CH) {

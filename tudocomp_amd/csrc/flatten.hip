@@ -91,7 +91,8 @@ __global__ __launch_bounds__(OW_T) void owner_count_kernel(const u32* __restrict
 }
 
 __global__ __launch_bounds__(OW_T) void owner_build_kernel(const u32* __restrict__ flen, size_t n, const u32* __restrict__ tilebase,
-                                                           u32* __restrict__ pos, u32* __restrict__ owner, uint2* __restrict__ cross) {
+                                                           u32* __restrict__ pos, u32* __restrict__ owner, uint2* __restrict__ cross,
+                                                           u8* __restrict__ cls) {
     __shared__ u32 s[OW_TILE + OW_TILE / 16 + 16];
     __shared__ u32 sm[OW_T / 64 + 1], smx[OW_T / 64];
     const size_t base = (size_t)blockIdx.x * OW_TILE;
@@ -141,6 +142,17 @@ __global__ __launch_bounds__(OW_T) void owner_build_kernel(const u32* __restrict
         }
         out[k] = (cur_start != 0 && pl - (cur_start - 1) < cur_len) ? cur_rank : NONE32;
     }
+    if (cls) {                                                  // class bytes of the thread's 16 positions (FactorSpace::cls)
+        u32 w4[4] = { 0, 0, 0, 0 };
+#pragma unroll
+        for (int k = 0; k < OW_PER; ++k) {
+            const u32 cl = (out[k] == NONE32) ? 0u : (f[k] != 0 ? 2u : 3u);
+            w4[k >> 2] |= cl << (8 * (k & 3));
+        }
+        const size_t p = base + l0;
+        if (p + OW_PER <= n) *(uint4*)(cls + p) = make_uint4(w4[0], w4[1], w4[2], w4[3]);      // (cls is 16-byte aligned, l0 a multiple of 16)
+        else for (int k = 0; k < OW_PER; ++k) if (p + k < n) cls[p + k] = (u8)(w4[k >> 2] >> (8 * (k & 3)));
+    }
     if (threadIdx.x == OW_T - 1) {                              // the tile's last factor may extend into the following tiles
         const u32 end = cur_start ? cur_start - 1 + cur_len : 0u;          // (lengths are < 2^31)
         cross[blockIdx.x] = (end > (u32)OW_TILE) ? make_uint2(cur_rank, end - (u32)OW_TILE) : make_uint2(NONE32, 0u);
@@ -159,15 +171,16 @@ __global__ __launch_bounds__(OW_T) void owner_build_kernel(const u32* __restrict
     }
 }
 
-__global__ __launch_bounds__(256) void owner_cross_kernel(const uint2* __restrict__ cross, size_t n, u32* __restrict__ owner) {
+__global__ __launch_bounds__(256) void owner_cross_kernel(const uint2* __restrict__ cross, size_t n, u32* __restrict__ owner, u8* __restrict__ cls) {
     const uint2 cr = cross[blockIdx.x];
     if (cr.y == 0) return;
     const size_t start = ((size_t)blockIdx.x + 1) * OW_TILE;
-    for (size_t j = threadIdx.x; j < cr.y && start + j < n; j += 256) owner[start + j] = cr.x;
+    for (size_t j = threadIdx.x; j < cr.y && start + j < n; j += 256) { owner[start + j] = cr.x; if (cls) cls[start + j] = (u8)3; }
 }
 
 void build_owner(Ctx& c, size_t n, FactorSpace& fs) {
     fs.have_list = false;
+    fs.have_cls = false;
     if (n == 0) return;
     const size_t mark = c.arena.mark();
     const u32 tiles = cdiv(n, OW_TILE);
@@ -183,9 +196,10 @@ void build_owner(Ctx& c, size_t n, FactorSpace& fs) {
     exclusive_sum_u32(c, tilecnt, tilecnt, tiles, d_total);
     {
         Ctx::ProfScope prof(c, K_EXTRACT, (u64)n * 8);
-        owner_build_kernel<<<tiles, OW_T, 0, c.stream>>>(fs.flen, n, tilecnt, pos, fs.owner, cross);
+        owner_build_kernel<<<tiles, OW_T, 0, c.stream>>>(fs.flen, n, tilecnt, pos, fs.owner, cross, fs.cls);
         LAUNCH_CHECK();
-        owner_cross_kernel<<<tiles, 256, 0, c.stream>>>(cross, n, fs.owner);
+        owner_cross_kernel<<<tiles, 256, 0, c.stream>>>(cross, n, fs.owner, fs.cls);
+        fs.have_cls = fs.cls != nullptr;
         LAUNCH_CHECK();
     }
     const size_t z = c.read(d_total);

@@ -54,6 +54,10 @@ struct FactorSpace {
     u32* fpos = nullptr;
     size_t nfact = 0;
     bool have_list = false;
+    // optional: one class byte per position -- 0 literal, 2 factor start, 3 covered by a factor that started earlier.  build_owner()
+    // fills it (have_cls); the encoder's streaming passes then read 1 byte instead of the 4-byte owner word per position.
+    u8* cls = nullptr;
+    bool have_cls = false;
 };
 
 struct FactorizeStats { u64 factors = 0; u32 maxlcp = 0; u32 levels = 0; u32 rounds = 0; u64 pushes = 0; u64 entries = 0; u32 small_levels = 0; u32 purges = 0;
