@@ -89,8 +89,10 @@ int guarded(tdc_gpu_ctx* ctx, F&& f) {
 }
 
 // + 192 MiB: fixed-size scratch (the SLE coder's 2^24-entry k-mer table and its sort buffers are the largest)
-bool g_test_extra = false;    // TDC_GPU_WSORT_SMALLRUN (tests): every run of tying records is handed on, the hand-over lists need ~48 B per byte
-size_t arena_need(size_t n) { return (g_test_extra ? 176 : 112) * n + ((size_t)192 << 20); }
+size_t arena_need(size_t n) { return 112 * n + ((size_t)192 << 20); }
+// (a context created with TDC_GPU_WSORT_SMALLRUN -- tests: every run of tying records is handed on -- needs ~48 B per byte more for the
+//  hand-over lists; per context, not per process: other contexts of a test run keep the product's budget)
+size_t arena_need(const Ctx& c, size_t n) { return arena_need(n) + (c.wsort_small ? 64 * n : 0); }
 
 // public coder id (+ SLE's kmer option in bits 8..) -> coder id of encode_stream
 int lcpcomp_enc_coder(int coder) {
@@ -339,7 +341,7 @@ int tdc_gpu_ctx_create(int device, tdc_gpu_ctx** out) {
         if (const char* m = getenv("TDC_GPU_WSORT_MIN")) { const long v = atol(m); ctx->c.wsort_min = v < 4096 ? 4096 : (size_t)v; }
         if (const char* m = getenv("TDC_GPU_WSORT_KW")) { const int v = atoi(m); ctx->c.wsort_kw = (v == 1 || v == 2) ? v : 0; }
         if (const char* m = getenv("TDC_GPU_WSORT_ROUNDS")) { const int v = atoi(m); ctx->c.wsort_rounds = v < 0 ? 0 : (v > 100 ? 100 : v); }
-        if (const char* m = getenv("TDC_GPU_WSORT_SMALLRUN")) { ctx->c.wsort_small = atoi(m) ? 1 : 0; if (ctx->c.wsort_small) g_test_extra = true; }
+        if (const char* m = getenv("TDC_GPU_WSORT_SMALLRUN")) ctx->c.wsort_small = atoi(m) ? 1 : 0;
         if (const char* m = getenv("TDC_GPU_WSORT_OVERLAP")) ctx->c.wsort_overlap = atoi(m) ? 1 : 0;
         if (const char* m = getenv("TDC_GPU_WSORT_FUSE")) ctx->c.wsort_fuse = atoi(m) ? 1 : 0;
         if (const char* m = getenv("TDC_GPU_WSORT_TWO")) { const int v = atoi(m); ctx->c.wsort_two = (v >= 0 && v <= 2) ? v : 0; }
@@ -421,7 +423,7 @@ int tdc_gpu_device_memory(int device, size_t* free_bytes, size_t* total_bytes) {
 }
 
 int tdc_gpu_ctx_reserve(tdc_gpu_ctx* ctx, size_t n) {
-    return guarded(ctx, [&] { reserve_arena(ctx->c, arena_need(n)); });
+    return guarded(ctx, [&] { reserve_arena(ctx->c, arena_need(ctx->c, n)); });
 }
 
 size_t tdc_gpu_lcpcomp_bound(size_t n) { return align_up(encode_bound(n) + 16, 8); }
@@ -437,7 +439,7 @@ int tdc_gpu_lcpcomp_compress_dev(tdc_gpu_ctx* ctx, const void* d_text, size_t n,
         if (!d_out || !out_len || ((uintptr_t)d_out & 7)) throw ArgError{TDC_GPU_ERR_ARG, "d_out must be non-NULL and 8-byte aligned"};
         Ctx& c = ctx->c;
         if (stats) memset(stats, 0, sizeof(*stats));
-        reserve_arena(c, arena_need(n));
+        reserve_arena(c, arena_need(c, n));
         Events ev(c);
         const int e0 = ev.tick();
         u8* dst = (u8*)d_out;
@@ -469,7 +471,7 @@ void compress_host(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, bool raw, ui
     Ctx& c = ctx->c;
     if (stats) memset(stats, 0, sizeof(*stats));
     // raw input: sized for a text without escapes first; the 0x00 / 0xFF bytes are counted on the device after the upload
-    reserve_arena(c, raw ? arena_need(n + 1) + n + 64 : arena_need(n));
+    reserve_arena(c, raw ? arena_need(c, n + 1) + n + 64 : arena_need(c, n));
     Events ev(c);
     const int e0 = ev.tick();
     u8* d_text;
@@ -479,9 +481,9 @@ void compress_host(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, bool raw, ui
         if (n) HIP_TRY(hipMemcpyAsync(d_raw, text, n, hipMemcpyHostToDevice, c.stream));
         tn = n + count_escapes_device(c, d_raw, n) + 1;
         if (tn >= 0x7FFFFFFFull) throw ArgError{TDC_GPU_ERR_TOO_LARGE, "raw input too large: the escaped text must stay < 2^31 - 1 bytes"};
-        if (c.arena.size < arena_need(tn) + n + 64) {                        // many escapes: a larger arena, upload once more
+        if (c.arena.size < arena_need(c, tn) + n + 64) {                        // many escapes: a larger arena, upload once more
             HIP_TRY(hipStreamSynchronize(c.stream));
-            reserve_arena(c, arena_need(tn) + n + 64);
+            reserve_arena(c, arena_need(c, tn) + n + 64);
             d_raw = c.arena.get<u8>(n + 64);
             if (n) HIP_TRY(hipMemcpyAsync(d_raw, text, n, hipMemcpyHostToDevice, c.stream));
         }
@@ -646,7 +648,7 @@ namespace {
 void run_lzss_lcp(Ctx& c, const uint8_t* text, size_t n, uint32_t threshold, u8** d_text_out, DevArrays& A, tdc_gpu_stats* st, Events& ev) {
     if (threshold == 0) throw ArgError{TDC_GPU_ERR_ARG, "threshold must be >= 1"};
     if (text[n - 1] != 0) throw ArgError{TDC_GPU_ERR_NO_SENTINEL, "text does not end with a 0 sentinel"};
-    reserve_arena(c, arena_need(n));
+    reserve_arena(c, arena_need(c, n));
     u8* d_text = c.arena.get<u8>(n + 64);
     HIP_TRY(hipMemcpyAsync(d_text, text, n, hipMemcpyHostToDevice, c.stream));
     validate_device_text(c, d_text, n);
@@ -795,7 +797,7 @@ int tdc_gpu_textds(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, uint32_t* sa
         check_text_args(text, n);
         if (text[n - 1] != 0) throw ArgError{TDC_GPU_ERR_NO_SENTINEL, "text does not end with a 0 sentinel"};
         Ctx& c = ctx->c;
-        reserve_arena(c, arena_need(n));
+        reserve_arena(c, arena_need(c, n));
         u8* d_text = c.arena.get<u8>(n + 64);
         HIP_TRY(hipMemcpyAsync(d_text, text, n, hipMemcpyHostToDevice, c.stream));
         validate_device_text(c, d_text, n);
@@ -830,7 +832,7 @@ int tdc_gpu_lcpcomp_factorize(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, u
         if (text[n - 1] != 0) throw ArgError{TDC_GPU_ERR_NO_SENTINEL, "text does not end with a 0 sentinel"};
         Ctx& c = ctx->c;
         if (stats) memset(stats, 0, sizeof(*stats));
-        reserve_arena(c, arena_need(n));
+        reserve_arena(c, arena_need(c, n));
         Events ev(c);
         u8* d_text = c.arena.get<u8>(n + 64);
         HIP_TRY(hipMemcpyAsync(d_text, text, n, hipMemcpyHostToDevice, c.stream));
@@ -859,7 +861,7 @@ int tdc_gpu_flatten(tdc_gpu_ctx* ctx, size_t n, const uint32_t* pos, uint32_t* s
         if (z && (!pos || !src || !len)) throw ArgError{TDC_GPU_ERR_ARG, "factor arrays are NULL"};
         validate_factor_list(n, pos, src, len, z);
         Ctx& c = ctx->c;
-        reserve_arena(c, arena_need(n));
+        reserve_arena(c, arena_need(c, n));
         FactorSpace fs;
         fs.flen = c.arena.get<u32>(n); fs.owner = c.arena.get<u32>(n); fs.fsrc = c.arena.get<u32>(n);
         u32* d_pos = c.arena.get<u32>(z + 1), *d_src = c.arena.get<u32>(z + 1), *d_len = c.arena.get<u32>(z + 1);
@@ -931,7 +933,7 @@ static int encode_entry(tdc_gpu_ctx* ctx, int coder, const uint8_t* text, size_t
         if (z && (!pos || !src || !len)) throw ArgError{TDC_GPU_ERR_ARG, "factor arrays are NULL"};
         validate_factor_list(n, pos, src, len, z);
         Ctx& c = ctx->c;
-        reserve_arena(c, arena_need(n));
+        reserve_arena(c, arena_need(c, n));
         u8* d_text = c.arena.get<u8>(n + 64);
         HIP_TRY(hipMemcpyAsync(d_text, text, n, hipMemcpyHostToDevice, c.stream));
         FactorSpace fs;

@@ -166,25 +166,49 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TDC_FS_WPE,
 // After the partition by the top 2 * DB index bits, window w holds exactly the records of the positions [w * W, (w + 1) * W) (position
 // n - 1 = sa[0] has no record).  One workgroup per window: each array is scattered into an LDS image of the window and leaves as whole
 // lines.
-__global__ __launch_bounds__(256) void fs_image_kernel(const u32* __restrict__ idx, const u64* __restrict__ rp, int lsh, size_t m, u32 W,
-                                                        u32* __restrict__ isa, u32* __restrict__ phi, u32* __restrict__ plcp, u32* __restrict__ d_max) {
+constexpr int FS_IMG_T = 1024;       // threads of the image kernel: a window's records are loaded ONCE, eight per thread
+__global__ __launch_bounds__(FS_IMG_T) void fs_image_kernel(const u32* __restrict__ idx, const u64* __restrict__ rp, int lsh, size_t m, u32 W,
+                                                             u32* __restrict__ isa, u32* __restrict__ phi, u32* __restrict__ plcp, u32* __restrict__ d_max) {
     __shared__ u32 img[FS_WMAX];
+    __shared__ u32 smx[FS_IMG_T / 64];
+    constexpr int R = FS_WMAX / FS_IMG_T;
     const size_t base = (size_t)blockIdx.x * W;
     const size_t end = (base + W < m) ? base + W : m;
+    u32 ix[R];
+    u64 rr[R];
     u32 mx = 0;
-    for (size_t j = base + threadIdx.x; j < end; j += 256) img[idx[j] & (W - 1)] = (u32)rp[j];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {                               // (round 2 of this kernel read idx three times and rp twice: 28 bytes per record)
+        const size_t j = base + (size_t)r * FS_IMG_T + threadIdx.x;
+        const bool have = j < end;
+        ix[r] = have ? idx[j] : 0xFFFFFFFFu;
+        rr[r] = have ? rp[j] : 0ull;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) if (ix[r] != 0xFFFFFFFFu) img[ix[r] & (W - 1)] = (u32)rr[r];
     __syncthreads();
-    for (size_t q = base + threadIdx.x; q < end; q += 256) isa[q] = img[q - base];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { const size_t q = base + (size_t)r * FS_IMG_T + threadIdx.x; if (q < end) isa[q] = img[q - base]; }
     __syncthreads();
-    for (size_t j = base + threadIdx.x; j < end; j += 256) img[idx[j] & (W - 1)] = (u32)(rp[j] >> 32);     // (the window's records are still in L2)
+#pragma unroll
+    for (int r = 0; r < R; ++r) if (ix[r] != 0xFFFFFFFFu) img[ix[r] & (W - 1)] = (u32)(rr[r] >> 32);
     __syncthreads();
-    for (size_t q = base + threadIdx.x; q < end; q += 256) phi[q] = img[q - base];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { const size_t q = base + (size_t)r * FS_IMG_T + threadIdx.x; if (q < end) phi[q] = img[q - base]; }
     __syncthreads();
-    for (size_t j = base + threadIdx.x; j < end; j += 256) { const u32 x = idx[j], l = (x >> lsh) & 0xFFu; img[x & (W - 1)] = l; mx = max(mx, l); }
+#pragma unroll
+    for (int r = 0; r < R; ++r) if (ix[r] != 0xFFFFFFFFu) { const u32 l = (ix[r] >> lsh) & 0xFFu; img[ix[r] & (W - 1)] = l; mx = max(mx, l); }
     __syncthreads();
-    for (size_t q = base + threadIdx.x; q < end; q += 256) plcp[q] = img[q - base];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { const size_t q = base + (size_t)r * FS_IMG_T + threadIdx.x; if (q < end) plcp[q] = img[q - base]; }
     mx = wave_reduce_max(mx);
-    if (lane_id() == 0 && mx) atomicMax(d_max, mx);
+    if (lane_id() == 0) smx[wave_id()] = mx;
+    __syncthreads();
+    if (wave_id() == 0) {                                       // (the whole wave takes part in the reduction)
+        u32 v = (lane_id() < FS_IMG_T / 64) ? smx[lane_id()] : 0u;
+        v = wave_reduce_max(v);
+        if (lane_id() == 0 && v) atomicMax(d_max, v);
+    }
 }
 
 __global__ void fs_first_kernel(const u32* __restrict__ sa, size_t n, u32* __restrict__ isa, u32* __restrict__ phi, u32* __restrict__ plcp) {
@@ -261,8 +285,8 @@ void build_isa_phi_plcp_fused(Ctx& c, const u32* sa, const u8* lcp8, size_t n, u
     {
         const u32 W = 1u << (bits - 2 * db);
         if (W > FS_WMAX) throw HipError{hipErrorUnknown, "fused scatter: window larger than the LDS image", (int)__LINE__};
-        Ctx::ProfScope prof(c, K_FS_IMAGE, (u64)m * 24);
-        fs_image_kernel<<<cdiv(m, W), 256, 0, s>>>(idx[1], rp[1], bits - db, m, W, isa, phi, plcp, d_maxlcp);
+        Ctx::ProfScope prof(c, K_FS_IMAGE, (u64)m * 24);          // 12 bytes in, 12 out
+        fs_image_kernel<<<cdiv(m, W), FS_IMG_T, 0, s>>>(idx[1], rp[1], bits - db, m, W, isa, phi, plcp, d_maxlcp);
         LAUNCH_CHECK();
         fs_first_kernel<<<1, 1, 0, s>>>(sa, n, isa, phi, plcp);
         LAUNCH_CHECK();
