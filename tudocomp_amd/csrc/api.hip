@@ -329,6 +329,7 @@ int tdc_gpu_ctx_create(int device, tdc_gpu_ctx** out) {
         if (const char* m = getenv("TDC_GPU_PLCP_SAMPLES")) ctx->c.plcp_samples = atoi(m) != 0;
         if (const char* m = getenv("TDC_GPU_SMALL_PIPELINE")) ctx->c.small_pipeline = atoi(m) != 0;
         if (const char* m = getenv("TDC_GPU_SMALL_BIG")) ctx->c.small_big = atoi(m);
+        if (const char* m = getenv("TDC_GPU_FS_PAIR")) ctx->c.fs_pair = atoi(m) != 0;
         if (const char* m = getenv("TDC_GPU_LEVEL_PURGE")) ctx->c.level_purge = atoi(m) != 0;
         if (const char* m = getenv("TDC_GPU_SA_REFINE")) ctx->c.sa_refine = atoi(m) != 0;
         if (const char* m = getenv("TDC_GPU_SA_FUSED_INIT")) ctx->c.sa_fused_init = atoi(m) != 0;

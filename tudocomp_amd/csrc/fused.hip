@@ -72,19 +72,29 @@ __global__ __launch_bounds__(256) void fs_count_kernel(FSLevel P, u32 rows) {
 #ifndef TDC_FS_WPE
 #define TDC_FS_WPE 4
 #endif
-template <int DB, bool FIRST>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TDC_FS_WPE, TDC_FS_WPE))) void fs_scatter_kernel(FSLevel P, u32 rows) {
+// PAIR = 2: a workgroup of 512 threads takes two consecutive rows of a row block as ONE tile of 8 192 records -- rows of a block lie in
+// one segment, their inputs are adjacent and so are their runs of every digit in the output (the offsets are a running prefix inside
+// the block), and the order inside a bucket does not matter here.  With 512 buckets a 4 096-record tile leaves 8 records per bucket:
+// 32-byte runs of index words, i.e. partial lines (1.5 x the algorithmic write traffic in the PMC counters); twice the tile, twice the run.
+template <int DB, bool FIRST, int PAIR>
+__global__ __launch_bounds__(256 * PAIR) __attribute__((amdgpu_waves_per_eu(TDC_FS_WPE, TDC_FS_WPE))) void fs_scatter_kernel(FSLevel P, u32 rows) {
+    constexpr int NT = 256 * PAIR;
+    constexpr u32 TILE = (u32)FS_TILE * PAIR;
     constexpr u32 D = 1u << DB;
     __shared__ u32 tcnt[D];
     __shared__ u32 gbase[D];
-    __shared__ __align__(16) u64 stage[FS_TILE];
-    __shared__ u32 scan_sm[5];
+    __shared__ __align__(16) u64 stage[TILE];
+    __shared__ u32 scan_sm[NT / 64 + 1];
     const int lane = lane_id();
-    const u32 row = xcd_tile(blockIdx.x, P.per_xcd);
+    const u32 row = xcd_tile(blockIdx.x, P.per_xcd) * PAIR;
     if (row >= rows) return;
     size_t base; u32 cnt;
     if (!fs_row(P, row, base, cnt) || cnt == 0) return;
-    for (u32 i = threadIdx.x; i < D; i += 256) tcnt[i] = 0;
+    if (PAIR == 2 && row + 1 < rows) {                          // (the second row of the pair: same block, its records follow directly)
+        size_t base2; u32 cnt2;
+        if (fs_row(P, row + 1, base2, cnt2) && cnt2) cnt += cnt2;
+    }
+    for (u32 i = threadIdx.x; i < D; i += NT) tcnt[i] = 0;
     __syncthreads();
     const u32 lb = wave_id() * (64 * FS_ITEMS) + lane;
     const u32* ip = P.idx_in + base + lb;
@@ -117,16 +127,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TDC_FS_WPE,
     __syncthreads();
     {
         const u32 t = threadIdx.x;
-        u32 tot[D / 256], sum = 0;
+        constexpr u32 DPT = (D + NT - 1) / NT;                  // digits per thread
+        u32 tot[DPT], sum = 0;
 #pragma unroll
-        for (u32 q = 0; q < D / 256; ++q) { tot[q] = tcnt[t * (D / 256) + q]; sum += tot[q]; }
+        for (u32 q = 0; q < DPT; ++q) { const u32 d = t * DPT + q; tot[q] = d < D ? tcnt[d] : 0u; sum += tot[q]; }
         u32 total;
-        u32 start = block_exclusive_sum<u32, 4>(sum, scan_sm, total);
+        u32 start = block_exclusive_sum<u32, NT / 64>(sum, scan_sm, total);
 #pragma unroll
-        for (u32 q = 0; q < D / 256; ++q) {
-            const u32 d = t * (D / 256) + q;
-            tcnt[d] = start;
-            gbase[d] = P.counts[(size_t)row * D + d] - start;
+        for (u32 q = 0; q < DPT; ++q) {
+            const u32 d = t * DPT + q;
+            if (d < D) {
+                tcnt[d] = start;
+                gbase[d] = P.counts[(size_t)row * D + d] - start;
+            }
             start += tot[q];
         }
     }
@@ -134,7 +147,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TDC_FS_WPE,
     u32 dst[FS_ITEMS];
     u32* stage32 = (u32*)stage;
     // stream 1: the destination index (FIRST: low bits + the LCP byte); its bucket gives every slot of the sorted tile its global address
-    unsigned short* stage_d = (unsigned short*)(stage + FS_TILE / 2);          // digits of the staged words: second half of the buffer
+    unsigned short* stage_d = (unsigned short*)(stage + TILE / 2);          // digits of the staged words: second half of the buffer
 #pragma unroll
     for (int j = 0; j < FS_ITEMS; ++j) {
         if (lb + (u32)j * 64 < cnt) {
@@ -147,7 +160,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TDC_FS_WPE,
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < FS_ITEMS; ++r) {
-        const u32 sp = (u32)r * 256 + threadIdx.x;
+        const u32 sp = (u32)r * NT + threadIdx.x;
         dst[r] = 0xFFFFFFFFu;
         if (sp < cnt) {
             dst[r] = gbase[stage_d[sp]] + sp;
@@ -160,7 +173,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TDC_FS_WPE,
     for (int j = 0; j < FS_ITEMS; ++j) if (lb + (u32)j * 64 < cnt) stage[pos[j]] = rp[j];
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < FS_ITEMS; ++r) if (dst[r] != 0xFFFFFFFFu) P.rp_out[dst[r]] = stage[(u32)r * 256 + threadIdx.x];
+    for (int r = 0; r < FS_ITEMS; ++r) if (dst[r] != 0xFFFFFFFFu) P.rp_out[dst[r]] = stage[(u32)r * NT + threadIdx.x];
 }
 
 // After the partition by the top 2 * DB index bits, window w holds exactly the records of the positions [w * W, (w + 1) * W) (position
@@ -273,8 +286,18 @@ void build_isa_phi_plcp_fused(Ctx& c, const u32* sa, const u8* lcp8, size_t n, u
         ss_level_offsets(c, Tb, seg_start, nseg, D, nstart, m);
         {
             const int ps = c.prof_begin(K_RS_SCATTER_U32, (u64)m * (l == 0 ? 5 + 12 : 24));
-            if (l == 0) { if (db == 9) fs_scatter_kernel<9, true><<<grid, 256, 0, s>>>(P, rows); else fs_scatter_kernel<8, true><<<grid, 256, 0, s>>>(P, rows); }
-            else { if (db == 9) fs_scatter_kernel<9, false><<<grid, 256, 0, s>>>(P, rows); else fs_scatter_kernel<8, false><<<grid, 256, 0, s>>>(P, rows); }
+            const bool pair = (Tb.R % 2) == 0 && c.fs_pair;             // (rows per block is a power of two: a pair never straddles a block)
+            FSLevel P2 = P;
+            const u32 groups = pair ? (rows + 1) / 2 : rows;
+            P2.per_xcd = (c.xcd_remap == 1 && groups >= 64) ? cdiv(groups, 8) : 0u;
+            const u32 grid2 = P2.per_xcd ? 8 * P2.per_xcd : groups;
+            if (pair) {
+                if (l == 0) { if (db == 9) fs_scatter_kernel<9, true, 2><<<grid2, 512, 0, s>>>(P2, rows); else fs_scatter_kernel<8, true, 2><<<grid2, 512, 0, s>>>(P2, rows); }
+                else { if (db == 9) fs_scatter_kernel<9, false, 2><<<grid2, 512, 0, s>>>(P2, rows); else fs_scatter_kernel<8, false, 2><<<grid2, 512, 0, s>>>(P2, rows); }
+            } else {
+                if (l == 0) { if (db == 9) fs_scatter_kernel<9, true, 1><<<grid, 256, 0, s>>>(P, rows); else fs_scatter_kernel<8, true, 1><<<grid, 256, 0, s>>>(P, rows); }
+                else { if (db == 9) fs_scatter_kernel<9, false, 1><<<grid, 256, 0, s>>>(P, rows); else fs_scatter_kernel<8, false, 1><<<grid, 256, 0, s>>>(P, rows); }
+            }
             LAUNCH_CHECK();
             c.prof_end(ps);
         }
