@@ -729,6 +729,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
                         E.rng[2 * i + 1] = (a + e) | 0x80000000u;
                         s_any = 1;
                     }
+                    h |= 2u;                                    // (bit 1: the slot lies in a run that goes on -- its second word is written back)
                 }
                 P32[L] = tgt | (h << 16);
             }
@@ -737,7 +738,6 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
         u32 tr[ROWS];
 #pragma unroll
         for (int j = 0; j < ROWS; ++j) { const u32 L = wbase + (u32)j * 64; tr[j] = (L < m) ? P32[L] : 0u; }
-        const bool handed = s_any != 0;
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < ROWS; ++j) {
@@ -749,10 +749,11 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4)))
         for (int j = 0; j < ROWS; ++j) {
             const u32 L = wbase + (u32)j * 64;
             if (L < m) {
-                const bool h = hf[L] != 0;
+                const u32 hfl = hf[L];
+                const bool h = (hfl & 1u) != 0;
                 const bool old = (hb[L >> 6] >> (L & 63)) & 1ull;
                 A.v[(size_t)a + L] = P32[L];
-                if (PAIRS || handed) K2[L] = Wl[L];             // (a run that goes on is read from here by the next stage)
+                if (PAIRS || (hfl & 2u)) K2[L] = Wl[L];         // (a run that goes on is read from here by the next stage; nobody reads the rest)
                 if (h && !old) {
                     const u64 x = Wl[L] ^ Wl[L - 1];
                     A.flags[(size_t)a + L] = 1;
