@@ -345,6 +345,7 @@ int tdc_gpu_ctx_create(int device, tdc_gpu_ctx** out) {
         if (const char* m = getenv("TDC_GPU_WSORT_SMALLRUN")) ctx->c.wsort_small = atoi(m) ? 1 : 0;
         if (const char* m = getenv("TDC_GPU_WSORT_OVERLAP")) ctx->c.wsort_overlap = atoi(m) ? 1 : 0;
         if (const char* m = getenv("TDC_GPU_WSORT_FUSE")) ctx->c.wsort_fuse = atoi(m) ? 1 : 0;
+        if (const char* m = getenv("TDC_GPU_WSORT_ORDER")) ctx->c.wsort_order = atoi(m) ? 1 : 0;
         if (const char* m = getenv("TDC_GPU_WSORT_TWO")) { const int v = atoi(m); ctx->c.wsort_two = (v >= 0 && v <= 2) ? v : 0; }
         if (const char* m = getenv("TDC_GPU_WSORT_LEAF")) ctx->c.wsort_leaf = atoi(m) == 1024 ? 1024 : 2048;
         if (const char* m = getenv("TDC_GPU_WSORT_PACK")) { const int v = atoi(m); ctx->c.wsort_pack = (v == 1024 || v == 4096) ? v : 2048; }

@@ -1192,6 +1192,7 @@ bool wsort_applicable(const Ctx& c, size_t n) { return c.wsort && n >= c.wsort_m
 int wsort_result_index(Ctx& c, size_t n) {                    // index of the V buffer that will hold wsort_suffixes' result
     int L; u32 F[3], os;
     ss_fanouts(c, n, L, F, os, (u32)c.wsort_leaf, c.wsort_two);
+    if (c.wsort_order == 1 && L == 3) std::swap(F[0], F[2]);   // the widest level first (it runs behind the upload)
     return (L - 1) & 1;
 }
 
@@ -1238,6 +1239,7 @@ int ws_sort_impl(Ctx& c, const WKeyGen* gen, u64* K1[2], u64* K2[2], u32* V[2], 
         sp1 = pre->sp1; sp2 = pre->sp2;
     } else {
         ss_fanouts(c, n, pl.L, pl.F, pl.os, (u32)c.wsort_leaf, c.wsort_two);
+        if (c.wsort_order == 1 && pl.L == 3) std::swap(pl.F[0], pl.F[2]);
         pl.NLr = pl.F[0] * pl.F[1] * pl.F[2]; pl.NS = pl.NLr - 1; pl.S = pl.os * pl.NLr;
         sp1 = c.arena.get<u64>((size_t)pl.NS + 1);
         sp2 = KW == 2 ? c.arena.get<u64>((size_t)pl.NS + 1) : nullptr;
@@ -1550,6 +1552,7 @@ bool wsort_pre_begin(Ctx& c, WPre& P, const u8* text, size_t n, size_t chunk_len
     P.text = text; P.n = n; P.chunk_len = chunk_len; P.nchunks = nchunks;
     wsort_make_keygen(c, text, n, sigma, code, P.KW, P.g);
     ss_fanouts(c, n, P.L, P.F, P.os, (u32)c.wsort_leaf, c.wsort_two);
+    if (c.wsort_order == 1 && P.L == 3) std::swap(P.F[0], P.F[2]);
     if (P.L < 2) return false;
     P.NLr = P.F[0] * P.F[1] * P.F[2]; P.NS = P.NLr - 1; P.S = P.os * P.NLr;
     Arena& A = c.arena;
