@@ -181,7 +181,7 @@ void run_textds(Ctx& c, const u8* d_text, size_t n, DevArrays& A, tdc_gpu_stats*
     u32* d_max = c.arena.get<u32>(1);
     SAStats ss;
     SAExtra ex;
-    ex.lcp8 = c.arena.get<u8>(n + 8);                         // neighbour LCPs of the wide path (suffix_array.hip)
+    ex.lcp8 = c.arena.get<u8>(n + 64);                        // neighbour LCPs of the wide path (suffix_array.hip)
     const int e0 = ev ? ev->tick() : 0;
     build_suffix_array(c, d_text, n, A.sa, A.isa, &ss, &ex);
     const int e1 = ev ? ev->tick() : 0;

@@ -104,13 +104,23 @@ __global__ __launch_bounds__(256 * PAIR) __attribute__((amdgpu_waves_per_eu(TDC_
     // every stream of the thread's records is requested up front: the staging phases below then never wait for global memory
     u64 rp[FS_ITEMS];
     u32 lc[FS_ITEMS];
+    const u8* lst = (const u8*)stage;                           // FIRST: the tile's LCP bytes, staged with 16-byte loads (sixteen byte loads per
+    size_t lmis = 0;                                            // thread fetched 64 bytes per wave instruction)
+    if (FIRST) {
+        const u8* src = P.lcp_in + base;
+        lmis = ((size_t)src) & 15;
+        const uint4* a0 = (const uint4*)(src - lmis);           // (the array starts 16-byte aligned and is padded: no access outside it)
+        const u32 nv = (cnt + (u32)lmis + 15u) / 16u;
+        for (u32 i = threadIdx.x; i < nv; i += NT) ((uint4*)stage)[i] = a0[i];
+        __syncthreads();
+    }
 #pragma unroll
     for (int j = 0; j < FS_ITEMS; ++j) {
         const u32 e = lb + (u32)j * 64;
         const bool valid = e < cnt;
         if (FIRST) rp[j] = (u64)(u32)(base + e + 1) | ((u64)(valid ? P.prev_in[base + e] : 0u) << 32);
         else rp[j] = valid ? P.rp_in[base + e] : 0ull;
-        lc[j] = (FIRST && valid) ? (u32)P.lcp_in[base + e] : 0u;
+        lc[j] = (FIRST && valid) ? (u32)lst[lmis + e] : 0u;
     }
 #pragma unroll
     for (int j = 0; j < FS_ITEMS; ++j) {
