@@ -293,7 +293,9 @@ __global__ __launch_bounds__(256) void ws_count_kernel(WSLevel P, WKeyGen g, u32
 template <int KW, bool GEN, bool LAST, int FMAX>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FMAX > 256 ? 3 : 4, FMAX > 256 ? 3 : 4))) void ws_scatter_kernel(WSLevel P, WKeyGen g, u32 rows) {
     constexpr int DMAX = LAST ? 2 * FMAX : FMAX;
-    constexpr bool MATCH = LAST && FMAX <= 256;               // ranks from the wave-level LDS match (its tables need 8 bytes per wave and digit)
+    // ranks from the wave-level LDS match (its tables need 8 bytes per wave and digit).  Round 3 measured it on the inner levels too: LDS
+    // atomics with the two-group peel serialise on the 64 counters of a skewed level -- 22.6 -> 19 ms for level 2 at 2e9
+    constexpr bool MATCH = FMAX <= 256;
     __shared__ u32 tcnt[MATCH ? 4 : DMAX];
     __shared__ __align__(16) u16 wcnt[MATCH ? 4 : 1][MATCH ? DMAX : 8];
     __shared__ u32 gbase[DMAX];
