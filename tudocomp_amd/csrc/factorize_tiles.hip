@@ -229,7 +229,8 @@ __global__ __launch_bounds__(KT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                 const u64 mq = __ballot(lane < iL - 1 && q < wl && (u32)cur8[PA(q < wl ? q : 0)] >= L);
                 if (mq) dfr = fr + __builtin_ctzll(mq) - (iL - 1);
             }
-            if (((lds_load(&s_lvlmask) >> L) & 1ull) == 0) { fl = dfl; fr = dfr; continue; }   // nothing resides in list L
+            const u64 lvl_seen = lds_load(&s_lvlmask);
+            if (((lvl_seen >> L) & 1ull) == 0) { fl = dfl; fr = dfr; continue; }   // nothing resides in list L
             const int lo = fl > 0 ? fl : 0, hi = fr < wl ? fr : wl;
             // ---- 1. collect the alive entries of list L in position order --------------------------------------
             // (branch-free per 8-position word: byte flags 0x80 for "resides in list L" and for "still alive", a shift cascade turns
@@ -412,11 +413,17 @@ __global__ __launch_bounds__(KT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                     if (p < mid) atomicMax(&s_tl, p + 1); else atomicMin(&s_tr, p);
                     e_set_state(ent, i, S_DROP);
                 } else if (v >= threshold) {
-                    const int k = atomicAdd(&s_npush, 1);
+                    // (the lanes that push in this step share one atomic: two thirds of all entry visits are pushes, and one LDS word
+                    //  per push serialises; the level mask is only touched for a level it does not show yet)
+                    const u64 act = __ballot(true);
+                    const int leader = __builtin_ctzll(act);
+                    int kb = 0;
+                    if (lane == leader) kb = atomicAdd(&s_npush, (int)__popcll(act));
+                    const int k = __builtin_amdgcn_readlane(kb, leader) + (int)__popcll(act & ((1ull << lane) - 1ull));
                     if (k < TP) { pkey[k] = e_key(e); pidx[k] = (unsigned short)i; }
                     e_set_val(ent, i, v);
                     e_set_state(ent, i, S_PUSH);
-                    atomicOr((unsigned long long*)&s_lvlmask, 1ull << v);
+                    if (!((lvl_seen >> v) & 1ull)) atomicOr((unsigned long long*)&s_lvlmask, 1ull << v);
                 } else e_set_state(ent, i, S_DROP);
             }
             lds_barrier();
