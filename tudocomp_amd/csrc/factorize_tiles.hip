@@ -348,7 +348,10 @@ __global__ __launch_bounds__(KT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                     else if (!blocked) {
                         const bool exposed = (p < dfl) || (p >= dfr);
                         e_set_state(ent, i, ((unc || exposed) ? S_UNC : S_SEL) | keep);
-                    } else atomicAdd(&s_und[rn], 1);
+                    } else {                                    // (still undecided: one atomic for the lanes that are)
+                        const u64 act = __ballot(true);
+                        if (lane == __builtin_ctzll(act)) atomicAdd(&s_und[rn], (int)__popcll(act));
+                    }
                 }
                 lds_barrier();
                 r = rn;
