@@ -37,7 +37,7 @@ void msd_partition_pairs_u32(Ctx& c, const u32* idx, const u32* val, size_t m, i
 
 // ---- internals of the splitter sort shared between ssort.hip and wsort.hip ------------------------------------------------------
 struct SegTables { u32* blk_start; u32* blk_seg; u32* counts; u32* bs; u32 R, blocks_ub, rows; };
-struct UnitTables { u32* unit_rng; u32* cls_list; u32* large; u32 cap, large_cap; u32 hc[6]; /* large leaves, units, units per size class */ };
+struct UnitTables { u32* unit_rng; u32* cls_list; u32* large; u32 cap, large_cap; u32 hc[6]; /* large leaves, units, units per size class */ int wide_classes = 0; /* size classes of wsort.hip */ };
 u32* ss_first_segment(Ctx& c, size_t n);                                           // seg_start[2] = { 0, n } on the device
 void ss_level_tables(Ctx& c, const u32* seg_start, u32 nseg, size_t n, u32 D, SegTables& T);      // row-block tables + count arrays (arena)
 void ss_level_offsets(Ctx& c, const SegTables& T, const u32* seg_start, u32 nseg, u32 D, u32* nstart, size_t n);   // counts -> offsets, next segment starts

@@ -990,13 +990,15 @@ __global__ __launch_bounds__(LS_NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4
 }
 
 // units by size class (rows per wave of the composite kernel): class c = units of (2048 c, 2048 (c + 1)] pairs
+// wide = 1 (wsort.hip): the size classes of its leaf kernels -- <= 2048, <= 3072, <= 4096, <= 8192 records (a unit of 2 600 records in
+// a 4 096-slot workgroup runs a quarter of its rows empty)
 __global__ void ss_unit_class_kernel(const u32* __restrict__ unit_rng, const u32* __restrict__ d_nunits, u32* __restrict__ cls_count,
-                                     u32* __restrict__ cls_list, u32 cap) {
+                                     u32* __restrict__ cls_list, u32 cap, int wide = 0) {
     const u32 u = blockIdx.x * blockDim.x + threadIdx.x;
     u32 c = 4;
     if (u < *d_nunits) {
         const u32 m = unit_rng[2 * u + 1] - unit_rng[2 * u];
-        if (m > 1 && m <= SS_UNIT_MAX) c = (m - 1) / 2048;
+        if (m > 1 && m <= SS_UNIT_MAX) c = wide ? (m <= 2048u ? 0u : (m <= 3072u ? 1u : (m <= 4096u ? 2u : 3u))) : (m - 1) / 2048;
     }
     const int lane = lane_id();
 #pragma unroll
@@ -1269,7 +1271,7 @@ void ss_build_units(Ctx& c, const u32* leaf_start, u32 nleaf, UnitTables& U, u32
     exclusive_sum_u32(c, flag, flag, nleaf, U.large + 1);
     ss_unit_fill_kernel<<<cdiv(nleaf, 256), 256, 0, s>>>(leaf_start, nleaf, flag, U.unit_rng, small);
     LAUNCH_CHECK();
-    ss_unit_class_kernel<<<cdiv((size_t)nleaf + 1, 256), 256, 0, s>>>(U.unit_rng, U.large + 1, U.large + 2, U.cls_list, nleaf + 1);
+    ss_unit_class_kernel<<<cdiv((size_t)nleaf + 1, 256), 256, 0, s>>>(U.unit_rng, U.large + 1, U.large + 2, U.cls_list, nleaf + 1, U.wide_classes);
     LAUNCH_CHECK();
     c.read_n(U.large, U.hc, 6);
 }

@@ -919,7 +919,7 @@ __global__ __launch_bounds__(256) void ws_emit_compact_kernel(const u32* __restr
             const u32 m = (braw & 0x7FFFFFFFu) - a;
             if (m > 0) {
                 if ((braw >> 31) && m <= WS_WAVE_MAX) code = m <= 32 ? 1u : (m <= 64 ? 2u : (m <= 256 ? 3u : 4u));
-                else code = 5u + (m - 1) / 2048;
+                else code = 5u + (m <= 2048u ? 0u : (m <= 3072u ? 1u : (m <= 4096u ? 2u : 3u)));
             }
         }
         codes[q >> 3] |= code << (4 * (q & 7));
@@ -1383,6 +1383,7 @@ int ws_sort_impl(Ctx& c, const WKeyGen* gen, u64* K1[2], u64* K2[2], u32* V[2], 
 
     // ---- units + leaf sort ----
     UnitTables U;
+    U.wide_classes = 1;                                        // classes of <= 2048 / 3072 / 4096 / 8192 records
     ss_build_units(c, leaf_start, nleaf, U, (u32)c.wsort_pack);   // small units: the 12- and 16-row leaf kernels run out of registers
     const u32 nlarge = U.hc[0];
     st->units = U.hc[1]; st->large_leaves = nlarge;
@@ -1436,8 +1437,8 @@ int ws_sort_impl(Ctx& c, const WKeyGen* gen, u64* K1[2], u64* K2[2], u32* V[2], 
                 // (units of <= 2048 records: four waves of eight rows -- a smaller workgroup, more units in flight per CU; the kernel
                 //  is bound by its chain of dependent steps, not by throughput)
                 if (q == 0) ws_leaf_sort_kernel<KW, 8, 4, PAIRS><<<cnt, 4 * 64, 0, s>>>(A, lst, cnt, Q, EA);
-                else if (q == 1) ws_leaf_sort_kernel<KW, 8, 8, PAIRS><<<cnt, 8 * 64, 0, s>>>(A, lst, cnt, Q, EA);
-                else if (q == 2) ws_leaf_sort_kernel<KW, 12, 8, PAIRS><<<cnt, 8 * 64, 0, s>>>(A, lst, cnt, Q, EA);
+                else if (q == 1) ws_leaf_sort_kernel<KW, 6, 8, PAIRS><<<cnt, 8 * 64, 0, s>>>(A, lst, cnt, Q, EA);
+                else if (q == 2) ws_leaf_sort_kernel<KW, 8, 8, PAIRS><<<cnt, 8 * 64, 0, s>>>(A, lst, cnt, Q, EA);
                 else ws_leaf_sort_kernel<KW, 16, 8, PAIRS><<<cnt, 8 * 64, 0, s>>>(A, lst, cnt, Q, EA);
                 LAUNCH_CHECK();
             }
@@ -1449,8 +1450,8 @@ int ws_sort_impl(Ctx& c, const WKeyGen* gen, u64* K1[2], u64* K2[2], u32* V[2], 
             auto count_pass = [&](int q, const u32* lst, u32 cnt, u32 mask, u32 val, const WCount& R, const WEmit& Em) {
                 if (!cnt) return;
                 if (q == 0) ws_leaf_count_kernel<8, 4, PAIRS><<<cnt, 4 * 64, 0, s>>>(A, lst, cnt, mask, val, R, Em);
-                else if (q == 1) ws_leaf_count_kernel<8, 8, PAIRS><<<cnt, 8 * 64, 0, s>>>(A, lst, cnt, mask, val, R, Em);
-                else if (q == 2) ws_leaf_count_kernel<12, 8, PAIRS><<<cnt, 8 * 64, 0, s>>>(A, lst, cnt, mask, val, R, Em);
+                else if (q == 1) ws_leaf_count_kernel<6, 8, PAIRS><<<cnt, 8 * 64, 0, s>>>(A, lst, cnt, mask, val, R, Em);
+                else if (q == 2) ws_leaf_count_kernel<8, 8, PAIRS><<<cnt, 8 * 64, 0, s>>>(A, lst, cnt, mask, val, R, Em);
                 else ws_leaf_count_kernel<16, 8, PAIRS><<<cnt, 8 * 64, 0, s>>>(A, lst, cnt, mask, val, R, Em);
                 LAUNCH_CHECK();
             };
