@@ -37,7 +37,10 @@ void msd_partition_pairs_u32(Ctx& c, const u32* idx, const u32* val, size_t m, i
 
 // ---- internals of the splitter sort shared between ssort.hip and wsort.hip ------------------------------------------------------
 struct SegTables { u32* blk_start; u32* blk_seg; u32* counts; u32* bs; u32 R, blocks_ub, rows; };
-struct UnitTables { u32* unit_rng; u32* cls_list; u32* large; u32 cap, large_cap; u32 hc[6]; /* large leaves, units, units per size class */ int wide_classes = 0; /* size classes of wsort.hip */ };
+struct UnitTables { u32* unit_rng; u32* cls_list; u32* large; u32 cap, large_cap; u32 hc[6]; /* large leaves, units, units per size class */ int wide_classes = 0; /* size classes of wsort.hip */ u32 whc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; /* units per wide class */ };
+// size classes of the leaf kernels of wsort.hip (records): the kernel of a class has just enough rows
+constexpr int WIDE_NCLS = 6;
+__host__ __device__ inline u32 wide_class(u32 m) { return m <= 1536u ? 0u : (m <= 2048u ? 1u : (m <= 2560u ? 2u : (m <= 3072u ? 3u : (m <= 4096u ? 4u : 5u)))); }
 u32* ss_first_segment(Ctx& c, size_t n);                                           // seg_start[2] = { 0, n } on the device
 void ss_level_tables(Ctx& c, const u32* seg_start, u32 nseg, size_t n, u32 D, SegTables& T);      // row-block tables + count arrays (arena)
 void ss_level_offsets(Ctx& c, const SegTables& T, const u32* seg_start, u32 nseg, u32 D, u32* nstart, size_t n);   // counts -> offsets, next segment starts

@@ -990,19 +990,19 @@ __global__ __launch_bounds__(LS_NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4
 }
 
 // units by size class (rows per wave of the composite kernel): class c = units of (2048 c, 2048 (c + 1)] pairs
-// wide = 1 (wsort.hip): the size classes of its leaf kernels -- <= 2048, <= 3072, <= 4096, <= 8192 records (a unit of 2 600 records in
-// a 4 096-slot workgroup runs a quarter of its rows empty)
+// wide = 1 (wsort.hip): the six size classes of its leaf kernels (prim.hpp wide_class: a unit of 2 600 records in a 4 096-slot
+// workgroup runs a quarter of its rows empty)
 __global__ void ss_unit_class_kernel(const u32* __restrict__ unit_rng, const u32* __restrict__ d_nunits, u32* __restrict__ cls_count,
                                      u32* __restrict__ cls_list, u32 cap, int wide = 0) {
     const u32 u = blockIdx.x * blockDim.x + threadIdx.x;
-    u32 c = 4;
+    u32 c = wide ? 8u : 4u;                                      // (no unit)
     if (u < *d_nunits) {
         const u32 m = unit_rng[2 * u + 1] - unit_rng[2 * u];
-        if (m > 1 && m <= SS_UNIT_MAX) c = wide ? (m <= 2048u ? 0u : (m <= 3072u ? 1u : (m <= 4096u ? 2u : 3u))) : (m - 1) / 2048;
+        if (m > 1 && m <= SS_UNIT_MAX) c = wide ? wide_class(m) : (m - 1) / 2048;
     }
     const int lane = lane_id();
 #pragma unroll
-    for (u32 q = 0; q < 4; ++q) {                               // one atomic per wave and class
+    for (u32 q = 0; q < (wide ? (u32)WIDE_NCLS : 4u); ++q) {     // one atomic per wave and class
         const u64 mask = __ballot(c == q);
         if (!mask) continue;
         u32 basei = 0;
@@ -1263,7 +1263,9 @@ void ss_build_units(Ctx& c, const u32* leaf_start, u32 nleaf, UnitTables& U, u32
     u32* flag = c.arena.get<u32>((size_t)nleaf + 1);
     U.unit_rng = c.arena.get<u32>(2 * ((size_t)nleaf + 1));
     U.large = c.arena.get<u32>(LARGE_CAP + 6);
-    U.cls_list = c.arena.get<u32>(4 * ((size_t)nleaf + 1));
+    U.cls_list = c.arena.get<u32>((U.wide_classes ? (size_t)WIDE_NCLS : 4) * ((size_t)nleaf + 1));
+    u32* wcnt = U.wide_classes ? c.arena.get<u32>(8) : nullptr;
+    if (wcnt) HIP_TRY(hipMemsetAsync(wcnt, 0, 8 * sizeof(u32), s));
     U.cap = nleaf + 1;
     HIP_TRY(hipMemsetAsync(U.large, 0, 6 * sizeof(u32), s));
     ss_unit_flag_kernel<<<cdiv(nleaf, 256), 256, 0, s>>>(leaf_start, nleaf, flag, U.large + 6, U.large, LARGE_CAP, small);
@@ -1271,9 +1273,10 @@ void ss_build_units(Ctx& c, const u32* leaf_start, u32 nleaf, UnitTables& U, u32
     exclusive_sum_u32(c, flag, flag, nleaf, U.large + 1);
     ss_unit_fill_kernel<<<cdiv(nleaf, 256), 256, 0, s>>>(leaf_start, nleaf, flag, U.unit_rng, small);
     LAUNCH_CHECK();
-    ss_unit_class_kernel<<<cdiv((size_t)nleaf + 1, 256), 256, 0, s>>>(U.unit_rng, U.large + 1, U.large + 2, U.cls_list, nleaf + 1, U.wide_classes);
+    ss_unit_class_kernel<<<cdiv((size_t)nleaf + 1, 256), 256, 0, s>>>(U.unit_rng, U.large + 1, wcnt ? wcnt : U.large + 2, U.cls_list, nleaf + 1, U.wide_classes);
     LAUNCH_CHECK();
     c.read_n(U.large, U.hc, 6);
+    if (wcnt) c.read_n(wcnt, U.whc, 8);
 }
 void ss_fanouts(Ctx& c, size_t n, int& L, u32 F[3], u32& os, u32 leaf3, int wide2) {
     L = n <= (size_t)256 * 3072 ? 1 : ((n + 65535) / 65536 <= 4352 ? 2 : 3);

@@ -903,7 +903,7 @@ __global__ __launch_bounds__(NW * 64) void ws_leaf_count_kernel(WLeaf A, const u
 // the runs handed on by the counting kernel, listed by class.  Runs whose records tie on all of k1 ("pure"): 0 = <= 32 records and
 // 1 = <= 64 (lane kernel), 2 = <= 256 and 3 = <= 1024 (wave kernel); everything else: 4 .. 7 = kernel A by size
 constexpr u32 EC_TILE = 256 * 32;
-constexpr int EC_NCLS = 8;
+constexpr int EC_NCLS = 4 + WIDE_NCLS;
 __global__ __launch_bounds__(256) void ws_emit_compact_kernel(const u32* __restrict__ rng, u32 nent, u32* __restrict__ lists, u32 cap, u32* __restrict__ counters) {
     __shared__ u32 cnt[EC_NCLS], base[EC_NCLS];
     if (threadIdx.x < EC_NCLS) cnt[threadIdx.x] = 0;
@@ -919,7 +919,7 @@ __global__ __launch_bounds__(256) void ws_emit_compact_kernel(const u32* __restr
             const u32 m = (braw & 0x7FFFFFFFu) - a;
             if (m > 0) {
                 if ((braw >> 31) && m <= WS_WAVE_MAX) code = m <= 32 ? 1u : (m <= 64 ? 2u : (m <= 256 ? 3u : 4u));
-                else code = 5u + (m <= 2048u ? 0u : (m <= 3072u ? 1u : (m <= 4096u ? 2u : 3u)));
+                else code = 5u + wide_class(m);
             }
         }
         codes[q >> 3] |= code << (4 * (q & 7));
@@ -1383,7 +1383,7 @@ int ws_sort_impl(Ctx& c, const WKeyGen* gen, u64* K1[2], u64* K2[2], u32* V[2], 
 
     // ---- units + leaf sort ----
     UnitTables U;
-    U.wide_classes = 1;                                        // classes of <= 2048 / 3072 / 4096 / 8192 records
+    U.wide_classes = 1;                                        // the six size classes of prim.hpp wide_class
     ss_build_units(c, leaf_start, nleaf, U, (u32)c.wsort_pack);   // small units: the 12- and 16-row leaf kernels run out of registers
     const u32 nlarge = U.hc[0];
     st->units = U.hc[1]; st->large_leaves = nlarge;
@@ -1397,14 +1397,16 @@ int ws_sort_impl(Ctx& c, const WKeyGen* gen, u64* K1[2], u64* K2[2], u32* V[2], 
         const u32* cur_rng = U.unit_rng;
         const u32* cur_cls = U.cls_list;
         size_t cur_cap = U.cap;
-        u32 cur_cnt[4] = { U.hc[2], U.hc[3], U.hc[4], U.hc[5] };
+        constexpr int NB = WIDE_NCLS;
+        u32 cur_cnt[NB];
+        for (int q = 0; q < NB; ++q) cur_cnt[q] = U.whc[q];
         u32 wave_cnt[4] = { 0, 0, 0, 0 };                        // runs for the lane / wave kernels (classes 0 .. 3 of the previous stage's hand-over)
         const u32* wave_list = nullptr;
         const u32 ediv = A.cmax + 1;                            // a run that is handed on has more than cmax members
         const u32 ecap2 = (u32)(n / ediv + 2);
         u32* e_rng[2] = { c.arena.get<u32>(2 * (size_t)ecap2), c.arena.get<u32>(2 * (size_t)ecap2) };
         u32* e_cls[2] = { c.arena.get<u32>(EC_NCLS * (size_t)ecap2), c.arena.get<u32>(EC_NCLS * (size_t)ecap2) };
-        u32* lc = c.arena.get<u32>(16);                          // [0..7]: per class |rlist|, |tlist|; [8..15]: next stage's units per class
+        u32* lc = c.arena.get<u32>(32);                          // [0 .. 2 NB): per class |rlist|, |tlist|; [2 NB ..): next stage's runs / units per class
         for (int stage = 0; stage < 8; ++stage) {
             if (wave_cnt[0] | wave_cnt[1] | wave_cnt[2] | wave_cnt[3]) {
                 Ctx::ProfScope prof(c, K_WS_RUN, 0);
@@ -1417,45 +1419,49 @@ int ws_sort_impl(Ctx& c, const WKeyGen* gen, u64* K1[2], u64* K2[2], u32* V[2], 
                 st->wave_runs += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
                 wave_cnt[0] = wave_cnt[1] = wave_cnt[2] = wave_cnt[3] = 0;
             }
-            if (!(cur_cnt[0] | cur_cnt[1] | cur_cnt[2] | cur_cnt[3])) break;
+            { u32 any = 0; for (int q = 0; q < NB; ++q) any |= cur_cnt[q]; if (!any) break; }
             if (stage == 7) throw HipError{hipErrorUnknown, "wide splitter sort: leaf stages did not converge", (int)__LINE__};
             const size_t lm3 = c.arena.mark();
-            u32* rl = c.arena.get<u32>(4 * cur_cap);
-            u32* tl = c.arena.get<u32>(4 * cur_cap);
-            HIP_TRY(hipMemsetAsync(lc, 0, 16 * sizeof(u32), s));
+            u32* rl = c.arena.get<u32>(NB * cur_cap);
+            u32* tl = c.arena.get<u32>(NB * cur_cap);
+            HIP_TRY(hipMemsetAsync(lc, 0, 32 * sizeof(u32), s));
             A.unit_rng = cur_rng;
             // (stage 0 sorts every record once: keys + position in, position + flag + LCP out; the later stages re-sort the long runs)
             HIP_TRY(hipMemsetAsync(e_rng[stage & 1], 0, 2 * (size_t)ecap2 * sizeof(u32), s));
             const WEmit E = { e_rng[stage & 1], ediv };
             const WEmit EA = { c.wsort_fuse ? E.rng : nullptr, ediv };   // kernel A orders the short runs of its units itself
             const int pa = c.prof_begin(K_WS_LEAF_SORT, stage == 0 ? (u64)n * (4 + 8 * KW + 6) : 0);
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < NB; ++q) {
                 const u32 cnt = cur_cnt[q];
                 if (!cnt) continue;
                 const WLists Q = { rl + q * cur_cap, tl + q * cur_cap, lc + 2 * q };
                 const u32* lst = cur_cls + q * cur_cap;
-                // (units of <= 2048 records: four waves of eight rows -- a smaller workgroup, more units in flight per CU; the kernel
-                //  is bound by its chain of dependent steps, not by throughput)
-                if (q == 0) ws_leaf_sort_kernel<KW, 8, 4, PAIRS><<<cnt, 4 * 64, 0, s>>>(A, lst, cnt, Q, EA);
-                else if (q == 1) ws_leaf_sort_kernel<KW, 6, 8, PAIRS><<<cnt, 8 * 64, 0, s>>>(A, lst, cnt, Q, EA);
-                else if (q == 2) ws_leaf_sort_kernel<KW, 8, 8, PAIRS><<<cnt, 8 * 64, 0, s>>>(A, lst, cnt, Q, EA);
+                // (units of <= 2048 records: four waves -- a smaller workgroup, more units in flight per CU; every class has just the rows
+                //  its units need: 1 536 = 6 x 4 waves, 2 048 = 8 x 4, 2 560 = 5 x 8, 3 072 = 6 x 8, 4 096 = 8 x 8, 8 192 = 16 x 8)
+                if (q == 0) ws_leaf_sort_kernel<KW, 6, 4, PAIRS><<<cnt, 4 * 64, 0, s>>>(A, lst, cnt, Q, EA);
+                else if (q == 1) ws_leaf_sort_kernel<KW, 8, 4, PAIRS><<<cnt, 4 * 64, 0, s>>>(A, lst, cnt, Q, EA);
+                else if (q == 2) ws_leaf_sort_kernel<KW, 5, 8, PAIRS><<<cnt, 8 * 64, 0, s>>>(A, lst, cnt, Q, EA);
+                else if (q == 3) ws_leaf_sort_kernel<KW, 6, 8, PAIRS><<<cnt, 8 * 64, 0, s>>>(A, lst, cnt, Q, EA);
+                else if (q == 4) ws_leaf_sort_kernel<KW, 8, 8, PAIRS><<<cnt, 8 * 64, 0, s>>>(A, lst, cnt, Q, EA);
                 else ws_leaf_sort_kernel<KW, 16, 8, PAIRS><<<cnt, 8 * 64, 0, s>>>(A, lst, cnt, Q, EA);
                 LAUNCH_CHECK();
             }
             c.prof_end(pa);
-            u32 hl[8];
-            c.read_n(lc, hl, 8);
+            u32 hl[2 * NB];
+            c.read_n(lc, hl, 2 * NB);
             const int pb = c.prof_begin(K_WS_LEAF_COUNT, stage == 0 ? (u64)n * (8 + 4 + 1 + 4 + 2) : 0);
             const WEmit noE = { nullptr, 1 };
             auto count_pass = [&](int q, const u32* lst, u32 cnt, u32 mask, u32 val, const WCount& R, const WEmit& Em) {
                 if (!cnt) return;
-                if (q == 0) ws_leaf_count_kernel<8, 4, PAIRS><<<cnt, 4 * 64, 0, s>>>(A, lst, cnt, mask, val, R, Em);
-                else if (q == 1) ws_leaf_count_kernel<6, 8, PAIRS><<<cnt, 8 * 64, 0, s>>>(A, lst, cnt, mask, val, R, Em);
-                else if (q == 2) ws_leaf_count_kernel<8, 8, PAIRS><<<cnt, 8 * 64, 0, s>>>(A, lst, cnt, mask, val, R, Em);
+                if (q == 0) ws_leaf_count_kernel<6, 4, PAIRS><<<cnt, 4 * 64, 0, s>>>(A, lst, cnt, mask, val, R, Em);
+                else if (q == 1) ws_leaf_count_kernel<8, 4, PAIRS><<<cnt, 4 * 64, 0, s>>>(A, lst, cnt, mask, val, R, Em);
+                else if (q == 2) ws_leaf_count_kernel<5, 8, PAIRS><<<cnt, 8 * 64, 0, s>>>(A, lst, cnt, mask, val, R, Em);
+                else if (q == 3) ws_leaf_count_kernel<6, 8, PAIRS><<<cnt, 8 * 64, 0, s>>>(A, lst, cnt, mask, val, R, Em);
+                else if (q == 4) ws_leaf_count_kernel<8, 8, PAIRS><<<cnt, 8 * 64, 0, s>>>(A, lst, cnt, mask, val, R, Em);
                 else ws_leaf_count_kernel<16, 8, PAIRS><<<cnt, 8 * 64, 0, s>>>(A, lst, cnt, mask, val, R, Em);
                 LAUNCH_CHECK();
             };
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < NB; ++q) {
                 const u32 nt = hl[2 * q + 1], nr = hl[2 * q];
                 if (nt) {                                        // ties on a truncated word: by the word itself ...
                     st->trunc_units += nt;
@@ -1474,18 +1480,25 @@ int ws_sort_impl(Ctx& c, const WKeyGen* gen, u64* K1[2], u64* K2[2], u32* V[2], 
                 }
             }
             c.prof_end(pb);
-            ws_emit_compact_kernel<<<cdiv(ecap2, EC_TILE), 256, 0, s>>>(e_rng[stage & 1], ecap2, e_cls[stage & 1], ecap2, lc + 8);
+            ws_emit_compact_kernel<<<cdiv(ecap2, EC_TILE), 256, 0, s>>>(e_rng[stage & 1], ecap2, e_cls[stage & 1], ecap2, lc + 2 * NB);
             LAUNCH_CHECK();
             u32 he[EC_NCLS];
-            c.read_n(lc + 8, he, EC_NCLS);
-            if (getenv("TDC_GPU_WSORT_LOG"))
-                fprintf(stderr, "[wsort] n=%zu stage %d: units %u %u %u %u | r/t lists %u/%u %u/%u %u/%u %u/%u | handed on: lane %u %u wave %u %u block %u %u %u %u\n", n, stage,
-                        cur_cnt[0], cur_cnt[1], cur_cnt[2], cur_cnt[3], hl[0], hl[1], hl[2], hl[3], hl[4], hl[5], hl[6], hl[7], he[0], he[1], he[2], he[3], he[4], he[5], he[6], he[7]);
+            c.read_n(lc + 2 * NB, he, EC_NCLS);
+            if (getenv("TDC_GPU_WSORT_LOG")) {
+                fprintf(stderr, "[wsort] n=%zu stage %d: units", n, stage);
+                for (int q = 0; q < NB; ++q) fprintf(stderr, " %u", cur_cnt[q]);
+                fprintf(stderr, " | r/t lists");
+                for (int q = 0; q < NB; ++q) fprintf(stderr, " %u/%u", hl[2 * q], hl[2 * q + 1]);
+                fprintf(stderr, " | handed on: lane %u %u wave %u %u block", he[0], he[1], he[2], he[3]);
+                for (int q = 0; q < NB; ++q) fprintf(stderr, " %u", he[4 + q]);
+                fprintf(stderr, "\n");
+            }
             c.arena.release(lm3);
             for (int q = 0; q < EC_NCLS; ++q) st->longrun_units += he[q];
             cur_rng = e_rng[stage & 1]; cur_cls = e_cls[stage & 1] + 4 * (size_t)ecap2; cur_cap = ecap2;
             wave_list = e_cls[stage & 1];
-            for (int q = 0; q < 4; ++q) { wave_cnt[q] = he[q]; cur_cnt[q] = he[4 + q]; }
+            for (int q = 0; q < 4; ++q) wave_cnt[q] = he[q];
+            for (int q = 0; q < NB; ++q) cur_cnt[q] = he[4 + q];
             st->leaf_stages = (u32)stage + 1;
         }
     }
