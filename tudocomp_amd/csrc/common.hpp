@@ -157,7 +157,7 @@ struct Ctx {
     int wsort_two = 0;             // wide sort of more than 285 M records: two partition levels of up to 1024 buckets instead of three of up to 256 (env TDC_GPU_WSORT_TWO)
     int wsort_leaf = 2048;         // leaf size the three-level wide sort aims at (env TDC_GPU_WSORT_LEAF: 1024 | 2048)
     int wsort_pack = 2048;         // leaf sort: leaves up to this size are packed into units of at most twice that (env TDC_GPU_WSORT_PACK: 1024 | 2048 | 4096)
-    int wsort_order = 0;           // wide sort with three levels: 1 = the widest level (256 buckets) first, where it runs behind the upload (env TDC_GPU_WSORT_ORDER)
+    int wsort_order = 1;           // wide sort with three levels: 1 = the widest level (256 buckets) first, where it runs behind the upload (env TDC_GPU_WSORT_ORDER)
     int wsort_fuse = 1;            // leaf sort: kernel A orders the short runs of its units itself instead of listing the unit for the counting kernel (env TDC_GPU_WSORT_FUSE)
     int wsort_small = 0;           // tests: 1 = every run of a leaf unit counts as "big" (the chunk iterations run everywhere) (env TDC_GPU_WSORT_SMALLRUN)
     int msd_partition = 1;         // bucketed scatter: MSD partition with atomic slots instead of two stable LSD passes (env TDC_GPU_MSD_PARTITION=0)

@@ -37,10 +37,15 @@ void msd_partition_pairs_u32(Ctx& c, const u32* idx, const u32* val, size_t m, i
 
 // ---- internals of the splitter sort shared between ssort.hip and wsort.hip ------------------------------------------------------
 struct SegTables { u32* blk_start; u32* blk_seg; u32* counts; u32* bs; u32 R, blocks_ub, rows; };
-struct UnitTables { u32* unit_rng; u32* cls_list; u32* large; u32 cap, large_cap; u32 hc[6]; /* large leaves, units, units per size class */ int wide_classes = 0; /* size classes of wsort.hip */ u32 whc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; /* units per wide class */ };
+struct UnitTables { u32* unit_rng; u32* cls_list; u32* large; u32 cap, large_cap; u32 hc[6]; /* large leaves, units, units per size class */ int wide_classes = 0; /* size classes of wsort.hip */ u32 whc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; /* units per wide class */ };
 // size classes of the leaf kernels of wsort.hip (records): the kernel of a class has just enough rows
-constexpr int WIDE_NCLS = 6;
-__host__ __device__ inline u32 wide_class(u32 m) { return m <= 1536u ? 0u : (m <= 2048u ? 1u : (m <= 2560u ? 2u : (m <= 3072u ? 3u : (m <= 4096u ? 4u : 5u)))); }
+constexpr int WIDE_NCLS = 10;
+// classes 0 .. 4: 4 .. 8 rows of four waves (1 024 .. 2 048 records), 5 .. 8: 5 .. 8 rows of eight waves (2 560 .. 4 096), 9: 16 rows (8 192)
+__host__ __device__ inline u32 wide_class(u32 m) {
+    if (m <= 2048u) return m <= 1024u ? 0u : (m - 769u) / 256u;          // 1025..1280 -> 1, ..1536 -> 2, ..1792 -> 3, ..2048 -> 4
+    if (m <= 4096u) return 5u + (m <= 2560u ? 0u : (m - 2049u) / 512u);  // ..2560 -> 5, ..3072 -> 6, ..3584 -> 7, ..4096 -> 8
+    return 9u;
+}
 u32* ss_first_segment(Ctx& c, size_t n);                                           // seg_start[2] = { 0, n } on the device
 void ss_level_tables(Ctx& c, const u32* seg_start, u32 nseg, size_t n, u32 D, SegTables& T);      // row-block tables + count arrays (arena)
 void ss_level_offsets(Ctx& c, const SegTables& T, const u32* seg_start, u32 nseg, u32 D, u32* nstart, size_t n);   // counts -> offsets, next segment starts

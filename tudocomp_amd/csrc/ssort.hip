@@ -995,7 +995,7 @@ __global__ __launch_bounds__(LS_NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4
 __global__ void ss_unit_class_kernel(const u32* __restrict__ unit_rng, const u32* __restrict__ d_nunits, u32* __restrict__ cls_count,
                                      u32* __restrict__ cls_list, u32 cap, int wide = 0) {
     const u32 u = blockIdx.x * blockDim.x + threadIdx.x;
-    u32 c = wide ? 8u : 4u;                                      // (no unit)
+    u32 c = wide ? 15u : 4u;                                     // (no unit)
     if (u < *d_nunits) {
         const u32 m = unit_rng[2 * u + 1] - unit_rng[2 * u];
         if (m > 1 && m <= SS_UNIT_MAX) c = wide ? wide_class(m) : (m - 1) / 2048;
@@ -1264,8 +1264,8 @@ void ss_build_units(Ctx& c, const u32* leaf_start, u32 nleaf, UnitTables& U, u32
     U.unit_rng = c.arena.get<u32>(2 * ((size_t)nleaf + 1));
     U.large = c.arena.get<u32>(LARGE_CAP + 6);
     U.cls_list = c.arena.get<u32>((U.wide_classes ? (size_t)WIDE_NCLS : 4) * ((size_t)nleaf + 1));
-    u32* wcnt = U.wide_classes ? c.arena.get<u32>(8) : nullptr;
-    if (wcnt) HIP_TRY(hipMemsetAsync(wcnt, 0, 8 * sizeof(u32), s));
+    u32* wcnt = U.wide_classes ? c.arena.get<u32>(16) : nullptr;
+    if (wcnt) HIP_TRY(hipMemsetAsync(wcnt, 0, 16 * sizeof(u32), s));
     U.cap = nleaf + 1;
     HIP_TRY(hipMemsetAsync(U.large, 0, 6 * sizeof(u32), s));
     ss_unit_flag_kernel<<<cdiv(nleaf, 256), 256, 0, s>>>(leaf_start, nleaf, flag, U.large + 6, U.large, LARGE_CAP, small);
@@ -1276,7 +1276,7 @@ void ss_build_units(Ctx& c, const u32* leaf_start, u32 nleaf, UnitTables& U, u32
     ss_unit_class_kernel<<<cdiv((size_t)nleaf + 1, 256), 256, 0, s>>>(U.unit_rng, U.large + 1, wcnt ? wcnt : U.large + 2, U.cls_list, nleaf + 1, U.wide_classes);
     LAUNCH_CHECK();
     c.read_n(U.large, U.hc, 6);
-    if (wcnt) c.read_n(wcnt, U.whc, 8);
+    if (wcnt) c.read_n(wcnt, U.whc, 16);
 }
 void ss_fanouts(Ctx& c, size_t n, int& L, u32 F[3], u32& os, u32 leaf3, int wide2) {
     L = n <= (size_t)256 * 3072 ? 1 : ((n + 65535) / 65536 <= 4352 ? 2 : 3);

@@ -1406,7 +1406,7 @@ int ws_sort_impl(Ctx& c, const WKeyGen* gen, u64* K1[2], u64* K2[2], u32* V[2], 
         const u32 ecap2 = (u32)(n / ediv + 2);
         u32* e_rng[2] = { c.arena.get<u32>(2 * (size_t)ecap2), c.arena.get<u32>(2 * (size_t)ecap2) };
         u32* e_cls[2] = { c.arena.get<u32>(EC_NCLS * (size_t)ecap2), c.arena.get<u32>(EC_NCLS * (size_t)ecap2) };
-        u32* lc = c.arena.get<u32>(32);                          // [0 .. 2 NB): per class |rlist|, |tlist|; [2 NB ..): next stage's runs / units per class
+        u32* lc = c.arena.get<u32>(64);                          // [0 .. 2 NB): per class |rlist|, |tlist|; [2 NB ..): next stage's runs / units per class
         for (int stage = 0; stage < 8; ++stage) {
             if (wave_cnt[0] | wave_cnt[1] | wave_cnt[2] | wave_cnt[3]) {
                 Ctx::ProfScope prof(c, K_WS_RUN, 0);
@@ -1424,7 +1424,7 @@ int ws_sort_impl(Ctx& c, const WKeyGen* gen, u64* K1[2], u64* K2[2], u32* V[2], 
             const size_t lm3 = c.arena.mark();
             u32* rl = c.arena.get<u32>(NB * cur_cap);
             u32* tl = c.arena.get<u32>(NB * cur_cap);
-            HIP_TRY(hipMemsetAsync(lc, 0, 32 * sizeof(u32), s));
+            HIP_TRY(hipMemsetAsync(lc, 0, 64 * sizeof(u32), s));
             A.unit_rng = cur_rng;
             // (stage 0 sorts every record once: keys + position in, position + flag + LCP out; the later stages re-sort the long runs)
             HIP_TRY(hipMemsetAsync(e_rng[stage & 1], 0, 2 * (size_t)ecap2 * sizeof(u32), s));
@@ -1437,13 +1437,19 @@ int ws_sort_impl(Ctx& c, const WKeyGen* gen, u64* K1[2], u64* K2[2], u32* V[2], 
                 const WLists Q = { rl + q * cur_cap, tl + q * cur_cap, lc + 2 * q };
                 const u32* lst = cur_cls + q * cur_cap;
                 // (units of <= 2048 records: four waves -- a smaller workgroup, more units in flight per CU; every class has just the rows
-                //  its units need: 1 536 = 6 x 4 waves, 2 048 = 8 x 4, 2 560 = 5 x 8, 3 072 = 6 x 8, 4 096 = 8 x 8, 8 192 = 16 x 8)
-                if (q == 0) ws_leaf_sort_kernel<KW, 6, 4, PAIRS><<<cnt, 4 * 64, 0, s>>>(A, lst, cnt, Q, EA);
-                else if (q == 1) ws_leaf_sort_kernel<KW, 8, 4, PAIRS><<<cnt, 4 * 64, 0, s>>>(A, lst, cnt, Q, EA);
-                else if (q == 2) ws_leaf_sort_kernel<KW, 5, 8, PAIRS><<<cnt, 8 * 64, 0, s>>>(A, lst, cnt, Q, EA);
-                else if (q == 3) ws_leaf_sort_kernel<KW, 6, 8, PAIRS><<<cnt, 8 * 64, 0, s>>>(A, lst, cnt, Q, EA);
-                else if (q == 4) ws_leaf_sort_kernel<KW, 8, 8, PAIRS><<<cnt, 8 * 64, 0, s>>>(A, lst, cnt, Q, EA);
-                else ws_leaf_sort_kernel<KW, 16, 8, PAIRS><<<cnt, 8 * 64, 0, s>>>(A, lst, cnt, Q, EA);
+                //  its units need: prim.hpp wide_class -- 4 .. 8 rows of four waves, 5 .. 8 rows of eight, 16 rows of eight)
+                switch (q) {
+                case 0: ws_leaf_sort_kernel<KW, 4, 4, PAIRS><<<cnt, 4 * 64, 0, s>>>(A, lst, cnt, Q, EA); break;
+                case 1: ws_leaf_sort_kernel<KW, 5, 4, PAIRS><<<cnt, 4 * 64, 0, s>>>(A, lst, cnt, Q, EA); break;
+                case 2: ws_leaf_sort_kernel<KW, 6, 4, PAIRS><<<cnt, 4 * 64, 0, s>>>(A, lst, cnt, Q, EA); break;
+                case 3: ws_leaf_sort_kernel<KW, 7, 4, PAIRS><<<cnt, 4 * 64, 0, s>>>(A, lst, cnt, Q, EA); break;
+                case 4: ws_leaf_sort_kernel<KW, 8, 4, PAIRS><<<cnt, 4 * 64, 0, s>>>(A, lst, cnt, Q, EA); break;
+                case 5: ws_leaf_sort_kernel<KW, 5, 8, PAIRS><<<cnt, 8 * 64, 0, s>>>(A, lst, cnt, Q, EA); break;
+                case 6: ws_leaf_sort_kernel<KW, 6, 8, PAIRS><<<cnt, 8 * 64, 0, s>>>(A, lst, cnt, Q, EA); break;
+                case 7: ws_leaf_sort_kernel<KW, 7, 8, PAIRS><<<cnt, 8 * 64, 0, s>>>(A, lst, cnt, Q, EA); break;
+                case 8: ws_leaf_sort_kernel<KW, 8, 8, PAIRS><<<cnt, 8 * 64, 0, s>>>(A, lst, cnt, Q, EA); break;
+                default: ws_leaf_sort_kernel<KW, 16, 8, PAIRS><<<cnt, 8 * 64, 0, s>>>(A, lst, cnt, Q, EA); break;
+                }
                 LAUNCH_CHECK();
             }
             c.prof_end(pa);
@@ -1453,12 +1459,18 @@ int ws_sort_impl(Ctx& c, const WKeyGen* gen, u64* K1[2], u64* K2[2], u32* V[2], 
             const WEmit noE = { nullptr, 1 };
             auto count_pass = [&](int q, const u32* lst, u32 cnt, u32 mask, u32 val, const WCount& R, const WEmit& Em) {
                 if (!cnt) return;
-                if (q == 0) ws_leaf_count_kernel<6, 4, PAIRS><<<cnt, 4 * 64, 0, s>>>(A, lst, cnt, mask, val, R, Em);
-                else if (q == 1) ws_leaf_count_kernel<8, 4, PAIRS><<<cnt, 4 * 64, 0, s>>>(A, lst, cnt, mask, val, R, Em);
-                else if (q == 2) ws_leaf_count_kernel<5, 8, PAIRS><<<cnt, 8 * 64, 0, s>>>(A, lst, cnt, mask, val, R, Em);
-                else if (q == 3) ws_leaf_count_kernel<6, 8, PAIRS><<<cnt, 8 * 64, 0, s>>>(A, lst, cnt, mask, val, R, Em);
-                else if (q == 4) ws_leaf_count_kernel<8, 8, PAIRS><<<cnt, 8 * 64, 0, s>>>(A, lst, cnt, mask, val, R, Em);
-                else ws_leaf_count_kernel<16, 8, PAIRS><<<cnt, 8 * 64, 0, s>>>(A, lst, cnt, mask, val, R, Em);
+                switch (q) {
+                case 0: ws_leaf_count_kernel<4, 4, PAIRS><<<cnt, 4 * 64, 0, s>>>(A, lst, cnt, mask, val, R, Em); break;
+                case 1: ws_leaf_count_kernel<5, 4, PAIRS><<<cnt, 4 * 64, 0, s>>>(A, lst, cnt, mask, val, R, Em); break;
+                case 2: ws_leaf_count_kernel<6, 4, PAIRS><<<cnt, 4 * 64, 0, s>>>(A, lst, cnt, mask, val, R, Em); break;
+                case 3: ws_leaf_count_kernel<7, 4, PAIRS><<<cnt, 4 * 64, 0, s>>>(A, lst, cnt, mask, val, R, Em); break;
+                case 4: ws_leaf_count_kernel<8, 4, PAIRS><<<cnt, 4 * 64, 0, s>>>(A, lst, cnt, mask, val, R, Em); break;
+                case 5: ws_leaf_count_kernel<5, 8, PAIRS><<<cnt, 8 * 64, 0, s>>>(A, lst, cnt, mask, val, R, Em); break;
+                case 6: ws_leaf_count_kernel<6, 8, PAIRS><<<cnt, 8 * 64, 0, s>>>(A, lst, cnt, mask, val, R, Em); break;
+                case 7: ws_leaf_count_kernel<7, 8, PAIRS><<<cnt, 8 * 64, 0, s>>>(A, lst, cnt, mask, val, R, Em); break;
+                case 8: ws_leaf_count_kernel<8, 8, PAIRS><<<cnt, 8 * 64, 0, s>>>(A, lst, cnt, mask, val, R, Em); break;
+                default: ws_leaf_count_kernel<16, 8, PAIRS><<<cnt, 8 * 64, 0, s>>>(A, lst, cnt, mask, val, R, Em); break;
+                }
                 LAUNCH_CHECK();
             };
             for (int q = 0; q < NB; ++q) {
