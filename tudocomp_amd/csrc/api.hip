@@ -209,6 +209,8 @@ void run_factorize(Ctx& c, size_t n, DevArrays& A, u32 threshold, int flatten, t
     A.fs.owner = c.arena.get<u32>(n);
     A.fs.fsrc = c.arena.get<u32>(n);
     A.fs.fpos = c.arena.get<u32>(n);
+    A.fs.flenl = threshold >= 2 ? A.fs.fpos + (n + 1) / 2 : nullptr;    // (a factor covers >= threshold positions: at most n / 2 of them, the list of
+                                                                         //  their lengths fits the upper half of the position list)
     A.fs.cls = c.arena.get<u8>(n + 64);                  // class bytes for the encoder (filled by build_owner)
     FactorizeStats fz;
     FlattenStats fl;

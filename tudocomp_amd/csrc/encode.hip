@@ -454,7 +454,7 @@ struct EncPrelude { size_t z; u32 hist[256]; EncScalars sc; };
 static void encode_prelude(Ctx& c, const u8* text, size_t n, FactorSpace& fs, EncPrelude& pre) {
     hipStream_t s = c.stream;
     u32* fpos = fs.have_list ? fs.fpos : c.arena.get<u32>(n);
-    u32* flist = fs.have_list ? nullptr : c.arena.get<u32>(n);
+    u32* flist = fs.have_list ? fs.flenl : c.arena.get<u32>(n);        // (nullptr: the lengths are read at the factor starts)
     const size_t z = fs.have_list ? fs.nfact : extract_factors(c, n, fs, fpos, nullptr, flist, n);
     EncScalars* d_sc = (EncScalars*)c.arena.alloc(sizeof(EncScalars));
     EncScalars h_sc = { 0xFFFFFFFFu, 0u, 0u, 0u };          // LZSSFactors.hpp:33-38 : INDEX_MAX / 0

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(OW_T) void owner_count_kernel(const u32* __restrict
 
 __global__ __launch_bounds__(OW_T) void owner_build_kernel(const u32* __restrict__ flen, size_t n, const u32* __restrict__ tilebase,
                                                            u32* __restrict__ pos, u32* __restrict__ owner, uint2* __restrict__ cross,
-                                                           u8* __restrict__ cls) {
+                                                           u8* __restrict__ cls, u32* __restrict__ lenl) {
     __shared__ u32 s[OW_TILE + OW_TILE / 16 + 16];
     __shared__ u32 sm[OW_T / 64 + 1], smx[OW_T / 64];
     const size_t base = (size_t)blockIdx.x * OW_TILE;
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(OW_T) void owner_build_kernel(const u32* __restrict
         const u32 pl = l0 + k;
         if (f[k] != 0) {
             cur_start = pl + 1; cur_len = f[k]; cur_rank = rank++;
-            if (base + pl < n) pos[cur_rank] = (u32)(base + pl);
+            if (base + pl < n) { pos[cur_rank] = (u32)(base + pl); if (lenl) lenl[cur_rank] = f[k]; }
         }
         out[k] = (cur_start != 0 && pl - (cur_start - 1) < cur_len) ? cur_rank : NONE32;
     }
@@ -196,7 +196,7 @@ void build_owner(Ctx& c, size_t n, FactorSpace& fs) {
     exclusive_sum_u32(c, tilecnt, tilecnt, tiles, d_total);
     {
         Ctx::ProfScope prof(c, K_EXTRACT, (u64)n * 8);
-        owner_build_kernel<<<tiles, OW_T, 0, c.stream>>>(fs.flen, n, tilecnt, pos, fs.owner, cross, fs.cls);
+        owner_build_kernel<<<tiles, OW_T, 0, c.stream>>>(fs.flen, n, tilecnt, pos, fs.owner, cross, fs.cls, fs.fpos ? fs.flenl : nullptr);
         LAUNCH_CHECK();
         owner_cross_kernel<<<tiles, 256, 0, c.stream>>>(cross, n, fs.owner, fs.cls);
         fs.have_cls = fs.cls != nullptr;
@@ -248,11 +248,11 @@ struct FlattenScalars { u32 waiting; u32 num_flattened; u32 max_depth; u32 pad; 
 // rounds read and write their work lists sequentially (appended per wave, in any order -- the result of a factor does not
 // depend on the order in which the waiting ones are visited), nothing about a waiting factor is gathered again.
 __global__ void flatten_init_kernel(const u32* __restrict__ fpos, size_t z, const u32* __restrict__ flen, const u32* __restrict__ orig,
-                                    uint4* __restrict__ rec) {
+                                    uint4* __restrict__ rec, const u32* __restrict__ lenl) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= z) return;
     const u32 p = fpos[i];
-    rec[i] = make_uint4(p, flen[p], orig[p], NOT_DONE);
+    rec[i] = make_uint4(p, lenl ? lenl[i] : flen[p], orig[p], NOT_DONE);     // (lenl: the lengths in list order -- one scattered line less per factor)
 }
 
 // One round over the still-waiting factors.  FIRST: every factor, state taken from its record; else the items of `work`.
@@ -362,7 +362,7 @@ void flatten_factors(Ctx& c, size_t n, FactorSpace fs, FlattenStats* st) {
     FlattenScalars* d_sc = (FlattenScalars*)c.arena.alloc(sizeof(FlattenScalars));
     HIP_TRY(hipMemsetAsync(d_sc, 0, sizeof(FlattenScalars), s));
     const unsigned gz = cdiv(z, 256);
-    flatten_init_kernel<<<gz, 256, 0, s>>>(fpos, z, fs.flen, fs.fsrc, rec);
+    flatten_init_kernel<<<gz, 256, 0, s>>>(fpos, z, fs.flen, fs.fsrc, rec, fs.have_list ? fs.flenl : nullptr);
     LAUNCH_CHECK();
     // work lists of the still-waiting factors (the first round visits every factor)
     uint4* work[2] = { (uint4*)c.arena.alloc(z * sizeof(uint4)), nullptr };

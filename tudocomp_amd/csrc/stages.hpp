@@ -52,6 +52,7 @@ struct FactorSpace {
     // optional: the factor starts in position order (n entries of capacity).  build_owner() fills it and sets
     // have_list; flatten and encode then skip their own extraction (factor positions never change after that).
     u32* fpos = nullptr;
+    u32* flenl = nullptr;      // optional companion of fpos: the factor lengths in the same order (filled with it)
     size_t nfact = 0;
     bool have_list = false;
     // optional: one class byte per position -- 0 literal, 2 factor start, 3 covered by a factor that started earlier.  build_owner()
