@@ -88,6 +88,52 @@ def test_compress_bitexact_random(gpu_ctx):
             assert got == want, (name, thr, data)
 
 
+def _ctx_env(env):
+    import os
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return T.Context(0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("mode", ["2", "2_norec", "0"])
+def test_first_half_of_the_encoder_inside_the_flatten_stage(gpu_ctx, mode):
+    """TDC_GPU_ENC_EARLY: texts of 1 MiB and more run gaps / histogram / code table / bits per tile on the copy stream next to the
+    first flatten round, and the pack takes lengths and flattened sources from the flatten stage's records (the default context does,
+    see the medium and full-size tests); 2 does so for every text, 0 for none; TDC_GPU_ENC_REC=0 keeps the early half but packs from
+    flen[] / fsrc[].  Same streams every way, with and without factors, flatten on and off, also for the coders that never take the
+    early half."""
+    ctx = _ctx_env({"TDC_GPU_ENC_EARLY": mode[0], "TDC_GPU_ENC_REC": "0" if mode.endswith("norec") else "1"})
+    try:
+        cases = list(SMALL) + list(corpus.random_small(60, seed=5)) + [("english_3M", T.gen_english(3_000_000, 8).tobytes()),
+                                                                       ("dna_2M", T.gen_dna(2_000_000, 3).tobytes())]
+        for name, data in cases:
+            text = O.escape(data)
+            for thr in ((2, 5) if len(text) < 100000 else (2,)):
+                for fl in (1, 0):
+                    got, st = ctx.lcpcomp_compress(text, thr, fl)
+                    if len(text) < 100000:
+                        want, wst = O.lcpcomp_huff_compress(text, thr, fl)
+                        assert st["num_flattened"] == wst["num_flattened"], (name, thr, fl)
+                    else:
+                        want, _ = gpu_ctx.lcpcomp_compress(text, thr, fl)          # (the default context is checked against the oracle elsewhere)
+                        assert O.lcpcomp_huff_decompress(got) == text
+                    assert got == want, (name, thr, fl, len(got), len(want))
+        text = O.escape(T.gen_english(200_000, 4).tobytes())
+        for coder in (T.CODER_ARITH, T.CODER_ASCII):
+            a, _ = ctx.lcpcomp_compress(text, 2, 1, coder=coder)
+            b, _ = gpu_ctx.lcpcomp_compress(text, 2, 1, coder=coder)
+            assert a == b
+    finally:
+        ctx.close()
+
+
 def test_survey_example(gpu_ctx):
     e = ANCH["example"]
     comp = T.LCPCompressor(gpu_ctx, coder="huff", threshold=e["threshold"])

@@ -151,6 +151,18 @@ struct DevArrays {
     u32 *sa = nullptr, *isa = nullptr, *phi = nullptr, *plcp = nullptr;
     FactorSpace fs;
     u32 maxlcp = 0;
+    EncodeEarly* early = nullptr;           // first half of the encoder, run inside the flatten stage (run_factorize)
+    DevArrays() = default;
+    DevArrays(const DevArrays&) = delete;
+    DevArrays& operator=(const DevArrays&) = delete;
+    ~DevArrays() { encode_early_free(early); }
+};
+
+// c.stream points at another stream for the lifetime of the object (the stage functions enqueue on c.stream)
+struct StreamSwap {
+    Ctx& c; hipStream_t saved;
+    StreamSwap(Ctx& ctx, hipStream_t other) : c(ctx), saved(ctx.stream) { c.stream = other; }
+    ~StreamSwap() { c.stream = saved; }
 };
 
 // Checks that the 0 byte occurs exactly once, at n - 1 (ds/TextDS.hpp:132-138).  The count comes from the byte histogram of the text,
@@ -204,7 +216,10 @@ void run_textds(Ctx& c, const u8* d_text, size_t n, DevArrays& A, tdc_gpu_stats*
     }
 }
 
-void run_factorize(Ctx& c, size_t n, DevArrays& A, u32 threshold, int flatten, tdc_gpu_stats* st, Events* ev, int strategy = 0) {
+// enc_coder >= 0 (with d_text): the stream is encoded next with this coder of encode_stream -- the first half of the encoder may run
+// inside the flatten stage
+void run_factorize(Ctx& c, size_t n, DevArrays& A, u32 threshold, int flatten, tdc_gpu_stats* st, Events* ev, int strategy = 0,
+                   int enc_coder = -1, const u8* d_text = nullptr) {
     A.fs.flen = c.arena.get<u32>(n);
     A.fs.owner = c.arena.get<u32>(n);
     A.fs.fsrc = c.arena.get<u32>(n);
@@ -220,7 +235,22 @@ void run_factorize(Ctx& c, size_t n, DevArrays& A, u32 threshold, int flatten, t
     else if (strategy == TDC_GPU_COMP_HEAP) factorize_max_heap(c, n, A.sa, A.isa, A.plcp, A.maxlcp, threshold, A.fs, &fz);
     else factorize_arrays(c, n, A.sa, A.isa, A.phi, A.plcp, A.maxlcp, threshold, A.fs, &fz);
     const int e1 = ev ? ev->tick() : 0;
-    if (flatten) flatten_factors(c, n, A.fs, &fl);
+    // The first half of the Huffman encoder (gaps, literal histogram, code table, bits per tile and their scan: 4-5 ms of streaming
+    // kernels and three host round trips at 2e9 B) reads positions, lengths and class bytes but no source, and the flatten rounds are
+    // bound by the latency of their chains, not by bandwidth: it runs on the copy stream next to the first round.
+    const bool early = flatten && enc_coder == 0 && d_text && c.enc_early && c.copy_stream && c.huff_ok && n >= (c.enc_early >= 2 ? (size_t)1 : ((size_t)1 << 20)) &&
+                       A.fs.have_list && A.fs.have_cls && A.fs.flenl && A.fs.nfact > 0;
+    if (early) {
+        A.early = encode_early_reserve(c, n, c.enc_rec ? A.fs.nfact : 0);
+        HIP_TRY(hipEventRecord(c.ev_copy[0], c.stream));                  // the factors are in place
+        flatten_factors(c, n, A.fs, &fl, [&]() {
+            StreamSwap sw(c, c.copy_stream);
+            HIP_TRY(hipStreamWaitEvent(c.stream, c.ev_copy[0], 0));
+            encode_early_run(c, d_text, n, A.fs, enc_coder, A.early);
+        }, c.enc_rec ? encode_early_rec(A.early) : nullptr);
+    } else if (flatten) {
+        flatten_factors(c, n, A.fs, &fl);
+    }
     const int e2 = ev ? ev->tick() : 0;
     if (st) {
         st->factors = fz.factors; st->entries = fz.entries; st->pushes = fz.pushes;
@@ -238,13 +268,13 @@ size_t run_pipeline(Ctx& c, const u8* d_text, size_t n, u32 threshold, int flatt
     validate_device_text(c, d_text, n);
     DevArrays A;
     run_textds(c, d_text, n, A, st, &ev);
-    run_factorize(c, n, A, threshold, flatten, st, &ev, strategy);
-    EncodeStats es;
     const int enc_coder = lcpcomp_enc_coder(coder);
+    run_factorize(c, n, A, threshold, flatten, st, &ev, strategy, enc_coder, d_text);
+    EncodeStats es;
     if (!*d_out_io) { out_cap = align_up(encode_bound_coder(n, enc_coder) + 16, 8); *d_out_io = c.arena.get<u8>(out_cap); }
     u8* d_out = *d_out_io;
     const int e0 = ev.tick();
-    const size_t out_len = encode_stream(c, d_text, n, A.fs, enc_coder, d_out, out_cap, &es);
+    const size_t out_len = encode_stream(c, d_text, n, A.fs, enc_coder, d_out, out_cap, &es, A.early);
     const int e1 = ev.tick();
     HIP_TRY(hipStreamSynchronize(c.stream));
     if (st) {
@@ -332,6 +362,8 @@ int tdc_gpu_ctx_create(int device, tdc_gpu_ctx** out) {
         if (const char* m = getenv("TDC_GPU_SMALL_PIPELINE")) ctx->c.small_pipeline = atoi(m) != 0;
         if (const char* m = getenv("TDC_GPU_SMALL_BIG")) ctx->c.small_big = atoi(m);
         if (const char* m = getenv("TDC_GPU_FS_PAIR")) ctx->c.fs_pair = atoi(m) != 0;
+        if (const char* m = getenv("TDC_GPU_ENC_EARLY")) ctx->c.enc_early = atoi(m);
+        if (const char* m = getenv("TDC_GPU_ENC_REC")) ctx->c.enc_rec = atoi(m) != 0;
         if (const char* m = getenv("TDC_GPU_LEVEL_PURGE")) ctx->c.level_purge = atoi(m) != 0;
         if (const char* m = getenv("TDC_GPU_SA_REFINE")) ctx->c.sa_refine = atoi(m) != 0;
         if (const char* m = getenv("TDC_GPU_SA_FUSED_INIT")) ctx->c.sa_fused_init = atoi(m) != 0;

@@ -133,6 +133,8 @@ struct Ctx {
     int plcp_samples = 1;          // PLCP: exact values at every 256th position first, as lower bounds for the chunks (env TDC_GPU_PLCP_SAMPLES=0: chunks start from 0)
     bool huff_ok = true;           // the start-up self-check of the host Huffman table passed (else coder=huff calls fail with TDC_GPU_ERR_INTERNAL)
     int level_purge = 1;           // factorize: the lists of the next 64 levels are purged in place before they are read (env TDC_GPU_LEVEL_PURGE=0 disables)
+    int enc_rec = 1;               // with enc_early: the pack reads lengths and flattened sources from the records of the flatten stage (env TDC_GPU_ENC_REC=0: from flen[] / fsrc[])
+    int enc_early = 1;             // first half of the Huffman encoder next to the first flatten round (texts of 1 MiB and more; env TDC_GPU_ENC_EARLY=0: after the flatten stage, 2: for every text)
     int fs_pair = 1;               // fused scatter: two rows per workgroup (tiles of 8192 records; env TDC_GPU_FS_PAIR=0: one)
     int small_big = 1;             // factorize: one-workgroup levels with up to 4096 survivors run on a 512-thread instance of the kernel (env TDC_GPU_SMALL_BIG=0: multi-launch path above 2048)
     int small_pipeline = 1;        // factorize: the kernel of the next one-workgroup level is queued while the current one runs (env TDC_GPU_SMALL_PIPELINE=0 disables)

@@ -217,14 +217,15 @@ __global__ __launch_bounds__(256) void tile_bits_kernel(const u8* __restrict__ t
     if (threadIdx.x == 0) tile_bits[blockIdx.x] = (u64)sm[0] + sm[1] + sm[2] + sm[3];
 }
 
+// tile_starts (optional): the number of factors that start in the tile (their scan gives pack_cls_kernel<true> the rank of a tile's first factor)
 __global__ __launch_bounds__(256) void tile_bits_cls_kernel(const u8* __restrict__ text, const u8* __restrict__ cls, size_t n, CodeTable tab, EncParams P,
-                                                             ArithDev A, u64* __restrict__ tile_bits) {
+                                                             ArithDev A, u64* __restrict__ tile_bits, u32* __restrict__ tile_starts) {
     __shared__ u8 clen[256];
-    __shared__ u32 sm[4];
+    __shared__ u32 sm[4], sc[4];
     clen[threadIdx.x] = tab.len[threadIdx.x];
     __syncthreads();
     const size_t p0 = (size_t)blockIdx.x * ENC_TILE + (size_t)threadIdx.x * ENC_PER_THREAD;
-    u32 sum = 0;
+    u32 sum = 0, starts = 0;
     if (p0 < n) {
         u8 cl[ENC_PER_THREAD], ch[ENC_PER_THREAD];
         load8_u8(cls, p0, n, cl); load8_u8(text, p0, n, ch);
@@ -234,14 +235,19 @@ __global__ __launch_bounds__(256) void tile_bits_cls_kernel(const u8* __restrict
             const size_t p = p0 + j;
             if (p < n) {
                 sum += position_cost_cls(cl[j], prev, p == 0, ch[j], (u32)p, clen, P, A);
+                starts += (cl[j] == 2u) ? 1u : 0u;
                 prev = cl[j];
             }
         }
     }
     sum = wave_reduce_sum(sum);
-    if (lane_id() == 0) sm[wave_id()] = sum;
+    starts = wave_reduce_sum(starts);
+    if (lane_id() == 0) { sm[wave_id()] = sum; sc[wave_id()] = starts; }
     __syncthreads();
-    if (threadIdx.x == 0) tile_bits[blockIdx.x] = (u64)sm[0] + sm[1] + sm[2] + sm[3];
+    if (threadIdx.x == 0) {
+        tile_bits[blockIdx.x] = (u64)sm[0] + sm[1] + sm[2] + sm[3];
+        if (tile_starts) tile_starts[blockIdx.x] = sc[0] + sc[1] + sc[2] + sc[3];
+    }
 }
 
 // Append `nbits` (1..64) bits of `val` at absolute bit position `bitpos`; the stream is MSB-first, so the output is
@@ -361,14 +367,21 @@ __global__ __launch_bounds__(256) void pack_kernel(const u8* __restrict__ text, 
     sink.flush();
 }
 
-// pack_kernel<false> on the class bytes of FactorSpace::cls instead of owner[] (3 bytes less per position in each of the two passes of a tile)
+// pack_kernel<false> on the class bytes of FactorSpace::cls instead of owner[] (3 bytes less per position in each of the two passes of a tile).
+// REC: length and final source of a factor come from the records of the flatten stage (flatten.hip: {pos, len, original source, final
+// source}, indexed by the factor's rank in position order; the rank of a tile's first factor from the scanned start counts of
+// tile_bits_cls_kernel, inside the tile by the scan that also gives the bit offsets), and the length of a literal run from the position
+// of the factor that follows it: no flen[] / fsrc[] stream at all (8 + 8 bytes per position), and the flatten stage need not write its
+// results back into fsrc[].
+template <bool REC>
 __global__ __launch_bounds__(256) void pack_cls_kernel(const u8* __restrict__ text, const u8* __restrict__ cls,
                                                         const u32* __restrict__ flen, const u32* __restrict__ fsrc, size_t n,
                                                         CodeTable tab, EncParams P, ArithDev A, const u64* __restrict__ tile_off,
-                                                        u64 base_bits, u64* __restrict__ out, u32 tile0) {
+                                                        u64 base_bits, u64* __restrict__ out, u32 tile0,
+                                                        const uint4* __restrict__ rec, const u32* __restrict__ tile_rank, u32 z) {
     __shared__ u8 clen[256];
     __shared__ u64 code[256];
-    __shared__ u32 sm[5];
+    __shared__ u64 sm[5];
     clen[threadIdx.x] = tab.len[threadIdx.x];
     code[threadIdx.x] = tab.code[threadIdx.x];
     __syncthreads();
@@ -376,9 +389,10 @@ __global__ __launch_bounds__(256) void pack_cls_kernel(const u8* __restrict__ te
     const size_t p0 = (size_t)tile * ENC_TILE + (size_t)threadIdx.x * ENC_PER_THREAD;
     u32 fl[ENC_PER_THREAD];
     u8 cl[ENC_PER_THREAD], ch[ENC_PER_THREAD];
-    u32 prev0 = 0, sum = 0;
+    u32 prev0 = 0, sum = 0, starts = 0;
     if (p0 < n) {
-        load8_u8(cls, p0, n, cl); load8_u32(flen, p0, n, fl); load8_u8(text, p0, n, ch);
+        load8_u8(cls, p0, n, cl); load8_u8(text, p0, n, ch);
+        if (!REC) load8_u32(flen, p0, n, fl);
         prev0 = (p0 == 0) ? 0u : (u32)cls[p0 - 1];
         u32 prev = prev0;
 #pragma unroll
@@ -386,13 +400,16 @@ __global__ __launch_bounds__(256) void pack_cls_kernel(const u8* __restrict__ te
             const size_t p = p0 + j;
             if (p < n) {
                 sum += position_cost_cls(cl[j], prev, p == 0, ch[j], (u32)p, clen, P, A);
+                if (REC) starts += (cl[j] == 2u) ? 1u : 0u;
                 prev = cl[j];
             }
         }
     }
-    u32 total;
-    const u32 excl = block_exclusive_sum<u32, 4>(sum, sm, total);
+    u64 total;
+    const u64 ex = block_exclusive_sum<u64, 4>((u64)sum | ((u64)starts << 40), sm, total);     // (bits of a tile < 2^40, starts <= 2048)
+    const u64 excl = ex & ((1ull << 40) - 1ull);
     if (p0 >= n) return;
+    u32 k = REC ? tile_rank[tile] + (u32)(ex >> 40) : 0u;          // rank of the next factor that starts at or behind the thread's first position
     BitSink sink;
     sink.out = out;
     sink.pos = base_bits + tile_off[tile] + excl;
@@ -405,18 +422,27 @@ __global__ __launch_bounds__(256) void pack_cls_kernel(const u8* __restrict__ te
         if (p < n) {
             const u32 o = cl[j];
             if (o == 0u) {
-                if (p == 0 || prev != 0u) { sink.append(1, 1); sink.append(fl[j], P.dbits); }   // LZSSCoding.hpp:62-68, :83-86 (a literal run starts)
+                if (p == 0 || prev != 0u) {                                               // LZSSCoding.hpp:62-68, :83-86 (a literal run starts)
+                    const u32 run = REC ? ((k < z ? rec[k].x : (u32)n) - (u32)p) : fl[j];
+                    sink.append(1, 1); sink.append(run, P.dbits);
+                }
                 if (A.litidx) {                                                           // ArithmeticCoder.hpp:96-104, :151-155
-                    const u32 k = A.litidx[p];
-                    if (A.amark[k]) sink.append(A.fval[k], 64);
-                    if (k == A.lc_index) { sink.append(A.pp_lb, 64); sink.append(~0ull, 64); }
+                    const u32 q = A.litidx[p];
+                    if (A.amark[q]) sink.append(A.fval[q], 64);
+                    if (q == A.lc_index) { sink.append(A.pp_lb, 64); sink.append(~0ull, 64); }
                 }
                 else if (P.raw_literals) sink.append(ch[j], 8);                           // HuffmanCoder.hpp:565-566
                 else sink.append(code[ch[j]], clen[ch[j]]);                               // :568 huffman_encode
             } else if (o == 2u) {
                 if (p == 0 || prev != 0u) sink.append(0, 1);                              // LZSSCoding.hpp:57-59
-                sink.append(fsrc[p], P.W);                                                // :77
-                sink.append(fl[j] - P.flen_min, P.lbits);                                 // :78
+                if (REC) {
+                    const uint4 r = rec[k++];
+                    sink.append(r.w, P.W);                                                // :77 (the flattened source)
+                    sink.append(r.y - P.flen_min, P.lbits);                               // :78
+                } else {
+                    sink.append(fsrc[p], P.W);                                            // :77
+                    sink.append(fl[j] - P.flen_min, P.lbits);                             // :78
+                }
             }
             prev = o;
         }
@@ -446,20 +472,20 @@ size_t encode_bound(size_t n) { return 12 * n + 4096; }
 size_t encode_bound_coder(size_t n, int coder) { return ((coder & 0xFF) == 2 ? 24 : 12) * n + ((coder & 0xFF) == 3 ? 32768 : 4096); }
 
 size_t encode_huff(Ctx& c, const u8* text, size_t n, FactorSpace fs, u8* d_out, size_t out_cap, EncodeStats* st) {
-    return encode_stream(c, text, n, fs, 0, d_out, out_cap, st);
+    return encode_stream(c, text, n, fs, 0, d_out, out_cap, st, nullptr);
 }
 
 // factor list in position order, gaps + min/max lengths (run lengths stored at run starts), literal histogram
 struct EncPrelude { size_t z; u32 hist[256]; EncScalars sc; };
-static void encode_prelude(Ctx& c, const u8* text, size_t n, FactorSpace& fs, EncPrelude& pre) {
+static void encode_prelude(Ctx& c, const u8* text, size_t n, FactorSpace& fs, EncPrelude& pre, EncScalars* r_sc = nullptr, u32* r_hist = nullptr) {
     hipStream_t s = c.stream;
     u32* fpos = fs.have_list ? fs.fpos : c.arena.get<u32>(n);
     u32* flist = fs.have_list ? fs.flenl : c.arena.get<u32>(n);        // (nullptr: the lengths are read at the factor starts)
     const size_t z = fs.have_list ? fs.nfact : extract_factors(c, n, fs, fpos, nullptr, flist, n);
-    EncScalars* d_sc = (EncScalars*)c.arena.alloc(sizeof(EncScalars));
+    EncScalars* d_sc = r_sc ? r_sc : (EncScalars*)c.arena.alloc(sizeof(EncScalars));
     EncScalars h_sc = { 0xFFFFFFFFu, 0u, 0u, 0u };          // LZSSFactors.hpp:33-38 : INDEX_MAX / 0
     HIP_TRY(hipMemcpyAsync(d_sc, &h_sc, sizeof(h_sc), hipMemcpyHostToDevice, s));
-    u32* d_hist = c.arena.get<u32>(256);
+    u32* d_hist = r_hist ? r_hist : c.arena.get<u32>(256);
     HIP_TRY(hipMemsetAsync(d_hist, 0, 256 * sizeof(u32), s));
     if (z) {
         unsigned g = cdiv(z, 256); if (g > 2048) g = 2048;
@@ -487,25 +513,59 @@ static void encode_prelude(Ctx& c, const u8* text, size_t n, FactorSpace& fs, En
 
 static size_t encode_sle(Ctx& c, const u8* text, size_t n, FactorSpace fs, u32 k, u8* d_out, size_t out_cap, EncodeStats* st);
 
-size_t encode_stream(Ctx& c, const u8* text, size_t n, FactorSpace fs, int coder, u8* d_out, size_t out_cap, EncodeStats* st) {
-    EncodeStats local;
-    if (!st) st = &local;
-    *st = EncodeStats();
-    if ((coder & 0xFF) == 3) return encode_sle(c, text, n, fs, (u32)(coder >> 8), d_out, out_cap, st);
-    hipStream_t s = c.stream;
-    const size_t mark = c.arena.mark();
+// The encoder in two halves.  The first one -- gaps, literal histogram, coder header, bits per tile, their scan -- needs the factors'
+// positions and lengths but not their sources, so the caller may run it while the factors are still being flattened (api.hip,
+// run_factorize: on the copy stream, next to the first flatten round); the second half packs the bits and needs everything.
+constexpr u32 PACK_CH = 8;
+struct EncodeEarly {
+    // scratch; reserved ahead of the flatten stage when the first half runs inside it (arena order: these, then flatten's lists)
+    EncScalars* d_sc = nullptr; u32* d_hist = nullptr; u64* tile_bits = nullptr; u64* d_tp = nullptr;   // d_tp: total, then PACK_CH chunk ends
+    u32* tile_rank = nullptr;      // rank of the first factor of every tile (only with rec)
+    uint4* rec = nullptr;          // the records of the flatten stage, kept for the pack (flatten_factors fills them; z_rec entries)
+    size_t z_rec = 0;
+    unsigned tiles = 0;
+    bool done = false;
+    // results of the first half
+    size_t z = 0;
+    EncScalars sc;
+    HuffTable ht;
+    HostBitWriter hw;
+    ArithDev A;
+    EncParams P;
+    CodeTable tab;
+    u64 base_bits = 0, total_bits = 0;
+    size_t out_len = 0;
+    bool overlap = false;
+    u64 h_end[PACK_CH];
+};
 
+static void encode_reserve(Ctx& c, size_t n, EncodeEarly& E, size_t z_rec = 0) {
+    E.tiles = cdiv(n, ENC_TILE);
+    if (z_rec) {
+        E.z_rec = z_rec;
+        E.rec = (uint4*)c.arena.alloc(z_rec * sizeof(uint4));
+        E.tile_rank = c.arena.get<u32>(E.tiles + 1);
+    }
+    E.d_sc = (EncScalars*)c.arena.alloc(sizeof(EncScalars));
+    E.d_hist = c.arena.get<u32>(256);
+    E.tile_bits = c.arena.get<u64>(E.tiles + 1);
+    E.d_tp = c.arena.get<u64>(1 + PACK_CH);
+}
+
+static void encode_first_half(Ctx& c, const u8* text, size_t n, FactorSpace& fs, int coder, EncodeEarly& E) {
+    hipStream_t s = c.stream;
     EncPrelude pre;
-    encode_prelude(c, text, n, fs, pre);
-    const size_t z = pre.z;
+    encode_prelude(c, text, n, fs, pre, E.d_sc, E.d_hist);
+    E.z = pre.z;
     const u32* h_hist = pre.hist;
-    EncScalars h_sc = pre.sc;
+    E.sc = pre.sc;
+    const EncScalars& h_sc = E.sc;
 
     // ---- host: coder header (HuffmanCoder::Encoder ctor :526-547 / ArithmeticCoder::Encoder ctor :158-164),
     //      then the fields of LZSSCoding.hpp:47-50
-    HuffTable ht;
-    HostBitWriter hw;
-    ArithDev A = { nullptr, nullptr, nullptr, 0, 0 };
+    HuffTable& ht = E.ht;
+    HostBitWriter& hw = E.hw;
+    E.A = { nullptr, nullptr, nullptr, 0, 0 };
     if (coder == 2) {
         memset(&ht, 0, sizeof(ht));                                        // ASCIICoder writes no header
     } else if (coder == 0) {
@@ -519,9 +579,9 @@ size_t encode_stream(Ctx& c, const u8* text, size_t n, FactorSpace fs, int coder
             throw HipError{hipErrorInvalidValue, "arithmetic coder: all literal bytes >= 1 are absent (the reference divides by zero)", -1};
         ArithPlan plan;
         arith_prepare(c, text, n, fs.owner, am, &plan);
-        A.litidx = plan.litidx; A.amark = plan.amark; A.fval = plan.fval; A.lc_index = plan.lc_index; A.pp_lb = plan.pp_lb;
+        E.A.litidx = plan.litidx; E.A.amark = plan.amark; E.A.fval = plan.fval; E.A.lc_index = plan.lc_index; E.A.pp_lb = plan.pp_lb;
     }
-    EncParams P;
+    EncParams& P = E.P;
     P.W = bits_for(n);
     P.lbits = bits_for((u64)h_sc.flen_max - (u64)h_sc.flen_min);       // only used when z > 0
     P.dbits = bits_for(h_sc.fdist_max);
@@ -542,25 +602,74 @@ size_t encode_stream(Ctx& c, const u8* text, size_t n, FactorSpace fs, int coder
         hw.write_int(h_sc.flen_max, P.W);
         hw.write_int(h_sc.fdist_max, P.W);
     }
-    const u64 base_bits = hw.nbits;
-    CodeTable tab;
-    memcpy(tab.code, ht.code_of, sizeof(tab.code));
-    memcpy(tab.len, ht.len_of, sizeof(tab.len));
+    E.base_bits = hw.nbits;
+    memcpy(E.tab.code, ht.code_of, sizeof(E.tab.code));
+    memcpy(E.tab.len, ht.len_of, sizeof(E.tab.len));
 
     // ---- pass 1: bits per tile, scan -------------------------------------------------------------------------
-    const unsigned tiles = cdiv(n, ENC_TILE);
-    u64* tile_bits = c.arena.get<u64>(tiles + 1);
-    u64* d_total = c.arena.get<u64>(1);
+    const unsigned tiles = E.tiles;
+    u64* tile_bits = E.tile_bits;
     {
         Ctx::ProfScope prof(c, K_ENC_TILE_BITS, (u64)n * 9);
-        if (P.ascii) tile_bits_kernel<true><<<tiles, 256, 0, s>>>(text, fs.owner, fs.flen, fs.fsrc, n, tab, P, A, tile_bits);
-        else if (fs.have_cls) tile_bits_cls_kernel<<<tiles, 256, 0, s>>>(text, fs.cls, n, tab, P, A, tile_bits);
-        else         tile_bits_kernel<false><<<tiles, 256, 0, s>>>(text, fs.owner, fs.flen, fs.fsrc, n, tab, P, A, tile_bits);
+        if (P.ascii) tile_bits_kernel<true><<<tiles, 256, 0, s>>>(text, fs.owner, fs.flen, fs.fsrc, n, E.tab, P, E.A, tile_bits);
+        else if (fs.have_cls) tile_bits_cls_kernel<<<tiles, 256, 0, s>>>(text, fs.cls, n, E.tab, P, E.A, tile_bits, E.tile_rank);
+        else         tile_bits_kernel<false><<<tiles, 256, 0, s>>>(text, fs.owner, fs.flen, fs.fsrc, n, E.tab, P, E.A, tile_bits);
         LAUNCH_CHECK();
     }
-    exclusive_sum_u64(c, tile_bits, tile_bits, tiles, d_total);
-    const u64 total_bits = base_bits + c.read(d_total);
-    const size_t out_len = (size_t)(total_bits >> 3) + ((total_bits & 7) <= 5 ? 1 : 2);
+    exclusive_sum_u64(c, tile_bits, tile_bits, tiles, E.d_tp);
+    if (E.tile_rank) exclusive_sum_u32(c, E.tile_rank, E.tile_rank, tiles, nullptr);
+    // With a host destination (end-to-end entry point) the pack runs in PACK_CH chunks of tiles (second half): the bit offsets at
+    // which the chunks end travel with the total
+    const bool may_overlap = c.d2h_host && tiles >= 64 * PACK_CH && c.copy_stream;
+    u64 h_tp[1 + PACK_CH] = { 0 };
+    if (may_overlap) {
+        pick_u64_kernel<<<1, 64, 0, s>>>(tile_bits, tiles, PACK_CH, E.d_tp + 1);
+        LAUNCH_CHECK();
+        c.read_n(E.d_tp, h_tp, 1 + PACK_CH);
+    } else {
+        h_tp[0] = c.read(E.d_tp);
+    }
+    E.total_bits = E.base_bits + h_tp[0];
+    E.out_len = (size_t)(E.total_bits >> 3) + ((E.total_bits & 7) <= 5 ? 1 : 2);
+    E.overlap = may_overlap && E.out_len <= c.d2h_cap;
+    for (u32 q = 0; q < PACK_CH; ++q) E.h_end[q] = h_tp[1 + q];
+    E.done = true;
+}
+
+EncodeEarly* encode_early_reserve(Ctx& c, size_t n, size_t z_rec) {
+    EncodeEarly* E = new EncodeEarly();
+    try { encode_reserve(c, n, *E, z_rec); } catch (...) { delete E; throw; }
+    return E;
+}
+void* encode_early_rec(EncodeEarly* E) { return E->rec; }
+void encode_early_run(Ctx& c, const u8* text, size_t n, FactorSpace fs, int coder, EncodeEarly* E) { encode_first_half(c, text, n, fs, coder, *E); }
+void encode_early_free(EncodeEarly* E) { delete E; }
+
+size_t encode_stream(Ctx& c, const u8* text, size_t n, FactorSpace fs, int coder, u8* d_out, size_t out_cap, EncodeStats* st, EncodeEarly* early) {
+    EncodeStats local;
+    if (!st) st = &local;
+    *st = EncodeStats();
+    if ((coder & 0xFF) == 3) return encode_sle(c, text, n, fs, (u32)(coder >> 8), d_out, out_cap, st);
+    hipStream_t s = c.stream;
+    const size_t mark = c.arena.mark();
+
+    EncodeEarly mine;
+    if (!early || !early->done) {
+        early = &mine;
+        encode_reserve(c, n, mine);
+        encode_first_half(c, text, n, fs, coder, mine);
+    }
+    EncodeEarly& E = *early;
+    const size_t z = E.z;
+    const EncScalars h_sc = E.sc;
+    const EncParams P = E.P;
+    const ArithDev A = E.A;
+    const CodeTable& tab = E.tab;
+    HostBitWriter& hw = E.hw;
+    const u64 base_bits = E.base_bits, total_bits = E.total_bits;
+    const unsigned tiles = E.tiles;
+    const u64* tile_bits = E.tile_bits;
+    const size_t out_len = E.out_len;
     const size_t padded = align_up(out_len + 8, 8);
     if (padded > out_cap) throw HipError{hipErrorOutOfMemory, "encode: output buffer too small", (int)__LINE__};
 
@@ -569,23 +678,18 @@ size_t encode_stream(Ctx& c, const u8* text, size_t n, FactorSpace fs, int coder
     HIP_TRY(hipMemcpyAsync(d_out, hw.bytes.data(), hw.bytes.size(), hipMemcpyHostToDevice, s));
     {
         Ctx::ProfScope prof(c, K_ENC_PACK, (u64)n * 9 + (u64)z * 4 + out_len);
-        // With a host destination (end-to-end entry point) the pack runs in 8 chunks of tiles: once a chunk is done the bytes in
-        // front of its last (possibly shared) 64-bit word are final and start their way to the host on the copy stream, while
-        // the next chunk is being packed.
-        constexpr u32 CH = 8;
-        const bool overlap = c.d2h_host && out_len <= c.d2h_cap && tiles >= 64 * CH && c.copy_stream;
-        u64 h_end[CH];
-        if (overlap) {
-            u64* d_pick = c.arena.get<u64>(CH);
-            pick_u64_kernel<<<1, 64, 0, s>>>(tile_bits, tiles, CH, d_pick);
-            LAUNCH_CHECK();
-            c.read_n(d_pick, h_end, CH);
-        }
+        // in PACK_CH chunks of tiles when the stream goes to the host: once a chunk is done the bytes in front of its last
+        // (possibly shared) 64-bit word are final and start their way to the host on the copy stream, while the next chunk is
+        // being packed.
+        constexpr u32 CH = PACK_CH;
+        const bool overlap = E.overlap;
+        const u64* h_end = E.h_end;
         size_t copied = 0;
         for (u32 q = 0; q < (overlap ? CH : 1u); ++q) {
             const u32 t0 = overlap ? (u32)((u64)tiles * q / CH) : 0u, t1 = overlap ? (u32)((u64)tiles * (q + 1) / CH) : tiles;
             if (P.ascii) pack_kernel<true><<<t1 - t0, 256, 0, s>>>(text, fs.owner, fs.flen, fs.fsrc, n, tab, P, A, tile_bits, base_bits, (u64*)d_out, t0);
-            else if (fs.have_cls) pack_cls_kernel<<<t1 - t0, 256, 0, s>>>(text, fs.cls, fs.flen, fs.fsrc, n, tab, P, A, tile_bits, base_bits, (u64*)d_out, t0);
+            else if (fs.have_cls && E.rec) pack_cls_kernel<true><<<t1 - t0, 256, 0, s>>>(text, fs.cls, fs.flen, fs.fsrc, n, tab, P, A, tile_bits, base_bits, (u64*)d_out, t0, E.rec, E.tile_rank, (u32)E.z_rec);
+            else if (fs.have_cls) pack_cls_kernel<false><<<t1 - t0, 256, 0, s>>>(text, fs.cls, fs.flen, fs.fsrc, n, tab, P, A, tile_bits, base_bits, (u64*)d_out, t0, nullptr, nullptr, 0u);
             else         pack_kernel<false><<<t1 - t0, 256, 0, s>>>(text, fs.owner, fs.flen, fs.fsrc, n, tab, P, A, tile_bits, base_bits, (u64*)d_out, t0);
             LAUNCH_CHECK();
             if (overlap && q + 1 < CH) {
@@ -608,7 +712,7 @@ size_t encode_stream(Ctx& c, const u8* text, size_t n, FactorSpace fs, int coder
     st->factors = z;
     st->flen_min = h_sc.flen_min; st->flen_max = h_sc.flen_max; st->fdist_max = h_sc.fdist_max;
     st->out_bits = total_bits;
-    st->sigma = ht.sigma;
+    st->sigma = E.ht.sigma;
     c.arena.release(mark);
     return out_len;
 }

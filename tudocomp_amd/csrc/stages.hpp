@@ -3,6 +3,7 @@
 // /root/reference/include/tudocomp/.
 #pragma once
 #include "common.hpp"
+#include <functional>
 
 namespace tdc {
 
@@ -90,7 +91,12 @@ void factorize_max_heap(Ctx& c, size_t n, const u32* sa, const u32* isa, const u
 
 struct FlattenStats { u64 num_flattened = 0; u64 max_depth_lb = 0; u32 rounds = 0; };
 // a10: compressors/lzss/LZSSFactors.hpp:79-132 ; rewrites fs.fsrc in place.
-void flatten_factors(Ctx& c, size_t n, FactorSpace fs, FlattenStats* st);
+// `between` (optional) is called once the first round has been enqueued and before the host waits for its count: the place for work
+// that does not need the flattened sources (api.hip runs the first half of the encoder there, on another stream).  Whatever it
+// takes from the arena is gone when flatten_factors returns.
+// rec_keep (optional, room for 16 bytes per factor): the records {pos, len, original source, final source} in position order are built
+// there and stay valid for the caller; fs.fsrc is NOT rewritten then.
+void flatten_factors(Ctx& c, size_t n, FactorSpace fs, FlattenStats* st, const std::function<void()>& between = {}, void* rec_keep = nullptr);
 
 // a9: extract the factor list sorted by pos (LZSSFactors.hpp:69-76): pos[], src[], len[] (z entries each,
 // arrays caller-provided with capacity cap).  Returns z.
@@ -105,7 +111,18 @@ struct EncodeStats { u64 factors = 0; u64 flen_min = 0, flen_max = 0, fdist_max 
 size_t encode_huff(Ctx& c, const u8* text, size_t n, FactorSpace fs, u8* d_out, size_t out_cap, EncodeStats* st);
 // the same with a selectable coder: 0 = HuffmanCoder, 1 = ArithmeticCoder (a15: coders/ArithmeticCoder.hpp:35-177),
 // 2 = ASCIICoder (coders/ASCIICoder.hpp:29-50; every integer and bit of the token stream as text)
-size_t encode_stream(Ctx& c, const u8* text, size_t n, FactorSpace fs, int coder, u8* d_out, size_t out_cap, EncodeStats* st);
+// `early`: the first half (everything in front of the pack: gaps, histogram, coder header, bits per tile and their scan -- none of
+// it reads the factors' sources) has already run, see encode_early_*
+struct EncodeEarly;
+size_t encode_stream(Ctx& c, const u8* text, size_t n, FactorSpace fs, int coder, u8* d_out, size_t out_cap, EncodeStats* st, EncodeEarly* early = nullptr);
+// the first half on its own, for coder 0 and a factor space with list and class bytes (build_owner): _reserve takes the scratch from
+// the arena (call it BEFORE flatten_factors takes its lists), _run enqueues on c.stream and waits for the results
+// z_rec > 0: also room for the z_rec records of the flatten stage (encode_early_rec; hand it to flatten_factors as rec_keep): the pack
+// then takes lengths and flattened sources from the records and flatten_factors leaves fs.fsrc as it is
+EncodeEarly* encode_early_reserve(Ctx& c, size_t n, size_t z_rec = 0);
+void* encode_early_rec(EncodeEarly* e);
+void encode_early_run(Ctx& c, const u8* text, size_t n, FactorSpace fs, int coder, EncodeEarly* e);
+void encode_early_free(EncodeEarly* e);
 
 // worst-case output size of encode_huff for a text of n bytes
 size_t encode_bound(size_t n);
