@@ -13,4 +13,4 @@ text = np.concatenate([data, np.zeros(1, dtype=np.uint8)])
 with T.Context(0) as ctx:
     for _ in range(2):
         out, st = ctx.lcpcomp_compress(text, thr, 1, coder, comp)
-    print({k: (round(v, 2) if isinstance(v, float) else v) for k, v in st.items() if k.startswith("ms_") or k in ("out_len", "factors", "levels")})
+    print({k: (round(v, 2) if isinstance(v, float) else v) for k, v in st.items() if k.startswith("ms_") or k.startswith("sa_") or k in ("out_len", "factors", "levels")})

@@ -245,6 +245,16 @@ struct Ctx {
         *seq = ++zc_seq; *dst = zc_dev + (size_t)block * ZC_WORDS; *flag = *dst + 1024;
         return true;
     }
+    // read-back under way: the words at dptr travel to block `block` of the mapped host area once the stream gets there; returns the
+    // sequence number publish_wait() takes, 0 if the fast path is not available (the caller then reads synchronously)
+    u32 publish_async(const void* dptr, size_t bytes, u32 block) {
+        if (!fast_read || !zc_host || bytes == 0 || bytes > 4096 || (bytes & 3) || ((uintptr_t)dptr & 3) || block >= ZC_BLOCKS) return 0;
+        u32 seq = ++zc_seq;
+        if (seq == 0) seq = ++zc_seq;
+        u32* dst = zc_dev + (size_t)block * ZC_WORDS;
+        publish_words_kernel<<<1, 64, 0, stream>>>((const u32*)dptr, (u32)(bytes / 4), dst, dst + 1024, seq);
+        return hipGetLastError() == hipSuccess ? seq : 0;
+    }
     void publish_wait(u32 seq, void* out, size_t bytes, u32 block = 0) {
         volatile u32* flag = zc_host + (size_t)block * ZC_WORDS + 1024;
         for (u64 spins = 0;; ++spins) {

@@ -85,8 +85,9 @@ __device__ __forceinline__ void load8_u8(const u8* __restrict__ a, size_t p0, si
 
 // gaps between consecutive factors (LZSSCoding.hpp:28-38) + min/max factor length (LZSSFactors.hpp:41-47);
 // stores the literal-run length at the first position of every run.
+// store = false: only the maxima (a pack that takes the run lengths from the flatten records, pack_cls_kernel<true>)
 __global__ __launch_bounds__(256) void gaps_kernel(const u32* __restrict__ fpos, const u32* __restrict__ flen_list, size_t z,
-                                                    size_t n, u32* __restrict__ flen, EncScalars* __restrict__ sc) {
+                                                    size_t n, u32* __restrict__ flen, EncScalars* __restrict__ sc, bool store) {
     __shared__ u32 sg[4], smax[4], smin[4];
     u32 gmax = 0, lmin = 0xFFFFFFFFu, lmax = 0;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -95,13 +96,13 @@ __global__ __launch_bounds__(256) void gaps_kernel(const u32* __restrict__ fpos,
         const u32 p = fpos[i], l = flen_list ? flen_list[i] : flen[p];
         const u32 prev_end = (i == 0) ? 0u : fpos[i - 1] + (flen_list ? flen_list[i - 1] : flen[fpos[i - 1]]);
         const u32 gap = p - prev_end;
-        if (gap) flen[prev_end] = gap;
+        if (gap && store) flen[prev_end] = gap;
         gmax = max(gmax, gap);
         lmin = min(lmin, l);
         lmax = max(lmax, l);
         if (i + 1 == z) {
             const u32 end = p + l;
-            if ((size_t)end < n) { const u32 tail = (u32)(n - end); flen[end] = tail; gmax = max(gmax, tail); }
+            if ((size_t)end < n) { const u32 tail = (u32)(n - end); if (store) flen[end] = tail; gmax = max(gmax, tail); }
         }
     }
     gmax = wave_reduce_max(gmax);
@@ -477,20 +478,21 @@ size_t encode_huff(Ctx& c, const u8* text, size_t n, FactorSpace fs, u8* d_out, 
 
 // factor list in position order, gaps + min/max lengths (run lengths stored at run starts), literal histogram
 struct EncPrelude { size_t z; u32 hist[256]; EncScalars sc; };
-static void encode_prelude(Ctx& c, const u8* text, size_t n, FactorSpace& fs, EncPrelude& pre, EncScalars* r_sc = nullptr, u32* r_hist = nullptr) {
+// r_hist (optional): 260 words -- the histogram, then the scalars (one read-back for both)
+static void encode_prelude_launch(Ctx& c, const u8* text, size_t n, FactorSpace& fs, EncPrelude& pre, u32* r_hist, bool store_runs, u32** o_hist, EncScalars** o_sc) {
     hipStream_t s = c.stream;
     u32* fpos = fs.have_list ? fs.fpos : c.arena.get<u32>(n);
     u32* flist = fs.have_list ? fs.flenl : c.arena.get<u32>(n);        // (nullptr: the lengths are read at the factor starts)
     const size_t z = fs.have_list ? fs.nfact : extract_factors(c, n, fs, fpos, nullptr, flist, n);
-    EncScalars* d_sc = r_sc ? r_sc : (EncScalars*)c.arena.alloc(sizeof(EncScalars));
+    u32* d_hist = r_hist ? r_hist : c.arena.get<u32>(256 + 4);
+    EncScalars* d_sc = (EncScalars*)(d_hist + 256);
     EncScalars h_sc = { 0xFFFFFFFFu, 0u, 0u, 0u };          // LZSSFactors.hpp:33-38 : INDEX_MAX / 0
     HIP_TRY(hipMemcpyAsync(d_sc, &h_sc, sizeof(h_sc), hipMemcpyHostToDevice, s));
-    u32* d_hist = r_hist ? r_hist : c.arena.get<u32>(256);
     HIP_TRY(hipMemsetAsync(d_hist, 0, 256 * sizeof(u32), s));
     if (z) {
         unsigned g = cdiv(z, 256); if (g > 2048) g = 2048;
         Ctx::ProfScope prof(c, K_ENC_GAPS, (u64)z * 12);
-        gaps_kernel<<<g, 256, 0, s>>>(fpos, flist, z, n, fs.flen, d_sc);
+        gaps_kernel<<<g, 256, 0, s>>>(fpos, flist, z, n, fs.flen, d_sc, store_runs || !flist);
         LAUNCH_CHECK();
     } else {
         // no factor: one literal run covering the whole text (LZSSCoding.hpp:38, :83-91)
@@ -506,9 +508,16 @@ static void encode_prelude(Ctx& c, const u8* text, size_t n, FactorSpace& fs, En
         else literal_hist_kernel<<<g, 256, 0, s>>>(text, fs.owner, n, d_hist);
         LAUNCH_CHECK();
     }
-    c.read_n(d_hist, pre.hist, 256);
-    pre.sc = c.read(d_sc);
     pre.z = z;
+    *o_hist = d_hist; *o_sc = d_sc;
+}
+static void encode_prelude(Ctx& c, const u8* text, size_t n, FactorSpace& fs, EncPrelude& pre) {
+    u32* d_hist; EncScalars* d_sc;
+    encode_prelude_launch(c, text, n, fs, pre, nullptr, true, &d_hist, &d_sc);
+    u32 h[260];
+    c.read_n(d_hist, h, 260);
+    memcpy(pre.hist, h, sizeof(pre.hist));
+    memcpy(&pre.sc, h + 256, sizeof(pre.sc));
 }
 
 static size_t encode_sle(Ctx& c, const u8* text, size_t n, FactorSpace fs, u32 k, u8* d_out, size_t out_cap, EncodeStats* st);
@@ -519,7 +528,12 @@ static size_t encode_sle(Ctx& c, const u8* text, size_t n, FactorSpace fs, u32 k
 constexpr u32 PACK_CH = 8;
 struct EncodeEarly {
     // scratch; reserved ahead of the flatten stage when the first half runs inside it (arena order: these, then flatten's lists)
-    EncScalars* d_sc = nullptr; u32* d_hist = nullptr; u64* tile_bits = nullptr; u64* d_tp = nullptr;   // d_tp: total, then PACK_CH chunk ends
+    u32* d_hist = nullptr; u64* tile_bits = nullptr; u64* d_tp = nullptr;   // d_hist: 256 counters + the EncScalars; d_tp: total, then PACK_CH chunk ends
+    // the three steps of the first half: A gaps + histogram, B code table + bits per tile + scans, C collect; seq_*: read-backs under way
+    // (Ctx::publish_async; 0: read synchronously)
+    int step = 0;
+    u32 seq_a = 0, seq_b = 0;
+    bool may_overlap = false;
     u32* tile_rank = nullptr;      // rank of the first factor of every tile (only with rec)
     uint4* rec = nullptr;          // the records of the flatten stage, kept for the pack (flatten_factors fills them; z_rec entries)
     size_t z_rec = 0;
@@ -546,19 +560,28 @@ static void encode_reserve(Ctx& c, size_t n, EncodeEarly& E, size_t z_rec = 0) {
         E.rec = (uint4*)c.arena.alloc(z_rec * sizeof(uint4));
         E.tile_rank = c.arena.get<u32>(E.tiles + 1);
     }
-    E.d_sc = (EncScalars*)c.arena.alloc(sizeof(EncScalars));
-    E.d_hist = c.arena.get<u32>(256);
+    E.d_hist = c.arena.get<u32>(256 + 4);
     E.tile_bits = c.arena.get<u64>(E.tiles + 1);
     E.d_tp = c.arena.get<u64>(1 + PACK_CH);
 }
 
-static void encode_first_half(Ctx& c, const u8* text, size_t n, FactorSpace& fs, int coder, EncodeEarly& E) {
-    hipStream_t s = c.stream;
+// Blocks 1 and 2 of the mapped host area carry the read-backs of steps A and B (free here: they belong to the one-workgroup levels of the
+// factorizer), so a step never waits for the step before it unless it has to.
+static void encode_step_a(Ctx& c, const u8* text, size_t n, FactorSpace& fs, EncodeEarly& E) {
     EncPrelude pre;
-    encode_prelude(c, text, n, fs, pre, E.d_sc, E.d_hist);
+    u32* d_hist; EncScalars* d_sc;
+    encode_prelude_launch(c, text, n, fs, pre, E.d_hist, E.rec == nullptr, &d_hist, &d_sc);
     E.z = pre.z;
-    const u32* h_hist = pre.hist;
-    E.sc = pre.sc;
+    E.seq_a = c.publish_async(E.d_hist, 260 * sizeof(u32), 1);
+    E.step = 1;
+}
+
+static void encode_step_b(Ctx& c, const u8* text, size_t n, FactorSpace& fs, int coder, EncodeEarly& E) {
+    hipStream_t s = c.stream;
+    u32 h[260];
+    if (E.seq_a) c.publish_wait(E.seq_a, h, sizeof(h), 1); else c.read_n(E.d_hist, h, 260);
+    const u32* h_hist = h;
+    memcpy(&E.sc, h + 256, sizeof(E.sc));
     const EncScalars& h_sc = E.sc;
 
     // ---- host: coder header (HuffmanCoder::Encoder ctor :526-547 / ArithmeticCoder::Encoder ctor :158-164),
@@ -620,20 +643,32 @@ static void encode_first_half(Ctx& c, const u8* text, size_t n, FactorSpace& fs,
     if (E.tile_rank) exclusive_sum_u32(c, E.tile_rank, E.tile_rank, tiles, nullptr);
     // With a host destination (end-to-end entry point) the pack runs in PACK_CH chunks of tiles (second half): the bit offsets at
     // which the chunks end travel with the total
-    const bool may_overlap = c.d2h_host && tiles >= 64 * PACK_CH && c.copy_stream;
+    E.may_overlap = c.d2h_host && tiles >= 64 * PACK_CH && c.copy_stream;
+    pick_u64_kernel<<<1, 64, 0, s>>>(tile_bits, tiles, PACK_CH, E.d_tp + 1);
+    LAUNCH_CHECK();
+    E.seq_b = c.publish_async(E.d_tp, (1 + PACK_CH) * sizeof(u64), 2);
+    E.step = 2;
+}
+
+static void encode_step_c(Ctx& c, EncodeEarly& E) {
     u64 h_tp[1 + PACK_CH] = { 0 };
-    if (may_overlap) {
-        pick_u64_kernel<<<1, 64, 0, s>>>(tile_bits, tiles, PACK_CH, E.d_tp + 1);
-        LAUNCH_CHECK();
-        c.read_n(E.d_tp, h_tp, 1 + PACK_CH);
-    } else {
-        h_tp[0] = c.read(E.d_tp);
-    }
+    if (E.seq_b) c.publish_wait(E.seq_b, h_tp, sizeof(h_tp), 2); else c.read_n(E.d_tp, h_tp, 1 + PACK_CH);
+    const bool may_overlap = E.may_overlap;
     E.total_bits = E.base_bits + h_tp[0];
     E.out_len = (size_t)(E.total_bits >> 3) + ((E.total_bits & 7) <= 5 ? 1 : 2);
     E.overlap = may_overlap && E.out_len <= c.d2h_cap;
     for (u32 q = 0; q < PACK_CH; ++q) E.h_end[q] = h_tp[1 + q];
+    E.step = 3;
     E.done = true;
+}
+
+// the next step(s) of the first half: one per call (finish = false), or everything that is left
+static void encode_first_half(Ctx& c, const u8* text, size_t n, FactorSpace& fs, int coder, EncodeEarly& E, bool finish = true) {
+    do {
+        if (E.step == 0) encode_step_a(c, text, n, fs, E);
+        else if (E.step == 1) encode_step_b(c, text, n, fs, coder, E);
+        else if (E.step == 2) encode_step_c(c, E);
+    } while (finish && E.step < 3);
 }
 
 EncodeEarly* encode_early_reserve(Ctx& c, size_t n, size_t z_rec) {
@@ -642,7 +677,7 @@ EncodeEarly* encode_early_reserve(Ctx& c, size_t n, size_t z_rec) {
     return E;
 }
 void* encode_early_rec(EncodeEarly* E) { return E->rec; }
-void encode_early_run(Ctx& c, const u8* text, size_t n, FactorSpace fs, int coder, EncodeEarly* E) { encode_first_half(c, text, n, fs, coder, *E); }
+void encode_early_run(Ctx& c, const u8* text, size_t n, FactorSpace fs, int coder, EncodeEarly* E, bool finish) { encode_first_half(c, text, n, fs, coder, *E, finish); }
 void encode_early_free(EncodeEarly* E) { delete E; }
 
 size_t encode_stream(Ctx& c, const u8* text, size_t n, FactorSpace fs, int coder, u8* d_out, size_t out_cap, EncodeStats* st, EncodeEarly* early) {

@@ -88,12 +88,30 @@ __global__ __launch_bounds__(256) void cand_class_kernel(const u32* __restrict__
     __syncthreads();
     u32 cnt = 0;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
+    // four positions per thread and step: one 16-byte load, 16- / 4-byte stores (the arrays are 16-byte aligned: arena)
+    const size_t n4 = n / 4;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += stride) {
+        const uint4 x = ((const uint4*)plcp)[q];
+        const u32 v[4] = { x.x, x.y, x.z, x.w };
+        u32 cw = 0, rw = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const u32 is_cand = (v[j] >= threshold) ? 1u : 0u;   // PLCP[n-1] = 0, so the sentinel (SA index 0) is never a candidate
+            cw |= ((is_cand && v[j] > lo) ? 1u : 0u) << (8 * j);
+            rw |= (is_cand ? (v[j] > 255u ? 255u : v[j]) : 0u) << (8 * j);     // list that holds the entry of p (saturated)
+            cnt += is_cand;
+            if (lvl_hist && is_cand && v[j] < 64u && j == 0 && (q & 3) == 0) atomicAdd(&sh[v[j]], 1u);     // (every 16th position)
+        }
+        ((u32*)cls)[q] = cw;
+        ((uint4*)flen)[q] = make_uint4(0, 0, 0, 0);
+        if (res8) ((u32*)res8)[q] = rw;
+    }
+    for (size_t p = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
         const u32 v = plcp[p];
-        const u32 is_cand = (v >= threshold) ? 1u : 0u;   // PLCP[n-1] = 0, so the sentinel (SA index 0) is never a candidate
+        const u32 is_cand = (v >= threshold) ? 1u : 0u;
         cls[p] = (is_cand && v > lo) ? 1 : 0;
         flen[p] = 0;
-        if (res8) res8[p] = is_cand ? (u8)(v > 255u ? 255u : v) : (u8)0;   // list that holds the entry of p (saturated)
+        if (res8) res8[p] = is_cand ? (u8)(v > 255u ? 255u : v) : (u8)0;
         cnt += is_cand;
         if (lvl_hist && is_cand && v < 64u && (p & 15) == 0) atomicAdd(&sh[v], 1u);
     }

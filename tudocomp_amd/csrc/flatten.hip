@@ -348,16 +348,16 @@ __global__ void flatten_commit_kernel(size_t z, const uint4* __restrict__ rec, u
     if (q.w != q.z) fsrc[q.x] = q.w;              // only the flattened ones moved
 }
 
-void flatten_factors(Ctx& c, size_t n, FactorSpace fs, FlattenStats* st, const std::function<void()>& between, void* rec_keep) {
+void flatten_factors(Ctx& c, size_t n, FactorSpace fs, FlattenStats* st, const std::function<void(int)>& between, void* rec_keep) {
     FlattenStats local;
     if (!st) st = &local;
     *st = FlattenStats();
-    if (n == 0) { if (between) between(); return; }
+    if (n == 0) { if (between) between(0); return; }
     hipStream_t s = c.stream;
     const size_t mark = c.arena.mark();
     u32* fpos = fs.have_list ? fs.fpos : c.arena.get<u32>(n);
     const size_t z = fs.have_list ? fs.nfact : extract_factors(c, n, fs, fpos, nullptr, nullptr, n);
-    if (z == 0) { if (between) between(); c.arena.release(mark); return; }
+    if (z == 0) { if (between) between(0); c.arena.release(mark); return; }
     uint4* rec = rec_keep ? (uint4*)rec_keep : (uint4*)c.arena.alloc(z * sizeof(uint4));
     FlattenScalars* d_sc = (FlattenScalars*)c.arena.alloc(sizeof(FlattenScalars));
     HIP_TRY(hipMemsetAsync(d_sc, 0, sizeof(FlattenScalars), s));
@@ -386,9 +386,9 @@ void flatten_factors(Ctx& c, size_t n, FactorSpace fs, FlattenStats* st, const s
             else flatten_round_kernel<false><<<cdiv(waiting, 256 * FL_K), 256, 0, s>>>(work[cur_w], waiting, n, fs.owner, rec, work[nxt], d_sc, max_steps);
             LAUNCH_CHECK();
         }
-        // (the first round is on its way: 150 M factors at 2e9 B, 55 M of them wait for the second -- the later rounds are too short
-        //  to hide anything behind: called after round 2 / 3 the stage is 0.6 ms longer, after round 4 nothing is gained)
-        if (cur_w < 0 && between) between();
+        // (this round is on its way: 150 M factors in the first one at 2e9 B, 55 M in the second, 9 M in the third; the later ones are too
+        //  short to hide anything behind)
+        if (between) between((int)st->rounds + 1);
         const u32 now = c.read(&d_sc->waiting);
         st->rounds++;
         if (getenv("TDC_GPU_LEVEL_LOG")) fprintf(stderr, "flatten round %u: %u waiting -> %u\n", st->rounds, waiting, now);
@@ -399,6 +399,7 @@ void flatten_factors(Ctx& c, size_t n, FactorSpace fs, FlattenStats* st, const s
         cur_w = nxt;
         if (max_steps < (1u << 30)) max_steps = (max_steps > (1u << 30) / flat_growth) ? (1u << 30) : max_steps * flat_growth;
     }
+    if (between) between(0);
     if (!rec_keep) {                                   // (a caller that keeps the records reads the final sources there)
         flatten_commit_kernel<<<gz, 256, 0, s>>>(z, rec, fs.fsrc);
         LAUNCH_CHECK();

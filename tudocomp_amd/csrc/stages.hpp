@@ -91,12 +91,12 @@ void factorize_max_heap(Ctx& c, size_t n, const u32* sa, const u32* isa, const u
 
 struct FlattenStats { u64 num_flattened = 0; u64 max_depth_lb = 0; u32 rounds = 0; };
 // a10: compressors/lzss/LZSSFactors.hpp:79-132 ; rewrites fs.fsrc in place.
-// `between` (optional) is called once the first round has been enqueued and before the host waits for its count: the place for work
-// that does not need the flattened sources (api.hip runs the first half of the encoder there, on another stream).  Whatever it
-// takes from the arena is gone when flatten_factors returns.
+// `between` (optional) is called with r = 1, 2, ... once round r has been enqueued and before the host waits for its count, and with 0
+// when the rounds are over: the place for work that does not need the flattened sources (api.hip runs the first half of the encoder
+// there, step by step on another stream).  Whatever it takes from the arena is gone when flatten_factors returns.
 // rec_keep (optional, room for 16 bytes per factor): the records {pos, len, original source, final source} in position order are built
 // there and stay valid for the caller; fs.fsrc is NOT rewritten then.
-void flatten_factors(Ctx& c, size_t n, FactorSpace fs, FlattenStats* st, const std::function<void()>& between = {}, void* rec_keep = nullptr);
+void flatten_factors(Ctx& c, size_t n, FactorSpace fs, FlattenStats* st, const std::function<void(int)>& between = {}, void* rec_keep = nullptr);
 
 // a9: extract the factor list sorted by pos (LZSSFactors.hpp:69-76): pos[], src[], len[] (z entries each,
 // arrays caller-provided with capacity cap).  Returns z.
@@ -121,7 +121,9 @@ size_t encode_stream(Ctx& c, const u8* text, size_t n, FactorSpace fs, int coder
 // then takes lengths and flattened sources from the records and flatten_factors leaves fs.fsrc as it is
 EncodeEarly* encode_early_reserve(Ctx& c, size_t n, size_t z_rec = 0);
 void* encode_early_rec(EncodeEarly* e);
-void encode_early_run(Ctx& c, const u8* text, size_t n, FactorSpace fs, int coder, EncodeEarly* e);
+// _run: the next of its three steps (gaps + histogram | code table, bits per tile, scans | collect), or with finish = true all that are left.
+// Only the last one waits for the device if the steps are spread over time (their read-backs travel through the mapped host area).
+void encode_early_run(Ctx& c, const u8* text, size_t n, FactorSpace fs, int coder, EncodeEarly* e, bool finish = true);
 void encode_early_free(EncodeEarly* e);
 
 // worst-case output size of encode_huff for a text of n bytes
