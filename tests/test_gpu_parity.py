@@ -102,14 +102,15 @@ def _ctx_env(env):
                 os.environ[k] = v
 
 
-@pytest.mark.parametrize("mode", ["2", "2_norec", "0"])
+@pytest.mark.parametrize("mode", ["2", "2_norec", "2_slowread", "0"])
 def test_first_half_of_the_encoder_inside_the_flatten_stage(gpu_ctx, mode):
     """TDC_GPU_ENC_EARLY: texts of 1 MiB and more run gaps / histogram / code table / bits per tile on the copy stream next to the
     first flatten round, and the pack takes lengths and flattened sources from the flatten stage's records (the default context does,
     see the medium and full-size tests); 2 does so for every text, 0 for none; TDC_GPU_ENC_REC=0 keeps the early half but packs from
-    flen[] / fsrc[].  Same streams every way, with and without factors, flatten on and off, also for the coders that never take the
+    flen[] / fsrc[]; TDC_GPU_FASTREAD=0 takes the read-backs of the steps through hipMemcpy instead of the mapped host area.  Same streams every way, with and without factors, flatten on and off, also for the coders that never take the
     early half."""
-    ctx = _ctx_env({"TDC_GPU_ENC_EARLY": mode[0], "TDC_GPU_ENC_REC": "0" if mode.endswith("norec") else "1"})
+    ctx = _ctx_env({"TDC_GPU_ENC_EARLY": mode[0], "TDC_GPU_ENC_REC": "0" if mode.endswith("norec") else "1",
+                    "TDC_GPU_FASTREAD": "0" if mode.endswith("slowread") else "1"})
     try:
         cases = list(SMALL) + list(corpus.random_small(60, seed=5)) + [("english_3M", T.gen_english(3_000_000, 8).tobytes()),
                                                                        ("dna_2M", T.gen_dna(2_000_000, 3).tobytes())]

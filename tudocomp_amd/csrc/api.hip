@@ -245,12 +245,17 @@ void run_factorize(Ctx& c, size_t n, DevArrays& A, u32 threshold, int flatten, t
         HIP_TRY(hipEventRecord(c.ev_copy[0], c.stream));                  // the factors are in place
         // one step per round (the host never waits for the copy stream while a round needs it), the rest when the rounds are over
         bool waited = false;
-        flatten_factors(c, n, A.fs, &fl, [&](int round) {
-            StreamSwap sw(c, c.copy_stream);
-            if (!waited) { HIP_TRY(hipStreamWaitEvent(c.stream, c.ev_copy[0], 0)); waited = true; }
-            if (round == 1 || round == 2) encode_early_run(c, d_text, n, A.fs, enc_coder, A.early, false);
-            else if (round == 0) encode_early_run(c, d_text, n, A.fs, enc_coder, A.early, true);
-        }, c.enc_rec ? encode_early_rec(A.early) : nullptr);
+        try {
+            flatten_factors(c, n, A.fs, &fl, [&](int round) {
+                StreamSwap sw(c, c.copy_stream);
+                if (!waited) { HIP_TRY(hipStreamWaitEvent(c.stream, c.ev_copy[0], 0)); waited = true; }
+                if (round == 1 || round == 2) encode_early_run(c, d_text, n, A.fs, enc_coder, A.early, false);
+                else if (round == 0) encode_early_run(c, d_text, n, A.fs, enc_coder, A.early, true);
+            }, c.enc_rec ? encode_early_rec(A.early) : nullptr);
+        } catch (...) {
+            (void)hipStreamSynchronize(c.copy_stream);         // nothing of this call stays behind on the second stream
+            throw;
+        }
     } else if (flatten) {
         flatten_factors(c, n, A.fs, &fl);
     }

@@ -525,7 +525,10 @@ static size_t encode_sle(Ctx& c, const u8* text, size_t n, FactorSpace fs, u32 k
 // The encoder in two halves.  The first one -- gaps, literal histogram, coder header, bits per tile, their scan -- needs the factors'
 // positions and lengths but not their sources, so the caller may run it while the factors are still being flattened (api.hip,
 // run_factorize: on the copy stream, next to the first flatten round); the second half packs the bits and needs everything.
-constexpr u32 PACK_CH = 8;
+#ifndef TDC_PACK_CH
+#define TDC_PACK_CH 16     // (8: 0.3 ms more behind the last chunk at 2e9 B, 32: the same as 16)
+#endif
+constexpr u32 PACK_CH = TDC_PACK_CH;
 struct EncodeEarly {
     // scratch; reserved ahead of the flatten stage when the first half runs inside it (arena order: these, then flatten's lists)
     u32* d_hist = nullptr; u64* tile_bits = nullptr; u64* d_tp = nullptr;   // d_hist: 256 counters + the EncScalars; d_tp: total, then PACK_CH chunk ends
