@@ -292,7 +292,6 @@ constexpr u32 SMALL_RAW = 8192;     // list entries a small level may hold befor
 // row whose lists hold 5 000 - 10 000 entries, 2 500 - 5 000 of them still alive (10^9 B of DNA: 1 383 levels, 0.36 ms each on the
 // multi-launch path against ~0.06 ms here).
 constexpr u32 SMALL_M_BIG = 4096;
-constexpr u32 SMALL_RAW_BIG = 16384;
 // ... and a third one with 1 024 threads holds 8 192 (the SLIM layout of the kernel: LDS is what limits it)
 constexpr u32 SMALL_M_SLIM = 8192;
 constexpr u32 SMALL_RAW_SLIM = 32768;

@@ -58,7 +58,6 @@ constexpr int TH_MAX = 2048;         // halo on either side: a run-time value (m
 #endif
 constexpr int TT = TDC_WIN_TT;       // threads per workgroup (the first TW / 64 of them own a 64-position chunk of the window: TT >= TW / 64)
 constexpr int TCH = 64;              // consecutive window positions per thread in the dense passes (the first TW / 64 threads own a chunk)
-constexpr int NWV = TT / 64;
 constexpr int CPT = TW / (64 * TT) > 0 ? TW / (64 * TT) : 1;   // 64-position chunks per thread in the dense passes (thread t owns the chunks t * CPT ..)
 static_assert(TW % 64 == 0 && (TW / 64 <= TT * CPT), "every chunk of the window needs an owner");
 // Two sizes of the per-level LDS lists (alive entries / pushes per level and window).  The small one leaves 40 KB of LDS

@@ -29,8 +29,6 @@ namespace tdc {
 constexpr int WS_TILE = 4096;        // records per partition tile: 256 threads x 16
 constexpr int WS_ITEMS = 16;
 constexpr int WS_HALO = 64;          // symbols staged beyond a tile (s <= 64)
-constexpr int WS_SMALL = 4096;       // (as SS_SMALL: leaves up to this size are packed into units)
-constexpr int WS_UNIT_MAX = 8192;
 #ifndef TDC_WS_CMAX
 #define TDC_WS_CMAX 64
 #endif
