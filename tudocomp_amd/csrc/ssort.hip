@@ -1279,7 +1279,10 @@ void ss_build_units(Ctx& c, const u32* leaf_start, u32 nleaf, UnitTables& U, u32
     if (wcnt) c.read_n(wcnt, U.whc, 16);
 }
 void ss_fanouts(Ctx& c, size_t n, int& L, u32 F[3], u32& os, u32 leaf3, int wide2) {
-    L = n <= (size_t)256 * 3072 ? 1 : ((n + 65535) / 65536 <= 4352 ? 2 : 3);
+    // two levels reach 65 536 leaves: beyond 3 584 pairs per leaf the largest (slowest) size class of the leaf kernels takes over and a
+    // third level is cheaper (256 MiB of text, 4 096 per leaf: suffix array 25.0 -> 20.8 ms, the call 55.9 -> 51.9 ms; 220 M, 3 357 per
+    // leaf: no difference; the limit was 4 352)
+    L = n <= (size_t)256 * 3072 ? 1 : ((n + 65535) / 65536 <= 3584 ? 2 : 3);
     if (c.ssort_levels >= 1 && c.ssort_levels <= 3) L = c.ssort_levels;
     F[0] = F[1] = F[2] = 1;
     if (leaf3 == 0) leaf3 = 2048;                              // target leaf size with three levels
