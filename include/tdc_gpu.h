@@ -135,6 +135,9 @@ int tdc_gpu_lcpcomp_compress_into(tdc_gpu_ctx* ctx, const uint8_t* text, size_t 
 int tdc_gpu_lcpcomp_compress_keep(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, uint32_t threshold, int flatten, int coder,
                                   int comp, size_t* out_len, tdc_gpu_stats* stats);
 int tdc_gpu_stream_fetch(tdc_gpu_ctx* ctx, uint8_t* dst, size_t cap, size_t* len);
+/* The same with a DEVICE destination on the context's GPU (e.g. the send buffer of an RCCL gather of the per-block streams to one
+ * rank, SURVEY.md 8e "Collective"): a device-to-device copy on the context's stream, synchronised before the call returns. */
+int tdc_gpu_stream_fetch_dev(tdc_gpu_ctx* ctx, void* d_dst, size_t cap, size_t* len);
 /* Page-lock / release host memory the embedding program allocated itself (hipHostRegister): transfers then run at PCIe rate. */
 int tdc_gpu_host_register(void* p, size_t bytes);
 int tdc_gpu_host_unregister(void* p);
@@ -218,6 +221,9 @@ int tdc_gpu_lcpcomp_decompress(tdc_gpu_ctx* ctx, const uint8_t* stream, size_t l
  * coders/ASCIICoder.hpp:53-84) or TDC_GPU_CODER_SLE / TDC_GPU_CODER_SLE_K(k) (SLECoder::Decoder, coders/SLECoder.hpp:301-453). */
 int tdc_gpu_lcpcomp_decompress_coder(tdc_gpu_ctx* ctx, const uint8_t* stream, size_t len, int coder, uint8_t** out, size_t* out_len,
                                      uint64_t* factors, uint32_t* rounds);
+/* 1 if the last tdc_gpu_lcpcomp_decompress(_coder) call on this context parsed the token stream on the device (coder=huff streams
+ * of 1 MiB and more whose longest literal run is at most 512; env TDC_GPU_DEC_PARSE = 0 never / 2 every size), 0 if on the host. */
+int tdc_gpu_ctx_last_decode_on_device(const tdc_gpu_ctx* ctx);
 
 /* HuffmanCoder::Encoder + lzss::encode_text on a caller-supplied factor list sorted by pos (LZSSCoding.hpp:18-92) */
 int tdc_gpu_encode_huff(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, const uint32_t* pos, const uint32_t* src,

@@ -86,6 +86,8 @@ def test_huffman_selfcheck_passes_and_fixture_is_current():
     assert L.tdc_huffman_selfcheck() == 0
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     inc = os.path.join(root, "tudocomp_amd", "csrc", "huffman_selfcheck.inc")
-    before = open(inc).read()
-    subprocess.check_call([sys.executable, os.path.join(root, "tools", "make_huffman_selfcheck.py")], stdout=subprocess.DEVNULL)
-    assert open(inc).read() == before
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:        # (never rewrites the tracked file: a new mtime would make `make` relink the library)
+        fresh = os.path.join(tmp, "huffman_selfcheck.inc")
+        subprocess.check_call([sys.executable, os.path.join(root, "tools", "make_huffman_selfcheck.py"), fresh], stdout=subprocess.DEVNULL)
+        assert open(fresh).read() == open(inc).read()

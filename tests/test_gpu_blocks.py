@@ -157,3 +157,40 @@ def test_blocks_container_of_several_megabytes(gpu_ctx):
         single, _ = gpu_ctx.lcpcomp_compress_raw(data[k * block_size:(k + 1) * block_size], 2, 1)
         assert bytes(payload) == single, k
     assert gpu_ctx.blocks_decompress(blob) == data
+
+
+def test_bench_launches_its_own_ranks_two_rank_rehearsal(gpu_ctx):
+    """`python bench.py --gpus 2` WITHOUT torchrun's environment: the parent runs the CPU baseline and starts the two ranks as a child
+    process (torch.distributed.run); both ranks share this box's one GPU, the collectives run on the gloo backend.  The line must carry
+    both exchange variants (shared host memory = value, the gather to rank 0 beside it), the roofline object and the CPU baseline."""
+    import json
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["TDC_BENCH_BACKEND"] = "gloo"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size", str(1 << 24), "--steps", "2", "--warmup", "1",
+                        "--cpu-sample", str(1 << 22), "--cpu-multi-sample", str(1 << 20), "--no-extra"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["ranks_seen"] == 2 and j["world_size"] == 2
+    assert j["exchange"] == "shared host memory" and j["container_ok"] is True
+    assert j["rccl_gather"]["container_ok"] is True and j["rccl_gather"]["value"] > 0
+    assert j["roofline"]["achieved"] > 0 and j["cpu_baseline"]["value"] > 0 and j["cpu_baseline"]["bit_exact_vs_gpu_on_sample"] is True
+    assert j["value"] > 0 and j["scaling"] == "weak"
+
+
+def test_kept_stream_is_fetched_to_device_memory(gpu_ctx):
+    """tdc_gpu_stream_fetch_dev: the kept stream as the send buffer of the RCCL gather (device-to-device)"""
+    import torch
+    data = T.gen_english(2_000_000, 5).tobytes()
+    text = O.escape(data)
+    want, _ = O.lcpcomp_huff_compress(text, 2, 1)
+    ta = np.frombuffer(text, dtype=np.uint8)
+    ln, _ = gpu_ctx.lcpcomp_compress_keep(ta, len(ta), 2, 1)
+    d = torch.zeros(ln + 64, dtype=torch.uint8, device="cuda:0")
+    assert gpu_ctx.stream_fetch_dev(d.data_ptr(), d.numel()) == ln
+    assert bytes(d[:ln].cpu().numpy()) == want
+    with pytest.raises(T.TdcGpuError):
+        gpu_ctx.stream_fetch_dev(d.data_ptr(), ln - 1)

@@ -1,0 +1,125 @@
+"""GPU tests of the device-side parse of the lcpcomp(coder=huff) token stream (pytest -m gpu; SURVEY 8f #2, first half:
+decode_text_internal, compressors/LCPCompressor.hpp:23-76, with HuffmanCoder::Decoder, coders/HuffmanCoder.hpp:377-397 / :572-612).
+
+A context created with TDC_GPU_DEC_PARSE=2 parses EVERY stream on the device (the default takes streams of 1 MiB and more), so the
+small corpus, random inputs, the reference-held decode vectors and damaged streams all go through the next() / chain-marking /
+count / scan / emit kernels; the oracle's streams must decode to the oracle's texts, damaged streams must be refused, never crash."""
+import os
+
+import numpy as np
+import pytest
+
+import tudocomp_amd as T
+from oracle import oracle as O
+from tests import corpus
+from tests.util import load_json, decode_sequence_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev_ctx():
+    old = os.environ.get("TDC_GPU_DEC_PARSE")
+    os.environ["TDC_GPU_DEC_PARSE"] = "2"
+    try:
+        ctx = T.Context(0)
+    finally:
+        if old is None:
+            del os.environ["TDC_GPU_DEC_PARSE"]
+        else:
+            os.environ["TDC_GPU_DEC_PARSE"] = old
+    yield ctx
+    ctx.close()
+
+
+def _decodable(stream, text):
+    try:
+        return O.lcpcomp_huff_decompress(stream) == text
+    except RuntimeError:
+        return False
+
+
+def test_small_corpus_streams_parse_on_the_device(dev_ctx):
+    cases = corpus.small_corpus() + [("english_300k", T.gen_english(300_000, 9).tobytes()), ("dna_200k", T.gen_dna(200_000, 7).tobytes())]
+    on_device = 0
+    for name, data in cases:
+        text = O.escape(data)
+        for thr, fl in ((1, 1), (2, 0), (2, 1), (5, 1)):
+            stream, _ = O.lcpcomp_huff_compress(text, thr, fl)
+            if not _decodable(stream, text):          # (256 equal-length codes: the reference cannot decode it either)
+                try:
+                    dev_ctx.lcpcomp_decompress(stream)
+                except T.TdcGpuError:
+                    pass
+                continue
+            back, st = dev_ctx.lcpcomp_decompress(stream)
+            assert back == text, "%s t=%d flatten=%d" % (name, thr, fl)
+            on_device += st["device_parse"]
+        s2, _ = O.lzss_lcp_huff_compress(text, 3)     # same format (LZSSLCPCompressor.hpp:125-130)
+        assert dev_ctx.lcpcomp_decompress(s2)[0] == text, name
+    assert on_device > len(cases)                     # (streams whose longest literal run exceeds 512 keep the host parse)
+
+
+def test_reference_decode_sequences_on_the_device(dev_ctx):
+    for k in load_json("reference_kats.json")["decode_sequences"]:
+        text, f = decode_sequence_case(k)
+        stream, _ = O.encode_huff(text, f)
+        back, st = dev_ctx.lcpcomp_decompress(stream)
+        assert back == text and st["device_parse"] == 1 and st["factors"] == len(f), k["source"]
+
+
+def test_random_texts_roundtrip_through_the_device_parse(dev_ctx):
+    rng = np.random.default_rng(99)
+    for trial in range(40):
+        sigma = int(rng.integers(2, 60))
+        n = int(rng.integers(50, 40_000))
+        base = rng.integers(1, sigma + 1, size=n, dtype=np.uint8) + 64
+        # planted repeats so that factors of many lengths occur
+        for _ in range(int(rng.integers(0, 30))):
+            a, l = int(rng.integers(0, n)), int(rng.integers(2, 300))
+            b = int(rng.integers(0, n))
+            l = min(l, n - a, n - b)
+            base[b:b + l] = base[a:a + l].copy()
+        text = O.escape(base.tobytes())
+        thr = int(rng.integers(1, 7))
+        stream, _ = O.lcpcomp_huff_compress(text, thr, int(rng.integers(0, 2)))
+        back, st = dev_ctx.lcpcomp_decompress(stream)
+        assert back == text, trial
+
+
+def test_large_stream_takes_the_device_parse_by_default(gpu_ctx):
+    """32 MiB English through the product's default decoder path: device parse, references on the device"""
+    data = T.gen_english(1 << 25, 42)
+    text = np.concatenate([data, np.zeros(1, dtype=np.uint8)]).tobytes()
+    got, cst = gpu_ctx.lcpcomp_compress(text, 2, 1)
+    back, st = gpu_ctx.lcpcomp_decompress(got)
+    assert back == text and st["device_parse"] == 1 and st["factors"] == cst["factors"]
+    got5, cst5 = gpu_ctx.lcpcomp_compress(text, 5, 0)
+    back, st = gpu_ctx.lcpcomp_decompress(got5)
+    assert back == text and st["device_parse"] == 1 and st["factors"] == cst5["factors"]
+    dna = np.concatenate([T.gen_dna(1 << 24, 7), np.zeros(1, dtype=np.uint8)]).tobytes()
+    gd, cd = gpu_ctx.lcpcomp_compress(dna, 5, 1)
+    back, st = gpu_ctx.lcpcomp_decompress(gd)
+    assert back == dna and st["factors"] == cd["factors"]
+
+
+def test_damaged_streams_are_refused_by_the_device_parse(dev_ctx):
+    text = O.escape(T.gen_english(20_000, 3).tobytes())
+    good = O.lcpcomp_huff_compress(text, 2, 1)[0]
+    assert dev_ctx.lcpcomp_decompress(good)[0] == text
+    rng = np.random.default_rng(5)
+    refused = 0
+    for trial in range(150):
+        bad = bytearray(good)
+        where = int(rng.integers(0, len(bad)))        # anywhere: header, table, tokens, terminator
+        bad[where] ^= 1 << int(rng.integers(0, 8))
+        try:
+            back, _ = dev_ctx.lcpcomp_decompress(bytes(bad))
+            assert len(back) > 0                      # (a flipped literal bit may still be a well-formed stream)
+        except T.TdcGpuError as e:
+            assert e.status in (-2, -5)
+            refused += 1
+    assert refused > 0
+    for bad in (b"", b"\x00", good[:1000], good[:len(good) // 2] + b"\x05"):
+        with pytest.raises(T.TdcGpuError):
+            dev_ctx.lcpcomp_decompress(bad)

@@ -11,9 +11,23 @@ import pytest
 
 import tudocomp_amd as T
 from oracle import oracle as O
-from tests.util import sha256
+from tests.util import sha256, load_json
 
 pytestmark = pytest.mark.gpu
+
+# size + SHA-256 of the ORACLE's streams at full size (tests/make_fullsize_golden.py; minutes and tens of GB per entry, so they are
+# committed instead of recomputed): the device stream is compared with them byte for byte, by hash
+FULL = load_json("oracle_fullsize.json")
+
+
+def _assert_golden(name, stream, st=None):
+    g = FULL[name]
+    assert len(stream) == g["size"], (name, len(stream), g["size"])
+    assert sha256(stream) == g["sha256"], name
+    if st is not None:
+        for k in ("factors", "num_flattened", "maxlcp"):
+            if k in g:
+                assert st[k] == g[k], (name, k, st[k], g[k])
 
 
 class _Bits:
@@ -70,6 +84,8 @@ def test_metric_config_2e9_end_to_end(gpu_ctx):
         assert st["n"] == n and st["out_len"] == out_len and 0 < out_len < N
         assert st["ms_h2d"] > 0 and st["ms_d2h"] > 0 and st["ms_total"] >= st["ms_h2d"] + st["ms_d2h"]
         stream = h_out.a[:out_len]
+        assert sha256(h_text.a[:N]) == FULL["english_2e9"]["text_sha256"]
+        _assert_golden("english_2e9", stream, st)          # byte for byte (by hash) the oracle's stream of the same 2*10^9 B text
         hn, fmin, fmax, dmax = _header(stream)
         assert (hn, fmin, fmax, dmax) == (n, st["flen_min"], st["flen_max"], st["fdist_max"])
         assert fmin >= 2 and fmax <= st["maxlcp"]
@@ -93,6 +109,24 @@ def test_metric_config_2e9_end_to_end(gpu_ctx):
     finally:
         h_text.free()
         h_out.free()
+
+
+def test_configs1_english_256MiB_golden(gpu_ctx):
+    """BASELINE configs[1] through the end-to-end entry point against the committed oracle hash"""
+    N = 1 << 28
+    text = np.concatenate([T.gen_english(N, 42), np.zeros(1, dtype=np.uint8)])
+    assert sha256(text[:N]) == FULL["english_256MiB"]["text_sha256"]
+    got, st = gpu_ctx.lcpcomp_compress(text, 2, 1)
+    _assert_golden("english_256MiB", got, st)
+
+
+def test_configs2_dna_1e9_arith_golden(gpu_ctx):
+    """BASELINE configs[2] at its full size (10^9 B DNA, LCPCompressor + ArithmeticCoder, threshold 5) against the committed oracle hash"""
+    N = 10**9
+    text = np.concatenate([T.gen_dna(N, 7), np.zeros(1, dtype=np.uint8)])
+    assert sha256(text[:N]) == FULL["dna_1e9_arith"]["text_sha256"]
+    got, st = gpu_ctx.lcpcomp_compress(text, 5, 1, T.CODER_ARITH)
+    _assert_golden("dna_1e9_arith", got, st)
 
 
 def test_config2_arithmetic_dna_256MiB(gpu_ctx):

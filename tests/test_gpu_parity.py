@@ -462,6 +462,20 @@ def test_lcpcomp_max_lcp_strategy(gpu_ctx):
     assert c.decompress(c.compress(data)) == data
 
 
+def test_device_decompress_reference_sequences(gpu_ctx):
+    """the three literal / factor sequences of test/lzss_test.cpp:141-189 (back references, chained forward references, several
+    forward references into one factor; golden/reference_kats.json) through the device encoder and the device's reference resolver"""
+    from tests.util import decode_sequence_case
+    for k in load_json("reference_kats.json")["decode_sequences"]:
+        text, f = decode_sequence_case(k)
+        stream = gpu_ctx.encode_huff(text, f["pos"], f["src"], f["len"])
+        assert stream == O.encode_huff(text, f)[0], k["source"]
+        back, st = gpu_ctx.lcpcomp_decompress(stream)
+        assert back == text and st["factors"] == len(f), k["source"]
+        a = gpu_ctx.encode_ascii(text, f["pos"], f["src"], f["len"])
+        assert gpu_ctx.lcpcomp_decompress(a, T.CODER_ASCII)[0] == text, k["source"]
+
+
 def test_device_decompress_rejects_corrupt_tables(gpu_ctx):
     """fuzzed Huffman tables / headers: the host parse in front of the device resolver refuses or decodes, never reads
     behind its tables"""

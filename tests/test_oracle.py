@@ -4,7 +4,7 @@ import pytest
 
 from oracle import oracle as O
 from tests import corpus
-from tests.util import load_json, pack_fields, sha256, naive_suffix_array
+from tests.util import load_json, pack_fields, sha256, naive_suffix_array, decode_sequence_case
 
 KATS = load_json("reference_kats.json")
 ANCH = load_json("survey_anchors.json")
@@ -47,6 +47,16 @@ def test_huffman_stream_kats(k):
 def test_text_literals_kats(k):
     f = np.array([tuple(x) for x in k["factors"]], dtype=O.FACTOR_DTYPE)
     assert list(O.literal_positions(k["n"], f)) == k["positions"]
+
+
+@pytest.mark.parametrize("k", KATS["decode_sequences"], ids=lambda k: k["source"][:24])
+def test_decode_sequence_kats(k):
+    """test/lzss_test.cpp:141-189: back references, chained forward references and several forward references into one factor all
+    decode to "bananabanana" -- the only vectors the reference holds for the forest resolution of LCPCompressor::decompress"""
+    text, f = decode_sequence_case(k)
+    stream, _ = O.encode_huff(text, f)
+    assert O.lcpcomp_huff_decompress(stream) == text
+    assert O.lcpcomp_ascii_decompress(O.encode_ascii(text, f)[0]) == text
 
 
 @pytest.mark.parametrize("k", KATS["lz78_factors"], ids=lambda k: k["source"])

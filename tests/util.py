@@ -35,3 +35,20 @@ def factors_struct(pos, src, length):
     f = np.empty(len(pos), dtype=O.FACTOR_DTYPE)
     f["pos"], f["src"], f["len"] = pos, src, length
     return f
+
+
+def decode_sequence_case(k):
+    """a literal / factor(src, len) sequence of the reference's decode-buffer tests (golden/reference_kats.json "decode_sequences")
+    -> (0-terminated text the sequence must decode to, its factors as a FACTOR_DTYPE array in position order).  The literals of the
+    sequence are checked against the expected text on the way."""
+    want = k["expected"].encode()
+    pos, src, length, p = [], [], [], 0
+    for tok in k["tokens"]:
+        if tok[0] == "lit":
+            assert want[p:p + 1] == tok[1].encode(), (k["source"], p)
+            p += 1
+        else:
+            pos.append(p); src.append(tok[1]); length.append(tok[2])
+            p += tok[2]
+    assert p == len(want)
+    return want + b"\0", factors_struct(pos, src, length)

@@ -243,6 +243,12 @@ class Context:
         self._check(self._L.tdc_gpu_stream_fetch(self._h, _ptr(oa), oa.size, ctypes.byref(ln)))
         return ln.value
 
+    def stream_fetch_dev(self, d_dst, cap):
+        """copy the kept stream to device memory of this context's GPU (`d_dst`: raw device pointer, `cap` bytes).  Returns its length."""
+        ln = ctypes.c_size_t()
+        self._check(self._L.tdc_gpu_stream_fetch_dev(self._h, ctypes.c_void_p(d_dst), cap, ctypes.byref(ln)))
+        return ln.value
+
     def lcpcomp_compress_raw(self, data, threshold=5, flatten=1, coder=CODER_HUFF):
         """data: unrestricted input; escaping + sentinel happen on the device.  Returns (compressed bytes, stats dict)."""
         a = _u8(data)
@@ -319,7 +325,8 @@ class Context:
         f, r = ctypes.c_uint64(), ctypes.c_uint32()
         self._check(self._L.tdc_gpu_lcpcomp_decompress_coder(self._h, _ptr(a), len(a), coder, ctypes.byref(p), ctypes.byref(n),
                                                              ctypes.byref(f), ctypes.byref(r)))
-        return self._take(p, n.value), {"factors": f.value, "rounds": r.value}
+        return self._take(p, n.value), {"factors": f.value, "rounds": r.value,
+                                        "device_parse": int(self._L.tdc_gpu_ctx_last_decode_on_device(self._h))}
 
     def blocks_decompress(self, blob, coder=CODER_HUFF):
         """inverse of blocks_compress on this context's device: the concatenated raw bytes"""

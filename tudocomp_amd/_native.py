@@ -23,10 +23,10 @@ SYMBOLS = [
     "tdc_gpu_encode_arith",
     "tdc_gpu_encode_ascii",
     "tdc_gpu_encode_sle",
-    "tdc_gpu_lcpcomp_decompress_coder",
+    "tdc_gpu_lcpcomp_decompress_coder", "tdc_gpu_ctx_last_decode_on_device",
     "tdc_escape", "tdc_unescape", "tdc_huffman_table", "tdc_huffman_selfcheck", "tdc_gpu_blocks_count", "tdc_gpu_blocks_compress", "tdc_gpu_blocks_decompress", "tdc_gpu_device_count", "tdc_gen_english", "tdc_gen_dna",
     "tdc_gpu_arena_bytes", "tdc_gpu_device_memory",
-    "tdc_gpu_lcpcomp_compress_keep", "tdc_gpu_stream_fetch", "tdc_gpu_host_register", "tdc_gpu_host_unregister",
+    "tdc_gpu_lcpcomp_compress_keep", "tdc_gpu_stream_fetch", "tdc_gpu_stream_fetch_dev", "tdc_gpu_host_register", "tdc_gpu_host_unregister",
 ]
 
 
@@ -92,6 +92,8 @@ def load():
     L.tdc_gpu_lcpcomp_compress_into.argtypes = [vp, vp, sz, u32, i32, i32, i32, vp, sz, psz, ctypes.POINTER(Stats)]
     L.tdc_gpu_lcpcomp_compress_keep.argtypes = [vp, vp, sz, u32, i32, i32, i32, psz, ctypes.POINTER(Stats)]
     L.tdc_gpu_stream_fetch.argtypes = [vp, vp, sz, psz]
+    L.tdc_gpu_stream_fetch_dev.argtypes = [vp, vp, sz, psz]
+    L.tdc_gpu_ctx_last_decode_on_device.argtypes = [vp]
     L.tdc_gpu_host_register.argtypes = [vp, sz]
     L.tdc_gpu_host_unregister.argtypes = [vp]
     L.tdc_gpu_blocks_count.argtypes = [sz, sz]

@@ -102,6 +102,16 @@ class SharedContainer:
         _, end = payload_offsets(sizes)
         return bytes(self.a[:end])
 
+    def unlink(self):
+        """remove the name from /dev/shm (rank 0, once every rank has mapped the segment): the mappings stay valid, and nothing is
+        left behind -- holding host memory until reboot -- if a rank is killed before close()"""
+        if self.created:
+            try:
+                os.unlink(self.path)
+            except OSError:
+                pass
+            self.created = False
+
     def close(self, host_unregister=None):
         if self.registered and host_unregister is not None:
             host_unregister(self.a)

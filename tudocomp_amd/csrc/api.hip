@@ -16,6 +16,7 @@ struct tdc_gpu_ctx {
     Ctx c;
     WPre pre;                   // level 1 of the suffix sort behind the upload (compress_host); c.wpre points here
     std::string last_error;
+    int last_decode_device = 0; // the last decompression parsed its token stream on the device
     const u8* kept = nullptr;   // tdc_gpu_lcpcomp_compress_keep: the stream of the last call, in the arena (until the next call)
     size_t kept_len = 0;
 };
@@ -365,6 +366,7 @@ int tdc_gpu_ctx_create(int device, tdc_gpu_ctx** out) {
         if (const char* m = getenv("TDC_GPU_RADIX_WAVES")) ctx->c.radix_waves = (atoi(m) == 8) ? 8 : 4;
         if (const char* m = getenv("TDC_GPU_WINDOW_LCUT")) { const int v = atoi(m); ctx->c.window_lcut = v < 0 ? 0 : (v > 63 ? 63 : v); }
         if (const char* m = getenv("TDC_GPU_WINDOW_HALO")) { const int v = atoi(m); ctx->c.window_halo = v < 0 ? 0 : (v > 2048 ? 2048 : v); }
+        if (const char* m = getenv("TDC_GPU_DEC_PARSE")) { const int v = atoi(m); ctx->c.dec_parse = v < 0 ? 0 : (v > 2 ? 2 : v); }
         if (const char* m = getenv("TDC_GPU_WINDOW_LARGE")) ctx->c.window_large_lists = atoi(m) ? 1 : 0;
         if (const char* m = getenv("TDC_GPU_PLCP_SAMPLES")) ctx->c.plcp_samples = atoi(m) != 0;
         if (const char* m = getenv("TDC_GPU_SMALL_PIPELINE")) ctx->c.small_pipeline = atoi(m) != 0;
@@ -652,6 +654,21 @@ int tdc_gpu_stream_fetch(tdc_gpu_ctx* ctx, uint8_t* dst, size_t cap, size_t* len
         if (len) *len = kept_len;
         if (!dst || cap < kept_len) throw ArgError{TDC_GPU_ERR_OOM, "destination too small (*len holds the stream length)"};
         if (kept_len) HIP_TRY(hipMemcpyAsync(dst, kept, kept_len, hipMemcpyDeviceToHost, ctx->c.stream));
+        HIP_TRY(hipStreamSynchronize(ctx->c.stream));
+    });
+    ctx->kept = kept; ctx->kept_len = kept_len;      // (may be fetched again)
+    return rc;
+}
+
+int tdc_gpu_stream_fetch_dev(tdc_gpu_ctx* ctx, void* d_dst, size_t cap, size_t* len) {
+    if (!ctx) return TDC_GPU_ERR_ARG;
+    const u8* kept = ctx->kept;
+    const size_t kept_len = ctx->kept_len;
+    const int rc = guarded(ctx, [&] {
+        if (!kept) throw ArgError{TDC_GPU_ERR_ARG, "no stream is kept on this context (tdc_gpu_lcpcomp_compress_keep, and no other call since)"};
+        if (len) *len = kept_len;
+        if (!d_dst || cap < kept_len) throw ArgError{TDC_GPU_ERR_OOM, "destination too small (*len holds the stream length)"};
+        if (kept_len) HIP_TRY(hipMemcpyAsync(d_dst, kept, kept_len, hipMemcpyDeviceToDevice, ctx->c.stream));
         HIP_TRY(hipStreamSynchronize(ctx->c.stream));
     });
     ctx->kept = kept; ctx->kept_len = kept_len;      // (may be fetched again)
@@ -947,8 +964,11 @@ int tdc_gpu_lcpcomp_decompress_coder(tdc_gpu_ctx* ctx, const uint8_t* stream, si
         *out = h.release<uint8_t>(); *out_len = n;
         if (factors) *factors = ds.factors;
         if (rounds) *rounds = ds.rounds;
+        ctx->last_decode_device = (int)ds.device_parse;
     });
 }
+
+int tdc_gpu_ctx_last_decode_on_device(const tdc_gpu_ctx* ctx) { return ctx ? ctx->last_decode_device : 0; }
 
 static int encode_entry(tdc_gpu_ctx* ctx, int coder, const uint8_t* text, size_t n, const uint32_t* pos, const uint32_t* src,
                         const uint32_t* len, size_t z, uint8_t** out, size_t* out_len);

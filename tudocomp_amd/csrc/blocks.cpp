@@ -13,6 +13,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <memory>
 #include <thread>
 #include <vector>
 
@@ -86,9 +87,12 @@ int tdc_gpu_blocks_compress(const int* devices, int ndev, const uint8_t* data, s
         int rc = status.load();
         size_t total = MAGIC_LEN + 4 + 16 * G;
         for (size_t k = 0; k < G; ++k) total += lens[k];
-        uint8_t* blob = nullptr;
-        if (rc == TDC_GPU_OK && !(blob = (uint8_t*)malloc(total ? total : 1))) rc = TDC_GPU_ERR_OOM;
+        // (owned until it is handed to the caller: an exception below -- the offset table, a copy thread -- must not leak gigabytes)
+        struct Free { void operator()(uint8_t* p) const { free(p); } };
+        std::unique_ptr<uint8_t, Free> blob_own;
+        if (rc == TDC_GPU_OK) { blob_own.reset((uint8_t*)malloc(total ? total : 1)); if (!blob_own) rc = TDC_GPU_ERR_OOM; }
         if (rc == TDC_GPU_OK) {
+            uint8_t* blob = blob_own.get();
             memcpy(blob, MAGIC, MAGIC_LEN);
             put_u32(blob + MAGIC_LEN, (uint32_t)G);
             size_t dir = MAGIC_LEN + 4, pay = dir + 16 * G;
@@ -99,21 +103,26 @@ int tdc_gpu_blocks_compress(const int* devices, int ndev, const uint8_t* data, s
                 at[k] = pay; pay += lens[k];
             }
             // the payloads into place: a 2 GB block leaves 0.7 GB of stream, one thread copies that at ~8 GB/s -- several blocks are
-            // copied side by side (the copies are independent; if a thread cannot be started the loop below does it all)
+            // copied side by side (the copies are independent).  Thread i owns the blocks i, i + nt, ..; if only `started` threads could
+            // be created, the calling thread copies the blocks of the others -- never a block a running thread owns.
             const size_t nt = (total > ((size_t)1 << 20) && G > 1) ? (G < 8 ? G : 8) : 1;
-            bool copied = false;
-            if (nt > 1) {
-                try {
-                    std::vector<std::thread> ct;
-                    struct Joiner { std::vector<std::thread>& t; ~Joiner() { for (auto& x : t) if (x.joinable()) x.join(); } } cj{ct};
-                    ct.reserve(nt);
-                    for (size_t i = 0; i < nt; ++i)
-                        ct.emplace_back([&, i] { for (size_t k = i; k < G; k += nt) memcpy(blob + at[k], streams[k], lens[k]); });
-                    copied = true;
-                } catch (...) { copied = false; }
-            }
-            if (!copied) for (size_t k = 0; k < G; ++k) memcpy(blob + at[k], streams[k], lens[k]);
-            *out = blob; *out_len = total;
+            size_t started = 0;
+            {
+                std::vector<std::thread> ct;
+                struct Joiner { std::vector<std::thread>& t; ~Joiner() { for (auto& x : t) if (x.joinable()) x.join(); } } cj{ct};
+                if (nt > 1) {
+                    try {
+                        ct.reserve(nt);
+                        for (size_t i = 0; i < nt; ++i) {
+                            ct.emplace_back([&, i] { for (size_t k = i; k < G; k += nt) memcpy(blob + at[k], streams[k], lens[k]); });
+                            ++started;
+                        }
+                    } catch (...) {}
+                }
+                for (size_t i = started; i < nt; ++i)
+                    for (size_t k = i; k < G; k += nt) memcpy(blob + at[k], streams[k], lens[k]);
+            }                                                                   // (copy threads joined here)
+            *out = blob_own.release(); *out_len = total;
         }
         return rc;
     } catch (const std::bad_alloc&) {

@@ -91,56 +91,247 @@ __global__ void ref_copy_kernel(const u32* __restrict__ ref, size_t n, u8* text)
     if (q != NONE32) text[p] = text[q];          // q is a literal position: never written by this kernel
 }
 
+constexpr unsigned LUT_BITS = 12;
+
+// ============================================================================================================
+// Device parse of the Huffman-coded token stream (first half).
+//
+// The stream has no synchronisation points, but "where does the token that starts at bit x end" is a function of the bits behind x
+// alone:   next(x) = x + 1 [+ dbits + the r literal codes] + W + lbits      (LZSSCoding.hpp:57-80 / decode_text_internal :23-76)
+// It is evaluated for EVERY bit position of the stream in parallel (a candidate whose run length exceeds fdist_max is no token: the
+// field bounds the work of a candidate), the real token starts are the orbit of the first token start under next() -- marked by the
+// hierarchical chain marking the lzss_lcp parse and the arithmetic coder's flush points use (prim.hip mark_orbit_u32) --, and the
+// tokens are then decoded side by side: count pass (literals + factor length per token), exclusive scan = text positions, emit
+// pass (literal bytes, factor list).  Streams above 2^30 bits take several segments, the exit of one is the entry of the next.
+// Streams whose longest literal run exceeds DEC_MAX_RUN (poorly compressible inputs: a candidate would decode thousands of
+// codes) keep the sequential host parse.
+// ============================================================================================================
+struct DevTab {                     // Huffman decode tables as the host parser builds them (HuffHeader)
+    u16 lut[1 << LUT_BITS];
+    u64 firstcode[64];
+    u32 prefix_sum[64];
+    u32 longest, sigma, have_table, pad;
+    u8 numl[64];
+    u8 order[256];
+};
+static_assert(sizeof(DevTab) % 4 == 0, "copied word by word");
+struct ParseParams { u64 total, n, flen_min; u32 W, lbits, dbits, fdist_max; };
+constexpr u64 DEC_MAX_RUN = 512;            // longest literal run (fdist_max) the device parse takes
+constexpr u32 DEC_TILE = 32768;             // bit positions per workgroup of the next() pass
+constexpr size_t DEC_SEG = (size_t)1 << 30; // bit positions per segment of the chain marking
+
+// 64 stream bits from absolute bit position x on (MSB first), zeros behind `total` (BitIStream reads zeros at eof).  `words` are the
+// stream's 32-bit words, byte-swapped so that bit 31 of word k is stream bit 32 k; word index kb is words[0].
+struct BitWin {
+    const u32* words; u64 kb; u64 total;
+    __device__ __forceinline__ u64 peek(u64 x) const {
+        if (x >= total) return 0ull;
+        const u64 k = (x >> 5) - kb;
+        const u32 sh = (u32)x & 31u;
+        const u64 hi = ((u64)words[k] << 32) | words[k + 1];
+        u64 w = sh ? (hi << sh) | (u64)(words[k + 2] >> (32 - sh)) : hi;
+        if (x + 64 > total) w &= ~0ull << (64 - (total - x));
+        return w;
+    }
+};
+// the same over the stream in global memory (bytes; the buffer is padded with 16 zero bytes)
+struct BitWinG {
+    const u32* s32; u64 total;
+    __device__ __forceinline__ u64 peek(u64 x) const {
+        if (x >= total) return 0ull;
+        const u64 k = x >> 5;
+        const u32 sh = (u32)x & 31u;
+        const u32 a = __builtin_bswap32(s32[k]), b = __builtin_bswap32(s32[k + 1]), c = __builtin_bswap32(s32[k + 2]);
+        const u64 hi = ((u64)a << 32) | b;
+        u64 w = sh ? (hi << sh) | (u64)(c >> (32 - sh)) : hi;
+        if (x + 64 > total) w &= ~0ull << (64 - (total - x));
+        return w;
+    }
+};
+
+// huffman_decode (HuffmanCoder.hpp:377-397) on a 64-bit window: code length (0: no code of the table) and symbol
+__device__ __forceinline__ u32 dec_code(const DevTab* T, u64 w, u32& sym) {
+    if (!T->have_table) { sym = (u32)(w >> 56); return 8u; }                     // :606-607
+    const u32 e = T->lut[w >> (64 - LUT_BITS)];
+    if (e) { sym = e >> 4; return e & 15u; }
+    u64 value = 0; u32 length = 0;
+    do { value = (value << 1) | ((w >> (63 - length)) & 1u); ++length; } while (length <= T->longest && value < T->firstcode[length - 1]);
+    if (length > T->longest) return 0u;
+    --length;
+    const u64 off = value - T->firstcode[length];
+    if (off >= T->numl[length] || T->prefix_sum[length] + off >= T->sigma) return 0u;
+    sym = T->order[T->prefix_sum[length] + off];
+    return length + 1;
+}
+
+// The token that starts at bit x.  Returns 0: literals + factor, 1: literals, then the stream ends (:83-91), < 0: no token.
+template <typename Win, typename Lit>
+__device__ __forceinline__ int dec_token(const Win& bw, u64 x, const ParseParams& P, const DevTab* T, Lit&& lit, u64& next, u32& r, u32& src, u32& len) {
+    r = 0; src = 0; len = 0; next = x;
+    if (x >= P.total) return -1;
+    u64 w = bw.peek(x);
+    u64 y = x + 1;
+    if (w >> 63) {
+        r = (u32)((w << 1) >> (64 - P.dbits));
+        y += P.dbits;
+        if (r > P.fdist_max) return -2;
+        for (u32 i = 0; i < r; ++i) {
+            u32 sym = 0;
+            const u32 l = dec_code(T, bw.peek(y), sym);
+            if (!l) return -3;
+            lit(i, (u8)sym);
+            y += l;
+        }
+        if (y > P.total) return -4;
+    }
+    if (y >= P.total) { next = y; return 1; }
+    w = bw.peek(y);
+    src = (u32)(w >> (64 - P.W));
+    len = (u32)P.flen_min + (u32)((w << P.W) >> (64 - P.lbits));
+    y += P.W + P.lbits;
+    if (y > P.total) return -5;
+    next = y;
+    return 0;
+}
+
+__device__ __forceinline__ void dec_tab_to_lds(const DevTab* g, DevTab* l) {
+    const u32* a = (const u32*)g; u32* b = (u32*)l;
+    for (u32 i = threadIdx.x; i < sizeof(DevTab) / 4; i += blockDim.x) b[i] = a[i];
+}
+
+// next() for the bit positions x_in .. x_in + m - 1 (array index = position - x_in; m = "leaves the segment"; no token: m as well --
+// the chain ends there and the count pass reports it)
+__global__ __launch_bounds__(256) void dec_next_kernel(const u32* __restrict__ s32, u64 x_in, u32 m, ParseParams P, const DevTab* __restrict__ gT,
+                                                        u32 nwords, u32* __restrict__ next) {
+    extern __shared__ __attribute__((aligned(16))) u32 dyn[];
+    DevTab* T = (DevTab*)dyn;
+    u32* sw = dyn + sizeof(DevTab) / 4;
+    dec_tab_to_lds(gT, T);
+    const u32 i0 = blockIdx.x * DEC_TILE;
+    const u64 a0 = x_in + i0;
+    const u64 kb = a0 >> 5;
+    const u64 wmax = (P.total + 31) / 32 + 3;                 // (the buffer is padded: words up to here exist)
+    for (u32 k = threadIdx.x; k < nwords; k += 256) sw[k] = (kb + k < wmax) ? __builtin_bswap32(s32[kb + k]) : 0u;
+    __syncthreads();
+    const BitWin bw{sw, kb, P.total};
+    auto nolit = [](u32, u8) {};
+    for (u32 i = threadIdx.x; i < DEC_TILE; i += 256) {
+        const u32 idx = i0 + i;
+        if (idx >= m) break;
+        u64 nx; u32 r, src, len;
+        const int st = dec_token(bw, x_in + idx, P, T, nolit, nx, r, src, len);
+        u32 v = m;
+        if (st >= 0 && nx > x_in + idx) { const u64 d = nx - x_in; v = d < (u64)m ? (u32)d : m; }
+        next[idx] = v;
+    }
+}
+
+struct DecScalars { u64 exit_bit; u64 total_out; u32 exit_status; u32 err; };
+
+// the tokens of a segment: absolute bit position, text positions it produces (literals + factor length)
+__global__ __launch_bounds__(256) void dec_count_kernel(const u32* __restrict__ s32, u64 x_in, const u32* __restrict__ idx, u32 cnt, ParseParams P,
+                                                         const DevTab* __restrict__ gT, u64* __restrict__ tokx, u32* __restrict__ outc, DecScalars* __restrict__ sc) {
+    __shared__ DevTab T;
+    dec_tab_to_lds(gT, &T);
+    __syncthreads();
+    const BitWinG bw{s32, P.total};
+    auto nolit = [](u32, u8) {};
+    for (u32 j = blockIdx.x * 256 + threadIdx.x; j < cnt; j += gridDim.x * 256) {
+        const u64 x = x_in + idx[j];
+        u64 nx; u32 r, src, len;
+        const int st = dec_token(bw, x, P, &T, nolit, nx, r, src, len);
+        tokx[j] = x;
+        outc[j] = (st >= 0) ? r + len : 0u;
+        if (st < 0 || (st == 0 && len == 0)) atomicOr(&sc->err, 1u);
+        if (j == cnt - 1) { sc->exit_bit = nx; sc->exit_status = (u32)(st < 0 ? 2 : st); }
+    }
+}
+
+// literal bytes to their text positions, the factor list (a token without factor gets length 0)
+__global__ __launch_bounds__(256) void dec_emit_kernel(const u32* __restrict__ s32, const u64* __restrict__ tokx, const u32* __restrict__ base, u32 z, ParseParams P,
+                                                        const DevTab* __restrict__ gT, u8* __restrict__ text, u32* __restrict__ fpos, u32* __restrict__ fsrc,
+                                                        u32* __restrict__ flen, DecScalars* __restrict__ sc) {
+    __shared__ DevTab T;
+    dec_tab_to_lds(gT, &T);
+    __syncthreads();
+    const BitWinG bw{s32, P.total};
+    for (u32 j = blockIdx.x * 256 + threadIdx.x; j < z; j += gridDim.x * 256) {
+        const u64 p = base[j];
+        u8* dst = text + p;
+        const u64 room = P.n - p;                                 // (base[j] <= n: checked on the host through the total)
+        u64 nx; u32 r, src, len;
+        const int st = dec_token(bw, tokx[j], P, &T, [&](u32 i, u8 b) { if (i < room) dst[i] = b; }, nx, r, src, len);
+        bool bad = st < 0 || p + r > P.n;
+        if (st == 0) bad = bad || len == 0 || p + r + len > P.n || (u64)src + len > P.n;
+        if (bad) { atomicOr(&sc->err, 2u); len = 0; }
+        fpos[j] = (u32)(p + r); fsrc[j] = src; flen[j] = (st == 0) ? len : 0u;
+    }
+}
+
+
 }  // namespace
 
-// Host parse: literals go straight to their text positions in `text` (n bytes), factors into the three vectors.
-// Returns n.  Throws StreamError for malformed input.
-static u64 parse_lzss_huff_stream(const u8* in, size_t len, std::vector<u8>& text, std::vector<u32>& fpos, std::vector<u32>& fsrc,
-                                  std::vector<u32>& flen) {
-    FastBits bs(in, len);
-    // HuffmanCoder::Decoder ctor (HuffmanCoder.hpp:581-597) + huffmantable_decode (:278-290)
-    const bool have_table = bs.read(1) != 0;
+// Header of a lcpcomp(coder=huff) stream: HuffmanCoder::Decoder ctor (HuffmanCoder.hpp:581-597) + huffmantable_decode (:278-290),
+// then the four fields of decode_text_internal (LCPCompressor.hpp:23-76).  Shared by the host parse and the device parse.
+struct HuffHeader {
+    bool have_table = false;
     u8 order[256];
     u64 firstcode[64];
     size_t prefix_sum[64];
     unsigned longest = 0;
     u8 numl[64] = {0};
     size_t sigma = 0;
-    constexpr unsigned LUT_BITS = 12;
     std::vector<unsigned short> lut;                          // (symbol << 4) | code length, 0 = longer than LUT_BITS / invalid
-    if (have_table) {
-        longest = (unsigned)(bs.read_compressed_int() & 0xFF);
-        if (longest == 0 || longest > 57) throw StreamError{"corrupt Huffman table"};
-        for (unsigned i = 0; i < longest; ++i) numl[i] = (u8)bs.read_compressed_int();
-        sigma = (size_t)bs.read_compressed_int();
-        if (sigma > 256) throw StreamError{"corrupt Huffman table"};
-        for (size_t i = 0; i < sigma; ++i) order[i] = (u8)bs.read(8);
-        firstcode[longest - 1] = 0;                                              // gen_first_codes :192-198
-        for (unsigned i = longest - 1; i > 0; --i) firstcode[i - 1] = (firstcode[i] + numl[i]) / 2;
-        size_t acc = 0;                                                           // gen_prefix_sum_lengths :350-370
-        for (unsigned l = 0; l < longest; ++l) { prefix_sum[l] = acc; acc += numl[l]; }
-        if (acc > sigma) throw StreamError{"corrupt Huffman table"};
-        lut.assign((size_t)1 << LUT_BITS, 0);
-        for (unsigned l = 1; l <= longest && l <= LUT_BITS; ++l)
-            for (unsigned k = 0; k < numl[l - 1]; ++k) {
-                const u64 code = firstcode[l - 1] + k;
+    u64 n = 0, flen_min = 0, flen_max = 0, fdist_max = 0;
+    unsigned W = 0, lbits = 0, dbits = 0;
+};
+static void parse_huff_header(FastBits& bs, size_t len, HuffHeader& H) {
+    H.have_table = bs.read(1) != 0;
+    if (H.have_table) {
+        H.longest = (unsigned)(bs.read_compressed_int() & 0xFF);
+        if (H.longest == 0 || H.longest > 57) throw StreamError{"corrupt Huffman table"};
+        for (unsigned i = 0; i < H.longest; ++i) H.numl[i] = (u8)bs.read_compressed_int();
+        H.sigma = (size_t)bs.read_compressed_int();
+        if (H.sigma > 256) throw StreamError{"corrupt Huffman table"};
+        for (size_t i = 0; i < H.sigma; ++i) H.order[i] = (u8)bs.read(8);
+        H.firstcode[H.longest - 1] = 0;                                              // gen_first_codes :192-198
+        for (unsigned i = H.longest - 1; i > 0; --i) H.firstcode[i - 1] = (H.firstcode[i] + H.numl[i]) / 2;
+        size_t acc = 0;                                                               // gen_prefix_sum_lengths :350-370
+        for (unsigned l = 0; l < H.longest; ++l) { H.prefix_sum[l] = acc; acc += H.numl[l]; }
+        if (acc > H.sigma) throw StreamError{"corrupt Huffman table"};
+        H.lut.assign((size_t)1 << LUT_BITS, 0);
+        for (unsigned l = 1; l <= H.longest && l <= LUT_BITS; ++l)
+            for (unsigned k = 0; k < H.numl[l - 1]; ++k) {
+                const u64 code = H.firstcode[l - 1] + k;
                 if (code >> l) throw StreamError{"corrupt Huffman table"};
-                const unsigned short e = (unsigned short)((order[prefix_sum[l - 1] + k] << 4) | l);
+                const unsigned short e = (unsigned short)((H.order[H.prefix_sum[l - 1] + k] << 4) | l);
                 const size_t base = (size_t)code << (LUT_BITS - l);
-                for (size_t x = 0; x < ((size_t)1 << (LUT_BITS - l)); ++x) lut[base + x] = e;
+                for (size_t x = 0; x < ((size_t)1 << (LUT_BITS - l)); ++x) H.lut[base + x] = e;
             }
     }
     // decode_text_internal (LCPCompressor.hpp:23-76)
-    const u64 n = bs.read(32);
-    const unsigned W = bits_for(n);
-    const u64 flen_min = bs.read(W), flen_max = bs.read(W), fdist_max = bs.read(W);
-    const unsigned lbits = bits_for(flen_max - flen_min), dbits = bits_for(fdist_max);
-    if (n == 0 || n >= 0x7FFFFFFFull) throw StreamError{"text length out of range"};     // a text always holds its sentinel
+    H.n = bs.read(32);
+    H.W = bits_for(H.n);
+    H.flen_min = bs.read(H.W); H.flen_max = bs.read(H.W); H.fdist_max = bs.read(H.W);
+    H.lbits = bits_for(H.flen_max - H.flen_min); H.dbits = bits_for(H.fdist_max);
+    if (H.n == 0 || H.n >= 0x7FFFFFFFull) throw StreamError{"text length out of range"};     // a text always holds its sentinel
     {   // plausibility (a corrupt header would otherwise ask for gigabytes): a literal costs at least one bit, a factor at least W
         // bits and covers at most flen_max positions
         const u64 bits = (u64)len * 8;
-        if (n > bits + (bits / W + 1) * (flen_max ? flen_max : 1)) throw StreamError{"text length out of range"};
+        if (H.n > bits + (bits / H.W + 1) * (H.flen_max ? H.flen_max : 1)) throw StreamError{"text length out of range"};
     }
+}
+
+// Host parse: literals go straight to their text positions in `text` (n bytes), factors into the three vectors.
+// Returns n.  Throws StreamError for malformed input.
+static u64 parse_lzss_huff_stream(FastBits& bs, const HuffHeader& H, std::vector<u8>& text, std::vector<u32>& fpos, std::vector<u32>& fsrc,
+                                  std::vector<u32>& flen) {
+    const bool have_table = H.have_table;
+    const unsigned longest = H.longest, W = H.W, lbits = H.lbits, dbits = H.dbits;
+    const u64 n = H.n, flen_min = H.flen_min;
+    const u64* firstcode = H.firstcode; const size_t* prefix_sum = H.prefix_sum; const u8* numl = H.numl; const u8* order = H.order;
+    const size_t sigma = H.sigma;
+    const std::vector<unsigned short>& lut = H.lut;
     text.assign((size_t)n, 0);
     u64 p = 0;
     while (!bs.eof()) {
@@ -287,6 +478,116 @@ size_t decode_lzss_huff(Ctx& c, const u8* stream, size_t len, std::vector<u8>& t
     return decode_lzss(c, stream, len, 0, text, st);
 }
 
+// Resolves the reference forest of n text positions on the device (d_text holds the literals at their positions, the factor list is
+// on the device as well) and downloads the text.
+static void resolve_and_download(Ctx& c, size_t n, u8* d_text, u32* d_ref, const u32* d_pos, const u32* d_src, const u32* d_len, size_t z,
+                                 u32* d_changed, std::vector<u8>& text, DecodeStats* st) {
+    hipStream_t s = c.stream;
+    fill_u32(c, d_ref, n, NONE32);
+    const int G = (z * 64 > n) ? 8 : 64;
+    ref_scatter_kernel<<<cdiv(z * G, 256), 256, 0, s>>>(d_pos, d_src, d_len, z, G, d_ref);
+    LAUNCH_CHECK();
+    unsigned g = cdiv(n, 256 * 8); if (g > 16384) g = 16384;
+    for (u32 round = 0;; ++round) {
+        if (round > 40) throw StreamFormatError{"corrupt stream: reference cycle"};     // depth < 2^31
+        HIP_TRY(hipMemsetAsync(d_changed, 0, sizeof(u32), s));
+        ref_jump_kernel<<<g, 256, 0, s>>>(d_ref, n, d_changed);
+        LAUNCH_CHECK();
+        st->rounds = round + 1;
+        if (c.read(d_changed) == 0) break;
+    }
+    ref_copy_kernel<<<cdiv(n, 256), 256, 0, s>>>(d_ref, n, d_text);
+    LAUNCH_CHECK();
+    text.resize(n);
+    HIP_TRY(hipMemcpyAsync(text.data(), d_text, n, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+}
+
+// lcpcomp(coder=huff) with the token stream parsed on the device.  Returns false if this stream keeps the host parse (long literal
+// runs); throws StreamFormatError for malformed input.
+static bool decode_lzss_huff_device(Ctx& c, const u8* stream, size_t len, const HuffHeader& H, u64 x0, u64 total, std::vector<u8>& text,
+                                    DecodeStats* st) {
+    if (H.fdist_max > DEC_MAX_RUN) return false;
+    const u64 code_max = H.have_table ? H.longest : 8;
+    const u64 la_bits = 1 + H.dbits + H.fdist_max * code_max + H.W + H.lbits;          // the longest token a candidate may read
+    const u32 nwords = (u32)((DEC_TILE + la_bits + 31) / 32 + 4);
+    const size_t lds = sizeof(DevTab) + (size_t)nwords * 4;
+    if (lds > 60 * 1024) return false;
+    const size_t n = (size_t)H.n;
+    const u64 min_tok = 1 + H.W + H.lbits;
+    const size_t zmax = (size_t)((total - x0) / min_tok + 2);
+    const size_t seg = (size_t)std::min<u64>(DEC_SEG, total - x0 + 1);
+    hipStream_t s = c.stream;
+    c.ensure_arena(len + 64 + n * 5 + zmax * 28 + seg * 17 + sizeof(DevTab) + ((size_t)16 << 20));
+    const size_t mark0 = c.arena.mark();
+    u8* d_stream = c.arena.get<u8>(len + 64);
+    HIP_TRY(hipMemcpyAsync(d_stream, stream, len, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(d_stream + len, 0, 64, s));
+    const u32* s32 = (const u32*)d_stream;                                              // (arena allocations are 256-byte aligned)
+    DevTab* d_tab = (DevTab*)c.arena.alloc(sizeof(DevTab));
+    {
+        std::vector<u8> hb(sizeof(DevTab), 0);
+        DevTab* t = (DevTab*)hb.data();
+        t->have_table = H.have_table ? 1u : 0u; t->longest = H.longest; t->sigma = (u32)H.sigma;
+        if (H.have_table) {
+            memcpy(t->lut, H.lut.data(), sizeof(t->lut));
+            for (unsigned i = 0; i < 64; ++i) { t->firstcode[i] = i < H.longest ? H.firstcode[i] : 0; t->prefix_sum[i] = i < H.longest ? (u32)H.prefix_sum[i] : 0; t->numl[i] = H.numl[i]; }
+            memcpy(t->order, H.order, 256);
+        }
+        HIP_TRY(hipMemcpyAsync(d_tab, hb.data(), sizeof(DevTab), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));                                               // (hb leaves scope)
+    }
+    const ParseParams P{ total, H.n, H.flen_min, H.W, H.lbits, H.dbits, (u32)H.fdist_max };
+    u64* tokx = c.arena.get<u64>(zmax);
+    u32* outc = c.arena.get<u32>(zmax + 1);
+    u32* d_pos = c.arena.get<u32>(zmax), *d_src = c.arena.get<u32>(zmax), *d_len = c.arena.get<u32>(zmax);
+    DecScalars* d_sc = (DecScalars*)c.arena.alloc(sizeof(DecScalars));
+    u32* d_cnt = c.arena.get<u32>(2);
+    HIP_TRY(hipMemsetAsync(d_sc, 0, sizeof(DecScalars), s));
+    size_t z = 0;
+    u64 x_in = x0;
+    while (x_in < total) {
+        const u32 m = (u32)std::min<u64>(DEC_SEG, total - x_in);
+        const size_t mk = c.arena.mark();
+        u32* next = c.arena.get<u32>(m);
+        u32* e1 = c.arena.get<u32>(m), *e2 = c.arena.get<u32>(m);
+        u8* mark = c.arena.get<u8>(m);
+        dec_next_kernel<<<cdiv(m, DEC_TILE), 256, lds, s>>>(s32, x_in, m, P, d_tab, nwords, next);
+        LAUNCH_CHECK();
+        mark_orbit_u32(c, next, m, mark, e1, e2);
+        u32* idx = e1;                                                                  // (the exit arrays are free again)
+        select_by_class(c, mark, 1, m, nullptr, idx, nullptr, nullptr, d_cnt);
+        const u32 cnt = c.read(d_cnt);
+        if (cnt == 0 || z + cnt > zmax) throw StreamFormatError{"corrupt stream: token chain"};
+        dec_count_kernel<<<std::min<u32>(cdiv(cnt, 256), 4096u), 256, 0, s>>>(s32, x_in, idx, cnt, P, d_tab, tokx + z, outc + z, d_sc);
+        LAUNCH_CHECK();
+        const DecScalars h = c.read(d_sc);
+        c.arena.release(mk);
+        z += cnt;
+        if (h.err || h.exit_status == 2) throw StreamFormatError{"corrupt stream: malformed token"};
+        if (h.exit_status == 1 || h.exit_bit >= total) break;
+        if (h.exit_bit <= x_in) throw StreamFormatError{"corrupt stream: token chain"};
+        x_in = h.exit_bit;
+    }
+    // text positions of the tokens
+    u32* base = outc;                                                                   // in place
+    exclusive_sum_u32(c, outc, base, z, d_cnt);
+    const u32 produced = c.read(d_cnt);
+    if ((u64)produced != H.n) throw StreamFormatError{"corrupt stream: length mismatch"};
+    u8* d_text = c.arena.get<u8>(n + 64);
+    u32* d_ref = c.arena.get<u32>(n);
+    HIP_TRY(hipMemsetAsync(d_text, 0, n, s));
+    dec_emit_kernel<<<std::min<u32>(cdiv(z, 256), 4096u), 256, 0, s>>>(s32, tokx, base, (u32)z, P, d_tab, d_text, d_pos, d_src, d_len, d_sc);
+    LAUNCH_CHECK();
+    const DecScalars h = c.read(d_sc);
+    if (h.err) throw StreamFormatError{"corrupt stream: factor out of range"};
+    st->factors = z ? z - 1 : 0;                                                        // (every token but the last carries a factor)
+    if (z && h.exit_status == 0) st->factors = z;
+    resolve_and_download(c, n, d_text, d_ref, d_pos, d_src, d_len, z, d_cnt, text, st);
+    c.arena.release(mark0);
+    return true;
+}
+
 // coder: 0 = HuffmanCoder, 2 = ASCIICoder, 3 | kmer << 8 = SLECoder (the coder ids of encode_stream)
 size_t decode_lzss(Ctx& c, const u8* stream, size_t len, int coder, std::vector<u8>& text, DecodeStats* st) {
     DecodeStats local;
@@ -296,7 +597,18 @@ size_t decode_lzss(Ctx& c, const u8* stream, size_t len, int coder, std::vector<
     u64 n;
     if ((coder & 0xFF) == 3) n = parse_lzss_sle_stream(stream, len, (unsigned)(coder >> 8) ? (unsigned)(coder >> 8) : 3u, text, fpos, fsrc, flen);
     else if (coder == 2) n = parse_lzss_ascii_stream(stream, len, text, fpos, fsrc, flen);
-    else n = parse_lzss_huff_stream(stream, len, text, fpos, fsrc, flen);
+    else {
+        FastBits bs(stream, len);
+        HuffHeader H;
+        parse_huff_header(bs, len, H);
+        // the token stream itself: on the device (streams of 1 MiB and more; TDC_GPU_DEC_PARSE = 0 never / 2 always: tests), else on the host
+        if (bs.pos < bs.total && c.dec_parse && (c.dec_parse >= 2 || len >= ((size_t)1 << 20)) &&
+            decode_lzss_huff_device(c, stream, len, H, bs.pos, bs.total, text, st)) {
+            st->device_parse = 1;
+            return (size_t)H.n;
+        }
+        n = parse_lzss_huff_stream(bs, H, text, fpos, fsrc, flen);
+    }
     const size_t z = fpos.size();
     st->factors = z;
     if (n == 0 || z == 0) return (size_t)n;
@@ -311,23 +623,7 @@ size_t decode_lzss(Ctx& c, const u8* stream, size_t len, int coder, std::vector<
     HIP_TRY(hipMemcpyAsync(d_pos, fpos.data(), z * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(d_src, fsrc.data(), z * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(d_len, flen.data(), z * 4, hipMemcpyHostToDevice, s));
-    fill_u32(c, d_ref, (size_t)n, NONE32);
-    const int G = (z * 64 > n) ? 8 : 64;
-    ref_scatter_kernel<<<cdiv(z * G, 256), 256, 0, s>>>(d_pos, d_src, d_len, z, G, d_ref);
-    LAUNCH_CHECK();
-    unsigned g = cdiv((size_t)n, 256 * 8); if (g > 16384) g = 16384;
-    for (u32 round = 0;; ++round) {
-        if (round > 40) throw StreamFormatError{"corrupt stream: reference cycle"};     // depth < 2^31
-        HIP_TRY(hipMemsetAsync(d_changed, 0, sizeof(u32), s));
-        ref_jump_kernel<<<g, 256, 0, s>>>(d_ref, (size_t)n, d_changed);
-        LAUNCH_CHECK();
-        st->rounds = round + 1;
-        if (c.read(d_changed) == 0) break;
-    }
-    ref_copy_kernel<<<cdiv((size_t)n, 256), 256, 0, s>>>(d_ref, (size_t)n, d_text);
-    LAUNCH_CHECK();
-    HIP_TRY(hipMemcpyAsync(text.data(), d_text, (size_t)n, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    resolve_and_download(c, (size_t)n, d_text, d_ref, d_pos, d_src, d_len, z, d_changed, text, st);
     c.arena.release(mark);
     return (size_t)n;
 }

@@ -692,7 +692,11 @@ size_t encode_stream(Ctx& c, const u8* text, size_t n, FactorSpace fs, int coder
     const size_t mark = c.arena.mark();
 
     EncodeEarly mine;
-    if (!early || !early->done) {
+    // An early first half that did not finish must not be replaced silently: with its flatten records kept (rec != nullptr) the
+    // flattened sources were never written back to fs.fsrc, a private first half would pack the unflattened ones.
+    if (early && !early->done)
+        throw HipError{hipErrorUnknown, "encode: the first half started inside the flatten stage did not complete", (int)__LINE__};
+    if (!early) {
         early = &mine;
         encode_reserve(c, n, mine);
         encode_first_half(c, text, n, fs, coder, mine);

@@ -141,7 +141,7 @@ void lzss_lcp_factorize(Ctx& c, const u8* text, size_t n, const u32* sa, const u
 namespace tdc {
 // LCPCompressor::decompress (LCPCompressor.hpp:140-150; also lzss_lcp streams): host parse of the Huffman token stream,
 // references resolved on the device by pointer jumping.  `text` receives the (still escaped, 0-terminated) text.
-struct DecodeStats { u64 factors = 0; u32 rounds = 0; };
+struct DecodeStats { u64 factors = 0; u32 rounds = 0; u32 device_parse = 0; };
 struct StreamFormatError { const char* what; };          // malformed input
 size_t decode_lzss_huff(Ctx& c, const u8* stream, size_t len, std::vector<u8>& text, DecodeStats* st);
 // the same for streams written with another coder: 0 = HuffmanCoder, 2 = ASCIICoder, 3 | kmer << 8 = SLECoder
