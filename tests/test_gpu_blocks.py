@@ -182,15 +182,26 @@ def test_bench_launches_its_own_ranks_two_rank_rehearsal(gpu_ctx):
 
 
 def test_kept_stream_is_fetched_to_device_memory(gpu_ctx):
-    """tdc_gpu_stream_fetch_dev: the kept stream as the send buffer of the RCCL gather (device-to-device)"""
-    import torch
+    """tdc_gpu_stream_fetch_dev: the kept stream as the send buffer of the RCCL gather (device-to-device).  Device memory comes from
+    the HIP runtime directly (ctypes), so the test does not depend on torch's device initialisation."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
     data = T.gen_english(2_000_000, 5).tobytes()
     text = O.escape(data)
     want, _ = O.lcpcomp_huff_compress(text, 2, 1)
     ta = np.frombuffer(text, dtype=np.uint8)
     ln, _ = gpu_ctx.lcpcomp_compress_keep(ta, len(ta), 2, 1)
-    d = torch.zeros(ln + 64, dtype=torch.uint8, device="cuda:0")
-    assert gpu_ctx.stream_fetch_dev(d.data_ptr(), d.numel()) == ln
-    assert bytes(d[:ln].cpu().numpy()) == want
-    with pytest.raises(T.TdcGpuError):
-        gpu_ctx.stream_fetch_dev(d.data_ptr(), ln - 1)
+    d = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(d), ln + 64) == 0
+    try:
+        assert gpu_ctx.stream_fetch_dev(d.value, ln + 64) == ln
+        back = np.zeros(ln, dtype=np.uint8)
+        assert hip.hipMemcpy(back.ctypes.data_as(ctypes.c_void_p), d, ln, 2) == 0       # hipMemcpyDeviceToHost
+        assert back.tobytes() == want
+        with pytest.raises(T.TdcGpuError):
+            gpu_ctx.stream_fetch_dev(d.value, ln - 1)
+    finally:
+        hip.hipFree(d)

@@ -123,3 +123,26 @@ def test_damaged_streams_are_refused_by_the_device_parse(dev_ctx):
     for bad in (b"", b"\x00", good[:1000], good[:len(good) // 2] + b"\x05"):
         with pytest.raises(T.TdcGpuError):
             dev_ctx.lcpcomp_decompress(bad)
+
+
+def test_decompress_into_caller_buffer(gpu_ctx):
+    """tdc_gpu_lcpcomp_decompress_into: the text lands in the caller's (pinned) buffer; a buffer that is too small is refused"""
+    data = T.gen_english(3_000_000, 21)
+    text = np.concatenate([data, np.zeros(1, dtype=np.uint8)])
+    stream, _ = gpu_ctx.lcpcomp_compress(text, 2, 1)
+    out = T.PinnedBuffer(len(text) + 100)
+    try:
+        out.a[:] = 0xA5
+        n, st = gpu_ctx.lcpcomp_decompress_into(stream, out)
+        assert n == len(text) and out.a[:n].tobytes() == text.tobytes() and st["device_parse"] == 1
+        assert bool((out.a[n:] == 0xA5).all())
+        small = np.zeros(1000, dtype=np.uint8)
+        with pytest.raises(T.TdcGpuError) as e:
+            gpu_ctx.lcpcomp_decompress_into(stream, small)
+        assert e.value.status == -5
+        tiny_text = O.escape(b"abcabcabc hello hello")
+        s2, _ = O.lcpcomp_huff_compress(tiny_text, 2, 1)              # (host parse path into a caller buffer)
+        n2, st2 = gpu_ctx.lcpcomp_decompress_into(s2, out)
+        assert out.a[:n2].tobytes() == tiny_text and st2["device_parse"] == 0
+    finally:
+        out.free()

@@ -328,6 +328,17 @@ class Context:
         return self._take(p, n.value), {"factors": f.value, "rounds": r.value,
                                         "device_parse": int(self._L.tdc_gpu_ctx_last_decode_on_device(self._h))}
 
+    def lcpcomp_decompress_into(self, stream, out, coder=CODER_HUFF):
+        """lcpcomp_decompress into a caller-owned buffer (a PinnedBuffer or a writable uint8 array; `stream` may be a PinnedBuffer too):
+        returns (text length, {"factors", "rounds", "device_parse"})."""
+        a = stream.a if isinstance(stream, PinnedBuffer) else _u8(stream)
+        oa = out.a if isinstance(out, PinnedBuffer) else out
+        n = ctypes.c_size_t()
+        f, r = ctypes.c_uint64(), ctypes.c_uint32()
+        self._check(self._L.tdc_gpu_lcpcomp_decompress_into(self._h, _ptr(a), len(a), coder, _ptr(oa), oa.size, ctypes.byref(n),
+                                                            ctypes.byref(f), ctypes.byref(r)))
+        return n.value, {"factors": f.value, "rounds": r.value, "device_parse": int(self._L.tdc_gpu_ctx_last_decode_on_device(self._h))}
+
     def blocks_decompress(self, blob, coder=CODER_HUFF):
         """inverse of blocks_compress on this context's device: the concatenated raw bytes"""
         a = _u8(blob)

@@ -23,7 +23,7 @@ SYMBOLS = [
     "tdc_gpu_encode_arith",
     "tdc_gpu_encode_ascii",
     "tdc_gpu_encode_sle",
-    "tdc_gpu_lcpcomp_decompress_coder", "tdc_gpu_ctx_last_decode_on_device",
+    "tdc_gpu_lcpcomp_decompress_coder", "tdc_gpu_ctx_last_decode_on_device", "tdc_gpu_lcpcomp_decompress_into",
     "tdc_escape", "tdc_unescape", "tdc_huffman_table", "tdc_huffman_selfcheck", "tdc_gpu_blocks_count", "tdc_gpu_blocks_compress", "tdc_gpu_blocks_decompress", "tdc_gpu_device_count", "tdc_gen_english", "tdc_gen_dna",
     "tdc_gpu_arena_bytes", "tdc_gpu_device_memory",
     "tdc_gpu_lcpcomp_compress_keep", "tdc_gpu_stream_fetch", "tdc_gpu_stream_fetch_dev", "tdc_gpu_host_register", "tdc_gpu_host_unregister",
@@ -94,6 +94,7 @@ def load():
     L.tdc_gpu_stream_fetch.argtypes = [vp, vp, sz, psz]
     L.tdc_gpu_stream_fetch_dev.argtypes = [vp, vp, sz, psz]
     L.tdc_gpu_ctx_last_decode_on_device.argtypes = [vp]
+    L.tdc_gpu_lcpcomp_decompress_into.argtypes = [vp, vp, sz, i32, vp, sz, psz, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32)]
     L.tdc_gpu_host_register.argtypes = [vp, sz]
     L.tdc_gpu_host_unregister.argtypes = [vp]
     L.tdc_gpu_blocks_count.argtypes = [sz, sz]

@@ -948,23 +948,40 @@ int tdc_gpu_lcpcomp_decompress(tdc_gpu_ctx* ctx, const uint8_t* stream, size_t l
     return tdc_gpu_lcpcomp_decompress_coder(ctx, stream, len, TDC_GPU_CODER_HUFF, out, out_len, factors, rounds);
 }
 
+namespace {
+void decompress_common(tdc_gpu_ctx* ctx, const uint8_t* stream, size_t len, int coder, DecodeOut& o, size_t* out_len, uint64_t* factors, uint32_t* rounds) {
+    if (!stream || !out_len) throw ArgError{TDC_GPU_ERR_ARG, "NULL argument"};
+    const int enc = lcpcomp_enc_coder(coder);
+    if (enc == 1) throw ArgError{TDC_GPU_ERR_UNSUPPORTED, "lcpcomp(coder=arithmetic) streams cannot be decoded (neither can the reference)"};
+    DecodeStats ds;
+    size_t n = 0;
+    try { n = decode_lzss(ctx->c, stream, len, enc, o, &ds); }
+    catch (const StreamFormatError& e) { free(o.owned); o.owned = nullptr; throw ArgError{TDC_GPU_ERR_ARG, e.what}; }
+    catch (...) { free(o.owned); o.owned = nullptr; throw; }
+    *out_len = n;
+    if (factors) *factors = ds.factors;
+    if (rounds) *rounds = ds.rounds;
+    ctx->last_decode_device = (int)ds.device_parse;
+}
+}  // namespace
+
 int tdc_gpu_lcpcomp_decompress_coder(tdc_gpu_ctx* ctx, const uint8_t* stream, size_t len, int coder, uint8_t** out, size_t* out_len,
                                      uint64_t* factors, uint32_t* rounds) {
     return guarded(ctx, [&] {
-        if (!stream || !out || !out_len) throw ArgError{TDC_GPU_ERR_ARG, "NULL argument"};
-        const int enc = lcpcomp_enc_coder(coder);
-        if (enc == 1) throw ArgError{TDC_GPU_ERR_UNSUPPORTED, "lcpcomp(coder=arithmetic) streams cannot be decoded (neither can the reference)"};
-        std::vector<u8> text;
-        DecodeStats ds;
-        size_t n = 0;
-        try { n = decode_lzss(ctx->c, stream, len, enc, text, &ds); }
-        catch (const StreamFormatError& e) { throw ArgError{TDC_GPU_ERR_ARG, e.what}; }
-        HostBuf h(n);
-        if (n) memcpy(h.p, text.data(), n);
-        *out = h.release<uint8_t>(); *out_len = n;
-        if (factors) *factors = ds.factors;
-        if (rounds) *rounds = ds.rounds;
-        ctx->last_decode_device = (int)ds.device_parse;
+        if (!out) throw ArgError{TDC_GPU_ERR_ARG, "NULL argument"};
+        DecodeOut o;
+        decompress_common(ctx, stream, len, coder, o, out_len, factors, rounds);
+        *out = o.owned;
+    });
+}
+
+int tdc_gpu_lcpcomp_decompress_into(tdc_gpu_ctx* ctx, const uint8_t* stream, size_t len, int coder, uint8_t* out, size_t out_cap,
+                                    size_t* out_len, uint64_t* factors, uint32_t* rounds) {
+    return guarded(ctx, [&] {
+        if (!out) throw ArgError{TDC_GPU_ERR_ARG, "out is NULL"};
+        DecodeOut o;
+        o.into = out; o.cap = out_cap;
+        decompress_common(ctx, stream, len, coder, o, out_len, factors, rounds);
     });
 }
 

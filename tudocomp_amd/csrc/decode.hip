@@ -15,6 +15,10 @@
 #include "stages.hpp"
 #include "prim.hpp"
 
+#include <chrono>
+#include <new>
+#include <stdlib.h>
+#include <sys/mman.h>
 #include <vector>
 
 namespace tdc {
@@ -474,19 +478,43 @@ static u64 parse_lzss_ascii_stream(const u8* in, size_t in_len, std::vector<u8>&
     return n;
 }
 
-size_t decode_lzss_huff(Ctx& c, const u8* stream, size_t len, std::vector<u8>& text, DecodeStats* st) {
-    return decode_lzss(c, stream, len, 0, text, st);
+// where the decoded text goes: the caller's buffer, or a buffer allocated here (2 MiB aligned, transparent huge pages asked for: a
+// 256 MiB text otherwise pays 65 536 page faults in front of the download) that the caller releases with free()
+static u8* decode_dest(DecodeOut& o, size_t n) {
+    if (o.into) {
+        if (n > o.cap) throw HipError{hipErrorOutOfMemory, "decompress: output buffer too small", (int)__LINE__};
+        return o.into;
+    }
+    void* p = nullptr;
+    const size_t bytes = n ? n : 1;
+    if (bytes >= ((size_t)4 << 20)) {
+        if (posix_memalign(&p, (size_t)2 << 20, bytes) != 0) p = nullptr;
+        else (void)madvise(p, bytes, MADV_HUGEPAGE);
+    } else p = malloc(bytes);
+    if (!p) throw std::bad_alloc();
+    o.owned = (u8*)p;
+    return o.owned;
 }
 
 // Resolves the reference forest of n text positions on the device (d_text holds the literals at their positions, the factor list is
 // on the device as well) and downloads the text.
 static void resolve_and_download(Ctx& c, size_t n, u8* d_text, u32* d_ref, const u32* d_pos, const u32* d_src, const u32* d_len, size_t z,
-                                 u32* d_changed, std::vector<u8>& text, DecodeStats* st) {
+                                 u32* d_changed, DecodeOut& out, DecodeStats* st) {
     hipStream_t s = c.stream;
+    const bool dlog = getenv("TDC_GPU_DEC_LOG") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto tick = [&](const char* what) {
+        if (!dlog) return;
+        (void)hipStreamSynchronize(s);
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "decode:   %-26s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     fill_u32(c, d_ref, n, NONE32);
     const int G = (z * 64 > n) ? 8 : 64;
     ref_scatter_kernel<<<cdiv(z * G, 256), 256, 0, s>>>(d_pos, d_src, d_len, z, G, d_ref);
     LAUNCH_CHECK();
+    tick("fill + reference scatter");
     unsigned g = cdiv(n, 256 * 8); if (g > 16384) g = 16384;
     for (u32 round = 0;; ++round) {
         if (round > 40) throw StreamFormatError{"corrupt stream: reference cycle"};     // depth < 2^31
@@ -496,16 +524,20 @@ static void resolve_and_download(Ctx& c, size_t n, u8* d_text, u32* d_ref, const
         st->rounds = round + 1;
         if (c.read(d_changed) == 0) break;
     }
+    tick("pointer jumping");
     ref_copy_kernel<<<cdiv(n, 256), 256, 0, s>>>(d_ref, n, d_text);
     LAUNCH_CHECK();
-    text.resize(n);
-    HIP_TRY(hipMemcpyAsync(text.data(), d_text, n, hipMemcpyDeviceToHost, s));
+    tick("copy pass");
+    u8* dst = decode_dest(out, n);
+    tick("host buffer");
+    HIP_TRY(hipMemcpyAsync(dst, d_text, n, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    tick("download");
 }
 
 // lcpcomp(coder=huff) with the token stream parsed on the device.  Returns false if this stream keeps the host parse (long literal
 // runs); throws StreamFormatError for malformed input.
-static bool decode_lzss_huff_device(Ctx& c, const u8* stream, size_t len, const HuffHeader& H, u64 x0, u64 total, std::vector<u8>& text,
+static bool decode_lzss_huff_device(Ctx& c, const u8* stream, size_t len, const HuffHeader& H, u64 x0, u64 total, DecodeOut& out,
                                     DecodeStats* st) {
     if (H.fdist_max > DEC_MAX_RUN) return false;
     const u64 code_max = H.have_table ? H.longest : 8;
@@ -518,6 +550,15 @@ static bool decode_lzss_huff_device(Ctx& c, const u8* stream, size_t len, const 
     const size_t zmax = (size_t)((total - x0) / min_tok + 2);
     const size_t seg = (size_t)std::min<u64>(DEC_SEG, total - x0 + 1);
     hipStream_t s = c.stream;
+    const bool dlog = getenv("TDC_GPU_DEC_LOG") != nullptr;                              // stage times on stderr (synchronises)
+    auto t_last = std::chrono::steady_clock::now();
+    auto tick = [&](const char* what) {
+        if (!dlog) return;
+        (void)hipStreamSynchronize(s);
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "decode: %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     c.ensure_arena(len + 64 + n * 5 + zmax * 28 + seg * 17 + sizeof(DevTab) + ((size_t)16 << 20));
     const size_t mark0 = c.arena.mark();
     u8* d_stream = c.arena.get<u8>(len + 64);
@@ -552,16 +593,21 @@ static bool decode_lzss_huff_device(Ctx& c, const u8* stream, size_t len, const 
         u32* next = c.arena.get<u32>(m);
         u32* e1 = c.arena.get<u32>(m), *e2 = c.arena.get<u32>(m);
         u8* mark = c.arena.get<u8>(m);
+        tick("upload + tables");
         dec_next_kernel<<<cdiv(m, DEC_TILE), 256, lds, s>>>(s32, x_in, m, P, d_tab, nwords, next);
         LAUNCH_CHECK();
+        tick("next() of every bit");
         mark_orbit_u32(c, next, m, mark, e1, e2);
+        tick("chain marking");
         u32* idx = e1;                                                                  // (the exit arrays are free again)
         select_by_class(c, mark, 1, m, nullptr, idx, nullptr, nullptr, d_cnt);
         const u32 cnt = c.read(d_cnt);
+        tick("token list");
         if (cnt == 0 || z + cnt > zmax) throw StreamFormatError{"corrupt stream: token chain"};
         dec_count_kernel<<<std::min<u32>(cdiv(cnt, 256), 4096u), 256, 0, s>>>(s32, x_in, idx, cnt, P, d_tab, tokx + z, outc + z, d_sc);
         LAUNCH_CHECK();
         const DecScalars h = c.read(d_sc);
+        tick("count pass");
         c.arena.release(mk);
         z += cnt;
         if (h.err || h.exit_status == 2) throw StreamFormatError{"corrupt stream: malformed token"};
@@ -580,19 +626,22 @@ static bool decode_lzss_huff_device(Ctx& c, const u8* stream, size_t len, const 
     dec_emit_kernel<<<std::min<u32>(cdiv(z, 256), 4096u), 256, 0, s>>>(s32, tokx, base, (u32)z, P, d_tab, d_text, d_pos, d_src, d_len, d_sc);
     LAUNCH_CHECK();
     const DecScalars h = c.read(d_sc);
+    tick("scan + emit pass");
     if (h.err) throw StreamFormatError{"corrupt stream: factor out of range"};
     st->factors = z ? z - 1 : 0;                                                        // (every token but the last carries a factor)
     if (z && h.exit_status == 0) st->factors = z;
-    resolve_and_download(c, n, d_text, d_ref, d_pos, d_src, d_len, z, d_cnt, text, st);
+    resolve_and_download(c, n, d_text, d_ref, d_pos, d_src, d_len, z, d_cnt, out, st);
+    tick("references + download");
     c.arena.release(mark0);
     return true;
 }
 
 // coder: 0 = HuffmanCoder, 2 = ASCIICoder, 3 | kmer << 8 = SLECoder (the coder ids of encode_stream)
-size_t decode_lzss(Ctx& c, const u8* stream, size_t len, int coder, std::vector<u8>& text, DecodeStats* st) {
+size_t decode_lzss(Ctx& c, const u8* stream, size_t len, int coder, DecodeOut& out, DecodeStats* st) {
     DecodeStats local;
     if (!st) st = &local;
     *st = DecodeStats();
+    std::vector<u8> text;                                    // (host parse only: the literals at their text positions)
     std::vector<u32> fpos, fsrc, flen;
     u64 n;
     if ((coder & 0xFF) == 3) n = parse_lzss_sle_stream(stream, len, (unsigned)(coder >> 8) ? (unsigned)(coder >> 8) : 3u, text, fpos, fsrc, flen);
@@ -603,7 +652,7 @@ size_t decode_lzss(Ctx& c, const u8* stream, size_t len, int coder, std::vector<
         parse_huff_header(bs, len, H);
         // the token stream itself: on the device (streams of 1 MiB and more; TDC_GPU_DEC_PARSE = 0 never / 2 always: tests), else on the host
         if (bs.pos < bs.total && c.dec_parse && (c.dec_parse >= 2 || len >= ((size_t)1 << 20)) &&
-            decode_lzss_huff_device(c, stream, len, H, bs.pos, bs.total, text, st)) {
+            decode_lzss_huff_device(c, stream, len, H, bs.pos, bs.total, out, st)) {
             st->device_parse = 1;
             return (size_t)H.n;
         }
@@ -611,7 +660,11 @@ size_t decode_lzss(Ctx& c, const u8* stream, size_t len, int coder, std::vector<
     }
     const size_t z = fpos.size();
     st->factors = z;
-    if (n == 0 || z == 0) return (size_t)n;
+    if (n == 0 || z == 0) {                                   // nothing to resolve
+        u8* dst = decode_dest(out, (size_t)n);
+        if (n) memcpy(dst, text.data(), (size_t)n);
+        return (size_t)n;
+    }
     hipStream_t s = c.stream;
     c.ensure_arena((size_t)n * 5 + z * 12 + ((size_t)16 << 20));
     const size_t mark = c.arena.mark();
@@ -623,7 +676,7 @@ size_t decode_lzss(Ctx& c, const u8* stream, size_t len, int coder, std::vector<
     HIP_TRY(hipMemcpyAsync(d_pos, fpos.data(), z * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(d_src, fsrc.data(), z * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(d_len, flen.data(), z * 4, hipMemcpyHostToDevice, s));
-    resolve_and_download(c, (size_t)n, d_text, d_ref, d_pos, d_src, d_len, z, d_changed, text, st);
+    resolve_and_download(c, (size_t)n, d_text, d_ref, d_pos, d_src, d_len, z, d_changed, out, st);
     c.arena.release(mark);
     return (size_t)n;
 }

@@ -143,9 +143,10 @@ namespace tdc {
 // references resolved on the device by pointer jumping.  `text` receives the (still escaped, 0-terminated) text.
 struct DecodeStats { u64 factors = 0; u32 rounds = 0; u32 device_parse = 0; };
 struct StreamFormatError { const char* what; };          // malformed input
-size_t decode_lzss_huff(Ctx& c, const u8* stream, size_t len, std::vector<u8>& text, DecodeStats* st);
+// destination of a decoded text: `into` (cap bytes) if set, else `owned` is allocated by the decoder (release with free())
+struct DecodeOut { u8* into = nullptr; size_t cap = 0; u8* owned = nullptr; };
 // the same for streams written with another coder: 0 = HuffmanCoder, 2 = ASCIICoder, 3 | kmer << 8 = SLECoder
-size_t decode_lzss(Ctx& c, const u8* stream, size_t len, int coder, std::vector<u8>& text, DecodeStats* st);
+size_t decode_lzss(Ctx& c, const u8* stream, size_t len, int coder, DecodeOut& out, DecodeStats* st);
 // a17: compressors/LZ78Compressor.hpp:64-140 -- sequential parse on the host; returns the number of (id, char) pairs
 size_t lz78_parse_host(const u8* in, size_t n, std::vector<u32>& ids, std::vector<u8>& chars, bool* leftover_is_high);
 // a16: coders/EliasGammaCoder.hpp:26-29 + io/BitOStream.hpp:105-129 on the device; returns the stream length
