@@ -103,6 +103,20 @@ def test_large_stream_takes_the_device_parse_by_default(gpu_ctx):
     assert back == dna and st["factors"] == cd["factors"]
 
 
+def test_streams_longer_than_one_segment(monkeypatch):
+    """the chain marking runs in segments of bit positions (2^30 by default: streams above 128 MiB); with 20 000-bit segments a
+    3 MB text takes hundreds of them -- the exit of one segment is the entry of the next"""
+    monkeypatch.setenv("TDC_GPU_DEC_PARSE", "2")
+    monkeypatch.setenv("TDC_GPU_DEC_SEG", "20000")
+    with T.Context(0) as ctx:
+        for name, data, thr in (("english", T.gen_english(3_000_000, 4).tobytes(), 2), ("dna", T.gen_dna(1_000_000, 7).tobytes(), 5),
+                                ("small", b"abcabcabc hello hello abcabc", 2)):
+            text = O.escape(data)
+            stream, _ = O.lcpcomp_huff_compress(text, thr, 1)
+            back, st = ctx.lcpcomp_decompress(stream)
+            assert back == text and st["device_parse"] == 1, name
+
+
 def test_damaged_streams_are_refused_by_the_device_parse(dev_ctx):
     text = O.escape(T.gen_english(20_000, 3).tobytes())
     good = O.lcpcomp_huff_compress(text, 2, 1)[0]

@@ -93,6 +93,14 @@ def test_metric_config_2e9_end_to_end(gpu_ctx):
         assert len(back) == n
         assert sha256(back) == sha256(h_text.a)
         del back
+        # ... and the device decoder (token stream parsed on the device in six segments of 2^30 bit positions) into a pinned buffer
+        h_back = T.PinnedBuffer(n)
+        try:
+            nb, dst = gpu_ctx.lcpcomp_decompress_into(h_out.a[:out_len], h_back)
+            assert nb == n and dst["device_parse"] == 1 and dst["factors"] == st["factors"]
+            assert sha256(h_back.a) == sha256(h_text.a)
+        finally:
+            h_back.free()
         # a buffer that is too small is refused with the required size, nothing is written past it
         tiny = np.concatenate([h_text.a[:1 << 22], np.zeros(1, dtype=np.uint8)])
         small = np.full(4096, 0xA5, dtype=np.uint8)

@@ -548,7 +548,8 @@ static bool decode_lzss_huff_device(Ctx& c, const u8* stream, size_t len, const 
     const size_t n = (size_t)H.n;
     const u64 min_tok = 1 + H.W + H.lbits;
     const size_t zmax = (size_t)((total - x0) / min_tok + 2);
-    const size_t seg = (size_t)std::min<u64>(DEC_SEG, total - x0 + 1);
+    const u64 seg_bits = c.dec_seg ? (u64)c.dec_seg : (u64)DEC_SEG;                    // (tests shrink the segments)
+    const size_t seg = (size_t)std::min<u64>(seg_bits, total - x0 + 1);
     hipStream_t s = c.stream;
     const bool dlog = getenv("TDC_GPU_DEC_LOG") != nullptr;                              // stage times on stderr (synchronises)
     auto t_last = std::chrono::steady_clock::now();
@@ -588,7 +589,7 @@ static bool decode_lzss_huff_device(Ctx& c, const u8* stream, size_t len, const 
     size_t z = 0;
     u64 x_in = x0;
     while (x_in < total) {
-        const u32 m = (u32)std::min<u64>(DEC_SEG, total - x_in);
+        const u32 m = (u32)std::min<u64>(seg_bits, total - x_in);
         const size_t mk = c.arena.mark();
         u32* next = c.arena.get<u32>(m);
         u32* e1 = c.arena.get<u32>(m), *e2 = c.arena.get<u32>(m);
