@@ -10,7 +10,10 @@ host memory.  Both transfers are INSIDE the timed region; `value` = input bytes 
           Extra keys (never `value`): "hbm_resident" = the same steps without the two transfers (device time of the
           same calls), "configs1_256MiB" = BASELINE.json configs[1] (256 MiB) through the same entry point,
           "configs2_dna_1e9" = BASELINE.json configs[2] (10^9 B DNA, LCPCompressor + ArithmeticCoder, threshold 5) through
-          the same entry point, its stream checked against the CPU oracle on a 32 MiB DNA sample.
+          the same entry point, its stream checked against the CPU oracle on a 32 MiB DNA sample,
+          "configs3_lz78" = BASELINE.json configs[3] on a 32 MiB sample (host-bound: the LZ78 parse runs on the host).
+          "stream_matches_golden" (headline and extras): size + SHA-256 of the device stream against the ORACLE's stream of the
+          same full-size text (tests/golden/oracle_fullsize.json).
   N > 1 : BASELINE.json configs[4]: one process per GPU (torch.distributed, backend nccl = RCCL); every rank compresses
           its own 2*10^9 B shard (seed 42 + rank: weak scaling) exactly as in the N = 1 case (pinned host text, upload
           overlapped with the first partition level) and keeps the stream on its GPU.  BOTH ways of putting the block
@@ -571,6 +574,17 @@ def main():
                 dna["bit_exact_vs_oracle_on_sample"] = bool(len(got3) == want_len3 and hashlib.sha256(got3).hexdigest() == want_sha3)
                 dna["sample"] = "first %d bytes of the DNA text; oracle (1 core) %.1f s" % (m3, cpu_s)
             line["configs2_dna_1e9"] = dna
+            # BASELINE.json configs[3]: lz78(coder=gamma).  The parse is sequential by nature (one dependent dictionary step per input byte,
+            # compressors/LZ78Compressor.hpp:97-121) and runs on the HOST; only the Elias-gamma packing is a GPU kernel: a host-bound
+            # figure, measured on a 32 MiB sample (the full 10^9 B take 69 s; its stream equals the oracle's, tests/golden/oracle_fullsize.json)
+            ml = 1 << 25
+            lz = T.gen_english(ml, 42)
+            t1 = time.perf_counter()
+            out3, st4 = ctx.lz78_compress(lz)
+            t = time.perf_counter() - t1
+            line["configs3_lz78"] = {"value": round(ml / 1e6 / t, 2), "unit": "MB/s", "bound": "host parse (sequential trie walk; not a GPU figure)",
+                                     "sample": "first %d bytes of the 10^9 B English text, one call: host parse + device gamma pack %.1f ms" % (ml, st4["ms_total"]),
+                                     "phrases": st4["factors"], "out_len": len(out3)}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()                                     # nobody unmaps the container while rank 0 still reads it
