@@ -186,7 +186,9 @@ void validate_device_text(Ctx& c, const u8* d_text, size_t n) {
 }
 
 // SA -> ISA -> Phi -> PLCP  (TextDS::require, ds/TextDS.hpp:247-292)
-void run_textds(Ctx& c, const u8* d_text, size_t n, DevArrays& A, tdc_gpu_stats* st, Events* ev) {
+// want_phi = false (lcpcomp with comp=arrays): where the fused scatter runs, Phi is not materialised -- 8-byte instead of 12-byte records
+// through its two partition levels; the factorizer takes a factor's source from SA[ISA[p] - 1] (A.phi stays NULL)
+void run_textds(Ctx& c, const u8* d_text, size_t n, DevArrays& A, tdc_gpu_stats* st, Events* ev, bool want_phi = true) {
     A.sa = c.arena.get<u32>(n);
     A.isa = c.arena.get<u32>(n);
     A.phi = c.arena.get<u32>(n);
@@ -200,6 +202,7 @@ void run_textds(Ctx& c, const u8* d_text, size_t n, DevArrays& A, tdc_gpu_stats*
     const int e1 = ev ? ev->tick() : 0;
     int e2;
     if (ex.mode == 1) {                                       // ISA + Phi + PLCP in one scatter of the final suffix array
+        if (!want_phi && c.phi_lazy) A.phi = nullptr;
         build_isa_phi_plcp_fused(c, A.sa, ex.lcp8, n, A.isa, A.phi, A.plcp, d_max);
         e2 = ev ? ev->tick() : 0;
     } else {
@@ -276,7 +279,7 @@ size_t run_pipeline(Ctx& c, const u8* d_text, size_t n, u32 threshold, int flatt
     if (threshold == 0) throw ArgError{TDC_GPU_ERR_ARG, "threshold must be >= 1"};
     validate_device_text(c, d_text, n);
     DevArrays A;
-    run_textds(c, d_text, n, A, st, &ev);
+    run_textds(c, d_text, n, A, st, &ev, strategy != TDC_GPU_COMP_ARRAYS);
     const int enc_coder = lcpcomp_enc_coder(coder);
     run_factorize(c, n, A, threshold, flatten, st, &ev, strategy, enc_coder, d_text);
     EncodeStats es;
@@ -372,6 +375,7 @@ int tdc_gpu_ctx_create(int device, tdc_gpu_ctx** out) {
         if (const char* m = getenv("TDC_GPU_PLCP_SAMPLES")) ctx->c.plcp_samples = atoi(m) != 0;
         if (const char* m = getenv("TDC_GPU_SMALL_PIPELINE")) ctx->c.small_pipeline = atoi(m) != 0;
         if (const char* m = getenv("TDC_GPU_SMALL_BIG")) ctx->c.small_big = atoi(m);
+        if (const char* m = getenv("TDC_GPU_PHI_LAZY")) ctx->c.phi_lazy = atoi(m) != 0;
         if (const char* m = getenv("TDC_GPU_FS_PAIR")) ctx->c.fs_pair = atoi(m) != 0;
         if (const char* m = getenv("TDC_GPU_ENC_EARLY")) ctx->c.enc_early = atoi(m);
         if (const char* m = getenv("TDC_GPU_ENC_REC")) ctx->c.enc_rec = atoi(m) != 0;

@@ -148,6 +148,7 @@ struct Ctx {
     int window_lcut = 48;          // factorize: levels <= this run window-local in one launch (env TDC_GPU_WINDOW_LCUT, 0 disables)
     int window_halo = 384;         // window pass: halo of the first attempt (env TDC_GPU_WINDOW_HALO; a failed border retries with 2048)
     size_t dec_seg = 0;            // decompression: bit positions per segment of the chain marking (0: 2^30; env TDC_GPU_DEC_SEG, tests)
+    bool phi_lazy = true;          // lcpcomp(comp=arrays) behind the fused scatter: no Phi array, a factor's source is SA[ISA[p] - 1] (env TDC_GPU_PHI_LAZY=0: Phi as before)
     int dec_parse = 1;             // decompression: token stream parsed on the device (env TDC_GPU_DEC_PARSE: 0 host parse, 1 streams >= 1 MiB, 2 always)
     int window_large_lists = 0;    // window pass: start with the large per-level lists (env TDC_GPU_WINDOW_LARGE=1; tests)
     int ssort = 1;                 // suffix array: splitter-partition sort (ssort.hip) instead of the 8-pass LSD sort for large inputs (env TDC_GPU_SSORT=0 disables)

@@ -79,9 +79,12 @@ __device__ __forceinline__ u32 bm_state(const u64* __restrict__ bm, u32 p) { ret
 // window pass fails); *d_entries counts all candidates ("entries" of the reference's log)
 // lvl_hist (nullable, 64 counters): every 16th candidate of a level below 64 is counted -- an estimate of how many entries a window of
 // the window pass will find in one level (its per-level LDS lists come in two sizes)
+// src_sa != nullptr (no Phi array: fused scatter without it): the source of a factor at p is SA[ISA[p] - 1] (ds/PhiFromSA.hpp:35-45); the
+// candidates of the global levels get it NOW, into fsrc[] -- their priorities (= ISA) may be overwritten by a push before they are selected
 __global__ __launch_bounds__(256) void cand_class_kernel(const u32* __restrict__ plcp, size_t n, u32 threshold, u32 lo, u8* __restrict__ cls,
                                                           u32* __restrict__ flen, u8* __restrict__ res8, u32* __restrict__ d_entries,
-                                                          u32* __restrict__ lvl_hist) {
+                                                          u32* __restrict__ lvl_hist, const u32* __restrict__ src_sa, const u32* __restrict__ src_isa,
+                                                          u32* __restrict__ fsrc) {
     __shared__ u32 sm[4];
     __shared__ u32 sh[64];
     if (threadIdx.x < 64) sh[threadIdx.x] = 0;
@@ -101,6 +104,7 @@ __global__ __launch_bounds__(256) void cand_class_kernel(const u32* __restrict__
             rw |= (is_cand ? (v[j] > 255u ? 255u : v[j]) : 0u) << (8 * j);     // list that holds the entry of p (saturated)
             cnt += is_cand;
             if (lvl_hist && is_cand && v[j] < 64u && j == 0 && (q & 3) == 0) atomicAdd(&sh[v[j]], 1u);     // (every 16th position)
+            if (src_sa && is_cand && v[j] > lo) { const u32 r = src_isa[4 * q + j]; fsrc[4 * q + j] = r ? src_sa[r - 1] : src_sa[n - 1]; }
         }
         ((u32*)cls)[q] = cw;
         ((uint4*)flen)[q] = make_uint4(0, 0, 0, 0);
@@ -114,6 +118,7 @@ __global__ __launch_bounds__(256) void cand_class_kernel(const u32* __restrict__
         if (res8) res8[p] = is_cand ? (u8)(v > 255u ? 255u : v) : (u8)0;
         cnt += is_cand;
         if (lvl_hist && is_cand && v < 64u && (p & 15) == 0) atomicAdd(&sh[v], 1u);
+        if (src_sa && is_cand && v > lo) { const u32 r = src_isa[p]; fsrc[p] = r ? src_sa[r - 1] : src_sa[n - 1]; }
     }
     cnt = wave_reduce_sum(cnt);
     if (lane_id() == 0) sm[wave_id()] = cnt;
@@ -124,11 +129,14 @@ __global__ __launch_bounds__(256) void cand_class_kernel(const u32* __restrict__
 // after a failed window pass: the original candidates of the levels threshold .. lcut that are still in their lists
 // (pushed entries carry priorities >= n and are tracked by the push pool)
 __global__ void cand_rebuild_class_kernel(const u8* __restrict__ res8, const u32* __restrict__ prio, size_t n, u32 threshold, u32 lcut,
-                                          u8* __restrict__ cls) {
+                                          u8* __restrict__ cls, const u32* __restrict__ src_sa, u32* __restrict__ fsrc) {
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     const u32 r = res8[p];
-    cls[p] = (r >= threshold && r <= lcut && prio[p] < (u32)n) ? 1 : 0;
+    const u32 pr = prio[p];
+    const bool c1 = r >= threshold && r <= lcut && pr < (u32)n;
+    cls[p] = c1 ? 1 : 0;
+    if (c1 && src_sa) fsrc[p] = pr ? src_sa[pr - 1] : src_sa[n - 1];          // (no Phi array: see cand_class_kernel)
 }
 __global__ void gather_u8_kernel(const u32* __restrict__ idx, size_t m, const u8* __restrict__ src, u32* __restrict__ dst) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1051,7 +1059,11 @@ __global__ __launch_bounds__(256) void apply_kernel(const u32* __restrict__ live
 
 void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi, u32* plcp, u32 maxlcp, u32 threshold,
                       FactorSpace& fs, FactorizeStats* st) {
-    (void)sa;    // the candidate order of the reference (ascending SA index) is carried by prio[] = ISA
+    // (the candidate order of the reference -- ascending SA index -- is carried by prio[] = ISA.)  phi == nullptr: there is no Phi array;
+    // the source of a factor at p is SA[ISA[p] - 1].  The candidates of the global levels get theirs into fsrc[] up front
+    // (cand_class_kernel), so the global kernels read "Phi" from fsrc[] itself (fsrc[p] = fsrc[p] at a selection); the window kernel
+    // computes it at its factor starts (their ISA is intact: window-local pushes do not touch prio[]).
+    const u32* phi_eff = phi ? phi : fs.fsrc;
     FactorizeStats local;
     if (!st) st = &local;
     *st = FactorizeStats();
@@ -1081,7 +1093,8 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
     HIP_TRY(hipMemsetAsync(d_lvlhist, 0, 64 * sizeof(u32), s));
     {
         Ctx::ProfScope prof(c, K_CAND, (u64)n * (lcut ? 10 : 9));
-        cand_class_kernel<<<(gn < 8192u ? gn : 8192u), 256, 0, s>>>(plcp, n, threshold, lcut, cls, fs.flen, res8, d_cnt + 1, lcut ? d_lvlhist : nullptr);
+        cand_class_kernel<<<(gn < 8192u ? gn : 8192u), 256, 0, s>>>(plcp, n, threshold, lcut, cls, fs.flen, res8, d_cnt + 1, lcut ? d_lvlhist : nullptr,
+                                                                    phi ? nullptr : sa, isa, fs.fsrc);
         LAUNCH_CHECK();
     }
     if ((u64)maxlcp + 1 <= threshold || threshold == 0) { c.arena.release(mark); build_owner(c, n, fs); return; }   // ArraysComp.hpp:50
@@ -1228,7 +1241,7 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
                 for (u32 v = threshold; v <= lcut && v < 64u; ++v) mx = std::max<u64>(mx, hh[v]);
                 start_large = (double)mx * 16.0 * (double)window_levels_window() / (double)n > 4.0 * (double)window_levels_small_list();
             }
-            const int why = factorize_window_levels(c, n, cur, prio, res8, phi, lcut, threshold, fs, &nf, start_large);
+            const int why = factorize_window_levels(c, n, cur, prio, res8, phi, sa, lcut, threshold, fs, &nf, start_large);
             const bool ok = why == 0;
             st->window_pass = ok ? 1 : 2;
             st->window_lcut = lcut;
@@ -1236,7 +1249,7 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
             // the lists of the levels L .. threshold were never materialised: build them from the residence bytes
             {
                 Ctx::ProfScope prof(c, K_CAND, (u64)n * 6);
-                cand_rebuild_class_kernel<<<gn, 256, 0, s>>>(res8, prio, n, threshold, L, cls);
+                cand_rebuild_class_kernel<<<gn, 256, 0, s>>>(res8, prio, n, threshold, L, cls, phi ? nullptr : sa, fs.fsrc);
                 LAUNCH_CHECK();
             }
             build_lists(false, L);
@@ -1481,17 +1494,17 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
                     u32* zsegs = zc ? c.zc_dev + (size_t)(1 + slot) * Ctx::ZC_WORDS + Ctx::ZC_SEG_OFF : nullptr;
                     if (inst == 2)
                         small_level_kernel<1024, true><<<1, 1024, 0, s>>>(cand + h_segstart[lv], a0, pushed_src, (u32)mm, pool, d_hgtab ? d_hgtab + (size_t)slot * half : nullptr, gn, lv,
-                                                                  threshold, n, cur, prio, phi, fs.flen, res8, fs.fsrc, (u32)pool_top, prio_base, d_segs2[slot], seg_cap, live,
+                                                                  threshold, n, cur, prio, phi_eff, fs.flen, res8, fs.fsrc, (u32)pool_top, prio_base, d_segs2[slot], seg_cap, live,
                                                                   /*inline_budget=*/1u << 17, d_sc2[slot], zdst, zflag, zseq, d_sprof, zsegs,
                                                                   d_ctl, spec ? 1u : 0u, d_sc2[slot ^ 1], d_segs2[slot ^ 1], d_lcount + lv);
                     else if (inst == 1)
                         small_level_kernel<512><<<1, 512, 0, s>>>(cand + h_segstart[lv], a0, pushed_src, (u32)mm, pool, d_hgtab ? d_hgtab + (size_t)slot * half : nullptr, gn, lv,
-                                                                  threshold, n, cur, prio, phi, fs.flen, res8, fs.fsrc, (u32)pool_top, prio_base, d_segs2[slot], seg_cap, live,
+                                                                  threshold, n, cur, prio, phi_eff, fs.flen, res8, fs.fsrc, (u32)pool_top, prio_base, d_segs2[slot], seg_cap, live,
                                                                   /*inline_budget=*/1u << 17, d_sc2[slot], zdst, zflag, zseq, d_sprof, zsegs,
                                                                   d_ctl, spec ? 1u : 0u, d_sc2[slot ^ 1], d_segs2[slot ^ 1], d_lcount + lv);
                     else
                         small_level_kernel<256><<<1, 256, 0, s>>>(cand + h_segstart[lv], a0, pushed_src, (u32)mm, pool, d_hgtab ? d_hgtab + (size_t)slot * half : nullptr, gn, lv,
-                                                                  threshold, n, cur, prio, phi, fs.flen, res8, fs.fsrc, (u32)pool_top, prio_base, d_segs2[slot], seg_cap, live,
+                                                                  threshold, n, cur, prio, phi_eff, fs.flen, res8, fs.fsrc, (u32)pool_top, prio_base, d_segs2[slot], seg_cap, live,
                                                                   /*inline_budget=*/1u << 17, d_sc2[slot], zdst, zflag, zseq, d_sprof, zsegs,
                                                                   d_ctl, spec ? 1u : 0u, d_sc2[slot ^ 1], d_segs2[slot ^ 1], d_lcount + lv);
                     LAUNCH_CHECK();
@@ -1540,7 +1553,7 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
                     last_alive = h_sc.nlive + h_sc.nstale;
                     if (slim_penalty) --slim_penalty;
                     if (h_sc.pad[0]) {                             // many long factors: the kills are spread over the whole chip
-                        apply_list_kernel<<<cdiv((size_t)h_sc.selected * 64, 256), 256, 0, s>>>(live, &d_sc2[cur_f.slot]->selected, LL, n, phi, cur, fs.flen, fs.fsrc);
+                        apply_list_kernel<<<cdiv((size_t)h_sc.selected * 64, 256), 256, 0, s>>>(live, &d_sc2[cur_f.slot]->selected, LL, n, phi_eff, cur, fs.flen, fs.fsrc);
                         LAUNCH_CHECK();
                     }
                     pushed_into.drop(LL);
@@ -1680,8 +1693,8 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
         if (nl) {
             // per entry: list + state (5); per factor: Phi, flen, fsrc (12) + L kills (8 B each) + L truncations (4 B each)
             Ctx::ProfScope prof(c, K_APPLY, (u64)nl * 5 + (u64)nl * (12 + 12ull * L));
-            if (wide) apply_kernel<64><<<gl, 256, 0, s>>>(live, nl, L, n, bm, phi, cur, fs.flen, fs.fsrc, d_sc);
-            else      apply_kernel<1><<<gl, 256, 0, s>>>(live, nl, L, n, bm, phi, cur, fs.flen, fs.fsrc, d_sc);
+            if (wide) apply_kernel<64><<<gl, 256, 0, s>>>(live, nl, L, n, bm, phi_eff, cur, fs.flen, fs.fsrc, d_sc);
+            else      apply_kernel<1><<<gl, 256, 0, s>>>(live, nl, L, n, bm, phi_eff, cur, fs.flen, fs.fsrc, d_sc);
             LAUNCH_CHECK();
         }
         c.read_n((const u32*)d_sc, (u32*)&h_sc, 8);
@@ -1976,7 +1989,7 @@ void factorize_max_lcp(Ctx& c, size_t n, u32* isa, const u32* phi, u32* plcp, u3
     u32* cvals[2] = { c.arena.get<u32>(n), c.arena.get<u32>(n) };
     u32* d_cnt = c.arena.get<u32>(4);
     HIP_TRY(hipMemsetAsync(d_cnt, 0, 4 * sizeof(u32), s));
-    cand_class_kernel<<<(gn < 8192u ? gn : 8192u), 256, 0, s>>>(plcp, n, threshold, 0u, cls, fs.flen, nullptr, d_cnt + 1, nullptr);
+    cand_class_kernel<<<(gn < 8192u ? gn : 8192u), 256, 0, s>>>(plcp, n, threshold, 0u, cls, fs.flen, nullptr, d_cnt + 1, nullptr, nullptr, nullptr, nullptr);
     LAUNCH_CHECK();
     if (maxlcp < threshold || threshold == 0) { c.arena.release(mark); build_owner(c, n, fs); return; }
     mlcp_init_prio_kernel<<<gn, 256, 0, s>>>(prio, n);

@@ -10,6 +10,8 @@
 #include "stages.hpp"
 #include "prim.hpp"
 
+#include <type_traits>
+
 namespace tdc {
 
 constexpr int FS_TILE = 4096;        // = SS_TILE of ssort.hip (the row-block tables assume it)
@@ -17,8 +19,8 @@ constexpr int FS_ITEMS = 16;
 constexpr u32 FS_WMAX = 8192;
 
 struct FSLevel {
-    const u32* idx_in; const u64* rp_in; const u32* prev_in; const u8* lcp_in;    // rp: rank | predecessor << 32 (level 1: rank = index, prev_in = sa)
-    u32* idx_out; u64* rp_out; u8* lcp_out;
+    const u32* idx_in; const void* rp_in; const u32* prev_in; const u8* lcp_in;   // rp: rank | predecessor << 32 (level 1: rank = index, prev_in = sa);
+    u32* idx_out; void* rp_out; u8* lcp_out;                                      //     without Phi (WP = false) the rank alone, 4 bytes
     u32* counts; const u32* blk_seg; const u32* blk_start; const u32* seg_start;
     u32 nseg, R, per_xcd; int shift;
     int lsh;                                                  // FIRST: the LCP byte goes to the bits [lsh, lsh + 8) of the index word (the top digit leaves)
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(256) void fs_count_kernel(FSLevel P, u32 rows) {
 // one segment, their inputs are adjacent and so are their runs of every digit in the output (the offsets are a running prefix inside
 // the block), and the order inside a bucket does not matter here.  With 512 buckets a 4 096-record tile leaves 8 records per bucket:
 // 32-byte runs of index words, i.e. partial lines (1.5 x the algorithmic write traffic in the PMC counters); twice the tile, twice the run.
-template <int DB, bool FIRST, int PAIR>
+template <int DB, bool FIRST, int PAIR, bool WP>
 __global__ __launch_bounds__(256 * PAIR) __attribute__((amdgpu_waves_per_eu(TDC_FS_WPE, TDC_FS_WPE))) void fs_scatter_kernel(FSLevel P, u32 rows) {
     constexpr int NT = 256 * PAIR;
     constexpr u32 TILE = (u32)FS_TILE * PAIR;
@@ -102,7 +104,8 @@ __global__ __launch_bounds__(256 * PAIR) __attribute__((amdgpu_waves_per_eu(TDC_
 #pragma unroll
     for (int j = 0; j < FS_ITEMS; ++j) k[j] = (lb + (u32)j * 64 < cnt) ? ip[j * 64] : 0u;
     // every stream of the thread's records is requested up front: the staging phases below then never wait for global memory
-    u64 rp[FS_ITEMS];
+    using RT = typename std::conditional<WP, u64, u32>::type;   // the second stream: rank (| predecessor)
+    RT rp[FS_ITEMS];
     u32 lc[FS_ITEMS];
     const u8* lst = (const u8*)stage;                           // FIRST: the tile's LCP bytes, staged with 16-byte loads (sixteen byte loads per
     size_t lmis = 0;                                            // thread fetched 64 bytes per wave instruction)
@@ -118,8 +121,8 @@ __global__ __launch_bounds__(256 * PAIR) __attribute__((amdgpu_waves_per_eu(TDC_
     for (int j = 0; j < FS_ITEMS; ++j) {
         const u32 e = lb + (u32)j * 64;
         const bool valid = e < cnt;
-        if (FIRST) rp[j] = (u64)(u32)(base + e + 1) | ((u64)(valid ? P.prev_in[base + e] : 0u) << 32);
-        else rp[j] = valid ? P.rp_in[base + e] : 0ull;
+        if (FIRST) { if constexpr (WP) rp[j] = (u64)(u32)(base + e + 1) | ((u64)(valid ? P.prev_in[base + e] : 0u) << 32); else rp[j] = (u32)(base + e + 1); }
+        else rp[j] = valid ? ((const RT*)P.rp_in)[base + e] : (RT)0;
         lc[j] = (FIRST && valid) ? (u32)lst[lmis + e] : 0u;
     }
 #pragma unroll
@@ -178,34 +181,38 @@ __global__ __launch_bounds__(256 * PAIR) __attribute__((amdgpu_waves_per_eu(TDC_
         }
     }
     __syncthreads();
-    // stream 2: rank and predecessor as one 8-byte word
+    // stream 2: rank and predecessor as one 8-byte word (the rank alone without Phi)
+    RT* stage2 = (RT*)stage;
 #pragma unroll
-    for (int j = 0; j < FS_ITEMS; ++j) if (lb + (u32)j * 64 < cnt) stage[pos[j]] = rp[j];
+    for (int j = 0; j < FS_ITEMS; ++j) if (lb + (u32)j * 64 < cnt) stage2[pos[j]] = rp[j];
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < FS_ITEMS; ++r) if (dst[r] != 0xFFFFFFFFu) P.rp_out[dst[r]] = stage[(u32)r * NT + threadIdx.x];
+    for (int r = 0; r < FS_ITEMS; ++r) if (dst[r] != 0xFFFFFFFFu) ((RT*)P.rp_out)[dst[r]] = stage2[(u32)r * NT + threadIdx.x];
 }
 
 // After the partition by the top 2 * DB index bits, window w holds exactly the records of the positions [w * W, (w + 1) * W) (position
 // n - 1 = sa[0] has no record).  One workgroup per window: each array is scattered into an LDS image of the window and leaves as whole
 // lines.
 constexpr int FS_IMG_T = 1024;       // threads of the image kernel: a window's records are loaded ONCE, eight per thread
-__global__ __launch_bounds__(FS_IMG_T) void fs_image_kernel(const u32* __restrict__ idx, const u64* __restrict__ rp, int lsh, size_t m, u32 W,
+template <bool WP>
+__global__ __launch_bounds__(FS_IMG_T) void fs_image_kernel(const u32* __restrict__ idx, const void* __restrict__ rp_v, int lsh, size_t m, u32 W,
                                                              u32* __restrict__ isa, u32* __restrict__ phi, u32* __restrict__ plcp, u32* __restrict__ d_max) {
     __shared__ u32 img[FS_WMAX];
     __shared__ u32 smx[FS_IMG_T / 64];
     constexpr int R = FS_WMAX / FS_IMG_T;
     const size_t base = (size_t)blockIdx.x * W;
     const size_t end = (base + W < m) ? base + W : m;
+    using RT = typename std::conditional<WP, u64, u32>::type;
+    const RT* rp = (const RT*)rp_v;
     u32 ix[R];
-    u64 rr[R];
+    RT rr[R];
     u32 mx = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {                               // (round 2 of this kernel read idx three times and rp twice: 28 bytes per record)
         const size_t j = base + (size_t)r * FS_IMG_T + threadIdx.x;
         const bool have = j < end;
         ix[r] = have ? idx[j] : 0xFFFFFFFFu;
-        rr[r] = have ? rp[j] : 0ull;
+        rr[r] = have ? rp[j] : (RT)0;
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) if (ix[r] != 0xFFFFFFFFu) img[ix[r] & (W - 1)] = (u32)rr[r];
@@ -213,12 +220,14 @@ __global__ __launch_bounds__(FS_IMG_T) void fs_image_kernel(const u32* __restric
 #pragma unroll
     for (int r = 0; r < R; ++r) { const size_t q = base + (size_t)r * FS_IMG_T + threadIdx.x; if (q < end) isa[q] = img[q - base]; }
     __syncthreads();
+    if constexpr (WP) {
 #pragma unroll
-    for (int r = 0; r < R; ++r) if (ix[r] != 0xFFFFFFFFu) img[ix[r] & (W - 1)] = (u32)(rr[r] >> 32);
-    __syncthreads();
+        for (int r = 0; r < R; ++r) if (ix[r] != 0xFFFFFFFFu) img[ix[r] & (W - 1)] = (u32)(rr[r] >> 32);
+        __syncthreads();
 #pragma unroll
-    for (int r = 0; r < R; ++r) { const size_t q = base + (size_t)r * FS_IMG_T + threadIdx.x; if (q < end) phi[q] = img[q - base]; }
-    __syncthreads();
+        for (int r = 0; r < R; ++r) { const size_t q = base + (size_t)r * FS_IMG_T + threadIdx.x; if (q < end) phi[q] = img[q - base]; }
+        __syncthreads();
+    }
 #pragma unroll
     for (int r = 0; r < R; ++r) if (ix[r] != 0xFFFFFFFFu) { const u32 l = (ix[r] >> lsh) & 0xFFu; img[ix[r] & (W - 1)] = l; mx = max(mx, l); }
     __syncthreads();
@@ -236,7 +245,7 @@ __global__ __launch_bounds__(FS_IMG_T) void fs_image_kernel(const u32* __restric
 
 __global__ void fs_first_kernel(const u32* __restrict__ sa, size_t n, u32* __restrict__ isa, u32* __restrict__ phi, u32* __restrict__ plcp) {
     const u32 p = sa[0];
-    isa[p] = 0; phi[p] = sa[n - 1]; plcp[p] = 0;
+    isa[p] = 0; if (phi) phi[p] = sa[n - 1]; plcp[p] = 0;
 }
 __global__ void fs_direct_kernel(const u32* __restrict__ sa, const u8* __restrict__ lcp8, size_t n, u32* __restrict__ isa, u32* __restrict__ phi,
                                  u32* __restrict__ plcp, u32* __restrict__ d_max) {
@@ -245,7 +254,7 @@ __global__ void fs_direct_kernel(const u32* __restrict__ sa, const u8* __restric
     if (i < n) {
         const u32 p = sa[i];
         isa[p] = (u32)i;
-        phi[p] = (i == 0) ? sa[n - 1] : sa[i - 1];
+        if (phi) phi[p] = (i == 0) ? sa[n - 1] : sa[i - 1];
         l = (i == 0) ? 0u : (u32)lcp8[i];
         plcp[p] = l;
     }
@@ -269,7 +278,8 @@ void build_isa_phi_plcp_fused(Ctx& c, const u32* sa, const u8* lcp8, size_t n, u
     const int db = (bits - 16 > 13) ? 9 : 8;
     const u32 D = 1u << db;
     u32* idx[2] = { c.arena.get<u32>(m), c.arena.get<u32>(m) };
-    u64* rp[2] = { c.arena.get<u64>(m), c.arena.get<u64>(m) };
+    const bool wp = phi != nullptr;                           // phi == nullptr: ISA and PLCP only, 8-byte records (the factorizer then takes a factor's source from SA[ISA[p] - 1])
+    void* rp[2] = { c.arena.alloc(m * (wp ? 8 : 4)), c.arena.alloc(m * (wp ? 8 : 4)) };
     const u32* seg_start = ss_first_segment(c, m);
     u32 nseg = 1;
     for (int l = 0; l < 2; ++l) {
@@ -295,19 +305,23 @@ void build_isa_phi_plcp_fused(Ctx& c, const u32* sa, const u8* lcp8, size_t n, u
         }
         ss_level_offsets(c, Tb, seg_start, nseg, D, nstart, m);
         {
-            const int ps = c.prof_begin(K_RS_SCATTER_U32, (u64)m * (l == 0 ? 5 + 12 : 24));
+            const int ps = c.prof_begin(K_RS_SCATTER_U32, (u64)m * (wp ? (l == 0 ? 5 + 12 : 24) : (l == 0 ? 5 + 8 : 16)));
             const bool pair = (Tb.R % 2) == 0 && c.fs_pair;             // (rows per block is a power of two: a pair never straddles a block)
             FSLevel P2 = P;
             const u32 groups = pair ? (rows + 1) / 2 : rows;
             P2.per_xcd = (c.xcd_remap == 1 && groups >= 64) ? cdiv(groups, 8) : 0u;
             const u32 grid2 = P2.per_xcd ? 8 * P2.per_xcd : groups;
-            if (pair) {
-                if (l == 0) { if (db == 9) fs_scatter_kernel<9, true, 2><<<grid2, 512, 0, s>>>(P2, rows); else fs_scatter_kernel<8, true, 2><<<grid2, 512, 0, s>>>(P2, rows); }
-                else { if (db == 9) fs_scatter_kernel<9, false, 2><<<grid2, 512, 0, s>>>(P2, rows); else fs_scatter_kernel<8, false, 2><<<grid2, 512, 0, s>>>(P2, rows); }
-            } else {
-                if (l == 0) { if (db == 9) fs_scatter_kernel<9, true, 1><<<grid, 256, 0, s>>>(P, rows); else fs_scatter_kernel<8, true, 1><<<grid, 256, 0, s>>>(P, rows); }
-                else { if (db == 9) fs_scatter_kernel<9, false, 1><<<grid, 256, 0, s>>>(P, rows); else fs_scatter_kernel<8, false, 1><<<grid, 256, 0, s>>>(P, rows); }
-            }
+            auto launch = [&](auto wpc) {
+                constexpr bool WPC = decltype(wpc)::value;
+                if (pair) {
+                    if (l == 0) { if (db == 9) fs_scatter_kernel<9, true, 2, WPC><<<grid2, 512, 0, s>>>(P2, rows); else fs_scatter_kernel<8, true, 2, WPC><<<grid2, 512, 0, s>>>(P2, rows); }
+                    else { if (db == 9) fs_scatter_kernel<9, false, 2, WPC><<<grid2, 512, 0, s>>>(P2, rows); else fs_scatter_kernel<8, false, 2, WPC><<<grid2, 512, 0, s>>>(P2, rows); }
+                } else {
+                    if (l == 0) { if (db == 9) fs_scatter_kernel<9, true, 1, WPC><<<grid, 256, 0, s>>>(P, rows); else fs_scatter_kernel<8, true, 1, WPC><<<grid, 256, 0, s>>>(P, rows); }
+                    else { if (db == 9) fs_scatter_kernel<9, false, 1, WPC><<<grid, 256, 0, s>>>(P, rows); else fs_scatter_kernel<8, false, 1, WPC><<<grid, 256, 0, s>>>(P, rows); }
+                }
+            };
+            if (wp) launch(std::true_type{}); else launch(std::false_type{});
             LAUNCH_CHECK();
             c.prof_end(ps);
         }
@@ -318,8 +332,9 @@ void build_isa_phi_plcp_fused(Ctx& c, const u32* sa, const u8* lcp8, size_t n, u
     {
         const u32 W = 1u << (bits - 2 * db);
         if (W > FS_WMAX) throw HipError{hipErrorUnknown, "fused scatter: window larger than the LDS image", (int)__LINE__};
-        Ctx::ProfScope prof(c, K_FS_IMAGE, (u64)m * 24);          // 12 bytes in, 12 out
-        fs_image_kernel<<<cdiv(m, W), FS_IMG_T, 0, s>>>(idx[1], rp[1], bits - db, m, W, isa, phi, plcp, d_maxlcp);
+        Ctx::ProfScope prof(c, K_FS_IMAGE, (u64)m * (wp ? 24 : 16));          // 12 bytes in, 12 out (8 + 8 without Phi)
+        if (wp) fs_image_kernel<true><<<cdiv(m, W), FS_IMG_T, 0, s>>>(idx[1], rp[1], bits - db, m, W, isa, phi, plcp, d_maxlcp);
+        else fs_image_kernel<false><<<cdiv(m, W), FS_IMG_T, 0, s>>>(idx[1], rp[1], bits - db, m, W, isa, phi, plcp, d_maxlcp);
         LAUNCH_CHECK();
         fs_first_kernel<<<1, 1, 0, s>>>(sa, n, isa, phi, plcp);
         LAUNCH_CHECK();
