@@ -262,6 +262,8 @@ void run_factorize(Ctx& c, size_t n, DevArrays& A, u32 threshold, int flatten, t
         }
     } else if (flatten) {
         flatten_factors(c, n, A.fs, &fl);
+    } else {
+        materialize_sources(c, n, A.fs);                   // (no Phi array: the encoder reads fsrc[] at every factor start)
     }
     const int e2 = ev ? ev->tick() : 0;
     if (st) {

@@ -1097,7 +1097,7 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
                                                                     phi ? nullptr : sa, isa, fs.fsrc);
         LAUNCH_CHECK();
     }
-    if ((u64)maxlcp + 1 <= threshold || threshold == 0) { c.arena.release(mark); build_owner(c, n, fs); return; }   // ArraysComp.hpp:50
+    if ((u64)maxlcp + 1 <= threshold || threshold == 0) { c.arena.release(mark); build_owner(c, n, fs); if (!phi) { fs.src_prio = prio; fs.src_sa = sa; fs.src_n = n; } return; }   // ArraysComp.hpp:50
     const size_t nlev = (size_t)maxlcp + 2;
     // first / last candidate index per level (device copies only live from seg_bounds_kernel to the read-back: they share the
     // memory of the push records of the general path; a text that is one long run has as many levels as positions)
@@ -1241,7 +1241,7 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
                 for (u32 v = threshold; v <= lcut && v < 64u; ++v) mx = std::max<u64>(mx, hh[v]);
                 start_large = (double)mx * 16.0 * (double)window_levels_window() / (double)n > 4.0 * (double)window_levels_small_list();
             }
-            const int why = factorize_window_levels(c, n, cur, prio, res8, phi, sa, lcut, threshold, fs, &nf, start_large);
+            const int why = factorize_window_levels(c, n, cur, prio, res8, phi, lcut, threshold, fs, &nf, start_large);
             const bool ok = why == 0;
             st->window_pass = ok ? 1 : 2;
             st->window_lcut = lcut;
@@ -1754,7 +1754,7 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
         }
     }
     c.arena.release(mark);
-    build_owner(c, n, fs);
+    build_owner(c, n, fs); if (!phi) { fs.src_prio = prio; fs.src_sa = sa; fs.src_n = n; }
 }
 
 // ============================================================================================================

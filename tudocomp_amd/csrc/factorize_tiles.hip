@@ -127,9 +127,9 @@ struct WinScalars { u32 fail; int min_margin; unsigned long long factors; u32 ma
 // (the window-local priorities) is ordered by the one full barrier per level.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int KT, int TE, int TP, int WPE>      // threads, list sizes; WPE = waves per SIMD the register budget is set for
+template <int KT, int TE, int TP, int WPE, bool WPHI>      // threads, list sizes; WPE = waves per SIMD the register budget is set for; WPHI: sources from a Phi array
 __global__ __launch_bounds__(KT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void window_levels_kernel(const u32* __restrict__ cur_g, const u32* __restrict__ prio_g,
-                                                            const u8* __restrict__ res_g, const u32* __restrict__ phi, const u32* __restrict__ sa, size_t n,
+                                                            const u8* __restrict__ res_g, const u32* __restrict__ phi, size_t n,
                                                             u32 lcut, u32 threshold, u32 ntiles, u32 halo, u32* __restrict__ lprio_all,
                                                             u32* __restrict__ flen, u32* __restrict__ fsrc, WinScalars* __restrict__ sc) {
     // (the constants of the small variant, redefined for this instance's thread count: the large lists leave room for one workgroup per
@@ -513,11 +513,8 @@ __global__ __launch_bounds__(KT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                             if (pos < ia || pos >= ib) continue;
                             const size_t gp = w0 + pos;
                             flen[gp] = (u32)(rw >> (8 * bb)) & 0x3Fu;
-                            if (phi) fsrc[gp] = phi[gp];
-                            else {                          // no Phi array: SA[ISA[p] - 1]; a position pushed at a global level got its source then
-                                const u32 pr = prio_g[gp];
-                                if (pr < (u32)n) fsrc[gp] = pr ? sa[pr - 1] : sa[n - 1];
-                            }
+                            if constexpr (WPHI) fsrc[gp] = phi[gp];     // (without a Phi array the sources are computed from SA[ISA[p] - 1] where they
+                                                                        //  are needed: FactorSpace::src_prio, flatten.hip)
                             ++nsel_interior;
                         }
                     }
@@ -544,7 +541,7 @@ u32 window_levels_window() { return (u32)TW; }
 u32 window_levels_small_list() { return (u32)TE_SMALL; }
 size_t window_levels_min_text() { return (size_t)4 * TW; }
 
-int factorize_window_levels(Ctx& c, size_t n, const u32* cur, const u32* prio, const u8* res8, const u32* phi, const u32* sa, u32 lcut, u32 threshold,
+int factorize_window_levels(Ctx& c, size_t n, const u32* cur, const u32* prio, const u8* res8, const u32* phi, u32 lcut, u32 threshold,
                             FactorSpace fs, u64* nfactors, bool start_large) {
     *nfactors = 0;
     if (lcut < threshold) return 0;
@@ -572,10 +569,13 @@ int factorize_window_levels(Ctx& c, size_t n, const u32* cur, const u32* prio, c
         {
             // per window position: cur (4) + residence (1); per text position: ~0.3 priority reads and the factor output
             Ctx::ProfScope prof(c, K_WINDOW_LEVELS, (u64)((double)n * TW / ti * 5) + (u64)n * 2);
-            if (!large)
-                window_levels_kernel<TT, TE_SMALL, TP_SMALL, TDC_WIN_WPE><<<grid, TT, 0, s>>>(cur, prio, res8, phi, sa, n, lcut, threshold, ntiles, halo, lprio, fs.flen, fs.fsrc, d_sc);
-            else
-                window_levels_kernel<TT_LARGE, TE_LARGE, TP_LARGE, TT_LARGE / 256><<<grid < 512u ? grid : 512u, TT_LARGE, 0, s>>>(cur, prio, res8, phi, sa, n, lcut, threshold, ntiles, halo, lprio, fs.flen, fs.fsrc, d_sc);
+            if (!large) {
+                if (phi) window_levels_kernel<TT, TE_SMALL, TP_SMALL, TDC_WIN_WPE, true><<<grid, TT, 0, s>>>(cur, prio, res8, phi, n, lcut, threshold, ntiles, halo, lprio, fs.flen, fs.fsrc, d_sc);
+                else window_levels_kernel<TT, TE_SMALL, TP_SMALL, TDC_WIN_WPE, false><<<grid, TT, 0, s>>>(cur, prio, res8, phi, n, lcut, threshold, ntiles, halo, lprio, fs.flen, fs.fsrc, d_sc);
+            } else {
+                if (phi) window_levels_kernel<TT_LARGE, TE_LARGE, TP_LARGE, TT_LARGE / 256, true><<<grid < 512u ? grid : 512u, TT_LARGE, 0, s>>>(cur, prio, res8, phi, n, lcut, threshold, ntiles, halo, lprio, fs.flen, fs.fsrc, d_sc);
+                else window_levels_kernel<TT_LARGE, TE_LARGE, TP_LARGE, TT_LARGE / 256, false><<<grid < 512u ? grid : 512u, TT_LARGE, 0, s>>>(cur, prio, res8, phi, n, lcut, threshold, ntiles, halo, lprio, fs.flen, fs.fsrc, d_sc);
+            }
             LAUNCH_CHECK();
         }
         h = c.read(d_sc);

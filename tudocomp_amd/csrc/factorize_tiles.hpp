@@ -11,9 +11,9 @@ namespace tdc {
 // not be completed -- bit 0: the known range shrank into an interior (a lower lcut may still work), bit 1: a level had
 // more entries than even the large LDS lists hold (the pass retries by itself with the large lists when the small ones
 // overflow) -- in which case the caller runs the global level loop.
-// phi may be NULL: the source of a factor at p is then sa[prio[p] - 1] where prio[p] is still ISA[p] (a position whose priority was overwritten
-// by a push at a global level has its source in fsrc[] already).
-int factorize_window_levels(Ctx& c, size_t n, const u32* cur, const u32* prio, const u8* res8, const u32* phi, const u32* sa, u32 lcut, u32 threshold,
+// phi may be NULL: fsrc[] is then left alone at the factor starts of this pass -- their sources are computed where they are needed
+// (FactorSpace::src_prio: SA[ISA[p] - 1]; prio[p] is still ISA[p] unless a push at a global level overwrote it, and then fsrc[p] was saved).
+int factorize_window_levels(Ctx& c, size_t n, const u32* cur, const u32* prio, const u8* res8, const u32* phi, u32 lcut, u32 threshold,
                              FactorSpace fs, u64* nfactors, bool start_large = false);
 u32 window_levels_window();         // positions per window
 u32 window_levels_small_list();     // entries of one level the small per-level lists hold

@@ -60,7 +60,15 @@ struct FactorSpace {
     // fills it (have_cls); the encoder's streaming passes then read 1 byte instead of the 4-byte owner word per position.
     u8* cls = nullptr;
     bool have_cls = false;
+    // lazy sources (round 4): set by factorize_arrays when there is no Phi array -- fsrc[] then holds the sources of the factors of the
+    // global levels only; the source of any factor start p is  src_prio[p] < src_n ? src_sa[src_prio[p] - 1] : fsrc[p]  (src_prio = ISA
+    // unless a push at a global level overwrote it, and such a position had its source saved first).  flatten_factors computes it
+    // while it builds its records; everyone else calls materialize_sources() first.
+    const u32* src_prio = nullptr;
+    const u32* src_sa = nullptr;
+    size_t src_n = 0;
 };
+void materialize_sources(Ctx& c, size_t n, FactorSpace& fs);    // fills fsrc[] at every factor start, clears src_prio
 
 struct FactorizeStats { u64 factors = 0; u32 maxlcp = 0; u32 levels = 0; u32 rounds = 0; u64 pushes = 0; u64 entries = 0; u32 small_levels = 0; u32 purges = 0;
                         u32 window_pass = 0; /* 0 not used, 1 low levels done window-local, 2 window pass failed -> global loop */
