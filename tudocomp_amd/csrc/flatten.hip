@@ -247,12 +247,31 @@ struct FlattenScalars { u32 waiting; u32 num_flattened; u32 max_depth; u32 pad; 
 // A factor that has to wait for the next round travels as a 16-byte work item { rank, len, current source, depth }: the
 // rounds read and write their work lists sequentially (appended per wave, in any order -- the result of a factor does not
 // depend on the order in which the waiting ones are visited), nothing about a waiting factor is gathered again.
+// the source of the factor that starts at p when there is no Phi array (FactorSpace::src_prio): SA[ISA[p] - 1], ds/PhiFromSA.hpp:35-45
+__device__ __forceinline__ u32 lazy_source(const u32* __restrict__ prio, const u32* __restrict__ sa, size_t n, const u32* __restrict__ fsrc, u32 p) {
+    const u32 r = prio[p];
+    return r < (u32)n ? (r ? sa[r - 1] : sa[n - 1]) : fsrc[p];
+}
 __global__ void flatten_init_kernel(const u32* __restrict__ fpos, size_t z, const u32* __restrict__ flen, const u32* __restrict__ orig,
-                                    uint4* __restrict__ rec, const u32* __restrict__ lenl) {
+                                    uint4* __restrict__ rec, const u32* __restrict__ lenl, const u32* __restrict__ src_prio,
+                                    const u32* __restrict__ src_sa, size_t src_n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= z) return;
     const u32 p = fpos[i];
-    rec[i] = make_uint4(p, lenl ? lenl[i] : flen[p], orig[p], NOT_DONE);     // (lenl: the lengths in list order -- one scattered line less per factor)
+    const u32 o = src_prio ? lazy_source(src_prio, src_sa, src_n, orig, p) : orig[p];
+    rec[i] = make_uint4(p, lenl ? lenl[i] : flen[p], o, NOT_DONE);     // (lenl: the lengths in list order -- one scattered line less per factor)
+}
+__global__ void sources_fill_kernel(const u32* __restrict__ fpos, size_t z, const u32* __restrict__ src_prio, const u32* __restrict__ src_sa,
+                                    size_t src_n, u32* fsrc) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= z) return;
+    const u32 p = fpos[i];
+    fsrc[p] = lazy_source(src_prio, src_sa, src_n, fsrc, p);
+}
+__global__ void sources_fill_pos_kernel(const u32* __restrict__ flen, size_t n, const u32* __restrict__ src_prio, const u32* __restrict__ src_sa,
+                                        size_t src_n, u32* fsrc) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n && flen[p]) fsrc[p] = lazy_source(src_prio, src_sa, src_n, fsrc, (u32)p);
 }
 
 // One round over the still-waiting factors.  FIRST: every factor, state taken from its record; else the items of `work`.
@@ -348,7 +367,18 @@ __global__ void flatten_commit_kernel(size_t z, const uint4* __restrict__ rec, u
     if (q.w != q.z) fsrc[q.x] = q.w;              // only the flattened ones moved
 }
 
+void materialize_sources(Ctx& c, size_t n, FactorSpace& fs) {
+    if (!fs.src_prio) return;
+    if (n) {
+        if (fs.have_list) { if (fs.nfact) sources_fill_kernel<<<cdiv(fs.nfact, 256), 256, 0, c.stream>>>(fs.fpos, fs.nfact, fs.src_prio, fs.src_sa, fs.src_n, fs.fsrc); }
+        else sources_fill_pos_kernel<<<cdiv(n, 256), 256, 0, c.stream>>>(fs.flen, n, fs.src_prio, fs.src_sa, fs.src_n, fs.fsrc);
+        LAUNCH_CHECK();
+    }
+    fs.src_prio = nullptr;
+}
+
 void flatten_factors(Ctx& c, size_t n, FactorSpace fs, FlattenStats* st, const std::function<void(int)>& between, void* rec_keep) {
+    if (fs.src_prio && !rec_keep) materialize_sources(c, n, fs);       // (the commit pass only writes the sources that moved)
     FlattenStats local;
     if (!st) st = &local;
     *st = FlattenStats();
@@ -362,7 +392,8 @@ void flatten_factors(Ctx& c, size_t n, FactorSpace fs, FlattenStats* st, const s
     FlattenScalars* d_sc = (FlattenScalars*)c.arena.alloc(sizeof(FlattenScalars));
     HIP_TRY(hipMemsetAsync(d_sc, 0, sizeof(FlattenScalars), s));
     const unsigned gz = cdiv(z, 256);
-    flatten_init_kernel<<<gz, 256, 0, s>>>(fpos, z, fs.flen, fs.fsrc, rec, fs.have_list ? fs.flenl : nullptr);
+    // (lazy sources are only left to this kernel by a caller that keeps the records: nothing is written back into fsrc[] then)
+    flatten_init_kernel<<<gz, 256, 0, s>>>(fpos, z, fs.flen, fs.fsrc, rec, fs.have_list ? fs.flenl : nullptr, fs.src_prio, fs.src_sa, fs.src_n);
     LAUNCH_CHECK();
     // work lists of the still-waiting factors (the first round visits every factor)
     uint4* work[2] = { (uint4*)c.arena.alloc(z * sizeof(uint4)), nullptr };
