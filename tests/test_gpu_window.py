@@ -207,3 +207,18 @@ def test_large_lists_give_the_same_factors(monkeypatch):
                 got, st = ctx.lcpcomp_compress(text, threshold=thr, flatten=1)
                 assert st["window_pass"] in (1, 2), (name, thr)
                 assert got == want, "%s t=%d (window_pass %d)" % (name, thr, st["window_pass"])
+
+
+def test_discarded_window_pass_falls_back_to_the_level_loop(monkeypatch):
+    """TDC_GPU_WINDOW_FORCE_FAIL=1: every window pass is discarded as if a border had failed, the global level loop evaluates the low
+    levels from the residence bytes.  On a text that takes the fused ISA / PLCP scatter without a Phi array (1 MiB and more, no deep
+    repeats) the sources of those levels' factors must then come from SA[ISA[p] - 1] saved by cand_rebuild_class_kernel."""
+    monkeypatch.setenv("TDC_GPU_WINDOW_FORCE_FAIL", "1")
+    with T.Context(0) as ctx:
+        for name, data, thr in (("english_3M", T.gen_english(3_000_000, 12).tobytes(), 2), ("english_1.5M_t5", T.gen_english(1_500_000, 13).tobytes(), 5)):
+            text = O.escape(data)
+            for fl in (1, 0):
+                want, _ = O.lcpcomp_huff_compress(text, thr, fl)
+                got, st = ctx.lcpcomp_compress(text, threshold=thr, flatten=fl)
+                assert st["window_pass"] == 2 and st["sa_mode"] == 1, (name, st["window_pass"], st["sa_mode"])
+                assert got == want, (name, fl)

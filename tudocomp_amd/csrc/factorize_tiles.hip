@@ -588,6 +588,7 @@ int factorize_window_levels(Ctx& c, size_t n, const u32* cur, const u32* prio, c
         }
 #endif
         if (getenv("TDC_GPU_LEVEL_LOG")) fprintf(stderr, "window pass: attempt %d halo %u lists %s -> fail %u, smallest margin %d\n", attempt, halo, large ? "large" : "small", h.fail, h.min_margin);
+        if (c.window_force_fail) h.fail |= 1u;                 // (tests: the pass is discarded as if a border had failed with the largest halo)
         result = (int)h.fail;
         if (!h.fail) break;
         window_cleanup_kernel<<<cdiv(n, 256), 256, 0, s>>>(fs.flen, n, lcut);     // forget the factors of the failed pass
@@ -595,7 +596,7 @@ int factorize_window_levels(Ctx& c, size_t n, const u32* cur, const u32* prio, c
         bool again = false;
         if ((h.fail & 2u) && !large) { large = true; again = true; }
         // (started with the large lists on a guess and a border failed: the retry keeps them -- they hold whatever the small ones do)
-        if ((h.fail & 1u) && halo < (u32)TH_MAX) { halo = TH_MAX; again = true; }
+        if ((h.fail & 1u) && halo < (u32)TH_MAX && !c.window_force_fail) { halo = TH_MAX; again = true; }
         if (!again) break;
     }
     c.arena.release(mark);
