@@ -491,3 +491,179 @@ def max_lcp_position_space(n, isa, phi, plcp, maxlcp, threshold):
                     pool.setdefault(d, []).append(s)
         t += len(sel)
     return factors
+
+
+def factorize_eager(n, isa, plcp, maxlcp, threshold, rng=None):
+    """Round 5: ArraysComp as a function of the factor SET (LCPCompressor sorts the factors by position before anything
+    reads them, LZSSFactors.hpp:69-76, so the emission order of ArraysComp.hpp:82-110 is not observable).
+
+    An entry is NATURAL while its working value is still its PLCP value and TRUNCATED once a selected factor at
+    p = x + cur[x] cut it.  A truncated entry x with cur[x] = v has no entry of value v in (x, x + v) (everything there
+    was cut to < v by the same factor) and no truncated one in (x - v, x) (its cutting factor would have cut x further),
+    so truncated entries of one level never conflict with each other and only ever lose against NATURAL entries to
+    their left -- which are originals of list v and therefore precede every pushed entry (ArraysComp.hpp:85-89 appends).
+    Hence: the order among pushed entries is irrelevant, and neither is the list an entry waits in: a cut entry can move
+    to list cur[x] at once (eager push-down).  Level L = all x with cur[x] == L; naturals in ISA order, then the truncated
+    ones in any order.  Returns the factor set {(pos, len)} and the number of entry visits."""
+    if maxlcp + 1 <= threshold:
+        return set(), 0
+    cur = [int(x) for x in plcp]
+    cur[n - 1] = 0
+    for p in range(n):
+        if isa[p] == 0:
+            cur[p] = 0                               # the candidate loop starts at SA index 1 (:54)
+    trunc = [False] * n
+    out = set()
+    visits = 0
+    for L in range(maxlcp, threshold - 1, -1):
+        ent = [p for p in range(n) if cur[p] == L]
+        nat = sorted((p for p in ent if not trunc[p]), key=lambda p: int(isa[p]))
+        tr = [p for p in ent if trunc[p]]
+        if rng:
+            rng.shuffle(tr)
+        for p in nat + tr:
+            visits += 1
+            if cur[p] != L:
+                continue
+            out.add((p, L))
+            for j in range(L):
+                cur[p + j] = 0
+            for j in range(min(L, p)):
+                q = p - 1 - j
+                if cur[q] > j + 1:
+                    cur[q] = j + 1
+                    trunc[q] = True
+    return out, visits
+
+
+def _global_levels_eager(n, isa, plcp, maxlcp, threshold, lcut):
+    """Levels maxlcp .. lcut+1 of factorize_eager; returns (factors, cur, trunc): the state handed to the eager tile pass."""
+    cur = [int(x) for x in plcp]
+    cur[n - 1] = 0
+    for p in range(n):
+        if isa[p] == 0:
+            cur[p] = 0
+    trunc = [False] * n
+    factors = []
+    for L in range(maxlcp, max(lcut, threshold - 1), -1):
+        ent = [p for p in range(n) if cur[p] == L]
+        order = sorted((p for p in ent if not trunc[p]), key=lambda p: int(isa[p])) + [p for p in ent if trunc[p]]
+        for p in order:
+            if cur[p] != L:
+                continue
+            factors.append((p, L))
+            for j in range(L):
+                cur[p + j] = 0
+            for j in range(min(L, p)):
+                q = p - 1 - j
+                if cur[q] > j + 1:
+                    cur[q] = j + 1
+                    trunc[q] = True
+    return factors, cur, trunc
+
+
+def factorize_tile_eager(n, w0, w1, a, b, cur_g, trunc_g, isa, threshold, lcut):
+    """Round 5 window pass (factorize_tiles.hip, window_eager_kernel): levels lcut .. threshold of the window [w0, w1) from ONE state
+    byte per position -- value (the working LCP, which is also the list the entry waits in: cut entries move at once), a
+    TRUNCATED flag and a factor-start mark.  Priorities (= ISA) are only ever compared between NATURAL entries; a natural entry
+    precedes a truncated one; truncated entries never meet.  The known range [fl, fr) works as in factorize_tile.
+    Returns (factors with a <= pos < b, valid)."""
+    INF = 1 << 60
+    val = {p: (cur_g[p] if cur_g[p] >= threshold else 0) for p in range(w0, w1)}
+    tr = {p: bool(trunc_g[p]) for p in range(w0, w1)}
+    sel_mark = {}
+    strip = max(lcut - 1, 0)
+    fl = w0 + strip if w0 > 0 else -INF
+    fr = w1 - strip if w1 < n else INF
+    mid = (w0 + w1) // 2
+    UND, SEL, REJ, UNC = 0, 1, 2, 3
+    for L in range(lcut, threshold - 1, -1):
+        lo, hi = max(w0, fl), min(w1, fr)
+        ub = lambda q: 0 if q in sel_mark else val[q]          # upper bound of the working value (a certain factor start is exact: 0)
+        dfl, dfr = fl, fr
+        if fl > -INF:
+            qs = [q for q in range(max(fl - L + 1, w0), min(fl, w1)) if ub(q) >= L]
+            if qs:
+                dfl = max(qs) + L
+        if fr < INF:
+            qs = [q for q in range(max(fr, w0), min(fr + L - 1, w1)) if ub(q) >= L]
+            if qs:
+                dfr = min(qs) - (L - 1)
+        ent = [p for p in range(lo, hi) if p not in sel_mark and val[p] == L]
+        exposed = lambda p: (p < dfl) or (p >= dfr)
+
+        def before(q, p):                      # q precedes p in list order
+            if tr[q] != tr[p]:
+                return not tr[q]
+            if tr[q]:
+                return False                   # (never meet)
+            return int(isa[q]) < int(isa[p])
+
+        st = {p: UND for p in ent}
+        while any(s == UND for s in st.values()):
+            snap = dict(st)
+            progressed = False
+            for p, s in snap.items():
+                if s != UND:
+                    continue
+                hit = blocked = unc = False
+                for q in range(p - L + 1, p + L):
+                    if q == p or q not in snap:
+                        continue
+                    sq = snap[q]
+                    if sq == SEL:
+                        hit = True
+                        break
+                    if (sq == UND or sq == UNC) and before(q, p):
+                        if sq == UND:
+                            blocked = True
+                        else:
+                            unc = True
+                if hit:
+                    st[p] = REJ
+                elif not blocked:
+                    st[p] = UNC if (unc or exposed(p)) else SEL
+                if st[p] != UND:
+                    progressed = True
+            assert progressed
+        tl, trr = -INF, INF
+        sel = [p for p in ent if st[p] == SEL]
+        for p in ent:
+            if st[p] == UNC:
+                if p < mid:
+                    tl = max(tl, p + L)
+                else:
+                    trr = min(trr, p - (L - 1))
+        for p in sel:                          # kills first ...
+            for j in range(L):
+                if p + j in val:
+                    val[p + j] = 0
+            sel_mark[p] = L
+        for p in sel:                          # ... then the cuts (a killed position stays dead)
+            for k in range(1, L):
+                q = p - k
+                if q in val and q not in sel_mark and val[q] > k:
+                    val[q] = k if k >= threshold else 0
+                    tr[q] = True
+        fl, fr = max(dfl, tl), min(dfr, trr)
+    out = [(p, L) for p, L in sel_mark.items() if a <= p < b]
+    return out, (fl <= a and fr >= b)
+
+
+def factorize_hybrid_tiles_eager(n, isa, plcp, maxlcp, threshold, lcut, interior, halo):
+    if maxlcp + 1 <= threshold:
+        return set(), 0, 0
+    factors, cur, trunc = _global_levels_eager(n, isa, plcp, maxlcp, threshold, lcut)
+    out = set(factors)
+    tiles = invalid = 0
+    for a in range(0, n, interior):
+        b = min(n, a + interior)
+        w0, w1 = max(0, a - halo), min(n, b + halo)
+        fs, ok = factorize_tile_eager(n, w0, w1, a, b, cur, trunc, isa, threshold, min(lcut, maxlcp))
+        tiles += 1
+        if ok:
+            out.update(fs)
+        else:
+            invalid += 1
+            out.add(("invalid", a, b))
+    return out, tiles, invalid

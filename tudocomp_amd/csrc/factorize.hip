@@ -74,6 +74,12 @@ __device__ __forceinline__ u64 bm_range_mask(size_t word, size_t lo, size_t hi) 
 __device__ __forceinline__ u64 bm_load(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ u32 bm_state(const u64* __restrict__ bm, u32 p) { return (u32)(bm[p >> 5] >> (2 * (p & 31))) & 3u; }
 
+// Residence byte of an entry that a push moves to list t (res8[], read by the window pass and by the list rebuild after a failed one):
+// the window pass tells natural entries (working value == PLCP value) from cut ones by "residence == working value", so a pushed
+// entry must never satisfy that -- targets the window pass can see (<= 63) carry bit 7, the others saturate as before.  (The flagged
+// values 128 .. 191 only collide with real residences above every possible window cut.)
+__device__ __forceinline__ u8 res8_pushed(u32 t) { return (u8)(t <= 63u ? (0x80u | t) : (t > 255u ? 255u : t)); }
+
 // ---- candidates ("Fill candidates", :54-66) ----------------------------------------------------------------
 // cls[p] = 1 for the candidates whose level is above `lo` (the lists of the levels <= lo are only materialised if the
 // window pass fails); *d_entries counts all candidates ("entries" of the reference's log)
@@ -676,7 +682,7 @@ __global__ __launch_bounds__(NT) void small_level_kernel(const u32* __restrict__
                 const u32 f = lo + rk, p = pos_s[i];
                 prio[p] = prio_base + f;
                 pool[f] = p;
-                if (res8) res8[p] = (u8)(t > 255u ? 255u : t);
+                if (res8) res8[p] = res8_pushed(t);
             }
         }
         if (tid == 0) { s_out[5] = nseg; s_out[4] = npush; s_sel = 0; ctl->pool_top = pool_top + npush; ctl->prio_base = prio_base + npush; }
@@ -787,7 +793,7 @@ full_sort:
         const u32 p = v_s[i];
         prio[p] = prio_base + i;
         pool[i] = p;
-        if (res8) { const u32 tgt = pr_s[i]; res8[p] = (u8)(tgt > 255u ? 255u : tgt); }
+        if (res8) res8[p] = res8_pushed(pr_s[i]);
     }
     {   // segment starts (a new target level), numbered in order of their start: flags + workgroup prefix sum
         u32 heads = 0, cnt = 0;
@@ -1017,7 +1023,7 @@ __global__ void push_finalize_kernel(const u64* __restrict__ keys, const u32* __
     const u32 p = vals[i];
     prio[p] = prio_base + i;
     pool[i] = p;
-    if (res8) res8[p] = (u8)(tgt > 255u ? 255u : tgt);
+    if (res8) res8[p] = res8_pushed(tgt);
     if (i == 0 || (u32)(keys[i - 1] >> 32) != tgt) {
         const u32 j = atomicAdd(&sc->nseg, 1u);
         if (j < SEG_INLINE) sc->segs[j] = PushSeg{tgt, i};
