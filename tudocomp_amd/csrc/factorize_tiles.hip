@@ -51,7 +51,10 @@ namespace {
 #define TDC_WIN_TW 16384
 #endif
 #ifndef TDC_WIN_WPE
-#define TDC_WIN_WPE 4
+#define TDC_WIN_WPE 7
+#endif
+#ifndef TDC_WIN_LB
+#define TDC_WIN_LB 4
 #endif
 #ifndef TDC_WIN_TE
 #define TDC_WIN_TE 512
@@ -105,11 +108,14 @@ struct WinScalars { u32 fail; int min_margin; unsigned long long factors; u32 ma
 #define WPROF(i) do { const unsigned long long wp_n = __builtin_readcyclecounter(); wp_acc[i] += wp_n - wp_t; wp_t = wp_n; } while (0)
 #define WPROF_CNT(i, v) do { wp_acc[i] += (v); } while (0)
 #define WPROF_FLUSH do { if (tid == 0) for (int wi = 0; wi < 12; ++wi) atomicAdd(&sc->prof[wi], wp_acc[wi]); } while (0)
+// executions of a code block by wave 0 (whatever lanes are active)
+#define WTRIP(i) do { if (tid < 64) { const u64 wt_a = __ballot(true); if (lane == __builtin_ctzll(wt_a)) atomicAdd(&sc->prof[i], 1ull); } } while (0)
 #else
 #define WPROF_DECL
 #define WPROF(i) do {} while (0)
 #define WPROF_CNT(i, v) do {} while (0)
 #define WPROF_FLUSH do {} while (0)
+#define WTRIP(i) do {} while (0)
 #endif
 
 // Workgroup barrier that only waits for this wave's LDS traffic (__syncthreads() also drains the vector-memory counter; nothing
@@ -121,14 +127,6 @@ __device__ __forceinline__ u32 hit4(u32 w, u32 pat) {
     const u32 x = (w & 0x7F7F7F7Fu) ^ pat;               // a zero byte = a match; bytes are <= 0x7F, so the addition never carries
     return ~(x + 0x7F7F7F7Fu) & 0x80808080u;
 }
-// the four flags at bits 7, 15, 23, 31 -> bits 0..3
-__device__ __forceinline__ u32 flags4(u32 h) {
-    u32 b = h >> 7;
-    b |= b >> 7;
-    b |= b >> 14;
-    return b & 0xFu;
-}
-
 template <int KT, int TE, int WPE, bool WPHI>      // threads, entries per level; WPE = waves per SIMD the register budget is set for; WPHI: sources from a Phi array
 __global__ __launch_bounds__(KT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void window_eager_kernel(const u32* __restrict__ cur_g, const u32* __restrict__ prio_g,
                                                             const u8* __restrict__ res_g, const u32* __restrict__ phi, size_t n,
@@ -167,37 +165,70 @@ __global__ __launch_bounds__(KT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
         //      natural iff the list it waits in (res: its PLCP value until a push moves it, and pushes write flagged values, see
         //      factorize.hip) is its working value -------------------------------------------------------------------------------
         u64 mymask = 0;
-        for (int i = tid * 4; i < TW; i += KT * 4) {
-            u32 sw = 0;
-            const size_t gp = w0 + i;
-            if (gp + 4 <= w1) {
-                const uint4 cv = *(const uint4*)(cur_g + gp);                  // w0 and i are multiples of 4
-                const u32 rv4 = *(const u32*)(res_g + gp);
-                const u32 c4[4] = { cv.x, cv.y, cv.z, cv.w };
+        constexpr int LIT = TW / (KT * 4);                 // 4-position groups per thread
+        constexpr int LB = LIT < TDC_WIN_LB ? LIT : TDC_WIN_LB;   // a full window is loaded in batches of LB groups per thread: the loads of a batch are in flight together
+        static_assert(TW % (KT * 4) == 0 && LIT % LB == 0, "window load");
+        if (wl == TW) {
+#pragma unroll 1
+            for (int it0 = 0; it0 < LIT; it0 += LB) {
+                uint4 cv[LB];
+                u32 rv4[LB];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    u32 c = c4[k] > 63u ? 63u : c4[k];
-                    if (c < threshold) c = 0;
-                    const u32 rv = (rv4 >> (8 * k)) & 0xFFu;
-                    const u32 bb = c ? (c | (rv != c ? B_TRUNC : 0u)) : 0u;
-                    sw |= bb << (8 * k);
-                    mymask |= 1ull << c;
+                for (int u = 0; u < LB; ++u) {
+                    const size_t gp = w0 + (size_t)((it0 + u) * KT * 4 + tid * 4);      // w0 and the offset are multiples of 4
+                    cv[u] = *(const uint4*)(cur_g + gp);
+                    rv4[u] = *(const u32*)(res_g + gp);
                 }
-            } else {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (gp + k < w1) {
-                        u32 c = cur_g[gp + k];
-                        c = c > 63u ? 63u : c;
+                for (int u = 0; u < LB; ++u) {
+                    const int i = (it0 + u) * KT * 4 + tid * 4;
+                    const u32 c4[4] = { cv[u].x, cv[u].y, cv[u].z, cv[u].w };
+                    u32 sw = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        u32 c = c4[k] > 63u ? 63u : c4[k];
                         if (c < threshold) c = 0;
-                        const u32 rv = res_g[gp + k];
+                        const u32 rv = (rv4[u] >> (8 * k)) & 0xFFu;
                         const u32 bb = c ? (c | (rv != c ? B_TRUNC : 0u)) : 0u;
                         sw |= bb << (8 * k);
                         mymask |= 1ull << c;
                     }
+                    *(u32*)&S[PA(i)] = sw;
                 }
             }
-            *(u32*)&S[PA(i)] = sw;
+        } else {
+            for (int i = tid * 4; i < TW; i += KT * 4) {
+                u32 sw = 0;
+                const size_t gp = w0 + i;
+                if (gp + 4 <= w1) {
+                    const uint4 cv = *(const uint4*)(cur_g + gp);                  // w0 and i are multiples of 4
+                    const u32 rv4 = *(const u32*)(res_g + gp);
+                    const u32 c4[4] = { cv.x, cv.y, cv.z, cv.w };
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        u32 c = c4[k] > 63u ? 63u : c4[k];
+                        if (c < threshold) c = 0;
+                        const u32 rv = (rv4 >> (8 * k)) & 0xFFu;
+                        const u32 bb = c ? (c | (rv != c ? B_TRUNC : 0u)) : 0u;
+                        sw |= bb << (8 * k);
+                        mymask |= 1ull << c;
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (gp + k < w1) {
+                            u32 c = cur_g[gp + k];
+                            c = c > 63u ? 63u : c;
+                            if (c < threshold) c = 0;
+                            const u32 rv = res_g[gp + k];
+                            const u32 bb = c ? (c | (rv != c ? B_TRUNC : 0u)) : 0u;
+                            sw |= bb << (8 * k);
+                            mymask |= 1ull << c;
+                            }
+                    }
+                }
+                *(u32*)&S[PA(i)] = sw;
+            }
         }
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) mymask |= __shfl_xor(mymask, d, 64);
@@ -246,8 +277,12 @@ __global__ __launch_bounds__(KT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                     for (int k = 0; k < TCH / 8; ++k) ws[k] = *(const u64*)&S[PW(chunk, k)];
 #pragma unroll
                     for (int k = 0; k < TCH / 8; ++k) {
-                        const u32 f = flags4(hit4((u32)ws[k], pat)) | (flags4(hit4((u32)(ws[k] >> 32), pat)) << 4);
-                        if (k < 4) ml |= f << (8 * k); else mh |= f << (8 * (k - 4));
+                        // the eight flags of a word -> eight mask bits: two byte dot products (weights 1, 2, 4, 8 and 16 .. 128) give 128 * mask
+                        const u32 f = __builtin_amdgcn_udot4(hit4((u32)(ws[k] >> 32), pat), 0x80402010u,
+                                                             __builtin_amdgcn_udot4(hit4((u32)ws[k], pat), 0x08040201u, 0u, false), false);
+                        const int kk = k & 3;
+                        const u32 g = (kk == 0) ? (f >> 7) : (f << (8 * kk - 7));
+                        if (k < 4) ml |= g; else mh |= g;
                     }
                     const int rlo = lo - base, rhi = hi - base;                     // known range, relative to the chunk
                     if (rlo > 0) { if (rlo >= 32) { ml = 0; mh &= ~((1u << (rlo - 32)) - 1u); } else ml &= ~((1u << rlo) - 1u); }
@@ -269,11 +304,13 @@ __global__ __launch_bounds__(KT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
             if (tid == 0) atomicMax(&sc->max_entries, total);
 #endif
             if (tid == 0) { s_und[0] = m; s_und[1] = 0; s_und[2] = 0; }
+            // (the first two priorities of a thread are requested together; a thread rarely holds more entries of one level.  Measured and
+            //  rejected, profiles/r05_window.md: priorities fetched only for natural entries with a natural neighbour, in the first round;
+            //  priorities requested one natural level ahead by the chunk's owner)
 #pragma unroll
             for (int cc = 0; cc < CPT; ++cc) {
                 u64 amask = ((u64)ahi[cc] << 32) | alo[cc];
                 const int base = (tid * CPT + cc) * TCH;
-                // (the first two priorities of a thread are requested together; a thread rarely holds more entries of one level)
                 int p0 = -1, p1 = -1;
                 u32 t0 = 0, t1 = 0, r0 = 0, r1 = 0;
                 if (amask) { p0 = base + __builtin_ctzll(amask); amask &= amask - 1; t0 = S[PA(p0)] >> 7; }
@@ -283,6 +320,7 @@ __global__ __launch_bounds__(KT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                 if (p0 >= 0) { ent[off] = (u32)p0 | (t0 << 18); pri[off] = r0; ++off; }
                 if (p1 >= 0) { ent[off] = (u32)p1 | (t1 << 18); pri[off] = r1; ++off; }
                 while (amask) {
+                    WTRIP(11);
                     const int pos = base + __builtin_ctzll(amask);
                     amask &= amask - 1;
                     const u32 t = S[PA(pos)] >> 7;
@@ -305,32 +343,35 @@ __global__ __launch_bounds__(KT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                 const int rn = (r + 1) % 3, rc = (r + 2) % 3;
                 if (tid == 0) s_und[rc] = 0;
                 for (int i = lane * NWV + wv; i < m; i += KT) {       // (entries are dealt round-robin to the waves: every phase is a latency chain)
+                    WTRIP(12);
                     const u32 e = lds_load(&ent[i]);
                     u32 fL = (i > 0) ? lds_load(&ent[i - 1]) : 0u;               // both direct neighbours are requested up front
                     u32 fR = (i + 1 < m) ? lds_load(&ent[i + 1]) : 0u;
                     if (e_state(e) != S_UND) continue;
                     const int p = e_pos(e);
                     const u32 et = e_trunc(e);
-                    const u32 mypri = pri[i];
                     bool hit = false, blocked = false, unc = false;
+                    const u32 mypri = pri[i];
                     for (int j = i - 1; j >= 0; --j) {
+                        WTRIP(13);
                         const u32 f = (j == i - 1) ? fL : lds_load(&ent[j]);
                         if (p - e_pos(f) >= iL) break;
-                        const u32 s = e_state(f);
-                        if (s == S_SEL) { hit = true; break; }
-                        if (s == S_UND || s == S_UNC) {
+                        const u32 st = e_state(f);
+                        if (st == S_SEL) { hit = true; break; }
+                        if (st == S_UND || st == S_UNC) {
                             const bool before = e_trunc(f) ? false : (et ? true : pri[j] < mypri);     // natural before truncated, naturals by priority
-                            if (before) { if (s == S_UND) blocked = true; else unc = true; }
+                            if (before) { if (st == S_UND) blocked = true; else unc = true; }
                         }
                     }
                     for (int j = i + 1; j < m && !hit; ++j) {
+                        WTRIP(14);
                         const u32 f = (j == i + 1) ? fR : lds_load(&ent[j]);
                         if (e_pos(f) - p >= iL) break;
-                        const u32 s = e_state(f);
-                        if (s == S_SEL) { hit = true; break; }
-                        if (s == S_UND || s == S_UNC) {
+                        const u32 st = e_state(f);
+                        if (st == S_SEL) { hit = true; break; }
+                        if (st == S_UND || st == S_UNC) {
                             const bool before = e_trunc(f) ? false : (et ? true : pri[j] < mypri);
-                            if (before) { if (s == S_UND) blocked = true; else unc = true; }
+                            if (before) { if (st == S_UND) blocked = true; else unc = true; }
                         }
                     }
                     if (hit) e_set_state(ent, i, e, S_REJ);
@@ -373,6 +414,7 @@ __global__ __launch_bounds__(KT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                     if (s == S_SEL) lds_store(&selp[wv][__popcll(selm & ((1ull << lane) - 1ull))], (unsigned short)p);
                     __builtin_amdgcn_wave_barrier();
                     for (int b0 = 0; b0 < nsel; b0 += EPB) {
+                        WTRIP(15);
                         const int k = b0 + gi;
                         if (k < nsel && gj < iL) {
                             const int ps = (int)lds_load(&selp[wv][k]);
@@ -508,8 +550,8 @@ int factorize_window_levels(Ctx& c, size_t n, const u32* cur, const u32* prio, c
         h = c.read(d_sc);
 #ifdef TDC_WIN_PROF
         {
-            static const char* nm[12] = { "wait_prev", "load", "dense", "scan+write", "select", "apply", "borders", "tail", "levels", "entries", "rounds", "-" };
-            for (int i = 0; i < 12; ++i) fprintf(stderr, "winprof %-10s %llu\n", nm[i], h.prof[i]);
+            static const char* nm[16] = { "wait_prev", "load", "dense", "scan+write", "select", "apply", "borders", "tail", "levels", "entries", "rounds", "w0 collect3+", "w0 round body", "w0 walk left", "w0 walk right", "w0 apply batch" };
+            for (int i = 0; i < 16; ++i) fprintf(stderr, "winprof %-10s %llu\n", nm[i], h.prof[i]);
             fprintf(stderr, "winprof windows %u grid %u attempt %d halo %u min_margin %d fail %u max_entries %u\n", ntiles, grid, attempt,
                     halo, h.min_margin, h.fail, h.max_entries);
         }
