@@ -160,3 +160,28 @@ def test_decompress_into_caller_buffer(gpu_ctx):
         assert out.a[:n2].tobytes() == tiny_text and st2["device_parse"] == 0
     finally:
         out.free()
+
+
+def test_token_counts_that_wrap_32_bits_are_refused(dev_ctx):
+    """ADVICE r4 (decode.hip): three factor tokens of length n = 2^31 - 2 plus four literals add up to n modulo 2^32.  With 32-bit
+    counts the total looked right and the emit pass wrote literals 4 GiB behind the text; the count pass now sums in 64 bits, a
+    token that claims more than the text is an error by itself and the emit pass clamps its room."""
+    n = (1 << 31) - 2
+    W = 31
+    ops = [(0, 0, 1),                               # no Huffman table: literals are 8 raw bits
+           (1, n, 32), (1, 0, W), (1, n, W), (1, 4, W)]          # n, flen_min, flen_max, fdist_max -> lbits = 31, dbits = 3
+    for _ in range(3):
+        ops += [(0, 0, 1), (1, 0, W), (1, n, 31)]   # factor token: no literals, source 0, length n
+    ops += [(0, 1, 1), (1, 4, 3)] + [(1, 65, 8)] * 4             # last token: four literals
+    stream = O.bitstream_script(ops)
+    with pytest.raises(T.TdcGpuError) as e:
+        dev_ctx.lcpcomp_decompress(stream)
+    assert e.value.status in (-2, -5)
+    # many tokens that each fit but wrap together
+    n2 = 1 << 30
+    ops = [(0, 0, 1), (1, n2, 32), (1, 0, 31), (1, n2, 31), (1, 4, 31)]
+    for _ in range(5):
+        ops += [(0, 0, 1), (1, 0, 31), (1, n2 if _ < 4 else n2, 31)]    # 5 * 2^30 = 2^32 + 2^30
+    stream = O.bitstream_script(ops)
+    with pytest.raises(T.TdcGpuError):
+        dev_ctx.lcpcomp_decompress(stream)

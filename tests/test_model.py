@@ -102,3 +102,54 @@ def test_max_lcp_position_space_model():
         for thr in (1, 2, 5):
             want = [(int(f["pos"]), int(f["src"]), int(f["len"])) for f in O.max_lcp(sa, isa, lcp, maxlcp, thr)]
             assert max_lcp_position_space(len(t), isa, phi, plcp, maxlcp, thr) == want, (name, thr)
+
+
+def test_eager_factor_set_model():
+    """Round 5: ArraysComp as a function of the factor SET (the factors are sorted by position before anything reads them).  The order
+    among pushed-down entries is irrelevant -- truncated entries of one level never meet, and they only lose against natural entries
+    to their left -- so a cut entry may move to list cur[x] at once.  factorize_eager visits the truncated entries of every level in
+    SHUFFLED order and must still produce the oracle's factor set."""
+    import random
+    from tests.models.position_space import factorize_eager
+    rng = random.Random(3)
+    cases = corpus.random_small(500, seed=21) + [c for c in corpus.small_corpus() if len(c[1]) <= 3000]
+    total_visits = 0
+    for name, data in cases:
+        text = O.escape(data)
+        n = len(text)
+        sa = O.suffix_array(text)
+        isa, phi, plcp, maxlcp = O.isa_phi_plcp(text, sa)
+        for thr in (1, 2, 3, 5):
+            lcp = O.lcp_array(sa, plcp)
+            ref = {(int(a), int(c)) for a, b, c in O.arrays_comp(sa, isa, lcp, maxlcp, thr)}
+            got, visits = factorize_eager(n, isa, plcp, maxlcp, thr, rng)
+            assert got == ref, (name, thr)
+            total_visits += visits
+    assert total_visits > 0
+
+
+def test_eager_tile_model():
+    """The window pass of round 5 (factorize_tiles.hip, window_eager_kernel): one state byte per position, eager push-down, priorities
+    only between natural entries, known-range borders as before -- every window that reports itself valid reproduces the oracle's
+    factors inside its interior."""
+    from tests.models.position_space import factorize_hybrid_tiles_eager
+    tiles = invalid = 0
+    cases = corpus.random_small(100, seed=11) + [c for c in corpus.small_corpus() if len(c[1]) <= 2000]
+    for name, data in cases:
+        text = O.escape(data)
+        n = len(text)
+        sa = O.suffix_array(text)
+        isa, phi, plcp, maxlcp = O.isa_phi_plcp(text, sa)
+        for thr in (1, 2, 5):
+            lcp = O.lcp_array(sa, plcp)
+            ref = {(int(a), int(c)) for a, b, c in O.arrays_comp(sa, isa, lcp, maxlcp, thr)}
+            for lcut, interior, halo in ((4, 32, 16), (6, 64, 40), (3, 16, 8), (100, 64, 32)):
+                got, t, i = factorize_hybrid_tiles_eager(n, isa, plcp, maxlcp, thr, lcut, interior, halo)
+                inv = [(x[1], x[2]) for x in got if x[0] == "invalid"]
+                g = {x for x in got if x[0] != "invalid"}
+                covered = lambda p: any(a <= p < b for a, b in inv)
+                assert all(f in g for f in ref if not (f[1] <= lcut and covered(f[0]))), (name, thr, lcut)
+                assert all(f in ref for f in g), (name, thr, lcut)
+                tiles += t
+                invalid += i
+    assert 0 < invalid < tiles // 2

@@ -191,7 +191,7 @@ void validate_device_text(Ctx& c, const u8* d_text, size_t n) {
 void run_textds(Ctx& c, const u8* d_text, size_t n, DevArrays& A, tdc_gpu_stats* st, Events* ev, bool want_phi = true) {
     A.sa = c.arena.get<u32>(n);
     A.isa = c.arena.get<u32>(n);
-    A.phi = c.arena.get<u32>(n);
+    A.phi = nullptr;                                          // (taken behind the suffix array, and only where a Phi array is built)
     A.plcp = c.arena.get<u32>(n);
     u32* d_max = c.arena.get<u32>(1);
     SAStats ss;
@@ -201,8 +201,8 @@ void run_textds(Ctx& c, const u8* d_text, size_t n, DevArrays& A, tdc_gpu_stats*
     build_suffix_array(c, d_text, n, A.sa, A.isa, &ss, &ex);
     const int e1 = ev ? ev->tick() : 0;
     int e2;
+    if (!(ex.mode == 1 && !want_phi && c.phi_lazy)) A.phi = c.arena.get<u32>(n);
     if (ex.mode == 1) {                                       // ISA + Phi + PLCP in one scatter of the final suffix array
-        if (!want_phi && c.phi_lazy) A.phi = nullptr;
         build_isa_phi_plcp_fused(c, A.sa, ex.lcp8, n, A.isa, A.phi, A.plcp, d_max);
         e2 = ev ? ev->tick() : 0;
     } else {
@@ -958,6 +958,7 @@ int tdc_gpu_lcpcomp_decompress(tdc_gpu_ctx* ctx, const uint8_t* stream, size_t l
 
 namespace {
 void decompress_common(tdc_gpu_ctx* ctx, const uint8_t* stream, size_t len, int coder, DecodeOut& o, size_t* out_len, uint64_t* factors, uint32_t* rounds) {
+    ctx->last_decode_device = 0;                             // (a failed call must not report the previous call's value)
     if (!stream || !out_len) throw ArgError{TDC_GPU_ERR_ARG, "NULL argument"};
     const int enc = lcpcomp_enc_coder(coder);
     if (enc == 1) throw ArgError{TDC_GPU_ERR_UNSUPPORTED, "lcpcomp(coder=arithmetic) streams cannot be decoded (neither can the reference)"};

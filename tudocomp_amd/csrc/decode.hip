@@ -240,15 +240,22 @@ __global__ __launch_bounds__(256) void dec_count_kernel(const u32* __restrict__ 
     __syncthreads();
     const BitWinG bw{s32, P.total};
     auto nolit = [](u32, u8) {};
+    u64 acc = 0;
     for (u32 j = blockIdx.x * 256 + threadIdx.x; j < cnt; j += gridDim.x * 256) {
         const u64 x = x_in + idx[j];
         u64 nx; u32 r, src, len;
         const int st = dec_token(bw, x, P, &T, nolit, nx, r, src, len);
         tokx[j] = x;
-        outc[j] = (st >= 0) ? r + len : 0u;
-        if (st < 0 || (st == 0 && len == 0)) atomicOr(&sc->err, 1u);
+        // (64-bit: the u32 counts and their u32 scan must not be able to wrap for a crafted stream -- a token that claims more than the
+        //  text is an error by itself, and the exact total is checked on the host before anything is written through base[])
+        const u64 produced = (st >= 0) ? (u64)r + (u64)len : 0ull;
+        outc[j] = produced > P.n ? (u32)P.n + 1u : (u32)produced;
+        acc += produced > P.n ? P.n + 1 : produced;
+        if (st < 0 || (st == 0 && len == 0) || produced > P.n) atomicOr(&sc->err, 1u);
         if (j == cnt - 1) { sc->exit_bit = nx; sc->exit_status = (u32)(st < 0 ? 2 : st); }
     }
+    acc = wave_reduce_sum(acc);                                  // one atomic per wave of the capped grid
+    if (lane_id() == 0 && acc) atomicAdd((unsigned long long*)&sc->total_out, (unsigned long long)acc);
 }
 
 // literal bytes to their text positions, the factor list (a token without factor gets length 0)
@@ -262,7 +269,7 @@ __global__ __launch_bounds__(256) void dec_emit_kernel(const u32* __restrict__ s
     for (u32 j = blockIdx.x * 256 + threadIdx.x; j < z; j += gridDim.x * 256) {
         const u64 p = base[j];
         u8* dst = text + p;
-        const u64 room = P.n - p;                                 // (base[j] <= n: checked on the host through the total)
+        const u64 room = p < P.n ? P.n - p : 0;                   // (base[j] <= n is checked on the host through the 64-bit total; clamped all the same)
         u64 nx; u32 r, src, len;
         const int st = dec_token(bw, tokx[j], P, &T, [&](u32 i, u8 b) { if (i < room) dst[i] = b; }, nx, r, src, len);
         bool bad = st < 0 || p + r > P.n;
@@ -560,7 +567,11 @@ static bool decode_lzss_huff_device(Ctx& c, const u8* stream, size_t len, const 
         fprintf(stderr, "decode: %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
         t_last = now;
     };
-    c.ensure_arena(len + 64 + n * 5 + zmax * 28 + seg * 17 + sizeof(DevTab) + ((size_t)16 << 20));
+    if (out.into && n > out.cap) throw HipError{hipErrorOutOfMemory, "decode: the caller's buffer is too small for the text", (int)__LINE__};   // (known from the header: before any device work)
+    // (the device parse needs ~17 bytes of arena per stream bit of a segment on top of 5 n + 28 zmax; the host parse needs 5 n + 12 z: if
+    //  the device cannot provide the former, the host parse takes the stream instead of the call failing)
+    try { c.ensure_arena(len + 64 + n * 5 + zmax * 28 + seg * 17 + sizeof(DevTab) + ((size_t)16 << 20)); }
+    catch (const HipError& e) { if (e.e != hipErrorOutOfMemory) throw; (void)hipGetLastError(); return false; }
     const size_t mark0 = c.arena.mark();
     u8* d_stream = c.arena.get<u8>(len + 64);
     HIP_TRY(hipMemcpyAsync(d_stream, stream, len, hipMemcpyHostToDevice, s));
@@ -620,6 +631,10 @@ static bool decode_lzss_huff_device(Ctx& c, const u8* stream, size_t len, const 
     u32* base = outc;                                                                   // in place
     exclusive_sum_u32(c, outc, base, z, d_cnt);
     const u32 produced = c.read(d_cnt);
+    {   // the exact 64-bit total of the count passes: equal to n means that no partial sum of the 32-bit scan can have wrapped
+        const DecScalars ht = c.read(d_sc);
+        if (ht.total_out != H.n) throw StreamFormatError{"corrupt stream: length mismatch"};
+    }
     if ((u64)produced != H.n) throw StreamFormatError{"corrupt stream: length mismatch"};
     u8* d_text = c.arena.get<u8>(n + 64);
     u32* d_ref = c.arena.get<u32>(n);

@@ -835,7 +835,7 @@ full_sort:
         __syncthreads();
         for (u32 f = wv; f < nsel; f += NWV) {
             const u32 p = sval[f];
-            if (lane == 0) { flen[p] = L; fsrc[p] = phi[p]; }
+            if (lane == 0) { flen[p] = L; if (phi != fsrc) fsrc[p] = phi[p]; }      // (no Phi array: phi IS fsrc, already filled for this candidate)
             for (u32 j = lane; j < L && (size_t)p + j < n; j += 64) cur[p + j] = 0;
             const u32 aff = (L < p) ? L : p;
             for (u32 j0 = 0; j0 < aff; j0 += 64 * 8) {
@@ -919,7 +919,7 @@ __global__ __launch_bounds__(256) void apply_list_kernel(const u32* __restrict__
     const u32 lane = threadIdx.x & 63;
     if (i >= *d_count) return;
     const u32 p = list[i];
-    if (lane == 0) { flen[p] = L; fsrc[p] = phi[p]; }
+    if (lane == 0) { flen[p] = L; if (phi != fsrc) fsrc[p] = phi[p]; }
     for (u32 j = lane; j < L && (size_t)p + j < n; j += 64) cur[p + j] = 0;
     const u32 aff = (L < p) ? L : p;
     for (u32 j = lane; j < aff; j += 64) { u32* q = &cur[p - 1 - j]; if (*q > j + 1) atomicMin(q, j + 1); }
@@ -1042,7 +1042,7 @@ __global__ __launch_bounds__(256) void apply_kernel(const u32* __restrict__ live
     u32 p = 0;
     if (i < nl) { p = live[i]; sel = (bm_state(bm, p) == 2u); }
     if (sel) {
-        if (sub == 0) { flen[p] = L; fsrc[p] = phi[p]; }
+        if (sub == 0) { flen[p] = L; if (phi != fsrc) fsrc[p] = phi[p]; }
         for (u32 j = sub; j < L && (size_t)p + j < n; j += G) cur[p + j] = 0;   // :99-101
         const u32 aff = (L < p) ? L : p;                           // :103
         for (u32 j = sub; j < aff; j += G) {                         // :105-109
