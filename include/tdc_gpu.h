@@ -74,6 +74,8 @@ typedef struct {
     uint32_t sa_text_rounds;    /* rank-free refinement rounds keyed from the text (wide path)     */
     uint32_t sa_mode;           /* 1: ISA / Phi / PLCP came from the fused scatter of the final suffix array, 0: classic */
     uint32_t sa_overlapped;     /* 1: the first partition level of the suffix sort ran chunk by chunk behind the upload */
+    uint32_t eager_levels;      /* levels processed inside one-launch runs of small levels (factorize_eager.hip)           */
+    uint32_t eager_phases;      /* such runs                                                                            */
 } tdc_gpu_stats;
 
 /* ---- context -------------------------------------------------------------------------------------------- */

@@ -667,3 +667,110 @@ def factorize_hybrid_tiles_eager(n, isa, plcp, maxlcp, threshold, lcut, interior
             invalid += 1
             out.add(("invalid", a, b))
     return out, tiles, invalid
+
+
+def factorize_heads(n, isa, plcp, maxlcp, threshold, rng=None):
+    """Round 5, global levels (factorize.hip, eager_levels_kernel): the eager formulation with explicit lists, in which a cut only ever
+    inserts ONE entry.  A factor at p cuts a contiguous run [q_h, p) of alive positions (q + PLCP[q] is non-decreasing in q, and no
+    selected factor can lie inside the run); the run's values p - q fall towards p, so its head q_h is decided first, at level
+    p - q_h, and if it is selected it covers the whole run.  The tail can only matter if the head is covered by a factor that
+    ends INSIDE the run -- at a position e whose predecessor e - 1 was alive with cur[e - 1] = cur[e] + 1 when that factor was
+    selected: then e is the new head and is inserted by the factor that covered its predecessor (right-head rule).
+    Lists: originals (positions with PLCP = L; skipped unless still natural, cur = L) + inserted entries (skipped unless cur = L;
+    duplicates are harmless).  Returns (factor set, number of list insertions, number of cuts)."""
+    if maxlcp + 1 <= threshold:
+        return set(), 0, 0
+    cur = [int(x) for x in plcp]
+    cur[n - 1] = 0
+    for p in range(n):
+        if isa[p] == 0:
+            cur[p] = 0
+    orig = {}
+    for p in range(n):
+        if cur[p] >= threshold:
+            orig.setdefault(cur[p], []).append(p)
+    ins = {}
+    out = set()
+    inserts = cuts = 0
+    for L in range(maxlcp, threshold - 1, -1):
+        nat = sorted((p for p in orig.get(L, ()) if cur[p] == L), key=lambda p: int(isa[p]))
+        natset = set(nat)
+        tr = [p for p in dict.fromkeys(ins.get(L, ())) if cur[p] == L and p not in natset]      # (deduplicated)
+        if rng:
+            rng.shuffle(tr)
+        for p in nat + tr:
+            if cur[p] != L:
+                continue
+            out.add((p, L))
+            last = cur[p + L - 1]                     # value of the last covered position before it is killed
+            if L == 1:
+                last = L
+            for j in range(L):
+                cur[p + j] = 0
+            head = None
+            for j in range(min(L - 1, p)):            # distances 1 .. L - 1 (distance L never lowers anything)
+                q = p - 1 - j
+                if cur[q] > j + 1:
+                    cur[q] = j + 1
+                    cuts += 1
+                    head = q                          # the leftmost cut position
+            if head is not None and cur[head] >= threshold:
+                ins.setdefault(cur[head], []).append(head)
+                inserts += 1
+            r = p + L                                 # right-head rule
+            if r < n and cur[r] >= threshold and last == cur[r] + 1:
+                ins.setdefault(cur[r], []).append(r)
+                inserts += 1
+    return out, inserts, cuts
+
+
+def factorize_heads_only(n, isa, plcp, maxlcp, threshold, rng=None):
+    """factorize_heads with the NATURAL lists restricted to run heads as well (factorize_eager.hip as built): a position whose
+    predecessor is alive with cur[q - 1] = cur[q] + 1 -- the body of a PLCP ramp, or of a cut run -- is listed nowhere; its predecessor is
+    decided one level earlier and either covers it or is itself covered by a factor that ends right in front of it, and then the
+    right-head rule inserts it (with its class: natural iff its value is still its PLCP value).  Returns (factor set, listed, inserted)."""
+    if maxlcp + 1 <= threshold:
+        return set(), 0, 0
+    orig_plcp = [int(x) for x in plcp]
+    cur = list(orig_plcp)
+    cur[n - 1] = 0
+    for p in range(n):
+        if isa[p] == 0:
+            cur[p] = 0
+    lists = {}
+    listed = 0
+    for p in range(n):
+        if cur[p] >= threshold and not (p > 0 and cur[p - 1] == cur[p] + 1):
+            lists.setdefault(cur[p], []).append(p)
+            listed += 1
+    out = set()
+    inserted = 0
+    for L in range(maxlcp, threshold - 1, -1):
+        ent = [p for p in dict.fromkeys(lists.get(L, ())) if cur[p] == L]
+        nat = sorted((p for p in ent if cur[p] == orig_plcp[p]), key=lambda p: int(isa[p]))
+        tr = [p for p in ent if cur[p] != orig_plcp[p]]
+        if rng:
+            rng.shuffle(tr)
+        for p in nat + tr:
+            if cur[p] != L:
+                continue
+            out.add((p, L))
+            last = cur[p + L - 1]
+            for j in range(L):
+                cur[p + j] = 0
+            head = None
+            for j in range(min(L - 1, p)):
+                q = p - 1 - j
+                if cur[q] > j + 1:
+                    cur[q] = j + 1
+                    head = q
+                else:
+                    break                          # the cut positions are one contiguous run that ends in front of the factor
+            if head is not None and cur[head] >= threshold:
+                lists.setdefault(cur[head], []).append(head)
+                inserted += 1
+            r = p + L
+            if r < n and cur[r] >= threshold and last == cur[r] + 1:
+                lists.setdefault(cur[r], []).append(r)
+                inserted += 1
+    return out, listed, inserted

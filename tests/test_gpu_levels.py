@@ -59,7 +59,7 @@ def test_levels_with_thousands_of_stale_entries(K, spread):
     want, _ = O.lcpcomp_huff_compress(text, 3, 1)
     seen = {}
     for mode in ("1", "0", "2", "3"):
-        ctx = _ctx_env({"TDC_GPU_SMALL_BIG": mode})
+        ctx = _ctx_env({"TDC_GPU_SMALL_BIG": mode, "TDC_GPU_EAGER": "0"})       # (the instances of the lazy one-workgroup kernel are what is tested here)
         try:
             got, st = ctx.lcpcomp_compress(text, threshold=3, flatten=1)
         finally:
@@ -72,7 +72,7 @@ def test_levels_with_thousands_of_stale_entries(K, spread):
 
 @pytest.mark.parametrize("mode", ["2", "3"])
 def test_every_small_level_on_the_large_instance(mode):
-    ctx = _ctx_env({"TDC_GPU_SMALL_BIG": mode})
+    ctx = _ctx_env({"TDC_GPU_SMALL_BIG": mode, "TDC_GPU_EAGER": "0"})
     try:
         for name, data in (("english_600k", T.gen_english(600_000, 5).tobytes()), ("dna_500k", T.gen_dna(500_000, 9).tobytes()),
                            ("runs", b"ab" * 5000 + b"c" + b"abc" * 7000 + bytes(range(1, 200)) * 40)):

@@ -268,7 +268,7 @@ void run_factorize(Ctx& c, size_t n, DevArrays& A, u32 threshold, int flatten, t
     const int e2 = ev ? ev->tick() : 0;
     if (st) {
         st->factors = fz.factors; st->entries = fz.entries; st->pushes = fz.pushes;
-        st->levels = fz.levels; st->mis_rounds = fz.rounds; st->small_levels = fz.small_levels; st->purges = fz.purges; st->window_pass = fz.window_pass; st->window_lcut = fz.window_lcut;
+        st->levels = fz.levels; st->mis_rounds = fz.rounds; st->small_levels = fz.small_levels; st->purges = fz.purges; st->window_pass = fz.window_pass; st->window_lcut = fz.window_lcut; st->eager_levels = fz.eager_levels; st->eager_phases = fz.eager_phases;
         st->num_flattened = fl.num_flattened; st->max_depth_lb = fl.max_depth_lb; st->flatten_rounds = fl.rounds;
         if (ev) { ev->span(&st->ms_factorize, e0, e1); ev->span(&st->ms_flatten, e1, e2); }
     }
@@ -383,6 +383,7 @@ int tdc_gpu_ctx_create(int device, tdc_gpu_ctx** out) {
         if (const char* m = getenv("TDC_GPU_ENC_EARLY")) ctx->c.enc_early = atoi(m);
         if (const char* m = getenv("TDC_GPU_ENC_REC")) ctx->c.enc_rec = atoi(m) != 0;
         if (const char* m = getenv("TDC_GPU_LEVEL_PURGE")) ctx->c.level_purge = atoi(m) != 0;
+        if (const char* m = getenv("TDC_GPU_EAGER")) ctx->c.eager_levels = atoi(m) != 0;
         if (const char* m = getenv("TDC_GPU_SA_REFINE")) ctx->c.sa_refine = atoi(m) != 0;
         if (const char* m = getenv("TDC_GPU_SA_FUSED_INIT")) ctx->c.sa_fused_init = atoi(m) != 0;
         if (const char* m = getenv("TDC_GPU_RADIX_LDS")) { const int v = atoi(m); ctx->c.radix_lds = (v >= 0 && v <= 2) ? v : 2; }

@@ -28,6 +28,7 @@
 #include "stages.hpp"
 #include "prim.hpp"
 #include "factorize_tiles.hpp"
+#include "factorize_eager.hpp"
 
 #include <algorithm>
 #include <map>
@@ -74,11 +75,13 @@ __device__ __forceinline__ u64 bm_range_mask(size_t word, size_t lo, size_t hi) 
 __device__ __forceinline__ u64 bm_load(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ u32 bm_state(const u64* __restrict__ bm, u32 p) { return (u32)(bm[p >> 5] >> (2 * (p & 31))) & 3u; }
 
-// Residence byte of an entry that a push moves to list t (res8[], read by the window pass and by the list rebuild after a failed one):
-// the window pass tells natural entries (working value == PLCP value) from cut ones by "residence == working value", so a pushed
-// entry must never satisfy that -- targets the window pass can see (<= 63) carry bit 7, the others saturate as before.  (The flagged
-// values 128 .. 191 only collide with real residences above every possible window cut.)
-__device__ __forceinline__ u8 res8_pushed(u32 t) { return (u8)(t <= 63u ? (0x80u | t) : (t > 255u ? 255u : t)); }
+// Residence byte res8[] (present whenever a window pass or an eager phase may follow): min(PLCP, 255) while the entry is NATURAL (its
+// working value is still its PLCP value), a MARK from its first effective cut on -- 0x80 | t for values t <= 63 (the window pass reads
+// those), 0 above -- written by every cut (lazy apply kernels, eager kernel) and every push.  A mark never equals the working value,
+// so  natural <=> (cur < 255 ? res8 == cur : res8 == 255)  holds for every alive entry, whatever formulation processed the levels
+// above: the window pass tells natural from truncated entries by it, and the lists of either formulation can be rebuilt from cur[].
+__device__ __forceinline__ u8 res8_mark(u32 t) { return (u8)(t <= 63u ? (0x80u | t) : 0u); }
+__device__ __forceinline__ u8 res8_pushed(u32 t) { return res8_mark(t); }
 
 // ---- candidates ("Fill candidates", :54-66) ----------------------------------------------------------------
 // cls[p] = 1 for the candidates whose level is above `lo` (the lists of the levels <= lo are only materialised if the
@@ -131,22 +134,6 @@ __global__ __launch_bounds__(256) void cand_class_kernel(const u32* __restrict__
     __syncthreads();
     if (threadIdx.x == 0) { const u32 t = sm[0] + sm[1] + sm[2] + sm[3]; if (t) atomicAdd(d_entries, t); }   // one atomic per workgroup (capped grid)
     if (lvl_hist && threadIdx.x < 64 && sh[threadIdx.x]) atomicAdd(&lvl_hist[threadIdx.x], sh[threadIdx.x]);
-}
-// after a failed window pass: the original candidates of the levels threshold .. lcut that are still in their lists
-// (pushed entries carry priorities >= n and are tracked by the push pool)
-__global__ void cand_rebuild_class_kernel(const u8* __restrict__ res8, const u32* __restrict__ prio, size_t n, u32 threshold, u32 lcut,
-                                          u8* __restrict__ cls, const u32* __restrict__ src_sa, u32* __restrict__ fsrc) {
-    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
-    const u32 r = res8[p];
-    const u32 pr = prio[p];
-    const bool c1 = r >= threshold && r <= lcut && pr < (u32)n;
-    cls[p] = c1 ? 1 : 0;
-    if (c1 && src_sa) fsrc[p] = pr ? src_sa[pr - 1] : src_sa[n - 1];          // (no Phi array: see cand_class_kernel)
-}
-__global__ void gather_u8_kernel(const u32* __restrict__ idx, size_t m, const u8* __restrict__ src, u32* __restrict__ dst) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < m) dst[i] = src[idx[i]];
 }
 __global__ void gather_kernel(const u32* __restrict__ idx, size_t m, const u32* __restrict__ src, u32* __restrict__ dst) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -843,7 +830,7 @@ full_sort:
 #pragma unroll
                 for (u32 r = 0; r < 8; ++r) { const u32 j = j0 + r * 64 + lane; vv[r] = (j < aff) ? cur[p - 1 - j] : 0u; }
 #pragma unroll
-                for (u32 r = 0; r < 8; ++r) { const u32 j = j0 + r * 64 + lane; if (j < aff && vv[r] > j + 1) atomicMin(&cur[p - 1 - j], j + 1); }
+                for (u32 r = 0; r < 8; ++r) { const u32 j = j0 + r * 64 + lane; if (j < aff && vv[r] > j + 1) { if (atomicMin(&cur[p - 1 - j], j + 1) > j + 1 && res8) res8[p - 1 - j] = res8_mark(j + 1); } }
             }
         }
     } else {
@@ -914,7 +901,7 @@ __global__ __launch_bounds__(1024) void level_purge_kernel(u32* __restrict__ can
 // apply for a list of selected positions whose length is only known on the device (one wave per factor)
 __global__ __launch_bounds__(256) void apply_list_kernel(const u32* __restrict__ list, const u32* __restrict__ d_count, u32 L, size_t n,
                                                           const u32* __restrict__ phi, u32* __restrict__ cur, u32* __restrict__ flen,
-                                                          u32* __restrict__ fsrc) {
+                                                          u32* __restrict__ fsrc, u8* __restrict__ res8) {
     const u32 i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const u32 lane = threadIdx.x & 63;
     if (i >= *d_count) return;
@@ -922,7 +909,7 @@ __global__ __launch_bounds__(256) void apply_list_kernel(const u32* __restrict__
     if (lane == 0) { flen[p] = L; if (phi != fsrc) fsrc[p] = phi[p]; }
     for (u32 j = lane; j < L && (size_t)p + j < n; j += 64) cur[p + j] = 0;
     const u32 aff = (L < p) ? L : p;
-    for (u32 j = lane; j < aff; j += 64) { u32* q = &cur[p - 1 - j]; if (*q > j + 1) atomicMin(q, j + 1); }
+    for (u32 j = lane; j < aff; j += 64) { u32* q = &cur[p - 1 - j]; if (*q > j + 1) { if (atomicMin(q, j + 1) > j + 1 && res8) res8[p - 1 - j] = res8_mark(j + 1); } }
 }
 
 // ---- purge: drop the candidates that were erased by longer factors from all levels that are still to come ------------
@@ -1035,7 +1022,7 @@ __global__ void push_finalize_kernel(const u64* __restrict__ keys, const u32* __
 template <int G>
 __global__ __launch_bounds__(256) void apply_kernel(const u32* __restrict__ live, u32 nl, u32 L, size_t n, u64* bm,
                                                      const u32* __restrict__ phi, u32* __restrict__ cur, u32* __restrict__ flen,
-                                                     u32* __restrict__ fsrc, LevelScalars* __restrict__ sc) {
+                                                     u32* __restrict__ fsrc, LevelScalars* __restrict__ sc, u8* __restrict__ res8) {
     const u32 i = (blockIdx.x * blockDim.x + threadIdx.x) / G;
     const u32 sub = (G == 1) ? 0u : (threadIdx.x & (G - 1));
     bool sel = false;
@@ -1047,7 +1034,7 @@ __global__ __launch_bounds__(256) void apply_kernel(const u32* __restrict__ live
         const u32 aff = (L < p) ? L : p;                           // :103
         for (u32 j = sub; j < aff; j += G) {                         // :105-109
             u32* q = &cur[p - 1 - j];
-            if (*q > j + 1) atomicMin(q, j + 1);                     // values only ever decrease: a stale read can only cause a redundant atomic
+            if (*q > j + 1) { if (atomicMin(q, j + 1) > j + 1 && res8) res8[p - 1 - j] = res8_mark(j + 1); }   // values only ever decrease: a stale read can only cause a redundant atomic
         }
     }
     // leave the bitmap all-zero for the next level (every reader of this level's state ran in an earlier kernel)
@@ -1113,15 +1100,13 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
     std::vector<u32> h_segstart(nlev), h_segend(nlev);
     int x = 0;
     size_t cand_count = 0;
-    // candidate lists: the class-1 positions in position order, stably sorted by their level (key_plcp: level = PLCP value,
-    // else the residence byte)
-    auto build_lists = [&](bool key_plcp, u32 max_level) {
+    // candidate lists: the class-1 positions in position order, stably sorted by their level (= the working value: the PLCP value at the start)
+    auto build_lists = [&](u32 max_level) {
         select_by_class(c, cls, 1, n, nullptr, cvals[0], nullptr, nullptr, d_cnt);
         cand_count = c.read(d_cnt);
         if (cand_count) {
             Ctx::ProfScope prof(c, K_CAND, (u64)cand_count * 12);
-            if (key_plcp) gather_kernel<<<cdiv(cand_count, 256), 256, 0, s>>>(cvals[0], cand_count, plcp, ckeys[0]);
-            else          gather_u8_kernel<<<cdiv(cand_count, 256), 256, 0, s>>>(cvals[0], cand_count, res8, ckeys[0]);
+            gather_kernel<<<cdiv(cand_count, 256), 256, 0, s>>>(cvals[0], cand_count, plcp, ckeys[0]);
             LAUNCH_CHECK();
         }
         x = radix_sort_pairs_u32(c, ckeys, cvals, cand_count, 0, (int)bits_for(max_level));
@@ -1134,7 +1119,7 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
         c.read_n(d_segstart, h_segstart.data(), nlev);
         c.read_n(d_segend, h_segend.data(), nlev);
     };
-    build_lists(true, maxlcp);
+    build_lists(maxlcp);
     st->entries = c.read(d_cnt + 1);
     const u32* cand = cvals[x];
 
@@ -1229,6 +1214,95 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
     bool probe_dead = false;                    // the previous level held erased candidates only
 
     const bool level_log = getenv("TDC_GPU_LEVEL_LOG") != nullptr;     // debugging aid: one line per large level on stderr
+    // ---- lists from cur[]: both formulations can restart from the working values and the residence marks alone (res8_mark) ----------
+    // The lazy formulation: every alive position of the levels (lo, hi] becomes an entry of list cur[q] (natural ones keep their ISA as
+    // priority, truncated ones follow them); the push pool is forgotten -- its alive entries are among the rebuilt ones.
+    auto rebuild_from_cur = [&](u32 lo, u32 hi) {
+        {
+            Ctx::ProfScope prof(c, K_CAND, (u64)n * 5);
+            lazy_rebuild_class(c, cur, n, lo, hi, cls);
+        }
+        build_lists(hi);
+        cand = cvals[x];
+        if ((u64)prio_base + cand_count > 0xFFFFFFFFull) throw HipError{hipErrorUnknown, "factorize: priority space exhausted", (int)__LINE__};
+        lazy_rebuild_prio(c, cand, cand_count, cur, res8, n, prio, prio_base, phi ? nullptr : sa, fs.fsrc);
+        prio_base += (u32)cand_count;
+        for (u32 v = lo + 1; v <= hi; ++v) { pushed_into.drop(v); if (v == 0xFFFFFFFFu) break; }
+        pool_top = 0;
+        HIP_TRY(hipMemsetAsync(d_lcount, 0xFF, nlev * sizeof(u32), s));
+        purge_next = 0xFFFFFFFFu;
+        dead_streak = 0; levels_since_purge = 1u << 30; purge_pays = false; dead_levels_run = 0; nolive_run = 0; probe_dead = false;
+        force_general_level = NONE32;
+    };
+    // The eager formulation (factorize_eager.hip): a run of small levels inside one launch.  Taken when the levels ahead are small and
+    // many (texts with long repeats); at most a few phases per call, each framed by two dense passes.
+    const u32 eager_floor = std::max<u32>(threshold, lcut ? lcut + 1 : 0);       // lowest level of the global loop
+    const bool eager_possible = c.eager_levels && res8 && nlev <= ((size_t)1 << 22) && maxlcp > eager_floor + 256;
+    u32 eager_phases = 0, small_lazy_streak = 0;
+    u32* d_eseg = eager_possible ? c.arena.get<u32>(4 * nlev) : nullptr;        // segstart | segend | tstart | tend
+    u32* d_ehead = eager_possible ? c.arena.get<u32>(nlev) : nullptr;
+    EagerCtl* d_ectl = eager_possible ? (EagerCtl*)c.arena.alloc(sizeof(EagerCtl)) : nullptr;
+    auto run_eager = [&](u32 Lfrom) -> u32 {                                     // returns the next level to be processed
+        // run heads of the levels [eager_floor, Lfrom] (natural and truncated alike): dense pass, then sorted by level like the candidates
+        {
+            Ctx::ProfScope prof(c, K_CAND, (u64)n * 6);
+            eager_heads_class(c, cur, n, eager_floor - 1, Lfrom, cls);
+        }
+        select_by_class(c, cls, 1, n, nullptr, ent, nullptr, nullptr, d_cnt);
+        const size_t tcount = c.read(d_cnt);
+        u32* tk[2] = { live, stale };
+        u32* tv[2] = { ent, rval };
+        int y = 0;
+        HIP_TRY(hipMemsetAsync(d_eseg + 2 * nlev, 0, 2 * nlev * sizeof(u32), s));
+        if (tcount) {
+            gather_kernel<<<cdiv(tcount, 256), 256, 0, s>>>(ent, tcount, cur, live);
+            LAUNCH_CHECK();
+            y = radix_sort_pairs_u32(c, tk, tv, tcount, 0, (int)bits_for(Lfrom));
+            seg_bounds_kernel<<<cdiv(tcount, 256), 256, 0, s>>>(tk[y], tcount, d_eseg + 2 * nlev, d_eseg + 3 * nlev);
+            LAUNCH_CHECK();
+        }
+        HIP_TRY(hipMemsetAsync(d_ehead, 0, nlev * sizeof(u32), s));
+        HIP_TRY(hipMemsetAsync(d_ectl, 0, sizeof(EagerCtl), s));
+        EagerParams P;
+        P.tcand = tv[y]; P.tstart = d_eseg + 2 * nlev; P.tend = d_eseg + 3 * nlev;
+        P.head = d_ehead;
+        P.blk = pool; P.blk_cap = (u32)std::min<size_t>(n / 16, (size_t)1 << 28);   // (the push pool of the lazy formulation is forgotten anyway)
+        P.cur = cur; P.prio = prio; P.phi = phi_eff; P.flen = fs.flen; P.fsrc = fs.fsrc; P.res8 = res8;
+        P.n = n; P.threshold = threshold; P.L_from = Lfrom; P.L_stop = eager_floor; P.raw_cap = eager_levels_raw_cap();
+        P.ctl = d_ectl;
+        P.dbg = nullptr;
+        const size_t dbg_mark = c.arena.mark();
+        if (level_log) { P.dbg = c.arena.get<u32>(4 * nlev); HIP_TRY(hipMemsetAsync(P.dbg, 0, 4 * nlev * sizeof(u32), s)); }
+        {
+            Ctx::ProfScope prof(c, K_SMALL_LEVEL, (u64)(Lfrom - eager_floor + 1) * 64);
+            eager_levels_launch(c, P);
+        }
+        EagerCtl h;
+        HIP_TRY(hipMemcpyAsync(&h, d_ectl, sizeof(EagerCtl), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (P.dbg) {
+            std::vector<u32> dv(4 * nlev);
+            HIP_TRY(hipMemcpy(dv.data(), P.dbg, 4 * nlev * sizeof(u32), hipMemcpyDeviceToHost));
+            unsigned long long tot = 0;
+            for (size_t lv = 0; lv < nlev; ++lv) tot += dv[4 * lv + 2];
+            unsigned long long acc = 0; u32 shown = 0;
+            for (size_t lv = nlev; lv-- > 0;) {
+                if (!dv[4 * lv + 2]) continue;
+                acc += dv[4 * lv + 2];
+                if (dv[4 * lv + 2] > 400000u || (shown++ % 256) == 0) fprintf(stderr, "eager level %zu: %u entries of %u candidates, %u factors, %u cycles (running %.1f %% of %llu)\n", lv, dv[4 * lv], dv[4 * lv + 3], dv[4 * lv + 1], dv[4 * lv + 2], 100.0 * (double)acc / (double)(tot ? tot : 1), tot);
+            }
+            c.arena.release(dbg_mark);
+        }
+        st->factors += h.factors;
+        st->levels += h.levels_done;
+        st->small_levels += h.levels_done;
+        st->eager_levels += h.levels_done;
+        ++eager_phases;
+        st->eager_phases = eager_phases;
+        if (level_log) fprintf(stderr, "eager phase %u: levels %u .. %u, %u processed, %llu factors, %zu heads at the start, %u blocks, status %u\n",
+                               eager_phases, Lfrom, h.level + 1, h.levels_done, h.factors, tcount, h.nblk, h.status);
+        return h.level;
+    };
     auto t_prev = std::chrono::steady_clock::now();
     for (u32 L = maxlcp; L >= threshold; --L) {
         if (lcut && L == lcut) {
@@ -1252,18 +1326,22 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
             st->window_pass = ok ? 1 : 2;
             st->window_lcut = lcut;
             if (ok) { st->factors += nf; break; }
-            // the lists of the levels L .. threshold were never materialised: build them from the residence bytes
-            {
-                Ctx::ProfScope prof(c, K_CAND, (u64)n * 6);
-                cand_rebuild_class_kernel<<<gn, 256, 0, s>>>(res8, prio, n, threshold, L, cls, phi ? nullptr : sa, fs.fsrc);
-                LAUNCH_CHECK();
-            }
-            build_lists(false, L);
-            HIP_TRY(hipMemsetAsync(d_lcount, 0xFF, nlev * sizeof(u32), s));
-            purge_next = 0xFFFFFFFFu;
-            cand = cvals[x];
-            dead_streak = 0; levels_since_purge = 1u << 30;
+            // the lists of the levels L .. threshold were never materialised: every alive position becomes an entry of list cur[q]
+            rebuild_from_cur(threshold - 1, L);
+            eager_phases = 99;                                 // (the floor of the global loop moves: no eager phase any more)
             lcut = (why == 1 && L > 24 && threshold <= 24) ? 24 : 0;      // borders only: they move half as far from level 24 on
+        }
+        // ---- a run of small levels ahead: the eager formulation takes them inside one launch ---------------------------------------
+        if (eager_possible && eager_phases < 4 && L > eager_floor + 256 && small_lazy_streak >= 4 && L != force_general_level) {
+            const bool small_ahead = true;                     // (the eager lists hold run heads only: the size of the candidate segments does not matter)
+            if (small_ahead) {
+                const u32 next = run_eager(L);
+                small_lazy_streak = 0;
+                if (next >= eager_floor && next >= threshold) rebuild_from_cur(eager_floor - 1, next);     // it gave up on level `next`: the lazy loop goes on there
+                else { for (u32 v = eager_floor; v <= L; ++v) pushed_into.drop(v); }
+                L = next + 1;                                  // (the loop's --L lands on `next`; below the floor: the window pass or the end)
+                continue;
+            }
         }
         // ---- purge: after a run of large levels whose entries were (almost) all erased, drop the erased candidates of
         //      every level still to come (they can never come back to life: cur only decreases)
@@ -1559,7 +1637,7 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
                     last_alive = h_sc.nlive + h_sc.nstale;
                     if (slim_penalty) --slim_penalty;
                     if (h_sc.pad[0]) {                             // many long factors: the kills are spread over the whole chip
-                        apply_list_kernel<<<cdiv((size_t)h_sc.selected * 64, 256), 256, 0, s>>>(live, &d_sc2[cur_f.slot]->selected, LL, n, phi_eff, cur, fs.flen, fs.fsrc);
+                        apply_list_kernel<<<cdiv((size_t)h_sc.selected * 64, 256), 256, 0, s>>>(live, &d_sc2[cur_f.slot]->selected, LL, n, phi_eff, cur, fs.flen, fs.fsrc, res8);
                         LAUNCH_CHECK();
                     }
                     pushed_into.drop(LL);
@@ -1567,6 +1645,7 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
                     if (level_log) fprintf(stderr, "small %u m %u m0 %u live %u stale %u npush %u big %d\n", LL, cur_f.m, cur_f.m0, h_sc.nlive, h_sc.nstale, h_sc.npush, cur_f.inst);
                     if (LL != L) { st->levels++; ++levels_since_purge; }   // (the level the outer loop stands on has been counted)
                     if (h_sc.nlive == 0) ++nolive_run; else nolive_run = 0;
+                    if (h_sc.nlive <= 1024) ++small_lazy_streak; else small_lazy_streak = 0;
                     if (h_sc.nlive == 0 && h_sc.nstale == 0) { probe_dead = true; ++dead_levels_run; stop_chain = true; }   // small levels do not count for the purge heuristic
                     else {
                         probe_dead = false;
@@ -1656,6 +1735,7 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
             if (L > floor_lv && (u64)(L - floor_lv) * 1500000ull > cnt) purge_pays = true;
         }
         if (nl == 0) ++nolive_run; else nolive_run = 0;
+        if (nl <= 1024) ++small_lazy_streak; else small_lazy_streak = 0;
         if (nl == 0 && ns == 0) { probe_dead = true; ++dead_levels_run; continue; }   // every entry already erased (:86)
         dead_levels_run = 0;
         const bool wide = (L > 24);
@@ -1699,8 +1779,8 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
         if (nl) {
             // per entry: list + state (5); per factor: Phi, flen, fsrc (12) + L kills (8 B each) + L truncations (4 B each)
             Ctx::ProfScope prof(c, K_APPLY, (u64)nl * 5 + (u64)nl * (12 + 12ull * L));
-            if (wide) apply_kernel<64><<<gl, 256, 0, s>>>(live, nl, L, n, bm, phi_eff, cur, fs.flen, fs.fsrc, d_sc);
-            else      apply_kernel<1><<<gl, 256, 0, s>>>(live, nl, L, n, bm, phi_eff, cur, fs.flen, fs.fsrc, d_sc);
+            if (wide) apply_kernel<64><<<gl, 256, 0, s>>>(live, nl, L, n, bm, phi_eff, cur, fs.flen, fs.fsrc, d_sc, res8);
+            else      apply_kernel<1><<<gl, 256, 0, s>>>(live, nl, L, n, bm, phi_eff, cur, fs.flen, fs.fsrc, d_sc, res8);
             LAUNCH_CHECK();
         }
         c.read_n((const u32*)d_sc, (u32*)&h_sc, 8);

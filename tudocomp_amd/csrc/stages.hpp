@@ -73,7 +73,8 @@ void materialize_sources(Ctx& c, size_t n, FactorSpace& fs);    // fills fsrc[] 
 struct FactorizeStats { u64 factors = 0; u32 maxlcp = 0; u32 levels = 0; u32 rounds = 0; u64 pushes = 0; u64 entries = 0; u32 small_levels = 0; u32 purges = 0;
                         u32 window_pass = 0; /* 0 not used, 1 low levels done window-local, 2 window pass failed -> global loop */
                         u32 window_lcut = 0; /* highest level of the last window pass */
-                        u32 probes = 0; /* skip-ahead probes over runs of erased levels */ };
+                        u32 probes = 0; /* skip-ahead probes over runs of erased levels */
+                        u32 eager_levels = 0, eager_phases = 0; /* levels inside one-launch runs of small levels (factorize_eager.hip), runs */ };
 
 // a8: compressors/lcpcomp/compress/ArraysComp.hpp:36-117 in position space.
 // Inputs: isa, phi, plcp.  isa and plcp are consumed: they become the working priority / LCP arrays.
