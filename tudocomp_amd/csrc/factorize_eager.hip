@@ -304,8 +304,7 @@ __global__ __launch_bounds__(256) void lazy_rebuild_class_kernel(const u32* __re
     const u32 c = cur[q];
     cls[q] = (c > lo && c <= hi) ? 1 : 0;
 }
-// ... and their list order: truncated entries follow the natural ones (priority n + index; their ISA is gone afterwards, so the source
-// of a truncated entry is saved first -- FactorSpace::src_prio)
+// ... and their list order: truncated entries follow the natural ones (priority prio_base + index; FactorSpace::src_prio)
 __global__ __launch_bounds__(256) void lazy_rebuild_prio_kernel(const u32* __restrict__ list, size_t m, const u32* __restrict__ cur, const u8* __restrict__ res8,
                                                                 size_t n, u32* __restrict__ prio, u32 prio_base, const u32* __restrict__ src_sa, u32* __restrict__ fsrc) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -313,12 +312,12 @@ __global__ __launch_bounds__(256) void lazy_rebuild_prio_kernel(const u32* __res
     const u32 q = list[i];
     const u32 c = cur[q], r = res8[q];
     const bool natural = c < 255u ? r == c : r == 255u;
-    if (natural) return;
     const u32 pr = prio[q];
-    if (pr < (u32)n) {
-        if (src_sa) fsrc[q] = pr ? src_sa[pr - 1] : src_sa[n - 1];
-        prio[q] = prio_base + (u32)i;
-    }
+    if (pr >= (u32)n) return;                                    // pushed by an earlier lazy level: its source was saved then
+    // no Phi array: the source of a factor at q is SA[ISA[q] - 1] (ds/PhiFromSA.hpp:35-45) -- saved now for EVERY listed entry, a push
+    // of the lazy levels to come may overwrite its priority (= ISA) before it is selected
+    if (src_sa) fsrc[q] = pr ? src_sa[pr - 1] : src_sa[n - 1];
+    if (!natural) prio[q] = prio_base + (u32)i;
 }
 
 }  // namespace

@@ -173,6 +173,7 @@ __global__ __launch_bounds__(KT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
             for (int it0 = 0; it0 < LIT; it0 += LB) {
                 uint4 cv[LB];
                 u32 rv4[LB];
+                u64 bmask = 0;
 #pragma unroll
                 for (int u = 0; u < LB; ++u) {
                     const size_t gp = w0 + (size_t)((it0 + u) * KT * 4 + tid * 4);      // w0 and the offset are multiples of 4
@@ -191,10 +192,11 @@ __global__ __launch_bounds__(KT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                         const u32 rv = (rv4[u] >> (8 * k)) & 0xFFu;
                         const u32 bb = c ? (c | (rv != c ? B_TRUNC : 0u)) : 0u;
                         sw |= bb << (8 * k);
-                        mymask |= 1ull << c;
+                        bmask |= 1ull << c;
                     }
                     *(u32*)&S[PA(i)] = sw;
                 }
+                mymask |= bmask;
             }
         } else {
             for (int i = tid * 4; i < TW; i += KT * 4) {
