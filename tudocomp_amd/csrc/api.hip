@@ -385,6 +385,7 @@ int tdc_gpu_ctx_create(int device, tdc_gpu_ctx** out) {
         if (const char* m = getenv("TDC_GPU_LEVEL_PURGE")) ctx->c.level_purge = atoi(m) != 0;
         if (const char* m = getenv("TDC_GPU_EAGER")) ctx->c.eager_levels = atoi(m) != 0;
         if (const char* m = getenv("TDC_GPU_SA_REFINE")) ctx->c.sa_refine = atoi(m) != 0;
+        if (const char* m = getenv("TDC_GPU_SA_PAIRS")) ctx->c.sa_pairs = atoi(m) != 0;
         if (const char* m = getenv("TDC_GPU_SA_FUSED_INIT")) ctx->c.sa_fused_init = atoi(m) != 0;
         if (const char* m = getenv("TDC_GPU_RADIX_LDS")) { const int v = atoi(m); ctx->c.radix_lds = (v >= 0 && v <= 2) ? v : 2; }
         if (const char* m = getenv("TDC_GPU_XCD_REMAP")) { const int v = atoi(m); ctx->c.xcd_remap = (v >= 0 && v <= 2) ? v : 0; }

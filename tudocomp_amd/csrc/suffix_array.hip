@@ -616,6 +616,44 @@ size_t first_groups(Ctx& c, size_t n, int bn, const u64* keys, const u32* vals, 
     return h_tot[0];
 }
 
+// ---- groups of exactly two suffixes, ordered from the text in one pass (round 5) -------------------------------------------------------
+// Texts with long repeats (copied blocks) leave most unresolved suffixes in PAIRS {x, y}: a position of the copy and the same position
+// of its source.  Doubling orders such a pair once h exceeds the rest of the repeat -- log(4096 / h) rounds over every position of
+// every repeat (10^9 B of DNA: 8 rounds of ~33 ms over 250 M suffixes).  But the longest common extension of a pair is the one of the
+// pair one position earlier minus one (as long as both are pairs, the partner of x + 1 is the partner of x plus one): the values
+// lce(x, partner) satisfy the bound of the PLCP array, len[x] >= len[x - 1] - 1, and the chunked carry evaluation of build_plcp
+// (textds.hip, build_lce_with_carry) computes all of them in one pass over the text.  The first byte behind the common extension
+// decides the order.  What remains for the doubling rounds are the groups of three and more.
+__global__ __launch_bounds__(256) void sa_pair_mark_kernel(const u32* __restrict__ a_sa, const u32* __restrict__ a_r1, size_t m, u32* __restrict__ src) {
+    const size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a + 1 >= m) return;
+    const u32 r = a_r1[a];
+    if (a_r1[a + 1] != r || (a > 0 && a_r1[a - 1] == r) || (a + 2 < m && a_r1[a + 2] == r)) return;       // not the first member of a pair
+    const u32 x = a_sa[a], y = a_sa[a + 1];
+    if (x > y) src[x] = y; else src[y] = x;         // the later position carries the pair: consecutive pairs of one repeat then sit at consecutive positions
+}
+__global__ __launch_bounds__(256) void sa_pair_resolve_kernel(const u8* __restrict__ text, size_t n, const u32* __restrict__ a_sa, const u32* __restrict__ a_pos,
+                                                              const u32* __restrict__ a_r1, size_t m, const u32* __restrict__ len, u32* __restrict__ sa,
+                                                              u32* __restrict__ rank, u8* __restrict__ keep) {
+    const size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= m) return;
+    const u32 r = a_r1[a];
+    const bool eq_prev = a > 0 && a_r1[a - 1] == r, eq_next = a + 1 < m && a_r1[a + 1] == r;
+    const bool first = !eq_prev && eq_next && !(a + 2 < m && a_r1[a + 2] == r);
+    const bool second = eq_prev && !eq_next && !(a >= 2 && a_r1[a - 2] == r);
+    keep[a] = (first || second) ? 0 : 1;
+    if (!first) return;
+    const u32 x = a_sa[a], y = a_sa[a + 1];
+    const u32 hi = x > y ? x : y, lo = x > y ? y : x;
+    const u32 L = len[hi];
+    // the unique sentinel ends the later suffix first: hi + L < n always; the byte behind the common extension decides
+    const u8 ch = ((size_t)hi + L < n) ? text[(size_t)hi + L] : (u8)0, cl = ((size_t)lo + L < n) ? text[(size_t)lo + L] : (u8)0;
+    const u32 small = (ch < cl) ? hi : lo, large = (ch < cl) ? lo : hi;
+    const u32 p0 = a_pos[a];
+    sa[p0] = small; sa[p0 + 1] = large;
+    rank[small] = p0; rank[large] = p0 + 1;
+}
+
 // prefix doubling from h on: the active list (A_sa, A_pos, A_r1) holds the m unresolved suffixes, rank[] is up to date
 void doubling_rounds(Ctx& c, size_t n, int bn, u32* sa, u32* rank, SABufs& B, size_t m, u64 h, u32 h_tot[4], SAStats* st) {
     hipStream_t s = c.stream;
@@ -811,6 +849,37 @@ int build_suffix_array_wide(Ctx& c, const u8* text, size_t n, u32* sa, u32* isa,
     if (text_rounds > 0) {
         // the rounds gave up: ranks of the state reached so far (sa + head flags), then doubling from the common depth h
         m = first_groups(c, n, bn, nullptr, sa, flags, sa, isa, B, true, h_tot);
+    }
+    if (c.sa_pairs && m >= n / 64 && m >= ((size_t)1 << 20)) {
+        // pairs first: one pass over the text instead of log(repeat length / h) rounds over them
+        const size_t pm = c.arena.mark();
+        u32* src = (u32*)K2[0];                            // (the second key words of the wide sort are not used any more: 8 n bytes)
+        u32* len = src + n;
+        u32* d_mx = c.arena.get<u32>(1);
+        u8* keep = (u8*)B.keep;
+        fill_u32(c, src, n, NONE32);
+        {
+            Ctx::ProfScope prof(c, K_SA_BUILD_KEYS, (u64)m * 12);
+            sa_pair_mark_kernel<<<cdiv(m, 256), 256, 0, s>>>(B.A_sa, B.A_r1, m, src);
+            LAUNCH_CHECK();
+        }
+        build_lce_with_carry(c, text, n, src, len, d_mx);
+        {
+            Ctx::ProfScope prof(c, K_SA_RANK_SCATTER, (u64)m * 30);
+            sa_pair_resolve_kernel<<<cdiv(m, 256), 256, 0, s>>>(text, n, B.A_sa, B.A_pos, B.A_r1, m, len, sa, isa, keep);
+            LAUNCH_CHECK();
+        }
+        select_by_class(c, keep, 1, m, B.A_sa, B.B_sa, nullptr, nullptr, B.d_total);
+        select_by_class(c, keep, 1, m, B.A_pos, B.B_pos, nullptr, nullptr, B.d_total);
+        select_by_class(c, keep, 1, m, B.A_r1, B.B_r1, nullptr, nullptr, B.d_total);
+        const size_t m2 = c.read(B.d_total);
+        u32* t;
+        t = B.A_sa; B.A_sa = B.B_sa; B.B_sa = t;
+        t = B.A_pos; B.A_pos = B.B_pos; B.B_pos = t;
+        t = B.A_r1; B.A_r1 = B.B_r1; B.B_r1 = t;
+        st->pair_resolved = (u64)(m - m2);
+        m = m2;
+        c.arena.release(pm);
     }
     doubling_rounds(c, n, bn, sa, isa, B, m, (u64)h, h_tot, st);
     return 0;
