@@ -231,6 +231,11 @@ void run_factorize(Ctx& c, size_t n, DevArrays& A, u32 threshold, int flatten, t
     A.fs.flenl = threshold >= 2 ? A.fs.fpos + (n + 1) / 2 : nullptr;    // (a factor covers >= threshold positions: at most n / 2 of them, the list of
                                                                          //  their lengths fits the upper half of the position list)
     A.fs.cls = c.arena.get<u8>(n + 64);                  // class bytes for the encoder (filled by build_owner)
+    // the metric's path (lcpcomp(comp=arrays, coder=huff) with the encoder's first half inside the flatten stage: nothing reads the dense
+    // flen[] array behind build_owner): the factor lengths travel as bytes until then
+    const bool early_planned = strategy == TDC_GPU_COMP_ARRAYS && flatten && enc_coder == 0 && d_text && c.enc_early && c.enc_rec && c.copy_stream && c.huff_ok &&
+                               n >= (c.enc_early >= 2 ? (size_t)1 : ((size_t)1 << 20)) && threshold >= 2;
+    if (early_planned && c.flen_bytes) A.fs.flen8 = c.arena.get<u8>(n + 64);
     FactorizeStats fz;
     FlattenStats fl;
     const int e0 = ev ? ev->tick() : 0;
@@ -244,6 +249,7 @@ void run_factorize(Ctx& c, size_t n, DevArrays& A, u32 threshold, int flatten, t
     // bound by the latency of their chains, not by bandwidth: it runs on the copy stream next to the first round.
     const bool early = flatten && enc_coder == 0 && d_text && c.enc_early && c.copy_stream && c.huff_ok && n >= (c.enc_early >= 2 ? (size_t)1 : ((size_t)1 << 20)) &&
                        A.fs.have_list && A.fs.have_cls && A.fs.flenl && A.fs.nfact > 0;
+    if (!early) expand_flen8(c, n, A.fs);                  // (planned, but there is no factor list to run it on: everybody else reads the dense array)
     if (early) {
         A.early = encode_early_reserve(c, n, c.enc_rec ? A.fs.nfact : 0);
         HIP_TRY(hipEventRecord(c.ev_copy[0], c.stream));                  // the factors are in place
@@ -384,6 +390,7 @@ int tdc_gpu_ctx_create(int device, tdc_gpu_ctx** out) {
         if (const char* m = getenv("TDC_GPU_ENC_REC")) ctx->c.enc_rec = atoi(m) != 0;
         if (const char* m = getenv("TDC_GPU_LEVEL_PURGE")) ctx->c.level_purge = atoi(m) != 0;
         if (const char* m = getenv("TDC_GPU_EAGER")) ctx->c.eager_levels = atoi(m) != 0;
+        if (const char* m = getenv("TDC_GPU_FLEN_BYTES")) ctx->c.flen_bytes = atoi(m) != 0;
         if (const char* m = getenv("TDC_GPU_SA_REFINE")) ctx->c.sa_refine = atoi(m) != 0;
         if (const char* m = getenv("TDC_GPU_SA_PAIRS")) ctx->c.sa_pairs = atoi(m) != 0;
         if (const char* m = getenv("TDC_GPU_SA_FUSED_INIT")) ctx->c.sa_fused_init = atoi(m) != 0;

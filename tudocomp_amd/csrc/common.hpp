@@ -132,6 +132,7 @@ struct Ctx {
     int radix_waves = 4;           // waves per radix-sort workgroup for large inputs (env TDC_GPU_RADIX_WAVES = 4 | 8; no measurable difference)
     int plcp_samples = 1;          // PLCP: exact values at every 256th position first, as lower bounds for the chunks (env TDC_GPU_PLCP_SAMPLES=0: chunks start from 0)
     bool huff_ok = true;           // the start-up self-check of the host Huffman table passed (else coder=huff calls fail with TDC_GPU_ERR_INTERNAL)
+    int flen_bytes = 1;            // the metric's path: factor lengths as bytes until build_owner (FactorSpace::flen8; env TDC_GPU_FLEN_BYTES=0: the dense u32 array)
     int eager_levels = 1;          // factorize: runs of small levels inside one launch (factorize_eager.hip; env TDC_GPU_EAGER=0: every level through the lazy loop)
     int level_purge = 1;           // factorize: the lists of the next 64 levels are purged in place before they are read (env TDC_GPU_LEVEL_PURGE=0 disables)
     int enc_rec = 1;               // with enc_early: the pack reads lengths and flattened sources from the records of the flatten stage (env TDC_GPU_ENC_REC=0: from flen[] / fsrc[])

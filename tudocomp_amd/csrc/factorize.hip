@@ -82,6 +82,11 @@ __device__ __forceinline__ u32 bm_state(const u64* __restrict__ bm, u32 p) { ret
 // above: the window pass tells natural from truncated entries by it, and the lists of either formulation can be rebuilt from cur[].
 __device__ __forceinline__ u8 res8_mark(u32 t) { return (u8)(t <= 63u ? (0x80u | t) : 0u); }
 __device__ __forceinline__ u8 res8_pushed(u32 t) { return res8_mark(t); }
+// a factor of length L starts at p: the dense u32 array, or -- FactorSpace::flen8 -- the byte array (255: the length is flen[p])
+__device__ __forceinline__ void put_flen(u32* __restrict__ flen, u8* __restrict__ flen8, u32 p, u32 L) {
+    if (flen8) { flen8[p] = (u8)(L < 255u ? L : 255u); if (L >= 255u) flen[p] = L; }
+    else flen[p] = L;
+}
 
 // ---- candidates ("Fill candidates", :54-66) ----------------------------------------------------------------
 // cls[p] = 1 for the candidates whose level is above `lo` (the lists of the levels <= lo are only materialised if the
@@ -93,7 +98,7 @@ __device__ __forceinline__ u8 res8_pushed(u32 t) { return res8_mark(t); }
 __global__ __launch_bounds__(256) void cand_class_kernel(const u32* __restrict__ plcp, size_t n, u32 threshold, u32 lo, u8* __restrict__ cls,
                                                           u32* __restrict__ flen, u8* __restrict__ res8, u32* __restrict__ d_entries,
                                                           u32* __restrict__ lvl_hist, const u32* __restrict__ src_sa, const u32* __restrict__ src_isa,
-                                                          u32* __restrict__ fsrc) {
+                                                          u32* __restrict__ fsrc, u8* __restrict__ flen8) {
     __shared__ u32 sm[4];
     __shared__ u32 sh[64];
     if (threadIdx.x < 64) sh[threadIdx.x] = 0;
@@ -116,14 +121,14 @@ __global__ __launch_bounds__(256) void cand_class_kernel(const u32* __restrict__
             if (src_sa && is_cand && v[j] > lo) { const u32 r = src_isa[4 * q + j]; fsrc[4 * q + j] = r ? src_sa[r - 1] : src_sa[n - 1]; }
         }
         ((u32*)cls)[q] = cw;
-        ((uint4*)flen)[q] = make_uint4(0, 0, 0, 0);
+        if (flen8) ((u32*)flen8)[q] = 0; else ((uint4*)flen)[q] = make_uint4(0, 0, 0, 0);
         if (res8) ((u32*)res8)[q] = rw;
     }
     for (size_t p = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
         const u32 v = plcp[p];
         const u32 is_cand = (v >= threshold) ? 1u : 0u;
         cls[p] = (is_cand && v > lo) ? 1 : 0;
-        flen[p] = 0;
+        if (flen8) flen8[p] = 0; else flen[p] = 0;
         if (res8) res8[p] = is_cand ? (u8)(v > 255u ? 255u : v) : (u8)0;
         cnt += is_cand;
         if (lvl_hist && is_cand && v < 64u && (p & 15) == 0) atomicAdd(&sh[v], 1u);
@@ -310,7 +315,7 @@ __global__ __launch_bounds__(NT) void small_level_kernel(const u32* __restrict__
                                                            u32 inline_budget, LevelScalars* __restrict__ sc,
                                                            u32* zc_dst, u32* zc_flag, u32 zc_seq, unsigned long long* prof, u32* zc_segs,
                                                            SmallCtl* __restrict__ ctl, u32 spec, const LevelScalars* prev_sc, const PushSeg* prev_segs,
-                                                           const u32* __restrict__ m0_dev) {
+                                                           const u32* __restrict__ m0_dev, u8* __restrict__ flen8) {
     // Everything the first step needs from global memory is requested before anything waits: the purged length of the list, the first
     // entries of the original candidates (entries behind the purged length are copies of one erased entry: harmless) and, further
     // down, the gather table -- a one-workgroup kernel has nothing else to hide these round trips behind (20 us of the 40 a level takes).
@@ -822,7 +827,7 @@ full_sort:
         __syncthreads();
         for (u32 f = wv; f < nsel; f += NWV) {
             const u32 p = sval[f];
-            if (lane == 0) { flen[p] = L; if (phi != fsrc) fsrc[p] = phi[p]; }      // (no Phi array: phi IS fsrc, already filled for this candidate)
+            if (lane == 0) { put_flen(flen, flen8, p, L); if (phi != fsrc) fsrc[p] = phi[p]; }      // (no Phi array: phi IS fsrc, already filled for this candidate)
             for (u32 j = lane; j < L && (size_t)p + j < n; j += 64) cur[p + j] = 0;
             const u32 aff = (L < p) ? L : p;
             for (u32 j0 = 0; j0 < aff; j0 += 64 * 8) {
@@ -901,12 +906,12 @@ __global__ __launch_bounds__(1024) void level_purge_kernel(u32* __restrict__ can
 // apply for a list of selected positions whose length is only known on the device (one wave per factor)
 __global__ __launch_bounds__(256) void apply_list_kernel(const u32* __restrict__ list, const u32* __restrict__ d_count, u32 L, size_t n,
                                                           const u32* __restrict__ phi, u32* __restrict__ cur, u32* __restrict__ flen,
-                                                          u32* __restrict__ fsrc, u8* __restrict__ res8) {
+                                                          u32* __restrict__ fsrc, u8* __restrict__ res8, u8* __restrict__ flen8) {
     const u32 i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const u32 lane = threadIdx.x & 63;
     if (i >= *d_count) return;
     const u32 p = list[i];
-    if (lane == 0) { flen[p] = L; if (phi != fsrc) fsrc[p] = phi[p]; }
+    if (lane == 0) { put_flen(flen, flen8, p, L); if (phi != fsrc) fsrc[p] = phi[p]; }
     for (u32 j = lane; j < L && (size_t)p + j < n; j += 64) cur[p + j] = 0;
     const u32 aff = (L < p) ? L : p;
     for (u32 j = lane; j < aff; j += 64) { u32* q = &cur[p - 1 - j]; if (*q > j + 1) { if (atomicMin(q, j + 1) > j + 1 && res8) res8[p - 1 - j] = res8_mark(j + 1); } }
@@ -1022,14 +1027,14 @@ __global__ void push_finalize_kernel(const u64* __restrict__ keys, const u32* __
 template <int G>
 __global__ __launch_bounds__(256) void apply_kernel(const u32* __restrict__ live, u32 nl, u32 L, size_t n, u64* bm,
                                                      const u32* __restrict__ phi, u32* __restrict__ cur, u32* __restrict__ flen,
-                                                     u32* __restrict__ fsrc, LevelScalars* __restrict__ sc, u8* __restrict__ res8) {
+                                                     u32* __restrict__ fsrc, LevelScalars* __restrict__ sc, u8* __restrict__ res8, u8* __restrict__ flen8) {
     const u32 i = (blockIdx.x * blockDim.x + threadIdx.x) / G;
     const u32 sub = (G == 1) ? 0u : (threadIdx.x & (G - 1));
     bool sel = false;
     u32 p = 0;
     if (i < nl) { p = live[i]; sel = (bm_state(bm, p) == 2u); }
     if (sel) {
-        if (sub == 0) { flen[p] = L; if (phi != fsrc) fsrc[p] = phi[p]; }
+        if (sub == 0) { put_flen(flen, flen8, p, L); if (phi != fsrc) fsrc[p] = phi[p]; }
         for (u32 j = sub; j < L && (size_t)p + j < n; j += G) cur[p + j] = 0;   // :99-101
         const u32 aff = (L < p) ? L : p;                           // :103
         for (u32 j = sub; j < aff; j += G) {                         // :105-109
@@ -1085,9 +1090,9 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
     u32* d_lvlhist = c.arena.get<u32>(64);
     HIP_TRY(hipMemsetAsync(d_lvlhist, 0, 64 * sizeof(u32), s));
     {
-        Ctx::ProfScope prof(c, K_CAND, (u64)n * (lcut ? 10 : 9));
+        Ctx::ProfScope prof(c, K_CAND, (u64)n * (lcut ? 10 : 9) - (fs.flen8 ? (u64)n * 3 : 0));
         cand_class_kernel<<<(gn < 8192u ? gn : 8192u), 256, 0, s>>>(plcp, n, threshold, lcut, cls, fs.flen, res8, d_cnt + 1, lcut ? d_lvlhist : nullptr,
-                                                                    phi ? nullptr : sa, isa, fs.fsrc);
+                                                                    phi ? nullptr : sa, isa, fs.fsrc, fs.flen8);
         LAUNCH_CHECK();
     }
     if ((u64)maxlcp + 1 <= threshold || threshold == 0) { c.arena.release(mark); build_owner(c, n, fs); if (!phi) { fs.src_prio = prio; fs.src_sa = sa; fs.src_n = n; } return; }   // ArraysComp.hpp:50
@@ -1267,7 +1272,7 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
         P.tcand = tv[y]; P.tstart = d_eseg + 2 * nlev; P.tend = d_eseg + 3 * nlev;
         P.head = d_ehead;
         P.blk = pool; P.blk_cap = (u32)std::min<size_t>(n / 16, (size_t)1 << 28);   // (the push pool of the lazy formulation is forgotten anyway)
-        P.cur = cur; P.prio = prio; P.phi = phi_eff; P.flen = fs.flen; P.fsrc = fs.fsrc; P.res8 = res8;
+        P.cur = cur; P.prio = prio; P.phi = phi_eff; P.flen = fs.flen; P.flen8 = fs.flen8; P.fsrc = fs.fsrc; P.res8 = res8;
         P.n = n; P.threshold = threshold; P.L_from = Lfrom; P.L_stop = eager_floor; P.raw_cap = eager_levels_raw_cap();
         P.ctl = d_ectl;
         P.dbg = nullptr;
@@ -1580,17 +1585,17 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
                         small_level_kernel<1024, true><<<1, 1024, 0, s>>>(cand + h_segstart[lv], a0, pushed_src, (u32)mm, pool, d_hgtab ? d_hgtab + (size_t)slot * half : nullptr, gn, lv,
                                                                   threshold, n, cur, prio, phi_eff, fs.flen, res8, fs.fsrc, (u32)pool_top, prio_base, d_segs2[slot], seg_cap, live,
                                                                   /*inline_budget=*/1u << 17, d_sc2[slot], zdst, zflag, zseq, d_sprof, zsegs,
-                                                                  d_ctl, spec ? 1u : 0u, d_sc2[slot ^ 1], d_segs2[slot ^ 1], d_lcount + lv);
+                                                                  d_ctl, spec ? 1u : 0u, d_sc2[slot ^ 1], d_segs2[slot ^ 1], d_lcount + lv, fs.flen8);
                     else if (inst == 1)
                         small_level_kernel<512><<<1, 512, 0, s>>>(cand + h_segstart[lv], a0, pushed_src, (u32)mm, pool, d_hgtab ? d_hgtab + (size_t)slot * half : nullptr, gn, lv,
                                                                   threshold, n, cur, prio, phi_eff, fs.flen, res8, fs.fsrc, (u32)pool_top, prio_base, d_segs2[slot], seg_cap, live,
                                                                   /*inline_budget=*/1u << 17, d_sc2[slot], zdst, zflag, zseq, d_sprof, zsegs,
-                                                                  d_ctl, spec ? 1u : 0u, d_sc2[slot ^ 1], d_segs2[slot ^ 1], d_lcount + lv);
+                                                                  d_ctl, spec ? 1u : 0u, d_sc2[slot ^ 1], d_segs2[slot ^ 1], d_lcount + lv, fs.flen8);
                     else
                         small_level_kernel<256><<<1, 256, 0, s>>>(cand + h_segstart[lv], a0, pushed_src, (u32)mm, pool, d_hgtab ? d_hgtab + (size_t)slot * half : nullptr, gn, lv,
                                                                   threshold, n, cur, prio, phi_eff, fs.flen, res8, fs.fsrc, (u32)pool_top, prio_base, d_segs2[slot], seg_cap, live,
                                                                   /*inline_budget=*/1u << 17, d_sc2[slot], zdst, zflag, zseq, d_sprof, zsegs,
-                                                                  d_ctl, spec ? 1u : 0u, d_sc2[slot ^ 1], d_segs2[slot ^ 1], d_lcount + lv);
+                                                                  d_ctl, spec ? 1u : 0u, d_sc2[slot ^ 1], d_segs2[slot ^ 1], d_lcount + lv, fs.flen8);
                     LAUNCH_CHECK();
                 }
                 inflight_push_max += push_max;
@@ -1637,7 +1642,7 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
                     last_alive = h_sc.nlive + h_sc.nstale;
                     if (slim_penalty) --slim_penalty;
                     if (h_sc.pad[0]) {                             // many long factors: the kills are spread over the whole chip
-                        apply_list_kernel<<<cdiv((size_t)h_sc.selected * 64, 256), 256, 0, s>>>(live, &d_sc2[cur_f.slot]->selected, LL, n, phi_eff, cur, fs.flen, fs.fsrc, res8);
+                        apply_list_kernel<<<cdiv((size_t)h_sc.selected * 64, 256), 256, 0, s>>>(live, &d_sc2[cur_f.slot]->selected, LL, n, phi_eff, cur, fs.flen, fs.fsrc, res8, fs.flen8);
                         LAUNCH_CHECK();
                     }
                     pushed_into.drop(LL);
@@ -1779,8 +1784,8 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
         if (nl) {
             // per entry: list + state (5); per factor: Phi, flen, fsrc (12) + L kills (8 B each) + L truncations (4 B each)
             Ctx::ProfScope prof(c, K_APPLY, (u64)nl * 5 + (u64)nl * (12 + 12ull * L));
-            if (wide) apply_kernel<64><<<gl, 256, 0, s>>>(live, nl, L, n, bm, phi_eff, cur, fs.flen, fs.fsrc, d_sc, res8);
-            else      apply_kernel<1><<<gl, 256, 0, s>>>(live, nl, L, n, bm, phi_eff, cur, fs.flen, fs.fsrc, d_sc, res8);
+            if (wide) apply_kernel<64><<<gl, 256, 0, s>>>(live, nl, L, n, bm, phi_eff, cur, fs.flen, fs.fsrc, d_sc, res8, fs.flen8);
+            else      apply_kernel<1><<<gl, 256, 0, s>>>(live, nl, L, n, bm, phi_eff, cur, fs.flen, fs.fsrc, d_sc, res8, fs.flen8);
             LAUNCH_CHECK();
         }
         c.read_n((const u32*)d_sc, (u32*)&h_sc, 8);
@@ -2075,7 +2080,7 @@ void factorize_max_lcp(Ctx& c, size_t n, u32* isa, const u32* phi, u32* plcp, u3
     u32* cvals[2] = { c.arena.get<u32>(n), c.arena.get<u32>(n) };
     u32* d_cnt = c.arena.get<u32>(4);
     HIP_TRY(hipMemsetAsync(d_cnt, 0, 4 * sizeof(u32), s));
-    cand_class_kernel<<<(gn < 8192u ? gn : 8192u), 256, 0, s>>>(plcp, n, threshold, 0u, cls, fs.flen, nullptr, d_cnt + 1, nullptr, nullptr, nullptr, nullptr);
+    cand_class_kernel<<<(gn < 8192u ? gn : 8192u), 256, 0, s>>>(plcp, n, threshold, 0u, cls, fs.flen, nullptr, d_cnt + 1, nullptr, nullptr, nullptr, nullptr, nullptr);
     LAUNCH_CHECK();
     if (maxlcp < threshold || threshold == 0) { c.arena.release(mark); build_owner(c, n, fs); return; }
     mlcp_init_prio_kernel<<<gn, 256, 0, s>>>(prio, n);

@@ -235,7 +235,7 @@ __global__ __launch_bounds__(ENT) void eager_levels_kernel(EagerParams P) {
         }
         for (u32 s = tid; s < ns; s += ENT) {
             const u32 p = sel[s];
-            P.flen[p] = L;
+            if (P.flen8) { P.flen8[p] = (u8)(L < 255u ? L : 255u); if (L >= 255u) P.flen[p] = L; } else P.flen[p] = L;
             if (P.phi != P.fsrc) P.fsrc[p] = P.phi[p];
         }
         if (tid == 0) factors += ns;

@@ -10,7 +10,7 @@ struct EagerParams {
     const u32* tcand; const u32* tstart; const u32* tend;        // run heads that existed when the phase started: positions by level, [tstart, tend) per level
     u32* head;                                                   // per level: index + 1 of the newest block of entries inserted since (0: none)
     u32* blk; u32 blk_cap;                                       // blocks of 16 words: next (index + 1), count, 14 positions
-    u32* cur; const u32* prio; const u32* phi; u32* flen; u32* fsrc; u8* res8;
+    u32* cur; const u32* prio; const u32* phi; u32* flen; u8* flen8; u32* fsrc; u8* res8;     // flen8: FactorSpace::flen8 (nullable)
     size_t n; u32 threshold;
     u32 L_from, L_stop;                                          // levels L_from .. L_stop (inclusive), downwards
     u32 raw_cap;                                                 // longest head segment the workgroup reads

@@ -131,7 +131,7 @@ template <int KT, int TE, int WPE, bool WPHI>      // threads, entries per level
 __global__ __launch_bounds__(KT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void window_eager_kernel(const u32* __restrict__ cur_g, const u32* __restrict__ prio_g,
                                                             const u8* __restrict__ res_g, const u32* __restrict__ phi, size_t n,
                                                             u32 lcut, u32 threshold, u32 ntiles, u32 halo,
-                                                            u32* __restrict__ flen, u32* __restrict__ fsrc, WinScalars* __restrict__ sc) {
+                                                            u32* __restrict__ flen, u8* __restrict__ flen8, u32* __restrict__ fsrc, WinScalars* __restrict__ sc) {
     constexpr int NWV = KT / 64;
     constexpr int CPT = TW / (64 * KT) > 0 ? TW / (64 * KT) : 1;   // 64-position chunks per thread (the first TW / 64 / CPT threads own some)
     static_assert(TW % 64 == 0 && TW / 64 <= KT * CPT, "every chunk of the window needs an owner");
@@ -484,7 +484,8 @@ __global__ __launch_bounds__(KT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                             const int pos = base + k + bb;
                             if (pos < ia || pos >= ib) continue;
                             const size_t gp = w0 + pos;
-                            flen[gp] = (u32)(rw >> (8 * bb)) & 0x3Fu;
+                            if (flen8) flen8[gp] = (u8)((rw >> (8 * bb)) & 0x3Fu);      // (FactorSpace::flen8: the lengths as bytes)
+                            else flen[gp] = (u32)(rw >> (8 * bb)) & 0x3Fu;
                             if constexpr (WPHI) fsrc[gp] = phi[gp];     // (without a Phi array the sources are computed from SA[ISA[p] - 1] where they
                                                                         //  are needed: FactorSpace::src_prio, flatten.hip)
                             ++nsel_interior;
@@ -501,9 +502,11 @@ __global__ __launch_bounds__(KT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
 }
 
 // a failed pass leaves factors of the low levels behind: remove them (factors of the global levels are longer than lcut)
-__global__ void window_cleanup_kernel(u32* __restrict__ flen, size_t n, u32 lcut) {
+__global__ void window_cleanup_kernel(u32* __restrict__ flen, u8* __restrict__ flen8, size_t n, u32 lcut) {
     const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < n && flen[p] <= lcut) flen[p] = 0;
+    if (p >= n) return;
+    if (flen8) { if (flen8[p] <= lcut) flen8[p] = 0; }
+    else if (flen[p] <= lcut) flen[p] = 0;
 }
 
 }  // namespace
@@ -541,11 +544,11 @@ int factorize_window_levels(Ctx& c, size_t n, const u32* cur, const u32* prio, c
             // per window position: cur (4) + residence (1); per text position: ~0.1 priority reads and the factor output
             Ctx::ProfScope prof(c, K_WINDOW_LEVELS, (u64)((double)n * TW / ti * 5) + (u64)n * 2);
             if (!large) {
-                if (phi) window_eager_kernel<TT, TE_SMALL, TDC_WIN_WPE, true><<<grid, TT, 0, s>>>(cur, prio, res8, phi, n, lcut, threshold, ntiles, halo, fs.flen, fs.fsrc, d_sc);
-                else window_eager_kernel<TT, TE_SMALL, TDC_WIN_WPE, false><<<grid, TT, 0, s>>>(cur, prio, res8, phi, n, lcut, threshold, ntiles, halo, fs.flen, fs.fsrc, d_sc);
+                if (phi) window_eager_kernel<TT, TE_SMALL, TDC_WIN_WPE, true><<<grid, TT, 0, s>>>(cur, prio, res8, phi, n, lcut, threshold, ntiles, halo, fs.flen, fs.flen8, fs.fsrc, d_sc);
+                else window_eager_kernel<TT, TE_SMALL, TDC_WIN_WPE, false><<<grid, TT, 0, s>>>(cur, prio, res8, phi, n, lcut, threshold, ntiles, halo, fs.flen, fs.flen8, fs.fsrc, d_sc);
             } else {
-                if (phi) window_eager_kernel<TT_LARGE, TE_LARGE, TT_LARGE / 256, true><<<grid, TT_LARGE, 0, s>>>(cur, prio, res8, phi, n, lcut, threshold, ntiles, halo, fs.flen, fs.fsrc, d_sc);
-                else window_eager_kernel<TT_LARGE, TE_LARGE, TT_LARGE / 256, false><<<grid, TT_LARGE, 0, s>>>(cur, prio, res8, phi, n, lcut, threshold, ntiles, halo, fs.flen, fs.fsrc, d_sc);
+                if (phi) window_eager_kernel<TT_LARGE, TE_LARGE, TT_LARGE / 256, true><<<grid, TT_LARGE, 0, s>>>(cur, prio, res8, phi, n, lcut, threshold, ntiles, halo, fs.flen, fs.flen8, fs.fsrc, d_sc);
+                else window_eager_kernel<TT_LARGE, TE_LARGE, TT_LARGE / 256, false><<<grid, TT_LARGE, 0, s>>>(cur, prio, res8, phi, n, lcut, threshold, ntiles, halo, fs.flen, fs.flen8, fs.fsrc, d_sc);
             }
             LAUNCH_CHECK();
         }
@@ -562,7 +565,7 @@ int factorize_window_levels(Ctx& c, size_t n, const u32* cur, const u32* prio, c
         if (c.window_force_fail) h.fail |= 1u;                 // (tests: the pass is discarded as if a border had failed with the largest halo)
         result = (int)h.fail;
         if (!h.fail) break;
-        window_cleanup_kernel<<<cdiv(n, 256), 256, 0, s>>>(fs.flen, n, lcut);     // forget the factors of the failed pass
+        window_cleanup_kernel<<<cdiv(n, 256), 256, 0, s>>>(fs.flen, fs.flen8, n, lcut);     // forget the factors of the failed pass
         LAUNCH_CHECK();
         bool again = false;
         if ((h.fail & 2u) && !large) { large = true; again = true; }

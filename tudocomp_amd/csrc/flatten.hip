@@ -70,18 +70,34 @@ size_t extract_factors(Ctx& c, size_t n, FactorSpace fs, u32* pos, u32* src, u32
 constexpr int OW_T = 256, OW_PER = 16, OW_TILE = OW_T * OW_PER;
 __device__ __forceinline__ u32 ow_idx(u32 i) { return i + (i >> 4); }      // LDS slot of tile position i: a thread reads 16 consecutive positions
 
-__global__ __launch_bounds__(OW_T) void owner_count_kernel(const u32* __restrict__ flen, size_t n, u32* __restrict__ tilecnt) {
+__global__ __launch_bounds__(OW_T) void owner_count_kernel(const u32* __restrict__ flen, const u8* __restrict__ flen8, size_t n, u32* __restrict__ tilecnt) {
     __shared__ u32 sm[OW_T / 64];
     const size_t base = (size_t)blockIdx.x * OW_TILE;
     u32 cnt = 0;
+    if (flen8) {                                                // compact lengths: 16 positions per thread in one 16-byte load
+        const size_t p = base + (size_t)threadIdx.x * OW_PER;
+        if (p + OW_PER <= n) {
+            const uint4 v = *(const uint4*)(flen8 + p);
+            const u32 w4[4] = { v.x, v.y, v.z, v.w };
 #pragma unroll
-    for (int r = 0; r < OW_PER / 4; ++r) {
-        const size_t p = base + ((size_t)r * OW_T + threadIdx.x) * 4;
-        if (p + 4 <= n) {
-            const uint4 v = *(const uint4*)(flen + p);
-            cnt += (v.x != 0) + (v.y != 0) + (v.z != 0) + (v.w != 0);
+            for (int k = 0; k < 4; ++k) {                       // bytes that are not zero
+                const u32 w = w4[k];
+                const u32 nz = ((w & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | w;
+                cnt += (u32)__popc(nz & 0x80808080u);
+            }
         } else {
-            for (int k = 0; k < 4; ++k) if (p + k < n && flen[p + k] != 0) ++cnt;
+            for (int k = 0; k < OW_PER; ++k) if (p + k < n && flen8[p + k] != 0) ++cnt;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < OW_PER / 4; ++r) {
+            const size_t p = base + ((size_t)r * OW_T + threadIdx.x) * 4;
+            if (p + 4 <= n) {
+                const uint4 v = *(const uint4*)(flen + p);
+                cnt += (v.x != 0) + (v.y != 0) + (v.z != 0) + (v.w != 0);
+            } else {
+                for (int k = 0; k < 4; ++k) if (p + k < n && flen[p + k] != 0) ++cnt;
+            }
         }
     }
     cnt = wave_reduce_sum(cnt);
@@ -90,13 +106,26 @@ __global__ __launch_bounds__(OW_T) void owner_count_kernel(const u32* __restrict
     if (threadIdx.x == 0) { u32 t = 0; for (int i = 0; i < OW_T / 64; ++i) t += sm[i]; tilecnt[blockIdx.x] = t; }
 }
 
-__global__ __launch_bounds__(OW_T) void owner_build_kernel(const u32* __restrict__ flen, size_t n, const u32* __restrict__ tilebase,
+__global__ __launch_bounds__(OW_T) void owner_build_kernel(const u32* __restrict__ flen, const u8* __restrict__ flen8, size_t n, const u32* __restrict__ tilebase,
                                                            u32* __restrict__ pos, u32* __restrict__ owner, uint2* __restrict__ cross,
                                                            u8* __restrict__ cls, u32* __restrict__ lenl) {
     __shared__ u32 s[OW_TILE + OW_TILE / 16 + 16];
     __shared__ u32 sm[OW_T / 64 + 1], smx[OW_T / 64];
     const size_t base = (size_t)blockIdx.x * OW_TILE;
     const int lane = lane_id(), w = wave_id();
+    if (flen8) {                                                // compact lengths: a thread's 16 positions are one 16-byte load (255: flen[p])
+        const u32 i = threadIdx.x * OW_PER;
+        const size_t p = base + i;
+        u32 w4[4] = { 0, 0, 0, 0 };
+        if (p + OW_PER <= n) { const uint4 v = *(const uint4*)(flen8 + p); w4[0] = v.x; w4[1] = v.y; w4[2] = v.z; w4[3] = v.w; }
+        else for (int k = 0; k < OW_PER; ++k) if (p + k < n) w4[k >> 2] |= (u32)flen8[p + k] << (8 * (k & 3));
+#pragma unroll
+        for (int k = 0; k < OW_PER; ++k) {
+            u32 l = (w4[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+            if (l == 255u) l = flen[p + k];
+            s[ow_idx(i + k)] = l;
+        }
+    } else {
 #pragma unroll
     for (int r = 0; r < OW_PER / 4; ++r) {                      // coalesced loads into LDS
         const u32 i = ((u32)r * OW_T + threadIdx.x) * 4;
@@ -110,6 +139,7 @@ __global__ __launch_bounds__(OW_T) void owner_build_kernel(const u32* __restrict
         }
         const u32 q = ow_idx(i);                                // i is a multiple of 4: the four slots are consecutive
         s[q] = v.x; s[q + 1] = v.y; s[q + 2] = v.z; s[q + 3] = v.w;
+    }
     }
     __syncthreads();
     const u32 l0 = threadIdx.x * OW_PER;
@@ -189,14 +219,14 @@ void build_owner(Ctx& c, size_t n, FactorSpace& fs) {
     u32* pos = fs.fpos ? fs.fpos : c.arena.get<u32>(n);
     u32* d_total = c.arena.get<u32>(1);
     {
-        Ctx::ProfScope prof(c, K_EXTRACT, (u64)n * 4);
-        owner_count_kernel<<<tiles, OW_T, 0, c.stream>>>(fs.flen, n, tilecnt);
+        Ctx::ProfScope prof(c, K_EXTRACT, (u64)n * (fs.flen8 ? 1 : 4));
+        owner_count_kernel<<<tiles, OW_T, 0, c.stream>>>(fs.flen, fs.flen8, n, tilecnt);
         LAUNCH_CHECK();
     }
     exclusive_sum_u32(c, tilecnt, tilecnt, tiles, d_total);
     {
-        Ctx::ProfScope prof(c, K_EXTRACT, (u64)n * 8);
-        owner_build_kernel<<<tiles, OW_T, 0, c.stream>>>(fs.flen, n, tilecnt, pos, fs.owner, cross, fs.cls, fs.fpos ? fs.flenl : nullptr);
+        Ctx::ProfScope prof(c, K_EXTRACT, (u64)n * (fs.flen8 ? 6 : 9));
+        owner_build_kernel<<<tiles, OW_T, 0, c.stream>>>(fs.flen, fs.flen8, n, tilecnt, pos, fs.owner, cross, fs.cls, fs.fpos ? fs.flenl : nullptr);
         LAUNCH_CHECK();
         owner_cross_kernel<<<tiles, 256, 0, c.stream>>>(cross, n, fs.owner, fs.cls);
         fs.have_cls = fs.cls != nullptr;
@@ -205,6 +235,18 @@ void build_owner(Ctx& c, size_t n, FactorSpace& fs) {
     const size_t z = c.read(d_total);
     if (fs.fpos) { fs.nfact = z; fs.have_list = true; }
     c.arena.release(mark);
+}
+
+__global__ void expand_flen8_kernel(const u8* __restrict__ flen8, size_t n, u32* __restrict__ flen) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const u32 l = flen8[p];
+    if (l != 255u) flen[p] = l;                                 // (255: flen[p] already holds the length)
+}
+void expand_flen8(Ctx& c, size_t n, FactorSpace& fs) {
+    if (!fs.flen8) return;
+    if (n) { expand_flen8_kernel<<<cdiv(n, 256), 256, 0, c.stream>>>(fs.flen8, n, fs.flen); LAUNCH_CHECK(); }
+    fs.flen8 = nullptr;
 }
 
 __global__ void fspace_clear_kernel(size_t n, u32* __restrict__ flen, u32* __restrict__ owner) {

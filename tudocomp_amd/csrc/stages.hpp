@@ -49,6 +49,11 @@ void build_lcp(Ctx& c, const u32* sa, const u32* plcp, size_t n, u32* lcp);
 //   fsrc[p]  : source of the factor starting at p (valid where flen[p] > 0 and owner[p] == p)
 struct FactorSpace {
     u32* flen = nullptr;
+    // optional (round 5, the metric's path): the factor lengths as BYTES until build_owner() has turned them into the list -- flen8[p] = length
+    // of the factor that starts at p (255: the length is flen[p]), 0 elsewhere.  Only flen8 is zero-filled then (2 instead of 8 bytes of
+    // traffic per position for the fill and for either pass of build_owner); flen[] is valid at the starts of factors of 255 and more
+    // positions only, until expand_flen8() fills it for a caller that wants the dense array after all.
+    u8* flen8 = nullptr;
     u32* owner = nullptr;
     u32* fsrc = nullptr;
     // optional: the factor starts in position order (n entries of capacity).  build_owner() fills it and sets
@@ -85,6 +90,8 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
 
 // owner[] from the factor starts (flen[p] != 0 exactly at factor starts): owner[q] = start of the factor covering q, else NONE32
 void build_owner(Ctx& c, size_t n, FactorSpace& fs);
+// compact lengths (fs.flen8) -> the dense flen[] array; fs.flen8 is cleared
+void expand_flen8(Ctx& c, size_t n, FactorSpace& fs);
 
 // lcpcomp(comp=plcppeaks): lcpcomp::PLCPPeaksStrategy (compressors/lcpcomp/compress/PLCPPeaksStrategy.hpp:36-80); fills fs
 // (flen, fsrc, owner, factor list) like factorize_arrays
