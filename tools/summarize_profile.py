@@ -39,7 +39,7 @@ with open(os.path.join(dst, prefix + "_pmc_fetch_write.csv"), "w") as f:
 # per step come from the bench line, the number of steps of the PMC run from the window kernel (one launch per step).
 import re
 CLASS_PATTERNS = {
-    "window_levels_kernel": [r"window_levels_kernel"],
+    "window_levels_kernel": [r"window_levels_kernel", r"window_eager_kernel"],
     "rs_scatter_kernel<u64>": [r"ws_scatter_kernel", r"rs_scatter\w*<unsigned long", r"ss_scatter\w*"],
     "rs_scatter_kernel<u32>": [r"fs_scatter_kernel", r"rs_scatter\w*<unsigned int", r"msd_scatter\w*"],
     "rs_count_kernel": [r"ws_count_kernel", r"fs_count_kernel", r"rs_count_kernel", r"ss_count\w*", r"msd_count\w*"],
@@ -57,7 +57,7 @@ CLASS_PATTERNS = {
     "extract_kernels": [r"owner_\w+_kernel"],
     "cand_kernels": [r"cand_\w+_kernel"],
     "scan_kernels": [r"scan_reduce_kernel", r"scan_apply_kernel", r"rs_col\w+", r"ss_blocksum_kernel", r"ss_apply_kernel", r"ss_segbase_kernel"],
-    "small_level_kernel": [r"small_level_kernel"],
+    "small_level_kernel": [r"small_level_kernel", r"eager_levels_kernel"],
 }
 
 
@@ -70,7 +70,7 @@ def class_bytes(cls):
 
 
 dom = bench["roofline"]["kernel"]
-steps = max([v[0] for k, v in fetch.items() if "window_levels_kernel" in k] + [0])
+steps = max([v[0] for k, v in fetch.items() if "window_levels_kernel" in k or "window_eager_kernel" in k] + [0])
 if steps and fetch and write:
     kernels = {}
     for cls, info in bench.get("kernels", {}).items():

@@ -144,13 +144,31 @@ __device__ __forceinline__ void ws_key_roll(const WKeyGen& g, u64& a, u64& b, u3
         a = (u64)(k >> 64); b = (u64)k;
     }
 }
-// key of text position p straight from global memory (samples, unit borders)
+// key of text position p straight from global memory (samples, unit borders).  The s <= 64 bytes are fetched as 8-byte words (round
+// 5: one byte load per symbol made the sample kernel re-fetch its line for every symbol -- 24 GB of HBM reads per step for 16 M
+// samples of 25 symbols, with a hundred thousand of them in flight the lines did not survive in L2 between two loads of a thread).
 template <int KW>
 __device__ __forceinline__ void ws_key_global(const WKeyGen& g, const u8* __restrict__ code, size_t p, u64& a, u64& b) {
     unsigned __int128 k = 0;
-    for (int t = 0; t < g.s; ++t) {
-        const size_t q = p + t;
-        k = (k << g.b) | ((q < g.n) ? (u32)code[g.text[q]] : 0u);
+    const int nw = (g.s + 7) >> 3;
+    u64 w[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        w[i] = 0;
+        if (i < nw) {
+            const size_t q = p + (size_t)i * 8;
+            if (q + 8 <= g.n) __builtin_memcpy(&w[i], g.text + q, 8);
+            else for (int t = 0; t < 8; ++t) if (q + t < g.n) w[i] |= (u64)g.text[q + t] << (8 * t);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (i < nw) {
+            for (int t = 0; t < 8 && i * 8 + t < g.s; ++t) {
+                const size_t q = p + (size_t)(i * 8 + t);
+                k = (k << g.b) | ((q < g.n) ? (u32)code[(w[i] >> (8 * t)) & 0xFFu] : 0u);
+            }
+        }
     }
     if (KW == 1) { a = (u64)k << g.pad; b = 0; }
     else { k <<= g.pad; a = (u64)(k >> 64); b = (u64)k; }
@@ -1114,11 +1132,21 @@ __global__ __launch_bounds__(256) void ws_fix_kernel(const u32* __restrict__ lea
     flags[s] = 1;
     if (s == 0) { lcp[0] = 0; return; }
     const size_t pa = v[s - 1], pb = v[s];
+    // (eight text bytes per step: distinct bytes have distinct codes, so the first differing byte is the first differing symbol; a
+    //  suffix that ends inside the key reads as code 0 from there on, like the keys the sort compared)
     u32 t = 0;
     while (t < (u32)g.s) {
-        const u32 ca = (pa + t < g.n) ? code[g.text[pa + t]] : 0u, cb = (pb + t < g.n) ? code[g.text[pb + t]] : 0u;
-        if (ca != cb) break;
-        ++t;
+        u64 wa = 0, wb = 0;
+        if (pa + t + 8 <= g.n) __builtin_memcpy(&wa, g.text + pa + t, 8);
+        else for (int e = 0; e < 8; ++e) if (pa + t + e < g.n) wa |= (u64)g.text[pa + t + e] << (8 * e);
+        if (pb + t + 8 <= g.n) __builtin_memcpy(&wb, g.text + pb + t, 8);
+        else for (int e = 0; e < 8; ++e) if (pb + t + e < g.n) wb |= (u64)g.text[pb + t + e] << (8 * e);
+        bool stop = false;
+        for (int e = 0; e < 8 && t < (u32)g.s; ++e, ++t) {
+            const u32 ca = (pa + t < g.n) ? code[(wa >> (8 * e)) & 0xFFu] : 0u, cb = (pb + t < g.n) ? code[(wb >> (8 * e)) & 0xFFu] : 0u;
+            if (ca != cb) { stop = true; break; }
+        }
+        if (stop) break;
     }
     lcp[s] = (u8)t;
 }
