@@ -53,4 +53,5 @@ with T.Context(0) as ctx:
             print("MISMATCH kind %d n %d thr %d flatten %d (window_pass %d, levels %d)" % (kind, len(text), thr, fl, st["window_pass"], st["levels"]))
             sys.exit(1)
         cases += 1
+        if cases % 200 == 0: print("... %d texts, %.0f s" % (cases, time.time() - t0), flush=True)
 print("stress ok: %d texts in %.0f s, all streams equal to the oracle's" % (cases, time.time() - t0))
