@@ -604,8 +604,21 @@ __device__ __forceinline__ u32 wl_run_end(const u64* hb, u32 s) {
 // with its predecessor; X and k2 in the same order where a later kernel (or the caller: PAIRS) reads them.  Units with runs left go
 // to `rlist` (ties on the whole of k1: to be ordered by k2) or `tlist` (ties on a truncated word: to be ordered by the word itself
 // first); the counting kernel takes them from there.
+#ifndef TDC_WL_W58
+#define TDC_WL_W58 6
+#endif
+#ifndef TDC_WL_W44
+#define TDC_WL_W44 6
+#endif
+#ifndef TDC_WL_W4X
+#define TDC_WL_W4X 5
+#endif
+// (waves per SIMD the register budget is set for.  The kernel waits on LDS most of the time, so its throughput follows the number of
+//  resident workgroups: the 8-wave instances with up to 5 rows hold 53 KB of LDS -- three of them fit a CU if they stay within 80
+//  registers (two with the 128 of round 4: leaf stage 48.9 -> 45.4 ms); the 4-wave instances with up to 5 rows hold 27 KB)
+#define WL_WPE(R, W) ((W) == 8 && (R) <= 5 ? TDC_WL_W58 : ((W) == 4 && (R) <= 5 ? TDC_WL_W44 : ((W) == 4 && (R) <= 8 ? TDC_WL_W4X : 4)))
 template <int KW, int ROWS, int NW, bool PAIRS>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void ws_leaf_sort_kernel(WLeaf A, const u32* __restrict__ list, u32 count, WLists Q, WEmit E) {
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WL_WPE(ROWS, NW), WL_WPE(ROWS, NW)))) void ws_leaf_sort_kernel(WLeaf A, const u32* __restrict__ list, u32 count, WLists Q, WEmit E) {
     constexpr u32 CAP = (u32)ROWS * NW * 64;
     constexpr bool FUSE = KW == 2 && CAP <= 2u * NW * 256u;   // the counting step below needs a word per slot in the counter tables
     __shared__ __align__(16) u32 wtab[2][NW][256];
