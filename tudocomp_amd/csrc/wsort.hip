@@ -1349,8 +1349,9 @@ int ws_sort_impl(Ctx& c, const WKeyGen* gen, u64* K1[2], u64* K2[2], u32* V[2], 
         const u32 grid = P.per_xcd ? 8 * P.per_xcd : rows;
         {
             const int pc = c.prof_begin(K_RS_COUNT, (u64)n * 8 * KW);
-            if (last) { if (P.F > 256) ws_count_kernel<KW, false, true, 1024><<<grid, 256, 0, s>>>(P, g, rows); else ws_count_kernel<KW, false, true, 256><<<grid, 256, 0, s>>>(P, g, rows); }
-            else { if (P.F > 256) ws_count_kernel<KW, false, false, 1024><<<grid, 256, 0, s>>>(P, g, rows); else ws_count_kernel<KW, false, false, 256><<<grid, 256, 0, s>>>(P, g, rows); }
+            // (the splitter search takes log2 FMAX steps whatever the fan-out: the 64-way levels get an instance of their own -- six steps instead of eight)
+            if (last) { if (P.F > 256) ws_count_kernel<KW, false, true, 1024><<<grid, 256, 0, s>>>(P, g, rows); else if (P.F > 64) ws_count_kernel<KW, false, true, 256><<<grid, 256, 0, s>>>(P, g, rows); else ws_count_kernel<KW, false, true, 64><<<grid, 256, 0, s>>>(P, g, rows); }
+            else { if (P.F > 256) ws_count_kernel<KW, false, false, 1024><<<grid, 256, 0, s>>>(P, g, rows); else if (P.F > 64) ws_count_kernel<KW, false, false, 256><<<grid, 256, 0, s>>>(P, g, rows); else ws_count_kernel<KW, false, false, 64><<<grid, 256, 0, s>>>(P, g, rows); }
             LAUNCH_CHECK();
             c.prof_end(pc);
         }
@@ -1397,8 +1398,8 @@ int ws_sort_impl(Ctx& c, const WKeyGen* gen, u64* K1[2], u64* K2[2], u32* V[2], 
             const int pc = c.prof_begin(K_RS_COUNT, (u64)n * (gl ? 1 : 8 * KW));
             if (gl && last) { if (P.F > 256) ws_count_kernel<KW, GEN, true, 1024><<<grid, 256, 0, s>>>(P, g, rows); else ws_count_kernel<KW, GEN, true, 256><<<grid, 256, 0, s>>>(P, g, rows); }
             else if (gl) { if (P.F > 256) ws_count_kernel<KW, GEN, false, 1024><<<grid, 256, 0, s>>>(P, g, rows); else ws_count_kernel<KW, GEN, false, 256><<<grid, 256, 0, s>>>(P, g, rows); }
-            else if (last) { if (P.F > 256) ws_count_kernel<KW, false, true, 1024><<<grid, 256, 0, s>>>(P, g, rows); else ws_count_kernel<KW, false, true, 256><<<grid, 256, 0, s>>>(P, g, rows); }
-            else { if (P.F > 256) ws_count_kernel<KW, false, false, 1024><<<grid, 256, 0, s>>>(P, g, rows); else ws_count_kernel<KW, false, false, 256><<<grid, 256, 0, s>>>(P, g, rows); }
+            else if (last) { if (P.F > 256) ws_count_kernel<KW, false, true, 1024><<<grid, 256, 0, s>>>(P, g, rows); else if (P.F > 64) ws_count_kernel<KW, false, true, 256><<<grid, 256, 0, s>>>(P, g, rows); else ws_count_kernel<KW, false, true, 64><<<grid, 256, 0, s>>>(P, g, rows); }
+            else { if (P.F > 256) ws_count_kernel<KW, false, false, 1024><<<grid, 256, 0, s>>>(P, g, rows); else if (P.F > 64) ws_count_kernel<KW, false, false, 256><<<grid, 256, 0, s>>>(P, g, rows); else ws_count_kernel<KW, false, false, 64><<<grid, 256, 0, s>>>(P, g, rows); }
             LAUNCH_CHECK();
             c.prof_end(pc);
         }
