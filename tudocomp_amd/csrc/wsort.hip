@@ -336,6 +336,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FMAX > 256 
     u32 ld[WS_ITEMS];                                       // digit << 16 | rank inside the digit's (wave's) run, later position in the sorted tile
     const u32 lbs = GEN ? (u32)(w * (64 * WS_ITEMS) + lane * WS_ITEMS) : (u32)(w * (64 * WS_ITEMS) + lane);
     const u32 estep = GEN ? 1u : 64u;                       // element e of item j: lbs + j * estep
+    // Round 5: on the carried levels the positions and the first key word of the thread's records are requested up front, the second key
+    // word while the first one is staged -- the staging phases then do not start with a round trip to HBM each (registers: 118 of the 128
+    // the occupancy of four workgroups per CU leaves).
+#ifndef TDC_WS_PRELOAD
+#define TDC_WS_PRELOAD 1
+#endif
+    constexpr bool PRE = TDC_WS_PRELOAD && !GEN;
+    u32 vpre[PRE ? WS_ITEMS : 1];
+    u64 k1pre[PRE ? WS_ITEMS : 1];
+    if constexpr (PRE) {
+#pragma unroll
+        for (int j = 0; j < WS_ITEMS; ++j) {
+            const bool in = lbs + (u32)j * 64 < cnt;
+            vpre[j] = in ? P.v_in[base + lbs + (u32)j * 64] : 0u;
+            k1pre[j] = in ? P.k1_in[base + lbs + (u32)j * 64] : 0ull;
+        }
+    }
     {
         u32 dg[WS_ITEMS];
         if (GEN) {
@@ -424,7 +441,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FMAX > 256 
         u32 pos = ld[j] & 0xFFFFu;
         if constexpr (MATCH) pos += (u32)wcnt[w][d]; else pos += tcnt[d];
         ld[j] = pos;
-        if (e < cnt) { stage32[pos] = GEN ? (u32)(P.gen_off + base + e) : P.v_in[base + e]; stage_d[pos] = (u16)d; }
+        if (e < cnt) { stage32[pos] = GEN ? (u32)(P.gen_off + base + e) : (PRE ? vpre[PRE ? j : 0] : P.v_in[base + e]); stage_d[pos] = (u16)d; }
     }
     __syncthreads();
 #pragma unroll
@@ -438,6 +455,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FMAX > 256 
     }
     __syncthreads();
     // key words, one stream at a time
+    u64 k2pre[(PRE && KW == 2) ? WS_ITEMS : 1];
 #pragma unroll
     for (int word = 0; word < KW; ++word) {
         if (GEN) {
@@ -449,12 +467,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FMAX > 256 
                 ws_key_roll<KW>(g, ka, kb, sy[lbs + j + g.s]);
             }
         } else {
-            const u64* kp = (word == 0 ? P.k1_in : P.k2_in) + base + lbs;
-            u64 kk[WS_ITEMS];
+            if constexpr (PRE) {
+                if (word == 0) {
+                    // (the second key word goes on its way before the first one is staged)
+                    if (KW == 2) {
 #pragma unroll
-            for (int j = 0; j < WS_ITEMS; ++j) kk[j] = (lbs + (u32)j * 64 < cnt) ? kp[j * 64] : 0ull;
+                        for (int j = 0; j < WS_ITEMS; ++j) k2pre[j] = (lbs + (u32)j * 64 < cnt) ? P.k2_in[base + lbs + (u32)j * 64] : 0ull;
+                    }
 #pragma unroll
-            for (int j = 0; j < WS_ITEMS; ++j) if (lbs + (u32)j * 64 < cnt) stage[ld[j]] = kk[j];
+                    for (int j = 0; j < WS_ITEMS; ++j) if (lbs + (u32)j * 64 < cnt) stage[ld[j]] = k1pre[PRE ? j : 0];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < WS_ITEMS; ++j) if (lbs + (u32)j * 64 < cnt) stage[ld[j]] = k2pre[(PRE && KW == 2) ? j : 0];
+                }
+            } else {
+                const u64* kp = (word == 0 ? P.k1_in : P.k2_in) + base + lbs;
+                u64 kk[WS_ITEMS];
+#pragma unroll
+                for (int j = 0; j < WS_ITEMS; ++j) kk[j] = (lbs + (u32)j * 64 < cnt) ? kp[j * 64] : 0ull;
+#pragma unroll
+                for (int j = 0; j < WS_ITEMS; ++j) if (lbs + (u32)j * 64 < cnt) stage[ld[j]] = kk[j];
+            }
         }
         __syncthreads();
         u64* outp = word == 0 ? P.k1_out : P.k2_out;
