@@ -17,17 +17,21 @@ from tests.util import load_json, decode_sequence_case
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def dev_ctx():
-    old = os.environ.get("TDC_GPU_DEC_PARSE")
-    os.environ["TDC_GPU_DEC_PARSE"] = "2"
+@pytest.fixture(scope="module", params=["lean", "general"])
+def dev_ctx(request):
+    """both markings of the device parse: the lean one (per-tile exits of the few possible entries; streams of short tokens -- the
+    default for them) and the general one (next() / exits of every bit position; TDC_GPU_DEC_LEAN=0 gives it every stream)"""
+    want = {"TDC_GPU_DEC_PARSE": "2", "TDC_GPU_DEC_LEAN": "1" if request.param == "lean" else "0"}
+    old = {k: os.environ.get(k) for k in want}
+    os.environ.update(want)
     try:
         ctx = T.Context(0)
     finally:
-        if old is None:
-            del os.environ["TDC_GPU_DEC_PARSE"]
-        else:
-            os.environ["TDC_GPU_DEC_PARSE"] = old
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
     yield ctx
     ctx.close()
 
@@ -103,10 +107,12 @@ def test_large_stream_takes_the_device_parse_by_default(gpu_ctx):
     assert back == dna and st["factors"] == cd["factors"]
 
 
-def test_streams_longer_than_one_segment(monkeypatch):
+@pytest.mark.parametrize("lean", ["1", "0"])
+def test_streams_longer_than_one_segment(monkeypatch, lean):
     """the chain marking runs in segments of bit positions (2^30 by default: streams above 128 MiB); with 20 000-bit segments a
     3 MB text takes hundreds of them -- the exit of one segment is the entry of the next"""
     monkeypatch.setenv("TDC_GPU_DEC_PARSE", "2")
+    monkeypatch.setenv("TDC_GPU_DEC_LEAN", lean)
     monkeypatch.setenv("TDC_GPU_DEC_SEG", "20000")
     with T.Context(0) as ctx:
         for name, data, thr in (("english", T.gen_english(3_000_000, 4).tobytes(), 2), ("dna", T.gen_dna(1_000_000, 7).tobytes(), 5),

@@ -378,6 +378,7 @@ int tdc_gpu_ctx_create(int device, tdc_gpu_ctx** out) {
         if (const char* m = getenv("TDC_GPU_WINDOW_LCUT")) { const int v = atoi(m); ctx->c.window_lcut = v < 0 ? 0 : (v > 63 ? 63 : v); }
         if (const char* m = getenv("TDC_GPU_WINDOW_HALO")) { const int v = atoi(m); ctx->c.window_halo = v < 0 ? 0 : (v > 2048 ? 2048 : v); }
         if (const char* m = getenv("TDC_GPU_DEC_SEG")) { const long v = atol(m); ctx->c.dec_seg = v < 4096 ? 4096 : (v > (1l << 30) ? (size_t)1 << 30 : (size_t)v); }
+        if (const char* m = getenv("TDC_GPU_DEC_LEAN")) ctx->c.dec_lean = atoi(m) != 0;
         if (const char* m = getenv("TDC_GPU_DEC_PARSE")) { const int v = atoi(m); ctx->c.dec_parse = v < 0 ? 0 : (v > 2 ? 2 : v); }
         if (const char* m = getenv("TDC_GPU_WINDOW_FORCE_FAIL")) ctx->c.window_force_fail = atoi(m) ? 1 : 0;
         if (const char* m = getenv("TDC_GPU_WINDOW_LARGE")) ctx->c.window_large_lists = atoi(m) ? 1 : 0;

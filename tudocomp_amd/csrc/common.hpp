@@ -152,6 +152,7 @@ struct Ctx {
     int window_halo = 384;         // window pass: halo of the first attempt (env TDC_GPU_WINDOW_HALO; a failed border retries with 2048)
     size_t dec_seg = 0;            // decompression: bit positions per segment of the chain marking (0: 2^30; env TDC_GPU_DEC_SEG, tests)
     bool phi_lazy = true;          // lcpcomp(comp=arrays) behind the fused scatter: no Phi array, a factor's source is SA[ISA[p] - 1] (env TDC_GPU_PHI_LAZY=0: Phi as before)
+    int dec_lean = 1;              // decompression, device parse: lean marking for streams of short tokens (env TDC_GPU_DEC_LEAN=0: the general marking for every stream; tests)
     int dec_parse = 1;             // decompression: token stream parsed on the device (env TDC_GPU_DEC_PARSE: 0 host parse, 1 streams >= 1 MiB, 2 always)
     int window_force_fail = 0;     // tests (env TDC_GPU_WINDOW_FORCE_FAIL=1): every window pass is reported as failed -> the global level loop takes the low levels
     int window_large_lists = 0;    // window pass: start with the large per-level lists (env TDC_GPU_WINDOW_LARGE=1; tests)

@@ -75,15 +75,64 @@ __global__ void ref_scatter_kernel(const u32* __restrict__ pos, const u32* __res
     for (u32 j = sub; j < l; j += G) ref[p + j] = s + j;
 }
 
-// one round of in-place pointer jumping; *changed != 0 if some reference moved
+// one round of in-place pointer jumping: a position follows its chain for up to HOPS references and stops early at a literal
+// position (ref == NONE32: final).  *changed != 0 only if some position used up its hops without seeing the literal -- a round in
+// which every chain ended needs no further round to confirm it.  (Concurrent updates of ref[] by other threads are benign: every
+// value a position can read lies on its own chain, closer to the literal.)
+#ifndef TDC_DEC_HOPS
+#define TDC_DEC_HOPS 16
+#endif
 __global__ __launch_bounds__(256) void ref_jump_kernel(u32* ref, size_t n, u32* __restrict__ changed) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     bool any = false;
     for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
         const u32 q = ref[p];
         if (q == NONE32) continue;
-        const u32 r = ref[q];
-        if (r != NONE32) { ref[p] = r; any = true; }
+        u32 r = ref[q];
+        if (r == NONE32) continue;                              // q is a literal position: final already
+        bool open = true;
+#pragma unroll
+        for (int k = 1; k < TDC_DEC_HOPS; ++k) {
+            const u32 r2 = ref[r];
+            if (r2 == NONE32) { open = false; break; }
+            r = r2;
+        }
+        ref[p] = r;
+        any = any || open;
+    }
+    if (__any(any) && lane_id() == 0) atomicOr(changed, 1u);
+}
+// The same with one "final" bit per position (a wave owns 64 consecutive positions = one word of done[], written without atomics):
+// positions that are final cost one broadcast word per wave in the later rounds instead of two loads each.
+__global__ __launch_bounds__(256) void ref_jump_done_kernel(u32* ref, size_t n, u64* done, u32* __restrict__ changed) {
+    const size_t nw = ((size_t)gridDim.x * blockDim.x) >> 6;
+    const int lane = lane_id();
+    bool any = false;
+    for (size_t b = (((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) << 6; b < n; b += nw << 6) {
+        const u64 d = done[b >> 6];
+        if (d == ~0ull) continue;
+        const size_t p = b + lane;
+        bool fin = ((d >> lane) & 1ull) != 0 || p >= n;
+        if (!fin) {
+            const u32 q = ref[p];
+            if (q == NONE32) fin = true;
+            else {
+                u32 r = ref[q];
+                if (r == NONE32) fin = true;
+                else {
+#pragma unroll
+                    for (int k = 1; k < TDC_DEC_HOPS; ++k) {
+                        const u32 r2 = ref[r];
+                        if (r2 == NONE32) { fin = true; break; }
+                        r = r2;
+                    }
+                    ref[p] = r;
+                }
+            }
+        }
+        const u64 nd = __ballot(fin);
+        if (lane == 0 && nd != d) done[b >> 6] = nd;
+        any = any || !fin;
     }
     if (__any(any) && lane_id() == 0) atomicOr(changed, 1u);
 }
@@ -276,6 +325,151 @@ __global__ __launch_bounds__(256) void dec_emit_kernel(const u32* __restrict__ s
         if (st == 0) bad = bad || len == 0 || p + r + len > P.n || (u64)src + len > P.n;
         if (bad) { atomicOr(&sc->err, 2u); len = 0; }
         fpos[j] = (u32)(p + r); fsrc[j] = src; flen[j] = (st == 0) ? len : 0u;
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------
+// Lean marking for streams whose longest possible token is short (la <= DL_LA_MAX bits: literal runs of a few codes -- every
+// well-compressible text).  A token chain can only enter a tile of DL_T bit positions within the first la positions behind the
+// tile's start, so next() never leaves the workgroup that computes it: per tile only "where does the chain that enters at offset
+// o leave" is written (la 16-bit words instead of 2048 x (next, exit1, exit2, mark) = 13 bytes per bit position), a second level
+// composes DL_G tiles, one thread walks the groups, and the tokens are then decoded tile by tile from their entries -- counted,
+// scanned per tile, and emitted (literals and factor list) by a second walk.  Same results as the general path below
+// (dec_next_kernel + mark_orbit_u32 + token list + count / emit per token), which keeps the streams with longer tokens.
+// ------------------------------------------------------------------------------------------------------------
+constexpr u32 DL_T = 2048;                  // bit positions per tile
+constexpr u32 DL_G = 512;                   // tiles per group (2^20 bit positions)
+constexpr u32 DL_CH = 16384;                // bit positions per workgroup of the exit pass
+constexpr u32 DL_LA_MAX = 1024;             // longest token (bits) the lean path takes
+constexpr u16 DL_NONE = 0xFFFFu;
+
+__global__ __launch_bounds__(256) void dec_lean_exit_kernel(const u32* __restrict__ s32, u64 x_in, u32 m, ParseParams P, const DevTab* __restrict__ gT,
+                                                             u32 nwords, u32 LA, u16* __restrict__ exit1) {
+    extern __shared__ __attribute__((aligned(16))) u32 dyn[];
+    DevTab* T = (DevTab*)dyn;
+    u32* sw = dyn + sizeof(DevTab) / 4;
+    u16* nxl = (u16*)(sw + nwords);                            // next(x) - x of the workgroup's positions; 0: the chain ends at x
+    dec_tab_to_lds(gT, T);
+    const u32 i0 = blockIdx.x * DL_CH;
+    const u64 a0 = x_in + i0;
+    const u64 kb = a0 >> 5;
+    const u64 wmax = (P.total + 31) / 32 + 3;
+    for (u32 k = threadIdx.x; k < nwords; k += 256) sw[k] = (kb + k < wmax) ? __builtin_bswap32(s32[kb + k]) : 0u;
+    __syncthreads();
+    const BitWin bw{sw, kb, P.total};
+    auto nolit = [](u32, u8) {};
+    const u64 seg_end = x_in + m;
+    for (u32 i = threadIdx.x; i < DL_CH; i += 256) {
+        const u32 idx = i0 + i;
+        u32 d = 0;
+        if (idx < m) {
+            u64 nx; u32 r, src, len;
+            const int st = dec_token(bw, x_in + idx, P, T, nolit, nx, r, src, len);
+            if (st == 0 && nx < seg_end) d = (u32)(nx - (x_in + idx));          // (st == 0: nx > x; at most la <= DL_LA_MAX)
+        }
+        nxl[i] = (u16)d;
+    }
+    __syncthreads();
+    constexpr u32 TPW = DL_CH / DL_T;
+    for (u32 w = threadIdx.x; w < TPW * LA; w += 256) {
+        const u32 tt = w / LA, o = w - tt * LA;
+        const u32 tile = blockIdx.x * TPW + tt;
+        if ((u64)tile * DL_T >= m) continue;
+        const u32 tend = (tt + 1) * DL_T;
+        u32 e = tt * DL_T + o, res = DL_NONE;
+        for (u32 guard = 0; guard <= DL_T; ++guard) {
+            if (e >= tend) { res = e - tend; break; }
+            const u32 d = nxl[e];
+            if (!d) break;
+            e += d;
+        }
+        exit1[(size_t)tile * LA + o] = (u16)res;
+    }
+}
+__global__ void dec_lean_exit2_kernel(const u16* __restrict__ exit1, u32 ntiles, u32 ngroups, u32 LA, u16* __restrict__ exit2) {
+    const u32 w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= ngroups * LA) return;
+    const u32 g = w / LA, o = w - g * LA;
+    const u32 t1 = min((g + 1) * DL_G, ntiles);
+    u32 e = o;
+    for (u32 t = g * DL_G; t < t1 && e != DL_NONE; ++t) e = exit1[(size_t)t * LA + e];
+    exit2[w] = (u16)e;
+}
+__global__ void dec_lean_groups_kernel(const u16* __restrict__ exit2, u32 ngroups, u32 LA, u16* __restrict__ group_entry) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    u32 e = 0;                                                  // the segment's first token starts at its first bit position
+    for (u32 g = 0; g < ngroups; ++g) {
+        group_entry[g] = (u16)e;
+        if (e != DL_NONE) e = exit2[(size_t)g * LA + e];
+    }
+}
+__global__ void dec_lean_tiles_kernel(const u16* __restrict__ exit1, const u16* __restrict__ group_entry, u32 ntiles, u32 ngroups, u32 LA,
+                                      u16* __restrict__ tile_entry) {
+    const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ngroups) return;
+    const u32 t1 = min((g + 1) * DL_G, ntiles);
+    u32 e = group_entry[g];
+    for (u32 t = g * DL_G; t < t1; ++t) {
+        tile_entry[t] = (u16)e;
+        if (e != DL_NONE) e = exit1[(size_t)t * LA + e];
+    }
+}
+// the tokens of every tile, walked from the tile's entry: EMIT = false counts them (tokens, text positions they produce), EMIT = true
+// writes the literal bytes and the factor list (tok0 / out0: what the earlier segments hold; tbase_*: exclusive sums over the tiles)
+template <bool EMIT>
+__global__ __launch_bounds__(256) void dec_lean_walk_kernel(const u32* __restrict__ s32, u64 x_in, u32 m, ParseParams P, const DevTab* __restrict__ gT,
+                                                             const u16* __restrict__ tile_entry, u32 ntiles, u32* __restrict__ tcount, u32* __restrict__ tout,
+                                                             u64 tok0, u64 out0, u8* __restrict__ text, u32* __restrict__ fpos, u32* __restrict__ fsrc,
+                                                             u32* __restrict__ flen, DecScalars* __restrict__ sc) {
+    __shared__ DevTab T;
+    dec_tab_to_lds(gT, &T);
+    __syncthreads();
+    const BitWinG bw{s32, P.total};
+    const u64 seg_end = x_in + m;
+    u64 acc = 0;
+    for (u32 t = blockIdx.x * 256 + threadIdx.x; t < ntiles; t += gridDim.x * 256) {
+        const u32 e = tile_entry[t];
+        u32 cnt = 0;
+        u64 out = 0;
+        if (e != DL_NONE) {
+            u64 x = x_in + (u64)t * DL_T + e;
+            const u64 tile_end = min(x_in + (u64)(t + 1) * DL_T, seg_end);
+            u64 j = EMIT ? tok0 + tcount[t] : 0;
+            u64 p = EMIT ? out0 + tout[t] : 0;
+            for (u32 guard = 0; x < tile_end && guard <= DL_T; ++guard) {
+                u64 nx; u32 r, src, len;
+                int st;
+                if (EMIT) {
+                    u8* dst = text + (p < P.n ? p : P.n);
+                    const u64 room = p < P.n ? P.n - p : 0;
+                    st = dec_token(bw, x, P, &T, [&](u32 i, u8 b) { if (i < room) dst[i] = b; }, nx, r, src, len);
+                    bool bad = st < 0 || p + r > P.n;
+                    if (st == 0) bad = bad || len == 0 || p + r + len > P.n || (u64)src + len > P.n;
+                    if (bad) { atomicOr(&sc->err, 2u); len = 0; }
+                    fpos[j] = (u32)(p + r); fsrc[j] = src; flen[j] = (st == 0) ? len : 0u;
+                    ++j;
+                    p += (u64)r + len;
+                } else {
+                    auto nolit = [](u32, u8) {};
+                    st = dec_token(bw, x, P, &T, nolit, nx, r, src, len);
+                    const u64 produced = (st >= 0) ? (u64)r + (u64)len : 0ull;
+                    out += produced > P.n ? P.n + 1 : produced;
+                    if (st < 0 || (st == 0 && len == 0) || produced > P.n) atomicOr(&sc->err, 1u);
+                }
+                ++cnt;
+                if (st != 0 || nx >= seg_end || nx <= x) {         // the segment's last token
+                    if (!EMIT) { sc->exit_bit = nx; sc->exit_status = (u32)(st < 0 ? 2 : st); }
+                    break;
+                }
+                x = nx;
+            }
+        }
+        if (!EMIT) { tcount[t] = cnt; tout[t] = out > P.n ? (u32)P.n + 1u : (u32)out; acc += out; }
+    }
+    if (!EMIT) {
+        acc = wave_reduce_sum(acc);
+        if (lane_id() == 0 && acc) atomicAdd((unsigned long long*)&sc->total_out, (unsigned long long)acc);
     }
 }
 
@@ -523,10 +717,17 @@ static void resolve_and_download(Ctx& c, size_t n, u8* d_text, u32* d_ref, const
     LAUNCH_CHECK();
     tick("fill + reference scatter");
     unsigned g = cdiv(n, 256 * 8); if (g > 16384) g = 16384;
+    const bool use_done = !getenv("TDC_GPU_DEC_DONE") || atoi(getenv("TDC_GPU_DEC_DONE")) != 0;      // (A/B switch)
+    u64* d_done = nullptr;
+    if (use_done) {
+        d_done = c.arena.get<u64>(n / 64 + 1);
+        HIP_TRY(hipMemsetAsync(d_done, 0, (n / 64 + 1) * sizeof(u64), s));
+    }
     for (u32 round = 0;; ++round) {
         if (round > 40) throw StreamFormatError{"corrupt stream: reference cycle"};     // depth < 2^31
         HIP_TRY(hipMemsetAsync(d_changed, 0, sizeof(u32), s));
-        ref_jump_kernel<<<g, 256, 0, s>>>(d_ref, n, d_changed);
+        if (d_done) ref_jump_done_kernel<<<g, 256, 0, s>>>(d_ref, n, d_done, d_changed);
+        else ref_jump_kernel<<<g, 256, 0, s>>>(d_ref, n, d_changed);
         LAUNCH_CHECK();
         st->rounds = round + 1;
         if (c.read(d_changed) == 0) break;
@@ -570,7 +771,7 @@ static bool decode_lzss_huff_device(Ctx& c, const u8* stream, size_t len, const 
     if (out.into && n > out.cap) throw HipError{hipErrorOutOfMemory, "decode: the caller's buffer is too small for the text", (int)__LINE__};   // (known from the header: before any device work)
     // (the device parse needs ~17 bytes of arena per stream bit of a segment on top of 5 n + 28 zmax; the host parse needs 5 n + 12 z: if
     //  the device cannot provide the former, the host parse takes the stream instead of the call failing)
-    try { c.ensure_arena(len + 64 + n * 5 + zmax * 28 + seg * 17 + sizeof(DevTab) + ((size_t)16 << 20)); }
+    try { c.ensure_arena(len + 64 + n * 5 + n / 8 + zmax * 28 + seg * 17 + sizeof(DevTab) + ((size_t)16 << 20)); }
     catch (const HipError& e) { if (e.e != hipErrorOutOfMemory) throw; (void)hipGetLastError(); return false; }
     const size_t mark0 = c.arena.mark();
     u8* d_stream = c.arena.get<u8>(len + 64);
@@ -591,6 +792,73 @@ static bool decode_lzss_huff_device(Ctx& c, const u8* stream, size_t len, const 
         HIP_TRY(hipStreamSynchronize(s));                                               // (hb leaves scope)
     }
     const ParseParams P{ total, H.n, H.flen_min, H.W, H.lbits, H.dbits, (u32)H.fdist_max };
+    if (la_bits <= DL_LA_MAX && c.dec_lean) {
+        // ---- lean marking (short tokens): per segment exits per tile entry -> groups -> tile entries -> count walk -> scans -> emit walk
+        const u32 LA = (u32)la_bits;
+        u32* d_pos = c.arena.get<u32>(zmax), *d_src = c.arena.get<u32>(zmax), *d_len = c.arena.get<u32>(zmax);
+        DecScalars* d_sc = (DecScalars*)c.arena.alloc(sizeof(DecScalars));
+        u32* d_cnt = c.arena.get<u32>(2);
+        u8* d_text = c.arena.get<u8>(n + 64);
+        u32* d_ref = c.arena.get<u32>(n);
+        HIP_TRY(hipMemsetAsync(d_sc, 0, sizeof(DecScalars), s));
+        HIP_TRY(hipMemsetAsync(d_text, 0, n, s));
+        const u32 nw_l = (u32)((DL_CH + la_bits + 31) / 32 + 4);
+        const size_t lds_l = sizeof(DevTab) + (size_t)nw_l * 4 + (size_t)DL_CH * 2;
+        size_t z = 0;
+        u64 x_in = x0, out0 = 0;
+        u32 last_status = 0;
+        while (x_in < total) {
+            const u32 m = (u32)std::min<u64>(seg_bits, total - x_in);
+            const u32 ntiles = cdiv(m, DL_T), ngroups = cdiv(ntiles, DL_G);
+            const size_t mk = c.arena.mark();
+            u16* exit1 = c.arena.get<u16>((size_t)ntiles * LA);
+            u16* exit2 = c.arena.get<u16>((size_t)ngroups * LA);
+            u16* gentry = c.arena.get<u16>(ngroups);
+            u16* tentry = c.arena.get<u16>(ntiles);
+            u32* tcount = c.arena.get<u32>(ntiles), *tout = c.arena.get<u32>(ntiles);
+            tick("upload + tables");
+            dec_lean_exit_kernel<<<cdiv(m, DL_CH), 256, lds_l, s>>>(s32, x_in, m, P, d_tab, nw_l, LA, exit1);
+            LAUNCH_CHECK();
+            tick("next() + tile exits");
+            dec_lean_exit2_kernel<<<cdiv((size_t)ngroups * LA, 256), 256, 0, s>>>(exit1, ntiles, ngroups, LA, exit2);
+            LAUNCH_CHECK();
+            dec_lean_groups_kernel<<<1, 64, 0, s>>>(exit2, ngroups, LA, gentry);
+            LAUNCH_CHECK();
+            dec_lean_tiles_kernel<<<cdiv(ngroups, 64), 64, 0, s>>>(exit1, gentry, ntiles, ngroups, LA, tentry);
+            LAUNCH_CHECK();
+            tick("group + tile entries");
+            const unsigned gw = std::min<u32>(cdiv(ntiles, 256), 4096u);
+            dec_lean_walk_kernel<false><<<gw, 256, 0, s>>>(s32, x_in, m, P, d_tab, tentry, ntiles, tcount, tout, 0, 0, nullptr, nullptr, nullptr, nullptr, d_sc);
+            LAUNCH_CHECK();
+            exclusive_sum_u32(c, tcount, tcount, ntiles, d_cnt);
+            const u32 cnt = c.read(d_cnt);
+            exclusive_sum_u32(c, tout, tout, ntiles, d_cnt);
+            const DecScalars h = c.read(d_sc);
+            tick("count walk + scans");
+            if (cnt == 0 || z + cnt > zmax) throw StreamFormatError{"corrupt stream: token chain"};
+            if (h.err || h.exit_status == 2) throw StreamFormatError{"corrupt stream: malformed token"};
+            if (h.total_out > H.n) throw StreamFormatError{"corrupt stream: length mismatch"};   // (64-bit total over all segments so far: no 32-bit sum below it can have wrapped)
+            dec_lean_walk_kernel<true><<<gw, 256, 0, s>>>(s32, x_in, m, P, d_tab, tentry, ntiles, tcount, tout, (u64)z, out0, d_text, d_pos, d_src, d_len, d_sc);
+            LAUNCH_CHECK();
+            tick("emit walk");
+            c.arena.release(mk);
+            z += cnt;
+            out0 = h.total_out;
+            last_status = h.exit_status;
+            if (h.exit_status == 1 || h.exit_bit >= total) break;
+            if (h.exit_bit <= x_in) throw StreamFormatError{"corrupt stream: token chain"};
+            x_in = h.exit_bit;
+        }
+        if (out0 != H.n) throw StreamFormatError{"corrupt stream: length mismatch"};
+        const DecScalars h = c.read(d_sc);
+        if (h.err) throw StreamFormatError{"corrupt stream: factor out of range"};
+        st->factors = z ? z - 1 : 0;
+        if (z && last_status == 0) st->factors = z;
+        resolve_and_download(c, n, d_text, d_ref, d_pos, d_src, d_len, z, d_cnt, out, st);
+        tick("references + download");
+        c.arena.release(mark0);
+        return true;
+    }
     u64* tokx = c.arena.get<u64>(zmax);
     u32* outc = c.arena.get<u32>(zmax + 1);
     u32* d_pos = c.arena.get<u32>(zmax), *d_src = c.arena.get<u32>(zmax), *d_len = c.arena.get<u32>(zmax);
@@ -682,7 +950,7 @@ size_t decode_lzss(Ctx& c, const u8* stream, size_t len, int coder, DecodeOut& o
         return (size_t)n;
     }
     hipStream_t s = c.stream;
-    c.ensure_arena((size_t)n * 5 + z * 12 + ((size_t)16 << 20));
+    c.ensure_arena((size_t)n * 5 + (size_t)n / 8 + z * 12 + ((size_t)16 << 20));
     const size_t mark = c.arena.mark();
     u8* d_text = c.arena.get<u8>((size_t)n);
     u32* d_ref = c.arena.get<u32>((size_t)n);
