@@ -225,6 +225,7 @@ struct Ctx {
         if (arena.size >= bytes) { arena.top = 0; return; }
         if (arena.base) { HIP_TRY(hipFree(arena.base)); arena.base = nullptr; arena.size = 0; }
         HIP_TRY(hipMalloc((void**)&arena.base, bytes));
+        if (getenv("TDC_GPU_ARENA_LOG")) fprintf(stderr, "arena: %zu bytes at %p\n", bytes, (void*)arena.base);
         arena.size = bytes;
         arena.top = 0;
     }
