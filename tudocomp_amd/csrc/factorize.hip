@@ -309,8 +309,8 @@ template <int NT, bool SLIM = false>
 __global__ __launch_bounds__(NT) void small_level_kernel(const u32* __restrict__ orig, u32 m0_arg, const u32* __restrict__ pushed, u32 m_raw_arg,
                                                            const u32* __restrict__ pool_all, const GatherSeg* __restrict__ gtab, u32 gn,
                                                            u32 L, u32 threshold, size_t n, u32* cur, u32* prio,
-                                                           const u32* __restrict__ phi, u32* __restrict__ flen, u8* __restrict__ res8,
-                                                           u32* __restrict__ fsrc, u32 pool_top_arg, u32 prio_base_arg,
+                                                           const u32* phi, u32* __restrict__ flen, u8* __restrict__ res8,
+                                                           u32* fsrc, u32 pool_top_arg, u32 prio_base_arg,      // (phi may BE fsrc -- no Phi array: fsrc[p] = phi[p] -- so neither is restrict)
                                                            PushSeg* __restrict__ segs, u32 seg_cap, u32* __restrict__ sel_list,
                                                            u32 inline_budget, LevelScalars* __restrict__ sc,
                                                            u32* zc_dst, u32* zc_flag, u32 zc_seq, unsigned long long* prof, u32* zc_segs,
@@ -905,8 +905,8 @@ __global__ __launch_bounds__(1024) void level_purge_kernel(u32* __restrict__ can
 
 // apply for a list of selected positions whose length is only known on the device (one wave per factor)
 __global__ __launch_bounds__(256) void apply_list_kernel(const u32* __restrict__ list, const u32* __restrict__ d_count, u32 L, size_t n,
-                                                          const u32* __restrict__ phi, u32* __restrict__ cur, u32* __restrict__ flen,
-                                                          u32* __restrict__ fsrc, u8* __restrict__ res8, u8* __restrict__ flen8) {
+                                                          const u32* phi, u32* __restrict__ cur, u32* __restrict__ flen,
+                                                          u32* fsrc, u8* __restrict__ res8, u8* __restrict__ flen8) {      // (phi may be fsrc)
     const u32 i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const u32 lane = threadIdx.x & 63;
     if (i >= *d_count) return;
@@ -1026,8 +1026,8 @@ __global__ void push_finalize_kernel(const u64* __restrict__ keys, const u32* __
 // Emit the selected entries: factor (p, Phi[p], L); kill the covered positions, truncate the ones in front.
 template <int G>
 __global__ __launch_bounds__(256) void apply_kernel(const u32* __restrict__ live, u32 nl, u32 L, size_t n, u64* bm,
-                                                     const u32* __restrict__ phi, u32* __restrict__ cur, u32* __restrict__ flen,
-                                                     u32* __restrict__ fsrc, LevelScalars* __restrict__ sc, u8* __restrict__ res8, u8* __restrict__ flen8) {
+                                                     const u32* phi, u32* __restrict__ cur, u32* __restrict__ flen,
+                                                     u32* fsrc, LevelScalars* __restrict__ sc, u8* __restrict__ res8, u8* __restrict__ flen8) {      // (phi may be fsrc)
     const u32 i = (blockIdx.x * blockDim.x + threadIdx.x) / G;
     const u32 sub = (G == 1) ? 0u : (threadIdx.x & (G - 1));
     bool sel = false;
