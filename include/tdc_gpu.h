@@ -228,7 +228,8 @@ int tdc_gpu_lcpcomp_decompress_coder(tdc_gpu_ctx* ctx, const uint8_t* stream, si
 int tdc_gpu_lcpcomp_decompress_into(tdc_gpu_ctx* ctx, const uint8_t* stream, size_t len, int coder, uint8_t* out, size_t out_cap,
                                     size_t* out_len, uint64_t* factors, uint32_t* rounds);
 /* 1 if the last tdc_gpu_lcpcomp_decompress / _decompress_coder / _decompress_into call on this context succeeded and parsed the token stream on the device (coder=huff streams
- * of 1 MiB and more whose longest literal run is at most 512; env TDC_GPU_DEC_PARSE = 0 never / 2 every size), 0 if on the host. */
+ * of 1 MiB and more whose longest literal run is at most 512; env TDC_GPU_DEC_PARSE = 0 never / 2 every size; TDC_GPU_DEC_LEAN = 0: the
+ * general marking also for streams of short tokens -- tests), 0 if on the host. */
 int tdc_gpu_ctx_last_decode_on_device(const tdc_gpu_ctx* ctx);
 
 /* HuffmanCoder::Encoder + lzss::encode_text on a caller-supplied factor list sorted by pos (LZSSCoding.hpp:18-92) */
