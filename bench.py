@@ -11,7 +11,8 @@ host memory.  Both transfers are INSIDE the timed region; `value` = input bytes 
           same calls), "configs1_256MiB" = BASELINE.json configs[1] (256 MiB) through the same entry point,
           "configs2_dna_1e9" = BASELINE.json configs[2] (10^9 B DNA, LCPCompressor + ArithmeticCoder, threshold 5) through
           the same entry point, its stream checked against the CPU oracle on a 32 MiB DNA sample,
-          "configs3_lz78" = BASELINE.json configs[3] on a 32 MiB sample (host-bound: the LZ78 parse runs on the host).
+          "configs3_lz78" = BASELINE.json configs[3] on a 32 MiB sample (host-bound: the LZ78 parse runs on the host),
+          "decompress" = SURVEY 8f #2: the stream of the timed steps back to the text (device parse + references), compared with the input.
           "stream_matches_golden" (headline and extras): size + SHA-256 of the device stream against the ORACLE's stream of the
           same full-size text (tests/golden/oracle_fullsize.json).
   N > 1 : BASELINE.json configs[4]: one process per GPU (torch.distributed, backend nccl = RCCL); every rank compresses
@@ -537,6 +538,22 @@ def main():
             gpu_prefix, _ = ctx.lcpcomp_compress(sample, args.threshold, 1)
             cpu_res["bit_exact_vs_gpu_on_sample"] = bool(len(gpu_prefix) == want_len and hashlib.sha256(gpu_prefix).hexdigest() == want_sha)
             line["cpu_baseline"] = cpu_res
+        if world == 1 and not args.no_extra:
+            # the stream of the timed steps back to the text (tdc_gpu_lcpcomp_decompress_into, stream and text in pinned host
+            # memory: H2D of the stream, device parse, references, D2H of the text); the result is compared with the input text
+            h_stream = T.PinnedBuffer(out_len)
+            h_stream.a[:] = h_out.a[:out_len]
+            h_back = T.PinnedBuffer(n)
+            ts, nb, dst = [], 0, None
+            for i in range(4):
+                t1 = time.perf_counter()
+                nb, dst = ctx.lcpcomp_decompress_into(h_stream, h_back)
+                ts.append(time.perf_counter() - t1)
+            t = min(ts[1:])
+            line["decompress"] = {"value": round(N / 1e6 / t, 2), "unit": "MB/s of text", "ms": round(t * 1e3, 3), "device_parse": dst["device_parse"],
+                                  "rounds": dst["rounds"], "round_trip": bool(nb == n and np.array_equal(h_back.a[:n], h_text.a[:n])),
+                                  "note": "the stream of the timed steps through tdc_gpu_lcpcomp_decompress_into, best of 3 after 1 warm-up"}
+            h_stream.free(); h_back.free()
         if world == 1 and not args.no_extra and N > (1 << 28):
             m = 1 << 28
             h_text.a[m] = 0                               # the first 256 MiB of the generator's output ARE its 256 MiB text
