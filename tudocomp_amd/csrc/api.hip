@@ -402,6 +402,7 @@ int tdc_gpu_ctx_create(int device, tdc_gpu_ctx** out) {
         if (const char* m = getenv("TDC_GPU_MSD_PARTITION")) ctx->c.msd_partition = atoi(m) ? 1 : 0;
         if (const char* m = getenv("TDC_GPU_WSORT")) ctx->c.wsort = atoi(m) ? 1 : 0;
         if (const char* m = getenv("TDC_GPU_WSORT_MIN")) { const long v = atol(m); ctx->c.wsort_min = v < 4096 ? 4096 : (size_t)v; }
+        if (const char* m = getenv("TDC_GPU_WSORT_SYMS")) { const int v = atoi(m); ctx->c.wsort_syms = (v >= 4 && v <= 64) ? v : 0; }
         if (const char* m = getenv("TDC_GPU_WSORT_KW")) { const int v = atoi(m); ctx->c.wsort_kw = (v == 1 || v == 2) ? v : 0; }
         if (const char* m = getenv("TDC_GPU_WSORT_ROUNDS")) { const int v = atoi(m); ctx->c.wsort_rounds = v < 0 ? 0 : (v > 100 ? 100 : v); }
         if (const char* m = getenv("TDC_GPU_WSORT_SMALLRUN")) ctx->c.wsort_small = atoi(m) ? 1 : 0;

@@ -160,6 +160,7 @@ struct Ctx {
     int ssort_levels = 0;          // force the number of partition levels of the splitter sort (env TDC_GPU_SSORT_LEVELS = 1..3; tests)
     int wsort = 1;                 // suffix array: wide-key (bit-packed, 2 x 64 bits) initial sort + text rounds + fused ISA / Phi / PLCP scatter (env TDC_GPU_WSORT=0: round-2 path)
     size_t wsort_min = (size_t)1 << 20;   // smallest text that takes it (env TDC_GPU_WSORT_MIN, >= 4096; tests)
+    int wsort_syms = 0;            // cap on the symbols per key of the wide sort (env TDC_GPU_WSORT_SYMS; 0: as many as the key words hold) -- measurements only
     int wsort_kw = 0;              // key words: 0 = by alphabet (2 when a word holds fewer than 16 symbols), 1 | 2 forced (env TDC_GPU_WSORT_KW)
     int wsort_rounds = 24;         // most text rounds before the doubling fallback (env TDC_GPU_WSORT_ROUNDS; 0: straight to doubling)
     int wsort_cmax = 16;           // leaf sort: runs of tying records up to this length are ordered by counting, longer ones by the wave kernel (env TDC_GPU_WSORT_CMAX, 1 .. 64)

@@ -1258,6 +1258,7 @@ void wsort_make_keygen(const Ctx& c, const u8* text, size_t n, u32 sigma, const 
     KW = c.wsort_kw ? c.wsort_kw : (per_word < 16 ? 2 : 1);
     g.text = text; g.n = n; g.b = b;
     g.s = (64 * KW) / b; if (g.s > 64) g.s = 64;
+    if (c.wsort_syms > 0 && g.s > c.wsort_syms) g.s = c.wsort_syms;      // (measurements: what would a narrower record cost in ties?)
     g.pad = 64 * KW - g.s * b;
     g.inv = (65536u + (u32)b - 1) / (u32)b;
     memcpy(g.code, code, 256);
