@@ -279,7 +279,7 @@ void scatter_factors(Ctx& c, size_t n, const u32* pos, const u32* src, const u32
 // ------------------------------------------------------------------------------------------------------------
 constexpr u32 NOT_DONE = 0xFFFFFFFFu;
 
-struct FlattenScalars { u32 waiting; u32 num_flattened; u32 max_depth; u32 pad; };
+struct FlattenScalars { u32 waiting; u32 num_flattened; u32 max_depth; u32 pad; unsigned long long steps, waits; };
 
 // Everything a chain step needs about a factor lives in ONE 16-byte record, indexed by the factor's rank r in position order:
 //   rec[r] = { pos, len, original source, final source (NOT_DONE until known) }
@@ -343,6 +343,9 @@ __global__ __launch_bounds__(256) void flatten_round_kernel(const uint4* __restr
         }
     }
     act = valid;
+#ifdef TDC_FL_PROF
+    u32 psteps = 0, pwaits = 0;
+#endif
     for (u32 step = 0; step < max_steps && __any(act != 0); ++step) {   // a long chain continues in the next round, regrouped with its peers
         u32 rr[FL_K];
 #pragma unroll
@@ -353,6 +356,9 @@ __global__ __launch_bounds__(256) void flatten_round_kernel(const uint4* __restr
                 else rr[r] = owner[src[r]];
             }
         }
+#ifdef TDC_FL_PROF
+        psteps += (u32)__popc(act);
+#endif
         uint4 sr[FL_K];
 #pragma unroll
         for (int r = 0; r < FL_K; ++r) {
@@ -370,7 +376,11 @@ __global__ __launch_bounds__(256) void flatten_round_kernel(const uint4* __restr
             u32 ssrc;
             if (rr[r] < fi[r]) {                                            // earlier factor: needs its final source
                 ssrc = sr[r].w;
-                if (ssrc == NOT_DONE) { act &= ~(1u << r); continue; }      // wait for the next round
+                if (ssrc == NOT_DONE) { act &= ~(1u << r);
+#ifdef TDC_FL_PROF
+                    ++pwaits;
+#endif
+                    continue; }      // wait for the next round
             } else {
                 ssrc = sr[r].z;                                             // later factor: still unflattened at this point
             }
@@ -378,6 +388,10 @@ __global__ __launch_bounds__(256) void flatten_round_kernel(const uint4* __restr
             ++dep[r];
         }
     }
+#ifdef TDC_FL_PROF
+    { const u32 a = wave_reduce_sum(psteps), b = wave_reduce_sum(pwaits);
+      if (lane_id() == 0) { atomicAdd(&sc->steps, (unsigned long long)a); atomicAdd(&sc->waits, (unsigned long long)b); } }
+#endif
     u32 nflat = 0, mxdep = 0;
 #pragma unroll
     for (int r = 0; r < FL_K; ++r) {
@@ -464,7 +478,10 @@ void flatten_factors(Ctx& c, size_t n, FactorSpace fs, FlattenStats* st, const s
         if (between) between((int)st->rounds + 1);
         const u32 now = c.read(&d_sc->waiting);
         st->rounds++;
-        if (getenv("TDC_GPU_LEVEL_LOG")) fprintf(stderr, "flatten round %u: %u waiting -> %u\n", st->rounds, waiting, now);
+        if (getenv("TDC_GPU_LEVEL_LOG")) {
+            const FlattenScalars hs = c.read(d_sc);
+            fprintf(stderr, "flatten round %u: %u waiting -> %u (budget %u steps; cumulative: %llu visits, %llu of them waits)\n", st->rounds, waiting, now, max_steps, hs.steps, hs.waits);
+        }
         stalled = (now == waiting) ? stalled + 1 : 0;         // (a round with a small budget may finish nothing; never many in a row)
         if (now > waiting || (now == waiting && max_steps >= (1u << 30)) || stalled > 40)
             throw HipError{hipErrorUnknown, "flatten: rounds made no progress", (int)__LINE__};
