@@ -137,8 +137,8 @@ __global__ __launch_bounds__(256) void ref_jump_done_kernel(u32* ref, size_t n, 
     if (__any(any) && lane_id() == 0) atomicOr(changed, 1u);
 }
 
-__global__ void ref_copy_kernel(const u32* __restrict__ ref, size_t n, u8* text) {
-    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void ref_copy_kernel(const u32* __restrict__ ref, size_t a, size_t n, u8* text) {      // positions [a, n)
+    const size_t p = a + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     const u32 q = ref[p];
     if (q != NONE32) text[p] = text[q];          // q is a literal position: never written by this kernel
@@ -679,6 +679,14 @@ static u64 parse_lzss_ascii_stream(const u8* in, size_t in_len, std::vector<u8>&
     return n;
 }
 
+// page-locked host memory (hipHostMalloc / hipHostRegister)?  Asynchronous copies overlap with kernels only for such buffers; a copy
+// from or to pageable memory is staged by the runtime and holds the calling thread.
+static bool host_pinned(const void* p) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return at.type == hipMemoryTypeHost;
+}
+
 // where the decoded text goes: the caller's buffer, or a buffer allocated here (2 MiB aligned, transparent huge pages asked for: a
 // 256 MiB text otherwise pays 65 536 page faults in front of the download) that the caller releases with free()
 static u8* decode_dest(DecodeOut& o, size_t n) {
@@ -733,11 +741,30 @@ static void resolve_and_download(Ctx& c, size_t n, u8* d_text, u32* d_ref, const
         if (c.read(d_changed) == 0) break;
     }
     tick("pointer jumping");
-    ref_copy_kernel<<<cdiv(n, 256), 256, 0, s>>>(d_ref, n, d_text);
-    LAUNCH_CHECK();
-    tick("copy pass");
     u8* dst = decode_dest(out, n);
     tick("host buffer");
+    constexpr size_t CH = (size_t)64 << 20;
+    if (c.copy_stream && n >= 2 * CH && !dlog && host_pinned(dst)) {
+        // the copy pass in chunks, every chunk downloaded on the second stream while the next one is copied (a chunk reads literal
+        // positions only, wherever they are: the chunks do not depend on one another)
+        struct Drain { Ctx& c; ~Drain() { (void)hipStreamSynchronize(c.copy_stream); } } drain{c};   // nothing of this call stays behind on the second stream
+        u32 k = 0;
+        for (size_t a = 0; a < n; a += CH, ++k) {
+            const size_t b = std::min(n, a + CH);
+            ref_copy_kernel<<<cdiv(b - a, 256), 256, 0, s>>>(d_ref, a, b, d_text);
+            LAUNCH_CHECK();
+            hipEvent_t ev = c.ev_copy[k & 31];
+            HIP_TRY(hipEventRecord(ev, s));
+            HIP_TRY(hipStreamWaitEvent(c.copy_stream, ev, 0));
+            HIP_TRY(hipMemcpyAsync(dst + a, d_text + a, b - a, hipMemcpyDeviceToHost, c.copy_stream));
+        }
+        HIP_TRY(hipStreamSynchronize(c.copy_stream));
+        HIP_TRY(hipStreamSynchronize(s));
+        return;
+    }
+    ref_copy_kernel<<<cdiv(n, 256), 256, 0, s>>>(d_ref, 0, n, d_text);
+    LAUNCH_CHECK();
+    tick("copy pass");
     HIP_TRY(hipMemcpyAsync(dst, d_text, n, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     tick("download");
@@ -775,7 +802,31 @@ static bool decode_lzss_huff_device(Ctx& c, const u8* stream, size_t len, const 
     catch (const HipError& e) { if (e.e != hipErrorOutOfMemory) throw; (void)hipGetLastError(); return false; }
     const size_t mark0 = c.arena.mark();
     u8* d_stream = c.arena.get<u8>(len + 64);
-    HIP_TRY(hipMemcpyAsync(d_stream, stream, len, hipMemcpyHostToDevice, s));
+    // long streams go up in chunks on the second stream; a segment waits for the chunks its bit positions (and the longest token behind
+    // them) lie in, so the parse of segment k runs while segment k + 1 is still on its way
+    struct Upload {
+        Ctx& c; size_t chunk = 0, nchunks = 0, waited = 0;
+        explicit Upload(Ctx& cc) : c(cc) {}
+        ~Upload() { if (nchunks) (void)hipStreamSynchronize(c.copy_stream); }    // (the caller's buffer is not read after the call returns)
+        void need(size_t bytes, size_t len, hipStream_t s) {
+            if (!nchunks) return;
+            const size_t upto = std::min(nchunks, (std::min(bytes, len) + chunk - 1) / chunk);
+            for (; waited < upto; ++waited) HIP_TRY(hipStreamWaitEvent(s, c.ev_copy[waited], 0));
+        }
+    } up(c);
+    if (c.copy_stream && len >= ((size_t)64 << 20) && host_pinned(stream)) {
+        up.chunk = std::max((size_t)32 << 20, (len + 31) / 32);
+        up.chunk = (up.chunk + 4095) & ~(size_t)4095;
+        up.nchunks = (len + up.chunk - 1) / up.chunk;
+        for (size_t k = 0; k < up.nchunks; ++k) {
+            const size_t a = k * up.chunk, b = std::min(len, a + up.chunk);
+            HIP_TRY(hipMemcpyAsync(d_stream + a, stream + a, b - a, hipMemcpyHostToDevice, c.copy_stream));
+            HIP_TRY(hipEventRecord(c.ev_copy[k], c.copy_stream));
+        }
+        (void)hipStreamQuery(c.copy_stream);                                                 // (submit now)
+    } else {
+        HIP_TRY(hipMemcpyAsync(d_stream, stream, len, hipMemcpyHostToDevice, s));
+    }
     HIP_TRY(hipMemsetAsync(d_stream + len, 0, 64, s));
     const u32* s32 = (const u32*)d_stream;                                              // (arena allocations are 256-byte aligned)
     DevTab* d_tab = (DevTab*)c.arena.alloc(sizeof(DevTab));
@@ -816,6 +867,7 @@ static bool decode_lzss_huff_device(Ctx& c, const u8* stream, size_t len, const 
             u16* gentry = c.arena.get<u16>(ngroups);
             u16* tentry = c.arena.get<u16>(ntiles);
             u32* tcount = c.arena.get<u32>(ntiles), *tout = c.arena.get<u32>(ntiles);
+            up.need((size_t)((x_in + m + la_bits) / 8 + 64), len, s);
             tick("upload + tables");
             dec_lean_exit_kernel<<<cdiv(m, DL_CH), 256, lds_l, s>>>(s32, x_in, m, P, d_tab, nw_l, LA, exit1);
             LAUNCH_CHECK();
@@ -873,6 +925,7 @@ static bool decode_lzss_huff_device(Ctx& c, const u8* stream, size_t len, const 
         u32* next = c.arena.get<u32>(m);
         u32* e1 = c.arena.get<u32>(m), *e2 = c.arena.get<u32>(m);
         u8* mark = c.arena.get<u8>(m);
+        up.need((size_t)((x_in + m + la_bits) / 8 + 64), len, s);
         tick("upload + tables");
         dec_next_kernel<<<cdiv(m, DEC_TILE), 256, lds, s>>>(s32, x_in, m, P, d_tab, nwords, next);
         LAUNCH_CHECK();
