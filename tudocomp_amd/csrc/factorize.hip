@@ -1291,8 +1291,10 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
             unsigned long long tot = 0;
             for (size_t lv = 0; lv < nlev; ++lv) tot += dv[4 * lv + 2];
             unsigned long long acc = 0; u32 shown = 0;
+            const bool dump_all = getenv("TDC_GPU_EAGER_DUMP") != nullptr;          // (tools/eager_levels_log.py)
             for (size_t lv = nlev; lv-- > 0;) {
                 if (!dv[4 * lv + 2]) continue;
+                if (dump_all) { fprintf(stderr, "eager level %zu: entries %u factors %u cycles %u\n", lv, dv[4 * lv], dv[4 * lv + 1], dv[4 * lv + 2]); continue; }
                 acc += dv[4 * lv + 2];
                 if (dv[4 * lv + 2] > 400000u || (shown++ % 256) == 0) fprintf(stderr, "eager level %zu: %u entries of %u candidates, %u factors, %u cycles (running %.1f %% of %llu)\n", lv, dv[4 * lv], dv[4 * lv + 3], dv[4 * lv + 1], dv[4 * lv + 2], 100.0 * (double)acc / (double)(tot ? tot : 1), tot);
             }

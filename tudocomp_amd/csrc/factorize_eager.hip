@@ -55,7 +55,25 @@ __device__ __forceinline__ void lds_bitonic(T* a, u32 np2) {
     }
 }
 
+// the same for up to ENT elements by ranking: every thread counts the elements in front of its own (cnt broadcast reads) -- two
+// barriers instead of log^2: the levels of a repeat-rich text hold a handful of entries each, and forty barriers of sixteen waves
+// were most of a level's 12 microseconds.  tmp: as large as a; the sorted sequence is back in a[] on return.
+template <typename T>
+__device__ __forceinline__ void lds_ranksort(T* a, T* tmp, u32 cnt) {
+    const u32 i = threadIdx.x;
+    if (i < cnt) {
+        const T k = a[i];
+        u32 r = 0;
+        for (u32 j = 0; j < cnt; ++j) { const T kj = a[j]; r += (kj < k || (kj == k && j < i)) ? 1u : 0u; }
+        tmp[r] = k;
+    }
+    __syncthreads();
+    if (i < cnt) a[i] = tmp[i];
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(ENT) void eager_levels_kernel(EagerParams P) {
+    __shared__ u64 tmp64[ENT];                // rank sorts of up to ENT elements (keys: the first half as 32-bit words)
     __shared__ u32 key[E_CAP];                // position << 1 | truncated, sorted
     __shared__ u32 pri[E_CAP];
     __shared__ u8 st[E_CAP];
@@ -128,11 +146,14 @@ __global__ __launch_bounds__(ENT) void eager_levels_kernel(EagerParams P) {
             continue;
         }
         // ---- position order, duplicates out (an inserted position may also be a natural candidate: the natural copy sorts first) -------
-        u32 np2 = 1;
-        while (np2 < cnt) np2 <<= 1;
-        for (u32 i = cnt + tid; i < np2; i += ENT) key[i] = 0xFFFFFFFFu;
-        __syncthreads();
-        lds_bitonic(key, np2);
+        if (cnt <= (u32)ENT) lds_ranksort(key, (u32*)tmp64, cnt);
+        else {
+            u32 np2 = 1;
+            while (np2 < cnt) np2 <<= 1;
+            for (u32 i = cnt + tid; i < np2; i += ENT) key[i] = 0xFFFFFFFFu;
+            __syncthreads();
+            lds_bitonic(key, np2);
+        }
         for (u32 i = tid; i < cnt; i += ENT) {
             const u32 k = key[i];
             const bool dup = i > 0 && (key[i - 1] >> 1) == (k >> 1);
@@ -242,11 +263,14 @@ __global__ __launch_bounds__(ENT) void eager_levels_kernel(EagerParams P) {
         // ---- insertions: sorted by level, one thread per level appends its run to the level's newest block (or opens a new one) -------
         const u32 ni = s_nins;                                                   // (<= 2 ns <= E_INS)
         if (ni) {
-            u32 ip2 = 1;
-            while (ip2 < ni) ip2 <<= 1;
-            for (u32 i = ni + tid; i < ip2; i += ENT) ins[i] = ~0ull;
-            __syncthreads();
-            lds_bitonic(ins, ip2);
+            if (ni <= (u32)ENT) lds_ranksort(ins, tmp64, ni);
+            else {
+                u32 ip2 = 1;
+                while (ip2 < ni) ip2 <<= 1;
+                for (u32 i = ni + tid; i < ip2; i += ENT) ins[i] = ~0ull;
+                __syncthreads();
+                lds_bitonic(ins, ip2);
+            }
             for (u32 i = tid; i < ni; i += ENT) {
                 const u32 lv = (u32)(ins[i] >> 32);
                 if (i > 0 && (u32)(ins[i - 1] >> 32) == lv) continue;            // not the first of its run
