@@ -30,7 +30,10 @@ namespace tdc {
 
 namespace {
 
-constexpr int ENT = 1024;                 // threads of the one workgroup
+#ifndef TDC_EAGER_ENT
+#define TDC_EAGER_ENT 1024
+#endif
+constexpr int ENT = TDC_EAGER_ENT;        // threads of the one workgroup
 constexpr u32 E_CAP = 4096;               // alive entries of one level
 constexpr u32 E_SEL = 1024;               // selected factors of one level
 constexpr u32 E_INS = 2 * E_SEL;          // list insertions of one level
@@ -88,6 +91,12 @@ __global__ __launch_bounds__(ENT) void eager_levels_kernel(EagerParams P) {
     unsigned long long factors = 0;           // (thread 0 counts)
     u32 status = 0;
     unsigned long long t_lvl = P.dbg ? __builtin_readcyclecounter() : 0ull;
+#ifdef TDC_EAGER_PROF
+    unsigned long long ph[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, tp = __builtin_readcyclecounter();
+#define EPH(k) do { if (tid == 0) { const unsigned long long tn = __builtin_readcyclecounter(); ph[k] += tn - tp; tp = tn; } } while (0)
+#else
+#define EPH(k) do { } while (0)
+#endif
     for (;;) {
         if (L < P.L_stop || L == 0) break;
         const u32 t0 = P.tstart[L], m1 = P.tend[L] - t0;
@@ -96,8 +105,7 @@ __global__ __launch_bounds__(ENT) void eager_levels_kernel(EagerParams P) {
         if (tid == 0) { s_cnt = 0; s_nsel = 0; s_nins = 0; s_fail = 0; }
         __syncthreads();
         // ---- entries: the heads of this level that still hold the value L (key: position << 1 | truncated) ---------------------------
-        auto take = [&](u32 q) {
-            const u32 r = P.res8[q];
+        auto take = [&](u32 q, u32 r) {                                            // r = res8[q], requested together with cur[q]
             const bool natural = L < 255u ? r == L : r == 255u;                  // (res8_mark, factorize.hip)
             const u32 k = atomicAdd(&s_cnt, 1u);
             if (k < E_CAP) key[k] = (q << 1) | (natural ? 0u : 1u);
@@ -106,22 +114,24 @@ __global__ __launch_bounds__(ENT) void eager_levels_kernel(EagerParams P) {
             u32 q[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) { const u32 i = i0 + (u32)u * ENT + tid; q[u] = i < m1 ? P.tcand[t0 + i] : NONE32; }
-            u32 c[8];
+            u32 c[8], r8[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) c[u] = q[u] != NONE32 ? P.cur[q[u]] : 0u;
+            for (int u = 0; u < 8; ++u) { c[u] = q[u] != NONE32 ? P.cur[q[u]] : 0u; r8[u] = q[u] != NONE32 ? (u32)P.res8[q[u]] : 0u; }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) if (q[u] != NONE32 && c[u] == L) take(q[u]);
+            for (int u = 0; u < 8; ++u) if (q[u] != NONE32 && c[u] == L) take(q[u], r8[u]);
         }
         for (u32 guard = 0; hb != 0 && guard < P.blk_cap; ++guard) {          // blocks inserted since the phase started (newest first)
             const u32* b = P.blk + (size_t)(hb - 1) * E_BLK_WORDS;
             const u32 nx = b[0], bc = b[1];
+            const u32 qb = tid < E_BLK_POS ? b[2 + tid] : 0u;                     // (the block is one 64-byte line: link, count and positions in one round trip)
             if (tid < bc && tid < E_BLK_POS) {
-                const u32 q = b[2 + tid];
-                if (P.cur[q] == L) take(q);
+                const u32 cq = P.cur[qb], rq = (u32)P.res8[qb];
+                if (cq == L) take(qb, rq);
             }
             hb = nx;
         }
         __syncthreads();
+        EPH(0);
         const u32 cnt = s_cnt;
         if (cnt > E_CAP) { status = 2; break; }                                // (nothing of this level has been touched)
         if (cnt == 0) {
@@ -162,6 +172,7 @@ __global__ __launch_bounds__(ENT) void eager_levels_kernel(EagerParams P) {
         }
         if (tid == 0) { s_und[0] = cnt; s_und[1] = 0; }
         __syncthreads();
+        EPH(1);
         // ---- selection rounds: lexicographically-first maximal independent set (conflict: distance < L; natural before truncated,
         //      naturals by priority = ISA); an entry decides once every earlier entry within reach has ---------------------------------
         for (u32 round = 0; round <= cnt; ++round) {
@@ -198,6 +209,7 @@ __global__ __launch_bounds__(ENT) void eager_levels_kernel(EagerParams P) {
             if (st[i] == ES_SEL) { const u32 k = atomicAdd(&s_nsel, 1u); if (k < E_SEL) { sel[k] = key[i] >> 1; headq[k] = NONE32; } }
         __syncthreads();
         const u32 ns = s_nsel;
+        EPH(2);
         if (ns > E_SEL) { status = 4; break; }                                 // (still nothing touched: the host takes the level)
         // ---- cuts (:105-109): distances 1 .. L - 1 in front of every selected entry.  The positions a factor cuts form ONE contiguous run
         //      that ends right in front of it (see the header): a wave walks leftwards in steps of 64 positions and stops at the first
@@ -226,6 +238,7 @@ __global__ __launch_bounds__(ENT) void eager_levels_kernel(EagerParams P) {
             }
         }
         __syncthreads();
+        EPH(3);
         // ---- the entries that change lists: the head of the cut run, and the position behind the factor if it continues a run whose
         //      previous position the factor covers (right-head rule) -- read after all cuts, before the kills ---------------------------
         for (u32 s = tid; s < ns; s += ENT) {
@@ -242,6 +255,7 @@ __global__ __launch_bounds__(ENT) void eager_levels_kernel(EagerParams P) {
             }
         }
         __syncthreads();
+        EPH(4);
         // ---- kills (:99-101) and the factors (:91-96) ------------------------------------------------------------------------------------
         if ((u64)ns * L < (1ull << 30)) {
             const u32 tot = ns * L;
@@ -260,6 +274,7 @@ __global__ __launch_bounds__(ENT) void eager_levels_kernel(EagerParams P) {
             if (P.phi != P.fsrc) P.fsrc[p] = P.phi[p];
         }
         if (tid == 0) factors += ns;
+        EPH(5);
         // ---- insertions: sorted by level, one thread per level appends its run to the level's newest block (or opens a new one) -------
         const u32 ni = s_nins;                                                   // (<= 2 ns <= E_INS)
         if (ni) {
@@ -292,6 +307,7 @@ __global__ __launch_bounds__(ENT) void eager_levels_kernel(EagerParams P) {
             }
         }
         __syncthreads();
+        EPH(6);
         ++levels_done;
         if (P.dbg && tid == 0) {                                                 // (TDC_GPU_LEVEL_LOG: entries, factors, cycles of every level)
             const unsigned long long t1 = __builtin_readcyclecounter();
@@ -305,6 +321,9 @@ __global__ __launch_bounds__(ENT) void eager_levels_kernel(EagerParams P) {
         L = L - 1;
     }
     __syncthreads();
+#ifdef TDC_EAGER_PROF
+    if (P.dbg && tid == 0) for (int k = 0; k < 8; ++k) P.dbg[k] = (u32)(ph[k] >> 8);     // (phase totals in units of 256 cycles: words of the unused levels 0 and 1)
+#endif
     if (tid == 0) {
         P.ctl->level = L;                     // the next level to be processed (L_stop - 1: the phase is complete)
         P.ctl->status = status;
