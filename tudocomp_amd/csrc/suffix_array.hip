@@ -578,11 +578,18 @@ __global__ __launch_bounds__(256) void sa_flag_compact_kernel(const u8* __restri
     if (!cnt) return;
     if (blockIdx.x > 0) run = max(run, tile_lastscan[blockIdx.x - 1]);
     u32 o = tile_off[blockIdx.x] + pre;
+    const u32 want = valid & ~single;                                // the slots this thread lists
+    u32 vv[16];                                                     // their suffixes: all requested before the first store
+#pragma unroll
+    for (int q = 0; q < 16; ++q) vv[q] = ((want >> q) & 1u) ? v[i0 + q] : 0u;
+    const u32 hv = h & valid;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-        if (!((valid >> q) & 1u)) break;
-        if ((h >> q) & 1u) run = (u32)(i0 + q) + 1u;
-        if (!((single >> q) & 1u)) { o_sa[o] = v[i0 + q]; o_pos[o] = (u32)(i0 + q); o_r1[o] = run - 1u; ++o; }
+        if ((want >> q) & 1u) {
+            const u32 hq = hv & ((2u << q) - 1u);                    // heads at or in front of slot q inside the thread's range
+            const u32 r = hq ? (u32)(i0 + 31 - __builtin_clz(hq)) + 1u : run;
+            o_sa[o] = vv[q]; o_pos[o] = (u32)(i0 + q); o_r1[o] = r - 1u; ++o;
+        }
     }
 }
 
