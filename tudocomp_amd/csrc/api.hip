@@ -566,13 +566,15 @@ void compress_host(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, bool raw, ui
             HIP_TRY(hipEventRecord(c.ev_copy[8], c.stream));                   // (the copy stream starts behind whatever the compute stream did before)
             HIP_TRY(hipStreamWaitEvent(c.copy_stream, c.ev_copy[8], 0));
             const bool try_pre = c.wsort_overlap && c.wpre && wsort_applicable(c, n);
-            const size_t CH = try_pre ? 16 : 8;
+            const size_t CH = try_pre ? (getenv("TDC_GPU_UPLOAD_CHUNKS") ? (size_t)std::min(24, std::max(2, atoi(getenv("TDC_GPU_UPLOAD_CHUNKS")))) : 16) : 8;      // (at most 24: ev_copy[16 ..])
             const size_t step = ((n + CH - 1) / CH + 4095) & ~(size_t)4095;
             const size_t nch = (n + step - 1) / step;
             size_t queued = 0;                                                  // copies handed to the copy stream so far
             auto queue_copies = [&](size_t upto) {                              // (a few chunks ahead of the compute stream's work, not all at once:
                 for (; queued < nch && queued < upto; ++queued) {               //  the runtime batches what it is given in one go)
-                    const size_t off = queued * step, len = std::min(step, n - off);
+                    // (a copy takes the first 64 bytes of the next chunk along -- a key reads that far ahead --, so level 1 of a chunk
+                    //  can start as soon as the chunk itself is there: behind the last copy one chunk's level 1 is left, not two)
+                    const size_t off = queued * step, len = std::min(step + 64, n - off);
                     HIP_TRY(hipMemcpyAsync(d_text + off, text + off, len, hipMemcpyHostToDevice, c.copy_stream));
                     HIP_TRY(hipEventRecord(c.ev_copy[16 + queued], c.copy_stream));
                     (void)hipStreamQuery(c.copy_stream);                        // (submit now)
@@ -590,9 +592,8 @@ void compress_host(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, bool raw, ui
                     pre_on = wsort_pre_begin(c, *c.wpre, d_text, n, step, (u32)nch, h0);
                     if (!pre_on) c.arena.release_top();
                 }
-                if (pre_on && q >= 1) wsort_pre_chunk(c, *c.wpre, (u32)q - 1);
+                if (pre_on) wsort_pre_chunk(c, *c.wpre, (u32)q);
             }
-            if (pre_on) wsort_pre_chunk(c, *c.wpre, (u32)nch - 1);
             text_histogram_finish(c, d_text, n, d_hist);
             if (pre_on) {
                 wsort_pre_finish(c, *c.wpre, c.hist_cache);

@@ -76,7 +76,7 @@ struct WPre {
     u32 present[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };   // byte values of the provisional code map
 };
 bool wsort_pre_begin(Ctx& c, WPre& P, const u8* text, size_t n, size_t chunk_len, u32 nchunks, const u32* hist0);   // false: not applicable
-void wsort_pre_chunk(Ctx& c, WPre& P, u32 q);                  // level 1 of chunk q (chunk q + 1 must have arrived)
+void wsort_pre_chunk(Ctx& c, WPre& P, u32 q);                  // level 1 of chunk q (the chunk and the 64 bytes behind it must have arrived)
 void wsort_pre_finish(Ctx& c, WPre& P, const u32* hist_full);  // sets P.active if the full histogram confirms the code map
 bool wsort_applicable(const Ctx& c, size_t n);
 void wsort_make_keygen(const Ctx& c, const u8* text, size_t n, u32 sigma, const u8* code, int& KW, WKeyGen& g);   // key layout for an alphabet
