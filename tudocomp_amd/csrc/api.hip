@@ -567,7 +567,8 @@ void compress_host(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, bool raw, ui
             HIP_TRY(hipStreamWaitEvent(c.copy_stream, c.ev_copy[8], 0));
             const bool try_pre = c.wsort_overlap && c.wpre && wsort_applicable(c, n);
             const size_t CH = try_pre ? (getenv("TDC_GPU_UPLOAD_CHUNKS") ? (size_t)std::min(24, std::max(2, atoi(getenv("TDC_GPU_UPLOAD_CHUNKS")))) : 16) : 8;      // (at most 24: ev_copy[16 ..])
-            const size_t step = ((n + CH - 1) / CH + 4095) & ~(size_t)4095;
+            // (with level 1 behind it the LAST chunk is a quarter of the others: what is left behind the last copy is that chunk's level 1)
+            const size_t step = try_pre ? (((size_t)((double)n / ((double)CH - 0.75)) + 4095) & ~(size_t)4095) : (((n + CH - 1) / CH + 4095) & ~(size_t)4095);
             const size_t nch = (n + step - 1) / step;
             size_t queued = 0;                                                  // copies handed to the copy stream so far
             auto queue_copies = [&](size_t upto) {                              // (a few chunks ahead of the compute stream's work, not all at once:
