@@ -566,31 +566,48 @@ void compress_host(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, bool raw, ui
             HIP_TRY(hipEventRecord(c.ev_copy[8], c.stream));                   // (the copy stream starts behind whatever the compute stream did before)
             HIP_TRY(hipStreamWaitEvent(c.copy_stream, c.ev_copy[8], 0));
             const bool try_pre = c.wsort_overlap && c.wpre && wsort_applicable(c, n);
-            const size_t CH = try_pre ? (getenv("TDC_GPU_UPLOAD_CHUNKS") ? (size_t)std::min(24, std::max(2, atoi(getenv("TDC_GPU_UPLOAD_CHUNKS")))) : 16) : 8;      // (at most 24: ev_copy[16 ..])
-            // (with level 1 behind it the LAST chunk is a quarter of the others: what is left behind the last copy is that chunk's level 1)
-            const size_t step = try_pre ? (((size_t)((double)n / ((double)CH - 0.75)) + 4095) & ~(size_t)4095) : (((n + CH - 1) / CH + 4095) & ~(size_t)4095);
-            const size_t nch = (n + step - 1) / step;
+            const size_t CH = try_pre ? (getenv("TDC_GPU_UPLOAD_CHUNKS") ? (size_t)std::min(24, std::max(4, atoi(getenv("TDC_GPU_UPLOAD_CHUNKS")))) : 16) : 8;      // (at most 24: ev_copy[16 ..])
+            // Chunk boundaries (multiples of 4096).  With level 1 behind the copies the last three chunks shrink geometrically (0.6, 0.36,
+            // 0.22 of the others): level 1 of a chunk runs 1.7 x as fast as its copy, so each of them is done before the next, shorter copy
+            // ends, and what is left behind the last copy is the level 1 of a fifth of a chunk.
+            std::vector<size_t> coff;
+            {
+                std::vector<double> w(CH, 1.0);
+                if (try_pre) { w[CH - 3] = 0.6; w[CH - 2] = 0.36; w[CH - 1] = 0.22; }
+                double tot = 0; for (double x : w) tot += x;
+                coff.push_back(0);
+                double acc = 0;
+                for (size_t k = 0; k + 1 < CH; ++k) {
+                    acc += w[k];
+                    size_t o = ((size_t)((double)n * (acc / tot)) + 4095) & ~(size_t)4095;
+                    if (o <= coff.back()) o = coff.back() + 4096;
+                    if (o >= n) break;
+                    coff.push_back(o);
+                }
+                coff.push_back(n);
+            }
+            const size_t nch = coff.size() - 1;
             size_t queued = 0;                                                  // copies handed to the copy stream so far
             auto queue_copies = [&](size_t upto) {                              // (a few chunks ahead of the compute stream's work, not all at once:
                 for (; queued < nch && queued < upto; ++queued) {               //  the runtime batches what it is given in one go)
                     // (a copy takes the first 64 bytes of the next chunk along -- a key reads that far ahead --, so level 1 of a chunk
                     //  can start as soon as the chunk itself is there: behind the last copy one chunk's level 1 is left, not two)
-                    const size_t off = queued * step, len = std::min(step + 64, n - off);
+                    const size_t off = coff[queued], len = std::min(coff[queued + 1] - off + 64, n - off);
                     HIP_TRY(hipMemcpyAsync(d_text + off, text + off, len, hipMemcpyHostToDevice, c.copy_stream));
                     HIP_TRY(hipEventRecord(c.ev_copy[16 + queued], c.copy_stream));
                     (void)hipStreamQuery(c.copy_stream);                        // (submit now)
                 }
             };
             bool pre_on = false;
-            for (size_t q = 0, off = 0; q < nch; ++q, off += step) {
-                const size_t len = std::min(step, n - off);
+            for (size_t q = 0; q < nch; ++q) {
+                const size_t off = coff[q], len = coff[q + 1] - off;
                 queue_copies(q + 4);
                 HIP_TRY(hipStreamWaitEvent(c.stream, c.ev_copy[16 + q], 0));
                 text_histogram_add(c, d_text + off, len, d_hist);
                 if (q == 0 && try_pre) {
                     u32 h0[256];
                     c.read_n(d_hist, h0, 256);                                 // (waits for chunk 0 only; chunks 1 .. 3 are on their way)
-                    pre_on = wsort_pre_begin(c, *c.wpre, d_text, n, step, (u32)nch, h0);
+                    pre_on = wsort_pre_begin(c, *c.wpre, d_text, n, coff.data(), (u32)nch, h0);
                     if (!pre_on) c.arena.release_top();
                 }
                 if (pre_on) wsort_pre_chunk(c, *c.wpre, (u32)q);

@@ -71,11 +71,11 @@ struct WPre {
     int L = 0; u32 F[3] = { 1, 1, 1 }; u32 os = 0, NLr = 0, NS = 0, S = 0;
     u64* K1[2] = { nullptr, nullptr }; u64* K2[2] = { nullptr, nullptr }; u32* V[2] = { nullptr, nullptr };
     u16* digits = nullptr; u64* sp1 = nullptr; u64* sp2 = nullptr;
-    u32 nchunks = 0; size_t chunk_len = 0;
+    u32 nchunks = 0; size_t chunk_off[33] = {};   // chunk q = text positions [chunk_off[q], chunk_off[q + 1]) (multiples of the partition tile; the last one ends at n)
     u32* nstart_all = nullptr;       // [nchunks][F[0] + 1]: bucket starts of every chunk (absolute slots)
     u32 present[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };   // byte values of the provisional code map
 };
-bool wsort_pre_begin(Ctx& c, WPre& P, const u8* text, size_t n, size_t chunk_len, u32 nchunks, const u32* hist0);   // false: not applicable
+bool wsort_pre_begin(Ctx& c, WPre& P, const u8* text, size_t n, const size_t* chunk_off, u32 nchunks, const u32* hist0);   // false: not applicable
 void wsort_pre_chunk(Ctx& c, WPre& P, u32 q);                  // level 1 of chunk q (the chunk and the 64 bytes behind it must have arrived)
 void wsort_pre_finish(Ctx& c, WPre& P, const u32* hist_full);  // sets P.active if the full histogram confirms the code map
 bool wsort_applicable(const Ctx& c, size_t n);

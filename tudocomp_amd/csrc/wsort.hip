@@ -1641,9 +1641,11 @@ void wsort_suffixes_pre(Ctx& c, const WPre& P, u32* v_final, u8* flags, u8* lcp8
     else (void)ws_sort_impl<1, true, false>(c, &P.g, K1, K2, V, P.n, 64, flags, lcp8, st, &P, v_final);
 }
 
-bool wsort_pre_begin(Ctx& c, WPre& P, const u8* text, size_t n, size_t chunk_len, u32 nchunks, const u32* hist0) {
+bool wsort_pre_begin(Ctx& c, WPre& P, const u8* text, size_t n, const size_t* chunk_off, u32 nchunks, const u32* hist0) {
     P = WPre();
-    if (!c.wsort_overlap || !wsort_applicable(c, n) || nchunks < 2 || (chunk_len % WS_TILE) != 0 || chunk_len < ((size_t)1 << 22)) return false;
+    if (!c.wsort_overlap || !wsort_applicable(c, n) || nchunks < 2 || nchunks > 32 || chunk_off[1] < ((size_t)1 << 22)) return false;
+    for (u32 q = 0; q < nchunks; ++q) if (chunk_off[q] % WS_TILE != 0 || chunk_off[q] > chunk_off[q + 1]) return false;
+    if (chunk_off[0] != 0 || chunk_off[nchunks] != n) return false;
     // provisional code map: the sentinel and the byte values of chunk 0, dense and in byte order
     u8 code[256];
     u32 sigma = 0;
@@ -1651,7 +1653,8 @@ bool wsort_pre_begin(Ctx& c, WPre& P, const u8* text, size_t n, size_t chunk_len
         code[i] = (u8)sigma;
         if (i == 0 || hist0[i]) { ++sigma; P.present[i >> 5] |= 1u << (i & 31); }
     }
-    P.text = text; P.n = n; P.chunk_len = chunk_len; P.nchunks = nchunks;
+    P.text = text; P.n = n; P.nchunks = nchunks;
+    for (u32 q = 0; q <= nchunks; ++q) P.chunk_off[q] = chunk_off[q];
     wsort_make_keygen(c, text, n, sigma, code, P.KW, P.g);
     ss_fanouts(c, n, P.L, P.F, P.os, (u32)c.wsort_leaf, c.wsort_two);
     if (c.wsort_order == 1 && P.L == 3) std::swap(P.F[0], P.F[2]);
@@ -1668,7 +1671,7 @@ bool wsort_pre_begin(Ctx& c, WPre& P, const u8* text, size_t n, size_t chunk_len
     // splitters from a sample of chunk 0 (a key reads up to 64 bytes ahead: chunk 1 need not be there)
     WPlan pl;
     pl.L = P.L; pl.F[0] = P.F[0]; pl.F[1] = P.F[1]; pl.F[2] = P.F[2]; pl.os = P.os; pl.NLr = P.NLr; pl.NS = P.NS; pl.S = P.S;
-    const size_t n_sample = chunk_len - 64;
+    const size_t n_sample = chunk_off[1] - 64;
     if (P.KW == 2) ws_splitters<2, true>(c, pl, nullptr, nullptr, P.g, n_sample, P.sp1, P.sp2);
     else ws_splitters<1, true>(c, pl, nullptr, nullptr, P.g, n_sample, P.sp1, nullptr);
     P.begun = true;
@@ -1678,12 +1681,12 @@ bool wsort_pre_begin(Ctx& c, WPre& P, const u8* text, size_t n, size_t chunk_len
 void wsort_pre_chunk(Ctx& c, WPre& P, u32 q) {
     if (!P.begun) return;
     hipStream_t s = c.stream;
-    const size_t off = (size_t)q * P.chunk_len;
+    const size_t off = P.chunk_off[q];
     if (off >= P.n) {                                          // (more chunks than text: an empty part)
         ws_set2_kernel<<<1, 1, 0, s>>>(P.nstart_all + (size_t)q * (P.F[0] + 1), (u32)P.n, (u32)P.n);
         return;
     }
-    const size_t len = std::min(P.chunk_len, P.n - off);
+    const size_t len = P.chunk_off[q + 1] - off;
     const size_t mark = c.arena.mark();
     u32* seg2 = c.arena.get<u32>(2);
     ws_set2_kernel<<<1, 1, 0, s>>>(seg2, (u32)off, (u32)(off + len));
