@@ -637,6 +637,9 @@ __device__ __forceinline__ u32 wl_run_end(const u64* hb, u32 s) {
 // with its predecessor; X and k2 in the same order where a later kernel (or the caller: PAIRS) reads them.  Units with runs left go
 // to `rlist` (ties on the whole of k1: to be ordered by k2) or `tlist` (ties on a truncated word: to be ordered by the word itself
 // first); the counting kernel takes them from there.
+#ifndef TDC_WL_FILL
+#define TDC_WL_FILL 0
+#endif
 #ifndef TDC_WL_W58
 #define TDC_WL_W58 6
 #endif
@@ -650,6 +653,12 @@ __device__ __forceinline__ u32 wl_run_end(const u64* hb, u32 s) {
 //  resident workgroups: the 8-wave instances with up to 5 rows hold 53 KB of LDS -- three of them fit a CU if they stay within 80
 //  registers (two with the 128 of round 4: leaf stage 48.9 -> 45.4 ms); the 4-wave instances with up to 5 rows hold 27 KB)
 #define WL_WPE(R, W) ((W) == 8 && (R) <= 5 ? TDC_WL_W58 : ((W) == 4 && (R) <= 5 ? TDC_WL_W44 : ((W) == 4 && (R) <= 8 ? TDC_WL_W4X : 4)))
+#ifdef TDC_WL_PROF
+__device__ unsigned long long wl_prof[16];
+#define WLP(i) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); atomicAdd(&wl_prof[i], t_ - tp_); tp_ = t_; } } while (0)
+#else
+#define WLP(i) do { } while (0)
+#endif
 template <int KW, int ROWS, int NW, bool PAIRS>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WL_WPE(ROWS, NW), WL_WPE(ROWS, NW)))) void ws_leaf_sort_kernel(WLeaf A, const u32* __restrict__ list, u32 count, WLists Q, WEmit E) {
     constexpr u32 CAP = (u32)ROWS * NW * 64;
@@ -671,6 +680,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WL_WPE(
     if (m > CAP) { if (threadIdx.x == 0) atomicOr(A.d_err, 2u); return; }
     if (threadIdx.x == 0) { A.flags[a] = 1; s_any = 0; }      // a unit starts at a leaf start / run start
     if (m == 1) return;
+#ifdef TDC_WL_PROF
+    unsigned long long tp_ = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) { atomicAdd(&wl_prof[15], 1ull); atomicAdd(&wl_prof[14], (unsigned long long)m); }
+#endif
     const int lane = lane_id(), w = wave_id();
     WLState<ROWS, NW> T;
     T.wcnt = wcnt; T.wst = wst; T.wm = wm; T.stage = stage;
@@ -700,9 +713,31 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WL_WPE(
     const int nb = nbits > WL_NBMAX ? WL_NBMAX : nbits;         // bits of X in the composite
     const int sh = nbits - nb;                                  // low bits of X left out (ties on the rest are handed on)
     const u64 cmask = (1ull << nb) - 1;
+    // The passes sort whole digits: the bits of the last digit that X does not fill take the leading bits of the second word (KW == 2,
+    // X = k1) -- the runs that are left then tie on k1 AND on those bits, for nothing (TDC_WL_FILL == 2: one more digit of them)
+    int nbf = 0;
+    if (TDC_WL_FILL && KW == 2 && !pure && nbits < WL_NBMAX) {
+        int tgt = ((nbits + 7) & ~7) + (TDC_WL_FILL == 2 ? 8 : 0);
+        if (tgt > WL_NBMAX) tgt = WL_NBMAX;
+        nbf = tgt - nbits;
+    }
+    if (nbf) {
 #pragma unroll
-    for (int j = 0; j < ROWS; ++j) c[j] = (((c[j] >> sh) & cmask) << 13) | (u64)(wbase + (u32)j * 64);
-    wl_lsd<ROWS, NW>(T, c, 13, nb);
+        for (int j = 0; j < ROWS; ++j) {
+            const u32 L = wbase + (u32)j * 64;
+            const u64 f = (L < m) ? (K2[L] >> (64 - nbf)) : 0ull;
+            c[j] = ((((c[j] & cmask) << nbf) | f) << 13) | (u64)L;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) c[j] = (((c[j] >> sh) & cmask) << 13) | (u64)(wbase + (u32)j * 64);
+    }
+    WLP(0);
+#ifdef TDC_WL_PROF
+    if (threadIdx.x == 0) atomicAdd(&wl_prof[13], (unsigned long long)((nb + nbf + 7) / 8));
+#endif
+    wl_lsd<ROWS, NW>(T, c, 13, nb + nbf);
+    WLP(1);
     // heads, LCPs
     const u32 base_bits = pure ? 64u : 0u;
     bool anyrun = false;
@@ -715,7 +750,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WL_WPE(
         if (L < m && L > 0) {
             const u64 x = (c[j] >> 13) ^ (stage[L - 1] >> 13);
             A.flags[(size_t)a + L] = x ? 1 : 0;
-            if (x) { hd = true; if (!PAIRS) A.lcp[(size_t)a + L] = (u8)(((base_bits + (u32)__builtin_clzll(x) - (u32)sh) * A.inv) >> 16); }
+            if (x) { hd = true; if (!PAIRS) A.lcp[(size_t)a + L] = (u8)(((base_bits + (u32)__builtin_clzll(x) - (u32)sh + (u32)nbf) * A.inv) >> 16); }
             else anyrun = true;
         }
         if (FUSE) { const u64 bm = __ballot(hd || L == m); if (lane == 0) hb[w * ROWS + j] = bm; }
@@ -725,6 +760,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WL_WPE(
     __syncthreads();                                            // (the staged composites have been read)
     const bool runs = s_any != 0;
     const bool trunc_ties = sh > 0 && runs;                     // the counting kernel orders these runs by X itself first
+    WLP(2);
     // positions in sorted order
     u32 vs[ROWS];
     {
@@ -735,6 +771,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WL_WPE(
 #pragma unroll
         for (int j = 0; j < ROWS; ++j) { const u32 L = wbase + (u32)j * 64; vs[j] = (L < m) ? stage32[(u32)c[j] & 8191u] : 0u; }
     }
+    WLP(3);
     if (FUSE && runs && !pure && !trunc_ties && E.rng) {
         // The runs that are left tie on all of k1: ordered by k2 right here, by counting, as ws_leaf_count_kernel does it for the units
         // of the lists (the sorted k2, the positions and the head bits never leave the workgroup; runs of more than cmax records are
@@ -762,12 +799,13 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WL_WPE(
         if (PAIRS) {                                            // k1 in sorted order (rebuilt from the composite: sh == 0)
             const u64 high = kmin & ~cmask;
 #pragma unroll
-            for (int j = 0; j < ROWS; ++j) { const u32 L = wbase + (u32)j * 64; if (L < m) K1[L] = ((c[j] >> 13) & cmask) | high; }
+            for (int j = 0; j < ROWS; ++j) { const u32 L = wbase + (u32)j * 64; if (L < m) K1[L] = ((c[j] >> (13 + nbf)) & cmask) | high; }
         }
 #pragma unroll
         for (int j = 0; j < ROWS; ++j) { const u32 L = wbase + (u32)j * 64; if (L < m) Wl[L] = t[j]; }
         if (threadIdx.x == 0) s_any = 0;                        // from here on: some run of the unit is handed on
         __syncthreads();
+        WLP(4);
 #pragma unroll 1
         for (int j = 0; j < ROWS; ++j) {
             const u32 L = wbase + (u32)j * 64;
@@ -799,6 +837,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WL_WPE(
             }
         }
         __syncthreads();
+        WLP(5);
         u32 tr[ROWS];
 #pragma unroll
         for (int j = 0; j < ROWS; ++j) { const u32 L = wbase + (u32)j * 64; tr[j] = (L < m) ? P32[L] : 0u; }
@@ -825,6 +864,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WL_WPE(
                 }
             }
         }
+        WLP(6);
         return;
     }
 #pragma unroll
@@ -833,7 +873,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WL_WPE(
         if (sh == 0) {                                          // rebuilt from the composite
             const u64 high = kmin & ~cmask;
 #pragma unroll
-            for (int j = 0; j < ROWS; ++j) { const u32 L = wbase + (u32)j * 64; if (L < m) Xp[L] = ((c[j] >> 13) & cmask) | high; }
+            for (int j = 0; j < ROWS; ++j) { const u32 L = wbase + (u32)j * 64; if (L < m) Xp[L] = ((c[j] >> (13 + nbf)) & cmask) | high; }
         } else {                                                // (all reads before the first write)
             u64 t[ROWS];
 #pragma unroll
@@ -851,6 +891,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WL_WPE(
 #pragma unroll
         for (int j = 0; j < ROWS; ++j) { const u32 L = wbase + (u32)j * 64; if (L < m) K2[L] = t[j]; }
     }
+    WLP(7);
     if (threadIdx.x == 0) {
         if (trunc_ties) Q.tlist[atomicAdd(Q.counters + 1, 1u)] = u | (pure ? 0x80000000u : 0u);
         else if (runs && KW == 2 && !pure) Q.rlist[atomicAdd(Q.counters, 1u)] = u;
@@ -1328,6 +1369,9 @@ int ws_sort_impl(Ctx& c, const WKeyGen* gen, u64* K1[2], u64* K2[2], u32* V[2], 
     if (PAIRS) flags = c.arena.get<u8>(n + 8);                 // (internal in this mode: run heads between the two leaf kernels)
     HIP_TRY(hipMemsetAsync(flags, 0, n, s));
 
+#ifdef TDC_EXP_OVERLAP
+    WSLevel expP; u32 exp_rows = 0, exp_grid = 0; bool exp_have = false;
+#endif
     // ---- partition levels ----
     u16* digits = pre ? pre->digits : c.arena.get<u16>(align_up(n, WS_TILE) + WS_TILE);
     const u32* seg_start = pre ? nullptr : ss_first_segment(c, n);
@@ -1447,6 +1491,10 @@ int ws_sort_impl(Ctx& c, const WKeyGen* gen, u64* K1[2], u64* K2[2], u32* V[2], 
             LAUNCH_CHECK();
             c.prof_end(ps);
         }
+#ifdef TDC_EXP_OVERLAP
+        if (last && !gl && !PAIRS && getenv("TDC_GPU_EXP_OVERLAP") && atoi(getenv("TDC_GPU_EXP_OVERLAP")) > 0 && P.F <= 256) { expP = P; exp_rows = rows; exp_grid = grid; exp_have = true; }
+        else
+#endif
         c.arena.release(lm2);
         seg_start = nstart;
         nseg = nseg * D;
@@ -1465,6 +1513,23 @@ int ws_sort_impl(Ctx& c, const WKeyGen* gen, u64* K1[2], u64* K2[2], u32* V[2], 
     A.k1 = K1[cur]; A.k2 = KW == 2 ? K2[cur] : nullptr; A.v = Vlast; A.unit_rng = U.unit_rng; A.flags = flags; A.lcp = lcp8;
     A.d_err = c.d_err; A.inv = g.b ? (65536u + (u32)g.b - 1) / (u32)g.b : 65536u;
     A.cmax = c.wsort_small ? 1u : (c.wsort_cmax < 1 ? 1u : (c.wsort_cmax > (int)WS_CMAX ? WS_CMAX : (u32)c.wsort_cmax));
+#ifdef TDC_EXP_OVERLAP
+    static hipEvent_t exp_e0 = nullptr, exp_e1 = nullptr;
+    int exp_mode = 0;
+    if (exp_have) {
+        static char* dummy = nullptr; static size_t dummy_n = 0;
+        if (dummy_n < n) { if (dummy) (void)hipFree(dummy); HIP_TRY(hipMalloc((void**)&dummy, 20 * n + 4096)); dummy_n = n; }
+        if (!exp_e0) { HIP_TRY(hipEventCreateWithFlags(&exp_e0, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&exp_e1, hipEventDisableTiming)); }
+        exp_mode = atoi(getenv("TDC_GPU_EXP_OVERLAP"));
+        const int reps = getenv("TDC_GPU_EXP_REPS") ? atoi(getenv("TDC_GPU_EXP_REPS")) : 3;
+        WSLevel P2 = expP;
+        P2.k1_out = (u64*)dummy; P2.k2_out = (u64*)(dummy + 8 * n); P2.v_out = (u32*)(dummy + 16 * n);
+        hipStream_t s2 = exp_mode == 1 ? c.copy_stream : s;
+        if (exp_mode == 1) { HIP_TRY(hipEventRecord(exp_e0, s)); HIP_TRY(hipStreamWaitEvent(s2, exp_e0, 0)); }
+        for (int r = 0; r < reps; ++r) { ws_scatter_kernel<KW, false, true, 256><<<exp_grid, 256, 0, s2>>>(P2, g, exp_rows); LAUNCH_CHECK(); }
+        if (exp_mode == 1) HIP_TRY(hipEventRecord(exp_e1, s2));
+    }
+#endif
     {
         // Stage 0: the units of the leaves.  Kernel A sorts every unit by its first differing word; the counting kernel orders the runs
         // that are left (<= 256 members) by the next word and hands longer runs back as the units of the next stage.
@@ -1588,6 +1653,9 @@ int ws_sort_impl(Ctx& c, const WKeyGen* gen, u64* K1[2], u64* K2[2], u32* V[2], 
             st->leaf_stages = (u32)stage + 1;
         }
     }
+#ifdef TDC_EXP_OVERLAP
+    if (exp_have && exp_mode == 1) HIP_TRY(hipStreamWaitEvent(s, exp_e1, 0));
+#endif
     if (nlarge) {                                              // leaves above the workgroup capacity: LSD sort, one by one
         if (nlarge > U.large_cap) throw HipError{hipErrorUnknown, "wide splitter sort: too many oversized leaves", (int)__LINE__};
         std::vector<u32> ll(nlarge), ls((size_t)nleaf + 1);
@@ -1619,6 +1687,17 @@ int ws_sort_impl(Ctx& c, const WKeyGen* gen, u64* K1[2], u64* K2[2], u32* V[2], 
         c.read_n((const u64*)d_nonheads, &nh, 1);
         st->nonheads = nh;
     }
+#ifdef TDC_WL_PROF
+    if (!PAIRS) {
+        unsigned long long hp[16];
+        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(hipMemcpyFromSymbol(hp, HIP_SYMBOL(wl_prof), sizeof(hp)));
+        fprintf(stderr, "[wl_prof] wgs %llu records %llu passes %llu | ticks: load %llu lsd %llu heads %llu pos %llu k2 %llu count %llu fin %llu nofuse %llu\n", hp[15], hp[14], hp[13],
+                hp[0], hp[1], hp[2], hp[3], hp[4], hp[5], hp[6], hp[7]);
+        memset(hp, 0, sizeof(hp));
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(wl_prof), hp, sizeof(hp)));
+    }
+#endif
     c.arena.release(mark);
     return cur;
 }
