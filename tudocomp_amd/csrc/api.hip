@@ -587,13 +587,15 @@ void compress_host(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, bool raw, ui
                 coff.push_back(n);
             }
             const size_t nch = coff.size() - 1;
+            if (nch > 24) throw HipError{hipErrorUnknown, "upload: more chunks than copy events (ev_copy[16 .. 39])", (int)__LINE__};
             size_t queued = 0;                                                  // copies handed to the copy stream so far
             auto queue_copies = [&](size_t upto) {                              // (a few chunks ahead of the compute stream's work, not all at once:
                 for (; queued < nch && queued < upto; ++queued) {               //  the runtime batches what it is given in one go)
                     // (a copy takes the first 64 bytes of the next chunk along -- a key reads that far ahead --, so level 1 of a chunk
                     //  can start as soon as the chunk itself is there: behind the last copy one chunk's level 1 is left, not two)
-                    const size_t off = coff[queued], len = std::min(coff[queued + 1] - off + 64, n - off);
-                    HIP_TRY(hipMemcpyAsync(d_text + off, text + off, len, hipMemcpyHostToDevice, c.copy_stream));
+                    //  -- and a copy starts behind the 64 bytes its predecessor delivered: no byte is written twice while level 1 reads it)
+                    const size_t off = coff[queued] + (queued ? 64 : 0), end = std::min(coff[queued + 1] + 64, n);
+                    if (end > off) HIP_TRY(hipMemcpyAsync(d_text + off, text + off, end - off, hipMemcpyHostToDevice, c.copy_stream));
                     HIP_TRY(hipEventRecord(c.ev_copy[16 + queued], c.copy_stream));
                     (void)hipStreamQuery(c.copy_stream);                        // (submit now)
                 }

@@ -818,6 +818,9 @@ static bool decode_lzss_huff_device(Ctx& c, const u8* stream, size_t len, const 
         up.chunk = std::max((size_t)32 << 20, (len + 31) / 32);
         up.chunk = (up.chunk + 4095) & ~(size_t)4095;
         up.nchunks = (len + up.chunk - 1) / up.chunk;
+        // (decompression has ev_copy[0 .. 31] to itself -- the compress path's slots 0, 8, 9, 16 .. 39 belong to calls that never overlap
+        //  this one, every path drains the copy stream before it returns --; the chunk size above keeps the count within them)
+        if (up.nchunks > 32) throw HipError{hipErrorUnknown, "decode: more upload chunks than copy events", (int)__LINE__};
         for (size_t k = 0; k < up.nchunks; ++k) {
             const size_t a = k * up.chunk, b = std::min(len, a + up.chunk);
             HIP_TRY(hipMemcpyAsync(d_stream + a, stream + a, b - a, hipMemcpyHostToDevice, c.copy_stream));

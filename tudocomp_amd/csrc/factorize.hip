@@ -1229,9 +1229,12 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
         }
         build_lists(hi);
         cand = cvals[x];
-        if ((u64)prio_base + cand_count > 0xFFFFFFFFull) throw HipError{hipErrorUnknown, "factorize: priority space exhausted", (int)__LINE__};
-        lazy_rebuild_prio(c, cand, cand_count, cur, res8, n, prio, prio_base, phi ? nullptr : sa, fs.fsrc);
-        prio_base += (u32)cand_count;
+        // (truncated entries take prio_base + their index inside their level: the rebuild consumes what its longest level holds)
+        u32 longest = 0;
+        for (u32 v = lo + 1; v <= hi && v < (u32)nlev; ++v) { longest = std::max(longest, h_segend[v] - h_segstart[v]); if (v == 0xFFFFFFFFu) break; }
+        if ((u64)prio_base + longest > 0xFFFFFFFFull) throw HipError{hipErrorUnknown, "factorize: priority space exhausted", (int)__LINE__};
+        lazy_rebuild_prio(c, cand, cand_count, cur, res8, n, prio, prio_base, d_segstart, phi ? nullptr : sa, fs.fsrc);
+        prio_base += longest;
         for (u32 v = lo + 1; v <= hi; ++v) { pushed_into.drop(v); if (v == 0xFFFFFFFFu) break; }
         pool_top = 0;
         HIP_TRY(hipMemsetAsync(d_lcount, 0xFF, nlev * sizeof(u32), s));
@@ -1242,9 +1245,10 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
     // The eager formulation (factorize_eager.hip): a run of small levels inside one launch.  Taken when the levels ahead are small and
     // many (texts with long repeats); at most a few phases per call, each framed by two dense passes.
     const u32 eager_floor = std::max<u32>(threshold, lcut ? lcut + 1 : 0);       // lowest level of the global loop
-    const bool eager_possible = c.eager_levels && res8 && nlev <= ((size_t)1 << 22) && maxlcp > eager_floor + 256;
+    // (the eager kernel packs an entry as position << 1 | truncated in 32 bits: n <= 2^31)
+    const bool eager_possible = c.eager_levels && res8 && nlev <= ((size_t)1 << 22) && maxlcp > eager_floor + 256 && n <= ((size_t)1 << 31);
     u32 eager_phases = 0, small_lazy_streak = 0;
-    u32* d_eseg = eager_possible ? c.arena.get<u32>(4 * nlev) : nullptr;        // segstart | segend | tstart | tend
+    u32* d_eseg = eager_possible ? c.arena.get<u32>(2 * nlev) : nullptr;        // tstart | tend
     u32* d_ehead = eager_possible ? c.arena.get<u32>(nlev) : nullptr;
     EagerCtl* d_ectl = eager_possible ? (EagerCtl*)c.arena.alloc(sizeof(EagerCtl)) : nullptr;
     auto run_eager = [&](u32 Lfrom) -> u32 {                                     // returns the next level to be processed
@@ -1258,18 +1262,18 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
         u32* tk[2] = { live, stale };
         u32* tv[2] = { ent, rval };
         int y = 0;
-        HIP_TRY(hipMemsetAsync(d_eseg + 2 * nlev, 0, 2 * nlev * sizeof(u32), s));
+        HIP_TRY(hipMemsetAsync(d_eseg, 0, 2 * nlev * sizeof(u32), s));
         if (tcount) {
             gather_kernel<<<cdiv(tcount, 256), 256, 0, s>>>(ent, tcount, cur, live);
             LAUNCH_CHECK();
             y = radix_sort_pairs_u32(c, tk, tv, tcount, 0, (int)bits_for(Lfrom));
-            seg_bounds_kernel<<<cdiv(tcount, 256), 256, 0, s>>>(tk[y], tcount, d_eseg + 2 * nlev, d_eseg + 3 * nlev);
+            seg_bounds_kernel<<<cdiv(tcount, 256), 256, 0, s>>>(tk[y], tcount, d_eseg, d_eseg + nlev);
             LAUNCH_CHECK();
         }
         HIP_TRY(hipMemsetAsync(d_ehead, 0, nlev * sizeof(u32), s));
         HIP_TRY(hipMemsetAsync(d_ectl, 0, sizeof(EagerCtl), s));
         EagerParams P;
-        P.tcand = tv[y]; P.tstart = d_eseg + 2 * nlev; P.tend = d_eseg + 3 * nlev;
+        P.tcand = tv[y]; P.tstart = d_eseg; P.tend = d_eseg + nlev;
         P.head = d_ehead;
         P.blk = pool; P.blk_cap = (u32)std::min<size_t>(n / 16, (size_t)1 << 28);   // (the push pool of the lazy formulation is forgotten anyway)
         P.cur = cur; P.prio = prio; P.phi = phi_eff; P.flen = fs.flen; P.flen8 = fs.flen8; P.fsrc = fs.fsrc; P.res8 = res8;

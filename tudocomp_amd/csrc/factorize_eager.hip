@@ -151,7 +151,8 @@ __global__ __launch_bounds__(ENT) void eager_levels_kernel(EagerParams P) {
             }
             __syncthreads();
             const u32 nx = s_next;
-            if (nx) L = nx; else if (span == (u32)ENT) L = L - ENT; else { L = P.L_stop - 1; break; }    // (level 0 never holds anything: threshold >= 1)
+            // (none of the span levels is alive: the next one to look at lies below all of them -- level L - ENT itself was probed too)
+            if (nx) L = nx; else if (span == (u32)ENT) L = L - ENT - 1; else { L = P.L_stop - 1; break; }    // (level 0 never holds anything: threshold >= 1)
             __syncthreads();
             continue;
         }
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(ENT) void eager_levels_kernel(EagerParams P) {
     if (tid == 0) {
         P.ctl->level = L;                     // the next level to be processed (L_stop - 1: the phase is complete)
         P.ctl->status = status;
-        P.ctl->levels_done = levels_done;
+        P.ctl->levels_done = levels_done;     // levels looked at (runs without a head are skipped ENT at a time and count once)
         P.ctl->factors = factors;
     }
 }
@@ -347,9 +348,13 @@ __global__ __launch_bounds__(256) void lazy_rebuild_class_kernel(const u32* __re
     const u32 c = cur[q];
     cls[q] = (c > lo && c <= hi) ? 1 : 0;
 }
-// ... and their list order: truncated entries follow the natural ones (priority prio_base + index; FactorSpace::src_prio)
+// ... and their list order: truncated entries follow the natural ones (FactorSpace::src_prio).  Priorities are only ever compared inside
+// one level, so a truncated entry takes prio_base + its index INSIDE its level's segment of the list (segstart[level]): the rebuild
+// consumes as much priority space as its longest level holds entries, not as the whole list does (a text near 2^31 bytes
+// with most positions alive used to run out of 32-bit priorities on its second rebuild)
 __global__ __launch_bounds__(256) void lazy_rebuild_prio_kernel(const u32* __restrict__ list, size_t m, const u32* __restrict__ cur, const u8* __restrict__ res8,
-                                                                size_t n, u32* __restrict__ prio, u32 prio_base, const u32* __restrict__ src_sa, u32* __restrict__ fsrc) {
+                                                                size_t n, u32* __restrict__ prio, u32 prio_base, const u32* __restrict__ segstart,
+                                                                const u32* __restrict__ src_sa, u32* __restrict__ fsrc) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
     const u32 q = list[i];
@@ -360,7 +365,7 @@ __global__ __launch_bounds__(256) void lazy_rebuild_prio_kernel(const u32* __res
     // no Phi array: the source of a factor at q is SA[ISA[q] - 1] (ds/PhiFromSA.hpp:35-45) -- saved now for EVERY listed entry, a push
     // of the lazy levels to come may overwrite its priority (= ISA) before it is selected
     if (src_sa) fsrc[q] = pr ? src_sa[pr - 1] : src_sa[n - 1];
-    if (!natural) prio[q] = prio_base + (u32)i;
+    if (!natural) prio[q] = prio_base + ((u32)i - segstart[c]);
 }
 
 }  // namespace
@@ -380,9 +385,10 @@ void lazy_rebuild_class(Ctx& c, const u32* cur, size_t n, u32 lo, u32 hi, u8* cl
     lazy_rebuild_class_kernel<<<cdiv(n, 256), 256, 0, c.stream>>>(cur, n, lo, hi, cls);
     LAUNCH_CHECK();
 }
-void lazy_rebuild_prio(Ctx& c, const u32* list, size_t m, const u32* cur, const u8* res8, size_t n, u32* prio, u32 prio_base, const u32* src_sa, u32* fsrc) {
+void lazy_rebuild_prio(Ctx& c, const u32* list, size_t m, const u32* cur, const u8* res8, size_t n, u32* prio, u32 prio_base, const u32* segstart,
+                       const u32* src_sa, u32* fsrc) {
     if (!m) return;
-    lazy_rebuild_prio_kernel<<<cdiv(m, 256), 256, 0, c.stream>>>(list, m, cur, res8, n, prio, prio_base, src_sa, fsrc);
+    lazy_rebuild_prio_kernel<<<cdiv(m, 256), 256, 0, c.stream>>>(list, m, cur, res8, n, prio, prio_base, segstart, src_sa, fsrc);
     LAUNCH_CHECK();
 }
 

@@ -27,6 +27,6 @@ void eager_heads_class(Ctx& c, const u32* cur, size_t n, u32 lo, u32 hi, u8* cls
 // cls[q] = 1 for every alive position of the levels (lo, hi]
 void lazy_rebuild_class(Ctx& c, const u32* cur, size_t n, u32 lo, u32 hi, u8* cls);
 // list[0 .. m): truncated entries that still carry their ISA as priority get prio_base + index (their source is saved first if src_sa)
-void lazy_rebuild_prio(Ctx& c, const u32* list, size_t m, const u32* cur, const u8* res8, size_t n, u32* prio, u32 prio_base, const u32* src_sa, u32* fsrc);
+void lazy_rebuild_prio(Ctx& c, const u32* list, size_t m, const u32* cur, const u8* res8, size_t n, u32* prio, u32 prio_base, const u32* segstart, const u32* src_sa, u32* fsrc);
 
 }  // namespace tdc

@@ -638,7 +638,10 @@ __device__ __forceinline__ u32 wl_run_end(const u64* hb, u32 s) {
 // to `rlist` (ties on the whole of k1: to be ordered by k2) or `tlist` (ties on a truncated word: to be ordered by the word itself
 // first); the counting kernel takes them from there.
 #ifndef TDC_WL_FILL
-#define TDC_WL_FILL 0
+#define TDC_WL_FILL 2
+#endif
+#ifndef TDC_WL_PRE
+#define TDC_WL_PRE 1
 #endif
 #ifndef TDC_WL_W58
 #define TDC_WL_W58 6
@@ -692,18 +695,38 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WL_WPE(
     u64* K1 = A.k1 + a;
     u64* K2 = KW == 2 ? A.k2 + a : nullptr;
 
+    // Round 6: the kernel used to spend more than half of its time waiting for global memory in front of its later phases (positions after the
+    // passes: 23 %, the gather of the second words: 8 %, the second words of a pure unit).  Now everything a unit needs is requested in
+    // its first instructions -- k1, the positions and the second words, all in slot order -- and travels while the passes run; positions and
+    // second words then follow the permutation through LDS (v in the counter tables, k2 in the staging buffer, one barrier for both).
+    constexpr bool PRE = TDC_WL_PRE && ROWS <= 8;               // (16 rows: the positions do not fit the counter tables -- the old order of things)
     u64 c[ROWS];
+    u32 vp[PRE ? ROWS : 1];
+    u64 t2[(PRE && KW == 2) ? ROWS : 1];
     u64 kmin = 0, kmax = 0;
     if (!known_pure) {                                          // (the k1 slots of such a run were never brought into sorted order)
 #pragma unroll
         for (int j = 0; j < ROWS; ++j) { const u32 L = wbase + (u32)j * 64; c[j] = (L < m) ? K1[L] : 0ull; }
-        wl_minmax<ROWS, NW>(red, c, m, wbase, lane, w, kmin, kmax);
     }
+    if constexpr (PRE) {
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) { const u32 L = wbase + (u32)j * 64; vp[j] = (L < m) ? A.v[(size_t)a + L] : 0u; }
+        if constexpr (KW == 2) {
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j) { const u32 L = wbase + (u32)j * 64; t2[j] = (L < m) ? K2[L] : 0ull; }
+        }
+    }
+    if (!known_pure) wl_minmax<ROWS, NW>(red, c, m, wbase, lane, w, kmin, kmax);
     bool pure = false;
     if (kmin == kmax) {
         if (KW == 1) return;                                    // one group: nothing moves
+        if constexpr (PRE && KW == 2) {
 #pragma unroll
-        for (int j = 0; j < ROWS; ++j) { const u32 L = wbase + (u32)j * 64; c[j] = (L < m) ? K2[L] : 0ull; }
+            for (int j = 0; j < ROWS; ++j) c[j] = t2[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j) { const u32 L = wbase + (u32)j * 64; c[j] = (L < m) ? K2[L] : 0ull; }
+        }
         wl_minmax<ROWS, NW>(red, c, m, wbase, lane, w, kmin, kmax);
         pure = true;
         if (kmin == kmax) return;
@@ -725,7 +748,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WL_WPE(
 #pragma unroll
         for (int j = 0; j < ROWS; ++j) {
             const u32 L = wbase + (u32)j * 64;
-            const u64 f = (L < m) ? (K2[L] >> (64 - nbf)) : 0ull;
+            u64 f;
+            if constexpr (PRE && KW == 2) f = t2[j] >> (64 - nbf);
+            else f = (L < m) ? (K2[L] >> (64 - nbf)) : 0ull;
             c[j] = ((((c[j] & cmask) << nbf) | f) << 13) | (u64)L;
         }
     } else {
@@ -760,10 +785,27 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WL_WPE(
     __syncthreads();                                            // (the staged composites have been read)
     const bool runs = s_any != 0;
     const bool trunc_ties = sh > 0 && runs;                     // the counting kernel orders these runs by X itself first
+    const bool k2_follows = KW == 2 && !pure && (runs || PAIRS);
     WLP(2);
-    // positions in sorted order
+    // positions (and second words) in sorted order
     u32 vs[ROWS];
-    {
+    u64 t[KW == 2 ? ROWS : 1];
+    if constexpr (PRE) {
+        u32* v32 = &wtab[0][0][0];
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) {
+            const u32 L = wbase + (u32)j * 64;
+            if (L < m) { v32[L] = vp[j]; if constexpr (KW == 2) { if (k2_follows) stage[L] = t2[j]; } }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) {
+            const u32 L = wbase + (u32)j * 64;
+            const u32 idx = (u32)c[j] & 8191u;
+            vs[j] = (L < m) ? v32[idx] : 0u;
+            if constexpr (KW == 2) t[j] = (L < m && k2_follows) ? stage[idx] : 0ull;
+        }
+    } else {
         u32* stage32 = (u32*)stage;
 #pragma unroll
         for (int j = 0; j < ROWS; ++j) { const u32 L = wbase + (u32)j * 64; if (L < m) stage32[L] = A.v[(size_t)a + L]; }
@@ -776,26 +818,13 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WL_WPE(
         // The runs that are left tie on all of k1: ordered by k2 right here, by counting, as ws_leaf_count_kernel does it for the units
         // of the lists (the sorted k2, the positions and the head bits never leave the workgroup; runs of more than cmax records are
         // handed on).  All per-slot state in LDS, the row loops are real loops.
-        u64 t[ROWS];
         u64* Wl = stage;
         u32* P32 = &wtab[0][0][0];
-#ifndef WL_K2_LDS                                            // (through LDS instead -- coalesced load, permuted LDS read -- measured the same: 55.9 vs 55.6 ms)
+        if constexpr (!PRE) {
 #pragma unroll
-        for (int j = 0; j < ROWS; ++j) { const u32 L = wbase + (u32)j * 64; t[j] = (L < m) ? K2[c[j] & 8191ull] : 0ull; }
-        __syncthreads();                                        // (the staged positions have been read)
-#else
-        // the second words follow the permutation through LDS as well (coalesced load, permuted LDS read): a gather from global
-        // memory moves a whole line per record
-#pragma unroll
-        for (int j = 0; j < ROWS; ++j) { const u32 L = wbase + (u32)j * 64; t[j] = (L < m) ? K2[L] : 0ull; }
-        __syncthreads();                                        // (the staged positions have been read)
-#pragma unroll
-        for (int j = 0; j < ROWS; ++j) { const u32 L = wbase + (u32)j * 64; if (L < m) Wl[L] = t[j]; }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < ROWS; ++j) { const u32 L = wbase + (u32)j * 64; t[j] = (L < m) ? Wl[c[j] & 8191ull] : 0ull; }
-        __syncthreads();
-#endif
+            for (int j = 0; j < ROWS; ++j) { const u32 L = wbase + (u32)j * 64; t[j] = (L < m) ? K2[c[j] & 8191ull] : 0ull; }
+        }
+        __syncthreads();                                        // (the staged positions / second words have been read)
         if (PAIRS) {                                            // k1 in sorted order (rebuilt from the composite: sh == 0)
             const u64 high = kmin & ~cmask;
 #pragma unroll
@@ -875,21 +904,25 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WL_WPE(
 #pragma unroll
             for (int j = 0; j < ROWS; ++j) { const u32 L = wbase + (u32)j * 64; if (L < m) Xp[L] = ((c[j] >> (13 + nbf)) & cmask) | high; }
         } else {                                                // (all reads before the first write)
-            u64 t[ROWS];
+            u64 tx[ROWS];
 #pragma unroll
-            for (int j = 0; j < ROWS; ++j) { const u32 L = wbase + (u32)j * 64; t[j] = (L < m) ? Xp[c[j] & 8191ull] : 0ull; }
+            for (int j = 0; j < ROWS; ++j) { const u32 L = wbase + (u32)j * 64; tx[j] = (L < m) ? Xp[c[j] & 8191ull] : 0ull; }
             __syncthreads();
 #pragma unroll
-            for (int j = 0; j < ROWS; ++j) { const u32 L = wbase + (u32)j * 64; if (L < m) Xp[L] = t[j]; }
+            for (int j = 0; j < ROWS; ++j) { const u32 L = wbase + (u32)j * 64; if (L < m) Xp[L] = tx[j]; }
         }
     }
-    if (KW == 2 && !pure && (runs || PAIRS)) {                  // k2 follows
-        u64 t[ROWS];
+    if (k2_follows) {                                           // k2 follows
+        if constexpr (PRE && KW == 2) {                         // (every slot's old word has been read: they were requested up front)
 #pragma unroll
-        for (int j = 0; j < ROWS; ++j) { const u32 L = wbase + (u32)j * 64; t[j] = (L < m) ? K2[c[j] & 8191ull] : 0ull; }
-        __syncthreads();
+            for (int j = 0; j < ROWS; ++j) { const u32 L = wbase + (u32)j * 64; if (L < m) K2[L] = t[j]; }
+        } else {
 #pragma unroll
-        for (int j = 0; j < ROWS; ++j) { const u32 L = wbase + (u32)j * 64; if (L < m) K2[L] = t[j]; }
+            for (int j = 0; j < ROWS; ++j) { const u32 L = wbase + (u32)j * 64; t[j] = (L < m) ? K2[c[j] & 8191ull] : 0ull; }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j) { const u32 L = wbase + (u32)j * 64; if (L < m) K2[L] = t[j]; }
+        }
     }
     WLP(7);
     if (threadIdx.x == 0) {
@@ -1369,9 +1402,6 @@ int ws_sort_impl(Ctx& c, const WKeyGen* gen, u64* K1[2], u64* K2[2], u32* V[2], 
     if (PAIRS) flags = c.arena.get<u8>(n + 8);                 // (internal in this mode: run heads between the two leaf kernels)
     HIP_TRY(hipMemsetAsync(flags, 0, n, s));
 
-#ifdef TDC_EXP_OVERLAP
-    WSLevel expP; u32 exp_rows = 0, exp_grid = 0; bool exp_have = false;
-#endif
     // ---- partition levels ----
     u16* digits = pre ? pre->digits : c.arena.get<u16>(align_up(n, WS_TILE) + WS_TILE);
     const u32* seg_start = pre ? nullptr : ss_first_segment(c, n);
@@ -1491,10 +1521,6 @@ int ws_sort_impl(Ctx& c, const WKeyGen* gen, u64* K1[2], u64* K2[2], u32* V[2], 
             LAUNCH_CHECK();
             c.prof_end(ps);
         }
-#ifdef TDC_EXP_OVERLAP
-        if (last && !gl && !PAIRS && getenv("TDC_GPU_EXP_OVERLAP") && atoi(getenv("TDC_GPU_EXP_OVERLAP")) > 0 && P.F <= 256) { expP = P; exp_rows = rows; exp_grid = grid; exp_have = true; }
-        else
-#endif
         c.arena.release(lm2);
         seg_start = nstart;
         nseg = nseg * D;
@@ -1513,23 +1539,6 @@ int ws_sort_impl(Ctx& c, const WKeyGen* gen, u64* K1[2], u64* K2[2], u32* V[2], 
     A.k1 = K1[cur]; A.k2 = KW == 2 ? K2[cur] : nullptr; A.v = Vlast; A.unit_rng = U.unit_rng; A.flags = flags; A.lcp = lcp8;
     A.d_err = c.d_err; A.inv = g.b ? (65536u + (u32)g.b - 1) / (u32)g.b : 65536u;
     A.cmax = c.wsort_small ? 1u : (c.wsort_cmax < 1 ? 1u : (c.wsort_cmax > (int)WS_CMAX ? WS_CMAX : (u32)c.wsort_cmax));
-#ifdef TDC_EXP_OVERLAP
-    static hipEvent_t exp_e0 = nullptr, exp_e1 = nullptr;
-    int exp_mode = 0;
-    if (exp_have) {
-        static char* dummy = nullptr; static size_t dummy_n = 0;
-        if (dummy_n < n) { if (dummy) (void)hipFree(dummy); HIP_TRY(hipMalloc((void**)&dummy, 20 * n + 4096)); dummy_n = n; }
-        if (!exp_e0) { HIP_TRY(hipEventCreateWithFlags(&exp_e0, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&exp_e1, hipEventDisableTiming)); }
-        exp_mode = atoi(getenv("TDC_GPU_EXP_OVERLAP"));
-        const int reps = getenv("TDC_GPU_EXP_REPS") ? atoi(getenv("TDC_GPU_EXP_REPS")) : 3;
-        WSLevel P2 = expP;
-        P2.k1_out = (u64*)dummy; P2.k2_out = (u64*)(dummy + 8 * n); P2.v_out = (u32*)(dummy + 16 * n);
-        hipStream_t s2 = exp_mode == 1 ? c.copy_stream : s;
-        if (exp_mode == 1) { HIP_TRY(hipEventRecord(exp_e0, s)); HIP_TRY(hipStreamWaitEvent(s2, exp_e0, 0)); }
-        for (int r = 0; r < reps; ++r) { ws_scatter_kernel<KW, false, true, 256><<<exp_grid, 256, 0, s2>>>(P2, g, exp_rows); LAUNCH_CHECK(); }
-        if (exp_mode == 1) HIP_TRY(hipEventRecord(exp_e1, s2));
-    }
-#endif
     {
         // Stage 0: the units of the leaves.  Kernel A sorts every unit by its first differing word; the counting kernel orders the runs
         // that are left (<= 256 members) by the next word and hands longer runs back as the units of the next stage.
@@ -1653,9 +1662,6 @@ int ws_sort_impl(Ctx& c, const WKeyGen* gen, u64* K1[2], u64* K2[2], u32* V[2], 
             st->leaf_stages = (u32)stage + 1;
         }
     }
-#ifdef TDC_EXP_OVERLAP
-    if (exp_have && exp_mode == 1) HIP_TRY(hipStreamWaitEvent(s, exp_e1, 0));
-#endif
     if (nlarge) {                                              // leaves above the workgroup capacity: LSD sort, one by one
         if (nlarge > U.large_cap) throw HipError{hipErrorUnknown, "wide splitter sort: too many oversized leaves", (int)__LINE__};
         std::vector<u32> ll(nlarge), ls((size_t)nleaf + 1);
