@@ -255,6 +255,10 @@ size_t tdc_unescape(const uint8_t* in, size_t n, uint8_t* out);
 /* coders/HuffmanCoder.hpp:442-474 : canonical code for a literal histogram (for tests of the host table builder) */
 int tdc_huffman_table(const uint32_t counts[256], uint32_t* sigma, uint32_t* longest, uint8_t order[256],
                       uint8_t len_of[256], uint64_t code_of[256]);
+/* compressors/LZ78Compressor.hpp:97-131 : the LZ78 parse on its own (host; what tdc_gpu_lz78_compress codes on the device).
+ * ids[k] = id of the longest dictionary phrase at the start of factor k (0: none; ids count from 1 in insertion order), chars[k] = the byte
+ * behind it, a leftover phrase at the end of the text as (parent id, last byte).  *ids / *chars are malloc'd (tdc_gpu_free). */
+int tdc_lz78_factors(const uint8_t* in, size_t n, uint32_t** ids, uint8_t** chars, size_t* z);
 /* The start-up check of tdc_gpu_ctx_create() on its own (no GPU): rebuilds two built-in fixture tables (sigma 40 and 200, many
  * equal counts) and compares them with what the reference build yields; TDC_GPU_ERR_INTERNAL if this build's C++ library
  * orders ties differently (coders/HuffmanCoder.hpp:88-120 heap functions, :455 unstable std::sort) -- every call with

@@ -91,3 +91,29 @@ def test_block_container_through_the_command_line(tmp_path):
     bad[20] ^= 0xFF                                # directory entry
     (tmp_path / "bad.tdc").write_bytes(b"lcpcomp(coder=huff,threshold=2)%" + bytes(bad))
     assert subprocess.call([TDC, "-d", "-f", "-o", str(tmp_path / "x"), str(tmp_path / "bad.tdc")], stderr=subprocess.DEVNULL) == 1
+
+
+def test_lz78_host_parse_matches_oracle():
+    """The host LZ78 parse (csrc/lz78_host.cpp: nodes placed at the hash of the string they spell, the slots of a phrase's next depths
+    requested ahead) against the oracle's trie walk (compressors/LZ78Compressor.hpp:97-131; the reference's own vector is in
+    test_oracle.py): identical (id, char) pairs incl. the leftover phrase, on edge cases, small alphabets (long phrases, window
+    top-ups), table growth and texts."""
+    import random
+    rng = random.Random(1)
+
+    def check(d, name):
+        gi, gc = T.lz78_factors(d)
+        wi, wc = O.lz78_factors(bytes(d))
+        assert len(gi) == len(wi), (name, len(gi), len(wi))
+        assert (gi == wi).all() and bytes(gc) == bytes(wc), name
+
+    for i, d in enumerate([b"", b"a", b"aa", b"ab", b"abab" * 10, b"a" * 1000, bytes(range(256)) * 3, b"abcabcabcabd" * 50, b"\xff\x00" * 70]):
+        check(d, "case%d" % i)
+    for t in range(200):
+        n = rng.randrange(1, 5000)
+        sig = rng.choice([1, 2, 3, 4, 26, 256])
+        check(bytes(rng.randrange(sig) for _ in range(n)), "rand%d" % t)
+    check(T.gen_english(1 << 20, 7).tobytes(), "english")
+    check(T.gen_dna(1 << 20, 7).tobytes(), "dna")
+    check(b"a" * 300000, "run")                                    # phrases of up to 774 bytes: the window is topped up hundreds of times
+    check(bytes(rng.randrange(256) for _ in range(200000)), "random bytes")   # z ~ n / 2.3: the table grows

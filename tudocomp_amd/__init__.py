@@ -78,6 +78,22 @@ def gen_dna(n, seed=7, out=None):
     return out[:n]
 
 
+def lz78_factors(data):
+    """The LZ78 parse on its own (host; compressors/LZ78Compressor.hpp:97-131): (ids, chars) as numpy arrays."""
+    L = _native.load()
+    a = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, dtype=np.uint8)
+    ids, ch, z = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_size_t()
+    rc = L.tdc_lz78_factors(_ptr(a) if len(a) else None, len(a), ctypes.byref(ids), ctypes.byref(ch), ctypes.byref(z))
+    if rc:
+        raise TdcGpuError(rc)
+    try:
+        i = np.ctypeslib.as_array(ctypes.cast(ids, ctypes.POINTER(ctypes.c_uint32)), (max(z.value, 1),))[:z.value].copy()
+        c = np.ctypeslib.as_array(ctypes.cast(ch, ctypes.POINTER(ctypes.c_uint8)), (max(z.value, 1),))[:z.value].copy()
+    finally:
+        L.tdc_gpu_free(ids); L.tdc_gpu_free(ch)
+    return i, c
+
+
 def huffman_table(counts):
     L = _native.load()
     C = np.ascontiguousarray(counts, dtype=np.uint32)

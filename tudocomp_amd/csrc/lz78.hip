@@ -2,8 +2,7 @@
 // (coders/EliasGammaCoder.hpp:26-29, io/BitOStream.hpp:105-129); BASELINE.json configs[3].
 //
 // The LZ78 parse is inherently sequential (every step depends on the whole dictionary so far), so it stays on the
-// host (option a): a hashed (parent, byte) -> child dictionary instead of the reference's trie
-// back-ends -- all of them yield identical factor ids by contract (test/lz78_trie_tests.cpp:61-100).
+// host (option a; lz78_host.cpp).
 // The coder side is data-parallel and runs on the GPU with the same cost / scan / pack scheme as encode.hip:
 // gamma(v) = bits_for(v) zeros, "1", v in bits_for(v) bits; pair i contributes gamma(id_i) gamma(c_i).
 #include "stages.hpp"
@@ -12,84 +11,10 @@
 #include <vector>
 #include <stdlib.h>
 #include <string.h>
-#include <sys/mman.h>
-#include <new>
 
 namespace tdc {
 
-// ---- host: LZ78 parse ------------------------------------------------------------------------------------------
-namespace {
-struct PhraseTable {                 // open addressing: key = (parent << 8 | byte) + 1, value = child id
-    struct Slot { u64 key; u32 val; u32 pad; };          // key and value in one 16-byte slot: a step down the trie is ONE cache miss
-    // the table of a 1 GB input is gigabytes large and every step lands on a random page: huge pages where the kernel grants them
-    struct Buf {
-        Slot* p = nullptr; size_t n = 0;
-        ~Buf() { free(p); }
-        void alloc(size_t count) {
-            free(p); p = nullptr; n = count;
-            const size_t bytes = (count * sizeof(Slot) + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
-            p = (Slot*)aligned_alloc((size_t)2 << 20, bytes);
-            if (!p) throw std::bad_alloc();
-#ifdef MADV_HUGEPAGE
-            (void)madvise(p, bytes, MADV_HUGEPAGE);
-#endif
-            memset(p, 0, count * sizeof(Slot));
-        }
-        Slot& operator[](size_t i) { return p[i]; }
-        const Slot& operator[](size_t i) const { return p[i]; }
-        size_t size() const { return n; }
-        void swap(Buf& o) { std::swap(p, o.p); std::swap(n, o.n); }
-    } slots;
-    u64 mask = 0;
-    size_t used = 0;
-    void init(size_t cap_pow2) { slots.alloc(cap_pow2); mask = cap_pow2 - 1; used = 0; }
-    static u64 hash(u64 k) { k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33; return k; }
-    void grow() {
-        Buf os; os.swap(slots);
-        init((mask + 1) * 2);
-        for (size_t i = 0; i < os.size(); ++i) if (os[i].key) insert(os[i].key, os[i].val);
-    }
-    void insert(u64 key, u32 val) {
-        u64 h = hash(key) & mask;
-        while (slots[h].key) h = (h + 1) & mask;
-        slots[h].key = key; slots[h].val = val; ++used;
-    }
-    // returns child id or 0xFFFFFFFF
-    u32 find(u64 key) const {
-        u64 h = hash(key) & mask;
-        while (slots[h].key) { if (slots[h].key == key) return slots[h].val; h = (h + 1) & mask; }
-        return NONE32;
-    }
-};
-}  // namespace
-
-size_t lz78_parse_host(const u8* in, size_t n, std::vector<u32>& ids, std::vector<u8>& chars, bool* leftover_is_high) {
-    ids.clear(); chars.clear();
-    if (leftover_is_high) *leftover_is_high = false;
-    PhraseTable tab;
-    size_t cap = 1024;
-    while (cap < n / 4 + 16) cap <<= 1;
-    tab.init(cap);
-    u32 next_id = 1;                                   // root = 0, ids in insertion order from 1 (LZ78Compressor.hpp:78-84)
-    u32 node = 0, parent = 0;
-    u8 c = 0;
-    for (size_t i = 0; i < n; ++i) {                   // :97-121
-        c = in[i];
-        const u64 key = (((u64)node << 8) | c) + 1;
-        const u32 child = tab.find(key);
-        if (child == NONE32) {
-            if (tab.used * 2 >= tab.mask) tab.grow();
-            tab.insert(key, next_id++);
-            ids.push_back(node); chars.push_back(c);   // encode(node.id(), Range(factor_count)); encode(c, literal_r)  :101-102
-            parent = node = 0;
-        } else { parent = node; node = child; }
-    }
-    if (node != 0) {                                   // :124-131 leftover phrase: (parent.id(), c)
-        ids.push_back(parent); chars.push_back(c);
-        if (leftover_is_high && c >= 0x80) *leftover_is_high = true;   // the reference passes a signed char here
-    }
-    return ids.size();
-}
+// (the LZ78 parse itself: lz78_host.cpp)
 
 // ---- device: gamma coding of the (id, char) pairs --------------------------------------------------------------
 constexpr int G_PER_THREAD = 8;
