@@ -81,6 +81,15 @@ typedef struct {
 /* ---- context -------------------------------------------------------------------------------------------- */
 int  tdc_gpu_ctx_create(int device, tdc_gpu_ctx** ctx);
 void tdc_gpu_ctx_destroy(tdc_gpu_ctx* ctx);
+/* Options (round 6).  The library's defaults are the product; every switch that tests, A/B measurements and diagnostics need is an
+ * option of the context, set through this function and through nothing else: the library does not read TDC_GPU_* environment variables
+ * (an embedding process cannot change the algorithm by accident) -- unless TDC_GPU_DEBUG_KNOBS=1 is set, in which case
+ * tdc_gpu_ctx_create() applies every TDC_GPU_<OPTION NAME IN UPPER CASE> variable through this same function (development aid,
+ * tools/ab.sh).  `name`: an option name (README.md lists them; "wsort_min" and "TDC_GPU_WSORT_MIN" are the same option); out-of-range
+ * values are clamped.  TDC_GPU_ERR_ARG for an unknown name.  tdc_gpu_option_count / _name enumerate the table. */
+int tdc_gpu_ctx_set_option(tdc_gpu_ctx* ctx, const char* name, long value);
+int tdc_gpu_option_count(void);
+const char* tdc_gpu_option_name(int i);
 /* Pre-size the device arena for texts up to n bytes (optional; otherwise grown on demand). */
 int  tdc_gpu_ctx_reserve(tdc_gpu_ctx* ctx, size_t n);
 /* Device memory a context holds while it works on a text of n bytes (its arena; 112 bytes per text byte + 192 MiB), and what the
@@ -213,8 +222,10 @@ int tdc_gpu_flatten(tdc_gpu_ctx* ctx, size_t n, const uint32_t* pos, uint32_t* s
                     uint64_t* num_flattened, uint64_t* max_depth_lb);
 /* ---- LCPCompressor::decompress (LCPCompressor.hpp:140-150 -> decode_text_internal :23-76, HuffmanCoder::Decoder
  * coders/HuffmanCoder.hpp:572-612); lzss_lcp(coder=huff) streams have the same format (LZSSLCPCompressor.hpp:125-130).
- * The token stream is parsed on the host (it has no synchronisation points); the references -- what ScanDec / CompactDec
- * spend their time on (lcpcomp/decompress/ScanDec.hpp:146-247) -- are resolved on the device by pointer jumping.
+ * Streams of 1 MiB and more whose longest literal run is at most 512 are parsed ON THE DEVICE (rounds 4-5, DESIGN.md section 5: where
+ * the token that starts at a bit position ends is evaluated for every bit position, the real token starts are the orbit of the
+ * first one); smaller streams, longer literal runs and the SLE / ASCII coders take the host parse.  The references -- what ScanDec /
+ * CompactDec spend their time on (lcpcomp/decompress/ScanDec.hpp:146-247) -- are resolved on the device by pointer jumping.
  * *out (malloc'd, free with tdc_gpu_free) receives the escaped, 0-terminated text exactly as compress() was given it.
  * factors / rounds (nullable): number of factors in the stream / pointer-jumping rounds.  Malformed input: TDC_GPU_ERR_ARG. */
 int tdc_gpu_lcpcomp_decompress(tdc_gpu_ctx* ctx, const uint8_t* stream, size_t len, uint8_t** out, size_t* out_len,

@@ -21,17 +21,7 @@ pytestmark = pytest.mark.gpu
 def dev_ctx(request):
     """both markings of the device parse: the lean one (per-tile exits of the few possible entries; streams of short tokens -- the
     default for them) and the general one (next() / exits of every bit position; TDC_GPU_DEC_LEAN=0 gives it every stream)"""
-    want = {"TDC_GPU_DEC_PARSE": "2", "TDC_GPU_DEC_LEAN": "1" if request.param == "lean" else "0"}
-    old = {k: os.environ.get(k) for k in want}
-    os.environ.update(want)
-    try:
-        ctx = T.Context(0)
-    finally:
-        for k, v in old.items():
-            if v is None:
-                del os.environ[k]
-            else:
-                os.environ[k] = v
+    ctx = T.Context(0, options={"dec_parse": 2, "dec_lean": 1 if request.param == "lean" else 0})
     yield ctx
     ctx.close()
 
@@ -108,13 +98,10 @@ def test_large_stream_takes_the_device_parse_by_default(gpu_ctx):
 
 
 @pytest.mark.parametrize("lean", ["1", "0"])
-def test_streams_longer_than_one_segment(monkeypatch, lean):
+def test_streams_longer_than_one_segment(lean):
     """the chain marking runs in segments of bit positions (2^30 by default: streams above 128 MiB); with 20 000-bit segments a
     3 MB text takes hundreds of them -- the exit of one segment is the entry of the next"""
-    monkeypatch.setenv("TDC_GPU_DEC_PARSE", "2")
-    monkeypatch.setenv("TDC_GPU_DEC_LEAN", lean)
-    monkeypatch.setenv("TDC_GPU_DEC_SEG", "20000")
-    with T.Context(0) as ctx:
+    with T.Context(0, options={"dec_parse": 2, "dec_lean": int(lean), "dec_seg": 20000}) as ctx:
         for name, data, thr in (("english", T.gen_english(3_000_000, 4).tobytes(), 2), ("dna", T.gen_dna(1_000_000, 7).tobytes(), 5),
                                 ("small", b"abcabcabc hello hello abcabc", 2)):
             text = O.escape(data)

@@ -89,17 +89,8 @@ def test_compress_bitexact_random(gpu_ctx):
 
 
 def _ctx_env(env):
-    import os
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
-    try:
-        return T.Context(0)
-    finally:
-        for k, v in old.items():
-            if v is None:
-                del os.environ[k]
-            else:
-                os.environ[k] = v
+    """a context with these options (tdc_gpu_ctx_set_option: the library does not read the environment)"""
+    return T.Context(0, options=env)
 
 
 @pytest.mark.parametrize("mode", ["2", "2_norec", "2_slowread", "0"])
@@ -599,3 +590,91 @@ def test_device_decompress_sle_and_ascii(gpu_ctx):
             gpu_ctx.lcpcomp_decompress(bad, T.CODER_SLE)
     with pytest.raises(T.TdcGpuError):
         gpu_ctx.lcpcomp_decompress(b"12:x", T.CODER_ASCII)
+
+
+def test_poisoned_environment_does_not_change_the_library(monkeypatch):
+    """The shipped library reads no TDC_GPU_* option from the environment: with every algorithm switch set to its
+    non-default value in the environment -- and TDC_GPU_DEBUG_KNOBS not set -- a new context takes exactly the default paths (wide
+    suffix sort with level 1 behind the upload semantics, window pass, eager levels, device parse) and produces the oracle's stream.
+    With TDC_GPU_DEBUG_KNOBS=1 the same variables are applied (development aid), through the same function as explicit options."""
+    poison = {"TDC_GPU_WSORT": "0", "TDC_GPU_SSORT": "0", "TDC_GPU_EAGER": "0", "TDC_GPU_WINDOW_LCUT": "0", "TDC_GPU_ENC_EARLY": "0",
+              "TDC_GPU_PHI_LAZY": "0", "TDC_GPU_FLEN_BYTES": "0", "TDC_GPU_DEC_PARSE": "0", "TDC_GPU_FASTREAD": "0", "TDC_GPU_SA_REFINE": "0",
+              "TDC_GPU_WINDOW_FORCE_FAIL": "1", "TDC_GPU_WSORT_KW": "1", "TDC_GPU_BUCKET_SCATTER": "0", "TDC_GPU_RADIX_LDS": "0"}
+    monkeypatch.delenv("TDC_GPU_DEBUG_KNOBS", raising=False)
+    for k, v in poison.items():
+        monkeypatch.setenv(k, v)
+    data = T.gen_english(3_000_000, 42).tobytes()
+    text = O.escape(data)
+    want, _ = O.lcpcomp_huff_compress(text, 2, 1)
+    with T.Context(0) as plain:
+        got, st = plain.lcpcomp_compress(text, threshold=2, flatten=1)
+        assert got == want
+        assert st["window_pass"] == 1 and st["sa_key_words"] == 2, st          # the default paths, whatever the environment says
+        back, dst = plain.lcpcomp_decompress(got)
+        assert back == text and dst["device_parse"] == 1
+    monkeypatch.setenv("TDC_GPU_DEBUG_KNOBS", "1")
+    with T.Context(0) as dev:
+        got2, st2 = dev.lcpcomp_compress(text, threshold=2, flatten=1)
+        assert got2 == want
+        assert st2["window_pass"] == 0 and st2["sa_key_words"] != 2, st2        # now the variables count
+
+
+def test_options_api():
+    """tdc_gpu_ctx_set_option: every name of the table is accepted (with and without the TDC_GPU_ prefix, any case), unknown names are
+    refused, and an option set after creation takes effect on the next call."""
+    names = T.option_names()
+    assert len(names) >= 40 and len(set(names)) == len(names)
+    with T.Context(0) as ctx:
+        with pytest.raises(T.TdcGpuError):
+            ctx.set_option("no_such_option", 1)
+        text = O.escape(T.gen_english(1 << 21, 5).tobytes())
+        want, _ = O.lcpcomp_huff_compress(text, 2, 1)
+        a, sa_ = ctx.lcpcomp_compress(text, threshold=2, flatten=1)
+        ctx.set_option("TDC_GPU_WINDOW_LCUT", 0)
+        b, sb_ = ctx.lcpcomp_compress(text, threshold=2, flatten=1)
+        ctx.set_option("Window_Lcut", 48)
+        c, sc_ = ctx.lcpcomp_compress(text, threshold=2, flatten=1)
+        assert a == want and b == want and c == want
+        assert (sa_["window_pass"], sb_["window_pass"], sc_["window_pass"]) == (1, 0, 1)
+
+
+# every algorithm switch of the option table with its non-default values (diagnostic options -- *_log, eager_dump, small_prof, arena_log --
+# only print; dec_* are exercised by test_gpu_decode.py, ssort_levels / wsort_* in depth by test_gpu_sort.py / test_gpu_wsort.py)
+OPTION_VALUES = {
+    "fastread": [0], "sa_local": [0, 2], "radix_waves": [8], "window_lcut": [0, 20], "window_halo": [0], "window_force_fail": [1],
+    "window_large": [1], "plcp_samples": [0], "small_pipeline": [0], "small_big": [0], "phi_lazy": [0], "fs_pair": [0],
+    "enc_early": [0, 2], "enc_rec": [0], "level_purge": [0], "eager": [0], "flen_bytes": [0], "flatten_steps": [0, 4], "flatten_growth": [2],
+    "sa_refine": [0], "sa_pairs": [0], "sa_fused_init": [0], "sa_init_syms": [5], "radix_lds": [0, 2], "xcd_remap": [0, 2],
+    "bucket_scatter": [0], "ssort": [0], "ssort_levels": [2], "msd_partition": [0], "wsort": [0], "wsort_min": [4096], "wsort_syms": [19],
+    "wsort_kw": [1], "wsort_rounds": [0], "wsort_smallrun": [1], "wsort_overlap": [0], "wsort_fuse": [0], "wsort_order": [0],
+    "wsort_two": [2], "wsort_leaf": [1024], "wsort_pack": [1024, 4096], "wsort_cmax": [1, 64], "upload_chunks": [4, 24],
+    "dec_seg": [1 << 20], "dec_lean": [0], "dec_parse": [0, 2], "dec_done": [0],
+}
+
+
+def test_every_option_value_is_bit_exact(gpu_ctx):
+    """One named test for every switch of the library: each option of tdc_gpu_ctx_set_option's table, at each of its
+    non-default values, compresses an English-like text (wide suffix sort, window pass) and a DNA text with copied blocks (doubling
+    fall-back, eager levels, one-workgroup levels) to the oracle's stream and decompresses it again; the options that only matter for
+    host-buffer calls of 2^26 bytes and more are compared with the default context on such a text."""
+    names = set(T.option_names())
+    diag = {n for n in names if n.endswith("_log")} | {"eager_dump", "small_prof"}
+    assert names - diag == set(OPTION_VALUES), sorted((names - diag) ^ set(OPTION_VALUES))
+    rng = np.random.default_rng(3)
+    blk = bytes(rng.integers(0, 4, 40_000, dtype=np.uint8).astype(np.uint8) + 65)
+    texts = [O.escape(T.gen_english(3_000_000, 17).tobytes()),
+             O.escape(T.gen_dna(1_200_000, 5).tobytes() + blk + b"#" + blk[100:30_000] + T.gen_dna(300_000, 6).tobytes() + blk[5_000:])]
+    wants = [O.lcpcomp_huff_compress(t, 2, 1)[0] for t in texts]
+    big = np.concatenate([T.gen_english((1 << 26) + 4321, 3), np.zeros(1, dtype=np.uint8)])
+    big_want, _ = gpu_ctx.lcpcomp_compress(big, threshold=2, flatten=1)
+    for name, values in sorted(OPTION_VALUES.items()):
+        for v in values:
+            with T.Context(0, options={name: v}) as ctx:
+                for t, w in zip(texts, wants):
+                    got, st = ctx.lcpcomp_compress(t, threshold=2, flatten=1)
+                    assert got == w, (name, v)
+                    back, _ = ctx.lcpcomp_decompress(got)
+                    assert back == t, (name, v)
+                if name in ("upload_chunks", "wsort_overlap", "xcd_remap", "wsort_two"):
+                    got, _ = ctx.lcpcomp_compress(big, threshold=2, flatten=1)
+                    assert got == big_want, (name, v)

@@ -54,16 +54,7 @@ def test_round_sort_choice_on_large_groups(gpu_ctx, ctx_plain, ctx_global_rounds
 
 
 def _ctx_with(var, value):
-    import os
-    old = os.environ.get(var)
-    os.environ[var] = value
-    try:
-        return T.Context(0)
-    finally:
-        if old is None:
-            del os.environ[var]
-        else:
-            os.environ[var] = old
+    return T.Context(0, options={var: value})
 
 
 @pytest.fixture(scope="module")

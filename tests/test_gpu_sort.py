@@ -44,22 +44,13 @@ def _check(ctx, keys, algo):
 @pytest.mark.parametrize("levels", [0, 1, 2, 3])
 def test_splitter_sort_vs_numpy(levels):
     rng = np.random.default_rng(1234 + levels)
-    old = os.environ.get("TDC_GPU_SSORT_LEVELS")
-    if levels:
-        os.environ["TDC_GPU_SSORT_LEVELS"] = str(levels)
-    try:
-        with T.Context(0) as ctx:
-            sizes = (1, 2, 777, 5000, 70001, (1 << 20) + 123) if levels in (0, 1) else (4096, 70001, (1 << 20) + 123, 3_000_001)
-            for n in sizes:
-                if levels == 1 and n > 300000:
-                    continue                                     # one level: at most 256 range leaves of <= 8192 pairs
-                for name, keys in _cases(n, rng):
-                    _check(ctx, keys, 1)
-    finally:
-        if old is None:
-            os.environ.pop("TDC_GPU_SSORT_LEVELS", None)
-        else:
-            os.environ["TDC_GPU_SSORT_LEVELS"] = old
+    with T.Context(0, options={"ssort_levels": levels} if levels else None) as ctx:
+        sizes = (1, 2, 777, 5000, 70001, (1 << 20) + 123) if levels in (0, 1) else (4096, 70001, (1 << 20) + 123, 3_000_001)
+        for n in sizes:
+            if levels == 1 and n > 300000:
+                continue                                     # one level: at most 256 range leaves of <= 8192 pairs
+            for name, keys in _cases(n, rng):
+                _check(ctx, keys, 1)
 
 
 def test_lsd_sort_vs_numpy(gpu_ctx):
@@ -73,23 +64,15 @@ def test_lsd_sort_vs_numpy(gpu_ctx):
 def test_suffix_array_pipeline_with_forced_levels(levels):
     """the suffix array's initial sort (keys computed from the text) and the sorts of the doubling rounds through the
     splitter sort with 2 / 3 partition levels: stream byte-identical to the oracle's"""
-    old = os.environ.get("TDC_GPU_SSORT_LEVELS")
-    os.environ["TDC_GPU_SSORT_LEVELS"] = str(levels)
-    try:
-        with T.Context(0) as ctx:
-            for gen, n, thr in (("english", 1 << 22, 2), ("dna", (1 << 21) + 17, 5)):
-                data = (T.gen_english(n, 42) if gen == "english" else T.gen_dna(n, 7)).tobytes()
-                text = O.escape(data)
-                want, _ = O.lcpcomp_huff_compress(text, thr, 1)
-                got, st = ctx.lcpcomp_compress(text, thr, 1)
-                assert got == want, (gen, levels)
-            # a text that is one long run plus noise: almost all keys of the initial sort are equal
-            data = b"a" * 1500000 + bytes(np.random.default_rng(5).integers(97, 101, size=600000, dtype=np.uint8))
+    with T.Context(0, options={"ssort_levels": levels}) as ctx:
+        for gen, n, thr in (("english", 1 << 22, 2), ("dna", (1 << 21) + 17, 5)):
+            data = (T.gen_english(n, 42) if gen == "english" else T.gen_dna(n, 7)).tobytes()
             text = O.escape(data)
-            sa, isa = ctx.suffix_array(text)
-            assert np.array_equal(sa, O.suffix_array(text))
-    finally:
-        if old is None:
-            os.environ.pop("TDC_GPU_SSORT_LEVELS", None)
-        else:
-            os.environ["TDC_GPU_SSORT_LEVELS"] = old
+            want, _ = O.lcpcomp_huff_compress(text, thr, 1)
+            got, st = ctx.lcpcomp_compress(text, thr, 1)
+            assert got == want, (gen, levels)
+        # a text that is one long run plus noise: almost all keys of the initial sort are equal
+        data = b"a" * 1500000 + bytes(np.random.default_rng(5).integers(97, 101, size=600000, dtype=np.uint8))
+        text = O.escape(data)
+        sa, isa = ctx.suffix_array(text)
+        assert np.array_equal(sa, O.suffix_array(text))

@@ -39,20 +39,12 @@ TEXTS = _texts()
 
 @pytest.fixture(scope="module")
 def ctx_for():
-    """Contexts per TDC_GPU_WINDOW_LCUT value (the knob is read when a context is created)."""
+    """Contexts per window_lcut value (option of the context)."""
     made = {}
 
     def get(lcut):
         if lcut not in made:
-            old = os.environ.get("TDC_GPU_WINDOW_LCUT")
-            os.environ["TDC_GPU_WINDOW_LCUT"] = str(lcut)
-            try:
-                made[lcut] = T.Context(0)
-            finally:
-                if old is None:
-                    del os.environ["TDC_GPU_WINDOW_LCUT"]
-                else:
-                    os.environ["TDC_GPU_WINDOW_LCUT"] = old
+            made[lcut] = T.Context(0, options={"window_lcut": lcut})
         return made[lcut]
     yield get
     for c in made.values():
@@ -83,7 +75,7 @@ def test_window_levels_match_oracle(ctx_for, name, data):
     assert seen & {1, 2}, "the window pass never ran"
 
 
-def test_smallest_halo_and_retry_with_the_largest(monkeypatch):
+def test_smallest_halo_and_retry_with_the_largest():
     """The borders of a window's known range only move where an unknown factor can exist, so the first attempt runs with a small
     halo (TDC_GPU_WINDOW_HALO; clamped to 2 * lcut + 64) and a failed border retries with the largest one.  Both outcomes must
     give the oracle's factors: texts whose repeats are longer than the halo force the retry."""
@@ -92,9 +84,7 @@ def test_smallest_halo_and_retry_with_the_largest(monkeypatch):
     texts = [("english", T.gen_english(1 << 19, 3).tobytes()),
              ("periodic", (unit * 2000)[:200000] + bytes(rng.integers(97, 123, 70000, dtype=np.uint8))),
              ("mutated", b"".join(bytes([c if rng.random() > 0.002 else 120 for c in unit]) for _ in range(1500)))]
-    monkeypatch.setenv("TDC_GPU_WINDOW_HALO", "0")
-    monkeypatch.setenv("TDC_GPU_WINDOW_LCUT", "48")
-    with T.Context(0) as ctx:
+    with T.Context(0, options={"window_halo": 0, "window_lcut": 48}) as ctx:
         for name, data in texts:
             text = O.escape(data)
             for thr in (2, 5):
@@ -195,11 +185,10 @@ def test_extreme_repeat_structure(gpu_ctx):
                 assert dt < 1.5, "%s comp=%d: %.2f s (a level-by-level walk over the ramp)" % (name, comp, dt)
 
 
-def test_large_lists_give_the_same_factors(monkeypatch):
+def test_large_lists_give_the_same_factors():
     """TDC_GPU_WINDOW_LARGE=1: the window pass starts with the large per-level lists (one workgroup per CU).  Texts with one crowded
     level overflow the small lists and end up there by themselves; here every text is forced through them."""
-    monkeypatch.setenv("TDC_GPU_WINDOW_LARGE", "1")
-    with T.Context(0) as ctx:
+    with T.Context(0, options={"window_large": 1}) as ctx:
         for name, data in TEXTS[:7] + [("dna_1M", T.gen_dna(1 << 20, 3).tobytes())]:
             text = O.escape(data)
             for thr in (2, 5):
@@ -209,12 +198,11 @@ def test_large_lists_give_the_same_factors(monkeypatch):
                 assert got == want, "%s t=%d (window_pass %d)" % (name, thr, st["window_pass"])
 
 
-def test_discarded_window_pass_falls_back_to_the_level_loop(monkeypatch):
+def test_discarded_window_pass_falls_back_to_the_level_loop():
     """TDC_GPU_WINDOW_FORCE_FAIL=1: every window pass is discarded as if a border had failed, the global level loop evaluates the low
     levels from the residence bytes.  On a text that takes the fused ISA / PLCP scatter without a Phi array (1 MiB and more, no deep
     repeats) the sources of those levels' factors must then come from SA[ISA[p] - 1] saved by cand_rebuild_class_kernel."""
-    monkeypatch.setenv("TDC_GPU_WINDOW_FORCE_FAIL", "1")
-    with T.Context(0) as ctx:
+    with T.Context(0, options={"window_force_fail": 1}) as ctx:
         for name, data, thr in (("english_3M", T.gen_english(3_000_000, 12).tobytes(), 2), ("english_1.5M_t5", T.gen_english(1_500_000, 13).tobytes(), 5)):
             text = O.escape(data)
             for fl in (1, 0):

@@ -19,16 +19,8 @@ pytestmark = pytest.mark.gpu
 
 
 def _ctx_env(env):
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
-    try:
-        return T.Context(0)
-    finally:
-        for k, v in old.items():
-            if v is None:
-                del os.environ[k]
-            else:
-                os.environ[k] = v
+    """a context with these options (tdc_gpu_ctx_set_option: the library does not read the environment)"""
+    return T.Context(0, options=env)
 
 
 VARIANTS = {

@@ -3,7 +3,7 @@
 # prints value, stage times and the top kernel classes for every setting
 for cfg in "$@"; do
   echo "== $cfg"
-  env $cfg python bench.py --steps 2 --warmup 1 --no-cpu-baseline ${BENCH_ARGS} 2>>gpurun_out/ab_stderr.log | python3 -c '
+  env TDC_GPU_DEBUG_KNOBS=1 $cfg python bench.py --steps 2 --warmup 1 --no-cpu-baseline ${BENCH_ARGS} 2>>gpurun_out/ab_stderr.log | python3 -c '
 import json,sys
 j=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print("value",j["value"],"ms",j["ms_per_step"])

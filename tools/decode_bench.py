@@ -1,5 +1,6 @@
 """Decompression timing: tdc_gpu_lcpcomp_decompress on the stream of a synthetic text, token stream parsed on the
 host (TDC_GPU_DEC_PARSE=0) vs on the device (default).  Usage: python3 tools/decode_bench.py [english|dna] [N] [threshold]"""
+import os; os.environ.setdefault("TDC_GPU_DEBUG_KNOBS", "1")   # (development tool: the TDC_GPU_* variables below are applied -- include/tdc_gpu.h, options)
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

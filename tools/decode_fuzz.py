@@ -2,6 +2,7 @@
 truncations, spliced tails) and decoded with both markings of the device parse (lean / general, TDC_GPU_DEC_PARSE=2) and small segments;
 every call must either return a text or raise TdcGpuError(-2 / -5) -- never crash, hang or fault.  The undamaged streams must decode to
 their texts.  Usage: python3 tools/decode_fuzz.py [trials per text and mode]"""
+import os; os.environ.setdefault("TDC_GPU_DEBUG_KNOBS", "1")   # (development tool: the TDC_GPU_* variables below are applied -- include/tdc_gpu.h, options)
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

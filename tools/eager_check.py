@@ -1,5 +1,6 @@
 """Development aid: eager runs of small levels on / off on a synthetic text -- same stream, stage times.
 Usage: python3 tools/eager_check.py dna|english N [threshold] [arith|huff]"""
+import os; os.environ.setdefault("TDC_GPU_DEBUG_KNOBS", "1")   # (development tool: the TDC_GPU_* variables below are applied -- include/tdc_gpu.h, options)
 import os, sys, hashlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

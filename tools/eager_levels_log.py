@@ -2,7 +2,7 @@
 entries per level.  Usage: python3 tools/eager_levels_log.py [N]   (stderr of the library is parsed)"""
 import os, sys, subprocess, re, collections
 N = sys.argv[1] if len(sys.argv) > 1 else "268435456"
-env = dict(os.environ, TDC_GPU_LEVEL_LOG="1", TDC_GPU_EAGER_DUMP="1")
+env = dict(os.environ, TDC_GPU_DEBUG_KNOBS="1", TDC_GPU_LEVEL_LOG="1", TDC_GPU_EAGER_DUMP="1")
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 p = subprocess.run([sys.executable, os.path.join(root, "tools", "run_once.py"), "dna", N, "5", "arith"], env=env, capture_output=True, text=True)
 rows = []

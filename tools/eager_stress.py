@@ -2,6 +2,7 @@
 copied blocks (random block size, alphabet, mutation rate, copies of copies), long runs and periodic stretches mixed with random
 background -- hundreds to thousands of LCP levels each --, every stream compared byte for byte with the oracle's, eager runs on and off.
 Usage: python3 tools/eager_stress.py [seconds] [seed]"""
+import os; os.environ.setdefault("TDC_GPU_DEBUG_KNOBS", "1")   # (development tool: the TDC_GPU_* variables below are applied -- include/tdc_gpu.h, options)
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -94,6 +94,12 @@ def lz78_factors(data):
     return i, c
 
 
+def option_names():
+    """Names of the library's options (tdc_gpu_ctx_set_option)."""
+    L = _native.load()
+    return [L.tdc_gpu_option_name(i).decode() for i in range(L.tdc_gpu_option_count())]
+
+
 def huffman_table(counts):
     L = _native.load()
     C = np.ascontiguousarray(counts, dtype=np.uint32)
@@ -166,7 +172,9 @@ def host_unregister(a):
 class Context:
     """One GPU, one HIP stream, one device arena (tdc_gpu_ctx)."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, options=None):
+        """options: {name: value} applied through tdc_gpu_ctx_set_option ("wsort_min" or "TDC_GPU_WSORT_MIN": the same option) --
+        the way tests and A/B runs reach the library's switches; the environment is not read (include/tdc_gpu.h)."""
         self._L = _native.load()
         h = ctypes.c_void_p()
         rc = self._L.tdc_gpu_ctx_create(device, ctypes.byref(h))
@@ -174,6 +182,13 @@ class Context:
             raise TdcGpuError(rc, "tdc_gpu_ctx_create(device=%d)" % device)
         self._h = h
         self.device = device
+        for k, v in (options or {}).items():
+            self.set_option(k, v)
+
+    def set_option(self, name, value):
+        rc = self._L.tdc_gpu_ctx_set_option(self._h, str(name).encode(), int(value))
+        if rc:
+            raise TdcGpuError(rc, "unknown option %r" % (name,))
 
     def close(self):
         if getattr(self, "_h", None):

@@ -24,7 +24,7 @@ SYMBOLS = [
     "tdc_gpu_encode_ascii",
     "tdc_gpu_encode_sle",
     "tdc_gpu_lcpcomp_decompress_coder", "tdc_gpu_ctx_last_decode_on_device", "tdc_gpu_lcpcomp_decompress_into",
-    "tdc_escape", "tdc_unescape", "tdc_lz78_factors", "tdc_huffman_table", "tdc_huffman_selfcheck", "tdc_gpu_blocks_count", "tdc_gpu_blocks_compress", "tdc_gpu_blocks_decompress", "tdc_gpu_device_count", "tdc_gen_english", "tdc_gen_dna",
+    "tdc_gpu_ctx_set_option", "tdc_gpu_option_count", "tdc_gpu_option_name", "tdc_escape", "tdc_unescape", "tdc_lz78_factors", "tdc_huffman_table", "tdc_huffman_selfcheck", "tdc_gpu_blocks_count", "tdc_gpu_blocks_compress", "tdc_gpu_blocks_decompress", "tdc_gpu_device_count", "tdc_gen_english", "tdc_gen_dna",
     "tdc_gpu_arena_bytes", "tdc_gpu_device_memory",
     "tdc_gpu_lcpcomp_compress_keep", "tdc_gpu_stream_fetch", "tdc_gpu_stream_fetch_dev", "tdc_gpu_host_register", "tdc_gpu_host_unregister",
 ]
@@ -121,6 +121,10 @@ def load():
     L.tdc_unescape.argtypes = [vp, sz, vp]
     L.tdc_unescape.restype = sz
     L.tdc_lz78_factors.argtypes = [vp, sz, pvp, pvp, psz]
+    L.tdc_gpu_ctx_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_long]
+    L.tdc_gpu_option_count.argtypes = []
+    L.tdc_gpu_option_name.argtypes = [i32]
+    L.tdc_gpu_option_name.restype = ctypes.c_char_p
     L.tdc_huffman_table.argtypes = [vp, ctypes.POINTER(u32), ctypes.POINTER(u32), vp, vp, vp]
     L.tdc_gen_english.argtypes = [vp, sz, ctypes.c_uint64]
     L.tdc_gen_dna.argtypes = [vp, sz, ctypes.c_uint64]

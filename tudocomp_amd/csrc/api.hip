@@ -9,6 +9,8 @@
 #include <vector>
 #include <stdlib.h>
 #include <string.h>
+#include <strings.h>
+#include <ctype.h>
 
 using namespace tdc;
 
@@ -339,6 +341,99 @@ const char* tdc_gpu_last_error(const tdc_gpu_ctx* ctx) { return ctx ? ctx->last_
 
 void tdc_gpu_free(void* p) { free(p); }
 
+// ---- options ---------------------------------------------------------------------------------------------------------------------
+// Every switch of the library, in ONE table: name (the environment variable of the development aid is TDC_GPU_ + upper case), the
+// field, and the values it accepts (out-of-range values are clamped the way the environment parser of rounds 1-5 did).  README.md
+// lists them with the test that exercises each.
+namespace {
+struct OptionDef { const char* name; void (*set)(Ctx&, long); };
+inline int clampi(long v, long lo, long hi) { return (int)(v < lo ? lo : (v > hi ? hi : v)); }
+const OptionDef OPTIONS[] = {
+    { "fastread",         [](Ctx& c, long v) { c.fast_read = v ? 1 : 0; } },
+    { "sa_local",         [](Ctx& c, long v) { c.sa_local_sort = (int)v; } },
+    { "radix_waves",      [](Ctx& c, long v) { c.radix_waves = v == 8 ? 8 : 4; } },
+    { "window_lcut",      [](Ctx& c, long v) { c.window_lcut = clampi(v, 0, 63); } },
+    { "window_halo",      [](Ctx& c, long v) { c.window_halo = clampi(v, 0, 2048); } },
+    { "dec_seg",          [](Ctx& c, long v) { c.dec_seg = v < 4096 ? 4096 : (v > (1l << 30) ? (size_t)1 << 30 : (size_t)v); } },
+    { "dec_lean",         [](Ctx& c, long v) { c.dec_lean = v != 0; } },
+    { "dec_parse",        [](Ctx& c, long v) { c.dec_parse = clampi(v, 0, 2); } },
+    { "dec_done",         [](Ctx& c, long v) { c.dec_done = v != 0; } },
+    { "dec_log",          [](Ctx& c, long v) { c.dec_log = v != 0; } },
+    { "window_force_fail",[](Ctx& c, long v) { c.window_force_fail = v ? 1 : 0; } },
+    { "window_large",     [](Ctx& c, long v) { c.window_large_lists = v ? 1 : 0; } },
+    { "plcp_samples",     [](Ctx& c, long v) { c.plcp_samples = v != 0; } },
+    { "small_pipeline",   [](Ctx& c, long v) { c.small_pipeline = v != 0; } },
+    { "small_big",        [](Ctx& c, long v) { c.small_big = (int)v; } },
+    { "small_prof",       [](Ctx& c, long v) { c.small_prof = v != 0; } },
+    { "phi_lazy",         [](Ctx& c, long v) { c.phi_lazy = v != 0; } },
+    { "fs_pair",          [](Ctx& c, long v) { c.fs_pair = v != 0; } },
+    { "enc_early",        [](Ctx& c, long v) { c.enc_early = (int)v; } },
+    { "enc_rec",          [](Ctx& c, long v) { c.enc_rec = v != 0; } },
+    { "level_purge",      [](Ctx& c, long v) { c.level_purge = v != 0; } },
+    { "level_log",        [](Ctx& c, long v) { c.level_log = v != 0; } },
+    { "eager",            [](Ctx& c, long v) { c.eager_levels = v != 0; } },
+    { "eager_dump",       [](Ctx& c, long v) { c.eager_dump = v != 0; } },
+    { "flen_bytes",       [](Ctx& c, long v) { c.flen_bytes = v != 0; } },
+    { "flatten_steps",    [](Ctx& c, long v) { c.flatten_steps = v <= 0 ? (1 << 30) : clampi(v, 1, 1 << 30); } },
+    { "flatten_growth",   [](Ctx& c, long v) { c.flatten_growth = clampi(v, 2, 1 << 20); } },
+    { "sa_refine",        [](Ctx& c, long v) { c.sa_refine = v != 0; } },
+    { "sa_pairs",         [](Ctx& c, long v) { c.sa_pairs = v != 0; } },
+    { "sa_fused_init",    [](Ctx& c, long v) { c.sa_fused_init = v != 0; } },
+    { "sa_init_syms",     [](Ctx& c, long v) { c.sa_init_syms = clampi(v, 0, 64); } },
+    { "radix_lds",        [](Ctx& c, long v) { c.radix_lds = (v >= 0 && v <= 2) ? (int)v : 2; } },
+    { "xcd_remap",        [](Ctx& c, long v) { c.xcd_remap = (v >= 0 && v <= 2) ? (int)v : 0; } },
+    { "bucket_scatter",   [](Ctx& c, long v) { c.bucket_scatter = v ? 1 : 0; } },
+    { "ssort",            [](Ctx& c, long v) { c.ssort = v ? 1 : 0; } },
+    { "ssort_levels",     [](Ctx& c, long v) { c.ssort_levels = (v >= 1 && v <= 3) ? (int)v : 0; } },
+    { "msd_partition",    [](Ctx& c, long v) { c.msd_partition = v ? 1 : 0; } },
+    { "wsort",            [](Ctx& c, long v) { c.wsort = v ? 1 : 0; } },
+    { "wsort_min",        [](Ctx& c, long v) { c.wsort_min = v < 4096 ? 4096 : (size_t)v; } },
+    { "wsort_syms",       [](Ctx& c, long v) { c.wsort_syms = (v >= 4 && v <= 64) ? (int)v : 0; } },
+    { "wsort_kw",         [](Ctx& c, long v) { c.wsort_kw = (v == 1 || v == 2) ? (int)v : 0; } },
+    { "wsort_rounds",     [](Ctx& c, long v) { c.wsort_rounds = clampi(v, 0, 100); } },
+    { "wsort_smallrun",   [](Ctx& c, long v) { c.wsort_small = v ? 1 : 0; } },
+    { "wsort_overlap",    [](Ctx& c, long v) { c.wsort_overlap = v ? 1 : 0; } },
+    { "wsort_fuse",       [](Ctx& c, long v) { c.wsort_fuse = v ? 1 : 0; } },
+    { "wsort_order",      [](Ctx& c, long v) { c.wsort_order = v ? 1 : 0; } },
+    { "wsort_two",        [](Ctx& c, long v) { c.wsort_two = (v >= 0 && v <= 2) ? (int)v : 0; } },
+    { "wsort_leaf",       [](Ctx& c, long v) { c.wsort_leaf = v == 1024 ? 1024 : 2048; } },
+    { "wsort_pack",       [](Ctx& c, long v) { c.wsort_pack = (v == 1024 || v == 4096) ? (int)v : 2048; } },
+    { "wsort_cmax",       [](Ctx& c, long v) { c.wsort_cmax = clampi(v, 1, 64); } },
+    { "wsort_log",        [](Ctx& c, long v) { c.wsort_log = v != 0; } },
+    { "upload_chunks",    [](Ctx& c, long v) { c.upload_chunks = clampi(v, 4, 24); } },
+    { "arena_log",        [](Ctx& c, long v) { c.arena_log = v != 0; } },
+};
+constexpr size_t NOPTIONS = sizeof(OPTIONS) / sizeof(OPTIONS[0]);
+const OptionDef* find_option(const char* name) {
+    if (!name) return nullptr;
+    if (!strncasecmp(name, "TDC_GPU_", 8)) name += 8;
+    for (size_t i = 0; i < NOPTIONS; ++i) if (!strcasecmp(name, OPTIONS[i].name)) return &OPTIONS[i];
+    return nullptr;
+}
+// the ONE place that reads TDC_GPU_* variables (besides TDC_GPU_LIB of the Python loader, which picks the library file)
+void apply_env_options(tdc_gpu_ctx* ctx) {
+    const char* on = getenv("TDC_GPU_DEBUG_KNOBS");
+    if (!on || atoi(on) == 0) return;
+    for (size_t i = 0; i < NOPTIONS; ++i) {
+        char var[64] = "TDC_GPU_";
+        size_t k = 8;
+        for (const char* q = OPTIONS[i].name; *q && k + 1 < sizeof(var); ++q) var[k++] = (char)toupper((unsigned char)*q);
+        var[k] = 0;
+        if (const char* m = getenv(var)) OPTIONS[i].set(ctx->c, atol(m));
+    }
+}
+}  // namespace
+
+int tdc_gpu_ctx_set_option(tdc_gpu_ctx* ctx, const char* name, long value) {
+    if (!ctx) return TDC_GPU_ERR_ARG;
+    const OptionDef* o = find_option(name);
+    if (!o) return TDC_GPU_ERR_ARG;
+    o->set(ctx->c, value);
+    return TDC_GPU_OK;
+}
+int tdc_gpu_option_count(void) { return (int)NOPTIONS; }
+const char* tdc_gpu_option_name(int i) { return (i >= 0 && (size_t)i < NOPTIONS) ? OPTIONS[i].name : nullptr; }
+
 int tdc_gpu_ctx_create(int device, tdc_gpu_ctx** out) {
     if (!out) return TDC_GPU_ERR_ARG;
     *out = nullptr;
@@ -362,7 +457,6 @@ int tdc_gpu_ctx_create(int device, tdc_gpu_ctx** out) {
         for (auto& e : ctx->c.ev_copy) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         ctx->c.pinned_size = 4096;
         HIP_TRY(hipHostMalloc(&ctx->c.pinned, ctx->c.pinned_size, hipHostMallocDefault));
-        if (const char* m = getenv("TDC_GPU_FASTREAD")) ctx->c.fast_read = atoi(m) ? 1 : 0;
         if (ctx->c.fast_read) {
             void* zc = nullptr;
             if (hipHostMalloc(&zc, (size_t)Ctx::ZC_WORDS * Ctx::ZC_BLOCKS * 4, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
@@ -373,47 +467,10 @@ int tdc_gpu_ctx_create(int device, tdc_gpu_ctx** out) {
         }
         HIP_TRY(hipMalloc((void**)&ctx->c.d_err, 256));
         HIP_TRY(hipMemset(ctx->c.d_err, 0, 256));
-        if (const char* m = getenv("TDC_GPU_SA_LOCAL")) ctx->c.sa_local_sort = atoi(m);
-        if (const char* m = getenv("TDC_GPU_RADIX_WAVES")) ctx->c.radix_waves = (atoi(m) == 8) ? 8 : 4;
-        if (const char* m = getenv("TDC_GPU_WINDOW_LCUT")) { const int v = atoi(m); ctx->c.window_lcut = v < 0 ? 0 : (v > 63 ? 63 : v); }
-        if (const char* m = getenv("TDC_GPU_WINDOW_HALO")) { const int v = atoi(m); ctx->c.window_halo = v < 0 ? 0 : (v > 2048 ? 2048 : v); }
-        if (const char* m = getenv("TDC_GPU_DEC_SEG")) { const long v = atol(m); ctx->c.dec_seg = v < 4096 ? 4096 : (v > (1l << 30) ? (size_t)1 << 30 : (size_t)v); }
-        if (const char* m = getenv("TDC_GPU_DEC_LEAN")) ctx->c.dec_lean = atoi(m) != 0;
-        if (const char* m = getenv("TDC_GPU_DEC_PARSE")) { const int v = atoi(m); ctx->c.dec_parse = v < 0 ? 0 : (v > 2 ? 2 : v); }
-        if (const char* m = getenv("TDC_GPU_WINDOW_FORCE_FAIL")) ctx->c.window_force_fail = atoi(m) ? 1 : 0;
-        if (const char* m = getenv("TDC_GPU_WINDOW_LARGE")) ctx->c.window_large_lists = atoi(m) ? 1 : 0;
-        if (const char* m = getenv("TDC_GPU_PLCP_SAMPLES")) ctx->c.plcp_samples = atoi(m) != 0;
-        if (const char* m = getenv("TDC_GPU_SMALL_PIPELINE")) ctx->c.small_pipeline = atoi(m) != 0;
-        if (const char* m = getenv("TDC_GPU_SMALL_BIG")) ctx->c.small_big = atoi(m);
-        if (const char* m = getenv("TDC_GPU_PHI_LAZY")) ctx->c.phi_lazy = atoi(m) != 0;
-        if (const char* m = getenv("TDC_GPU_FS_PAIR")) ctx->c.fs_pair = atoi(m) != 0;
-        if (const char* m = getenv("TDC_GPU_ENC_EARLY")) ctx->c.enc_early = atoi(m);
-        if (const char* m = getenv("TDC_GPU_ENC_REC")) ctx->c.enc_rec = atoi(m) != 0;
-        if (const char* m = getenv("TDC_GPU_LEVEL_PURGE")) ctx->c.level_purge = atoi(m) != 0;
-        if (const char* m = getenv("TDC_GPU_EAGER")) ctx->c.eager_levels = atoi(m) != 0;
-        if (const char* m = getenv("TDC_GPU_FLEN_BYTES")) ctx->c.flen_bytes = atoi(m) != 0;
-        if (const char* m = getenv("TDC_GPU_SA_REFINE")) ctx->c.sa_refine = atoi(m) != 0;
-        if (const char* m = getenv("TDC_GPU_SA_PAIRS")) ctx->c.sa_pairs = atoi(m) != 0;
-        if (const char* m = getenv("TDC_GPU_SA_FUSED_INIT")) ctx->c.sa_fused_init = atoi(m) != 0;
-        if (const char* m = getenv("TDC_GPU_RADIX_LDS")) { const int v = atoi(m); ctx->c.radix_lds = (v >= 0 && v <= 2) ? v : 2; }
-        if (const char* m = getenv("TDC_GPU_XCD_REMAP")) { const int v = atoi(m); ctx->c.xcd_remap = (v >= 0 && v <= 2) ? v : 0; }
-        if (const char* m = getenv("TDC_GPU_BUCKET_SCATTER")) ctx->c.bucket_scatter = atoi(m) ? 1 : 0;
-        if (const char* m = getenv("TDC_GPU_SSORT")) ctx->c.ssort = atoi(m) ? 1 : 0;
-        if (const char* m = getenv("TDC_GPU_MSD_PARTITION")) ctx->c.msd_partition = atoi(m) ? 1 : 0;
-        if (const char* m = getenv("TDC_GPU_WSORT")) ctx->c.wsort = atoi(m) ? 1 : 0;
-        if (const char* m = getenv("TDC_GPU_WSORT_MIN")) { const long v = atol(m); ctx->c.wsort_min = v < 4096 ? 4096 : (size_t)v; }
-        if (const char* m = getenv("TDC_GPU_WSORT_SYMS")) { const int v = atoi(m); ctx->c.wsort_syms = (v >= 4 && v <= 64) ? v : 0; }
-        if (const char* m = getenv("TDC_GPU_WSORT_KW")) { const int v = atoi(m); ctx->c.wsort_kw = (v == 1 || v == 2) ? v : 0; }
-        if (const char* m = getenv("TDC_GPU_WSORT_ROUNDS")) { const int v = atoi(m); ctx->c.wsort_rounds = v < 0 ? 0 : (v > 100 ? 100 : v); }
-        if (const char* m = getenv("TDC_GPU_WSORT_SMALLRUN")) ctx->c.wsort_small = atoi(m) ? 1 : 0;
-        if (const char* m = getenv("TDC_GPU_WSORT_OVERLAP")) ctx->c.wsort_overlap = atoi(m) ? 1 : 0;
-        if (const char* m = getenv("TDC_GPU_WSORT_FUSE")) ctx->c.wsort_fuse = atoi(m) ? 1 : 0;
-        if (const char* m = getenv("TDC_GPU_WSORT_ORDER")) ctx->c.wsort_order = atoi(m) ? 1 : 0;
-        if (const char* m = getenv("TDC_GPU_WSORT_TWO")) { const int v = atoi(m); ctx->c.wsort_two = (v >= 0 && v <= 2) ? v : 0; }
-        if (const char* m = getenv("TDC_GPU_WSORT_LEAF")) ctx->c.wsort_leaf = atoi(m) == 1024 ? 1024 : 2048;
-        if (const char* m = getenv("TDC_GPU_WSORT_PACK")) { const int v = atoi(m); ctx->c.wsort_pack = (v == 1024 || v == 4096) ? v : 2048; }
-        if (const char* m = getenv("TDC_GPU_WSORT_CMAX")) { const int v = atoi(m); ctx->c.wsort_cmax = v < 1 ? 1 : (v > 64 ? 64 : v); }
-        if (const char* m = getenv("TDC_GPU_SSORT_LEVELS")) { const int v = atoi(m); ctx->c.ssort_levels = (v >= 1 && v <= 3) ? v : 0; }
+        // Development aid: with TDC_GPU_DEBUG_KNOBS=1 every TDC_GPU_<OPTION> variable of the environment is applied through
+        // tdc_gpu_ctx_set_option().  Without it the library never reads an option from the environment: an embedding process cannot change
+        // the algorithm by accident.
+        apply_env_options(ctx);
     } catch (const HipError&) {
         (void)hipGetLastError();
         tdc_gpu_ctx_destroy(ctx);
@@ -566,7 +623,7 @@ void compress_host(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, bool raw, ui
             HIP_TRY(hipEventRecord(c.ev_copy[8], c.stream));                   // (the copy stream starts behind whatever the compute stream did before)
             HIP_TRY(hipStreamWaitEvent(c.copy_stream, c.ev_copy[8], 0));
             const bool try_pre = c.wsort_overlap && c.wpre && wsort_applicable(c, n);
-            const size_t CH = try_pre ? (getenv("TDC_GPU_UPLOAD_CHUNKS") ? (size_t)std::min(24, std::max(4, atoi(getenv("TDC_GPU_UPLOAD_CHUNKS")))) : 16) : 8;      // (at most 24: ev_copy[16 ..])
+            const size_t CH = try_pre ? (size_t)c.upload_chunks : 8;      // (at most 24: ev_copy[16 ..])
             // Chunk boundaries (multiples of 4096).  With level 1 behind the copies the last three chunks shrink geometrically (0.6, 0.36,
             // 0.22 of the others): level 1 of a chunk runs 1.7 x as fast as its copy, so each of them is done before the next, shorter copy
             // ends, and what is left behind the last copy is the level 1 of a fifth of a chunk.

@@ -173,6 +173,15 @@ struct Ctx {
     int wsort_small = 0;           // tests: 1 = every run of a leaf unit counts as "big" (the chunk iterations run everywhere) (env TDC_GPU_WSORT_SMALLRUN)
     int msd_partition = 1;         // bucketed scatter: MSD partition with atomic slots instead of two stable LSD passes (env TDC_GPU_MSD_PARTITION=0)
     int bucket_scatter = 1;        // big random scatters (rank, Phi) go through one radix partition by destination window (env TDC_GPU_BUCKET_SCATTER=0 disables)
+    // (the options below used to be read from the environment wherever they were used; since round 6 every option is a field that only
+    //  tdc_gpu_ctx_set_option() writes -- api.hip, one table -- and the shipped library never looks at TDC_GPU_* variables unless
+    //  TDC_GPU_DEBUG_KNOBS=1 asks tdc_gpu_ctx_create() to apply them through that same function)
+    int upload_chunks = 16;        // chunks of the overlapped upload (4 .. 24: ev_copy[16 ..]; option upload_chunks)
+    int flatten_steps = 1;         // flatten: chain steps per factor in the first round (0: unlimited; measured: 1,2,4,.. 8.5 ms; unlimited 11.2 ms)
+    int flatten_growth = 8;        // ... and the factor the budget grows by per round (measured at 256 MiB: x2 8.4 ms, x4 7.4 ms, x8 7.0 ms)
+    int sa_init_syms = 0;          // classic suffix sort: cap on the symbols of the initial key (0: as many as 64 bits hold; tuning)
+    int dec_done = 1;              // decompression: final-bit mask in the pointer-jumping rounds (0: A/B switch)
+    int dec_log = 0, level_log = 0, wsort_log = 0, eager_dump = 0, small_prof = 0, arena_log = 0;   // diagnostics on stderr
 
     // overlapped D2H of the compressed stream (end-to-end entry point with a caller buffer): while the pack kernel works on the
     // later tiles, the finished front part of the stream already travels to the host on a second stream
@@ -226,7 +235,7 @@ struct Ctx {
         if (arena.size >= bytes) { arena.top = 0; return; }
         if (arena.base) { HIP_TRY(hipFree(arena.base)); arena.base = nullptr; arena.size = 0; }
         HIP_TRY(hipMalloc((void**)&arena.base, bytes));
-        if (getenv("TDC_GPU_ARENA_LOG")) fprintf(stderr, "arena: %zu bytes at %p\n", bytes, (void*)arena.base);
+        if (arena_log) fprintf(stderr, "arena: %zu bytes at %p\n", bytes, (void*)arena.base);
         arena.size = bytes;
         arena.top = 0;
     }

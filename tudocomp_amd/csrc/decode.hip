@@ -710,7 +710,7 @@ static u8* decode_dest(DecodeOut& o, size_t n) {
 static void resolve_and_download(Ctx& c, size_t n, u8* d_text, u32* d_ref, const u32* d_pos, const u32* d_src, const u32* d_len, size_t z,
                                  u32* d_changed, DecodeOut& out, DecodeStats* st) {
     hipStream_t s = c.stream;
-    const bool dlog = getenv("TDC_GPU_DEC_LOG") != nullptr;
+    const bool dlog = c.dec_log != 0;
     auto t_last = std::chrono::steady_clock::now();
     auto tick = [&](const char* what) {
         if (!dlog) return;
@@ -725,7 +725,7 @@ static void resolve_and_download(Ctx& c, size_t n, u8* d_text, u32* d_ref, const
     LAUNCH_CHECK();
     tick("fill + reference scatter");
     unsigned g = cdiv(n, 256 * 8); if (g > 16384) g = 16384;
-    const bool use_done = !getenv("TDC_GPU_DEC_DONE") || atoi(getenv("TDC_GPU_DEC_DONE")) != 0;      // (A/B switch)
+    const bool use_done = c.dec_done != 0;      // (A/B switch: option dec_done)
     u64* d_done = nullptr;
     if (use_done) {
         d_done = c.arena.get<u64>(n / 64 + 1);
@@ -786,7 +786,7 @@ static bool decode_lzss_huff_device(Ctx& c, const u8* stream, size_t len, const 
     const u64 seg_bits = c.dec_seg ? (u64)c.dec_seg : (u64)DEC_SEG;                    // (tests shrink the segments)
     const size_t seg = (size_t)std::min<u64>(seg_bits, total - x0 + 1);
     hipStream_t s = c.stream;
-    const bool dlog = getenv("TDC_GPU_DEC_LOG") != nullptr;                              // stage times on stderr (synchronises)
+    const bool dlog = c.dec_log != 0;                                                    // stage times on stderr (synchronises)
     auto t_last = std::chrono::steady_clock::now();
     auto tick = [&](const char* what) {
         if (!dlog) return;

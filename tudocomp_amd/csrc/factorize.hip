@@ -1215,10 +1215,10 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
     u32 nolive_run = 0, stale_trigger = 8;                 // consecutive levels without a live entry; run length that triggers the batch push
     double host_prof[5] = {0, 0, 0, 0, 0};                // small levels, host side: prepare / launch / wait / bookkeeping (us), count
     unsigned long long* d_sprof = nullptr;                 // TDC_GPU_SMALL_PROF=1: phase times of the small-level kernel on stderr
-    if (getenv("TDC_GPU_SMALL_PROF")) { d_sprof = (unsigned long long*)c.arena.alloc(32 * sizeof(unsigned long long)); HIP_TRY(hipMemsetAsync(d_sprof, 0, 32 * sizeof(unsigned long long), s)); }
+    if (c.small_prof) { d_sprof = (unsigned long long*)c.arena.alloc(32 * sizeof(unsigned long long)); HIP_TRY(hipMemsetAsync(d_sprof, 0, 32 * sizeof(unsigned long long), s)); }
     bool probe_dead = false;                    // the previous level held erased candidates only
 
-    const bool level_log = getenv("TDC_GPU_LEVEL_LOG") != nullptr;     // debugging aid: one line per large level on stderr
+    const bool level_log = c.level_log != 0;     // debugging aid: one line per large level on stderr
     // ---- lists from cur[]: both formulations can restart from the working values and the residence marks alone (res8_mark) ----------
     // The lazy formulation: every alive position of the levels (lo, hi] becomes an entry of list cur[q] (natural ones keep their ISA as
     // priority, truncated ones follow them); the push pool is forgotten -- its alive entries are among the rebuilt ones.
@@ -1295,7 +1295,7 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
             unsigned long long tot = 0;
             for (size_t lv = 0; lv < nlev; ++lv) tot += dv[4 * lv + 2];
             unsigned long long acc = 0; u32 shown = 0;
-            const bool dump_all = getenv("TDC_GPU_EAGER_DUMP") != nullptr;          // (tools/eager_levels_log.py)
+            const bool dump_all = c.eager_dump != 0;          // (tools/eager_levels_log.py)
             for (size_t lv = nlev; lv-- > 0;) {
                 if (!dv[4 * lv + 2]) continue;
                 if (dump_all) { fprintf(stderr, "eager level %zu: entries %u factors %u cycles %u\n", lv, dv[4 * lv], dv[4 * lv + 1], dv[4 * lv + 2]); continue; }

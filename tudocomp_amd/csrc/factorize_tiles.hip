@@ -561,7 +561,7 @@ int factorize_window_levels(Ctx& c, size_t n, const u32* cur, const u32* prio, c
                     halo, h.min_margin, h.fail, h.max_entries);
         }
 #endif
-        if (getenv("TDC_GPU_LEVEL_LOG")) fprintf(stderr, "window pass: attempt %d halo %u lists %s -> fail %u, smallest margin %d\n", attempt, halo, large ? "large" : "small", h.fail, h.min_margin);
+        if (c.level_log) fprintf(stderr, "window pass: attempt %d halo %u lists %s -> fail %u, smallest margin %d\n", attempt, halo, large ? "large" : "small", h.fail, h.min_margin);
         if (c.window_force_fail) h.fail |= 1u;                 // (tests: the pass is discarded as if a border had failed with the largest halo)
         result = (int)h.fail;
         if (!h.fail) break;

@@ -457,10 +457,10 @@ void flatten_factors(Ctx& c, size_t n, FactorSpace fs, FlattenStats* st, const s
     int cur_w = -1;                               // -1: every factor (first round)
     // steps per round: few in the first rounds (most chains are short; the lanes of a wave wait for the longest one),
     // growing afterwards
-    u32 max_steps = getenv("TDC_GPU_FLATTEN_STEPS") ? (u32)atoi(getenv("TDC_GPU_FLATTEN_STEPS")) : 1u;   // measured: 1,2,4,.. 8.5 ms; unlimited 11.2 ms
+    u32 max_steps = (u32)c.flatten_steps;   // (option flatten_steps; measured: 1,2,4,.. 8.5 ms; unlimited 11.2 ms)
     if (max_steps == 0) max_steps = 1u << 30;
     // budget growth per round (measured at 256 MiB: x2 8.4 ms, x4 7.4 ms, x8 7.0 ms)
-    u32 flat_growth = getenv("TDC_GPU_FLATTEN_GROWTH") ? (u32)atoi(getenv("TDC_GPU_FLATTEN_GROWTH")) : 8u;
+    u32 flat_growth = (u32)c.flatten_growth;
     if (flat_growth < 2) flat_growth = 2;
     u32 stalled = 0;
     while (waiting) {
@@ -478,7 +478,7 @@ void flatten_factors(Ctx& c, size_t n, FactorSpace fs, FlattenStats* st, const s
         if (between) between((int)st->rounds + 1);
         const u32 now = c.read(&d_sc->waiting);
         st->rounds++;
-        if (getenv("TDC_GPU_LEVEL_LOG")) {
+        if (c.level_log) {
             const FlattenScalars hs = c.read(d_sc);
             fprintf(stderr, "flatten round %u: %u waiting -> %u (budget %u steps; cumulative: %llu visits, %llu of them waits)\n", st->rounds, waiting, now, max_steps, hs.steps, hs.waits);
         }

@@ -929,7 +929,7 @@ void build_suffix_array(Ctx& c, const u8* text, size_t n, u32* sa, u32* isa, SAS
     {
         unsigned __int128 pw = 1;
         while (k < 32 && pw * base <= ((unsigned __int128)1 << 64)) { pw *= base; ++k; }
-        if (const char* e = getenv("TDC_GPU_SA_INIT_SYMS")) { const int v = atoi(e); if (v >= 1 && v < k) { k = v; pw = 1; for (int i = 0; i < k; ++i) pw *= base; } }   // tuning knob
+        if (c.sa_init_syms >= 1 && c.sa_init_syms < k) { k = c.sa_init_syms; pw = 1; for (int i = 0; i < k; ++i) pw *= base; }   // tuning knob
         key_bits = (pw > ((unsigned __int128)1 << 63)) ? 64 : (int)bits_for((u64)(pw - 1));
     }
     st->sym_bits = b; st->init_syms = k;

@@ -1644,7 +1644,7 @@ int ws_sort_impl(Ctx& c, const WKeyGen* gen, u64* K1[2], u64* K2[2], u32* V[2], 
             LAUNCH_CHECK();
             u32 he[EC_NCLS];
             c.read_n(lc + 2 * NB, he, EC_NCLS);
-            if (getenv("TDC_GPU_WSORT_LOG")) {
+            if (c.wsort_log) {
                 fprintf(stderr, "[wsort] n=%zu stage %d: units", n, stage);
                 for (int q = 0; q < NB; ++q) fprintf(stderr, " %u", cur_cnt[q]);
                 fprintf(stderr, " | r/t lists");
