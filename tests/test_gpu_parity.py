@@ -647,7 +647,7 @@ OPTION_VALUES = {
     "sa_refine": [0], "sa_pairs": [0], "sa_fused_init": [0], "sa_init_syms": [5], "radix_lds": [0, 2], "xcd_remap": [0, 2],
     "bucket_scatter": [0], "ssort": [0], "ssort_levels": [2], "msd_partition": [0], "wsort": [0], "wsort_min": [4096], "wsort_syms": [19],
     "wsort_kw": [1], "wsort_rounds": [0], "wsort_smallrun": [1], "wsort_overlap": [0], "wsort_fuse": [0], "wsort_order": [0],
-    "wsort_two": [2], "wsort_leaf": [1024], "wsort_pack": [1024, 4096], "wsort_cmax": [1, 64], "upload_chunks": [4, 24],
+    "wsort_two": [2], "wsort_leaf": [1024], "wsort_pack": [1024, 4096], "wsort_cmax": [8, 64], "upload_chunks": [4, 24],
     "dec_seg": [1 << 20], "dec_lean": [0], "dec_parse": [0, 2], "dec_done": [0],
 }
 

@@ -95,7 +95,7 @@ int guarded(tdc_gpu_ctx* ctx, F&& f) {
 size_t arena_need(size_t n) { return 112 * n + ((size_t)192 << 20); }
 // (a context created with TDC_GPU_WSORT_SMALLRUN -- tests: every run of tying records is handed on -- needs ~48 B per byte more for the
 //  hand-over lists; per context, not per process: other contexts of a test run keep the product's budget)
-size_t arena_need(const Ctx& c, size_t n) { return arena_need(n) + (c.wsort_small ? 64 * n : 0); }
+size_t arena_need(const Ctx& c, size_t n) { return arena_need(n) + (c.wsort_small ? 64 * n : 0) + (c.wsort_cmax < 16 ? 8 * n : 0); }
 
 // public coder id (+ SLE's kmer option in bits 8..) -> coder id of encode_stream
 int lcpcomp_enc_coder(int coder) {
@@ -398,7 +398,7 @@ const OptionDef OPTIONS[] = {
     { "wsort_two",        [](Ctx& c, long v) { c.wsort_two = (v >= 0 && v <= 2) ? (int)v : 0; } },
     { "wsort_leaf",       [](Ctx& c, long v) { c.wsort_leaf = v == 1024 ? 1024 : 2048; } },
     { "wsort_pack",       [](Ctx& c, long v) { c.wsort_pack = (v == 1024 || v == 4096) ? (int)v : 2048; } },
-    { "wsort_cmax",       [](Ctx& c, long v) { c.wsort_cmax = clampi(v, 1, 64); } },
+    { "wsort_cmax",       [](Ctx& c, long v) { c.wsort_cmax = clampi(v, 8, 64); } },       // (the hand-over lists take 128 n / (cmax + 1) bytes: below 8 they outgrow the arena)
     { "wsort_log",        [](Ctx& c, long v) { c.wsort_log = v != 0; } },
     { "upload_chunks",    [](Ctx& c, long v) { c.upload_chunks = clampi(v, 4, 24); } },
     { "arena_log",        [](Ctx& c, long v) { c.arena_log = v != 0; } },

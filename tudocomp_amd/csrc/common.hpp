@@ -163,7 +163,7 @@ struct Ctx {
     int wsort_syms = 0;            // cap on the symbols per key of the wide sort (env TDC_GPU_WSORT_SYMS; 0: as many as the key words hold) -- measurements only
     int wsort_kw = 0;              // key words: 0 = by alphabet (2 when a word holds fewer than 16 symbols), 1 | 2 forced (env TDC_GPU_WSORT_KW)
     int wsort_rounds = 24;         // most text rounds before the doubling fallback (env TDC_GPU_WSORT_ROUNDS; 0: straight to doubling)
-    int wsort_cmax = 16;           // leaf sort: runs of tying records up to this length are ordered by counting, longer ones by the wave kernel (env TDC_GPU_WSORT_CMAX, 1 .. 64)
+    int wsort_cmax = 16;           // leaf sort: runs of tying records up to this length are ordered by counting, longer ones by the wave kernel (option wsort_cmax, 8 .. 64)
     int wsort_overlap = 1;         // host-buffer calls: level 1 of the wide suffix sort runs chunk by chunk behind the upload (env TDC_GPU_WSORT_OVERLAP=0 disables)
     int wsort_two = 0;             // wide sort of more than 235 M records: two partition levels of up to 1024 buckets instead of three of up to 256 (env TDC_GPU_WSORT_TWO)
     int wsort_leaf = 2048;         // leaf size the three-level wide sort aims at (env TDC_GPU_WSORT_LEAF: 1024 | 2048)
