@@ -76,6 +76,7 @@ typedef struct {
     uint32_t sa_overlapped;     /* 1: the first partition level of the suffix sort ran chunk by chunk behind the upload */
     uint32_t eager_levels;      /* levels processed inside one-launch runs of small levels (factorize_eager.hip)           */
     uint32_t eager_phases;      /* such runs                                                                            */
+    uint32_t sa_star_chains;    /* chains of the star step of the suffix array's doubling fall-back (0: the step was not taken) */
 } tdc_gpu_stats;
 
 /* ---- context -------------------------------------------------------------------------------------------- */

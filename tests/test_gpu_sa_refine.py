@@ -85,3 +85,52 @@ def test_text_index_with_and_without_refinement(gpu_ctx, ctx_plain, ctx_global_r
         assert np.array_equal(g["phi"], phi), "%s %s: Phi" % (name, label)
         assert np.array_equal(g["plcp"], plcp), "%s %s: PLCP" % (name, label)
         assert g["maxlcp"] == maxlcp
+
+
+def _copied_text(n, sigma, blk, seed, copies_of_copies=True):
+    """random text in which every fourth block is a copy of an earlier window -- sources overlap, copies are copied again: groups of
+    two, three and more suffixes with common extensions of up to `blk` symbols (the structure of the SURVEY 8d DNA generator)"""
+    rng = np.random.default_rng(seed)
+    out = np.empty(n + blk, dtype=np.uint8)
+    pos = 0
+    while pos < n:
+        if pos >= blk and rng.integers(0, 4) == 0:
+            src = int(rng.integers(0, pos - blk + 1)) if copies_of_copies else int(rng.integers(0, max(1, pos // 4)))
+            out[pos:pos + blk] = out[src:src + blk]
+        else:
+            out[pos:pos + blk] = rng.integers(0, sigma, blk, dtype=np.uint8) + 65
+        pos += blk
+    return out[:n].tobytes()
+
+
+def test_star_step_orders_groups_of_any_size(gpu_ctx):
+    """Round 6: in the doubling fall-back of the wide path every group of unresolved suffixes is ordered against its smallest member
+    from the text (lce along chains of consecutive positions) before the doubling rounds.  Texts of 2^25 bytes and more with copied
+    blocks take it (sa_star_chains > 0): suffix array and stream equal the oracle's / the pair step's; a periodic text (one head per
+    member) must NOT take it."""
+    plain = T.Context(0, options={"sa_stars": 0})
+    try:
+        n = (1 << 25) + 4097
+        for name, data in (("dna_copies", _copied_text(n, 4, 4096, 1)), ("sigma2_short_copies", _copied_text(n, 2, 700, 2)),
+                           ("sigma20_long_copies", _copied_text(n, 20, 20000, 3, False)), ("dna_gen", T.gen_dna(n, 11).tobytes())):
+            text = O.escape(data)
+            a, st = gpu_ctx.lcpcomp_compress(text, threshold=3, flatten=1)
+            b, sb = plain.lcpcomp_compress(text, threshold=3, flatten=1)
+            assert st["sa_mode"] == 0 and st["sa_star_chains"] > 0, (name, st)
+            assert sb["sa_star_chains"] == 0
+            assert a == b, name
+            sa, isa = gpu_ctx.suffix_array(text)
+            sa2, _ = plain.suffix_array(text)
+            assert np.array_equal(sa, sa2), name
+            assert np.array_equal(isa[sa], np.arange(len(sa), dtype=np.uint32))
+        # the oracle itself on the smallest interesting size
+        text = O.escape(_copied_text(n, 4, 4096, 5))
+        sa, _ = gpu_ctx.suffix_array(text)
+        assert np.array_equal(sa, O.suffix_array(text))
+        # periodic: every suffix of a run has the same representative -- one chain per member, the guard leaves it to the other paths
+        text = O.escape((b"abcab" * 8_000_000)[:n])
+        got, st = gpu_ctx.lcpcomp_compress(text, threshold=3, flatten=1)
+        assert st["sa_star_chains"] == 0
+        assert got == plain.lcpcomp_compress(text, threshold=3, flatten=1)[0]
+    finally:
+        plain.close()

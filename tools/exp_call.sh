@@ -1,11 +1,16 @@
 cd $GRAFT_REPO_ROOT
-timeout -k 10 1100 python -m pytest tests -m gpu -x -q > gpurun_out/c5_gputests.log 2>&1; tail -5 gpurun_out/c5_gputests.log
-python tools/lz78_check.py 33554432 2>&1 | tail -2
-python tools/lz78_check.py 1000000000 2>&1 | tail -2
-python bench.py --steps 5 --warmup 2 > gpurun_out/c5_bench.json 2> gpurun_out/c5_bench.err; python3 -c "
-import json
-j=json.loads(open('gpurun_out/c5_bench.json').read().strip().splitlines()[-1])
-print(j['value'], j['ms_per_step'], j['stages_ms'])
-for k in j:
-    if k.startswith('configs') or k in ('decompress','hbm_resident','stream_matches_golden'): print(k, j[k])
-"
+timeout -k 10 900 python -m pytest tests/test_gpu_sa_refine.py tests/test_gpu_wsort.py tests/test_gpu_sort.py -x -q 2>&1 | tail -15
+python - <<'PY'
+import sys, time
+sys.path.insert(0, '.')
+import numpy as np
+import tudocomp_amd as T
+n = 1_000_000_000
+d = T.gen_dna(n, 7)
+text = np.concatenate([d, np.zeros(1, dtype=np.uint8)])
+for opts in ({}, {"sa_stars": 0}):
+    with T.Context(0, options=opts) as ctx:
+        for it in range(2):
+            out, st = ctx.lcpcomp_compress(text, 2, 1, T.CODER_ARITH)
+        print(opts, {k: (round(v, 1) if isinstance(v, float) else v) for k, v in st.items() if k.startswith("ms_") or k in ("sa_rounds", "sa_star_chains", "out_len")}, flush=True)
+PY

@@ -39,7 +39,7 @@ class Stats(ctypes.Structure):
         [(k, ctypes.c_float) for k in ("ms_h2d", "ms_sa", "ms_phi", "ms_plcp", "ms_factorize", "ms_flatten", "ms_encode",
                                        "ms_d2h", "ms_total")] +
         [(k, ctypes.c_uint32) for k in ("small_levels", "purges", "window_pass", "window_lcut",
-                                        "sa_key_words", "sa_text_rounds", "sa_mode", "sa_overlapped", "eager_levels", "eager_phases")])
+                                        "sa_key_words", "sa_text_rounds", "sa_mode", "sa_overlapped", "eager_levels", "eager_phases", "sa_star_chains")])
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

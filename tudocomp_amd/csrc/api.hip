@@ -218,6 +218,7 @@ void run_textds(Ctx& c, const u8* d_text, size_t n, DevArrays& A, tdc_gpu_stats*
         st->maxlcp = A.maxlcp;
         st->sa_rounds = ss.rounds; st->sa_init_syms = ss.init_syms; st->sa_sorted_elems = ss.sorted_elems;
         st->sa_key_words = ss.wide_kw; st->sa_text_rounds = ss.text_rounds; st->sa_mode = (uint32_t)ex.mode; st->sa_overlapped = ss.overlapped;
+        st->sa_star_chains = (uint32_t)std::min<u64>(ss.star_chains, 0xFFFFFFFFull);
         if (ev) { ev->span(&st->ms_sa, e0, e1); ev->span(&st->ms_phi, e1, e2); ev->span(&st->ms_plcp, e2, e3); }
     }
 }
@@ -378,6 +379,7 @@ const OptionDef OPTIONS[] = {
     { "flatten_growth",   [](Ctx& c, long v) { c.flatten_growth = clampi(v, 2, 1 << 20); } },
     { "sa_refine",        [](Ctx& c, long v) { c.sa_refine = v != 0; } },
     { "sa_pairs",         [](Ctx& c, long v) { c.sa_pairs = v != 0; } },
+    { "sa_stars",         [](Ctx& c, long v) { c.sa_stars = v != 0; } },
     { "sa_fused_init",    [](Ctx& c, long v) { c.sa_fused_init = v != 0; } },
     { "sa_init_syms",     [](Ctx& c, long v) { c.sa_init_syms = clampi(v, 0, 64); } },
     { "radix_lds",        [](Ctx& c, long v) { c.radix_lds = (v >= 0 && v <= 2) ? (int)v : 2; } },

@@ -141,6 +141,7 @@ struct Ctx {
     int small_big = 1;             // factorize: one-workgroup levels with up to 4096 survivors run on a 512-thread instance of the kernel (env TDC_GPU_SMALL_BIG=0: multi-launch path above 2048)
     int small_pipeline = 1;        // factorize: the kernel of the next one-workgroup level is queued while the current one runs (env TDC_GPU_SMALL_PIPELINE=0 disables)
     int sa_pairs = 1;              // suffix array, doubling fall-back of the wide path: groups of exactly two suffixes are ordered from the text in one pass first (env TDC_GPU_SA_PAIRS=0 disables)
+    int sa_stars = 1;              // suffix array, doubling fall-back of the wide path: every group is ordered against its smallest member from the text in one pass first (round 6; option sa_stars=0: the pair step)
     int sa_refine = 1;             // suffix array: small groups of the initial order are refined from the text before the first round (env TDC_GPU_SA_REFINE=0 disables)
     int sa_fused_init = 1;         // suffix array: pass 0 of the initial sort computes its keys from the text (env TDC_GPU_SA_FUSED_INIT=0: separate key kernel)
     int radix_lds = 1;             // radix scatter: reorder the tile in LDS before writing: 0 never, 1 always, 2 for 32-bit keys only

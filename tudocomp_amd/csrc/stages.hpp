@@ -14,7 +14,8 @@ size_t count_escapes_device(Ctx& c, const u8* d_in, size_t n);     // bytes the 
 struct SAStats { u32 rounds = 0; u32 sym_bits = 0; u32 init_syms = 0; u64 sorted_elems = 0;
                  u32 wide_kw = 0; /* key words of the wide initial sort (0: classic path) */ u32 text_rounds = 0; u64 wide_nonheads = 0;
                  u32 overlapped = 0; /* 1: level 1 of the wide sort ran behind the upload */
-                 u64 pair_resolved = 0; /* suffixes of two-member groups ordered by the one-pass pair step in front of the doubling rounds */ };
+                 u64 pair_resolved = 0; /* suffixes of two-member groups ordered by the one-pass pair step in front of the doubling rounds */
+                 u64 star_chains = 0; /* chains of the star step (round 6: every group ordered against its smallest member in one pass) */ };
 // Optional sink of the wide path (suffix_array.hip): lcp8 = n bytes for the LCP (in symbols) of every suffix-array slot with its
 // predecessor.  mode (out): 0 = classic result (sa and isa written), 1 = sa final and lcp8 valid but isa NOT written -- the caller
 // derives ISA, Phi and PLCP with build_isa_phi_plcp_fused().

@@ -661,8 +661,112 @@ __global__ __launch_bounds__(256) void sa_pair_resolve_kernel(const u8* __restri
     rank[small] = p0; rank[large] = p0 + 1;
 }
 
+// ---- star step (round 6): every group ordered against ONE of its members, from the text, in one pass ------------------------------------
+// The pair step generalised.  r = the smallest position of a group; for a member p != r let l = lce(p, r) and (cp, cr) the bytes behind
+// the common extension.  Members with cp < cr lie below r, the others above; below r a SMALLER l sorts first (p leaves r's path earlier,
+// downwards), above r a LARGER l sorts first; equal l: by cp; equal (side, l, cp): the members agree on l + 1 >= h symbols and stay one
+// group.  So one sort by (group, side, l', cp) orders every group up to such ties -- whatever its size -- and what the doubling rounds
+// have left are the tie groups (copies of copies that continue alike).
+// The lce values come cheap: inside a repeat the members at consecutive positions p, p + 1, ... have the representatives r, r + 1, ...
+// (a CHAIN), and lce(p + k, r + k) = lce(p, r) - k exactly, with the same two bytes behind it.  One wave per chain head compares from
+// the text (512 bytes per step, from the known common prefix h on) and then walks its chain, writing (lce, side, byte) for 64
+// positions per step.  10^9 B of DNA with copied 4 KiB blocks: 400 M unresolved suffixes in 1.4 M chains.
+constexpr u64 STAR_REP = ~0ull;
+// longest common extension of the suffixes i and j from offset l on (l symbols are known to agree), a whole wave at 512 bytes per step
+// (textds.hip wave_lcp)
+__device__ __forceinline__ u32 wave_lcp_ext(const u8* __restrict__ text, size_t n, size_t i, size_t j, u32 l) {
+    const size_t lim = n - (i > j ? i : j);                   // the unique sentinel ends the comparison before either suffix leaves the text
+    const int lane = lane_id();
+    for (;;) {
+        const size_t off = (size_t)l + 8 * (size_t)lane;
+        const bool full = off + 8 <= lim;
+        u64 a = 0, b = 0;
+        if (full) { __builtin_memcpy(&a, text + i + off, 8); __builtin_memcpy(&b, text + j + off, 8); }
+        const u64 x = a ^ b;
+        const u64 bad = __ballot(!full || x != 0);
+        if (bad == 0) { l += 512; continue; }
+        const int f = __builtin_ctzll(bad);                    // first lane with a mismatch or a word that sticks out of the text
+        const u64 xf = __shfl(x, f);
+        const bool ff = __shfl((int)full, f) != 0;
+        l += 8 * (u32)f;
+        if (ff) return l + ((u32)__builtin_ctzll(xf) >> 3);
+        while ((size_t)l < lim && text[i + l] == text[j + l]) ++l;     // the last few bytes in front of the sentinel
+        return l;
+    }
+}
+__global__ __launch_bounds__(256) void sa_star_init_kernel(const u32* __restrict__ a_r1, size_t m, u32* __restrict__ gmin) {
+    const size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a < m) gmin[a_r1[a]] = NONE32;
+}
+__global__ __launch_bounds__(256) void sa_star_min_kernel(const u32* __restrict__ a_sa, const u32* __restrict__ a_r1, size_t m, u32* __restrict__ gmin) {
+    const size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= m) return;
+    // (the members of a group are neighbours in the list: a lane whose left neighbour belongs to the same group and holds a smaller
+    //  position leaves the atomic to it -- most of a large group's atomics go away)
+    const u32 r = a_r1[a], p = a_sa[a];
+    if (a > 0 && (threadIdx.x & 63) != 0 && a_r1[a - 1] == r && a_sa[a - 1] < p) return;
+    atomicMin(&gmin[r], p);
+}
+__global__ __launch_bounds__(256) void sa_star_mark_kernel(const u32* __restrict__ a_sa, const u32* __restrict__ a_r1, size_t m, const u32* __restrict__ gmin,
+                                                           u32* __restrict__ src, u64* __restrict__ pk) {
+    const size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= m) return;
+    const u32 p = a_sa[a], r = gmin[a_r1[a]];
+    if (p != r) src[p] = r; else pk[p] = STAR_REP;
+}
+__global__ __launch_bounds__(256) void sa_star_headflag_kernel(const u32* __restrict__ src, size_t n, u8* __restrict__ cls) {
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const u32 s = src[p];
+    cls[p] = (s != NONE32 && (p == 0 || src[p - 1] == NONE32 || src[p - 1] + 1u != s)) ? 1 : 0;
+}
+// pk[q] = lce | side << 32 (0: below the representative, 2: above) | byte << 40 for every position q of the chain
+__global__ __launch_bounds__(256) void sa_star_chain_kernel(const u8* __restrict__ text, size_t n, const u32* __restrict__ heads, u32 nheads,
+                                                            const u32* __restrict__ src, u32 h0, u64* __restrict__ pk) {
+    const u32 k = (u32)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (k >= nheads) return;
+    const int lane = lane_id();
+    const u32 p = heads[k], r = src[p];
+    // (h0 symbols are known to agree; the suffix with the smaller remainder ends at the unique sentinel, so the comparison stops in the text)
+    const u32 L = wave_lcp_ext(text, n, p, r, h0);
+    const u8 cp = ((size_t)p + L < n) ? text[(size_t)p + L] : (u8)0, cr = ((size_t)r + L < n) ? text[(size_t)r + L] : (u8)0;
+    const u64 code = ((u64)(cp < cr ? 0u : 2u) << 32) | ((u64)cp << 40);
+    for (u32 k0 = 0;; k0 += 64) {
+        const u32 d = k0 + (u32)lane;
+        const size_t q = (size_t)p + d;
+        const bool ok = d <= L && q < n && (d == 0 || src[q] == r + d);
+        const u64 okm = __ballot(ok);
+        const int run = (~okm == 0ull) ? 64 : __builtin_ctzll(~okm);          // the chain goes on for `run` more positions
+        if (lane < run) pk[q] = (u64)(L - d) | code;
+        if (run < 64) break;
+    }
+}
+__global__ __launch_bounds__(256) void sa_star_keys_kernel(const u32* __restrict__ a_sa, const u32* __restrict__ a_r1, size_t m, int bn,
+                                                           const u64* __restrict__ pk, u64* __restrict__ keys, u32* __restrict__ vals) {
+    const size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= m) return;
+    const u32 p = a_sa[a];
+    const u64 v = pk[p];
+    const int W = bn - 10;                                       // bits of the length field (bn >= 26 here: lce up to 2^16 and more)
+    const u32 maxl = (1u << W) - 1u;
+    u32 second;
+    if (v == STAR_REP) second = 1u << (bn - 2);
+    else {
+        u32 L = (u32)v;
+        const u32 side = (u32)(v >> 32) & 3u;
+        u32 ch = (u32)(v >> 40) & 0xFFu;
+        if (L >= maxl) { L = maxl - 1u; ch = 0; }                // (beyond the field: such members tie -- the doubling rounds order them)
+        const u32 f = side == 0 ? L : maxl - L;
+        second = (side << (bn - 2)) | (f << 8) | ch;
+    }
+    keys[a] = ((u64)a_r1[a] << bn) | second;
+    vals[a] = p;
+}
+
 // prefix doubling from h on: the active list (A_sa, A_pos, A_r1) holds the m unresolved suffixes, rank[] is up to date
-void doubling_rounds(Ctx& c, size_t n, int bn, u32* sa, u32* rank, SABufs& B, size_t m, u64 h, u32 h_tot[4], SAStats* st) {
+// keys_ready: the first round's keys (keys[0] / vals[0]) have been built by the caller (star step) -- that round orders the groups by
+// them and leaves h as it is
+void doubling_rounds(Ctx& c, size_t n, int bn, u32* sa, u32* rank, SABufs& B, size_t m, u64 h, u32 h_tot[4], SAStats* st, bool keys_ready = false) {
     hipStream_t s = c.stream;
     u64** keys = B.keys; u32** vals = B.vals;
     // Sort of a round: groups of a handful of suffixes (random texts, DNA) are sorted inside 2048-element tiles and only the
@@ -674,7 +778,9 @@ void doubling_rounds(Ctx& c, size_t n, int bn, u32* sa, u32* rank, SABufs& B, si
     while (m > 0) {
         if (h >= n) throw HipError{hipErrorUnknown, "suffix_array: doubling did not converge", (int)__LINE__};
         const unsigned gm = cdiv(m, 256);
-        {   // per element: read sa + r1 (8 B), gather rank[sa+h] (4 B), write key + value (12 B)
+        const bool ready = keys_ready;
+        keys_ready = false;
+        if (!ready) {   // per element: read sa + r1 (8 B), gather rank[sa+h] (4 B), write key + value (12 B)
             Ctx::ProfScope prof(c, K_SA_BUILD_KEYS, (u64)m * 24);
             sa_build_keys_kernel<<<gm, 256, 0, s>>>(B.A_sa, B.A_r1, m, n, (u32)h, bn, rank, keys[0], vals[0]);
             LAUNCH_CHECK();
@@ -735,7 +841,7 @@ void doubling_rounds(Ctx& c, size_t n, int bn, u32* sa, u32* rank, SABufs& B, si
         t = B.A_sa; B.A_sa = B.B_sa; B.B_sa = t;
         t = B.A_pos; B.A_pos = B.B_pos; B.B_pos = t;
         t = B.A_r1; B.A_r1 = B.B_r1; B.B_r1 = t;
-        h *= 2;
+        if (!ready) h *= 2;
         st->rounds++;
     }
 }
@@ -857,7 +963,50 @@ int build_suffix_array_wide(Ctx& c, const u8* text, size_t n, u32* sa, u32* isa,
         // the rounds gave up: ranks of the state reached so far (sa + head flags), then doubling from the common depth h
         m = first_groups(c, n, bn, nullptr, sa, flags, sa, isa, B, true, h_tot);
     }
-    if (c.sa_pairs && m >= n / 64 && m >= ((size_t)1 << 20)) {
+    bool keys_ready = false;
+    if (c.sa_stars && m >= n / 64 && m >= ((size_t)1 << 20) && bn >= 26 && h <= 0xFFFFu) {
+        // star step: the keys of one ordering round from the text (see sa_star_* above); the round itself is the first one of doubling_rounds
+        const size_t pm = c.arena.mark();
+        u32* src = (u32*)K2[0];                            // (the second key words of the wide sort are not used any more: 2 x 8 n bytes)
+        u32* gmin = src + n;
+        u64* pk = K2[1];
+        u8* cls = (u8*)B.keep;
+        u32* heads = c.arena.get<u32>(m);
+        fill_u32(c, src, n, NONE32);
+        {
+            Ctx::ProfScope prof(c, K_SA_BUILD_KEYS, (u64)m * 28);
+            sa_star_init_kernel<<<cdiv(m, 256), 256, 0, s>>>(B.A_r1, m, gmin);
+            LAUNCH_CHECK();
+            sa_star_min_kernel<<<cdiv(m, 256), 256, 0, s>>>(B.A_sa, B.A_r1, m, gmin);
+            LAUNCH_CHECK();
+            sa_star_mark_kernel<<<cdiv(m, 256), 256, 0, s>>>(B.A_sa, B.A_r1, m, gmin, src, pk);
+            LAUNCH_CHECK();
+            sa_star_headflag_kernel<<<cdiv(n, 256), 256, 0, s>>>(src, n, cls);
+            LAUNCH_CHECK();
+        }
+        select_by_class(c, cls, 1, n, nullptr, heads, nullptr, nullptr, B.d_total);
+        const size_t nheads = c.read(B.d_total);
+        if (nheads > m) throw HipError{hipErrorUnknown, "suffix_array: star step (more chain heads than members)", (int)__LINE__};
+        // (a chain head costs a comparison over its whole common extension.  Copied blocks give chains of hundreds of positions; a
+        //  periodic text -- a^N: every suffix of the run has the same representative -- gives one head per member, each with an
+        //  extension as long as the run: the step is only taken where the chains are long)
+        if (nheads <= m / 16) {
+        {
+            Ctx::ProfScope prof(c, K_PLCP, (u64)m * 12 + (u64)nheads * 64);
+            if (nheads) sa_star_chain_kernel<<<cdiv(nheads * 64, 256), 256, 0, s>>>(text, n, heads, (u32)nheads, src, (u32)h, pk);
+            LAUNCH_CHECK();
+        }
+        {
+            Ctx::ProfScope prof(c, K_SA_BUILD_KEYS, (u64)m * 28);
+            sa_star_keys_kernel<<<cdiv(m, 256), 256, 0, s>>>(B.A_sa, B.A_r1, m, bn, pk, B.keys[0], B.vals[0]);
+            LAUNCH_CHECK();
+        }
+        st->star_chains = (u64)nheads;
+        keys_ready = true;
+        }
+        c.arena.release(pm);
+    }
+    if (!keys_ready && c.sa_pairs && m >= n / 64 && m >= ((size_t)1 << 20)) {
         // pairs first: one pass over the text instead of log(repeat length / h) rounds over them
         const size_t pm = c.arena.mark();
         u32* src = (u32*)K2[0];                            // (the second key words of the wide sort are not used any more: 8 n bytes)
@@ -888,7 +1037,7 @@ int build_suffix_array_wide(Ctx& c, const u8* text, size_t n, u32* sa, u32* isa,
         m = m2;
         c.arena.release(pm);
     }
-    doubling_rounds(c, n, bn, sa, isa, B, m, (u64)h, h_tot, st);
+    doubling_rounds(c, n, bn, sa, isa, B, m, (u64)h, h_tot, st, keys_ready);
     return 0;
 }
 }  // namespace
