@@ -1,16 +1,6 @@
 cd $GRAFT_REPO_ROOT
-timeout -k 10 900 python -m pytest tests/test_gpu_sa_refine.py tests/test_gpu_wsort.py tests/test_gpu_sort.py -x -q 2>&1 | tail -15
-python - <<'PY'
-import sys, time
-sys.path.insert(0, '.')
-import numpy as np
-import tudocomp_amd as T
-n = 1_000_000_000
-d = T.gen_dna(n, 7)
-text = np.concatenate([d, np.zeros(1, dtype=np.uint8)])
-for opts in ({}, {"sa_stars": 0}):
-    with T.Context(0, options=opts) as ctx:
-        for it in range(2):
-            out, st = ctx.lcpcomp_compress(text, 2, 1, T.CODER_ARITH)
-        print(opts, {k: (round(v, 1) if isinstance(v, float) else v) for k, v in st.items() if k.startswith("ms_") or k in ("sa_rounds", "sa_star_chains", "out_len")}, flush=True)
-PY
+export BENCH_ARGS="--no-extra"
+V=$PWD/tudocomp_amd/lib/variants
+tools/ab.sh "X=new" "TDC_GPU_LIB=$V/prev.so" "X=new" "TDC_GPU_LIB=$V/prev.so" > gpurun_out/c9_ab.log 2> gpurun_out/c9_ab.err
+grep -v "^ \|kernels" gpurun_out/c9_ab.log | cut -c1-300
+grep -o "rs_scatter_kernel<u64>=[0-9.]*\|rs_count_kernel=[0-9.]*\|ws_leaf_sort_kernel=[0-9.]*" gpurun_out/c9_ab.log | paste - - -

@@ -459,6 +459,7 @@ int tdc_gpu_ctx_create(int device, tdc_gpu_ctx** out) {
         for (auto& e : ctx->c.ev_copy) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         ctx->c.pinned_size = 4096;
         HIP_TRY(hipHostMalloc(&ctx->c.pinned, ctx->c.pinned_size, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void**)&ctx->c.pinned_hdr, Ctx::PINNED_HDR, hipHostMallocDefault));
         if (ctx->c.fast_read) {
             void* zc = nullptr;
             if (hipHostMalloc(&zc, (size_t)Ctx::ZC_WORDS * Ctx::ZC_BLOCKS * 4, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
@@ -489,6 +490,8 @@ void tdc_gpu_ctx_destroy(tdc_gpu_ctx* ctx) {
     if (ctx->c.stream) (void)hipStreamSynchronize(ctx->c.stream);
     if (ctx->c.arena.base) (void)hipFree(ctx->c.arena.base);
     if (ctx->c.pinned) (void)hipHostFree(ctx->c.pinned);
+    if (ctx->c.pinned_hdr) (void)hipHostFree(ctx->c.pinned_hdr);
+    if (ctx->c.pinned_tab) (void)hipHostFree(ctx->c.pinned_tab);
     if (ctx->c.zc_host) (void)hipHostFree(ctx->c.zc_host);
     if (ctx->c.d_err) (void)hipFree(ctx->c.d_err);
     for (auto& e : ctx->c.ev) if (e) (void)hipEventDestroy(e);

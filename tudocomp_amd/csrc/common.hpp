@@ -121,6 +121,20 @@ struct Ctx {
     hipEvent_t ev[16] = {};
     void* pinned = nullptr;        // small pinned staging block for device->host scalars
     size_t pinned_size = 0;
+    // page-locked scratch owned by the context (round 6: a hipHostMalloc / hipHostFree pair per call and every small copy from pageable
+    // memory showed up as 0.3 - 0.8 ms of idle device time in the kernel trace of a step):
+    void* pinned_tab = nullptr;    // the factorizer's gather-segment table (mapped: small levels read it in place); grown on demand
+    size_t pinned_tab_size = 0;
+    u8* pinned_hdr = nullptr;      // stream headers on their way to the device (64 KiB; rewritten only after the call's final synchronisation)
+    static constexpr size_t PINNED_HDR = 65536;
+    void* pinned_table(size_t bytes) {
+        if (pinned_tab_size < bytes) {
+            if (pinned_tab) { (void)hipHostFree(pinned_tab); pinned_tab = nullptr; pinned_tab_size = 0; }
+            HIP_TRY(hipHostMalloc(&pinned_tab, bytes, hipHostMallocDefault));
+            pinned_tab_size = bytes;
+        }
+        return pinned_tab;
+    }
     static constexpr u32 ZC_SEG_OFF = 1040, ZC_WORDS = 1040 + 16384;  // words 1040 ..: up to 8192 (target, start) pairs of a one-workgroup level
     static constexpr u32 ZC_BLOCKS = 3;                                // block 0: read() / publish_*; blocks 1, 2: two one-workgroup levels in flight
     u32* zc_host = nullptr;        // mapped host block for publish_words_kernel: 1024 data words + the sequence word (+ the segment area)

@@ -487,7 +487,9 @@ static void encode_prelude_launch(Ctx& c, const u8* text, size_t n, FactorSpace&
     u32* d_hist = r_hist ? r_hist : c.arena.get<u32>(256 + 4);
     EncScalars* d_sc = (EncScalars*)(d_hist + 256);
     EncScalars h_sc = { 0xFFFFFFFFu, 0u, 0u, 0u };          // LZSSFactors.hpp:33-38 : INDEX_MAX / 0
-    HIP_TRY(hipMemcpyAsync(d_sc, &h_sc, sizeof(h_sc), hipMemcpyHostToDevice, s));
+    static_assert(sizeof(EncScalars) == 16, "EncScalars: four words");
+    HIP_TRY(hipMemsetAsync(d_sc, 0, sizeof(h_sc), s));       // (two fills instead of a copy from pageable memory)
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)d_sc, 0xFFFFFFFFu, 1, s));
     HIP_TRY(hipMemsetAsync(d_hist, 0, 256 * sizeof(u32), s));
     if (z) {
         unsigned g = cdiv(z, 256); if (g > 2048) g = 2048;
@@ -717,7 +719,10 @@ size_t encode_stream(Ctx& c, const u8* text, size_t n, FactorSpace fs, int coder
 
     // ---- pass 2: pack ----------------------------------------------------------------------------------------
     HIP_TRY(hipMemsetAsync(d_out, 0, padded, s));
-    HIP_TRY(hipMemcpyAsync(d_out, hw.bytes.data(), hw.bytes.size(), hipMemcpyHostToDevice, s));
+    if (c.pinned_hdr && hw.bytes.size() <= Ctx::PINNED_HDR) {        // (through the context's page-locked block: a copy from pageable memory drains the stream)
+        memcpy(c.pinned_hdr, hw.bytes.data(), hw.bytes.size());
+        HIP_TRY(hipMemcpyAsync(d_out, c.pinned_hdr, hw.bytes.size(), hipMemcpyHostToDevice, s));
+    } else HIP_TRY(hipMemcpyAsync(d_out, hw.bytes.data(), hw.bytes.size(), hipMemcpyHostToDevice, s));
     {
         Ctx::ProfScope prof(c, K_ENC_PACK, (u64)n * 9 + (u64)z * 4 + out_len);
         // in PACK_CH chunks of tiles when the stream goes to the host: once a chunk is done the bytes in front of its last

@@ -1153,12 +1153,8 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
 
     const u32 gtab_cap = 1u << 16;
     GatherSeg* d_gtab = (GatherSeg*)c.arena.alloc(sizeof(GatherSeg) * gtab_cap);
-    struct PinnedTab {                         // pinned, so the H2D copy is truly asynchronous
-        GatherSeg* p = nullptr;
-        ~PinnedTab() { if (p) (void)hipHostFree(p); }
-    } h_gtab_mem;
-    HIP_TRY(hipHostMalloc((void**)&h_gtab_mem.p, sizeof(GatherSeg) * gtab_cap, hipHostMallocDefault));
-    GatherSeg* h_gtab = h_gtab_mem.p;
+    // (pinned, so the H2D copy is truly asynchronous; owned by the context: allocating and freeing it per call cost a millisecond of idle device)
+    GatherSeg* h_gtab = (GatherSeg*)c.pinned_table(sizeof(GatherSeg) * gtab_cap);
     GatherSeg* d_hgtab = nullptr;               // the same table as seen from the device (small levels read it in place)
     if (hipHostGetDevicePointer((void**)&d_hgtab, h_gtab, 0) != hipSuccess) { d_hgtab = nullptr; (void)hipGetLastError(); }
     struct PoolSeg { u32 off, cnt; };
@@ -1283,7 +1279,7 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
         const size_t dbg_mark = c.arena.mark();
         if (level_log) { P.dbg = c.arena.get<u32>(4 * nlev); HIP_TRY(hipMemsetAsync(P.dbg, 0, 4 * nlev * sizeof(u32), s)); }
         {
-            Ctx::ProfScope prof(c, K_SMALL_LEVEL, (u64)(Lfrom - eager_floor + 1) * 64);
+            Ctx::ProfScope prof(c, K_SMALL_LEVEL, (u64)tcount * 13 + (u64)(Lfrom - eager_floor + 1) * 16);   // per run head: position, working value, residence byte, priority; per level: its two table words + head
             eager_levels_launch(c, P);
         }
         EagerCtl h;

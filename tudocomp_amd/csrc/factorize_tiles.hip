@@ -539,7 +539,7 @@ int factorize_window_levels(Ctx& c, size_t n, const u32* cur, const u32* prio, c
         const u32 ntiles = cdiv(n, ti);
         const u32 grid = ntiles < max_grid ? ntiles : max_grid;
         HIP_TRY(hipMemsetAsync(d_sc, 0, sizeof(WinScalars), s));
-        { const int big = BIG; HIP_TRY(hipMemcpyAsync(&d_sc->min_margin, &big, sizeof(int), hipMemcpyHostToDevice, s)); }
+        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)&d_sc->min_margin, BIG, 1, s));       // (not a copy from pageable memory: that one drains the stream first)
         {
             // per window position: cur (4) + residence (1); per text position: ~0.1 priority reads and the factor output
             Ctx::ProfScope prof(c, K_WINDOW_LEVELS, (u64)((double)n * TW / ti * 5) + (u64)n * 2);

@@ -1041,28 +1041,33 @@ __global__ __launch_bounds__(NW * 64) void ws_leaf_count_kernel(WLeaf A, const u
 constexpr u32 EC_TILE = 256 * 32;
 constexpr int EC_NCLS = 4 + WIDE_NCLS;
 __global__ __launch_bounds__(256) void ws_emit_compact_kernel(const u32* __restrict__ rng, u32 nent, u32* __restrict__ lists, u32 cap, u32* __restrict__ counters) {
-    __shared__ u32 cnt[EC_NCLS], base[EC_NCLS];
-    if (threadIdx.x < EC_NCLS) cnt[threadIdx.x] = 0;
+    __shared__ u32 cnt[EC_NCLS], base[EC_NCLS], recs[EC_NCLS];
+    if (threadIdx.x < EC_NCLS) { cnt[threadIdx.x] = 0; recs[threadIdx.x] = 0; }
     __syncthreads();
     const u32 i0 = blockIdx.x * EC_TILE + threadIdx.x;
     u32 codes[4] = { 0, 0, 0, 0 };                             // 4 bits per entry: class + 1 (0 = empty)
 #pragma unroll
     for (int q = 0; q < 32; ++q) {
         const u32 i = i0 + (u32)q * 256;
-        u32 code = 0;
+        u32 code = 0, braw_m = 0;
         if (i < nent) {
             const u32 a = rng[2 * (size_t)i], braw = rng[2 * (size_t)i + 1];
             const u32 m = (braw & 0x7FFFFFFFu) - a;
+            braw_m = m;
             if (m > 0) {
                 if ((braw >> 31) && m <= WS_WAVE_MAX) code = m <= 32 ? 1u : (m <= 64 ? 2u : (m <= 256 ? 3u : 4u));
                 else code = 5u + wide_class(m);
             }
         }
         codes[q >> 3] |= code << (4 * (q & 7));
-        if (code) atomicAdd(&cnt[code - 1], 1u);
+        if (code) { atomicAdd(&cnt[code - 1], 1u); atomicAdd(&recs[code - 1], (braw_m)); }
     }
     __syncthreads();
-    if (threadIdx.x < EC_NCLS) { const u32 c = cnt[threadIdx.x]; base[threadIdx.x] = c ? atomicAdd(counters + threadIdx.x, c) : 0u; cnt[threadIdx.x] = 0; }
+    if (threadIdx.x < EC_NCLS) {
+        const u32 c = cnt[threadIdx.x];
+        base[threadIdx.x] = c ? atomicAdd(counters + threadIdx.x, c) : 0u; cnt[threadIdx.x] = 0;
+        if (recs[threadIdx.x]) atomicAdd(counters + EC_NCLS + threadIdx.x, recs[threadIdx.x]);      // records per class (the bench table's byte counts)
+    }
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < 32; ++q) {
@@ -1549,6 +1554,7 @@ int ws_sort_impl(Ctx& c, const WKeyGen* gen, u64* K1[2], u64* K2[2], u32* V[2], 
         u32 cur_cnt[NB];
         for (int q = 0; q < NB; ++q) cur_cnt[q] = U.whc[q];
         u32 wave_cnt[4] = { 0, 0, 0, 0 };                        // runs for the lane / wave kernels (classes 0 .. 3 of the previous stage's hand-over)
+        u64 wave_recs = 0;                                       // ... and the records in them
         const u32* wave_list = nullptr;
         const u32 ediv = A.cmax + 1;                            // a run that is handed on has more than cmax members
         const u32 ecap2 = (u32)(n / ediv + 2);
@@ -1557,7 +1563,7 @@ int ws_sort_impl(Ctx& c, const WKeyGen* gen, u64* K1[2], u64* K2[2], u32* V[2], 
         u32* lc = c.arena.get<u32>(64);                          // [0 .. 2 NB): per class |rlist|, |tlist|; [2 NB ..): next stage's runs / units per class
         for (int stage = 0; stage < 8; ++stage) {
             if (wave_cnt[0] | wave_cnt[1] | wave_cnt[2] | wave_cnt[3]) {
-                Ctx::ProfScope prof(c, K_WS_RUN, 0);
+                Ctx::ProfScope prof(c, K_WS_RUN, wave_recs * 18);          // per record: second word + position in (12 B), position + flag + LCP out (6 B)
                 A.unit_rng = cur_rng;
                 const u32* l0 = wave_list, *l1 = wave_list + cur_cap, *l2 = wave_list + 2 * cur_cap, *l3 = wave_list + 3 * cur_cap;
                 if (wave_cnt[0]) { ws_run_lane_kernel<32, PAIRS><<<cdiv(wave_cnt[0], 8), 256, 0, s>>>(A, l0, wave_cnt[0]); LAUNCH_CHECK(); }
@@ -1642,8 +1648,8 @@ int ws_sort_impl(Ctx& c, const WKeyGen* gen, u64* K1[2], u64* K2[2], u32* V[2], 
             c.prof_end(pb);
             ws_emit_compact_kernel<<<cdiv(ecap2, EC_TILE), 256, 0, s>>>(e_rng[stage & 1], ecap2, e_cls[stage & 1], ecap2, lc + 2 * NB);
             LAUNCH_CHECK();
-            u32 he[EC_NCLS];
-            c.read_n(lc + 2 * NB, he, EC_NCLS);
+            u32 he[2 * EC_NCLS];                                 // runs / units per class, then their records per class
+            c.read_n(lc + 2 * NB, he, 2 * EC_NCLS);
             if (c.wsort_log) {
                 fprintf(stderr, "[wsort] n=%zu stage %d: units", n, stage);
                 for (int q = 0; q < NB; ++q) fprintf(stderr, " %u", cur_cnt[q]);
@@ -1658,6 +1664,7 @@ int ws_sort_impl(Ctx& c, const WKeyGen* gen, u64* K1[2], u64* K2[2], u32* V[2], 
             cur_rng = e_rng[stage & 1]; cur_cls = e_cls[stage & 1] + 4 * (size_t)ecap2; cur_cap = ecap2;
             wave_list = e_cls[stage & 1];
             for (int q = 0; q < 4; ++q) wave_cnt[q] = he[q];
+            wave_recs = (u64)he[EC_NCLS] + he[EC_NCLS + 1] + he[EC_NCLS + 2] + he[EC_NCLS + 3];
             for (int q = 0; q < NB; ++q) cur_cnt[q] = he[4 + q];
             st->leaf_stages = (u32)stage + 1;
         }
