@@ -413,6 +413,37 @@ __device__ __forceinline__ u64 wave_match_lds(unsigned long long* M, u32 d, bool
     return peers;
 }
 
+// The same with the frequent digits taken out first (round 6).  Lanes that hold the same digit hit the same LDS word with their atomic
+// OR, and the LDS unit serialises them: in the passes over the high-order digits of a leaf (a handful of distinct values per row) one
+// match costs 16 - 32 LDS cycles instead of 2 -- `SQ_LDS_BANK_CONFLICT` was 46 % of the LDS array cycles of ws_leaf_sort_kernel.  Up to
+// PEEL times the digit of the first remaining lane is matched by a ballot instead (all of its lanes leave together, so the digits that
+// reach the table never mix with peeled ones); a group of fewer than MING lanes ends the peeling (the rest of the row is diverse: few
+// lanes per word).  Zero on entry, zero on exit, like wave_match_lds.
+template <int PEEL, int MING>
+__device__ __forceinline__ u64 wave_match_peel(unsigned long long* M, u32 d, bool valid, u64 lanebit) {
+    u64 rem = __ballot(valid);
+    u64 peers = 0;
+    bool done = !valid;
+#pragma unroll
+    for (int it = 0; it < PEEL; ++it) {
+        if (!rem) break;
+        const int lead = __builtin_ctzll(rem);
+        const u32 dl = (u32)__builtin_amdgcn_readlane((int)d, lead);
+        const u64 grp = __ballot(!done && d == dl);
+        if (__popcll(grp) < MING) break;
+        if (!done && d == dl) { peers = grp; done = true; }
+        rem &= ~grp;
+    }
+    if (rem) {                                                    // (uniform: the rest of the row through the table)
+        if (!done) atomicOr((unsigned*)&M[d] + (lane_id() >> 5), (unsigned)(lanebit >> (32 * (lane_id() >> 5))));
+        __builtin_amdgcn_wave_barrier();
+        if (!done) peers = lds_load(&M[d]);
+        __builtin_amdgcn_wave_barrier();
+        if (!done) lds_store(&M[d], 0ull);
+    }
+    return peers;
+}
+
 // Block-wide exclusive sum for a block of NW waves (NW*64 threads).  `smem` must hold NW+1 values of T.
 // Returns the exclusive prefix of `v` over the block in thread order; `total` receives the block sum.
 template <typename T, int NW>

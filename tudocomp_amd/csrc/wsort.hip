@@ -29,6 +29,9 @@ namespace tdc {
 constexpr int WS_TILE = 4096;        // records per partition tile: 256 threads x 16
 constexpr int WS_ITEMS = 16;
 constexpr int WS_HALO = 64;          // symbols staged beyond a tile (s <= 64)
+#ifndef TDC_WS_PEEL
+#define TDC_WS_PEEL 0
+#endif
 #ifndef TDC_WS_CMAX
 #define TDC_WS_CMAX 64
 #endif
@@ -374,7 +377,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FMAX > 256 
             for (int j = 0; j < WS_ITEMS; ++j) {
                 const bool valid = lbs + (u32)j * estep < cnt;
                 const u32 d = valid ? dg[j] : 0u;
+#if TDC_WS_PEEL > 0
+                const u64 peers = wave_match_peel<TDC_WS_PEEL, 8>(M, d, valid, lanebit);
+#else
                 const u64 peers = wave_match_lds(M, d, valid, lanebit);
+#endif
                 const u32 prefix = lds_load(&mycnt[d]);
                 const u32 rank = (u32)__popcll(peers & lt_mask);
                 ld[j] = (d << 16) | (prefix + rank);
@@ -505,8 +512,18 @@ constexpr int WL_NW = 8;             // waves per leaf workgroup
 #ifndef WL_NBMAX
 #define WL_NBMAX 51
 #endif
+#ifndef TDC_WL_PEEL
+#define TDC_WL_PEEL 1
+#endif
+#ifndef TDC_WL_MING
+#define TDC_WL_MING 8
+#endif
 __device__ __forceinline__ u32 wl_rank(u32 d, bool valid, u32* mycnt, unsigned long long* M, u64 lanebit, u64 lt_mask) {
+#if TDC_WL_PEEL > 0
+    const u64 peers = wave_match_peel<TDC_WL_PEEL, TDC_WL_MING>(M, d, valid, lanebit);
+#else
     const u64 peers = wave_match_lds(M, d, valid, lanebit);
+#endif
     const u32 prefix = lds_load(&mycnt[d]);
     const u32 rank = (u32)__popcll(peers & lt_mask);
     if (valid && rank == 0) lds_store(&mycnt[d], prefix + (u32)__popcll(peers));
