@@ -1,6 +1,7 @@
 cd $GRAFT_REPO_ROOT
 export BENCH_ARGS="--no-extra"
 V=$PWD/tudocomp_amd/lib/variants
-tools/ab.sh "TDC_GPU_LIB=$V/peel0.so" "TDC_GPU_LIB=$V/peel1.so" "TDC_GPU_LIB=$V/peel0.so" "TDC_GPU_LIB=$V/peel1.so" "TDC_GPU_LIB=$V/peel0.so" "TDC_GPU_LIB=$V/peel1.so" > gpurun_out/c11_ab.log 2> gpurun_out/c11_ab.err
-grep "^==\|^value" gpurun_out/c11_ab.log | cut -c1-200 | paste - -
-grep -o "ws_leaf_sort_kernel=[0-9.]*" gpurun_out/c11_ab.log | paste - - - - - -
+( timeout -k 10 600 python -m pytest tests/test_gpu_wsort.py tests/test_gpu_sa_refine.py tests/test_gpu_sort.py -x -q 2>&1 | tail -2 )
+tools/ab.sh "TDC_GPU_LIB=$V/cg0.so" "X=cg4" "TDC_GPU_LIB=$V/cg2.so" "TDC_GPU_LIB=$V/cg8.so" "TDC_GPU_LIB=$V/cg0.so" "X=cg4" > gpurun_out/c14_ab.log 2> gpurun_out/c14_ab.err
+grep "^==\|^value" gpurun_out/c14_ab.log | cut -c1-200 | paste - -
+grep -o "rs_count_kernel=[0-9.]*" gpurun_out/c14_ab.log | paste - - - - - -
