@@ -1,7 +1,5 @@
 cd $GRAFT_REPO_ROOT
-export BENCH_ARGS="--no-extra"
-V=$PWD/tudocomp_amd/lib/variants
-( timeout -k 10 600 python -m pytest tests/test_gpu_wsort.py tests/test_gpu_sa_refine.py tests/test_gpu_sort.py -x -q 2>&1 | tail -2 )
-tools/ab.sh "TDC_GPU_LIB=$V/cg0.so" "X=cg4" "TDC_GPU_LIB=$V/cg2.so" "TDC_GPU_LIB=$V/cg8.so" "TDC_GPU_LIB=$V/cg0.so" "X=cg4" > gpurun_out/c14_ab.log 2> gpurun_out/c14_ab.err
-grep "^==\|^value" gpurun_out/c14_ab.log | cut -c1-200 | paste - -
-grep -o "rs_count_kernel=[0-9.]*" gpurun_out/c14_ab.log | paste - - - - - -
+timeout -k 10 1100 python -m pytest tests -m gpu -x -q > gpurun_out/c15_gputests.log 2>&1; tail -4 gpurun_out/c15_gputests.log
+( timeout -k 10 400 python tools/stress_check.py 240 601 2>&1 | tail -3 ) > gpurun_out/r06_stress.txt; cat gpurun_out/r06_stress.txt
+( timeout -k 10 300 python tools/pathological_check.py 2>&1 | tail -12 ) > gpurun_out/r06_pathological.txt; tail -4 gpurun_out/r06_pathological.txt
+( timeout -k 10 300 python tools/pathological_check.py 40000000 2>&1 | tail -12 ) > gpurun_out/r06_pathological_40M.txt; tail -4 gpurun_out/r06_pathological_40M.txt

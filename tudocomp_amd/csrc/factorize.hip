@@ -2122,8 +2122,9 @@ void factorize_max_lcp(Ctx& c, size_t n, u32* isa, const u32* phi, u32* plcp, u3
     const size_t pool_cap = 4 * n;
     u32* pool = c.arena.get<u32>(pool_cap);
     LevelScalars* d_sc = (LevelScalars*)c.arena.alloc(sizeof(LevelScalars));
-    // one factor of length L can send up to L entries to L different levels (eager decreases): room for min(n, 4 Mi) targets
-    const u32 seg_cap = (u32)std::max<size_t>((size_t)1 << 16, std::min<size_t>(n, (size_t)4 << 20));
+    // one factor of length L can send up to L entries to L different levels (eager decreases): room for min(n, maxlcp + 2, 64 Mi) targets
+    // (the ramp of one giant repeat -- a Fibonacci word of 40 M symbols -- fills millions of them)
+    const u32 seg_cap = (u32)std::max<size_t>((size_t)1 << 16, std::min<size_t>(std::min<size_t>(n, (size_t)maxlcp + 2), (size_t)64 << 20));
     PushSeg* d_segs = (PushSeg*)c.arena.alloc(sizeof(PushSeg) * seg_cap);
     std::vector<PushSeg> h_segs;
     LevelScalars h_sc;
