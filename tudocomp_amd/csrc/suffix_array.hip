@@ -755,7 +755,9 @@ __global__ __launch_bounds__(256) void sa_star_keys_kernel(const u32* __restrict
         u32 L = (u32)v;
         const u32 side = (u32)(v >> 32) & 3u;
         u32 ch = (u32)(v >> 40) & 0xFFu;
-        if (L >= maxl) { L = maxl - 1u; ch = 0; }                // (beyond the field: such members tie -- the doubling rounds order them)
+        // (beyond the field: such members tie -- the doubling rounds order them.  The clamped class takes the value maxl - 1 for itself:
+        //  a member whose extension really is maxl - 1 long must not share it, its byte would order it against members it ties with)
+        if (L >= maxl - 1u) { L = maxl - 1u; ch = 0; }
         const u32 f = side == 0 ? L : maxl - L;
         second = (side << (bn - 2)) | (f << 8) | ch;
     }
