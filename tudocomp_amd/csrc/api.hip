@@ -362,6 +362,7 @@ const OptionDef OPTIONS[] = {
     { "dec_log",          [](Ctx& c, long v) { c.dec_log = v != 0; } },
     { "window_force_fail",[](Ctx& c, long v) { c.window_force_fail = v ? 1 : 0; } },
     { "window_large",     [](Ctx& c, long v) { c.window_large_lists = v ? 1 : 0; } },
+    { "window_src",       [](Ctx& c, long v) { c.window_src = v ? 1 : 0; } },
     { "plcp_samples",     [](Ctx& c, long v) { c.plcp_samples = v != 0; } },
     { "small_pipeline",   [](Ctx& c, long v) { c.small_pipeline = v != 0; } },
     { "small_big",        [](Ctx& c, long v) { c.small_big = (int)v; } },

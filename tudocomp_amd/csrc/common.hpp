@@ -163,6 +163,7 @@ struct Ctx {
     int xcd_remap = 1;             // XCD-contiguous tile walk (env TDC_GPU_XCD_REMAP): 0 = only in the final pass of the bucketed scatter
                                    // (-1.2 ms of 7.3), 1 = also in the radix sort kernels (with the LDS-reordered scatter the 128-byte
                                    // pieces of neighbouring tiles then meet in one L2: -13 %), 2 = nowhere
+    int window_src = 1;            // window pass without a Phi array: the kernel writes fsrc[p] = SA[ISA[p] - 1] at its factor starts itself -- its VALU-bound waves hide the two gathers that cost flatten_init 3.7 ms (window kernel + 1.1 ms: -2.5 ms per step; option window_src=0: the sources are computed in flatten_init)
     int window_lcut = 48;          // factorize: levels <= this run window-local in one launch (env TDC_GPU_WINDOW_LCUT, 0 disables)
     int window_halo = 384;         // window pass: halo of the first attempt (env TDC_GPU_WINDOW_HALO; a failed border retries with 2048)
     size_t dec_seg = 0;            // decompression: bit positions per segment of the chain marking (0: 2^30; env TDC_GPU_DEC_SEG, tests)

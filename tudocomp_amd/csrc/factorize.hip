@@ -1178,6 +1178,7 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
     pushed_into.init((size_t)maxlcp + 2);
     size_t pool_top = 0;
     u32 prio_base = (u32)n;
+    bool window_src_done = false;
 
     u32 dead_streak = 0, levels_since_purge = 1u << 30;
     bool purge_pays = false;                               // a level too large for the one-workgroup path consisted mostly of erased entries
@@ -1328,8 +1329,10 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
                 for (u32 v = threshold; v <= lcut && v < 64u; ++v) mx = std::max<u64>(mx, hh[v]);
                 start_large = (double)mx * 16.0 * (double)window_levels_window() / (double)n > 4.0 * (double)window_levels_small_list();
             }
-            const int why = factorize_window_levels(c, n, cur, prio, res8, phi, lcut, threshold, fs, &nf, start_large);
+            const bool wsrc = !phi && c.window_src;               // (option window_src: the window kernel fetches the sources of its factors itself)
+            const int why = factorize_window_levels(c, n, cur, prio, res8, phi, lcut, threshold, fs, &nf, start_large, wsrc ? sa : nullptr);
             const bool ok = why == 0;
+            if (ok && wsrc) window_src_done = true;
             st->window_pass = ok ? 1 : 2;
             st->window_lcut = lcut;
             if (ok) { st->factors += nf; break; }
@@ -1847,7 +1850,9 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
         }
     }
     c.arena.release(mark);
-    build_owner(c, n, fs); if (!phi) { fs.src_prio = prio; fs.src_sa = sa; fs.src_n = n; }
+    // (window_src_done: every factor start has its source in fsrc[] -- the candidates of the global levels since cand_class_kernel, pushed
+    //  entries since their push, the window pass' natural entries since the window kernel)
+    build_owner(c, n, fs); if (!phi && !window_src_done) { fs.src_prio = prio; fs.src_sa = sa; fs.src_n = n; }
 }
 
 // ============================================================================================================

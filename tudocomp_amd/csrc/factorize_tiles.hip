@@ -127,7 +127,7 @@ __device__ __forceinline__ u32 hit4(u32 w, u32 pat) {
     const u32 x = (w & 0x7F7F7F7Fu) ^ pat;               // a zero byte = a match; bytes are <= 0x7F, so the addition never carries
     return ~(x + 0x7F7F7F7Fu) & 0x80808080u;
 }
-template <int KT, int TE, int WPE, bool WPHI>      // threads, entries per level; WPE = waves per SIMD the register budget is set for; WPHI: sources from a Phi array
+template <int KT, int TE, int WPE, int WSRC>       // threads, entries per level; WPE = waves per SIMD the register budget is set for; WSRC: 0 no sources written, 1 from a Phi array, 2 SA[ISA[p] - 1] (`phi` is the suffix array then)
 __global__ __launch_bounds__(KT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void window_eager_kernel(const u32* __restrict__ cur_g, const u32* __restrict__ prio_g,
                                                             const u8* __restrict__ res_g, const u32* __restrict__ phi, size_t n,
                                                             u32 lcut, u32 threshold, u32 ntiles, u32 halo,
@@ -486,8 +486,10 @@ __global__ __launch_bounds__(KT) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) 
                             const size_t gp = w0 + pos;
                             if (flen8) flen8[gp] = (u8)((rw >> (8 * bb)) & 0x3Fu);      // (FactorSpace::flen8: the lengths as bytes)
                             else flen[gp] = (u32)(rw >> (8 * bb)) & 0x3Fu;
-                            if constexpr (WPHI) fsrc[gp] = phi[gp];     // (without a Phi array the sources are computed from SA[ISA[p] - 1] where they
-                                                                        //  are needed: FactorSpace::src_prio, flatten.hip)
+                            if constexpr (WSRC == 1) fsrc[gp] = phi[gp];    // (without a Phi array the sources are computed from SA[ISA[p] - 1] where they
+                                                                            //  are needed: FactorSpace::src_prio, flatten.hip -- or here, WSRC == 2: an entry
+                                                                            //  whose priority is no rank any more was pushed, its source was saved then)
+                            else if constexpr (WSRC == 2) { const u32 r = prio_g[gp]; if (r < (u32)n) fsrc[gp] = r ? phi[r - 1] : phi[n - 1]; }
                             ++nsel_interior;
                         }
                     }
@@ -517,7 +519,7 @@ u32 window_levels_small_list() { return (u32)TE_SMALL; }
 size_t window_levels_min_text() { return (size_t)4 * TW; }
 
 int factorize_window_levels(Ctx& c, size_t n, const u32* cur, const u32* prio, const u8* res8, const u32* phi, u32 lcut, u32 threshold,
-                            FactorSpace fs, u64* nfactors, bool start_large) {
+                            FactorSpace fs, u64* nfactors, bool start_large, const u32* src_sa) {
     *nfactors = 0;
     if (lcut < threshold) return 0;
     hipStream_t s = c.stream;
@@ -544,11 +546,13 @@ int factorize_window_levels(Ctx& c, size_t n, const u32* cur, const u32* prio, c
             // per window position: cur (4) + residence (1); per text position: ~0.1 priority reads and the factor output
             Ctx::ProfScope prof(c, K_WINDOW_LEVELS, (u64)((double)n * TW / ti * 5) + (u64)n * 2);
             if (!large) {
-                if (phi) window_eager_kernel<TT, TE_SMALL, TDC_WIN_WPE, true><<<grid, TT, 0, s>>>(cur, prio, res8, phi, n, lcut, threshold, ntiles, halo, fs.flen, fs.flen8, fs.fsrc, d_sc);
-                else window_eager_kernel<TT, TE_SMALL, TDC_WIN_WPE, false><<<grid, TT, 0, s>>>(cur, prio, res8, phi, n, lcut, threshold, ntiles, halo, fs.flen, fs.flen8, fs.fsrc, d_sc);
+                if (phi) window_eager_kernel<TT, TE_SMALL, TDC_WIN_WPE, 1><<<grid, TT, 0, s>>>(cur, prio, res8, phi, n, lcut, threshold, ntiles, halo, fs.flen, fs.flen8, fs.fsrc, d_sc);
+                else if (src_sa) window_eager_kernel<TT, TE_SMALL, TDC_WIN_WPE, 2><<<grid, TT, 0, s>>>(cur, prio, res8, src_sa, n, lcut, threshold, ntiles, halo, fs.flen, fs.flen8, fs.fsrc, d_sc);
+                else window_eager_kernel<TT, TE_SMALL, TDC_WIN_WPE, 0><<<grid, TT, 0, s>>>(cur, prio, res8, phi, n, lcut, threshold, ntiles, halo, fs.flen, fs.flen8, fs.fsrc, d_sc);
             } else {
-                if (phi) window_eager_kernel<TT_LARGE, TE_LARGE, TT_LARGE / 256, true><<<grid, TT_LARGE, 0, s>>>(cur, prio, res8, phi, n, lcut, threshold, ntiles, halo, fs.flen, fs.flen8, fs.fsrc, d_sc);
-                else window_eager_kernel<TT_LARGE, TE_LARGE, TT_LARGE / 256, false><<<grid, TT_LARGE, 0, s>>>(cur, prio, res8, phi, n, lcut, threshold, ntiles, halo, fs.flen, fs.flen8, fs.fsrc, d_sc);
+                if (phi) window_eager_kernel<TT_LARGE, TE_LARGE, TT_LARGE / 256, 1><<<grid, TT_LARGE, 0, s>>>(cur, prio, res8, phi, n, lcut, threshold, ntiles, halo, fs.flen, fs.flen8, fs.fsrc, d_sc);
+                else if (src_sa) window_eager_kernel<TT_LARGE, TE_LARGE, TT_LARGE / 256, 2><<<grid, TT_LARGE, 0, s>>>(cur, prio, res8, src_sa, n, lcut, threshold, ntiles, halo, fs.flen, fs.flen8, fs.fsrc, d_sc);
+                else window_eager_kernel<TT_LARGE, TE_LARGE, TT_LARGE / 256, 0><<<grid, TT_LARGE, 0, s>>>(cur, prio, res8, phi, n, lcut, threshold, ntiles, halo, fs.flen, fs.flen8, fs.fsrc, d_sc);
             }
             LAUNCH_CHECK();
         }

@@ -14,7 +14,7 @@ namespace tdc {
 // phi may be NULL: fsrc[] is then left alone at the factor starts of this pass -- their sources are computed where they are needed
 // (FactorSpace::src_prio: SA[ISA[p] - 1]; prio[p] is still ISA[p] unless a push at a global level overwrote it, and then fsrc[p] was saved).
 int factorize_window_levels(Ctx& c, size_t n, const u32* cur, const u32* prio, const u8* res8, const u32* phi, u32 lcut, u32 threshold,
-                             FactorSpace fs, u64* nfactors, bool start_large = false);
+                             FactorSpace fs, u64* nfactors, bool start_large = false, const u32* src_sa = nullptr);   // src_sa (with phi == NULL): the pass writes fsrc[p] = SA[ISA[p] - 1] itself
 u32 window_levels_window();         // positions per window
 u32 window_levels_small_list();     // entries of one level the small per-level lists hold
 u32 window_levels_max_lcut();       // one presence bit per level in a 64-bit mask
