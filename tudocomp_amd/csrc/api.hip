@@ -396,6 +396,8 @@ const OptionDef OPTIONS[] = {
     { "wsort_rounds",     [](Ctx& c, long v) { c.wsort_rounds = clampi(v, 0, 100); } },
     { "wsort_smallrun",   [](Ctx& c, long v) { c.wsort_small = v ? 1 : 0; } },
     { "wsort_overlap",    [](Ctx& c, long v) { c.wsort_overlap = v ? 1 : 0; } },
+    { "wsort_predig",     [](Ctx& c, long v) { c.wsort_predig = v ? 1 : 0; } },
+    { "wsort_predig_skip",[](Ctx& c, long v) { c.wsort_predig_skip = clampi(v, 0, 24); } },
     { "wsort_fuse",       [](Ctx& c, long v) { c.wsort_fuse = v ? 1 : 0; } },
     { "wsort_order",      [](Ctx& c, long v) { c.wsort_order = v ? 1 : 0; } },
     { "wsort_two",        [](Ctx& c, long v) { c.wsort_two = (v >= 0 && v <= 2) ? (int)v : 0; } },
@@ -404,6 +406,8 @@ const OptionDef OPTIONS[] = {
     { "wsort_cmax",       [](Ctx& c, long v) { c.wsort_cmax = clampi(v, 8, 64); } },       // (the hand-over lists take 128 n / (cmax + 1) bytes: below 8 they outgrow the arena)
     { "wsort_log",        [](Ctx& c, long v) { c.wsort_log = v != 0; } },
     { "upload_chunks",    [](Ctx& c, long v) { c.upload_chunks = clampi(v, 4, 24); } },
+    { "upload_tail_n",    [](Ctx& c, long v) { c.upload_tail_n = clampi(v, 0, 12); } },
+    { "upload_tail_pct",  [](Ctx& c, long v) { c.upload_tail_pct = clampi(v, 30, 100); } },
     { "arena_log",        [](Ctx& c, long v) { c.arena_log = v != 0; } },
 };
 constexpr size_t NOPTIONS = sizeof(OPTIONS) / sizeof(OPTIONS[0]);
@@ -457,6 +461,12 @@ int tdc_gpu_ctx_create(int device, tdc_gpu_ctx** out) {
         HIP_TRY(hipStreamCreateWithFlags(&ctx->c.stream, hipStreamNonBlocking));
         for (auto& e : ctx->c.ev) HIP_TRY(hipEventCreate(&e));
         HIP_TRY(hipStreamCreateWithFlags(&ctx->c.copy_stream, hipStreamNonBlocking));
+        {   // the side stream takes the lowest priority the device offers
+            int lo = 0, hi = 0;
+            if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = 0; (void)hipGetLastError(); }
+            if (hipStreamCreateWithPriority(&ctx->c.aux_stream, hipStreamNonBlocking, lo) != hipSuccess) { ctx->c.aux_stream = nullptr; (void)hipGetLastError(); }
+            for (auto& e : ctx->c.ev_aux) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
         for (auto& e : ctx->c.ev_copy) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         ctx->c.pinned_size = 4096;
         HIP_TRY(hipHostMalloc(&ctx->c.pinned, ctx->c.pinned_size, hipHostMallocDefault));
@@ -498,6 +508,8 @@ void tdc_gpu_ctx_destroy(tdc_gpu_ctx* ctx) {
     for (auto& e : ctx->c.ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : ctx->c.ev_copy) if (e) (void)hipEventDestroy(e);
     if (ctx->c.copy_stream) { (void)hipStreamSynchronize(ctx->c.copy_stream); (void)hipStreamDestroy(ctx->c.copy_stream); }
+    if (ctx->c.aux_stream) { (void)hipStreamSynchronize(ctx->c.aux_stream); (void)hipStreamDestroy(ctx->c.aux_stream); }
+    for (auto& e : ctx->c.ev_aux) if (e) (void)hipEventDestroy(e);
     if (ctx->c.ev_pool) { for (int i = 0; i < ctx->c.ev_pool_size; ++i) if (ctx->c.ev_pool[i]) (void)hipEventDestroy(ctx->c.ev_pool[i]); free(ctx->c.ev_pool); }
     free(ctx->c.pend);
     if (ctx->c.stream) (void)hipStreamDestroy(ctx->c.stream);
@@ -636,7 +648,11 @@ void compress_host(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, bool raw, ui
             std::vector<size_t> coff;
             {
                 std::vector<double> w(CH, 1.0);
-                if (try_pre) { w[CH - 3] = 0.6; w[CH - 2] = 0.36; w[CH - 1] = 0.22; }
+                if (try_pre) {                                   // (the last chunks shrink geometrically: options upload_tail_n / upload_tail_pct)
+                    const size_t T = std::min<size_t>((size_t)c.upload_tail_n, CH - 1);
+                    double f = 1.0;
+                    for (size_t k = 0; k < T; ++k) { f *= (double)c.upload_tail_pct / 100.0; w[CH - T + k] = f; }
+                }
                 double tot = 0; for (double x : w) tot += x;
                 coff.push_back(0);
                 double acc = 0;
@@ -691,7 +707,7 @@ void compress_host(tdc_gpu_ctx* ctx, const uint8_t* text, size_t n, bool raw, ui
         ~SinkGuard() { if (c.d2h_done && c.copy_stream) (void)hipStreamSynchronize(c.copy_stream); c.d2h_host = nullptr; c.d2h_cap = 0; c.d2h_done = 0; }
     } sink_guard{c};
     c.d2h_host = ho.into; c.d2h_cap = ho.into ? ho.cap : 0; c.d2h_done = 0;      // the encoder may start the D2H while it still packs
-    struct PreGuard { Ctx& c; ~PreGuard() { if (c.wpre) { c.wpre->active = false; c.wpre->begun = false; } c.arena.release_top(); } } pre_guard{c};
+    struct PreGuard { Ctx& c; ~PreGuard() { if (c.wpre) { c.wpre->active = false; c.wpre->begun = false; } if (c.aux_stream) (void)hipStreamSynchronize(c.aux_stream); c.arena.release_top(); } } pre_guard{c};   // (the side stream is idle by now unless the call failed half-way)
     const size_t len = run_pipeline(c, d_text, tn, threshold, flatten, coder, &d_out, 0, stats, ev, comp);
     const int e2 = ev.tick();
     *ho.out_len = len;

@@ -181,6 +181,8 @@ struct Ctx {
     int wsort_rounds = 24;         // most text rounds before the doubling fallback (env TDC_GPU_WSORT_ROUNDS; 0: straight to doubling)
     int wsort_cmax = 16;           // leaf sort: runs of tying records up to this length are ordered by counting, longer ones by the wave kernel (option wsort_cmax, 8 .. 64)
     int wsort_overlap = 1;         // host-buffer calls: level 1 of the wide suffix sort runs chunk by chunk behind the upload (env TDC_GPU_WSORT_OVERLAP=0 disables)
+    int wsort_predig_skip = 6;     // ... but not for the last chunks (their digits would only be ready after the last copy; option wsort_predig_skip; 0 / 2 / 3 / 4 / 6: 257.5 / 257.5 / 257.4 / 257.2 / 257.0 ms against 260.8 without)
+    int wsort_predig = 1;          // with the overlapped level 1: the digits of level 2 are computed chunk by chunk behind the upload too, on the low-priority side stream (option wsort_predig; round 4 measured it on the main stream, where it lengthened the upload by more than it saved)
     int wsort_two = 0;             // wide sort of more than 235 M records: two partition levels of up to 1024 buckets instead of three of up to 256 (env TDC_GPU_WSORT_TWO)
     int wsort_leaf = 2048;         // leaf size the three-level wide sort aims at (env TDC_GPU_WSORT_LEAF: 1024 | 2048)
     int wsort_pack = 2048;         // leaf sort: leaves up to this size are packed into units of at most twice that (env TDC_GPU_WSORT_PACK: 1024 | 2048 | 4096)
@@ -192,6 +194,7 @@ struct Ctx {
     // (the options below used to be read from the environment wherever they were used; since round 6 every option is a field that only
     //  tdc_gpu_ctx_set_option() writes -- api.hip, one table -- and the shipped library never looks at TDC_GPU_* variables unless
     //  TDC_GPU_DEBUG_KNOBS=1 asks tdc_gpu_ctx_create() to apply them through that same function)
+    int upload_tail_n = 3, upload_tail_pct = 60;   // the last upload_tail_n chunks of the overlapped upload shrink by this factor each (0.6, 0.36, 0.22: what is left behind the last copy is the device work of a small chunk)
     int upload_chunks = 16;        // chunks of the overlapped upload (4 .. 24: ev_copy[16 ..]; option upload_chunks)
     int flatten_steps = 1;         // flatten: chain steps per factor in the first round (0: unlimited; measured: 1,2,4,.. 8.5 ms; unlimited 11.2 ms)
     int flatten_growth = 8;        // ... and the factor the budget grows by per round (measured at 256 MiB: x2 8.4 ms, x4 7.4 ms, x8 7.0 ms)
@@ -207,6 +210,8 @@ struct Ctx {
     const u8* hist_ptr = nullptr;
     size_t hist_n = 0;
     hipStream_t copy_stream = nullptr;
+    hipStream_t aux_stream = nullptr;  // low-priority side stream: work that fills idle device time behind the upload (wsort.hip wsort_pre_chunk)
+    hipEvent_t ev_aux[2] = {};
     hipEvent_t ev_copy[40] = {};
     struct WPre* wpre = nullptr;   // level 1 of the suffix sort done behind the upload (prim.hpp), owned by the API context
     u8* d2h_host = nullptr;        // destination (host) of the running call, or null

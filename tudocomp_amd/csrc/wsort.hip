@@ -48,6 +48,7 @@ struct WSLevel {
     const u64* sp1; const u64* sp2;      // [NS + 1] splitters (high / low word), sp[NS] = ~0
     u16* digits;
     u32 nseg, F, stride, R, D, per_xcd;
+    u32 pre_digits = 0;          // count pass of the merging level: the pieces of the first pre_digits chunks have their digits in `digits` already (computed chunk by chunk behind the upload): read them, search nothing
     size_t gen_off, gen_len;     // GEN level: the tiles cover text positions [gen_off, gen_off + gen_len)
 };
 
@@ -283,6 +284,7 @@ __global__ __launch_bounds__(256) void ws_count_kernel(WSLevel P, WKeyGen g, u32
         dp[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
         dp[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
     } else {
+        const bool have_digits = (s % P.sub) < P.pre_digits;          // (piece s = bucket * chunks + chunk)
         const u32 lb = wave_id() * (64 * WS_ITEMS) + lane_id();
         const u64* kp1 = P.k1_in + base + lb;
         const u64* kp2 = KW == 2 ? P.k2_in + base + lb : nullptr;
@@ -291,10 +293,14 @@ __global__ __launch_bounds__(256) void ws_count_kernel(WSLevel P, WKeyGen g, u32
         for (int j = 0; j < WS_ITEMS; ++j) {
             const u32 e = lb + (u32)j * 64;
             const bool valid = e < cnt;
-            const u64 x1 = valid ? kp1[j * 64] : 0ull;
-            const u64 x2 = (KW == 2 && valid) ? kp2[j * 64] : 0ull;
-            const u32 d = valid ? ws_digit<KW, LAST, FMAX>(spl1, spl2, x1, x2) : 0u;
-            if (valid) dgp[j * 64] = (u16)d;
+            u32 d = 0;
+            if (have_digits) { if (valid) d = dgp[j * 64]; }
+            else {
+                const u64 x1 = valid ? kp1[j * 64] : 0ull;
+                const u64 x2 = (KW == 2 && valid) ? kp2[j * 64] : 0ull;
+                d = valid ? ws_digit<KW, LAST, FMAX>(spl1, spl2, x1, x2) : 0u;
+                if (valid) dgp[j * 64] = (u16)d;
+            }
             const u32 d0 = __builtin_amdgcn_readfirstlane(d);
             if (__all(valid && d == d0)) { if (lane_id() == 0) atomicAdd(&hist[d0], 64u); }
             else if (valid) atomicAdd(&hist[d], 1u);
@@ -1473,6 +1479,7 @@ int ws_sort_impl(Ctx& c, const WKeyGen* gen, u64* K1[2], u64* K2[2], u32* V[2], 
         P.counts = Tb.counts; P.blk_seg = Tb.blk_seg; P.blk_start = Tb.blk_start; P.seg_start = seg_begin; P.seg_end = seg_end; P.sub = nch;
         P.sp1 = sp1; P.sp2 = sp2;
         P.nseg = nsub; P.F = pl.F[l]; P.stride = stride; P.R = Tb.R; P.D = D;
+        P.pre_digits = pre->dig2 ? pre->dig2_chunks : 0u;
         P.gen_off = 0; P.gen_len = n;
         const u32 rows = Tb.rows;
         P.per_xcd = (c.xcd_remap == 1 && rows >= 64) ? cdiv(rows, 8) : 0u;
@@ -1777,6 +1784,9 @@ bool wsort_pre_begin(Ctx& c, WPre& P, const u8* text, size_t n, const size_t* ch
     P.sp1 = A.get_top<u64>((size_t)P.NS + 1);
     P.sp2 = P.KW == 2 ? A.get_top<u64>((size_t)P.NS + 1) : nullptr;
     P.nstart_all = A.get_top<u32>((size_t)nchunks * (P.F[0] + 1));
+    P.dig2 = c.wsort_predig != 0 && c.aux_stream != nullptr;
+    // (the last chunks keep the search in the merging level: their digits would only be ready after the last copy)
+    P.dig2_chunks = P.dig2 ? (nchunks > (u32)c.wsort_predig_skip ? nchunks - (u32)c.wsort_predig_skip : 0u) : 0u;
     // splitters from a sample of chunk 0 (a key reads up to 64 bytes ahead: chunk 1 need not be there)
     WPlan pl;
     pl.L = P.L; pl.F[0] = P.F[0]; pl.F[1] = P.F[1]; pl.F[2] = P.F[2]; pl.os = P.os; pl.NLr = P.NLr; pl.NS = P.NS; pl.S = P.S;
@@ -1830,12 +1840,54 @@ void wsort_pre_chunk(Ctx& c, WPre& P, u32 q) {
         c.prof_end(ps);
     }
     c.arena.release(mark);
+    if (P.dig2 && q < P.dig2_chunks) {
+        // (on the context's low-priority side stream, behind this chunk's level 1: the chain copy -> level 1 -> next copy is not lengthened,
+        //  the digits fill the device's idle time behind the upload.  Its tables are allocated where this chunk's level-1 scratch was and
+        //  stay: the next chunk's scratch lies above them, the side stream only touches them once level 1 is through -- the event)
+        HIP_TRY(hipEventRecord(c.ev_aux[0], c.stream));
+        HIP_TRY(hipStreamWaitEvent(c.aux_stream, c.ev_aux[0], 0));
+        struct Swap { Ctx& c; hipStream_t saved; ~Swap() { c.stream = saved; } } swap{c, c.stream};
+        c.stream = c.aux_stream;
+        hipStream_t s = c.stream;
+        // ---- round 6 (round 4's variant re-measured now that a chunk's level 1 takes 1.3 instead of 1.7 ms of its 2.2 ms copy): the
+        //      level-2 DIGITS of this chunk's records behind the upload as well -- the chunk's F0 buckets are the segments, every bucket is
+        //      searched against its own splitters; the merging level then counts from the digits (2 bytes per record instead of the 16
+        //      bytes of keys and a splitter search) ----
+        const u32* seg_start = P.nstart_all + (size_t)q * (P.F[0] + 1);
+        const bool last2 = (P.L == 2);
+        const u32 nseg = P.F[0], D2 = last2 ? 2 * P.F[1] : P.F[1];
+        SegTables T2;
+        ss_level_tables(c, seg_start, nseg, len, D2, T2);
+        WSLevel L2;
+        L2.k1_in = P.K1[0]; L2.k2_in = P.KW == 2 ? P.K2[0] : nullptr; L2.v_in = P.V[0];
+        L2.k1_out = nullptr; L2.k2_out = nullptr; L2.v_out = nullptr;
+        L2.digits = P.digits;
+        L2.counts = T2.counts; L2.blk_seg = T2.blk_seg; L2.blk_start = T2.blk_start; L2.seg_start = seg_start; L2.seg_end = seg_start + 1; L2.sub = 1;
+        L2.sp1 = P.sp1; L2.sp2 = P.sp2;
+        L2.nseg = nseg; L2.F = P.F[1]; L2.stride = last2 ? 1u : P.F[2]; L2.R = T2.R; L2.D = D2;
+        L2.gen_off = 0; L2.gen_len = P.n;
+        const u32 rows2 = T2.rows;
+        L2.per_xcd = (c.xcd_remap == 1 && rows2 >= 64) ? cdiv(rows2, 8) : 0u;
+        const u32 grid2 = L2.per_xcd ? 8 * L2.per_xcd : rows2;
+        const int pc = c.prof_begin(K_RS_COUNT, (u64)len * 8 * P.KW);
+        auto launch = [&](auto kw, auto lastc) {
+            constexpr int KWc = decltype(kw)::value; constexpr bool LASTc = decltype(lastc)::value;
+            if (L2.F > 256) ws_count_kernel<KWc, false, LASTc, 1024><<<grid2, 256, 0, s>>>(L2, P.g, rows2);
+            else if (L2.F > 64) ws_count_kernel<KWc, false, LASTc, 256><<<grid2, 256, 0, s>>>(L2, P.g, rows2);
+            else ws_count_kernel<KWc, false, LASTc, 64><<<grid2, 256, 0, s>>>(L2, P.g, rows2);
+        };
+        if (P.KW == 2) { if (last2) launch(std::integral_constant<int, 2>{}, std::true_type{}); else launch(std::integral_constant<int, 2>{}, std::false_type{}); }
+        else { if (last2) launch(std::integral_constant<int, 1>{}, std::true_type{}); else launch(std::integral_constant<int, 1>{}, std::false_type{}); }
+        LAUNCH_CHECK();
+        c.prof_end(pc);
+        HIP_TRY(hipEventRecord(c.ev_aux[1], c.aux_stream));
+    }
 }
 
 void wsort_pre_finish(Ctx& c, WPre& P, const u32* hist_full) {
-    (void)c;
     P.active = false;
     if (!P.begun) return;
+    if (P.dig2) HIP_TRY(hipStreamWaitEvent(c.stream, c.ev_aux[1], 0));     // (the level-2 digits of the last chunks)
     for (int i = 1; i < 256; ++i) {
         const bool in_map = (P.present[i >> 5] >> (i & 31)) & 1u;
         if ((hist_full[i] != 0) != in_map) return;            // a byte value chunk 0 did not show (or the reverse): the keys are worthless
