@@ -73,6 +73,7 @@ struct WPre {
     u16* digits = nullptr; u64* sp1 = nullptr; u64* sp2 = nullptr;
     u32 nchunks = 0; size_t chunk_off[33] = {};   // chunk q = text positions [chunk_off[q], chunk_off[q + 1]) (multiples of the partition tile; the last one ends at n)
     u32* nstart_all = nullptr;       // [nchunks][F[0] + 1]: bucket starts of every chunk (absolute slots)
+    const u32* dig2_counts[32] = {}; const u32* dig2_blk[32] = {}; u32 dig2_R[32] = {};   // ... and the tile histograms of that count pass, per chunk (rows of dig2_R tiles per block, block starts per bucket)
     bool dig2 = false; u32 dig2_chunks = 0;   // the digits of the merging level are computed chunk by chunk as well, for the first dig2_chunks chunks (its count pass only reads them)
     u32 present[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };   // byte values of the provisional code map
 };

@@ -48,6 +48,7 @@ struct WSLevel {
     const u64* sp1; const u64* sp2;      // [NS + 1] splitters (high / low word), sp[NS] = ~0
     u16* digits;
     u32 nseg, F, stride, R, D, per_xcd;
+    u32 pre_counts = 0;          // ... and their tile histograms have been copied into `counts` already (ws_pre_hist_kernel): the count pass skips their rows
     u32 pre_digits = 0;          // count pass of the merging level: the pieces of the first pre_digits chunks have their digits in `digits` already (computed chunk by chunk behind the upload): read them, search nothing
     size_t gen_off, gen_len;     // GEN level: the tiles cover text positions [gen_off, gen_off + gen_len)
 };
@@ -256,6 +257,7 @@ __global__ __launch_bounds__(256) void ws_count_kernel(WSLevel P, WKeyGen g, u32
     if (row >= rows) return;
     u32 s, cnt; size_t base;
     if (!ws_row(P, row, s, base, cnt)) return;
+    if (!GEN && (s % P.sub) < P.pre_counts) return;          // (histogram and digits of this piece come from the chunk-wise pass behind the upload)
     for (u32 i = threadIdx.x; i < P.D; i += 256) hist[i] = 0;
     if (cnt == 0) {
         for (u32 i = threadIdx.x; i < P.D; i += 256) P.counts[(size_t)row * P.D + i] = 0;
@@ -1353,6 +1355,26 @@ __global__ void ws_blk_super_kernel(const u32* __restrict__ blk_start, u32 nsupe
 }
 __global__ void ws_set2_kernel(u32* p, u32 a, u32 b) { p[0] = a; p[1] = b; }
 
+// The tile histograms of the pieces whose level-2 digits were computed chunk by chunk behind the upload (wsort_pre_chunk), copied from
+// the chunks' count tables into the merging level's: piece s = bucket * nch + chunk; its tile t is row lblk[bucket] * Rq + t of chunk
+// q's table (blocks of Rq rows per bucket) and row (blk_start[s]) * R + t of the merged one.  One 64-thread workgroup per merged row.
+struct WPreHist { const u32* counts[32]; const u32* blk[32]; u32 R[32]; u32 nch, chunks; };
+__global__ __launch_bounds__(64) void ws_pre_hist_kernel(WPreHist H, const u32* __restrict__ blk_start, const u32* __restrict__ blk_seg, u32 nsub, u32 R, u32 D,
+                                                         u32 rows, u32* __restrict__ counts) {
+    const u32 row = blockIdx.x;
+    if (row >= rows) return;
+    const u32 blk = row / R;
+    if (blk >= blk_start[nsub]) return;
+    const u32 s = blk_seg[blk];
+    const u32 q = s % H.nch, b = s / H.nch;
+    if (q >= H.chunks) return;
+    const u32 t = (blk - blk_start[s]) * R + row % R;
+    const u32 lb0 = H.blk[q][b], lb1 = H.blk[q][b + 1], Rq = H.R[q];
+    const bool in = t < (lb1 - lb0) * Rq;
+    const u32* src = H.counts[q] + ((size_t)lb0 * Rq + t) * D;
+    for (u32 d = threadIdx.x; d < D; d += 64) counts[(size_t)row * D + d] = in ? src[d] : 0u;
+}
+
 // ---- host -------------------------------------------------------------------------------------------------------------------------
 void wsort_make_keygen(const Ctx& c, const u8* text, size_t n, u32 sigma, const u8* code, int& KW, WKeyGen& g) {
     const int b = (int)bits_for(sigma > 1 ? sigma - 1 : 1);
@@ -1480,10 +1502,18 @@ int ws_sort_impl(Ctx& c, const WKeyGen* gen, u64* K1[2], u64* K2[2], u32* V[2], 
         P.sp1 = sp1; P.sp2 = sp2;
         P.nseg = nsub; P.F = pl.F[l]; P.stride = stride; P.R = Tb.R; P.D = D;
         P.pre_digits = pre->dig2 ? pre->dig2_chunks : 0u;
+        P.pre_counts = (pre->dig2 && c.wsort_prehist) ? pre->dig2_chunks : 0u;
         P.gen_off = 0; P.gen_len = n;
         const u32 rows = Tb.rows;
         P.per_xcd = (c.xcd_remap == 1 && rows >= 64) ? cdiv(rows, 8) : 0u;
         const u32 grid = P.per_xcd ? 8 * P.per_xcd : rows;
+        if (P.pre_counts) {
+            WPreHist H;
+            for (u32 q = 0; q < 32; ++q) { H.counts[q] = pre->dig2_counts[q]; H.blk[q] = pre->dig2_blk[q]; H.R[q] = pre->dig2_R[q]; }
+            H.nch = nch; H.chunks = P.pre_counts;
+            ws_pre_hist_kernel<<<Tb.rows, 64, 0, s>>>(H, Tb.blk_start, Tb.blk_seg, nsub, Tb.R, D, Tb.rows, Tb.counts);
+            LAUNCH_CHECK();
+        }
         {
             const int pc = c.prof_begin(K_RS_COUNT, (u64)n * 8 * KW);
             // (the splitter search takes log2 FMAX steps whatever the fan-out: the 64-way levels get an instance of their own -- six steps instead of eight)
@@ -1858,6 +1888,7 @@ void wsort_pre_chunk(Ctx& c, WPre& P, u32 q) {
         const u32 nseg = P.F[0], D2 = last2 ? 2 * P.F[1] : P.F[1];
         SegTables T2;
         ss_level_tables(c, seg_start, nseg, len, D2, T2);
+        P.dig2_counts[q] = T2.counts; P.dig2_blk[q] = T2.blk_start; P.dig2_R[q] = T2.R;
         WSLevel L2;
         L2.k1_in = P.K1[0]; L2.k2_in = P.KW == 2 ? P.K2[0] : nullptr; L2.v_in = P.V[0];
         L2.k1_out = nullptr; L2.k2_out = nullptr; L2.v_out = nullptr;
