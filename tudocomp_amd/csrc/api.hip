@@ -239,6 +239,7 @@ void run_factorize(Ctx& c, size_t n, DevArrays& A, u32 threshold, int flatten, t
     const bool early_planned = strategy == TDC_GPU_COMP_ARRAYS && flatten && enc_coder == 0 && d_text && c.enc_early && c.enc_rec && c.copy_stream && c.huff_ok &&
                                n >= (c.enc_early >= 2 ? (size_t)1 : ((size_t)1 << 20)) && threshold >= 2;
     if (early_planned && c.flen_bytes) A.fs.flen8 = c.arena.get<u8>(n + 64);
+    A.fs.want_owner_rem = early_planned ? (u32)c.owner_rem : 0u;   // (behind build_owner only the flatten rounds read owner[] on this path: the encoder reads cls[] and the records)
     FactorizeStats fz;
     FlattenStats fl;
     const int e0 = ev ? ev->tick() : 0;
@@ -370,6 +371,7 @@ const OptionDef OPTIONS[] = {
     { "phi_lazy",         [](Ctx& c, long v) { c.phi_lazy = v != 0; } },
     { "fs_pair",          [](Ctx& c, long v) { c.fs_pair = v != 0; } },
     { "enc_early",        [](Ctx& c, long v) { c.enc_early = (int)v; } },
+    { "owner_rem",        [](Ctx& c, long v) { c.owner_rem = (int)std::min<long>(std::max<long>(v, 0), 8); } },
     { "enc_rec",          [](Ctx& c, long v) { c.enc_rec = v != 0; } },
     { "level_purge",      [](Ctx& c, long v) { c.level_purge = v != 0; } },
     { "level_log",        [](Ctx& c, long v) { c.level_log = v != 0; } },

@@ -150,6 +150,7 @@ struct Ctx {
     int eager_levels = 1;          // factorize: runs of small levels inside one launch (factorize_eager.hip; env TDC_GPU_EAGER=0: every level through the lazy loop)
     int level_purge = 1;           // factorize: the lists of the next 64 levels are purged in place before they are read (env TDC_GPU_LEVEL_PURGE=0 disables)
     int enc_rec = 1;               // with enc_early: the pack reads lengths and flattened sources from the records of the flatten stage (env TDC_GPU_ENC_REC=0: from flen[] / fsrc[])
+    int owner_rem = 8;             // metric's path: owner words carry how far their factor still reaches, in at most this many bits (FactorSpace::owner_rem_bits; 0: plain ranks)
     int enc_early = 1;             // first half of the Huffman encoder next to the first flatten round (texts of 1 MiB and more; env TDC_GPU_ENC_EARLY=0: after the flatten stage, 2: for every text)
     int fs_pair = 1;               // fused scatter: two rows per workgroup (tiles of 8192 records; env TDC_GPU_FS_PAIR=0: one)
     int small_big = 1;             // factorize: one-workgroup levels with up to 4096 survivors run on a 512-thread instance of the kernel (env TDC_GPU_SMALL_BIG=0: multi-launch path above 2048)

@@ -507,7 +507,7 @@ static void encode_prelude_launch(Ctx& c, const u8* text, size_t n, FactorSpace&
         unsigned g = cdiv(n, 256 * 16); if (g > 2048) g = 2048; if (g == 0) g = 1;
         Ctx::ProfScope prof(c, K_ENC_HIST, (u64)n * 5);
         if (fs.have_cls) literal_hist_cls_kernel<<<g, 256, 0, s>>>(text, fs.cls, n, d_hist);
-        else literal_hist_kernel<<<g, 256, 0, s>>>(text, fs.owner, n, d_hist);
+        else literal_hist_kernel<<<g, 256, 0, s>>>(text, plain_owner(fs), n, d_hist);
         LAUNCH_CHECK();
     }
     pre.z = z;
@@ -606,7 +606,7 @@ static void encode_step_b(Ctx& c, const u8* text, size_t n, FactorSpace& fs, int
         if (!arith_build_model(h_hist, &am, hw))
             throw HipError{hipErrorInvalidValue, "arithmetic coder: all literal bytes >= 1 are absent (the reference divides by zero)", -1};
         ArithPlan plan;
-        arith_prepare(c, text, n, fs.owner, am, &plan);
+        arith_prepare(c, text, n, plain_owner(fs), am, &plan);
         E.A.litidx = plan.litidx; E.A.amark = plan.amark; E.A.fval = plan.fval; E.A.lc_index = plan.lc_index; E.A.pp_lb = plan.pp_lb;
     }
     EncParams& P = E.P;
@@ -639,9 +639,9 @@ static void encode_step_b(Ctx& c, const u8* text, size_t n, FactorSpace& fs, int
     u64* tile_bits = E.tile_bits;
     {
         Ctx::ProfScope prof(c, K_ENC_TILE_BITS, (u64)n * 9);
-        if (P.ascii) tile_bits_kernel<true><<<tiles, 256, 0, s>>>(text, fs.owner, fs.flen, fs.fsrc, n, E.tab, P, E.A, tile_bits);
+        if (P.ascii) tile_bits_kernel<true><<<tiles, 256, 0, s>>>(text, plain_owner(fs), fs.flen, fs.fsrc, n, E.tab, P, E.A, tile_bits);
         else if (fs.have_cls) tile_bits_cls_kernel<<<tiles, 256, 0, s>>>(text, fs.cls, n, E.tab, P, E.A, tile_bits, E.tile_rank);
-        else         tile_bits_kernel<false><<<tiles, 256, 0, s>>>(text, fs.owner, fs.flen, fs.fsrc, n, E.tab, P, E.A, tile_bits);
+        else         tile_bits_kernel<false><<<tiles, 256, 0, s>>>(text, plain_owner(fs), fs.flen, fs.fsrc, n, E.tab, P, E.A, tile_bits);
         LAUNCH_CHECK();
     }
     exclusive_sum_u64(c, tile_bits, tile_bits, tiles, E.d_tp);
@@ -734,10 +734,10 @@ size_t encode_stream(Ctx& c, const u8* text, size_t n, FactorSpace fs, int coder
         size_t copied = 0;
         for (u32 q = 0; q < (overlap ? CH : 1u); ++q) {
             const u32 t0 = overlap ? (u32)((u64)tiles * q / CH) : 0u, t1 = overlap ? (u32)((u64)tiles * (q + 1) / CH) : tiles;
-            if (P.ascii) pack_kernel<true><<<t1 - t0, 256, 0, s>>>(text, fs.owner, fs.flen, fs.fsrc, n, tab, P, A, tile_bits, base_bits, (u64*)d_out, t0);
+            if (P.ascii) pack_kernel<true><<<t1 - t0, 256, 0, s>>>(text, plain_owner(fs), fs.flen, fs.fsrc, n, tab, P, A, tile_bits, base_bits, (u64*)d_out, t0);
             else if (fs.have_cls && E.rec) pack_cls_kernel<true><<<t1 - t0, 256, 0, s>>>(text, fs.cls, fs.flen, fs.fsrc, n, tab, P, A, tile_bits, base_bits, (u64*)d_out, t0, E.rec, E.tile_rank, (u32)E.z_rec);
             else if (fs.have_cls) pack_cls_kernel<false><<<t1 - t0, 256, 0, s>>>(text, fs.cls, fs.flen, fs.fsrc, n, tab, P, A, tile_bits, base_bits, (u64*)d_out, t0, nullptr, nullptr, 0u);
-            else         pack_kernel<false><<<t1 - t0, 256, 0, s>>>(text, fs.owner, fs.flen, fs.fsrc, n, tab, P, A, tile_bits, base_bits, (u64*)d_out, t0);
+            else         pack_kernel<false><<<t1 - t0, 256, 0, s>>>(text, plain_owner(fs), fs.flen, fs.fsrc, n, tab, P, A, tile_bits, base_bits, (u64*)d_out, t0);
             LAUNCH_CHECK();
             if (overlap && q + 1 < CH) {
                 const size_t safe = (size_t)((base_bits + h_end[q]) / 64) * 8;          // bytes in front of the word the next chunk may still touch
@@ -1086,7 +1086,7 @@ static size_t encode_sle(Ctx& c, const u8* text, size_t n, FactorSpace fs, u32 k
             HIP_TRY(hipMemsetAsync(cnt, 0, tsize * sizeof(u32), s));
             if (n >= k) {
                 unsigned g = cdiv(n, 256 * 8); if (g > 8192) g = 8192; if (g == 0) g = 1;
-                sle_kmer_count_kernel<<<g, 256, 0, s>>>(text, fs.owner, n, k, cnt);
+                sle_kmer_count_kernel<<<g, 256, 0, s>>>(text, plain_owner(fs), n, k, cnt);
                 LAUNCH_CHECK();
             }
             const size_t cap = std::min(tsize, n) + 64;
@@ -1112,7 +1112,7 @@ static size_t encode_sle(Ctx& c, const u8* text, size_t n, FactorSpace fs, u32 k
             u32* vals[2] = { c.arena.get<u32>(n), c.arena.get<u32>(n) };
             {
                 unsigned g = cdiv(n, 256 * 8); if (g > 8192) g = 8192; if (g == 0) g = 1;
-                sle_kmer_keys_kernel<<<g, 256, 0, s>>>(text, fs.owner, n, k, keys[0], d_count);
+                sle_kmer_keys_kernel<<<g, 256, 0, s>>>(text, plain_owner(fs), n, k, keys[0], d_count);
                 LAUNCH_CHECK();
             }
             const size_t windows = c.read(d_count);
@@ -1182,7 +1182,7 @@ static size_t encode_sle(Ctx& c, const u8* text, size_t n, FactorSpace fs, u32 k
     u16* minfo = c.arena.get<u16>(n + 8);
     {
         unsigned g = cdiv(n, 256 * 8); if (g > 8192) g = 8192; if (g == 0) g = 1;
-        sle_minfo_kernel<<<g, 256, 0, s>>>(text, fs.owner, n, D, minfo);
+        sle_minfo_kernel<<<g, 256, 0, s>>>(text, plain_owner(fs), n, D, minfo);
         LAUNCH_CHECK();
     }
     if (D.nk) {
@@ -1210,7 +1210,7 @@ static size_t encode_sle(Ctx& c, const u8* text, size_t n, FactorSpace fs, u32 k
     const u64 base_bits = hw.nbits;
     u64* tile_bits = c.arena.get<u64>(tiles + 1);
     u64* d_total = c.arena.get<u64>(1);
-    sle_stream_kernel<false><<<tiles, 256, 0, s>>>(text, fs.owner, fs.flen, fs.fsrc, minfo, n, D, P, tile_bits, 0, nullptr);
+    sle_stream_kernel<false><<<tiles, 256, 0, s>>>(text, plain_owner(fs), fs.flen, fs.fsrc, minfo, n, D, P, tile_bits, 0, nullptr);
     LAUNCH_CHECK();
     exclusive_sum_u64(c, tile_bits, tile_bits, tiles, d_total);
     const u64 total_bits = base_bits + c.read(d_total);
@@ -1219,7 +1219,7 @@ static size_t encode_sle(Ctx& c, const u8* text, size_t n, FactorSpace fs, u32 k
     if (padded > out_cap) throw HipError{hipErrorOutOfMemory, "encode: output buffer too small", (int)__LINE__};
     HIP_TRY(hipMemsetAsync(d_out, 0, padded, s));
     HIP_TRY(hipMemcpyAsync(d_out, hw.bytes.data(), hw.bytes.size(), hipMemcpyHostToDevice, s));
-    sle_stream_kernel<true><<<tiles, 256, 0, s>>>(text, fs.owner, fs.flen, fs.fsrc, minfo, n, D, P, tile_bits, base_bits, (u64*)d_out);
+    sle_stream_kernel<true><<<tiles, 256, 0, s>>>(text, plain_owner(fs), fs.flen, fs.fsrc, minfo, n, D, P, tile_bits, base_bits, (u64*)d_out);
     LAUNCH_CHECK();
     terminator_kernel<<<1, 64, 0, s>>>(d_out, total_bits);
     LAUNCH_CHECK();

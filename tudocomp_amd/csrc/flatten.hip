@@ -38,6 +38,7 @@ __global__ void fstart_scatter_kernel(const u32* __restrict__ flen, const u32* _
 
 size_t extract_factors(Ctx& c, size_t n, FactorSpace fs, u32* pos, u32* src, u32* len, size_t cap) {
     if (n == 0) return 0;
+    if (fs.owner_rem_bits) throw HipError{hipErrorUnknown, "extract_factors: owner[] carries remainder bits", (int)__LINE__};
     const size_t mark = c.arena.mark();
     u32* offs = c.arena.get<u32>(n);
     u32* d_total = c.arena.get<u32>(1);
@@ -68,6 +69,12 @@ size_t extract_factors(Ctx& c, size_t n, FactorSpace fs, u32* pos, u32* src, u32
 //   owner_cross_kernel : fills the part of such a factor that lies in the following tiles (they hold no start there).
 // (Before: flag array, scan, scatter of the starts and a fill pass -- 72 B of traffic per position.)
 constexpr int OW_T = 256, OW_PER = 16, OW_TILE = OW_T * OW_PER;
+// FactorSpace::owner_rem_bits for z factors: the bits the ranks 0 .. z - 1 leave free in a 32-bit word that must not read NONE32 (at most cap <= 8)
+__host__ __device__ __forceinline__ u32 owner_rem_bits_for(u32 z, u32 cap) {
+    u32 b = 0;
+    while (b < cap && (((u64)z + 1) >> (31 - b)) == 0) ++b;       // (b + 1 bits are free iff z + 1 < 2^(31 - b))
+    return b;
+}
 __device__ __forceinline__ u32 ow_idx(u32 i) { return i + (i >> 4); }      // LDS slot of tile position i: a thread reads 16 consecutive positions
 
 __global__ __launch_bounds__(OW_T) void owner_count_kernel(const u32* __restrict__ flen, const u8* __restrict__ flen8, size_t n, u32* __restrict__ tilecnt) {
@@ -108,7 +115,7 @@ __global__ __launch_bounds__(OW_T) void owner_count_kernel(const u32* __restrict
 
 __global__ __launch_bounds__(OW_T) void owner_build_kernel(const u32* __restrict__ flen, const u8* __restrict__ flen8, size_t n, const u32* __restrict__ tilebase,
                                                            u32* __restrict__ pos, u32* __restrict__ owner, uint2* __restrict__ cross,
-                                                           u8* __restrict__ cls, u32* __restrict__ lenl) {
+                                                           u8* __restrict__ cls, u32* __restrict__ lenl, const u32* __restrict__ rem_total, u32 rem_cap) {
     __shared__ u32 s[OW_TILE + OW_TILE / 16 + 16];
     __shared__ u32 sm[OW_T / 64 + 1], smx[OW_T / 64];
     const size_t base = (size_t)blockIdx.x * OW_TILE;
@@ -163,6 +170,8 @@ __global__ __launch_bounds__(OW_T) void owner_build_kernel(const u32* __restrict
     u32 cur_rank = rank - 1;                                    // rank of the start at cur_start (if any)
     u32 cur_len = cur_start ? s[ow_idx(cur_start - 1)] : 0u;
     u32 out[OW_PER];
+    const u32 remb = rem_total ? owner_rem_bits_for(*rem_total, rem_cap) : 0u;     // FactorSpace::owner_rem_bits (the scan has written the total)
+    const u32 qmax = (1u << remb) - 1u, rsh = (32u - remb) & 31u;         // (remb == 0: qmax == 0, the shifted field is 0)
 #pragma unroll
     for (int k = 0; k < OW_PER; ++k) {
         const u32 pl = l0 + k;
@@ -170,7 +179,8 @@ __global__ __launch_bounds__(OW_T) void owner_build_kernel(const u32* __restrict
             cur_start = pl + 1; cur_len = f[k]; cur_rank = rank++;
             if (base + pl < n) { pos[cur_rank] = (u32)(base + pl); if (lenl) lenl[cur_rank] = f[k]; }
         }
-        out[k] = (cur_start != 0 && pl - (cur_start - 1) < cur_len) ? cur_rank : NONE32;
+        const u32 d = pl - (cur_start - 1);                             // distance from the start of the last factor at or before pl
+        out[k] = (cur_start != 0 && d < cur_len) ? (cur_rank | (min(cur_len - d - 1u, qmax) << rsh)) : NONE32;
     }
     if (cls) {                                                  // class bytes of the thread's 16 positions (FactorSpace::cls)
         u32 w4[4] = { 0, 0, 0, 0 };
@@ -201,16 +211,23 @@ __global__ __launch_bounds__(OW_T) void owner_build_kernel(const u32* __restrict
     }
 }
 
-__global__ __launch_bounds__(256) void owner_cross_kernel(const uint2* __restrict__ cross, size_t n, u32* __restrict__ owner, u8* __restrict__ cls) {
+__global__ __launch_bounds__(256) void owner_cross_kernel(const uint2* __restrict__ cross, size_t n, u32* __restrict__ owner, u8* __restrict__ cls,
+                                                          const u32* __restrict__ rem_total, u32 rem_cap) {
     const uint2 cr = cross[blockIdx.x];
     if (cr.y == 0) return;
+    const u32 remb = rem_total ? owner_rem_bits_for(*rem_total, rem_cap) : 0u;
+    const u32 qmax = (1u << remb) - 1u, rsh = (32u - remb) & 31u;
     const size_t start = ((size_t)blockIdx.x + 1) * OW_TILE;
-    for (size_t j = threadIdx.x; j < cr.y && start + j < n; j += 256) { owner[start + j] = cr.x; if (cls) cls[start + j] = (u8)3; }
+    for (size_t j = threadIdx.x; j < cr.y && start + j < n; j += 256) {
+        owner[start + j] = cr.x | (min(cr.y - (u32)j - 1u, qmax) << rsh);
+        if (cls) cls[start + j] = (u8)3;
+    }
 }
 
 void build_owner(Ctx& c, size_t n, FactorSpace& fs) {
     fs.have_list = false;
     fs.have_cls = false;
+    fs.owner_rem_bits = 0;
     if (n == 0) return;
     const size_t mark = c.arena.mark();
     const u32 tiles = cdiv(n, OW_TILE);
@@ -226,14 +243,17 @@ void build_owner(Ctx& c, size_t n, FactorSpace& fs) {
     exclusive_sum_u32(c, tilecnt, tilecnt, tiles, d_total);
     {
         Ctx::ProfScope prof(c, K_EXTRACT, (u64)n * (fs.flen8 ? 6 : 9));
-        owner_build_kernel<<<tiles, OW_T, 0, c.stream>>>(fs.flen, fs.flen8, n, tilecnt, pos, fs.owner, cross, fs.cls, fs.fpos ? fs.flenl : nullptr);
+        const u32* rem_total = fs.want_owner_rem ? d_total : nullptr;
+        const u32 rem_cap = std::min<u32>(fs.want_owner_rem, 8u);
+        owner_build_kernel<<<tiles, OW_T, 0, c.stream>>>(fs.flen, fs.flen8, n, tilecnt, pos, fs.owner, cross, fs.cls, fs.fpos ? fs.flenl : nullptr, rem_total, rem_cap);
         LAUNCH_CHECK();
-        owner_cross_kernel<<<tiles, 256, 0, c.stream>>>(cross, n, fs.owner, fs.cls);
+        owner_cross_kernel<<<tiles, 256, 0, c.stream>>>(cross, n, fs.owner, fs.cls, rem_total, rem_cap);
         fs.have_cls = fs.cls != nullptr;
         LAUNCH_CHECK();
     }
     const size_t z = c.read(d_total);
     if (fs.fpos) { fs.nfact = z; fs.have_list = true; }
+    fs.owner_rem_bits = fs.want_owner_rem ? owner_rem_bits_for((u32)z, std::min<u32>(fs.want_owner_rem, 8u)) : 0u;
     c.arena.release(mark);
 }
 
@@ -324,9 +344,10 @@ __global__ void sources_fill_pos_kernel(const u32* __restrict__ flen, size_t n, 
 #define TDC_FL_K 4
 #endif
 constexpr int FL_K = TDC_FL_K;
-template <bool FIRST>
+template <bool FIRST, bool REM>    // REM: owner words carry rem_bits remainder bits above the rank (FactorSpace::owner_rem_bits >= 1)
 __global__ __launch_bounds__(256) void flatten_round_kernel(const uint4* __restrict__ work, u32 nwork, size_t n, const u32* __restrict__ owner,
-                                                             uint4* rec, uint4* __restrict__ next, FlattenScalars* __restrict__ sc, u32 max_steps) {
+                                                             uint4* rec, uint4* __restrict__ next, FlattenScalars* __restrict__ sc, u32 max_steps, u32 rem_bits) {
+    const u32 rsh = 32u - rem_bits, qmax = (1u << rem_bits) - 1u, rmask = REM ? ((1u << rsh) - 1u) : 0xFFFFFFFFu;
     __shared__ u32 sm[5];
     __shared__ u32 s_base;
     const u32 base = blockIdx.x * (256u * FL_K);
@@ -365,7 +386,14 @@ __global__ __launch_bounds__(256) void flatten_round_kernel(const uint4* __restr
             sr[r] = make_uint4(0, 0, 0, 0);
             if (act & (1u << r)) {
                 if (rr[r] == NONE32) { act &= ~(1u << r); fin |= 1u << r; }                       // :106 fmap[src] == 0
-                else sr[r] = rec[rr[r]];
+                else {
+                    if (REM) {                                                                  // the covering factor ends q + 1 positions on (q < qmax)
+                        const u32 q = rr[r] >> rsh;
+                        rr[r] &= rmask;
+                        if (q < qmax && len[r] > q + 1u) { act &= ~(1u << r); fin |= 1u << r; continue; }   // :110 without the record
+                    }
+                    sr[r] = rec[rr[r]];
+                }
             }
         }
 #pragma unroll
@@ -469,8 +497,12 @@ void flatten_factors(Ctx& c, size_t n, FactorSpace fs, FlattenStats* st, const s
         HIP_TRY(hipMemsetAsync(&d_sc->waiting, 0, sizeof(u32), s));
         {   // per waiting factor: its item (16) + one chain step (owner word + record: 20) + item / final source out (16)
             Ctx::ProfScope prof(c, K_FLATTEN_ROUND, (u64)waiting * 52);
-            if (cur_w < 0) flatten_round_kernel<true><<<cdiv(waiting, 256 * FL_K), 256, 0, s>>>(nullptr, waiting, n, fs.owner, rec, work[nxt], d_sc, max_steps);
-            else flatten_round_kernel<false><<<cdiv(waiting, 256 * FL_K), 256, 0, s>>>(work[cur_w], waiting, n, fs.owner, rec, work[nxt], d_sc, max_steps);
+            const u32 rb = fs.owner_rem_bits;
+            const unsigned g = cdiv(waiting, 256 * FL_K);
+            if (cur_w < 0) { if (rb) flatten_round_kernel<true, true><<<g, 256, 0, s>>>(nullptr, waiting, n, fs.owner, rec, work[nxt], d_sc, max_steps, rb);
+                             else flatten_round_kernel<true, false><<<g, 256, 0, s>>>(nullptr, waiting, n, fs.owner, rec, work[nxt], d_sc, max_steps, 0u); }
+            else { if (rb) flatten_round_kernel<false, true><<<g, 256, 0, s>>>(work[cur_w], waiting, n, fs.owner, rec, work[nxt], d_sc, max_steps, rb);
+                   else flatten_round_kernel<false, false><<<g, 256, 0, s>>>(work[cur_w], waiting, n, fs.owner, rec, work[nxt], d_sc, max_steps, 0u); }
             LAUNCH_CHECK();
         }
         // (this round is on its way: 150 M factors in the first one at 2e9 B, 55 M in the second, 9 M in the third; the later ones are too

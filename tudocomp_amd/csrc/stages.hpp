@@ -67,6 +67,13 @@ struct FactorSpace {
     // fills it (have_cls); the encoder's streaming passes then read 1 byte instead of the 4-byte owner word per position.
     u8* cls = nullptr;
     bool have_cls = false;
+    // optional (round 6, the metric's path): the top owner_rem_bits bits of a covered position's owner word hold how far its factor still
+    // reaches -- q = min(end of the factor - p - 1, 2^bits - 1); the rank sits in the bits below.  A flatten step that lands on p with a
+    // copy longer than q + 1 (q not saturated) knows that the copy does not fit WITHOUT fetching the covering factor's record: 43 % of all
+    // chain visits on English text.  Requested with want_owner_rem by a caller whose later stages never read owner[] (they read cls[] and
+    // the flatten records); build_owner() takes the bits the ranks leave free (at most want_owner_rem, at most 8) and sets owner_rem_bits.  NONE32 stays NONE32.
+    u32 want_owner_rem = 0;     // 0: plain ranks; else the most bits to take (8 is all build_owner() ever takes)
+    u32 owner_rem_bits = 0;
     // lazy sources (round 4): set by factorize_arrays when there is no Phi array -- fsrc[] then holds the sources of the factors of the
     // global levels only; the source of any factor start p is  src_prio[p] < src_n ? src_sa[src_prio[p] - 1] : fsrc[p]  (src_prio = ISA
     // unless a push at a global level overwrote it, and such a position had its source saved first).  flatten_factors computes it
@@ -75,6 +82,11 @@ struct FactorSpace {
     const u32* src_sa = nullptr;
     size_t src_n = 0;
 };
+// owner[] for a reader that compares whole words (everyone but the flatten rounds): refuses an array that carries remainder bits
+inline const u32* plain_owner(const FactorSpace& fs) {
+    if (fs.owner_rem_bits) throw HipError{hipErrorUnknown, "owner[] carries remainder bits (FactorSpace::owner_rem_bits): this stage reads plain ranks", (int)__LINE__};
+    return fs.owner;
+}
 void materialize_sources(Ctx& c, size_t n, FactorSpace& fs);    // fills fsrc[] at every factor start, clears src_prio
 
 struct FactorizeStats { u64 factors = 0; u32 maxlcp = 0; u32 levels = 0; u32 rounds = 0; u64 pushes = 0; u64 entries = 0; u32 small_levels = 0; u32 purges = 0;
