@@ -992,24 +992,36 @@ __global__ __launch_bounds__(LS_NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4
 // units by size class (rows per wave of the composite kernel): class c = units of (2048 c, 2048 (c + 1)] pairs
 // wide = 1 (wsort.hip): the six size classes of its leaf kernels (prim.hpp wide_class: a unit of 2 600 records in a 4 096-slot
 // workgroup runs a quarter of its rows empty)
-__global__ void ss_unit_class_kernel(const u32* __restrict__ unit_rng, const u32* __restrict__ d_nunits, u32* __restrict__ cls_count,
-                                     u32* __restrict__ cls_list, u32 cap, int wide = 0) {
+constexpr int UC_T = 1024;                                       // threads per workgroup of ss_unit_class_kernel
+__global__ __launch_bounds__(UC_T) void ss_unit_class_kernel(const u32* __restrict__ unit_rng, const u32* __restrict__ d_nunits, u32* __restrict__ cls_count,
+                                                            u32* __restrict__ cls_list, u32 cap, int wide = 0) {
+    // one atomic per WORKGROUP and class (round 6: per wave it was 500 000 atomics on ten addresses at 2e9 B -- 1.8 ms of a kernel that
+    // moves 16 MB; the lists stay in nearly ascending unit order)
+    __shared__ u32 wcnt[UC_T / 64][16];
+    __shared__ u32 wbase[16];
     const u32 u = blockIdx.x * blockDim.x + threadIdx.x;
-    u32 c = wide ? 15u : 4u;                                     // (no unit)
+    const u32 ncls = wide ? (u32)WIDE_NCLS : 4u;
+    u32 c = 15u;                                                 // (no unit)
     if (u < *d_nunits) {
         const u32 m = unit_rng[2 * u + 1] - unit_rng[2 * u];
         if (m > 1 && m <= SS_UNIT_MAX) c = wide ? wide_class(m) : (m - 1) / 2048;
     }
-    const int lane = lane_id();
-#pragma unroll
-    for (u32 q = 0; q < (wide ? (u32)WIDE_NCLS : 4u); ++q) {     // one atomic per wave and class
+    const int lane = lane_id(), w = wave_id();
+    u32 below = 0;                                               // lanes of this wave in front of me with my class
+    for (u32 q = 0; q < ncls; ++q) {
         const u64 mask = __ballot(c == q);
-        if (!mask) continue;
-        u32 basei = 0;
-        if (lane == __ffsll((long long)mask) - 1) basei = atomicAdd(&cls_count[q], (u32)__popcll(mask));
-        basei = __shfl(basei, __ffsll((long long)mask) - 1, 64);
-        if (c == q) cls_list[(size_t)q * cap + basei + (u32)__popcll(mask & ((1ull << lane) - 1))] = u;
+        if (lane == 0) wcnt[w][q] = (u32)__popcll(mask);
+        if (c == q) below = (u32)__popcll(mask & ((1ull << lane) - 1));
     }
+    __syncthreads();
+    if (threadIdx.x < ncls) {
+        const u32 q = threadIdx.x;
+        u32 tot = 0;
+        for (int i = 0; i < UC_T / 64; ++i) { const u32 t = wcnt[i][q]; wcnt[i][q] = tot; tot += t; }
+        wbase[q] = tot ? atomicAdd(&cls_count[q], tot) : 0u;
+    }
+    __syncthreads();
+    if (c < ncls) cls_list[(size_t)c * cap + wbase[c] + wcnt[w][c] + below] = u;
 }
 
 // ---- host ---------------------------------------------------------------------------------------------------------------------
@@ -1158,7 +1170,7 @@ int splitter_sort_pairs_u64(Ctx& c, u64* keys[2], u32* vals[2], size_t n, const 
     exclusive_sum_u32(c, flag, flag, nleaf, large + 1);
     ss_unit_fill_kernel<<<cdiv(nleaf, 256), 256, 0, s>>>(leaf_start, nleaf, flag, unit_rng);
     LAUNCH_CHECK();
-    ss_unit_class_kernel<<<cdiv((size_t)nleaf + 1, 256), 256, 0, s>>>(unit_rng, large + 1, large + 2, cls_list, nleaf + 1);
+    ss_unit_class_kernel<<<cdiv((size_t)nleaf + 1, UC_T), UC_T, 0, s>>>(unit_rng, large + 1, large + 2, cls_list, nleaf + 1);
     LAUNCH_CHECK();
     u32 hc[6];
     c.read_n(large, hc, 6);
@@ -1273,7 +1285,7 @@ void ss_build_units(Ctx& c, const u32* leaf_start, u32 nleaf, UnitTables& U, u32
     exclusive_sum_u32(c, flag, flag, nleaf, U.large + 1);
     ss_unit_fill_kernel<<<cdiv(nleaf, 256), 256, 0, s>>>(leaf_start, nleaf, flag, U.unit_rng, small);
     LAUNCH_CHECK();
-    ss_unit_class_kernel<<<cdiv((size_t)nleaf + 1, 256), 256, 0, s>>>(U.unit_rng, U.large + 1, wcnt ? wcnt : U.large + 2, U.cls_list, nleaf + 1, U.wide_classes);
+    ss_unit_class_kernel<<<cdiv((size_t)nleaf + 1, UC_T), UC_T, 0, s>>>(U.unit_rng, U.large + 1, wcnt ? wcnt : U.large + 2, U.cls_list, nleaf + 1, U.wide_classes);
     LAUNCH_CHECK();
     c.read_n(U.large, U.hc, 6);
     if (wcnt) c.read_n(wcnt, U.whc, 16);

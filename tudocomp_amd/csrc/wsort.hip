@@ -291,6 +291,43 @@ __global__ __launch_bounds__(256) void ws_count_kernel(WSLevel P, WKeyGen g, u32
         const u64* kp1 = P.k1_in + base + lb;
         const u64* kp2 = KW == 2 ? P.k2_in + base + lb : nullptr;
         u16* dgp = P.digits + base + lb;
+#ifndef TDC_WC_PF
+#define TDC_WC_PF 1      // (measured at 2e9 B, class rs_count_kernel: 0 -> 38.4 ms, 1 -> 35.5, 2 -> 37.8, 4 -> 37.4)
+#endif
+#if TDC_WC_PF > 0
+        // the keys of the next TDC_WC_PF rows are requested before a row is searched (the search is a chain of dependent LDS loads: without
+        // this a wave has one row's 16 bytes per lane in flight, and none while it searches)
+        constexpr int PF = TDC_WC_PF;
+        u64 q1[PF], q2[PF];
+        if (!have_digits) {
+#pragma unroll
+            for (int j = 0; j < PF; ++j) {
+                const bool in = lb + (u32)j * 64 < cnt;
+                q1[j] = in ? kp1[j * 64] : 0ull;
+                q2[j] = (KW == 2 && in) ? kp2[j * 64] : 0ull;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < WS_ITEMS; ++j) {
+            const u32 e = lb + (u32)j * 64;
+            const bool valid = e < cnt;
+            u32 d = 0;
+            if (have_digits) { if (valid) d = dgp[j * 64]; }
+            else {
+                const u64 x1 = q1[j % PF], x2 = q2[j % PF];
+                if (j + PF < WS_ITEMS) {
+                    const bool in = lb + (u32)(j + PF) * 64 < cnt;
+                    q1[j % PF] = in ? kp1[(j + PF) * 64] : 0ull;
+                    q2[j % PF] = (KW == 2 && in) ? kp2[(j + PF) * 64] : 0ull;
+                }
+                d = valid ? ws_digit<KW, LAST, FMAX>(spl1, spl2, x1, x2) : 0u;
+                if (valid) dgp[j * 64] = (u16)d;
+            }
+            const u32 d0 = __builtin_amdgcn_readfirstlane(d);
+            if (__all(valid && d == d0)) { if (lane_id() == 0) atomicAdd(&hist[d0], 64u); }
+            else if (valid) atomicAdd(&hist[d], 1u);
+        }
+#else
 #pragma unroll 4
         for (int j = 0; j < WS_ITEMS; ++j) {
             const u32 e = lb + (u32)j * 64;
@@ -307,6 +344,7 @@ __global__ __launch_bounds__(256) void ws_count_kernel(WSLevel P, WKeyGen g, u32
             if (__all(valid && d == d0)) { if (lane_id() == 0) atomicAdd(&hist[d0], 64u); }
             else if (valid) atomicAdd(&hist[d], 1u);
         }
+#endif
     }
     __syncthreads();
     for (u32 i = threadIdx.x; i < P.D; i += 256) P.counts[(size_t)row * P.D + i] = hist[i];
