@@ -1658,10 +1658,25 @@ int ws_sort_impl(Ctx& c, const WKeyGen* gen, u64* K1[2], u64* K2[2], u32* V[2], 
                 Ctx::ProfScope prof(c, K_WS_RUN, wave_recs * 18);          // per record: second word + position in (12 B), position + flag + LCP out (6 B)
                 A.unit_rng = cur_rng;
                 const u32* l0 = wave_list, *l1 = wave_list + cur_cap, *l2 = wave_list + 2 * cur_cap, *l3 = wave_list + 3 * cur_cap;
-                if (wave_cnt[0]) { ws_run_lane_kernel<32, PAIRS><<<cdiv(wave_cnt[0], 8), 256, 0, s>>>(A, l0, wave_cnt[0]); LAUNCH_CHECK(); }
-                if (wave_cnt[1]) { ws_run_lane_kernel<64, PAIRS><<<cdiv(wave_cnt[1], 4), 256, 0, s>>>(A, l1, wave_cnt[1]); LAUNCH_CHECK(); }
-                if (wave_cnt[2]) { ws_run_wave_kernel<256, PAIRS><<<cdiv(wave_cnt[2], 4), 256, 0, s>>>(A, l2, wave_cnt[2]); LAUNCH_CHECK(); }
+                // The four kernels work on disjoint runs and each is a chain of dependent loads per wave with little work behind it (none of
+                // them fills the device): with the context's two other streams at hand they run side by side (option wsort_run_streams).
+                const bool fork = c.wsort_run_streams && c.copy_stream && c.aux_stream && (wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3]) >= 4096;
+                hipStream_t sl = fork ? c.copy_stream : s, sw = fork ? c.aux_stream : s;
+                if (fork) {
+                    HIP_TRY(hipEventRecord(c.ev_copy[10], s));
+                    HIP_TRY(hipStreamWaitEvent(sl, c.ev_copy[10], 0));
+                    HIP_TRY(hipStreamWaitEvent(sw, c.ev_copy[10], 0));
+                }
                 if (wave_cnt[3]) { ws_run_wave_kernel<1024, PAIRS><<<cdiv(wave_cnt[3], 4), 256, 0, s>>>(A, l3, wave_cnt[3]); LAUNCH_CHECK(); }
+                if (wave_cnt[2]) { ws_run_wave_kernel<256, PAIRS><<<cdiv(wave_cnt[2], 4), 256, 0, sw>>>(A, l2, wave_cnt[2]); LAUNCH_CHECK(); }
+                if (wave_cnt[0]) { ws_run_lane_kernel<32, PAIRS><<<cdiv(wave_cnt[0], 8), 256, 0, sl>>>(A, l0, wave_cnt[0]); LAUNCH_CHECK(); }
+                if (wave_cnt[1]) { ws_run_lane_kernel<64, PAIRS><<<cdiv(wave_cnt[1], 4), 256, 0, sl>>>(A, l1, wave_cnt[1]); LAUNCH_CHECK(); }
+                if (fork) {
+                    HIP_TRY(hipEventRecord(c.ev_copy[11], sl));
+                    HIP_TRY(hipEventRecord(c.ev_copy[12], sw));
+                    HIP_TRY(hipStreamWaitEvent(s, c.ev_copy[11], 0));
+                    HIP_TRY(hipStreamWaitEvent(s, c.ev_copy[12], 0));
+                }
                 st->wave_runs += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
                 wave_cnt[0] = wave_cnt[1] = wave_cnt[2] = wave_cnt[3] = 0;
             }
