@@ -895,14 +895,20 @@ int build_suffix_array_wide(Ctx& c, const u8* text, size_t n, u32* sa, u32* isa,
 
     WSortStats ws;
     int x = 0;
-    if (pre) wsort_suffixes_pre(c, *pre, sa, flags, lcp8, &ws);
-    else x = wsort_suffixes(c, KW, g, K1, K2, V, n, flags, lcp8, &ws);
+    // (with a sink the unresolved slots are counted below, by the first pass of their compaction: the sort need not count its non-heads)
+    const bool count_here = ex != nullptr && c.wsort_rounds > 0;
+    {
+        struct Restore { Ctx& c; ~Restore() { c.wsort_count_nonheads = true; } } restore{c};
+        c.wsort_count_nonheads = !count_here;
+        if (pre) wsort_suffixes_pre(c, *pre, sa, flags, lcp8, &ws);
+        else x = wsort_suffixes(c, KW, g, K1, K2, V, n, flags, lcp8, &ws);
+    }
     st->sorted_elems += n;
     st->overlapped = pre ? 1u : 0u;
     st->wide_kw = (u32)KW; st->wide_nonheads = ws.nonheads;
 
-    // unresolved suffixes <= 2 * (slots that are not group heads): the text rounds pay while they are few
-    bool fast = ex != nullptr && c.wsort_rounds > 0 && 2 * ws.nonheads <= n / 8;
+    // the text rounds pay while the unresolved suffixes are few (<= n / 8; unresolved <= 2 * (slots that are not group heads))
+    bool fast = count_here;
     u32 h_tot[4] = { 0, 0, 0, 0 };
     size_t m;
     if (!pre) {
@@ -915,15 +921,22 @@ int build_suffix_array_wide(Ctx& c, const u8* text, size_t n, u32* sa, u32* isa,
         const u32 tiles = cdiv(n, FC_TILE);
         u32* tile_cnt = c.arena.get<u32>(tiles + 1);
         u32* tile_last = c.arena.get<u32>(tiles + 1);
-        Ctx::ProfScope prof(c, K_SA_RANK_SCATTER, (u64)n * 2 + 2 * ws.nonheads * 16);
+        const int pf = c.prof_begin(K_SA_RANK_SCATTER, (u64)n);
         sa_flag_count_kernel<<<tiles, 256, 0, s>>>(flags, n, tile_cnt, tile_last);
         LAUNCH_CHECK();
         exclusive_sum_u32(c, tile_cnt, tile_cnt, tiles, B.d_total);
-        inclusive_max_u32(c, tile_last, tile_last, tiles);
-        sa_flag_compact_kernel<<<tiles, 256, 0, s>>>(flags, sa, n, tile_cnt, tile_last, B.A_sa, B.A_pos, B.A_r1);
-        LAUNCH_CHECK();
+        c.prof_end(pf);
         m = c.read(B.d_total);
-    } else m = first_groups(c, n, bn, nullptr, sa, flags, sa, isa, B, true, h_tot);
+        st->wide_nonheads = m;                                 // (slots in groups of two and more: between the non-heads and twice their number)
+        if (m > n / 8) fast = false;
+        else {
+            Ctx::ProfScope prof(c, K_SA_RANK_SCATTER, (u64)n + (u64)m * 16);
+            inclusive_max_u32(c, tile_last, tile_last, tiles);
+            sa_flag_compact_kernel<<<tiles, 256, 0, s>>>(flags, sa, n, tile_cnt, tile_last, B.A_sa, B.A_pos, B.A_r1);
+            LAUNCH_CHECK();
+        }
+    }
+    if (!fast) m = first_groups(c, n, bn, nullptr, sa, flags, sa, isa, B, true, h_tot);
     st->rounds = 1;
     u32 h = (u32)g.s;
     int text_rounds = 0;

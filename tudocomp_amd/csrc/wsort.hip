@@ -1801,11 +1801,13 @@ int ws_sort_impl(Ctx& c, const WKeyGen* gen, u64* K1[2], u64* K2[2], u32* V[2], 
     if (!PAIRS) {
         ws_fix_kernel<KW><<<cdiv(nleaf, 256), 256, 0, s>>>(leaf_start, nleaf, Vlast, g, flags, lcp8);
         LAUNCH_CHECK();
-        { unsigned gq = cdiv(n, 256 * 16); if (gq > 4096) gq = 4096; ws_count_flags_kernel<<<gq, 256, 0, s>>>(flags, n, d_nonheads); }
-        LAUNCH_CHECK();
-        u64 nh = 0;
-        c.read_n((const u64*)d_nonheads, &nh, 1);
-        st->nonheads = nh;
+        if (c.wsort_count_nonheads) {                           // (the suffix array counts the unresolved slots itself: one pass over the flags less)
+            { unsigned gq = cdiv(n, 256 * 16); if (gq > 4096) gq = 4096; ws_count_flags_kernel<<<gq, 256, 0, s>>>(flags, n, d_nonheads); }
+            LAUNCH_CHECK();
+            u64 nh = 0;
+            c.read_n((const u64*)d_nonheads, &nh, 1);
+            st->nonheads = nh;
+        }
     }
 #ifdef TDC_WL_PROF
     if (!PAIRS) {
