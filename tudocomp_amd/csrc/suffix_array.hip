@@ -21,14 +21,31 @@ namespace tdc {
 
 struct CodeMap { u8 code[256]; };
 
+// (round 6: 16 bytes per thread and step, eight copies of the histogram in rows of 257 words -- lane l counts in copy l % 8, the copies of
+//  one byte value lie in eight different banks: the blanks of a text, a sixth of its bytes, no longer queue up on one LDS word.  One byte
+//  per thread and one histogram: 0.15 ms per 125 MB chunk = 0.8 TB/s, 2.5 ms of device time per step behind the upload)
 __global__ __launch_bounds__(256) void byte_hist_kernel(const u8* __restrict__ text, size_t n, u32* __restrict__ hist) {
-    __shared__ u32 h[256];
-    h[threadIdx.x] = 0;
+    __shared__ u32 h[8 * 257];
+    for (int i = threadIdx.x; i < 8 * 257; i += 256) h[i] = 0;
     __syncthreads();
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) atomicAdd(&h[text[i]], 1u);
+    u32* mine = h + (threadIdx.x & 7) * 257;
+    const size_t stride = (size_t)gridDim.x * blockDim.x * 16;
+    const bool aligned = (((size_t)text) & 15) == 0;
+    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 16; i < n; i += stride) {
+        if (aligned && i + 16 <= n) {
+            const uint4 v = *(const uint4*)(text + i);
+            const u32 w[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+            for (int q = 0; q < 16; ++q) atomicAdd(&mine[(w[q >> 2] >> (8 * (q & 3))) & 0xFFu], 1u);
+        } else {
+            for (size_t j = i; j < n && j < i + 16; ++j) atomicAdd(&mine[text[j]], 1u);
+        }
+    }
     __syncthreads();
-    if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+    u32 t = 0;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t += h[r * 257 + threadIdx.x];
+    if (t) atomicAdd(&hist[threadIdx.x], t);
 }
 
 void text_histogram_add(Ctx& c, const u8* part, size_t len, u32* d_hist) {       // d_hist: 256 device counters, accumulated
