@@ -75,3 +75,17 @@ def test_every_small_level_on_the_large_instance(mode):
                 assert got == want, (name, thr)
     finally:
         ctx.close()
+
+
+def test_one_long_run_keeps_its_level_tables_outside_the_arena(gpu_ctx):
+    """A text that is one run has as many LCP levels as positions: the two tables with a word (two) per level do not fit the arena that
+    tdc_gpu_arena_bytes() budgets per position (64 MB of one letter: out of memory in round 6's robustness run) -- beyond 2^22 levels
+    they live in an allocation of their own (factorize.hip LevelTables).  Streams against the oracle's, and back."""
+    for name, data in (("a^N", b"a" * 4_600_000), ("(ab)^N/2", b"ab" * 2_300_000), ("x a^N", b"x" + b"a" * 4_600_000)):
+        text = O.escape(data)
+        want, _ = O.lcpcomp_huff_compress(text, 5, 1)
+        got, st = gpu_ctx.lcpcomp_compress(text, threshold=5, flatten=1)
+        assert st["maxlcp"] + 2 > (1 << 22), name
+        assert got == want, name
+        back, _ = gpu_ctx.lcpcomp_decompress(got)
+        assert back == text, name

@@ -1186,7 +1186,13 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
     u32 last_alive = 0;                                    // survivors of the last one-workgroup level (chooses the instance of the next one)
     int force_inst = -1;                                   // the instance a level is run again on
     u32 slim_penalty = 0;                                  // levels for which the 1 024-thread instance is not tried (it gave up on a level)
-    u32* d_lcount = c.arena.get<u32>(nlev);                // per level: entries of the original list that are left after level_purge_kernel (all ones: not purged)
+    // Two tables have one word (two) per LEVEL.  A text that is one long run has as many levels as positions: 12 more bytes per position
+    // than tdc_gpu_arena_bytes() budgets (64 MB of one letter ran out of arena here).  Beyond 2^22 levels they live in an allocation of
+    // their own for the duration of the call -- a hipMalloc / hipFree pair only such texts pay for.
+    struct LevelTables { u32* p = nullptr; ~LevelTables() { if (p) (void)hipFree(p); } } level_tables;
+    const bool levels_outside = nlev > ((size_t)1 << 22);
+    if (levels_outside) HIP_TRY(hipMalloc((void**)&level_tables.p, 3 * nlev * sizeof(u32)));
+    u32* d_lcount = levels_outside ? level_tables.p : c.arena.get<u32>(nlev);   // per level: entries of the original list that are left after level_purge_kernel (all ones: not purged)
     HIP_TRY(hipMemsetAsync(d_lcount, 0xFF, nlev * sizeof(u32), s));
     u32 purge_next = 0xFFFFFFFFu;                          // level_purge_kernel has been run for the levels >= purge_next
     auto purge_ahead = [&](u32 lv) {                       // called before anything reads the list of level lv
@@ -1245,7 +1251,7 @@ void factorize_arrays(Ctx& c, size_t n, const u32* sa, u32* isa, const u32* phi,
     // (the eager kernel packs an entry as position << 1 | truncated in 32 bits: n <= 2^31)
     const bool eager_possible = c.eager_levels && res8 && nlev <= ((size_t)1 << 22) && maxlcp > eager_floor + 256 && n <= ((size_t)1 << 31);
     u32 eager_phases = 0, small_lazy_streak = 0;
-    u32* d_eseg = eager_possible ? c.arena.get<u32>(2 * nlev) : nullptr;        // tstart | tend
+    u32* d_eseg = !eager_possible ? nullptr : (levels_outside ? level_tables.p + nlev : c.arena.get<u32>(2 * nlev));        // tstart | tend
     u32* d_ehead = eager_possible ? c.arena.get<u32>(nlev) : nullptr;
     EagerCtl* d_ectl = eager_possible ? (EagerCtl*)c.arena.alloc(sizeof(EagerCtl)) : nullptr;
     auto run_eager = [&](u32 Lfrom) -> u32 {                                     // returns the next level to be processed
