@@ -91,6 +91,11 @@ int wsort_suffixes(Ctx& c, int KW, const WKeyGen& g, u64* K1[2], u64* K2[2], u32
 void wsort_suffixes_pre(Ctx& c, const WPre& P, u32* v_final, u8* flags, u8* lcp8, WSortStats* st);
 // Sorts m records (K1[0][j], K2[0][j], V[0][j]) by (k1, k2); k1_bits = significant bits of k1.  Returns the buffer index of the result.
 int wsort_records(Ctx& c, u64* K1[2], u64* K2[2], u32* V[2], size_t m, int k1_bits, WSortStats* st);
+// Records whose first words are already in order (k1[j] non-decreasing): every run of equal first words is sorted by k2 in place (k2 and v
+// move).  Runs of more members than one wave orders (1 024) go through wsort_records in a list of their own.  Returns false if there are more of
+// them than its table holds (65 536) -- shorter runs may have been ordered by then, the records are still the same list: the caller sorts
+// it as a whole.
+bool wsort_sorted_runs(Ctx& c, const u64* k1, u64* k2, u32* v, size_t m, int k1_bits);
 
 // Same contract as radix_sort_pairs_u64 for keys that are pairwise DISTINCT on the sorted bits (stability is then
 // irrelevant): inputs of at most 2048 pairs are sorted by one workgroup in LDS (bitonic network), larger ones by the

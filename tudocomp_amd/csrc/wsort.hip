@@ -1981,6 +1981,158 @@ void wsort_pre_finish(Ctx& c, WPre& P, const u32* hist_full) {
     P.active = true;
 }
 
+// ---- records whose first word is already in order: every run of equal first words sorted by the second (text rounds) -----------------
+// The runs of a text round are the groups of still-equal suffixes: 2.5 members on average on English text, so most of them are ordered
+// by their members themselves -- a tile of records in LDS, every record counts the members of its run that go before it (runs of up to
+// SG_MAXG members; a run that crosses the tile's end is seen whole through the halo, and belongs to the tile it starts in).  Longer runs
+// (up to WS_WAVE_MAX) are entered into the table the run kernels' lists are compiled from (entry start / 2: runs have two members and
+// more, so two never share an entry); beyond that the caller sorts the list as a whole.
+constexpr u32 SG_T = 1024, SG_H = 16, SG_MAXG = 16, SG_BIG_CAP = 1u << 16;
+struct SegCounters { u32 overflow, nbig, big_recs, pad; };
+__global__ __launch_bounds__(256) void ws_seg_tile_kernel(const u64* __restrict__ k1, u64* k2, u32* v, u32 m, u32* __restrict__ rng, u32* __restrict__ big,
+                                                          SegCounters* __restrict__ sc) {
+    __shared__ u64 sk[SG_T + SG_H];
+    __shared__ u32 sv[SG_T + SG_H];
+    __shared__ u8 sh[SG_T + SG_H];           // record t0 + j starts a run (records behind the list count as starts)
+    __shared__ u8 sg[SG_T];                  // members of the run that starts at j, if this tile orders it (else 0)
+    const u32 t0 = blockIdx.x * SG_T;
+    for (u32 j = threadIdx.x; j < SG_T + SG_H; j += 256) {
+        const u32 i = t0 + j;
+        bool head = true; u64 b = 0; u32 x = 0;
+        if (i < m) { const u64 a = k1[i]; head = (i == 0) || (k1[i - 1] != a); b = k2[i]; x = v[i]; }
+        sk[j] = b; sv[j] = x; sh[j] = head ? 1 : 0;
+    }
+    __syncthreads();
+    for (u32 j = threadIdx.x; j < SG_T; j += 256) {
+        u32 size = 0;
+        if (t0 + j < m && sh[j]) {
+            u32 g = 1;
+            while (g <= SG_MAXG && !sh[j + g]) ++g;            // (j + g <= j + SG_MAXG < SG_T + SG_H)
+            if (g <= SG_MAXG) { if (g >= 2) size = g; }
+            else {                                              // a longer run: its end from the list itself
+                // (the first words are in order: the end of the run by galloping + bisection -- a dozen dependent loads, not one per member)
+                const u32 i = t0 + j;
+                const u64 k = k1[i];
+                u32 lo = i + g, hi = m;                          // records i .. lo - 1 belong to the run; the end lies in [lo, hi]
+                for (u32 step = 16; lo < hi; step *= 2) {
+                    const u32 p = (hi - lo > step) ? lo + step - 1 : hi - 1;
+                    if (k1[p] == k) lo = p + 1; else { hi = p; break; }
+                }
+                while (lo < hi) { const u32 mid = lo + (hi - lo) / 2; if (k1[mid] == k) lo = mid + 1; else hi = mid; }
+                const u32 e = lo;
+                if (e - i <= WS_WAVE_MAX) { rng[2 * (size_t)(i >> 1)] = i; rng[2 * (size_t)(i >> 1) + 1] = e | 0x80000000u; }     // bit 31: the records tie on all of k1
+                else {                                          // beyond what a wave orders
+                    const u32 slot = atomicAdd(&sc->nbig, 1u);
+                    if (slot < SG_BIG_CAP) { big[2 * slot] = i; big[2 * slot + 1] = e; atomicAdd(&sc->big_recs, e - i); }
+                    else sc->overflow = 1u;
+                }
+            }
+        }
+        sg[j] = (u8)size;
+    }
+    __syncthreads();
+    for (u32 j = threadIdx.x; j < SG_T + SG_H; j += 256) {
+        if (t0 + j >= m) continue;
+        u32 st = j, steps = 0;
+        while (!sh[st] && st > 0 && steps < SG_MAXG) { --st; ++steps; }
+        if (!sh[st] || st >= SG_T) continue;                  // the run started in front of the tile (or too far back), or starts in the halo
+        const u32 g = sg[st];
+        if (g < 2 || j - st >= g) continue;
+        const u64 kj = sk[j];
+        u32 r = 0;
+        for (u32 l = st; l < st + g; ++l) { const u64 kl = sk[l]; r += (kl < kj || (kl == kj && l < j)) ? 1u : 0u; }
+        k2[(size_t)t0 + st + r] = kj;
+        v[(size_t)t0 + st + r] = sv[j];
+    }
+}
+// the long runs to / from a list of their own: tab[r] = { first record, end, offset in the list }; one workgroup per run
+struct SegBig { u32 a, e, off, pad; };
+__global__ __launch_bounds__(256) void ws_seg_gather_kernel(const SegBig* __restrict__ tab, const u64* __restrict__ k1, const u64* __restrict__ k2, const u32* __restrict__ v,
+                                                            u64* __restrict__ t1, u64* __restrict__ t2, u32* __restrict__ tv) {
+    const SegBig b = tab[blockIdx.x];
+    for (u32 j = threadIdx.x; j < b.e - b.a; j += 256) { t1[b.off + j] = k1[b.a + j]; t2[b.off + j] = k2[b.a + j]; tv[b.off + j] = v[b.a + j]; }
+}
+__global__ __launch_bounds__(256) void ws_seg_putback_kernel(const SegBig* __restrict__ tab, const u64* __restrict__ t2, const u32* __restrict__ tv, u64* __restrict__ k2, u32* __restrict__ v) {
+    const SegBig b = tab[blockIdx.x];
+    for (u32 j = threadIdx.x; j < b.e - b.a; j += 256) { k2[b.a + j] = t2[b.off + j]; v[b.a + j] = tv[b.off + j]; }
+}
+
+bool wsort_sorted_runs(Ctx& c, const u64* k1, u64* k2, u32* v, size_t m, int k1_bits) {
+    if (m < 2) return true;
+    if (m >= ((size_t)1 << 31)) return false;
+    hipStream_t s = c.stream;
+    const size_t mark = c.arena.mark();
+    const u32 nent = (u32)(m / 2 + 2);
+    u32* rng = c.arena.get<u32>(2 * (size_t)nent);
+    u32* lists = c.arena.get<u32>(4 * (size_t)nent);              // (classes 0 .. 3 only: no entry is longer than WS_WAVE_MAX)
+    u32* cnt = c.arena.get<u32>(2 * EC_NCLS);                      // per class: runs, records
+    SegCounters* d_sc = (SegCounters*)c.arena.alloc(sizeof(SegCounters));
+    u32* big = c.arena.get<u32>(2 * (size_t)SG_BIG_CAP);
+    u8* flags = c.arena.get<u8>(m + 8);                            // (the run kernels mark the heads inside a run: not used here)
+    HIP_TRY(hipMemsetAsync(rng, 0, 2 * (size_t)nent * sizeof(u32), s));
+    HIP_TRY(hipMemsetAsync(cnt, 0, 2 * EC_NCLS * sizeof(u32), s));
+    HIP_TRY(hipMemsetAsync(d_sc, 0, sizeof(SegCounters), s));
+    {
+        Ctx::ProfScope prof(c, K_WS_RUN, (u64)m * 32 + (u64)nent * 16);
+        ws_seg_tile_kernel<<<cdiv(m, SG_T), 256, 0, s>>>(k1, k2, v, (u32)m, rng, big, d_sc);
+        LAUNCH_CHECK();
+        ws_emit_compact_kernel<<<cdiv(nent, EC_TILE), 256, 0, s>>>(rng, nent, lists, nent, cnt);
+        LAUNCH_CHECK();
+    }
+    u32 hc[2 * EC_NCLS];
+    c.read_n(cnt, hc, 2 * EC_NCLS);
+    const SegCounters hs = c.read(d_sc);
+    if (c.wsort_log) {
+        fprintf(stderr, "[sorted runs] m %zu | runs (records) of <= 32 / 64 / 256 / 1024:", m);
+        for (int q = 0; q < 4; ++q) fprintf(stderr, " %u (%u)", hc[q], hc[EC_NCLS + q]);
+        fprintf(stderr, " | longer: %u (%u)%s\n", hs.nbig, hs.big_recs, hs.overflow ? " -- too many" : "");
+    }
+    bool ok = !hs.overflow;
+    for (int q = 4; q < EC_NCLS; ++q) ok = ok && hc[q] == 0;      // (cannot happen: such runs went to the list of long ones)
+    if (ok) {
+        WLeaf A;
+        A.k1 = nullptr; A.k2 = k2; A.v = v; A.unit_rng = rng; A.flags = flags; A.lcp = nullptr; A.d_err = c.d_err; A.inv = 0; A.cmax = 1;
+        const u64 recs = (u64)hc[EC_NCLS] + hc[EC_NCLS + 1] + hc[EC_NCLS + 2] + hc[EC_NCLS + 3];
+        {
+            Ctx::ProfScope prof(c, K_WS_RUN, recs * 18);
+            const u32* l0 = lists, *l1 = lists + nent, *l2 = lists + 2 * (size_t)nent, *l3 = lists + 3 * (size_t)nent;
+            if (hc[3]) { ws_run_wave_kernel<1024, true><<<cdiv(hc[3], 4), 256, 0, s>>>(A, l3, hc[3]); LAUNCH_CHECK(); }
+            if (hc[2]) { ws_run_wave_kernel<256, true><<<cdiv(hc[2], 4), 256, 0, s>>>(A, l2, hc[2]); LAUNCH_CHECK(); }
+            if (hc[0]) { ws_run_lane_kernel<32, true><<<cdiv(hc[0], 8), 256, 0, s>>>(A, l0, hc[0]); LAUNCH_CHECK(); }
+            if (hc[1]) { ws_run_lane_kernel<64, true><<<cdiv(hc[1], 4), 256, 0, s>>>(A, l1, hc[1]); LAUNCH_CHECK(); }
+        }
+        if (hs.nbig) {
+            // the runs no wave orders (a phrase that occurs thousands of times: 1 700 runs with 3 % of the records in the first round at 2e9 B
+            // of English): copied into a list of their own, sorted as a whole -- first words included, so the runs stay in their order --,
+            // copied back
+            const u32 nb = hs.nbig;
+            const size_t mb = hs.big_recs;
+            std::vector<u32> hb(2 * (size_t)nb);
+            c.read_n(big, hb.data(), 2 * (size_t)nb);
+            std::vector<std::pair<u32, u32>> runs(nb);
+            for (u32 r = 0; r < nb; ++r) runs[r] = { hb[2 * r], hb[2 * r + 1] };
+            std::sort(runs.begin(), runs.end());
+            SegBig* h_tab = (SegBig*)c.pinned_table(sizeof(SegBig) * nb);
+            u32 off = 0;
+            for (u32 r = 0; r < nb; ++r) { h_tab[r] = { runs[r].first, runs[r].second, off, 0u }; off += runs[r].second - runs[r].first; }
+            if (off != mb) throw HipError{hipErrorUnknown, "sorted runs: the long runs do not add up", (int)__LINE__};
+            SegBig* d_tab = (SegBig*)c.arena.alloc(sizeof(SegBig) * nb);
+            HIP_TRY(hipMemcpyAsync(d_tab, h_tab, sizeof(SegBig) * nb, hipMemcpyHostToDevice, s));
+            u64* T1[2] = { c.arena.get<u64>(mb), c.arena.get<u64>(mb) };
+            u64* T2[2] = { c.arena.get<u64>(mb), c.arena.get<u64>(mb) };
+            u32* TV[2] = { c.arena.get<u32>(mb), c.arena.get<u32>(mb) };
+            ws_seg_gather_kernel<<<nb, 256, 0, s>>>(d_tab, k1, k2, v, T1[0], T2[0], TV[0]);
+            LAUNCH_CHECK();
+            const int y = wsort_records(c, T1, T2, TV, mb, k1_bits, nullptr);
+            ws_seg_putback_kernel<<<nb, 256, 0, s>>>(d_tab, T2[y], TV[y], k2, v);
+            LAUNCH_CHECK();
+            HIP_TRY(hipStreamSynchronize(s));                      // (the pinned table is the context's: nobody else may fill it before the copy is through)
+        }
+    }
+    c.arena.release(mark);
+    return ok;
+}
+
 int wsort_records(Ctx& c, u64* K1[2], u64* K2[2], u32* V[2], size_t m, int k1_bits, WSortStats* st) {
     WSortStats local;
     if (!st) st = &local;
