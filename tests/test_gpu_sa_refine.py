@@ -137,3 +137,37 @@ def test_star_step_orders_groups_of_any_size(gpu_ctx):
         assert got == plain.lcpcomp_compress(text, threshold=3, flatten=1)[0]
     finally:
         plain.close()
+
+
+def _phrases_text(seed):
+    """random letters with phrases of 40 letters that occur r times each, every occurrence followed by other letters: after the wide
+    sort's 25 symbols the suffixes inside a phrase form groups of exactly r members -- r from 2 to 3 000, around every limit of
+    wsort_sorted_runs (16 members by themselves in an LDS tile, 32 / 64 / 256 / 1 024 by the run kernels, more through the record sort)"""
+    rng = np.random.default_rng(seed)
+    letters = lambda k: rng.integers(97, 123, k, dtype=np.uint8).tobytes()
+    parts = []
+    for r in (2, 3, 5, 9, 15, 16, 17, 18, 31, 32, 33, 64, 65, 200, 256, 257, 1000, 1024, 1025, 1500, 3000, 2, 7, 1100):
+        ph = letters(40)
+        for _ in range(r):
+            parts.append(ph + letters(int(rng.integers(8, 30))))
+    order = rng.permutation(len(parts))
+    body = b"".join(parts[int(i)] for i in order)
+    return letters(1_300_000) + body + letters(1_000_000)
+
+
+def test_text_rounds_order_their_groups_in_place():
+    """Round 6: the text rounds of the wide path order every group of still-equal suffixes in place (wsort_sorted_runs) instead of sorting
+    their list as a whole.  Groups of every size around its limits; with the list of long groups too small (sa_seg_bigcap = 1) the round
+    must fall back to the record sort on a list whose short groups have been ordered already.  Suffix array = the oracle's, streams equal."""
+    text = O.escape(_phrases_text(77))
+    want_sa = O.suffix_array(text)
+    streams = []
+    for opts in ({}, {"sa_seg_rounds": 0}, {"sa_seg_bigcap": 1}, {"sa_seg_bigcap": 0}):
+        with T.Context(0, options=opts) as ctx:
+            got, st = ctx.lcpcomp_compress(text, threshold=2, flatten=1)
+            assert st["sa_mode"] == 1 and st["sa_text_rounds"] >= 1, (opts, st)
+            streams.append(got)
+            sa, isa = ctx.suffix_array(text)
+            assert np.array_equal(sa, want_sa), opts
+    assert all(s == streams[0] for s in streams)
+    assert streams[0] == O.lcpcomp_huff_compress(text, 2, 1)[0]

@@ -1990,7 +1990,7 @@ void wsort_pre_finish(Ctx& c, WPre& P, const u32* hist_full) {
 constexpr u32 SG_T = 1024, SG_H = 16, SG_MAXG = 16, SG_BIG_CAP = 1u << 16;
 struct SegCounters { u32 overflow, nbig, big_recs, pad; };
 __global__ __launch_bounds__(256) void ws_seg_tile_kernel(const u64* __restrict__ k1, u64* k2, u32* v, u32 m, u32* __restrict__ rng, u32* __restrict__ big,
-                                                          SegCounters* __restrict__ sc) {
+                                                          u32 big_cap, SegCounters* __restrict__ sc) {
     __shared__ u64 sk[SG_T + SG_H];
     __shared__ u32 sv[SG_T + SG_H];
     __shared__ u8 sh[SG_T + SG_H];           // record t0 + j starts a run (records behind the list count as starts)
@@ -2023,7 +2023,7 @@ __global__ __launch_bounds__(256) void ws_seg_tile_kernel(const u64* __restrict_
                 if (e - i <= WS_WAVE_MAX) { rng[2 * (size_t)(i >> 1)] = i; rng[2 * (size_t)(i >> 1) + 1] = e | 0x80000000u; }     // bit 31: the records tie on all of k1
                 else {                                          // beyond what a wave orders
                     const u32 slot = atomicAdd(&sc->nbig, 1u);
-                    if (slot < SG_BIG_CAP) { big[2 * slot] = i; big[2 * slot + 1] = e; atomicAdd(&sc->big_recs, e - i); }
+                    if (slot < big_cap) { big[2 * slot] = i; big[2 * slot + 1] = e; atomicAdd(&sc->big_recs, e - i); }
                     else sc->overflow = 1u;
                 }
             }
@@ -2067,6 +2067,7 @@ bool wsort_sorted_runs(Ctx& c, const u64* k1, u64* k2, u32* v, size_t m, int k1_
     u32* lists = c.arena.get<u32>(4 * (size_t)nent);              // (classes 0 .. 3 only: no entry is longer than WS_WAVE_MAX)
     u32* cnt = c.arena.get<u32>(2 * EC_NCLS);                      // per class: runs, records
     SegCounters* d_sc = (SegCounters*)c.arena.alloc(sizeof(SegCounters));
+    const u32 big_cap = (u32)std::min<long>(std::max<long>(c.sa_seg_bigcap, 0), (long)SG_BIG_CAP);   // (option sa_seg_bigcap: tests make the table overflow)
     u32* big = c.arena.get<u32>(2 * (size_t)SG_BIG_CAP);
     u8* flags = c.arena.get<u8>(m + 8);                            // (the run kernels mark the heads inside a run: not used here)
     HIP_TRY(hipMemsetAsync(rng, 0, 2 * (size_t)nent * sizeof(u32), s));
@@ -2074,7 +2075,7 @@ bool wsort_sorted_runs(Ctx& c, const u64* k1, u64* k2, u32* v, size_t m, int k1_
     HIP_TRY(hipMemsetAsync(d_sc, 0, sizeof(SegCounters), s));
     {
         Ctx::ProfScope prof(c, K_WS_RUN, (u64)m * 32 + (u64)nent * 16);
-        ws_seg_tile_kernel<<<cdiv(m, SG_T), 256, 0, s>>>(k1, k2, v, (u32)m, rng, big, d_sc);
+        ws_seg_tile_kernel<<<cdiv(m, SG_T), 256, 0, s>>>(k1, k2, v, (u32)m, rng, big, big_cap, d_sc);
         LAUNCH_CHECK();
         ws_emit_compact_kernel<<<cdiv(nent, EC_TILE), 256, 0, s>>>(rng, nent, lists, nent, cnt);
         LAUNCH_CHECK();
