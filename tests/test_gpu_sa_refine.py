@@ -162,7 +162,7 @@ def test_text_rounds_order_their_groups_in_place():
     text = O.escape(_phrases_text(77))
     want_sa = O.suffix_array(text)
     streams = []
-    for opts in ({}, {"sa_seg_rounds": 0}, {"sa_seg_bigcap": 1}, {"sa_seg_bigcap": 0}):
+    for opts in ({}, {"sa_seg_rounds": 0}, {"sa_seg_rounds": 1}, {"sa_seg_rounds": 2}, {"sa_seg_bigcap": 1}, {"sa_seg_bigcap": 0}, {"sa_seg_rounds": 2, "sa_seg_bigcap": 1}):
         with T.Context(0, options=opts) as ctx:
             got, st = ctx.lcpcomp_compress(text, threshold=2, flatten=1)
             assert st["sa_mode"] == 1 and st["sa_text_rounds"] >= 1, (opts, st)

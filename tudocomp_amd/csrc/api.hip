@@ -401,7 +401,7 @@ const OptionDef OPTIONS[] = {
     { "wsort_predig",     [](Ctx& c, long v) { c.wsort_predig = v ? 1 : 0; } },
     { "wsort_prehist",    [](Ctx& c, long v) { c.wsort_prehist = v ? 1 : 0; } },
     { "sa_seg_bigcap",    [](Ctx& c, long v) { c.sa_seg_bigcap = clampi(v, 0, 65536); } },
-    { "sa_seg_rounds",    [](Ctx& c, long v) { c.sa_seg_rounds = v != 0; } },
+    { "sa_seg_rounds",    [](Ctx& c, long v) { c.sa_seg_rounds = clampi(v, 0, 2); } },
     { "wsort_run_streams",[](Ctx& c, long v) { c.wsort_run_streams = v != 0; } },
     { "wsort_predig_skip",[](Ctx& c, long v) { c.wsort_predig_skip = clampi(v, 0, 24); } },
     { "wsort_fuse",       [](Ctx& c, long v) { c.wsort_fuse = v ? 1 : 0; } },

@@ -185,7 +185,7 @@ struct Ctx {
     int wsort_prehist = 1;         // ... and the tile histograms of that pass are copied into the merging level's table, whose count pass skips those pieces (option wsort_prehist)
     bool wsort_count_nonheads = true;   // (transient, set by the caller of the wide sort) false: WSortStats::nonheads is not wanted -- the pass over the flags that counts it is skipped
     int sa_seg_bigcap = 65536;     // ... with room for this many groups of more than 1 024 members (more: the round sorts its list as a whole; tests: 1)
-    int sa_seg_rounds = 1;         // text rounds: the groups are ordered in place by the run kernels (0: the list is sorted as a whole; option sa_seg_rounds)
+    int sa_seg_rounds = 2;         // text rounds: the groups are ordered in place (0: the list is sorted as a whole; 1: in place, behind a key pass of its own; 2: the in-place pass makes the records itself: 105.8 against 106.5 ms of suffix array; option sa_seg_rounds)
     int wsort_run_streams = 1;     // the four run kernels of a leaf stage side by side on the context's three streams (option wsort_run_streams)
     int wsort_predig_skip = 4;     // ... but not for the last chunks (their digits would only be ready after the last copy; option wsort_predig_skip; 0 / 2 / 3 / 4 / 6: 257.5 / 257.5 / 257.4 / 257.2 / 257.0 ms against 260.8 without; with the count pass that requests a row ahead: 4 against 6 = 247.1 against 247.7 ms, three alternating pairs)
     int wsort_predig = 1;          // with the overlapped level 1: the digits of level 2 are computed chunk by chunk behind the upload too, on the low-priority side stream (option wsort_predig; round 4 measured it on the main stream, where it lengthened the upload by more than it saved)

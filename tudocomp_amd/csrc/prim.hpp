@@ -96,6 +96,9 @@ int wsort_records(Ctx& c, u64* K1[2], u64* K2[2], u32* V[2], size_t m, int k1_bi
 // them than its table holds (65 536) -- shorter runs may have been ordered by then, the records are still the same list: the caller sorts
 // it as a whole.
 bool wsort_sorted_runs(Ctx& c, const u64* k1, u64* k2, u32* v, size_t m, int k1_bits);
+// the same for the records of a text round, made on the way: record i = (a_r1[i], the next g.s symbols of suffix a_sa[i] from text position
+// a_sa[i] + h, a_sa[i]) lands in (k1, k2, v) -- whatever the result, the three arrays hold the whole list afterwards
+bool wsort_sorted_runs_from_text(Ctx& c, const u32* a_sa, const u32* a_r1, size_t m, const WKeyGen& g, u32 h, u64* k1, u64* k2, u32* v, int k1_bits);
 
 // Same contract as radix_sort_pairs_u64 for keys that are pairwise DISTINCT on the sorted bits (stability is then
 // irrelevant): inputs of at most 2048 pairs are sorted by one workgroup in LDS (bitonic network), larger ones by the

@@ -959,14 +959,20 @@ int build_suffix_array_wide(Ctx& c, const u8* text, size_t n, u32* sa, u32* isa,
     int text_rounds = 0;
     while (fast && m > 0) {
         if (text_rounds >= c.wsort_rounds || h + (u32)g1.s > 250u) { fast = false; break; }
-        {   // per element: position, head (8 B), one scattered text read, three record words (20 B)
-            Ctx::ProfScope prof(c, K_SA_BUILD_KEYS, (u64)m * 28);
-            sa_round_keys_kernel<<<cdiv(m, 256), 256, 0, s>>>(B.A_sa, B.A_r1, m, g1, h, K1[0], K2[0], V[0]);
-            LAUNCH_CHECK();
-        }
         // (the list is in slot order, its first words -- the slots of the group heads -- are in order already: the round only has to order the
-        //  members of every group by their next key bits, which the run kernels of the leaf stage do in one pass; option sa_seg_rounds)
-        const int y = (c.sa_seg_rounds && wsort_sorted_runs(c, K1[0], K2[0], V[0], m, bn)) ? 0 : wsort_records(c, K1, K2, V, m, bn, nullptr);
+        //  members of every group by their next key bits, in place; option sa_seg_rounds.  2: the records are made by that pass itself --
+        //  per element: position, head (8 B), one scattered text read, three record words (20 B))
+        int y;
+        if (c.sa_seg_rounds >= 2 && g1.s <= 64) {
+            y = wsort_sorted_runs_from_text(c, B.A_sa, B.A_r1, m, g1, h, K1[0], K2[0], V[0], bn) ? 0 : wsort_records(c, K1, K2, V, m, bn, nullptr);
+        } else {
+            {
+                Ctx::ProfScope prof(c, K_SA_BUILD_KEYS, (u64)m * 28);
+                sa_round_keys_kernel<<<cdiv(m, 256), 256, 0, s>>>(B.A_sa, B.A_r1, m, g1, h, K1[0], K2[0], V[0]);
+                LAUNCH_CHECK();
+            }
+            y = (c.sa_seg_rounds && wsort_sorted_runs(c, K1[0], K2[0], V[0], m, bn)) ? 0 : wsort_records(c, K1, K2, V, m, bn, nullptr);
+        }
         st->sorted_elems += m;
         const u32 tiles = cdiv(m, GR_TILE);
         HIP_TRY(hipMemsetAsync(B.gdesc, 0, (size_t)tiles * sizeof(u64), s));

@@ -2045,6 +2045,82 @@ __global__ __launch_bounds__(256) void ws_seg_tile_kernel(const u64* __restrict_
         v[(size_t)t0 + st + r] = sv[j];
     }
 }
+// The same with the records MADE here (text rounds: record i = (slot of the group head r1[i], the next g.s symbols of suffix sa[i] from text
+// position sa[i] + h, sa[i])): the text gathers of a round's key pass run inside this kernel, whose LDS work hides behind them, and the
+// list is written once instead of written, read and written.  Every record has to be written by exactly one tile: a run of up to SG_MAXG
+// members by the tile it starts in (all of it, sorted: it reaches at most SG_H - 1 records into the right halo), every other record --
+// members of longer runs -- in place by the tile it lies in.  A halo on the left as well tells a tile whether a run that reaches into
+// it from the tile before is one of the short ones (then that tile writes it).
+__global__ __launch_bounds__(256) void ws_seg_tile_keys_kernel(const u32* __restrict__ a_sa, const u32* __restrict__ a_r1, u32 m, WKeyGen g, u32 h,
+                                                               u64* __restrict__ k1, u64* __restrict__ k2, u32* __restrict__ v,
+                                                               u32* __restrict__ rng, u32* __restrict__ big, u32 big_cap, SegCounters* __restrict__ sc) {
+    constexpr u32 LN = SG_T + 2 * SG_H;
+    __shared__ u64 sk[LN];
+    __shared__ u32 sv[LN];
+    __shared__ u8 sh[LN];                    // record (t0 - SG_H + j) starts a run (records outside the list count as starts)
+    __shared__ u8 sg[LN];                    // members of the run that starts at j if it has at most SG_MAXG (else SG_MAXG + 1; 0: no start)
+    __shared__ u8 code[256];
+    code[threadIdx.x] = g.code[threadIdx.x];
+    __syncthreads();
+    const long long t0 = (long long)blockIdx.x * SG_T - (long long)SG_H;      // list index of LDS slot 0
+    for (u32 j = threadIdx.x; j < LN; j += 256) {
+        const long long i = t0 + j;
+        bool head = true; u64 b = 0; u32 x = 0;
+        if (i >= 0 && i < (long long)m) {
+            const u32 r = a_r1[i];
+            head = (i == 0) || (a_r1[i - 1] != r);
+            x = a_sa[i];
+            u64 a2 = 0;
+            ws_key_global<1>(g, code, (size_t)x + h, b, a2);
+            if (j >= SG_H && j < SG_H + SG_T) k1[i] = (u64)r;
+        }
+        sk[j] = b; sv[j] = x; sh[j] = head ? 1 : 0;
+    }
+    __syncthreads();
+    for (u32 j = threadIdx.x; j < LN; j += 256) {
+        u32 size = 0;
+        const long long i = t0 + j;
+        if (i >= 0 && i < (long long)m && sh[j] && j < SG_H + SG_T) {          // starts in the left halo and in the tile (the right halo's belong to the next tile)
+            u32 gsz = 1;
+            while (gsz <= SG_MAXG && j + gsz < LN && !sh[j + gsz]) ++gsz;      // (j + SG_MAXG < LN for the starts looked at)
+            size = gsz <= SG_MAXG ? gsz : SG_MAXG + 1;
+            if (gsz > SG_MAXG && j >= SG_H) {                                   // a longer run that starts in this tile: its end from the list itself
+                const u32 r = a_r1[i];
+                u32 lo = (u32)i + gsz, hi = m;
+                for (u32 step = 16; lo < hi; step *= 2) {
+                    const u32 p = (hi - lo > step) ? lo + step - 1 : hi - 1;
+                    if (a_r1[p] == r) lo = p + 1; else { hi = p; break; }
+                }
+                while (lo < hi) { const u32 mid = lo + (hi - lo) / 2; if (a_r1[mid] == r) lo = mid + 1; else hi = mid; }
+                const u32 e = lo, i32 = (u32)i;
+                if (e - i32 <= WS_WAVE_MAX) { rng[2 * (size_t)(i32 >> 1)] = i32; rng[2 * (size_t)(i32 >> 1) + 1] = e | 0x80000000u; }
+                else {
+                    const u32 slot = atomicAdd(&sc->nbig, 1u);
+                    if (slot < big_cap) { big[2 * slot] = i32; big[2 * slot + 1] = e; atomicAdd(&sc->big_recs, e - i32); }
+                    else sc->overflow = 1u;
+                }
+            }
+        }
+        sg[j] = (u8)size;
+    }
+    __syncthreads();
+    for (u32 j = threadIdx.x; j < LN; j += 256) {
+        const long long i = t0 + j;
+        if (i < 0 || i >= (long long)m) continue;
+        const bool own = j >= SG_H && j < SG_H + SG_T;
+        u32 st = j, steps = 0;
+        while (!sh[st] && st > 0 && steps < SG_MAXG) { --st; ++steps; }
+        const u32 gsz = sh[st] ? sg[st] : SG_MAXG + 1;          // (no start within SG_MAXG records in front of it: a long run)
+        if (gsz <= SG_MAXG && gsz >= 1) {                       // a short run (one member: a record alone -- cannot happen in a list of groups, written in place)
+            if (st < SG_H || st >= SG_H + SG_T) continue;      // ... that starts in another tile: written there
+            const u64 kj = sk[j];
+            u32 r = 0;
+            for (u32 l = st; l < st + gsz; ++l) { const u64 kl = sk[l]; r += (kl < kj || (kl == kj && l < j)) ? 1u : 0u; }
+            const size_t o = (size_t)(t0 + st + r);
+            k2[o] = kj; v[o] = sv[j];
+        } else if (own) { k2[i] = sk[j]; v[i] = sv[j]; }       // a member of a long run: in place
+    }
+}
 // the long runs to / from a list of their own: tab[r] = { first record, end, offset in the list }; one workgroup per run
 struct SegBig { u32 a, e, off, pad; };
 __global__ __launch_bounds__(256) void ws_seg_gather_kernel(const SegBig* __restrict__ tab, const u64* __restrict__ k1, const u64* __restrict__ k2, const u32* __restrict__ v,
@@ -2057,9 +2133,14 @@ __global__ __launch_bounds__(256) void ws_seg_putback_kernel(const SegBig* __res
     for (u32 j = threadIdx.x; j < b.e - b.a; j += 256) { k2[b.a + j] = t2[b.off + j]; v[b.a + j] = tv[b.off + j]; }
 }
 
-bool wsort_sorted_runs(Ctx& c, const u64* k1, u64* k2, u32* v, size_t m, int k1_bits) {
-    if (m < 2) return true;
-    if (m >= ((size_t)1 << 31)) return false;
+static bool ws_sorted_runs_impl(Ctx& c, const u64* k1, u64* k2, u32* v, size_t m, int k1_bits, const u32* a_sa, const u32* a_r1, const WKeyGen* g, u32 h, u64* k1_out);
+bool wsort_sorted_runs(Ctx& c, const u64* k1, u64* k2, u32* v, size_t m, int k1_bits) { return ws_sorted_runs_impl(c, k1, k2, v, m, k1_bits, nullptr, nullptr, nullptr, 0, nullptr); }
+bool wsort_sorted_runs_from_text(Ctx& c, const u32* a_sa, const u32* a_r1, size_t m, const WKeyGen& g, u32 h, u64* k1, u64* k2, u32* v, int k1_bits) {
+    return ws_sorted_runs_impl(c, k1, k2, v, m, k1_bits, a_sa, a_r1, &g, h, k1);
+}
+static bool ws_sorted_runs_impl(Ctx& c, const u64* k1, u64* k2, u32* v, size_t m, int k1_bits, const u32* a_sa, const u32* a_r1, const WKeyGen* g, u32 h, u64* k1_out) {
+    if (m < 2 && !g) return true;
+    if (m >= ((size_t)1 << 31) || m == 0) return false;
     hipStream_t s = c.stream;
     const size_t mark = c.arena.mark();
     const u32 nent = (u32)(m / 2 + 2);
@@ -2075,7 +2156,8 @@ bool wsort_sorted_runs(Ctx& c, const u64* k1, u64* k2, u32* v, size_t m, int k1_
     HIP_TRY(hipMemsetAsync(d_sc, 0, sizeof(SegCounters), s));
     {
         Ctx::ProfScope prof(c, K_WS_RUN, (u64)m * 32 + (u64)nent * 16);
-        ws_seg_tile_kernel<<<cdiv(m, SG_T), 256, 0, s>>>(k1, k2, v, (u32)m, rng, big, big_cap, d_sc);
+        if (g) ws_seg_tile_keys_kernel<<<cdiv(m, SG_T), 256, 0, s>>>(a_sa, a_r1, (u32)m, *g, h, k1_out, k2, v, rng, big, big_cap, d_sc);
+        else ws_seg_tile_kernel<<<cdiv(m, SG_T), 256, 0, s>>>(k1, k2, v, (u32)m, rng, big, big_cap, d_sc);
         LAUNCH_CHECK();
         ws_emit_compact_kernel<<<cdiv(nent, EC_TILE), 256, 0, s>>>(rng, nent, lists, nent, cnt);
         LAUNCH_CHECK();
