@@ -592,21 +592,32 @@ __global__ __launch_bounds__(256) void sa_flag_compact_kernel(const u8* __restri
     // head of the run that is open at the thread's first slot: the last head in front of it (earlier threads, earlier tiles)
     u32 run = __shfl_up(inc, 1, 64);
     if (lane_id() == 0) run = sm2[wave_id()];                       // (block_inclusive_max leaves the exclusive wave prefixes in sm2[0..3])
-    if (!cnt) return;
-    if (blockIdx.x > 0) run = max(run, tile_lastscan[blockIdx.x - 1]);
-    u32 o = tile_off[blockIdx.x] + pre;
-    const u32 want = valid & ~single;                                // the slots this thread lists
-    u32 vv[16];                                                     // their suffixes: all requested before the first store
+    // (round 6: a thread owns 16 slots of which one is listed on average -- loading and storing from there meant sixteen loads and
+    //  forty-eight stores per wave with a few lanes each.  The listed slots go through LDS instead: the thread enters its slots and
+    //  their heads, then consecutive lanes take consecutive entries -- every load and store of the list has all its lanes, the
+    //  stores are whole lines.  2.78 -> see DESIGN section 9)
+    __shared__ unsigned short l_slot[FC_TILE];
+    __shared__ u32 l_head[FC_TILE];
+    if (cnt) {
+        if (blockIdx.x > 0) run = max(run, tile_lastscan[blockIdx.x - 1]);
+        u32 o = pre;
+        const u32 want = valid & ~single;                            // the slots this thread lists
+        const u32 hv = h & valid;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) vv[q] = ((want >> q) & 1u) ? v[i0 + q] : 0u;
-    const u32 hv = h & valid;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        if ((want >> q) & 1u) {
-            const u32 hq = hv & ((2u << q) - 1u);                    // heads at or in front of slot q inside the thread's range
-            const u32 r = hq ? (u32)(i0 + 31 - __builtin_clz(hq)) + 1u : run;
-            o_sa[o] = vv[q]; o_pos[o] = (u32)(i0 + q); o_r1[o] = r - 1u; ++o;
+        for (int q = 0; q < 16; ++q) {
+            if ((want >> q) & 1u) {
+                const u32 hq = hv & ((2u << q) - 1u);                // heads at or in front of slot q inside the thread's range
+                const u32 r = hq ? (u32)(i0 + 31 - __builtin_clz(hq)) + 1u : run;
+                l_slot[o] = (unsigned short)(threadIdx.x * 16 + q); l_head[o] = r - 1u; ++o;
+            }
         }
+    }
+    __syncthreads();
+    const size_t t0 = (size_t)blockIdx.x * FC_TILE;
+    const u32 obase = tile_off[blockIdx.x];
+    for (u32 e = threadIdx.x; e < total; e += 256) {
+        const size_t slot = t0 + l_slot[e];
+        o_sa[obase + e] = v[slot]; o_pos[obase + e] = (u32)slot; o_r1[obase + e] = l_head[e];
     }
 }
 
