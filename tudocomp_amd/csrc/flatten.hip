@@ -170,6 +170,10 @@ __global__ __launch_bounds__(OW_T) void owner_build_kernel(const u32* __restrict
     u32 cur_rank = rank - 1;                                    // rank of the start at cur_start (if any)
     u32 cur_len = cur_start ? s[ow_idx(cur_start - 1)] : 0u;
     u32 out[OW_PER];
+    // (round 6: a thread's 16 positions hold 1.2 factor starts on average; storing their list entries from the loop below meant 32 store
+    //  instructions per wave with a few lanes each.  With at most half a tile of starts -- always, for a threshold of 2 and more -- they
+    //  go through the LDS tile once the owner words have left it, and leave as whole lines)
+    const bool stage_starts = total <= (u32)OW_TILE / 2;
     const u32 remb = rem_total ? owner_rem_bits_for(*rem_total, rem_cap) : 0u;     // FactorSpace::owner_rem_bits (the scan has written the total)
     const u32 qmax = (1u << remb) - 1u, rsh = (32u - remb) & 31u;         // (remb == 0: qmax == 0, the shifted field is 0)
 #pragma unroll
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(OW_T) void owner_build_kernel(const u32* __restrict
         const u32 pl = l0 + k;
         if (f[k] != 0) {
             cur_start = pl + 1; cur_len = f[k]; cur_rank = rank++;
-            if (base + pl < n) { pos[cur_rank] = (u32)(base + pl); if (lenl) lenl[cur_rank] = f[k]; }
+            if (!stage_starts && base + pl < n) { pos[cur_rank] = (u32)(base + pl); if (lenl) lenl[cur_rank] = f[k]; }
         }
         const u32 d = pl - (cur_start - 1);                             // distance from the start of the last factor at or before pl
         out[k] = (cur_start != 0 && d < cur_len) ? (cur_rank | (min(cur_len - d - 1u, qmax) << rsh)) : NONE32;
@@ -208,6 +212,18 @@ __global__ __launch_bounds__(OW_T) void owner_build_kernel(const u32* __restrict
         const u32 q = ow_idx(i);
         if (p + 4 <= n) *(uint4*)(owner + p) = make_uint4(s[q], s[q + 1], s[q + 2], s[q + 3]);
         else for (int k = 0; k < 4; ++k) if (p + k < n) owner[p + k] = s[q + k];
+    }
+    if (stage_starts && total) {
+        __syncthreads();                                        // the owner words have left the tile
+        u32 o = excl;
+#pragma unroll
+        for (int k = 0; k < OW_PER; ++k) if (f[k] != 0) { s[o] = l0 + k; s[OW_TILE / 2 + o] = f[k]; ++o; }
+        __syncthreads();
+        const u32 tb = tilebase[blockIdx.x];
+        for (u32 e = threadIdx.x; e < total; e += OW_T) {
+            const size_t p = base + s[e];
+            if (p < n) { pos[tb + e] = (u32)p; if (lenl) lenl[tb + e] = s[OW_TILE / 2 + e]; }
+        }
     }
 }
 
