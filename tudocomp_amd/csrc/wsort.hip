@@ -1985,9 +1985,10 @@ void wsort_pre_finish(Ctx& c, WPre& P, const u32* hist_full) {
 // The runs of a text round are the groups of still-equal suffixes: 2.5 members on average on English text, so most of them are ordered
 // by their members themselves -- a tile of records in LDS, every record counts the members of its run that go before it (runs of up to
 // SG_MAXG members; a run that crosses the tile's end is seen whole through the halo, and belongs to the tile it starts in).  Longer runs
-// (up to WS_WAVE_MAX) are entered into the table the run kernels' lists are compiled from (entry start / 2: runs have two members and
-// more, so two never share an entry); beyond that the caller sorts the list as a whole.
+// (up to WS_WAVE_MAX) are entered into the table the run kernels' lists are compiled from (entry start / (SG_MAXG + 1): such a run has
+// more members than that, so two never share an entry); beyond that the caller sorts the list as a whole.
 constexpr u32 SG_T = 1024, SG_H = 16, SG_MAXG = 16, SG_BIG_CAP = 1u << 16;
+constexpr u32 SG_EDIV = SG_MAXG + 1;      // a run that is entered into the table has more than SG_MAXG members: entry = start / SG_EDIV, no two runs share one
 struct SegCounters { u32 overflow, nbig, big_recs, pad; };
 __global__ __launch_bounds__(256) void ws_seg_tile_kernel(const u64* __restrict__ k1, u64* k2, u32* v, u32 m, u32* __restrict__ rng, u32* __restrict__ big,
                                                           u32 big_cap, SegCounters* __restrict__ sc) {
@@ -2020,7 +2021,7 @@ __global__ __launch_bounds__(256) void ws_seg_tile_kernel(const u64* __restrict_
                 }
                 while (lo < hi) { const u32 mid = lo + (hi - lo) / 2; if (k1[mid] == k) lo = mid + 1; else hi = mid; }
                 const u32 e = lo;
-                if (e - i <= WS_WAVE_MAX) { rng[2 * (size_t)(i >> 1)] = i; rng[2 * (size_t)(i >> 1) + 1] = e | 0x80000000u; }     // bit 31: the records tie on all of k1
+                if (e - i <= WS_WAVE_MAX) { rng[2 * (size_t)(i / SG_EDIV)] = i; rng[2 * (size_t)(i / SG_EDIV) + 1] = e | 0x80000000u; }     // bit 31: the records tie on all of k1
                 else {                                          // beyond what a wave orders
                     const u32 slot = atomicAdd(&sc->nbig, 1u);
                     if (slot < big_cap) { big[2 * slot] = i; big[2 * slot + 1] = e; atomicAdd(&sc->big_recs, e - i); }
@@ -2093,7 +2094,7 @@ __global__ __launch_bounds__(256) void ws_seg_tile_keys_kernel(const u32* __rest
                 }
                 while (lo < hi) { const u32 mid = lo + (hi - lo) / 2; if (a_r1[mid] == r) lo = mid + 1; else hi = mid; }
                 const u32 e = lo, i32 = (u32)i;
-                if (e - i32 <= WS_WAVE_MAX) { rng[2 * (size_t)(i32 >> 1)] = i32; rng[2 * (size_t)(i32 >> 1) + 1] = e | 0x80000000u; }
+                if (e - i32 <= WS_WAVE_MAX) { rng[2 * (size_t)(i32 / SG_EDIV)] = i32; rng[2 * (size_t)(i32 / SG_EDIV) + 1] = e | 0x80000000u; }
                 else {
                     const u32 slot = atomicAdd(&sc->nbig, 1u);
                     if (slot < big_cap) { big[2 * slot] = i32; big[2 * slot + 1] = e; atomicAdd(&sc->big_recs, e - i32); }
@@ -2143,7 +2144,7 @@ static bool ws_sorted_runs_impl(Ctx& c, const u64* k1, u64* k2, u32* v, size_t m
     if (m >= ((size_t)1 << 31) || m == 0) return false;
     hipStream_t s = c.stream;
     const size_t mark = c.arena.mark();
-    const u32 nent = (u32)(m / 2 + 2);
+    const u32 nent = (u32)(m / SG_EDIV + 2);
     u32* rng = c.arena.get<u32>(2 * (size_t)nent);
     u32* lists = c.arena.get<u32>(4 * (size_t)nent);              // (classes 0 .. 3 only: no entry is longer than WS_WAVE_MAX)
     u32* cnt = c.arena.get<u32>(2 * EC_NCLS);                      // per class: runs, records
