@@ -641,13 +641,13 @@ def test_options_api():
 # every algorithm switch of the option table with its non-default values (diagnostic options -- *_log, eager_dump, small_prof, arena_log --
 # only print; dec_* are exercised by test_gpu_decode.py, ssort_levels / wsort_* in depth by test_gpu_sort.py / test_gpu_wsort.py)
 OPTION_VALUES = {
-    "fastread": [0], "sa_local": [0, 2], "radix_waves": [8], "window_lcut": [0, 20], "window_halo": [0], "window_force_fail": [1],
+    "fastread": [0], "sa_local": [0, 2], "radix_waves": [8], "window_lcut": [0, 20, 48], "window_halo": [0, 384], "window_force_fail": [1],
     "window_large": [1], "window_src": [0], "plcp_samples": [0], "small_pipeline": [0], "small_big": [0], "phi_lazy": [0], "fs_pair": [0],
     "enc_early": [0, 2], "enc_rec": [0], "owner_rem": [0, 1, 3], "level_purge": [0], "eager": [0], "flen_bytes": [0], "flatten_steps": [0, 4], "flatten_growth": [2],
     "sa_refine": [0], "sa_pairs": [0], "sa_stars": [0], "sa_seg_rounds": [0, 1], "sa_seg_bigcap": [0], "sa_fused_init": [0], "sa_init_syms": [5], "radix_lds": [0, 2], "xcd_remap": [0, 2],
     "bucket_scatter": [0], "ssort": [0], "ssort_levels": [2], "msd_partition": [0], "wsort": [0], "wsort_min": [4096], "wsort_syms": [19],
     "wsort_kw": [1], "wsort_rounds": [0], "wsort_smallrun": [1], "wsort_overlap": [0], "wsort_predig": [0], "wsort_predig_skip": [0, 6], "wsort_prehist": [0], "wsort_run_streams": [0], "wsort_fuse": [0], "wsort_order": [0],
-    "wsort_two": [2], "wsort_leaf": [1024], "wsort_pack": [1024, 4096], "wsort_cmax": [8, 64], "upload_chunks": [4, 24], "upload_tail_n": [0, 8], "upload_tail_pct": [85],
+    "wsort_two": [2], "wsort_leaf": [1024], "wsort_pack": [2048, 4096], "wsort_cmax": [8, 16, 64], "upload_chunks": [4, 24], "upload_tail_n": [0, 8], "upload_tail_pct": [85],
     "dec_seg": [1 << 20], "dec_lean": [0], "dec_parse": [0, 2], "dec_done": [0],
 }
 

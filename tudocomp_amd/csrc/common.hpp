@@ -165,8 +165,8 @@ struct Ctx {
                                    // (-1.2 ms of 7.3), 1 = also in the radix sort kernels (with the LDS-reordered scatter the 128-byte
                                    // pieces of neighbouring tiles then meet in one L2: -13 %), 2 = nowhere
     int window_src = 1;            // window pass without a Phi array: the kernel writes fsrc[p] = SA[ISA[p] - 1] at its factor starts itself -- its VALU-bound waves hide the two gathers that cost flatten_init 3.7 ms (window kernel + 1.1 ms: -2.5 ms per step; option window_src=0: the sources are computed in flatten_init)
-    int window_lcut = 48;          // factorize: levels <= this run window-local in one launch (env TDC_GPU_WINDOW_LCUT, 0 disables)
-    int window_halo = 384;         // window pass: halo of the first attempt (env TDC_GPU_WINDOW_HALO; a failed border retries with 2048)
+    int window_lcut = 56;          // factorize: levels <= this run window-local in one launch (option window_lcut, 0 disables; factorize stage in the kernel trace of a step at 2e9 B: 40 / 44 / 48 / 52 / 56 / 60 / 63 -> 36.1 / 35.3 / 33.7 / 33.2 / 33.3 / 33.2 / 33.3 ms)
+    int window_halo = 320;         // window pass: halo of the first attempt (option window_halo; a failed border retries with 2048.  With window_lcut 56 at 2e9 B: 256 / 320 / 384 -> factorize 32.8 / 33.1 / 33.3 ms with a smallest margin of 64 / 126 / 185 positions left: 320 keeps 40 % of the halo in reserve)
     size_t dec_seg = 0;            // decompression: bit positions per segment of the chain marking (0: 2^30; env TDC_GPU_DEC_SEG, tests)
     bool phi_lazy = true;          // lcpcomp(comp=arrays) behind the fused scatter: no Phi array, a factor's source is SA[ISA[p] - 1] (env TDC_GPU_PHI_LAZY=0: Phi as before)
     int dec_lean = 1;              // decompression, device parse: lean marking for streams of short tokens (env TDC_GPU_DEC_LEAN=0: the general marking for every stream; tests)
@@ -180,7 +180,7 @@ struct Ctx {
     int wsort_syms = 0;            // cap on the symbols per key of the wide sort (env TDC_GPU_WSORT_SYMS; 0: as many as the key words hold) -- measurements only
     int wsort_kw = 0;              // key words: 0 = by alphabet (2 when a word holds fewer than 16 symbols), 1 | 2 forced (env TDC_GPU_WSORT_KW)
     int wsort_rounds = 24;         // most text rounds before the doubling fallback (env TDC_GPU_WSORT_ROUNDS; 0: straight to doubling)
-    int wsort_cmax = 16;           // leaf sort: runs of tying records up to this length are ordered by counting, longer ones by the wave kernel (option wsort_cmax, 8 .. 64)
+    int wsort_cmax = 24;           // leaf sort: runs of tying records up to this length are ordered by counting, longer ones by the wave kernel (option wsort_cmax, 8 .. 64; leaf stage in the trace with wsort_pack 1024: 16 / 24 / 32 -> 49.4 / 49.2 / 49.7 ms)
     int wsort_overlap = 1;         // host-buffer calls: level 1 of the wide suffix sort runs chunk by chunk behind the upload (env TDC_GPU_WSORT_OVERLAP=0 disables)
     int wsort_prehist = 1;         // ... and the tile histograms of that pass are copied into the merging level's table, whose count pass skips those pieces (option wsort_prehist)
     bool wsort_count_nonheads = true;   // (transient, set by the caller of the wide sort) false: WSortStats::nonheads is not wanted -- the pass over the flags that counts it is skipped
@@ -191,7 +191,7 @@ struct Ctx {
     int wsort_predig = 1;          // with the overlapped level 1: the digits of level 2 are computed chunk by chunk behind the upload too, on the low-priority side stream (option wsort_predig; round 4 measured it on the main stream, where it lengthened the upload by more than it saved)
     int wsort_two = 0;             // wide sort of more than 235 M records: two partition levels of up to 1024 buckets instead of three of up to 256 (env TDC_GPU_WSORT_TWO)
     int wsort_leaf = 2048;         // leaf size the three-level wide sort aims at (env TDC_GPU_WSORT_LEAF: 1024 | 2048)
-    int wsort_pack = 2048;         // leaf sort: leaves up to this size are packed into units of at most twice that (env TDC_GPU_WSORT_PACK: 1024 | 2048 | 4096)
+    int wsort_pack = 1024;         // leaf sort: leaves up to this size are packed into units of at most twice that (option wsort_pack: 1024 | 2048 | 4096; leaf stage in the kernel trace of a step at 2e9 B: 1024 -> 49.4 ms, 2048 -> 50.5 ms in six runs each -- with 1024 every unit fits a four-wave instance; round 6's A/B of whole steps had put the difference at 0.3 ms, inside its noise)
     int wsort_order = 1;           // wide sort with three levels: 1 = the widest level (256 buckets) first, where it runs behind the upload (env TDC_GPU_WSORT_ORDER)
     int wsort_fuse = 1;            // leaf sort: kernel A orders the short runs of its units itself instead of listing the unit for the counting kernel (env TDC_GPU_WSORT_FUSE)
     int wsort_small = 0;           // tests: 1 = every run of a leaf unit counts as "big" (the chunk iterations run everywhere) (env TDC_GPU_WSORT_SMALLRUN)
