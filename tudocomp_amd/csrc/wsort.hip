@@ -1987,7 +1987,13 @@ void wsort_pre_finish(Ctx& c, WPre& P, const u32* hist_full) {
 // SG_MAXG members; a run that crosses the tile's end is seen whole through the halo, and belongs to the tile it starts in).  Longer runs
 // (up to WS_WAVE_MAX) are entered into the table the run kernels' lists are compiled from (entry start / (SG_MAXG + 1): such a run has
 // more members than that, so two never share an entry); beyond that the caller sorts the list as a whole.
-constexpr u32 SG_T = 1024, SG_H = 16, SG_MAXG = 16, SG_BIG_CAP = 1u << 16;
+#ifndef TDC_SG_MAXG
+#define TDC_SG_MAXG 16
+#endif
+#ifndef TDC_SG_T
+#define TDC_SG_T 1024
+#endif
+constexpr u32 SG_T = TDC_SG_T, SG_H = TDC_SG_MAXG, SG_MAXG = TDC_SG_MAXG, SG_BIG_CAP = 1u << 16;
 constexpr u32 SG_EDIV = SG_MAXG + 1;      // a run that is entered into the table has more than SG_MAXG members: entry = start / SG_EDIV, no two runs share one
 struct SegCounters { u32 overflow, nbig, big_recs, pad; };
 __global__ __launch_bounds__(256) void ws_seg_tile_kernel(const u64* __restrict__ k1, u64* k2, u32* v, u32 m, u32* __restrict__ rng, u32* __restrict__ big,
